@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Capture golden input/output vectors from the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference).  It imports the
+reference's model classes (CPU, fp32), injects weights produced by this
+repo's own seeded NumPy routine, runs forward (+ backward, + a short
+Adam/clip training trajectory restating eval/q_and_v_eval.py:124-139) and
+dumps inputs, weights and results as small .npz fixtures under
+tests/golden/.  Nothing from the reference's sources is copied: the
+fixtures are data only.
+
+Weight naming follows the reference's GPU-flavour state_dict
+(film_attn_pt_stem.py:84-86 registers film_layer as a ModuleList only
+when CUDA is available; on this CPU box it is a plain list, so we read
+and write it by attribute).  The unregistered conv1x1_layers
+(film_attn_pt_stem.py:44,101-104) are exported as
+`conv1x1_layers.<k>.{weight,bias}`.
+
+usage: python tools/capture_goldens.py [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = os.environ.get("VNQA_REFERENCE", "/root/reference")
+
+
+def _named_tensors(model):
+    """All tensors that define the model, incl. the unregistered ones."""
+    out = {}
+    for k, v in model.state_dict().items():
+        out[k] = v
+    if hasattr(model, "film_layer") and not isinstance(model.film_layer, nn.ModuleList):
+        for i, op in enumerate(model.film_layer):
+            for k, v in op.state_dict().items():
+                out["film_layer.%d.%s" % (i, k)] = v
+    if hasattr(model, "conv1x1_layers"):
+        for i, op in enumerate(model.conv1x1_layers):
+            for k, v in op.state_dict().items():
+                out["conv1x1_layers.%d.%s" % (i, k)] = v
+    return out
+
+
+def _named_params(model):
+    """name -> Parameter for everything that receives a gradient."""
+    out = dict(model.named_parameters())
+    if hasattr(model, "film_layer") and not isinstance(model.film_layer, nn.ModuleList):
+        for i, op in enumerate(model.film_layer):
+            for k, v in op.named_parameters():
+                out["film_layer.%d.%s" % (i, k)] = v
+    if hasattr(model, "conv1x1_layers"):
+        for i, op in enumerate(model.conv1x1_layers):
+            for k, v in op.named_parameters():
+                out["conv1x1_layers.%d.%s" % (i, k)] = v
+    return out
+
+
+def seeded_fill(model, seed):
+    """Deterministic, O(1)-activation weights from a NumPy RNG (our routine)."""
+    rng = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, t in sorted(_named_tensors(model).items()):
+            if name.endswith("num_batches_tracked"):
+                t.zero_()
+                continue
+            shape = tuple(t.shape)
+            if name.endswith("running_var"):
+                a = rng.uniform(0.5, 1.5, size=shape)
+            elif name.endswith("running_mean"):
+                a = rng.normal(0, 0.2, size=shape)
+            elif ("bn" in name or "norm" in name) and name.endswith("weight"):
+                a = rng.uniform(0.6, 1.4, size=shape)
+            elif name.endswith("bias") or "bias_" in name:
+                a = rng.normal(0, 0.1, size=shape)
+            elif name == "embed.weight":
+                a = rng.normal(0, 0.7, size=shape)
+            else:
+                fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+                a = rng.normal(0, 1.0 / np.sqrt(max(fan_in, 1)), size=shape)
+                if "film_layer.1.weight" in name or "fc_attn_out.weight" in name:
+                    a = a * 2.0
+            t.copy_(torch.from_numpy(a.astype(np.float32)))
+    # film_layer.1 bias positive so that ReLU'd gammas are not all dead
+    tensors = _named_tensors(model)
+    if "film_layer.1.bias" in tensors:
+        with torch.no_grad():
+            tensors["film_layer.1.bias"].add_(0.5)
+
+
+def make_inputs(rng, B, C_in, h, w, T, L, vocab, nb_classes, v_lens, q_lens):
+    v = rng.uniform(0, 1.5, size=(B, C_in, h, w, T)).astype(np.float32)
+    q = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        q[b, : q_lens[b]] = rng.randint(1, vocab, size=q_lens[b])
+    y = rng.randint(0, nb_classes, size=(B,)).astype(np.int64)
+    return v, q, np.asarray(v_lens, np.int64), np.asarray(q_lens, np.int64), y
+
+
+def run_qv_case(out_dir, name, cls, ctor_kwargs, B, C_in, T, L, v_lens, q_lens, seed,
+                spatial=(10, 13), train_steps=3, lr=1e-3, patch_spatial=None):
+    """Forward/backward/trajectory for one of the three FiLM models."""
+    torch.manual_seed(0)
+    model = cls(**ctor_kwargs)
+    h, w = spatial
+    if patch_spatial is not None:
+        # 130 is hard-coded in the reference (film_attn_pt_stem.py:56); for
+        # other spatial sizes replace attributes on the INSTANCE only.
+        h, w = patch_spatial
+        S = h * w
+        C = ctor_kwargs["num_res_block_channels"]
+        if hasattr(model, "fc_embed_attn"):
+            model.fc_embed_attn = nn.Linear(S * C, model.at_hidden_size)
+        else:
+            model.out_linear = nn.Linear(S * ctor_kwargs["num_tail_channels"], model.nb_classes)
+    seeded_fill(model, seed)
+    rng = np.random.RandomState(seed + 1)
+    vocab = ctor_kwargs["vocab_size"]
+    nb_classes = ctor_kwargs["nb_classes"]
+    v, q, vl, ql, y = make_inputs(rng, B, C_in, h, w, T, L, vocab, nb_classes, v_lens, q_lens)
+    tv, tq, tvl, tql, ty = map(torch.from_numpy, (v, q, vl, ql, y))
+
+    rec = {"v": v, "q": q, "v_lens": vl, "q_lens": ql, "y": y}
+    for k, t in _named_tensors(model).items():
+        rec["w0/" + k] = t.detach().cpu().numpy().copy()
+
+    loss_fn = nn.CrossEntropyLoss(reduction="sum")
+
+    # ---- eval-mode forward (q_and_v_eval.py:159-206) ----
+    model.eval()
+    with torch.no_grad():
+        model.init_hidden()
+        rec["eval_logits"] = model(tv, tq, tvl, tql).numpy().copy()
+
+    # ---- train-mode forward + backward (q_and_v_eval.py:119-136) ----
+    model.train()
+    params = _named_params(model)
+    for p in params.values():
+        p.grad = None
+    model.init_hidden()
+    logits = model(tv, tq, tvl, tql)
+    loss = loss_fn(logits, ty)
+    loss.backward()
+    rec["train_logits"] = logits.detach().numpy().copy()
+    rec["train_loss"] = np.float32(loss.item())
+    for k, p in params.items():
+        rec["grad/" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+    rec["bn_running_mean_after"] = model.bn_init.running_mean.numpy().copy()
+    rec["bn_running_var_after"] = model.bn_init.running_var.numpy().copy()
+    rec["film_hidden_h_after"] = model.film_hidden[0].detach().numpy().copy()
+    rec["film_hidden_c_after"] = model.film_hidden[1].detach().numpy().copy()
+
+    # ---- short training trajectory: clip 1.0 + Adam over REGISTERED params
+    #      (q_and_v_eval.py:136-139, :333) ----
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    opt.zero_grad()
+    for p in params.values():
+        p.grad = None
+    losses = [rec["train_loss"]]
+    # first step reuses the same batch as above: redo it from current state
+    for step in range(train_steps):
+        model.init_hidden()
+        logits = model(tv, tq, tvl, tql)
+        loss = loss_fn(logits, ty)
+        if step > 0:
+            losses.append(np.float32(loss.item()))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+    rec["traj_lr"] = np.float32(lr)
+    rec["traj_losses"] = np.asarray(losses, np.float32)
+    model.eval()
+    with torch.no_grad():
+        model.init_hidden()
+        rec["traj_final_eval_logits"] = model(tv, tq, tvl, tql).numpy().copy()
+    for k, t in model.state_dict().items():
+        rec["w_final/" + k] = t.detach().cpu().numpy().copy()
+
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
+def run_objdet_case(out_dir, name, num_filters, N, H, W, seed):
+    from models.obj_detector import ObjDetectCNN
+    torch.manual_seed(0)
+    model = ObjDetectCNN(nb_classes=5, num_filters=num_filters, tail_hidden_dim=8,
+                         tail_dropout_p=0, logits=True, pretrained_features=True)
+    seeded_fill(model, seed)
+    model.eval()  # eval/utils.py:50
+    rng = np.random.RandomState(seed + 1)
+    x = rng.uniform(0, 2.0, size=(N, 128, H, W)).astype(np.float32)
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+    rec = {"x": x, "y": y}
+    for k, t in model.state_dict().items():
+        rec["w/" + k] = t.numpy().copy()
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
+def run_cnn3d_case(out_dir, name, seed):
+    from models.v_only_cnn3d import VideoOnlyCNN3D
+    torch.manual_seed(0)
+    model = VideoOnlyCNN3D(nb_classes=5)
+    # reference geometry: Conv3d sees (D,H,W)=(H,W,T): 160x208x35 -> 7680 features
+    # (v_only_cnn3d.py:28); the conv trunk below is geometry-free, so the golden
+    # pins the conv/pool/BN3d stack (v_only_cnn3d.py:59-72) on a small clip.
+    seeded_fill(model, seed)
+    rng = np.random.RandomState(seed + 1)
+    x = rng.uniform(0, 1, size=(2, 3, 16, 32, 32)).astype(np.float32)
+    model.eval()
+    with torch.no_grad():
+        h = model.bn_input(torch.from_numpy(x))
+        h = model.pool1(model.relu(model.conv1(h)))
+        h = model.bn1(h)
+        h = model.pool2(model.relu(model.conv2(h)))
+        h = model.bn2(h)
+        h = model.pool3(model.relu(model.conv3a(h)))
+        feat = model.bn3(h).numpy()
+    rec = {"x": x, "conv_features": feat}
+    for k, t in model.state_dict().items():
+        if k.startswith("fc") or "bn6" in k or "bn7" in k:
+            continue
+        rec["w/" + k] = t.numpy().copy()
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
+def run_qonly_case(out_dir, name, seed):
+    # q_only_lstm.py:53-54 calls .cuda() unconditionally: patch to identity on this CPU box.
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        from models.q_only_lstm import QOnlyLSTM
+        torch.manual_seed(0)
+        B, L, E, Hd, K, V = 6, 9, 12, 16, 7, 20
+        model = QOnlyLSTM(B, E, Hd, K, V)
+        seeded_fill(model, seed)
+        rng = np.random.RandomState(seed + 1)
+        q_lens = np.sort(rng.randint(2, L + 1, size=B))[::-1].copy().astype(np.int64)
+        q = np.zeros((B, L), np.int64)
+        for b in range(B):
+            q[b, : q_lens[b]] = rng.randint(1, V, size=q_lens[b])
+        h0 = rng.normal(0, 1, size=(1, B, Hd)).astype(np.float32)
+        c0 = rng.normal(0, 1, size=(1, B, Hd)).astype(np.float32)
+        model.hidden_1 = (torch.from_numpy(h0), torch.from_numpy(c0))
+        with torch.no_grad():
+            out = model(torch.from_numpy(q), torch.from_numpy(q_lens)).numpy()
+        rec = {"q": q, "q_lens": q_lens, "h0": h0, "c0": c0, "logits": out}
+        for k, t in model.state_dict().items():
+            rec["w/" + k] = t.numpy().copy()
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **rec)
+        print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+    finally:
+        torch.Tensor.cuda = orig
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    out_dir = os.path.abspath(args.out)
+    os.makedirs(out_dir, exist_ok=True)
+    sys.path.insert(0, REF)
+    torch.set_num_threads(1)  # bit-stable captures
+
+    from models.film_attn_pt_stem import FiLMAttnPretrainedStem
+    from models.film_global_pooling_pt_stem import FiLMGlobalPoolingPretrainedStem
+    from models.time_multi_hop_pt_stem import TimeMultiHopFiLMPretrainedStem
+
+    B, C_in, C, T, L = 3, 8, 8, 6, 9
+    attn_kw = dict(batch_size=B, q_embedding_size=12, nb_classes=7, num_input_channels=C_in,
+                   num_res_block_channels=C, num_res_blocks=2, hidden_size=16,
+                   at_hidden_size=16, max_num_frames=T, q_encoder="lstm", vocab_size=20)
+    run_qv_case(out_dir, "film_attn_full", FiLMAttnPretrainedStem, attn_kw, B, C_in, T, L,
+                v_lens=[6, 6, 6], q_lens=[9, 5, 7], seed=11)
+    run_qv_case(out_dir, "film_attn_ragged", FiLMAttnPretrainedStem, attn_kw, B, C_in, T, L,
+                v_lens=[6, 4, 2], q_lens=[4, 9, 6], seed=12)
+    # longest video shorter than max_num_frames: frames past it are un-masked zeros (§8 a11)
+    run_qv_case(out_dir, "film_attn_short", FiLMAttnPretrainedStem, attn_kw, B, C_in, T, L,
+                v_lens=[4, 3, 3], q_lens=[3, 3, 8], seed=13)
+    attn196 = dict(attn_kw)
+    attn196["num_res_blocks"] = 1
+    run_qv_case(out_dir, "film_attn_s196", FiLMAttnPretrainedStem, attn196, B, C_in, T, L,
+                v_lens=[6, 5, 3], q_lens=[9, 2, 7], seed=14, patch_spatial=(14, 14))
+
+    gp_kw = dict(batch_size=B, q_embedding_size=12, nb_classes=7, num_input_channels=C_in,
+                 num_res_block_channels=C, num_tail_channels=4, num_res_blocks=2,
+                 hidden_size=16, q_encoder="lstm", vocab_size=20)
+    run_qv_case(out_dir, "film_gp_full", FiLMGlobalPoolingPretrainedStem, gp_kw, B, C_in, T, L,
+                v_lens=[6, 6, 6], q_lens=[9, 5, 7], seed=21)
+    run_qv_case(out_dir, "film_gp_ragged", FiLMGlobalPoolingPretrainedStem, gp_kw, B, C_in, T, L,
+                v_lens=[6, 4, 2], q_lens=[4, 9, 6], seed=22)
+
+    tmh_kw = dict(batch_size=B, q_embedding_size=12, nb_classes=7, num_input_channels=C_in,
+                  num_res_block_channels=C, num_res_blocks=2, num_tail_channels=4,
+                  hidden_size=16, vocab_size=20)
+    run_qv_case(out_dir, "tmh_full", TimeMultiHopFiLMPretrainedStem, tmh_kw, B, C_in, T, L,
+                v_lens=[6, 6, 6], q_lens=[9, 5, 7], seed=31)
+    run_qv_case(out_dir, "tmh_ragged", TimeMultiHopFiLMPretrainedStem, tmh_kw, B, C_in, T, L,
+                v_lens=[6, 4, 2], q_lens=[4, 9, 6], seed=32)
+
+    run_objdet_case(out_dir, "objdet_f16", num_filters=16, N=2, H=16, W=24, seed=41)
+    if os.environ.get("VNQA_CAPTURE_CNN3D"):  # config-2 ladder rung: 2.7 MB, not committed by default
+        run_cnn3d_case(out_dir, "cnn3d_small", seed=51)
+    run_qonly_case(out_dir, "qonly_small", seed=61)
+
+
+if __name__ == "__main__":
+    main()
