@@ -1,0 +1,134 @@
+/* vnqa_hip.h — C ABI of libvnqa_hip.so, the MI355X (gfx950) kernel library for the
+ * VideoNavQA video-question fusion path.
+ *
+ * The reference (catalina17/VideoNavQA) has no native layer: every op below replaces an
+ * implicit ATen/cuDNN dispatch made from the Python files cited per entry point.  The
+ * boundary is plain C: raw device pointers + sizes, a caller-owned stream, no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named host_*;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden syncs,
+ *     no allocation: the caller owns every buffer (workspaces are explicit arguments);
+ *   - return value: 0 on success, a negative VNQA_ERR_* otherwise; the message is available
+ *     from vnqa_last_error() (thread-local); nothing aborts or throws across the ABI;
+ *   - dtype: VNQA_BF16 (bf16 storage, fp32 MFMA accumulate) or VNQA_F32 (exact fp32 MFMA);
+ *   - activation layout: "padded NHWC" = [n_img][h+2*halo][w+2*halo][c] with a ZERO halo that
+ *     kernels never write; channel counts are padded to a multiple of 64 by the caller.
+ */
+#ifndef VNQA_HIP_H_
+#define VNQA_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VNQA_BF16 0
+#define VNQA_F32 1
+
+#define VNQA_OK 0
+#define VNQA_ERR_INVALID_ARG (-1)
+#define VNQA_ERR_HIP (-2)
+#define VNQA_ERR_UNSUPPORTED (-3)
+
+int vnqa_version(void);
+const char* vnqa_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * conv2d, stride 1, 'same' (3x3 pad 1 or 1x1), implicit GEMM on MFMA.
+ * Replaces nn.Conv2d forward at models/obj_detector.py:72,77,82 (+ the folded eval-mode
+ * BatchNorm2d / ReLU / MaxPool2d of :70-86), the VGG-16 front convs reached through
+ * eval/q_and_v_eval.py:106, and models/film_attn_pt_stem.py:211,219,224 (conv_init,
+ * conv1x1, FiLM 3x3).  The same entry point computes dgrad (conv of dY with the
+ * flipped/transposed weights from vnqa_pack_conv_weight(..., transpose_flip=1)).
+ *
+ *   y = post( pool2?( relu?( conv(x, wt) + bias ) ) ),  post(v) = v*post_scale + post_shift
+ *
+ * x  : padded NHWC [n_img][h+2*x_halo][w+2*x_halo][c_in]
+ * wt : [c_out][taps][c_in]  (K-major; see vnqa_pack_conv_weight)
+ * y  : padded NHWC [n_img][ho+2*y_halo][wo+2*y_halo][c_y], ho = h (or h/2 with pool2)
+ * bias, post_scale, post_shift: fp32 [c_out] or NULL.
+ */
+typedef struct vnqa_conv_desc {
+  int32_t dtype;   /* VNQA_BF16 | VNQA_F32 : element type of x, wt, y */
+  int32_t n_img;
+  int32_t h, w;    /* spatial size of the conv output (== input) before pooling */
+  int32_t c_in;    /* multiple of 64 (bf16) / 32 (f32) */
+  int32_t c_out;   /* multiple of 8; rows of wt */
+  int32_t c_y;     /* channel stride of y, >= c_out */
+  int32_t taps;    /* 9 or 1 */
+  int32_t x_halo;  /* 1 for taps==9; 0 or 1 for taps==1 */
+  int32_t y_halo;  /* 0 or 1 */
+  int32_t relu;
+  int32_t pool2;   /* requires h, w even */
+  int32_t tile;    /* 0 = auto, else a VNQA_TILE_* id */
+} vnqa_conv_desc;
+
+#define VNQA_TILE_AUTO 0
+#define VNQA_TILE_256x256 1
+#define VNQA_TILE_256x128 2
+#define VNQA_TILE_256x64 3
+#define VNQA_TILE_128x128 4
+#define VNQA_TILE_128x64 5
+
+int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
+                          const float* bias, const float* post_scale, const float* post_shift,
+                          void* y, void* stream);
+
+/* First VGG conv (3 -> c_out, 3x3 pad 1) + ReLU straight from the reference's clip layout.
+ * Replaces the strided frame slice v_inputs[:, :, :, :, j] + conv1_1 of the external
+ * feature extractor (eval/q_and_v_eval.py:104-106; eval/dataset.py:63,81-91 for the layout).
+ * clip   : fp32 [b][3][h][w][t]  (frames on the LAST axis)
+ * w      : fp32 [c_out][3][3][3] (OIHW), bias fp32 [c_out]; c_out == 64
+ * img_of : int32 [b*t] -> destination image index in y, or -1 to skip that frame
+ * y      : padded NHWC [n_img][h+2][w+2][c_out], halo 1, dtype as given
+ */
+int vnqa_conv_first_fwd(const float* clip, const float* w, const float* bias,
+                        const int32_t* img_of, void* y, int32_t b, int32_t t, int32_t h,
+                        int32_t wd, int32_t c_out, int32_t dtype, void* stream);
+
+/* Repack an OIHW fp32 conv weight into the K-major layout the igemm consumes.
+ *   transpose_flip == 0:  wt[o][tap][i]        = w[o][i][r][s] * (out_scale ? out_scale[o] : 1)
+ *   transpose_flip == 1:  wt[i][(2-r)*3+(2-s)][o] = w[o][i][r][s]        (dgrad weights)
+ * rows/cols beyond the real sizes are zero-filled up to rows_pad / k_pad channels.
+ */
+int vnqa_pack_conv_weight(const float* w_oihw, int32_t c_out, int32_t c_in, int32_t taps,
+                          int32_t c_out_pad, int32_t c_in_pad, const float* out_scale,
+                          int32_t transpose_flip, int32_t dtype, void* wt, void* stream);
+
+/* Inverse of the above for gradients: dW (fp32, [c_out_pad][taps][c_in_pad]) -> OIHW fp32. */
+int vnqa_unpack_conv_wgrad(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps,
+                           int32_t c_out_pad, int32_t c_in_pad, float* dw_oihw, void* stream);
+
+/* Layout converters between the reference's tensors and padded NHWC.
+ *   vnqa_feat_to_nhwc : v fp32 [b][c][h][w][t] (the model-input layout, eval/q_and_v_eval.py:110)
+ *                       -> y padded NHWC [n_img][h+2][w+2][c_pad], frame (b,t) -> image img_of[b*t_n+t]
+ *   vnqa_nchw_to_nhwc : dense fp32 [n][c][h][w] -> padded NHWC halo 1
+ *   vnqa_nhwc_to_nchw : padded NHWC (halo 0/1) -> dense fp32 [n][c][h][w]
+ */
+int vnqa_feat_to_nhwc(const float* v, const int32_t* img_of, void* y, int32_t b, int32_t c,
+                      int32_t h, int32_t w, int32_t t, int32_t c_pad, int32_t dtype, void* stream);
+int vnqa_nchw_to_nhwc(const float* x, void* y, int32_t n_img, int32_t c, int32_t h, int32_t w,
+                      int32_t c_pad, int32_t dtype, void* stream);
+int vnqa_nhwc_to_nchw(const void* x, float* out, int32_t n_img, int32_t c, int32_t h, int32_t w,
+                      int32_t c_pad, int32_t halo, int32_t dtype, void* stream);
+
+/* conv2d weight gradient (+ optional bias gradient), stride 1 'same'.
+ * Replaces the autograd wgrad of nn.Conv2d on the trainable convs
+ * (models/film_attn_pt_stem.py:40,98 reached by loss.backward(), eval/q_and_v_eval.py:136).
+ *   dwt[o][tap][i] = sum_{n,y,x} dy[n,y,x,o] * x[n,y+r-1,x+s-1,i]      (fp32 output)
+ *   dbias[o]       = sum_{n,y,x} dy[n,y,x,o]                            (fp32, nullable)
+ * x : padded NHWC [n_img][h+2][w+2][c_in] (halo 1), dy : padded NHWC [n_img][h+2][w+2][c_out]
+ * (halo 1, ZERO halo).  workspace: fp32, vnqa_conv2d_wgrad_workspace() bytes.
+ */
+int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t w, int32_t c_in,
+                                    int32_t c_out, int32_t taps);
+int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace,
+                      int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
+                      int32_t taps, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VNQA_HIP_H_ */

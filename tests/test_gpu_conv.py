@@ -1,0 +1,164 @@
+"""GPU parity: HIP conv kernels (through the C ABI) vs a plain PyTorch fp32 reference of the same
+op on identical seeded inputs.  Tolerances: f32 path 2e-5 relative to max|ref| (exact-f32 MFMA,
+summation order differs); bf16 path is checked against the reference evaluated on the SAME
+bf16-rounded operands, 1e-2 relative (bf16 output rounding = 2^-9)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dt):
+    return 2e-5 if dt == torch.float32 else 1e-2
+
+
+def _q(t, dt):
+    """round operands to the kernel's storage type so that only accumulation order differs"""
+    return t.to(dt).float()
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, taps, relu, pool, post
+    (3, 10, 13, 64, 64, 9, True, False, False),
+    (2, 14, 14, 128, 192, 9, False, False, False),
+    (2, 16, 12, 64, 128, 9, True, True, True),
+    (5, 14, 14, 64, 320, 1, True, False, False),
+    (1, 28, 28, 256, 512, 9, True, True, False),
+    (7, 6, 8, 64, 72, 9, False, False, True),
+])
+def test_conv_igemm_vs_torch(dt, cfg):
+    from videonavqa_amd import kernels as K
+    N, H, W, Cin, Cout, taps, relu, pool, post = cfg
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]))
+    k = 3 if taps == 9 else 1
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * taps) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda() * 0.1
+    sc = (torch.rand(Cout, generator=g) + 0.5).cuda() * torch.where(torch.rand(Cout, generator=g) > 0.3, 1.0, -1.0).cuda()
+    sh = torch.randn(Cout, generator=g).cuda() * 0.2
+    xq, wq = _q(x, dt), _q(w, dt)
+    ref = F.conv2d(xq, wq, b, padding=k // 2)
+    if relu:
+        ref = F.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    if post:
+        ref = ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    xn = K.nchw_to_nhwc(x, dt, c_pad=Cin)
+    wt = K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=Cin)
+    y = K.conv2d_igemm(xn, wt, bias=b, relu=relu, pool2=pool, post_scale=sc if post else None,
+                       post_shift=sh if post else None)
+    got = K.nhwc_to_nchw(y, Cout)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < _tol(dt), _rel(got, ref)
+    # the halo must stay zero
+    assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0
+    assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+def test_conv_igemm_tiles_agree(tile):
+    from videonavqa_amd import kernels as K
+    g = torch.Generator(device="cpu").manual_seed(tile)
+    N, H, W, Cin, Cout = 4, 14, 14, 128, 256
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+    dt = torch.bfloat16
+    ref = F.relu(F.conv2d(_q(x, dt), _q(w, dt), None, padding=1))
+    y = K.conv2d_igemm(K.nchw_to_nhwc(x, dt, c_pad=Cin), K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=Cin),
+                       relu=True, tile=tile)
+    assert _rel(K.nhwc_to_nchw(y, Cout), ref) < 1e-2
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_channel_padding_small_channels(dt):
+    """tiny-channel layers (golden configs) run by zero-padding channels to 64."""
+    from videonavqa_amd import kernels as K
+    g = torch.Generator(device="cpu").manual_seed(5)
+    N, H, W, Cin, Cout = 3, 10, 13, 8, 12
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+    ref = F.conv2d(_q(x, dt), _q(w, dt), b, padding=1)
+    y = K.conv2d_igemm(K.nchw_to_nhwc(x, dt), K.pack_conv_weight(w, dt), bias=K.pad_vec(b, 64))
+    assert y.shape[-1] == 64
+    assert _rel(K.nhwc_to_nchw(y, Cout), ref) < _tol(dt)
+    assert float(y[..., Cout:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_dgrad_via_flipped_weights(dt):
+    from videonavqa_amd import kernels as K
+    g = torch.Generator(device="cpu").manual_seed(9)
+    N, H, W, Cin, Cout = 3, 10, 13, 64, 128
+    x = torch.randn(N, Cin, H, W, generator=g).cuda().requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+    dy = torch.randn(N, Cout, H, W, generator=g).cuda()
+    F.conv2d(x, _q(w, dt), None, padding=1).backward(_q(dy, dt))
+    wt_d = K.pack_conv_weight(w, dt, transpose_flip=True, c_out_pad=Cout, c_in_pad=Cin)
+    dx = K.conv2d_igemm(K.nchw_to_nhwc(dy, dt, c_pad=Cout), wt_d)
+    assert _rel(K.nhwc_to_nchw(dx, Cin), x.grad) < _tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(3, 10, 13, 64, 64, 9), (6, 14, 14, 128, 320, 9), (4, 14, 14, 512, 64, 1),
+                                 (40, 14, 14, 256, 256, 9)])
+def test_wgrad_vs_torch(dt, cfg):
+    from videonavqa_amd import kernels as K
+    N, H, W, Cin, Cout, taps = cfg
+    k = 3 if taps == 9 else 1
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg))
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = torch.zeros(Cout, Cin, k, k).cuda().requires_grad_(True)
+    b = torch.zeros(Cout).cuda().requires_grad_(True)
+    dy = torch.randn(N, Cout, H, W, generator=g).cuda()
+    F.conv2d(_q(x, dt), w, b, padding=k // 2).backward(_q(dy, dt))
+    dwt, dbias = K.conv2d_wgrad(K.nchw_to_nhwc(x, dt, c_pad=Cin), K.nchw_to_nhwc(dy, dt, c_pad=Cout), taps)
+    dw = K.unpack_conv_wgrad(dwt, Cout, Cin)
+    tol = 2e-5 if dt == torch.float32 else 2e-5  # products of bf16 operands are exact in fp32: order only
+    assert _rel(dw, w.grad) < 5e-5, _rel(dw, w.grad)
+    assert _rel(dbias, b.grad) < 5e-5
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_conv_first_vs_torch(dt):
+    from videonavqa_amd import kernels as K
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, T, H, W = 2, 5, 20, 36
+    clip = torch.rand(B, 3, H, W, T, generator=g).cuda()
+    w = (torch.randn(64, 3, 3, 3, generator=g) / 27 ** 0.5).cuda()
+    b = torch.randn(64, generator=g).cuda() * 0.1
+    img_of = torch.full((B * T,), -1, dtype=torch.int32)
+    order = [(bb, t) for t in range(T) for bb in range(B) if not (bb == 1 and t >= 3)]
+    for n, (bb, t) in enumerate(order):
+        img_of[bb * T + t] = n
+    y = K.conv_first(clip, w, b, img_of.cuda(), len(order), dt)
+    got = K.nhwc_to_nchw(y, 64)
+    for n, (bb, t) in enumerate(order):
+        ref = F.relu(F.conv2d(_q(clip[bb:bb + 1, :, :, :, t], dt), _q(w, dt), b, padding=1))
+        assert _rel(got[n:n + 1], ref) < _tol(dt), (n, _rel(got[n:n + 1], ref))
+
+
+def test_feat_to_nhwc_roundtrip():
+    from videonavqa_amd import kernels as K
+    g = torch.Generator(device="cpu").manual_seed(4)
+    B, C, h, w, T = 3, 8, 10, 13, 6
+    v = torch.randn(B, C, h, w, T, generator=g).cuda()
+    img_of = torch.arange(B * T, dtype=torch.int32).view(B, T).t().contiguous()  # image = t*B + b
+    img_of_bt = torch.empty(B * T, dtype=torch.int32)
+    for bb in range(B):
+        for t in range(T):
+            img_of_bt[bb * T + t] = t * B + bb
+    y = K.feat_to_nhwc(v, img_of_bt.cuda(), B * T, torch.float32)
+    back = K.nhwc_to_nchw(y, C)  # [T*B, C, h, w]
+    ref = v.permute(4, 0, 1, 2, 3).reshape(T * B, C, h, w)
+    assert torch.equal(back, ref)

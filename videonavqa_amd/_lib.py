@@ -1,0 +1,90 @@
+"""ctypes binding of libvnqa_hip.so (the C ABI declared in include/vnqa_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvnqa_hip.so")
+
+BF16, F32 = 0, 1
+TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64 = range(6)
+
+_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, _i32) for n in ("dtype", "n_img", "h", "w", "c_in", "c_out", "c_y", "taps",
+                                    "x_halo", "y_halo", "relu", "pool2", "tile")]
+
+
+_SIGNATURES = {
+    "vnqa_version": (ctypes.c_int, []),
+    "vnqa_last_error": (ctypes.c_char_p, []),
+    "vnqa_conv2d_igemm_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vnqa_conv_first_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_pack_conv_weight": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "vnqa_unpack_conv_wgrad": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vnqa_feat_to_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_nchw_to_nhwc": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_nhwc_to_nchw": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_conv2d_wgrad_workspace": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "vnqa_conv2d_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class VnqaError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the CDLL; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VnqaError(
+                "libvnqa_hip.so not found at %s — build it with `python -m videonavqa_amd.build` "
+                "(there is no CPU/PyTorch fallback for the HIP path)" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(_lib, name)  # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise VnqaError("%s failed (%d): %s" % (what, rc, lib().vnqa_last_error().decode()))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "vnqa kernels need contiguous device tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_id(dt):
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float32:
+        return F32
+    raise VnqaError("unsupported dtype %s" % dt)
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m

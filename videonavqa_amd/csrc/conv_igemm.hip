@@ -1,0 +1,379 @@
+// conv_igemm.hip — implicit-GEMM 3x3 / 1x1 convolution on CDNA4 MFMA (gfx950).
+//
+// GEMM view:  D[cout][pixel] = sum_k Wt[cout][k] * X[pixel][k],  k = tap*Cin + ci.
+// The weight tile is the MFMA "A" operand and the pixel tile the "B" operand, so the 32x32
+// accumulator holds 4 CONSECUTIVE output channels of one pixel in 4 consecutive registers:
+// the epilogue packs them and goes through LDS once to emit full 16-byte NHWC stores.
+//
+// Staging: every K-step is one (tap, 64-channel) slab = a 128-byte contiguous run per pixel
+// (bf16; 32 channels for f32).  Tiles are copied HBM->LDS by global_load_lds_dwordx4
+// (1 KiB = 8 rows x 128 B per wave instruction, LDS destination lane-linear).  The XOR
+// swizzle (chunk ^= (row>>1)&7) is applied on the per-lane SOURCE address and again on the
+// ds_read_b128 address (same involution), which makes the 32x32x16 fragment reads
+// conflict-free (rows r and r+1 sit in the two 128-B halves of a 256-B bank row, the 8 row
+// pairs of a 16-lane group land in 8 different 16-B slots).
+// Zero padding costs nothing: activations live in "padded NHWC" buffers with a zero halo.
+//
+// Loop: 2-stage LDS double buffer, one barrier per K-step; the next slab's DMA is in flight
+// while the current slab's MFMAs run.
+#include "vnqa_common.h"
+
+namespace {
+
+struct ConvArgs {
+  const char* x;
+  const char* wt;
+  const float* bias;
+  const float* post_scale;
+  const float* post_shift;
+  char* y;
+  int n_img, H, W, Hp, Wp;  // Hp/Wp: padded input dims
+  int Cin, Cout, Cy;
+  int taps, x_halo, y_halo;
+  int relu, pool;
+  int M;                    // n_img*H*W conv-output pixels
+  int tilesN;
+  int Hyp, Wyp;             // padded OUTPUT dims (after pooling)
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<vnqa_bf16> {
+  static __device__ __forceinline__ void run(const vnqa_f32x4& a, const vnqa_f32x4& b, vnqa_f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vnqa_bf16x8, a),
+                                                __builtin_bit_cast(vnqa_bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  // 16 bytes = 4 f32 k-values per lane; the k permutation is the same for A and B.
+  static __device__ __forceinline__ void run(const vnqa_f32x4& a, const vnqa_f32x4& b, vnqa_f32x16& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// conv-output pixel index m -> (n, y, x); pooled layers enumerate pixels quad-major so that
+// the four members of a 2x2 pooling window are consecutive m.
+__device__ __forceinline__ void decode_pixel(int m, int H, int W, int pool, int& n, int& y, int& x) {
+  if (pool) {
+    const int q = m >> 2, d = m & 3;
+    const int W2 = W >> 1, H2 = H >> 1;
+    n = q / (H2 * W2);
+    const int rem = q - n * (H2 * W2);
+    const int yo = rem / W2;
+    y = 2 * yo + (d >> 1);
+    x = 2 * (rem - yo * W2) + (d & 1);
+  } else {
+    n = m / (H * W);
+    const int rem = m - n * (H * W);
+    y = rem / W;
+    x = rem - y * W;
+  }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const ConvArgs p) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int NT = NW * 64;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = 128 / ES;  // channels per K-step
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_PER_WAVE = (BM / 8) / NW, B_PER_WAVE = (BN / 8) / NW;
+  constexpr int EPC = 16 / ES;                // elements per 16-byte chunk
+  constexpr int CROW = BN * ES + 16;          // epilogue LDS row stride (bytes)
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
+  static_assert(TM >= 1 && TN >= 1, "wave tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // XCD-aware, bijective remap: blocks that share an XCD (bid % 8) get a contiguous run of
+  // tiles, n-tile fastest, so neighbouring tiles share pixel rows / weight panels in one L2.
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tile_n = swz % p.tilesN;
+    tile_m = swz / p.tilesN;
+  }
+
+  const int kchunks = p.Cin / BK;
+  const int KT = p.taps * kchunks;
+  const size_t w_row_bytes = (size_t)p.taps * p.Cin * ES;
+
+  // ---- per-lane source offsets (constant over the K loop) ----
+  size_t a_off[A_PER_WAVE];
+  size_t b_off[B_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < A_PER_WAVE; ++j) {
+    const int row = (wave * A_PER_WAVE + j) * 8 + (lane >> 3);
+    int m = tile_m * BM + row;
+    m = m < p.M ? m : p.M - 1;
+    int n, y, x;
+    decode_pixel(m, p.H, p.W, p.pool, n, y, x);
+    const int lc = (lane & 7) ^ ((row >> 1) & 7);
+    a_off[j] = (((size_t)n * p.Hp + y) * p.Wp + x) * (size_t)p.Cin * ES + (size_t)lc * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < B_PER_WAVE; ++j) {
+    const int row = (wave * B_PER_WAVE + j) * 8 + (lane >> 3);
+    int co = tile_n * BN + row;
+    co = co < p.Cout ? co : p.Cout - 1;
+    const int lc = (lane & 7) ^ ((row >> 1) & 7);
+    b_off[j] = (size_t)co * w_row_bytes + (size_t)lc * 16;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    const int tap = kt / kchunks;
+    const int kc = kt - tap * kchunks;
+    int r, s;
+    if (p.taps == 9) {
+      r = tap / 3;
+      s = tap - 3 * r;
+    } else {
+      r = p.x_halo;
+      s = p.x_halo;
+    }
+    const size_t tapoff = ((size_t)(r * p.Wp + s) * p.Cin + (size_t)kc * BK) * ES;
+    char* lds = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j)
+      glds16(p.x + a_off[j] + tapoff, lds + (wave * A_PER_WAVE + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j)
+      glds16(p.wt + b_off[j] + (size_t)kt * 128, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
+  };
+
+  vnqa_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment read addresses: row = lane&31 within a 32-row sub-tile, half h = lane>>5
+  const int fr = lane & 31, fh = lane >> 5;
+  int x_rd[TM], w_rd[TN], x_sw[TM], w_sw[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = wm * WTM + i * 32 + fr;
+    x_rd[i] = row * 128;
+    x_sw[i] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * WTN + j * 32 + fr;
+    w_rd[j] = A_BYTES + row * 128;
+    w_sw[j] = (row >> 1) & 7;
+  }
+
+  stage(0, 0);
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+    const char* lds = smem + cur * STAGE_BYTES;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      vnqa_f32x4 xf[TM], wf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        xf[i] = *(const vnqa_f32x4*)(lds + x_rd[i] + (((2 * s + fh) ^ x_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        wf[j] = *(const vnqa_f32x4*)(lds + w_rd[j] + (((2 * s + fh) ^ w_sw[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(wf[j], xf[i], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  // ---------------- epilogue ----------------
+  // acc[i][j][4g+e]: pixel = wm*WTM + i*32 + fr ; cout = wn*WTN + j*32 + 8g + 4*fh + e
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = wn * WTN + j * 32 + 8 * g + 4 * fh;  // tile-local cout of e=0
+      const int co = tile_n * BN + col;
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b4[e] = (co + e < p.Cout) ? p.bias[co + e] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int prow = wm * WTM + i * 32 + fr;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[i][j][4 * g + e] + b4[e];
+          if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        char* dst = smem + prow * CROW + col * ES;
+        if constexpr (ES == 2) {
+          uint2 pk;
+          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          *(uint2*)dst = pk;
+        } else {
+          *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  constexpr int CH = BN * ES / 16;  // 16-byte chunks per tile row
+  const bool has_post = (p.post_scale != nullptr);
+  const int rows_out = p.pool ? BM / 4 : BM;
+  const int M_out = p.pool ? (p.M >> 2) : p.M;
+  const int Ho = p.pool ? (p.H >> 1) : p.H, Wo = p.pool ? (p.W >> 1) : p.W;
+  for (int idx = threadIdx.x; idx < rows_out * CH; idx += NT) {
+    const int orow = idx / CH, c = idx - orow * CH;
+    const int mo = tile_m * rows_out + orow;
+    const int co0 = tile_n * BN + c * EPC;
+    if (mo >= M_out || co0 >= p.Cout) continue;
+    float v[EPC];
+    if (p.pool) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = -INFINITY;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const T* src = (const T*)(smem + (orow * 4 + d) * CROW + c * 16);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = fmaxf(v[e], ElemOps<T>::load(src[e]));
+      }
+    } else {
+      const T* src = (const T*)(smem + orow * CROW + c * 16);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = ElemOps<T>::load(src[e]);
+    }
+    if (has_post) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
+    }
+    const int n = mo / (Ho * Wo);
+    const int rem = mo - n * (Ho * Wo);
+    const int yo = rem / Wo, xo = rem - yo * Wo;
+    T* dst = (T*)(p.y) + (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+    T out[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) out[e] = ElemOps<T>::store(v[e]);
+    *(uint4*)dst = *(const uint4*)out;
+  }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+int launch(const ConvArgs& a, hipStream_t stream) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int CT = BM * (BN * ES + 16);
+  constexpr int LDS = (2 * STAGE > CT) ? 2 * STAGE : CT;
+  static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
+  ConvArgs p = a;
+  const int tilesM = (p.M + BM - 1) / BM;
+  p.tilesN = (p.Cout + BN - 1) / BN;
+  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) {
+      vnqa_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", LDS, hipGetErrorString(e));
+      return VNQA_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tilesM * p.tilesN), dim3(NT), LDS, stream, p);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+}  // namespace
+
+extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
+                                     const float* bias, const float* post_scale,
+                                     const float* post_shift, void* y, void* stream) {
+  VNQA_CHECK_ARG(d && x && wt && y, "conv2d_igemm_fwd: null pointer");
+  VNQA_CHECK_ARG(d->dtype == VNQA_BF16 || d->dtype == VNQA_F32, "conv2d_igemm_fwd: bad dtype %d", d->dtype);
+  const int bk = d->dtype == VNQA_BF16 ? 64 : 32;
+  VNQA_CHECK_ARG(d->taps == 9 || d->taps == 1, "conv2d_igemm_fwd: taps must be 9 or 1 (got %d)", d->taps);
+  VNQA_CHECK_ARG(d->c_in > 0 && d->c_in % bk == 0, "conv2d_igemm_fwd: c_in=%d must be a multiple of %d", d->c_in, bk);
+  VNQA_CHECK_ARG(d->c_out > 0 && d->c_out % 8 == 0 && d->c_y >= d->c_out && d->c_y % 8 == 0,
+                 "conv2d_igemm_fwd: c_out=%d c_y=%d must be multiples of 8, c_y>=c_out", d->c_out, d->c_y);
+  VNQA_CHECK_ARG(d->n_img > 0 && d->h > 0 && d->w > 0, "conv2d_igemm_fwd: empty problem");
+  VNQA_CHECK_ARG((d->taps == 9 && d->x_halo == 1) || (d->taps == 1 && (d->x_halo == 0 || d->x_halo == 1)),
+                 "conv2d_igemm_fwd: x_halo=%d invalid for taps=%d", d->x_halo, d->taps);
+  VNQA_CHECK_ARG(d->y_halo == 0 || d->y_halo == 1, "conv2d_igemm_fwd: y_halo must be 0/1");
+  VNQA_CHECK_ARG(!d->pool2 || (d->h % 2 == 0 && d->w % 2 == 0), "conv2d_igemm_fwd: pool2 needs even h,w");
+  VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv2d_igemm_fwd: post_scale/post_shift must come together");
+  VNQA_CHECK_ARG((long long)d->n_img * d->h * d->w < (1ll << 31), "conv2d_igemm_fwd: too many pixels");
+
+  ConvArgs a;
+  a.x = (const char*)x;
+  a.wt = (const char*)wt;
+  a.bias = bias;
+  a.post_scale = post_scale;
+  a.post_shift = post_shift;
+  a.y = (char*)y;
+  a.n_img = d->n_img;
+  a.H = d->h;
+  a.W = d->w;
+  a.Hp = d->h + 2 * d->x_halo;
+  a.Wp = d->w + 2 * d->x_halo;
+  a.Cin = d->c_in;
+  a.Cout = d->c_out;
+  a.Cy = d->c_y;
+  a.taps = d->taps;
+  a.x_halo = d->x_halo;
+  a.y_halo = d->y_halo;
+  a.relu = d->relu;
+  a.pool = d->pool2;
+  a.M = d->n_img * d->h * d->w;
+  a.tilesN = 0;
+  const int ho = d->pool2 ? d->h / 2 : d->h, wo = d->pool2 ? d->w / 2 : d->w;
+  a.Hyp = ho + 2 * d->y_halo;
+  a.Wyp = wo + 2 * d->y_halo;
+  hipStream_t st = (hipStream_t)stream;
+
+  int tile = d->tile;
+  if (d->dtype == VNQA_BF16) {
+    if (tile == VNQA_TILE_AUTO) {
+      if (d->c_out <= 64) tile = VNQA_TILE_256x64;
+      else if (d->c_out <= 128) tile = VNQA_TILE_256x128;
+      else tile = VNQA_TILE_256x256;
+    }
+    switch (tile) {
+      case VNQA_TILE_256x256: return launch<vnqa_bf16, 256, 256, 2, 4>(a, st);
+      case VNQA_TILE_256x128: return launch<vnqa_bf16, 256, 128, 4, 2>(a, st);
+      case VNQA_TILE_256x64: return launch<vnqa_bf16, 256, 64, 8, 1>(a, st);
+      case VNQA_TILE_128x128: return launch<vnqa_bf16, 128, 128, 2, 2>(a, st);
+      case VNQA_TILE_128x64: return launch<vnqa_bf16, 128, 64, 4, 1>(a, st);
+      default: break;
+    }
+  } else {
+    if (tile == VNQA_TILE_AUTO) tile = d->c_out <= 64 ? VNQA_TILE_128x64 : VNQA_TILE_128x128;
+    switch (tile) {
+      case VNQA_TILE_128x128: return launch<float, 128, 128, 2, 2>(a, st);
+      case VNQA_TILE_128x64: return launch<float, 128, 64, 4, 1>(a, st);
+      default: break;
+    }
+  }
+  vnqa_set_error("conv2d_igemm_fwd: tile id %d not available for dtype %d", tile, d->dtype);
+  return VNQA_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,323 @@
+// conv_wgrad.hip — conv2d weight gradient on MFMA (gfx950).
+//
+//   dWt[co][tap][ci] = sum_P dY[P][co] * X[P + d_tap][ci],   d_tap = (r-1)*Wp + (s-1)
+//
+// X and dY are padded-NHWC buffers of the SAME geometry [n][H+2][W+2][C]; P is the flat
+// padded pixel index.  Because dY's halo is zero, the sum may run over ALL padded positions:
+// a tap is then nothing but a constant shift of the X row pointer, and the contraction index
+// (pixels) is the contiguous-row direction of both operands.  Both tiles are therefore
+// [pixels][channels] images in LDS (filled by global_load_lds, 16-byte chunks XOR-swizzled on
+// the source side), and the MFMA operands — which need 8 consecutive PIXELS of one channel
+// per lane — come out of LDS through the CDNA4 transposed read ds_read_b64_tr_b16.
+// The exact-f32 variant uses v_mfma_f32_32x32x2_f32, whose operands are one element per lane
+// (plain ds_read_b32 of a [pixel][channel] image, no transpose needed).
+//
+// The pixel dimension is split over workgroups (split-K); partial tiles go to fp32 slabs in a
+// caller-provided workspace and a second kernel sums them in a fixed order (deterministic).
+#include "vnqa_common.h"
+
+namespace {
+
+struct WgradArgs {
+  const char* x;
+  const char* dy;
+  float* out;       // slab base: [slices][Cout][taps][Cin]
+  long long Ptot;   // n*Hp*Wp
+  int Wp;
+  int Cin, Cout, taps;
+  int tilesCo, tilesCi;
+  int ksteps_total, ksteps_per_slice, slices;
+};
+
+__device__ __forceinline__ void glds16w(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+// BM = BN = 256 channels, 8 waves as 2 (co) x 4 (ci): wave tile 128 co x 64 ci.
+template <typename T>
+__global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BCH = 256;                 // channels per tile side
+  constexpr int RB = BCH * ES;             // LDS row bytes
+  constexpr int KP = 32768 / RB;           // pixels per K-step (64 bf16 / 32 f32)
+  constexpr int CPR = RB / 16;             // 16-byte chunks per row
+  constexpr int TILE_BYTES = 32768;
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int TM = 4, TN = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // block -> (slice, co tile, tap, ci tile); ci fastest so neighbours share the dY tile
+  int bid = blockIdx.x;
+  const int tile_ci = bid % p.tilesCi; bid /= p.tilesCi;
+  const int tap = bid % p.taps; bid /= p.taps;
+  const int tile_co = bid % p.tilesCo; bid /= p.tilesCo;
+  const int slice = bid;
+
+  int dtap = 0;
+  if (p.taps == 9) {
+    const int r = tap / 3, s = tap - 3 * r;
+    dtap = (r - 1) * p.Wp + (s - 1);
+  }
+
+  // ---- per-lane staging geometry: instruction q = wave*4 + j covers 1 KiB of the tile ----
+  int st_row[4], st_coff_a[4], st_coff_b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int lin = (wave * 4 + j) * 64 + lane;   // 16-byte chunk index within the tile
+    const int row = lin / CPR, phys = lin - row * CPR;
+    const int logical = (ES == 2) ? (phys ^ ((row & 3) << 2)) : phys;
+    st_row[j] = row;
+    // clamp channel tiles that stick out of the tensor (results for those rows/cols are dropped)
+    int ca = tile_co * BCH + logical * (16 / ES);
+    int cb = tile_ci * BCH + logical * (16 / ES);
+    ca = ca < p.Cout ? ca : p.Cout - (16 / ES);
+    cb = cb < p.Cin ? cb : p.Cin - (16 / ES);
+    st_coff_a[j] = ca * ES;
+    st_coff_b[j] = cb * ES;
+  }
+  const size_t rowA = (size_t)p.Cout * ES, rowB = (size_t)p.Cin * ES;
+
+  auto stage = [&](int kstep, int buf) {
+    char* lds = smem + buf * STAGE_BYTES;
+    const long long p0 = (long long)kstep * KP;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long long pa = p0 + st_row[j];
+      pa = pa < p.Ptot ? pa : p.Ptot - 1;
+      long long pb = p0 + st_row[j] + dtap;
+      pb = pb < 0 ? 0 : (pb < p.Ptot ? pb : p.Ptot - 1);
+      glds16w(p.dy + (size_t)pa * rowA + st_coff_a[j], lds + (wave * 4 + j) * 1024);
+      glds16w(p.x + (size_t)pb * rowB + st_coff_b[j], lds + TILE_BYTES + (wave * 4 + j) * 1024);
+    }
+  };
+
+  vnqa_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int k_begin = slice * p.ksteps_per_slice;
+  int k_end = k_begin + p.ksteps_per_slice;
+  k_end = k_end < p.ksteps_total ? k_end : p.ksteps_total;
+
+  // fragment-read lane geometry
+  const int g = lane >> 4, il = lane & 15, q4 = il >> 2, pp = il & 3;  // tr-read roles
+  const int fh = lane >> 5, fr = lane & 31;                            // mfma roles
+
+  if (k_begin < k_end) {
+    stage(k_begin, 0);
+    __syncthreads();
+    for (int kt = k_begin; kt < k_end; ++kt) {
+      const int cur = (kt - k_begin) & 1;
+      if (kt + 1 < k_end) stage(kt + 1, cur ^ 1);
+      const char* ldsA = smem + cur * STAGE_BYTES;
+      const char* ldsB = ldsA + TILE_BYTES;
+      if constexpr (ES == 2) {
+#pragma unroll
+        for (int s = 0; s < KP / 16; ++s) {
+          // lane supplies row (16 s + 8 (g>>1) + q4 [+4]), 4 channels starting at 16(g&1) + 4 pp
+          const int row0 = 16 * s + 8 * (g >> 1) + q4;
+          const int sw = (row0 & 3) << 2;
+          vnqa_bf16x8 af[TM], bf[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int chunk = (wm * 128 + i * 32 + 16 * (g & 1)) / 8 + (pp >> 1);
+            const int off = ((chunk ^ sw) << 4) + ((pp & 1) << 3);
+            const s16x4 lo = lds_tr_read(ldsA + row0 * RB + off);
+            const s16x4 hi = lds_tr_read(ldsA + (row0 + 4) * RB + off);
+            af[i] = vnqa_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int chunk = (wn * 64 + j * 32 + 16 * (g & 1)) / 8 + (pp >> 1);
+            const int off = ((chunk ^ sw) << 4) + ((pp & 1) << 3);
+            const s16x4 lo = lds_tr_read(ldsB + row0 * RB + off);
+            const s16x4 hi = lds_tr_read(ldsB + (row0 + 4) * RB + off);
+            bf[j] = vnqa_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      } else {
+#pragma unroll 4
+        for (int s = 0; s < KP / 2; ++s) {
+          const int row = 2 * s + fh;
+          float af[TM], bf[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = *(const float*)(ldsA + row * RB + (wm * 128 + i * 32 + fr) * 4);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[j] = *(const float*)(ldsB + row * RB + (wn * 64 + j * 32 + fr) * 4);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- store the partial tile: D[co][ci], co = (reg&3)+8(reg>>2)+4 fh, ci = fr ----
+  float* slab = p.out + (size_t)slice * p.Cout * p.taps * p.Cin;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ci = tile_ci * BCH + wn * 64 + j * 32 + fr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = tile_co * BCH + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (co < p.Cout && ci < p.Cin) slab[((size_t)co * p.taps + tap) * p.Cin + ci] = acc[i][j][e];
+      }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n, int slices) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += slabs[(size_t)k * n + i];
+    out[i] = s;
+  }
+}
+
+// column sums of a [P][C] matrix: partial[blk][c] over a pixel range, then slab_reduce.
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ m, float* __restrict__ partial, long long P, int C,
+                                      long long rows_per_block) {
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  r1 = r1 < P ? r1 : P;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (long long r = r0; r < r1; ++r) s += ElemOps<T>::load(m[(size_t)r * C + c]);
+    partial[(size_t)blockIdx.x * C + c] = s;
+  }
+}
+
+struct Plan {
+  int tilesCo, tilesCi, ksteps_total, slices, ksteps_per_slice, colsum_blocks;
+  long long Ptot;
+};
+
+Plan make_plan(int n_img, int h, int w, int c_in, int c_out, int taps, int dtype) {
+  Plan pl;
+  pl.Ptot = (long long)n_img * (h + 2) * (w + 2);
+  const int KP = dtype == VNQA_BF16 ? 64 : 32;
+  pl.tilesCo = (c_out + 255) / 256;
+  pl.tilesCi = (c_in + 255) / 256;
+  pl.ksteps_total = (int)((pl.Ptot + KP - 1) / KP);
+  const int tiles = pl.tilesCo * pl.tilesCi * taps;
+  int slices = (512 + tiles - 1) / tiles;
+  const int max_slices = pl.ksteps_total / 8 > 0 ? pl.ksteps_total / 8 : 1;
+  slices = slices < 1 ? 1 : (slices > max_slices ? max_slices : slices);
+  pl.ksteps_per_slice = (pl.ksteps_total + slices - 1) / slices;
+  pl.slices = (pl.ksteps_total + pl.ksteps_per_slice - 1) / pl.ksteps_per_slice;
+  long long cb = pl.Ptot / 64;
+  pl.colsum_blocks = (int)(cb < 1 ? 1 : (cb > 512 ? 512 : cb));
+  return pl;
+}
+
+}  // namespace
+
+extern "C" int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t w, int32_t c_in,
+                                               int32_t c_out, int32_t taps) {
+  // sized for the larger (f32: smaller K-step -> never fewer slices than bf16) of both dtypes
+  int64_t need = 0;
+  for (int dt = 0; dt < 2; ++dt) {
+    const Plan pl = make_plan(n_img, h, w, c_in, c_out, taps, dt);
+    const int64_t b = ((int64_t)pl.slices * c_out * taps * c_in + (int64_t)pl.colsum_blocks * c_out) * 4;
+    need = b > need ? b : need;
+  }
+  return need;
+}
+
+extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace,
+                                 int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
+                                 int32_t taps, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(x && dy && dwt && workspace, "conv2d_wgrad: null pointer");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv2d_wgrad: bad dtype %d", dtype);
+  VNQA_CHECK_ARG(taps == 9 || taps == 1, "conv2d_wgrad: taps must be 9 or 1");
+  VNQA_CHECK_ARG(c_in % 8 == 0 && c_out % 8 == 0 && c_in >= 8 && c_out >= 8, "conv2d_wgrad: channels must be multiples of 8");
+  VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0, "conv2d_wgrad: empty problem");
+  const Plan pl = make_plan(n_img, h, w, c_in, c_out, taps, dtype);
+  hipStream_t st = (hipStream_t)stream;
+  WgradArgs a;
+  a.x = (const char*)x;
+  a.dy = (const char*)dy;
+  a.out = pl.slices == 1 ? dwt : (float*)workspace;
+  a.Ptot = pl.Ptot;
+  a.Wp = w + 2;
+  a.Cin = c_in;
+  a.Cout = c_out;
+  a.taps = taps;
+  a.tilesCo = pl.tilesCo;
+  a.tilesCi = pl.tilesCi;
+  a.ksteps_total = pl.ksteps_total;
+  a.ksteps_per_slice = pl.ksteps_per_slice;
+  a.slices = pl.slices;
+  const int lds = 2 * 65536;
+  const int grid = pl.slices * pl.tilesCo * taps * pl.tilesCi;
+  static bool attr_done[2] = {false, false};
+  if (dtype == VNQA_BF16) {
+    auto kern = conv_wgrad_kernel<vnqa_bf16>;
+    if (!attr_done[0]) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        vnqa_set_error("conv2d_wgrad: cannot reserve %d B of LDS", lds);
+        return VNQA_ERR_HIP;
+      }
+      attr_done[0] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+  } else {
+    auto kern = conv_wgrad_kernel<float>;
+    if (!attr_done[1]) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        vnqa_set_error("conv2d_wgrad: cannot reserve %d B of LDS", lds);
+        return VNQA_ERR_HIP;
+      }
+      attr_done[1] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+  }
+  VNQA_CHECK_LAUNCH();
+  const size_t n = (size_t)c_out * taps * c_in;
+  if (pl.slices > 1) {
+    int g = (int)((n + 255) / 256);
+    g = g > 2048 ? 2048 : g;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(g), dim3(256), 0, st, (const float*)workspace, dwt, n, pl.slices);
+    VNQA_CHECK_LAUNCH();
+  }
+  if (dbias != nullptr) {
+    float* partial = (float*)workspace + (size_t)pl.slices * n;
+    const long long rpb = (pl.Ptot + pl.colsum_blocks - 1) / pl.colsum_blocks;
+    if (dtype == VNQA_BF16)
+      hipLaunchKernelGGL(colsum_partial_kernel<vnqa_bf16>, dim3(pl.colsum_blocks), dim3(256), 0, st,
+                         (const vnqa_bf16*)dy, partial, pl.Ptot, c_out, rpb);
+    else
+      hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(pl.colsum_blocks), dim3(256), 0, st, (const float*)dy,
+                         partial, pl.Ptot, c_out, rpb);
+    VNQA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((c_out + 255) / 256), dim3(256), 0, st, (const float*)partial, dbias,
+                       (size_t)c_out, pl.colsum_blocks);
+    VNQA_CHECK_LAUNCH();
+  }
+  return VNQA_OK;
+}

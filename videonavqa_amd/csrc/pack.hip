@@ -1,0 +1,177 @@
+// pack.hip — layout conversion kernels between the reference's tensor layouts (OIHW fp32
+// weights, [B][C][h][w][T] fp32 features) and the kernel-native ones (K-major weights,
+// padded NHWC activations).  All memory-bound, one pass each.
+#include "vnqa_common.h"
+
+namespace {
+
+template <typename T>
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, int c_out, int c_in, int taps,
+                                        int rows_pad, int k_ch_pad, const float* __restrict__ out_scale,
+                                        int transpose_flip, T* __restrict__ wt) {
+  // destination index space: [row][tap][ch]
+  const size_t total = (size_t)rows_pad * taps * k_ch_pad;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % k_ch_pad);
+    const int tap = (int)((i / k_ch_pad) % taps);
+    const int row = (int)(i / ((size_t)k_ch_pad * taps));
+    float v = 0.f;
+    if (!transpose_flip) {
+      if (row < c_out && ch < c_in) {
+        v = w[((size_t)row * c_in + ch) * taps + tap];
+        if (out_scale) v *= out_scale[row];
+      }
+    } else {
+      // row = input channel, ch = output channel, tap index flipped (180 degree rotation)
+      if (row < c_in && ch < c_out) v = w[((size_t)ch * c_in + row) * taps + (taps - 1 - tap)];
+    }
+    wt[i] = ElemOps<T>::store(v);
+  }
+}
+
+__global__ void unpack_conv_wgrad_kernel(const float* __restrict__ dwt, int c_out, int c_in, int taps,
+                                         int c_out_pad, int c_in_pad, float* __restrict__ dw) {
+  const size_t total = (size_t)c_out * c_in * taps;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const int ci = (int)((i / taps) % c_in);
+    const int co = (int)(i / ((size_t)taps * c_in));
+    dw[i] = dwt[((size_t)co * taps + tap) * c_in_pad + ci];
+  }
+}
+
+// [B][C][h][w][T] fp32 -> padded NHWC [n_img][h+2][w+2][c_pad]; one block per (b, y, x-chunk)
+template <typename T>
+__global__ void feat_to_nhwc_kernel(const float* __restrict__ v, const int* __restrict__ img_of, T* __restrict__ y,
+                                    int B, int C, int h, int w, int Tn, int c_pad) {
+  // grid: (h*w, B); threads sweep (t, c) with c fastest on the write side
+  const int pix = blockIdx.x, b = blockIdx.y;
+  const int py = pix / w, px = pix - py * w;
+  for (int i = threadIdx.x; i < Tn * c_pad; i += blockDim.x) {
+    const int t = i / c_pad, c = i - t * c_pad;
+    const int img = img_of[b * Tn + t];
+    if (img < 0) continue;
+    float val = 0.f;
+    if (c < C) val = v[((((size_t)b * C + c) * h + py) * w + px) * Tn + t];
+    y[((((size_t)img * (h + 2)) + py + 1) * (w + 2) + px + 1) * c_pad + c] = ElemOps<T>::store(val);
+  }
+}
+
+// padded NHWC [n][h+2*halo][w+2*halo][c_pad] -> dense NCHW fp32 [n][C][h][w]
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ out, int n_img, int C, int h, int w,
+                                    int c_pad, int halo) {
+  const size_t total = (size_t)n_img * C * h * w;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int px = (int)(i % w);
+    const int py = (int)((i / w) % h);
+    const int c = (int)((i / ((size_t)w * h)) % C);
+    const int n = (int)(i / ((size_t)w * h * C));
+    out[i] = ElemOps<T>::load(x[((((size_t)n * (h + 2 * halo)) + py + halo) * (w + 2 * halo) + px + halo) * c_pad + c]);
+  }
+}
+
+// dense NCHW fp32 [n][C][h][w] -> padded NHWC (halo 1), channels zero-padded to c_pad
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int n_img, int C, int h, int w,
+                                    int c_pad) {
+  const size_t total = (size_t)n_img * h * w * c_pad;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c_pad);
+    const int px = (int)((i / c_pad) % w);
+    const int py = (int)((i / ((size_t)c_pad * w)) % h);
+    const int n = (int)(i / ((size_t)c_pad * w * h));
+    const float v = c < C ? x[(((size_t)n * C + c) * h + py) * w + px] : 0.f;
+    y[((((size_t)n * (h + 2)) + py + 1) * (w + 2) + px + 1) * c_pad + c] = ElemOps<T>::store(v);
+  }
+}
+
+inline int grid_for(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" int vnqa_pack_conv_weight(const float* w_oihw, int32_t c_out, int32_t c_in, int32_t taps,
+                                     int32_t c_out_pad, int32_t c_in_pad, const float* out_scale,
+                                     int32_t transpose_flip, int32_t dtype, void* wt, void* stream) {
+  VNQA_CHECK_ARG(w_oihw && wt, "pack_conv_weight: null pointer");
+  VNQA_CHECK_ARG(taps == 9 || taps == 1, "pack_conv_weight: taps must be 9 or 1");
+  VNQA_CHECK_ARG(c_out_pad >= c_out && c_in_pad >= c_in, "pack_conv_weight: pads smaller than sizes");
+  VNQA_CHECK_ARG(!(transpose_flip && out_scale), "pack_conv_weight: out_scale unsupported with transpose_flip");
+  const int rows = transpose_flip ? c_in_pad : c_out_pad;
+  const int kch = transpose_flip ? c_out_pad : c_in_pad;
+  const size_t total = (size_t)rows * taps * kch;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VNQA_BF16)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<vnqa_bf16>, dim3(grid_for(total, 256)), dim3(256), 0, st, w_oihw, c_out,
+                       c_in, taps, rows, kch, out_scale, transpose_flip, (vnqa_bf16*)wt);
+  else if (dtype == VNQA_F32)
+    hipLaunchKernelGGL(pack_conv_weight_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, w_oihw, c_out, c_in,
+                       taps, rows, kch, out_scale, transpose_flip, (float*)wt);
+  else
+    VNQA_CHECK_ARG(false, "pack_conv_weight: bad dtype %d", dtype);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_unpack_conv_wgrad(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps,
+                                      int32_t c_out_pad, int32_t c_in_pad, float* dw_oihw, void* stream) {
+  VNQA_CHECK_ARG(dwt && dw_oihw, "unpack_conv_wgrad: null pointer");
+  const size_t total = (size_t)c_out * c_in * taps;
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dwt, c_out,
+                     c_in, taps, c_out_pad, c_in_pad, dw_oihw);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_feat_to_nhwc(const float* v, const int32_t* img_of, void* y, int32_t b, int32_t c,
+                                 int32_t h, int32_t w, int32_t t, int32_t c_pad, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(v && img_of && y, "feat_to_nhwc: null pointer");
+  VNQA_CHECK_ARG(c_pad >= c, "feat_to_nhwc: c_pad < c");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(h * w, b);
+  if (dtype == VNQA_BF16)
+    hipLaunchKernelGGL(feat_to_nhwc_kernel<vnqa_bf16>, grid, dim3(256), 0, st, v, img_of, (vnqa_bf16*)y, b, c, h, w, t, c_pad);
+  else if (dtype == VNQA_F32)
+    hipLaunchKernelGGL(feat_to_nhwc_kernel<float>, grid, dim3(256), 0, st, v, img_of, (float*)y, b, c, h, w, t, c_pad);
+  else
+    VNQA_CHECK_ARG(false, "feat_to_nhwc: bad dtype %d", dtype);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_nhwc_to_nchw(const void* x, float* out, int32_t n_img, int32_t c, int32_t h, int32_t w,
+                                 int32_t c_pad, int32_t halo, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(x && out, "nhwc_to_nchw: null pointer");
+  const size_t total = (size_t)n_img * c * h * w;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VNQA_BF16)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<vnqa_bf16>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const vnqa_bf16*)x, out,
+                       n_img, c, h, w, c_pad, halo);
+  else if (dtype == VNQA_F32)
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const float*)x, out, n_img,
+                       c, h, w, c_pad, halo);
+  else
+    VNQA_CHECK_ARG(false, "nhwc_to_nchw: bad dtype %d", dtype);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_nchw_to_nhwc(const float* x, void* y, int32_t n_img, int32_t c, int32_t h, int32_t w,
+                                 int32_t c_pad, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(x && y, "nchw_to_nhwc: null pointer");
+  const size_t total = (size_t)n_img * h * w * c_pad;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VNQA_BF16)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<vnqa_bf16>, dim3(grid_for(total, 256)), dim3(256), 0, st, x, (vnqa_bf16*)y, n_img, c,
+                       h, w, c_pad);
+  else if (dtype == VNQA_F32)
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, st, x, (float*)y, n_img, c, h, w,
+                       c_pad);
+  else
+    VNQA_CHECK_ARG(false, "nchw_to_nhwc: bad dtype %d", dtype);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}

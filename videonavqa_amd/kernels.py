@@ -1,0 +1,128 @@
+"""Thin Python wrappers over the C ABI: one function per entry point, device tensors in/out.
+
+Activations are "padded NHWC" tensors [N, H+2, W+2, C] (zero halo) — see include/vnqa_hip.h.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+
+def pack_conv_weight(w_oihw, dtype, out_scale=None, transpose_flip=False, c_out_pad=None, c_in_pad=None):
+    """OIHW fp32 -> K-major [rows][taps][ch] in `dtype` (rows=c_out_pad, or c_in_pad if flipped)."""
+    w = w_oihw.detach().float().contiguous()
+    c_out, c_in, kh, kw = w.shape
+    taps = kh * kw
+    c_out_pad = c_out_pad or L.round_up(c_out, 64)
+    c_in_pad = c_in_pad or L.round_up(c_in, 64)
+    rows, kch = (c_in_pad, c_out_pad) if transpose_flip else (c_out_pad, c_in_pad)
+    wt = torch.empty((rows, taps, kch), dtype=dtype, device=w.device)
+    sc = out_scale.detach().float().contiguous() if out_scale is not None else None
+    L.check(L.lib().vnqa_pack_conv_weight(L.ptr(w), c_out, c_in, taps, c_out_pad, c_in_pad, L.ptr(sc),
+                                          1 if transpose_flip else 0, L.dtype_id(dtype), L.ptr(wt),
+                                          L.stream()), "vnqa_pack_conv_weight")
+    return wt
+
+
+def pad_vec(v, n):
+    """fp32 per-channel vector zero-padded to n entries."""
+    out = torch.zeros(n, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v.detach().float()
+    return out
+
+
+def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
+                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO):
+    """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin]; returns padded NHWC output."""
+    N, Hp, Wp, Cin = x.shape
+    H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
+    c_out, taps, cin_w = wt.shape
+    assert cin_w == Cin and wt.dtype == x.dtype, (wt.shape, x.shape, wt.dtype, x.dtype)
+    Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
+    if out is None:
+        out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
+    d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], taps, x_halo, y_halo,
+                   1 if relu else 0, 1 if pool2 else 0, tile)
+    L.check(L.lib().vnqa_conv2d_igemm_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
+                                          L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_igemm_fwd")
+    return out
+
+
+def conv_first(clip, w, bias, img_of, n_img, dtype, out=None):
+    """clip fp32 [B,3,H,W,T] -> padded NHWC [n_img,H+2,W+2,64] (conv1_1 + ReLU)."""
+    B, C, H, W, T = clip.shape
+    assert C == 3 and clip.dtype == torch.float32
+    c_out = w.shape[0]
+    if out is None:
+        out = torch.zeros((n_img, H + 2, W + 2, c_out), dtype=dtype, device=clip.device)
+    L.check(L.lib().vnqa_conv_first_fwd(L.ptr(clip), L.ptr(w.detach().float().contiguous()),
+                                        L.ptr(bias.detach().float().contiguous()), L.ptr(img_of), L.ptr(out),
+                                        B, T, H, W, c_out, L.dtype_id(dtype), L.stream()), "vnqa_conv_first_fwd")
+    return out
+
+
+def feat_to_nhwc(v, img_of, n_img, dtype, c_pad=None):
+    """v fp32 [B,C,h,w,T] -> padded NHWC [n_img,h+2,w+2,c_pad]; frame (b,t) -> image img_of[b*T+t]."""
+    B, C, h, w, T = v.shape
+    c_pad = c_pad or L.round_up(C, 64)
+    out = torch.zeros((n_img, h + 2, w + 2, c_pad), dtype=dtype, device=v.device)
+    L.check(L.lib().vnqa_feat_to_nhwc(L.ptr(v.float().contiguous()), L.ptr(img_of), L.ptr(out), B, C, h, w, T,
+                                      c_pad, L.dtype_id(dtype), L.stream()), "vnqa_feat_to_nhwc")
+    return out
+
+
+def nchw_to_nhwc(x, dtype, c_pad=None):
+    N, C, h, w = x.shape
+    c_pad = c_pad or L.round_up(C, 64)
+    out = torch.zeros((N, h + 2, w + 2, c_pad), dtype=dtype, device=x.device)
+    L.check(L.lib().vnqa_nchw_to_nhwc(L.ptr(x.float().contiguous()), L.ptr(out), N, C, h, w, c_pad,
+                                      L.dtype_id(dtype), L.stream()), "vnqa_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, C, halo=1):
+    N, Hp, Wp, c_pad = x.shape
+    h, w = Hp - 2 * halo, Wp - 2 * halo
+    out = torch.empty((N, C, h, w), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vnqa_nhwc_to_nchw(L.ptr(x), L.ptr(out), N, C, h, w, c_pad, halo, L.dtype_id(x.dtype),
+                                      L.stream()), "vnqa_nhwc_to_nchw")
+    return out
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only fp32 scratch buffer per device (caller-owned workspace of the C ABI)."""
+    key = str(device)
+    n = (int(nbytes) + 3) // 4
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1), dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def conv2d_wgrad(x, dy, taps, want_bias=True):
+    """x, dy: padded NHWC (halo 1, same N/H/W). Returns (dwt fp32 [Cout][taps][Cin], dbias fp32 [Cout])."""
+    N, Hp, Wp, Cin = x.shape
+    Cout = dy.shape[-1]
+    assert dy.shape[:3] == x.shape[:3] and dy.dtype == x.dtype
+    h, w = Hp - 2, Wp - 2
+    ws = workspace(L.lib().vnqa_conv2d_wgrad_workspace(N, h, w, Cin, Cout, taps), x.device)
+    dwt = torch.empty((Cout, taps, Cin), dtype=torch.float32, device=x.device)
+    dbias = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwt), L.ptr(dbias), L.ptr(ws), N, h, w, Cin, Cout,
+                                      taps, L.dtype_id(x.dtype), L.stream()), "vnqa_conv2d_wgrad")
+    return dwt, dbias
+
+
+def unpack_conv_wgrad(dwt, c_out, c_in):
+    """fp32 [c_out_pad][taps][c_in_pad] -> OIHW fp32 [c_out][c_in][k][k]."""
+    c_out_pad, taps, c_in_pad = dwt.shape
+    k = 3 if taps == 9 else 1
+    out = torch.empty((c_out, c_in, k, k), dtype=torch.float32, device=dwt.device)
+    L.check(L.lib().vnqa_unpack_conv_wgrad(L.ptr(dwt), c_out, c_in, taps, c_out_pad, c_in_pad, L.ptr(out),
+                                           L.stream()), "vnqa_unpack_conv_wgrad")
+    return out
