@@ -128,6 +128,20 @@ int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, v
                       int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
                       int32_t taps, int32_t dtype, void* stream);
 
+/* Dense GEMMs on the same MFMA kernels (nn.Linear fc_embed_attn forward/backward,
+ * models/film_attn_pt_stem.py:57,244).
+ *   vnqa_gemm_nt : out[m][n] = act( sum_k a[m][k] * b[n][k] + bias[n] )   (a, b, out: dtype; K-major operands)
+ *                  K is split over workgroups when m x n alone cannot fill the chip; workspace of
+ *                  vnqa_gemm_nt_workspace() bytes (may be 0 -> NULL allowed).  ldo = row stride of out.
+ *   vnqa_gemm_tn : out[m][n] = sum_k a[k][m] * b[k][n]   (fp32 out; the wgrad kernel with explicit K)
+ */
+int64_t vnqa_gemm_nt_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype);
+int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bias, void* out, void* workspace,
+                 int32_t m, int32_t n, int32_t k, int32_t ldo, int32_t relu, int32_t dtype, void* stream);
+int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype);
+int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void* workspace, int32_t m, int32_t n,
+                 int32_t k, int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,3 +39,36 @@ def model_of_case(case):
 
 QV_CASES = ["film_attn_full", "film_attn_ragged", "film_attn_short", "film_attn_s196",
             "film_gp_full", "film_gp_ragged", "tmh_full", "tmh_ragged"]
+
+
+# constructor arguments used by tools/capture_goldens.py for each golden case
+_B, _CIN, _C, _T, _L = 3, 8, 8, 6, 9
+ATTN_KW = dict(batch_size=_B, q_embedding_size=12, nb_classes=7, num_input_channels=_CIN,
+               num_res_block_channels=_C, num_res_blocks=2, hidden_size=16, at_hidden_size=16,
+               max_num_frames=_T, q_encoder="lstm", vocab_size=20)
+GP_KW = dict(batch_size=_B, q_embedding_size=12, nb_classes=7, num_input_channels=_CIN,
+             num_res_block_channels=_C, num_tail_channels=4, num_res_blocks=2, hidden_size=16,
+             q_encoder="lstm", vocab_size=20)
+TMH_KW = dict(batch_size=_B, q_embedding_size=12, nb_classes=7, num_input_channels=_CIN,
+              num_res_block_channels=_C, num_res_blocks=2, num_tail_channels=4, hidden_size=16,
+              vocab_size=20)
+
+
+def build_product_model(case, precision):
+    """The product (HIP) model configured like the golden case, on the GPU, golden weights loaded."""
+    import videonavqa_amd.models as M
+    g = load_golden(case)
+    if case.startswith("film_attn"):
+        kw = dict(ATTN_KW)
+        spatial = 130
+        if case == "film_attn_s196":
+            kw["num_res_blocks"] = 1
+            spatial = 196
+        model = M.FiLMAttnPretrainedStem(spatial_size=spatial, precision=precision, **kw)
+    elif case.startswith("film_gp"):
+        model = M.FiLMGlobalPoolingPretrainedStem(spatial_size=130, precision=precision, **GP_KW)
+    else:
+        model = M.TimeMultiHopFiLMPretrainedStem(spatial_size=130, precision=precision, **TMH_KW)
+    model = model.cuda()
+    model.load_reference_tensors(weights_from(g, "w0"))
+    return model, g

@@ -31,6 +31,10 @@ _SIGNATURES = {
     "vnqa_feat_to_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_nchw_to_nhwc": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_nhwc_to_nchw": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_gemm_nt_workspace": (_i64, [_i32, _i32, _i32, _i32]),
+    "vnqa_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_gemm_tn_workspace": (_i64, [_i32, _i32, _i32, _i32]),
+    "vnqa_gemm_tn": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_conv2d_wgrad_workspace": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "vnqa_conv2d_wgrad": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
 }

@@ -34,6 +34,8 @@ struct ConvArgs {
   int M;                    // n_img*H*W conv-output pixels
   int tilesN;
   int Hyp, Wyp;             // padded OUTPUT dims (after pooling)
+  int slices, kt_per_slice; // split-K: K-steps [slice*kt_per_slice, ...) -> fp32 slab
+  float* partial;           // [slices][M][Cout] fp32 when slices > 1
 };
 
 template <typename T> struct Mma;
@@ -98,9 +100,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
 
   // XCD-aware, bijective remap: blocks that share an XCD (bid % 8) get a contiguous run of
   // tiles, n-tile fastest, so neighbouring tiles share pixel rows / weight panels in one L2.
-  int tile_m, tile_n;
+  int tile_m, tile_n, slice;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int nwg = gridDim.x / p.slices;
+    slice = blockIdx.x / nwg;
+    const int bid = blockIdx.x - slice * nwg;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     tile_n = swz % p.tilesN;
@@ -178,12 +182,14 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     w_sw[j] = (row >> 1) & 7;
   }
 
-  stage(0, 0);
+  const int kt0 = slice * p.kt_per_slice;
+  const int kt1 = (kt0 + p.kt_per_slice < KT) ? kt0 + p.kt_per_slice : KT;
+  stage(kt0, 0);
   __syncthreads();
 
-  for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
     const char* lds = smem + cur * STAGE_BYTES;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -204,6 +210,24 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
 
   // ---------------- epilogue ----------------
   // acc[i][j][4g+e]: pixel = wm*WTM + i*32 + fr ; cout = wn*WTN + j*32 + 8g + 4*fh + e
+  if (p.partial != nullptr) {
+    // split-K: raw fp32 partial sums, 4 consecutive couts per lane -> 16-byte stores
+    float* slab = p.partial + (size_t)slice * p.M * p.Cout;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = tile_m * BM + wm * WTM + i * 32 + fr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = tile_n * BN + wn * WTN + j * 32 + 8 * g + 4 * fh;
+          if (m < p.M && co < p.Cout)
+            *(float4*)(slab + (size_t)m * p.Cout + co) =
+                make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -299,12 +323,117 @@ int launch(const ConvArgs& a, hipStream_t stream) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(tilesM * p.tilesN), dim3(NT), LDS, stream, p);
+  hipLaunchKernelGGL(kern, dim3(tilesM * p.tilesN * p.slices), dim3(NT), LDS, stream, p);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
 
+int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
+  if (dtype == VNQA_BF16) {
+    if (tile == VNQA_TILE_AUTO) {
+      if (a.Cout <= 64) tile = VNQA_TILE_256x64;
+      else if (a.Cout <= 128) tile = VNQA_TILE_256x128;
+      else tile = VNQA_TILE_256x256;
+    }
+    switch (tile) {
+      case VNQA_TILE_256x256: return launch<vnqa_bf16, 256, 256, 2, 4>(a, st);
+      case VNQA_TILE_256x128: return launch<vnqa_bf16, 256, 128, 4, 2>(a, st);
+      case VNQA_TILE_256x64: return launch<vnqa_bf16, 256, 64, 8, 1>(a, st);
+      case VNQA_TILE_128x128: return launch<vnqa_bf16, 128, 128, 2, 2>(a, st);
+      case VNQA_TILE_128x64: return launch<vnqa_bf16, 128, 64, 4, 1>(a, st);
+      default: break;
+    }
+  } else {
+    if (tile == VNQA_TILE_AUTO) tile = a.Cout <= 64 ? VNQA_TILE_128x64 : VNQA_TILE_128x128;
+    switch (tile) {
+      case VNQA_TILE_128x128: return launch<float, 128, 128, 2, 2>(a, st);
+      case VNQA_TILE_128x64: return launch<float, 128, 64, 4, 1>(a, st);
+      default: break;
+    }
+  }
+  vnqa_set_error("conv2d_igemm_fwd: tile id %d not available for dtype %d", tile, dtype);
+  return VNQA_ERR_UNSUPPORTED;
+}
+
+
+// out[m][n] = act( sum_s slab[s][m][n] + bias[n] ), fixed summation order (deterministic)
+template <typename T>
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias, T* __restrict__ out,
+                                     int M, int N, int ldo, int slices, int relu) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N);
+    const size_t m = i / N;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += slab[(size_t)k * total + i];
+    if (bias) s += bias[n];
+    if (relu) s = fmaxf(s, 0.f);
+    out[m * ldo + n] = ElemOps<T>::store(s);
+  }
+}
+
 }  // namespace
+
+extern "C" int64_t vnqa_gemm_nt_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype) {
+  const int bk = dtype == VNQA_BF16 ? 64 : 32;
+  const int bm = dtype == VNQA_BF16 ? 256 : 128;
+  const int tiles = ((m + bm - 1) / bm) * ((n + 127) / 128);
+  const int kt = k / bk;
+  int slices = (512 + tiles - 1) / tiles;
+  const int max_slices = kt / 8 > 0 ? kt / 8 : 1;
+  slices = slices < 1 ? 1 : (slices > max_slices ? max_slices : slices);
+  return slices <= 1 ? 0 : (int64_t)slices * m * n * 4;
+}
+
+// out[m][n] = act( sum_k a[m][k] * b[n][k] + bias[n] ): the igemm with 1x1 "images"; K is split
+// over workgroups when the M x N tile grid alone cannot fill 256 CUs.
+extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bias, void* out, void* workspace,
+                            int32_t m, int32_t n, int32_t k, int32_t ldo, int32_t relu, int32_t dtype,
+                            void* stream) {
+  VNQA_CHECK_ARG(a_mk && b_nk && out, "gemm_nt: null pointer");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "gemm_nt: bad dtype %d", dtype);
+  const int bk = dtype == VNQA_BF16 ? 64 : 32;
+  VNQA_CHECK_ARG(m > 0 && n > 0 && k > 0 && k % bk == 0, "gemm_nt: k=%d must be a positive multiple of %d", k, bk);
+  VNQA_CHECK_ARG(n % 8 == 0 && ldo >= n && ldo % 8 == 0, "gemm_nt: n=%d ldo=%d must be multiples of 8", n, ldo);
+  const int64_t ws = vnqa_gemm_nt_workspace(m, n, k, dtype);
+  VNQA_CHECK_ARG(ws == 0 || workspace != nullptr, "gemm_nt: workspace of %lld bytes required", (long long)ws);
+  ConvArgs a;
+  a.x = (const char*)a_mk;
+  a.wt = (const char*)b_nk;
+  a.bias = bias;
+  a.post_scale = nullptr;
+  a.post_shift = nullptr;
+  a.y = (char*)out;
+  a.n_img = m; a.H = 1; a.W = 1; a.Hp = 1; a.Wp = 1;
+  a.Cin = k; a.Cout = n; a.Cy = ldo;
+  a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = relu; a.pool = 0;
+  a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1;
+  a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int tile = dtype == VNQA_BF16 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+  if (ws > 0) {
+    const int slices_req = (int)(ws / ((int64_t)m * n * 4));
+    const int kt = k / bk;
+    a.kt_per_slice = (kt + slices_req - 1) / slices_req;
+    a.slices = (kt + a.kt_per_slice - 1) / a.kt_per_slice;
+    a.partial = (float*)workspace;
+    a.bias = nullptr;
+    const int rc = conv_dispatch(a, dtype, tile, st);
+    if (rc != VNQA_OK) return rc;
+    const size_t total = (size_t)m * n;
+    int g = (int)((total + 255) / 256);
+    g = g > 2048 ? 2048 : g;
+    if (dtype == VNQA_BF16)
+      hipLaunchKernelGGL(splitk_reduce_kernel<vnqa_bf16>, dim3(g), dim3(256), 0, st, (const float*)workspace, bias,
+                         (vnqa_bf16*)out, m, n, ldo, a.slices, relu);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)workspace, bias,
+                         (float*)out, m, n, ldo, a.slices, relu);
+    VNQA_CHECK_LAUNCH();
+    return VNQA_OK;
+  }
+  return conv_dispatch(a, dtype, tile, st);
+}
 
 extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
                                      const float* bias, const float* post_scale,
@@ -346,34 +475,11 @@ extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, con
   a.pool = d->pool2;
   a.M = d->n_img * d->h * d->w;
   a.tilesN = 0;
+  a.slices = 1;
+  a.kt_per_slice = 1 << 30;
+  a.partial = nullptr;
   const int ho = d->pool2 ? d->h / 2 : d->h, wo = d->pool2 ? d->w / 2 : d->w;
   a.Hyp = ho + 2 * d->y_halo;
   a.Wyp = wo + 2 * d->y_halo;
-  hipStream_t st = (hipStream_t)stream;
-
-  int tile = d->tile;
-  if (d->dtype == VNQA_BF16) {
-    if (tile == VNQA_TILE_AUTO) {
-      if (d->c_out <= 64) tile = VNQA_TILE_256x64;
-      else if (d->c_out <= 128) tile = VNQA_TILE_256x128;
-      else tile = VNQA_TILE_256x256;
-    }
-    switch (tile) {
-      case VNQA_TILE_256x256: return launch<vnqa_bf16, 256, 256, 2, 4>(a, st);
-      case VNQA_TILE_256x128: return launch<vnqa_bf16, 256, 128, 4, 2>(a, st);
-      case VNQA_TILE_256x64: return launch<vnqa_bf16, 256, 64, 8, 1>(a, st);
-      case VNQA_TILE_128x128: return launch<vnqa_bf16, 128, 128, 2, 2>(a, st);
-      case VNQA_TILE_128x64: return launch<vnqa_bf16, 128, 64, 4, 1>(a, st);
-      default: break;
-    }
-  } else {
-    if (tile == VNQA_TILE_AUTO) tile = d->c_out <= 64 ? VNQA_TILE_128x64 : VNQA_TILE_128x128;
-    switch (tile) {
-      case VNQA_TILE_128x128: return launch<float, 128, 128, 2, 2>(a, st);
-      case VNQA_TILE_128x64: return launch<float, 128, 64, 4, 1>(a, st);
-      default: break;
-    }
-  }
-  vnqa_set_error("conv2d_igemm_fwd: tile id %d not available for dtype %d", tile, d->dtype);
-  return VNQA_ERR_UNSUPPORTED;
+  return conv_dispatch(a, d->dtype, d->tile, (hipStream_t)stream);
 }

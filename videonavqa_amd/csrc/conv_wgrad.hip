@@ -217,9 +217,15 @@ struct Plan {
   long long Ptot;
 };
 
+Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype);
+
 Plan make_plan(int n_img, int h, int w, int c_in, int c_out, int taps, int dtype) {
+  return make_plan_k((long long)n_img * (h + 2) * (w + 2), c_in, c_out, taps, dtype);
+}
+
+Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype) {
   Plan pl;
-  pl.Ptot = (long long)n_img * (h + 2) * (w + 2);
+  pl.Ptot = Ptot;
   const int KP = dtype == VNQA_BF16 ? 64 : 32;
   pl.tilesCo = (c_out + 255) / 256;
   pl.tilesCi = (c_in + 255) / 256;
@@ -249,6 +255,9 @@ extern "C" int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t
   return need;
 }
 
+static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
+                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream);
+
 extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace,
                                  int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
                                  int32_t taps, int32_t dtype, void* stream) {
@@ -258,6 +267,26 @@ extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, floa
   VNQA_CHECK_ARG(c_in % 8 == 0 && c_out % 8 == 0 && c_in >= 8 && c_out >= 8, "conv2d_wgrad: channels must be multiples of 8");
   VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0, "conv2d_wgrad: empty problem");
   const Plan pl = make_plan(n_img, h, w, c_in, c_out, taps, dtype);
+  return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, taps, dtype, stream);
+}
+
+extern "C" int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype) {
+  const Plan pl = make_plan_k(k, n, m, 1, dtype);
+  return ((int64_t)pl.slices * m * n + (int64_t)pl.colsum_blocks * m) * 4;
+}
+
+// out[m][n] = sum_k a[k][m] * b[k][n]  ==  wgrad with taps = 1, "dy" = a, "x" = b, pixels = k
+extern "C" int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void* workspace, int32_t m, int32_t n,
+                            int32_t k, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(a_km && b_kn && out && workspace, "gemm_tn: null pointer");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "gemm_tn: bad dtype %d", dtype);
+  VNQA_CHECK_ARG(m % 8 == 0 && n % 8 == 0 && m >= 8 && n >= 8 && k > 0, "gemm_tn: m, n must be multiples of 8");
+  const Plan pl = make_plan_k(k, n, m, 1, dtype);
+  return wgrad_run(b_kn, a_km, out, nullptr, workspace, pl, 0, n, m, 1, dtype, stream);
+}
+
+static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
+                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   WgradArgs a;
   a.x = (const char*)x;

@@ -126,3 +126,31 @@ def unpack_conv_wgrad(dwt, c_out, c_in):
     L.check(L.lib().vnqa_unpack_conv_wgrad(L.ptr(dwt), c_out, c_in, taps, c_out_pad, c_in_pad, L.ptr(out),
                                            L.stream()), "vnqa_unpack_conv_wgrad")
     return out
+
+
+def gemm_nt(a, b, bias=None, relu=False, out=None):
+    """out[m][n] = act(sum_k a[m][k] b[n][k] + bias[n]); a [M,K], b [N,K] (same dtype), out dtype = a.dtype."""
+    M, Kd = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == Kd and a.dtype == b.dtype
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    did = L.dtype_id(a.dtype)
+    ws_bytes = L.lib().vnqa_gemm_nt_workspace(M, N, Kd, did)
+    ws = workspace(ws_bytes, a.device) if ws_bytes > 0 else None
+    L.check(L.lib().vnqa_gemm_nt(L.ptr(a), L.ptr(b), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, Kd, out.stride(0),
+                                 1 if relu else 0, did, L.stream()), "vnqa_gemm_nt")
+    return out
+
+
+def gemm_tn(a, b):
+    """out[m][n] = sum_k a[k][m] b[k][n]; a [K,M], b [K,N] (same dtype) -> fp32 [M,N]."""
+    Kd, M = a.shape
+    N = b.shape[1]
+    assert b.shape[0] == Kd and a.dtype == b.dtype
+    did = L.dtype_id(a.dtype)
+    ws = workspace(L.lib().vnqa_gemm_tn_workspace(M, N, Kd, did), a.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    L.check(L.lib().vnqa_gemm_tn(L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(ws), M, N, Kd, did, L.stream()),
+            "vnqa_gemm_tn")
+    return out

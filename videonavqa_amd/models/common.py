@@ -1,0 +1,301 @@
+"""Shared machinery of the three FiLM video-question models (host side).
+
+The reference walks frames one by one in Python (models/film_attn_pt_stem.py:201-251): per
+frame a `ct_batch_size` prefix of the (length-sorted) batch goes through conv_init -> ReLU ->
+train-mode BN -> FiLM residual blocks.  Here ALL valid (sample, frame) pairs of the minibatch
+are packed into one image list — frame-major, so the images of one frame are contiguous — and
+every conv runs once over the whole list on the MFMA igemm.  Everything that made the
+per-frame loop necessary is re-expressed on the packed list:
+  * per-frame BatchNorm statistics  -> segmented reduction over the image->frame map;
+  * per-frame FiLM gamma/beta       -> a gather [frame, sample] per image;
+  * the question LSTM re-run per frame with carried state (film_attn_pt_stem.py:160,213)
+                                    -> ONE long sequence per sample (its tokens repeated
+                                       n_frames times), outputs sampled at each repeat's end.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib as L
+from .. import kernels as K
+from .. import ops
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def compute_dtype(precision):
+    if precision in ("bf16", torch.bfloat16):
+        return torch.bfloat16
+    if precision in ("fp32", "f32", torch.float32):
+        return torch.float32
+    raise ValueError("precision must be 'bf16' or 'fp32' (got %r)" % (precision,))
+
+
+class FrameLayout(object):
+    """Packed image list for one minibatch: image n <-> (frame t, sample b), frame-major.
+    cts[t] = #videos with v_len >= t+1 (film_attn_pt_stem.py:201-208); v_lens sorted descending."""
+
+    def __init__(self, v_lens, num_frames, device):
+        vl = [int(v) for v in (v_lens.tolist() if torch.is_tensor(v_lens) else v_lens)]
+        assert all(vl[i] >= vl[i + 1] for i in range(len(vl) - 1)), "v_lens must be sorted descending"
+        B = len(vl)
+        self.B, self.T = B, int(num_frames)
+        self.cts = []
+        for i in range(self.T):
+            ct = sum(1 for v in vl if v >= i + 1)
+            if ct == 0:
+                break
+            self.cts.append(ct)
+        self.n_frames = len(self.cts)
+        self.offsets = [0]
+        for ct in self.cts:
+            self.offsets.append(self.offsets[-1] + ct)
+        self.n_img = self.offsets[-1]
+        img_of = np.full((B * self.T,), -1, np.int32)
+        frame_of, sample_of = [], []
+        for t, ct in enumerate(self.cts):
+            for b in range(ct):
+                img_of[b * self.T + t] = self.offsets[t] + b
+                frame_of.append(t)
+                sample_of.append(b)
+        self.img_of = torch.from_numpy(img_of).to(device)
+        self.frame_of = torch.tensor(frame_of, dtype=torch.long, device=device)
+        self.sample_of = torch.tensor(sample_of, dtype=torch.long, device=device)
+        self.cts_t = torch.tensor(self.cts, dtype=torch.float32, device=device)
+        self.uniform = all(ct == B for ct in self.cts)
+
+
+class NativeFeatures(object):
+    """Stem output kept in kernel-native form: padded NHWC [n_img, h+2, w+2, Cpad] packed by `layout`."""
+
+    def __init__(self, data, layout, channels, h, w):
+        self.data, self.layout, self.channels, self.h, self.w = data, layout, channels, h, w
+
+    @property
+    def shape(self):  # what the reference tensor [B, C, h, w, T] would report
+        return (self.layout.B, self.channels, self.h, self.w, self.layout.T)
+
+
+def interior_mask(hp, wp, device, dtype=torch.float32):
+    m = torch.zeros(1, hp, wp, 1, device=device, dtype=dtype)
+    m[:, 1:-1, 1:-1, :] = 1
+    return m
+
+
+def pad_channels(v, c_pad):
+    """[..., C] -> [..., c_pad] zero-padded."""
+    c = v.shape[-1]
+    return v if c == c_pad else F.pad(v, (0, c_pad - c))
+
+
+def frame_batchnorm(r, bn, layout, training, cdt):
+    """BatchNorm2d applied per frame to relu(conv_init) (film_attn_pt_stem.py:211).
+    Train mode: batch statistics over the ct_B*h*w values of each (frame, channel), running
+    statistics advanced once per frame in frame order.  r: padded NHWC (zero halo)."""
+    N, hp, wp, c_pad = r.shape
+    C = bn.num_features
+    S = (hp - 2) * (wp - 2)
+    mask = interior_mask(hp, wp, r.device)
+    rf = r.float()
+    gamma = pad_channels(bn.weight, c_pad)
+    beta = pad_channels(bn.bias, c_pad)
+    if training:
+        cnt = (layout.cts_t * S).unsqueeze(1)                                  # [T,1]
+        s1 = torch.zeros(layout.n_frames, c_pad, device=r.device).index_add_(0, layout.frame_of, rf.sum((1, 2)))
+        mean = s1 / cnt                                                        # halo is zero: sums are interior sums
+        d = (rf - mean[layout.frame_of].view(N, 1, 1, c_pad)) * mask
+        s2 = torch.zeros(layout.n_frames, c_pad, device=r.device).index_add_(0, layout.frame_of, (d * d).sum((1, 2)))
+        var = s2 / cnt
+        with torch.no_grad():
+            T = layout.n_frames
+            decay = (1.0 - BN_MOMENTUM) ** torch.arange(T - 1, -1, -1, device=r.device, dtype=torch.float32)
+            coef = (BN_MOMENTUM * decay).unsqueeze(1)                          # weight of frame t's statistic
+            unbias = cnt / torch.clamp(cnt - 1, min=1.0)
+            keep = (1.0 - BN_MOMENTUM) ** T
+            bn.running_mean.mul_(keep).add_((coef * mean.detach()[:, :C]).sum(0))
+            bn.running_var.mul_(keep).add_((coef * (var.detach() * unbias)[:, :C]).sum(0))
+            bn.num_batches_tracked += T
+        rstd = torch.rsqrt(var + BN_EPS)
+        xh = d * rstd[layout.frame_of].view(N, 1, 1, c_pad)
+    else:
+        mean = pad_channels(bn.running_mean, c_pad)
+        rstd = torch.rsqrt(pad_channels(bn.running_var, c_pad) + BN_EPS)
+        xh = (rf - mean) * rstd
+    out = (xh * gamma + beta) * mask
+    return out.to(cdt)
+
+
+def film_relu_residual(z, res, gamma, beta, cdt):
+    """relu(gamma * z + beta) + res, gamma/beta per (image, channel) (film_attn_pt_stem.py:231-241)."""
+    N, hp, wp, c_pad = z.shape
+    mask = interior_mask(hp, wp, z.device)
+    g = pad_channels(gamma, c_pad).view(N, 1, 1, c_pad)
+    b = pad_channels(beta, c_pad).view(N, 1, 1, c_pad)
+    out = (F.relu(g * z.float() + b) + res.float()) * mask
+    return out.to(cdt)
+
+
+def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=False):
+    """The question LSTM re-run once per frame with its state carried over
+    (film_attn_pt_stem.py:146-171 called from :213) == one sequence per sample made of its
+    q_len tokens repeated n_frames times.
+    emb [B,L,E]; h0,c0 [B,H] per-sample.  Returns h_last [B,n_frames,H] (output at the last
+    token of each repeat), optional per-frame states [B,n_frames,Lmax,H] (zero past q_len),
+    and the final (h,c) per sample."""
+    B, Lq, E = emb.shape
+    dev = emb.device
+    ql = q_lens.to(dev).long()
+    tot = ql * n_frames
+    Ltot = int(tot.max())
+    steps = torch.arange(Ltot, device=dev).unsqueeze(0).expand(B, Ltot)
+    tok_pos = steps % ql.unsqueeze(1)
+    x_long = emb.gather(1, tok_pos.unsqueeze(2).expand(B, Ltot, E))
+    packed = nn.utils.rnn.pack_padded_sequence(x_long, tot.cpu(), batch_first=True, enforce_sorted=False)
+    out_p, (hn, cn) = lstm(packed, (h0.unsqueeze(0).contiguous(), c0.unsqueeze(0).contiguous()))
+    out, _ = nn.utils.rnn.pad_packed_sequence(out_p, batch_first=True, total_length=Ltot)   # [B,Ltot,H]
+    H = out.shape[-1]
+    rep = torch.arange(n_frames, device=dev).unsqueeze(0)                                   # [1,F]
+    last_idx = rep * ql.unsqueeze(1) + ql.unsqueeze(1) - 1                                  # [B,F]
+    h_last = out.gather(1, last_idx.unsqueeze(2).expand(B, n_frames, H))
+    states = None
+    if want_states:
+        Lmax = int(ql.max())
+        w = torch.arange(Lmax, device=dev).view(1, 1, Lmax)
+        idx = rep.unsqueeze(2) * ql.view(B, 1, 1) + w                                       # [B,F,Lmax]
+        valid = (w < ql.view(B, 1, 1)).expand(B, n_frames, Lmax)
+        idx = torch.where(valid, idx, torch.zeros_like(idx))
+        states = out.gather(1, idx.reshape(B, -1, 1).expand(B, n_frames * Lmax, H)).view(B, n_frames, Lmax, H)
+        states = states * valid.unsqueeze(3).to(states.dtype)
+    return h_last, states, (hn[0], cn[0])
+
+
+class FiLMTrunkBase(nn.Module):
+    """Common constructor pieces / conv trunk of the three models.  Parameter containers are
+    stock torch.nn modules so that names, shapes, init and state_dict match the reference
+    (GPU flavour: film_layer registered, conv1x1_layers a plain list — SURVEY §0.5/0.6);
+    their forward() is never called: compute goes through videonavqa_amd.ops."""
+
+    def _build_trunk(self, num_input_channels, num_res_block_channels, num_res_blocks):
+        self.relu = nn.ReLU(inplace=True)
+        self.conv_init = nn.Conv2d(num_input_channels, num_res_block_channels, kernel_size=3, padding=1)
+        self.bn_init = nn.BatchNorm2d(num_res_block_channels)
+        self.conv1x1_layers = []  # plain list on purpose (film_attn_pt_stem.py:44)
+        layers = []
+        in_channels = num_res_block_channels
+        for _ in range(num_res_blocks):
+            layers.append(nn.Conv2d(in_channels, num_res_block_channels, kernel_size=3, padding=1))
+            c1 = nn.Conv2d(in_channels, num_res_block_channels, kernel_size=1)
+            for p in c1.parameters():
+                p.requires_grad_(False)   # never optimised upstream (not in parameters()); frozen here
+            self.conv1x1_layers.append(c1)
+        self.film_pipeline = nn.ModuleList(layers)
+        self.num_res_blocks = num_res_blocks
+        self.num_res_block_channels = num_res_block_channels
+
+    def weights_init(self, m):
+        """film_attn_pt_stem.py:111-127."""
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            nn.init.xavier_uniform_(m.weight.data)
+            m.bias.data.fill_(0.0)
+        if isinstance(m, nn.LSTM):
+            nn.init.xavier_uniform_(m.weight_ih_l0)
+            nn.init.orthogonal_(m.weight_hh_l0)
+            for names in m._all_weights:
+                for name in filter(lambda n: "bias" in n, names):
+                    bias = getattr(m, name)
+                    n = bias.size(0)
+                    bias.data[n // 4:n // 2].fill_(1.0)
+            m.bias_ih_l0.data.fill_(0.0)
+
+    # nn.Module._apply does not see the plain list: keep the frozen 1x1 convs on the model's device
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        for c in self.conv1x1_layers:
+            c._apply(fn)
+        if getattr(self, "film_hidden", None) is not None:
+            self.film_hidden = tuple(fn(t) for t in self.film_hidden)
+        return self
+
+    def extra_state_tensors(self):
+        """Tensors the reference silently leaves out of state_dict() (conv1x1_layers)."""
+        out = {}
+        for i, c in enumerate(self.conv1x1_layers):
+            out["conv1x1_layers.%d.weight" % i] = c.weight
+            out["conv1x1_layers.%d.bias" % i] = c.bias
+        return out
+
+    def load_reference_tensors(self, tensors):
+        """Load a {name: tensor} dict that may also carry conv1x1_layers.* (goldens, rank-0 broadcast)."""
+        own = dict(self.state_dict())
+        own.update(self.extra_state_tensors())
+        with torch.no_grad():
+            for k, v in tensors.items():
+                if k in own:
+                    own[k].copy_(torch.as_tensor(v).to(own[k].device).view_as(own[k]))
+
+    # ---- input handling -------------------------------------------------------------------
+    def _prepare_input(self, v_input, v_lens):
+        cdt = self.compute_dtype
+        if isinstance(v_input, NativeFeatures):
+            lay = v_input.layout
+            assert v_input.data.dtype == cdt
+            return v_input.data, lay, v_input.h, v_input.w
+        assert v_input.is_cuda, "the HIP path needs device tensors (no CPU fallback)"
+        B, C, h, w, T = v_input.shape
+        lay = FrameLayout(v_lens, T, v_input.device)
+        x = K.feat_to_nhwc(v_input, lay.img_of, lay.n_img, cdt)
+        return x, lay, h, w
+
+    def _question_state(self, B, H, q_lens, device):
+        """Per-sample initial (h, c); the reference stores it in q_len-sorted order (:150,:160)."""
+        fh = getattr(self, "film_hidden", None)
+        if fh is None:
+            z = torch.zeros(B, H, device=device)
+            return z, z.clone()
+        perm = q_lens.sort(0, descending=True)[1].to(device)
+        h0 = torch.empty(B, H, device=device)
+        c0 = torch.empty(B, H, device=device)
+        h0[perm] = fh[0][0].to(device)
+        c0[perm] = fh[1][0].to(device)
+        return h0, c0
+
+    def _store_question_state(self, hn, cn, q_lens):
+        perm = q_lens.sort(0, descending=True)[1].to(hn.device)
+        self.film_hidden = (hn.detach()[perm].unsqueeze(0), cn.detach()[perm].unsqueeze(0))
+
+    # ---- conv trunk on the packed image list -------------------------------------------------
+    def _trunk(self, x, lay, film_fn):
+        """conv_init -> ReLU -> per-frame BN -> FiLM residual blocks.
+        film_fn(k) -> (gamma [n_img,C], beta [n_img,C]) for block k."""
+        cdt = self.compute_dtype
+        r = ops.conv(x, self.conv_init.weight, self.conv_init.bias, relu=True)
+        x = frame_batchnorm(r, self.bn_init, lay, self.training, cdt)
+        for k in range(self.num_res_blocks):
+            c1 = self.conv1x1_layers[k]
+            res = ops.conv(x, c1.weight, c1.bias, relu=True)
+            z = ops.conv(res, self.film_pipeline[k].weight, self.film_pipeline[k].bias, relu=False)
+            gamma, beta = film_fn(k)
+            x = film_relu_residual(z, res, gamma, beta, cdt)
+        return x
+
+    def _fc_native_weight(self, weight, channels, h, w, c_pad, rows_pad):
+        """nn.Linear weight over a NCHW-flattened map [rows, channels*h*w] -> the column order of a
+        flattened padded-NHWC image [rows_pad, (h+2)*(w+2)*c_pad] (zero columns on halo/pad)."""
+        rows = weight.shape[0]
+        w4 = weight.view(rows, channels, h, w).permute(0, 2, 3, 1)
+        w4 = F.pad(w4, (0, c_pad - channels, 1, 1, 1, 1, 0, rows_pad - rows))
+        return w4.reshape(rows_pad, -1)
+
+    def _gp_tail(self, x, lay, h, w):
+        """relu(c1x1_tail) -> zero-padded stack over frames -> max over frames -> out_linear
+        (film_global_pooling_pt_stem.py:228-238)."""
+        t = ops.conv(x, self.c1x1_tail.weight, self.c1x1_tail.bias, relu=True)     # [n_img,hp,wp,tail_pad]
+        n_img, hp, wp, tp = t.shape
+        tail = self.c1x1_tail.out_channels
+        dense = torch.zeros(lay.n_frames, lay.B, hp, wp, tp, device=t.device, dtype=torch.float32)
+        dense = dense.index_put((lay.frame_of, lay.sample_of), t.float())
+        pooled = dense.max(dim=0)[0].reshape(lay.B, -1)
+        w_nat = self._fc_native_weight(self.out_linear.weight, tail, h, w, tp, self.out_linear.out_features)
+        return pooled @ w_nat.t() + self.out_linear.bias

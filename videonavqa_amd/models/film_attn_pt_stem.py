@@ -1,0 +1,114 @@
+"""FiLMAttnPretrainedStem — drop-in for models/film_attn_pt_stem.py of the reference."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib as L
+from .. import ops
+from .common import (FiLMTrunkBase, NativeFeatures, compute_dtype, repeated_question_lstm)
+
+NEG_MASK = float(-(1 << 31))  # film_attn_pt_stem.py:251
+
+
+class FiLMAttnPretrainedStem(FiLMTrunkBase):
+    """Same positional signature and defaults as the reference (film_attn_pt_stem.py:14-25).
+    Extra keyword-only options: spatial_size (the reference hard-codes 130 = 10x13, :56) and
+    precision ('bf16' MFMA fast path | 'fp32' exact-f32 MFMA path)."""
+
+    def __init__(self, batch_size, q_embedding_size, nb_classes, num_input_channels=512,
+                 num_res_block_channels=512, num_res_blocks=1, hidden_size=128, at_hidden_size=128,
+                 max_num_frames=35, q_encoder='lstm', vocab_size=134, *, spatial_size=130,
+                 precision='bf16'):
+        super(FiLMAttnPretrainedStem, self).__init__()
+        assert q_encoder.lower() in ['lstm', 'bow'], "Invalid question encoder! ('lstm', 'bow')"
+        if q_encoder.lower() != 'lstm':
+            # the reference's BoW branch is CUDA-only and discards its division (:173-177); not built
+            raise NotImplementedError("q_encoder='bow' is not implemented on the MI355X path")
+        self.q_encoder = q_encoder
+        self.nb_classes = nb_classes
+        self.batch_size = batch_size
+        self.q_embedding_size = q_embedding_size
+        self.at_hidden_size = at_hidden_size
+        self.hidden_size = hidden_size
+        self.spatial_size = spatial_size
+        self.compute_dtype = compute_dtype(precision)
+
+        self.embed = nn.Embedding(vocab_size, q_embedding_size)                       # :37
+        self._build_trunk(num_input_channels, num_res_block_channels, num_res_blocks)  # :40-52,93-108
+        total_out_size = 2 * num_res_block_channels * num_res_blocks
+        self.film_layer = nn.ModuleList([nn.LSTM(q_embedding_size, hidden_size),      # :75-87 (GPU flavour)
+                                         nn.Linear(hidden_size, total_out_size),
+                                         nn.ReLU(inplace=True)])
+        self.fc_embed_attn = nn.Linear(spatial_size * num_res_block_channels, at_hidden_size)  # :56-57
+        self.fc_attn_1 = nn.Linear(at_hidden_size, 1)                                 # :58
+        self.fc_hidden_attn = nn.Linear(at_hidden_size, 1)                            # :60
+        self.lstm_attn = nn.LSTMCell(at_hidden_size, at_hidden_size)                  # :62
+        self.out_linear = nn.Linear(max_num_frames * at_hidden_size, nb_classes)      # :65
+        for module in self.modules():                                                 # :67-68
+            self.weights_init(module)
+        self.film_hidden = None
+        self.init_hidden()
+
+    def init_hidden(self):
+        """film_attn_pt_stem.py:133-138."""
+        dev = self.embed.weight.device
+        self.film_hidden = (torch.zeros(1, self.batch_size, self.hidden_size, device=dev),
+                            torch.zeros(1, self.batch_size, self.hidden_size, device=dev))
+
+    def forward(self, v_input, q_input, v_lens, q_lens):
+        """v_input: fp32 [B, C_in, h, w, T] (reference layout) or NativeFeatures from the stem;
+        v_lens sorted descending.  Returns fp32 logits [batch_size, nb_classes] (:188-301)."""
+        x, lay, h, w = self._prepare_input(v_input, v_lens)
+        assert lay.B == self.batch_size, "B must equal batch_size (film_attn_pt_stem.py:168)"
+        assert h * w == self.spatial_size, "spatial size %dx%d != spatial_size=%d" % (h, w, self.spatial_size)
+        dev = x.device
+        B, T = lay.B, lay.T
+        C = self.num_res_block_channels
+
+        # FiLM generator: question LSTM re-run per processed frame with carried state (:213)
+        emb = self.embed(q_input)
+        h0, c0 = self._question_state(B, self.hidden_size, q_lens, dev)
+        h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0)
+        self._store_question_state(hn, cn, q_lens)
+        film = F.relu(self.film_layer[1](h_last))                       # [B, n_frames, 2*C*blocks] (:179)
+        film_img = film[lay.sample_of, lay.frame_of]                    # [n_img, 2*C*blocks]
+
+        def film_fn(k):
+            s = 2 * C * k
+            return film_img[:, s:s + C], film_img[:, s + C:s + 2 * C]   # :229-233
+
+        x = self._trunk(x, lay, film_fn)
+
+        # fc_embed_attn over the flattened map (:244) as one split-K GEMM for all images
+        n_img, hp, wp, c_pad = x.shape
+        at = self.at_hidden_size
+        at_pad = L.round_up(at, 64)
+        w_nat = self._fc_native_weight(self.fc_embed_attn.weight, C, h, w, c_pad, at_pad)
+        f = ops.linear_nt(x.view(n_img, -1), w_nat, F.pad(self.fc_embed_attn.bias, (0, at_pad - at)))
+        f = f[:, :at].float()
+        all_features = torch.zeros(B, T, at, device=dev).index_put((lay.sample_of, lay.frame_of), f)  # :245-256
+        valid = torch.zeros(B, T, 1, device=dev).index_put(
+            (lay.sample_of, lay.frame_of), torch.ones(n_img, 1, device=dev))
+        # masks: -(1<<31) where a frame was processed without this sample (:251); frames past the
+        # longest video keep mask 0 and feature 0 (un-masked on purpose)
+        processed = torch.zeros(1, T, 1, device=dev)
+        processed[:, :lay.n_frames] = 1
+        masks = (processed - valid) * NEG_MASK
+        features = self.fc_attn_1(all_features) * valid                 # :268-281
+
+        # temporal attention (:283-295).  v_i = fc_hidden_attn(h) is constant along the frame axis
+        # and softmax is shift invariant, so coefs/ctxt are the same at every step: compute once.
+        coefs = torch.softmax(features + masks, dim=1)                  # :288
+        ctxt = torch.bmm(coefs.permute(0, 2, 1), all_features).view(B, at)  # :290
+        gi = F.linear(ctxt, self.lstm_attn.weight_ih, self.lstm_attn.bias_ih)
+        hh = torch.zeros(B, at, device=dev)
+        cc = torch.zeros(B, at, device=dev)
+        hs = []
+        for _ in range(T):                                              # :283,293
+            g = gi + F.linear(hh, self.lstm_attn.weight_hh, self.lstm_attn.bias_hh)
+            i_, f_, g_, o_ = g.chunk(4, dim=1)
+            cc = torch.sigmoid(f_) * cc + torch.sigmoid(i_) * torch.tanh(g_)
+            hh = torch.sigmoid(o_) * torch.tanh(cc)
+            hs.append(hh)
+        hs = torch.stack(hs, 1).reshape(B, T * at)                      # :294-298
+        return self.out_linear(hs)                                      # :301

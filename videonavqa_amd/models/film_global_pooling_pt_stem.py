@@ -1,0 +1,65 @@
+"""FiLMGlobalPoolingPretrainedStem — drop-in for models/film_global_pooling_pt_stem.py."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .common import FiLMTrunkBase, compute_dtype, repeated_question_lstm
+
+
+class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
+    """Signature/defaults: film_global_pooling_pt_stem.py:13-23; extra keyword-only spatial_size, precision."""
+
+    def __init__(self, batch_size, q_embedding_size, nb_classes, num_input_channels=512,
+                 num_res_block_channels=512, num_tail_channels=16, num_res_blocks=1, hidden_size=128,
+                 q_encoder='lstm', vocab_size=134, *, spatial_size=130, precision='bf16'):
+        super(FiLMGlobalPoolingPretrainedStem, self).__init__()
+        assert q_encoder.lower() in ['lstm', 'bow'], "Invalid question encoder! ('lstm', 'bow')"
+        if q_encoder.lower() != 'lstm':
+            raise NotImplementedError("q_encoder='bow' is not implemented on the MI355X path")
+        self.q_encoder = q_encoder
+        self.nb_classes = nb_classes
+        self.batch_size = batch_size
+        self.q_embedding_size = q_embedding_size
+        self.hidden_size = hidden_size
+        self.spatial_size = spatial_size
+        self.compute_dtype = compute_dtype(precision)
+
+        self.embed = nn.Embedding(vocab_size, q_embedding_size, padding_idx=0)        # :34
+        self._build_trunk(num_input_channels, num_res_block_channels, num_res_blocks)
+        total_out_size = 2 * num_res_block_channels * num_res_blocks
+        self.film_layer = nn.ModuleList([nn.LSTM(q_embedding_size, hidden_size),
+                                         nn.Linear(hidden_size, total_out_size),
+                                         nn.ReLU(inplace=True)])
+        self.c1x1_tail = nn.Conv2d(num_res_block_channels, num_tail_channels, kernel_size=1)  # :52
+        self.out_linear = nn.Linear(spatial_size * num_tail_channels, nb_classes)     # :56
+        for module in self.modules():                                                 # :58-59
+            self.weights_init(module)
+        for module in self.conv1x1_layers:                                            # :60-61
+            self.weights_init(module)
+        self.film_hidden = None
+        self.init_hidden()
+
+    def init_hidden(self):
+        dev = self.embed.weight.device
+        self.film_hidden = (torch.zeros(1, self.batch_size, self.hidden_size, device=dev),
+                            torch.zeros(1, self.batch_size, self.hidden_size, device=dev))
+
+    def forward(self, v_input, q_input, v_lens, q_lens):
+        """film_global_pooling_pt_stem.py:180-238."""
+        x, lay, h, w = self._prepare_input(v_input, v_lens)
+        assert lay.B == self.batch_size
+        assert h * w == self.spatial_size
+        C = self.num_res_block_channels
+        emb = self.embed(q_input)
+        h0, c0 = self._question_state(lay.B, self.hidden_size, q_lens, x.device)
+        h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0)
+        self._store_question_state(hn, cn, q_lens)
+        film = F.relu(self.film_layer[1](h_last))
+        film_img = film[lay.sample_of, lay.frame_of]
+
+        def film_fn(k):
+            s = 2 * C * k
+            return film_img[:, s:s + C], film_img[:, s + C:s + 2 * C]
+
+        x = self._trunk(x, lay, film_fn)
+        return self._gp_tail(x, lay, h, w)

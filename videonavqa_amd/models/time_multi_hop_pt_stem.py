@@ -1,0 +1,78 @@
+"""TimeMultiHopFiLMPretrainedStem — drop-in for models/time_multi_hop_pt_stem.py."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .common import FiLMTrunkBase, compute_dtype, repeated_question_lstm
+
+
+class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
+    """Signature/defaults: time_multi_hop_pt_stem.py:13-22; extra keyword-only spatial_size, precision."""
+
+    def __init__(self, batch_size, q_embedding_size, nb_classes, num_input_channels=512,
+                 num_res_block_channels=512, num_res_blocks=1, num_tail_channels=32, hidden_size=128,
+                 vocab_size=134, *, spatial_size=130, precision='bf16'):
+        super(TimeMultiHopFiLMPretrainedStem, self).__init__()
+        self.nb_classes = nb_classes
+        self.batch_size = batch_size
+        self.q_embedding_size = q_embedding_size
+        self.hidden_size = hidden_size
+        self.spatial_size = spatial_size
+        self.compute_dtype = compute_dtype(precision)
+
+        self.embed = nn.Embedding(vocab_size, q_embedding_size, padding_idx=0)        # :30
+        self._build_trunk(num_input_channels, num_res_block_channels, num_res_blocks)
+        total_out_size = 2 * num_res_block_channels * num_res_blocks
+        self.q_encoder = nn.LSTM(q_embedding_size, hidden_size)                       # :45
+        self.encoder_norm = nn.LayerNorm(hidden_size)                                 # :46
+        self.h = None
+        self.fc_hidden_attn = nn.Linear(hidden_size, 1)                               # :49
+        self.fc_attn_out = nn.Linear(hidden_size, total_out_size)                     # :50
+        self.decoder_norm = nn.LayerNorm(total_out_size)                              # :51
+        self.c1x1_tail = nn.Conv2d(num_res_block_channels, num_tail_channels, kernel_size=1)  # :56
+        self.out_linear = nn.Linear(spatial_size * num_tail_channels, nb_classes)     # :60
+        for module in self.modules():                                                 # :62-65
+            self.weights_init(module)
+        for module in self.conv1x1_layers:
+            self.weights_init(module)
+        self.film_hidden = None
+        self.init_hidden()
+
+    def init_hidden(self):
+        """time_multi_hop_pt_stem.py:111-116."""
+        dev = self.embed.weight.device
+        self.film_hidden = (torch.zeros(1, self.batch_size, self.hidden_size, device=dev),
+                            torch.zeros(1, self.batch_size, self.hidden_size, device=dev))
+        self.h = None
+
+    def forward(self, v_input, q_input, v_lens, q_lens):
+        """time_multi_hop_pt_stem.py:191-250 with compute_film_encoding (:124-158) and
+        decode_to_film_values (:165-184) evaluated for all frames at once."""
+        x, lay, h, w = self._prepare_input(v_input, v_lens)
+        assert lay.B == self.batch_size
+        assert h * w == self.spatial_size
+        B, Fn, Hq = lay.B, lay.n_frames, self.hidden_size
+        C = self.num_res_block_channels
+        emb = self.embed(q_input)
+        h0, c0 = self._question_state(B, Hq, q_lens, x.device)
+        h_last, states, (hn, cn) = repeated_question_lstm(self.q_encoder, emb, q_lens, Fn, h0, c0,
+                                                          want_states=True)
+        self._store_question_state(hn, cn, q_lens)
+        enc = self.encoder_norm(h_last)                                   # [B,F,H]   :148
+        # per-image context, reset at every frame (:157-158); the hop chain runs over blocks
+        hv = enc[lay.sample_of, lay.frame_of]                             # [n_img,H]
+        st = states[lay.sample_of, lay.frame_of]                          # [n_img,Lmax,H] zero past q_len
+        film_per_block = []
+        for _ in range(self.num_res_blocks):
+            prod = hv.unsqueeze(1) * st                                   # :170
+            coefs = torch.softmax(self.fc_hidden_attn(prod), dim=1)       # unmasked over words :171-172
+            hv = torch.bmm(coefs.permute(0, 2, 1), prod).squeeze(1)       # :175-176
+            film_per_block.append(self.decoder_norm(self.fc_attn_out(hv)))  # :179,184
+
+        def film_fn(k):
+            s = 2 * C * k
+            fv = film_per_block[k]
+            return fv[:, s:s + C], fv[:, s + C:s + 2 * C]                 # :228-230
+
+        x = self._trunk(x, lay, film_fn)
+        return self._gp_tail(x, lay, h, w)                                # :240-250

@@ -1,0 +1,80 @@
+"""torch.autograd.Function wrappers over the HIP kernels (videonavqa_amd/kernels.py).
+
+Activations are padded-NHWC tensors [N, H+2, W+2, Cpad] in the compute dtype (bf16 or fp32) with
+a ZERO halo; every op here preserves that invariant (gradients included), because the conv
+kernels get their zero padding — and wgrad its summation domain — from it.
+"""
+import torch
+
+from . import _lib as L
+from . import kernels as K
+
+
+class ConvFn(torch.autograd.Function):
+    """y = [relu](conv2d(x, weight) + bias), 3x3 pad 1 or 1x1; weight/bias are the reference-layout
+    fp32 parameters (OIHW).  Backward: dgrad = the same igemm on flipped weights, wgrad = MFMA
+    split-K kernel.  Replaces nn.Conv2d at models/film_attn_pt_stem.py:211,219,224."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        c_out, c_in, k, _ = weight.shape
+        cdt = x.dtype
+        c_in_pad = x.shape[-1]
+        c_out_pad = L.round_up(c_out, 64)
+        wt = K.pack_conv_weight(weight, cdt, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+        y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu)
+        ctx.relu = relu
+        ctx.dims = (c_out, c_in, k, c_out_pad, c_in_pad)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        c_out, c_in, k, c_out_pad, c_in_pad = ctx.dims
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = dy * (y > 0).to(dy.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dwt, dbias = K.conv2d_wgrad(x, dy, k * k)
+            dw = K.unpack_conv_wgrad(dwt, c_out, c_in)
+            db = dbias[:c_out].clone()
+        if ctx.needs_input_grad[0]:
+            wt_d = K.pack_conv_weight(weight, dy.dtype, transpose_flip=True, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+            dx = K.conv2d_igemm(dy, wt_d)
+        return dx, dw, db, None
+
+
+class LinearNTFn(torch.autograd.Function):
+    """out = x @ w.T + bias on the MFMA GEMM (split-K).  x [M,K] compute dtype, w [N,K] fp32 in the
+    kernel-native column order, N a multiple of 64.  Replaces nn.Linear fc_embed_attn
+    (models/film_attn_pt_stem.py:244) and out_linear of the pooling models."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        wc = w.to(x.dtype).contiguous()
+        out = K.gemm_nt(x.contiguous(), wc, bias=bias.float().contiguous())
+        ctx.save_for_backward(x, wc)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wc = ctx.saved_tensors
+        dout = dout.to(x.dtype).contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = K.gemm_nt(dout, wc.t().contiguous())
+        if ctx.needs_input_grad[1]:
+            dw = K.gemm_tn(dout, x.contiguous())
+        if ctx.needs_input_grad[2]:
+            db = dout.float().sum(0)
+        return dx, dw, db
+
+
+def conv(x, weight, bias, relu=False):
+    return ConvFn.apply(x, weight, bias, relu)
+
+
+def linear_nt(x, w, bias):
+    return LinearNTFn.apply(x, w, bias)
