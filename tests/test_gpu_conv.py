@@ -162,3 +162,30 @@ def test_feat_to_nhwc_roundtrip():
     back = K.nhwc_to_nchw(y, C)  # [T*B, C, h, w]
     ref = v.permute(4, 0, 1, 2, 3).reshape(T * B, C, h, w)
     assert torch.equal(back, ref)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("mnk", [(18, 64, 4096), (280, 128, 8192), (300, 192, 64), (5, 64, 64)])
+def test_gemm_nt(dt, mnk):
+    from videonavqa_amd import kernels as K
+    M, N, Kd = mnk
+    g = torch.Generator(device="cpu").manual_seed(M + N + Kd)
+    a = (torch.randn(M, Kd, generator=g) / Kd ** 0.5).cuda()
+    b = torch.randn(N, Kd, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = F.relu(_q(a, dt) @ _q(b, dt).t() + bias)
+    out = K.gemm_nt(a.to(dt), b.to(dt), bias=bias, relu=True)
+    assert _rel(out.float(), ref) < _tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("mnk", [(64, 4096, 18), (128, 1024, 280), (64, 64, 7), (192, 320, 100)])
+def test_gemm_tn(dt, mnk):
+    from videonavqa_amd import kernels as K
+    M, N, Kd = mnk
+    g = torch.Generator(device="cpu").manual_seed(M + N + Kd)
+    a = torch.randn(Kd, M, generator=g).cuda()
+    b = torch.randn(Kd, N, generator=g).cuda()
+    ref = _q(a, dt).t() @ _q(b, dt)
+    out = K.gemm_tn(a.to(dt), b.to(dt))
+    assert _rel(out, ref) < 5e-5

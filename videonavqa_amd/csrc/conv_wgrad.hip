@@ -36,6 +36,9 @@ __device__ __forceinline__ void glds16w(const char* src, char* lds_wave_base) {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// rows of the contraction range that do not exist read zeros from here
+__device__ __attribute__((aligned(16))) char vnqa_zero_page[64];
+
 __device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
@@ -93,11 +96,11 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
     const long long p0 = (long long)kstep * KP;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      long long pa = p0 + st_row[j];
-      pa = pa < p.Ptot ? pa : p.Ptot - 1;
-      long long pb = p0 + st_row[j] + dtap;
+      const long long pa = p0 + st_row[j];
+      long long pb = pa + dtap;
       pb = pb < 0 ? 0 : (pb < p.Ptot ? pb : p.Ptot - 1);
-      glds16w(p.dy + (size_t)pa * rowA + st_coff_a[j], lds + (wave * 4 + j) * 1024);
+      const char* srcA = pa < p.Ptot ? p.dy + (size_t)pa * rowA + st_coff_a[j] : (const char*)vnqa_zero_page;
+      glds16w(srcA, lds + (wave * 4 + j) * 1024);
       glds16w(p.x + (size_t)pb * rowB + st_coff_b[j], lds + TILE_BYTES + (wave * 4 + j) * 1024);
     }
   };

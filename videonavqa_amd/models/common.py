@@ -254,7 +254,7 @@ class FiLMTrunkBase(nn.Module):
         if fh is None:
             z = torch.zeros(B, H, device=device)
             return z, z.clone()
-        perm = q_lens.sort(0, descending=True)[1].to(device)
+        perm = torch.sort(q_lens.cpu(), dim=0, descending=True, stable=True)[1].to(device)
         h0 = torch.empty(B, H, device=device)
         c0 = torch.empty(B, H, device=device)
         h0[perm] = fh[0][0].to(device)
@@ -262,7 +262,7 @@ class FiLMTrunkBase(nn.Module):
         return h0, c0
 
     def _store_question_state(self, hn, cn, q_lens):
-        perm = q_lens.sort(0, descending=True)[1].to(hn.device)
+        perm = torch.sort(q_lens.cpu(), dim=0, descending=True, stable=True)[1].to(hn.device)
         self.film_hidden = (hn.detach()[perm].unsqueeze(0), cn.detach()[perm].unsqueeze(0))
 
     # ---- conv trunk on the packed image list -------------------------------------------------
