@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — FiLM-attn video-QA training throughput (clips/s) on N MI355X, weak scaling.
+
+One "step" = the hot path on one per-GPU minibatch of synthetic clips:
+  frozen VGG-16[:10] + ObjDetectCNN(512) stem forward over all B*T frames, FiLMAttnPretrainedStem
+  forward + backward, gradient all-reduce (N>1), global-norm clip, Adam  (eval/q_and_v_eval.py:84-139).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "video-QA clips/sec (35×224² frames) FiLM-attn fwd+bwd, 1→8 MI355X"
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+# Algorithmic FLOPs (2*MAC) per frame of the stem igemm layers with Cout=512, at 224x224
+# conv11 3.6994 + conv12 14.7975 + conv21 3.6994 + conv22 3.6994 + conv31 0.9248 + conv32 0.9248
+def stem512_flops_per_frame(H, W):
+    px = lambda d: (H // d) * (W // d)
+    f = lambda p, ci, co: 2.0 * p * ci * co * 9
+    return (f(px(4), 128, 512) + f(px(4), 512, 512) + 2 * f(px(8), 512, 512) + 2 * f(px(16), 512, 512))
+
+
+def stem_flops_per_frame(H, W):
+    px = lambda d: (H // d) * (W // d)
+    f = lambda p, ci, co: 2.0 * p * ci * co * 9
+    return (f(px(1), 3, 64) + f(px(1), 64, 64) + f(px(2), 64, 128) + f(px(2), 128, 128)) + stem512_flops_per_frame(H, W)
+
+
+def trunk_flops_per_frame(S, C_in, C, blocks, at):
+    conv_init = 2.0 * S * C_in * C * 9
+    block = 2.0 * S * C * C * (1 + 9)
+    fc = 2.0 * S * C * at
+    fwd = conv_init + blocks * block + fc
+    return fwd, 3 * fwd - conv_init       # fwd, fwd+bwd (no dgrad through conv_init's input)
+
+
+def build(args, device):
+    from videonavqa_amd.models import FiLMAttnPretrainedStem, ObjDetectCNN
+    from videonavqa_amd.stem import FrozenStem, VGGFront
+    import torch.nn as nn
+    torch.manual_seed(0)     # identical replicas on every rank
+    prec = args.precision
+    vgg = VGGFront(prec)
+    od = ObjDetectCNN(27, 512, 1024, 0, True, True, precision=prec)   # eval/utils.py:43-48
+    with torch.no_grad():
+        for conv in vgg.features.values():
+            nn.init.kaiming_uniform_(conv.weight, a=1.0)
+            conv.bias.normal_(0, 0.02)
+        for m in od.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1.0)
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.8, 1.2)
+    S = (args.height // 16) * (args.width // 16)
+    model = FiLMAttnPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
+                                   num_res_block_channels=args.channels, max_num_frames=args.frames,
+                                   spatial_size=S, precision=prec)
+    vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
+    stem = FrozenStem(vgg, od, prec)
+    return model, stem, vgg, od
+
+
+def synth_batch(args, rank, device):
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    B, T = args.batch, args.frames
+    clip = torch.rand(B, 3, args.height, args.width, T, generator=g)
+    q_lens = torch.randint(5, 26, (B,), generator=g)
+    q = torch.randint(1, 134, (B, 56), generator=g)
+    q = q * (torch.arange(56).unsqueeze(0) < q_lens.unsqueeze(1)).long()
+    v_lens = torch.full((B,), T, dtype=torch.long)
+    y = torch.randint(0, 70, (B,), generator=g)
+    return clip.to(device), q.to(device), v_lens, q_lens, y.to(device)
+
+
+def cpu_baseline(args, model, vgg, od):
+    """The oracle (a CPU restatement of the reference, kind 'port') timed on this host's cores on a
+    bounded sample of the same workload: 2 clips x T frames, full fwd+bwd+clip+Adam step."""
+    from oracle import vnqa_oracle as O
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    Bs = 2
+    g = torch.Generator(device="cpu").manual_seed(99)
+    clip = torch.rand(Bs, 3, args.height, args.width, args.frames, generator=g)
+    q_lens = torch.randint(5, 26, (Bs,), generator=g)
+    q = torch.randint(1, 134, (Bs, 56), generator=g)
+    v_lens = torch.full((Bs,), args.frames, dtype=torch.long)
+    y = torch.randint(0, 70, (Bs,), generator=g)
+    W = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    W.update({k: v.detach().float().cpu().clone() for k, v in model.extra_state_tensors().items()})
+    W_vgg = {k: v.detach().float().cpu() for k, v in vgg.state_dict().items()}
+    W_od = {k: v.detach().float().cpu() for k, v in od.state_dict().items()}
+    adam = O.AdamState(list(W))
+
+    def one():
+        feats = O.stem_forward(clip, W_vgg, W_od)
+        v2, q2, vl2, ql2, y2, _ = O.sort_batch(feats, q, v_lens, q_lens, y)
+        O.train_step("film_attn_pt", W, v2, q2, vl2, ql2, y2, adam, 1e-4)
+
+    one()
+    t0 = time.time()
+    n = 2
+    for _ in range(n):
+        one()
+    dt = (time.time() - t0) / n
+    return {"value": round(Bs / dt, 4), "unit": "clips/s", "cores": nthreads, "kind": "port",
+            "sample": "%d clips x %d frames %dx%d, full step (stem fwd + FiLM-attn fwd/bwd + clip + Adam), "
+                      "%d timed steps after 1 warm-up, torch CPU fp32" % (Bs, args.frames, args.height, args.width, n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=35)
+    ap.add_argument("--height", type=int, default=224)
+    ap.add_argument("--width", type=int, default=224)
+    ap.add_argument("--blocks", type=int, default=1)
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from videonavqa_amd.train import Trainer
+    model, stem, vgg, od = build(args, device)
+    trainer = Trainer(model, stem, lr=1e-4, clip=1.0, loss_reduction="sum", world_size=world, rank=rank)
+    batch = synth_batch(args, rank, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(*batch)
+    stem.timing = []          # (start, end) HIP events around every stem-tagged igemm launch
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(*batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    events = stem.timing
+    stem.timing = None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        clips = args.batch * world * args.steps / dt
+        H, W, T, B = args.height, args.width, args.frames, args.batch
+        n_frames = B * T
+        dur_ms = [s.elapsed_time(e) for s, e in events]
+        avg_ms = sum(dur_ms) / max(len(dur_ms), 1)
+        launches_per_step = max(len(dur_ms) // args.steps, 1)
+        flops_per_launch = n_frames * stem512_flops_per_frame(H, W) / launches_per_step
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        S = (H // 16) * (W // 16)
+        _, trunk_fb = trunk_flops_per_frame(S, 512, args.channels, args.blocks, 128)
+        flops_clip = T * (stem_flops_per_frame(H, W) + trunk_fb)
+        out = {
+            "metric": METRIC, "value": round(clips, 3), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "film_attn_pt_stem training step: VGG-16[:10]+ObjDetectCNN(512) frozen stem + "
+                                   "FiLMAttnPretrainedStem(%d block(s), C=%d, spatial %d) fwd+bwd + clip + Adam; "
+                                   "bs=%d/GPU, %d-frame %dx%d clips, data-parallel"
+                                   % (args.blocks, args.channels, S, B, T, H, W),
+                       "global_batch": B * world, "frames": T, "parallelism": "dp%d" % world,
+                       "gflop_per_clip": round(flops_clip / 1e9, 1),
+                       "whole_step_tflops": round(clips * flops_clip / 1e12, 1),
+                       "final_loss": round(float(loss), 4)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "kernel": "conv_igemm_kernel<bf16,256,256,2,4,TAG=1> (frozen-stem 3x3 igemm, Cout=512 layers)",
+                         "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
+                         "gflop_per_launch": round(flops_per_launch / 1e9, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, model, vgg, od)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

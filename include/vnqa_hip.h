@@ -71,6 +71,7 @@ typedef struct vnqa_conv_desc {
 #define VNQA_TILE_256x64 3
 #define VNQA_TILE_128x128 4
 #define VNQA_TILE_128x64 5
+#define VNQA_TILE_STEM_256x256 6 /* 256x256 geometry, own kernel symbol for the frozen stem (bf16) */
 
 int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
                           const float* bias, const float* post_scale, const float* post_shift,
@@ -141,6 +142,20 @@ int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bias, void* ou
 int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype);
 int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void* workspace, int32_t m, int32_t n,
                  int32_t k, int32_t dtype, void* stream);
+
+/* Fused global-norm clip + Adam + zero_grad over flat fp32 buffers.
+ * Replaces clip_grad_norm(model.parameters(), clip); optimizer.step(); optimizer.zero_grad()
+ * (eval/q_and_v_eval.py:137-139, torch.optim.Adam defaults betas .9/.999 eps 1e-8).
+ *   vnqa_l2norm_partial : partial[i] = sum of squares of block i's slice (n_partial = return of
+ *                         vnqa_l2norm_blocks(n)); deterministic two-stage reduction
+ *   vnqa_clip_adam      : coef = min(1, clip/(sqrt(sum partial)+1e-6)); g*=coef; Adam update of
+ *                         p, m, v; g = 0.  step = 1-based step count (bias correction).
+ */
+int32_t vnqa_l2norm_blocks(int64_t n);
+int vnqa_l2norm_partial(const float* g, int64_t n, float* partial, void* stream);
+int vnqa_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const float* partial,
+                   int32_t n_partial, float clip, float lr, float beta1, float beta2, float eps,
+                   int32_t step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,9 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvnqa_hip.so")
 
 BF16, F32 = 0, 1
-TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64 = range(6)
+TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 
-_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
 
 class ConvDesc(ctypes.Structure):
@@ -31,6 +31,9 @@ _SIGNATURES = {
     "vnqa_feat_to_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_nchw_to_nhwc": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_nhwc_to_nchw": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_l2norm_blocks": (_i32, [_i64]),
+    "vnqa_l2norm_partial": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
+    "vnqa_clip_adam": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
     "vnqa_gemm_nt_workspace": (_i64, [_i32, _i32, _i32, _i32]),
     "vnqa_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_gemm_tn_workspace": (_i64, [_i32, _i32, _i32, _i32]),

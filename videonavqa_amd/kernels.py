@@ -154,3 +154,13 @@ def gemm_tn(a, b):
     L.check(L.lib().vnqa_gemm_tn(L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(ws), M, N, Kd, did, L.stream()),
             "vnqa_gemm_tn")
     return out
+
+
+def clip_adam_step(p, g, m, v, partial, step, lr, clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+    """Fused clip_grad_norm + Adam + zero_grad on flat fp32 buffers (in place)."""
+    n = p.numel()
+    nb = L.lib().vnqa_l2norm_blocks(n)
+    assert partial.numel() >= nb
+    L.check(L.lib().vnqa_l2norm_partial(L.ptr(g), n, L.ptr(partial), L.stream()), "vnqa_l2norm_partial")
+    L.check(L.lib().vnqa_clip_adam(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, L.ptr(partial), nb, clip, lr,
+                                   beta1, beta2, eps, step, L.stream()), "vnqa_clip_adam")

@@ -37,8 +37,12 @@ class FrameLayout(object):
     """Packed image list for one minibatch: image n <-> (frame t, sample b), frame-major.
     cts[t] = #videos with v_len >= t+1 (film_attn_pt_stem.py:201-208); v_lens sorted descending."""
 
-    def __init__(self, v_lens, num_frames, device):
+    def __init__(self, v_lens, num_frames, device, perm=None):
+        """perm (optional): sorted position s holds ORIGINAL sample perm[s] (the batch sort of
+        eval/q_and_v_eval.py:113-116); img_of is then indexed by the original sample order, so the
+        clip tensor itself never needs to be permuted."""
         vl = [int(v) for v in (v_lens.tolist() if torch.is_tensor(v_lens) else v_lens)]
+        pm = list(range(len(vl))) if perm is None else [int(i) for i in perm]
         assert all(vl[i] >= vl[i + 1] for i in range(len(vl) - 1)), "v_lens must be sorted descending"
         B = len(vl)
         self.B, self.T = B, int(num_frames)
@@ -57,7 +61,7 @@ class FrameLayout(object):
         frame_of, sample_of = [], []
         for t, ct in enumerate(self.cts):
             for b in range(ct):
-                img_of[b * self.T + t] = self.offsets[t] + b
+                img_of[pm[b] * self.T + t] = self.offsets[t] + b
                 frame_of.append(t)
                 sample_of.append(b)
         self.img_of = torch.from_numpy(img_of).to(device)
@@ -146,13 +150,14 @@ def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=Fals
     and the final (h,c) per sample."""
     B, Lq, E = emb.shape
     dev = emb.device
-    ql = q_lens.to(dev).long()
+    ql_cpu = q_lens.detach().cpu().long()      # host-side lengths (a DataLoader delivers them on the host)
+    ql = ql_cpu.to(dev)
     tot = ql * n_frames
-    Ltot = int(tot.max())
+    Ltot = int(ql_cpu.max()) * n_frames
     steps = torch.arange(Ltot, device=dev).unsqueeze(0).expand(B, Ltot)
     tok_pos = steps % ql.unsqueeze(1)
     x_long = emb.gather(1, tok_pos.unsqueeze(2).expand(B, Ltot, E))
-    packed = nn.utils.rnn.pack_padded_sequence(x_long, tot.cpu(), batch_first=True, enforce_sorted=False)
+    packed = nn.utils.rnn.pack_padded_sequence(x_long, ql_cpu * n_frames, batch_first=True, enforce_sorted=False)
     out_p, (hn, cn) = lstm(packed, (h0.unsqueeze(0).contiguous(), c0.unsqueeze(0).contiguous()))
     out, _ = nn.utils.rnn.pad_packed_sequence(out_p, batch_first=True, total_length=Ltot)   # [B,Ltot,H]
     H = out.shape[-1]
@@ -161,7 +166,7 @@ def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=Fals
     h_last = out.gather(1, last_idx.unsqueeze(2).expand(B, n_frames, H))
     states = None
     if want_states:
-        Lmax = int(ql.max())
+        Lmax = int(ql_cpu.max())
         w = torch.arange(Lmax, device=dev).view(1, 1, Lmax)
         idx = rep.unsqueeze(2) * ql.view(B, 1, 1) + w                                       # [B,F,Lmax]
         valid = (w < ql.view(B, 1, 1)).expand(B, n_frames, Lmax)

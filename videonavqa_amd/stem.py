@@ -79,6 +79,7 @@ class FrozenStem(object):
         self.layers_vgg, self.layers_od = [], []
         self.first = None
         self._bufs = {}
+        self.timing = None   # bench hook: list collecting (start, end) events around stem-tagged launches
         if vgg is not None:
             f = vgg.features
             dev = f["0"].weight.device
@@ -126,9 +127,17 @@ class FrozenStem(object):
             ho, wo = (h // 2, w // 2) if ly["pool"] else (h, w)
             out = self._buf((tag, i, ho, wo), (n, ho + 2, wo + 2, ly["c_out_pad"]))
             post = ly["post"]
+            tile = L.TILE_STEM_256x256 if (self.cdt == torch.bfloat16 and ly["c_out_pad"] >= 256) else L.TILE_AUTO
+            timed = self.timing is not None and tile == L.TILE_STEM_256x256
+            if timed:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             x = K.conv2d_igemm(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                post_scale=post[0] if post else None, post_shift=post[1] if post else None,
-                               out=out)
+                               out=out, tile=tile)
+            if timed:
+                ev1.record()
+                self.timing.append((ev0, ev1))
         return x
 
     # ---- fused fast path: clip -> packed native features ------------------------------------

@@ -1,0 +1,95 @@
+"""One training step of the video-question fusion path, data-parallel over GPUs.
+
+Restates the inner loop of train_epoch (eval/q_and_v_eval.py:84-139):
+  frozen stem under no_grad (:102-110) -> sort by video length (:113-116) -> init_hidden (:120)
+  -> forward (:121) -> CrossEntropyLoss (:124, reduction per --loss_reduction) -> backward (:136)
+  -> clip_grad_norm 1.0 (:137) -> Adam (:138) -> zero_grad (:139)
+with the MI355X-native pieces: the stem runs on all frames of the minibatch at once and hands
+its output to the model in kernel-native layout; parameters and gradients live in ONE flat
+fp32 buffer each, so the data-parallel gradient sum is a single RCCL all-reduce on that
+buffer and clip+Adam+zero_grad are two HIP launches.
+
+Data parallelism (new; the reference is single-GPU): one process per GPU, every rank holds a
+full replica and its own minibatch; gradients are SUMMED across ranks (loss reduction 'sum',
+eval.sh:16), the global-norm clip then applies to the reduced gradient, and every rank performs
+the identical Adam update.  BatchNorm statistics stay rank-local (no SyncBN upstream).
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import kernels as K
+from .models.common import FrameLayout, NativeFeatures
+
+
+class FlatParams(object):
+    """Re-homes a model's trainable parameters (and their .grad) into flat fp32 buffers."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        n = sum(p.numel() for p in self.params)
+        n_pad = (n + 3) // 4 * 4
+        self.n = n_pad
+        self.flat = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view_as(p)
+            p.grad = self.grad[off:off + k].view_as(p)
+            off += k
+        self.partial = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.step_count = 0
+
+
+class Trainer(object):
+    def __init__(self, model, stem, lr=1e-4, clip=1.0, loss_reduction="sum", class_weights=None,
+                 world_size=1, rank=0, feature_channels=512):
+        self.model, self.stem = model, stem
+        self.lr, self.clip = lr, clip
+        self.world_size, self.rank = world_size, rank
+        self.loss_fn = nn.CrossEntropyLoss(weight=class_weights, reduction=loss_reduction)
+        self.loss_reduction = loss_reduction
+        self.feature_channels = feature_channels
+        if world_size > 1:
+            self.sync_replicas()
+        self.fp = FlatParams(model.parameters())
+
+    def sync_replicas(self):
+        """Rank 0's weights everywhere, INCLUDING the frozen unregistered conv1x1 layers
+        (which state_dict() does not carry)."""
+        tensors = list(self.model.state_dict().values()) + list(self.model.extra_state_tensors().values())
+        for t in tensors:
+            dist.broadcast(t, src=0)
+
+    def extract_features(self, clip, v_lens_cpu):
+        """Stem + batch sort.  clip fp32 [B,3,H,W,T] on the GPU; returns NativeFeatures, perm."""
+        B, _, H, W, T = clip.shape
+        v_sorted, perm = torch.sort(v_lens_cpu, dim=0, descending=True, stable=True)
+        lay = FrameLayout(v_sorted, T, clip.device, perm=perm)
+        feats = self.stem.forward_clip(clip, lay.img_of, lay.n_img)
+        return NativeFeatures(feats, lay, self.feature_channels, H // 16, W // 16), v_sorted, perm
+
+    def step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys):
+        """One optimisation step.  v_lens_cpu / q_lens_cpu are host int64 tensors (as a DataLoader
+        delivers them); clip, q_input, ys are on the GPU.  Returns (loss, logits) — logits rows in
+        length-sorted order like the reference (:121-130)."""
+        self.model.train()
+        native, v_sorted, perm = self.extract_features(clip, v_lens_cpu)
+        perm_d = perm.to(clip.device)
+        self.model.init_hidden()
+        logits = self.model(native, q_input[perm_d], v_sorted, q_lens_cpu[perm])
+        loss = self.loss_fn(logits, ys[perm_d])
+        loss.backward()
+        if self.world_size > 1:
+            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)
+            if self.loss_reduction != "sum":      # 'mean' losses average over the global batch
+                self.fp.grad.div_(self.world_size)
+        self.fp.step_count += 1
+        K.clip_adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.fp.partial,
+                         self.fp.step_count, self.lr, self.clip)
+        return loss.detach(), logits.detach()
