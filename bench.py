@@ -85,23 +85,57 @@ def synth_batch(args, rank, device):
     return clip.to(device), q.to(device), v_lens, q_lens, y.to(device)
 
 
-def cpu_baseline(args, model, vgg, od):
-    """The oracle (a CPU restatement of the reference, kind 'port') timed on this host's cores on a
-    bounded sample of the same workload: 2 clips x T frames, full fwd+bwd+clip+Adam step."""
+def cpu_baseline_child(args):
+    """Runs in a CPU-only child process (`bench.py --cpu-baseline-only`): the oracle — a CPU
+    restatement of the reference, kind 'port' — timed on this host's cores on a bounded sample of
+    the same workload: 2 clips x T frames, full step (stem fwd + FiLM-attn fwd/bwd + clip + Adam)."""
     from oracle import vnqa_oracle as O
-    nthreads = os.cpu_count() or 1
-    torch.set_num_threads(nthreads)
+    import torch.nn as nn
+    torch.manual_seed(0)
+    nthreads = torch.get_num_threads()
     Bs = 2
+    S = (args.height // 16) * (args.width // 16)
+    C = args.channels
     g = torch.Generator(device="cpu").manual_seed(99)
+
+    def rnd(*shape, fan=None):
+        return torch.randn(*shape, generator=g) / (fan or shape[-1]) ** 0.5
+
+    W_vgg = {}
+    for idx, (ci, co) in zip((0, 2, 5, 7), ((3, 64), (64, 64), (64, 128), (128, 128))):
+        W_vgg["features.%d.weight" % idx] = rnd(co, ci, 3, 3, fan=ci * 9)
+        W_vgg["features.%d.bias" % idx] = torch.zeros(co)
+    W_od = {}
+    for name, ci in (("conv11", 128), ("conv12", 512), ("conv21", 512), ("conv22", 512), ("conv31", 512), ("conv32", 512)):
+        W_od[name + ".weight"] = rnd(512, ci, 3, 3, fan=ci * 9)
+        W_od[name + ".bias"] = torch.zeros(512)
+    for name, c in (("bn_input", 128), ("bn1", 512), ("bn2", 512), ("bn3", 512)):
+        W_od[name + ".weight"], W_od[name + ".bias"] = torch.ones(c), torch.zeros(c)
+        W_od[name + ".running_mean"], W_od[name + ".running_var"] = torch.zeros(c), torch.ones(c)
+    at, Hq, E = 128, 128, 128
+    W = {"embed.weight": rnd(134, E, fan=1), "conv_init.weight": rnd(C, 512, 3, 3, fan=4608),
+         "conv_init.bias": torch.zeros(C), "bn_init.weight": torch.ones(C), "bn_init.bias": torch.zeros(C),
+         "bn_init.running_mean": torch.zeros(C), "bn_init.running_var": torch.ones(C),
+         "bn_init.num_batches_tracked": torch.tensor(0),
+         "film_layer.0.weight_ih_l0": rnd(4 * Hq, E), "film_layer.0.weight_hh_l0": rnd(4 * Hq, Hq),
+         "film_layer.0.bias_ih_l0": torch.zeros(4 * Hq), "film_layer.0.bias_hh_l0": torch.zeros(4 * Hq),
+         "film_layer.1.weight": rnd(2 * C * args.blocks, Hq), "film_layer.1.bias": torch.ones(2 * C * args.blocks) * 0.5,
+         "fc_embed_attn.weight": rnd(at, S * C), "fc_embed_attn.bias": torch.zeros(at),
+         "fc_attn_1.weight": rnd(1, at), "fc_attn_1.bias": torch.zeros(1),
+         "fc_hidden_attn.weight": rnd(1, at), "fc_hidden_attn.bias": torch.zeros(1),
+         "lstm_attn.weight_ih": rnd(4 * at, at), "lstm_attn.weight_hh": rnd(4 * at, at),
+         "lstm_attn.bias_ih": torch.zeros(4 * at), "lstm_attn.bias_hh": torch.zeros(4 * at),
+         "out_linear.weight": rnd(70, args.frames * at), "out_linear.bias": torch.zeros(70)}
+    for k in range(args.blocks):
+        W["film_pipeline.%d.weight" % k] = rnd(C, C, 3, 3, fan=C * 9)
+        W["film_pipeline.%d.bias" % k] = torch.zeros(C)
+        W["conv1x1_layers.%d.weight" % k] = rnd(C, C, 1, 1, fan=C)
+        W["conv1x1_layers.%d.bias" % k] = torch.zeros(C)
     clip = torch.rand(Bs, 3, args.height, args.width, args.frames, generator=g)
     q_lens = torch.randint(5, 26, (Bs,), generator=g)
     q = torch.randint(1, 134, (Bs, 56), generator=g)
     v_lens = torch.full((Bs,), args.frames, dtype=torch.long)
     y = torch.randint(0, 70, (Bs,), generator=g)
-    W = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
-    W.update({k: v.detach().float().cpu().clone() for k, v in model.extra_state_tensors().items()})
-    W_vgg = {k: v.detach().float().cpu() for k, v in vgg.state_dict().items()}
-    W_od = {k: v.detach().float().cpu() for k, v in od.state_dict().items()}
     adam = O.AdamState(list(W))
 
     def one():
@@ -115,9 +149,29 @@ def cpu_baseline(args, model, vgg, od):
     for _ in range(n):
         one()
     dt = (time.time() - t0) / n
-    return {"value": round(Bs / dt, 4), "unit": "clips/s", "cores": nthreads, "kind": "port",
-            "sample": "%d clips x %d frames %dx%d, full step (stem fwd + FiLM-attn fwd/bwd + clip + Adam), "
-                      "%d timed steps after 1 warm-up, torch CPU fp32" % (Bs, args.frames, args.height, args.width, n)}
+    print(json.dumps({"value": round(Bs / dt, 4), "unit": "clips/s", "cores": nthreads, "kind": "port",
+                      "sample": "%d clips x %d frames %dx%d, full step (stem fwd + FiLM-attn fwd/bwd + clip + Adam), "
+                                "%d timed steps after 1 warm-up, torch CPU fp32, %d threads"
+                                % (Bs, args.frames, args.height, args.width, n, nthreads)}), flush=True)
+
+
+def cpu_baseline(argv, limit_s=420):
+    """Launch the CPU leg as a child process BEFORE this process touches the GPU; bounded by a timeout."""
+    import subprocess
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"] + argv, env=env,
+                           capture_output=True, text=True, timeout=limit_s)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "clips/s", "cores": None, "kind": "port",
+                "sample": "cpu leg failed: %s" % r.stderr.strip()[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "clips/s", "cores": None, "kind": "port",
+                "sample": "cpu leg exceeded its %d s budget" % limit_s}
 
 
 def main():
@@ -133,13 +187,21 @@ def main():
     ap.add_argument("--blocks", type=int, default=1)
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        cpu_baseline_child(args)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    cpu_leg = None
+    if world == 1 and not args.no_cpu_baseline:
+        fwd = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
+        cpu_leg = cpu_baseline(fwd)          # child process, before any GPU initialisation here
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -206,8 +268,8 @@ def main():
                          "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
                          "gflop_per_launch": round(flops_per_launch / 1e9, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, model, vgg, od)
+        if cpu_leg is not None:
+            out["cpu_baseline"] = cpu_leg
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
