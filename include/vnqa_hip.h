@@ -143,6 +143,28 @@ int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype);
 int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void* workspace, int32_t m, int32_t n,
                  int32_t k, int32_t dtype, void* stream);
 
+/* Persistent LSTM over a repeated sequence (one workgroup per sample, W_hh rows in registers).
+ * Replaces the per-frame packed nn.LSTM calls with carried state of compute_film_values /
+ * compute_film_encoding (models/film_attn_pt_stem.py:146-171 called at :213;
+ * models/time_multi_hop_pt_stem.py:124-158) and, with q_lens == 1, the 35-step nn.LSTMCell chain of the
+ * attention tail (models/film_attn_pt_stem.py:283-295).
+ * Sample b advances q_lens[b] * n_rep cells; at cell t its input gates are xg[b][t % q_lens[b]].
+ *   xg    : fp32 [b][lq][4*hidden]  = x W_ih^T + b_ih + b_hh, gate order i,f,g,o
+ *   w_hh  : fp32 [4*hidden][hidden]
+ *   hs    : fp32 [b][s][hidden]   h after every cell (s >= max q_len*n_rep; rows past a sample's end untouched)
+ *   gates : fp32 [b][s][5*hidden] activated i,f,g,o and c per cell (saved for backward)
+ * backward: dhs = external gradient on every cell's h (same shape as hs, zero where unused);
+ *   dgates fp32 [b][s][4*hidden] = gradient w.r.t. the gate pre-activations of every cell; the caller
+ *   forms dW_hh = sum dgates^T h_prev, dxg[b][pos] = sum over repeats, db = sum dgates from it.
+ * hidden in {16, 32, 64, 128}.
+ */
+int vnqa_lstm_seq_fwd(const float* xg, const float* w_hh, const int32_t* q_lens, const float* h0,
+                      const float* c0, float* hs, float* gates, float* hN, float* cN, int32_t b,
+                      int32_t lq, int32_t hidden, int32_t s, int32_t n_rep, void* stream);
+int vnqa_lstm_seq_bwd(const float* w_hh, const int32_t* q_lens, const float* c0, const float* gates,
+                      const float* dhs, const float* dhN, const float* dcN, float* dgates, float* dh0,
+                      float* dc0, int32_t b, int32_t hidden, int32_t s, int32_t n_rep, void* stream);
+
 /* Fused global-norm clip + Adam + zero_grad over flat fp32 buffers.
  * Replaces clip_grad_norm(model.parameters(), clip); optimizer.step(); optimizer.zero_grad()
  * (eval/q_and_v_eval.py:137-139, torch.optim.Adam defaults betas .9/.999 eps 1e-8).

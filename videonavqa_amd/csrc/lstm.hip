@@ -1,0 +1,216 @@
+// lstm.hip — persistent LSTM over a whole (repeated) sequence, forward and BPTT.
+//
+// The reference re-runs the question LSTM once per video frame with its state carried over
+// (models/film_attn_pt_stem.py:146-171 from :213), i.e. each sample advances through
+// q_len * n_frames cells strictly in sequence, and the attention tail runs a 35-step LSTMCell
+// chain (:283-295).  cuDNN/MIOpen issue several kernels PER TIME STEP; here one launch covers the
+// whole chain: samples are independent, so ONE WORKGROUP OWNS ONE SAMPLE, thread j keeps row j of
+// W_hh (H floats) in registers for the entire sequence, h lives in LDS and is broadcast-read,
+// and a step costs two workgroup barriers.  The input projection x_t W_ih^T + b is the same at
+// every repeat of the question, so it is precomputed once per token ("xg").
+//
+// Latency-bound by construction (a chain of ~800 dependent matvecs of 4H x H); exact fp32.
+#include "vnqa_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+struct LstmArgs {
+  const float* xg;     // [B][Lq][4H]  (gate order i,f,g,o; all biases folded in)
+  const float* w_hh;   // [4H][H]
+  const int* q_lens;   // [B] tokens per repeat
+  const float* h0;     // [B][H]
+  const float* c0;
+  float* hs;           // [B][S][H]   h after every step
+  float* gates;        // [B][S][5H]  i,f,g,o (activated) and c, per step
+  float* hN;
+  float* cN;
+  // backward only
+  const float* dhs;    // [B][S][H] external gradient on every step's h
+  const float* dhN;    // [B][H] or null
+  const float* dcN;
+  float* dgates;       // [B][S][4H] gradient w.r.t. gate pre-activations
+  float* dh0;
+  float* dc0;
+  int B, Lq, S, n_rep;
+};
+
+template <int H>
+__global__ void __launch_bounds__(4 * H) lstm_seq_fwd_kernel(const LstmArgs p) {
+  __shared__ __attribute__((aligned(16))) float s_h[H];
+  __shared__ float s_g[4 * H];
+  const int b = blockIdx.x, j = threadIdx.x;
+  const int ql = p.q_lens[b];
+  const int steps = ql * p.n_rep;
+  float w[H];
+#pragma unroll
+  for (int k = 0; k < H; ++k) w[k] = p.w_hh[(size_t)j * H + k];
+  float c = 0.f;
+  if (j < H) {
+    s_h[j] = p.h0[(size_t)b * H + j];
+    c = p.c0[(size_t)b * H + j];
+  }
+  __syncthreads();
+  const float* xg_b = p.xg + (size_t)b * p.Lq * 4 * H;
+  float* hs_b = p.hs + (size_t)b * p.S * H;
+  float* gt_b = p.gates + (size_t)b * p.S * 5 * H;
+  int pos = 0;
+  float xnext = steps > 0 ? xg_b[j] : 0.f;
+  for (int t = 0; t < steps; ++t) {
+    float acc = xnext;
+    int npos = pos + 1;
+    npos = npos == ql ? 0 : npos;
+    if (t + 1 < steps) xnext = xg_b[(size_t)npos * 4 * H + j];   // prefetch the next step's input gates
+#pragma unroll
+    for (int k = 0; k < H; k += 4) {
+      const float4 hv = *(const float4*)(s_h + k);
+      acc = fmaf(w[k], hv.x, acc);
+      acc = fmaf(w[k + 1], hv.y, acc);
+      acc = fmaf(w[k + 2], hv.z, acc);
+      acc = fmaf(w[k + 3], hv.w, acc);
+    }
+    s_g[j] = acc;
+    __syncthreads();
+    if (j < H) {
+      const float ig = sigmoidf_(s_g[j]);
+      const float fg = sigmoidf_(s_g[H + j]);
+      const float gg = tanhf(s_g[2 * H + j]);
+      const float og = sigmoidf_(s_g[3 * H + j]);
+      c = fg * c + ig * gg;
+      const float h = og * tanhf(c);
+      s_h[j] = h;
+      hs_b[(size_t)t * H + j] = h;
+      float* gt = gt_b + (size_t)t * 5 * H;
+      gt[j] = ig;
+      gt[H + j] = fg;
+      gt[2 * H + j] = gg;
+      gt[3 * H + j] = og;
+      gt[4 * H + j] = c;
+    }
+    __syncthreads();
+    pos = npos;
+  }
+  if (j < H) {
+    p.hN[(size_t)b * H + j] = s_h[j];
+    p.cN[(size_t)b * H + j] = c;
+  }
+}
+
+template <int H>
+__global__ void __launch_bounds__(4 * H) lstm_seq_bwd_kernel(const LstmArgs p) {
+  __shared__ __attribute__((aligned(16))) float s_dg[4 * H];
+  __shared__ float s_part[4 * H];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int part = tid / H, k = tid - part * H;
+  const int steps = p.q_lens[b] * p.n_rep;
+  // thread (part, k) keeps W_hh[part*H + jj][k], jj = 0..H-1: the slice of W_hh^T it needs
+  float wt[H];
+#pragma unroll
+  for (int jj = 0; jj < H; ++jj) wt[jj] = p.w_hh[(size_t)(part * H + jj) * H + k];
+  const float* gt_b = p.gates + (size_t)b * p.S * 5 * H;
+  const float* dhs_b = p.dhs + (size_t)b * p.S * H;
+  float* dg_b = p.dgates + (size_t)b * p.S * 4 * H;
+  float dh_rec = 0.f, dc = 0.f;
+  if (tid < H) {
+    if (p.dhN) dh_rec = p.dhN[(size_t)b * H + tid];
+    if (p.dcN) dc = p.dcN[(size_t)b * H + tid];
+  }
+  for (int t = steps - 1; t >= 0; --t) {
+    if (tid < H) {
+      const int u = tid;
+      const float* gt = gt_b + (size_t)t * 5 * H;
+      const float ig = gt[u], fg = gt[H + u], gg = gt[2 * H + u], og = gt[3 * H + u], ct = gt[4 * H + u];
+      const float cprev = t > 0 ? gt_b[(size_t)(t - 1) * 5 * H + 4 * H + u] : p.c0[(size_t)b * H + u];
+      const float dh = dhs_b[(size_t)t * H + u] + dh_rec;
+      const float tc = tanhf(ct);
+      const float d_o = dh * tc * og * (1.f - og);
+      dc += dh * og * (1.f - tc * tc);
+      const float d_i = dc * gg * ig * (1.f - ig);
+      const float d_f = dc * cprev * fg * (1.f - fg);
+      const float d_g = dc * ig * (1.f - gg * gg);
+      dc *= fg;
+      s_dg[u] = d_i;
+      s_dg[H + u] = d_f;
+      s_dg[2 * H + u] = d_g;
+      s_dg[3 * H + u] = d_o;
+      float* dg = dg_b + (size_t)t * 4 * H;
+      dg[u] = d_i;
+      dg[H + u] = d_f;
+      dg[2 * H + u] = d_g;
+      dg[3 * H + u] = d_o;
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < H; jj += 4) {
+      const float4 dv = *(const float4*)(s_dg + part * H + jj);
+      acc = fmaf(wt[jj], dv.x, acc);
+      acc = fmaf(wt[jj + 1], dv.y, acc);
+      acc = fmaf(wt[jj + 2], dv.z, acc);
+      acc = fmaf(wt[jj + 3], dv.w, acc);
+    }
+    s_part[tid] = acc;
+    __syncthreads();
+    if (tid < H) dh_rec = s_part[tid] + s_part[H + tid] + s_part[2 * H + tid] + s_part[3 * H + tid];
+  }
+  if (tid < H) {
+    p.dh0[(size_t)b * H + tid] = dh_rec;
+    p.dc0[(size_t)b * H + tid] = dc;
+  }
+}
+
+template <int H>
+int launch_fwd(const LstmArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_seq_fwd_kernel<H>, dim3(a.B), dim3(4 * H), 0, st, a);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+template <int H>
+int launch_bwd(const LstmArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_seq_bwd_kernel<H>, dim3(a.B), dim3(4 * H), 0, st, a);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+}  // namespace
+
+extern "C" int vnqa_lstm_seq_fwd(const float* xg, const float* w_hh, const int32_t* q_lens, const float* h0,
+                                 const float* c0, float* hs, float* gates, float* hN, float* cN, int32_t b,
+                                 int32_t lq, int32_t hidden, int32_t s, int32_t n_rep, void* stream) {
+  VNQA_CHECK_ARG(xg && w_hh && q_lens && h0 && c0 && hs && gates && hN && cN, "lstm_seq_fwd: null pointer");
+  VNQA_CHECK_ARG(b > 0 && lq > 0 && s > 0 && n_rep > 0, "lstm_seq_fwd: empty problem");
+  LstmArgs a{};
+  a.xg = xg; a.w_hh = w_hh; a.q_lens = q_lens; a.h0 = h0; a.c0 = c0; a.hs = hs; a.gates = gates;
+  a.hN = hN; a.cN = cN; a.B = b; a.Lq = lq; a.S = s; a.n_rep = n_rep;
+  hipStream_t st = (hipStream_t)stream;
+  switch (hidden) {
+    case 16: return launch_fwd<16>(a, st);
+    case 32: return launch_fwd<32>(a, st);
+    case 64: return launch_fwd<64>(a, st);
+    case 128: return launch_fwd<128>(a, st);
+    default: break;
+  }
+  vnqa_set_error("lstm_seq_fwd: hidden size %d not built (16, 32, 64, 128)", hidden);
+  return VNQA_ERR_UNSUPPORTED;
+}
+
+extern "C" int vnqa_lstm_seq_bwd(const float* w_hh, const int32_t* q_lens, const float* c0, const float* gates,
+                                 const float* dhs, const float* dhN, const float* dcN, float* dgates, float* dh0,
+                                 float* dc0, int32_t b, int32_t hidden, int32_t s, int32_t n_rep, void* stream) {
+  VNQA_CHECK_ARG(w_hh && q_lens && c0 && gates && dhs && dgates && dh0 && dc0, "lstm_seq_bwd: null pointer");
+  VNQA_CHECK_ARG(b > 0 && s > 0 && n_rep > 0, "lstm_seq_bwd: empty problem");
+  LstmArgs a{};
+  a.w_hh = w_hh; a.q_lens = q_lens; a.c0 = c0; a.gates = const_cast<float*>(gates); a.dhs = dhs; a.dhN = dhN; a.dcN = dcN;
+  a.dgates = dgates; a.dh0 = dh0; a.dc0 = dc0; a.B = b; a.S = s; a.n_rep = n_rep;
+  hipStream_t st = (hipStream_t)stream;
+  switch (hidden) {
+    case 16: return launch_bwd<16>(a, st);
+    case 32: return launch_bwd<32>(a, st);
+    case 64: return launch_bwd<64>(a, st);
+    case 128: return launch_bwd<128>(a, st);
+    default: break;
+  }
+  vnqa_set_error("lstm_seq_bwd: hidden size %d not built (16, 32, 64, 128)", hidden);
+  return VNQA_ERR_UNSUPPORTED;
+}

@@ -164,3 +164,32 @@ def clip_adam_step(p, g, m, v, partial, step, lr, clip=1.0, beta1=0.9, beta2=0.9
     L.check(L.lib().vnqa_l2norm_partial(L.ptr(g), n, L.ptr(partial), L.stream()), "vnqa_l2norm_partial")
     L.check(L.lib().vnqa_clip_adam(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, L.ptr(partial), nb, clip, lr,
                                    beta1, beta2, eps, step, L.stream()), "vnqa_clip_adam")
+
+
+def lstm_seq_fwd(xg, w_hh, q_lens_i32, h0, c0, n_rep, S):
+    """Persistent LSTM forward.  xg [B,Lq,4H] fp32; returns hs [B,S,H], gates [B,S,5H], hN, cN."""
+    B, Lq, H4 = xg.shape
+    H = H4 // 4
+    dev = xg.device
+    hs = torch.zeros((B, S, H), dtype=torch.float32, device=dev)
+    gates = torch.zeros((B, S, 5 * H), dtype=torch.float32, device=dev)
+    hN = torch.empty((B, H), dtype=torch.float32, device=dev)
+    cN = torch.empty((B, H), dtype=torch.float32, device=dev)
+    L.check(L.lib().vnqa_lstm_seq_fwd(L.ptr(xg), L.ptr(w_hh), L.ptr(q_lens_i32), L.ptr(h0), L.ptr(c0), L.ptr(hs),
+                                      L.ptr(gates), L.ptr(hN), L.ptr(cN), B, Lq, H, S, n_rep, L.stream()),
+            "vnqa_lstm_seq_fwd")
+    return hs, gates, hN, cN
+
+
+def lstm_seq_bwd(w_hh, q_lens_i32, c0, gates, dhs, dhN, dcN, n_rep):
+    """Persistent BPTT.  Returns dgates [B,S,4H], dh0, dc0."""
+    B, S, H5 = gates.shape
+    H = H5 // 5
+    dev = gates.device
+    dgates = torch.zeros((B, S, 4 * H), dtype=torch.float32, device=dev)
+    dh0 = torch.empty((B, H), dtype=torch.float32, device=dev)
+    dc0 = torch.empty((B, H), dtype=torch.float32, device=dev)
+    L.check(L.lib().vnqa_lstm_seq_bwd(L.ptr(w_hh), L.ptr(q_lens_i32), L.ptr(c0), L.ptr(gates), L.ptr(dhs),
+                                      L.ptr(dhN), L.ptr(dcN), L.ptr(dgates), L.ptr(dh0), L.ptr(dc0), B, H, S,
+                                      n_rep, L.stream()), "vnqa_lstm_seq_bwd")
+    return dgates, dh0, dc0

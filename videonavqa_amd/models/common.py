@@ -143,8 +143,8 @@ def film_relu_residual(z, res, gamma, beta, cdt):
 
 def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=False):
     """The question LSTM re-run once per frame with its state carried over
-    (film_attn_pt_stem.py:146-171 called from :213) == one sequence per sample made of its
-    q_len tokens repeated n_frames times.
+    (film_attn_pt_stem.py:146-171 called from :213) == one chain per sample made of its q_len
+    tokens repeated n_frames times — ONE persistent HIP launch (ops.lstm_seq).
     emb [B,L,E]; h0,c0 [B,H] per-sample.  Returns h_last [B,n_frames,H] (output at the last
     token of each repeat), optional per-frame states [B,n_frames,Lmax,H] (zero past q_len),
     and the final (h,c) per sample."""
@@ -152,28 +152,24 @@ def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=Fals
     dev = emb.device
     ql_cpu = q_lens.detach().cpu().long()      # host-side lengths (a DataLoader delivers them on the host)
     ql = ql_cpu.to(dev)
-    tot = ql * n_frames
-    Ltot = int(ql_cpu.max()) * n_frames
-    steps = torch.arange(Ltot, device=dev).unsqueeze(0).expand(B, Ltot)
-    tok_pos = steps % ql.unsqueeze(1)
-    x_long = emb.gather(1, tok_pos.unsqueeze(2).expand(B, Ltot, E))
-    packed = nn.utils.rnn.pack_padded_sequence(x_long, ql_cpu * n_frames, batch_first=True, enforce_sorted=False)
-    out_p, (hn, cn) = lstm(packed, (h0.unsqueeze(0).contiguous(), c0.unsqueeze(0).contiguous()))
-    out, _ = nn.utils.rnn.pad_packed_sequence(out_p, batch_first=True, total_length=Ltot)   # [B,Ltot,H]
-    H = out.shape[-1]
+    Lmax = int(ql_cpu.max())
+    S = Lmax * n_frames
+    H = lstm.hidden_size
+    # input projection is identical at every repeat: once per token, both biases folded in
+    xg = F.linear(emb, lstm.weight_ih_l0, lstm.bias_ih_l0 + lstm.bias_hh_l0)
+    out, hn, cn = ops.lstm_seq(xg, lstm.weight_hh_l0, h0, c0, ql.to(torch.int32), n_frames, S)   # [B,S,H]
     rep = torch.arange(n_frames, device=dev).unsqueeze(0)                                   # [1,F]
     last_idx = rep * ql.unsqueeze(1) + ql.unsqueeze(1) - 1                                  # [B,F]
     h_last = out.gather(1, last_idx.unsqueeze(2).expand(B, n_frames, H))
     states = None
     if want_states:
-        Lmax = int(ql_cpu.max())
         w = torch.arange(Lmax, device=dev).view(1, 1, Lmax)
         idx = rep.unsqueeze(2) * ql.view(B, 1, 1) + w                                       # [B,F,Lmax]
         valid = (w < ql.view(B, 1, 1)).expand(B, n_frames, Lmax)
         idx = torch.where(valid, idx, torch.zeros_like(idx))
         states = out.gather(1, idx.reshape(B, -1, 1).expand(B, n_frames * Lmax, H)).view(B, n_frames, Lmax, H)
         states = states * valid.unsqueeze(3).to(states.dtype)
-    return h_last, states, (hn[0], cn[0])
+    return h_last, states, (hn, cn)
 
 
 class FiLMTrunkBase(nn.Module):

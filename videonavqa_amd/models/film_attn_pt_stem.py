@@ -100,15 +100,11 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         # and softmax is shift invariant, so coefs/ctxt are the same at every step: compute once.
         coefs = torch.softmax(features + masks, dim=1)                  # :288
         ctxt = torch.bmm(coefs.permute(0, 2, 1), all_features).view(B, at)  # :290
-        gi = F.linear(ctxt, self.lstm_attn.weight_ih, self.lstm_attn.bias_ih)
-        hh = torch.zeros(B, at, device=dev)
-        cc = torch.zeros(B, at, device=dev)
-        hs = []
-        for _ in range(T):                                              # :283,293
-            g = gi + F.linear(hh, self.lstm_attn.weight_hh, self.lstm_attn.bias_hh)
-            i_, f_, g_, o_ = g.chunk(4, dim=1)
-            cc = torch.sigmoid(f_) * cc + torch.sigmoid(i_) * torch.tanh(g_)
-            hh = torch.sigmoid(o_) * torch.tanh(cc)
-            hs.append(hh)
-        hs = torch.stack(hs, 1).reshape(B, T * at)                      # :294-298
+        # the 35-step LSTMCell chain on a constant input = the persistent LSTM kernel with
+        # one "token" repeated T times (:283,293-298)
+        gi = F.linear(ctxt, self.lstm_attn.weight_ih, self.lstm_attn.bias_ih + self.lstm_attn.bias_hh)
+        zeros = torch.zeros(B, at, device=dev)
+        ones = torch.ones(B, dtype=torch.int32, device=dev)
+        hs, _, _ = ops.lstm_seq(gi.unsqueeze(1), self.lstm_attn.weight_hh, zeros, zeros, ones, T, T)
+        hs = hs.reshape(B, T * at)
         return self.out_linear(hs)                                      # :301

@@ -78,3 +78,43 @@ def conv(x, weight, bias, relu=False):
 
 def linear_nt(x, w, bias):
     return LinearNTFn.apply(x, w, bias)
+
+
+class LstmSeqFn(torch.autograd.Function):
+    """hs, hN, cN = LSTM over each sample's tokens repeated n_rep times (state carried), one HIP
+    launch for the whole chain; BPTT in one launch too.  Inputs: xg [B,Lq,4H] (input projection
+    with both biases), w_hh [4H,H], h0/c0 [B,H]; q_lens_i32 device int32 [B]; S = max cells."""
+
+    @staticmethod
+    def forward(ctx, xg, w_hh, h0, c0, q_lens_i32, n_rep, S):
+        xg = xg.float().contiguous()
+        w = w_hh.float().contiguous()
+        h0 = h0.float().contiguous()
+        c0 = c0.float().contiguous()
+        hs, gates, hN, cN = K.lstm_seq_fwd(xg, w, q_lens_i32, h0, c0, n_rep, S)
+        ctx.save_for_backward(w, h0, c0, hs, gates, q_lens_i32)
+        ctx.n_rep, ctx.Lq = n_rep, xg.shape[1]
+        return hs, hN, cN
+
+    @staticmethod
+    def backward(ctx, dhs, dhN, dcN):
+        w, h0, c0, hs, gates, q_lens_i32 = ctx.saved_tensors
+        B, S, H = hs.shape
+        n_rep, Lq = ctx.n_rep, ctx.Lq
+        dhs = torch.zeros_like(hs) if dhs is None else dhs.float().contiguous()
+        dhN = None if dhN is None else dhN.float().contiguous()
+        dcN = None if dcN is None else dcN.float().contiguous()
+        dgates, dh0, dc0 = K.lstm_seq_bwd(w, q_lens_i32, c0, gates, dhs, dhN, dcN, n_rep)
+        # dW_hh = sum_{b,t} dgates[b,t]^T h_{t-1}[b]   (rows past a sample's last cell are zero)
+        hprev = torch.cat([h0.unsqueeze(1), hs[:, :-1]], dim=1)
+        dw = K.gemm_tn(dgates.view(B * S, 4 * H), hprev.reshape(B * S, H).contiguous())
+        # dxg[b][pos] = sum over repeats of dgates at cells t with t % q_len == pos
+        ql = q_lens_i32.long().clamp(min=1).unsqueeze(1)
+        t = torch.arange(S, device=hs.device).unsqueeze(0)
+        pos = (t % ql).unsqueeze(2).expand(B, S, 4 * H)
+        dxg = torch.zeros(B, Lq, 4 * H, device=hs.device).scatter_add_(1, pos, dgates)
+        return dxg, dw, dh0, dc0, None, None, None
+
+
+def lstm_seq(xg, w_hh, h0, c0, q_lens_i32, n_rep, S):
+    return LstmSeqFn.apply(xg, w_hh, h0, c0, q_lens_i32, n_rep, S)
