@@ -143,6 +143,34 @@ int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype);
 int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void* workspace, int32_t m, int32_t n,
                  int32_t k, int32_t dtype, void* stream);
 
+/* Fused memory-bound glue of the FiLM trunk on padded-NHWC activations [n_img][hp][wp][c], c % 64 == 0,
+ * zero halo (outputs get their halo written as zero).
+ *   vnqa_frame_bn_stats : per-(frame, channel) mean / biased variance over the frame's images, i.e. the
+ *                         batch statistics of train-mode bn_init applied frame by frame
+ *                         (models/film_attn_pt_stem.py:211); frame f owns images [frame_off[f], frame_off[f+1])
+ *   vnqa_frame_bn_apply : y = (x - mean[f]) * rstd[f] * gamma + beta, f = frame_of[image]
+ *   vnqa_frame_bn_bwd   : BatchNorm backward per frame (s1 = sum dy, s2 = sum dy*xhat are returned for
+ *                         dbeta/dgamma); relu_mask != 0 also applies the mask of the ReLU that produced x
+ *   vnqa_film_relu_res_fwd : out = relu(gamma[n] * z + beta[n]) + res            (:229-241)
+ *   vnqa_film_relu_res_bwd : dz, dgamma[n][c], dbeta[n][c] (wave/LDS reductions over pixels); dres == dout
+ *   vnqa_relu_bwd       : g = (a [+ b]) * [y > 0]
+ */
+int vnqa_frame_bn_stats(const void* x, const int32_t* frame_off, float* mean, float* var, int32_t n_frames,
+                        int32_t hp, int32_t wp, int32_t c, int32_t dtype, void* stream);
+int vnqa_frame_bn_apply(const void* x, const int32_t* frame_of, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, void* y, int32_t n_img, int32_t hp,
+                        int32_t wp, int32_t c, int32_t dtype, void* stream);
+int vnqa_frame_bn_bwd(const void* dy, const void* x, const int32_t* frame_of, const int32_t* frame_off,
+                      const float* mean, const float* rstd, const float* gamma, float* s1, float* s2,
+                      void* dx, int32_t n_img, int32_t n_frames, int32_t hp, int32_t wp, int32_t c,
+                      int32_t relu_mask, int32_t dtype, void* stream);
+int vnqa_film_relu_res_fwd(const void* z, const void* res, const float* gamma, const float* beta, void* out,
+                           int32_t n_img, int32_t hp, int32_t wp, int32_t c, int32_t dtype, void* stream);
+int vnqa_film_relu_res_bwd(const void* dout, const void* z, const float* gamma, const float* beta, void* dz,
+                           float* dgamma, float* dbeta, int32_t n_img, int32_t hp, int32_t wp, int32_t c,
+                           int32_t dtype, void* stream);
+int vnqa_relu_bwd(const void* a, const void* b, const void* y, void* g, int64_t n, int32_t dtype, void* stream);
+
 /* Persistent LSTM over a repeated sequence (one workgroup per sample, W_hh rows in registers).
  * Replaces the per-frame packed nn.LSTM calls with carried state of compute_film_values /
  * compute_film_encoding (models/film_attn_pt_stem.py:146-171 called at :213;

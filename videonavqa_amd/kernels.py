@@ -193,3 +193,59 @@ def lstm_seq_bwd(w_hh, q_lens_i32, c0, gates, dhs, dhN, dcN, n_rep):
                                       L.ptr(dhN), L.ptr(dcN), L.ptr(dgates), L.ptr(dh0), L.ptr(dc0), B, H, S,
                                       n_rep, L.stream()), "vnqa_lstm_seq_bwd")
     return dgates, dh0, dc0
+
+
+def frame_bn_stats(x, frame_off_i32, n_frames):
+    N, hp, wp, c = x.shape
+    mean = torch.empty((n_frames, c), dtype=torch.float32, device=x.device)
+    var = torch.empty((n_frames, c), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vnqa_frame_bn_stats(L.ptr(x), L.ptr(frame_off_i32), L.ptr(mean), L.ptr(var), n_frames, hp, wp, c,
+                                        L.dtype_id(x.dtype), L.stream()), "vnqa_frame_bn_stats")
+    return mean, var
+
+
+def frame_bn_apply(x, frame_of_i32, mean, rstd, gamma, beta):
+    N, hp, wp, c = x.shape
+    y = torch.empty_like(x)
+    L.check(L.lib().vnqa_frame_bn_apply(L.ptr(x), L.ptr(frame_of_i32), L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
+                                        L.ptr(beta), L.ptr(y), N, hp, wp, c, L.dtype_id(x.dtype), L.stream()),
+            "vnqa_frame_bn_apply")
+    return y
+
+
+def frame_bn_bwd(dy, x, frame_of_i32, frame_off_i32, mean, rstd, gamma, n_frames, relu_mask):
+    N, hp, wp, c = x.shape
+    s1 = torch.empty((n_frames, c), dtype=torch.float32, device=x.device)
+    s2 = torch.empty((n_frames, c), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    L.check(L.lib().vnqa_frame_bn_bwd(L.ptr(dy), L.ptr(x), L.ptr(frame_of_i32), L.ptr(frame_off_i32), L.ptr(mean),
+                                      L.ptr(rstd), L.ptr(gamma), L.ptr(s1), L.ptr(s2), L.ptr(dx), N, n_frames, hp, wp,
+                                      c, 1 if relu_mask else 0, L.dtype_id(x.dtype), L.stream()), "vnqa_frame_bn_bwd")
+    return dx, s1, s2
+
+
+def film_relu_res_fwd(z, res, gamma, beta):
+    N, hp, wp, c = z.shape
+    out = torch.empty_like(z)
+    L.check(L.lib().vnqa_film_relu_res_fwd(L.ptr(z), L.ptr(res), L.ptr(gamma), L.ptr(beta), L.ptr(out), N, hp, wp, c,
+                                           L.dtype_id(z.dtype), L.stream()), "vnqa_film_relu_res_fwd")
+    return out
+
+
+def film_relu_res_bwd(dout, z, gamma, beta):
+    N, hp, wp, c = z.shape
+    dz = torch.empty_like(z)
+    dgamma = torch.empty((N, c), dtype=torch.float32, device=z.device)
+    dbeta = torch.empty((N, c), dtype=torch.float32, device=z.device)
+    L.check(L.lib().vnqa_film_relu_res_bwd(L.ptr(dout), L.ptr(z), L.ptr(gamma), L.ptr(beta), L.ptr(dz), L.ptr(dgamma),
+                                           L.ptr(dbeta), N, hp, wp, c, L.dtype_id(z.dtype), L.stream()),
+            "vnqa_film_relu_res_bwd")
+    return dz, dgamma, dbeta
+
+
+def relu_bwd(a, y, b=None):
+    """(a [+ b]) * [y > 0], all padded-NHWC tensors of the same shape/dtype."""
+    g = torch.empty_like(a)
+    L.check(L.lib().vnqa_relu_bwd(L.ptr(a), L.ptr(b), L.ptr(y), L.ptr(g), a.numel(), L.dtype_id(a.dtype), L.stream()),
+            "vnqa_relu_bwd")
+    return g

@@ -68,6 +68,8 @@ class FrameLayout(object):
         self.frame_of = torch.tensor(frame_of, dtype=torch.long, device=device)
         self.sample_of = torch.tensor(sample_of, dtype=torch.long, device=device)
         self.cts_t = torch.tensor(self.cts, dtype=torch.float32, device=device)
+        self.frame_of_i32 = self.frame_of.to(torch.int32)
+        self.frame_off_i32 = torch.tensor(self.offsets, dtype=torch.int32, device=device)
         self.uniform = all(ct == B for ct in self.cts)
 
 
@@ -95,50 +97,41 @@ def pad_channels(v, c_pad):
 
 
 def frame_batchnorm(r, bn, layout, training, cdt):
-    """BatchNorm2d applied per frame to relu(conv_init) (film_attn_pt_stem.py:211).
-    Train mode: batch statistics over the ct_B*h*w values of each (frame, channel), running
-    statistics advanced once per frame in frame order.  r: padded NHWC (zero halo)."""
+    """BatchNorm2d applied per frame to relu(conv_init) (film_attn_pt_stem.py:211) on fused HIP kernels.
+    Train mode: batch statistics over the ct_B*h*w values of each (frame, channel); running statistics
+    advanced once per frame in frame order (closed form of the 35 sequential EMA updates).
+    r: padded NHWC (zero halo), the output of a ReLU whose mask this op's backward applies."""
     N, hp, wp, c_pad = r.shape
     C = bn.num_features
     S = (hp - 2) * (wp - 2)
-    mask = interior_mask(hp, wp, r.device)
-    rf = r.float()
     gamma = pad_channels(bn.weight, c_pad)
     beta = pad_channels(bn.bias, c_pad)
     if training:
-        cnt = (layout.cts_t * S).unsqueeze(1)                                  # [T,1]
-        s1 = torch.zeros(layout.n_frames, c_pad, device=r.device).index_add_(0, layout.frame_of, rf.sum((1, 2)))
-        mean = s1 / cnt                                                        # halo is zero: sums are interior sums
-        d = (rf - mean[layout.frame_of].view(N, 1, 1, c_pad)) * mask
-        s2 = torch.zeros(layout.n_frames, c_pad, device=r.device).index_add_(0, layout.frame_of, (d * d).sum((1, 2)))
-        var = s2 / cnt
+        y, mean, var = ops.frame_bn_train(r, gamma, beta, layout.frame_of_i32, layout.frame_off_i32,
+                                          layout.n_frames, BN_EPS, True)
         with torch.no_grad():
             T = layout.n_frames
+            cnt = (layout.cts_t * S).unsqueeze(1)
             decay = (1.0 - BN_MOMENTUM) ** torch.arange(T - 1, -1, -1, device=r.device, dtype=torch.float32)
             coef = (BN_MOMENTUM * decay).unsqueeze(1)                          # weight of frame t's statistic
             unbias = cnt / torch.clamp(cnt - 1, min=1.0)
             keep = (1.0 - BN_MOMENTUM) ** T
-            bn.running_mean.mul_(keep).add_((coef * mean.detach()[:, :C]).sum(0))
-            bn.running_var.mul_(keep).add_((coef * (var.detach() * unbias)[:, :C]).sum(0))
+            bn.running_mean.mul_(keep).add_((coef * mean[:, :C]).sum(0))
+            bn.running_var.mul_(keep).add_((coef * (var * unbias)[:, :C]).sum(0))
             bn.num_batches_tracked += T
-        rstd = torch.rsqrt(var + BN_EPS)
-        xh = d * rstd[layout.frame_of].view(N, 1, 1, c_pad)
-    else:
-        mean = pad_channels(bn.running_mean, c_pad)
-        rstd = torch.rsqrt(pad_channels(bn.running_var, c_pad) + BN_EPS)
-        xh = (rf - mean) * rstd
-    out = (xh * gamma + beta) * mask
-    return out.to(cdt)
+        return y
+    # eval: running statistics for every frame (one pseudo-frame holding all images)
+    mean = pad_channels(bn.running_mean, c_pad).float().view(1, c_pad).contiguous()
+    rstd = torch.rsqrt(pad_channels(bn.running_var, c_pad).float() + BN_EPS).view(1, c_pad).contiguous()
+    zeros = torch.zeros(N, dtype=torch.int32, device=r.device)
+    return K.frame_bn_apply(r, zeros, mean, rstd, gamma.detach().float().contiguous(),
+                            beta.detach().float().contiguous())
 
 
 def film_relu_residual(z, res, gamma, beta, cdt):
     """relu(gamma * z + beta) + res, gamma/beta per (image, channel) (film_attn_pt_stem.py:231-241)."""
-    N, hp, wp, c_pad = z.shape
-    mask = interior_mask(hp, wp, z.device)
-    g = pad_channels(gamma, c_pad).view(N, 1, 1, c_pad)
-    b = pad_channels(beta, c_pad).view(N, 1, 1, c_pad)
-    out = (F.relu(g * z.float() + b) + res.float()) * mask
-    return out.to(cdt)
+    c_pad = z.shape[-1]
+    return ops.film_relu_res(z, res, pad_channels(gamma, c_pad), pad_channels(beta, c_pad))
 
 
 def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=False):
@@ -271,7 +264,8 @@ class FiLMTrunkBase(nn.Module):
         """conv_init -> ReLU -> per-frame BN -> FiLM residual blocks.
         film_fn(k) -> (gamma [n_img,C], beta [n_img,C]) for block k."""
         cdt = self.compute_dtype
-        r = ops.conv(x, self.conv_init.weight, self.conv_init.bias, relu=True)
+        # in train mode the BN backward applies conv_init's ReLU mask itself (fused)
+        r = ops.conv(x, self.conv_init.weight, self.conv_init.bias, relu=True, mask_in_backward=not self.training)
         x = frame_batchnorm(r, self.bn_init, lay, self.training, cdt)
         for k in range(self.num_res_blocks):
             c1 = self.conv1x1_layers[k]

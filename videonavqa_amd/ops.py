@@ -16,16 +16,16 @@ class ConvFn(torch.autograd.Function):
     split-K kernel.  Replaces nn.Conv2d at models/film_attn_pt_stem.py:211,219,224."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, mask_in_backward=True):
         c_out, c_in, k, _ = weight.shape
         cdt = x.dtype
         c_in_pad = x.shape[-1]
         c_out_pad = L.round_up(c_out, 64)
         wt = K.pack_conv_weight(weight, cdt, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu)
-        ctx.relu = relu
+        ctx.relu = relu and mask_in_backward   # False: the consumer's backward applies the ReLU mask
         ctx.dims = (c_out, c_in, k, c_out_pad, c_in_pad)
-        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.save_for_backward(x, weight, y if ctx.relu else None)
         return y
 
     @staticmethod
@@ -34,7 +34,7 @@ class ConvFn(torch.autograd.Function):
         c_out, c_in, k, c_out_pad, c_in_pad = ctx.dims
         dy = dy.contiguous()
         if ctx.relu:
-            dy = dy * (y > 0).to(dy.dtype)
+            dy = K.relu_bwd(dy, y)
         dx = dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dwt, dbias = K.conv2d_wgrad(x, dy, k * k)
@@ -43,7 +43,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt_d = K.pack_conv_weight(weight, dy.dtype, transpose_flip=True, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
             dx = K.conv2d_igemm(dy, wt_d)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class LinearNTFn(torch.autograd.Function):
@@ -72,8 +72,59 @@ class LinearNTFn(torch.autograd.Function):
         return dx, dw, db
 
 
-def conv(x, weight, bias, relu=False):
-    return ConvFn.apply(x, weight, bias, relu)
+def conv(x, weight, bias, relu=False, mask_in_backward=True):
+    return ConvFn.apply(x, weight, bias, relu, mask_in_backward)
+
+
+class FrameBNTrainFn(torch.autograd.Function):
+    """Train-mode BatchNorm2d applied frame by frame to a ReLU output (film_attn_pt_stem.py:211):
+    statistics per (frame, channel), two HIP launches forward, two backward; the backward also applies
+    the mask of the producing ReLU (x > 0).  Returns (y, mean [F,C], biased var [F,C])."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, frame_of_i32, frame_off_i32, n_frames, eps, relu_input):
+        mean, var = K.frame_bn_stats(x, frame_off_i32, n_frames)
+        rstd = torch.rsqrt(var + eps)
+        g = gamma.detach().float().contiguous()
+        y = K.frame_bn_apply(x, frame_of_i32, mean, rstd, g, beta.detach().float().contiguous())
+        ctx.save_for_backward(x, mean, rstd, g, frame_of_i32, frame_off_i32)
+        ctx.n_frames, ctx.relu_input = n_frames, relu_input
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv):
+        x, mean, rstd, g, frame_of_i32, frame_off_i32 = ctx.saved_tensors
+        dx, s1, s2 = K.frame_bn_bwd(dy.contiguous(), x, frame_of_i32, frame_off_i32, mean, rstd, g, ctx.n_frames,
+                                    ctx.relu_input)
+        return dx, s2.sum(0), s1.sum(0), None, None, None, None, None
+
+
+class FilmReluResFn(torch.autograd.Function):
+    """out = relu(gamma[n] * z + beta[n]) + res (film_attn_pt_stem.py:229-241); gamma/beta fp32 [N, Cpad]."""
+
+    @staticmethod
+    def forward(ctx, z, res, gamma, beta):
+        gamma = gamma.float().contiguous()
+        beta = beta.float().contiguous()
+        out = K.film_relu_res_fwd(z, res, gamma, beta)
+        ctx.save_for_backward(z, gamma, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, gamma, beta = ctx.saved_tensors
+        dout = dout.contiguous()
+        dz, dgamma, dbeta = K.film_relu_res_bwd(dout, z, gamma, beta)
+        return dz, dout, dgamma, dbeta
+
+
+def frame_bn_train(x, gamma, beta, frame_of_i32, frame_off_i32, n_frames, eps, relu_input=True):
+    return FrameBNTrainFn.apply(x, gamma, beta, frame_of_i32, frame_off_i32, n_frames, eps, relu_input)
+
+
+def film_relu_res(z, res, gamma, beta):
+    return FilmReluResFn.apply(z, res, gamma, beta)
 
 
 def linear_nt(x, w, bias):
