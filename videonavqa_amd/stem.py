@@ -120,12 +120,13 @@ class FrozenStem(object):
             self._bufs[key] = cap
         return cap[:shape[0]]
 
-    def _run(self, x, layers, tag):
+    def _run(self, x, layers, tag, last_slot=0):
         for i, ly in enumerate(layers):
             n, hp, wp, _ = x.shape
             h, w = hp - 2, wp - 2
             ho, wo = (h // 2, w // 2) if ly["pool"] else (h, w)
-            out = self._buf((tag, i, ho, wo), (n, ho + 2, wo + 2, ly["c_out_pad"]))
+            key = (tag, i, ho, wo) if i + 1 < len(layers) else (tag, i, ho, wo, last_slot)
+            out = self._buf(key, (n, ho + 2, wo + 2, ly["c_out_pad"]))
             post = ly["post"]
             tile = L.TILE_STEM_256x256 if (self.cdt == torch.bfloat16 and ly["c_out_pad"] >= 256) else L.TILE_AUTO
             timed = self.timing is not None and tile == L.TILE_STEM_256x256
@@ -142,15 +143,17 @@ class FrozenStem(object):
 
     # ---- fused fast path: clip -> packed native features ------------------------------------
     @torch.no_grad()
-    def forward_clip(self, clip, img_of, n_img):
+    def forward_clip(self, clip, img_of, n_img, slot=0):
         """clip fp32 [B,3,H,W,T] on the GPU; img_of int32 [B*T] (image index or -1).
-        Returns padded NHWC [n_img, H/16+2, W/16+2, Cpad] in the compute dtype."""
+        Returns padded NHWC [n_img, H/16+2, W/16+2, Cpad] in the compute dtype.
+        `slot` selects one of several OUTPUT buffers (the intermediates are shared), so that the
+        features of step i stay alive for its backward while step i+1's stem already runs."""
         assert self.vgg is not None and self.objdet is not None
         B, _, H, W, T = clip.shape
         a = self._buf(("first", H, W), (n_img, H + 2, W + 2, 64))
         K.conv_first(clip, self.first[0], self.first[1], img_of, n_img, self.cdt, out=a)
         x = self._run(a, self.layers_vgg, "vgg")
-        return self._run(x, self.layers_od, "od")
+        return self._run(x, self.layers_od, "od", last_slot=slot)
 
     # ---- drop-in per-module paths (reference tensor layouts in and out) -----------------------
     @torch.no_grad()

@@ -58,6 +58,12 @@ class Trainer(object):
         if world_size > 1:
             self.sync_replicas()
         self.fp = FlatParams(model.parameters())
+        # software pipeline: the frozen stem of the NEXT minibatch runs on a side stream while this
+        # minibatch's trunk forward/backward runs on the main stream (two output slots)
+        self.stem_stream = torch.cuda.Stream()
+        self._prefetched = None          # (key, NativeFeatures, v_sorted, perm, done_event)
+        self._slot = 0
+        self._trunk_done = [None, None]  # event per slot: last trunk pass that read that slot
 
     def sync_replicas(self):
         """Rank 0's weights everywhere, INCLUDING the frozen unregistered conv1x1 layers
@@ -66,20 +72,43 @@ class Trainer(object):
         for t in tensors:
             dist.broadcast(t, src=0)
 
-    def extract_features(self, clip, v_lens_cpu):
-        """Stem + batch sort.  clip fp32 [B,3,H,W,T] on the GPU; returns NativeFeatures, perm."""
+    def extract_features(self, clip, v_lens_cpu, slot=0):
+        """Stem + batch sort on the CURRENT stream.  clip fp32 [B,3,H,W,T] on the GPU."""
         B, _, H, W, T = clip.shape
         v_sorted, perm = torch.sort(v_lens_cpu, dim=0, descending=True, stable=True)
         lay = FrameLayout(v_sorted, T, clip.device, perm=perm)
-        feats = self.stem.forward_clip(clip, lay.img_of, lay.n_img)
+        feats = self.stem.forward_clip(clip, lay.img_of, lay.n_img, slot=slot)
         return NativeFeatures(feats, lay, self.feature_channels, H // 16, W // 16), v_sorted, perm
 
-    def step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys):
+    def prefetch(self, clip, v_lens_cpu):
+        """Start the stem of an upcoming minibatch on the side stream (returns immediately)."""
+        slot = self._slot ^ 1
+        main = torch.cuda.current_stream()
+        self.stem_stream.wait_stream(main)                   # clip / layout uploads issued so far
+        if self._trunk_done[slot] is not None:
+            self.stem_stream.wait_event(self._trunk_done[slot])   # that slot's previous reader
+        with torch.cuda.stream(self.stem_stream):
+            native, v_sorted, perm = self.extract_features(clip, v_lens_cpu, slot=slot)
+            done = torch.cuda.Event()
+            done.record(self.stem_stream)
+        self._prefetched = (clip.data_ptr(), native, v_sorted, perm, done, slot)
+
+    def step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
         """One optimisation step.  v_lens_cpu / q_lens_cpu are host int64 tensors (as a DataLoader
-        delivers them); clip, q_input, ys are on the GPU.  Returns (loss, logits) — logits rows in
-        length-sorted order like the reference (:121-130)."""
+        delivers them); clip, q_input, ys are on the GPU.  If `next_clip` is given, its stem is
+        launched on the side stream so that it overlaps this step's trunk.  Returns (loss, logits) —
+        logits rows in length-sorted order like the reference (:121-130)."""
         self.model.train()
-        native, v_sorted, perm = self.extract_features(clip, v_lens_cpu)
+        main = torch.cuda.current_stream()
+        if self._prefetched is not None and self._prefetched[0] == clip.data_ptr():
+            _, native, v_sorted, perm, done, slot = self._prefetched
+            main.wait_event(done)
+            self._slot = slot
+        else:
+            native, v_sorted, perm = self.extract_features(clip, v_lens_cpu, slot=self._slot)
+        self._prefetched = None
+        if next_clip is not None:
+            self.prefetch(next_clip, next_v_lens_cpu if next_v_lens_cpu is not None else v_lens_cpu)
         perm_d = perm.to(clip.device)
         self.model.init_hidden()
         logits = self.model(native, q_input[perm_d], v_sorted, q_lens_cpu[perm])
@@ -92,4 +121,7 @@ class Trainer(object):
         self.fp.step_count += 1
         K.clip_adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.fp.partial,
                          self.fp.step_count, self.lr, self.clip)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._trunk_done[self._slot] = ev
         return loss.detach(), logits.detach()
