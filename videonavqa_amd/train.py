@@ -45,6 +45,26 @@ class FlatParams(object):
         self.partial = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.step_count = 0
 
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+def sync_replicas(tensors, src=0):
+    """Make every rank hold rank `src`'s tensors (weights, buffers AND the frozen unregistered
+    conv1x1 layers, which state_dict() does not carry — SURVEY §0.5)."""
+    for t in tensors:
+        dist.broadcast(t, src=src)
+
+
+def allreduce_gradients(flat_grad, world_size, loss_reduction="sum"):
+    """The one data-path collective of a step: SUM the flat gradient buffer over ranks (RCCL on GPUs).
+    With reduction='sum' (eval.sh:16) the summed gradient IS the gradient of the global-batch loss;
+    'mean' losses are averaged over ranks."""
+    if world_size > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        if loss_reduction != "sum":
+            flat_grad.div_(world_size)
+
 
 class Trainer(object):
     def __init__(self, model, stem, lr=1e-4, clip=1.0, loss_reduction="sum", class_weights=None,
@@ -68,9 +88,7 @@ class Trainer(object):
     def sync_replicas(self):
         """Rank 0's weights everywhere, INCLUDING the frozen unregistered conv1x1 layers
         (which state_dict() does not carry)."""
-        tensors = list(self.model.state_dict().values()) + list(self.model.extra_state_tensors().values())
-        for t in tensors:
-            dist.broadcast(t, src=0)
+        sync_replicas(list(self.model.state_dict().values()) + list(self.model.extra_state_tensors().values()))
 
     def extract_features(self, clip, v_lens_cpu, slot=0):
         """Stem + batch sort on the CURRENT stream.  clip fp32 [B,3,H,W,T] on the GPU."""
@@ -114,10 +132,7 @@ class Trainer(object):
         logits = self.model(native, q_input[perm_d], v_sorted, q_lens_cpu[perm])
         loss = self.loss_fn(logits, ys[perm_d])
         loss.backward()
-        if self.world_size > 1:
-            dist.all_reduce(self.fp.grad, op=dist.ReduceOp.SUM)
-            if self.loss_reduction != "sum":      # 'mean' losses average over the global batch
-                self.fp.grad.div_(self.world_size)
+        allreduce_gradients(self.fp.grad, self.world_size, self.loss_reduction)
         self.fp.step_count += 1
         K.clip_adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.fp.partial,
                          self.fp.step_count, self.lr, self.clip)
