@@ -65,7 +65,7 @@ def test_conv_igemm_vs_torch(dt, cfg):
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_conv_igemm_tiles_agree(tile):
     from videonavqa_amd import kernels as K
     g = torch.Generator(device="cpu").manual_seed(tile)
@@ -189,3 +189,26 @@ def test_gemm_tn(dt, mnk):
     ref = _q(a, dt).t() @ _q(b, dt)
     out = K.gemm_tn(a.to(dt), b.to(dt))
     assert _rel(out, ref) < 5e-5
+
+
+@pytest.mark.parametrize("tile", [7, 8, 9])
+@pytest.mark.parametrize("cfg", [(3, 10, 13, 64, 64, 9, True, False), (2, 16, 12, 64, 128, 9, True, True),
+                                 (5, 14, 14, 128, 320, 1, True, False), (9, 28, 28, 64, 64, 9, False, True)])
+def test_conv_igemm_ring_pipeline(tile, cfg):
+    """4-stage ring / counted-vmcnt main loop: short K loops (1..3 stages), pooling, 1x1, ragged tiles."""
+    from videonavqa_amd import kernels as K
+    N, H, W, Cin, Cout, taps, relu, pool = cfg
+    dt = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]) + tile)
+    k = 3 if taps == 9 else 1
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * taps) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda() * 0.1
+    ref = F.conv2d(_q(x, dt), _q(w, dt), b, padding=k // 2)
+    if relu:
+        ref = F.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    y = K.conv2d_igemm(K.nchw_to_nhwc(x, dt, c_pad=Cin), K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=Cin),
+                       bias=b, relu=relu, pool2=pool, tile=tile)
+    assert _rel(K.nhwc_to_nchw(y, Cout), ref) < 1e-2

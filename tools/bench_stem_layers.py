@@ -23,11 +23,14 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--tiles", default="0")
+    ap.add_argument("--layers", default="")
+    ap.add_argument("--relu-flags", type=int, default=1, help="diagnostic: value passed as the relu field")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     N = args.frames
     res = []
-    for name, H, W, Cin, Cout, pool in LAYERS:
+    layers = [l for l in LAYERS if not args.layers or l[0] in args.layers.split(",")]
+    for name, H, W, Cin, Cout, pool in layers:
         x = torch.zeros(N, H + 2, W + 2, Cin, dtype=dt, device="cuda")
         x[:, 1:-1, 1:-1, :] = torch.randn(N, H, W, Cin, device="cuda").to(dt)
         wt = (torch.randn(Cout, 9, Cin, device="cuda") / (9 * Cin) ** 0.5).to(dt)
@@ -37,7 +40,7 @@ def main():
         flops = 2.0 * N * H * W * Cin * Cout * 9
         for tile in [int(t) for t in args.tiles.split(",")]:
             try:
-                K.conv2d_igemm(x, wt, bias=b, relu=True, pool2=pool, out=out, tile=tile)
+                K.conv2d_igemm(x, wt, bias=b, relu=args.relu_flags, pool2=pool, out=out, tile=tile)
             except Exception as e:  # tile not available for this dtype
                 print(name, "tile", tile, "skipped:", e)
                 continue
@@ -45,7 +48,7 @@ def main():
             st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             st.record()
             for _ in range(args.iters):
-                K.conv2d_igemm(x, wt, bias=b, relu=True, pool2=pool, out=out, tile=tile)
+                K.conv2d_igemm(x, wt, bias=b, relu=args.relu_flags, pool2=pool, out=out, tile=tile)
             en.record()
             torch.cuda.synchronize()
             ms = st.elapsed_time(en) / args.iters
@@ -57,7 +60,7 @@ def main():
     for r in res:
         tot.setdefault(r["layer"], []).append(r["ms"])
     best = sum(min(v) for v in tot.values())
-    flops_all = sum(2.0 * N * H * W * Cin * Cout * 9 for _, H, W, Cin, Cout, _ in LAYERS)
+    flops_all = sum(2.0 * N * H * W * Cin * Cout * 9 for _, H, W, Cin, Cout, _ in layers)
     print(json.dumps(dict(total_best_ms=round(best, 3), tflops=round(flops_all / best / 1e9, 1))))
 
 

@@ -79,20 +79,34 @@ __device__ __forceinline__ void decode_pixel(int m, int H, int W, int pool, int&
 
 // TAG only gives the frozen-stem launches their own kernel symbol (so that profiles and the
 // bench's roofline line can name "the stem igemm" apart from the trunk's uses of the template).
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int TAG = 0>
+//
+// PIPE selects the main-loop structure:
+//   PIPE == 2 : two 128-byte-row stages, __syncthreads() (drains the DMA) once per 64-channel K-step;
+//   PIPE == 4 : a ring of four 64-byte-row stages (32 channels each); the DMA of three stages stays in
+//               flight ACROSS the workgroup barriers: counted s_waitcnt vmcnt(N) + raw s_barrier, one
+//               barrier per stage, a slot is refilled right after the barrier that retires its readers.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int TAG = 0, int PIPE = 2>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const ConvArgs p) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int NT = NW * 64;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int ES = (int)sizeof(T);
-  constexpr int BK = 128 / ES;  // channels per K-step
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int A_PER_WAVE = (BM / 8) / NW, B_PER_WAVE = (BN / 8) / NW;
+  constexpr int ROWB = PIPE == 4 ? 64 : 128;  // bytes of one tile row per stage
+  constexpr int BK = ROWB / ES;               // channels per stage
+  constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
+  constexpr int RPI = 1024 / ROWB;            // rows covered by one wave-level DMA instruction
+  constexpr int NSUB = ROWB / 32;             // 16-wide (bf16) k-substeps per stage
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_PER_WAVE = (BM / RPI) / NW, B_PER_WAVE = (BN / RPI) / NW;
+  constexpr int LPS = A_PER_WAVE + B_PER_WAVE;  // DMA instructions per wave per stage
   constexpr int EPC = 16 / ES;                // elements per 16-byte chunk
   constexpr int CROW = BN * ES + 16;          // epilogue LDS row stride (bytes)
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile/wave mismatch");
+  static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0, "tile/wave mismatch");
   static_assert(TM >= 1 && TN >= 1, "wave tile too small");
+  static_assert(PIPE == 2 || PIPE == 4, "PIPE must be 2 or 4");
+  // swizzle: spread the 16 rows a ds_read_b128 lane group touches over all 16 slots of a 256-B bank row
+  auto swz = [](int row) { return ROWB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -122,26 +136,29 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   size_t b_off[B_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < A_PER_WAVE; ++j) {
-    const int row = (wave * A_PER_WAVE + j) * 8 + (lane >> 3);
+    const int row = (wave * A_PER_WAVE + j) * RPI + lane / CPR;
     int m = tile_m * BM + row;
     m = m < p.M ? m : p.M - 1;
     int n, y, x;
     decode_pixel(m, p.H, p.W, p.pool, n, y, x);
-    const int lc = (lane & 7) ^ ((row >> 1) & 7);
+    const int lc = (lane % CPR) ^ swz(row);
     a_off[j] = (((size_t)n * p.Hp + y) * p.Wp + x) * (size_t)p.Cin * ES + (size_t)lc * 16;
   }
 #pragma unroll
   for (int j = 0; j < B_PER_WAVE; ++j) {
-    const int row = (wave * B_PER_WAVE + j) * 8 + (lane >> 3);
+    const int row = (wave * B_PER_WAVE + j) * RPI + lane / CPR;
     int co = tile_n * BN + row;
     co = co < p.Cout ? co : p.Cout - 1;
-    const int lc = (lane & 7) ^ ((row >> 1) & 7);
+    const int lc = (lane % CPR) ^ swz(row);
     b_off[j] = (size_t)co * w_row_bytes + (size_t)lc * 16;
   }
 
+  // K order: channel chunk OUTER, tap INNER.  Nine consecutive stages then re-read the same
+  // 128-byte runs of neighbouring pixels (L1/L2 hits); tap-major order would revisit a pixel row
+  // only after Cin/BK stages, by which time a 4 MiB XCD L2 shared by 32 workgroups has evicted it.
   auto stage = [&](int kt, int buf) {
-    const int tap = kt / kchunks;
-    const int kc = kt - tap * kchunks;
+    const int kc = kt / p.taps;
+    const int tap = kt - kc * p.taps;
     int r, s;
     if (p.taps == 9) {
       r = tap / 3;
@@ -151,13 +168,23 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       s = p.x_halo;
     }
     const size_t tapoff = ((size_t)(r * p.Wp + s) * p.Cin + (size_t)kc * BK) * ES;
+    const size_t woff = ((size_t)tap * p.Cin + (size_t)kc * BK) * ES;
     char* lds = smem + buf * STAGE_BYTES;
+#ifdef VNQA_DIAG_SKIP_DMA   // timing-only diagnostic build: drop one operand's DMA after the first stage
+    const bool skipA = (p.relu & 256) && kt != 0, skipB = (p.relu & 512) && kt != 0;
+#else
+    constexpr bool skipA = false, skipB = false;
+#endif
+    if (!skipA) {
 #pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j)
-      glds16(p.x + a_off[j] + tapoff, lds + (wave * A_PER_WAVE + j) * 1024);
+      for (int j = 0; j < A_PER_WAVE; ++j)
+        glds16(p.x + a_off[j] + tapoff, lds + (wave * A_PER_WAVE + j) * 1024);
+    }
+    if (!skipB) {
 #pragma unroll
-    for (int j = 0; j < B_PER_WAVE; ++j)
-      glds16(p.wt + b_off[j] + (size_t)kt * 128, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
+      for (int j = 0; j < B_PER_WAVE; ++j)
+        glds16(p.wt + b_off[j] + woff, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
+    }
   };
 
   vnqa_f32x16 acc[TM][TN];
@@ -174,40 +201,74 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int row = wm * WTM + i * 32 + fr;
-    x_rd[i] = row * 128;
-    x_sw[i] = (row >> 1) & 7;
+    x_rd[i] = row * ROWB;
+    x_sw[i] = swz(row);
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int row = wn * WTN + j * 32 + fr;
-    w_rd[j] = A_BYTES + row * 128;
-    w_sw[j] = (row >> 1) & 7;
+    w_rd[j] = A_BYTES + row * ROWB;
+    w_sw[j] = swz(row);
   }
 
   const int kt0 = slice * p.kt_per_slice;
   const int kt1 = (kt0 + p.kt_per_slice < KT) ? kt0 + p.kt_per_slice : KT;
-  stage(kt0, 0);
-  __syncthreads();
 
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
-    const char* lds = smem + cur * STAGE_BYTES;
+  // One stage = NSUB k-substeps.  Fragments are double-buffered in registers: the ds_read_b128s of
+  // substep s+1 are issued BEFORE the MFMAs of substep s, so LDS latency hides behind the matrix pipe
+  // of the same wave instead of relying on the SIMD's other wave.
+  auto load_frags = [&](const char* lds, int s, vnqa_f32x4* xf, vnqa_f32x4* wf) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      vnqa_f32x4 xf[TM], wf[TN];
+    for (int i = 0; i < TM; ++i)
+      xf[i] = *(const vnqa_f32x4*)(lds + x_rd[i] + (((2 * s + fh) ^ x_sw[i]) << 4));
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      wf[j] = *(const vnqa_f32x4*)(lds + w_rd[j] + (((2 * s + fh) ^ w_sw[j]) << 4));
+  };
+  auto compute = [&](const char* lds) {
+    vnqa_f32x4 xf[2][TM], wf[2][TN];
+    load_frags(lds, 0, xf[0], wf[0]);
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      if (s + 1 < NSUB) load_frags(lds, s + 1, xf[(s + 1) & 1], wf[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this substep's MFMAs
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        xf[i] = *(const vnqa_f32x4*)(lds + x_rd[i] + (((2 * s + fh) ^ x_sw[i]) << 4));
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        wf[j] = *(const vnqa_f32x4*)(lds + w_rd[j] + (((2 * s + fh) ^ w_sw[j]) << 4));
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::run(wf[j], xf[i], acc[i][j]);
+        for (int j = 0; j < TN; ++j) Mma<T>::run(wf[s & 1][j], xf[s & 1][i], acc[i][j]);
     }
+  };
+
+  if constexpr (PIPE == 2) {
+    stage(kt0, 0);
     __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
+      compute(smem + cur * STAGE_BYTES);
+      __syncthreads();
+    }
+  } else {
+    // ring of 4 slots; stages kt+1..kt+3 are in flight while stage kt is consumed
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      if (kt0 + d < kt1) stage(kt0 + d, d);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      // retire stage kt: all but the DMA of the (up to two) younger issued stages must have landed
+      if (kt + 2 < kt1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      } else if (kt + 1 < kt1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();   // stage kt visible to every wave; everyone is done reading stage kt-1
+      if (kt + 3 < kt1) stage(kt + 3, (kt + 3 - kt0) & 3);   // refill the slot stage kt-1 occupied
+      __builtin_amdgcn_s_setprio(1);
+      compute(smem + ((kt - kt0) & 3) * STAGE_BYTES);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_s_barrier();     // all fragment reads done before the epilogue reuses the LDS
   }
 
   // ---------------- epilogue ----------------
@@ -304,18 +365,18 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int TAG = 0>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int TAG = 0, int PIPE = 2>
 int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int ES = (int)sizeof(T);
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int STAGE = (BM + BN) * (PIPE == 4 ? 64 : 128);
   constexpr int CT = BM * (BN * ES + 16);
-  constexpr int LDS = (2 * STAGE > CT) ? 2 * STAGE : CT;
+  constexpr int LDS = (PIPE * STAGE > CT) ? PIPE * STAGE : CT;
   static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
   ConvArgs p = a;
   const int tilesM = (p.M + BM - 1) / BM;
   p.tilesN = (p.Cout + BN - 1) / BN;
-  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TAG>;
+  auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TAG, PIPE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -344,6 +405,9 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_128x128: return launch<vnqa_bf16, 128, 128, 2, 2>(a, st);
       case VNQA_TILE_128x64: return launch<vnqa_bf16, 128, 64, 4, 1>(a, st);
       case VNQA_TILE_STEM_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, 1>(a, st);
+      case VNQA_TILE_P4_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, 0, 4>(a, st);
+      case VNQA_TILE_P4_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, 0, 4>(a, st);
+      case VNQA_TILE_P4_256x64: return launch<vnqa_bf16, 256, 64, 4, 1, 0, 4>(a, st);
       default: break;
     }
   } else {

@@ -58,7 +58,8 @@ __global__ void __launch_bounds__(4 * H) lstm_seq_fwd_kernel(const LstmArgs p) {
   int pos = 0;
   float xnext = steps > 0 ? xg_b[j] : 0.f;
   for (int t = 0; t < steps; ++t) {
-    float acc = xnext;
+    // four independent accumulation chains: the matvec is a dependent-FMA latency chain otherwise
+    float acc = xnext, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
     int npos = pos + 1;
     npos = npos == ql ? 0 : npos;
     if (t + 1 < steps) xnext = xg_b[(size_t)npos * 4 * H + j];   // prefetch the next step's input gates
@@ -66,11 +67,11 @@ __global__ void __launch_bounds__(4 * H) lstm_seq_fwd_kernel(const LstmArgs p) {
     for (int k = 0; k < H; k += 4) {
       const float4 hv = *(const float4*)(s_h + k);
       acc = fmaf(w[k], hv.x, acc);
-      acc = fmaf(w[k + 1], hv.y, acc);
-      acc = fmaf(w[k + 2], hv.z, acc);
-      acc = fmaf(w[k + 3], hv.w, acc);
+      acc1 = fmaf(w[k + 1], hv.y, acc1);
+      acc2 = fmaf(w[k + 2], hv.z, acc2);
+      acc3 = fmaf(w[k + 3], hv.w, acc3);
     }
-    s_g[j] = acc;
+    s_g[j] = (acc + acc1) + (acc2 + acc3);
     __syncthreads();
     if (j < H) {
       const float ig = sigmoidf_(s_g[j]);
@@ -141,16 +142,16 @@ __global__ void __launch_bounds__(4 * H) lstm_seq_bwd_kernel(const LstmArgs p) {
       dg[3 * H + u] = d_o;
     }
     __syncthreads();
-    float acc = 0.f;
+    float acc = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 #pragma unroll
     for (int jj = 0; jj < H; jj += 4) {
       const float4 dv = *(const float4*)(s_dg + part * H + jj);
       acc = fmaf(wt[jj], dv.x, acc);
-      acc = fmaf(wt[jj + 1], dv.y, acc);
-      acc = fmaf(wt[jj + 2], dv.z, acc);
-      acc = fmaf(wt[jj + 3], dv.w, acc);
+      acc1 = fmaf(wt[jj + 1], dv.y, acc1);
+      acc2 = fmaf(wt[jj + 2], dv.z, acc2);
+      acc3 = fmaf(wt[jj + 3], dv.w, acc3);
     }
-    s_part[tid] = acc;
+    s_part[tid] = (acc + acc1) + (acc2 + acc3);
     __syncthreads();
     if (tid < H) dh_rec = s_part[tid] + s_part[H + tid] + s_part[2 * H + tid] + s_part[3 * H + tid];
   }

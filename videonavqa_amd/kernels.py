@@ -43,7 +43,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
     if out is None:
         out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], taps, x_halo, y_halo,
-                   1 if relu else 0, 1 if pool2 else 0, tile)
+                   int(relu), 1 if pool2 else 0, tile)
     L.check(L.lib().vnqa_conv2d_igemm_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                           L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_igemm_fwd")
     return out
