@@ -80,6 +80,13 @@ int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt
                           const float* bias, const float* post_scale, const float* post_shift,
                           void* y, void* stream);
 
+/* Persistent direct 3x3 conv for c_in == 64 (bf16): weights resident in LDS, 16x16 tiles with a DMA'd
+ * 18x18 halo patch, no barrier inside the K loop.  Same contract as vnqa_conv2d_igemm_fwd restricted to
+ * taps == 9, c_in == 64, c_out % 64 == 0, x_halo == y_halo == 1.  Used for VGG conv1_2 / conv2_1.
+ */
+int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
+                        const float* post_scale, const float* post_shift, void* y, void* stream);
+
 /* First VGG conv (3 -> c_out, 3x3 pad 1) + ReLU straight from the reference's clip layout.
  * Replaces the strided frame slice v_inputs[:, :, :, :, j] + conv1_1 of the external
  * feature extractor (eval/q_and_v_eval.py:104-106; eval/dataset.py:63,81-91 for the layout).

@@ -212,3 +212,36 @@ def test_conv_igemm_ring_pipeline(tile, cfg):
     y = K.conv2d_igemm(K.nchw_to_nhwc(x, dt, c_pad=Cin), K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=Cin),
                        bias=b, relu=relu, pool2=pool, tile=tile)
     assert _rel(K.nhwc_to_nchw(y, Cout), ref) < 1e-2
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cout, relu, pool, post
+    (3, 32, 48, 64, True, True, False),
+    (2, 16, 16, 128, True, False, False),
+    (5, 20, 26, 64, False, False, True),     # ragged tiles (not multiples of 16)
+    (300, 16, 32, 64, True, True, True),     # more tiles than workgroups: patch double-buffer ring
+    (1, 48, 16, 192, True, True, False),
+])
+def test_conv_c64_direct_vs_torch(cfg):
+    from videonavqa_amd import kernels as K
+    N, H, W, Cout, relu, pool, post = cfg
+    dt = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg[:4]))
+    x = torch.randn(N, 64, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, 64, 3, 3, generator=g) / 24.0).cuda()
+    b = torch.randn(Cout, generator=g).cuda() * 0.1
+    sc = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    sh = torch.randn(Cout, generator=g).cuda() * 0.2
+    ref = F.conv2d(_q(x, dt), _q(w, dt), b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    if post:
+        ref = ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    y = K.conv2d_c64(K.nchw_to_nhwc(x, dt, c_pad=64), K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=64), bias=b,
+                     relu=relu, pool2=pool, post_scale=sc if post else None, post_shift=sh if post else None)
+    got = K.nhwc_to_nchw(y, Cout)
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 1e-2, _rel(got, ref)
+    assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0

@@ -39,16 +39,21 @@ def main():
         out = torch.zeros(N, Ho + 2, Wo + 2, Cout, dtype=dt, device="cuda")
         flops = 2.0 * N * H * W * Cin * Cout * 9
         for tile in [int(t) for t in args.tiles.split(",")]:
+            def run():
+                if tile == 64:
+                    K.conv2d_c64(x, wt, bias=b, relu=True, pool2=pool, out=out)
+                else:
+                    K.conv2d_igemm(x, wt, bias=b, relu=args.relu_flags, pool2=pool, out=out, tile=tile)
             try:
-                K.conv2d_igemm(x, wt, bias=b, relu=args.relu_flags, pool2=pool, out=out, tile=tile)
-            except Exception as e:  # tile not available for this dtype
+                run()
+            except Exception as e:  # tile not available for this dtype / layer
                 print(name, "tile", tile, "skipped:", e)
                 continue
             torch.cuda.synchronize()
             st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             st.record()
             for _ in range(args.iters):
-                K.conv2d_igemm(x, wt, bias=b, relu=args.relu_flags, pool2=pool, out=out, tile=tile)
+                run()
             en.record()
             torch.cuda.synchronize()
             ms = st.elapsed_time(en) / args.iters

@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvnqa_hip.so")
+LIB_PATH = os.environ.get("VNQA_LIB", os.path.join(_HERE, "lib", "libvnqa_hip.so"))
 
 BF16, F32 = 0, 1
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
@@ -26,6 +26,7 @@ _SIGNATURES = {
     "vnqa_version": (ctypes.c_int, []),
     "vnqa_last_error": (ctypes.c_char_p, []),
     "vnqa_conv2d_igemm_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vnqa_conv2d_c64_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_conv_first_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_pack_conv_weight": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "vnqa_unpack_conv_wgrad": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

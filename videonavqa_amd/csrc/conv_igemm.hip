@@ -226,6 +226,18 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       wf[j] = *(const vnqa_f32x4*)(lds + w_rd[j] + (((2 * s + fh) ^ w_sw[j]) << 4));
   };
   auto compute = [&](const char* lds) {
+#ifdef VNQA_NO_FRAG_PREFETCH
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
+      vnqa_f32x4 xf1[TM], wf1[TN];
+      load_frags(lds, s, xf1, wf1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(wf1[j], xf1[i], acc[i][j]);
+    }
+    return;
+#endif
     vnqa_f32x4 xf[2][TM], wf[2][TN];
     load_frags(lds, 0, xf[0], wf[0]);
 #pragma unroll

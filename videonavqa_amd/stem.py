@@ -133,9 +133,14 @@ class FrozenStem(object):
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            x = K.conv2d_igemm(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
-                               post_scale=post[0] if post else None, post_shift=post[1] if post else None,
-                               out=out, tile=tile)
+            if self.cdt == torch.bfloat16 and x.shape[-1] == 64 and ly["wt"].shape[1] == 9:
+                # C_in = 64 layers (conv1_2, conv2_1): persistent direct conv with LDS-resident weights
+                x = K.conv2d_c64(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
+                                 post_scale=post[0] if post else None, post_shift=post[1] if post else None, out=out)
+            else:
+                x = K.conv2d_igemm(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
+                                   post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+                                   out=out, tile=tile)
             if timed:
                 ev1.record()
                 self.timing.append((ev0, ev1))
