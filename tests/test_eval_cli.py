@@ -1,0 +1,73 @@
+"""The q_and_v_eval entry point: flag surface (CPU) and an end-to-end synthetic run with checkpoint
+save / resume on the GPU."""
+import os
+
+import pytest
+import torch
+
+
+def test_parser_matches_reference_flags_and_defaults():
+    """Flag names and defaults of eval/q_and_v_eval.py:32-64."""
+    from videonavqa_amd.eval.q_and_v_eval import build_parser
+    a = build_parser().parse_args(["--model", "film_attn_pt"])
+    expect = dict(num_classes=70, q_encoder="lstm", use_obj_detector=True, use_visual_features=True,
+                  vocab_size=134, embed_size=128, hidden_size=128, at_hidden_size=128, num_res_blocks=1,
+                  num_res_block_channels=512, num_input_channels=512, num_tail_channels=16, mac_dim=512,
+                  mac_max_step=12, batch_size=8, clip_value=1.0, l_rate=1e-4, num_epochs=1,
+                  use_class_weights=False, checkpoint_path=None, frcnn_pretrained_path=None, num_workers=4,
+                  stats_after_every=400, val_only=False)
+    for k, v in expect.items():
+        assert getattr(a, k) == v, k
+    # eval.sh:44-59 command line parses (incl. its stray --best_acc)
+    b = build_parser().parse_args("--model time_multi_hop --num_classes 70 --vocab_size 134 --num_res_blocks 3 "
+                                  "--num_res_block_channels 1024 --num_tail_channels 64 --at_hidden_size 128 "
+                                  "--hidden_size 128 --batch_size 16 --loss_reduction sum --l_rate 0.00005 "
+                                  "--num_epochs 1 --best_acc 0 --frcnn_pretrained_path ../vgg16_caffe.pth "
+                                  "--checkpoint_path tmh.pt --stats_after_every 500".split())
+    assert b.num_res_block_channels == 1024 and b.batch_size == 16 and b.loss_reduction == "sum"
+
+
+def test_constants_match_reference():
+    from videonavqa_amd.eval import utils as U
+    assert (U.DROP_EVERY_N_FRAMES, U.MAX_ALLOWED_NUM_FRAMES_DROPPING, U.MAX_NUM_VIDEO_FRAMES, U.MAX_Q_LEN,
+            U.NUM_CLASSES, U.VID_HEIGHT, U.VID_WIDTH) == (4, 35, 400, 56, 70, 160, 208)
+    import numpy as np
+    acc = U.per_class_accuracies(np.array([0, 0, 1, 2]), np.array([0, 1, 1, 0]), 4)
+    assert acc.tolist() == [0.5, 1.0, 0.0, 0.0]
+
+
+def test_synthetic_dataset_contract():
+    from videonavqa_amd.eval.dataset import SyntheticVNQADataset
+    ds = SyntheticVNQADataset(5, 32, 48, seed=3)
+    X, y = ds[2]
+    assert X["video"].shape == (3, 32, 48, 35) and X["question"].shape == (56,) and X["question"].dtype == torch.int64
+    assert 3 <= X["v_len"] <= 35 and 5 <= X["q_len"] <= 25 and 0 <= y < 70
+    assert float(X["video"][..., X["v_len"]:].abs().max() if X["v_len"] < 35 else 0.0) == 0.0
+    assert int((X["question"][X["q_len"]:] != 0).sum()) == 0 and int((X["question"][:X["q_len"]] == 0).sum()) == 0
+    X2, y2 = ds[2]
+    assert torch.equal(X["video"], X2["video"]) and y == y2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["film_attn_pt", "film_gp_pt", "time_multi_hop"])
+def test_cli_synthetic_train_val_checkpoint_resume(model, tmp_path, capsys):
+    from videonavqa_amd.eval import q_and_v_eval as E
+    os.chdir(tmp_path)
+    argv = ["--model", model, "--synthetic", "6", "--batch_size", "2", "--num_workers", "0", "--height", "64",
+            "--width", "96", "--num_res_block_channels", "64", "--hidden_size", "16", "--at_hidden_size", "16",
+            "--embed_size", "16", "--precision", "fp32", "--checkpoint_path", "ck.pt", "--stats_after_every", "1"]
+    E.main(argv)
+    out = capsys.readouterr().out
+    assert "Train Epoch: 0" in out and "Validation:" in out and "Average loss after 1 iterations in epoch 1" in out
+    ck = torch.load(tmp_path / "e0_ck.pt", map_location="cpu")
+    assert set(ck) == {"epoch", "model", "state_dict", "train_f1w", "train_f1micro", "optimizer"}
+    assert ck["model"] == model and ck["epoch"] == 0
+    # the optimizer entry is a genuine torch.optim.Adam state_dict
+    params = [torch.nn.Parameter(torch.zeros_like(s["exp_avg"])) for s in ck["optimizer"]["state"].values()]
+    torch.optim.Adam(params, lr=1e-4).load_state_dict(ck["optimizer"])
+    # resume: reference convention = start from --checkpoint_path itself (q_and_v_eval.py:337-346)
+    os.replace(tmp_path / "e0_ck.pt", tmp_path / "ck.pt")
+    E.main(argv)
+    out = capsys.readouterr().out
+    assert "Restored checkpoint ck.pt (epoch 1)" in out and "Train Epoch: 1" in out
+    assert (tmp_path / "e1_ck.pt").exists()

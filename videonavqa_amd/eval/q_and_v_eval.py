@@ -1,0 +1,262 @@
+"""Counterpart of eval/q_and_v_eval.py: train / validate the video+question FiLM models on MI355X.
+
+Same command-line flags and defaults as the reference (eval/q_and_v_eval.py:29-64) for the three models
+on the hot path (`--model film_attn_pt | film_gp_pt | time_multi_hop`), same train_epoch / val_epoch
+flow, printed line formats and checkpoint schema (`e{epoch}_{checkpoint_path}`, keys epoch / model /
+state_dict / train_f1w / train_f1micro / optimizer).  Additions (all optional):
+  --synthetic N        N seeded synthetic items per split instead of ../data (no dataset on the box)
+  --precision bf16|fp32, --height/--width, and data-parallel launch through torchrun / torch.distributed.run
+  (one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE from the environment; rank 0 prints and checkpoints).
+Known upstream pitfalls kept or fixed deliberately: `type=bool` flags are parsed as real
+booleans here; `--loss_reduction` defaults to 'sum' (upstream has no default and eval.sh always passes sum);
+eval.sh's extra `--best_acc` flag is accepted and ignored.
+
+usage: python -m videonavqa_amd.eval.q_and_v_eval --model film_attn_pt --synthetic 64 --num_epochs 1
+"""
+import argparse
+import json
+import os
+import pprint as pp
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import utils as U
+
+
+def str2bool(v):
+    return str(v).lower() in ("1", "true", "yes", "y", "t")
+
+
+def build_parser():
+    parser = argparse.ArgumentParser()
+    # Model args (q_and_v_eval.py:32-38); the off-path baselines (concat2d/concat3d/mac) are not built
+    parser.add_argument('--model', type=str, choices=['film_gp_pt', 'film_attn_pt', 'time_multi_hop'],
+                        required=True)
+    parser.add_argument('--num_classes', type=int, default=70)
+    parser.add_argument('--q_encoder', type=str, choices=['lstm', 'bow'], default='lstm')
+    parser.add_argument('--use_obj_detector', type=str2bool, default=True)
+    parser.add_argument('--use_visual_features', type=str2bool, default=True)
+    parser.add_argument('--vocab_size', type=int, default=134)
+    # Model hyperparameters (:41-49)
+    parser.add_argument('--embed_size', type=int, default=128)
+    parser.add_argument('--hidden_size', type=int, default=128)
+    parser.add_argument('--at_hidden_size', type=int, default=128)
+    parser.add_argument('--num_res_blocks', type=int, default=1)
+    parser.add_argument('--num_res_block_channels', type=int, default=512)
+    parser.add_argument('--num_input_channels', type=int, default=512)
+    parser.add_argument('--num_tail_channels', type=int, default=16)
+    parser.add_argument('--mac_dim', type=int, default=512)
+    parser.add_argument('--mac_max_step', type=int, default=12)
+    # Optimization args (:52-57)
+    parser.add_argument('--batch_size', type=int, default=8)
+    parser.add_argument('--clip_value', type=float, default=1.0)
+    parser.add_argument('--l_rate', type=float, default=1e-4)
+    parser.add_argument('--loss_reduction', type=str, choices=['sum', 'mean', 'elementwise_mean'], default='sum')
+    parser.add_argument('--num_epochs', type=int, default=1)
+    parser.add_argument('--use_class_weights', type=str2bool, default=False)
+    # Other args (:60-64)
+    parser.add_argument('--checkpoint_path', type=str)
+    parser.add_argument('--frcnn_pretrained_path', type=str)
+    parser.add_argument('--num_workers', type=int, default=4)
+    parser.add_argument('--stats_after_every', type=int, default=400)
+    parser.add_argument('--val_only', type=str2bool, default=False)
+    parser.add_argument('--best_acc', type=float, default=0)          # passed by eval.sh:57, unused upstream
+    # additions
+    parser.add_argument('--synthetic', type=int, default=0)
+    parser.add_argument('--precision', type=str, choices=['bf16', 'fp32'], default='bf16')
+    parser.add_argument('--height', type=int, default=U.VID_HEIGHT)
+    parser.add_argument('--width', type=int, default=U.VID_WIDTH)
+    return parser
+
+
+def build_model(args, spatial_size):
+    """Model factory of q_and_v_eval.py:255-303."""
+    from ..models import (FiLMAttnPretrainedStem, FiLMGlobalPoolingPretrainedStem,
+                          TimeMultiHopFiLMPretrainedStem)
+    extra = dict(spatial_size=spatial_size, precision=args.precision)
+    if args.model == 'film_attn_pt':
+        return FiLMAttnPretrainedStem(batch_size=args.batch_size, q_embedding_size=args.embed_size,
+                                      nb_classes=args.num_classes, q_encoder=args.q_encoder,
+                                      num_input_channels=args.num_input_channels,
+                                      num_res_block_channels=args.num_res_block_channels,
+                                      num_res_blocks=args.num_res_blocks, hidden_size=args.hidden_size,
+                                      at_hidden_size=args.at_hidden_size,
+                                      max_num_frames=U.MAX_ALLOWED_NUM_FRAMES_DROPPING,
+                                      vocab_size=args.vocab_size, **extra)
+    if args.model == 'film_gp_pt':
+        return FiLMGlobalPoolingPretrainedStem(batch_size=args.batch_size, q_embedding_size=args.embed_size,
+                                               nb_classes=args.num_classes,
+                                               num_input_channels=args.num_input_channels,
+                                               num_res_block_channels=args.num_res_block_channels,
+                                               num_res_blocks=args.num_res_blocks, hidden_size=args.hidden_size,
+                                               num_tail_channels=args.num_tail_channels, q_encoder=args.q_encoder,
+                                               vocab_size=args.vocab_size, **extra)
+    return TimeMultiHopFiLMPretrainedStem(batch_size=args.batch_size, q_embedding_size=args.embed_size,
+                                          nb_classes=args.num_classes,
+                                          num_input_channels=args.num_input_channels,
+                                          num_res_block_channels=args.num_res_block_channels,
+                                          num_res_blocks=args.num_res_blocks,
+                                          num_tail_channels=args.num_tail_channels, hidden_size=args.hidden_size,
+                                          vocab_size=args.vocab_size, **extra)
+
+
+def _to_device(Xs, ys, device):
+    clip = Xs['video'].float().to(device, non_blocking=True)
+    q = Xs['question'].to(device, non_blocking=True)
+    return clip, q, Xs['v_len'].long().cpu(), Xs['q_len'].long().cpu(), ys.to(device, non_blocking=True)
+
+
+def train_epoch(epoch, args, trainer, data_loader, device, rank=0):
+    """q_and_v_eval.py:73-156 (stem, sort, forward, loss, clip, Adam are inside Trainer.step)."""
+    from sklearn.metrics import f1_score
+    avg_loss, hit, num_examples = 0.0, 0, 0
+    y_pred, y_target = np.array([]), np.array([])
+    for i, (Xs, ys) in enumerate(data_loader, 0):
+        if len(ys) < args.batch_size:                                   # :86-87
+            continue
+        num_examples += len(ys)
+        clip, q, v_lens, q_lens, ys = _to_device(Xs, ys, device)
+        perm = torch.sort(v_lens, dim=0, descending=True, stable=True)[1]
+        loss, logits = trainer.step(clip, q, v_lens, q_lens, ys)
+        ys_sorted = ys[perm.to(device)]
+        y_target = np.append(y_target, ys_sorted.cpu().numpy())        # :117
+        avg_loss += float(loss)
+        pred_class = logits.max(1)[1]                                   # :127
+        y_pred = np.append(y_pred, pred_class.cpu().numpy())
+        hit += int((pred_class == ys_sorted).sum())
+        if rank == 0 and (i + 1) % args.stats_after_every == 0:
+            print('Average loss after %d iterations in epoch %d: %.6f' % (i + 1, epoch + 1, avg_loss / num_examples))
+    f1_w = f1_score(y_target, y_pred, average='weighted')
+    f1_micro = f1_score(y_target, y_pred, average='micro')
+    if rank == 0:
+        print('Train Epoch: {}\tAverage loss: {:.6f}\tAccuracy: {}/{}\tF1: w{:.4f}, micro{:.4f}\n'.format(
+            epoch, avg_loss / max(num_examples, 1), hit, num_examples, f1_w, f1_micro))
+        if args.checkpoint_path is not None:
+            torch.save({'epoch': epoch, 'model': args.model, 'state_dict': trainer.model.state_dict(),
+                        'train_f1w': f1_w, 'train_f1micro': f1_micro,
+                        'optimizer': trainer.optimizer_state_dict()},
+                       'e' + str(epoch) + '_' + args.checkpoint_path)   # :148-156
+    return avg_loss / max(num_examples, 1)
+
+
+def val_epoch(args, trainer, data_loader, device, rank=0):
+    """q_and_v_eval.py:159-224."""
+    from sklearn.metrics import f1_score
+    model = trainer.model
+    model.eval()
+    val_loss, hit, num_examples = 0.0, 0, 0
+    y_pred, y_target = np.array([]), np.array([])
+    with torch.no_grad():
+        for Xs, ys in data_loader:
+            if len(ys) < args.batch_size:
+                continue
+            num_examples += len(ys)
+            clip, q, v_lens, q_lens, ys = _to_device(Xs, ys, device)
+            native, v_sorted, perm = trainer.extract_features(clip, v_lens)
+            perm_d = perm.to(device)
+            model.init_hidden()
+            output = model(native, q[perm_d], v_sorted, q_lens[perm])
+            ys_sorted = ys[perm_d]
+            y_target = np.append(y_target, ys_sorted.cpu().numpy())
+            val_loss += float(trainer.loss_fn(output, ys_sorted))
+            pred_class = output.max(1)[1]
+            y_pred = np.append(y_pred, pred_class.cpu().numpy())
+            hit += int((pred_class == ys_sorted).sum())
+    accs = U.per_class_accuracies(y_target, y_pred, args.num_classes)
+    f1_w = f1_score(y_target, y_pred, average='weighted') if num_examples else 0.0
+    f1_micro = f1_score(y_target, y_pred, average='micro') if num_examples else 0.0
+    if rank == 0:
+        pp.pprint({i: accs[i] for i in np.nonzero(accs)[0].tolist()})
+        print('Validation:\tAverage loss: {:.6f}, Accuracy: {}/{}, F1: w{:.4f}, micro{:.4f}\n'.format(
+            val_loss / max(num_examples, 1), hit, num_examples, f1_w, f1_micro))
+    return val_loss / max(num_examples, 1)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    import torch.distributed as dist
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    from ..stem import FrozenStem, get_frcnn_feature_extractor
+    from ..train import Trainer
+    from .dataset import SyntheticVNQADataset, VNQADataset
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "the MI355X path needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    if args.synthetic > 0:
+        train_data = SyntheticVNQADataset(args.synthetic, args.height, args.width, vocab_size=args.vocab_size,
+                                          num_classes=args.num_classes, seed=1234)
+        val_data = SyntheticVNQADataset(max(args.synthetic // 4, args.batch_size), args.height, args.width,
+                                        vocab_size=args.vocab_size, num_classes=args.num_classes, seed=4321)
+    else:
+        with open(U.SPLIT_FILE, 'r') as f:                              # :234-240
+            split = json.load(f)
+        with open(U.LABELS_FILE, 'r') as f:
+            labels = json.load(f)
+        train_data = VNQADataset(q_dir=U.QUESTIONS_DIR, v_dir=U.VIDEOS_DIR, filenames=split['train'], labels=labels)
+        val_data = VNQADataset(q_dir=U.QUESTIONS_DIR, v_dir=U.VIDEOS_DIR, filenames=split['val'], labels=labels)
+    if rank == 0:
+        print('%d train examples, %d validation examples' % (len(train_data), len(val_data)))
+    tr_sampler = DistributedSampler(train_data, world, rank, shuffle=True) if world > 1 else None
+    train_loader = DataLoader(dataset=train_data, batch_size=args.batch_size, shuffle=tr_sampler is None,
+                              sampler=tr_sampler, num_workers=args.num_workers, drop_last=False)
+    val_loader = DataLoader(dataset=val_data, batch_size=args.batch_size, shuffle=False,
+                            num_workers=args.num_workers)
+
+    spatial = (args.height // 16) * (args.width // 16)
+    torch.manual_seed(0)
+    model = build_model(args, spatial).to(device)
+    assert args.use_visual_features and args.use_obj_detector, \
+        "the MI355X path implements the --use_visual_features/--use_obj_detector configuration (the defaults)"
+    feature_extractor = get_frcnn_feature_extractor(args.frcnn_pretrained_path, args.precision).to(device)
+    obj_detector = U.get_object_detector(precision=args.precision,
+                                         load=args.synthetic == 0 or os.path.exists(U.OBJ_DETECTOR_PATH)).to(device)
+    if rank == 0:
+        print(obj_detector)
+        print(model)
+    stem = FrozenStem(feature_extractor, obj_detector, args.precision)
+
+    class_weights = None
+    if args.use_class_weights and hasattr(train_data, "get_class_weights"):
+        class_weights = torch.FloatTensor(train_data.get_class_weights()).to(device)
+    reduction = 'mean' if args.loss_reduction == 'elementwise_mean' else args.loss_reduction
+    trainer = Trainer(model, stem, lr=args.l_rate, clip=args.clip_value, loss_reduction=reduction,
+                      class_weights=class_weights, world_size=world, rank=rank,
+                      feature_channels=args.num_input_channels)
+
+    start_epoch = 0
+    if args.checkpoint_path is not None:                                # :337-346
+        if not os.path.exists(args.checkpoint_path):
+            if rank == 0:
+                print('=> No checkpoint existent - will save the model here')
+        else:
+            if rank == 0:
+                print('=> Restoring from checkpoint path %s' % args.checkpoint_path)
+            ckpt = torch.load(args.checkpoint_path, map_location=device)
+            start_epoch = ckpt['epoch'] + 1
+            trainer.load_checkpoint(ckpt)
+            if rank == 0:
+                print('==> Restored checkpoint %s (epoch %d)' % (args.checkpoint_path, start_epoch))
+
+    for epoch in range(start_epoch, start_epoch + args.num_epochs):     # :354-365
+        if tr_sampler is not None:
+            tr_sampler.set_epoch(epoch)
+        if not args.val_only:
+            train_epoch(epoch, args, trainer, train_loader, device, rank)
+        val_epoch(args, trainer, val_loader, device, rank)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

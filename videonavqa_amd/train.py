@@ -90,6 +90,36 @@ class Trainer(object):
         (which state_dict() does not carry)."""
         sync_replicas(list(self.model.state_dict().values()) + list(self.model.extra_state_tensors().values()))
 
+    # ---- checkpoint interface with torch.optim.Adam's state_dict layout (eval/q_and_v_eval.py:148-156,344-345) --
+    def optimizer_state_dict(self):
+        """Same structure as torch.optim.Adam(model.parameters()).state_dict(): per-parameter
+        step / exp_avg / exp_avg_sq, one param group."""
+        state, off = {}, 0
+        for i, p in enumerate(self.fp.params):
+            k = p.numel()
+            state[i] = {"step": torch.tensor(float(self.fp.step_count)),
+                        "exp_avg": self.fp.m[off:off + k].view_as(p).clone(),
+                        "exp_avg_sq": self.fp.v[off:off + k].view_as(p).clone()}
+            off += k
+        group = {"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False,
+                 "params": list(range(len(self.fp.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_checkpoint(self, ckpt):
+        """Restore model + optimizer from a reference-schema checkpoint dict."""
+        self.model.load_state_dict(ckpt["state_dict"])      # in-place copies: parameters stay views of the flat buffer
+        opt = ckpt.get("optimizer")
+        if opt and opt.get("state"):
+            off = 0
+            for i, p in enumerate(self.fp.params):
+                k = p.numel()
+                st = opt["state"].get(i)
+                if st is not None:
+                    self.fp.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    self.fp.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    self.fp.step_count = int(st["step"])
+                off += k
+
     def extract_features(self, clip, v_lens_cpu, slot=0):
         """Stem + batch sort on the CURRENT stream.  clip fp32 [B,3,H,W,T] on the GPU."""
         B, _, H, W, T = clip.shape
