@@ -71,3 +71,14 @@ def test_cli_synthetic_train_val_checkpoint_resume(model, tmp_path, capsys):
     out = capsys.readouterr().out
     assert "Restored checkpoint ck.pt (epoch 1)" in out and "Train Epoch: 1" in out
     assert (tmp_path / "e1_ck.pt").exists()
+    if model == "film_attn_pt":
+        # test-split script on the same checkpoint: 5 items with batch 2 -> the last batch is padded
+        from videonavqa_amd.eval import q_and_v_test as T
+        targv = [a for a in argv]
+        targv[targv.index("--synthetic") + 1] = "5"
+        T.main(targv)
+        out = capsys.readouterr().out
+        assert "Testing:" in out and "Accuracy:" in out
+        import numpy as np
+        t, p = np.load(tmp_path / "t_ck.pt.npy"), np.load(tmp_path / "p_ck.pt.npy")
+        assert t.shape == (5,) and p.shape == (5,)

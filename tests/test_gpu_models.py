@@ -166,3 +166,16 @@ def test_fused_stem_vs_oracle(precision):
     f = vgg(clip[:, :, :, :, 0].cuda())
     rf = O.vgg_front(clip[:, :, :, :, 0], W_vgg)
     assert float((f.cpu() - rf).abs().max() / rf.abs().max()) < tol
+
+
+def test_q_only_lstm_vs_reference_golden():
+    """config-1 plumbing model (models/q_only_lstm.py) through the persistent LSTM kernel."""
+    from videonavqa_amd.models import QOnlyLSTM
+    g = load_golden("qonly_small")
+    B, L = g["q"].shape
+    m = QOnlyLSTM(B, 12, 16, 7, 20).cuda()
+    m.load_state_dict(weights_from(g, "w"))
+    m.hidden_1 = (torch.from_numpy(g["h0"]).cuda(), torch.from_numpy(g["c0"]).cuda())
+    with torch.no_grad():
+        logits = m(torch.from_numpy(g["q"]).cuda(), torch.from_numpy(g["q_lens"]))
+    assert rel_err(logits.cpu().numpy(), g["logits"]) < 1e-4

@@ -1,0 +1,113 @@
+"""Counterpart of eval/q_and_v_test.py: test-split evaluation of a trained checkpoint on MI355X.
+
+Same flags as q_and_v_eval (the reference duplicates its parser, q_and_v_test.py:29-60), same `test()` flow
+(:64-142): the last short batch is PADDED to batch_size (questions 0 / q_len 1 / zero video / v_len 1 / q_id 35,
+:80-87) and logits sliced back to the real examples (:123); writes `t_/p_/q_<checkpoint_path>.npy`
+(targets, predictions, question ids; :268-271) for results_analysis.py.
+
+usage: python -m videonavqa_amd.eval.q_and_v_test --model film_attn_pt --checkpoint_path at.pt [--synthetic N]
+"""
+import json
+import os
+import pprint as pp
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import utils as U
+from .q_and_v_eval import build_model, build_parser
+
+
+def test(args, model, trainer, data_loader, loss_fn, device):
+    """q_and_v_test.py:64-142."""
+    from sklearn.metrics import f1_score
+    model.eval()
+    test_loss, hit, num_examples = 0.0, 0, 0
+    y_pred, y_target, qs = np.array([]), np.array([]), np.array([])
+    with torch.no_grad():
+        for Xs, ys in data_loader:
+            num_examples += len(ys)
+            num_real = ys.size(0)
+            q_ids = Xs.get('q_id', torch.zeros(num_real, dtype=torch.long))
+            if len(ys) < args.batch_size:                                                   # :80-87
+                padded = args.batch_size - ys.size(0)
+                Xs['question'] = F.pad(Xs['question'], (0, 0, 0, padded), 'constant', 0)
+                Xs['q_len'] = F.pad(Xs['q_len'], (0, padded), 'constant', 1)
+                Xs['video'] = F.pad(Xs['video'], (0, 0, 0, 0, 0, 0, 0, 0, 0, padded), 'constant', 0)
+                Xs['v_len'] = F.pad(Xs['v_len'], (0, padded), 'constant', 1)
+                q_ids = F.pad(q_ids, (0, padded), 'constant', 35)
+                ys = F.pad(ys, (0, padded), 'constant', 0)
+            clip = Xs['video'].float().to(device)
+            q = Xs['question'].to(device)
+            v_lens, q_lens = Xs['v_len'].long().cpu(), Xs['q_len'].long().cpu()
+            ys = ys.to(device)
+            native, v_sorted, perm = trainer.extract_features(clip, v_lens)                 # stem + sort (:101-116)
+            perm_d = perm.to(device)
+            ys_s, qid_s = ys[perm_d], q_ids[perm]
+            y_target = np.append(y_target, ys_s[:num_real].cpu().numpy())                   # :117-118
+            qs = np.append(qs, qid_s[:num_real].cpu().numpy())
+            model.init_hidden()
+            output = model(native, q[perm_d], v_sorted, q_lens[perm])[:num_real]            # :122-123
+            ys_s = ys_s[:num_real]
+            test_loss += float(loss_fn(output, ys_s))
+            pred_class = output.max(1)[1]
+            y_pred = np.append(y_pred, pred_class.cpu().numpy())
+            hit += int((pred_class == ys_s).sum())
+    accs = U.per_class_accuracies(y_target, y_pred, args.num_classes)
+    pp.pprint({i: accs[i] for i in np.nonzero(accs)[0].tolist()})
+    f1_w = f1_score(y_target, y_pred, average='weighted')
+    f1_micro = f1_score(y_target, y_pred, average='micro')
+    print('Testing:\tAverage loss: {:.6f}, Accuracy: {}/{}, F1: w{:.4f}, micro{:.4f}\n'.format(
+        test_loss / max(num_examples, 1), hit, num_examples, f1_w, f1_micro))
+    return y_target, y_pred, qs
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    from torch.utils.data import DataLoader
+    from ..stem import FrozenStem, get_frcnn_feature_extractor
+    from ..train import Trainer
+    from .dataset import SyntheticVNQADataset, VNQADataset
+    assert torch.cuda.is_available(), "the MI355X path needs a GPU (there is no CPU fallback)"
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    if args.synthetic > 0:
+        test_data = SyntheticVNQADataset(args.synthetic, args.height, args.width, vocab_size=args.vocab_size,
+                                         num_classes=args.num_classes, seed=777)
+    else:
+        with open(U.SPLIT_FILE, 'r') as f:
+            split = json.load(f)
+        with open(U.LABELS_FILE, 'r') as f:
+            labels = json.load(f)
+        test_data = VNQADataset(q_dir=U.QUESTIONS_DIR, v_dir=U.VIDEOS_DIR, filenames=split['test'], labels=labels,
+                                q_metadata=True)
+    print('%d test examples' % len(test_data))
+    test_loader = DataLoader(dataset=test_data, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
+    spatial = (args.height // 16) * (args.width // 16)
+    model = build_model(args, spatial).to(device)
+    feature_extractor = get_frcnn_feature_extractor(args.frcnn_pretrained_path, args.precision).to(device)
+    obj_detector = U.get_object_detector(precision=args.precision,
+                                         load=args.synthetic == 0 or os.path.exists(U.OBJ_DETECTOR_PATH)).to(device)
+    stem = FrozenStem(feature_extractor, obj_detector, args.precision)
+    reduction = 'mean' if args.loss_reduction == 'elementwise_mean' else args.loss_reduction
+    loss_fn = nn.CrossEntropyLoss(reduction=reduction)
+    trainer = Trainer(model, stem, loss_reduction=reduction, feature_channels=args.num_input_channels)
+    if args.checkpoint_path is None or not os.path.exists(args.checkpoint_path):            # :252-255
+        print('=> No checkpoint existent! Aborting.')
+        sys.exit(-1)
+    print('=> Restoring from checkpoint path %s' % args.checkpoint_path)
+    checkpoint = torch.load(args.checkpoint_path, map_location=device)
+    model.load_state_dict(checkpoint['state_dict'])
+    print('==> Restored checkpoint from epoch %d (validation accuracy %.4f)' %
+          (checkpoint['epoch'] + 1, checkpoint.get('val_acc', -1.0)))
+    t, p, q = test(args, model, trainer, test_loader, loss_fn, device)
+    np.save('t_' + args.checkpoint_path, t)                                                 # :268-271
+    np.save('p_' + args.checkpoint_path, p)
+    np.save('q_' + args.checkpoint_path, q)
+
+
+if __name__ == '__main__':
+    main()

@@ -4,6 +4,7 @@ from .film_attn_pt_stem import FiLMAttnPretrainedStem
 from .film_global_pooling_pt_stem import FiLMGlobalPoolingPretrainedStem
 from .time_multi_hop_pt_stem import TimeMultiHopFiLMPretrainedStem
 from .obj_detector import ObjDetectCNN
+from .q_only_lstm import QOnlyLSTM
 
 __all__ = ["FiLMAttnPretrainedStem", "FiLMGlobalPoolingPretrainedStem",
-           "TimeMultiHopFiLMPretrainedStem", "ObjDetectCNN"]
+           "TimeMultiHopFiLMPretrainedStem", "ObjDetectCNN", "QOnlyLSTM"]
