@@ -63,6 +63,7 @@ typedef struct vnqa_conv_desc {
   int32_t relu;
   int32_t pool2;   /* requires h, w even */
   int32_t tile;    /* 0 = auto, else a VNQA_TILE_* id */
+  int32_t wt_tiled; /* 0: wt is [c_out][taps][c_in]; 1: wt comes from vnqa_pack_conv_weight_tiled for THIS tile id */
 } vnqa_conv_desc;
 
 #define VNQA_TILE_AUTO 0
@@ -107,6 +108,17 @@ int vnqa_conv_first_fwd(const float* clip, const float* w, const float* bias,
 int vnqa_pack_conv_weight(const float* w_oihw, int32_t c_out, int32_t c_in, int32_t taps,
                           int32_t c_out_pad, int32_t c_in_pad, const float* out_scale,
                           int32_t transpose_flip, int32_t dtype, void* wt, void* stream);
+
+/* Pre-tiled weights: the exact LDS image of every (cout tile, K stage) weight tile, swizzle included, laid
+ * out contiguously in the order the igemm consumes them (channel chunk outer, tap inner), so that each
+ * wave-level DMA instruction of the B operand reads 1 KiB of consecutive bytes.  Valid for the 128-byte-row
+ * tiles (VNQA_TILE_256x256 / 256x128 / 256x64 / 128x128 / 128x64 / STEM_256x256); `tile` must be the id the
+ * conv will be launched with.  Size: vnqa_conv_weight_tiled_bytes().
+ */
+int64_t vnqa_conv_weight_tiled_bytes(int32_t c_out, int32_t c_in_pad, int32_t taps, int32_t tile, int32_t dtype);
+int vnqa_pack_conv_weight_tiled(const float* w_oihw, int32_t c_out, int32_t c_in, int32_t taps,
+                                int32_t c_in_pad, const float* out_scale, int32_t tile, int32_t dtype,
+                                void* wt_tiled, void* stream);
 
 /* Inverse of the above for gradients: dW (fp32, [c_out_pad][taps][c_in_pad]) -> OIHW fp32. */
 int vnqa_unpack_conv_wgrad(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps,

@@ -245,3 +245,21 @@ def test_conv_c64_direct_vs_torch(cfg):
     assert got.shape == ref.shape
     assert _rel(got, ref) < 1e-2, _rel(got, ref)
     assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+def test_conv_igemm_pretiled_weights(dt, tile):
+    """pre-tiled (LDS-image) weight layout gives the same result as the row layout"""
+    from videonavqa_amd import kernels as K
+    if dt == torch.float32 and tile not in (4, 5):
+        pytest.skip("f32 instantiates the 128-row tiles only")
+    g = torch.Generator(device="cpu").manual_seed(tile)
+    N, H, W, Cin, Cout = 3, 14, 14, 128, 320
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+    sc = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    ref = F.relu(F.conv2d(_q(x, dt), _q(w * sc.view(-1, 1, 1, 1), dt), None, padding=1))
+    wt = K.pack_conv_weight_tiled(w, dt, tile, out_scale=sc, c_out_pad=Cout, c_in_pad=Cin)
+    y = K.conv2d_igemm(K.nchw_to_nhwc(x, dt, c_pad=Cin), wt, relu=True)
+    assert _rel(K.nhwc_to_nchw(y, Cout), ref) < _tol(dt)

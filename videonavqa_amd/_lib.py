@@ -19,7 +19,7 @@ _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, _i32) for n in ("dtype", "n_img", "h", "w", "c_in", "c_out", "c_y", "taps",
-                                    "x_halo", "y_halo", "relu", "pool2", "tile")]
+                                    "x_halo", "y_halo", "relu", "pool2", "tile", "wt_tiled")]
 
 
 _SIGNATURES = {
@@ -29,6 +29,8 @@ _SIGNATURES = {
     "vnqa_conv2d_c64_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_conv_first_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_pack_conv_weight": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "vnqa_conv_weight_tiled_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "vnqa_pack_conv_weight_tiled": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "vnqa_unpack_conv_wgrad": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vnqa_feat_to_nhwc": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_nchw_to_nhwc": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -34,6 +34,7 @@ struct ConvArgs {
   int M;                    // n_img*H*W conv-output pixels
   int tilesN;
   int Hyp, Wyp;             // padded OUTPUT dims (after pooling)
+  int wt_tiled;             // weights are pre-tiled LDS images (vnqa_pack_conv_weight_tiled)
   int slices, kt_per_slice; // split-K: K-steps [slice*kt_per_slice, ...) -> fp32 slab
   float* partial;           // [slices][M][Cout] fp32 when slices > 1
 };
@@ -181,9 +182,17 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
         glds16(p.x + a_off[j] + tapoff, lds + (wave * A_PER_WAVE + j) * 1024);
     }
     if (!skipB) {
+      if (p.wt_tiled) {
+        // contiguous image of this (cout tile, stage): lane reads exactly the bytes it deposits
+        const char* src = p.wt + ((size_t)tile_n * KT + kt) * B_BYTES + (size_t)lane * 16;
 #pragma unroll
-      for (int j = 0; j < B_PER_WAVE; ++j)
-        glds16(p.wt + b_off[j] + woff, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
+        for (int j = 0; j < B_PER_WAVE; ++j)
+          glds16(src + (wave * B_PER_WAVE + j) * 1024, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
+      } else {
+#pragma unroll
+        for (int j = 0; j < B_PER_WAVE; ++j)
+          glds16(p.wt + b_off[j] + woff, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
+      }
     }
   };
 
@@ -453,6 +462,76 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float
 
 }  // namespace
 
+namespace {
+
+int tile_bn(int tile) {
+  switch (tile) {
+    case VNQA_TILE_256x256: case VNQA_TILE_STEM_256x256: return 256;
+    case VNQA_TILE_256x128: case VNQA_TILE_128x128: return 128;
+    case VNQA_TILE_256x64: case VNQA_TILE_128x64: return 64;
+    default: return 0;
+  }
+}
+
+template <typename T>
+__global__ void pack_tiled_kernel(const float* __restrict__ w, int c_out, int c_in, int taps, int c_in_pad,
+                                  const float* __restrict__ out_scale, int BN, T* __restrict__ dst, size_t total) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int BK = 128 / ES, EPC = 16 / ES;
+  const int KT = taps * (c_in_pad / BK);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % BK);
+    const int row = (int)((i / BK) % BN);
+    const size_t blk = i / ((size_t)BK * BN);
+    const int kt = (int)(blk % KT);
+    const int tile_n = (int)(blk / KT);
+    const int pc = col / EPC, within = col - pc * EPC;
+    const int lc = pc ^ ((row >> 1) & 7);
+    const int kc = kt / taps, tap = kt - kc * taps;
+    const int ch = kc * BK + lc * EPC + within;
+    const int co = tile_n * BN + row;
+    float v = 0.f;
+    if (co < c_out && ch < c_in) {
+      v = w[((size_t)co * c_in + ch) * taps + tap];
+      if (out_scale) v *= out_scale[co];
+    }
+    dst[i] = ElemOps<T>::store(v);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t vnqa_conv_weight_tiled_bytes(int32_t c_out, int32_t c_in_pad, int32_t taps, int32_t tile, int32_t dtype) {
+  const int bn = tile_bn(tile);
+  if (bn == 0) return -1;
+  const int es = dtype == VNQA_BF16 ? 2 : 4;
+  const int64_t tiles_n = (c_out + bn - 1) / bn;
+  return tiles_n * bn * (int64_t)taps * c_in_pad * es;
+}
+
+extern "C" int vnqa_pack_conv_weight_tiled(const float* w_oihw, int32_t c_out, int32_t c_in, int32_t taps,
+                                           int32_t c_in_pad, const float* out_scale, int32_t tile, int32_t dtype,
+                                           void* wt_tiled, void* stream) {
+  VNQA_CHECK_ARG(w_oihw && wt_tiled, "pack_conv_weight_tiled: null pointer");
+  const int bn = tile_bn(tile);
+  VNQA_CHECK_ARG(bn > 0, "pack_conv_weight_tiled: tile id %d has no tiled weight layout", tile);
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "pack_conv_weight_tiled: bad dtype");
+  const int bk = dtype == VNQA_BF16 ? 64 : 32;
+  VNQA_CHECK_ARG(c_in_pad % bk == 0 && c_in_pad >= c_in, "pack_conv_weight_tiled: c_in_pad must be a multiple of %d", bk);
+  const size_t total = (size_t)((c_out + bn - 1) / bn) * bn * taps * c_in_pad;
+  size_t g = (total + 255) / 256;
+  g = g > 4096 ? 4096 : g;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VNQA_BF16)
+    hipLaunchKernelGGL(pack_tiled_kernel<vnqa_bf16>, dim3((int)g), dim3(256), 0, st, w_oihw, c_out, c_in, taps, c_in_pad,
+                       out_scale, bn, (vnqa_bf16*)wt_tiled, total);
+  else
+    hipLaunchKernelGGL(pack_tiled_kernel<float>, dim3((int)g), dim3(256), 0, st, w_oihw, c_out, c_in, taps, c_in_pad,
+                       out_scale, bn, (float*)wt_tiled, total);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
 extern "C" int64_t vnqa_gemm_nt_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype) {
   const int bk = dtype == VNQA_BF16 ? 64 : 32;
   const int bm = dtype == VNQA_BF16 ? 256 : 128;
@@ -486,7 +565,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   a.n_img = m; a.H = 1; a.W = 1; a.Hp = 1; a.Wp = 1;
   a.Cin = k; a.Cout = n; a.Cy = ldo;
   a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = relu; a.pool = 0;
-  a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1;
+  a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0;
   a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int tile = dtype == VNQA_BF16 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
@@ -554,9 +633,13 @@ extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, con
   a.pool = d->pool2;
   a.M = d->n_img * d->h * d->w;
   a.tilesN = 0;
+  a.wt_tiled = d->wt_tiled;
   a.slices = 1;
   a.kt_per_slice = 1 << 30;
   a.partial = nullptr;
+  VNQA_CHECK_ARG(!d->wt_tiled || (d->tile != VNQA_TILE_AUTO && d->tile != VNQA_TILE_P4_256x256 &&
+                                  d->tile != VNQA_TILE_P4_256x128 && d->tile != VNQA_TILE_P4_256x64),
+                 "conv2d_igemm_fwd: wt_tiled needs an explicit 128-byte-row tile id");
   const int ho = d->pool2 ? d->h / 2 : d->h, wo = d->pool2 ? d->w / 2 : d->w;
   a.Hyp = ho + 2 * d->y_halo;
   a.Wyp = wo + 2 * d->y_halo;

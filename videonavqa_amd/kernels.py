@@ -32,18 +32,46 @@ def pad_vec(v, n):
     return out
 
 
+class TiledWeight(object):
+    """Pre-tiled conv weights (vnqa_pack_conv_weight_tiled): opaque LDS-image buffer + its geometry."""
+
+    def __init__(self, data, c_out, taps, c_in_pad, tile):
+        self.data, self.c_out, self.taps, self.c_in_pad, self.tile = data, c_out, taps, c_in_pad, tile
+
+
+def pack_conv_weight_tiled(w_oihw, dtype, tile, out_scale=None, c_out_pad=None, c_in_pad=None):
+    w = w_oihw.detach().float().contiguous()
+    c_out, c_in, kh, kw = w.shape
+    taps = kh * kw
+    c_out_pad = c_out_pad or L.round_up(c_out, 64)
+    c_in_pad = c_in_pad or L.round_up(c_in, 64)
+    did = L.dtype_id(dtype)
+    nbytes = L.lib().vnqa_conv_weight_tiled_bytes(c_out_pad, c_in_pad, taps, tile, did)
+    assert nbytes > 0, "tile %d has no tiled weight layout" % tile
+    buf = torch.empty(nbytes // (2 if dtype == torch.bfloat16 else 4), dtype=dtype, device=w.device)
+    sc = out_scale.detach().float().contiguous() if out_scale is not None else None
+    L.check(L.lib().vnqa_pack_conv_weight_tiled(L.ptr(w), c_out, c_in, taps, c_in_pad, L.ptr(sc), tile, did,
+                                                L.ptr(buf), L.stream()), "vnqa_pack_conv_weight_tiled")
+    return TiledWeight(buf, c_out_pad, taps, c_in_pad, tile)
+
+
 def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
                  x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO):
-    """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin]; returns padded NHWC output."""
+    """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output."""
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
-    c_out, taps, cin_w = wt.shape
-    assert cin_w == Cin and wt.dtype == x.dtype, (wt.shape, x.shape, wt.dtype, x.dtype)
+    tiled = isinstance(wt, TiledWeight)
+    if tiled:
+        c_out, taps, cin_w, tile = wt.c_out, wt.taps, wt.c_in_pad, wt.tile
+        wt = wt.data
+    else:
+        c_out, taps, cin_w = wt.shape
+    assert cin_w == Cin and wt.dtype == x.dtype, (cin_w, x.shape, wt.dtype, x.dtype)
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], taps, x_halo, y_halo,
-                   int(relu), 1 if pool2 else 0, tile)
+                   int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0)
     L.check(L.lib().vnqa_conv2d_igemm_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                           L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_igemm_fwd")
     return out
@@ -58,7 +86,7 @@ def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
-    d = L.ConvDesc(L.BF16, N, H, W, Cin, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0)
+    d = L.ConvDesc(L.BF16, N, H, W, Cin, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0)
     L.check(L.lib().vnqa_conv2d_c64_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                         L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_c64_fwd")
     return out

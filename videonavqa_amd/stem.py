@@ -108,9 +108,20 @@ class FrozenStem(object):
         if bn is not None:
             scale, shift = _fold_bn(bn)
             b = b * scale + shift
-        wt = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+        bf16 = self.cdt == torch.bfloat16
+        if bf16 and c_in_pad == 64:
+            tile = None                      # conv_c64 direct kernel (row layout, LDS-resident weights)
+        elif bf16:
+            tile = L.TILE_STEM_256x256 if c_out_pad >= 256 else (L.TILE_256x128 if c_out_pad > 64 else L.TILE_256x64)
+        else:
+            tile = L.TILE_128x64 if c_out_pad <= 64 else L.TILE_128x128
+        import os
+        if tile is None or os.environ.get("VNQA_STEM_TILED", "1") == "0":
+            wt = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+        else:   # frozen weights: pre-tiled once into the exact LDS images the igemm DMA consumes
+            wt = K.pack_conv_weight_tiled(w, self.cdt, tile, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         return dict(wt=wt, bias=K.pad_vec(b, c_out_pad), relu=relu, pool=pool, post=None,
-                    c_out=c_out, c_out_pad=c_out_pad)
+                    c_out=c_out, c_out_pad=c_out_pad, tile=tile)
 
     def _buf(self, key, shape):
         """Persistent zero-halo activation buffer, grown (never shrunk) along the image axis."""
@@ -128,12 +139,12 @@ class FrozenStem(object):
             key = (tag, i, ho, wo) if i + 1 < len(layers) else (tag, i, ho, wo, last_slot)
             out = self._buf(key, (n, ho + 2, wo + 2, ly["c_out_pad"]))
             post = ly["post"]
-            tile = L.TILE_STEM_256x256 if (self.cdt == torch.bfloat16 and ly["c_out_pad"] >= 256) else L.TILE_AUTO
+            tile = ly["tile"]
             timed = self.timing is not None and tile == L.TILE_STEM_256x256
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            if self.cdt == torch.bfloat16 and x.shape[-1] == 64 and ly["wt"].shape[1] == 9:
+            if tile is None:
                 # C_in = 64 layers (conv1_2, conv2_1): persistent direct conv with LDS-resident weights
                 x = K.conv2d_c64(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                  post_scale=post[0] if post else None, post_shift=post[1] if post else None, out=out)
