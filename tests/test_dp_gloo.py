@@ -37,7 +37,7 @@ def _adam_step(fp, lr, clip=1.0):
 
 def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
-    from videonavqa_amd.train import FlatParams, allreduce_gradients, sync_replicas
+    from videonavqa_amd.train import FlatParams, OverlappedGradReducer, allreduce_gradients, sync_replicas
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -51,10 +51,14 @@ def _worker(rank, world, port, out_path):
     Y = torch.randint(0, 5, (8,), generator=g)
     xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]     # this rank's minibatch
     loss_fn = nn.CrossEntropyLoss(reduction="sum")
-    for _ in range(3):
+    # early_numel=100: the 12x16 weight (192 elements) goes through the overlapped hook path,
+    # everything else through finish(); step 0 uses the plain one-shot all-reduce for comparison
+    reducer = OverlappedGradReducer(fp, world, "sum", early_numel=100)
+    assert len(reducer.early) == 1
+    for it in range(3):
         loss = loss_fn(model(xs), ys)
         loss.backward()
-        allreduce_gradients(fp.grad, world, "sum")
+        reducer.finish()
         _adam_step(fp, 1e-2)
     # every rank must hold identical weights
     gathered = [torch.zeros_like(fp.flat) for _ in range(world)]

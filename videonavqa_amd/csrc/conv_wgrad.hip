@@ -201,17 +201,50 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
   }
 }
 
-// column sums of a [P][C] matrix: partial[blk][c] over a pixel range, then slab_reduce.
+// column sums of a [P][C] matrix (dbias): 16-byte loads, thread = (row lane 0..31, 8-channel chunk 0..7),
+// partial[blk][c] per row block, then a final reduce with one thread per channel over <= 128 partials.
 template <typename T>
-__global__ void colsum_partial_kernel(const T* __restrict__ m, float* __restrict__ partial, long long P, int C,
-                                      long long rows_per_block) {
-  const long long r0 = (long long)blockIdx.x * rows_per_block;
+__device__ __forceinline__ void cs_load8(const T* p, float v[8]);
+template <>
+__device__ __forceinline__ void cs_load8<vnqa_bf16>(const vnqa_bf16* p, float v[8]) {
+  const uint4 u = *(const uint4*)p;
+  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <>
+__device__ __forceinline__ void cs_load8<float>(const float* p, float v[8]) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict__ m, float* __restrict__ partial,
+                                                             long long P, int C, long long rows_per_block) {
+  __shared__ float s_red[32 * 64];
+  const int cg = blockIdx.x;                       // 64-channel group
+  const int prow = threadIdx.x >> 3, chunk = threadIdx.x & 7;
+  const long long r0 = (long long)blockIdx.y * rows_per_block;
   long long r1 = r0 + rows_per_block;
   r1 = r1 < P ? r1 : P;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (long long r = r0; r < r1; ++r) s += ElemOps<T>::load(m[(size_t)r * C + c]);
-    partial[(size_t)blockIdx.x * C + c] = s;
+  const int c0 = cg * 64 + chunk * 8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < C) {
+    for (long long r = r0 + prow; r < r1; r += 32) {
+      float v[8];
+      cs_load8<T>(m + (size_t)r * C + c0, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s_red[prow * 64 + chunk * 8 + e] = s[e];
+  __syncthreads();
+  if (threadIdx.x < 64 && cg * 64 + threadIdx.x < C) {
+    float t = 0.f;
+    for (int r = 0; r < 32; ++r) t += s_red[r * 64 + threadIdx.x];
+    partial[(size_t)blockIdx.y * C + cg * 64 + threadIdx.x] = t;
   }
 }
 
@@ -239,8 +272,8 @@ Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype) {
   slices = slices < 1 ? 1 : (slices > max_slices ? max_slices : slices);
   pl.ksteps_per_slice = (pl.ksteps_total + slices - 1) / slices;
   pl.slices = (pl.ksteps_total + pl.ksteps_per_slice - 1) / pl.ksteps_per_slice;
-  long long cb = pl.Ptot / 64;
-  pl.colsum_blocks = (int)(cb < 1 ? 1 : (cb > 512 ? 512 : cb));
+  long long cb = pl.Ptot / 256;
+  pl.colsum_blocks = (int)(cb < 1 ? 1 : (cb > 128 ? 128 : cb));
   return pl;
 }
 
@@ -341,13 +374,13 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
     float* partial = (float*)workspace + (size_t)pl.slices * n;
     const long long rpb = (pl.Ptot + pl.colsum_blocks - 1) / pl.colsum_blocks;
     if (dtype == VNQA_BF16)
-      hipLaunchKernelGGL(colsum_partial_kernel<vnqa_bf16>, dim3(pl.colsum_blocks), dim3(256), 0, st,
+      hipLaunchKernelGGL(colsum_partial_kernel<vnqa_bf16>, dim3((c_out + 63) / 64, pl.colsum_blocks), dim3(256), 0, st,
                          (const vnqa_bf16*)dy, partial, pl.Ptot, c_out, rpb);
     else
-      hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(pl.colsum_blocks), dim3(256), 0, st, (const float*)dy,
-                         partial, pl.Ptot, c_out, rpb);
+      hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3((c_out + 63) / 64, pl.colsum_blocks), dim3(256), 0, st,
+                         (const float*)dy, partial, pl.Ptot, c_out, rpb);
     VNQA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((c_out + 255) / 256), dim3(256), 0, st, (const float*)partial, dbias,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((c_out + 63) / 64), dim3(64), 0, st, (const float*)partial, dbias,
                        (size_t)c_out, pl.colsum_blocks);
     VNQA_CHECK_LAUNCH();
   }

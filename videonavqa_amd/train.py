@@ -56,6 +56,47 @@ def sync_replicas(tensors, src=0):
         dist.broadcast(t, src=src)
 
 
+class OverlappedGradReducer(object):
+    """SUM all-reduce of the flat gradient buffer, overlapped with backward.
+
+    Big parameters (>= `early_numel` elements; for FiLM-attn that is fc_embed_attn.weight = 51 MB of
+    the 56 MB payload, whose gradient is complete early in backward) are reduced asynchronously from
+    a post-accumulate-grad hook, each as its own contiguous slice of the flat buffer; `finish()` reduces
+    the remaining ranges and waits for the early ones.  xGMI rings are per-link bound, so few large
+    transfers beat many small buckets here."""
+
+    def __init__(self, fp, world_size, loss_reduction="sum", early_numel=1 << 22):
+        self.fp, self.world, self.loss_reduction = fp, world_size, loss_reduction
+        self.early, self.pending, self.done_ranges = {}, [], []
+        off = 0
+        for p in fp.params:
+            k = p.numel()
+            if world_size > 1 and k >= early_numel:
+                self.early[p] = (off, off + k)
+                p.register_post_accumulate_grad_hook(self._hook)
+            off += k
+
+    def _hook(self, p):
+        a, b = self.early[p]
+        self.pending.append(dist.all_reduce(self.fp.grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
+        self.done_ranges.append((a, b))
+
+    def finish(self):
+        """Call after backward: reduce what the hooks did not cover, wait for everything."""
+        if self.world <= 1:
+            return
+        cur = 0
+        for a, b in sorted(self.done_ranges) + [(self.fp.n, self.fp.n)]:
+            if a > cur:
+                self.pending.append(dist.all_reduce(self.fp.grad[cur:a], op=dist.ReduceOp.SUM, async_op=True))
+            cur = max(cur, b)
+        for w in self.pending:
+            w.wait()
+        self.pending, self.done_ranges = [], []
+        if self.loss_reduction != "sum":
+            self.fp.grad.div_(self.world)
+
+
 def allreduce_gradients(flat_grad, world_size, loss_reduction="sum"):
     """The one data-path collective of a step: SUM the flat gradient buffer over ranks (RCCL on GPUs).
     With reduction='sum' (eval.sh:16) the summed gradient IS the gradient of the global-batch loss;
@@ -80,6 +121,7 @@ class Trainer(object):
         self.fp = FlatParams(model.parameters())
         # software pipeline: the frozen stem of the NEXT minibatch runs on a side stream while this
         # minibatch's trunk forward/backward runs on the main stream (two output slots)
+        self.reducer = OverlappedGradReducer(self.fp, world_size, loss_reduction)
         self.stem_stream = torch.cuda.Stream()
         self._prefetched = None          # (key, NativeFeatures, v_sorted, perm, done_event)
         self._slot = 0
@@ -162,7 +204,7 @@ class Trainer(object):
         logits = self.model(native, q_input[perm_d], v_sorted, q_lens_cpu[perm])
         loss = self.loss_fn(logits, ys[perm_d])
         loss.backward()
-        allreduce_gradients(self.fp.grad, self.world_size, self.loss_reduction)
+        self.reducer.finish()
         self.fp.step_count += 1
         K.clip_adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.fp.partial,
                          self.fp.step_count, self.lr, self.clip)
