@@ -252,6 +252,14 @@ def main():
         flops_per_launch = n_frames * stem512_flops_per_frame(H, W) / launches_per_step
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
+        # live; collected with rocprofv3 --pmc in separate runs, corrected per the microarch guide) — only
+        # valid for the default workload the passes were taken on
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        default_cfg = (args.precision == "bf16" and (B, T, H, W) == (8, 35, 224, 224))
+        if default_cfg and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         S = (H // 16) * (W // 16)
         _, trunk_fb = trunk_flops_per_frame(S, 512, args.channels, args.blocks, 128)
         flops_clip = T * (stem_flops_per_frame(H, W) + trunk_fb)
@@ -269,8 +277,9 @@ def main():
                        "whole_step_tflops": round(clips * flops_clip / 1e12, 1),
                        "final_loss": round(float(loss), 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
-                         "kernel": "conv_igemm_kernel<bf16,256,256,2,4,TAG=1> (frozen-stem 3x3 igemm, Cout=512 layers)",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "kernel": "conv_igemm_kernel<bf16,256,256,2,4,TAG=1> (frozen-stem 3x3 igemm on "
+                                   "v_mfma_f32_16x16x32_bf16, Cout=512 layers)",
                          "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
                          "gflop_per_launch": round(flops_per_launch / 1e9, 1)},
         }
