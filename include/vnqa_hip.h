@@ -64,6 +64,8 @@ typedef struct vnqa_conv_desc {
   int32_t pool2;   /* requires h, w even */
   int32_t tile;    /* 0 = auto, else a VNQA_TILE_* id */
   int32_t wt_tiled; /* 0: wt is [c_out][taps][c_in]; 1: wt comes from vnqa_pack_conv_weight_tiled for THIS tile id */
+  int32_t depth;   /* 0: 2-D conv.  > 0: 3-D conv (nn.Conv3d k=3 pad=1, models/v_only_cnn3d.py:13-26) with taps == 27:
+                    * x is [n_img][depth+2][h+2][w+2][c_in], y is [n_img][depth+2][ho+2][wo+2][c_y]; pool2 pools (1,2,2) */
 } vnqa_conv_desc;
 
 #define VNQA_TILE_AUTO 0
@@ -150,6 +152,11 @@ int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t w, int32_t
 int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace,
                       int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
                       int32_t taps, int32_t dtype, void* stream);
+
+/* 3-D counterpart of vnqa_conv2d_wgrad (taps = 27): x [n][d+2][h+2][w+2][c_in], dy [n][d+2][h+2][w+2][c_out]. */
+int64_t vnqa_conv3d_wgrad_workspace(int32_t n_img, int32_t d, int32_t h, int32_t w, int32_t c_in, int32_t c_out);
+int vnqa_conv3d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, int32_t n_img,
+                      int32_t d, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t dtype, void* stream);
 
 /* Dense GEMMs on the same MFMA kernels (nn.Linear fc_embed_attn forward/backward,
  * models/film_attn_pt_stem.py:57,244).

@@ -349,6 +349,34 @@ def q_only_lstm_forward(W, q_input, q_lens, h0, c0):
     return last @ W["out_linear.weight"].t() + W["out_linear.bias"], hidden
 
 
+# --------------------------------------------------------------------------
+# VideoOnlyCNN3D.forward (config 2: 3-D conv bring-up)
+# --------------------------------------------------------------------------
+def _bn(x, W, name, training):
+    return F.batch_norm(x, W[name + ".running_mean"].clone(), W[name + ".running_var"].clone(),
+                        W[name + ".weight"], W[name + ".bias"], training, BN_MOMENTUM, BN_EPS)
+
+
+def video_only_cnn3d_features(W, x, training=False):
+    """Conv trunk of VideoOnlyCNN3D.forward (models/v_only_cnn3d.py:59-72): x [B,3,D,H,W]."""
+    h = _bn(x, W, "bn_input", training)                                                    # :60
+    h = F.max_pool3d(F.relu(F.conv3d(h, W["conv1.weight"], W["conv1.bias"], padding=1)), (1, 2, 2), (1, 2, 2))
+    h = _bn(h, W, "bn1", training)                                                         # :62-64
+    h = F.max_pool3d(F.relu(F.conv3d(h, W["conv2.weight"], W["conv2.bias"], padding=1)), 4, 4)
+    h = _bn(h, W, "bn2", training)                                                         # :66-68
+    h = F.max_pool3d(F.relu(F.conv3d(h, W["conv3a.weight"], W["conv3a.bias"], padding=1)), 4, 4)
+    return _bn(h, W, "bn3", training)                                                      # :70-72
+
+
+def video_only_cnn3d_forward(W, x, training=False):
+    """VideoOnlyCNN3D.forward (models/v_only_cnn3d.py:59-81)."""
+    h = video_only_cnn3d_features(W, x, training)
+    h = h.reshape(h.shape[0], -1)                                                          # :74
+    h = _bn(F.relu(h @ W["fc6.weight"].t() + W["fc6.bias"]), W, "bn6", training)           # :76-77
+    h = _bn(F.relu(h @ W["fc7.weight"].t() + W["fc7.bias"]), W, "bn7", training)           # :78-79
+    return h @ W["fc8.weight"].t() + W["fc8.bias"]                                         # :81
+
+
 FORWARDS = {"film_attn_pt": film_attn_forward, "film_gp_pt": film_gp_forward,
             "time_multi_hop": tmh_forward}
 

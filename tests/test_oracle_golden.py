@@ -120,3 +120,13 @@ def test_sort_batch_matches_reference_rule():
     assert vl2.tolist() == [9, 9, 5, 3]
     assert sorted(y2.tolist()[:2]) == [11, 13] and y2.tolist()[2:] == [12, 10]
     assert O.ct_batch_sizes(vl2, 10) == [4, 4, 4, 3, 3, 2, 2, 2, 2]
+
+
+def test_video_only_cnn3d_features():
+    """conv/pool/BN3d trunk of VideoOnlyCNN3D (models/v_only_cnn3d.py:59-72) vs the reference golden"""
+    g = load_golden("cnn3d_small")
+    W = {k: v.float() for k, v in weights_from(g, "w").items()}
+    with torch.no_grad():
+        f = O.video_only_cnn3d_features(W, torch.from_numpy(g["x"]), training=False)
+    assert f.shape == g["conv_features"].shape
+    assert rel_err(f.numpy(), g["conv_features"]) < 2e-5

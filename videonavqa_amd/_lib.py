@@ -19,7 +19,7 @@ _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, _i32) for n in ("dtype", "n_img", "h", "w", "c_in", "c_out", "c_y", "taps",
-                                    "x_halo", "y_halo", "relu", "pool2", "tile", "wt_tiled")]
+                                    "x_halo", "y_halo", "relu", "pool2", "tile", "wt_tiled", "depth")]
 
 
 _SIGNATURES = {
@@ -46,6 +46,8 @@ _SIGNATURES = {
     "vnqa_l2norm_blocks": (_i32, [_i64]),
     "vnqa_l2norm_partial": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "vnqa_clip_adam": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "vnqa_conv3d_wgrad_workspace": (_i64, [_i32] * 6),
+    "vnqa_conv3d_wgrad": (ctypes.c_int, [_vp] * 5 + [_i32] * 7 + [_vp]),
     "vnqa_gemm_nt_workspace": (_i64, [_i32, _i32, _i32, _i32]),
     "vnqa_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_gemm_tn_workspace": (_i64, [_i32, _i32, _i32, _i32]),

@@ -35,6 +35,7 @@ struct ConvArgs {
   int tilesN;
   int Hyp, Wyp;             // padded OUTPUT dims (after pooling)
   int wt_tiled;             // weights are pre-tiled LDS images (vnqa_pack_conv_weight_tiled)
+  int D;                    // > 0: 3-D conv over [n][D+2][H+2][W+2][C]; "images" are (n, d) depth slices
   int slices, kt_per_slice; // split-K: K-steps [slice*kt_per_slice, ...) -> fp32 slab
   float* partial;           // [slices][M][Cout] fp32 when slices > 1
 };
@@ -163,8 +164,13 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     m = m < p.M ? m : p.M - 1;
     int n, y, x;
     decode_pixel(m, p.H, p.W, p.pool, n, y, x);
+    size_t img = n;
+    if (p.D > 0) {   // depth slice (nn, d): top-front-left tap sits at padded depth d
+      const int nn = n / p.D;
+      img = (size_t)nn * (p.D + 2) + (n - nn * p.D);
+    }
     const int lc = (lane % CPR) ^ swz(row);
-    a_off[j] = (((size_t)n * p.Hp + y) * p.Wp + x) * (size_t)p.Cin * ES + (size_t)lc * 16;
+    a_off[j] = ((img * p.Hp + y) * p.Wp + x) * (size_t)p.Cin * ES + (size_t)lc * 16;
   }
 #pragma unroll
   for (int j = 0; j < B_PER_WAVE; ++j) {
@@ -181,15 +187,20 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   auto stage = [&](int kt, int buf) {
     const int kc = kt / p.taps;
     const int tap = kt - kc * p.taps;
-    int r, s;
+    int r, s, q = 0;
     if (p.taps == 9) {
       r = tap / 3;
       s = tap - 3 * r;
+    } else if (p.taps == 27) {
+      q = tap / 9;
+      const int rs = tap - 9 * q;
+      r = rs / 3;
+      s = rs - 3 * r;
     } else {
       r = p.x_halo;
       s = p.x_halo;
     }
-    const size_t tapoff = ((size_t)(r * p.Wp + s) * p.Cin + (size_t)kc * BK) * ES;
+    const size_t tapoff = ((((size_t)q * p.Hp + r) * p.Wp + s) * p.Cin + (size_t)kc * BK) * ES;
     const size_t woff = ((size_t)tap * p.Cin + (size_t)kc * BK) * ES;
     char* lds = smem + buf * STAGE_BYTES;
 #ifdef VNQA_DIAG_SKIP_DMA   // timing-only diagnostic build: drop one operand's DMA after the first stage
@@ -400,7 +411,12 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     const int n = mo / (Ho * Wo);
     const int rem = mo - n * (Ho * Wo);
     const int yo = rem / Wo, xo = rem - yo * Wo;
-    T* dst = (T*)(p.y) + (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+    size_t oimg = n;
+    if (p.D > 0) {   // output depth slices carry a depth halo of 1 as well
+      const int nn = n / p.D;
+      oimg = (size_t)nn * (p.D + 2) + (n - nn * p.D) + 1;
+    }
+    T* dst = (T*)(p.y) + ((oimg * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
     T out[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) out[e] = ElemOps<T>::store(v[e]);
@@ -587,7 +603,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   a.n_img = m; a.H = 1; a.W = 1; a.Hp = 1; a.Wp = 1;
   a.Cin = k; a.Cout = n; a.Cy = ldo;
   a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = relu; a.pool = 0;
-  a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0;
+  a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
   a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int tile = dtype == VNQA_BF16 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
@@ -621,17 +637,18 @@ extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, con
   VNQA_CHECK_ARG(d && x && wt && y, "conv2d_igemm_fwd: null pointer");
   VNQA_CHECK_ARG(d->dtype == VNQA_BF16 || d->dtype == VNQA_F32, "conv2d_igemm_fwd: bad dtype %d", d->dtype);
   const int bk = d->dtype == VNQA_BF16 ? 64 : 32;
-  VNQA_CHECK_ARG(d->taps == 9 || d->taps == 1, "conv2d_igemm_fwd: taps must be 9 or 1 (got %d)", d->taps);
+  VNQA_CHECK_ARG(d->taps == 9 || d->taps == 1 || (d->taps == 27 && d->depth > 0),
+                 "conv2d_igemm_fwd: taps must be 9 or 1, or 27 with depth > 0 (got %d)", d->taps);
   VNQA_CHECK_ARG(d->c_in > 0 && d->c_in % bk == 0, "conv2d_igemm_fwd: c_in=%d must be a multiple of %d", d->c_in, bk);
   VNQA_CHECK_ARG(d->c_out > 0 && d->c_out % 8 == 0 && d->c_y >= d->c_out && d->c_y % 8 == 0,
                  "conv2d_igemm_fwd: c_out=%d c_y=%d must be multiples of 8, c_y>=c_out", d->c_out, d->c_y);
   VNQA_CHECK_ARG(d->n_img > 0 && d->h > 0 && d->w > 0, "conv2d_igemm_fwd: empty problem");
-  VNQA_CHECK_ARG((d->taps == 9 && d->x_halo == 1) || (d->taps == 1 && (d->x_halo == 0 || d->x_halo == 1)),
+  VNQA_CHECK_ARG((d->taps >= 9 && d->x_halo == 1) || (d->taps == 1 && (d->x_halo == 0 || d->x_halo == 1)),
                  "conv2d_igemm_fwd: x_halo=%d invalid for taps=%d", d->x_halo, d->taps);
   VNQA_CHECK_ARG(d->y_halo == 0 || d->y_halo == 1, "conv2d_igemm_fwd: y_halo must be 0/1");
   VNQA_CHECK_ARG(!d->pool2 || (d->h % 2 == 0 && d->w % 2 == 0), "conv2d_igemm_fwd: pool2 needs even h,w");
   VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv2d_igemm_fwd: post_scale/post_shift must come together");
-  VNQA_CHECK_ARG((long long)d->n_img * d->h * d->w < (1ll << 31), "conv2d_igemm_fwd: too many pixels");
+  VNQA_CHECK_ARG((long long)d->n_img * (d->depth > 0 ? d->depth : 1) * d->h * d->w < (1ll << 31), "conv2d_igemm_fwd: too many pixels");
 
   ConvArgs a;
   a.x = (const char*)x;
@@ -656,6 +673,11 @@ extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, con
   a.M = d->n_img * d->h * d->w;
   a.tilesN = 0;
   a.wt_tiled = d->wt_tiled;
+  a.D = d->depth;
+  if (d->depth > 0) {
+    VNQA_CHECK_ARG(d->taps == 27 && d->x_halo == 1 && d->y_halo == 1, "conv2d_igemm_fwd: depth > 0 needs taps == 27 and halos == 1");
+    a.M = d->n_img * d->depth * d->h * d->w;
+  }
   a.slices = 1;
   a.kt_per_slice = 1 << 30;
   a.partial = nullptr;

@@ -22,8 +22,8 @@ struct WgradArgs {
   const char* x;
   const char* dy;
   float* out;       // slab base: [slices][Cout][taps][Cin]
-  long long Ptot;   // n*Hp*Wp
-  int Wp;
+  long long Ptot;   // n*Hp*Wp  (n*Dp*Hp*Wp for 3-D)
+  int Wp, Hp;
   int Cin, Cout, taps;
   int tilesCo, tilesCi;
   int ksteps_total, ksteps_per_slice, slices;
@@ -71,6 +71,9 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
   if (p.taps == 9) {
     const int r = tap / 3, s = tap - 3 * r;
     dtap = (r - 1) * p.Wp + (s - 1);
+  } else if (p.taps == 27) {
+    const int q = tap / 9, rs = tap - 9 * q, r = rs / 3, s = rs - 3 * r;
+    dtap = ((q - 1) * p.Hp + (r - 1)) * p.Wp + (s - 1);
   }
 
   // ---- per-lane staging geometry: instruction q = wave*4 + j covers 1 KiB of the tile ----
@@ -292,7 +295,27 @@ extern "C" int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t
 }
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
-                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream);
+                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h = 0);
+
+extern "C" int64_t vnqa_conv3d_wgrad_workspace(int32_t n_img, int32_t d, int32_t h, int32_t w, int32_t c_in, int32_t c_out) {
+  int64_t need = 0;
+  for (int dt = 0; dt < 2; ++dt) {
+    const Plan pl = make_plan_k((long long)n_img * (d + 2) * (h + 2) * (w + 2), c_in, c_out, 27, dt);
+    const int64_t b = ((int64_t)pl.slices * c_out * 27 * c_in + (int64_t)pl.colsum_blocks * c_out) * 4;
+    need = b > need ? b : need;
+  }
+  return need;
+}
+
+extern "C" int vnqa_conv3d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, int32_t n_img,
+                                 int32_t d, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(x && dy && dwt && workspace, "conv3d_wgrad: null pointer");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv3d_wgrad: bad dtype %d", dtype);
+  VNQA_CHECK_ARG(c_in % 8 == 0 && c_out % 8 == 0 && c_in >= 8 && c_out >= 8, "conv3d_wgrad: channels must be multiples of 8");
+  VNQA_CHECK_ARG(n_img > 0 && d > 0 && h > 0 && w > 0, "conv3d_wgrad: empty problem");
+  const Plan pl = make_plan_k((long long)n_img * (d + 2) * (h + 2) * (w + 2), c_in, c_out, 27, dtype);
+  return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, 27, dtype, stream, h);
+}
 
 extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace,
                                  int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
@@ -322,7 +345,7 @@ extern "C" int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void
 }
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
-                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream) {
+                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h) {
   hipStream_t st = (hipStream_t)stream;
   WgradArgs a;
   a.x = (const char*)x;
@@ -330,6 +353,7 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   a.out = pl.slices == 1 ? dwt : (float*)workspace;
   a.Ptot = pl.Ptot;
   a.Wp = w + 2;
+  a.Hp = h + 2;
   a.Cin = c_in;
   a.Cout = c_out;
   a.taps = taps;

@@ -97,7 +97,7 @@ extern "C" int vnqa_pack_conv_weight(const float* w_oihw, int32_t c_out, int32_t
                                      int32_t c_out_pad, int32_t c_in_pad, const float* out_scale,
                                      int32_t transpose_flip, int32_t dtype, void* wt, void* stream) {
   VNQA_CHECK_ARG(w_oihw && wt, "pack_conv_weight: null pointer");
-  VNQA_CHECK_ARG(taps == 9 || taps == 1, "pack_conv_weight: taps must be 9 or 1");
+  VNQA_CHECK_ARG(taps == 9 || taps == 1 || taps == 27, "pack_conv_weight: taps must be 1, 9 or 27");
   VNQA_CHECK_ARG(c_out_pad >= c_out && c_in_pad >= c_in, "pack_conv_weight: pads smaller than sizes");
   VNQA_CHECK_ARG(!(transpose_flip && out_scale), "pack_conv_weight: out_scale unsupported with transpose_flip");
   const int rows = transpose_flip ? c_in_pad : c_out_pad;

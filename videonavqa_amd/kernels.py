@@ -12,8 +12,8 @@ from . import _lib as L
 def pack_conv_weight(w_oihw, dtype, out_scale=None, transpose_flip=False, c_out_pad=None, c_in_pad=None):
     """OIHW fp32 -> K-major [rows][taps][ch] in `dtype` (rows=c_out_pad, or c_in_pad if flipped)."""
     w = w_oihw.detach().float().contiguous()
-    c_out, c_in, kh, kw = w.shape
-    taps = kh * kw
+    c_out, c_in = w.shape[0], w.shape[1]
+    taps = w[0, 0].numel()                      # 1, 9 (OIHW) or 27 (OIDHW)
     c_out_pad = c_out_pad or L.round_up(c_out, 64)
     c_in_pad = c_in_pad or L.round_up(c_in, 64)
     rows, kch = (c_in_pad, c_out_pad) if transpose_flip else (c_out_pad, c_in_pad)
@@ -71,7 +71,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
     if out is None:
         out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], taps, x_halo, y_halo,
-                   int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0)
+                   int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0, 0)
     L.check(L.lib().vnqa_conv2d_igemm_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                           L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_igemm_fwd")
     return out
@@ -86,7 +86,7 @@ def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
-    d = L.ConvDesc(L.BF16, N, H, W, Cin, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0)
+    d = L.ConvDesc(L.BF16, N, H, W, Cin, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0, 0)
     L.check(L.lib().vnqa_conv2d_c64_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                         L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_c64_fwd")
     return out
@@ -164,8 +164,8 @@ def conv2d_wgrad(x, dy, taps, want_bias=True):
 def unpack_conv_wgrad(dwt, c_out, c_in):
     """fp32 [c_out_pad][taps][c_in_pad] -> OIHW fp32 [c_out][c_in][k][k]."""
     c_out_pad, taps, c_in_pad = dwt.shape
-    k = 3 if taps == 9 else 1
-    out = torch.empty((c_out, c_in, k, k), dtype=torch.float32, device=dwt.device)
+    shape = {1: (1, 1), 9: (3, 3), 27: (3, 3, 3)}[taps]
+    out = torch.empty((c_out, c_in) + shape, dtype=torch.float32, device=dwt.device)
     L.check(L.lib().vnqa_unpack_conv_wgrad(L.ptr(dwt), c_out, c_in, taps, c_out_pad, c_in_pad, L.ptr(out),
                                            L.stream()), "vnqa_unpack_conv_wgrad")
     return out
@@ -292,3 +292,34 @@ def relu_bwd(a, y, b=None):
     L.check(L.lib().vnqa_relu_bwd(L.ptr(a), L.ptr(b), L.ptr(y), L.ptr(g), a.numel(), L.dtype_id(a.dtype), L.stream()),
             "vnqa_relu_bwd")
     return g
+
+
+def conv3d_igemm(x, wt, bias=None, relu=False, pool2=False, out=None):
+    """3-D conv (k=3, pad=1).  x: padded NDHWC [N, D+2, H+2, W+2, Cin]; wt [Cout][27][Cin];
+    returns padded NDHWC [N, D+2, Ho+2, Wo+2, Cout] (pool2 pools (1,2,2))."""
+    N, Dp, Hp, Wp, Cin = x.shape
+    D, H, W = Dp - 2, Hp - 2, Wp - 2
+    c_out, taps, cin_w = wt.shape
+    assert taps == 27 and cin_w == Cin and wt.dtype == x.dtype
+    Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
+    if out is None:
+        out = torch.zeros((N, Dp, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
+    d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], 27, 1, 1, int(relu), 1 if pool2 else 0,
+                   L.TILE_AUTO, 0, D)
+    L.check(L.lib().vnqa_conv2d_igemm_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), None, None, L.ptr(out),
+                                          L.stream()), "vnqa_conv2d_igemm_fwd(3d)")
+    return out
+
+
+def conv3d_wgrad(x, dy, want_bias=True):
+    """x, dy: padded NDHWC of the same geometry.  Returns (dwt fp32 [Cout][27][Cin], dbias fp32 [Cout])."""
+    N, Dp, Hp, Wp, Cin = x.shape
+    Cout = dy.shape[-1]
+    assert dy.shape[:4] == x.shape[:4] and dy.dtype == x.dtype
+    d, h, w = Dp - 2, Hp - 2, Wp - 2
+    ws = workspace(L.lib().vnqa_conv3d_wgrad_workspace(N, d, h, w, Cin, Cout), x.device)
+    dwt = torch.empty((Cout, 27, Cin), dtype=torch.float32, device=x.device)
+    dbias = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    L.check(L.lib().vnqa_conv3d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwt), L.ptr(dbias), L.ptr(ws), N, d, h, w, Cin, Cout,
+                                      L.dtype_id(x.dtype), L.stream()), "vnqa_conv3d_wgrad")
+    return dwt, dbias

@@ -5,6 +5,7 @@ from .film_global_pooling_pt_stem import FiLMGlobalPoolingPretrainedStem
 from .time_multi_hop_pt_stem import TimeMultiHopFiLMPretrainedStem
 from .obj_detector import ObjDetectCNN
 from .q_only_lstm import QOnlyLSTM
+from .v_only_cnn3d import VideoOnlyCNN3D
 
 __all__ = ["FiLMAttnPretrainedStem", "FiLMGlobalPoolingPretrainedStem",
-           "TimeMultiHopFiLMPretrainedStem", "ObjDetectCNN", "QOnlyLSTM"]
+           "TimeMultiHopFiLMPretrainedStem", "ObjDetectCNN", "QOnlyLSTM", "VideoOnlyCNN3D"]

@@ -169,3 +169,54 @@ class LstmSeqFn(torch.autograd.Function):
 
 def lstm_seq(xg, w_hh, h0, c0, q_lens_i32, n_rep, S):
     return LstmSeqFn.apply(xg, w_hh, h0, c0, q_lens_i32, n_rep, S)
+
+
+class Conv3dFn(torch.autograd.Function):
+    """y = [relu](conv3d(x, weight, k=3, pad=1) + bias) on padded NDHWC [N, D+2, H+2, W+2, C]
+    (nn.Conv3d of models/v_only_cnn3d.py:13-26): forward and dgrad on the igemm with a 27-tap table, wgrad on
+    the MFMA wgrad kernel with 3-D tap shifts."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, need_dx):
+        c_out, c_in = weight.shape[0], weight.shape[1]
+        cdt = x.dtype
+        c_in_pad, c_out_pad = x.shape[-1], L.round_up(c_out, 64)
+        wt = K.pack_conv_weight(weight, cdt, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+        y = K.conv3d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu)
+        ctx.relu, ctx.need_dx = relu, need_dx
+        ctx.dims = (c_out, c_in, c_out_pad, c_in_pad)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        c_out, c_in, c_out_pad, c_in_pad = ctx.dims
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = K.relu_bwd(dy, y)
+        dwt, dbias = K.conv3d_wgrad(x, dy)
+        dw = K.unpack_conv_wgrad(dwt, c_out, c_in)
+        dx = None
+        if ctx.need_dx:
+            wt_d = K.pack_conv_weight(weight, dy.dtype, transpose_flip=True, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+            dx = K.conv3d_igemm(dy, wt_d)
+        return dx, dw, dbias[:c_out].clone(), None, None
+
+
+def conv3d(x, weight, bias, relu=False, need_dx=True):
+    return Conv3dFn.apply(x, weight, bias, relu, need_dx)
+
+
+def ncdhw_to_ndhwc_padded(x, dtype, c_pad=None):
+    """dense [N,C,D,H,W] -> padded NDHWC [N,D+2,H+2,W+2,c_pad] (differentiable torch plumbing)."""
+    C = x.shape[1]
+    c_pad = c_pad or L.round_up(C, 64)
+    y = x.permute(0, 2, 3, 4, 1)
+    y = torch.nn.functional.pad(y, (0, c_pad - C, 1, 1, 1, 1, 1, 1))
+    return y.to(dtype).contiguous()
+
+
+def ndhwc_padded_to_ncdhw(x, C):
+    """padded NDHWC -> dense fp32 [N,C,D,H,W] (differentiable)."""
+    return x[:, 1:-1, 1:-1, 1:-1, :C].permute(0, 4, 1, 2, 3).float()
