@@ -29,14 +29,14 @@ def test_conv3d_fwd_dgrad_wgrad_vs_torch(dt, cfg):
     w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) / (27 * Cin) ** 0.5).cuda()
     b = (torch.randn(Cout, generator=g) * 0.1).cuda()
     dy = torch.randn(N, Cout, D, H, W, generator=g).cuda()
-    xr = _q(x, dt).requires_grad_(True)
-    wr = _q(w, dt).requires_grad_(True)
-    br = b.clone().requires_grad_(True)
+    xr = _q(x, dt).detach().clone().requires_grad_(True)
+    wr = _q(w, dt).detach().clone().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
     ref = F.relu(F.conv3d(xr, wr, br, padding=1))
     ref.backward(_q(dy, dt))
-    xp = x.clone().requires_grad_(True)
-    wp = w.clone().requires_grad_(True)
-    bp = b.clone().requires_grad_(True)
+    xp = x.detach().clone().requires_grad_(True)
+    wp = w.detach().clone().requires_grad_(True)
+    bp = b.detach().clone().requires_grad_(True)
     y = ops.conv3d(ops.ncdhw_to_ndhwc_padded(xp, dt, c_pad=Cin), wp, bp, relu=True, need_dx=True)
     got = ops.ndhwc_padded_to_ncdhw(y, Cout)
     got.backward(dy)
@@ -84,4 +84,7 @@ def test_video_only_cnn3d_train_step_vs_oracle():
     loss.backward()
     assert _rel(out.detach().cpu(), ref.detach()) < 1e-3
     for k, p in m.named_parameters():
-        assert _rel(p.grad.cpu(), gref[k]) < 5e-3, (k, _rel(p.grad.cpu(), gref[k]))
+        # conv biases in front of a train-mode BatchNorm have a mathematically zero gradient (pure rounding
+        # noise on both sides): absolute floor next to the relative bound
+        err = float((p.grad.cpu() - gref[k]).abs().max())
+        assert err <= 5e-3 * float(gref[k].abs().max()) + 1e-4, (k, err)

@@ -47,7 +47,7 @@ class VideoOnlyCNN3D(nn.Module):
     def features(self, inputs):
         assert inputs.is_cuda, "the HIP path needs device tensors (no CPU fallback)"
         h = self.bn_input(inputs.float())                                       # :60
-        h = self._conv_block(h, self.conv1, self.pool1, self.bn1, need_dx=False)
+        h = self._conv_block(h, self.conv1, self.pool1, self.bn1, need_dx=True)   # bn_input is trainable: needs dgrad
         h = self._conv_block(h, self.conv2, self.pool2, self.bn2, need_dx=True)
         return self._conv_block(h, self.conv3a, self.pool3, self.bn3, need_dx=True)
 
