@@ -47,7 +47,8 @@ def trunk_flops_per_frame(S, C_in, C, blocks, at):
 
 
 def build(args, device):
-    from videonavqa_amd.models import FiLMAttnPretrainedStem, ObjDetectCNN
+    from videonavqa_amd.models import (FiLMAttnPretrainedStem, FiLMGlobalPoolingPretrainedStem, ObjDetectCNN,
+                                       TimeMultiHopFiLMPretrainedStem)
     from videonavqa_amd.stem import FrozenStem, VGGFront
     import torch.nn as nn
     torch.manual_seed(0)     # identical replicas on every rank
@@ -65,9 +66,16 @@ def build(args, device):
                 m.running_mean.normal_(0, 0.1)
                 m.running_var.uniform_(0.8, 1.2)
     S = (args.height // 16) * (args.width // 16)
-    model = FiLMAttnPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
-                                   num_res_block_channels=args.channels, max_num_frames=args.frames,
-                                   spatial_size=S, precision=prec)
+    if args.model == "film_attn_pt":
+        model = FiLMAttnPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
+                                       num_res_block_channels=args.channels, max_num_frames=args.frames,
+                                       spatial_size=S, precision=prec)
+    elif args.model == "film_gp_pt":       # BASELINE.json config 3
+        model = FiLMGlobalPoolingPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
+                                                num_res_block_channels=args.channels, spatial_size=S, precision=prec)
+    else:                                  # BASELINE.json config 5 (use --frames 70)
+        model = TimeMultiHopFiLMPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
+                                               num_res_block_channels=args.channels, spatial_size=S, precision=prec)
     vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
     stem = FrozenStem(vgg, od, prec)
     return model, stem, vgg, od
@@ -186,6 +194,8 @@ def main():
     ap.add_argument("--width", type=int, default=224)
     ap.add_argument("--blocks", type=int, default=1)
     ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop"],
+                    help="film_attn_pt is the metric's model; the others are BASELINE.json's ladder configs 3 and 5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the stem on the main stream (no side-stream pipeline)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -268,10 +278,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "film_attn_pt_stem training step: VGG-16[:10]+ObjDetectCNN(512) frozen stem + "
-                                   "FiLMAttnPretrainedStem(%d block(s), C=%d, spatial %d) fwd+bwd + clip + Adam; "
+            "config": {"workload": "%s training step: VGG-16[:10]+ObjDetectCNN(512) frozen stem + "
+                                   "FiLM trunk (%d block(s), C=%d, spatial %d) fwd+bwd + clip + Adam; "
                                    "bs=%d/GPU, %d-frame %dx%d clips, data-parallel"
-                                   % (args.blocks, args.channels, S, B, T, H, W),
+                                   % (args.model, args.blocks, args.channels, S, B, T, H, W),
                        "global_batch": B * world, "frames": T, "parallelism": "dp%d" % world,
                        "gflop_per_clip": round(flops_clip / 1e9, 1),
                        "whole_step_tflops": round(clips * flops_clip / 1e12, 1),

@@ -200,6 +200,18 @@ int vnqa_film_relu_res_bwd(const void* dout, const void* z, const float* gamma, 
                            int32_t dtype, void* stream);
 int vnqa_relu_bwd(const void* a, const void* b, const void* y, void* g, int64_t n, int32_t dtype, void* stream);
 
+/* Temporal softmax-attention over frames, fused (models/film_attn_pt_stem.py:268-290):
+ *   score[b,t] = valid[b,t]*(w . feat[b,t,:] + bias) + mask[b,t];  coef = softmax_t(score);  ctxt[b,:] = sum_t coef*feat
+ * feat fp32 [b][t][a] (frame rows contiguous), valid/mask/coef fp32 [b][t], w fp32 [a], bias fp32 [1], ctxt fp32 [b][a].
+ * backward: dfeat [b][t][a], per-sample partials dw_part [b][a] and db_part [b] (summed over b by the caller).
+ */
+int vnqa_temporal_attn_fwd(const float* feat, const float* valid, const float* mask, const float* w,
+                           const float* bias, float* coef, float* ctxt, int32_t b, int32_t t, int32_t a,
+                           void* stream);
+int vnqa_temporal_attn_bwd(const float* feat, const float* valid, const float* w, const float* coef,
+                           const float* dctxt, float* dfeat, float* dw_part, float* db_part, int32_t b,
+                           int32_t t, int32_t a, void* stream);
+
 /* Persistent LSTM over a repeated sequence (one workgroup per sample, W_hh rows in registers).
  * Replaces the per-frame packed nn.LSTM calls with carried state of compute_film_values /
  * compute_film_encoding (models/film_attn_pt_stem.py:146-171 called at :213;

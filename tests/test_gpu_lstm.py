@@ -58,3 +58,42 @@ def test_lstm_seq_forward_backward(H, E, B, Lq, n_rep):
     got = [emb_d.grad] + [p.grad for p in lstm_d.parameters()]
     for g, r in zip(got, ref_grads):
         assert rel(g, r) < 2e-4, rel(g, r)
+
+
+@pytest.mark.parametrize("B,T,A", [(3, 6, 16), (8, 35, 128), (5, 70, 200)])
+def test_temporal_attention_vs_torch(B, T, A):
+    """fused temporal softmax-attention kernel vs the plain PyTorch statement of film_attn_pt_stem.py:268-290"""
+    from videonavqa_amd import ops
+    torch.manual_seed(B * T)
+    feat = torch.randn(B, T, A)
+    valid = (torch.rand(B, T) > 0.3).float()
+    valid[:, 0] = 1
+    processed = torch.ones(B, T)
+    processed[:, T - 2:] = 0                      # frames past the longest video: un-masked, zero features
+    valid = valid * processed
+    feat = feat * valid.unsqueeze(2)
+    mask = (processed - valid) * float(-(1 << 31))
+    w = torch.randn(1, A) * 0.3
+    b = torch.randn(1) * 0.1
+    wctx = torch.randn(B, A)
+
+    def ref(feat, w, b):
+        score = (feat @ w.t() + b).squeeze(2) * valid + mask
+        coef = torch.softmax(score, dim=1)
+        return torch.bmm(coef.unsqueeze(1), feat).squeeze(1), coef
+
+    fr, wr, br = feat.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    cr, coef_r = ref(fr, wr, br)
+    (cr * wctx).sum().backward()
+    fd = feat.cuda().requires_grad_(True)
+    wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    cd, coef_d = ops.temporal_attention(fd, valid.cuda(), mask.cuda(), wd, bd)
+    (cd * wctx.cuda()).sum().backward()
+
+    def rel(a, b_):
+        return float((a.cpu() - b_).abs().max() / (b_.abs().max() + 1e-12))
+
+    assert rel(cd.detach(), cr.detach()) < 2e-5 and rel(coef_d, coef_r.detach()) < 2e-5
+    assert rel(fd.grad, fr.grad) < 1e-4 and rel(wd.grad, wr.grad) < 1e-4
+    # d bias = sum_t dscore_t is a cancellation (exactly 0 when every frame is valid): absolute scale of d w
+    assert float((bd.grad.cpu() - br.grad).abs().max()) < 1e-4 * float(wr.grad.abs().max()) + 1e-6

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "vnqa_film_relu_res_fwd": (ctypes.c_int, [_vp] * 5 + [_i32] * 5 + [_vp]),
     "vnqa_film_relu_res_bwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
     "vnqa_relu_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "vnqa_temporal_attn_fwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 3 + [_vp]),
+    "vnqa_temporal_attn_bwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 3 + [_vp]),
     "vnqa_lstm_seq_fwd": (ctypes.c_int, [_vp] * 9 + [_i32] * 5 + [_vp]),
     "vnqa_lstm_seq_bwd": (ctypes.c_int, [_vp] * 10 + [_i32] * 4 + [_vp]),
     "vnqa_l2norm_blocks": (_i32, [_i64]),

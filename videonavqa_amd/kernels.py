@@ -323,3 +323,22 @@ def conv3d_wgrad(x, dy, want_bias=True):
     L.check(L.lib().vnqa_conv3d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwt), L.ptr(dbias), L.ptr(ws), N, d, h, w, Cin, Cout,
                                       L.dtype_id(x.dtype), L.stream()), "vnqa_conv3d_wgrad")
     return dwt, dbias
+
+
+def temporal_attn_fwd(feat, valid, mask, w, bias):
+    B, T, A = feat.shape
+    coef = torch.empty((B, T), dtype=torch.float32, device=feat.device)
+    ctxt = torch.empty((B, A), dtype=torch.float32, device=feat.device)
+    L.check(L.lib().vnqa_temporal_attn_fwd(L.ptr(feat), L.ptr(valid), L.ptr(mask), L.ptr(w), L.ptr(bias), L.ptr(coef),
+                                           L.ptr(ctxt), B, T, A, L.stream()), "vnqa_temporal_attn_fwd")
+    return coef, ctxt
+
+
+def temporal_attn_bwd(feat, valid, w, coef, dctxt):
+    B, T, A = feat.shape
+    dfeat = torch.empty_like(feat)
+    dw_part = torch.empty((B, A), dtype=torch.float32, device=feat.device)
+    db_part = torch.empty((B,), dtype=torch.float32, device=feat.device)
+    L.check(L.lib().vnqa_temporal_attn_bwd(L.ptr(feat), L.ptr(valid), L.ptr(w), L.ptr(coef), L.ptr(dctxt), L.ptr(dfeat),
+                                           L.ptr(dw_part), L.ptr(db_part), B, T, A, L.stream()), "vnqa_temporal_attn_bwd")
+    return dfeat, dw_part, db_part

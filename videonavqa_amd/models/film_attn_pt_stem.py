@@ -94,12 +94,12 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         processed = torch.zeros(1, T, 1, device=dev)
         processed[:, :lay.n_frames] = 1
         masks = (processed - valid) * NEG_MASK
-        features = self.fc_attn_1(all_features) * valid                 # :268-281
-
-        # temporal attention (:283-295).  v_i = fc_hidden_attn(h) is constant along the frame axis
-        # and softmax is shift invariant, so coefs/ctxt are the same at every step: compute once.
-        coefs = torch.softmax(features + masks, dim=1)                  # :288
-        ctxt = torch.bmm(coefs.permute(0, 2, 1), all_features).view(B, at)  # :290
+        # temporal attention (:268-290) as ONE fused HIP kernel: fc_attn_1 scores on the valid entries,
+        # masked softmax over frames, weighted sum.  v_i = fc_hidden_attn(h) is constant along the frame
+        # axis and softmax is shift invariant, so coefs/ctxt are identical at every step of the
+        # :283 loop and are computed once (fc_hidden_attn consequently receives a zero gradient).
+        ctxt, coefs = ops.temporal_attention(all_features, valid.squeeze(2), masks.squeeze(2),
+                                             self.fc_attn_1.weight, self.fc_attn_1.bias)
         # the 35-step LSTMCell chain on a constant input = the persistent LSTM kernel with
         # one "token" repeated T times (:283,293-298)
         gi = F.linear(ctxt, self.lstm_attn.weight_ih, self.lstm_attn.bias_ih + self.lstm_attn.bias_hh)

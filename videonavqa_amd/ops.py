@@ -220,3 +220,31 @@ def ncdhw_to_ndhwc_padded(x, dtype, c_pad=None):
 def ndhwc_padded_to_ncdhw(x, C):
     """padded NDHWC -> dense fp32 [N,C,D,H,W] (differentiable)."""
     return x[:, 1:-1, 1:-1, 1:-1, :C].permute(0, 4, 1, 2, 3).float()
+
+
+class TemporalAttnFn(torch.autograd.Function):
+    """ctxt, coef = fused temporal attention (film_attn_pt_stem.py:268-290): fc_attn_1 scores on the valid
+    (sample, frame) entries, -(1<<31) masks, softmax over frames, weighted sum of the frame features."""
+
+    @staticmethod
+    def forward(ctx, feat, valid, mask, w, bias):
+        feat = feat.float().contiguous()
+        w1 = w.float().reshape(-1).contiguous()
+        b1 = bias.float().reshape(-1).contiguous()
+        valid = valid.float().contiguous()
+        coef, ctxt = K.temporal_attn_fwd(feat, valid, mask.float().contiguous(), w1, b1)
+        ctx.save_for_backward(feat, valid, w1, coef)
+        ctx.w_shape = w.shape
+        ctx.mark_non_differentiable(coef)
+        return ctxt, coef
+
+    @staticmethod
+    def backward(ctx, dctxt, _dcoef):
+        feat, valid, w1, coef = ctx.saved_tensors
+        dfeat, dw_part, db_part = K.temporal_attn_bwd(feat, valid, w1, coef, dctxt.float().contiguous())
+        return dfeat, None, None, dw_part.sum(0).view(ctx.w_shape), db_part.sum().view(1)
+
+
+def temporal_attention(feat, valid, mask, w, bias):
+    """feat [B,T,A], valid/mask [B,T]; w [1,A], bias [1] (fc_attn_1).  Returns (ctxt [B,A], coef [B,T])."""
+    return TemporalAttnFn.apply(feat, valid, mask, w, bias)
