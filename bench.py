@@ -246,6 +246,19 @@ def main():
     dt = time.perf_counter() - t0
     events = stem.timing
     stem.timing = None
+    # north-star side metric, outside the timed region: the frozen stem ALONE on the chip (all B*T frames,
+    # conv1_1 .. conv32), as a fraction of the dense bf16 MFMA peak
+    stem_ms = None
+    if rank == 0:
+        lay = trainer.extract_features(batch[0], batch[2])[0].layout
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            stem.forward_clip(batch[0], lay.img_of, lay.n_img)
+        e1.record()
+        torch.cuda.synchronize()
+        stem_ms = e0.elapsed_time(e1) / 5
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -285,7 +298,9 @@ def main():
                        "global_batch": B * world, "frames": T, "parallelism": "dp%d" % world,
                        "gflop_per_clip": round(flops_clip / 1e9, 1),
                        "whole_step_tflops": round(clips * flops_clip / 1e12, 1),
-                       "final_loss": round(float(loss), 4)},
+                       "final_loss": round(float(loss), 4),
+                       "stem_alone_ms": round(stem_ms, 3),
+                       "stem_alone_mfma_util": round(n_frames * stem_flops_per_frame(H, W) / (stem_ms * 1e-3) / 1e12 / peak, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
                          "kernel": "conv_igemm_kernel<bf16,256,256,2,4,TAG=1> (frozen-stem 3x3 igemm on "
