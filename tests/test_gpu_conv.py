@@ -222,7 +222,8 @@ def test_conv_igemm_ring_pipeline(tile, cfg):
     (300, 16, 32, 64, True, True, True),     # more tiles than workgroups: patch double-buffer ring
     (1, 48, 16, 192, True, True, False),
 ])
-def test_conv_c64_direct_vs_torch(cfg):
+@pytest.mark.parametrize("shape4", [False, True])
+def test_conv_c64_direct_vs_torch(cfg, shape4):
     from videonavqa_amd import kernels as K
     N, H, W, Cout, relu, pool, post = cfg
     dt = torch.bfloat16
@@ -240,7 +241,8 @@ def test_conv_c64_direct_vs_torch(cfg):
     if post:
         ref = ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
     y = K.conv2d_c64(K.nchw_to_nhwc(x, dt, c_pad=64), K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=64), bias=b,
-                     relu=relu, pool2=pool, post_scale=sc if post else None, post_shift=sh if post else None)
+                     relu=relu, pool2=pool, post_scale=sc if post else None, post_shift=sh if post else None,
+                     shape4=shape4)
     got = K.nhwc_to_nchw(y, Cout)
     assert got.shape == ref.shape
     assert _rel(got, ref) < 1e-2, _rel(got, ref)

@@ -40,8 +40,8 @@ def main():
         flops = 2.0 * N * H * W * Cin * Cout * 9
         for tile in [int(t) for t in args.tiles.split(",")]:
             def run():
-                if tile == 64:
-                    K.conv2d_c64(x, wt, bias=b, relu=True, pool2=pool, out=out)
+                if tile in (64, 65):
+                    K.conv2d_c64(x, wt, bias=b, relu=True, pool2=pool, out=out, shape4=(tile == 65))
                 else:
                     K.conv2d_igemm(x, wt, bias=b, relu=args.relu_flags, pool2=pool, out=out, tile=tile)
             try:

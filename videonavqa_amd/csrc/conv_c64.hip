@@ -45,13 +45,18 @@ __device__ __forceinline__ void glds16c(const char* src, char* lds_wave_base) {
 
 __device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
 
-__global__ void __launch_bounds__(512) conv_c64_kernel(const C64Args p) {
+// NW = 8: wave tile 64 px x 32 couts (2 waves per SIMD); NW = 4: wave tile 64 px x 64 couts (1 wave per SIMD,
+// 8 fragment reads per 16 MFMAs instead of 6 per 8: the 8-wave shape runs close to the LDS read bandwidth).
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
+  constexpr int TN = NW == 8 ? 2 : 4;              // 16-cout fragments per wave
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ldsW = smem;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 31, fh = lane >> 5;
+  const int wm = NW == 8 ? (wave >> 1) : wave, wn = NW == 8 ? (wave & 1) : 0;
+  const int fr = lane & 15, fh = lane >> 4;     // v_mfma_f32_16x16x32_bf16: row/col = lane&15, k-chunk = lane>>4
 
   // work items: this workgroup keeps ONE cout slice for its whole life (weights loaded once)
   const int G = gridDim.x;
@@ -63,8 +68,8 @@ __global__ void __launch_bounds__(512) conv_c64_kernel(const C64Args p) {
   {
     const size_t wbase = (size_t)nsl * 64 * 9 * 128;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const int q = wave * 9 + j;                  // 72 instructions, 8 rows each
+    for (int j = 0; j < 72 / NW; ++j) {
+      const int q = wave * (72 / NW) + j;          // 72 instructions, 8 rows each
       const int row = q * 8 + (lane >> 3);         // tap*64 + c
       const int tap = row >> 6, c = row & 63;
       const int lc = (lane & 7) ^ swz128(row);
@@ -81,14 +86,15 @@ __global__ void __launch_bounds__(512) conv_c64_kernel(const C64Args p) {
     x0 = (r - ty * p.tilesX) * TS;
   };
 
-  // number of patch DMA instructions this wave issues (41 spread over 8 waves: wave 0 has 6)
-  const int my_pinstr = wave == 0 ? 6 : 5;
+  // number of patch DMA instructions this wave issues (41 spread over NW waves: wave 0 has one more)
+  constexpr int PI = 40 / NW;
+  const int my_pinstr = wave == 0 ? PI + 1 : PI;
   auto issue_patch = [&](long long t, int slot) {
     int n, y0, x0;
     tile_coords(t, n, y0, x0);
     char* lds = smem + W_BYTES + slot * P_BYTES;
     for (int j = 0; j < my_pinstr; ++j) {
-      const int q = wave + 8 * j;
+      const int q = wave + NW * j;
       int row = q * 8 + (lane >> 3);
       const int lrow = row;
       row = row < PROWS ? row : PROWS - 1;
@@ -102,20 +108,22 @@ __global__ void __launch_bounds__(512) conv_c64_kernel(const C64Args p) {
   };
 
   // ---- fragment geometry ----
-  // sub-tile i of this wave: pixels (ty = 4*wm + 2*i + dy, tx), dy = fr >> 4, tx = fr & 15
-  int prow0[2];
+  // pixel fragment i of this wave = tile row ty = 4*wm + i, tx = fr; cout fragment j = couts wn*32 + 16j + (0..15)
+  int prow0[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) prow0[i] = (4 * wm + 2 * i + (fr >> 4)) * PS + (fr & 15);
-  const int brow = wn * 32 + fr;
-  const int b_rd = brow * 128, b_sw = swz128(brow);
+  for (int i = 0; i < 4; ++i) prow0[i] = (4 * wm + i) * PS + fr;
+  int b_rd[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_rd[j] = (wn * 32 + j * 16 + fr) * 128;
+  const int b_sw = swz128(fr);       // (wn*32 + 16j) is a multiple of 16: the swizzle only sees fr
 
-  // bias of this lane's 16 output channels: cout = nsl*64 + wn*32 + 8g + 4fh + e
-  float bias_r[16];
+  // bias of this lane's 8 output channels: cout = nsl*64 + wn*32 + 16j + 4fh + e
+  float bias_r[TN][4];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      bias_r[4 * g + e] = p.bias ? p.bias[nsl * 64 + wn * 32 + 8 * g + 4 * fh + e] : 0.f;
+      bias_r[j][e] = p.bias ? p.bias[nsl * 64 + wn * 32 + 16 * j + 4 * fh + e] : 0.f;
 
   long long t_cur = gslot;
   if (t_cur < tiles_total) issue_patch(t_cur, 0);
@@ -127,43 +135,49 @@ __global__ void __launch_bounds__(512) conv_c64_kernel(const C64Args p) {
     const bool have_next = t_cur + gstride < tiles_total;
     // everything but the youngest patch (tile it+1) must have landed: weights, this tile's patch
     if (have_next) {
-      if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
 
     const char* ldsP = smem + W_BYTES + slot * P_BYTES;
-    vnqa_f32x16 acc[2];
+    vnqa_f32x4 acc[4][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
-    // 36 k-steps (tap-major, 4 x 16 channels per tap), fragments double-buffered in registers: the
+    // 18 k-steps (tap-major, 2 x 32 channels per tap), fragments double-buffered in registers: the
     // LDS reads of step k+1 are issued before the MFMAs of step k
-    auto load_step = [&](int k, vnqa_f32x4& wf, vnqa_f32x4* xf) {
-      const int tap = k >> 2, s = k & 3;
+    auto load_step = [&](int k, vnqa_f32x4* wf, vnqa_f32x4* xf) {
+      const int tap = k >> 1, s = k & 1;
       const int toff = (tap / 3) * PS + (tap % 3);
-      wf = *(const vnqa_f32x4*)(ldsW + tap * 8192 + b_rd + (((2 * s + fh) ^ b_sw) << 4));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int j = 0; j < TN; ++j)
+        wf[j] = *(const vnqa_f32x4*)(ldsW + tap * 8192 + b_rd[j] + (((4 * s + fh) ^ b_sw) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
         const int pr = prow0[i] + toff;
-        xf[i] = *(const vnqa_f32x4*)(ldsP + pr * 128 + (((2 * s + fh) ^ swz128(pr)) << 4));
+        xf[i] = *(const vnqa_f32x4*)(ldsP + pr * 128 + (((4 * s + fh) ^ swz128(pr)) << 4));
       }
     };
-    vnqa_f32x4 wfb[2], xfb[2][2];
+    vnqa_f32x4 wfb[2][TN], xfb[2][4];
     load_step(0, wfb[0], xfb[0]);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int k = 0; k < 36; ++k) {
-      if (k + 1 < 36) load_step(k + 1, wfb[(k + 1) & 1], xfb[(k + 1) & 1]);
+    for (int k = 0; k < 18; ++k) {
+      if (k + 1 < 18) load_step(k + 1, wfb[(k + 1) & 1], xfb[(k + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vnqa_bf16x8, wfb[k & 1]),
-                                                         __builtin_bit_cast(vnqa_bf16x8, xfb[k & 1][i]), acc[i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vnqa_bf16x8, wfb[k & 1][j]),
+                                                             __builtin_bit_cast(vnqa_bf16x8, xfb[k & 1][i]), acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -172,21 +186,21 @@ __global__ void __launch_bounds__(512) conv_c64_kernel(const C64Args p) {
     // ---- epilogue: C tile [m][64 couts] in the patch slot; m is quad-major when pooling ----
     char* ldsC = smem + W_BYTES + slot * P_BYTES;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int ty = 4 * wm + 2 * i + (fr >> 4), tx = fr & 15;
+    for (int i = 0; i < 4; ++i) {
+      const int ty = 4 * wm + i, tx = fr;
       const int m = p.pool ? ((((ty >> 1) * 8 + (tx >> 1)) << 2) + ((ty & 1) << 1) + (tx & 1)) : (ty * TS + tx);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int j = 0; j < TN; ++j) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[i][4 * g + e] + bias_r[4 * g + e];
+          v[e] = acc[i][j][e] + bias_r[j][e];
           if (p.relu) v[e] = fmaxf(v[e], 0.f);
         }
         uint2 pk;
         pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
         pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-        *(uint2*)(ldsC + m * CROW + (wn * 32 + 8 * g + 4 * fh) * 2) = pk;
+        *(uint2*)(ldsC + m * CROW + (wn * 32 + 16 * j + 4 * fh) * 2) = pk;
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -199,7 +213,7 @@ __global__ void __launch_bounds__(512) conv_c64_kernel(const C64Args p) {
     const int side = p.pool ? 8 : 16;
     const int Ho = p.pool ? (p.H >> 1) : p.H, Wo = p.pool ? (p.W >> 1) : p.W;
     const int oy0 = p.pool ? (y0 >> 1) : y0, ox0 = p.pool ? (x0 >> 1) : x0;
-    for (int idx = threadIdx.x; idx < rows_out * 8; idx += 512) {
+    for (int idx = threadIdx.x; idx < rows_out * 8; idx += NT) {
       const int orow = idx >> 3, c = idx & 7;
       const int oy = oy0 + orow / side, ox = ox0 + orow % side;
       if (oy >= Ho || ox >= Wo) continue;
@@ -282,9 +296,11 @@ extern "C" int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const
   const int ho = d->pool2 ? d->h / 2 : d->h, wo = d->pool2 ? d->w / 2 : d->w;
   a.Hyp = ho + 2;
   a.Wyp = wo + 2;
+  const bool four = d->tile == 2;   // tile == 2 selects the 4-wave shape (A/B runs: 15 % slower); default = 8 waves
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)conv_c64_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_c64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
       vnqa_set_error("conv2d_c64_fwd: cannot reserve %d B of LDS", LDS_BYTES);
       return VNQA_ERR_HIP;
     }
@@ -294,7 +310,10 @@ extern "C" int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const
   grid = grid / a.nsplit * a.nsplit;
   if (grid > a.n_work) grid = (a.n_work / a.nsplit) * a.nsplit;
   if (grid < a.nsplit) grid = a.nsplit;
-  hipLaunchKernelGGL(conv_c64_kernel, dim3((int)grid), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  if (four)
+    hipLaunchKernelGGL(conv_c64_kernel<4>, dim3((int)grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(conv_c64_kernel<8>, dim3((int)grid), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -77,7 +77,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
     return out
 
 
-def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None):
+def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None, shape4=False):
     """Persistent direct conv for Cin == 64 (bf16, 3x3): same tensors as conv2d_igemm."""
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2, Wp - 2
@@ -86,7 +86,7 @@ def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
-    d = L.ConvDesc(L.BF16, N, H, W, Cin, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0, 0)
+    d = L.ConvDesc(L.BF16, N, H, W, Cin, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 2 if shape4 else 0, 0, 0)
     L.check(L.lib().vnqa_conv2d_c64_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                         L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_c64_fwd")
     return out
