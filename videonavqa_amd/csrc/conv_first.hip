@@ -32,17 +32,25 @@ __global__ void __launch_bounds__(256) conv_first_kernel(const FirstArgs p) {
   const int row_floats = (TX + 2) * T_;
 
   // ---- stage the input patch (zero outside the image) ----
+  // element i of a patch row is (px = i / T, t = i % T); its column validity does not depend on the row,
+  // so it is computed once per thread (no per-element integer division in the copy loop)
+  constexpr int MAXIT = 8;                         // row_floats <= 8 * 256 (T <= 113)
+  const int nit = (row_floats + 255) / 256;
+  unsigned colmask = 0;
+  for (int k = 0; k < nit && k < MAXIT; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    const int gx = x0 + i / T_ - 1;
+    if (i < row_floats && gx >= 0 && gx < p.W) colmask |= 1u << k;
+  }
   for (int rc = 0; rc < 3 * (TY + 2); ++rc) {
     const int c = rc / (TY + 2), py = rc - c * (TY + 2);
     const int gy = y0 + py - 1;
+    const bool rowok = gy >= 0 && gy < p.H;
     const float* src = p.clip + (((size_t)b * 3 + c) * p.H + gy) * (size_t)p.W * T_ + (size_t)(x0 - 1) * T_;
     float* dst = patch + rc * row_floats;
-    for (int i = threadIdx.x; i < row_floats; i += 256) {
-      const int px = i / T_;
-      const int gx = x0 + px - 1;
-      float v = 0.f;
-      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) v = src[i];
-      dst[i] = v;
+    for (int k = 0; k < nit; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < row_floats) dst[i] = (rowok && ((colmask >> k) & 1u)) ? src[i] : 0.f;
     }
   }
   __syncthreads();
@@ -92,6 +100,8 @@ __global__ void __launch_bounds__(256) conv_first_kernel(const FirstArgs p) {
           const float v = patch[pix_base + koff[s][e] + t];
           xb[s][e] = (short)(kval[s][e] ? f32_to_bf16(v) : 0);
         }
+      // both cout tiles -> wave-private LDS tile [32 px][64 co] (144-B rows), then 16-byte row-contiguous stores
+      char* ctile = (char*)(patch + 3 * (TY + 2) * row_floats) + wave * (32 * 144);
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         vnqa_f32x16 acc;
@@ -99,21 +109,26 @@ __global__ void __launch_bounds__(256) conv_first_kernel(const FirstArgs p) {
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tn][0], xb[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tn][1], xb[1], acc, 0, 0, 0);
-        if (inside) {
-          unsigned short* dst = (unsigned short*)p.y +
-              ((((size_t)img * (p.H + 2)) + gy + 1) * (p.W + 2) + gx + 1) * CO + tn * 32 + 4 * h;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            uint2 pk;
-            const float v0 = fmaxf(acc[4 * g + 0] + bias4[tn][g][0], 0.f);
-            const float v1 = fmaxf(acc[4 * g + 1] + bias4[tn][g][1], 0.f);
-            const float v2 = fmaxf(acc[4 * g + 2] + bias4[tn][g][2], 0.f);
-            const float v3 = fmaxf(acc[4 * g + 3] + bias4[tn][g][3], 0.f);
-            pk.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
-            pk.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
-            *(uint2*)(dst + 8 * g) = pk;
-          }
+        for (int g = 0; g < 4; ++g) {
+          uint2 pk;
+          const float v0 = fmaxf(acc[4 * g + 0] + bias4[tn][g][0], 0.f);
+          const float v1 = fmaxf(acc[4 * g + 1] + bias4[tn][g][1], 0.f);
+          const float v2 = fmaxf(acc[4 * g + 2] + bias4[tn][g][2], 0.f);
+          const float v3 = fmaxf(acc[4 * g + 3] + bias4[tn][g][3], 0.f);
+          pk.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+          pk.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+          *(uint2*)(ctile + col * 144 + (tn * 32 + 8 * g + 4 * h) * 2) = pk;
         }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;                 // 16-byte chunk of the 32 x 128-B tile
+        const int prow = c >> 3, chunk = c & 7;
+        const uint4 v = *(const uint4*)(ctile + prow * 144 + chunk * 16);
+        const int oy = y0 + (prow >> 4), ox = x0 + (prow & 15);
+        if (oy < p.H && ox < p.W)
+          *(uint4*)((unsigned short*)p.y + ((((size_t)img * (p.H + 2)) + oy + 1) * (p.W + 2) + ox + 1) * CO + chunk * 8) = v;
       }
     }
   } else {
@@ -174,8 +189,8 @@ extern "C" int vnqa_conv_first_fwd(const float* clip, const float* w, const floa
   VNQA_CHECK_ARG(c_out == CO, "conv_first_fwd: c_out must be 64 (got %d)", c_out);
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv_first_fwd: bad dtype %d", dtype);
   VNQA_CHECK_ARG(b > 0 && t > 0 && h > 0 && wd > 0, "conv_first_fwd: empty problem");
-  const size_t lds = (size_t)3 * (TY + 2) * (TX + 2) * t * sizeof(float);
-  VNQA_CHECK_ARG(lds <= 160 * 1024, "conv_first_fwd: t=%d frames do not fit the LDS patch", t);
+  const size_t lds = (size_t)3 * (TY + 2) * (TX + 2) * t * sizeof(float) + 4 * 32 * 144;   // patch + 4 wave output tiles
+  VNQA_CHECK_ARG(lds <= 160 * 1024 && 18 * t <= 8 * 256, "conv_first_fwd: t=%d frames do not fit the LDS patch", t);
   FirstArgs a{clip, w, bias, img_of, (char*)y, b, t, h, wd};
   dim3 grid((wd + TX - 1) / TX, (h + TY - 1) / TY, b);
   hipStream_t st = (hipStream_t)stream;
