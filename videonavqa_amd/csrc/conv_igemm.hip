@@ -292,7 +292,57 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     }
   };
 
-  if constexpr (PIPE == 2) {
+  auto mma_sub = [&](vnqa_f32x4* xf, vnqa_f32x4* wf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) Mma<T>::run(wf[j], xf[i], acc[i][j]);
+  };
+
+#ifndef VNQA_NO_STAGGER
+  constexpr bool kStagger = (PIPE == 2 && NSUB == 2 && NW == 8 && WAVES_M == 2);   // 256x256 tile only: measured -4 % on the 4x2-wave 256x128 tile
+#else
+  constexpr bool kStagger = false;
+#endif
+  if constexpr (kStagger) {
+    // Two waves share every SIMD (wave w and w+4).  Waves 4-7 run half a stage behind: right after the
+    // barrier they issue the MFMAs of substep 1 of the PREVIOUS stage (fragments already in registers)
+    // while waves 0-3 wait on their first LDS reads; the SIMD's matrix pipe and its LDS port are then used
+    // by different waves at any time instead of both waves stalling together.  Both variants execute the
+    // same barrier sequence; late waves never touch a slot after the barrier that allows its refill.
+    stage(kt0, 0);
+    __syncthreads();
+    vnqa_f32x4 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+    if (wave < 4) {
+      for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const char* lds = smem + cur * STAGE_BYTES;
+        if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
+        load_frags(lds, 0, xf0, wf0);
+        load_frags(lds, 1, xf1, wf1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_sub(xf0, wf0);
+        mma_sub(xf1, wf1);
+        __syncthreads();
+      }
+    } else {
+      for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const char* lds = smem + cur * STAGE_BYTES;
+        if (kt + 1 < kt1) stage(kt + 1, cur ^ 1);
+        if (kt > kt0) mma_sub(xf1, wf1);                 // substep 1 of stage kt-1 (registers only)
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(lds, 0, xf0, wf0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_sub(xf0, wf0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(lds, 1, xf1, wf1);                    // lands in registers before the barrier below
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                 // (its fence waits for lgkmcnt(0) and vmcnt(0))
+      }
+      mma_sub(xf1, wf1);
+    }
+  } else if constexpr (PIPE == 2) {
     stage(kt0, 0);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
