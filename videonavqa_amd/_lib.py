@@ -69,6 +69,10 @@ def lib():
     """Load (once) and return the CDLL; raises if the HIP library has not been built."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and "VNQA_LIB" not in os.environ and os.path.exists("/opt/rocm/bin/hipcc"):
+            # not a fallback: build the HIP library itself (hipcc cross-compiles gfx950 anywhere)
+            from .build import build as _build
+            _build(verbose=False)
         if not os.path.exists(LIB_PATH):
             raise VnqaError(
                 "libvnqa_hip.so not found at %s — build it with `python -m videonavqa_amd.build` "

@@ -75,6 +75,16 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// Rejected experiment, kept for A/B: non-temporal (aux = 2) weight-tile DMA measured -8 % on conv12/conv22
+// (every CU re-reads the weight tiles from L2; nt gives that reuse up).
+#ifdef VNQA_NT_WEIGHTS
+__device__ __forceinline__ void glds16w_(const char* src, char* lds_wave_base) {   // non-temporal
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+#else
+#define glds16w_ glds16
+#endif
 
 // conv-output pixel index m -> (n, y, x); pooled layers enumerate pixels quad-major so that
 // the four members of a 2x2 pooling window are consecutive m.
@@ -219,11 +229,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
         const char* src = p.wt + ((size_t)tile_n * KT + kt) * B_BYTES + (size_t)lane * 16;
 #pragma unroll
         for (int j = 0; j < B_PER_WAVE; ++j)
-          glds16(src + (wave * B_PER_WAVE + j) * 1024, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
+          glds16w_(src + (wave * B_PER_WAVE + j) * 1024, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
       } else {
 #pragma unroll
         for (int j = 0; j < B_PER_WAVE; ++j)
-          glds16(p.wt + b_off[j] + woff, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
+          glds16w_(p.wt + b_off[j] + woff, lds + A_BYTES + (wave * B_PER_WAVE + j) * 1024);
       }
     }
   };
@@ -656,7 +666,12 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
   a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const int tile = dtype == VNQA_BF16 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+  // bf16: 256-row tiles unless 128-row tiles waste fewer padded rows (e.g. m = 280: 384 instead of 512)
+  int tile = VNQA_TILE_128x128;
+  if (dtype == VNQA_BF16) {
+    const int pad256 = (m + 255) / 256 * 256, pad128 = (m + 127) / 128 * 128;
+    tile = (ws > 0 || pad128 >= pad256) ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+  }
   if (ws > 0) {
     const int slices_req = (int)(ws / ((int64_t)m * n * 4));
     const int kt = k / bk;
