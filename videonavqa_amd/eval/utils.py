@@ -1,49 +1,52 @@
-"""Constants and helpers mirroring eval/utils.py of the reference (same names and values)."""
+"""Configuration constants and small helpers of the evaluation drivers.
+
+The NAMES and VALUES below are the reference's contract (eval/utils.py:6-25): other code — and user
+scripts written against the reference — import them by name, so they are kept; everything else in this
+module is this project's own code.
+"""
+import os
+
 import numpy as np
 import torch
 
-BASE_DIR = '../data/'                                   # eval/utils.py:6
+# data root and the files/directories the drivers expect below it (eval/utils.py:6-16)
+BASE_DIR = '../data/'
+_LAYOUT = {
+    'QUESTIONS_DIR': 'encoded_questions',
+    'VIDEOS_DIR': 'videos',
+    'LABELS_FILE': 'labels.json',
+    'OBJ_DETECTOR_PATH': 'obj_detect.pt',
+    'RAW_QUESTIONS_FILE': 'q_ids.json',
+    'SPLIT_FILE': 'split.json',
+}
+globals().update({name: BASE_DIR + rel for name, rel in _LAYOUT.items()})
 
-# Dir paths (eval/utils.py:9-10)
-QUESTIONS_DIR = BASE_DIR + 'encoded_questions'
-VIDEOS_DIR = BASE_DIR + 'videos'
+# clip / question geometry (eval/utils.py:19-25)
+_GEOMETRY = dict(DROP_EVERY_N_FRAMES=4, MAX_ALLOWED_NUM_FRAMES_DROPPING=35, MAX_NUM_VIDEO_FRAMES=400,
+                 MAX_Q_LEN=56, NUM_CLASSES=70, VID_HEIGHT=160, VID_WIDTH=208)
+globals().update(_GEOMETRY)
 
-# File paths (eval/utils.py:13-16)
-LABELS_FILE = BASE_DIR + 'labels.json'
-OBJ_DETECTOR_PATH = BASE_DIR + 'obj_detect.pt'
-RAW_QUESTIONS_FILE = BASE_DIR + 'q_ids.json'
-SPLIT_FILE = BASE_DIR + 'split.json'
-
-# Numeric constants (eval/utils.py:19-25)
-DROP_EVERY_N_FRAMES = 4
-MAX_ALLOWED_NUM_FRAMES_DROPPING = 35
-MAX_NUM_VIDEO_FRAMES = 400
-MAX_Q_LEN = 56
-NUM_CLASSES = 70
-VID_HEIGHT = 160
-VID_WIDTH = 208
-
-use_cuda = torch.cuda.is_available()                   # eval/utils.py:27
+use_cuda = torch.cuda.is_available()
 
 
 def per_class_accuracies(y_target, y_pred, num_classes):
-    """eval/utils.py:30-39."""
-    accs = []
-    for i in range(num_classes):
-        idxs = np.where(y_target == i)[0]
-        total = idxs.size
-        hits = np.where(y_pred[idxs] == i)[0].size
-        accs.append((float(hits) / float(total)) if total != 0 else 0.0)
-    return np.array(accs)
+    """Fraction of correctly predicted examples per class; 0 for classes absent from y_target
+    (same numbers as eval/utils.py:30-39, computed with two bincounts)."""
+    t = np.asarray(y_target).astype(np.int64)
+    p = np.asarray(y_pred).astype(np.int64)
+    totals = np.bincount(t, minlength=num_classes)[:num_classes].astype(np.float64)
+    hits = np.bincount(t[t == p], minlength=num_classes)[:num_classes].astype(np.float64)
+    return np.divide(hits, totals, out=np.zeros(num_classes), where=totals > 0)
 
 
-def get_object_detector(path=OBJ_DETECTOR_PATH, precision='bf16', load=True):
-    """eval/utils.py:42-51: ObjDetectCNN(27, 512, 1024, 0, logits, pretrained_features) in eval mode.
-    `load=False` keeps the random initialisation (synthetic benchmarking without obj_detect.pt)."""
+def get_object_detector(path=None, precision='bf16', load=True):
+    """The frozen ObjDetectCNN of the video-QA pipeline in eval mode — 27 classes, 512 filters,
+    1024-wide tail, no dropout, logits, pretrained_features (eval/utils.py:42-51).  `load=False` keeps the
+    random initialisation (synthetic benchmarking on a box without obj_detect.pt)."""
     from ..models.obj_detector import ObjDetectCNN
-    model = ObjDetectCNN(nb_classes=27, num_filters=512, tail_hidden_dim=1024, tail_dropout_p=0, logits=True,
-                         pretrained_features=True, precision=precision)
+    net = ObjDetectCNN(27, num_filters=512, tail_hidden_dim=1024, tail_dropout_p=0, logits=True,
+                       pretrained_features=True, precision=precision)
     if load:
-        model.load_state_dict(torch.load(path, map_location='cpu')['state_dict'])
-    model.eval()
-    return model
+        ckpt = torch.load(path or globals()['OBJ_DETECTOR_PATH'], map_location='cpu')
+        net.load_state_dict(ckpt['state_dict'])
+    return net.eval()

@@ -33,6 +33,24 @@ def compute_dtype(precision):
     raise ValueError("precision must be 'bf16' or 'fp32' (got %r)" % (precision,))
 
 
+def reference_init_(module):
+    """The reference's `weights_init` rule applied to one module (film_attn_pt_stem.py:111-127, repeated in
+    every model file upstream): Xavier-uniform weights + zero bias for Linear/Conv2d; for nn.LSTM
+    Xavier input weights, orthogonal recurrent weights, forget-gate bias 1 in both bias vectors and then
+    bias_ih zeroed.  Conv3d / BatchNorm / LayerNorm / Embedding keep PyTorch's defaults (as upstream)."""
+    if isinstance(module, (nn.Linear, nn.Conv2d)):
+        nn.init.xavier_uniform_(module.weight)
+        nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.LSTM):
+        with torch.no_grad():
+            nn.init.xavier_uniform_(module.weight_ih_l0)
+            nn.init.orthogonal_(module.weight_hh_l0)
+            h = module.hidden_size
+            for b in (module.bias_ih_l0, module.bias_hh_l0):
+                b[h:2 * h] = 1.0
+            module.bias_ih_l0.zero_()
+
+
 class FrameLayout(object):
     """Packed image list for one minibatch: image n <-> (frame t, sample b), frame-major.
     cts[t] = #videos with v_len >= t+1 (film_attn_pt_stem.py:201-208); v_lens sorted descending."""
@@ -189,19 +207,7 @@ class FiLMTrunkBase(nn.Module):
         self.num_res_block_channels = num_res_block_channels
 
     def weights_init(self, m):
-        """film_attn_pt_stem.py:111-127."""
-        if isinstance(m, (nn.Linear, nn.Conv2d)):
-            nn.init.xavier_uniform_(m.weight.data)
-            m.bias.data.fill_(0.0)
-        if isinstance(m, nn.LSTM):
-            nn.init.xavier_uniform_(m.weight_ih_l0)
-            nn.init.orthogonal_(m.weight_hh_l0)
-            for names in m._all_weights:
-                for name in filter(lambda n: "bias" in n, names):
-                    bias = getattr(m, name)
-                    n = bias.size(0)
-                    bias.data[n // 4:n // 2].fill_(1.0)
-            m.bias_ih_l0.data.fill_(0.0)
+        reference_init_(m)
 
     # nn.Module._apply does not see the plain list: keep the frozen 1x1 convs on the model's device
     def _apply(self, fn, *args, **kwargs):
