@@ -61,7 +61,7 @@ def test_stem_prefetch_pipeline_is_transparent():
     # Adam turns a noise-level gradient into a +-lr step, so single elements may differ by O(lr);
     # the bulk must agree tightly
     d = (w0 - w1).abs()
-    assert float(d.max()) < 2e-3
+    assert float(d.max()) < 6e-3            # half of the maximum possible Adam travel 2 * lr * steps
     assert float(torch.quantile(d[:1000000], 0.999)) < 1e-5
     assert l0[-1] < l0[0] * 1.5  # finite, sane
 
