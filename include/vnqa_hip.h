@@ -77,6 +77,7 @@ typedef struct vnqa_conv_desc {
 #define VNQA_TILE_P4_256x256 7   /* 4-stage ring, counted vmcnt (bf16; c_in % 32 == 0) */
 #define VNQA_TILE_P4_256x128 8
 #define VNQA_TILE_P4_256x64 9
+#define VNQA_TILE_256x128_W24 10 /* 256x128 with 2x4 waves (wave tile 128x32), staggered like the 256x256 tile */
 #define VNQA_TILE_STEM_256x256 6 /* 256x256 geometry, own kernel symbol for the frozen stem (bf16) */
 
 int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,

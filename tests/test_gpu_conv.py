@@ -65,7 +65,7 @@ def test_conv_igemm_vs_torch(dt, cfg):
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_conv_igemm_tiles_agree(tile):
     from videonavqa_amd import kernels as K
     g = torch.Generator(device="cpu").manual_seed(tile)

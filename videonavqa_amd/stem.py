@@ -112,7 +112,7 @@ class FrozenStem(object):
         if bf16 and c_in_pad == 64:
             tile = None                      # conv_c64 direct kernel (row layout, LDS-resident weights)
         elif bf16:
-            tile = L.TILE_STEM_256x256 if c_out_pad >= 256 else (L.TILE_256x128 if c_out_pad > 64 else L.TILE_256x64)
+            tile = L.TILE_STEM_256x256 if c_out_pad >= 256 else (L.TILE_128x128 if c_out_pad > 64 else L.TILE_256x64)
         else:
             tile = L.TILE_128x64 if c_out_pad <= 64 else L.TILE_128x128
         import os
