@@ -238,12 +238,17 @@ def main():
     for _ in range(args.warmup):
         trainer.step(*batch, **nxt)
     stem.timing = []          # (start, end) HIP events around every stem-tagged igemm launch
+    import gc
+    gc.collect()
+    if os.environ.get("VNQA_BENCH_GC", "0") != "1":
+        gc.disable()          # the launch thread must not stall in the cyclic collector mid-step
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.step(*batch, **nxt)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     events = stem.timing
     stem.timing = None
     # north-star side metric, outside the timed region: the frozen stem ALONE on the chip (all B*T frames,

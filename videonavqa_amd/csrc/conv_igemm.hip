@@ -514,7 +514,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
   if (dtype == VNQA_BF16) {
     if (tile == VNQA_TILE_AUTO) {
       if (a.Cout <= 64) tile = VNQA_TILE_256x64;
-      else if (a.Cout <= 128) tile = VNQA_TILE_128x128;   // two workgroups per CU: 874 vs 709 TFLOP/s on conv2_2
+      else if (a.Cout <= 128) tile = VNQA_TILE_256x128;   // (128x128 is faster alone, slower when two streams co-run)
       else tile = VNQA_TILE_256x256;
     }
     switch (tile) {

@@ -18,6 +18,8 @@ each layer in ONE launch:
 Eval-mode BatchNorm after a conv folds exactly into that conv's weights and bias.
 Activation buffers are allocated once per geometry (zero halo written once, never touched again).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -112,10 +114,12 @@ class FrozenStem(object):
         if bf16 and c_in_pad == 64:
             tile = None                      # conv_c64 direct kernel (row layout, LDS-resident weights)
         elif bf16:
-            tile = L.TILE_STEM_256x256 if c_out_pad >= 256 else (L.TILE_128x128 if c_out_pad > 64 else L.TILE_256x64)
+            # 128x128 (2 workgroups/CU) is 20 % faster for conv2_2 ALONE but costs 10 % end to end when the trunk co-runs on
+            # the other stream (same-box A/B): finer interleaving of the two streams' workgroups hurts both
+            t128 = L.TILE_128x128 if os.environ.get("VNQA_STEM_T128", "0") == "1" else L.TILE_256x128
+            tile = L.TILE_STEM_256x256 if c_out_pad >= 256 else (t128 if c_out_pad > 64 else L.TILE_256x64)
         else:
             tile = L.TILE_128x64 if c_out_pad <= 64 else L.TILE_128x128
-        import os
         if tile is None or os.environ.get("VNQA_STEM_TILED", "1") == "0":
             wt = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         else:   # frozen weights: pre-tiled once into the exact LDS images the igemm DMA consumes

@@ -14,6 +14,8 @@ full replica and its own minibatch; gradients are SUMMED across ranks (loss redu
 eval.sh:16), the global-norm clip then applies to the reduced gradient, and every rank performs
 the identical Adam update.  BatchNorm statistics stay rank-local (no SyncBN upstream).
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -122,7 +124,10 @@ class Trainer(object):
         # software pipeline: the frozen stem of the NEXT minibatch runs on a side stream while this
         # minibatch's trunk forward/backward runs on the main stream (two output slots)
         self.reducer = OverlappedGradReducer(self.fp, world_size, loss_reduction)
-        self.stem_stream = torch.cuda.Stream()
+        prio = int(os.environ.get("VNQA_STEM_PRIO", "0"))
+        self.stem_stream = torch.cuda.Stream(priority=prio)
+        tprio = os.environ.get("VNQA_TRUNK_PRIO")
+        self.trunk_stream = torch.cuda.Stream(priority=int(tprio)) if tprio is not None else None
         self._prefetched = None          # (key, NativeFeatures, v_sorted, perm, done_event)
         self._slot = 0
         self._trunk_done = [None, None]  # event per slot: last trunk pass that read that slot
@@ -184,6 +189,16 @@ class Trainer(object):
         self._prefetched = (clip.data_ptr(), native, v_sorted, perm, done, slot)
 
     def step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
+        if self.trunk_stream is None:
+            return self._step(clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip, next_v_lens_cpu)
+        outer = torch.cuda.current_stream()
+        self.trunk_stream.wait_stream(outer)
+        with torch.cuda.stream(self.trunk_stream):
+            out = self._step(clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip, next_v_lens_cpu)
+        outer.wait_stream(self.trunk_stream)
+        return out
+
+    def _step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
         """One optimisation step.  v_lens_cpu / q_lens_cpu are host int64 tensors (as a DataLoader
         delivers them); clip, q_input, ys are on the GPU.  If `next_clip` is given, its stem is
         launched on the side stream so that it overlaps this step's trunk.  Returns (loss, logits) —
