@@ -124,6 +124,8 @@ class Trainer(object):
         # software pipeline: the frozen stem of the NEXT minibatch runs on a side stream while this
         # minibatch's trunk forward/backward runs on the main stream (two output slots)
         self.reducer = OverlappedGradReducer(self.fp, world_size, loss_reduction)
+        self.stem_device = self.fp.flat.device
+        self.copy_stream = None
         prio = int(os.environ.get("VNQA_STEM_PRIO", "0"))
         self.stem_stream = torch.cuda.Stream(priority=prio)
         tprio = os.environ.get("VNQA_TRUNK_PRIO")
@@ -175,6 +177,31 @@ class Trainer(object):
         feats = self.stem.forward_clip(clip, lay.img_of, lay.n_img, slot=slot)
         return NativeFeatures(feats, lay, self.feature_channels, H // 16, W // 16), v_sorted, perm
 
+    def upload(self, clip_host):
+        """Start the H2D copy of a (pinned) host clip on the copy stream into one of three rotating device
+        buffers and return that device tensor; consumers wait on its event.  With upload(i+2) issued while
+        stem(i+1) and trunk(i) run, the copy engine, the stem and the trunk form a 3-stage pipeline."""
+        if self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream()
+            self._up_bufs, self._up_idx, self._up_events = [None, None, None], 0, {}
+        i = self._up_idx
+        self._up_idx = (i + 1) % 3
+        if self._up_bufs[i] is None or self._up_bufs[i].shape != clip_host.shape:
+            self._up_bufs[i] = torch.empty(clip_host.shape, dtype=clip_host.dtype, device=self.stem_device)
+        buf = self._up_bufs[i]
+        self.copy_stream.wait_stream(self.stem_stream)       # the stem that last read this buffer is long queued
+        with torch.cuda.stream(self.copy_stream):
+            buf.copy_(clip_host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self._up_events[buf.data_ptr()] = ev
+        return buf
+
+    def _wait_upload(self, clip):
+        ev = self._up_events.get(clip.data_ptr()) if self.copy_stream is not None else None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def prefetch(self, clip, v_lens_cpu):
         """Start the stem of an upcoming minibatch on the side stream (returns immediately)."""
         slot = self._slot ^ 1
@@ -183,10 +210,14 @@ class Trainer(object):
         if self._trunk_done[slot] is not None:
             self.stem_stream.wait_event(self._trunk_done[slot])   # that slot's previous reader
         with torch.cuda.stream(self.stem_stream):
+            key = clip.data_ptr()
+            if not clip.is_cuda:     # host (pinned) clip: the H2D copy rides the stem stream (see upload() for a deeper pipeline)
+                clip = clip.to(self.stem_device, non_blocking=True)
+            self._wait_upload(clip)
             native, v_sorted, perm = self.extract_features(clip, v_lens_cpu, slot=slot)
             done = torch.cuda.Event()
             done.record(self.stem_stream)
-        self._prefetched = (clip.data_ptr(), native, v_sorted, perm, done, slot)
+        self._prefetched = (key, native, v_sorted, perm, done, slot)
 
     def step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
         if self.trunk_stream is None:
@@ -210,11 +241,14 @@ class Trainer(object):
             main.wait_event(done)
             self._slot = slot
         else:
+            if not clip.is_cuda:
+                clip = clip.to(self.stem_device, non_blocking=True)
+            self._wait_upload(clip)
             native, v_sorted, perm = self.extract_features(clip, v_lens_cpu, slot=self._slot)
         self._prefetched = None
         if next_clip is not None:
             self.prefetch(next_clip, next_v_lens_cpu if next_v_lens_cpu is not None else v_lens_cpu)
-        perm_d = perm.to(clip.device)
+        perm_d = perm.to(self.stem_device)
         self.model.init_hidden()
         logits = self.model(native, q_input[perm_d], v_sorted, q_lens_cpu[perm])
         loss = self.loss_fn(logits, ys[perm_d])
