@@ -108,18 +108,36 @@ def _to_device(Xs, ys, device):
     return clip, q, Xs['v_len'].long().cpu(), Xs['q_len'].long().cpu(), ys.to(device, non_blocking=True)
 
 
+def _staged_batches(args, trainer, data_loader, device):
+    """(index, batch, next_batch) with the clips already being uploaded: the H2D copy of the NEXT minibatch and its
+    frozen stem overlap the current minibatch's trunk pass (Trainer.upload / Trainer.step(next_clip=...))."""
+    def stage(item):
+        i, (Xs, ys) = item
+        clip = Xs['video'].float()
+        clip = trainer.upload(clip.pin_memory() if not clip.is_pinned() else clip)
+        return i, (clip, Xs['question'].to(device, non_blocking=True), Xs['v_len'].long().cpu(),
+                   Xs['q_len'].long().cpu(), ys.to(device, non_blocking=True))
+    full = (it for it in enumerate(data_loader, 0) if len(it[1][1]) >= args.batch_size)     # :86-87 skips short batches
+    cur = next(full, None)
+    cur = stage(cur) if cur is not None else None
+    while cur is not None:
+        nxt = next(full, None)
+        nxt = stage(nxt) if nxt is not None else None
+        yield cur[0], cur[1], (nxt[1] if nxt is not None else None)
+        cur = nxt
+
+
 def train_epoch(epoch, args, trainer, data_loader, device, rank=0):
     """q_and_v_eval.py:73-156 (stem, sort, forward, loss, clip, Adam are inside Trainer.step)."""
     from sklearn.metrics import f1_score
     avg_loss, hit, num_examples = 0.0, 0, 0
     y_pred, y_target = np.array([]), np.array([])
-    for i, (Xs, ys) in enumerate(data_loader, 0):
-        if len(ys) < args.batch_size:                                   # :86-87
-            continue
+    for i, batch, nxt in _staged_batches(args, trainer, data_loader, device):
+        clip, q, v_lens, q_lens, ys = batch
         num_examples += len(ys)
-        clip, q, v_lens, q_lens, ys = _to_device(Xs, ys, device)
         perm = torch.sort(v_lens, dim=0, descending=True, stable=True)[1]
-        loss, logits = trainer.step(clip, q, v_lens, q_lens, ys)
+        ahead = dict(next_clip=nxt[0], next_v_lens_cpu=nxt[2]) if nxt is not None else {}
+        loss, logits = trainer.step(clip, q, v_lens, q_lens, ys, **ahead)
         ys_sorted = ys[perm.to(device)]
         y_target = np.append(y_target, ys_sorted.cpu().numpy())        # :117
         avg_loss += float(loss)
