@@ -216,11 +216,19 @@ def main():
         fwd = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
         cpu_leg = cpu_baseline(fwd)          # child process, before any GPU initialisation here
     import torch.distributed as dist
+    # test hook: VNQA_DIST_BACKEND=gloo VNQA_SINGLE_DEVICE=1 runs N ranks on ONE GPU to exercise the multi-rank
+    # code path where only one GPU exists (never a benchmark configuration)
+    if os.environ.get("VNQA_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("VNQA_DIST_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from videonavqa_amd.train import Trainer
     model, stem, vgg, od = build(args, device)

@@ -70,6 +70,7 @@ class OverlappedGradReducer(object):
     def __init__(self, fp, world_size, loss_reduction="sum", early_numel=1 << 22):
         self.fp, self.world, self.loss_reduction = fp, world_size, loss_reduction
         self.early, self.pending, self.done_ranges = {}, [], []
+        self.enabled = world_size > 1
         off = 0
         for p in fp.params:
             k = p.numel()
@@ -79,13 +80,15 @@ class OverlappedGradReducer(object):
             off += k
 
     def _hook(self, p):
+        if not self.enabled:
+            return
         a, b = self.early[p]
         self.pending.append(dist.all_reduce(self.fp.grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
         self.done_ranges.append((a, b))
 
     def finish(self):
         """Call after backward: reduce what the hooks did not cover, wait for everything."""
-        if self.world <= 1:
+        if self.world <= 1 or not self.enabled:
             return
         cur = 0
         for a, b in sorted(self.done_ranges) + [(self.fp.n, self.fp.n)]:
