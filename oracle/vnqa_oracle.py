@@ -10,7 +10,7 @@ Parity status
 * Pinned against golden vectors captured from the reference itself by
   `tools/capture_goldens.py` (see tests/golden/*.npz, tests/test_oracle_golden.py):
   ObjDetectCNN, FiLMAttnPretrainedStem, FiLMGlobalPoolingPretrainedStem,
-  TimeMultiHopFiLMPretrainedStem, QOnlyLSTM, and the loss/clip/Adam step.
+  TimeMultiHopFiLMPretrainedStem, QOnlyLSTM, VideoOnlyCNN3D, MACNetwork, and the loss/clip/Adam step.
 * `vgg_front` (VGG-16 features[0:10]) restates a THIRD-PARTY dependency that
   is not vendored in the reference (`demo.get_frcnn_feature_extractor`,
   catalina17/faster-rcnn.pytorch, no pinned version; call sites
@@ -375,6 +375,148 @@ def video_only_cnn3d_forward(W, x, training=False):
     h = _bn(F.relu(h @ W["fc6.weight"].t() + W["fc6.bias"]), W, "bn6", training)           # :76-77
     h = _bn(F.relu(h @ W["fc7.weight"].t() + W["fc7.bias"]), W, "bn7", training)           # :78-79
     return h @ W["fc8.weight"].t() + W["fc8.bias"]                                         # :81
+
+
+# --------------------------------------------------------------------------
+# MACNetwork.forward (models/mac.py) — the fourth stem-consuming model of eval/q_and_v_eval.py
+# --------------------------------------------------------------------------
+def _lin(W, name, x):
+    y = x @ W[name + ".weight"].t()
+    return y + W[name + ".bias"] if (name + ".bias") in W else y
+
+
+def _lstm_dir(xg, lens, w_hh, b_hh, reverse):
+    """One direction of a packed nn.LSTM from a zero state.  xg [B,Lmax,4H] (input projection incl. b_ih).
+    Sample b walks t = 0..len-1 (or len-1..0 when reverse); outputs past its length are zero.
+    Returns out [B,Lmax,H] and the state after each sample's last processed step."""
+    B, Lmax, H4 = xg.shape
+    H = H4 // 4
+    h = xg.new_zeros(B, H)
+    c = xg.new_zeros(B, H)
+    outs = [None] * Lmax
+    order = range(Lmax - 1, -1, -1) if reverse else range(Lmax)
+    for t in order:
+        h2, c2 = lstm_cell(xg[:, t], h, c, w_hh, b_hh)
+        m = (lens > t).to(h.dtype).unsqueeze(1)
+        h = m * h2 + (1 - m) * h
+        c = m * c2 + (1 - m) * c
+        outs[t] = m * h2
+    return torch.stack(outs, 1), h
+
+
+def mac_question(W, question, q_lens):
+    """Question side of MACNetwork.forward (models/mac.py:203-221): embed (padding_idx 0) -> sort by
+    length -> packed bidirectional LSTM -> pad -> UNSORT lstm_out only -> lstm_proj.
+    `h` (final hidden of both directions) is returned in the SORTED order, exactly as upstream leaves it
+    (:221 never applies invperm_idx to h) — row s of h belongs to the sample at sorted position s."""
+    emb = F.embedding(question, W["embed.weight"], padding_idx=0)                       # :206
+    lens_sorted, perm = q_lens.sort(0, descending=True)                                 # :208
+    emb = emb[perm]
+    Lmax = int(lens_sorted[0])
+    outs, hs = [], []
+    for sfx, rev in (("", False), ("_reverse", True)):
+        xg = emb[:, :Lmax] @ W["lstm.weight_ih_l0" + sfx].t() + W["lstm.bias_ih_l0" + sfx]
+        o, hN = _lstm_dir(xg, lens_sorted, W["lstm.weight_hh_l0" + sfx], W["lstm.bias_hh_l0" + sfx], rev)
+        outs.append(o)
+        hs.append(hN)
+    lstm_out = torch.cat(outs, 2)                                                       # [B,Lmax,2*dim], zero past len
+    inv = perm.sort(0)[1]                                                               # :217
+    lstm_out = lstm_out[inv]
+    context = _lin(W, "lstm_proj", lstm_out)                                            # :220 (pads become the bias)
+    h = torch.cat(hs, 1)                                                                # :221, sorted order
+    return context, h
+
+
+def mac_unit(W, context, question, know, max_step, self_attention, memory_gate, masks=None):
+    """MACUnit.forward (models/mac.py:131-155) with its Control/Read/Write units (:15-107).
+    context [b,L,dim], question [b,2dim], know [b,dim,S].  masks = (control_mask, memory_mask) reproduces the
+    train-mode variational dropout (:137-141,146-147,152-153); None = no dropout."""
+    b = question.shape[0]
+    dim = W["mac.mem_0"].shape[1]
+    control = W["mac.control_0"].expand(b, dim)
+    memory = W["mac.mem_0"].expand(b, dim)
+    if masks is not None:
+        control = control * masks[0]
+        memory = memory * masks[1]
+    controls, memories = [control], [memory]
+    for i in range(max_step):
+        # ControlUnit (:28-42)
+        pa = _lin(W, "mac.control.position_aware.%d" % i, question)
+        cq = _lin(W, "mac.control.control_question", torch.cat([control, pa], 1)).unsqueeze(1)
+        aw = _lin(W, "mac.control.attn", cq * context)                                  # [b,L,1]
+        control = (F.softmax(aw, 1) * context).sum(1)
+        if masks is not None:
+            control = control * masks[0]
+        controls.append(control)
+        # ReadUnit (:53-62)
+        mem = _lin(W, "mac.read.mem", memories[-1]).unsqueeze(2)                        # [b,dim,1]
+        cc = _lin(W, "mac.read.concat", torch.cat([mem * know, know], 1).permute(0, 2, 1))   # [b,S,dim]
+        ra = _lin(W, "mac.read.attn", cc * controls[-1].unsqueeze(1)).squeeze(2)        # [b,S]
+        ra = F.softmax(ra, 1).unsqueeze(1)
+        read = (ra * know).sum(2)                                                       # [b,dim]
+        # WriteUnit (:82-105)
+        prev = memories[-1]
+        concat = _lin(W, "mac.write.concat", torch.cat([read, prev], 1))
+        nxt = concat
+        if self_attention:
+            ccat = torch.stack(controls[:-1], 2)                                        # [b,dim,i+1]
+            sa = controls[-1].unsqueeze(2) * ccat
+            sa = _lin(W, "mac.write.attn", sa.permute(0, 2, 1))                         # [b,i+1,1]
+            sa = F.softmax(sa, 1).permute(0, 2, 1)
+            mcat = torch.stack(memories, 2)
+            nxt = _lin(W, "mac.write.mem", (sa * mcat).sum(2)) + concat
+        if memory_gate:
+            gate = torch.sigmoid(_lin(W, "mac.write.control", controls[-1]))
+            nxt = gate * prev + (1 - gate) * nxt
+        memory = nxt
+        if masks is not None:
+            memory = memory * masks[1]
+        memories.append(memory)
+    return memory
+
+
+def mac_forward(W, images, question, v_lens, q_lens, max_step, max_num_frames=35, self_attention=False,
+                memory_gate=False, masks=None):
+    """MACNetwork.forward (models/mac.py:199-257).  images [B,512,h,w,T]; v_lens sorted descending.
+    masks: optional list, one (control_mask, memory_mask) pair per processed frame."""
+    B = images.shape[0]
+    dim = W["mac.mem_0"].shape[1]
+    context, h = mac_question(W, question[:B], q_lens)
+    cts = ct_batch_sizes(v_lens, int(v_lens[0]))                                        # :226-233
+    outs = []
+    for i, ct in enumerate(cts):
+        img = images[:ct, :, :, :, i]
+        for k in (0, 2, 4):                                                             # :177-182 conv+ELU x3
+            img = F.elu(F.conv2d(img, W["conv.%d.weight" % k], W["conv.%d.bias" % k], padding=1))
+        know = img.reshape(ct, dim, -1)
+        mem = mac_unit(W, context[:ct], h[:ct], know, max_step, self_attention, memory_gate,
+                       None if masks is None else masks[i])
+        out = torch.cat([mem, h[:ct]], 1)                                               # :240
+        outs.append(F.pad(out, (0, 0, 0, B - ct)).unsqueeze(1))                         # :242-243
+    outs = torch.cat(outs, 1)                                                           # [B,n_frames,3dim]
+    # packed lstm_tail from a zero state, output at each sample's last frame (:249-255); the zero padding
+    # up to max_num_frames (:246-247) is never read by a packed sequence
+    xg = outs @ W["lstm_tail.weight_ih_l0"].t() + W["lstm_tail.bias_ih_l0"]
+    tail, _ = _lstm_dir(xg, v_lens, W["lstm_tail.weight_hh_l0"], W["lstm_tail.bias_hh_l0"], False)
+    last = gather_last(tail, v_lens)
+    y = F.elu(_lin(W, "classifier.0", last))                                            # :187-189
+    return _lin(W, "classifier.2", y)
+
+
+def mac_train_step(W, images, question, v_lens, q_lens, ys, adam, lr, max_step, clip=1.0, grad_clamp=1.0, **kw):
+    """One optimisation step of `--model mac`: per-parameter gradient clamp to [-1,1] by tensor hooks
+    (eval/q_and_v_eval.py:348-351), then clip_grad_norm and Adam (:137-138).  Dropout masks via kw['masks']."""
+    names = [k for k in W if W[k].is_floating_point()]
+    for k in names:
+        W[k] = W[k].detach().requires_grad_(True)
+    logits = mac_forward(W, images, question, v_lens, q_lens, max_step, **kw)
+    loss = cross_entropy_sum(logits, ys)
+    gl = torch.autograd.grad(loss, [W[k] for k in names], allow_unused=True)
+    grads = {k: (None if g is None else g.clamp(-grad_clamp, grad_clamp)) for k, g in zip(names, gl)}
+    for k in names:
+        W[k] = W[k].detach()
+    clip_and_adam(W, grads, adam, lr, clip)
+    return float(loss.detach()), logits.detach(), grads
 
 
 FORWARDS = {"film_attn_pt": film_attn_forward, "film_gp_pt": film_gp_forward,

@@ -72,3 +72,21 @@ def build_product_model(case, precision):
     model = model.cuda()
     model.load_reference_tensors(weights_from(g, "w0"))
     return model, g
+
+
+MAC_CASES = ["mac_plain", "mac_sa_gate"]
+
+
+def mac_case(name):
+    """Golden MAC case -> (g, cfg dict, fp32 weights, inputs) as tools/capture_goldens.py:run_mac_case wrote them."""
+    g = load_golden(name)
+    dim, E, steps, K, V, T, sa, mg = [int(x) for x in g["cfg"]]
+    cfg = dict(dim=dim, embed_hidden=E, max_step=steps, classes=K, n_vocab=V, max_num_frames=T,
+               self_attention=bool(sa), memory_gate=bool(mg))
+    W = {k: v.float() for k, v in weights_from(g, "w0").items()}
+    inputs = (torch.from_numpy(g["v"].astype(np.float32)), torch.from_numpy(g["q"]), torch.from_numpy(g["v_lens"]),
+              torch.from_numpy(g["q_lens"]), torch.from_numpy(g["y"]))
+    n_frames = int(g["v_lens"][0])
+    masks = [(torch.from_numpy(g["drop_mask/%d/control" % i]), torch.from_numpy(g["drop_mask/%d/memory" % i]))
+             for i in range(n_frames)]
+    return g, cfg, W, inputs, masks

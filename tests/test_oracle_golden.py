@@ -130,3 +130,68 @@ def test_video_only_cnn3d_features():
         f = O.video_only_cnn3d_features(W, torch.from_numpy(g["x"]), training=False)
     assert f.shape == g["conv_features"].shape
     assert rel_err(f.numpy(), g["conv_features"]) < 2e-5
+
+
+# ---- MACNetwork (models/mac.py; `--model mac` of eval/q_and_v_eval.py) --------------------------
+from helpers import MAC_CASES, mac_case
+
+
+def _mac_kw(cfg):
+    return dict(max_num_frames=cfg["max_num_frames"], self_attention=cfg["self_attention"],
+                memory_gate=cfg["memory_gate"])
+
+
+@pytest.mark.parametrize("case", MAC_CASES)
+def test_mac_forward_and_gradients(case):
+    g, cfg, W, (v, q, vl, ql, y), masks = mac_case(case)
+    with torch.no_grad():
+        ev = O.mac_forward(W, v, q, vl, ql, cfg["max_step"], **_mac_kw(cfg))
+    assert rel_err(ev.numpy(), g["eval_logits"]) < 2e-5
+    for tag, mk in (("train", None), ("drop", masks)):
+        Wg = {k: t.clone().requires_grad_(True) for k, t in W.items()}
+        logits = O.mac_forward(Wg, v, q, vl, ql, cfg["max_step"], masks=mk, **_mac_kw(cfg))
+        loss = O.cross_entropy_sum(logits, y)
+        names = list(Wg)
+        grads = torch.autograd.grad(loss, [Wg[k] for k in names], allow_unused=True)
+        assert rel_err(logits.detach().numpy(), g[tag + "_logits"]) < 2e-5
+        assert abs(float(loss.detach()) - float(g[tag + "_loss"])) < 1e-4 * max(1.0, abs(float(g[tag + "_loss"])))
+        checked = 0
+        for k, gr in zip(names, grads):
+            if tag + "_grad/" + k not in g:
+                continue
+            ref = g[tag + "_grad/" + k]
+            got = np.zeros_like(ref) if gr is None else gr.numpy()
+            assert np.abs(got - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-6, (tag, k)
+            checked += 1
+        assert checked >= 30
+
+
+def test_mac_question_vector_stays_in_sorted_order():
+    """mac.py:221 leaves `h` in question-length-sorted order while lstm_out is unsorted (:217-218)."""
+    g, cfg, W, (v, q, vl, ql, y), _ = mac_case("mac_plain")
+    assert list(ql) != sorted(ql, reverse=True)
+    ctx, h = O.mac_question(W, q, ql)
+    perm = ql.sort(0, descending=True)[1]
+    ctx_s, h_s = O.mac_question(W, q[perm], ql[perm])      # already sorted: identity permutation
+    assert torch.allclose(h, h_s, atol=1e-6) and torch.allclose(ctx[perm], ctx_s, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", MAC_CASES)
+def test_mac_training_trajectory(case):
+    """clamp hooks (eval/q_and_v_eval.py:348-351) -> clip 1.0 -> Adam, 3 steps."""
+    g, cfg, W, (v, q, vl, ql, y), _ = mac_case(case)
+    adam = O.AdamState(list(W))
+    losses = []
+    for _ in range(len(g["traj_losses"])):
+        loss, _, _ = O.mac_train_step(W, v, q, vl, ql, y, adam, float(g["traj_lr"]), cfg["max_step"], **_mac_kw(cfg))
+        losses.append(loss)
+    assert np.allclose(losses, g["traj_losses"], rtol=2e-4, atol=1e-4)
+    with torch.no_grad():
+        logits = O.mac_forward(W, v, q, vl, ql, cfg["max_step"], **_mac_kw(cfg))
+    assert rel_err(logits.numpy(), g["traj_final_eval_logits"]) < 5e-4
+    travel = float(g["traj_lr"]) * len(g["traj_losses"])
+    for k, ref in weights_from(g, "w_final").items():
+        d = np.abs(W[k].numpy() - ref.numpy())
+        assert d.max() <= 0.5 * travel + 1e-7, k
+        if d.size >= 32:
+            assert np.quantile(d, 0.9) <= 2e-2 * travel + 1e-7, k

@@ -267,14 +267,100 @@ def run_qonly_case(out_dir, name, seed):
         torch.Tensor.cuda = orig
 
 
+def run_mac_case(out_dir, name, seed, v_lens, q_lens, self_attention, memory_gate, train_steps=3, lr=1e-3):
+    """MACNetwork (models/mac.py): eval forward, train forward/backward without dropout and with
+    injected dropout masks, and a clamp+clip+Adam trajectory restating eval/q_and_v_eval.py:136-139,348-351."""
+    from models.mac import MACNetwork
+    torch.manual_seed(0)
+    B, dim, E, steps, K, V, T, L, h, w = 3, 16, 12, 3, 7, 20, 6, 9, 4, 5
+    model = MACNetwork(n_vocab=V, dim=dim, embed_hidden=E, max_step=steps, self_attention=self_attention,
+                       memory_gate=memory_gate, classes=K, max_num_frames=T)
+    seeded_fill(model, seed)
+    rng = np.random.RandomState(seed + 1)
+    v, q, vl, ql, y = make_inputs(rng, B, 512, h, w, T, L, V, K, v_lens, q_lens)
+    # the 512-channel tensors are stored as float16 in the fixture: run the reference on exactly those values
+    v = v.astype(np.float16).astype(np.float32)
+    with torch.no_grad():
+        model.conv[0].weight.copy_(model.conv[0].weight.half().float())
+    tv, tq, tvl, tql, ty = map(torch.from_numpy, (v, q, vl, ql, y))
+    rec = {"v": v.astype(np.float16), "q": q, "v_lens": vl, "q_lens": ql, "y": y,
+           "cfg": np.asarray([dim, E, steps, K, V, T, int(self_attention), int(memory_gate)], np.int64)}
+    for k, t in model.state_dict().items():
+        a = t.detach().numpy().copy()
+        rec["w0/" + k] = a.astype(np.float16) if k == "conv.0.weight" else a
+    loss_fn = nn.CrossEntropyLoss(reduction="sum")
+
+    model.eval()
+    with torch.no_grad():
+        rec["eval_logits"] = model(tv, tq, tvl, tql).numpy().copy()
+
+    def fwd_bwd(tag):
+        for p in model.parameters():
+            p.grad = None
+        logits = model(tv, tq, tvl, tql)
+        loss = loss_fn(logits, ty)
+        loss.backward()
+        rec[tag + "_logits"] = logits.detach().numpy().copy()
+        rec[tag + "_loss"] = np.float32(loss.item())
+        for k, p in model.named_parameters():
+            if tag == "drop" and k == "conv.0.weight":
+                continue          # keeps the fixture small; the no-dropout pass pins this gradient
+            rec[tag + "_grad/" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+
+    model.train()
+    model.mac.dropout = 0.0          # bernoulli_(1)/1: exact all-ones masks (mac.py:125-129)
+    fwd_bwd("train")
+
+    # variational-dropout path with KNOWN masks: replace get_mask on the INSTANCE (no reference file touched)
+    n_frames = int(vl[0])
+    cts = [int((vl >= i + 1).sum()) for i in range(n_frames)]
+    keep = 0.85
+    masks = [(rng.rand(ct, dim) < keep).astype(np.float32) / keep for ct in cts for _ in range(2)]
+    it = iter(masks)
+    model.mac.get_mask = lambda x, dropout: torch.from_numpy(next(it))
+    fwd_bwd("drop")
+    for i in range(n_frames):
+        rec["drop_mask/%d/control" % i] = masks[2 * i]
+        rec["drop_mask/%d/memory" % i] = masks[2 * i + 1]
+    del model.mac.get_mask
+
+    # trajectory: per-parameter clamp hooks (:348-351), clip_grad_norm 1.0, Adam
+    for p in model.parameters():
+        p.grad = None
+        p.register_hook(lambda grad: torch.clamp(grad, -1.0, 1.0))
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    losses = []
+    for step in range(train_steps):
+        logits = model(tv, tq, tvl, tql)
+        loss = loss_fn(logits, ty)
+        losses.append(np.float32(loss.item()))
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad()
+    rec["traj_lr"] = np.float32(lr)
+    rec["traj_losses"] = np.asarray(losses, np.float32)
+    model.eval()
+    with torch.no_grad():
+        rec["traj_final_eval_logits"] = model(tv, tq, tvl, tql).numpy().copy()
+    for k, t in model.state_dict().items():
+        rec["w_final/" + k] = t.detach().numpy().copy()
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **rec)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="", help="comma-separated case-name prefixes (default: all)")
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
     sys.path.insert(0, REF)
     torch.set_num_threads(1)  # bit-stable captures
+    if args.only == "mac":
+        return run_mac_only(out_dir)
 
     from models.film_attn_pt_stem import FiLMAttnPretrainedStem
     from models.film_global_pooling_pt_stem import FiLMGlobalPoolingPretrainedStem
@@ -315,6 +401,15 @@ def main():
     run_objdet_case(out_dir, "objdet_f16", num_filters=16, N=2, H=16, W=24, seed=41)
     run_cnn3d_case(out_dir, "cnn3d_small", seed=51)
     run_qonly_case(out_dir, "qonly_small", seed=61)
+    run_mac_only(out_dir)
+
+
+def run_mac_only(out_dir):
+    # unsorted question lengths: upstream leaves `h` in length-sorted order (mac.py:221) — pinned here
+    run_mac_case(out_dir, "mac_plain", seed=71, v_lens=[5, 4, 2], q_lens=[4, 9, 6], self_attention=False,
+                 memory_gate=False)
+    run_mac_case(out_dir, "mac_sa_gate", seed=72, v_lens=[6, 6, 3], q_lens=[7, 7, 3], self_attention=True,
+                 memory_gate=True)
 
 
 if __name__ == "__main__":

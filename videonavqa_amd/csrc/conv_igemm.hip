@@ -78,9 +78,12 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
 // Rejected experiment, kept for A/B: non-temporal (aux = 2) weight-tile DMA measured -8 % on conv12/conv22
 // (every CU re-reads the weight tiles from L2; nt gives that reuse up).
 #ifdef VNQA_NT_WEIGHTS
-__device__ __forceinline__ void glds16w_(const char* src, char* lds_wave_base) {   // non-temporal
+#ifndef VNQA_W_AUX
+#define VNQA_W_AUX 2
+#endif
+__device__ __forceinline__ void glds16w_(const char* src, char* lds_wave_base) {   // cache-policy experiment
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, VNQA_W_AUX);
 }
 #else
 #define glds16w_ glds16
