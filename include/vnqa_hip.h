@@ -235,6 +235,29 @@ int vnqa_lstm_seq_bwd(const float* w_hh, const int32_t* q_lens, const float* c0,
                       const float* dhs, const float* dhN, const float* dcN, float* dgates, float* dh0,
                       float* dc0, int32_t b, int32_t hidden, int32_t s, int32_t n_rep, void* stream);
 
+/* Packed-sequence LSTM with a WIDE hidden state, one launch per time step (all enqueued by this call).
+ * Replaces nn.LSTM(embed_hidden, dim, bidirectional=True) and nn.LSTM(3*dim, 3*dim) of MACNetwork
+ * (models/mac.py:185-186,193 run at :210-213 and :249-251 on pack_padded_sequence inputs).
+ *   xg     : fp32 [t][b][4*hidden] time-major input projection (x W_ih^T + b_ih + b_hh), gates i,f,g,o
+ *   w_hh   : fp32 [4*hidden][hidden];  w_hh_t (backward): its transpose [hidden][4*hidden]
+ *   h0, c0 : fp32 [b][hidden] initial state of every sample at ITS first step, or NULL for zeros
+ *   batch_sizes_host : HOST int32 [t], batch_sizes[i] = #samples with length > i (samples sorted by
+ *                      length descending; positive, <= b, non-increasing) — PackedSequence.batch_sizes
+ *   hs, cs : fp32 [t][b][hidden] h / c after each step;  gates : fp32 [t][b][4*hidden] activated gates.
+ *            Rows of inactive (step, sample) pairs are not written: pass zero-filled buffers.
+ *   reverse: 0 = walk steps 0..t-1; 1 = walk t-1..0 (second direction of a bidirectional LSTM).
+ * backward: dhs = gradient on every step's h (zero where unused); dc_work fp32 [b][hidden] ZEROED scratch;
+ *   dgates fp32 [t][b][4*hidden] (pass zero-filled) = gradient w.r.t. the gate pre-activations = d xg; the
+ *   caller forms dW_hh = sum_t dgates_t^T h_pred(t) with vnqa_gemm_tn.  No gradient is produced for h0/c0.
+ * hidden must be a multiple of 4.  Exact fp32.
+ */
+int vnqa_lstm_wide_fwd(const float* xg, const float* w_hh, const float* h0, const float* c0,
+                       const int32_t* batch_sizes_host, float* hs, float* cs, float* gates, int32_t t,
+                       int32_t b, int32_t hidden, int32_t reverse, void* stream);
+int vnqa_lstm_wide_bwd(const float* w_hh_t, const float* c0, const int32_t* batch_sizes_host,
+                       const float* gates, const float* cs, const float* dhs, float* dgates,
+                       float* dc_work, int32_t t, int32_t b, int32_t hidden, int32_t reverse, void* stream);
+
 /* Fused global-norm clip + Adam + zero_grad over flat fp32 buffers.
  * Replaces clip_grad_norm(model.parameters(), clip); optimizer.step(); optimizer.zero_grad()
  * (eval/q_and_v_eval.py:137-139, torch.optim.Adam defaults betas .9/.999 eps 1e-8).

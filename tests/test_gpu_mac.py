@@ -1,0 +1,171 @@
+"""GPU parity: the wide packed LSTM kernels and MACNetwork (HIP path) vs the reference goldens / oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import MAC_CASES, mac_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _packed_reference(lstm, x_sorted, lens):
+    """torch.nn.LSTM on a packed batch (CPU fp32) -> padded output [B,Lmax,dirs*H] with grads enabled."""
+    packed = nn.utils.rnn.pack_padded_sequence(x_sorted, lens, batch_first=True)
+    out, _ = lstm(packed)
+    return nn.utils.rnn.pad_packed_sequence(out, batch_first=True)[0]
+
+
+@pytest.mark.parametrize("B,E,H,lens", [(5, 12, 16, [9, 7, 7, 3, 1]), (11, 20, 48, [6, 6, 5, 5, 5, 4, 3, 3, 2, 1, 1]),
+                                        (3, 300, 512, [13, 9, 4])])
+def test_lstm_wide_matches_torch_packed_bidirectional(B, E, H, lens):
+    """ops.lstm_wide (both directions) vs nn.LSTM(bidirectional) on pack_padded_sequence input:
+    outputs and gradients w.r.t. input projection weights, recurrent weights and inputs."""
+    from videonavqa_amd import ops
+    torch.manual_seed(3)
+    lstm = nn.LSTM(E, H, batch_first=True, bidirectional=True)
+    Lmax = lens[0]
+    x = torch.randn(B, Lmax, E)
+    for b, l in enumerate(lens):
+        x[b, l:] = 0
+    x.requires_grad_(True)
+    ref = _packed_reference(lstm, x, torch.tensor(lens))
+    gout = torch.randn_like(ref)
+    for b, l in enumerate(lens):
+        gout[b, l:] = 0          # padded positions carry no gradient upstream either
+    ref.backward(gout)
+
+    dev = torch.device("cuda")
+    xd = x.detach().to(dev).requires_grad_(True)
+    bsz = ops.packed_batch_sizes(lens)
+    outs, params = [], []
+    for sfx, rev in (("", False), ("_reverse", True)):
+        w_ih = getattr(lstm, "weight_ih_l0" + sfx).detach().to(dev).requires_grad_(True)
+        w_hh = getattr(lstm, "weight_hh_l0" + sfx).detach().to(dev).requires_grad_(True)
+        bias = (getattr(lstm, "bias_ih_l0" + sfx) + getattr(lstm, "bias_hh_l0" + sfx)).detach().to(dev).requires_grad_(True)
+        xg = torch.nn.functional.linear(xd, w_ih, bias).transpose(0, 1).contiguous()
+        outs.append(ops.lstm_wide(xg, w_hh, bsz, rev))
+        params.append((sfx, w_ih, w_hh, bias))
+    got = torch.cat(outs, 2).transpose(0, 1)
+    got.backward(gout.to(dev))
+    assert rel_err(got.detach().cpu().numpy(), ref.detach().numpy()) < 2e-5
+    assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 2e-4
+    for sfx, w_ih, w_hh, bias in params:
+        assert rel_err(w_ih.grad.cpu().numpy(), getattr(lstm, "weight_ih_l0" + sfx).grad.numpy()) < 2e-4, sfx
+        assert rel_err(w_hh.grad.cpu().numpy(), getattr(lstm, "weight_hh_l0" + sfx).grad.numpy()) < 2e-4, sfx
+        assert rel_err(bias.grad.cpu().numpy(), getattr(lstm, "bias_ih_l0" + sfx).grad.numpy()) < 2e-4, sfx
+
+
+def test_lstm_wide_rejects_bad_batch_sizes():
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd._lib import VnqaError
+    xg = torch.zeros(3, 2, 64, device="cuda")
+    w = torch.zeros(64, 16, device="cuda")
+    with pytest.raises(VnqaError):
+        K.lstm_wide_fwd(xg, w, [1, 2, 1])      # increasing
+    with pytest.raises(VnqaError):
+        K.lstm_wide_fwd(xg, w, [3, 2, 1])      # larger than the batch
+
+
+def _product(case, precision):
+    import videonavqa_amd.models as M
+    g, cfg, W, inputs, masks = mac_case(case)
+    model = M.MACNetwork(precision=precision, **cfg).cuda()
+    model.load_reference_tensors(W)
+    dev = torch.device("cuda")
+    v, q, vl, ql, y = inputs
+    return model, g, (v.to(dev), q.to(dev), vl, ql, y.to(dev)), masks
+
+
+@pytest.mark.parametrize("case", MAC_CASES)
+def test_mac_eval_logits_fp32(case):
+    model, g, (v, q, vl, ql, y), _ = _product(case, "fp32")
+    model.eval()
+    with torch.no_grad():
+        out = model(v, q, vl, ql)
+    assert rel_err(out.cpu().numpy(), g["eval_logits"]) < 1e-3
+    assert rel_err(out.cpu().numpy(), g["eval_logits"]) < 5e-5   # exact-f32 path: far inside the north-star bound
+
+
+@pytest.mark.parametrize("case", MAC_CASES)
+@pytest.mark.parametrize("tag", ["train", "drop"])
+def test_mac_train_forward_backward_fp32(case, tag):
+    """Train-mode logits, loss and every parameter gradient vs the reference; `drop` injects the variational
+    dropout masks the golden run used (one pair per frame, concatenated in packed-image order)."""
+    model, g, (v, q, vl, ql, y), masks = _product(case, "fp32")
+    model.train()
+    if tag == "drop":
+        model.dropout_masks = (torch.cat([m[0] for m in masks]).cuda(), torch.cat([m[1] for m in masks]).cuda())
+    else:
+        model.mac.dropout = 0.0
+    logits = model(v, q, vl, ql)
+    loss = nn.functional.cross_entropy(logits, y, reduction="sum")
+    loss.backward()
+    assert rel_err(logits.detach().cpu().numpy(), g[tag + "_logits"]) < 5e-5
+    assert abs(float(loss.detach()) - float(g[tag + "_loss"])) < 1e-4 * max(1.0, abs(float(g[tag + "_loss"])))
+    checked = 0
+    for k, p in model.named_parameters():
+        key = tag + "_grad/" + k
+        if key not in g:
+            continue
+        ref = g[key]
+        got = np.zeros_like(ref) if p.grad is None else p.grad.cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 2e-6, (k, np.abs(got - ref).max(), np.abs(ref).max())
+        checked += 1
+    assert checked >= 30
+
+
+@pytest.mark.parametrize("case", MAC_CASES)
+def test_mac_bf16_close_to_reference(case):
+    model, g, (v, q, vl, ql, y), _ = _product(case, "bf16")
+    model.eval()
+    with torch.no_grad():
+        out = model(v, q, vl, ql)
+    assert rel_err(out.cpu().numpy(), g["eval_logits"]) < 3e-2
+
+
+def test_mac_random_dropout_masks_are_variational():
+    """Without injected masks, train mode draws ONE Bernoulli(1-p)/(1-p) mask pair per packed image and reuses it at
+    every reasoning step (mac.py:137-153)."""
+    model, g, (v, q, vl, ql, y), _ = _product("mac_plain", "fp32")
+    model.train()
+    torch.manual_seed(0)
+    m = model._masks(64, v.device)
+    vals = torch.unique(torch.cat([m[0].flatten(), m[1].flatten()])).cpu().numpy()
+    assert all(min(abs(float(x)), abs(float(x) - 1 / 0.85)) < 1e-5 for x in vals)
+    assert 0.7 < float((m[0] > 0).float().mean()) < 0.95
+    a = model(v, q, vl, ql)
+    b = model(v, q, vl, ql)
+    assert not torch.allclose(a, b)          # fresh masks every forward
+    model.eval()
+    assert model._masks(4, v.device) is None
+
+
+@pytest.mark.parametrize("case", MAC_CASES)
+def test_mac_trainer_trajectory(case):
+    """Trainer (flat buffers, gradient clamp [-1,1] -> fused clip + Adam) vs the reference's 3-step trajectory."""
+    from videonavqa_amd.models.common import FrameLayout, NativeFeatures
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd.train import Trainer
+    model, g, (v, q, vl, ql, y), _ = _product(case, "fp32")
+    model.mac.dropout = 0.0
+    trainer = Trainer(model, stem=None, lr=float(g["traj_lr"]), clip=1.0, feature_channels=512)
+    lay = FrameLayout(vl, v.shape[-1], v.device)
+    native = NativeFeatures(K.feat_to_nhwc(v, lay.img_of, lay.n_img, torch.float32), lay, 512, v.shape[2], v.shape[3])
+    trainer.extract_features = lambda clip, v_lens_cpu, slot=0: (native, vl, torch.arange(len(vl)))
+    losses = []
+    for _ in range(len(g["traj_losses"])):
+        loss, _ = trainer.step(v, q, vl, ql, y)
+        losses.append(float(loss))
+    assert np.allclose(losses, g["traj_losses"], rtol=1e-3, atol=1e-3), (losses, g["traj_losses"])
+    model.eval()
+    with torch.no_grad():
+        out = model(v, q, vl, ql)
+    assert rel_err(out.cpu().numpy(), g["traj_final_eval_logits"]) < 2e-3
+    travel = float(g["traj_lr"]) * len(g["traj_losses"])
+    sd = model.state_dict()
+    for k in sd:
+        d = np.abs(sd[k].cpu().numpy() - g["w_final/" + k].astype(np.float32))
+        assert d.max() <= 0.7 * travel + 1e-7, k
+        if d.size >= 32:
+            assert np.quantile(d, 0.9) <= 5e-2 * travel + 1e-7, k

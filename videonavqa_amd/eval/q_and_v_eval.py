@@ -1,7 +1,7 @@
 """Counterpart of eval/q_and_v_eval.py: train / validate the video+question FiLM models on MI355X.
 
 Same command-line flags and defaults as the reference (eval/q_and_v_eval.py:29-64) for the three models
-on the hot path (`--model film_attn_pt | film_gp_pt | time_multi_hop`), same train_epoch / val_epoch
+on the hot path (`--model film_attn_pt | film_gp_pt | time_multi_hop | mac`), same train_epoch / val_epoch
 flow, printed line formats and checkpoint schema (`e{epoch}_{checkpoint_path}`, keys epoch / model /
 state_dict / train_f1w / train_f1micro / optimizer).  Additions (all optional):
   --synthetic N        N seeded synthetic items per split instead of ../data (no dataset on the box)
@@ -31,8 +31,8 @@ def str2bool(v):
 
 def build_parser():
     parser = argparse.ArgumentParser()
-    # Model args (q_and_v_eval.py:32-38); the off-path baselines (concat2d/concat3d/mac) are not built
-    parser.add_argument('--model', type=str, choices=['film_gp_pt', 'film_attn_pt', 'time_multi_hop'],
+    # Model args (q_and_v_eval.py:32-38); the off-path raw-video baselines (concat2d/concat3d) are not built
+    parser.add_argument('--model', type=str, choices=['film_gp_pt', 'film_attn_pt', 'mac', 'time_multi_hop'],
                         required=True)
     parser.add_argument('--num_classes', type=int, default=70)
     parser.add_argument('--q_encoder', type=str, choices=['lstm', 'bow'], default='lstm')
@@ -73,9 +73,12 @@ def build_parser():
 
 def build_model(args, spatial_size):
     """Model factory of q_and_v_eval.py:255-303."""
-    from ..models import (FiLMAttnPretrainedStem, FiLMGlobalPoolingPretrainedStem,
+    from ..models import (FiLMAttnPretrainedStem, FiLMGlobalPoolingPretrainedStem, MACNetwork,
                           TimeMultiHopFiLMPretrainedStem)
     extra = dict(spatial_size=spatial_size, precision=args.precision)
+    if args.model == 'mac':                                             # :288-293
+        return MACNetwork(n_vocab=args.vocab_size, dim=args.mac_dim, embed_hidden=args.embed_size,
+                          max_step=args.mac_max_step, classes=args.num_classes, precision=args.precision)
     if args.model == 'film_attn_pt':
         return FiLMAttnPretrainedStem(batch_size=args.batch_size, q_embedding_size=args.embed_size,
                                       nb_classes=args.num_classes, q_encoder=args.q_encoder,
@@ -174,7 +177,8 @@ def val_epoch(args, trainer, data_loader, device, rank=0):
             clip, q, v_lens, q_lens, ys = _to_device(Xs, ys, device)
             native, v_sorted, perm = trainer.extract_features(clip, v_lens)
             perm_d = perm.to(device)
-            model.init_hidden()
+            if args.model != 'mac':                                     # :204-205
+                model.init_hidden()
             output = model(native, q[perm_d], v_sorted, q_lens[perm])
             ys_sorted = ys[perm_d]
             y_target = np.append(y_target, ys_sorted.cpu().numpy())
@@ -271,6 +275,10 @@ def main(argv=None):
             tr_sampler.set_epoch(epoch)
         if not args.val_only:
             train_epoch(epoch, args, trainer, train_loader, device, rank)
+        if args.model == 'mac':                                         # :357-363, as upstream: AFTER epoch 0 the
+            trainer.lr = args.l_rate / 10. if epoch == 0 else args.l_rate   # rate drops to l_rate/10 for one epoch
+            if rank == 0:
+                print('learning rate %.5f' % trainer.lr)
         val_epoch(args, trainer, val_loader, device, rank)
     if world > 1:
         dist.destroy_process_group()

@@ -49,7 +49,8 @@ def test(args, model, trainer, data_loader, loss_fn, device):
             ys_s, qid_s = ys[perm_d], q_ids[perm]
             y_target = np.append(y_target, ys_s[:num_real].cpu().numpy())                   # :117-118
             qs = np.append(qs, qid_s[:num_real].cpu().numpy())
-            model.init_hidden()
+            if args.model != 'mac':                                                         # :121-122
+                model.init_hidden()
             output = model(native, q[perm_d], v_sorted, q_lens[perm])[:num_real]            # :122-123
             ys_s = ys_s[:num_real]
             test_loss += float(loss_fn(output, ys_s))

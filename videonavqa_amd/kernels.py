@@ -238,6 +238,34 @@ def lstm_seq_bwd(w_hh, q_lens_i32, c0, gates, dhs, dhN, dcN, n_rep):
     return dgates, dh0, dc0
 
 
+def lstm_wide_fwd(xg, w_hh, batch_sizes, reverse=False, h0=None, c0=None):
+    """Step-wise packed LSTM for wide hidden states.  xg fp32 [T,B,4H] time-major, batch_sizes a host int
+    sequence (PackedSequence.batch_sizes).  Returns hs, cs [T,B,H] and gates [T,B,4H] (zero on inactive rows)."""
+    T, B, H4 = xg.shape
+    H = H4 // 4
+    dev = xg.device
+    bs = (ctypes.c_int32 * T)(*[int(v) for v in batch_sizes])
+    hs = torch.zeros((T, B, H), dtype=torch.float32, device=dev)
+    cs = torch.zeros((T, B, H), dtype=torch.float32, device=dev)
+    gates = torch.zeros((T, B, H4), dtype=torch.float32, device=dev)
+    L.check(L.lib().vnqa_lstm_wide_fwd(L.ptr(xg), L.ptr(w_hh), L.ptr(h0), L.ptr(c0), bs, L.ptr(hs), L.ptr(cs),
+                                       L.ptr(gates), T, B, H, 1 if reverse else 0, L.stream()), "vnqa_lstm_wide_fwd")
+    return hs, cs, gates
+
+
+def lstm_wide_bwd(w_hh_t, batch_sizes, gates, cs, dhs, reverse=False, c0=None):
+    """BPTT of lstm_wide_fwd.  Returns dgates [T,B,4H] (= d xg)."""
+    T, B, H = cs.shape
+    dev = cs.device
+    bs = (ctypes.c_int32 * T)(*[int(v) for v in batch_sizes])
+    dgates = torch.zeros((T, B, 4 * H), dtype=torch.float32, device=dev)
+    dc = torch.zeros((B, H), dtype=torch.float32, device=dev)
+    L.check(L.lib().vnqa_lstm_wide_bwd(L.ptr(w_hh_t), L.ptr(c0), bs, L.ptr(gates), L.ptr(cs), L.ptr(dhs),
+                                       L.ptr(dgates), L.ptr(dc), T, B, H, 1 if reverse else 0, L.stream()),
+            "vnqa_lstm_wide_bwd")
+    return dgates
+
+
 def frame_bn_stats(x, frame_off_i32, n_frames):
     N, hp, wp, c = x.shape
     mean = torch.empty((n_frames, c), dtype=torch.float32, device=x.device)

@@ -6,6 +6,7 @@ from .time_multi_hop_pt_stem import TimeMultiHopFiLMPretrainedStem
 from .obj_detector import ObjDetectCNN
 from .q_only_lstm import QOnlyLSTM
 from .v_only_cnn3d import VideoOnlyCNN3D
+from .mac import MACNetwork
 
 __all__ = ["FiLMAttnPretrainedStem", "FiLMGlobalPoolingPretrainedStem",
-           "TimeMultiHopFiLMPretrainedStem", "ObjDetectCNN", "QOnlyLSTM", "VideoOnlyCNN3D"]
+           "TimeMultiHopFiLMPretrainedStem", "ObjDetectCNN", "QOnlyLSTM", "VideoOnlyCNN3D", "MACNetwork"]

@@ -1,0 +1,231 @@
+"""MACNetwork — drop-in for models/mac.py of the reference (`--model mac`, eval/q_and_v_eval.py:288-293).
+
+Same constructor signature, parameter names (state_dict keys) and forward() contract.  What differs is
+how the work is laid out for the MI355X:
+
+  * the reference runs conv stack + MAC cell chain once PER FRAME (mac.py:226-243).  Frames are
+    independent given the question encoding, so all valid (sample, frame) pairs of the minibatch form one
+    packed image list and the `max_step` reasoning steps run ONCE over that list;
+  * the three 3x3 convs run on the MFMA implicit-GEMM kernels (ops.conv) in padded NHWC;
+  * ReadUnit (mac.py:53-62) applies a dim*2 -> dim Linear to [mem*know ; know] at every position and
+    every step.  The score it feeds is linear in that projection, so it is re-associated:
+        score[n,s] = know[n,s,:] . (mem[n] * (W1^T v[n])) + (know W2^T + b)[n,s,:] . v[n] + b_attn,
+        v = control * w_attn, [W1 | W2] = concat.weight,
+    leaving ONE position-wise GEMM per forward (know W2^T, step-invariant) instead of max_step of twice
+    the size; the per-step work is three batched mat-vecs over the knowledge base;
+  * both nn.LSTMs (bidirectional question encoder, 3*dim tail) run on the step-wise wide-LSTM HIP
+    kernels (ops.lstm_wide) directly on PackedSequence batch sizes.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib as L
+from .. import kernels as K
+from .. import ops
+from .common import FrameLayout, NativeFeatures, compute_dtype
+
+
+def _xavier_linear(n_in, n_out):
+    """mac.py:7-13: Xavier-uniform weight, zero bias."""
+    lin = nn.Linear(n_in, n_out)
+    nn.init.xavier_uniform_(lin.weight)
+    nn.init.zeros_(lin.bias)
+    return lin
+
+
+class _Unit(nn.Module):
+    """Parameter holder; compute lives in MACNetwork._reason."""
+
+
+def _control_unit(dim, max_step):        # mac.py:16-26
+    u = _Unit()
+    u.position_aware = nn.ModuleList([_xavier_linear(2 * dim, dim) for _ in range(max_step)])
+    u.control_question = _xavier_linear(2 * dim, dim)
+    u.attn = _xavier_linear(dim, 1)
+    return u
+
+
+def _read_unit(dim):                     # mac.py:46-51
+    u = _Unit()
+    u.mem = _xavier_linear(dim, dim)
+    u.concat = _xavier_linear(2 * dim, dim)
+    u.attn = _xavier_linear(dim, 1)
+    return u
+
+
+def _write_unit(dim, self_attention, memory_gate):   # mac.py:66-80
+    u = _Unit()
+    u.concat = _xavier_linear(2 * dim, dim)
+    if self_attention:
+        u.attn = _xavier_linear(dim, 1)
+        u.mem = _xavier_linear(dim, dim)
+    if memory_gate:
+        u.control = _xavier_linear(dim, 1)
+    return u
+
+
+class MACNetwork(nn.Module):
+    """Positional signature and defaults of mac.py:169-171; keyword-only extras: precision."""
+
+    def __init__(self, n_vocab, dim, embed_hidden=300, max_step=12, self_attention=False, memory_gate=False,
+                 classes=28, dropout=0.15, max_num_frames=35, *, precision='bf16'):
+        super(MACNetwork, self).__init__()
+        self.compute_dtype = compute_dtype(precision)
+        self.conv = nn.Sequential(nn.Conv2d(512, dim, 3, padding=1), nn.ELU(),      # mac.py:174-179
+                                  nn.Conv2d(dim, dim, 3, padding=1), nn.ELU(),
+                                  nn.Conv2d(dim, dim, 3, padding=1), nn.ELU())
+        self.embed = nn.Embedding(n_vocab, embed_hidden, padding_idx=0)
+        self.lstm = nn.LSTM(embed_hidden, dim, batch_first=True, bidirectional=True)
+        self.lstm_proj = nn.Linear(dim * 2, dim)
+        mac = _Unit()
+        mac.control = _control_unit(dim, max_step)
+        mac.read = _read_unit(dim)
+        mac.write = _write_unit(dim, self_attention, memory_gate)
+        mac.mem_0 = nn.Parameter(torch.zeros(1, dim))
+        mac.control_0 = nn.Parameter(torch.zeros(1, dim))
+        self.mac = mac
+        self.lstm_tail = nn.LSTM(dim * 3, dim * 3)
+        self.classifier = nn.Sequential(_xavier_linear(dim * 3, dim * 2), nn.ELU(), _xavier_linear(dim * 2, classes))
+        self.max_step, self.dim, self.max_num_frames = max_step, dim, max_num_frames
+        self.self_attention, self.memory_gate = self_attention, memory_gate
+        mac.dropout = dropout       # where upstream keeps it (MACUnit.dropout, mac.py:123)
+        self.grad_clamp = 1.0        # eval/q_and_v_eval.py:348-351 (read by train.Trainer)
+        self.dropout_masks = None    # tests: (control_mask [n_img,dim], memory_mask [n_img,dim]) instead of bernoulli
+        self.reset()
+
+    def reset(self):
+        """mac.py:199-207: embedding U(0,1) (padding row included), He-uniform on the FIRST TWO convs and the
+        first classifier layer; the third conv and lstm_proj keep PyTorch's defaults."""
+        with torch.no_grad():
+            self.embed.weight.uniform_(0, 1)
+            for k in (0, 2):
+                nn.init.kaiming_uniform_(self.conv[k].weight)
+                self.conv[k].bias.zero_()
+            nn.init.kaiming_uniform_(self.classifier[0].weight)
+
+    def extra_state_tensors(self):
+        return {}
+
+    def load_reference_tensors(self, tensors):
+        own = self.state_dict()
+        with torch.no_grad():
+            for k, v in tensors.items():
+                own[k].copy_(torch.as_tensor(v).to(own[k].device).view_as(own[k]))
+
+    # ---- question side (mac.py:203-221) ------------------------------------------------------------
+    def _encode_question(self, question, q_lens, B, dev):
+        ql = q_lens.detach().cpu().long()
+        lens_sorted, perm = torch.sort(ql, dim=0, descending=True, stable=True)
+        perm_d = perm.to(dev)
+        Lmax = int(lens_sorted[0])
+        emb = F.embedding(question[:B], self.embed.weight, padding_idx=0)[perm_d][:, :Lmax]
+        bsz = ops.packed_batch_sizes(lens_sorted)
+        H = self.dim
+        outs, finals = [], []
+        for sfx, rev in (("", False), ("_reverse", True)):
+            w_ih, w_hh = getattr(self.lstm, "weight_ih_l0" + sfx), getattr(self.lstm, "weight_hh_l0" + sfx)
+            bias = getattr(self.lstm, "bias_ih_l0" + sfx) + getattr(self.lstm, "bias_hh_l0" + sfx)
+            xg = F.linear(emb, w_ih, bias).transpose(0, 1).contiguous()          # [Lmax,B,4H]
+            hs = ops.lstm_wide(xg, w_hh, bsz, rev)                                # [Lmax,B,H]
+            outs.append(hs)
+            finals.append(hs[0] if rev else hs[(lens_sorted - 1).to(dev), torch.arange(B, device=dev)])
+        lstm_out = torch.cat(outs, 2).transpose(0, 1)                             # [B,Lmax,2H] sorted order
+        inv = torch.sort(perm, dim=0)[1].to(dev)
+        context = self.lstm_proj(lstm_out[inv])                                   # :217-220 (pad rows -> bias)
+        hq = torch.cat(finals, 1)                                                 # :221: stays in SORTED order
+        return context, hq
+
+    # ---- image side ----------------------------------------------------------------------------------
+    def _prepare_input(self, images, v_lens):
+        if isinstance(images, NativeFeatures):
+            assert images.data.dtype == self.compute_dtype
+            return images.data, images.layout, images.h, images.w
+        assert images.is_cuda, "the HIP path needs device tensors (no CPU fallback)"
+        B, C, h, w, T = images.shape
+        lay = FrameLayout(v_lens, T, images.device)
+        return K.feat_to_nhwc(images, lay.img_of, lay.n_img, self.compute_dtype), lay, h, w
+
+    def _knowledge(self, x):
+        """conv -> ELU three times (mac.py:174-179,236); returns the dense interior [n_img*S, c_pad]."""
+        for k in (0, 2, 4):
+            x = F.elu(ops.conv(x, self.conv[k].weight, self.conv[k].bias, relu=False))   # elu(0)=0 keeps the halo
+        n_img, hp, wp, c_pad = x.shape
+        return x[:, 1:-1, 1:-1, :].reshape(n_img * (hp - 2) * (wp - 2), c_pad), n_img, (hp - 2) * (wp - 2), c_pad
+
+    def _masks(self, n_img, dev):
+        if not self.training:
+            return None
+        if self.dropout_masks is not None:
+            return self.dropout_masks
+        keep = 1.0 - self.mac.dropout                                                 # mac.py:125-129
+        return tuple(torch.empty(n_img, self.dim, device=dev).bernoulli_(keep) / keep for _ in range(2))
+
+    def _reason(self, context, hq, kd, n_img, S, c_pad, lay):
+        """MACUnit.forward for every image at once (mac.py:131-155 with the units at :28-42,53-62,82-105)."""
+        dim, m = self.dim, self.mac
+        dev = kd.device
+        so = lay.sample_of
+        ctx = context[so]                                                         # [N,L,dim]
+        # step-invariant half of ReadUnit.concat on the MFMA GEMM: know W2^T + b
+        w2 = F.pad(m.read.concat.weight[:, dim:], (0, c_pad - dim, 0, c_pad - dim))
+        pre = ops.linear_nt(kd, w2, F.pad(m.read.concat.bias, (0, c_pad - dim)))
+        pre = pre.view(n_img, S, c_pad)[:, :, :dim].float()
+        kn = kd.view(n_img, S, c_pad)[:, :, :dim].float()
+        w1 = m.read.concat.weight[:, :dim]
+        masks = self._masks(n_img, dev)
+        control = m.control_0.expand(n_img, dim)
+        memory = m.mem_0.expand(n_img, dim)
+        if masks is not None:
+            control, memory = control * masks[0], memory * masks[1]
+        controls, memories = [control], [memory]
+        for i in range(self.max_step):
+            # ControlUnit: attn(cq * context) = context . (cq * w) + b
+            pa = m.control.position_aware[i](hq)[so]
+            cq = m.control.control_question(torch.cat([control, pa], 1))
+            aw = torch.bmm(ctx, (cq * m.control.attn.weight).unsqueeze(2)).squeeze(2) + m.control.attn.bias
+            control = torch.bmm(F.softmax(aw, 1).unsqueeze(1), ctx).squeeze(1)
+            if masks is not None:
+                control = control * masks[0]
+            controls.append(control)
+            # ReadUnit, re-associated (module docstring)
+            mem = m.read.mem(memories[-1])
+            v = control * m.read.attn.weight
+            u = mem * (v @ w1)
+            score = (torch.bmm(kn, u.unsqueeze(2)) + torch.bmm(pre, v.unsqueeze(2))).squeeze(2) + m.read.attn.bias
+            read = torch.bmm(F.softmax(score, 1).unsqueeze(1), kn).squeeze(1)
+            # WriteUnit
+            prev = memories[-1]
+            concat = m.write.concat(torch.cat([read, prev], 1))
+            nxt = concat
+            if self.self_attention:
+                cc = torch.stack(controls[:-1], 1)                                 # [N,i+1,dim]
+                sa = torch.bmm(cc, (control * m.write.attn.weight).unsqueeze(2)) + m.write.attn.bias
+                sa = F.softmax(sa, 1)
+                nxt = m.write.mem((sa * torch.stack(memories, 1)).sum(1)) + concat
+            if self.memory_gate:
+                gate = torch.sigmoid(m.write.control(control))
+                nxt = gate * prev + (1 - gate) * nxt
+            memory = nxt
+            if masks is not None:
+                memory = memory * masks[1]
+            memories.append(memory)
+        return memory
+
+    def forward(self, images, question, v_lens, question_len, actions=None, dropout=0.15):
+        """images fp32 [B,512,h,w,T] (or NativeFeatures from the stem), v_lens sorted descending.
+        Returns fp32 logits [B, classes] (mac.py:199-257)."""
+        x, lay, h, w = self._prepare_input(images, v_lens)
+        dev = x.device
+        B = lay.B
+        context, hq = self._encode_question(question, question_len, B, dev)
+        kd, n_img, S, c_pad = self._knowledge(x)
+        memory = self._reason(context, hq, kd, n_img, S, c_pad, lay)
+        out = torch.cat([memory, hq[lay.sample_of]], 1)                            # :240
+        outs = torch.zeros(lay.n_frames, B, 3 * self.dim, device=dev).index_put((lay.frame_of, lay.sample_of), out)
+        t = self.lstm_tail
+        xg = F.linear(outs, t.weight_ih_l0, t.bias_ih_l0 + t.bias_hh_l0)
+        hs = ops.lstm_wide(xg, t.weight_hh_l0, lay.cts, False)                     # packed by v_lens (:249-251)
+        vl = torch.as_tensor([int(v) for v in (v_lens.tolist() if torch.is_tensor(v_lens) else v_lens)], device=dev)
+        last = hs[vl - 1, torch.arange(B, device=dev)]                             # :252-255
+        return self.classifier(last)

@@ -248,3 +248,41 @@ class TemporalAttnFn(torch.autograd.Function):
 def temporal_attention(feat, valid, mask, w, bias):
     """feat [B,T,A], valid/mask [B,T]; w [1,A], bias [1] (fc_attn_1).  Returns (ctxt [B,A], coef [B,T])."""
     return TemporalAttnFn.apply(feat, valid, mask, w, bias)
+
+
+class LstmWideFn(torch.autograd.Function):
+    """hs = packed LSTM over time-major xg [T,B,4H] (input projection incl. both biases) from a zero state,
+    for hidden sizes too wide for the persistent kernel (MACNetwork's nn.LSTMs, models/mac.py:185-186,193).
+    One HIP launch per step; BPTT likewise, then dW_hh as ONE GEMM over all steps."""
+
+    @staticmethod
+    def forward(ctx, xg, w_hh, batch_sizes, reverse):
+        xg = xg.float().contiguous()
+        w = w_hh.float().contiguous()
+        hs, cs, gates = K.lstm_wide_fwd(xg, w, batch_sizes, reverse)
+        ctx.save_for_backward(w, hs, cs, gates)
+        ctx.batch_sizes, ctx.reverse = tuple(batch_sizes), reverse
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        w, hs, cs, gates = ctx.saved_tensors
+        T, B, H = hs.shape
+        dgates = K.lstm_wide_bwd(w.t().contiguous(), ctx.batch_sizes, gates, cs, dhs.float().contiguous(), ctx.reverse)
+        # h of each step's predecessor in the chain (zero where the sample starts there: hs rows of inactive
+        # (step, sample) pairs are zero)
+        zero = torch.zeros(1, B, H, device=hs.device)
+        hpred = torch.cat([hs[1:], zero], 0) if ctx.reverse else torch.cat([zero, hs[:-1]], 0)
+        dw = K.gemm_tn(dgates.view(T * B, 4 * H), hpred.reshape(T * B, H).contiguous())
+        return dgates, dw, None, None
+
+
+def lstm_wide(xg, w_hh, batch_sizes, reverse=False):
+    return LstmWideFn.apply(xg, w_hh, batch_sizes, reverse)
+
+
+def packed_batch_sizes(lens_sorted, n_steps=None):
+    """PackedSequence.batch_sizes of host lengths sorted descending."""
+    lens = [int(v) for v in lens_sorted]
+    n_steps = n_steps or lens[0]
+    return [sum(1 for v in lens if v > t) for t in range(n_steps)]

@@ -252,11 +252,15 @@ class Trainer(object):
         if next_clip is not None:
             self.prefetch(next_clip, next_v_lens_cpu if next_v_lens_cpu is not None else v_lens_cpu)
         perm_d = perm.to(self.stem_device)
-        self.model.init_hidden()
+        if hasattr(self.model, "init_hidden"):     # `--model mac` has none (eval/q_and_v_eval.py:119-120)
+            self.model.init_hidden()
         logits = self.model(native, q_input[perm_d], v_sorted, q_lens_cpu[perm])
         loss = self.loss_fn(logits, ys[perm_d])
         loss.backward()
         self.reducer.finish()
+        clamp = getattr(self.model, "grad_clamp", None)
+        if clamp:    # MACNetwork: per-parameter gradient clamp hooks (eval/q_and_v_eval.py:348-351), on the reduced gradient
+            self.fp.grad.clamp_(-clamp, clamp)
         self.fp.step_count += 1
         K.clip_adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.fp.partial,
                          self.fp.step_count, self.lr, self.clip)
