@@ -70,6 +70,10 @@ def build(args, device):
         model = FiLMAttnPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
                                        num_res_block_channels=args.channels, max_num_frames=args.frames,
                                        spatial_size=S, precision=prec)
+    elif args.model == "mac":              # MACNetwork on the same stem (eval/q_and_v_eval.py:288-293)
+        from videonavqa_amd.models import MACNetwork
+        model = MACNetwork(n_vocab=134, dim=args.channels, embed_hidden=128, classes=70, max_num_frames=args.frames,
+                           precision=prec)
     elif args.model == "film_gp_pt":       # BASELINE.json config 3
         model = FiLMGlobalPoolingPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
                                                 num_res_block_channels=args.channels, spatial_size=S, precision=prec)
@@ -194,8 +198,9 @@ def main():
     ap.add_argument("--width", type=int, default=224)
     ap.add_argument("--blocks", type=int, default=1)
     ap.add_argument("--channels", type=int, default=512)
-    ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop"],
-                    help="film_attn_pt is the metric's model; the others are BASELINE.json's ladder configs 3 and 5")
+    ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop", "mac"],
+                    help="film_attn_pt is the metric's model; film_gp_pt / time_multi_hop are BASELINE.json's ladder "
+                         "configs 3 and 5, mac is the remaining stem-consuming model of the same CLI")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: clips start in pinned host memory "
                     "and are copied to the GPU every step (on the stem stream); never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -314,6 +319,10 @@ def main():
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         S = (H // 16) * (W // 16)
         _, trunk_fb = trunk_flops_per_frame(S, 512, args.channels, args.blocks, 128)
+        if args.model == "mac":     # three 3x3 convs (fwd + wgrad + dgrad except the first's) + the position-wise GEMM
+            d = args.channels
+            c1, c2 = 2.0 * S * 512 * d * 9, 2.0 * S * d * d * 9
+            trunk_fb = 3 * (c1 + 2 * c2) - c1 + 3 * 2.0 * S * d * d
         flops_clip = T * (stem_flops_per_frame(H, W) + trunk_fb)
         out = {
             "metric": METRIC, "value": round(clips, 3), "unit": "clips/s", "n_gpus": world,

@@ -4,10 +4,12 @@
 // tail LSTM over the per-frame outputs (3*dim -> 3*dim, :193,249-251).  With dim = 512 the recurrent
 // matrix W_hh is 4 MB / 37.7 MB: it cannot live in one workgroup's registers like the H <= 256
 // persistent kernel (lstm.hip), so here ONE LAUNCH PER TIME STEP streams W_hh through the whole chip:
-// a workgroup owns 4 hidden units (16 gate rows), 16 lanes share one row and split K, every lane keeps
-// one accumulator per sample, and the cell update of those units runs in the same launch.  A step is
+// a workgroup owns one hidden unit (its 4 gate rows), the 64 lanes of a wave share one row and split K,
+// every lane keeps one accumulator per sample, and the cell update of those units runs in the same launch.  A step is
 // weight-bandwidth-bound (4H*H*4 bytes from L2/MALL per step), the sequence is a chain of T such
-// launches enqueued back to back on the caller's stream by one C call.
+// launches enqueued back to back on the caller's stream by one C call.  (One wave per matrix row: H = 1536 gives
+// 1536 / 384 workgroups per step forward / backward; 16 rows per workgroup left the backward at 96 workgroups
+// and 3x slower.)
 //
 // Packed batches (nn.utils.rnn.pack_padded_sequence semantics, :210,249): samples are sorted by length,
 // batch_sizes[t] = number of samples with length > t (non-increasing), every sample starts from
@@ -24,8 +26,8 @@
 namespace {
 
 constexpr int NB = 8;        // samples per workgroup
-constexpr int KL = 16;       // lanes sharing one matrix row
-constexpr int ROWS = 16;     // matrix rows per workgroup (256 threads)
+constexpr int KL = 64;       // lanes sharing one matrix row (one wave)
+constexpr int ROWS = 4;      // matrix rows per workgroup (256 threads)
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -68,7 +70,7 @@ __global__ void __launch_bounds__(256) lstm_wide_fwd_step(const WideFwd p) {
   __shared__ float pre[ROWS][NB];
   const int H = p.H;
   const int r = threadIdx.x / KL, kl = threadIdx.x % KL;
-  const int gate = r >> 2, unit = blockIdx.x * 4 + (r & 3);
+  const int gate = r, unit = blockIdx.x;
   const int b0 = blockIdx.y * NB;
   const int nb = min(NB, p.n_act - b0);
   // samples of this chunk with a predecessor state form a prefix (batch sizes are non-increasing)
@@ -96,15 +98,15 @@ __global__ void __launch_bounds__(256) lstm_wide_fwd_step(const WideFwd p) {
     for (int j = 0; j < NB; ++j) pre[r][j] = acc[j];
   }
   __syncthreads();
-  if (threadIdx.x < 4 * NB) {
-    const int uu = threadIdx.x / NB, j = threadIdx.x % NB;
+  if (threadIdx.x < NB) {
+    const int j = threadIdx.x;
     if (j < nb) {
-      const int b = b0 + j, u = blockIdx.x * 4 + uu;
+      const int b = b0 + j, u = blockIdx.x;
       const float* xg = p.xg_t + (size_t)b * 4 * H;
-      const float gi = sigm(pre[uu][j] + xg[u]);
-      const float gf = sigm(pre[4 + uu][j] + xg[H + u]);
-      const float gg = tanhf(pre[8 + uu][j] + xg[2 * H + u]);
-      const float go = sigm(pre[12 + uu][j] + xg[3 * H + u]);
+      const float gi = sigm(pre[0][j] + xg[u]);
+      const float gf = sigm(pre[1][j] + xg[H + u]);
+      const float gg = tanhf(pre[2][j] + xg[2 * H + u]);
+      const float go = sigm(pre[3][j] + xg[3 * H + u]);
       const float cp = j < nprev ? p.c_prev[(size_t)b * H + u] : (p.c0 ? p.c0[(size_t)b * H + u] : 0.f);
       const float c = gf * cp + gi * gg;
       p.cs_t[(size_t)b * H + u] = c;
@@ -209,7 +211,7 @@ extern "C" int vnqa_lstm_wide_fwd(const float* xg, const float* w_hh, const floa
     a.n_prev = has_pred ? (batch_sizes_host[pred] < a.n_act ? batch_sizes_host[pred] : a.n_act) : 0;
     a.h_prev = has_pred ? hs + pred * sh : hs;
     a.c_prev = has_pred ? cs + pred * sh : cs;
-    dim3 grid(h / 4, (a.n_act + NB - 1) / NB);
+    dim3 grid(h, (a.n_act + NB - 1) / NB);
     hipLaunchKernelGGL(lstm_wide_fwd_step, grid, dim3(256), 0, st, a);
   }
   VNQA_CHECK_LAUNCH();
