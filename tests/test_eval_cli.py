@@ -49,15 +49,18 @@ def test_synthetic_dataset_contract():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["film_attn_pt", "film_gp_pt", "time_multi_hop"])
+@pytest.mark.parametrize("model", ["film_attn_pt", "film_gp_pt", "time_multi_hop", "mac"])
 def test_cli_synthetic_train_val_checkpoint_resume(model, tmp_path, capsys):
     from videonavqa_amd.eval import q_and_v_eval as E
     os.chdir(tmp_path)
     argv = ["--model", model, "--synthetic", "6", "--batch_size", "2", "--num_workers", "0", "--height", "64",
             "--width", "96", "--num_res_block_channels", "64", "--hidden_size", "16", "--at_hidden_size", "16",
-            "--embed_size", "16", "--precision", "fp32", "--checkpoint_path", "ck.pt", "--stats_after_every", "1"]
+            "--embed_size", "16", "--precision", "fp32", "--checkpoint_path", "ck.pt", "--stats_after_every", "1",
+            "--mac_dim", "64", "--mac_max_step", "3"]
     E.main(argv)
     out = capsys.readouterr().out
+    if model == "mac":      # eval/q_and_v_eval.py:357-363: after epoch 0 the rate drops to l_rate/10
+        assert "learning rate 0.00001" in out
     assert "Train Epoch: 0" in out and "Validation:" in out and "Average loss after 1 iterations in epoch 1" in out
     ck = torch.load(tmp_path / "e0_ck.pt", map_location="cpu")
     assert set(ck) == {"epoch", "model", "state_dict", "train_f1w", "train_f1micro", "optimizer"}

@@ -169,3 +169,38 @@ def test_mac_trainer_trajectory(case):
         assert d.max() <= 0.7 * travel + 1e-7, k
         if d.size >= 32:
             assert np.quantile(d, 0.9) <= 5e-2 * travel + 1e-7, k
+
+
+def test_mac_full_size_batch_independence_and_training():
+    """Default CLI size (dim 512, 12 steps, bs 8, 35 frames of 14x14x512, bf16).  MACNetwork has no batch
+    statistics, so with question lengths already sorted (which makes the upstream `h` ordering quirk the identity)
+    every sample's logits must not depend on what else is in the minibatch — a size-independent property that
+    exercises the packed image list, the ragged packed LSTMs and the batched reasoning steps at full size.
+    Then three optimisation steps through the Trainer must stay finite and reduce the loss on a fixed batch."""
+    import videonavqa_amd.models as M
+    from videonavqa_amd.train import Trainer
+    from videonavqa_amd.models.common import FrameLayout, NativeFeatures
+    from videonavqa_amd import kernels as K
+    torch.manual_seed(5)
+    dev = torch.device("cuda")
+    B, T = 8, 35
+    model = M.MACNetwork(n_vocab=134, dim=512, embed_hidden=128, classes=70, precision="bf16").to(dev)
+    v = torch.rand(B, 512, 14, 14, T, device=dev)
+    v_lens = torch.tensor([35, 35, 30, 22, 22, 9, 4, 3])
+    q_lens = torch.tensor([25, 19, 19, 12, 9, 7, 6, 5])
+    q = torch.randint(1, 134, (B, 56), device=dev) * (torch.arange(56, device=dev)[None] < q_lens.to(dev)[:, None])
+    model.eval()
+    with torch.no_grad():
+        full = model(v, q, v_lens, q_lens).float()
+        for b in (0, 3, 7):
+            solo = model(v[b:b + 1], q[b:b + 1], v_lens[b:b + 1], q_lens[b:b + 1]).float()
+            assert torch.isfinite(solo).all()
+            assert rel_err(solo.cpu().numpy(), full[b:b + 1].cpu().numpy()) < 2e-2, b
+    y = torch.randint(0, 70, (B,), device=dev)
+    trainer = Trainer(model, stem=None, lr=1e-4, clip=1.0, feature_channels=512)
+    lay = FrameLayout(v_lens, T, dev)
+    native = NativeFeatures(K.feat_to_nhwc(v, lay.img_of, lay.n_img, torch.bfloat16), lay, 512, 14, 14)
+    trainer.extract_features = lambda clip, v_lens_cpu, slot=0: (native, v_lens, torch.arange(B))
+    model.mac.dropout = 0.0
+    losses = [float(trainer.step(v, q, v_lens, q_lens, y)[0]) for _ in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
