@@ -265,3 +265,55 @@ def test_conv_igemm_pretiled_weights(dt, tile):
     wt = K.pack_conv_weight_tiled(w, dt, tile, out_scale=sc, c_out_pad=Cout, c_in_pad=Cin)
     y = K.conv2d_igemm(K.nchw_to_nhwc(x, dt, c_pad=Cin), wt, relu=True)
     assert _rel(K.nhwc_to_nchw(y, Cout), ref) < _tol(dt)
+
+
+@pytest.mark.parametrize("tile", [11, 12])
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, relu, pool, post
+    (3, 28, 28, 128, 512, True, True, True),      # 8x28 tiles straddle image boundaries (28 = 3.5 x 8)
+    (5, 14, 14, 64, 256, False, False, False),    # 16x14 tiles spanning up to three images; ragged last tile
+    (2, 56, 56, 64, 320, True, False, False),     # two column blocks; c_out not a multiple of the 256-wide tile
+    (1, 112, 28, 192, 64, True, True, False),     # tall images, three channel chunks (patch double buffer wraps)
+    (7, 8, 14, 64, 72, False, True, True),        # H < tile rows
+])
+def test_conv_patch_tile_vs_torch(tile, cfg):
+    """LDS-resident activation patch igemm (conv_patch.hip) vs torch on the same bf16-rounded operands."""
+    from videonavqa_amd import kernels as K
+    N, H, W, Cin, Cout, relu, pool, post = cfg
+    dt = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]) + tile)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda() * 0.1
+    sc = (torch.rand(Cout, generator=g) + 0.5).cuda() * torch.where(torch.rand(Cout, generator=g) > 0.3, 1.0, -1.0).cuda()
+    sh = torch.randn(Cout, generator=g).cuda() * 0.2
+    ref = F.conv2d(_q(x, dt), _q(w, dt), b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    if post:
+        ref = ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    y = K.conv2d_igemm(K.nchw_to_nhwc(x, dt, c_pad=Cin), K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=Cin),
+                       bias=b, relu=relu, pool2=pool, post_scale=sc if post else None,
+                       post_shift=sh if post else None, tile=tile)
+    got = K.nhwc_to_nchw(y, Cout)
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 1e-2, _rel(got, ref)
+    assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0
+    assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+    # bit-identical to the row-tile kernel is not required (different summation order), but it must agree closely
+    y1 = K.conv2d_igemm(K.nchw_to_nhwc(x, dt, c_pad=Cin), K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=Cin),
+                        bias=b, relu=relu, pool2=pool, post_scale=sc if post else None,
+                        post_shift=sh if post else None, tile=1)
+    assert _rel(y.float(), y1.float()) < 1e-2
+
+
+def test_conv_patch_tile_rejects_unsupported_geometry():
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd._lib import VnqaError
+    dt = torch.bfloat16
+    x = torch.zeros(2, 12, 15, 64, dtype=dt, device="cuda")      # 10x13 maps: width not a multiple of 14
+    wt = torch.zeros(64, 9, 64, dtype=dt, device="cuda")
+    with pytest.raises(VnqaError):
+        K.conv2d_igemm(x, wt, tile=11)

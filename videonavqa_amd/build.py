@@ -23,8 +23,8 @@ def sources():
 
 def _digest():
     h = hashlib.sha256()
-    for f in sources() + [os.path.join(CSRC, "vnqa_common.h"),
-                          os.path.join(HERE, "..", "include", "vnqa_hip.h")]:
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    for f in sources() + headers + [os.path.join(HERE, "..", "include", "vnqa_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

@@ -1,0 +1,27 @@
+// Internal: argument block shared by the implicit-GEMM conv kernels (conv_igemm.hip, conv_patch.hip).
+#pragma once
+#include "vnqa_common.h"
+
+struct ConvArgs {
+  const char* x;
+  const char* wt;
+  const float* bias;
+  const float* post_scale;
+  const float* post_shift;
+  char* y;
+  int n_img, H, W, Hp, Wp;  // Hp/Wp: padded input dims
+  int Cin, Cout, Cy;
+  int taps, x_halo, y_halo;
+  int relu, pool;
+  int M;                    // n_img*H*W conv-output pixels
+  int tilesN;
+  int Hyp, Wyp;             // padded OUTPUT dims (after pooling)
+  int wt_tiled;             // weights are pre-tiled LDS images (vnqa_pack_conv_weight_tiled)
+  int D;                    // > 0: 3-D conv over [n][D+2][H+2][W+2][C]; "images" are (n, d) depth slices
+  int slices, kt_per_slice; // split-K: K-steps [slice*kt_per_slice, ...) -> fp32 slab
+  float* partial;           // [slices][M][Cout] fp32 when slices > 1
+};
+
+// conv_patch.hip: 224-pixel 2-D tiles, activation patch DMA'd once per 64-channel chunk (bf16, 3x3, 2-D only).
+// Returns VNQA_ERR_UNSUPPORTED (with the reason in vnqa_last_error) when the geometry does not fit.
+int vnqa_conv_patch_dispatch(const ConvArgs& a, int tag, hipStream_t st);

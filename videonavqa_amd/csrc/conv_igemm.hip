@@ -16,29 +16,10 @@
 //
 // Loop: 2-stage LDS double buffer, one barrier per K-step; the next slab's DMA is in flight
 // while the current slab's MFMAs run.
-#include "vnqa_common.h"
+#include "conv_args.h"
 
 namespace {
 
-struct ConvArgs {
-  const char* x;
-  const char* wt;
-  const float* bias;
-  const float* post_scale;
-  const float* post_shift;
-  char* y;
-  int n_img, H, W, Hp, Wp;  // Hp/Wp: padded input dims
-  int Cin, Cout, Cy;
-  int taps, x_halo, y_halo;
-  int relu, pool;
-  int M;                    // n_img*H*W conv-output pixels
-  int tilesN;
-  int Hyp, Wyp;             // padded OUTPUT dims (after pooling)
-  int wt_tiled;             // weights are pre-tiled LDS images (vnqa_pack_conv_weight_tiled)
-  int D;                    // > 0: 3-D conv over [n][D+2][H+2][W+2][C]; "images" are (n, d) depth slices
-  int slices, kt_per_slice; // split-K: K-steps [slice*kt_per_slice, ...) -> fp32 slab
-  float* partial;           // [slices][M][Cout] fp32 when slices > 1
-};
 
 // MFMA shape per element type.  bf16 uses v_mfma_f32_16x16x32_bf16 by default: same FLOPs per LDS byte and
 // per cycle as 32x32x16, but the chip holds a higher clock on it under load (MI355X_MICROARCH.md, DVFS
@@ -531,6 +512,8 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_P4_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, 0, 4>(a, st);
       case VNQA_TILE_P4_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, 0, 4>(a, st);
       case VNQA_TILE_P4_256x64: return launch<vnqa_bf16, 256, 64, 4, 1, 0, 4>(a, st);
+      case VNQA_TILE_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 0, st);
+      case VNQA_TILE_STEM_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 1, st);
       default: break;
     }
   } else {
