@@ -274,6 +274,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = run_step()
+    t_enqueue = time.perf_counter() - t0      # host time to ENQUEUE the K steps (launch-thread cost, no device wait)
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -337,6 +338,7 @@ def main():
                        "gflop_per_clip": round(flops_clip / 1e9, 1),
                        "whole_step_tflops": round(clips * flops_clip / 1e12, 1),
                        "final_loss": round(float(loss), 4), "inputs": "pinned host memory, H2D every step" if args.h2d else "resident in HBM",
+                       "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
                        "stem_alone_ms": round(stem_ms, 3),
                        "stem_alone_mfma_util": round(n_frames * stem_flops_per_frame(H, W) / (stem_ms * 1e-3) / 1e12 / peak, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",

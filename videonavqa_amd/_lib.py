@@ -103,6 +103,16 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def to_device_async(t, device):
+    """Host tensor -> device without blocking the launch thread: stage through pinned memory (the caching host
+    allocator keeps the staging block alive until the copy has run).  A pageable-memory `.to(device)` makes the
+    host wait until the current stream has drained up to the copy."""
+    device = torch.device(device)
+    if device.type != "cuda" or t.is_cuda:
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -270,7 +270,13 @@ Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype) {
   pl.tilesCi = (c_in + 255) / 256;
   pl.ksteps_total = (int)((pl.Ptot + KP - 1) / KP);
   const int tiles = pl.tilesCo * pl.tilesCi * taps;
+  // one workgroup per CU (128 KiB LDS): aim for the largest grid <= 2 x 256 so the launch is two FULL rounds
+  // (36 tiles: 14 slices = 504 workgroups; 15 slices = 540 would need a third, 89 % empty round)
+#ifdef VNQA_WGRAD_CEIL_SLICES   // A/B: the previous rule
   int slices = (512 + tiles - 1) / tiles;
+#else
+  int slices = 512 / tiles;
+#endif
   const int max_slices = pl.ksteps_total / 8 > 0 ? pl.ksteps_total / 8 : 1;
   slices = slices < 1 ? 1 : (slices > max_slices ? max_slices : slices);
   pl.ksteps_per_slice = (pl.ksteps_total + slices - 1) / slices;

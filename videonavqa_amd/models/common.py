@@ -82,13 +82,30 @@ class FrameLayout(object):
                 img_of[pm[b] * self.T + t] = self.offsets[t] + b
                 frame_of.append(t)
                 sample_of.append(b)
-        self.img_of = torch.from_numpy(img_of).to(device)
-        self.frame_of = torch.tensor(frame_of, dtype=torch.long, device=device)
-        self.sample_of = torch.tensor(sample_of, dtype=torch.long, device=device)
-        self.cts_t = torch.tensor(self.cts, dtype=torch.float32, device=device)
-        self.frame_of_i32 = self.frame_of.to(torch.int32)
-        self.frame_off_i32 = torch.tensor(self.offsets, dtype=torch.int32, device=device)
+        # ONE pinned staging buffer and ONE asynchronous H2D copy for all index tables: a pageable-memory copy would
+        # block the launch thread until the stream it is issued on has drained (that stream holds a whole stem pass)
+        n_img, nf = self.n_img, self.n_frames
+        packed = torch.from_numpy(np.concatenate([img_of, np.asarray(frame_of, np.int32), np.asarray(sample_of, np.int32),
+                                                  np.asarray(self.offsets, np.int32)]))
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            packed = packed.pin_memory().to(dev, non_blocking=True)
+        o1, o2, o3 = B * self.T, B * self.T + n_img, B * self.T + 2 * n_img
+        self.img_of = packed[:o1]
+        self.frame_of_i32 = packed[o1:o2]
+        self.frame_off_i32 = packed[o3:o3 + nf + 1]
+        self.frame_of = packed[o1:o2].long()
+        self.sample_of = packed[o2:o3].long()
+        self.cts_t = (packed[o3 + 1:o3 + nf + 1] - packed[o3:o3 + nf]).float()
         self.uniform = all(ct == B for ct in self.cts)
+        self._device_tensors = [packed, self.frame_of, self.sample_of, self.cts_t]
+
+    def record_stream(self, stream):
+        """The tables were allocated on the stream current at construction (the stem's side stream when prefetched);
+        tell the caching allocator that `stream` reads them too, so their memory is not recycled under its kernels."""
+        for t in self._device_tensors:
+            if t.is_cuda:
+                t.record_stream(stream)
 
 
 class NativeFeatures(object):
@@ -162,7 +179,7 @@ def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=Fals
     B, Lq, E = emb.shape
     dev = emb.device
     ql_cpu = q_lens.detach().cpu().long()      # host-side lengths (a DataLoader delivers them on the host)
-    ql = ql_cpu.to(dev)
+    ql = L.to_device_async(ql_cpu, dev)
     Lmax = int(ql_cpu.max())
     S = Lmax * n_frames
     H = lstm.hidden_size
@@ -254,7 +271,7 @@ class FiLMTrunkBase(nn.Module):
         if fh is None:
             z = torch.zeros(B, H, device=device)
             return z, z.clone()
-        perm = torch.sort(q_lens.cpu(), dim=0, descending=True, stable=True)[1].to(device)
+        perm = L.to_device_async(torch.sort(q_lens.cpu(), dim=0, descending=True, stable=True)[1], device)
         h0 = torch.empty(B, H, device=device)
         c0 = torch.empty(B, H, device=device)
         h0[perm] = fh[0][0].to(device)
@@ -262,7 +279,7 @@ class FiLMTrunkBase(nn.Module):
         return h0, c0
 
     def _store_question_state(self, hn, cn, q_lens):
-        perm = torch.sort(q_lens.cpu(), dim=0, descending=True, stable=True)[1].to(hn.device)
+        perm = L.to_device_async(torch.sort(q_lens.cpu(), dim=0, descending=True, stable=True)[1], hn.device)
         self.film_hidden = (hn.detach()[perm].unsqueeze(0), cn.detach()[perm].unsqueeze(0))
 
     # ---- conv trunk on the packed image list -------------------------------------------------

@@ -117,7 +117,7 @@ class MACNetwork(nn.Module):
     def _encode_question(self, question, q_lens, B, dev):
         ql = q_lens.detach().cpu().long()
         lens_sorted, perm = torch.sort(ql, dim=0, descending=True, stable=True)
-        perm_d = perm.to(dev)
+        perm_d = L.to_device_async(perm, dev)
         Lmax = int(lens_sorted[0])
         emb = F.embedding(question[:B], self.embed.weight, padding_idx=0)[perm_d][:, :Lmax]
         bsz = ops.packed_batch_sizes(lens_sorted)
@@ -129,9 +129,9 @@ class MACNetwork(nn.Module):
             xg = F.linear(emb, w_ih, bias).transpose(0, 1).contiguous()          # [Lmax,B,4H]
             hs = ops.lstm_wide(xg, w_hh, bsz, rev)                                # [Lmax,B,H]
             outs.append(hs)
-            finals.append(hs[0] if rev else hs[(lens_sorted - 1).to(dev), torch.arange(B, device=dev)])
+            finals.append(hs[0] if rev else hs[L.to_device_async(lens_sorted - 1, dev), torch.arange(B, device=dev)])
         lstm_out = torch.cat(outs, 2).transpose(0, 1)                             # [B,Lmax,2H] sorted order
-        inv = torch.sort(perm, dim=0)[1].to(dev)
+        inv = L.to_device_async(torch.sort(perm, dim=0)[1], dev)
         context = self.lstm_proj(lstm_out[inv])                                   # :217-220 (pad rows -> bias)
         hq = torch.cat(finals, 1)                                                 # :221: stays in SORTED order
         return context, hq
@@ -226,6 +226,6 @@ class MACNetwork(nn.Module):
         t = self.lstm_tail
         xg = F.linear(outs, t.weight_ih_l0, t.bias_ih_l0 + t.bias_hh_l0)
         hs = ops.lstm_wide(xg, t.weight_hh_l0, lay.cts, False)                     # packed by v_lens (:249-251)
-        vl = torch.as_tensor([int(v) for v in (v_lens.tolist() if torch.is_tensor(v_lens) else v_lens)], device=dev)
+        vl = L.to_device_async(torch.as_tensor([int(v) for v in (v_lens.tolist() if torch.is_tensor(v_lens) else v_lens)]), dev)
         last = hs[vl - 1, torch.arange(B, device=dev)]                             # :252-255
         return self.classifier(last)

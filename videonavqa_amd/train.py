@@ -20,6 +20,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import _lib as L
 from . import kernels as K
 from .models.common import FrameLayout, NativeFeatures
 
@@ -242,6 +243,7 @@ class Trainer(object):
         if self._prefetched is not None and self._prefetched[0] == clip.data_ptr():
             _, native, v_sorted, perm, done, slot = self._prefetched
             main.wait_event(done)
+            native.layout.record_stream(main)
             self._slot = slot
         else:
             if not clip.is_cuda:
@@ -251,7 +253,7 @@ class Trainer(object):
         self._prefetched = None
         if next_clip is not None:
             self.prefetch(next_clip, next_v_lens_cpu if next_v_lens_cpu is not None else v_lens_cpu)
-        perm_d = perm.to(self.stem_device)
+        perm_d = L.to_device_async(perm, self.stem_device)
         if hasattr(self.model, "init_hidden"):     # `--model mac` has none (eval/q_and_v_eval.py:119-120)
             self.model.init_hidden()
         logits = self.model(native, q_input[perm_d], v_sorted, q_lens_cpu[perm])
