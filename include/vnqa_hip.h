@@ -261,6 +261,30 @@ int vnqa_lstm_wide_bwd(const float* w_hh_t, const float* c0, const int32_t* batc
                        const float* gates, const float* cs, const float* dhs, float* dgates,
                        float* dc_work, int32_t t, int32_t b, int32_t hidden, int32_t reverse, void* stream);
 
+/* Fused ReadUnit attention of MACNetwork (models/mac.py:53-62; replaces, per reasoning step, the Linear(2d->d)
+ * over [mem*know ; know] at every position, the control-weighted Linear(d->1), the softmax over positions and the
+ * weighted sum — see videonavqa_amd/models/mac.py for the re-association).
+ *   know, pre : [n][s][ld] in `dtype` (ld >= c channels per row, both multiples of 8); pre = know W2^T + b
+ *   u, v      : fp32 [n][c]   score[n][s] = know[n][s].u[n] + pre[n][s].v[n] + bias[0]
+ *   p         : fp32 [n][s]   softmax over s (saved for backward);  read : fp32 [n][c] = sum_s p know
+ * backward: dread fp32 [n][c] -> dscore fp32 [n][s], du, dv fp32 [n][c].  The outer-product gradients of know / pre
+ * are formed ONCE for all k reasoning steps by vnqa_mac_read_accum from the stacked per-step factors
+ * (dscore, p: [k][n][s]; u, v, dread: [k][n][c]):  dknow = sum_i dscore_i (x) u_i + p_i (x) dread_i,
+ * dpre = sum_i dscore_i (x) v_i, written in `dtype` with row stride ld (channels >= c zero).
+ * pre / v / dv / dpre may all be NULL: the kernels are then a plain dot-product attention pool over `know`, used for
+ * ControlUnit's attention over the question words (models/mac.py:36-42).
+ * s <= 1024; 3*k*c + 128*k floats must fit 160 KiB of LDS in vnqa_mac_read_accum.
+ */
+int vnqa_mac_read_fwd(const void* know, const void* pre, const float* u, const float* v, const float* bias,
+                      float* p, float* read, int32_t n, int32_t s, int32_t c, int32_t ld, int32_t dtype,
+                      void* stream);
+int vnqa_mac_read_bwd(const void* know, const void* pre, const float* p, const float* dread, float* dscore,
+                      float* du, float* dv, int32_t n, int32_t s, int32_t c, int32_t ld, int32_t dtype,
+                      void* stream);
+int vnqa_mac_read_accum(const float* dscore, const float* p, const float* u, const float* v,
+                        const float* dread, void* dknow, void* dpre, int32_t k, int32_t n, int32_t s,
+                        int32_t c, int32_t ld, int32_t dtype, void* stream);
+
 /* Fused global-norm clip + Adam + zero_grad over flat fp32 buffers.
  * Replaces clip_grad_norm(model.parameters(), clip); optimizer.step(); optimizer.zero_grad()
  * (eval/q_and_v_eval.py:137-139, torch.optim.Adam defaults betas .9/.999 eps 1e-8).

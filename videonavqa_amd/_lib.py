@@ -47,6 +47,9 @@ _SIGNATURES = {
     "vnqa_lstm_seq_bwd": (ctypes.c_int, [_vp] * 10 + [_i32] * 4 + [_vp]),
     "vnqa_lstm_wide_fwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
     "vnqa_lstm_wide_bwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
+    "vnqa_mac_read_fwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
+    "vnqa_mac_read_bwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
+    "vnqa_mac_read_accum": (ctypes.c_int, [_vp] * 7 + [_i32] * 6 + [_vp]),
     "vnqa_l2norm_blocks": (_i32, [_i64]),
     "vnqa_l2norm_partial": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "vnqa_clip_adam": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),

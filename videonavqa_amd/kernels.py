@@ -266,6 +266,36 @@ def lstm_wide_bwd(w_hh_t, batch_sizes, gates, cs, dhs, reverse=False, c0=None):
     return dgates
 
 
+def mac_read_fwd(know, pre, u, v, bias, n, s, c):
+    """Fused ReadUnit attention.  know/pre [n*s, ld] (compute dtype), u/v fp32 [n,c] -> p [n,s], read [n,c] fp32."""
+    ld = know.shape[-1]
+    p = torch.empty((n, s), dtype=torch.float32, device=know.device)
+    read = torch.empty((n, c), dtype=torch.float32, device=know.device)
+    L.check(L.lib().vnqa_mac_read_fwd(L.ptr(know), L.ptr(pre), L.ptr(u), L.ptr(v), L.ptr(bias), L.ptr(p), L.ptr(read),
+                                      n, s, c, ld, L.dtype_id(know.dtype), L.stream()), "vnqa_mac_read_fwd")
+    return p, read
+
+
+def mac_read_bwd(know, pre, p, dread, n, s, c):
+    ld = know.shape[-1]
+    dscore = torch.empty((n, s), dtype=torch.float32, device=know.device)
+    du = torch.empty((n, c), dtype=torch.float32, device=know.device)
+    dv = torch.empty((n, c), dtype=torch.float32, device=know.device) if pre is not None else None
+    L.check(L.lib().vnqa_mac_read_bwd(L.ptr(know), L.ptr(pre), L.ptr(p), L.ptr(dread), L.ptr(dscore), L.ptr(du),
+                                      L.ptr(dv), n, s, c, ld, L.dtype_id(know.dtype), L.stream()), "vnqa_mac_read_bwd")
+    return dscore, du, dv
+
+
+def mac_read_accum(dscore, p, u, v, dread, n, s, c, ld, dtype):
+    """Stacked per-step factors ([k,n,s] / [k,n,c] fp32) -> dknow, dpre [n*s, ld] in `dtype`."""
+    k = dscore.shape[0]
+    dknow = torch.empty((n * s, ld), dtype=dtype, device=dscore.device)
+    dpre = torch.empty((n * s, ld), dtype=dtype, device=dscore.device) if v is not None else None
+    L.check(L.lib().vnqa_mac_read_accum(L.ptr(dscore), L.ptr(p), L.ptr(u), L.ptr(v), L.ptr(dread), L.ptr(dknow),
+                                        L.ptr(dpre), k, n, s, c, ld, L.dtype_id(dtype), L.stream()), "vnqa_mac_read_accum")
+    return dknow, dpre
+
+
 def frame_bn_stats(x, frame_off_i32, n_frames):
     N, hp, wp, c = x.shape
     mean = torch.empty((n_frames, c), dtype=torch.float32, device=x.device)

@@ -12,7 +12,9 @@ how the work is laid out for the MI355X:
         score[n,s] = know[n,s,:] . (mem[n] * (W1^T v[n])) + (know W2^T + b)[n,s,:] . v[n] + b_attn,
         v = control * w_attn, [W1 | W2] = concat.weight,
     leaving ONE position-wise GEMM per forward (know W2^T, step-invariant) instead of max_step of twice
-    the size; the per-step work is three batched mat-vecs over the knowledge base;
+    the size; the per-step work is three sweeps over the knowledge base in one fused HIP kernel
+    (csrc/mac_read.hip: scores, softmax over positions, weighted read; backward with the outer-product
+    gradients of all steps formed in a single pass);
   * both nn.LSTMs (bidirectional question encoder, 3*dim tail) run on the step-wise wide-LSTM HIP
     kernels (ops.lstm_wide) directly on PackedSequence batch sizes.
 """
@@ -166,12 +168,17 @@ class MACNetwork(nn.Module):
         dim, m = self.dim, self.mac
         dev = kd.device
         so = lay.sample_of
-        ctx = context[so]                                                         # [N,L,dim]
-        # step-invariant half of ReadUnit.concat on the MFMA GEMM: know W2^T + b
+        Lq = context.shape[1]
+        ctx = context[so].reshape(n_img * Lq, dim).contiguous()                   # [N*L,dim] fp32
+        cstate = ops.MacReadState()
+        # all position_aware projections (one per reasoning step, mac.py:29) in one batched product
+        pw = torch.stack([l.weight for l in m.control.position_aware])            # [steps,dim,2dim]
+        pb = torch.stack([l.bias for l in m.control.position_aware])              # [steps,dim]
+        pa_all = (torch.matmul(hq, pw.transpose(1, 2)) + pb.unsqueeze(1))[:, so]  # [steps,N,dim]
+        # step-invariant half of ReadUnit.concat on the MFMA GEMM: know W2^T + b (kept in the compute dtype)
         w2 = F.pad(m.read.concat.weight[:, dim:], (0, c_pad - dim, 0, c_pad - dim))
         pre = ops.linear_nt(kd, w2, F.pad(m.read.concat.bias, (0, c_pad - dim)))
-        pre = pre.view(n_img, S, c_pad)[:, :, :dim].float()
-        kn = kd.view(n_img, S, c_pad)[:, :, :dim].float()
+        rstate = ops.MacReadState()
         w1 = m.read.concat.weight[:, :dim]
         masks = self._masks(n_img, dev)
         control = m.control_0.expand(n_img, dim)
@@ -181,10 +188,8 @@ class MACNetwork(nn.Module):
         controls, memories = [control], [memory]
         for i in range(self.max_step):
             # ControlUnit: attn(cq * context) = context . (cq * w) + b
-            pa = m.control.position_aware[i](hq)[so]
-            cq = m.control.control_question(torch.cat([control, pa], 1))
-            aw = torch.bmm(ctx, (cq * m.control.attn.weight).unsqueeze(2)).squeeze(2) + m.control.attn.bias
-            control = torch.bmm(F.softmax(aw, 1).unsqueeze(1), ctx).squeeze(1)
+            cq = m.control.control_question(torch.cat([control, pa_all[i]], 1))
+            control = ops.mac_read(ctx, None, cq * m.control.attn.weight, None, m.control.attn.bias, cstate, Lq, dim)
             if masks is not None:
                 control = control * masks[0]
             controls.append(control)
@@ -192,8 +197,7 @@ class MACNetwork(nn.Module):
             mem = m.read.mem(memories[-1])
             v = control * m.read.attn.weight
             u = mem * (v @ w1)
-            score = (torch.bmm(kn, u.unsqueeze(2)) + torch.bmm(pre, v.unsqueeze(2))).squeeze(2) + m.read.attn.bias
-            read = torch.bmm(F.softmax(score, 1).unsqueeze(1), kn).squeeze(1)
+            read = ops.mac_read(kd, pre, u, v, m.read.attn.bias, rstate, S, dim)      # fused scores/softmax/sum
             # WriteUnit
             prev = memories[-1]
             concat = m.write.concat(torch.cat([read, prev], 1))

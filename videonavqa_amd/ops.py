@@ -286,3 +286,53 @@ def packed_batch_sizes(lens_sorted, n_steps=None):
     lens = [int(v) for v in lens_sorted]
     n_steps = n_steps or lens[0]
     return [sum(1 for v in lens if v > t) for t in range(n_steps)]
+
+
+class MacReadState(object):
+    """Shared by the reasoning steps of ONE MACNetwork forward: collects each step's backward factors so that the
+    knowledge-base gradients are formed once (see MacReadFn)."""
+
+    def __init__(self):
+        self.n_calls = 0
+        self.factors = []
+
+
+class MacReadFn(torch.autograd.Function):
+    """read = ReadUnit attention of one reasoning step on the fused HIP kernel (models/mac.py:53-62 re-associated):
+    softmax_s(know.u + pre.v + bias) weighted sum of know.  know/pre [n*s, ld] in the compute dtype, u/v fp32 [n,c].
+    With pre = v = None it is a plain attention pool (ControlUnit's attention over the question words, :36-42).
+
+    Backward: du, dv (and the analytically zero bias gradient) per step; the [n,s,c]-sized gradients of know and pre
+    are outer products of small per-step factors, so steps > 0 only stash their factors and the FIRST step's backward
+    — which the engine necessarily runs last, every later step depends on its output through the memory chain —
+    forms both gradients for all steps in one pass (K.mac_read_accum)."""
+
+    @staticmethod
+    def forward(ctx, know, pre, u, v, bias, state, s, c):
+        n = know.shape[0] // s
+        u = u.float().contiguous()
+        v = None if v is None else v.float().contiguous()
+        p, read = K.mac_read_fwd(know, pre, u, v, bias.detach().float().contiguous(), n, s, c)
+        ctx.save_for_backward(know, pre, u, v, p)
+        ctx.state, ctx.dims, ctx.index = state, (n, s, c), state.n_calls
+        state.n_calls += 1
+        return read
+
+    @staticmethod
+    def backward(ctx, dread):
+        know, pre, u, v, p = ctx.saved_tensors
+        n, s, c = ctx.dims
+        dread = dread.float().contiguous()
+        dscore, du, dv = K.mac_read_bwd(know, pre, p, dread, n, s, c)
+        st = ctx.state
+        st.factors.append((dscore, p, u, v, dread))
+        dknow = dpre = None
+        if ctx.index == 0:
+            f = [None if t[0] is None else torch.stack(t) for t in zip(*st.factors)]
+            dknow, dpre = K.mac_read_accum(f[0], f[1], f[2], f[3], f[4], n, s, c, know.shape[-1], know.dtype)
+            st.factors = []
+        return dknow, dpre, du, dv, dscore.sum().view(1), None, None, None
+
+
+def mac_read(know, pre, u, v, bias, state, s, c):
+    return MacReadFn.apply(know, pre, u, v, bias, state, s, c)
