@@ -94,6 +94,22 @@ int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt
 int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
                         const float* post_scale, const float* post_shift, void* y, void* stream);
 
+/* conv1_1 + conv1_2 of the VGG front in ONE launch (get_frcnn_feature_extractor, features[0:4]; call sites
+ * eval/q_and_v_eval.py:106): the 3 -> 64 conv + ReLU is evaluated inside the c_in == 64 direct kernel for the
+ * 18x18 patch each 16x16 output tile needs, so its 64-channel output never goes to HBM.
+ *   vnqa_clip_to_nhwc4 : clip fp32 [b][3][h][w][t] (frames LAST, eval/dataset.py:63,81-91) -> img4 bf16
+ *                        [n_img][h+4][w+4][4] (image img_of[b*t+f] or -1 to skip; halo 2 and channel 3 are never
+ *                        written: zero the buffer once)
+ *   vnqa_conv_first_c64_fwd : d describes the SECOND conv (c_in = 64, h, w, c_out, relu, pool2 ...); w1 fp32
+ *                        [64][3][3][3], b1 fp32 [64] are the first conv's parameters; wt/bias/post_* as in
+ *                        vnqa_conv2d_c64_fwd; y padded NHWC bf16.
+ */
+int vnqa_clip_to_nhwc4(const float* clip, const int32_t* img_of, void* img4, int32_t b, int32_t t, int32_t h,
+                       int32_t w, void* stream);
+int vnqa_conv_first_c64_fwd(const vnqa_conv_desc* d, const void* img4, const float* w1, const float* b1,
+                            const void* wt, const float* bias, const float* post_scale,
+                            const float* post_shift, void* y, void* stream);
+
 /* First VGG conv (3 -> c_out, 3x3 pad 1) + ReLU straight from the reference's clip layout.
  * Replaces the strided frame slice v_inputs[:, :, :, :, j] + conv1_1 of the external
  * feature extractor (eval/q_and_v_eval.py:104-106; eval/dataset.py:63,81-91 for the layout).

@@ -317,3 +317,46 @@ def test_conv_patch_tile_rejects_unsupported_geometry():
     wt = torch.zeros(64, 9, 64, dtype=dt, device="cuda")
     with pytest.raises(VnqaError):
         K.conv2d_igemm(x, wt, tile=11)
+
+
+@pytest.mark.parametrize("cfg", [
+    # B, T, H, W, Cout, pool, ragged
+    (2, 3, 32, 48, 64, True, False),
+    (1, 2, 40, 24, 128, False, False),     # H, W not multiples of the 16-pixel tile; two 64-channel slices
+    (3, 4, 16, 16, 64, True, True),        # ragged frame list (img_of = -1 entries)
+])
+def test_conv_first_fused_into_c64(cfg):
+    """conv1_1 + ReLU evaluated inside the C_in=64 direct kernel (vnqa_clip_to_nhwc4 + vnqa_conv_first_c64_fwd) vs
+    torch on the same bf16-rounded operands, and vs the two-launch HIP path."""
+    from videonavqa_amd import kernels as K
+    B, T, H, W, Cout, pool, ragged = cfg
+    dt = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]))
+    clip = torch.rand(B, 3, H, W, T, generator=g).cuda()
+    w1 = (torch.randn(64, 3, 3, 3, generator=g) * 0.3).cuda()
+    b1 = (torch.randn(64, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(Cout, 64, 3, 3, generator=g) / 24.0).cuda()
+    b2 = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    order = [(b, t) for t in range(T) for b in range(B) if not (ragged and (b + t) % 3 == 2)]
+    img_of = torch.full((B * T,), -1, dtype=torch.int32)
+    for n, (b, t) in enumerate(order):
+        img_of[b * T + t] = n
+    img_of = img_of.cuda()
+    N = len(order)
+    frames = torch.stack([clip[b, :, :, :, t] for b, t in order])                       # [N,3,H,W]
+    a1 = F.relu(F.conv2d(_q(frames, dt), _q(w1, dt), b1, padding=1))
+    ref = F.relu(F.conv2d(_q(a1, dt), _q(w2, dt), b2, padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    wt = K.pack_conv_weight(w2, dt, c_out_pad=Cout, c_in_pad=64)
+    img4 = K.clip_to_nhwc4(clip, img_of, N)
+    assert float(img4[:, :2].abs().max()) == 0 and float(img4[:, :, -2:].abs().max()) == 0 and float(img4[..., 3].abs().max()) == 0
+    assert torch.equal(img4[:, 2:-2, 2:-2, :3].float(), _q(frames, dt).permute(0, 2, 3, 1))
+    y = K.conv_first_c64(img4, w1, b1, wt, bias=b2, relu=True, pool2=pool)
+    got = K.nhwc_to_nchw(y, Cout)
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 1e-2, _rel(got, ref)
+    assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0
+    assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+    two = K.conv2d_c64(K.conv_first(clip, w1, b1, img_of, N, dt), wt, bias=b2, relu=True, pool2=pool)
+    assert _rel(y.float(), two.float()) < 1e-2

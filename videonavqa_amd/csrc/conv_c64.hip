@@ -10,6 +10,13 @@
 //   D[cout][pixel] += W[tap][cout][:] . patch[pixel + tap][:]     (weights = MFMA A operand)
 // Epilogue: bias + ReLU in registers, through the (now free) patch slot for 2x2 max-pool / affine and
 // 16-byte NHWC stores.  C_out > 64 is handled by giving each workgroup one 64-channel slice.
+//
+// FUSE variant (conv1_1 + conv1_2 of the VGG front in one launch): the 64-channel input of conv1_2 is itself a
+// 3x3 conv of the 3-channel image, K = 27.  Instead of DMA-ing the 18x18x64 patch from a 1.8 GB intermediate
+// tensor, the workgroup reads the 20x20 pixels x 4 channels (3.2 KB) of the IMAGE under the patch, computes
+// conv1_1 + bias + ReLU for the 324 patch positions on MFMA (K padded to 32: one v_mfma_f32_16x16x32_bf16 per
+// 16 positions x 16 channels) and writes the result straight into the LDS patch image, zero where the position
+// lies in conv1_2's zero padding.  conv1_1's output never touches HBM (-3.7 GB of traffic per 280-frame pass).
 #include "vnqa_common.h"
 
 namespace {
@@ -22,6 +29,9 @@ constexpr int P_INSTR = (PROWS + 7) / 8;            // 41 wave-level DMA instruc
 constexpr int P_BYTES = P_INSTR * 1024;             // 41984
 constexpr int LDS_BYTES = W_BYTES + 2 * P_BYTES;    // 157696
 constexpr int CROW = 64 * 2 + 16;                   // epilogue row stride
+constexpr int IS = PS + 2;                          // fused variant: side of the image patch under the 18x18 patch
+constexpr int IN_BYTES = IS * IS * 8;               // [20][20][4 ch] bf16
+constexpr int LDS_BYTES_FUSED = W_BYTES + P_BYTES + IN_BYTES;
 
 struct C64Args {
   const char* x;
@@ -36,6 +46,9 @@ struct C64Args {
   int tilesX, tilesY, nsplit;   // nsplit = Cout / 64
   long long n_work;             // n_img * tilesY * tilesX * nsplit
   int Hyp, Wyp;
+  // fused conv1_1 (FUSE variant): x = image as [n][H+4][W+4][4] bf16 (zero halo of 2, channel 3 zero)
+  const float* w1;              // [64][27] fp32 (OIHW flattened)
+  const float* b1;              // [64]
 };
 
 __device__ __forceinline__ void glds16c(const char* src, char* lds_wave_base) {
@@ -47,7 +60,7 @@ __device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
 
 // NW = 8: wave tile 64 px x 32 couts (2 waves per SIMD); NW = 4: wave tile 64 px x 64 couts (1 wave per SIMD,
 // 8 fragment reads per 16 MFMAs instead of 6 per 8: the 8-wave shape runs close to the LDS read bandwidth).
-template <int NW>
+template <int NW, bool FUSE = false>
 __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
   constexpr int TN = NW == 8 ? 2 : 4;              // 16-cout fragments per wave
   constexpr int NT = NW * 64;
@@ -125,22 +138,105 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
     for (int e = 0; e < 4; ++e)
       bias_r[j][e] = p.bias ? p.bias[nsl * 64 + wn * 32 + 16 * j + 4 * fh + e] : 0.f;
 
+  // ---- fused conv1_1: weight fragments (A operand: cout 16j + fr, k = 8 fh + e) and per-lane tap offsets ----
+  vnqa_bf16x8 w1f[4];
+  float b1r[4][4];
+  int koff[8];
+  char* const ldsIn = smem + W_BYTES + P_BYTES;
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * fh + e;
+      const int kk = k < 27 ? k : 0;
+      const int c = kk / 9, r = (kk - 9 * c) / 3, s_ = kk - 9 * c - 3 * r;
+      koff[e] = k < 27 ? ((r * IS + s_) * 8 + c * 2) : -1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w1f[j][e] = (short)(k < 27 ? f32_to_bf16(p.w1[(16 * j + fr) * 27 + k]) : 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b1r[j][e] = p.b1[16 * j + 4 * fh + e];
+  }
+  // image pixels under the patch of tile t: thread i < 400 fetches pixel (i / 20, i % 20), 8 bytes
+  auto load_image_px = [&](long long t) -> uint2 {
+    uint2 v = make_uint2(0u, 0u);
+    if (threadIdx.x < IS * IS) {
+      int n, y0, x0;
+      tile_coords(t, n, y0, x0);
+      const int iy = threadIdx.x / IS, ix = threadIdx.x - iy * IS;
+      int gy = y0 + iy, gx = x0 + ix;                       // coordinates in the halo-2 image buffer
+      gy = gy < p.H + 4 ? gy : p.H + 3;
+      gx = gx < p.W + 4 ? gx : p.W + 3;
+      v = *(const uint2*)(p.x + (((size_t)n * (p.H + 4) + gy) * (p.W + 4) + gx) * 8);
+    }
+    return v;
+  };
+  // conv1_1 + bias + ReLU for the 324 patch positions of tile t -> LDS patch slot 0 (zero in conv1_2's padding)
+  auto compute_patch = [&](long long t) {
+    int n, y0, x0;
+    tile_coords(t, n, y0, x0);
+    char* ldsP = smem + W_BYTES;
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi) {
+      const int g = wave + NW * gi;                         // 16-position group; 21 groups cover 324 (+12) rows
+      if (g * 16 >= PROWS) break;
+      const int pr = g * 16 + fr;
+      const int prc = pr < PROWS ? pr : PROWS - 1;
+      const int py = prc / PS, px = prc - py * PS;
+      const char* base = ldsIn + (py * IS + px) * 8;
+      vnqa_bf16x8 xb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xb[e] = koff[e] >= 0 ? *(const short*)(base + koff[e]) : (short)0;
+      const int gy = y0 + py, gx = x0 + px;                 // padded (halo 1) coordinates of conv1_2's input
+      const bool inside = pr < PROWS && gy >= 1 && gy <= p.H && gx >= 1 && gx <= p.W;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vnqa_f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j], xb, a1, 0, 0, 0);
+        uint2 pk = make_uint2(0u, 0u);
+        if (inside) {
+          pk.x = (unsigned)f32_to_bf16(fmaxf(a1[0] + b1r[j][0], 0.f)) | ((unsigned)f32_to_bf16(fmaxf(a1[1] + b1r[j][1], 0.f)) << 16);
+          pk.y = (unsigned)f32_to_bf16(fmaxf(a1[2] + b1r[j][2], 0.f)) | ((unsigned)f32_to_bf16(fmaxf(a1[3] + b1r[j][3], 0.f)) << 16);
+        }
+        if (pr < PROWS)
+          *(uint2*)(ldsP + pr * 128 + (((2 * j + (fh >> 1)) ^ swz128(pr)) << 4) + ((fh & 1) << 3)) = pk;
+      }
+    }
+  };
+
   long long t_cur = gslot;
-  if (t_cur < tiles_total) issue_patch(t_cur, 0);
-  if (t_cur + gstride < tiles_total) issue_patch(t_cur + gstride, 1);
+  uint2 img_px = make_uint2(0u, 0u);
+  if constexpr (FUSE) {
+    if (t_cur < tiles_total) img_px = load_image_px(t_cur);
+  } else {
+    if (t_cur < tiles_total) issue_patch(t_cur, 0);
+    if (t_cur + gstride < tiles_total) issue_patch(t_cur + gstride, 1);
+  }
 
   int it = 0;
   for (; t_cur < tiles_total; t_cur += gstride, ++it) {
-    const int slot = it & 1;
+    const int slot = FUSE ? 0 : (it & 1);
     const bool have_next = t_cur + gstride < tiles_total;
-    // everything but the youngest patch (tile it+1) must have landed: weights, this tile's patch
-    if (have_next) {
-      if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI + 1) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI) : "memory");
+    if constexpr (FUSE) {
+      // image pixels (prefetched into registers during the previous tile) -> LDS, conv1_1 into the patch slot
+      if (threadIdx.x < IS * IS) *(uint2*)(ldsIn + threadIdx.x * 8) = img_px;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (also: the resident weights have landed)
+      __builtin_amdgcn_s_barrier();
+      compute_patch(t_cur);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (have_next) img_px = load_image_px(t_cur + gstride);          // in flight under this tile's MFMA loop
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // everything but the youngest patch (tile it+1) must have landed: weights, this tile's patch
+      if (have_next) {
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
     }
-    __builtin_amdgcn_s_barrier();
 
     const char* ldsP = smem + W_BYTES + slot * P_BYTES;
     vnqa_f32x4 acc[4][TN];
@@ -256,24 +352,51 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // C tile consumed: the slot may be refilled
-    if (t_cur + 2 * (long long)gstride < tiles_total) issue_patch(t_cur + 2 * (long long)gstride, slot);
+    if constexpr (!FUSE) {
+      if (t_cur + 2 * (long long)gstride < tiles_total) issue_patch(t_cur + 2 * (long long)gstride, slot);
+    }
+  }
+}
+
+// clip fp32 [B][3][H][W][T] (frames last) -> image list [n_img][H+4][W+4][4] bf16 (halo 2 and channel 3 stay zero:
+// the caller zeroes the buffer once).  One workgroup per (32-pixel run, row, sample): the 3 x 32 x T floats are read
+// as three contiguous runs, transposed through LDS, and every frame writes 32 x 8 contiguous bytes.
+__global__ void __launch_bounds__(256) clip_to_nhwc4_kernel(const float* __restrict__ clip, const int* __restrict__ img_of,
+                                                            unsigned short* __restrict__ out, int T, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float stage[];     // [3][32][T]
+  const int x0 = blockIdx.x * 32, y = blockIdx.y, b = blockIdx.z;
+  const int nx = min(32, W - x0);
+  const int run = nx * T;
+  for (int c = 0; c < 3; ++c) {
+    const float* src = clip + ((((size_t)b * 3 + c) * H + y) * W + x0) * (size_t)T;
+    for (int i = threadIdx.x; i < run; i += 256) stage[c * 32 * T + i] = src[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < T * nx; i += 256) {
+    const int t = i / nx, px = i - t * nx;
+    const int img = img_of[b * T + t];
+    if (img < 0) continue;
+    uint2 o;
+    o.x = (unsigned)f32_to_bf16(stage[px * T + t]) | ((unsigned)f32_to_bf16(stage[32 * T + px * T + t]) << 16);
+    o.y = (unsigned)f32_to_bf16(stage[2 * 32 * T + px * T + t]);
+    *(uint2*)(out + ((((size_t)img * (H + 4)) + y + 2) * (W + 4) + x0 + px + 2) * 4) = o;
   }
 }
 
 }  // namespace
 
-// 3x3 'same' conv for c_in == 64, bf16, fused bias/ReLU/pool2/affine; x and y padded NHWC with halo 1.
-extern "C" int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
-                                   const float* post_scale, const float* post_shift, void* y, void* stream) {
-  VNQA_CHECK_ARG(d && x && wt && y, "conv2d_c64_fwd: null pointer");
-  VNQA_CHECK_ARG(d->dtype == VNQA_BF16, "conv2d_c64_fwd: bf16 only");
+namespace {
+
+int c64_fill(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias, const float* post_scale,
+             const float* post_shift, void* y, C64Args& a, const char* who) {
+  VNQA_CHECK_ARG(d && x && wt && y, "%s: null pointer", who);
+  VNQA_CHECK_ARG(d->dtype == VNQA_BF16, "%s: bf16 only", who);
   VNQA_CHECK_ARG(d->c_in == 64 && d->taps == 9 && d->x_halo == 1 && d->y_halo == 1,
-                 "conv2d_c64_fwd: needs c_in == 64, taps == 9, halos == 1");
+                 "%s: needs c_in == 64, taps == 9, halos == 1", who);
   VNQA_CHECK_ARG(d->c_out % 64 == 0 && d->c_out >= 64 && d->c_y >= d->c_out && d->c_y % 8 == 0,
-                 "conv2d_c64_fwd: c_out must be a multiple of 64 (got %d)", d->c_out);
-  VNQA_CHECK_ARG(!d->pool2 || (d->h % 2 == 0 && d->w % 2 == 0), "conv2d_c64_fwd: pool2 needs even h,w");
-  VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv2d_c64_fwd: post_scale/post_shift must come together");
-  C64Args a;
+                 "%s: c_out must be a multiple of 64 (got %d)", who, d->c_out);
+  VNQA_CHECK_ARG(!d->pool2 || (d->h % 2 == 0 && d->w % 2 == 0), "%s: pool2 needs even h,w", who);
+  VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "%s: post_scale/post_shift must come together", who);
   a.x = (const char*)x;
   a.wt = (const char*)wt;
   a.bias = bias;
@@ -296,6 +419,27 @@ extern "C" int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const
   const int ho = d->pool2 ? d->h / 2 : d->h, wo = d->pool2 ? d->w / 2 : d->w;
   a.Hyp = ho + 2;
   a.Wyp = wo + 2;
+  a.w1 = nullptr;
+  a.b1 = nullptr;
+  return VNQA_OK;
+}
+
+long long c64_grid(const C64Args& a) {
+  long long grid = 256;                       // one persistent workgroup per CU
+  grid = grid / a.nsplit * a.nsplit;
+  if (grid > a.n_work) grid = (a.n_work / a.nsplit) * a.nsplit;
+  if (grid < a.nsplit) grid = a.nsplit;
+  return grid;
+}
+
+}  // namespace
+
+// 3x3 'same' conv for c_in == 64, bf16, fused bias/ReLU/pool2/affine; x and y padded NHWC with halo 1.
+extern "C" int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
+                                   const float* post_scale, const float* post_shift, void* y, void* stream) {
+  C64Args a;
+  const int rc = c64_fill(d, x, wt, bias, post_scale, post_shift, y, a, "conv2d_c64_fwd");
+  if (rc != VNQA_OK) return rc;
   const bool four = d->tile == 2;   // tile == 2 selects the 4-wave shape (A/B runs: 15 % slower); default = 8 waves
   static bool attr_set = false;
   if (!attr_set) {
@@ -306,14 +450,48 @@ extern "C" int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const
     }
     attr_set = true;
   }
-  long long grid = 256;                       // one persistent workgroup per CU
-  grid = grid / a.nsplit * a.nsplit;
-  if (grid > a.n_work) grid = (a.n_work / a.nsplit) * a.nsplit;
-  if (grid < a.nsplit) grid = a.nsplit;
+  const long long grid = c64_grid(a);
   if (four)
     hipLaunchKernelGGL(conv_c64_kernel<4>, dim3((int)grid), dim3(256), LDS_BYTES, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(conv_c64_kernel<8>, dim3((int)grid), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+// conv(3 -> 64) + ReLU fused into the following conv(64 -> c_out): `img4` is the image list [n][h+4][w+4][4] bf16
+// produced by vnqa_clip_to_nhwc4; w1/b1 are the first conv's OIHW fp32 weights [64][3][3][3] and bias.
+extern "C" int vnqa_conv_first_c64_fwd(const vnqa_conv_desc* d, const void* img4, const float* w1, const float* b1,
+                                       const void* wt, const float* bias, const float* post_scale,
+                                       const float* post_shift, void* y, void* stream) {
+  C64Args a;
+  const int rc = c64_fill(d, img4, wt, bias, post_scale, post_shift, y, a, "conv_first_c64_fwd");
+  if (rc != VNQA_OK) return rc;
+  VNQA_CHECK_ARG(w1 && b1, "conv_first_c64_fwd: null first-layer weights");
+  a.w1 = w1;
+  a.b1 = b1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_c64_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES_FUSED) != hipSuccess) {
+      vnqa_set_error("conv_first_c64_fwd: cannot reserve %d B of LDS", LDS_BYTES_FUSED);
+      return VNQA_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_c64_kernel<8, true>), dim3((int)c64_grid(a)), dim3(512), LDS_BYTES_FUSED, (hipStream_t)stream, a);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_clip_to_nhwc4(const float* clip, const int32_t* img_of, void* img4, int32_t b, int32_t t, int32_t h,
+                                  int32_t w, void* stream) {
+  VNQA_CHECK_ARG(clip && img_of && img4, "clip_to_nhwc4: null pointer");
+  VNQA_CHECK_ARG(b > 0 && t > 0 && h > 0 && w > 0, "clip_to_nhwc4: empty problem");
+  const size_t lds = (size_t)3 * 32 * t * sizeof(float);
+  VNQA_CHECK_ARG(lds <= 64 * 1024, "clip_to_nhwc4: t=%d frames do not fit the LDS stage", t);
+  hipLaunchKernelGGL(clip_to_nhwc4_kernel, dim3((w + 31) / 32, h, b), dim3(256), lds, (hipStream_t)stream, clip, img_of,
+                     (unsigned short*)img4, t, h, w);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

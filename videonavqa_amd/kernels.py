@@ -92,6 +92,35 @@ def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_
     return out
 
 
+def clip_to_nhwc4(clip, img_of, n_img, out=None):
+    """clip fp32 [B,3,H,W,T] (frames last) -> image list bf16 [n_img,H+4,W+4,4] (halo 2 and channel 3 zero)."""
+    B, C, H, W, T = clip.shape
+    assert C == 3 and clip.dtype == torch.float32
+    if out is None:
+        out = torch.zeros((n_img, H + 4, W + 4, 4), dtype=torch.bfloat16, device=clip.device)
+    L.check(L.lib().vnqa_clip_to_nhwc4(L.ptr(clip.contiguous()), L.ptr(img_of), L.ptr(out), B, T, H, W, L.stream()),
+            "vnqa_clip_to_nhwc4")
+    return out
+
+
+def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None):
+    """conv(3->64)+ReLU fused into the following C_in = 64 conv (see vnqa_conv_first_c64_fwd).  img4 from clip_to_nhwc4;
+    w1/b1 the first conv's fp32 OIHW weights and bias; wt/bias/... as conv2d_c64."""
+    N, Hp4, Wp4, c4 = img4.shape
+    H, W = Hp4 - 4, Wp4 - 4
+    c_out, taps, cin_w = wt.shape
+    assert c4 == 4 and cin_w == 64 and taps == 9 and img4.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16
+    Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
+    if out is None:
+        out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=img4.dtype, device=img4.device)
+    d = L.ConvDesc(L.BF16, N, H, W, 64, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0, 0)
+    L.check(L.lib().vnqa_conv_first_c64_fwd(ctypes.byref(d), L.ptr(img4), L.ptr(w1.detach().float().contiguous()),
+                                            L.ptr(b1.detach().float().contiguous()), L.ptr(wt), L.ptr(bias),
+                                            L.ptr(post_scale), L.ptr(post_shift), L.ptr(out), L.stream()),
+            "vnqa_conv_first_c64_fwd")
+    return out
+
+
 def conv_first(clip, w, bias, img_of, n_img, dtype, out=None):
     """clip fp32 [B,3,H,W,T] -> padded NHWC [n_img,H+2,W+2,64] (conv1_1 + ReLU)."""
     B, C, H, W, T = clip.shape

@@ -135,12 +135,12 @@ class FrozenStem(object):
             self._bufs[key] = cap
         return cap[:shape[0]]
 
-    def _run(self, x, layers, tag, last_slot=0):
-        for i, ly in enumerate(layers):
+    def _run(self, x, layers, tag, last_slot=0, first_index=0):
+        for i, ly in enumerate(layers, first_index):
             n, hp, wp, _ = x.shape
             h, w = hp - 2, wp - 2
             ho, wo = (h // 2, w // 2) if ly["pool"] else (h, w)
-            key = (tag, i, ho, wo) if i + 1 < len(layers) else (tag, i, ho, wo, last_slot)
+            key = (tag, i, ho, wo) if i + 1 < len(layers) + first_index else (tag, i, ho, wo, last_slot)
             out = self._buf(key, (n, ho + 2, wo + 2, ly["c_out_pad"]))
             post = ly["post"]
             tile = ly["tile"]
@@ -170,9 +170,23 @@ class FrozenStem(object):
         features of step i stay alive for its backward while step i+1's stem already runs."""
         assert self.vgg is not None and self.objdet is not None
         B, _, H, W, T = clip.shape
-        a = self._buf(("first", H, W), (n_img, H + 2, W + 2, 64))
-        K.conv_first(clip, self.first[0], self.first[1], img_of, n_img, self.cdt, out=a)
-        x = self._run(a, self.layers_vgg, "vgg")
+        ly = self.layers_vgg[0]
+        if self.cdt == torch.bfloat16 and ly["tile"] is None and os.environ.get("VNQA_FUSE_FIRST", "1") != "0":
+            # conv1_1 evaluated inside the conv1_2 kernel from a 4-channel bf16 image list: its 64-channel output
+            # (1.8 GB at 280 x 224 x 224) never goes to HBM
+            img4 = self._buf(("img4", H, W), (n_img, H + 4, W + 4, 4))
+            K.clip_to_nhwc4(clip, img_of, n_img, out=img4)
+            ho, wo = (H // 2, W // 2) if ly["pool"] else (H, W)
+            out = self._buf(("vgg", 0, ho, wo), (n_img, ho + 2, wo + 2, ly["c_out_pad"]))
+            post = ly["post"]
+            x = K.conv_first_c64(img4, self.first[0], self.first[1], ly["wt"], bias=ly["bias"], relu=ly["relu"],
+                                 pool2=ly["pool"], post_scale=post[0] if post else None,
+                                 post_shift=post[1] if post else None, out=out)
+            x = self._run(x, self.layers_vgg[1:], "vgg", first_index=1)
+        else:
+            a = self._buf(("first", H, W), (n_img, H + 2, W + 2, 64))
+            K.conv_first(clip, self.first[0], self.first[1], img_of, n_img, self.cdt, out=a)
+            x = self._run(a, self.layers_vgg, "vgg")
         return self._run(x, self.layers_od, "od", last_slot=slot)
 
     # ---- drop-in per-module paths (reference tensor layouts in and out) -----------------------
