@@ -108,13 +108,27 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
     }
   };
 
+#ifdef VNQA_WGRAD_MFMA32
+  constexpr bool kMma16 = false;
+#else
+  constexpr bool kMma16 = (ES == 2);       // bf16: v_mfma_f32_16x16x32_bf16 (8 x 4 tiles of 16x16 per wave)
+#endif
   vnqa_f32x16 acc[TM][TN];
+  vnqa_f32x4 acc16[kMma16 ? 8 : 1][kMma16 ? 4 : 1];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  if constexpr (kMma16) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
+  }
 
   const int k_begin = slice * p.ksteps_per_slice;
   int k_end = k_begin + p.ksteps_per_slice;
@@ -132,7 +146,54 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
       if (kt + 1 < k_end) stage(kt + 1, cur ^ 1);
       const char* ldsA = smem + cur * STAGE_BYTES;
       const char* ldsB = ldsA + TILE_BYTES;
-      if constexpr (ES == 2) {
+      if constexpr (kMma16) {
+        // 16x16x32: the 16-lane group g supplies pixels 32 s + 8 g .. + 7 (two 4-row transposed reads) of 16 channels;
+        // fragments of substep s+1 are read before the MFMAs of substep s are issued
+        auto load16 = [&](int s, vnqa_bf16x8* af, vnqa_bf16x8* bf) {
+          const int row0 = 32 * s + 8 * g + q4;
+          const int sw = (row0 & 3) << 2;
+          const int sub = (pp & 1) << 3;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int off = ((((wm * 128 + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4;
+            const s16x4 lo = lds_tr_read(ldsA + row0 * RB + off + sub);
+            const s16x4 hi = lds_tr_read(ldsA + (row0 + 4) * RB + off + sub);
+            af[i] = vnqa_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int off = ((((wn * 64 + j * 16) >> 3) + (pp >> 1)) ^ sw) << 4;
+            const s16x4 lo = lds_tr_read(ldsB + row0 * RB + off + sub);
+            const s16x4 hi = lds_tr_read(ldsB + (row0 + 4) * RB + off + sub);
+            bf[j] = vnqa_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          }
+        };
+#ifdef VNQA_WGRAD_PREFETCH   // register double-buffering of the fragments: 22 VGPR spills at 256 registers, measured slower
+        vnqa_bf16x8 af[2][8], bf[2][4];
+        load16(0, af[0], bf[0]);
+#pragma unroll
+        for (int s = 0; s < KP / 32; ++s) {
+          if (s + 1 < KP / 32) load16(s + 1, af[(s + 1) & 1], bf[(s + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s & 1][i], bf[s & 1][j], acc16[i][j], 0, 0, 0);
+        }
+#else
+#pragma unroll
+        for (int s = 0; s < KP / 32; ++s) {
+          vnqa_bf16x8 af[8], bf[4];
+          load16(s, af, bf);
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc16[i][j], 0, 0, 0);
+        }
+#endif
+      } else if constexpr (ES == 2) {
 #pragma unroll
         for (int s = 0; s < KP / 16; ++s) {
           // lane supplies row (16 s + 8 (g>>1) + q4 [+4]), 4 channels starting at 16(g&1) + 4 pp
@@ -183,6 +244,22 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
 
   // ---- store the partial tile: D[co][ci], co = (reg&3)+8(reg>>2)+4 fh, ci = fr ----
   float* slab = p.out + (size_t)slice * p.Cout * p.taps * p.Cin;
+  if constexpr (kMma16) {
+    // D[co = 16 i + 4 (lane>>4) + e][ci = 16 j + (lane&15)]
+    const int r16 = lane & 15, h16 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ci = tile_ci * BCH + wn * 64 + j * 16 + r16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = tile_co * BCH + wm * 128 + i * 16 + 4 * h16 + e;
+          if (co < p.Cout && ci < p.Cin) slab[((size_t)co * p.taps + tap) * p.Cin + ci] = acc16[i][j][e];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -270,12 +347,15 @@ Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype) {
   pl.tilesCi = (c_in + 255) / 256;
   pl.ksteps_total = (int)((pl.Ptot + KP - 1) / KP);
   const int tiles = pl.tilesCo * pl.tilesCi * taps;
-  // one workgroup per CU (128 KiB LDS): aim for the largest grid <= 2 x 256 so the launch is two FULL rounds
-  // (36 tiles: 14 slices = 504 workgroups; 15 slices = 540 would need a third, 89 % empty round)
-#ifdef VNQA_WGRAD_CEIL_SLICES   // A/B: the previous rule
+  // one workgroup per CU (128 KiB LDS): ONE full round of <= 256 workgroups.  Same-box A/B on the 512x512x3x3 layer
+  // (36 tiles): 7 slices = 252 workgroups 0.433 ms, 14 slices = 504 workgroups (two rounds) 0.472 ms — half the
+  // fp32 slab traffic for the same MFMA work; 15 slices = 540 needed a third, 89 % empty round.
+#if defined(VNQA_WGRAD_CEIL_SLICES)     // A/B: earlier rules
   int slices = (512 + tiles - 1) / tiles;
-#else
+#elif defined(VNQA_WGRAD_TWO_ROUNDS)
   int slices = 512 / tiles;
+#else
+  int slices = 256 / tiles;
 #endif
   const int max_slices = pl.ksteps_total / 8 > 0 ? pl.ksteps_total / 8 : 1;
   slices = slices < 1 ? 1 : (slices > max_slices ? max_slices : slices);
