@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, 
   const float n = (float)((i1 - i0) * (hp - 2) * (wp - 2));
   const T* base = x + (size_t)i0 * hp * wp * c + cg * 64 + chunk * 8;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (long long p = prow; p < P; p += 32) {   // halo is zero: plain sum over every padded position
+#pragma unroll 4
+  for (long long p = prow; p < P; p += 32) {   // halo is zero: plain sum over every padded position (4 loads in flight)
     float v[8];
     load8<T>(base + (size_t)p * c, v);
 #pragma unroll
@@ -95,6 +96,7 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, 
 #pragma unroll
   for (int e = 0; e < 8; ++e) m[e] = s_mean[chunk * 8 + e];
   const int hw = hp * wp;
+#pragma unroll 4
   for (long long p = prow; p < P; p += 32) {   // second pass (L2-resident): centred sum of squares, interior only
     if (!is_interior((int)(p % hw), hp, wp)) continue;
     float v[8];
