@@ -85,3 +85,42 @@ def test_cli_synthetic_train_val_checkpoint_resume(model, tmp_path, capsys):
         import numpy as np
         t, p = np.load(tmp_path / "t_ck.pt.npy"), np.load(tmp_path / "p_ck.pt.npy")
         assert t.shape == (5,) and p.shape == (5,)
+
+
+def test_single_modality_parsers_match_reference_defaults():
+    """Flag names / defaults of eval/q_only_eval.py:20-44 and eval/v_only_cnn3d_eval.py:21-38."""
+    from videonavqa_amd.eval import q_only_eval as Q, v_only_cnn3d_eval as V3
+    a = Q.build_parser().parse_args([])
+    assert (a.embed_size, a.hidden_size, a.num_classes, a.vocab_size, a.batch_size, a.l_rate, a.num_epochs,
+            a.stats_after_every, a.use_class_weights, a.num_workers, a.model) == (128, 128, 70, 134, 1024, 1e-5, 1000, 50,
+                                                                                  True, 4, 'lstm')
+    b = V3.build_parser().parse_args([])
+    assert (b.num_classes, b.use_class_weights, b.batch_size, b.l_rate, b.num_epochs, b.num_workers, b.stats_after_every,
+            b.val_only, b.loss_reduction) == (70, False, 8, 1e-4, 1, 4, 1000, False, None)
+
+
+@pytest.mark.gpu
+def test_q_only_cli_synthetic(tmp_path, capsys):
+    """Ladder config 1: 1k synthetic encoded questions through the q_only entry point."""
+    from videonavqa_amd.eval import q_only_eval as Q
+    os.chdir(tmp_path)
+    Q.main(["--synthetic", "1000", "--batch_size", "250", "--num_epochs", "2", "--stats_after_every", "1",
+            "--num_workers", "0", "--l_rate", "1e-3", "--checkpoint_path", "q.pt"])
+    out = capsys.readouterr().out
+    assert "1000 train examples" in out and out.count("Train Epoch:") == 2 and out.count("Validation:") == 2
+    ck = torch.load(tmp_path / "q.pt", map_location="cpu")
+    assert set(ck) == {"epoch", "model", "state_dict", "val_acc", "optimizer"} and ck["model"] == "lstm"
+
+
+@pytest.mark.gpu
+def test_v_only_cnn3d_cli_synthetic(tmp_path, capsys):
+    """Ladder config 2 geometry (16x112x112 clips), tiny run: train, checkpoint, resume."""
+    from videonavqa_amd.eval import v_only_cnn3d_eval as V3
+    os.chdir(tmp_path)
+    argv = ["--synthetic", "8", "--batch_size", "4", "--num_workers", "0", "--checkpoint_path", "c.pt"]
+    V3.main(argv)
+    out = capsys.readouterr().out
+    assert "Train Epoch: 0" in out and "Validation:" in out and (tmp_path / "e0_c.pt").exists()
+    os.replace(tmp_path / "e0_c.pt", tmp_path / "c.pt")
+    V3.main(argv)
+    assert "Restored checkpoint c.pt (epoch 1)" in capsys.readouterr().out
