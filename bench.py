@@ -263,6 +263,8 @@ def main():
     else:
         def run_step():
             return trainer.step(*batch, **nxt)
+    for _ in range(3):        # priming (lazy HIP attribute calls, allocator growth, pinned staging): not part of --warmup
+        run_step()
     for _ in range(args.warmup):
         run_step()
     stem.timing = []          # (start, end) HIP events around every stem-tagged igemm launch

@@ -261,6 +261,18 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       wf[j] = *(const vnqa_f32x4*)(lds + w_rd[j] + (((CPS * s + fh) ^ w_sw[j]) << 4));
   };
   auto compute = [&](const char* lds) {
+    if constexpr (NW == 16) {     // 4 waves per SIMD: 128-VGPR budget, the other waves hide the LDS latency
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) {
+        vnqa_f32x4 xf1[TM], wf1[TN];
+        load_frags(lds, s, xf1, wf1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mma<T>::run(wf1[j], xf1[i], acc[i][j]);
+      }
+      return;
+    }
 #ifdef VNQA_NO_FRAG_PREFETCH
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
@@ -512,6 +524,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_P4_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, 0, 4>(a, st);
       case VNQA_TILE_P4_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, 0, 4>(a, st);
       case VNQA_TILE_P4_256x64: return launch<vnqa_bf16, 256, 64, 4, 1, 0, 4>(a, st);
+      case VNQA_TILE_256x256_W16: return launch<vnqa_bf16, 256, 256, 4, 4, 2>(a, st);
       case VNQA_TILE_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 0, st);
       case VNQA_TILE_STEM_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 1, st);
       default: break;
