@@ -15,6 +15,12 @@
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// hardware exp2 / rcp forms for the in-loop activations (every cell of the ~800-cell chain waits for them):
+// sigmoid(x) = rcp(1 + 2^(-x log2 e)), tanh(x) = 2 sigmoid(2x) - 1; relative error ~1e-6, limits +-inf exact
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.442695040888963f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) { return 2.f * fast_sigmoid(2.f * x) - 1.f; }
 
 struct LstmArgs {
   const float* xg;     // [B][Lq][4H]  (gate order i,f,g,o; all biases folded in)
@@ -71,15 +77,18 @@ __global__ void __launch_bounds__(4 * H) lstm_seq_fwd_kernel(const LstmArgs p) {
       acc2 = fmaf(w[k + 2], hv.z, acc2);
       acc3 = fmaf(w[k + 3], hv.w, acc3);
     }
-    s_g[j] = (acc + acc1) + (acc2 + acc3);
+    // every thread activates ITS gate row (j / H: i, f, g, o) before the barrier: the four transcendental
+    // evaluations of a unit run in parallel on four threads instead of in sequence on one
+    const float pre = (acc + acc1) + (acc2 + acc3);
+    s_g[j] = (j >= 2 * H && j < 3 * H) ? fast_tanh(pre) : fast_sigmoid(pre);
     __syncthreads();
     if (j < H) {
-      const float ig = sigmoidf_(s_g[j]);
-      const float fg = sigmoidf_(s_g[H + j]);
-      const float gg = tanhf(s_g[2 * H + j]);
-      const float og = sigmoidf_(s_g[3 * H + j]);
+      const float ig = s_g[j];
+      const float fg = s_g[H + j];
+      const float gg = s_g[2 * H + j];
+      const float og = s_g[3 * H + j];
       c = fg * c + ig * gg;
-      const float h = og * tanhf(c);
+      const float h = og * fast_tanh(c);
       s_h[j] = h;
       hs_b[(size_t)t * H + j] = h;
       float* gt = gt_b + (size_t)t * 5 * H;
@@ -117,14 +126,29 @@ __global__ void __launch_bounds__(4 * H) lstm_seq_bwd_kernel(const LstmArgs p) {
     if (p.dhN) dh_rec = p.dhN[(size_t)b * H + tid];
     if (p.dcN) dc = p.dcN[(size_t)b * H + tid];
   }
+  // the saved gates / c / external dh of a cell do not depend on the recurrence: fetch cell t-1's while cell t
+  // is processed (an L2 round trip per cell on the critical path otherwise)
+  float n_ig = 0.f, n_fg = 0.f, n_gg = 0.f, n_og = 0.f, n_ct = 0.f, n_cp = 0.f, n_dh = 0.f;
+  auto fetch = [&](int t) {
+    if (tid < H && t >= 0) {
+      const float* gt = gt_b + (size_t)t * 5 * H;
+      n_ig = gt[tid];
+      n_fg = gt[H + tid];
+      n_gg = gt[2 * H + tid];
+      n_og = gt[3 * H + tid];
+      n_ct = gt[4 * H + tid];
+      n_cp = t > 0 ? gt_b[(size_t)(t - 1) * 5 * H + 4 * H + tid] : p.c0[(size_t)b * H + tid];
+      n_dh = dhs_b[(size_t)t * H + tid];
+    }
+  };
+  fetch(steps - 1);
   for (int t = steps - 1; t >= 0; --t) {
+    const float ig = n_ig, fg = n_fg, gg = n_gg, og = n_og, ct = n_ct, cprev = n_cp, dh_ext = n_dh;
+    fetch(t - 1);
     if (tid < H) {
       const int u = tid;
-      const float* gt = gt_b + (size_t)t * 5 * H;
-      const float ig = gt[u], fg = gt[H + u], gg = gt[2 * H + u], og = gt[3 * H + u], ct = gt[4 * H + u];
-      const float cprev = t > 0 ? gt_b[(size_t)(t - 1) * 5 * H + 4 * H + u] : p.c0[(size_t)b * H + u];
-      const float dh = dhs_b[(size_t)t * H + u] + dh_rec;
-      const float tc = tanhf(ct);
+      const float dh = dh_ext + dh_rec;
+      const float tc = fast_tanh(ct);
       const float d_o = dh * tc * og * (1.f - og);
       dc += dh * og * (1.f - tc * tc);
       const float d_i = dc * gg * ig * (1.f - ig);
