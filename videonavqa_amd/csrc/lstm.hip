@@ -105,6 +105,9 @@ __global__ void __launch_bounds__(4 * H) lstm_seq_fwd_kernel(const LstmArgs p) {
     p.hN[(size_t)b * H + j] = s_h[j];
     p.cN[(size_t)b * H + j] = c;
   }
+  // rows past this sample's last cell: h = 0 (the callers' dW_hh GEMM runs over all S rows); the gates rows there are
+  // never read.  Callers may therefore pass uninitialised buffers.
+  for (size_t i = (size_t)steps * H + j; i < (size_t)p.S * H; i += 4 * H) hs_b[i] = 0.f;
 }
 
 template <int H>
@@ -183,6 +186,8 @@ __global__ void __launch_bounds__(4 * H) lstm_seq_bwd_kernel(const LstmArgs p) {
     p.dh0[(size_t)b * H + tid] = dh_rec;
     p.dc0[(size_t)b * H + tid] = dc;
   }
+  // zero gate gradients on the rows past this sample's last cell (consumed by the callers' GEMM / scatter)
+  for (size_t i = (size_t)steps * 4 * H + tid; i < (size_t)p.S * 4 * H; i += 4 * H) dg_b[i] = 0.f;
 }
 
 template <int H>

@@ -243,8 +243,8 @@ def lstm_seq_fwd(xg, w_hh, q_lens_i32, h0, c0, n_rep, S):
     B, Lq, H4 = xg.shape
     H = H4 // 4
     dev = xg.device
-    hs = torch.zeros((B, S, H), dtype=torch.float32, device=dev)
-    gates = torch.zeros((B, S, 5 * H), dtype=torch.float32, device=dev)
+    hs = torch.empty((B, S, H), dtype=torch.float32, device=dev)         # the kernel zero-fills the rows past each chain
+    gates = torch.empty((B, S, 5 * H), dtype=torch.float32, device=dev)  # rows past a chain's end are never read
     hN = torch.empty((B, H), dtype=torch.float32, device=dev)
     cN = torch.empty((B, H), dtype=torch.float32, device=dev)
     L.check(L.lib().vnqa_lstm_seq_fwd(L.ptr(xg), L.ptr(w_hh), L.ptr(q_lens_i32), L.ptr(h0), L.ptr(c0), L.ptr(hs),
@@ -258,7 +258,7 @@ def lstm_seq_bwd(w_hh, q_lens_i32, c0, gates, dhs, dhN, dcN, n_rep):
     B, S, H5 = gates.shape
     H = H5 // 5
     dev = gates.device
-    dgates = torch.zeros((B, S, 4 * H), dtype=torch.float32, device=dev)
+    dgates = torch.empty((B, S, 4 * H), dtype=torch.float32, device=dev)  # tail rows zero-filled by the kernel
     dh0 = torch.empty((B, H), dtype=torch.float32, device=dev)
     dc0 = torch.empty((B, H), dtype=torch.float32, device=dev)
     L.check(L.lib().vnqa_lstm_seq_bwd(L.ptr(w_hh), L.ptr(q_lens_i32), L.ptr(c0), L.ptr(gates), L.ptr(dhs),

@@ -169,7 +169,7 @@ def film_relu_residual(z, res, gamma, beta, cdt):
     return ops.film_relu_res(z, res, pad_channels(gamma, c_pad), pad_channels(beta, c_pad))
 
 
-def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=False):
+def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=False, wgrad_dtype=torch.float32):
     """The question LSTM re-run once per frame with its state carried over
     (film_attn_pt_stem.py:146-171 called from :213) == one chain per sample made of its q_len
     tokens repeated n_frames times — ONE persistent HIP launch (ops.lstm_seq).
@@ -185,7 +185,7 @@ def repeated_question_lstm(lstm, emb, q_lens, n_frames, h0, c0, want_states=Fals
     H = lstm.hidden_size
     # input projection is identical at every repeat: once per token, both biases folded in
     xg = F.linear(emb, lstm.weight_ih_l0, lstm.bias_ih_l0 + lstm.bias_hh_l0)
-    out, hn, cn = ops.lstm_seq(xg, lstm.weight_hh_l0, h0, c0, ql.to(torch.int32), n_frames, S)   # [B,S,H]
+    out, hn, cn = ops.lstm_seq(xg, lstm.weight_hh_l0, h0, c0, ql.to(torch.int32), n_frames, S, wgrad_dtype)   # [B,S,H]
     rep = torch.arange(n_frames, device=dev).unsqueeze(0)                                   # [1,F]
     last_idx = rep * ql.unsqueeze(1) + ql.unsqueeze(1) - 1                                  # [B,F]
     h_last = out.gather(1, last_idx.unsqueeze(2).expand(B, n_frames, H))

@@ -68,7 +68,8 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         # FiLM generator: question LSTM re-run per processed frame with carried state (:213)
         emb = self.embed(q_input)
         h0, c0 = self._question_state(B, self.hidden_size, q_lens, dev)
-        h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0)
+        h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
+                                                        wgrad_dtype=self.compute_dtype)
         self._store_question_state(hn, cn, q_lens)
         film = F.relu(self.film_layer[1](h_last))                       # [B, n_frames, 2*C*blocks] (:179)
         film_img = film[lay.sample_of, lay.frame_of]                    # [n_img, 2*C*blocks]
@@ -105,6 +106,6 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         gi = F.linear(ctxt, self.lstm_attn.weight_ih, self.lstm_attn.bias_ih + self.lstm_attn.bias_hh)
         zeros = torch.zeros(B, at, device=dev)
         ones = torch.ones(B, dtype=torch.int32, device=dev)
-        hs, _, _ = ops.lstm_seq(gi.unsqueeze(1), self.lstm_attn.weight_hh, zeros, zeros, ones, T, T)
+        hs, _, _ = ops.lstm_seq(gi.unsqueeze(1), self.lstm_attn.weight_hh, zeros, zeros, ones, T, T, self.compute_dtype)
         hs = hs.reshape(B, T * at)
         return self.out_linear(hs)                                      # :301

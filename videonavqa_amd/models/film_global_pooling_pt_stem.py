@@ -52,7 +52,8 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
         C = self.num_res_block_channels
         emb = self.embed(q_input)
         h0, c0 = self._question_state(lay.B, self.hidden_size, q_lens, x.device)
-        h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0)
+        h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
+                                                        wgrad_dtype=self.compute_dtype)
         self._store_question_state(hn, cn, q_lens)
         film = F.relu(self.film_layer[1](h_last))
         film_img = film[lay.sample_of, lay.frame_of]

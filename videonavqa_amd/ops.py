@@ -137,7 +137,8 @@ class LstmSeqFn(torch.autograd.Function):
     with both biases), w_hh [4H,H], h0/c0 [B,H]; q_lens_i32 device int32 [B]; S = max cells."""
 
     @staticmethod
-    def forward(ctx, xg, w_hh, h0, c0, q_lens_i32, n_rep, S):
+    def forward(ctx, xg, w_hh, h0, c0, q_lens_i32, n_rep, S, wgrad_dtype=torch.float32):
+        ctx.wgrad_dtype = wgrad_dtype
         xg = xg.float().contiguous()
         w = w_hh.float().contiguous()
         h0 = h0.float().contiguous()
@@ -158,17 +159,20 @@ class LstmSeqFn(torch.autograd.Function):
         dgates, dh0, dc0 = K.lstm_seq_bwd(w, q_lens_i32, c0, gates, dhs, dhN, dcN, n_rep)
         # dW_hh = sum_{b,t} dgates[b,t]^T h_{t-1}[b]   (rows past a sample's last cell are zero)
         hprev = torch.cat([h0.unsqueeze(1), hs[:, :-1]], dim=1)
-        dw = K.gemm_tn(dgates.view(B * S, 4 * H), hprev.reshape(B * S, H).contiguous())
+        # exact-f32 MFMA in the fp32 (parity) mode; bf16 operands / fp32 accumulation in the bf16 mode (the f32 matrix
+        # path runs at 1/16 of the bf16 rate and this GEMM sits on the trunk's dependent chain)
+        wd = ctx.wgrad_dtype
+        dw = K.gemm_tn(dgates.view(B * S, 4 * H).to(wd), hprev.reshape(B * S, H).to(wd).contiguous())
         # dxg[b][pos] = sum over repeats of dgates at cells t with t % q_len == pos
         ql = q_lens_i32.long().clamp(min=1).unsqueeze(1)
         t = torch.arange(S, device=hs.device).unsqueeze(0)
         pos = (t % ql).unsqueeze(2).expand(B, S, 4 * H)
         dxg = torch.zeros(B, Lq, 4 * H, device=hs.device).scatter_add_(1, pos, dgates)
-        return dxg, dw, dh0, dc0, None, None, None
+        return dxg, dw, dh0, dc0, None, None, None, None
 
 
-def lstm_seq(xg, w_hh, h0, c0, q_lens_i32, n_rep, S):
-    return LstmSeqFn.apply(xg, w_hh, h0, c0, q_lens_i32, n_rep, S)
+def lstm_seq(xg, w_hh, h0, c0, q_lens_i32, n_rep, S, wgrad_dtype=torch.float32):
+    return LstmSeqFn.apply(xg, w_hh, h0, c0, q_lens_i32, n_rep, S, wgrad_dtype)
 
 
 class Conv3dFn(torch.autograd.Function):
