@@ -147,6 +147,18 @@ int vnqa_pack_conv_weight_tiled(const float* w_oihw, int32_t c_out, int32_t c_in
 int vnqa_unpack_conv_wgrad(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps,
                            int32_t c_out_pad, int32_t c_in_pad, float* dw_oihw, void* stream);
 
+/* fc_embed_attn = nn.Linear(spatial*C -> at_hidden) applied to the NCHW-flattened feature map
+ * (models/film_attn_pt_stem.py:56-57,244).  The kernels keep maps as padded NHWC, so its weight is re-laid out once
+ * per step:  w fp32 [rows][c][h][w]  ->  nat [rows_pad][(h+2)(w+2)][c_pad] (forward GEMM operand) and, when nat_t is
+ * not NULL, nat_t [(h+2)(w+2)][c_pad][rows_pad] (its transpose, the dX GEMM operand), both in `dtype`, zeros on halo
+ * positions / padded rows / padded channels (no memset needed).  vnqa_unpack_fc_wgrad maps the fp32 gradient of
+ * `nat` back to the parameter's layout.  rows_pad % 8 == 0, c_pad % 64 == 0.
+ */
+int vnqa_pack_fc_weight(const float* w, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t rows_pad,
+                        int32_t c_pad, int32_t dtype, void* nat, void* nat_t, void* stream);
+int vnqa_unpack_fc_wgrad(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad,
+                         float* dw, void* stream);
+
 /* Layout converters between the reference's tensors and padded NHWC.
  *   vnqa_feat_to_nhwc : v fp32 [b][c][h][w][t] (the model-input layout, eval/q_and_v_eval.py:110)
  *                       -> y padded NHWC [n_img][h+2][w+2][c_pad], frame (b,t) -> image img_of[b*t_n+t]

@@ -360,3 +360,21 @@ def test_conv_first_fused_into_c64(cfg):
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
     two = K.conv2d_c64(K.conv_first(clip, w1, b1, img_of, N, dt), wt, bias=b2, relu=True, pool2=pool)
     assert _rel(y.float(), two.float()) < 1e-2
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(16, 8, 10, 13, 64, 64), (128, 512, 14, 14, 512, 128), (20, 70, 5, 4, 128, 24)])
+def test_fc_weight_pack_unpack(dt, cfg):
+    """vnqa_pack_fc_weight / vnqa_unpack_fc_wgrad vs the permute+pad restatement (exact: pure data movement + rounding)."""
+    from videonavqa_amd import kernels as K
+    rows, C, h, w, c_pad, rows_pad = cfg
+    g = torch.Generator(device="cpu").manual_seed(rows + C)
+    wt = torch.randn(rows, C * h * w, generator=g).cuda()
+    nat, nat_t = K.pack_fc_weight(wt, C, h, w, c_pad, rows_pad, dt)
+    ref = F.pad(wt.view(rows, C, h, w).permute(0, 2, 3, 1), (0, c_pad - C, 1, 1, 1, 1, 0, rows_pad - rows)).reshape(rows_pad, -1)
+    assert torch.equal(nat.float(), ref.to(dt).float())
+    assert torch.equal(nat_t.float(), ref.to(dt).float().t())
+    gnat = torch.randn(rows_pad, (h + 2) * (w + 2) * c_pad, generator=g).cuda()
+    back = K.unpack_fc_wgrad(gnat, rows, C, h, w, c_pad)
+    ref_b = gnat.view(rows_pad, h + 2, w + 2, c_pad)[:rows, 1:-1, 1:-1, :C].permute(0, 3, 1, 2).reshape(rows, -1)
+    assert torch.equal(back, ref_b)

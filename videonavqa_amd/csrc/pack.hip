@@ -105,6 +105,91 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
   }
 }
 
+// ---- fc_embed_attn weight: nn.Linear over an NCHW-flattened map <-> the column order of a flattened padded-NHWC image --
+// w fp32 [rows][C][h][w]  ->  nat [rows_pad][(h+2)(w+2)][c_pad]   (kernel A: block = (row, 64-channel chunk))
+//                         ->  nat_t [(h+2)(w+2)][c_pad][rows_pad]  (kernel B: block = one channel, all rows)
+// Both read the source in contiguous h*w-float runs through LDS and write 128..256-byte segments; halo positions,
+// padded rows and padded channels are written as zeros, so the destinations need no memset.
+template <typename T>
+__global__ void __launch_bounds__(256) fc_pack_nat_kernel(const float* __restrict__ w, T* __restrict__ nat, int rows, int C,
+                                                          int h, int wd, int c_pad) {
+  extern __shared__ float tile[];                      // [64][S + 1]
+  const int row = blockIdx.y, c0 = blockIdx.x * 64;
+  const int S = h * wd, LD = S + 1, Sp = (h + 2) * (wd + 2);
+  const bool live = row < rows;
+  for (int i = threadIdx.x; i < 64 * S; i += 256) {
+    const int cc = i / S, sidx = i - cc * S;
+    tile[cc * LD + sidx] = (live && c0 + cc < C) ? w[((size_t)row * C + c0 + cc) * S + sidx] : 0.f;
+  }
+  __syncthreads();
+  T* dst = nat + (size_t)row * Sp * c_pad + c0;
+  for (int i = threadIdx.x; i < Sp * 8; i += 256) {
+    const int p = i >> 3, g = i & 7;
+    const int py = p / (wd + 2), px = p - py * (wd + 2);
+    const bool inside = py >= 1 && py <= h && px >= 1 && px <= wd;
+    const int sidx = (py - 1) * wd + px - 1;
+    T out[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = ElemOps<T>::store(inside ? tile[(g * 8 + e) * LD + sidx] : 0.f);
+    T* d = dst + (size_t)p * c_pad + g * 8;
+    if constexpr (sizeof(T) == 2) {
+      *(uint4*)d = *(const uint4*)out;
+    } else {
+      *(float4*)d = *(const float4*)out;
+      *(float4*)(d + 4) = *(const float4*)(out + 4);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) fc_pack_nat_t_kernel(const float* __restrict__ w, T* __restrict__ nat_t, int rows, int C,
+                                                            int h, int wd, int c_pad, int rows_pad) {
+  extern __shared__ float tile[];                      // [rows_pad][S + 1]
+  const int c = blockIdx.x;
+  const int S = h * wd, LD = S + 1, Sp = (h + 2) * (wd + 2);
+  for (int i = threadIdx.x; i < rows_pad * S; i += 256) {
+    const int r = i / S, sidx = i - r * S;
+    tile[r * LD + sidx] = (r < rows && c < C) ? w[((size_t)r * C + c) * S + sidx] : 0.f;
+  }
+  __syncthreads();
+  const int groups = rows_pad / 8;
+  for (int i = threadIdx.x; i < Sp * groups; i += 256) {
+    const int p = i / groups, g = i - p * groups;
+    const int py = p / (wd + 2), px = p - py * (wd + 2);
+    const bool inside = py >= 1 && py <= h && px >= 1 && px <= wd;
+    const int sidx = (py - 1) * wd + px - 1;
+    T out[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = ElemOps<T>::store(inside ? tile[(g * 8 + e) * LD + sidx] : 0.f);
+    T* d = nat_t + ((size_t)p * c_pad + c) * rows_pad + g * 8;
+    if constexpr (sizeof(T) == 2) {
+      *(uint4*)d = *(const uint4*)out;
+    } else {
+      *(float4*)d = *(const float4*)out;
+      *(float4*)(d + 4) = *(const float4*)(out + 4);
+    }
+  }
+}
+
+// dw_nat fp32 [rows_pad][(h+2)(w+2)][c_pad] -> dw fp32 [rows][C][h][w]   (block = (row, 64-channel chunk))
+__global__ void __launch_bounds__(256) fc_unpack_grad_kernel(const float* __restrict__ dnat, float* __restrict__ dw, int rows,
+                                                             int C, int h, int wd, int c_pad) {
+  extern __shared__ float tile[];                      // [S][64 + 1]
+  const int row = blockIdx.y, c0 = blockIdx.x * 64;
+  const int S = h * wd, Sp = (h + 2) * (wd + 2);
+  const float* src = dnat + (size_t)row * Sp * c_pad + c0;
+  for (int i = threadIdx.x; i < S * 64; i += 256) {
+    const int sidx = i >> 6, cc = i & 63;
+    const int py = sidx / wd + 1, px = sidx - (py - 1) * wd + 1;
+    tile[sidx * 65 + cc] = src[(size_t)(py * (wd + 2) + px) * c_pad + cc];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * S; i += 256) {
+    const int cc = i / S, sidx = i - cc * S;
+    if (c0 + cc < C) dw[((size_t)row * C + c0 + cc) * S + sidx] = tile[sidx * 65 + cc];
+  }
+}
+
 inline int grid_for(size_t total, int block) {
   size_t g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -211,6 +296,48 @@ extern "C" int vnqa_nchw_to_nhwc(const float* x, void* y, int32_t n_img, int32_t
                        c_pad);
   else
     VNQA_CHECK_ARG(false, "nchw_to_nhwc: bad dtype %d", dtype);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_pack_fc_weight(const float* w, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t rows_pad,
+                                   int32_t c_pad, int32_t dtype, void* nat, void* nat_t, void* stream) {
+  VNQA_CHECK_ARG(w && nat, "pack_fc_weight: null pointer");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "pack_fc_weight: bad dtype %d", dtype);
+  VNQA_CHECK_ARG(rows > 0 && c > 0 && h > 0 && wd > 0 && rows_pad >= rows && rows_pad % 8 == 0 && c_pad >= c && c_pad % 64 == 0,
+                 "pack_fc_weight: rows_pad must be a multiple of 8 >= rows, c_pad a multiple of 64 >= c");
+  const size_t ldsA = (size_t)64 * (h * wd + 1) * sizeof(float), ldsB = (size_t)rows_pad * (h * wd + 1) * sizeof(float);
+  VNQA_CHECK_ARG(ldsA <= 160 * 1024 && (nat_t == nullptr || ldsB <= 160 * 1024),
+                 "pack_fc_weight: a %dx%d map with %d rows does not fit the LDS tile", h, wd, rows_pad);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 gA(c_pad / 64, rows_pad);
+#define VNQA_FC_LAUNCH(T)                                                                                           \
+  do {                                                                                                             \
+    auto ka = fc_pack_nat_kernel<T>;                                                                               \
+    if (ldsA > 64 * 1024) hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA); \
+    hipLaunchKernelGGL(ka, gA, dim3(256), ldsA, st, w, (T*)nat, rows, c, h, wd, c_pad);                           \
+    if (nat_t != nullptr) {                                                                                        \
+      auto kb = fc_pack_nat_t_kernel<T>;                                                                           \
+      if (ldsB > 64 * 1024) hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB); \
+      hipLaunchKernelGGL(kb, dim3(c_pad), dim3(256), ldsB, st, w, (T*)nat_t, rows, c, h, wd, c_pad, rows_pad);    \
+    }                                                                                                              \
+  } while (0)
+  if (dtype == VNQA_BF16) VNQA_FC_LAUNCH(vnqa_bf16);
+  else VNQA_FC_LAUNCH(float);
+#undef VNQA_FC_LAUNCH
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_unpack_fc_wgrad(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad,
+                                    float* dw, void* stream) {
+  VNQA_CHECK_ARG(dw_nat && dw, "unpack_fc_wgrad: null pointer");
+  VNQA_CHECK_ARG(rows > 0 && c > 0 && h > 0 && wd > 0 && c_pad >= c && c_pad % 64 == 0, "unpack_fc_wgrad: bad geometry");
+  const size_t lds = (size_t)h * wd * 65 * sizeof(float);
+  VNQA_CHECK_ARG(lds <= 160 * 1024, "unpack_fc_wgrad: a %dx%d map does not fit the LDS tile", h, wd);
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fc_unpack_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(fc_unpack_grad_kernel, dim3((c + 63) / 64, rows), dim3(256), lds, (hipStream_t)stream, dw_nat, dw, rows, c, h,
+                     wd, c_pad);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -121,6 +121,27 @@ def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_sc
     return out
 
 
+def pack_fc_weight(w, C, h, wd, c_pad, rows_pad, dtype, want_t=True):
+    """nn.Linear weight over an NCHW-flattened map [rows, C*h*wd] fp32 -> (nat [rows_pad, (h+2)(wd+2)*c_pad],
+    nat_t [(h+2)(wd+2)*c_pad, rows_pad] or None) in `dtype`."""
+    rows = w.shape[0]
+    kn = (h + 2) * (wd + 2) * c_pad
+    w = w.detach().float().contiguous()
+    nat = torch.empty((rows_pad, kn), dtype=dtype, device=w.device)
+    nat_t = torch.empty((kn, rows_pad), dtype=dtype, device=w.device) if want_t else None
+    L.check(L.lib().vnqa_pack_fc_weight(L.ptr(w), rows, C, h, wd, rows_pad, c_pad, L.dtype_id(dtype), L.ptr(nat),
+                                        L.ptr(nat_t), L.stream()), "vnqa_pack_fc_weight")
+    return nat, nat_t
+
+
+def unpack_fc_wgrad(dw_nat, rows, C, h, wd, c_pad):
+    """fp32 gradient of the native-layout weight [rows_pad, (h+2)(wd+2)*c_pad] -> [rows, C*h*wd]."""
+    dw = torch.empty((rows, C * h * wd), dtype=torch.float32, device=dw_nat.device)
+    L.check(L.lib().vnqa_unpack_fc_wgrad(L.ptr(dw_nat), rows, C, h, wd, c_pad, L.ptr(dw), L.stream()),
+            "vnqa_unpack_fc_wgrad")
+    return dw
+
+
 def conv_first(clip, w, bias, img_of, n_img, dtype, out=None):
     """clip fp32 [B,3,H,W,T] -> padded NHWC [n_img,H+2,W+2,64] (conv1_1 + ReLU)."""
     B, C, H, W, T = clip.shape

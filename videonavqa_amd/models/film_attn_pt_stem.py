@@ -84,8 +84,7 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         n_img, hp, wp, c_pad = x.shape
         at = self.at_hidden_size
         at_pad = L.round_up(at, 64)
-        w_nat = self._fc_native_weight(self.fc_embed_attn.weight, C, h, w, c_pad, at_pad)
-        f = ops.linear_nt(x.view(n_img, -1), w_nat, F.pad(self.fc_embed_attn.bias, (0, at_pad - at)))
+        f = ops.fc_native(x.view(n_img, -1), self.fc_embed_attn.weight, self.fc_embed_attn.bias, C, h, w, at_pad)
         f = f[:, :at].float()
         all_features = torch.zeros(B, T, at, device=dev).index_put((lay.sample_of, lay.frame_of), f)  # :245-256
         valid = torch.zeros(B, T, 1, device=dev).index_put(

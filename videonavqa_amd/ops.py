@@ -340,3 +340,36 @@ class MacReadFn(torch.autograd.Function):
 
 def mac_read(know, pre, u, v, bias, state, s, c):
     return MacReadFn.apply(know, pre, u, v, bias, state, s, c)
+
+
+class FcNativeFn(torch.autograd.Function):
+    """out = flatten_NCHW(map) @ weight.T + bias for a map held as padded NHWC (fc_embed_attn, film_attn_pt_stem.py:244):
+    x [N, (h+2)(w+2)*c_pad] in the compute dtype, weight the reference-layout fp32 parameter [rows, C*h*w].  The weight is
+    re-laid out by two HIP kernels (forward operand + its transpose for dX); forward / dX / dW are MFMA GEMMs and the
+    weight gradient returns to the parameter layout in one kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, C, h, w, rows_pad):
+        rows = weight.shape[0]
+        c_pad = x.shape[1] // ((h + 2) * (w + 2))
+        need_dx = ctx.needs_input_grad[0]
+        nat, nat_t = K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, x.dtype, want_t=need_dx)
+        bias_p = torch.nn.functional.pad(bias.detach().float(), (0, rows_pad - rows)).contiguous()
+        out = K.gemm_nt(x.contiguous(), nat, bias=bias_p)
+        ctx.save_for_backward(x, nat_t)
+        ctx.geom = (rows, C, h, w, c_pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, nat_t = ctx.saved_tensors
+        rows, C, h, w, c_pad = ctx.geom
+        dout = dout.to(x.dtype).contiguous()
+        dx = K.gemm_nt(dout, nat_t) if ctx.needs_input_grad[0] else None
+        dw = K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad) if ctx.needs_input_grad[1] else None
+        db = dout.float().sum(0)[:rows] if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None, None, None
+
+
+def fc_native(x, weight, bias, C, h, w, rows_pad):
+    return FcNativeFn.apply(x, weight, bias, C, h, w, rows_pad)
