@@ -172,6 +172,11 @@ int vnqa_nchw_to_nhwc(const float* x, void* y, int32_t n_img, int32_t c, int32_t
 int vnqa_nhwc_to_nchw(const void* x, float* out, int32_t n_img, int32_t c, int32_t h, int32_t w,
                       int32_t c_pad, int32_t halo, int32_t dtype, void* stream);
 
+/* Zero the 1-pixel halo ring of a padded NHWC tensor [n_img][hp][wp][c] (the invariant every conv input relies on):
+ * a fresh output buffer needs only this, not a memset of the whole tensor — the conv kernels write every interior
+ * pixel and never the halo.  c * element size must be a multiple of 16 bytes. */
+int vnqa_zero_halo(void* y, int32_t n_img, int32_t hp, int32_t wp, int32_t c, int32_t dtype, void* stream);
+
 /* conv2d weight gradient (+ optional bias gradient), stride 1 'same'.
  * Replaces the autograd wgrad of nn.Conv2d on the trainable convs
  * (models/film_attn_pt_stem.py:40,98 reached by loss.backward(), eval/q_and_v_eval.py:136).

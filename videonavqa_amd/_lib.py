@@ -47,6 +47,7 @@ _SIGNATURES = {
     "vnqa_lstm_seq_bwd": (ctypes.c_int, [_vp] * 10 + [_i32] * 4 + [_vp]),
     "vnqa_lstm_wide_fwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
     "vnqa_lstm_wide_bwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
+    "vnqa_zero_halo": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_pack_fc_weight": (ctypes.c_int, [_vp] + [_i32] * 7 + [_vp, _vp, _vp]),
     "vnqa_unpack_fc_wgrad": (ctypes.c_int, [_vp] + [_i32] * 5 + [_vp, _vp]),
     "vnqa_clip_to_nhwc4": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

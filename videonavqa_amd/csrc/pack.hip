@@ -190,6 +190,22 @@ __global__ void __launch_bounds__(256) fc_unpack_grad_kernel(const float* __rest
   }
 }
 
+// zero the 1-pixel halo ring of a padded NHWC tensor [n][hp][wp][c] (16-byte pieces): what a fresh conv output needs
+// instead of a memset of the whole tensor (the kernels write every interior pixel, never the halo)
+__global__ void __launch_bounds__(256) zero_halo_kernel(uint4* __restrict__ y, int hp, int wp, int c16) {
+  const int ring = 2 * wp + 2 * (hp - 2);               // halo pixels per image
+  uint4* img = y + (size_t)blockIdx.x * hp * wp * c16;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = threadIdx.x; i < ring * c16; i += 256) {
+    const int r = i / c16, k = i - r * c16;
+    int py, px;
+    if (r < wp) { py = 0; px = r; }
+    else if (r < 2 * wp) { py = hp - 1; px = r - wp; }
+    else { const int q = r - 2 * wp; py = 1 + (q >> 1); px = (q & 1) ? wp - 1 : 0; }
+    img[((size_t)py * wp + px) * c16 + k] = z;
+  }
+}
+
 inline int grid_for(size_t total, int block) {
   size_t g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -338,6 +354,16 @@ extern "C" int vnqa_unpack_fc_wgrad(const float* dw_nat, int32_t rows, int32_t c
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fc_unpack_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(fc_unpack_grad_kernel, dim3((c + 63) / 64, rows), dim3(256), lds, (hipStream_t)stream, dw_nat, dw, rows, c, h,
                      wd, c_pad);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_zero_halo(void* y, int32_t n_img, int32_t hp, int32_t wp, int32_t c, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(y && n_img > 0 && hp >= 2 && wp >= 2, "zero_halo: bad arguments");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "zero_halo: bad dtype %d", dtype);
+  const int row_bytes = c * (dtype == VNQA_BF16 ? 2 : 4);
+  VNQA_CHECK_ARG(row_bytes % 16 == 0, "zero_halo: %d channels are not a whole number of 16-byte pieces", c);
+  hipLaunchKernelGGL(zero_halo_kernel, dim3(n_img), dim3(256), 0, (hipStream_t)stream, (uint4*)y, hp, wp, row_bytes / 16);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
