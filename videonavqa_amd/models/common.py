@@ -286,10 +286,16 @@ class FiLMTrunkBase(nn.Module):
     def _trunk(self, x, lay, film_fn):
         """conv_init -> ReLU -> per-frame BN -> FiLM residual blocks.
         film_fn(k) -> (gamma [n_img,C], beta [n_img,C]) for block k."""
-        cdt = self.compute_dtype
+        return self._trunk_blocks(self._trunk_head(x, lay), lay, film_fn)
+
+    def _trunk_head(self, x, lay):
+        """conv_init -> ReLU -> per-frame BN (film_attn_pt_stem.py:211): the part that does not need the question."""
         # in train mode the BN backward applies conv_init's ReLU mask itself (fused)
         r = ops.conv(x, self.conv_init.weight, self.conv_init.bias, relu=True, mask_in_backward=not self.training)
-        x = frame_batchnorm(r, self.bn_init, lay, self.training, cdt)
+        return frame_batchnorm(r, self.bn_init, lay, self.training, self.compute_dtype)
+
+    def _trunk_blocks(self, x, lay, film_fn):
+        cdt = self.compute_dtype
         for k in range(self.num_res_blocks):
             c1 = self.conv1x1_layers[k]
             res = ops.conv(x, c1.weight, c1.bias, relu=True)
@@ -297,6 +303,33 @@ class FiLMTrunkBase(nn.Module):
             gamma, beta = film_fn(k)
             x = film_relu_residual(z, res, gamma, beta, cdt)
         return x
+
+    # ---- FiLM generator on a side stream ---------------------------------------------------------
+    # The question LSTM chain (~800 dependent cells) needs nothing from the video: forked onto its own stream it
+    # runs beside conv_init / BN in forward, and — autograd replays every backward op on its forward's stream —
+    # its BPTT runs beside BN-backward / conv_init's wgrad in backward.  Opt-in (VNQA_SIDE_LSTM=1): measured +-0 at both
+    # 224x224 and 160x208 once the LSTM chain was shortened — the step is bound by the SUM of stem and trunk kernel work,
+    # not by the trunk's dependent chain, so taking the chain off the critical path buys nothing.
+    def _fork_generator(self, fn):
+        """Run fn() (returns a tensor or tuple of tensors) on the side stream; returns (result, join) where join()
+        makes the current stream wait for it and registers the cross-stream use with the caching allocator."""
+        import os
+        if not torch.cuda.is_available() or os.environ.get("VNQA_SIDE_LSTM", "0") != "1":
+            return fn(), (lambda: None)
+        main = torch.cuda.current_stream()
+        side = getattr(self, "_gen_stream", None)
+        if side is None:
+            side = self._gen_stream = torch.cuda.Stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = fn()
+
+        def join():
+            main.wait_stream(side)
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+        return out, join
 
     def _fc_native_weight(self, weight, channels, h, w, c_pad, rows_pad):
         """nn.Linear weight over a NCHW-flattened map [rows, channels*h*w] -> the column order of a

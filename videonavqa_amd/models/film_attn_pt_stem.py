@@ -65,20 +65,25 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         B, T = lay.B, lay.T
         C = self.num_res_block_channels
 
-        # FiLM generator: question LSTM re-run per processed frame with carried state (:213)
-        emb = self.embed(q_input)
-        h0, c0 = self._question_state(B, self.hidden_size, q_lens, dev)
-        h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
-                                                        wgrad_dtype=self.compute_dtype)
-        self._store_question_state(hn, cn, q_lens)
-        film = F.relu(self.film_layer[1](h_last))                       # [B, n_frames, 2*C*blocks] (:179)
-        film_img = film[lay.sample_of, lay.frame_of]                    # [n_img, 2*C*blocks]
+        # FiLM generator: question LSTM re-run per processed frame with carried state (:213) — on the side stream
+        def generator():
+            emb = self.embed(q_input)
+            h0, c0 = self._question_state(B, self.hidden_size, q_lens, dev)
+            h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
+                                                          wgrad_dtype=self.compute_dtype)
+            self._store_question_state(hn, cn, q_lens)
+            film = F.relu(self.film_layer[1](h_last))                   # [B, n_frames, 2*C*blocks] (:179)
+            return film[lay.sample_of, lay.frame_of]                    # [n_img, 2*C*blocks]
+
+        film_img, join = self._fork_generator(generator)
+        x = self._trunk_head(x, lay)
+        join()
 
         def film_fn(k):
             s = 2 * C * k
             return film_img[:, s:s + C], film_img[:, s + C:s + 2 * C]   # :229-233
 
-        x = self._trunk(x, lay, film_fn)
+        x = self._trunk_blocks(x, lay, film_fn)
 
         # fc_embed_attn over the flattened map (:244) as one split-K GEMM for all images
         n_img, hp, wp, c_pad = x.shape

@@ -50,17 +50,24 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
         assert lay.B == self.batch_size
         assert h * w == self.spatial_size
         C = self.num_res_block_channels
-        emb = self.embed(q_input)
-        h0, c0 = self._question_state(lay.B, self.hidden_size, q_lens, x.device)
-        h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
-                                                        wgrad_dtype=self.compute_dtype)
-        self._store_question_state(hn, cn, q_lens)
-        film = F.relu(self.film_layer[1](h_last))
-        film_img = film[lay.sample_of, lay.frame_of]
+        dev = x.device
+
+        def generator():     # question LSTM + FiLM projection on the side stream (common.FiLMTrunkBase._fork_generator)
+            emb = self.embed(q_input)
+            h0, c0 = self._question_state(lay.B, self.hidden_size, q_lens, dev)
+            h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
+                                                          wgrad_dtype=self.compute_dtype)
+            self._store_question_state(hn, cn, q_lens)
+            film = F.relu(self.film_layer[1](h_last))
+            return film[lay.sample_of, lay.frame_of]
+
+        film_img, join = self._fork_generator(generator)
+        x = self._trunk_head(x, lay)
+        join()
 
         def film_fn(k):
             s = 2 * C * k
             return film_img[:, s:s + C], film_img[:, s + C:s + 2 * C]
 
-        x = self._trunk(x, lay, film_fn)
+        x = self._trunk_blocks(x, lay, film_fn)
         return self._gp_tail(x, lay, h, w)
