@@ -196,11 +196,11 @@ extern "C" int vnqa_conv_first_fwd(const float* clip, const float* w, const floa
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VNQA_BF16) {
     auto kern = conv_first_kernel<vnqa_bf16>;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
   } else {
     auto kern = conv_first_kernel<float>;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
   }
   VNQA_CHECK_LAUNCH();

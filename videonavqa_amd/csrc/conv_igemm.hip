@@ -247,7 +247,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   }
 
   const int kt0 = slice * p.kt_per_slice;
+#ifdef VNQA_DIAG_SKIP_DMA   // 2048 = main loop cut to 2 K-steps (what is left is the per-tile fixed cost)
+  const int kt1 = (p.relu & 2048) ? kt0 + 2 : ((kt0 + p.kt_per_slice < KT) ? kt0 + p.kt_per_slice : KT);
+#else
   const int kt1 = (kt0 + p.kt_per_slice < KT) ? kt0 + p.kt_per_slice : KT;
+#endif
 
   // One stage = NSUB k-substeps.  Fragments are double-buffered in registers: the ds_read_b128s of
   // substep s+1 are issued BEFORE the MFMAs of substep s, so LDS latency hides behind the matrix pipe
@@ -380,9 +384,23 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     __builtin_amdgcn_s_barrier();     // all fragment reads done before the epilogue reuses the LDS
   }
 
+#ifdef VNQA_DIAG_SKIP_DMA   // timing-only diagnostic: 1024 = no epilogue at all (one lane keeps the accumulators alive)
+  if (p.relu & 1024) {
+    float sink = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sink += acc[i][j][0];
+    if (sink == 12345.678f) ((float*)p.y)[0] = sink;
+    return;
+  }
+#endif
   // ---------------- epilogue ----------------
   // acc[i][j][4g+e]: pixel = wm*WTM + i*MT + fr ; cout = wn*WTN + j*MT + (MT==32 ? 8g + 4fh : 4fh) + e
   auto col_of = [&](int j, int g) { return wn * WTN + j * MT + (MT == 32 ? 8 * g + 4 * fh : 4 * fh); };
+  // (Measured and rejected: an LDS-free epilogue for the stem launches — 8-byte stores straight from the accumulators,
+  // 2x2 pooling by quad lane exchange.  The 32-byte store segments cost more than the LDS round trip saves:
+  // conv11 1.26 -> 1.56 ms, conv12 3.2 -> 3.7 ms.)
   if (p.partial != nullptr) {
     // split-K: raw fp32 partial sums, 4 consecutive couts per lane -> 16-byte stores
     float* slab = p.partial + (size_t)slice * p.M * p.Cout;

@@ -330,11 +330,11 @@ extern "C" int vnqa_pack_fc_weight(const float* w, int32_t rows, int32_t c, int3
 #define VNQA_FC_LAUNCH(T)                                                                                           \
   do {                                                                                                             \
     auto ka = fc_pack_nat_kernel<T>;                                                                               \
-    if (ldsA > 64 * 1024) hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA); \
+    if (ldsA > 64 * 1024) (void)hipFuncSetAttribute((const void*)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsA); \
     hipLaunchKernelGGL(ka, gA, dim3(256), ldsA, st, w, (T*)nat, rows, c, h, wd, c_pad);                           \
     if (nat_t != nullptr) {                                                                                        \
       auto kb = fc_pack_nat_t_kernel<T>;                                                                           \
-      if (ldsB > 64 * 1024) hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB); \
+      if (ldsB > 64 * 1024) (void)hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsB); \
       hipLaunchKernelGGL(kb, dim3(c_pad), dim3(256), ldsB, st, w, (T*)nat_t, rows, c, h, wd, c_pad, rows_pad);    \
     }                                                                                                              \
   } while (0)
@@ -351,7 +351,7 @@ extern "C" int vnqa_unpack_fc_wgrad(const float* dw_nat, int32_t rows, int32_t c
   VNQA_CHECK_ARG(rows > 0 && c > 0 && h > 0 && wd > 0 && c_pad >= c && c_pad % 64 == 0, "unpack_fc_wgrad: bad geometry");
   const size_t lds = (size_t)h * wd * 65 * sizeof(float);
   VNQA_CHECK_ARG(lds <= 160 * 1024, "unpack_fc_wgrad: a %dx%d map does not fit the LDS tile", h, wd);
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)fc_unpack_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)fc_unpack_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(fc_unpack_grad_kernel, dim3((c + 63) / 64, rows), dim3(256), lds, (hipStream_t)stream, dw_nat, dw, rows, c, h,
                      wd, c_pad);
   VNQA_CHECK_LAUNCH();
