@@ -118,14 +118,19 @@ class FrozenStem(object):
             # the other stream (same-box A/B): finer interleaving of the two streams' workgroups hurts both
             t128 = L.TILE_128x128 if os.environ.get("VNQA_STEM_T128", "0") == "1" else L.TILE_256x128
             tile = L.TILE_STEM_256x256 if c_out_pad >= 256 else (t128 if c_out_pad > 64 else L.TILE_256x64)
+            # conv11 (C_in = 128: only 18 K-steps, and a 964 MB output to store): the 16-wave shape of the same tile
+            # keeps more store / DMA issue slots busy around its short main loop (+10 % on this layer, -2..4 % on the
+            # 72-K-step layers, which therefore keep the 8-wave staggered kernel)
+            if c_out_pad >= 256 and c_in_pad == 128 and os.environ.get("VNQA_STEM_W16", "1") != "0":
+                tile = L.TILE_256x256_W16
         else:
             tile = L.TILE_128x64 if c_out_pad <= 64 else L.TILE_128x128
-        if tile is None or os.environ.get("VNQA_STEM_TILED", "1") == "0":
+        if tile is None or tile == L.TILE_256x256_W16 or os.environ.get("VNQA_STEM_TILED", "1") == "0":
             wt = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         else:   # frozen weights: pre-tiled once into the exact LDS images the igemm DMA consumes
             wt = K.pack_conv_weight_tiled(w, self.cdt, tile, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         return dict(wt=wt, bias=K.pad_vec(b, c_out_pad), relu=relu, pool=pool, post=None,
-                    c_out=c_out, c_out_pad=c_out_pad, tile=tile)
+                    c_out=c_out, c_in=c_in, c_out_pad=c_out_pad, tile=tile)
 
     def _buf(self, key, shape):
         """Persistent zero-halo activation buffer, grown (never shrunk) along the image axis."""
@@ -158,7 +163,7 @@ class FrozenStem(object):
                                    out=out, tile=tile)
             if timed:
                 ev1.record()
-                self.timing.append((ev0, ev1))
+                self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9))
         return x
 
     # ---- fused fast path: clip -> packed native features ------------------------------------
