@@ -543,6 +543,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_P4_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, 0, 4>(a, st);
       case VNQA_TILE_P4_256x64: return launch<vnqa_bf16, 256, 64, 4, 1, 0, 4>(a, st);
       case VNQA_TILE_256x256_W16: return launch<vnqa_bf16, 256, 256, 4, 4, 2>(a, st);
+      case VNQA_TILE_256x128_W16: return launch<vnqa_bf16, 256, 128, 4, 4, 2>(a, st);
       case VNQA_TILE_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 0, st);
       case VNQA_TILE_STEM_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 1, st);
       default: break;
