@@ -347,15 +347,24 @@ Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype) {
   pl.tilesCi = (c_in + 255) / 256;
   pl.ksteps_total = (int)((pl.Ptot + KP - 1) / KP);
   const int tiles = pl.tilesCo * pl.tilesCi * taps;
-  // one workgroup per CU (128 KiB LDS): ONE full round of <= 256 workgroups.  Same-box A/B on the 512x512x3x3 layer
-  // (36 tiles): 7 slices = 252 workgroups 0.433 ms, 14 slices = 504 workgroups (two rounds) 0.472 ms — half the
-  // fp32 slab traffic for the same MFMA work; 15 slices = 540 needed a third, 89 % empty round.
-#if defined(VNQA_WGRAD_CEIL_SLICES)     // A/B: earlier rules
+  // One workgroup per CU (128 KiB LDS): the launch runs in rounds of 256 workgroups, so pick the slice count by ROUND
+  // EFFICIENCY e(s) = tiles*s / (256 * ceil(tiles*s / 256)): the smallest s <= 16 with e >= 0.9, else the best one.
+  // 36 tiles (512x512x3x3): 7 slices = 252 workgroups (0.433 ms; 14 slices / two rounds 0.472 ms, 15 slices 0.478 ms);
+  // 144 tiles (1024x1024x3x3): 5 slices = 720 workgroups in three 94 %-full rounds (1 slice would leave 112 CUs idle).
+  // Every extra slice costs one more fp32 slab of the whole weight gradient, hence "smallest".
+#if defined(VNQA_WGRAD_CEIL_SLICES)     // A/B: the first rule
   int slices = (512 + tiles - 1) / tiles;
-#elif defined(VNQA_WGRAD_TWO_ROUNDS)
-  int slices = 512 / tiles;
 #else
-  int slices = 256 / tiles;
+  int slices = 1;
+  {
+    double best = 0.0;
+    for (int sl = 1; sl <= 16; ++sl) {
+      const int wg = tiles * sl;
+      const double e = (double)wg / (256.0 * ((wg + 255) / 256));
+      if (e >= 0.9) { slices = sl; break; }
+      if (e > best + 1e-9) { best = e; slices = sl; }
+    }
+  }
 #endif
   const int max_slices = pl.ksteps_total / 8 > 0 ? pl.ksteps_total / 8 : 1;
   slices = slices < 1 ? 1 : (slices > max_slices ? max_slices : slices);
