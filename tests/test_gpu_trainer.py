@@ -85,3 +85,25 @@ def test_fused_clip_adam_matches_torch():
         K.clip_adam_step(p, gg, m, v, partial, step, 1e-3, 1.0)
         assert float(gg.abs().max()) == 0.0          # zero_grad fused
         assert float((p - p_ref.detach()).abs().max()) < 2e-6
+
+
+def test_bf16_and_fp32_paths_train_alike():
+    """40 optimisation steps on one fixed minibatch (whole pipeline: stem -> FiLM-attn trunk -> clip -> Adam) in the
+    benchmark precision (bf16 storage, bf16-operand weight-gradient GEMMs, hardware exp2/rcp LSTM activations) and in
+    the exact-f32 parity precision: both must fit the batch and their loss curves must stay close."""
+    curves = {}
+    from videonavqa_amd.train import Trainer
+    for prec in ("fp32", "bf16"):
+        model, stem, batches = _setup(prec, seed=3)
+        trainer = Trainer(model, stem, lr=3e-4)
+        losses = []
+        for _ in range(40):
+            loss, _ = trainer.step(*batches[0])
+            losses.append(float(loss))
+        assert all(l == l and l < 1e4 for l in losses), losses        # finite
+        curves[prec] = losses
+    f, b = curves["fp32"], curves["bf16"]
+    assert f[-1] < 0.6 * f[0] and b[-1] < 0.6 * b[0], (f[0], f[-1], b[0], b[-1])
+    assert abs(b[0] - f[0]) < 0.05 * abs(f[0]) + 0.05
+    rel = [abs(x - y) / max(abs(y), 1e-3) for x, y in zip(b[:20], f[:20])]
+    assert max(rel) < 0.25, rel
