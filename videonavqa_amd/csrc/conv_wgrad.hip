@@ -23,6 +23,8 @@ struct WgradArgs {
   const char* dy;
   float* out;       // slab base: [slices][Cout][taps][Cin]
   long long Ptot;   // n*Hp*Wp  (n*Dp*Hp*Wp for 3-D)
+  long long Vtot;   // contraction extent: Ptot, or n*H*Wp when the halo ROWS are skipped (2-D convs)
+  int vrow, prow;   // H*Wp and Hp*Wp: compact index v -> padded pixel (v / vrow) * prow + Wp + v % vrow (vrow = 0: identity)
   int Wp, Hp;
   int Cin, Cout, taps;
   int tilesCo, tilesCi;
@@ -99,10 +101,18 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
     const long long p0 = (long long)kstep * KP;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const long long pa = p0 + st_row[j];
+      // dY's top and bottom halo rows are zero: the contraction skips them (12.5 % of a 16x16 padded map); halo
+      // COLUMNS stay in, so a tap is still one constant shift of the row pointer
+      const long long v = p0 + st_row[j];
+      long long pa = v;
+      if (p.vrow > 0) {                       // 32-bit arithmetic: the 2-D plans are checked to stay below 2^31 pixels
+        const unsigned vi = (unsigned)v;
+        const unsigned img = vi / (unsigned)p.vrow;
+        pa = (long long)(img * (unsigned)p.prow + (unsigned)p.Wp + (vi - img * (unsigned)p.vrow));
+      }
       long long pb = pa + dtap;
       pb = pb < 0 ? 0 : (pb < p.Ptot ? pb : p.Ptot - 1);
-      const char* srcA = pa < p.Ptot ? p.dy + (size_t)pa * rowA + st_coff_a[j] : (const char*)vnqa_zero_page;
+      const char* srcA = v < p.Vtot ? p.dy + (size_t)pa * rowA + st_coff_a[j] : (const char*)vnqa_zero_page;
       glds16w(srcA, lds + (wave * 4 + j) * 1024);
       glds16w(p.x + (size_t)pb * rowB + st_coff_b[j], lds + TILE_BYTES + (wave * 4 + j) * 1024);
     }
@@ -330,22 +340,31 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict
 
 struct Plan {
   int tilesCo, tilesCi, ksteps_total, slices, ksteps_per_slice, colsum_blocks;
-  long long Ptot;
+  long long Ptot, Vtot;
+  int vrow, prow;
 };
 
-Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype);
+Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype, long long Vtot = -1, int vrow = 0, int prow = 0);
 
 Plan make_plan(int n_img, int h, int w, int c_in, int c_out, int taps, int dtype) {
+#ifdef VNQA_WGRAD_ALL_ROWS     // A/B: contract over every padded pixel
   return make_plan_k((long long)n_img * (h + 2) * (w + 2), c_in, c_out, taps, dtype);
+#else
+  return make_plan_k((long long)n_img * (h + 2) * (w + 2), c_in, c_out, taps, dtype, (long long)n_img * h * (w + 2),
+                     h * (w + 2), (h + 2) * (w + 2));
+#endif
 }
 
-Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype) {
+Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype, long long Vtot, int vrow, int prow) {
   Plan pl;
   pl.Ptot = Ptot;
+  pl.Vtot = Vtot < 0 ? Ptot : Vtot;
+  pl.vrow = vrow;
+  pl.prow = prow;
   const int KP = dtype == VNQA_BF16 ? 64 : 32;
   pl.tilesCo = (c_out + 255) / 256;
   pl.tilesCi = (c_in + 255) / 256;
-  pl.ksteps_total = (int)((pl.Ptot + KP - 1) / KP);
+  pl.ksteps_total = (int)((pl.Vtot + KP - 1) / KP);
   const int tiles = pl.tilesCo * pl.tilesCi * taps;
   // One workgroup per CU (128 KiB LDS): the launch runs in rounds of 256 workgroups, so pick the slice count by ROUND
   // EFFICIENCY e(s) = tiles*s / (256 * ceil(tiles*s / 256)): the smallest s <= 16 with e >= 0.9, else the best one.
@@ -420,6 +439,7 @@ extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, floa
   VNQA_CHECK_ARG(taps == 9 || taps == 1, "conv2d_wgrad: taps must be 9 or 1");
   VNQA_CHECK_ARG(c_in % 8 == 0 && c_out % 8 == 0 && c_in >= 8 && c_out >= 8, "conv2d_wgrad: channels must be multiples of 8");
   VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0, "conv2d_wgrad: empty problem");
+  VNQA_CHECK_ARG((long long)n_img * (h + 2) * (w + 2) < (1ll << 31), "conv2d_wgrad: too many pixels");
   const Plan pl = make_plan(n_img, h, w, c_in, c_out, taps, dtype);
   return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, taps, dtype, stream);
 }
@@ -447,6 +467,9 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   a.dy = (const char*)dy;
   a.out = pl.slices == 1 ? dwt : (float*)workspace;
   a.Ptot = pl.Ptot;
+  a.Vtot = pl.Vtot;
+  a.vrow = pl.vrow;
+  a.prow = pl.prow;
   a.Wp = w + 2;
   a.Hp = h + 2;
   a.Cin = c_in;
