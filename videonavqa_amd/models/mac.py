@@ -170,16 +170,19 @@ class MACNetwork(nn.Module):
         so = lay.sample_of
         Lq = context.shape[1]
         ctx = context[so].reshape(n_img * Lq, dim).contiguous()                   # [N*L,dim] fp32
-        cstate = ops.MacReadState()
-        # all position_aware projections (one per reasoning step, mac.py:29) in one batched product
+        # all position_aware projections (one per reasoning step, mac.py:29) and their share of control_question
+        # (:31-32: Linear([control ; position_aware])) in two batched products, hoisted out of the step loop
         pw = torch.stack([l.weight for l in m.control.position_aware])            # [steps,dim,2dim]
         pb = torch.stack([l.bias for l in m.control.position_aware])              # [steps,dim]
-        pa_all = (torch.matmul(hq, pw.transpose(1, 2)) + pb.unsqueeze(1))[:, so]  # [steps,N,dim]
+        pa_all = torch.matmul(hq, pw.transpose(1, 2)) + pb.unsqueeze(1)           # [steps,B,dim]
+        wcq = m.control.control_question.weight
+        pq_all = (torch.matmul(pa_all, wcq[:, dim:].t()) + m.control.control_question.bias)[:, so]   # [steps,N,dim]
         # step-invariant half of ReadUnit.concat on the MFMA GEMM: know W2^T + b (kept in the compute dtype)
         w2 = F.pad(m.read.concat.weight[:, dim:], (0, c_pad - dim, 0, c_pad - dim))
         pre = ops.linear_nt(kd, w2, F.pad(m.read.concat.bias, (0, c_pad - dim)))
-        rstate = ops.MacReadState()
-        w1 = m.read.concat.weight[:, :dim]
+        state = ops.MacCoreState()
+        wc, w1 = wcq[:, :dim], m.read.concat.weight[:, :dim]
+        wr, wmm = m.write.concat.weight[:, :dim], m.write.concat.weight[:, dim:]
         masks = self._masks(n_img, dev)
         control = m.control_0.expand(n_img, dim)
         memory = m.mem_0.expand(n_img, dim)
@@ -187,20 +190,14 @@ class MACNetwork(nn.Module):
             control, memory = control * masks[0], memory * masks[1]
         controls, memories = [control], [memory]
         for i in range(self.max_step):
-            # ControlUnit: attn(cq * context) = context . (cq * w) + b
-            cq = m.control.control_question(torch.cat([control, pa_all[i]], 1))
-            control = ops.mac_read(ctx, None, cq * m.control.attn.weight, None, m.control.attn.bias, cstate, Lq, dim)
-            if masks is not None:
-                control = control * masks[0]
-            controls.append(control)
-            # ReadUnit, re-associated (module docstring)
-            mem = m.read.mem(memories[-1])
-            v = control * m.read.attn.weight
-            u = mem * (v @ w1)
-            read = ops.mac_read(kd, pre, u, v, m.read.attn.bias, rstate, S, dim)      # fused scores/softmax/sum
-            # WriteUnit
+            # ControlUnit + ReadUnit + WriteUnit.concat as ONE autograd node (ops.MacCoreFn)
             prev = memories[-1]
-            concat = m.write.concat(torch.cat([read, prev], 1))
+            control, concat = ops.mac_core(control.contiguous(), prev.contiguous(), pq_all[i], ctx, kd, pre,
+                                           None if masks is None else masks[0], wc, m.control.attn.weight,
+                                           m.control.attn.bias, m.read.mem.weight, m.read.mem.bias, w1,
+                                           m.read.attn.weight, m.read.attn.bias, wr, wmm, m.write.concat.bias,
+                                           state, Lq, S)
+            controls.append(control)
             nxt = concat
             if self.self_attention:
                 cc = torch.stack(controls[:-1], 1)                                 # [N,i+1,dim]

@@ -373,3 +373,111 @@ class FcNativeFn(torch.autograd.Function):
 
 def fc_native(x, weight, bias, C, h, w, rows_pad):
     return FcNativeFn.apply(x, weight, bias, C, h, w, rows_pad)
+
+
+class MacCoreState(object):
+    """Shared by the MacCoreFn nodes of one forward: per-step factors of the two attention pools (question words,
+    knowledge base) whose [N, positions, C] gradients are formed once, in the first step's backward (see MacReadFn)."""
+
+    def __init__(self):
+        self.n_calls = 0
+        self.ctrl = []
+        self.read = []
+        self.grads = {}
+
+
+class MacCoreFn(torch.autograd.Function):
+    """One MAC reasoning step (ControlUnit, ReadUnit and WriteUnit.concat of models/mac.py:28-42,53-62,82-85) for all
+    packed images as ONE autograd node: inside, plain torch GEMMs and the fused attention kernels run without graph
+    recording, and the backward is written out by hand.  Motivation: the MAC training step was bound by the launch
+    thread (autograd bookkeeping of ~75 small ops per step and direction), not by the GPU.
+
+      cq      = control Wc^T + pq                       (pq = position_aware_i(question) Wp^T + b, hoisted by the caller)
+      control'= pool(ctx, cq * w_ca, b_ca) [* mask]     (attention over the question words)
+      mem     = memory Wm^T + bm ;  v = control' * w_ra ;  u = mem * (v W1)
+      read    = pool(know, pre; u, v, b_ra)             (re-associated ReadUnit, see models/mac.py)
+      concat  = read Wr^T + memory Wmm^T + bw
+    Returns (control', concat); self-attention / memory gate / the memory dropout mask stay with the caller."""
+
+    @staticmethod
+    def forward(ctx_, control, memory, pq, ctxw, know, pre, mask_c, wc, w_ca, b_ca, wm, bm, w1, w_ra, b_ra, wr, wmm, bw,
+                state, Lq, S):
+        N, d = control.shape
+        cq = torch.addmm(pq, control, wc.t())
+        qv = (cq * w_ca).contiguous()
+        p_c, cnew = K.mac_read_fwd(ctxw, None, qv, None, b_ca.detach().float().contiguous(), N, Lq, d)
+        if mask_c is not None:
+            cnew = cnew * mask_c
+        mem = torch.addmm(bm, memory, wm.t())
+        v = (cnew * w_ra).contiguous()
+        t = v @ w1
+        u = (mem * t).contiguous()
+        p_r, read = K.mac_read_fwd(know, pre, u, v, b_ra.detach().float().contiguous(), N, S, d)
+        concat = torch.addmm(bw, read, wr.t()).addmm_(memory, wmm.t())
+        ctx_.save_for_backward(control, memory, ctxw, know, pre, mask_c, wc, w_ca, wm, w1, w_ra, wr, wmm,
+                               cq, qv, p_c, cnew, mem, v, t, u, p_r, read)
+        ctx_.state, ctx_.dims, ctx_.index = state, (N, d, Lq, S), state.n_calls
+        state.n_calls += 1
+        return cnew, concat
+
+    @staticmethod
+    def backward(ctx_, d_cnew, d_concat):
+        (control, memory, ctxw, know, pre, mask_c, wc, w_ca, wm, w1, w_ra, wr, wmm,
+         cq, qv, p_c, cnew, mem, v, t, u, p_r, read) = ctx_.saved_tensors
+        N, d, Lq, S = ctx_.dims
+        st = ctx_.state
+        d_concat = d_concat.contiguous()
+        # Parameter gradients are ACCUMULATED in the shared state (GEMM with beta = 1 / GEMV against a ones vector, in
+        # place) and handed to autograd once, by the first step's node: 12 steps x 12 parameters would otherwise be
+        # ~150 AccumulateGrad adds and ~60 reductions of their own.
+        G = st.grads
+        if not G:
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=control.device)
+            G.update(wc=z(d, d), wca=z(d), bca=z(1), wm=z(d, d), bm=z(d), w1=z(d, d), wra=z(d), bra=z(1), wr=z(d, d),
+                     wmm=z(d, d), bw=z(d), ones=torch.ones(N, dtype=torch.float32, device=control.device))
+        ones = G["ones"]
+        # WriteUnit.concat
+        d_read = (d_concat @ wr).contiguous()
+        d_memory = d_concat @ wmm
+        G["wr"].addmm_(d_concat.t(), read)
+        G["wmm"].addmm_(d_concat.t(), memory)
+        G["bw"].addmv_(d_concat.t(), ones)
+        # ReadUnit attention
+        ds_r, du, dv = K.mac_read_bwd(know, pre, p_r, d_read, N, S, d)
+        st.read.append((ds_r, p_r, u, v, d_read))
+        G["bra"].add_(ds_r.sum())
+        d_mem, d_t = du * t, du * mem
+        dv = dv.addmm_(d_t, w1.t())
+        G["w1"].addmm_(v.t(), d_t)
+        G["wra"].addmv_((dv * cnew).t(), ones)
+        d_c = dv * w_ra if d_cnew is None else torch.addcmul(d_cnew, dv, w_ra)
+        d_memory = d_memory.addmm_(d_mem, wm)
+        G["wm"].addmm_(d_mem.t(), memory)
+        G["bm"].addmv_(d_mem.t(), ones)
+        if mask_c is not None:
+            d_c = d_c * mask_c
+        d_c = d_c.contiguous()
+        # ControlUnit attention
+        ds_c, dqv, _ = K.mac_read_bwd(ctxw, None, p_c, d_c, N, Lq, d)
+        st.ctrl.append((ds_c, p_c, qv, d_c))
+        G["bca"].add_(ds_c.sum())
+        d_cq = dqv * w_ca
+        G["wca"].addmv_((dqv * cq).t(), ones)
+        d_control = d_cq @ wc
+        G["wc"].addmm_(d_cq.t(), control)
+        d_ctxw = d_know = d_pre = None
+        g = [None] * 11
+        if ctx_.index == 0:      # runs last: every later step depends on this one's outputs
+            f = [torch.stack(x) for x in zip(*st.read)]
+            d_know, d_pre = K.mac_read_accum(f[0], f[1], f[2], f[3], f[4], N, S, d, know.shape[-1], know.dtype)
+            c = [torch.stack(x) for x in zip(*st.ctrl)]
+            d_ctxw, _ = K.mac_read_accum(c[0], c[1], c[2], None, c[3], N, Lq, d, ctxw.shape[-1], ctxw.dtype)
+            g = [G["wc"], G["wca"].view(1, d), G["bca"], G["wm"], G["bm"], G["w1"], G["wra"].view(1, d), G["bra"], G["wr"],
+                 G["wmm"], G["bw"]]
+            st.read, st.ctrl, st.grads = [], [], {}
+        return (d_control, d_memory, d_cq, d_ctxw, d_know, d_pre, None, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7],
+                g[8], g[9], g[10], None, None, None)
+
+
+def mac_core(*args):
+    return MacCoreFn.apply(*args)
