@@ -117,9 +117,20 @@ __global__ void __launch_bounds__(256) fc_pack_nat_kernel(const float* __restric
   const int row = blockIdx.y, c0 = blockIdx.x * 64;
   const int S = h * wd, LD = S + 1, Sp = (h + 2) * (wd + 2);
   const bool live = row < rows;
-  for (int i = threadIdx.x; i < 64 * S; i += 256) {
-    const int cc = i / S, sidx = i - cc * S;
-    tile[cc * LD + sidx] = (live && c0 + cc < C) ? w[((size_t)row * C + c0 + cc) * S + sidx] : 0.f;
+  if ((S & 3) == 0) {             // runs of S floats start 16-byte aligned: float4 loads
+    const int S4 = S >> 2;
+    for (int i = threadIdx.x; i < 64 * S4; i += 256) {
+      const int cc = i / S4, q = i - cc * S4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live && c0 + cc < C) v = *(const float4*)(w + ((size_t)row * C + c0 + cc) * S + 4 * q);
+      float* t = tile + cc * LD + 4 * q;
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < 64 * S; i += 256) {
+      const int cc = i / S, sidx = i - cc * S;
+      tile[cc * LD + sidx] = (live && c0 + cc < C) ? w[((size_t)row * C + c0 + cc) * S + sidx] : 0.f;
+    }
   }
   __syncthreads();
   T* dst = nat + (size_t)row * Sp * c_pad + c0;
@@ -147,9 +158,20 @@ __global__ void __launch_bounds__(256) fc_pack_nat_t_kernel(const float* __restr
   extern __shared__ float tile[];                      // [rows_pad][S + 1]
   const int c = blockIdx.x;
   const int S = h * wd, LD = S + 1, Sp = (h + 2) * (wd + 2);
-  for (int i = threadIdx.x; i < rows_pad * S; i += 256) {
-    const int r = i / S, sidx = i - r * S;
-    tile[r * LD + sidx] = (r < rows && c < C) ? w[((size_t)r * C + c) * S + sidx] : 0.f;
+  if ((S & 3) == 0) {
+    const int S4 = S >> 2;
+    for (int i = threadIdx.x; i < rows_pad * S4; i += 256) {
+      const int r = i / S4, q = i - r * S4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows && c < C) v = *(const float4*)(w + ((size_t)r * C + c) * S + 4 * q);
+      float* t = tile + r * LD + 4 * q;
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+  } else {
+    for (int i = threadIdx.x; i < rows_pad * S; i += 256) {
+      const int r = i / S, sidx = i - r * S;
+      tile[r * LD + sidx] = (r < rows && c < C) ? w[((size_t)r * C + c) * S + sidx] : 0.f;
+    }
   }
   __syncthreads();
   const int groups = rows_pad / 8;
