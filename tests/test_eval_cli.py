@@ -124,3 +124,38 @@ def test_v_only_cnn3d_cli_synthetic(tmp_path, capsys):
     os.replace(tmp_path / "e0_c.pt", tmp_path / "c.pt")
     V3.main(argv)
     assert "Restored checkpoint c.pt (epoch 1)" in capsys.readouterr().out
+
+
+def test_vnqa_dataset_contract_with_stubbed_decoder(tmp_path, monkeypatch):
+    """VNQADataset item layout (eval/dataset.py:57-106) without OpenCV: the mp4 reader is replaced by a stub that returns
+    numbered BGR frames, so the 1-in-4 subsampling, the 35-frame cap, the [3,H,W,35] frames-last layout, the /255
+    scaling and the zero padding can be checked exactly."""
+    import json
+    import numpy as np
+    from videonavqa_amd.eval import dataset as D, utils as U
+    qd, vd = tmp_path / "q", tmp_path / "v"
+    qd.mkdir()
+    vd.mkdir()
+    np.save(qd / "clip0.npy", np.array([5, 9, 2, 7], dtype=np.int64))
+    np.save(qd / "clip1.npy", np.arange(1, 31, dtype=np.int64))
+
+    def fake_frames(path):
+        n = 23 if path.endswith("clip0.mp4") else 200          # 200 raw frames -> 50 windows -> capped at 35
+        return [np.full((U.VID_HEIGHT, U.VID_WIDTH, 3), i % 256, np.uint8) for i in range(n)]
+    monkeypatch.setattr(D, "_read_frames", fake_frames)
+    ds = D.VNQADataset(q_dir=str(qd), v_dir=str(vd), filenames=["clip0", "clip1"], labels={"clip0": 3, "clip1": 60})
+    X, y = ds[0]
+    assert y == 3 and X["q_len"] == 4 and X["question"].tolist()[:5] == [5, 9, 2, 7, 0] and X["question"].shape == (U.MAX_Q_LEN,)
+    assert X["video"].shape == (3, U.VID_HEIGHT, U.VID_WIDTH, U.MAX_ALLOWED_NUM_FRAMES_DROPPING)
+    assert X["v_len"] == 6                                      # ceil(23 / 4) windows
+    picked = (X["video"][0, 0, 0, :6] * 255).round().long().tolist()
+    assert all(4 * k <= f <= min(4 * k + 3, 22) for k, f in enumerate(picked)), picked   # one frame out of every window of 4
+    assert float(X["video"][..., 6:].abs().max()) == 0.0 and float(X["video"].max()) <= 1.0
+    X1, y1 = ds[1]
+    assert X1["v_len"] == U.MAX_ALLOWED_NUM_FRAMES_DROPPING and y1 == 60 and X1["q_len"] == 30
+    w = ds.get_class_weights()
+    assert w.shape == (U.NUM_CLASSES,) and w[3] == 1.0 and w[60] == 1.0 and np.isinf(w[0])
+    # question-only / video-only modes (q_only_eval.py, v_only_cnn3d_eval.py)
+    qs = D.VNQADataset(q_dir=str(qd), v_dir=str(vd), filenames=["clip0"], labels={"clip0": 3}, q_only=True)[0][0]
+    vs = D.VNQADataset(q_dir=str(qd), v_dir=str(vd), filenames=["clip0"], labels={"clip0": 3}, v_only=True)[0][0]
+    assert set(qs) == {"question", "q_len"} and set(vs) == {"video", "v_len"}
