@@ -130,6 +130,17 @@ def _staged_batches(args, trainer, data_loader, device):
         cur = nxt
 
 
+def _global_stats(loss_sum, hit, n, device):
+    """Sum (loss, hits, examples) over data-parallel ranks for the per-epoch log line: the one scalar all-reduce per epoch
+    besides the gradient all-reduce (the reference is single-process; F1 stays rank-local)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([loss_sum, float(hit), float(n)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t[0]), int(t[1]), int(t[2])
+    return loss_sum, hit, n
+
+
 def train_epoch(epoch, args, trainer, data_loader, device, rank=0):
     """q_and_v_eval.py:73-156 (stem, sort, forward, loss, clip, Adam are inside Trainer.step)."""
     from sklearn.metrics import f1_score
@@ -151,6 +162,7 @@ def train_epoch(epoch, args, trainer, data_loader, device, rank=0):
             print('Average loss after %d iterations in epoch %d: %.6f' % (i + 1, epoch + 1, avg_loss / num_examples))
     f1_w = f1_score(y_target, y_pred, average='weighted')
     f1_micro = f1_score(y_target, y_pred, average='micro')
+    avg_loss, hit, num_examples = _global_stats(avg_loss, hit, num_examples, device)
     if rank == 0:
         print('Train Epoch: {}\tAverage loss: {:.6f}\tAccuracy: {}/{}\tF1: w{:.4f}, micro{:.4f}\n'.format(
             epoch, avg_loss / max(num_examples, 1), hit, num_examples, f1_w, f1_micro))
@@ -189,6 +201,7 @@ def val_epoch(args, trainer, data_loader, device, rank=0):
     accs = U.per_class_accuracies(y_target, y_pred, args.num_classes)
     f1_w = f1_score(y_target, y_pred, average='weighted') if num_examples else 0.0
     f1_micro = f1_score(y_target, y_pred, average='micro') if num_examples else 0.0
+    # (every rank evaluates the whole validation split: nothing to aggregate)
     if rank == 0:
         pp.pprint({i: accs[i] for i in np.nonzero(accs)[0].tolist()})
         print('Validation:\tAverage loss: {:.6f}, Accuracy: {}/{}, F1: w{:.4f}, micro{:.4f}\n'.format(
@@ -209,11 +222,17 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "the MI355X path needs a GPU (there is no CPU fallback)"
+    if os.environ.get("VNQA_SINGLE_DEVICE") == "1":       # test hook: several ranks on ONE GPU (with VNQA_DIST_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("VNQA_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.synthetic > 0:
         train_data = SyntheticVNQADataset(args.synthetic, args.height, args.width, vocab_size=args.vocab_size,
