@@ -89,6 +89,33 @@ int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt
                           const float* bias, const float* post_scale, const float* post_shift,
                           void* y, void* stream);
 
+/* Same conv with two extensions used by the frozen stem's COMPOSED layer (ObjDetectCNN applies conv12 directly to
+ * conv11's output, models/obj_detector.py:72 — no nonlinearity in between — so for frozen weights the pair equals ONE
+ * 5x5 conv with composed weights, 25*128 instead of 9*128 + 9*512 multiply-adds per output):
+ *   - taps == 25 (5x5, x_halo == 2; wt [c_out][25][c_in]); y_halo may be 0, 1 or 2;
+ *   - border_sub (optional): [n_img][2*w + 2*(h-2)][c_out] in `dtype`, SUBTRACTED from the sums of the image-border
+ *     pixels before ReLU / pooling (ring order: top row x = 0..w-1, bottom row, left column y = 1..h-2, right column).
+ *     It carries the exact correction for conv12 seeing zero padding rather than conv11 evaluated outside the image.
+ */
+int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
+                             const float* post_scale, const float* post_shift, const void* border_sub,
+                             void* y, void* stream);
+
+/* Operand builders of that border correction (all tensors in `dtype`, c * element size a multiple of 16 bytes; the
+ * outside ring of the (h+2)x(w+2) grid is enumerated top row (w+2), bottom row (w+2), left column (h), right column (h)):
+ *   vnqa_ring_im2col      : x halo-2 padded NHWC [n][h+4][w+4][c] -> [n][2(w+2)+2h][9][c], the 3x3 patches around the ring
+ *                           positions (GEMM with conv11's K-major weights gives conv11 evaluated OUTSIDE the image);
+ *   vnqa_ring_edge_gather : y1 [n][ring][c] -> [n][w|h][3][c]: per border pixel of edge 0/1/2/3 (top/bottom/left/right)
+ *                           its three outside neighbours (zeros where a corner belongs to the top/bottom group);
+ *   vnqa_ring_assemble    : the four edge GEMM results [n][w|h][c] -> border_sub [n][2w+2(h-2)][c] (corners summed).
+ */
+int vnqa_ring_im2col(const void* x, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype,
+                     void* stream);
+int vnqa_ring_edge_gather(const void* y1, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t edge,
+                          int32_t dtype, void* stream);
+int vnqa_ring_assemble(const void* top, const void* bottom, const void* left, const void* right, void* ring,
+                       int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream);
+
 /* Persistent direct 3x3 conv for c_in == 64 (bf16): weights resident in LDS, 16x16 tiles with a DMA'd
  * 18x18 halo patch, no barrier inside the K loop.  Same contract as vnqa_conv2d_igemm_fwd restricted to
  * taps == 9, c_in == 64, c_out % 64 == 0, x_halo == y_halo == 1.  Used for VGG conv1_2 / conv2_1.
@@ -203,6 +230,7 @@ int vnqa_conv3d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, v
  *                  K is split over workgroups when m x n alone cannot fill the chip; workspace of
  *                  vnqa_gemm_nt_workspace() bytes (may be 0 -> NULL allowed).  ldo = row stride of out.
  *   vnqa_gemm_tn : out[m][n] = sum_k a[k][m] * b[k][n]   (fp32 out; the wgrad kernel with explicit K)
+  * workspace == NULL opts out of split-K (single pass over K, summation order independent of m).
  */
 int64_t vnqa_gemm_nt_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype);
 int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bias, void* out, void* workspace,

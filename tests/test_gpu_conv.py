@@ -378,3 +378,41 @@ def test_fc_weight_pack_unpack(dt, cfg):
     back = K.unpack_fc_wgrad(gnat, rows, C, h, w, c_pad)
     ref_b = gnat.view(rows_pad, h + 2, w + 2, c_pad)[:rows, 1:-1, 1:-1, :C].permute(0, 3, 1, 2).reshape(rows, -1)
     assert torch.equal(back, ref_b)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 6, 8, 64, 128, 192), (3, 14, 12, 128, 512, 512), (1, 4, 4, 64, 64, 64)])
+def test_composed_conv_pair_matches_two_step(dt, cfg):
+    """FrozenStem._compose_pair: conv(3x3) -> conv(3x3) + eval BN + ReLU + pool as ONE 5x5 igemm launch with the exact
+    border correction, vs torch running the two convolutions (fp32: 1e-4; bf16 operands: 2e-2)."""
+    import torch.nn as nn
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd.stem import FrozenStem
+    N, H, W, Ci, Cm, Co = cfg
+    torch.manual_seed(sum(cfg))
+    c1, c2, bn = nn.Conv2d(Ci, Cm, 3, padding=1), nn.Conv2d(Cm, Co, 3, padding=1), nn.BatchNorm2d(Co)
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+        c1.bias.normal_(0, 0.5)
+    c1, c2, bn = c1.cuda(), c2.cuda(), bn.cuda().eval()
+    x = torch.randn(N, Ci, H, W).cuda()
+    with torch.no_grad():
+        ref = F.max_pool2d(F.relu(bn(c2(c1(x)))), 2, 2)
+    stem = FrozenStem(None, None, "bf16" if dt == torch.bfloat16 else "fp32")
+    stem.composed = stem._compose_pair(c1, c2, bn)
+    xn = F.pad(K.nchw_to_nhwc(x, dt, c_pad=Ci), (0, 0, 1, 1, 1, 1))          # halo 2
+    with torch.no_grad():
+        y = stem._run_composed(xn, ("t",))
+    got = K.nhwc_to_nchw(y, Co)
+    assert got.shape == ref.shape
+    tol = 1e-4 if dt == torch.float32 else 2e-2
+    assert _rel(got, ref) < tol, _rel(got, ref)
+    assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+    # the border really needs the correction: without it the ring of output pixels is wrong
+    with torch.no_grad():
+        cp = stem.composed
+        bad = K.conv2d_igemm(xn, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, tile=cp["tile"])
+    assert _rel(K.nhwc_to_nchw(bad, Co), ref) > 5 * tol

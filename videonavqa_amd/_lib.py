@@ -48,6 +48,10 @@ _SIGNATURES = {
     "vnqa_lstm_seq_bwd": (ctypes.c_int, [_vp] * 10 + [_i32] * 4 + [_vp]),
     "vnqa_lstm_wide_fwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
     "vnqa_lstm_wide_bwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
+    "vnqa_conv2d_igemm_fwd_ex": (ctypes.c_int, [_vp] * 9),
+    "vnqa_ring_im2col": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_ring_edge_gather": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_ring_assemble": (ctypes.c_int, [_vp] * 5 + [_i32] * 5 + [_vp]),
     "vnqa_zero_halo": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_pack_fc_weight": (ctypes.c_int, [_vp] + [_i32] * 7 + [_vp, _vp, _vp]),
     "vnqa_unpack_fc_wgrad": (ctypes.c_int, [_vp] + [_i32] * 5 + [_vp, _vp]),

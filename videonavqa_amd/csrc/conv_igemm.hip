@@ -185,6 +185,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     if (p.taps == 9) {
       r = tap / 3;
       s = tap - 3 * r;
+    } else if (p.taps == 25) {       // 5x5, input halo 2
+      r = tap / 5;
+      s = tap - 5 * r;
     } else if (p.taps == 27) {
       q = tap / 9;
       const int rs = tap - 9 * q;
@@ -419,6 +422,25 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     }
     return;
   }
+  // row of the border-correction tensor for each of this lane's pixels (-1: interior pixel or no correction)
+  int ring_row[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    ring_row[i] = -1;
+    if (p.border_sub != nullptr) {
+      const int m = tile_m * BM + wm * WTM + i * MT + fr;
+      if (m < p.M) {
+        int n, y, x;
+        decode_pixel(m, p.H, p.W, p.pool, n, y, x);
+        int ring = -1;
+        if (y == 0) ring = x;
+        else if (y == p.H - 1) ring = p.W + x;
+        else if (x == 0) ring = 2 * p.W + (y - 1);
+        else if (x == p.W - 1) ring = 2 * p.W + (p.H - 2) + (y - 1);
+        if (ring >= 0) ring_row[i] = n * (2 * p.W + 2 * (p.H - 2)) + ring;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -434,9 +456,15 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       for (int i = 0; i < TM; ++i) {
         const int prow = wm * WTM + i * MT + fr;
         float v[4];
+        float sub4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ring_row[i] >= 0) {             // composed-conv border correction (vnqa_conv2d_igemm_fwd_ex)
+          const T* src = (const T*)p.border_sub + (size_t)ring_row[i] * p.Cout + co;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sub4[e] = (co + e < p.Cout) ? ElemOps<T>::load(src[e]) : 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[i][j][4 * g + e] + b4[e];
+          v[e] = acc[i][j][4 * g + e] + b4[e] - sub4[e];
           if (p.relu) v[e] = fmaxf(v[e], 0.f);
         }
         char* dst = smem + prow * CROW + col * ES;
@@ -670,8 +698,9 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   const int bk = dtype == VNQA_BF16 ? 64 : 32;
   VNQA_CHECK_ARG(m > 0 && n > 0 && k > 0 && k % bk == 0, "gemm_nt: k=%d must be a positive multiple of %d", k, bk);
   VNQA_CHECK_ARG(n % 8 == 0 && ldo >= n && ldo % 8 == 0, "gemm_nt: n=%d ldo=%d must be multiples of 8", n, ldo);
-  const int64_t ws = vnqa_gemm_nt_workspace(m, n, k, dtype);
-  VNQA_CHECK_ARG(ws == 0 || workspace != nullptr, "gemm_nt: workspace of %lld bytes required", (long long)ws);
+  // workspace == NULL opts out of split-K: one pass over K in a fixed order whatever m is (the frozen stem's ring GEMMs
+  // use this so that a frame's features do not depend on how many other frames share the launch)
+  const int64_t ws = workspace != nullptr ? vnqa_gemm_nt_workspace(m, n, k, dtype) : 0;
   ConvArgs a;
   a.x = (const char*)a_mk;
   a.wt = (const char*)b_nk;
@@ -683,7 +712,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   a.Cin = k; a.Cout = n; a.Cy = ldo;
   a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = relu; a.pool = 0;
   a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
-  a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr;
+  a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // bf16: 256-row tiles unless 128-row tiles waste fewer padded rows (e.g. m = 280: 384 instead of 512)
   int tile = VNQA_TILE_128x128;
@@ -718,18 +747,27 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
 extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
                                      const float* bias, const float* post_scale,
                                      const float* post_shift, void* y, void* stream) {
+  return vnqa_conv2d_igemm_fwd_ex(d, x, wt, bias, post_scale, post_shift, nullptr, y, stream);
+}
+
+extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void* wt,
+                                        const float* bias, const float* post_scale, const float* post_shift,
+                                        const void* border_sub, void* y, void* stream) {
   VNQA_CHECK_ARG(d && x && wt && y, "conv2d_igemm_fwd: null pointer");
   VNQA_CHECK_ARG(d->dtype == VNQA_BF16 || d->dtype == VNQA_F32, "conv2d_igemm_fwd: bad dtype %d", d->dtype);
   const int bk = d->dtype == VNQA_BF16 ? 64 : 32;
-  VNQA_CHECK_ARG(d->taps == 9 || d->taps == 1 || (d->taps == 27 && d->depth > 0),
-                 "conv2d_igemm_fwd: taps must be 9 or 1, or 27 with depth > 0 (got %d)", d->taps);
+  VNQA_CHECK_ARG(d->taps == 9 || d->taps == 1 || d->taps == 25 || (d->taps == 27 && d->depth > 0),
+                 "conv2d_igemm_fwd: taps must be 9, 25 or 1, or 27 with depth > 0 (got %d)", d->taps);
   VNQA_CHECK_ARG(d->c_in > 0 && d->c_in % bk == 0, "conv2d_igemm_fwd: c_in=%d must be a multiple of %d", d->c_in, bk);
   VNQA_CHECK_ARG(d->c_out > 0 && d->c_out % 8 == 0 && d->c_y >= d->c_out && d->c_y % 8 == 0,
                  "conv2d_igemm_fwd: c_out=%d c_y=%d must be multiples of 8, c_y>=c_out", d->c_out, d->c_y);
   VNQA_CHECK_ARG(d->n_img > 0 && d->h > 0 && d->w > 0, "conv2d_igemm_fwd: empty problem");
-  VNQA_CHECK_ARG((d->taps >= 9 && d->x_halo == 1) || (d->taps == 1 && (d->x_halo == 0 || d->x_halo == 1)),
+  VNQA_CHECK_ARG((d->taps == 25 && d->x_halo == 2) || ((d->taps == 9 || d->taps == 27) && d->x_halo == 1) ||
+                     (d->taps == 1 && (d->x_halo == 0 || d->x_halo == 1)),
                  "conv2d_igemm_fwd: x_halo=%d invalid for taps=%d", d->x_halo, d->taps);
-  VNQA_CHECK_ARG(d->y_halo == 0 || d->y_halo == 1, "conv2d_igemm_fwd: y_halo must be 0/1");
+  VNQA_CHECK_ARG(d->y_halo >= 0 && d->y_halo <= 2, "conv2d_igemm_fwd: y_halo must be 0, 1 or 2");
+  VNQA_CHECK_ARG(border_sub == nullptr || (d->depth == 0 && d->h >= 2 && d->w >= 2),
+                 "conv2d_igemm_fwd: border_sub needs a 2-D conv over images of at least 2x2");
   VNQA_CHECK_ARG(!d->pool2 || (d->h % 2 == 0 && d->w % 2 == 0), "conv2d_igemm_fwd: pool2 needs even h,w");
   VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv2d_igemm_fwd: post_scale/post_shift must come together");
   VNQA_CHECK_ARG((long long)d->n_img * (d->depth > 0 ? d->depth : 1) * d->h * d->w < (1ll << 31), "conv2d_igemm_fwd: too many pixels");
@@ -765,6 +803,7 @@ extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, con
   a.slices = 1;
   a.kt_per_slice = 1 << 30;
   a.partial = nullptr;
+  a.border_sub = border_sub;
   VNQA_CHECK_ARG(!d->wt_tiled || (d->tile != VNQA_TILE_AUTO && d->tile != VNQA_TILE_P4_256x256 &&
                                   d->tile != VNQA_TILE_P4_256x128 && d->tile != VNQA_TILE_P4_256x64),
                  "conv2d_igemm_fwd: wt_tiled needs an explicit 128-byte-row tile id");

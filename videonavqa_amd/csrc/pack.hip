@@ -228,6 +228,82 @@ __global__ void __launch_bounds__(256) zero_halo_kernel(uint4* __restrict__ y, i
   }
 }
 
+// ---- border correction of the composed conv pair (stem.py: FrozenStem._compose_pair) --------------------------------
+// ring positions q of the (H+2)x(W+2) grid in the order top row (W+2), bottom row (W+2), left column (H), right column (H)
+__device__ __forceinline__ void ring_pos(int r, int H, int W, int& qy, int& qx) {
+  if (r < W + 2) { qy = -1; qx = r - 1; }
+  else if (r < 2 * (W + 2)) { qy = H; qx = r - (W + 2) - 1; }
+  else if (r < 2 * (W + 2) + H) { qy = r - 2 * (W + 2); qx = -1; }
+  else { qy = r - 2 * (W + 2) - H; qx = W; }
+}
+
+// out[n][r][tap][c] = x[n][qy + dy + 2][qx + dx + 2][c]   (x: halo-2 padded NHWC, 16-byte pieces)
+__global__ void __launch_bounds__(256) ring_im2col_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, int H, int W,
+                                                          int c16) {
+  const int R = 2 * (W + 2) + 2 * H;
+  const int r = blockIdx.x, n = blockIdx.y;
+  int qy, qx;
+  ring_pos(r, H, W, qy, qx);
+  const int Wp = W + 4;
+  const uint4* img = x + (size_t)n * (H + 4) * Wp * c16;
+  uint4* dst = out + ((size_t)n * R + r) * 9 * c16;
+  for (int i = threadIdx.x; i < 9 * c16; i += 256) {
+    const int tap = i / c16, k = i - tap * c16;
+    const int dy = tap / 3, dx = tap - 3 * dy;                      // 0..2 == -1..1 shifted by the +1 below
+    dst[i] = img[((size_t)(qy + dy + 1) * Wp + (qx + dx + 1)) * c16 + k];
+  }
+}
+
+// edge operands: for border pixel j of `edge` (0 top, 1 bottom: j = x; 2 left, 3 right: j = y) the three outside
+// neighbours' y1 rows, zero where the neighbour is a corner owned by the top / bottom group or lies inside the image.
+//   y1 [n][R][cm] -> out [n][len][3][cm], len = W (top/bottom) or H (left/right)
+__global__ void __launch_bounds__(256) ring_edge_gather_kernel(const uint4* __restrict__ y1, uint4* __restrict__ out, int H,
+                                                               int W, int c16, int edge) {
+  const int R = 2 * (W + 2) + 2 * H;
+  const int j = blockIdx.x, n = blockIdx.y;
+  const int len = edge < 2 ? W : H;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  uint4* dst = out + ((size_t)n * len + j) * 3 * c16;
+  for (int i = threadIdx.x; i < 3 * c16; i += 256) {
+    const int slot = i / c16, k = i - slot * c16;
+    int r = -1;
+    if (edge == 0) r = j + slot;                                    // q = (-1, j + slot - 1)
+    else if (edge == 1) r = (W + 2) + j + slot;                     // q = (H, j + slot - 1)
+    else {
+      const int yy = j + slot - 1;                                  // q = (yy, -1 | W); corners (yy = -1, H) excluded
+      if (yy >= 0 && yy < H) r = 2 * (W + 2) + (edge == 3 ? H : 0) + yy;
+    }
+    dst[i] = r >= 0 ? y1[((size_t)n * R + r) * c16 + k] : z;
+  }
+}
+
+// ring[n][2W + 2(H-2)][c] = top | bottom | left[1:-1] | right[1:-1], corners += left/right ends   (float accumulate)
+template <typename T>
+__global__ void __launch_bounds__(256) ring_assemble_kernel(const T* __restrict__ top, const T* __restrict__ bottom,
+                                                            const T* __restrict__ left, const T* __restrict__ right,
+                                                            T* __restrict__ ring, int H, int W, int C) {
+  const int RL = 2 * W + 2 * (H - 2);
+  const int r = blockIdx.x, n = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v;
+    if (r < W) {
+      v = ElemOps<T>::load(top[((size_t)n * W + r) * C + c]);
+      if (r == 0) v += ElemOps<T>::load(left[((size_t)n * H + 0) * C + c]);
+      if (r == W - 1) v += ElemOps<T>::load(right[((size_t)n * H + 0) * C + c]);
+    } else if (r < 2 * W) {
+      const int x = r - W;
+      v = ElemOps<T>::load(bottom[((size_t)n * W + x) * C + c]);
+      if (x == 0) v += ElemOps<T>::load(left[((size_t)n * H + H - 1) * C + c]);
+      if (x == W - 1) v += ElemOps<T>::load(right[((size_t)n * H + H - 1) * C + c]);
+    } else if (r < 2 * W + H - 2) {
+      v = ElemOps<T>::load(left[((size_t)n * H + (r - 2 * W) + 1) * C + c]);
+    } else {
+      v = ElemOps<T>::load(right[((size_t)n * H + (r - 2 * W - (H - 2)) + 1) * C + c]);
+    }
+    ring[((size_t)n * RL + r) * C + c] = ElemOps<T>::store(v);
+  }
+}
+
 inline int grid_for(size_t total, int block) {
   size_t g = (total + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -239,7 +315,7 @@ extern "C" int vnqa_pack_conv_weight(const float* w_oihw, int32_t c_out, int32_t
                                      int32_t c_out_pad, int32_t c_in_pad, const float* out_scale,
                                      int32_t transpose_flip, int32_t dtype, void* wt, void* stream) {
   VNQA_CHECK_ARG(w_oihw && wt, "pack_conv_weight: null pointer");
-  VNQA_CHECK_ARG(taps == 9 || taps == 1 || taps == 27, "pack_conv_weight: taps must be 1, 9 or 27");
+  VNQA_CHECK_ARG(taps == 9 || taps == 1 || taps == 25 || taps == 27, "pack_conv_weight: taps must be 1, 9, 25 or 27");
   VNQA_CHECK_ARG(c_out_pad >= c_out && c_in_pad >= c_in, "pack_conv_weight: pads smaller than sizes");
   VNQA_CHECK_ARG(!(transpose_flip && out_scale), "pack_conv_weight: out_scale unsupported with transpose_flip");
   const int rows = transpose_flip ? c_in_pad : c_out_pad;
@@ -386,6 +462,43 @@ extern "C" int vnqa_zero_halo(void* y, int32_t n_img, int32_t hp, int32_t wp, in
   const int row_bytes = c * (dtype == VNQA_BF16 ? 2 : 4);
   VNQA_CHECK_ARG(row_bytes % 16 == 0, "zero_halo: %d channels are not a whole number of 16-byte pieces", c);
   hipLaunchKernelGGL(zero_halo_kernel, dim3(n_img), dim3(256), 0, (hipStream_t)stream, (uint4*)y, hp, wp, row_bytes / 16);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_ring_im2col(const void* x, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype,
+                                void* stream) {
+  VNQA_CHECK_ARG(x && out && n_img > 0 && h >= 2 && w >= 2, "ring_im2col: bad arguments");
+  const int rb = c * (dtype == VNQA_BF16 ? 2 : 4);
+  VNQA_CHECK_ARG((dtype == VNQA_BF16 || dtype == VNQA_F32) && rb % 16 == 0, "ring_im2col: bad dtype / channel count");
+  hipLaunchKernelGGL(ring_im2col_kernel, dim3(2 * (w + 2) + 2 * h, n_img), dim3(256), 0, (hipStream_t)stream, (const uint4*)x,
+                     (uint4*)out, h, w, rb / 16);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_ring_edge_gather(const void* y1, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t edge,
+                                     int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(y1 && out && n_img > 0 && h >= 2 && w >= 2 && edge >= 0 && edge < 4, "ring_edge_gather: bad arguments");
+  const int rb = c * (dtype == VNQA_BF16 ? 2 : 4);
+  VNQA_CHECK_ARG((dtype == VNQA_BF16 || dtype == VNQA_F32) && rb % 16 == 0, "ring_edge_gather: bad dtype / channel count");
+  hipLaunchKernelGGL(ring_edge_gather_kernel, dim3(edge < 2 ? w : h, n_img), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)y1, (uint4*)out, h, w, rb / 16, edge);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_ring_assemble(const void* top, const void* bottom, const void* left, const void* right, void* ring,
+                                  int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(top && bottom && left && right && ring && n_img > 0 && h >= 2 && w >= 2, "ring_assemble: bad arguments");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "ring_assemble: bad dtype %d", dtype);
+  dim3 grid(2 * w + 2 * (h - 2), n_img);
+  if (dtype == VNQA_BF16)
+    hipLaunchKernelGGL(ring_assemble_kernel<vnqa_bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const vnqa_bf16*)top,
+                       (const vnqa_bf16*)bottom, (const vnqa_bf16*)left, (const vnqa_bf16*)right, (vnqa_bf16*)ring, h, w, c);
+  else
+    hipLaunchKernelGGL(ring_assemble_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)top,
+                       (const float*)bottom, (const float*)left, (const float*)right, (float*)ring, h, w, c);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -65,7 +65,7 @@ def empty_padded(shape, dtype, device):
 
 
 def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
-                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO):
+                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output."""
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
@@ -84,9 +84,37 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
             out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], taps, x_halo, y_halo,
                    int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0, 0)
-    L.check(L.lib().vnqa_conv2d_igemm_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
-                                          L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_igemm_fwd")
+    L.check(L.lib().vnqa_conv2d_igemm_fwd_ex(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
+                                             L.ptr(post_shift), L.ptr(border_sub), L.ptr(out), L.stream()),
+            "vnqa_conv2d_igemm_fwd")
     return out
+
+
+def ring_im2col(x, H, W):
+    """x halo-2 padded NHWC [n,H+4,W+4,c] -> [n*(2(W+2)+2H), 9*c]: 3x3 patches around the outside-ring positions."""
+    n, _, _, c = x.shape
+    R = 2 * (W + 2) + 2 * H
+    out = torch.empty((n * R, 9 * c), dtype=x.dtype, device=x.device)
+    L.check(L.lib().vnqa_ring_im2col(L.ptr(x), L.ptr(out), n, H, W, c, L.dtype_id(x.dtype), L.stream()), "vnqa_ring_im2col")
+    return out
+
+
+def ring_edge_gather(y1, n, H, W, edge):
+    """y1 [n*ring, c] -> [n*(W|H), 3*c] for edge 0/1/2/3 = top/bottom/left/right."""
+    c = y1.shape[-1]
+    ln = W if edge < 2 else H
+    out = torch.empty((n * ln, 3 * c), dtype=y1.dtype, device=y1.device)
+    L.check(L.lib().vnqa_ring_edge_gather(L.ptr(y1), L.ptr(out), n, H, W, c, edge, L.dtype_id(y1.dtype), L.stream()),
+            "vnqa_ring_edge_gather")
+    return out
+
+
+def ring_assemble(top, bottom, left, right, n, H, W):
+    c = top.shape[-1]
+    ring = torch.empty((n, 2 * W + 2 * (H - 2), c), dtype=top.dtype, device=top.device)
+    L.check(L.lib().vnqa_ring_assemble(L.ptr(top), L.ptr(bottom), L.ptr(left), L.ptr(right), L.ptr(ring), n, H, W, c,
+                                       L.dtype_id(top.dtype), L.stream()), "vnqa_ring_assemble")
+    return ring
 
 
 def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None, shape4=False):
@@ -199,8 +227,9 @@ _WS = {}
 
 
 def workspace(nbytes, device):
-    """Grow-only fp32 scratch buffer per device (caller-owned workspace of the C ABI)."""
-    key = str(device)
+    """Grow-only fp32 scratch buffer per device AND stream (caller-owned workspace of the C ABI): the frozen stem
+    runs its split-K GEMMs on a side stream while the trunk uses its own on the main stream."""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
     n = (int(nbytes) + 3) // 4
     buf = _WS.get(key)
     if buf is None or buf.numel() < n:
@@ -233,15 +262,16 @@ def unpack_conv_wgrad(dwt, c_out, c_in):
     return out
 
 
-def gemm_nt(a, b, bias=None, relu=False, out=None):
-    """out[m][n] = act(sum_k a[m][k] b[n][k] + bias[n]); a [M,K], b [N,K] (same dtype), out dtype = a.dtype."""
+def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
+    """out[m][n] = act(sum_k a[m][k] b[n][k] + bias[n]); a [M,K], b [N,K] (same dtype), out dtype = a.dtype.
+    split_k=False: one pass over K in a fixed order (result independent of M's tiling)."""
     M, Kd = a.shape
     N = b.shape[0]
     assert b.shape[1] == Kd and a.dtype == b.dtype
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
     did = L.dtype_id(a.dtype)
-    ws_bytes = L.lib().vnqa_gemm_nt_workspace(M, N, Kd, did)
+    ws_bytes = L.lib().vnqa_gemm_nt_workspace(M, N, Kd, did) if split_k else 0
     ws = workspace(ws_bytes, a.device) if ws_bytes > 0 else None
     L.check(L.lib().vnqa_gemm_nt(L.ptr(a), L.ptr(b), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, Kd, out.stride(0),
                                  1 if relu else 0, did, L.stream()), "vnqa_gemm_nt")

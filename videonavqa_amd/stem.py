@@ -79,6 +79,7 @@ class FrozenStem(object):
         self.cdt = torch.bfloat16 if precision in ("bf16", torch.bfloat16) else torch.float32
         self.vgg, self.objdet = vgg, objdet
         self.layers_vgg, self.layers_od = [], []
+        self.composed = None
         self.first = None
         self._bufs = {}
         self.timing = None   # bench hook: list collecting (start, end) events around stem-tagged launches
@@ -95,11 +96,21 @@ class FrozenStem(object):
             self.layers_od = [self._layer(od.conv11), self._layer(od.conv12, bn=od.bn1, relu=True, pool=True),
                               self._layer(od.conv21), self._layer(od.conv22, bn=od.bn2, relu=True, pool=True),
                               self._layer(od.conv31), self._layer(od.conv32, bn=od.bn3, relu=True, pool=False)]
+            # conv12 is applied straight to conv11's output (obj_detector.py:72: no nonlinearity between the two convs of
+            # a pair) and both are frozen: when the pair's 3x3 (c_in -> c_mid) . 3x3 (c_mid -> c_out) costs more than one
+            # 5x5 (c_in -> c_out) — 9*c_in + 9*c_mid > 25*c_in, true for 128 -> 512 -> 512 only — it is evaluated as the
+            # composed 5x5 conv plus an exact correction on the image border (see _compose_pair).
+            self.composed = None
+            ci, cm = od.conv11.in_channels, od.conv11.out_channels
+            if os.environ.get("VNQA_STEM_COMPOSE", "1") != "0" and 9 * ci + 9 * cm > 25 * ci:
+                self.composed = self._compose_pair(od.conv11, od.conv12, od.bn1)
             self.out_channels = od.conv32.out_channels
             if vgg is not None:
                 # bn_input becomes the post-affine of the last VGG layer's epilogue
                 s, t = self.bn_input
                 self.layers_vgg[-1]["post"] = (K.pad_vec(s, 128), K.pad_vec(t, 128))
+                if self.composed is not None:
+                    self.layers_vgg[-1]["y_halo"] = 2        # the composed 5x5 conv reads a halo-2 image
 
     def _layer(self, conv, bn=None, relu=False, pool=False):
         w = conv.weight.detach().float()
@@ -132,6 +143,67 @@ class FrozenStem(object):
         return dict(wt=wt, bias=K.pad_vec(b, c_out_pad), relu=relu, pool=pool, post=None,
                     c_out=c_out, c_in=c_in, c_out_pad=c_out_pad, tile=tile)
 
+    def _compose_pair(self, c1, c2, bn):
+        """Two stacked linear convs with frozen weights as ONE conv.
+          y2 = s*(W2 * (W1 * x + b1) + b2) + t        (* = 3x3 'same' conv, s/t = folded eval BatchNorm)
+             = Wc * x + bc  - R(x)                    with Wc = (s W2) (*) W1 (5x5), bc = s b2 + t + sum_taps(s W2) b1
+        R is non-zero on the 1-pixel image border only: conv2 must see ZEROS outside the image, not conv1 evaluated
+        there.  With Y1[q] = b1 + (W1 * x)[q] at the outside-ring positions q of the (H+2)x(W+2) grid,
+          R[p] = sum_{taps d: p+d outside} (s W2)[d] Y1[p+d]
+        i.e. one small GEMM for Y1 (ring im2col x W1) and four edge GEMMs (top / bottom / left / right, K = 3 c_mid);
+        the composed kernel subtracts R from the border pixels' sums before ReLU and pooling."""
+        dev = c1.weight.device
+        w1, b1 = c1.weight.detach().double(), c1.bias.detach().double()
+        w2, b2 = c2.weight.detach().double(), c2.bias.detach().double()
+        scale, shift = _fold_bn(bn)
+        w2 = w2 * scale.double().view(-1, 1, 1, 1)
+        b2 = b2 * scale.double() + shift.double()
+        wc = torch.nn.functional.conv2d(w1.permute(1, 0, 2, 3), w2.flip(2, 3), padding=2).permute(1, 0, 2, 3)   # [co,ci,5,5]
+        bc = b2 + w2.sum((2, 3)) @ b1
+        co, ci, cm = wc.shape[0], wc.shape[1], w1.shape[0]
+        co_pad, ci_pad, cm_pad = L.round_up(co, 64), L.round_up(ci, 64), L.round_up(cm, 64)
+        bf16 = self.cdt == torch.bfloat16
+        tile = L.TILE_STEM_256x256 if (bf16 and co_pad >= 256) else (L.TILE_AUTO if bf16 else L.TILE_128x128)
+        wcf = wc.float().contiguous()
+        if tile == L.TILE_STEM_256x256 and os.environ.get("VNQA_STEM_TILED", "1") != "0":
+            wt = K.pack_conv_weight_tiled(wcf, self.cdt, tile, c_out_pad=co_pad, c_in_pad=ci_pad)
+        else:
+            wt = K.pack_conv_weight(wcf, self.cdt, c_out_pad=co_pad, c_in_pad=ci_pad)
+        # ring GEMM operand: W1 K-major [cm_pad][9*ci_pad]; edge operands: (s W2) slices [co_pad][3*cm_pad]
+        w1m = K.pack_conv_weight(w1.float().contiguous(), self.cdt, c_out_pad=cm_pad, c_in_pad=ci_pad).view(cm_pad, -1)
+
+        def edge(sel):      # sel: [co,cm,3] -> [co_pad, 3*cm_pad] (slot-major, channels fastest)
+            e = torch.zeros(co_pad, 3, cm_pad, dtype=torch.float64, device=dev)
+            e[:co, :, :cm] = sel.permute(0, 2, 1)
+            return e.view(co_pad, -1).to(self.cdt).contiguous()
+        edges = dict(top=edge(w2[:, :, 0, :]), bottom=edge(w2[:, :, 2, :]), left=edge(w2[:, :, :, 0]), right=edge(w2[:, :, :, 2]))
+        return dict(wt=wt, bias=K.pad_vec(bc.float(), co_pad), b1=K.pad_vec(b1.float(), cm_pad), w1m=w1m, edges=edges,
+                    c_in=ci, c_out=co, c_out_pad=co_pad, c_mid_pad=cm_pad, tile=tile, taps=25)
+
+    def _run_composed(self, x, key, slot=0, use_slot=False):
+        """x: halo-2 padded NHWC [n, H+4, W+4, ci_pad] -> relu/pool'ed output of the composed pair (halo 1)."""
+        cp = self.composed
+        n, hp, wp, ci_pad = x.shape
+        H, W = hp - 4, wp - 4
+        cm = cp["c_mid_pad"]
+        # conv1 (+ b1) at the outside-ring positions, then the four edge GEMMs of conv2's outside taps -> ring of R[p]
+        y1 = K.gemm_nt(K.ring_im2col(x, H, W), cp["w1m"], bias=cp["b1"], split_k=False)        # [n*ring, cm_pad]
+        part = [K.gemm_nt(K.ring_edge_gather(y1, n, H, W, e), cp["edges"][name], split_k=False)
+                for e, name in enumerate(("top", "bottom", "left", "right"))]
+        ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
+        ho, wo = H // 2, W // 2
+        out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
+        timed = self.timing is not None and cp["tile"] == L.TILE_STEM_256x256
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        y = K.conv2d_igemm(x, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
+                           tile=cp["tile"], border_sub=ring)
+        if timed:
+            ev1.record()
+            self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25))
+        return y
+
     def _buf(self, key, shape):
         """Persistent zero-halo activation buffer, grown (never shrunk) along the image axis."""
         cap = self._bufs.get(key)
@@ -145,8 +217,9 @@ class FrozenStem(object):
             n, hp, wp, _ = x.shape
             h, w = hp - 2, wp - 2
             ho, wo = (h // 2, w // 2) if ly["pool"] else (h, w)
+            yh = ly.get("y_halo", 1)
             key = (tag, i, ho, wo) if i + 1 < len(layers) + first_index else (tag, i, ho, wo, last_slot)
-            out = self._buf(key, (n, ho + 2, wo + 2, ly["c_out_pad"]))
+            out = self._buf(key, (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
             post = ly["post"]
             tile = ly["tile"]
             timed = self.timing is not None and tile == L.TILE_STEM_256x256
@@ -160,7 +233,7 @@ class FrozenStem(object):
             else:
                 x = K.conv2d_igemm(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                    post_scale=post[0] if post else None, post_shift=post[1] if post else None,
-                                   out=out, tile=tile)
+                                   out=out, tile=tile, y_halo=yh)
             if timed:
                 ev1.record()
                 self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9))
@@ -192,7 +265,14 @@ class FrozenStem(object):
             a = self._buf(("first", H, W), (n_img, H + 2, W + 2, 64))
             K.conv_first(clip, self.first[0], self.first[1], img_of, n_img, self.cdt, out=a)
             x = self._run(a, self.layers_vgg, "vgg")
-        return self._run(x, self.layers_od, "od", last_slot=slot)
+        return self._run_od(x, "od", slot)
+
+    def _run_od(self, x, tag, slot=0):
+        """ObjDetectCNN trunk on a padded NHWC map (halo 2 when the first pair is composed, else halo 1)."""
+        if self.composed is None:
+            return self._run(x, self.layers_od, tag, last_slot=slot)
+        y = self._run_composed(x, (tag, "c"))
+        return self._run(y, self.layers_od[2:], tag, last_slot=slot, first_index=2)
 
     # ---- drop-in per-module paths (reference tensor layouts in and out) -----------------------
     @torch.no_grad()
@@ -211,5 +291,8 @@ class FrozenStem(object):
     def objdet_nchw(self, x):
         s, t = self.bn_input
         xin = x.float() * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1)          # bn_input, eval (obj_detector.py:70)
-        y = self._run(K.nchw_to_nhwc(xin, self.cdt), self.layers_od, "ods")
+        xn = K.nchw_to_nhwc(xin, self.cdt)
+        if self.composed is not None:
+            xn = torch.nn.functional.pad(xn, (0, 0, 1, 1, 1, 1))              # halo 1 -> halo 2
+        y = self._run_od(xn, "ods")
         return K.nhwc_to_nchw(y, self.out_channels)
