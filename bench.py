@@ -38,6 +38,18 @@ def stem_flops_per_frame(H, W):
     return (f(px(1), 3, 64) + f(px(1), 64, 64) + f(px(2), 64, 128) + f(px(2), 128, 128)) + stem512_flops_per_frame(H, W)
 
 
+def stem_executed_flops_per_frame(H, W, composed):
+    """FLOPs the stem actually executes per frame.  With the conv11 . conv12 pair evaluated as one composed 5x5 conv
+    (stem.py: FrozenStem._compose_pair) that pair costs 25*128*512 MACs per pixel plus the border-ring GEMMs instead of
+    (9*128 + 9*512)*512: the ALGORITHMIC figure (reference formulation) stays the work unit of the metric."""
+    if not composed:
+        return stem_flops_per_frame(H, W)
+    h, w = H // 4, W // 4
+    pair = 2.0 * h * w * 512 * (9 * 128 + 9 * 512)
+    ring = 2.0 * (2 * (w + 2) + 2 * h) * 512 * 9 * 128 + 2.0 * (2 * w + 2 * h) * 512 * 3 * 512
+    return stem_flops_per_frame(H, W) - pair + 2.0 * h * w * 128 * 512 * 25 + ring
+
+
 def trunk_flops_per_frame(S, C_in, C, blocks, at):
     conv_init = 2.0 * S * C_in * C * 9
     block = 2.0 * S * C * C * (1 + 9)
@@ -343,11 +355,18 @@ def main():
                        "final_loss": round(float(loss), 4), "inputs": "pinned host memory, H2D every step" if args.h2d else "resident in HBM",
                        "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
                        "stem_alone_ms": round(stem_ms, 3),
-                       "stem_alone_mfma_util": round(n_frames * stem_flops_per_frame(H, W) / (stem_ms * 1e-3) / 1e12 / peak, 4)},
+                       # whole frozen stem alone on the chip: EXECUTED FLOPs / time / peak (hardware utilisation) and the
+                       # same with the reference formulation's algorithmic FLOPs (37.167 GF/frame at 224x224)
+                       "stem_formulation": ("conv11.conv12 composed into one 5x5 conv + exact border correction"
+                                            if stem.composed is not None else "layer by layer"),
+                       "stem_alone_mfma_util": round(n_frames * stem_executed_flops_per_frame(H, W, stem.composed is not None)
+                                                     / (stem_ms * 1e-3) / 1e12 / peak, 4),
+                       "stem_alone_mfma_util_algorithmic": round(n_frames * stem_flops_per_frame(H, W) / (stem_ms * 1e-3)
+                                                                 / 1e12 / peak, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "kernel": "conv_igemm_kernel<bf16,256,256,2,4,TAG=1> (frozen-stem 3x3 igemm, C_in = 512 layers, on "
-                                   "v_mfma_f32_16x16x32_bf16, Cout=512 layers)",
+                         "kernel": "conv_igemm_kernel<bf16,256,256,2,4,TAG=1> (frozen-stem igemm on v_mfma_f32_16x16x32_bf16: "
+                                   "the C_out=512 layers; FLOPs = those its launches execute)",
                          "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
                          "gflop_per_launch": round(flops_per_launch / 1e9, 1)},
         }

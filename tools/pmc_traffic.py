@@ -27,10 +27,10 @@ n = sum(len(v) for v in fetch.values())
 f_avg = sum(sum(v) for v in fetch.values()) / n
 w_avg = sum(sum(v) for v in write.values()) / sum(len(v) for v in write.values())
 res = {
-    "kernel": "conv_igemm_kernel<bf16,256,256,2,4,TAG=1> (frozen-stem igemm: conv12, conv21, conv22, conv31, conv32)",
+    "kernel": "conv_igemm_kernel<bf16,256,256,2,4,TAG=1> (frozen-stem igemm: composed conv11.conv12 (5x5), conv21, conv22, conv31, conv32)",
     "command": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
                "--no-cpu-baseline --no-overlap (two separate passes)",
-    "per_launch_avg_over": "%d dispatches, 5 launches per stem pass (conv12 | conv21, conv22 | conv31, conv32 by grid size)" % n,
+    "per_launch_avg_over": "%d dispatches, 5 launches per stem pass (composed 5x5 | conv21, conv22 | conv31, conv32 by grid size)" % n,
     "FETCH_SIZE_KiB_raw_avg": round(f_avg, 1), "WRITE_SIZE_KiB_avg": round(w_avg, 1),
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> doubled "
                   "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
