@@ -83,6 +83,7 @@ typedef struct vnqa_conv_desc {
 #define VNQA_TILE_STEM_PATCH_224x256 12 /* same kernel, own symbol for the frozen stem */
 #define VNQA_TILE_256x256_W16 13 /* 256x256 with 16 waves (4 per SIMD, 64x64 wave tiles): measured variant, see DESIGN.md */
 #define VNQA_TILE_256x128_W16 14 /* 256x128 with 16 waves (64x32 wave tiles) */
+#define VNQA_TILE_512x128 15 /* 512 pixels x 128 couts, 4x2 waves (128x64 wave tiles as the 256x256 tile; 160 KiB of LDS) */
 #define VNQA_TILE_STEM_256x256 6 /* 256x256 geometry, own kernel symbol for the frozen stem (bf16) */
 
 int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,

@@ -65,7 +65,7 @@ def test_conv_igemm_vs_torch(dt, cfg):
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15])
 def test_conv_igemm_tiles_agree(tile):
     from videonavqa_amd import kernels as K
     g = torch.Generator(device="cpu").manual_seed(tile)
@@ -250,7 +250,7 @@ def test_conv_c64_direct_vs_torch(cfg, shape4):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 15])
 def test_conv_igemm_pretiled_weights(dt, tile):
     """pre-tiled (LDS-image) weight layout gives the same result as the row layout"""
     from videonavqa_amd import kernels as K

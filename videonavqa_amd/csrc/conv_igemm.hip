@@ -313,7 +313,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   };
 
 #ifndef VNQA_NO_STAGGER
+#ifdef VNQA_STAGGER_512
+  constexpr bool kStagger = (PIPE == 2 && NSUB == 2 && NW == 8 && (WAVES_M == 2 || BM == 512));
+#else
   constexpr bool kStagger = (PIPE == 2 && NSUB == 2 && NW == 8 && WAVES_M == 2);   // 256x256 tile only: measured -4 % on the 4x2-wave 256x128 tile
+#endif
 #else
   constexpr bool kStagger = false;
 #endif
@@ -572,6 +576,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_P4_256x64: return launch<vnqa_bf16, 256, 64, 4, 1, 0, 4>(a, st);
       case VNQA_TILE_256x256_W16: return launch<vnqa_bf16, 256, 256, 4, 4, 2>(a, st);
       case VNQA_TILE_256x128_W16: return launch<vnqa_bf16, 256, 128, 4, 4, 2>(a, st);
+      case VNQA_TILE_512x128: return launch<vnqa_bf16, 512, 128, 4, 2, 2>(a, st);
       case VNQA_TILE_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 0, st);
       case VNQA_TILE_STEM_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 1, st);
       default: break;
@@ -612,7 +617,7 @@ namespace {
 int tile_bn(int tile) {
   switch (tile) {
     case VNQA_TILE_256x256: case VNQA_TILE_STEM_256x256: return 256;
-    case VNQA_TILE_256x128: case VNQA_TILE_128x128: case VNQA_TILE_256x128_W24: return 128;
+    case VNQA_TILE_256x128: case VNQA_TILE_128x128: case VNQA_TILE_256x128_W24: case VNQA_TILE_512x128: return 128;
     case VNQA_TILE_256x64: case VNQA_TILE_128x64: return 64;
     default: return 0;
   }
