@@ -358,6 +358,321 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
   }
 }
 
+// ---- wide-tile fused variant: conv1_1 + conv1_2 on 32 x 16 pixel tiles ------------------------------------------------
+// Same algorithm as conv_c64_kernel<8, true>, other geometry: 512 pixels per tile and ALL 64 output channels per wave
+// give 64 px x 64 cout wave tiles (4 + 4 fragment reads per 16 MFMAs instead of 4 + 2 per 8): the 16 x 16 / 64 x 32
+// shape runs at the LDS read bandwidth.  Halo recompute of conv1_1 drops from 27 % to 19.5 % too.  One patch slot
+// (34 x 18 x 128 B), resident weights 72 KiB, image patch 36 x 20 x 8 B: 154.6 KiB of LDS.
+namespace wide {
+constexpr int TX = 32, TY = 16, PX = TX + 2, PY = TY + 2, PROWS_W = PX * PY;       // 612 patch rows
+constexpr int PW_BYTES = ((PROWS_W * 128 + 1023) / 1024) * 1024;                   // 78848
+constexpr int IX = PX + 2, IY = PY + 2, IN_PIX = IX * IY;                          // 36 x 20 = 720 image pixels
+constexpr int X_BYTES = 4096 + 256 + 256;                                         // conv1_1 fragments, its bias, conv1_2's bias
+constexpr int LDS_W = W_BYTES + PW_BYTES + IN_PIX * 8 + X_BYTES;                   // 162944
+static_assert(512 * CROW <= PW_BYTES, "epilogue tile must fit the patch slot");
+static_assert(LDS_W <= 160 * 1024, "LDS budget exceeded");
+}  // namespace wide
+
+__global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args p) {
+  using namespace wide;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ldsW = smem;
+  char* const ldsP = smem + W_BYTES;
+  char* const ldsIn = smem + W_BYTES + PW_BYTES;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fh = lane >> 4;
+
+  const int G = gridDim.x;
+  const int nsl = blockIdx.x % p.nsplit;
+  const long long tiles_total = p.n_work / p.nsplit;
+  const int gslot = blockIdx.x / p.nsplit, gstride = G / p.nsplit;
+
+  {   // resident weights: LDS row (tap*64 + c) <- wt[(nsl*64 + c)][tap][0..63]
+    const size_t wbase = (size_t)nsl * 64 * 9 * 128;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int q = wave * 9 + j;
+      const int row = q * 8 + (lane >> 3);
+      const int tap = row >> 6, c = row & 63;
+      const int lc = (lane & 7) ^ swz128(row);
+      glds16c(p.wt + wbase + ((size_t)c * 9 + tap) * 128 + lc * 16, ldsW + q * 1024);
+    }
+  }
+  auto tile_coords = [&](long long t, int& n, int& y0, int& x0) {
+    const int per_img = p.tilesX * p.tilesY;
+    n = (int)(t / per_img);
+    const int r = (int)(t - (long long)n * per_img);
+    const int ty = r / p.tilesX;
+    y0 = ty * TY;
+    x0 = (r - ty * p.tilesX) * TX;
+  };
+
+  // pixel fragment i of this wave: tile row 2*wave + (i >> 1), columns 16 (i & 1) + fr; all 64 couts (4 fragments)
+  int prow0[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) prow0[i] = (2 * wave + (i >> 1)) * PX + 16 * (i & 1) + fr;
+  int b_rd[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b_rd[j] = (j * 16 + fr) * 128;
+  const int b_sw = swz128(fr);
+  // Per-lane constants that are needed once per tile live in LDS, not in registers (acc 64 + fragments 64 VGPRs already):
+  // conv1_1 weight fragments (A operand: cout 16j + fr, k = 8 fh + e) [j][lane] x 16 B, conv1_1 bias and conv1_2 bias [64].
+  char* const ldsX = ldsIn + IN_PIX * 8;
+  float* const ldsB1 = (float*)(ldsX + 4096);
+  float* const ldsB2 = ldsB1 + 64;
+  int koff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 8 * fh + e;
+    const int kk = k < 27 ? k : 0;
+    const int c = kk / 9, r = (kk - 9 * c) / 3, s_ = kk - 9 * c - 3 * r;
+    koff[e] = k < 27 ? ((r * IX + s_) * 8 + c * 2) : -1;
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      vnqa_bf16x8 f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 8 * fh + e;
+        f[e] = (short)(k < 27 ? f32_to_bf16(p.w1[(16 * j + fr) * 27 + k]) : 0);
+      }
+      *(vnqa_bf16x8*)(ldsX + (j * 64 + lane) * 16) = f;
+    }
+    ldsB1[lane] = p.b1[lane];
+    ldsB2[lane] = p.bias ? p.bias[nsl * 64 + lane] : 0.f;
+  }
+
+  // image pixels under the patch: thread i fetches pixels i and i + 512 (720 in all), 8 bytes each
+  auto load_image_px = [&](long long t, uint2& v0, uint2& v1) {
+    int n, y0, x0;
+    tile_coords(t, n, y0, x0);
+    const size_t img = (size_t)n * (p.H + 4) * (p.W + 4);
+    auto px = [&](int i) {
+      const int iy = i / IX, ix = i - iy * IX;
+      int gy = y0 + iy, gx = x0 + ix;
+      gy = gy < p.H + 4 ? gy : p.H + 3;
+      gx = gx < p.W + 4 ? gx : p.W + 3;
+      return *(const uint2*)(p.x + (img + (size_t)gy * (p.W + 4) + gx) * 8);
+    };
+    v0 = px(threadIdx.x);
+    v1 = threadIdx.x + 512 < IN_PIX ? px(threadIdx.x + 512) : make_uint2(0u, 0u);
+  };
+  // conv1_1 for the 612 patch positions: 39 groups of 16, five per wave.  Three separate sweeps — all B-operand
+  // gathers, all 20 MFMAs, all bias/ReLU/stores — so that nothing waits on the group before it (done group by group
+  // this phase took 28 % of the kernel).
+  auto compute_patch = [&](long long t) {
+    int n, y0, x0;
+    tile_coords(t, n, y0, x0);
+    vnqa_bf16x8 xb[5];
+    int prs[5];
+    bool ins[5];
+#pragma unroll
+    for (int gi = 0; gi < 5; ++gi) {
+      const int pr = (wave + 8 * gi) * 16 + fr;
+      const int prc = pr < PROWS_W ? pr : PROWS_W - 1;
+      const int py = prc / PX, px = prc - py * PX;
+      const char* base = ldsIn + (py * IX + px) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xb[gi][e] = koff[e] >= 0 ? *(const short*)(base + koff[e]) : (short)0;
+      const int gy = y0 + py, gx = x0 + px;
+      prs[gi] = pr;
+      ins[gi] = pr < PROWS_W && gy >= 1 && gy <= p.H && gx >= 1 && gx <= p.W;
+    }
+    vnqa_f32x4 a1[5][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const vnqa_bf16x8 wf = *(const vnqa_bf16x8*)(ldsX + (j * 64 + lane) * 16);
+#pragma unroll
+      for (int gi = 0; gi < 5; ++gi) {
+        const vnqa_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        a1[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[gi], z, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 bb = *(const float4*)(ldsB1 + 16 * j + 4 * fh);
+#pragma unroll
+      for (int gi = 0; gi < 5; ++gi) {
+        uint2 pk = make_uint2(0u, 0u);
+        if (ins[gi]) {
+          pk.x = (unsigned)f32_to_bf16(fmaxf(a1[gi][j][0] + bb.x, 0.f)) | ((unsigned)f32_to_bf16(fmaxf(a1[gi][j][1] + bb.y, 0.f)) << 16);
+          pk.y = (unsigned)f32_to_bf16(fmaxf(a1[gi][j][2] + bb.z, 0.f)) | ((unsigned)f32_to_bf16(fmaxf(a1[gi][j][3] + bb.w, 0.f)) << 16);
+        }
+        const int pr = prs[gi];
+        if (pr < PROWS_W)
+          *(uint2*)(ldsP + pr * 128 + (((2 * j + (fh >> 1)) ^ swz128(pr)) << 4) + ((fh & 1) << 3)) = pk;
+      }
+    }
+  };
+
+  long long t_cur = gslot;
+  uint2 px0 = make_uint2(0u, 0u), px1 = make_uint2(0u, 0u);
+  if (t_cur < tiles_total) load_image_px(t_cur, px0, px1);
+  for (; t_cur < tiles_total; t_cur += gstride) {
+    const bool have_next = t_cur + gstride < tiles_total;
+    *(uint2*)(ldsIn + threadIdx.x * 8) = px0;
+    if (threadIdx.x + 512 < IN_PIX) *(uint2*)(ldsIn + (threadIdx.x + 512) * 8) = px1;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#ifdef VNQA_DIAG_SKIP_DMA   // timing-only: 256 = conv1_1 patch computed for the first tile only, 512 = no epilogue, 1024 = no MFMA loop
+    if (!(p.relu & 256) || t_cur == gslot)
+#endif
+    compute_patch(t_cur);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (have_next) load_image_px(t_cur + gstride, px0, px1);            // in flight under this tile's MFMA loop
+
+    vnqa_f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    auto load_step = [&](int k, vnqa_f32x4* wf, vnqa_f32x4* xf) {
+      const int tap = k >> 1, s = k & 1;
+      const int toff = (tap / 3) * PX + (tap % 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        wf[j] = *(const vnqa_f32x4*)(ldsW + tap * 8192 + b_rd[j] + (((4 * s + fh) ^ b_sw) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pr = prow0[i] + toff;
+        xf[i] = *(const vnqa_f32x4*)(ldsP + pr * 128 + (((4 * s + fh) ^ swz128(pr)) << 4));
+      }
+    };
+    // two k-steps per trip of a ROLLED loop (fragment double buffer a/b): fully unrolled, the compiler hoists all
+    // 18 x 8 swizzled fragment addresses into registers and spills (81 VGPRs over at 256)
+    vnqa_f32x4 wfa[4], xfa[4], wfbb[4], xfbb[4];
+    auto mma16 = [&](const vnqa_f32x4* wf, const vnqa_f32x4* xf) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vnqa_bf16x8, wf[j]),
+                                                             __builtin_bit_cast(vnqa_bf16x8, xf[i]), acc[i][j], 0, 0, 0);
+    };
+    load_step(0, wfa, xfa);
+    __builtin_amdgcn_s_setprio(1);
+#ifdef VNQA_DIAG_SKIP_DMA
+    const int k_end = (p.relu & 1024) ? 2 : 18;
+#else
+    constexpr int k_end = 18;
+#endif
+#pragma unroll 1
+    for (int k = 0; k < k_end; k += 2) {
+      load_step(k + 1, wfbb, xfbb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(wfa, xfa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (k + 2 < 18) load_step(k + 2, wfa, xfa);
+      __builtin_amdgcn_sched_barrier(0);
+      mma16(wfbb, xfbb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();          // every wave is done reading the patch
+
+#ifdef VNQA_DIAG_SKIP_DMA
+    if (p.relu & 512) {
+      float sink = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sink += acc[i][j][0];
+      if (sink == 12345.678f) ((float*)p.y)[0] = sink;
+      continue;
+    }
+#endif
+    // epilogue through the patch slot.  With pooling the 2x2 window is reduced IN REGISTERS first: its two rows are
+    // fragments i and i+2 of the same lane, its two columns the lanes fr and fr^1; only the pooled tile (128 px) goes
+    // through LDS.  (Staging the whole 512-pixel tile and pooling on the way out took 24 % of the kernel.)
+    char* ldsC = ldsP;
+    const bool has_post = p.post_scale != nullptr;
+    if (p.pool) {
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih) {             // column half: tile columns 16 ih + fr
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 bb = *(const float4*)(ldsB2 + 16 * j + 4 * fh);
+          const float b4[4] = {bb.x, bb.y, bb.z, bb.w};
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = fmaxf(acc[ih][j][e], acc[ih + 2][j][e]) + b4[e];       // rows 2 wave and 2 wave + 1 (bias commutes)
+            if (p.relu) t = fmaxf(t, 0.f);
+            v[e] = fmaxf(t, __shfl_xor(t, 1, 64));                            // columns fr and fr ^ 1
+          }
+          if ((fr & 1) == 0) {
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            const int m = wave * (TX / 2) + 8 * ih + (fr >> 1);               // pooled row-major index in the 8 x 16 tile
+            *(uint2*)(ldsC + m * CROW + (16 * j + 4 * fh) * 2) = pk;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ty = 2 * wave + (i >> 1), tx = 16 * (i & 1) + fr;
+        const int m = ty * TX + tx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 bb = *(const float4*)(ldsB2 + 16 * j + 4 * fh);
+          float v[4] = {acc[i][j][0] + bb.x, acc[i][j][1] + bb.y, acc[i][j][2] + bb.z, acc[i][j][3] + bb.w};
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          uint2 pk;
+          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          *(uint2*)(ldsC + m * CROW + (16 * j + 4 * fh) * 2) = pk;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int n, y0, x0;
+    tile_coords(t_cur, n, y0, x0);
+    const int rows_out = p.pool ? 128 : 512;
+    const int side = p.pool ? TX / 2 : TX;
+    const int Ho = p.pool ? (p.H >> 1) : p.H, Wo = p.pool ? (p.W >> 1) : p.W;
+    const int oy0 = p.pool ? (y0 >> 1) : y0, ox0 = p.pool ? (x0 >> 1) : x0;
+    for (int idx = threadIdx.x; idx < rows_out * 8; idx += 512) {
+      const int orow = idx >> 3, c = idx & 7;
+      const int oy = oy0 + orow / side, ox = ox0 + orow % side;
+      if (oy >= Ho || ox >= Wo) continue;
+      const uint4 u = *(const uint4*)(ldsC + orow * CROW + c * 16);
+      uint4 o = u;
+      const int co0 = nsl * 64 + c * 8;
+      if (has_post) {
+        const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] = __uint_as_float(w4[e] << 16);
+          v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
+        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+        o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+      }
+      unsigned short* dst = (unsigned short*)p.y + (((size_t)n * p.Hyp + oy + 1) * p.Wyp + ox + 1) * (size_t)p.Cy + co0;
+      *(uint4*)dst = o;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();          // C tile consumed: the slot may be refilled
+  }
+}
+
 // clip fp32 [B][3][H][W][T] (frames last) -> image list [n_img][H+4][W+4][4] bf16 (halo 2 and channel 3 stay zero:
 // the caller zeroes the buffer once).  One workgroup per (32-pixel run, row, sample): the 3 x 32 x T floats are read
 // as three contiguous runs, transposed through LDS, and every frame writes 32 x 8 contiguous bytes.
@@ -473,11 +788,21 @@ extern "C" int vnqa_conv_first_c64_fwd(const vnqa_conv_desc* d, const void* img4
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_c64_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            LDS_BYTES_FUSED) != hipSuccess) {
-      vnqa_set_error("conv_first_c64_fwd: cannot reserve %d B of LDS", LDS_BYTES_FUSED);
+                            LDS_BYTES_FUSED) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv_first_c64_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            wide::LDS_W) != hipSuccess) {
+      vnqa_set_error("conv_first_c64_fwd: cannot reserve %d B of LDS", wide::LDS_W);
       return VNQA_ERR_HIP;
     }
     attr_set = true;
+  }
+  if (d->tile != 3) {     // default: 32 x 16 pixel tiles (64 x 64 wave tiles); tile == 3 keeps the 16 x 16 shape for A/B runs
+    a.tilesX = (d->w + wide::TX - 1) / wide::TX;
+    a.tilesY = (d->h + wide::TY - 1) / wide::TY;
+    a.n_work = (long long)d->n_img * a.tilesX * a.tilesY * a.nsplit;
+    hipLaunchKernelGGL(conv_first_c64_wide_kernel, dim3((int)c64_grid(a)), dim3(512), wide::LDS_W, (hipStream_t)stream, a);
+    VNQA_CHECK_LAUNCH();
+    return VNQA_OK;
   }
   hipLaunchKernelGGL((conv_c64_kernel<8, true>), dim3((int)c64_grid(a)), dim3(512), LDS_BYTES_FUSED, (hipStream_t)stream, a);
   VNQA_CHECK_LAUNCH();
