@@ -166,6 +166,8 @@ class FrozenStem(object):
         co_pad, ci_pad, cm_pad = L.round_up(co, 64), L.round_up(ci, 64), L.round_up(cm, 64)
         bf16 = self.cdt == torch.bfloat16
         tile = L.TILE_STEM_256x256 if (bf16 and co_pad >= 256) else (L.TILE_AUTO if bf16 else L.TILE_128x128)
+        if bf16 and os.environ.get("VNQA_STEM_COMPOSE_TILE"):
+            tile = int(os.environ["VNQA_STEM_COMPOSE_TILE"])      # A/B hook
         wcf = wc.float().contiguous()
         if tile == L.TILE_STEM_256x256 and os.environ.get("VNQA_STEM_TILED", "1") != "0":
             wt = K.pack_conv_weight_tiled(wcf, self.cdt, tile, c_out_pad=co_pad, c_in_pad=ci_pad)
