@@ -107,3 +107,37 @@ def test_bf16_and_fp32_paths_train_alike():
     assert abs(b[0] - f[0]) < 0.05 * abs(f[0]) + 0.05
     rel = [abs(x - y) / max(abs(y), 1e-3) for x, y in zip(b[:20], f[:20])]
     assert max(rel) < 0.25, rel
+
+
+def test_overlapped_reducer_on_one_rank_rccl_group():
+    """The N>1 gradient path (hook-driven async all-reduces on RCCL's stream, finish(), clip+Adam on the reduced
+    buffer) exercised on the one GPU of this box through a ONE-rank RCCL group: it must reproduce the
+    non-distributed trainer, including with the stem pipeline running on its side stream."""
+    import socket
+    import torch.distributed as dist
+    from videonavqa_amd.train import OverlappedGradReducer, Trainer
+    l0, w0 = _run(True)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        model, stem, batches = _setup()
+        tr = Trainer(model, stem, lr=1e-3, collectives=True)
+        tr.reducer = OverlappedGradReducer(tr.fp, 1, "mean", early_numel=256, active=True)
+        assert len(tr.reducer.early) >= 3          # several parameters take the early (hook) path
+        losses = []
+        for i in range(6):
+            b, nb = batches[i % 3], batches[(i + 1) % 3]
+            loss, _ = tr.step(*b, next_clip=nb[0], next_v_lens_cpu=nb[2])
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        w1 = tr.fp.flat.clone()
+    finally:
+        dist.destroy_process_group()
+    assert all(abs(a - b) <= 1e-5 * max(1.0, abs(a)) for a, b in zip(l0, losses)), (l0, losses)
+    d = (w0 - w1).abs()                      # same tolerances as the pipeline test above (Adam on noise-level gradients)
+    assert float(d.max()) < 6e-3
+    assert float(torch.quantile(d[:1000000], 0.999)) < 1e-5

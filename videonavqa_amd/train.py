@@ -68,14 +68,15 @@ class OverlappedGradReducer(object):
     the remaining ranges and waits for the early ones.  xGMI rings are per-link bound, so few large
     transfers beat many small buckets here."""
 
-    def __init__(self, fp, world_size, loss_reduction="sum", early_numel=1 << 22):
+    def __init__(self, fp, world_size, loss_reduction="sum", early_numel=1 << 22, active=None):
         self.fp, self.world, self.loss_reduction = fp, world_size, loss_reduction
         self.early, self.pending, self.done_ranges = {}, [], []
-        self.enabled = world_size > 1
+        # active=True with world_size 1 runs the collectives on a one-rank group (RCCL code-path test on a 1-GPU box)
+        self.enabled = world_size > 1 if active is None else bool(active)
         off = 0
         for p in fp.params:
             k = p.numel()
-            if world_size > 1 and k >= early_numel:
+            if self.enabled and k >= early_numel:
                 self.early[p] = (off, off + k)
                 p.register_post_accumulate_grad_hook(self._hook)
             off += k
@@ -89,7 +90,7 @@ class OverlappedGradReducer(object):
 
     def finish(self):
         """Call after backward: reduce what the hooks did not cover, wait for everything."""
-        if self.world <= 1 or not self.enabled:
+        if not self.enabled:
             return
         cur = 0
         for a, b in sorted(self.done_ranges) + [(self.fp.n, self.fp.n)]:
@@ -115,19 +116,20 @@ def allreduce_gradients(flat_grad, world_size, loss_reduction="sum"):
 
 class Trainer(object):
     def __init__(self, model, stem, lr=1e-4, clip=1.0, loss_reduction="sum", class_weights=None,
-                 world_size=1, rank=0, feature_channels=512):
+                 world_size=1, rank=0, feature_channels=512, collectives=None):
         self.model, self.stem = model, stem
         self.lr, self.clip = lr, clip
         self.world_size, self.rank = world_size, rank
         self.loss_fn = nn.CrossEntropyLoss(weight=class_weights, reduction=loss_reduction)
         self.loss_reduction = loss_reduction
         self.feature_channels = feature_channels
-        if world_size > 1:
+        collectives = world_size > 1 if collectives is None else bool(collectives)
+        if collectives:
             self.sync_replicas()
         self.fp = FlatParams(model.parameters())
         # software pipeline: the frozen stem of the NEXT minibatch runs on a side stream while this
         # minibatch's trunk forward/backward runs on the main stream (two output slots)
-        self.reducer = OverlappedGradReducer(self.fp, world_size, loss_reduction)
+        self.reducer = OverlappedGradReducer(self.fp, world_size, loss_reduction, active=collectives)
         self.stem_device = self.fp.flat.device
         self.copy_stream = None
         prio = int(os.environ.get("VNQA_STEM_PRIO", "0"))
