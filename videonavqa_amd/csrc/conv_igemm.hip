@@ -445,30 +445,68 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       }
     }
   }
+  float bias_r[TN][NG][4];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const int col = col_of(j, g);  // tile-local cout of e=0
-      const int co = tile_n * BN + col;
-      float b4[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias != nullptr) {
+      const int co = tile_n * BN + col_of(j, g);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b4[e] = (co + e < p.Cout) ? p.bias[co + e] : 0.f;
+      for (int e = 0; e < 4; ++e) bias_r[j][g][e] = (p.bias != nullptr && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+    }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int prow = wm * WTM + i * MT + fr;
+    // composed-conv border correction (vnqa_conv2d_igemm_fwd_ex): all of this pixel's values in one batch of 8-byte loads
+    float sub[TN][NG][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sub[j][g][e] = 0.f;
+    if (ring_row[i] >= 0) {
+      const char* src = (const char*)p.border_sub + ((size_t)ring_row[i] * p.Cout + tile_n * BN) * ES;
+      if constexpr (ES == 2) {
+        uint2 raw[TN][NG];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const int col = col_of(j, g);
+            raw[j][g] = (tile_n * BN + col + 3 < p.Cout) ? *(const uint2*)(src + col * ES) : make_uint2(0u, 0u);
+          }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            sub[j][g][0] = __uint_as_float(raw[j][g].x << 16);
+            sub[j][g][1] = __uint_as_float(raw[j][g].x & 0xffff0000u);
+            sub[j][g][2] = __uint_as_float(raw[j][g].y << 16);
+            sub[j][g][3] = __uint_as_float(raw[j][g].y & 0xffff0000u);
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const int col = col_of(j, g);
+            if (tile_n * BN + col + 3 < p.Cout) {
+              const float4 raw = *(const float4*)(src + col * ES);
+              sub[j][g][0] = raw.x; sub[j][g][1] = raw.y; sub[j][g][2] = raw.z; sub[j][g][3] = raw.w;
+            }
+          }
       }
+    }
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int prow = wm * WTM + i * MT + fr;
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int col = col_of(j, g);  // tile-local cout of e=0
         float v[4];
-        float sub4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ring_row[i] >= 0) {             // composed-conv border correction (vnqa_conv2d_igemm_fwd_ex)
-          const T* src = (const T*)p.border_sub + (size_t)ring_row[i] * p.Cout + co;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) sub4[e] = (co + e < p.Cout) ? ElemOps<T>::load(src[e]) : 0.f;
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[i][j][4 * g + e] + b4[e] - sub4[e];
+          v[e] = acc[i][j][4 * g + e] + bias_r[j][g][e] - sub[j][g][e];
           if (p.relu) v[e] = fmaxf(v[e], 0.f);
         }
         char* dst = smem + prow * CROW + col * ES;
@@ -773,6 +811,7 @@ extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, 
   VNQA_CHECK_ARG(d->y_halo >= 0 && d->y_halo <= 2, "conv2d_igemm_fwd: y_halo must be 0, 1 or 2");
   VNQA_CHECK_ARG(border_sub == nullptr || (d->depth == 0 && d->h >= 2 && d->w >= 2),
                  "conv2d_igemm_fwd: border_sub needs a 2-D conv over images of at least 2x2");
+  VNQA_CHECK_ARG(border_sub == nullptr || d->c_out % 4 == 0, "conv2d_igemm_fwd: border_sub needs c_out % 4 == 0");
   VNQA_CHECK_ARG(!d->pool2 || (d->h % 2 == 0 && d->w % 2 == 0), "conv2d_igemm_fwd: pool2 needs even h,w");
   VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv2d_igemm_fwd: post_scale/post_shift must come together");
   VNQA_CHECK_ARG((long long)d->n_img * (d->depth > 0 ? d->depth : 1) * d->h * d->w < (1ll << 31), "conv2d_igemm_fwd: too many pixels");
