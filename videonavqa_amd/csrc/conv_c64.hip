@@ -507,15 +507,22 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
     }
   };
 
+  // Two workgroup barriers per tile: the image pixels of tile t+1 are fetched under tile t's MFMA loop and put into
+  // ldsIn before the barrier that closes the loop, and the pooled epilogue stores straight from registers.
   long long t_cur = gslot;
   uint2 px0 = make_uint2(0u, 0u), px1 = make_uint2(0u, 0u);
-  if (t_cur < tiles_total) load_image_px(t_cur, px0, px1);
-  for (; t_cur < tiles_total; t_cur += gstride) {
-    const bool have_next = t_cur + gstride < tiles_total;
+  auto put_image_px = [&]() {
     *(uint2*)(ldsIn + threadIdx.x * 8) = px0;
     if (threadIdx.x + 512 < IN_PIX) *(uint2*)(ldsIn + (threadIdx.x + 512) * 8) = px1;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+  };
+  if (t_cur < tiles_total) {
+    load_image_px(t_cur, px0, px1);
+    put_image_px();
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // resident weights, per-lane tables, first image patch
+  __builtin_amdgcn_s_barrier();
+  for (; t_cur < tiles_total; t_cur += gstride) {
+    const bool have_next = t_cur + gstride < tiles_total;
 #ifdef VNQA_DIAG_SKIP_DMA   // timing-only: 256 = conv1_1 patch computed for the first tile only, 512 = no epilogue, 1024 = no MFMA loop
     if (!(p.relu & 256) || t_cur == gslot)
 #endif
@@ -573,6 +580,8 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
+    if (have_next) put_image_px();         // ldsIn is idle during the loop; visible after the barrier below
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // every wave is done reading the patch
 
 #ifdef VNQA_DIAG_SKIP_DMA
@@ -586,14 +595,21 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
       continue;
     }
 #endif
-    // epilogue through the patch slot.  With pooling the 2x2 window is reduced IN REGISTERS first: its two rows are
-    // fragments i and i+2 of the same lane, its two columns the lanes fr and fr^1; only the pooled tile (128 px) goes
-    // through LDS.  (Staging the whole 512-pixel tile and pooling on the way out took 24 % of the kernel.)
-    char* ldsC = ldsP;
+    // Pooled epilogue straight from registers: the 2x2 window's rows are fragments i and i+2 of the same lane, its
+    // columns the lanes fr and fr^1, so after two max steps both lanes of a column pair hold the pooled pixel's 4 couts
+    // 16 j + 4 fh + e (j = 0..3).  Lanes fh and fh^1 swap one 8-byte group so that each of the four lanes
+    // (fr parity q, fh parity hp) owns 8 CONSECUTIVE couts of j = 2 hp + q: one 16-byte store per lane and column half,
+    // no LDS staging and no barrier.  (Staged through LDS this phase took 20 % of the kernel.)
     const bool has_post = p.post_scale != nullptr;
     if (p.pool) {
+      int n, y0, x0;
+      tile_coords(t_cur, n, y0, x0);
+      const int Ho = p.H >> 1, Wo = p.W >> 1;
+      const int oy = (y0 >> 1) + wave;
+      const int q = fr & 1, hp = fh & 1;
 #pragma unroll
       for (int ih = 0; ih < 2; ++ih) {             // column half: tile columns 16 ih + fr
+        uint2 P[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float4 bb = *(const float4*)(ldsB2 + 16 * j + 4 * fh);
@@ -603,18 +619,38 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
           for (int e = 0; e < 4; ++e) {
             float t = fmaxf(acc[ih][j][e], acc[ih + 2][j][e]) + b4[e];       // rows 2 wave and 2 wave + 1 (bias commutes)
             if (p.relu) t = fmaxf(t, 0.f);
-            v[e] = fmaxf(t, __shfl_xor(t, 1, 64));                            // columns fr and fr ^ 1
+            // columns fr and fr ^ 1: DPP quad_perm [1,0,3,2], no LDS-pipe permute
+            v[e] = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF,
+                                                                                     0xF, true)));
           }
-          if ((fr & 1) == 0) {
-            uint2 pk;
-            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            const int m = wave * (TX / 2) + 8 * ih + (fr >> 1);               // pooled row-major index in the 8 x 16 tile
-            *(uint2*)(ldsC + m * CROW + (16 * j + 4 * fh) * 2) = pk;
+          if (has_post) {                            // on the bf16-rounded value, as the LDS-staged variants do
+            const int co = nsl * 64 + 16 * j + 4 * fh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = bf16_to_f32(f32_to_bf16(v[e])) * p.post_scale[co + e] + p.post_shift[co + e];
           }
+          P[j].x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+          P[j].y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        }
+        // this lane stores j = 2 hp + q; its partner lane ^ 16 stores j = 2 (1 - hp) + q and needs this lane's group of it
+        const uint2 lo = q ? P[1] : P[0], hi = q ? P[3] : P[2];
+        // v_permlane16_swap: odd 16-lane rows (hp = 1) of `lo` trade places with the even rows (hp = 0) of `hi` — afterwards
+        // an hp = 0 lane holds {its lo, partner's lo} and an hp = 1 lane {partner's hi, its hi}: 8 consecutive couts each
+        const auto sx = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
+        const uint4 o = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        const int ox = (x0 >> 1) + 8 * ih + (fr >> 1);
+        if (oy < Ho && ox < Wo) {
+          unsigned short* dst = (unsigned short*)p.y + (((size_t)n * p.Hyp + oy + 1) * p.Wyp + ox + 1) * (size_t)p.Cy +
+                                nsl * 64 + 16 * (2 * hp + q) + 8 * (fh >> 1);
+          *(uint4*)dst = o;
         }
       }
-    } else {
+      continue;
+    }
+    // un-pooled epilogue through the patch slot
+    char* ldsC = ldsP;
+    {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ty = 2 * wave + (i >> 1), tx = 16 * (i & 1) + fr;
