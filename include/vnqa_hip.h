@@ -84,6 +84,7 @@ typedef struct vnqa_conv_desc {
 #define VNQA_TILE_256x256_W16 13 /* 256x256 with 16 waves (4 per SIMD, 64x64 wave tiles): measured variant, see DESIGN.md */
 #define VNQA_TILE_256x128_W16 14 /* 256x128 with 16 waves (64x32 wave tiles) */
 #define VNQA_TILE_512x128 15 /* 512 pixels x 128 couts, 4x2 waves (128x64 wave tiles as the 256x256 tile; 160 KiB of LDS) */
+#define VNQA_TILE_P3_256x128 16 /* 256x128, 4x2 waves, ring of three 32-channel stages: 72 KiB of LDS, two workgroups per CU */
 #define VNQA_TILE_STEM_256x256 6 /* 256x256 geometry, own kernel symbol for the frozen stem (bf16) */
 
 int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
@@ -114,6 +115,9 @@ int vnqa_ring_im2col(const void* x, void* out, int32_t n_img, int32_t h, int32_t
                      void* stream);
 int vnqa_ring_edge_gather(const void* y1, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t edge,
                           int32_t dtype, void* stream);
+/* all four edges in one launch: edge e -> rows [e * group_rows, e * group_rows + n_img * (w | h)) of out [4 * group_rows][3 * c] */
+int vnqa_ring_edge_gather_all(const void* y1, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c,
+                              int32_t group_rows, int32_t dtype, void* stream);
 int vnqa_ring_assemble(const void* top, const void* bottom, const void* left, const void* right, void* ring,
                        int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream);
 
@@ -236,6 +240,11 @@ int vnqa_conv3d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, v
 int64_t vnqa_gemm_nt_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype);
 int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bias, void* out, void* workspace,
                  int32_t m, int32_t n, int32_t k, int32_t ldo, int32_t relu, int32_t dtype, void* stream);
+/* Grouped form: `groups` independent products with one shape in ONE launch — a [groups][m_group][k], b [groups][n][k],
+ * out [groups][m_group][ldo]; m_group a multiple of the row tile (256 bf16 / 128 f32; pad rows are computed and ignored).
+ * No bias, no split-K.  Used for the four edge products of the composed stem conv's border correction (stem.py). */
+int vnqa_gemm_nt_grouped(const void* a_gmk, const void* b_gnk, void* out, int32_t groups, int32_t m_group,
+                         int32_t n, int32_t k, int32_t ldo, int32_t dtype, void* stream);
 int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype);
 int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void* workspace, int32_t m, int32_t n,
                  int32_t k, int32_t dtype, void* stream);

@@ -65,7 +65,7 @@ def test_conv_igemm_vs_torch(dt, cfg):
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16])
 def test_conv_igemm_tiles_agree(tile):
     from videonavqa_amd import kernels as K
     g = torch.Generator(device="cpu").manual_seed(tile)
@@ -416,3 +416,25 @@ def test_composed_conv_pair_matches_two_step(dt, cfg):
         cp = stem.composed
         bad = K.conv2d_igemm(xn, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, tile=cp["tile"])
     assert _rel(K.nhwc_to_nchw(bad, Co), ref) > 5 * tol
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_grouped_gemm_and_all_edge_gather_match_per_edge_calls(dt):
+    """vnqa_gemm_nt_grouped / vnqa_ring_edge_gather_all (one launch for the four edge products of the composed conv's
+    border correction) against the per-edge entry points: bit-identical rows."""
+    from videonavqa_amd import kernels as K
+    g = torch.Generator(device="cpu").manual_seed(11)
+    n, H, W, c, co = 3, 6, 9, 64, 72
+    R = 2 * (W + 2) + 2 * H
+    y1 = torch.randn(n * R, c, generator=g).cuda().to(dt)
+    wts = (torch.randn(4, co, 3 * c, generator=g) / (3 * c) ** 0.5).cuda().to(dt)
+    ops = K.ring_edge_gather_all(y1, n, H, W)
+    res = K.gemm_nt_grouped(ops, wts)
+    for e in range(4):
+        ln = W if e < 2 else H
+        one = K.ring_edge_gather(y1, n, H, W, e)
+        assert torch.equal(ops[e, :n * ln], one)
+        ref = K.gemm_nt(one, wts[e].contiguous(), split_k=False)
+        assert torch.equal(res[e, :n * ln], ref)
+        exact = one.float() @ wts[e].float().t()
+        assert _rel(res[e, :n * ln].float(), exact) < _tol(dt)

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "vnqa_conv2d_igemm_fwd_ex": (ctypes.c_int, [_vp] * 9),
     "vnqa_ring_im2col": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_ring_edge_gather": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_ring_edge_gather_all": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_ring_assemble": (ctypes.c_int, [_vp] * 5 + [_i32] * 5 + [_vp]),
     "vnqa_zero_halo": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_pack_fc_weight": (ctypes.c_int, [_vp] + [_i32] * 7 + [_vp, _vp, _vp]),
@@ -67,6 +68,7 @@ _SIGNATURES = {
     "vnqa_conv3d_wgrad": (ctypes.c_int, [_vp] * 5 + [_i32] * 7 + [_vp]),
     "vnqa_gemm_nt_workspace": (_i64, [_i32, _i32, _i32, _i32]),
     "vnqa_gemm_nt": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_gemm_nt_grouped": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_gemm_tn_workspace": (_i64, [_i32, _i32, _i32, _i32]),
     "vnqa_gemm_tn": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_conv2d_wgrad_workspace": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),

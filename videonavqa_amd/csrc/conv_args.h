@@ -20,6 +20,7 @@ struct ConvArgs {
   int D;                    // > 0: 3-D conv over [n][D+2][H+2][W+2][C]; "images" are (n, d) depth slices
   int slices, kt_per_slice; // split-K: K-steps [slice*kt_per_slice, ...) -> fp32 slab
   float* partial;           // [slices][M][Cout] fp32 when slices > 1
+  int group_tiles;          // > 0: grouped GEMM — pixel tile t uses weight rows [(t / group_tiles) * Cout, ...) (vnqa_gemm_nt_grouped)
   const void* border_sub;   // optional [n_img][2W + 2(H-2)][Cout] (element type of y): value SUBTRACTED from the border
                             // pixels' sums before ReLU/pool (ring order: top row, bottom row, left column, right column)
 };

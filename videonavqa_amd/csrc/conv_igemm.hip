@@ -16,6 +16,7 @@
 //
 // Loop: 2-stage LDS double buffer, one barrier per K-step; the next slab's DMA is in flight
 // while the current slab's MFMAs run.
+#include <cstdlib>
 #include "conv_args.h"
 
 namespace {
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   constexpr int NG = NR / 4;                  // groups of 4 consecutive couts per lane and tile
   constexpr int CPS = MT == 32 ? 2 : 4;       // 16-byte chunks one k-substep spans (lane takes chunk fh of them)
   constexpr int ES = (int)sizeof(T);
-  constexpr int ROWB = PIPE == 4 ? 64 : 128;  // bytes of one tile row per stage
+  constexpr int ROWB = PIPE >= 3 ? 64 : 128;  // bytes of one tile row per stage
   constexpr int BK = ROWB / ES;               // channels per stage
   constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
   constexpr int RPI = 1024 / ROWB;            // rows covered by one wave-level DMA instruction
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   constexpr int CROW = BN * ES + 16;          // epilogue LDS row stride (bytes)
   static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0, "tile/wave mismatch");
   static_assert(TM >= 1 && TN >= 1, "wave tile too small");
-  static_assert(PIPE == 2 || PIPE == 4, "PIPE must be 2 or 4");
+  static_assert(PIPE == 2 || PIPE == 3 || PIPE == 4, "PIPE must be 2, 3 or 4");
   // swizzle: spread the 16 rows a ds_read_b128 lane group touches over all 16 slots of a 256-B bank row
   auto swz = [](int row) { return ROWB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
@@ -171,6 +172,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     const int row = (wave * B_PER_WAVE + j) * RPI + lane / CPR;
     int co = tile_n * BN + row;
     co = co < p.Cout ? co : p.Cout - 1;
+    if (p.group_tiles > 0) co += (tile_m / p.group_tiles) * p.Cout;   // grouped GEMM: this pixel tile's own weight matrix
     const int lc = (lane % CPR) ^ swz(row);
     b_off[j] = (size_t)co * w_row_bytes + (size_t)lc * 16;
   }
@@ -368,6 +370,28 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       compute(smem + cur * STAGE_BYTES);
       __syncthreads();
     }
+  } else if constexpr (PIPE == 3) {
+    // ring of 3 slots (stages kt+1, kt+2 in flight): 3/4 of the 4-slot ring's LDS, so that TWO workgroups of the
+    // 256x128 tile share a CU and one's prologue / epilogue hides behind the other's main loop (short-K layers)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+      if (kt0 + d < kt1) stage(kt0 + d, d);
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      if (kt + 1 < kt1) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      const int nxt = cur == 0 ? 2 : cur - 1;               // slot of stage kt-1 == slot of stage kt+2
+      if (kt + 2 < kt1) stage(kt + 2, nxt);
+      __builtin_amdgcn_s_setprio(1);
+      compute(smem + cur * STAGE_BYTES);
+      __builtin_amdgcn_s_setprio(0);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    __builtin_amdgcn_s_barrier();
   } else {
     // ring of 4 slots; stages kt+1..kt+3 are in flight while stage kt is consumed
 #pragma unroll
@@ -572,7 +596,7 @@ template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int TAG = 0, int
 int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int ES = (int)sizeof(T);
-  constexpr int STAGE = (BM + BN) * (PIPE == 4 ? 64 : 128);
+  constexpr int STAGE = (BM + BN) * (PIPE >= 3 ? 64 : 128);
   constexpr int CT = BM * (BN * ES + 16);
   constexpr int LDS = (PIPE * STAGE > CT) ? PIPE * STAGE : CT;
   static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
@@ -615,6 +639,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_256x256_W16: return launch<vnqa_bf16, 256, 256, 4, 4, 2>(a, st);
       case VNQA_TILE_256x128_W16: return launch<vnqa_bf16, 256, 128, 4, 4, 2>(a, st);
       case VNQA_TILE_512x128: return launch<vnqa_bf16, 512, 128, 4, 2, 2>(a, st);
+      case VNQA_TILE_P3_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, 2, 3>(a, st);
       case VNQA_TILE_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 0, st);
       case VNQA_TILE_STEM_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 1, st);
       default: break;
@@ -655,7 +680,8 @@ namespace {
 int tile_bn(int tile) {
   switch (tile) {
     case VNQA_TILE_256x256: case VNQA_TILE_STEM_256x256: return 256;
-    case VNQA_TILE_256x128: case VNQA_TILE_128x128: case VNQA_TILE_256x128_W24: case VNQA_TILE_512x128: return 128;
+    case VNQA_TILE_256x128: case VNQA_TILE_128x128: case VNQA_TILE_256x128_W24: case VNQA_TILE_512x128:
+    case VNQA_TILE_P3_256x128: return 128;
     case VNQA_TILE_256x64: case VNQA_TILE_128x64: return 64;
     default: return 0;
   }
@@ -755,13 +781,15 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   a.Cin = k; a.Cout = n; a.Cy = ldo;
   a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = relu; a.pool = 0;
   a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
-  a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr;
+  a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr; a.group_tiles = 0;
   hipStream_t st = (hipStream_t)stream;
   // bf16: 256-row tiles unless 128-row tiles waste fewer padded rows (e.g. m = 280: 384 instead of 512)
   int tile = VNQA_TILE_128x128;
   if (dtype == VNQA_BF16) {
     const int pad256 = (m + 255) / 256 * 256, pad128 = (m + 127) / 128 * 128;
     tile = (ws > 0 || pad128 >= pad256) ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+    // wide outputs with enough rows to fill the chip with 256x256 tiles (the stem's ring GEMM: 112 -> 85 us)
+    if (ws == 0 && n % 256 == 0 && (int64_t)(pad256 / 256) * (n / 256) >= 384) tile = VNQA_TILE_256x256;
   }
   if (ws > 0) {
     const int slices_req = (int)(ws / ((int64_t)m * n * 4));
@@ -785,6 +813,32 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
     return VNQA_OK;
   }
   return conv_dispatch(a, dtype, tile, st);
+}
+
+extern "C" int vnqa_gemm_nt_grouped(const void* a_gmk, const void* b_gnk, void* out, int32_t groups, int32_t m_group,
+                                    int32_t n, int32_t k, int32_t ldo, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(a_gmk && b_gnk && out, "gemm_nt_grouped: null pointer");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "gemm_nt_grouped: bad dtype %d", dtype);
+  const int bk = dtype == VNQA_BF16 ? 64 : 32, bm = dtype == VNQA_BF16 ? 256 : 128;
+  VNQA_CHECK_ARG(groups > 0 && m_group > 0 && m_group % bm == 0,
+                 "gemm_nt_grouped: m_group=%d must be a positive multiple of the %d-row tile", m_group, bm);
+  VNQA_CHECK_ARG(n > 0 && k > 0 && k % bk == 0, "gemm_nt_grouped: k=%d must be a positive multiple of %d", k, bk);
+  VNQA_CHECK_ARG(n % 8 == 0 && ldo >= n && ldo % 8 == 0, "gemm_nt_grouped: n=%d ldo=%d must be multiples of 8", n, ldo);
+  VNQA_CHECK_ARG((int64_t)groups * m_group < (1ll << 31), "gemm_nt_grouped: too many rows");
+  ConvArgs a;
+  a.x = (const char*)a_gmk;
+  a.wt = (const char*)b_gnk;
+  a.bias = nullptr; a.post_scale = nullptr; a.post_shift = nullptr;
+  a.y = (char*)out;
+  a.n_img = groups * m_group; a.H = 1; a.W = 1; a.Hp = 1; a.Wp = 1;
+  a.Cin = k; a.Cout = n; a.Cy = ldo;
+  a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = 0; a.pool = 0;
+  a.M = groups * m_group; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
+  a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr;
+  a.group_tiles = m_group / bm;
+  int tile = dtype == VNQA_BF16 ? (n % 256 == 0 ? VNQA_TILE_256x256 : VNQA_TILE_256x128) : VNQA_TILE_128x128;
+  if (const char* e = getenv("VNQA_GROUPED_TILE")) tile = atoi(e);     // experiment hook (row tile must divide m_group)
+  return conv_dispatch(a, dtype, tile, (hipStream_t)stream);
 }
 
 extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
@@ -848,8 +902,10 @@ extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, 
   a.kt_per_slice = 1 << 30;
   a.partial = nullptr;
   a.border_sub = border_sub;
+  a.group_tiles = 0;
   VNQA_CHECK_ARG(!d->wt_tiled || (d->tile != VNQA_TILE_AUTO && d->tile != VNQA_TILE_P4_256x256 &&
-                                  d->tile != VNQA_TILE_P4_256x128 && d->tile != VNQA_TILE_P4_256x64),
+                                  d->tile != VNQA_TILE_P4_256x128 && d->tile != VNQA_TILE_P4_256x64 &&
+                                  d->tile != VNQA_TILE_P3_256x128),
                  "conv2d_igemm_fwd: wt_tiled needs an explicit 128-byte-row tile id");
   const int ho = d->pool2 ? d->h / 2 : d->h, wo = d->pool2 ? d->w / 2 : d->w;
   a.Hyp = ho + 2 * d->y_halo;

@@ -257,13 +257,17 @@ __global__ void __launch_bounds__(256) ring_im2col_kernel(const uint4* __restric
 // edge operands: for border pixel j of `edge` (0 top, 1 bottom: j = x; 2 left, 3 right: j = y) the three outside
 // neighbours' y1 rows, zero where the neighbour is a corner owned by the top / bottom group or lies inside the image.
 //   y1 [n][R][cm] -> out [n][len][3][cm], len = W (top/bottom) or H (left/right)
+// group_rows > 0: all four edges in one launch (edge = blockIdx.z), edge e written to rows [e * group_rows, ...) of out
+// — the row-padded operand of vnqa_gemm_nt_grouped.
 __global__ void __launch_bounds__(256) ring_edge_gather_kernel(const uint4* __restrict__ y1, uint4* __restrict__ out, int H,
-                                                               int W, int c16, int edge) {
+                                                               int W, int c16, int edge, int group_rows) {
   const int R = 2 * (W + 2) + 2 * H;
   const int j = blockIdx.x, n = blockIdx.y;
+  if (group_rows > 0) edge = blockIdx.z;
   const int len = edge < 2 ? W : H;
+  if (j >= len) return;
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  uint4* dst = out + ((size_t)n * len + j) * 3 * c16;
+  uint4* dst = out + ((size_t)(group_rows > 0 ? edge * group_rows : 0) + (size_t)n * len + j) * 3 * c16;
   for (int i = threadIdx.x; i < 3 * c16; i += 256) {
     const int slot = i / c16, k = i - slot * c16;
     int r = -1;
@@ -278,30 +282,47 @@ __global__ void __launch_bounds__(256) ring_edge_gather_kernel(const uint4* __re
 }
 
 // ring[n][2W + 2(H-2)][c] = top | bottom | left[1:-1] | right[1:-1], corners += left/right ends   (float accumulate)
+// One thread per 16-byte chunk of a ring row (8 bf16 / 4 f32), 256 threads cover 256 / (C * sizeof(T) / 16) rows.
 template <typename T>
 __global__ void __launch_bounds__(256) ring_assemble_kernel(const T* __restrict__ top, const T* __restrict__ bottom,
                                                             const T* __restrict__ left, const T* __restrict__ right,
-                                                            T* __restrict__ ring, int H, int W, int C) {
+                                                            T* __restrict__ ring, int n_img, int H, int W, int C) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cpr = C / EPC;                                 // chunks per row
   const int RL = 2 * W + 2 * (H - 2);
-  const int r = blockIdx.x, n = blockIdx.y;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float v;
-    if (r < W) {
-      v = ElemOps<T>::load(top[((size_t)n * W + r) * C + c]);
-      if (r == 0) v += ElemOps<T>::load(left[((size_t)n * H + 0) * C + c]);
-      if (r == W - 1) v += ElemOps<T>::load(right[((size_t)n * H + 0) * C + c]);
-    } else if (r < 2 * W) {
-      const int x = r - W;
-      v = ElemOps<T>::load(bottom[((size_t)n * W + x) * C + c]);
-      if (x == 0) v += ElemOps<T>::load(left[((size_t)n * H + H - 1) * C + c]);
-      if (x == W - 1) v += ElemOps<T>::load(right[((size_t)n * H + H - 1) * C + c]);
-    } else if (r < 2 * W + H - 2) {
-      v = ElemOps<T>::load(left[((size_t)n * H + (r - 2 * W) + 1) * C + c]);
-    } else {
-      v = ElemOps<T>::load(right[((size_t)n * H + (r - 2 * W - (H - 2)) + 1) * C + c]);
-    }
-    ring[((size_t)n * RL + r) * C + c] = ElemOps<T>::store(v);
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = idx / cpr;
+  if (row >= (long long)n_img * RL) return;
+  const int c = (int)(idx - row * cpr) * EPC;
+  const int n = (int)(row / RL), r = (int)(row - (long long)n * RL);
+  float v[EPC];
+  auto add = [&](const T* src, int j, int len) {
+    const uint4 raw = *(const uint4*)(src + ((size_t)n * len + j) * C + c);
+    const T* e = (const T*)&raw;
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) v[k] += ElemOps<T>::load(e[k]);
+  };
+#pragma unroll
+  for (int k = 0; k < EPC; ++k) v[k] = 0.f;
+  if (r < W) {
+    add(top, r, W);
+    if (r == 0) add(left, 0, H);
+    if (r == W - 1) add(right, 0, H);
+  } else if (r < 2 * W) {
+    const int x = r - W;
+    add(bottom, x, W);
+    if (x == 0) add(left, H - 1, H);
+    if (x == W - 1) add(right, H - 1, H);
+  } else if (r < 2 * W + H - 2) {
+    add(left, r - 2 * W + 1, H);
+  } else {
+    add(right, r - 2 * W - (H - 2) + 1, H);
   }
+  uint4 outv;
+  T* o = (T*)&outv;
+#pragma unroll
+  for (int k = 0; k < EPC; ++k) o[k] = ElemOps<T>::store(v[k]);
+  *(uint4*)(ring + (size_t)row * C + c) = outv;
 }
 
 inline int grid_for(size_t total, int block) {
@@ -483,7 +504,20 @@ extern "C" int vnqa_ring_edge_gather(const void* y1, void* out, int32_t n_img, i
   const int rb = c * (dtype == VNQA_BF16 ? 2 : 4);
   VNQA_CHECK_ARG((dtype == VNQA_BF16 || dtype == VNQA_F32) && rb % 16 == 0, "ring_edge_gather: bad dtype / channel count");
   hipLaunchKernelGGL(ring_edge_gather_kernel, dim3(edge < 2 ? w : h, n_img), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4*)y1, (uint4*)out, h, w, rb / 16, edge);
+                     (const uint4*)y1, (uint4*)out, h, w, rb / 16, edge, 0);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_ring_edge_gather_all(const void* y1, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c,
+                                         int32_t group_rows, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(y1 && out && n_img > 0 && h >= 2 && w >= 2, "ring_edge_gather_all: bad arguments");
+  VNQA_CHECK_ARG(group_rows >= n_img * (h > w ? h : w), "ring_edge_gather_all: group_rows=%d is smaller than an edge's %d rows",
+                 group_rows, n_img * (h > w ? h : w));
+  const int rb = c * (dtype == VNQA_BF16 ? 2 : 4);
+  VNQA_CHECK_ARG((dtype == VNQA_BF16 || dtype == VNQA_F32) && rb % 16 == 0, "ring_edge_gather_all: bad dtype / channel count");
+  hipLaunchKernelGGL(ring_edge_gather_kernel, dim3(h > w ? h : w, n_img, 4), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)y1, (uint4*)out, h, w, rb / 16, 0, group_rows);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
@@ -492,13 +526,17 @@ extern "C" int vnqa_ring_assemble(const void* top, const void* bottom, const voi
                                   int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream) {
   VNQA_CHECK_ARG(top && bottom && left && right && ring && n_img > 0 && h >= 2 && w >= 2, "ring_assemble: bad arguments");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "ring_assemble: bad dtype %d", dtype);
-  dim3 grid(2 * w + 2 * (h - 2), n_img);
+  const int es = dtype == VNQA_BF16 ? 2 : 4;
+  VNQA_CHECK_ARG(c > 0 && (c * es) % 16 == 0, "ring_assemble: c=%d must fill whole 16-byte chunks", c);
+  const long long chunks = (long long)n_img * (2 * w + 2 * (h - 2)) * (c * es / 16);
+  dim3 grid((unsigned)((chunks + 255) / 256));
   if (dtype == VNQA_BF16)
     hipLaunchKernelGGL(ring_assemble_kernel<vnqa_bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const vnqa_bf16*)top,
-                       (const vnqa_bf16*)bottom, (const vnqa_bf16*)left, (const vnqa_bf16*)right, (vnqa_bf16*)ring, h, w, c);
+                       (const vnqa_bf16*)bottom, (const vnqa_bf16*)left, (const vnqa_bf16*)right, (vnqa_bf16*)ring, n_img, h,
+                       w, c);
   else
     hipLaunchKernelGGL(ring_assemble_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)top,
-                       (const float*)bottom, (const float*)left, (const float*)right, (float*)ring, h, w, c);
+                       (const float*)bottom, (const float*)left, (const float*)right, (float*)ring, n_img, h, w, c);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -109,6 +109,31 @@ def ring_edge_gather(y1, n, H, W, edge):
     return out
 
 
+def ring_edge_gather_all(y1, n, H, W, out=None):
+    """All four edge operands in one launch: [4, group_rows, 3*c] with group_rows = n*max(H,W) rounded up to the 256-row
+    GEMM tile (edge e's n*(W|H) rows first, the pad rows are never read back)."""
+    c = y1.shape[-1]
+    group_rows = L.round_up(n * max(H, W), 256)
+    if out is None:
+        out = torch.empty((4, group_rows, 3 * c), dtype=y1.dtype, device=y1.device)   # pad rows: never read back
+    assert out.shape == (4, group_rows, 3 * c) and out.is_contiguous()
+    L.check(L.lib().vnqa_ring_edge_gather_all(L.ptr(y1), L.ptr(out), n, H, W, c, group_rows, L.dtype_id(y1.dtype),
+                                              L.stream()), "vnqa_ring_edge_gather_all")
+    return out
+
+
+def gemm_nt_grouped(a, b, out=None):
+    """out[g] = a[g] @ b[g].T for a [G, Mg, K], b [G, N, K] in one launch (Mg a multiple of 256)."""
+    G, Mg, Kd = a.shape
+    N = b.shape[1]
+    assert b.shape == (G, N, Kd) and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty((G, Mg, N), dtype=a.dtype, device=a.device)
+    L.check(L.lib().vnqa_gemm_nt_grouped(L.ptr(a), L.ptr(b), L.ptr(out), G, Mg, N, Kd, out.stride(1),
+                                         L.dtype_id(a.dtype), L.stream()), "vnqa_gemm_nt_grouped")
+    return out
+
+
 def ring_assemble(top, bottom, left, right, n, H, W):
     c = top.shape[-1]
     ring = torch.empty((n, 2 * W + 2 * (H - 2), c), dtype=top.dtype, device=top.device)

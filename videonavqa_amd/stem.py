@@ -181,7 +181,9 @@ class FrozenStem(object):
             e[:co, :, :cm] = sel.permute(0, 2, 1)
             return e.view(co_pad, -1).to(self.cdt).contiguous()
         edges = dict(top=edge(w2[:, :, 0, :]), bottom=edge(w2[:, :, 2, :]), left=edge(w2[:, :, :, 0]), right=edge(w2[:, :, :, 2]))
+        edges_all = torch.stack([edges[k] for k in ("top", "bottom", "left", "right")]).contiguous()   # [4, co_pad, 3*cm_pad]
         return dict(wt=wt, bias=K.pad_vec(bc.float(), co_pad), b1=K.pad_vec(b1.float(), cm_pad), w1m=w1m, edges=edges,
+                    edges_all=edges_all,
                     c_in=ci, c_out=co, c_out_pad=co_pad, c_mid_pad=cm_pad, tile=tile, taps=25)
 
     def _run_composed(self, x, key, slot=0, use_slot=False):
@@ -192,8 +194,13 @@ class FrozenStem(object):
         cm = cp["c_mid_pad"]
         # conv1 (+ b1) at the outside-ring positions, then the four edge GEMMs of conv2's outside taps -> ring of R[p]
         y1 = K.gemm_nt(K.ring_im2col(x, H, W), cp["w1m"], bias=cp["b1"], split_k=False)        # [n*ring, cm_pad]
-        part = [K.gemm_nt(K.ring_edge_gather(y1, n, H, W, e), cp["edges"][name], split_k=False)
-                for e, name in enumerate(("top", "bottom", "left", "right"))]
+        if os.environ.get("VNQA_RING_GROUPED", "1") != "0":
+            # the four edge products as ONE grouped GEMM (each alone is 124 tiles: half the chip)
+            res = K.gemm_nt_grouped(K.ring_edge_gather_all(y1, n, H, W), cp["edges_all"])
+            part = [res[0, :n * W], res[1, :n * W], res[2, :n * H], res[3, :n * H]]
+        else:
+            part = [K.gemm_nt(K.ring_edge_gather(y1, n, H, W, e), cp["edges"][name], split_k=False)
+                    for e, name in enumerate(("top", "bottom", "left", "right"))]
         ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
         out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
