@@ -75,6 +75,9 @@ def main():
         md.append("| `%s` | %.1f | %.3f | %.1f | %.1f |" % (n[:110], cnt / a.steps, tot / a.steps / 1e6, tot / cnt / 1e3,
                                                           100.0 * tot / total))
     md.append("")
+    md.append("`Cijk_Ailk_Bljk_DB_*` (an fp64 GEMM) and `im2col_kernel<double>` are ONE-TIME work at model construction — the fp64 "
+              "composition of conv11 and conv12 into the 5x5 kernel (stem.py `_compose_pair`) — divided here by the step count like "
+              "everything else; they do not run inside a training step.")
     md.append("Sum over all kernels: %.3f ms/step of GPU time (two streams overlap, so this exceeds the wall time per step)."
               % (total / a.steps / 1e6))
     with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.md"), "w") as f:
