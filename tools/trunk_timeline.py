@@ -27,3 +27,5 @@ for s, e, n in tr:
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 for k, (cnt, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
     print("%8.1f us  n=%3d  %s" % (us, cnt, k))
+if len(sys.argv) > 3:        # per-launch durations (us) of kernels whose name contains argv[3], in launch order
+    print([round((e - s) / 1e3, 1) for s, e, n in tr if sys.argv[3] in n])

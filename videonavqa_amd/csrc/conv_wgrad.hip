@@ -62,8 +62,20 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
-  // block -> (slice, co tile, tap, ci tile); ci fastest so neighbours share the dY tile
-  int bid = blockIdx.x;
+  // block -> (slice, co tile, tap, ci tile); ci fastest so neighbours share the dY tile.
+  // XCD-aware bijective remap first (hardware deals blocks to the 8 XCDs round-robin): an XCD gets a CONTIGUOUS run of
+  // this list, i.e. the tiles of one or two pixel slices, so the 18 workgroups that read the same dY rows and the same
+  // (tap-shifted) X rows hit one 4 MiB L2 instead of each fetching them from the Infinity Cache.
+  int bid;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+#ifndef VNQA_WGRAD_NO_XCD_REMAP
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+#else
+    bid = b;
+#endif
+  }
   const int tile_ci = bid % p.tilesCi; bid /= p.tilesCi;
   const int tap = bid % p.taps; bid /= p.taps;
   const int tile_co = bid % p.tilesCo; bid /= p.tilesCo;
@@ -96,25 +108,52 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
   }
   const size_t rowA = (size_t)p.Cout * ES, rowB = (size_t)p.Cin * ES;
 
-  auto stage = [&](int kstep, int buf) {
+  // Contraction position of this lane's four staging rows, advanced by KP per stage (no division in the loop):
+  // v = compact index (halo rows skipped when vrow > 0), pa = padded pixel index of the dY row, rem = v % vrow.
+  const int k_begin = slice * p.ksteps_per_slice;
+  int k_end = k_begin + p.ksteps_per_slice;
+  k_end = k_end < p.ksteps_total ? k_end : p.ksteps_total;
+  long long st_v[4], st_pa[4];
+  int st_rem[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long v = (long long)k_begin * KP + st_row[j];
+    st_v[j] = v;
+    st_pa[j] = v;
+    st_rem[j] = 0;
+    if (p.vrow > 0) {                         // 32-bit arithmetic: the 2-D plans are checked to stay below 2^31 pixels
+      const unsigned vi = (unsigned)v;
+      const unsigned img = vi / (unsigned)p.vrow;
+      st_rem[j] = (int)(vi - img * (unsigned)p.vrow);
+      st_pa[j] = (long long)(img * (unsigned)p.prow + (unsigned)p.Wp) + st_rem[j];
+    }
+  }
+  // stages are issued in K order: each call stages the current position and steps to the next
+  auto stage = [&](int buf) {
     char* lds = smem + buf * STAGE_BYTES;
-    const long long p0 = (long long)kstep * KP;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       // dY's top and bottom halo rows are zero: the contraction skips them (12.5 % of a 16x16 padded map); halo
       // COLUMNS stay in, so a tap is still one constant shift of the row pointer
-      const long long v = p0 + st_row[j];
-      long long pa = v;
-      if (p.vrow > 0) {                       // 32-bit arithmetic: the 2-D plans are checked to stay below 2^31 pixels
-        const unsigned vi = (unsigned)v;
-        const unsigned img = vi / (unsigned)p.vrow;
-        pa = (long long)(img * (unsigned)p.prow + (unsigned)p.Wp + (vi - img * (unsigned)p.vrow));
-      }
+      const long long pa = st_pa[j];
       long long pb = pa + dtap;
       pb = pb < 0 ? 0 : (pb < p.Ptot ? pb : p.Ptot - 1);
-      const char* srcA = v < p.Vtot ? p.dy + (size_t)pa * rowA + st_coff_a[j] : (const char*)vnqa_zero_page;
+      const char* srcA = st_v[j] < p.Vtot ? p.dy + (size_t)pa * rowA + st_coff_a[j] : (const char*)vnqa_zero_page;
+#ifndef VNQA_WGRAD_DIAG_NO_A
       glds16w(srcA, lds + (wave * 4 + j) * 1024);
+#endif
+#ifndef VNQA_WGRAD_DIAG_NO_B
       glds16w(p.x + (size_t)pb * rowB + st_coff_b[j], lds + TILE_BYTES + (wave * 4 + j) * 1024);
+#endif
+      st_v[j] += KP;
+      st_pa[j] += KP;
+      if (p.vrow > 0) {
+        st_rem[j] += KP;
+        while (st_rem[j] >= p.vrow) {          // crossed into the next image: jump its two halo rows
+          st_rem[j] -= p.vrow;
+          st_pa[j] += p.prow - p.vrow;
+        }
+      }
     }
   };
 
@@ -140,20 +179,20 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
         for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
   }
 
-  const int k_begin = slice * p.ksteps_per_slice;
-  int k_end = k_begin + p.ksteps_per_slice;
-  k_end = k_end < p.ksteps_total ? k_end : p.ksteps_total;
-
   // fragment-read lane geometry
   const int g = lane >> 4, il = lane & 15, q4 = il >> 2, pp = il & 3;  // tr-read roles
   const int fh = lane >> 5, fr = lane & 31;                            // mfma roles
 
   if (k_begin < k_end) {
-    stage(k_begin, 0);
+    stage(0);
     __syncthreads();
     for (int kt = k_begin; kt < k_end; ++kt) {
       const int cur = (kt - k_begin) & 1;
-      if (kt + 1 < k_end) stage(kt + 1, cur ^ 1);
+#ifdef VNQA_WGRAD_DIAG_NODMA   // timing-only build: the loop without its global->LDS transfers
+      if (kt + 1 < k_end && kt == k_begin) stage(cur ^ 1);
+#else
+      if (kt + 1 < k_end) stage(cur ^ 1);
+#endif
       const char* ldsA = smem + cur * STAGE_BYTES;
       const char* ldsB = ldsA + TILE_BYTES;
       if constexpr (kMma16) {
