@@ -23,8 +23,11 @@ struct WgradArgs {
   const char* dy;
   float* out;       // slab base: [slices][Cout][taps][Cin]
   long long Ptot;   // n*Hp*Wp  (n*Dp*Hp*Wp for 3-D)
-  long long Vtot;   // contraction extent: Ptot, or n*H*Wp when the halo ROWS are skipped (2-D convs)
-  int vrow, prow;   // H*Wp and Hp*Wp: compact index v -> padded pixel (v / vrow) * prow + Wp + v % vrow (vrow = 0: identity)
+  long long Vtot;   // contraction extent: Ptot, or n*H*W when only the VALID pixels are visited (2-D convs)
+  int vrow, prow;   // H*W and Hp*Wp: compact index v -> image v / vrow, (y, x) = divmod(v % vrow, vw) -> padded pixel
+                    // img * prow + (y + 1) * Wp + x + 1   (vrow = 0: identity, every padded position is visited)
+  int vw;           // W
+  unsigned vw_magic;  // ceil(2^32 / W): y = umulhi(rem, vw_magic) is exact for rem < 2^32 / W
   int Wp, Hp;
   int Cin, Cout, taps;
   int tilesCo, tilesCi;
@@ -125,7 +128,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
       const unsigned vi = (unsigned)v;
       const unsigned img = vi / (unsigned)p.vrow;
       st_rem[j] = (int)(vi - img * (unsigned)p.vrow);
-      st_pa[j] = (long long)(img * (unsigned)p.prow + (unsigned)p.Wp) + st_rem[j];
+      st_pa[j] = (long long)img * p.prow + p.Wp + 1;      // padded index of the image's first valid pixel
     }
   }
   // stages are issued in K order: each call stages the current position and steps to the next
@@ -133,9 +136,14 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
     char* lds = smem + buf * STAGE_BYTES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      // dY's top and bottom halo rows are zero: the contraction skips them (12.5 % of a 16x16 padded map); halo
-      // COLUMNS stay in, so a tap is still one constant shift of the row pointer
-      const long long pa = st_pa[j];
+      // dY's halo is zero: the contraction visits the valid pixels only (a 16x16 padded map has 23 % halo); a tap is
+      // still one constant shift of the padded pixel index
+      long long pa = st_pa[j];
+      if (p.vrow > 0) {
+        const unsigned rem = (unsigned)st_rem[j];
+        const unsigned y = __umulhi(rem, p.vw_magic);
+        pa += (long long)(y * (unsigned)p.Wp + (rem - y * (unsigned)p.vw));
+      }
       long long pb = pa + dtap;
       pb = pb < 0 ? 0 : (pb < p.Ptot ? pb : p.Ptot - 1);
       const char* srcA = st_v[j] < p.Vtot ? p.dy + (size_t)pa * rowA + st_coff_a[j] : (const char*)vnqa_zero_page;
@@ -146,13 +154,14 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
       glds16w(p.x + (size_t)pb * rowB + st_coff_b[j], lds + TILE_BYTES + (wave * 4 + j) * 1024);
 #endif
       st_v[j] += KP;
-      st_pa[j] += KP;
       if (p.vrow > 0) {
         st_rem[j] += KP;
-        while (st_rem[j] >= p.vrow) {          // crossed into the next image: jump its two halo rows
+        while (st_rem[j] >= p.vrow) {          // crossed into the next image
           st_rem[j] -= p.vrow;
-          st_pa[j] += p.prow - p.vrow;
+          st_pa[j] += p.prow;
         }
+      } else {
+        st_pa[j] += KP;
       }
     }
   };
@@ -380,22 +389,27 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const T* __restrict
 struct Plan {
   int tilesCo, tilesCi, ksteps_total, slices, ksteps_per_slice, colsum_blocks;
   long long Ptot, Vtot;
-  int vrow, prow;
+  int vrow, prow, vw;
 };
 
-Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype, long long Vtot = -1, int vrow = 0, int prow = 0);
+Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype, long long Vtot = -1, int vrow = 0, int prow = 0,
+                 int vw = 0);
 
 Plan make_plan(int n_img, int h, int w, int c_in, int c_out, int taps, int dtype) {
 #ifdef VNQA_WGRAD_ALL_ROWS     // A/B: contract over every padded pixel
   return make_plan_k((long long)n_img * (h + 2) * (w + 2), c_in, c_out, taps, dtype);
 #else
-  return make_plan_k((long long)n_img * (h + 2) * (w + 2), c_in, c_out, taps, dtype, (long long)n_img * h * (w + 2),
-                     h * (w + 2), (h + 2) * (w + 2));
+  // (the row decode's reciprocal multiply is exact for h * w * w < 2^32 and needs w >= 2; otherwise every padded pixel is visited)
+  if (w < 2 || (long long)h * w * w >= (1ll << 32))
+    return make_plan_k((long long)n_img * (h + 2) * (w + 2), c_in, c_out, taps, dtype);
+  return make_plan_k((long long)n_img * (h + 2) * (w + 2), c_in, c_out, taps, dtype, (long long)n_img * h * w, h * w,
+                     (h + 2) * (w + 2), w);
 #endif
 }
 
-Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype, long long Vtot, int vrow, int prow) {
+Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype, long long Vtot, int vrow, int prow, int vw) {
   Plan pl;
+  pl.vw = vw;
   pl.Ptot = Ptot;
   pl.Vtot = Vtot < 0 ? Ptot : Vtot;
   pl.vrow = vrow;
@@ -509,6 +523,8 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   a.Vtot = pl.Vtot;
   a.vrow = pl.vrow;
   a.prow = pl.prow;
+  a.vw = pl.vw;
+  a.vw_magic = pl.vw > 0 ? (unsigned)(((1ull << 32) + pl.vw - 1) / pl.vw) : 0u;
   a.Wp = w + 2;
   a.Hp = h + 2;
   a.Cin = c_in;
