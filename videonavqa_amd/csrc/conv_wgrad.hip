@@ -48,6 +48,13 @@ __device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
+// 16-byte-chunk XOR swizzle of a [pixel row][256 channels] bf16 tile (512-byte rows) for ds_read_b64_tr_b16, which is
+// served in two 32-lane groups over 64 banks x 4 B: the four rows q4 of a 16-lane group go to four different 64-byte
+// units (row bits 0-1 -> chunk bits 2-3), and the two 16-lane groups of a 32-lane access, 8 rows apart in the 16x16x32
+// fragment layout, to the two 32-byte halves of a unit (row bit 3 -> chunk bit 1).  Without the second term both groups
+// hit the same 32 banks (2-way conflict on every fragment read).  Rows r and r + 4 (the lo / hi halves) swizzle alike.
+__device__ __forceinline__ int swz_tr(int row) { return ((row & 3) << 2) | (((row >> 3) & 1) << 1); }
+
 // BM = BN = 256 channels, 8 waves as 2 (co) x 4 (ci): wave tile 128 co x 64 ci.
 template <typename T>
 __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
@@ -99,7 +106,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
   for (int j = 0; j < 4; ++j) {
     const int lin = (wave * 4 + j) * 64 + lane;   // 16-byte chunk index within the tile
     const int row = lin / CPR, phys = lin - row * CPR;
-    const int logical = (ES == 2) ? (phys ^ ((row & 3) << 2)) : phys;
+    const int logical = (ES == 2) ? (phys ^ swz_tr(row)) : phys;
     st_row[j] = row;
     // clamp channel tiles that stick out of the tensor (results for those rows/cols are dropped)
     int ca = tile_co * BCH + logical * (16 / ES);
@@ -209,7 +216,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
         // fragments of substep s+1 are read before the MFMAs of substep s are issued
         auto load16 = [&](int s, vnqa_bf16x8* af, vnqa_bf16x8* bf) {
           const int row0 = 32 * s + 8 * g + q4;
-          const int sw = (row0 & 3) << 2;
+          const int sw = swz_tr(row0);
           const int sub = (pp & 1) << 3;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
@@ -256,7 +263,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
         for (int s = 0; s < KP / 16; ++s) {
           // lane supplies row (16 s + 8 (g>>1) + q4 [+4]), 4 channels starting at 16(g&1) + 4 pp
           const int row0 = 16 * s + 8 * (g >> 1) + q4;
-          const int sw = (row0 & 3) << 2;
+          const int sw = swz_tr(row0);
           vnqa_bf16x8 af[TM], bf[TN];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
