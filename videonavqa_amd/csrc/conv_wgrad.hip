@@ -47,6 +47,20 @@ __device__ __attribute__((aligned(16))) char vnqa_zero_page[64];
 __device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
+// The same read as inline asm.  The compiler cannot tell that the transposed-read builtin does not alias the LDS-DMA of
+// the NEXT stage and puts `s_waitcnt vmcnt(0)` in front of the first fragment read of every K-step (the plain ds_read_b128
+// of conv_igemm.hip do not get one): the whole global->LDS transfer was exposed, 25 % of the kernel.  Reads issued from
+// asm are invisible to that pass; the caller waits for them with lds_tr_wait() and ties the fragments to it.
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr_read_asm(unsigned addr) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ void lds_tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // 16-byte-chunk XOR swizzle of a [pixel row][256 channels] bf16 tile (512-byte rows) for ds_read_b64_tr_b16, which is
 // served in two 32-lane groups over 64 banks x 4 B: the four rows q4 of a 16-lane group go to four different 64-byte
@@ -218,6 +232,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
           const int row0 = 32 * s + 8 * g + q4;
           const int sw = swz_tr(row0);
           const int sub = (pp & 1) << 3;
+#ifdef VNQA_WGRAD_TR_BUILTIN
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int off = ((((wm * 128 + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4;
@@ -232,6 +247,33 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
             const s16x4 hi = lds_tr_read(ldsB + (row0 + 4) * RB + off + sub);
             bf[j] = vnqa_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           }
+#else
+          const unsigned baseA = lds_addr(ldsA) + row0 * RB + sub, baseB = lds_addr(ldsB) + row0 * RB + sub;
+          s16x4 alo[8], ahi[8], blo[4], bhi[4];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const unsigned a = baseA + (((((wm * 128 + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
+            alo[i] = lds_tr_read_asm<0>(a);
+            ahi[i] = lds_tr_read_asm<4 * RB>(a);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned a = baseB + (((((wn * 64 + j * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
+            blo[j] = lds_tr_read_asm<0>(a);
+            bhi[j] = lds_tr_read_asm<4 * RB>(a);
+          }
+          lds_tr_wait();
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));      // the fragments exist only after the wait above
+            af[i] = vnqa_bf16x8{alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
+            bf[j] = vnqa_bf16x8{blo[j][0], blo[j][1], blo[j][2], blo[j][3], bhi[j][0], bhi[j][1], bhi[j][2], bhi[j][3]};
+          }
+#endif
         };
 #ifdef VNQA_WGRAD_PREFETCH   // register double-buffering of the fragments: 22 VGPR spills at 256 registers, measured slower
         vnqa_bf16x8 af[2][8], bf[2][4];
