@@ -788,8 +788,8 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   if (dtype == VNQA_BF16) {
     const int pad256 = (m + 255) / 256 * 256, pad128 = (m + 127) / 128 * 128;
     tile = (ws > 0 || pad128 >= pad256) ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
-    // wide outputs with enough rows to fill the chip with 256x256 tiles (the stem's ring GEMM: 112 -> 85 us)
-    if (ws == 0 && n % 256 == 0 && (int64_t)(pad256 / 256) * (n / 256) >= 384) tile = VNQA_TILE_256x256;
+    // (256x256 tiles for wide outputs — the stem's ring GEMM alone 112 -> 90 us — were measured and dropped: neutral end to
+    // end at 224x224, -9 % at 160x208 where 412 such tiles fill 1.6 rounds of the chip)
   }
   if (ws > 0) {
     const int slices_req = (int)(ws / ((int64_t)m * n * 4));

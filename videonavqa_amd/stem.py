@@ -194,8 +194,10 @@ class FrozenStem(object):
         cm = cp["c_mid_pad"]
         # conv1 (+ b1) at the outside-ring positions, then the four edge GEMMs of conv2's outside taps -> ring of R[p]
         y1 = K.gemm_nt(K.ring_im2col(x, H, W), cp["w1m"], bias=cp["b1"], split_k=False)        # [n*ring, cm_pad]
-        if os.environ.get("VNQA_RING_GROUPED", "1") != "0":
-            # the four edge products as ONE grouped GEMM (each alone is 124 tiles: half the chip)
+        if os.environ.get("VNQA_RING_GROUPED", "0") != "0":
+            # the four edge products as ONE grouped GEMM on 256x256 tiles: 164 -> 110 us alone and the stem alone 1 % faster,
+            # but END TO END the four small launches on 128x128 tiles (two workgroups per CU) interleave better with the
+            # co-running trunk: same-box A/B 836 vs 830 clips/s at 224x224, 1013 vs 982 at 160x208 — so this is opt-in
             res = K.gemm_nt_grouped(K.ring_edge_gather_all(y1, n, H, W), cp["edges_all"])
             part = [res[0, :n * W], res[1, :n * W], res[2, :n * H], res[3, :n * H]]
         else:
