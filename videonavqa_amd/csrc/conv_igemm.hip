@@ -623,7 +623,10 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
     if (tile == VNQA_TILE_AUTO) {
       if (a.Cout <= 64) tile = VNQA_TILE_256x64;
       else if (a.Cout <= 128) tile = VNQA_TILE_256x128;   // (128x128 is faster alone, slower when two streams co-run)
-      else tile = VNQA_TILE_256x256;
+      else {
+        static const int wide_tile = [] { const char* e = getenv("VNQA_AUTO_TILE_WIDE"); return e ? atoi(e) : VNQA_TILE_256x256; }();
+        tile = wide_tile;       // experiment hook for the trunk's C_out >= 256 layers (end-to-end A/B of tile shapes)
+      }
     }
     switch (tile) {
       case VNQA_TILE_256x256: return launch<vnqa_bf16, 256, 256, 2, 4>(a, st);

@@ -209,6 +209,16 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
         for (int e = 0; e < 4; ++e) acc16[i][j][e] = 0.f;
   }
 
+  // (Measured and dropped: an L2 warm-up two stages ahead — one 4-byte LDS-DMA per lane and stage to each of the next-but-one
+  // stage's 512 lines, left in flight by a vmcnt(1) wait.  The transfers are first touches (86 % L2 hits, 25 GB/s per CU,
+  // 28 % of the kernel), but the 64 separate lines of such an instruction cost the texture addresser as much as eight
+  // staging instructions: 0.347 -> 0.370 ms.)
+  // end of a stage: the staged tile of the next stage has landed, every wave is done reading the current one
+  auto stage_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
   // fragment-read lane geometry
   const int g = lane >> 4, il = lane & 15, q4 = il >> 2, pp = il & 3;  // tr-read roles
   const int fh = lane >> 5, fr = lane & 31;                            // mfma roles
@@ -345,7 +355,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
       }
-      __syncthreads();
+      stage_sync();
     }
   }
 
