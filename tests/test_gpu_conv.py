@@ -111,7 +111,10 @@ def test_dgrad_via_flipped_weights(dt):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cfg", [(3, 10, 13, 64, 64, 9), (6, 14, 14, 128, 320, 9), (4, 14, 14, 512, 64, 1),
-                                 (40, 14, 14, 256, 256, 9)])
+                                 (40, 14, 14, 256, 256, 9),
+                                 # valid-pixel contraction edge cases: maps smaller than one 64-pixel K-step (several image
+                                 # wraps per stage), a single row, a single column (falls back to the all-padded-pixels plan)
+                                 (37, 3, 5, 64, 64, 9), (70, 1, 7, 64, 128, 9), (9, 6, 1, 64, 64, 9), (150, 2, 2, 64, 64, 9)])
 def test_wgrad_vs_torch(dt, cfg):
     from videonavqa_amd import kernels as K
     N, H, W, Cin, Cout, taps = cfg
