@@ -130,7 +130,8 @@ class FrozenStem(object):
             # 128x128 (2 workgroups/CU) is 20 % faster for conv2_2 ALONE but costs 10 % end to end when the trunk co-runs on
             # the other stream (same-box A/B): finer interleaving of the two streams' workgroups hurts both
             t128 = L.TILE_128x128 if os.environ.get("VNQA_STEM_T128", "0") == "1" else int(os.environ.get("VNQA_STEM_C128_TILE", "15"))
-            tile = L.TILE_STEM_256x256 if c_out_pad >= 256 else (t128 if c_out_pad > 64 else L.TILE_256x64)
+            t512 = int(os.environ.get("VNQA_STEM_C512_TILE", str(L.TILE_STEM_256x256)))     # end-to-end A/B hook
+            tile = t512 if c_out_pad >= 256 else (t128 if c_out_pad > 64 else L.TILE_256x64)
             # conv11 (C_in = 128: only 18 K-steps, and a 964 MB output to store): the 16-wave shape of the same tile
             # keeps more store / DMA issue slots busy around its short main loop (+10 % on this layer, -2..4 % on the
             # 72-K-step layers, which therefore keep the 8-wave staggered kernel)
