@@ -97,3 +97,25 @@ def test_full_size_training_steps_are_sane():
     assert losses[-1] < losses[0], losses                        # fixed batch: the loss goes down
     assert float(tr.fp.grad.abs().max()) == 0.0                  # fused zero_grad
     assert bool(torch.isfinite(tr.fp.flat).all())
+
+
+def test_full_size_trunk_wgrad_vs_torch_and_additivity():
+    """The trunk's weight-gradient launch at BASELINE size (280 images x 14x14, 512 -> 512, 3x3: 36 tiles x 7 pixel slices,
+    XCD-remapped) against torch's fp32 conv backward on the same bf16-rounded operands, and additivity over a split of
+    the images (dW of all = dW of the first 100 + dW of the rest)."""
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(2)
+    N, H, W, C = 280, 14, 14, 512
+    x = torch.randn(N, C, H, W, generator=g).cuda().bfloat16().float()
+    dy = torch.randn(N, C, H, W, generator=g).cuda().bfloat16().float()
+    w = torch.zeros(C, C, 3, 3, device="cuda", requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    xn, dyn = K.nchw_to_nhwc(x, torch.bfloat16, c_pad=C), K.nchw_to_nhwc(dy, torch.bfloat16, c_pad=C)
+    dwt, dbias = K.conv2d_wgrad(xn, dyn, 9)
+    dw = K.unpack_conv_wgrad(dwt, C, C)
+    scale = float(w.grad.abs().max())
+    assert float((dw - w.grad).abs().max()) < 2e-4 * scale
+    assert float((dbias - dy.sum((0, 2, 3))).abs().max()) < 2e-4 * float(dy.sum((0, 2, 3)).abs().max())
+    a, _ = K.conv2d_wgrad(xn[:100].contiguous(), dyn[:100].contiguous(), 9)
+    b, _ = K.conv2d_wgrad(xn[100:].contiguous(), dyn[100:].contiguous(), 9)
+    assert float((a + b - dwt).abs().max()) < 2e-4 * scale
