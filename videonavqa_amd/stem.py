@@ -271,9 +271,13 @@ class FrozenStem(object):
             ho, wo = (H // 2, W // 2) if ly["pool"] else (H, W)
             out = self._buf(("vgg", 0, ho, wo), (n_img, ho + 2, wo + 2, ly["c_out_pad"]))
             post = ly["post"]
-            x = K.conv_first_c64(img4, self.first[0], self.first[1], ly["wt"], bias=ly["bias"], relu=ly["relu"],
+            split = int(os.environ.get("VNQA_C64_SPLIT", "1"))     # A/B hook: the persistent kernel as several shorter launches
+            step = (n_img + split - 1) // split
+            for n0 in range(0, n_img, step):
+                K.conv_first_c64(img4[n0:n0 + step], self.first[0], self.first[1], ly["wt"], bias=ly["bias"], relu=ly["relu"],
                                  pool2=ly["pool"], post_scale=post[0] if post else None,
-                                 post_shift=post[1] if post else None, out=out)
+                                 post_shift=post[1] if post else None, out=out[n0:n0 + step])
+            x = out
             x = self._run(x, self.layers_vgg[1:], "vgg", first_index=1)
         else:
             a = self._buf(("first", H, W), (n_img, H + 2, W + 2, 64))
