@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
             for (int j = 0; j < 4; ++j)
               acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s & 1][i], bf[s & 1][j], acc16[i][j], 0, 0, 0);
         }
-#else
+#elif defined(VNQA_WGRAD_TR_BUILTIN) || !defined(VNQA_WGRAD_ROLLING)
 #pragma unroll
         for (int s = 0; s < KP / 32; ++s) {
           vnqa_bf16x8 af[8], bf[4];
@@ -308,6 +308,65 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
               acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc16[i][j], 0, 0, 0);
+        }
+#else
+        // (-DVNQA_WGRAD_ROLLING, measured +-2 % for look-aheads 2..5 and left off: the loop is bound by its LDS-DMA, not by
+        // fragment latency.)  Rolling fragment reads (asm-issued, counted lgkmcnt waits): the four ci fragments and two co fragments are
+        // requested up front, then co fragment i+2 is requested before the 4 MFMAs of fragment i are issued — the LDS
+        // latency hides behind this wave's own MFMAs with 3 co fragments live instead of 8 (no register double buffer).
+        // LDS operations retire in order, so "at most N younger reads outstanding" identifies fragment i exactly; a
+        // stray scalar load in between could only make the wait longer.
+#pragma unroll
+        for (int s = 0; s < KP / 32; ++s) {
+          const int row0 = 32 * s + 8 * g + q4;
+          const int sw = swz_tr(row0);
+          const int sub = (pp & 1) << 3;
+          const unsigned baseA = lds_addr(ldsA) + row0 * RB + sub, baseB = lds_addr(ldsB) + row0 * RB + sub;
+          s16x4 alo[8], ahi[8], blo[4], bhi[4];
+          auto req_a = [&](int i) {
+            const unsigned a = baseA + (((((wm * 128 + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
+            alo[i] = lds_tr_read_asm<0>(a);
+            ahi[i] = lds_tr_read_asm<4 * RB>(a);
+          };
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned a = baseB + (((((wn * 64 + j * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
+            blo[j] = lds_tr_read_asm<0>(a);
+            bhi[j] = lds_tr_read_asm<4 * RB>(a);
+          }
+#ifndef VNQA_WGRAD_LOOKAHEAD
+#define VNQA_WGRAD_LOOKAHEAD 2
+#endif
+          constexpr int LA = VNQA_WGRAD_LOOKAHEAD;
+#pragma unroll
+          for (int i = 0; i < LA; ++i) req_a(i);
+          vnqa_bf16x8 bf[4];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (i + LA < 8) req_a(i + LA);
+            const int younger = ((i + LA < 8 ? i + LA : 7) - i) * 2;      // reads issued after fragment i's
+            switch (younger) {
+              case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+              case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+              case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+              case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+              case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+              default: asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory"); break;
+            }
+            if (i == 0) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                asm volatile("" : "+v"(blo[j]), "+v"(bhi[j]));
+                bf[j] = vnqa_bf16x8{blo[j][0], blo[j][1], blo[j][2], blo[j][3], bhi[j][0], bhi[j][1], bhi[j][2], bhi[j][3]};
+              }
+            }
+            asm volatile("" : "+v"(alo[i]), "+v"(ahi[i]));
+            const vnqa_bf16x8 af = vnqa_bf16x8{alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[j], acc16[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);     // keep request i+3 behind these MFMAs in program order
+          }
         }
 #endif
       } else if constexpr (ES == 2) {
