@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
   // (Measured and dropped: an L2 warm-up two stages ahead — one 4-byte LDS-DMA per lane and stage to each of the next-but-one
   // stage's 512 lines, left in flight by a vmcnt(1) wait.  The transfers are first touches (86 % L2 hits, 25 GB/s per CU,
   // 28 % of the kernel), but the 64 separate lines of such an instruction cost the texture addresser as much as eight
-  // staging instructions: 0.347 -> 0.370 ms.)
+  // staging instructions: 0.347 -> 0.370 ms.  A cooperative form — wave 0 of each of the 18 workgroups that stream the same
+  // rows touches only its 1/18 share, one instruction per workgroup and stage — was slower too: 0.355 -> 0.374 ms.)
   // end of a stage: the staged tile of the next stage has landed, every wave is done reading the current one
   auto stage_sync = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
