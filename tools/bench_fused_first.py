@@ -1,3 +1,5 @@
+"""Micro-benchmark of the fused conv1_1+conv1_2 kernel (280 frames x 224x224): 16x16 vs 32x16 (wide) tile shapes.
+argv[1] = value of the `relu` field (1, or the timing-only flags 256 / 512 / 1024 of a -DVNQA_DIAG_SKIP_DMA build)."""
 import torch
 from videonavqa_amd import kernels as K, _lib as L
 import ctypes

@@ -1,3 +1,4 @@
+"""Micro-benchmark of the trunk's weight-gradient launch (280 images x 14x14, 512 -> 512, 3x3, bf16)."""
 import torch, json
 from videonavqa_amd import kernels as K
 N, h, w, C = 280, 14, 14, 512

@@ -1,3 +1,4 @@
+"""Prints CPU model / core count / torch thread settings of the box (context for bench.py's cpu_baseline)."""
 import os, time, sys, torch
 sys.path.insert(0, "/root/repo")
 print("cpu_count", os.cpu_count(), "torch threads", torch.get_num_threads(), flush=True)

@@ -1,3 +1,4 @@
+"""Host-side (launch thread) cost of one MACNetwork training step: enqueue time of forward / backward + a cProfile."""
 import time, torch, cProfile, pstats
 from videonavqa_amd.models import MACNetwork
 from videonavqa_amd.models.common import FrameLayout, NativeFeatures
