@@ -17,6 +17,7 @@
 // conv1_1 + bias + ReLU for the 324 patch positions on MFMA (K padded to 32: one v_mfma_f32_16x16x32_bf16 per
 // 16 positions x 16 channels) and writes the result straight into the LDS patch image, zero where the position
 // lies in conv1_2's zero padding.  conv1_1's output never touches HBM (-3.7 GB of traffic per 280-frame pass).
+#include <cstdlib>
 #include "vnqa_common.h"
 
 namespace {
@@ -776,7 +777,12 @@ int c64_fill(const vnqa_conv_desc* d, const void* x, const void* wt, const float
 }
 
 long long c64_grid(const C64Args& a) {
-  long long grid = 256;                       // one persistent workgroup per CU
+  // one persistent workgroup per CU.  VNQA_PERSISTENT_RESERVE_CUS=n leaves n CUs to the other streams for the whole
+  // life of the kernel (1.0 / 0.6 ms): a knob for multi-GPU runs, where an RCCL all-reduce launched meanwhile would
+  // otherwise wait for a persistent workgroup to retire before it gets its first CU.
+  static const int reserve = [] { const char* e = getenv("VNQA_PERSISTENT_RESERVE_CUS"); const int v = e ? atoi(e) : 0;
+                                  return v < 0 ? 0 : (v > 128 ? 128 : v); }();
+  long long grid = 256 - reserve;
   grid = grid / a.nsplit * a.nsplit;
   if (grid > a.n_work) grid = (a.n_work / a.nsplit) * a.nsplit;
   if (grid < a.nsplit) grid = a.nsplit;
