@@ -433,7 +433,10 @@ class MacCoreFn(torch.autograd.Function):
         G = st.grads
         if not G:
             z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=control.device)
-            G.update(wc=z(d, d), wca=z(d), bca=z(1), wm=z(d, d), bm=z(d), w1=z(d, d), wra=z(d), bra=z(1), wr=z(d, d),
+            # wca / wra (gradients of the two attention weight vectors) are sums over images AND steps of an elementwise
+            # product: accumulated per image with one addcmul_ per step and reduced over the images once, by the last node;
+            # bca / bra (sums of the score gradients) come from the stacked score gradients the same node already holds
+            G.update(wc=z(d, d), wca=z(N, d), wm=z(d, d), bm=z(d), w1=z(d, d), wra=z(N, d), wr=z(d, d),
                      wmm=z(d, d), bw=z(d), ones=torch.ones(N, dtype=torch.float32, device=control.device))
         ones = G["ones"]
         # WriteUnit.concat
@@ -445,11 +448,10 @@ class MacCoreFn(torch.autograd.Function):
         # ReadUnit attention
         ds_r, du, dv = K.mac_read_bwd(know, pre, p_r, d_read, N, S, d)
         st.read.append((ds_r, p_r, u, v, d_read))
-        G["bra"].add_(ds_r.sum())
         d_mem, d_t = du * t, du * mem
         dv = dv.addmm_(d_t, w1.t())
         G["w1"].addmm_(v.t(), d_t)
-        G["wra"].addmv_((dv * cnew).t(), ones)
+        G["wra"].addcmul_(dv, cnew)
         d_c = dv * w_ra if d_cnew is None else torch.addcmul(d_cnew, dv, w_ra)
         d_memory = d_memory.addmm_(d_mem, wm)
         G["wm"].addmm_(d_mem.t(), memory)
@@ -460,9 +462,8 @@ class MacCoreFn(torch.autograd.Function):
         # ControlUnit attention
         ds_c, dqv, _ = K.mac_read_bwd(ctxw, None, p_c, d_c, N, Lq, d)
         st.ctrl.append((ds_c, p_c, qv, d_c))
-        G["bca"].add_(ds_c.sum())
         d_cq = dqv * w_ca
-        G["wca"].addmv_((dqv * cq).t(), ones)
+        G["wca"].addcmul_(dqv, cq)
         d_control = d_cq @ wc
         G["wc"].addmm_(d_cq.t(), control)
         d_ctxw = d_know = d_pre = None
@@ -472,8 +473,8 @@ class MacCoreFn(torch.autograd.Function):
             d_know, d_pre = K.mac_read_accum(f[0], f[1], f[2], f[3], f[4], N, S, d, know.shape[-1], know.dtype)
             c = [torch.stack(x) for x in zip(*st.ctrl)]
             d_ctxw, _ = K.mac_read_accum(c[0], c[1], c[2], None, c[3], N, Lq, d, ctxw.shape[-1], ctxw.dtype)
-            g = [G["wc"], G["wca"].view(1, d), G["bca"], G["wm"], G["bm"], G["w1"], G["wra"].view(1, d), G["bra"], G["wr"],
-                 G["wmm"], G["bw"]]
+            g = [G["wc"], G["wca"].sum(0, keepdim=True), c[0].sum().view(1), G["wm"], G["bm"], G["w1"],
+                 G["wra"].sum(0, keepdim=True), f[0].sum().view(1), G["wr"], G["wmm"], G["bw"]]
             st.read, st.ctrl, st.grads = [], [], {}
         return (d_control, d_memory, d_cq, d_ctxw, d_know, d_pre, None, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7],
                 g[8], g[9], g[10], None, None, None)
