@@ -422,22 +422,27 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
   char* const ldsX = ldsIn + IN_PIX * 8;
   float* const ldsB1 = (float*)(ldsX + 4096);
   float* const ldsB2 = ldsB1 + 64;
-  int koff[8];
+  // conv1_1 as TWO MFMAs over a K order that follows the image list's memory order (4 channels per pixel, channel 3 and
+  // pixel column 3 carry zero weights), so that the B operand is fetched with aligned 8-byte reads instead of eight
+  // 2-byte gathers plus packing:
+  //   v_mfma_f32_16x16x32_bf16: k-chunk fh = (window row r = fh >> 1, pixel pair 2 (fh & 1) ..+1), e -> (pixel e >> 2, channel e & 3)
+  //   v_mfma_f32_16x16x16_bf16: k = 4 fh + e = (window row 2, pixel fh, channel e)
+  // A fragments (weights): the first kind per (j, lane) in LDS, the second kind (8 bytes per j) in registers.
+  const int offA = ((fh >> 1) * IX + 2 * (fh & 1)) * 8, offB = (2 * IX + fh) * 8;
+  vnqa_bf16x4 w1b[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = 8 * fh + e;
-    const int kk = k < 27 ? k : 0;
-    const int c = kk / 9, r = (kk - 9 * c) / 3, s_ = kk - 9 * c - 3 * r;
-    koff[e] = k < 27 ? ((r * IX + s_) * 8 + c * 2) : -1;
-  }
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      w1b[j][e] = (short)((fh < 3 && e < 3) ? f32_to_bf16(p.w1[(16 * j + fr) * 27 + e * 9 + 2 * 3 + fh]) : 0);
   if (wave == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       vnqa_bf16x8 f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int k = 8 * fh + e;
-        f[e] = (short)(k < 27 ? f32_to_bf16(p.w1[(16 * j + fr) * 27 + k]) : 0);
+        const int r = fh >> 1, sx = 2 * (fh & 1) + (e >> 2), ch = e & 3;
+        f[e] = (short)((sx < 3 && ch < 3) ? f32_to_bf16(p.w1[(16 * j + fr) * 27 + ch * 9 + r * 3 + sx]) : 0);
       }
       *(vnqa_bf16x8*)(ldsX + (j * 64 + lane) * 16) = f;
     }
@@ -466,7 +471,8 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
   auto compute_patch = [&](long long t) {
     int n, y0, x0;
     tile_coords(t, n, y0, x0);
-    vnqa_bf16x8 xb[5];
+    vnqa_bf16x8 xa[5];
+    vnqa_bf16x4 xb[5];
     int prs[5];
     bool ins[5];
 #pragma unroll
@@ -475,8 +481,9 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
       const int prc = pr < PROWS_W ? pr : PROWS_W - 1;
       const int py = prc / PX, px = prc - py * PX;
       const char* base = ldsIn + (py * IX + px) * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) xb[gi][e] = koff[e] >= 0 ? *(const short*)(base + koff[e]) : (short)0;
+      const uint2 lo = *(const uint2*)(base + offA), hi = *(const uint2*)(base + offA + 8);
+      xa[gi] = __builtin_bit_cast(vnqa_bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+      xb[gi] = __builtin_bit_cast(vnqa_bf16x4, *(const uint2*)(base + offB));
       const int gy = y0 + py, gx = x0 + px;
       prs[gi] = pr;
       ins[gi] = pr < PROWS_W && gy >= 1 && gy <= p.H && gx >= 1 && gx <= p.W;
@@ -488,9 +495,14 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
 #pragma unroll
       for (int gi = 0; gi < 5; ++gi) {
         const vnqa_f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        a1[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xb[gi], z, 0, 0, 0);
+        a1[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xa[gi], z, 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int gi = 0; gi < 5; ++gi)
+        a1[gi][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w1b[j], xb[gi], a1[gi][j], 0, 0, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 bb = *(const float4*)(ldsB1 + 16 * j + 4 * fh);
