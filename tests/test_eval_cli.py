@@ -63,7 +63,10 @@ def test_cli_synthetic_train_val_checkpoint_resume(model, tmp_path, capsys):
         assert "learning rate 0.00001" in out
     assert "Train Epoch: 0" in out and "Validation:" in out and "Average loss after 1 iterations in epoch 1" in out
     ck = torch.load(tmp_path / "e0_ck.pt", map_location="cpu")
-    assert set(ck) == {"epoch", "model", "state_dict", "train_f1w", "train_f1micro", "optimizer"}
+    # reference schema (eval/q_and_v_eval.py:148-156) + 'extra_state' (the frozen conv1x1_layers state_dict() leaves out)
+    assert set(ck) == {"epoch", "model", "state_dict", "train_f1w", "train_f1micro", "optimizer", "extra_state"}
+    if model != "mac":
+        assert set(ck["extra_state"]) == {"conv1x1_layers.0.weight", "conv1x1_layers.0.bias"}
     assert ck["model"] == model and ck["epoch"] == 0
     # the optimizer entry is a genuine torch.optim.Adam state_dict
     params = [torch.nn.Parameter(torch.zeros_like(s["exp_avg"])) for s in ck["optimizer"]["state"].values()]
@@ -85,6 +88,38 @@ def test_cli_synthetic_train_val_checkpoint_resume(model, tmp_path, capsys):
         import numpy as np
         t, p = np.load(tmp_path / "t_ck.pt.npy"), np.load(tmp_path / "p_ck.pt.npy")
         assert t.shape == (5,) and p.shape == (5,)
+
+
+@pytest.mark.gpu
+def test_checkpoint_restores_frozen_conv1x1_layers(tmp_path, capsys):
+    """A checkpoint written from a model whose frozen conv1x1_layers do NOT come from seed 0 must evaluate identically
+    after q_and_v_test restores it: the 1x1 convs travel in the 'extra_state' key."""
+    import numpy as np
+    from videonavqa_amd.eval import q_and_v_eval as E, q_and_v_test as T
+    os.chdir(tmp_path)
+    argv = ["--model", "film_attn_pt", "--synthetic", "4", "--batch_size", "2", "--num_workers", "0", "--height", "64",
+            "--width", "96", "--num_res_block_channels", "64", "--hidden_size", "16", "--at_hidden_size", "16",
+            "--embed_size", "16", "--precision", "fp32", "--checkpoint_path", "ck.pt"]
+    E.main(argv)
+    capsys.readouterr()
+    ck = torch.load(tmp_path / "e0_ck.pt", map_location="cpu")
+    T.main(argv[:-1] + ["e0_ck.pt"])
+    base = capsys.readouterr().out
+    p0 = np.load(tmp_path / "p_e0_ck.pt.npy")
+    # same checkpoint with DIFFERENT 1x1 convs: predictions / loss must follow the stored tensors, not the seed
+    ck2 = dict(ck)
+    ck2["extra_state"] = {k: torch.randn_like(v) * 3 for k, v in ck["extra_state"].items()}
+    torch.save(ck2, tmp_path / "other.pt")
+    T.main(argv[:-1] + ["other.pt"])
+    other = capsys.readouterr().out
+    loss = lambda out: float(out.split("Average loss: ")[1].split(",")[0])
+    assert loss(base) != loss(other)
+    # and without the key (an upstream-written checkpoint) the seed-0 construction reproduces the training-time convs
+    ck3 = {k: v for k, v in ck.items() if k != "extra_state"}
+    torch.save(ck3, tmp_path / "plain.pt")
+    T.main(argv[:-1] + ["plain.pt"])
+    plain = capsys.readouterr().out
+    assert loss(plain) == loss(base) and (np.load(tmp_path / "p_plain.pt.npy") == p0).all()
 
 
 def test_single_modality_parsers_match_reference_defaults():

@@ -86,8 +86,10 @@ def lib():
     """Load (once) and return the CDLL; raises if the HIP library has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH) and "VNQA_LIB" not in os.environ and os.path.exists("/opt/rocm/bin/hipcc"):
-            # not a fallback: build the HIP library itself (hipcc cross-compiles gfx950 anywhere)
+        if "VNQA_LIB" not in os.environ and os.path.exists("/opt/rocm/bin/hipcc") \
+                and os.environ.get("VNQA_NO_REBUILD", "0") != "1":
+            # not a fallback: (re)build the HIP library itself when it is missing OR older than its sources (the digest
+            # check is cheap; build() takes a file lock, so torchrun ranks do not compile over each other)
             from .build import build as _build
             _build(verbose=False)
         if not os.path.exists(LIB_PATH):

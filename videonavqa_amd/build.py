@@ -32,24 +32,49 @@ def _digest():
 
 
 def build(force=False, verbose=True):
+    """Compile every source and link libvnqa_hip.so unless the source digest matches the stamp.  Safe to call from several
+    processes at once (torchrun ranks): an exclusive file lock serialises them, the winners of later turns find the stamp
+    up to date, and objects / the library are written to temporary names and renamed into place."""
+    import fcntl
+    import tempfile
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "libvnqa_hip.stamp")
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+
+    def fresh():
+        return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig
+
+    if not force and fresh():
         return LIB
-    objs = []
-    procs = []
-    for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
-        procs.append((src, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for src, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError("hipcc failed on %s" % src)
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    with open(stamp, "w") as fh:
-        fh.write(dig)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and fresh():          # another process built it while this one waited
+                return LIB
+            tmpdir = tempfile.mkdtemp(prefix=".build.", dir=LIBDIR)
+            try:
+                objs, procs = [], []
+                for src in sources():
+                    obj = os.path.join(tmpdir, os.path.basename(src) + ".o")
+                    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+                    procs.append((src, subprocess.Popen(cmd)))
+                    objs.append(obj)
+                failed = [src for src, p in procs if p.wait() != 0]
+                if failed:
+                    raise RuntimeError("hipcc failed on %s" % ", ".join(failed))
+                tmp_lib = os.path.join(tmpdir, "libvnqa_hip.so")
+                subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs)
+                for obj in objs:               # keep the objects next to the library (inspection: llvm-objdump)
+                    os.replace(obj, os.path.join(LIBDIR, os.path.basename(obj)))
+                os.replace(tmp_lib, LIB)
+                with open(stamp + ".tmp", "w") as fh:
+                    fh.write(dig)
+                os.replace(stamp + ".tmp", stamp)
+            finally:
+                import shutil
+                shutil.rmtree(tmpdir, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     if verbose:
         print("built", LIB)
     return LIB

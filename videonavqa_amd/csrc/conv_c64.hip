@@ -810,7 +810,7 @@ extern "C" int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const
   const int rc = c64_fill(d, x, wt, bias, post_scale, post_shift, y, a, "conv2d_c64_fwd");
   if (rc != VNQA_OK) return rc;
   const bool four = d->tile == 2;   // tile == 2 selects the 4-wave shape (A/B runs: 15 % slower); default = 8 waves
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: a race only repeats it
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_c64_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute((const void*)conv_c64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
@@ -839,7 +839,7 @@ extern "C" int vnqa_conv_first_c64_fwd(const vnqa_conv_desc* d, const void* img4
   VNQA_CHECK_ARG(w1 && b1, "conv_first_c64_fwd: null first-layer weights");
   a.w1 = w1;
   a.b1 = b1;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: a race only repeats it
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_c64_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES_FUSED) != hipSuccess ||

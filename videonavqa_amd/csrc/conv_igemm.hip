@@ -604,7 +604,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   const int tilesM = (p.M + BM - 1) / BM;
   p.tilesN = (p.Cout + BN - 1) / BN;
   auto kern = conv_igemm_kernel<T, BM, BN, WAVES_M, WAVES_N, TAG, PIPE>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: a race only repeats it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) {

@@ -289,7 +289,7 @@ int launch_patch(const ConvArgs& a, hipStream_t stream) {
   const int tilesM = ((rows + TR - 1) / TR) * (p.W / TC);
   p.tilesN = (p.Cout + BN - 1) / BN;
   auto kern = conv_patch_kernel<TC, TAG>;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: a race only repeats it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) {

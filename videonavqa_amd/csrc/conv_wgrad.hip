@@ -656,7 +656,7 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   a.slices = pl.slices;
   const int lds = 2 * 65536;
   const int grid = pl.slices * pl.tilesCo * taps * pl.tilesCi;
-  static bool attr_done[2] = {false, false};
+  static std::atomic<bool> attr_done[2] = {{false}, {false}};   // idempotent attribute call: a race only repeats it
   if (dtype == VNQA_BF16) {
     auto kern = conv_wgrad_kernel<vnqa_bf16>;
     if (!attr_done[0]) {

@@ -144,22 +144,30 @@ def _global_stats(loss_sum, hit, n, device):
 def train_epoch(epoch, args, trainer, data_loader, device, rank=0):
     """q_and_v_eval.py:73-156 (stem, sort, forward, loss, clip, Adam are inside Trainer.step)."""
     from sklearn.metrics import f1_score
-    avg_loss, hit, num_examples = 0.0, 0, 0
-    y_pred, y_target = np.array([]), np.array([])
+    # Loss, predictions and targets stay ON THE DEVICE during the epoch: a float(loss) / .cpu() per step would make the
+    # launch thread wait for the whole step and serialise upload(i+2) / stem(i+1) behind trunk(i).  They are read back at
+    # the --stats_after_every print and once at the end of the epoch.
+    num_examples = 0
+    loss_acc = torch.zeros((), dtype=torch.float64, device=device)
+    preds, targets = [], []
     for i, batch, nxt in _staged_batches(args, trainer, data_loader, device):
         clip, q, v_lens, q_lens, ys = batch
         num_examples += len(ys)
         perm = torch.sort(v_lens, dim=0, descending=True, stable=True)[1]
         ahead = dict(next_clip=nxt[0], next_v_lens_cpu=nxt[2]) if nxt is not None else {}
         loss, logits = trainer.step(clip, q, v_lens, q_lens, ys, **ahead)
-        ys_sorted = ys[perm.to(device)]
-        y_target = np.append(y_target, ys_sorted.cpu().numpy())        # :117
-        avg_loss += float(loss)
-        pred_class = logits.max(1)[1]                                   # :127
-        y_pred = np.append(y_pred, pred_class.cpu().numpy())
-        hit += int((pred_class == ys_sorted).sum())
+        targets.append(ys[trainer.to_device_async(perm)])              # :117 (sorted order, as the logits)
+        loss_acc += loss
+        preds.append(logits.max(1)[1])                                  # :127
         if rank == 0 and (i + 1) % args.stats_after_every == 0:
-            print('Average loss after %d iterations in epoch %d: %.6f' % (i + 1, epoch + 1, avg_loss / num_examples))
+            print('Average loss after %d iterations in epoch %d: %.6f' % (i + 1, epoch + 1, float(loss_acc) / num_examples))
+    if preds:
+        pred_t, targ_t = torch.cat(preds), torch.cat(targets)
+        hit = int((pred_t == targ_t).sum())
+        y_pred, y_target = pred_t.cpu().numpy().astype(np.float64), targ_t.cpu().numpy().astype(np.float64)
+    else:
+        hit, y_pred, y_target = 0, np.array([]), np.array([])
+    avg_loss = float(loss_acc)
     f1_w = f1_score(y_target, y_pred, average='weighted')
     f1_micro = f1_score(y_target, y_pred, average='micro')
     avg_loss, hit, num_examples = _global_stats(avg_loss, hit, num_examples, device)
@@ -169,7 +177,10 @@ def train_epoch(epoch, args, trainer, data_loader, device, rank=0):
         if args.checkpoint_path is not None:
             torch.save({'epoch': epoch, 'model': args.model, 'state_dict': trainer.model.state_dict(),
                         'train_f1w': f1_w, 'train_f1micro': f1_micro,
-                        'optimizer': trainer.optimizer_state_dict()},
+                        'optimizer': trainer.optimizer_state_dict(),
+                        # not in the reference schema (its loaders ignore unknown keys): the frozen conv1x1_layers, which
+                        # state_dict() does not carry — without them a restored model evaluates with different weights
+                        'extra_state': trainer.extra_state_dict()},
                        'e' + str(epoch) + '_' + args.checkpoint_path)   # :148-156
     return avg_loss / max(num_examples, 1)
 

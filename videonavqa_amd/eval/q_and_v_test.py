@@ -88,6 +88,9 @@ def main(argv=None):
     print('%d test examples' % len(test_data))
     test_loader = DataLoader(dataset=test_data, batch_size=args.batch_size, shuffle=False, num_workers=args.num_workers)
     spatial = (args.height // 16) * (args.width // 16)
+    # the frozen conv1x1_layers are not in state_dict(): same seed as q_and_v_eval.main so that a checkpoint WITHOUT the
+    # 'extra_state' key (written upstream / by an older build) still meets the 1x1 convs it was trained with
+    torch.manual_seed(0)
     model = build_model(args, spatial).to(device)
     feature_extractor = get_frcnn_feature_extractor(args.frcnn_pretrained_path, args.precision).to(device)
     obj_detector = U.get_object_detector(precision=args.precision,
@@ -102,6 +105,8 @@ def main(argv=None):
     print('=> Restoring from checkpoint path %s' % args.checkpoint_path)
     checkpoint = torch.load(args.checkpoint_path, map_location=device)
     model.load_state_dict(checkpoint['state_dict'])
+    if checkpoint.get('extra_state') and hasattr(model, 'load_reference_tensors'):
+        model.load_reference_tensors(checkpoint['extra_state'])
     print('==> Restored checkpoint from epoch %d (validation accuracy %.4f)' %
           (checkpoint['epoch'] + 1, checkpoint.get('val_acc', -1.0)))
     t, p, q = test(args, model, trainer, test_loader, loss_fn, device)

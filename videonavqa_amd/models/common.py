@@ -206,11 +206,18 @@ class FiLMTrunkBase(nn.Module):
     (GPU flavour: film_layer registered, conv1x1_layers a plain list — SURVEY §0.5/0.6);
     their forward() is never called: compute goes through videonavqa_amd.ops."""
 
-    def _build_trunk(self, num_input_channels, num_res_block_channels, num_res_blocks):
+    def _build_trunk_head(self, num_input_channels, num_res_block_channels):
+        """relu / conv_init / bn_init — registered first, as upstream (film_attn_pt_stem.py:39-42)."""
         self.relu = nn.ReLU(inplace=True)
         self.conv_init = nn.Conv2d(num_input_channels, num_res_block_channels, kernel_size=3, padding=1)
         self.bn_init = nn.BatchNorm2d(num_res_block_channels)
         self.conv1x1_layers = []  # plain list on purpose (film_attn_pt_stem.py:44)
+
+    def _build_film_pipeline(self, num_res_block_channels, num_res_blocks):
+        """film_pipeline (get_film_pipeline, film_attn_pt_stem.py:93-108).  Called AFTER the FiLM generator modules are
+        registered: upstream creates film_layer (time_multi_hop: q_encoder .. decoder_norm) before film_pipeline, and
+        torch.optim.Adam's state_dict indexes its state by position in model.parameters() — the registration order is
+        part of the checkpoint contract (eval/q_and_v_eval.py:148-156,344-345)."""
         layers = []
         in_channels = num_res_block_channels
         for _ in range(num_res_blocks):

@@ -34,11 +34,12 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         self.compute_dtype = compute_dtype(precision)
 
         self.embed = nn.Embedding(vocab_size, q_embedding_size)                       # :37
-        self._build_trunk(num_input_channels, num_res_block_channels, num_res_blocks)  # :40-52,93-108
+        self._build_trunk_head(num_input_channels, num_res_block_channels)             # :39-44
         total_out_size = 2 * num_res_block_channels * num_res_blocks
-        self.film_layer = nn.ModuleList([nn.LSTM(q_embedding_size, hidden_size),      # :75-87 (GPU flavour)
+        self.film_layer = nn.ModuleList([nn.LSTM(q_embedding_size, hidden_size),      # :51,75-87 (GPU flavour)
                                          nn.Linear(hidden_size, total_out_size),
                                          nn.ReLU(inplace=True)])
+        self._build_film_pipeline(num_res_block_channels, num_res_blocks)              # :52,93-108
         self.fc_embed_attn = nn.Linear(spatial_size * num_res_block_channels, at_hidden_size)  # :56-57
         self.fc_attn_1 = nn.Linear(at_hidden_size, 1)                                 # :58
         self.fc_hidden_attn = nn.Linear(at_hidden_size, 1)                            # :60

@@ -25,11 +25,12 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
         self.compute_dtype = compute_dtype(precision)
 
         self.embed = nn.Embedding(vocab_size, q_embedding_size, padding_idx=0)        # :34
-        self._build_trunk(num_input_channels, num_res_block_channels, num_res_blocks)
+        self._build_trunk_head(num_input_channels, num_res_block_channels)             # :38-41
         total_out_size = 2 * num_res_block_channels * num_res_blocks
-        self.film_layer = nn.ModuleList([nn.LSTM(q_embedding_size, hidden_size),
+        self.film_layer = nn.ModuleList([nn.LSTM(q_embedding_size, hidden_size),      # :48
                                          nn.Linear(hidden_size, total_out_size),
                                          nn.ReLU(inplace=True)])
+        self._build_film_pipeline(num_res_block_channels, num_res_blocks)              # :49
         self.c1x1_tail = nn.Conv2d(num_res_block_channels, num_tail_channels, kernel_size=1)  # :52
         self.out_linear = nn.Linear(spatial_size * num_tail_channels, nb_classes)     # :56
         for module in self.modules():                                                 # :58-59

@@ -21,7 +21,7 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
         self.compute_dtype = compute_dtype(precision)
 
         self.embed = nn.Embedding(vocab_size, q_embedding_size, padding_idx=0)        # :30
-        self._build_trunk(num_input_channels, num_res_block_channels, num_res_blocks)
+        self._build_trunk_head(num_input_channels, num_res_block_channels)             # :32-36
         total_out_size = 2 * num_res_block_channels * num_res_blocks
         self.q_encoder = nn.LSTM(q_embedding_size, hidden_size)                       # :45
         self.encoder_norm = nn.LayerNorm(hidden_size)                                 # :46
@@ -29,6 +29,7 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
         self.fc_hidden_attn = nn.Linear(hidden_size, 1)                               # :49
         self.fc_attn_out = nn.Linear(hidden_size, total_out_size)                     # :50
         self.decoder_norm = nn.LayerNorm(total_out_size)                              # :51
+        self._build_film_pipeline(num_res_block_channels, num_res_blocks)              # :53
         self.c1x1_tail = nn.Conv2d(num_res_block_channels, num_tail_channels, kernel_size=1)  # :56
         self.out_linear = nn.Linear(spatial_size * num_tail_channels, nb_classes)     # :60
         for module in self.modules():                                                 # :62-65

@@ -160,10 +160,22 @@ class Trainer(object):
                  "params": list(range(len(self.fp.params)))}
         return {"state": state, "param_groups": [group]}
 
+    def extra_state_dict(self):
+        """CPU copies of the tensors state_dict() does not carry (frozen conv1x1_layers) for the checkpoint's
+        'extra_state' key."""
+        fn = getattr(self.model, "extra_state_tensors", None)
+        return {k: v.detach().cpu().clone() for k, v in fn().items()} if fn else {}
+
     def load_checkpoint(self, ckpt):
         """Restore model + optimizer from a reference-schema checkpoint dict."""
         self.model.load_state_dict(ckpt["state_dict"])      # in-place copies: parameters stay views of the flat buffer
+        if ckpt.get("extra_state") and hasattr(self.model, "load_reference_tensors"):
+            # the frozen conv1x1_layers the reference leaves out of state_dict() (SURVEY 0.5); upstream loaders ignore the key
+            self.model.load_reference_tensors(ckpt["extra_state"])
         opt = ckpt.get("optimizer")
+        if opt and opt.get("param_groups"):
+            # optimizer.load_state_dict restores the saved learning rate upstream too (eval/q_and_v_eval.py:345)
+            self.lr = float(opt["param_groups"][0].get("lr", self.lr))
         if opt and opt.get("state"):
             off = 0
             for i, p in enumerate(self.fp.params):
@@ -174,6 +186,9 @@ class Trainer(object):
                     self.fp.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
                     self.fp.step_count = int(st["step"])
                 off += k
+
+    def to_device_async(self, t):
+        return L.to_device_async(t, self.stem_device)
 
     def extract_features(self, clip, v_lens_cpu, slot=0):
         """Stem + batch sort on the CURRENT stream.  clip fp32 [B,3,H,W,T] on the GPU."""
