@@ -76,3 +76,44 @@ def test_two_rank_dp_on_gpu_tensors(tmp_path):
     port = 29700 + (os.getpid() % 1500)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _run_bench(extra_env, argv, timeout=900):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-400:], r.stderr[-1500:])
+    lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline", "--no-parity", "--batch", "2",
+         "--frames", "4", "--height", "64", "--width", "96"]
+
+
+def test_bench_gpus2_spawns_its_own_ranks_single_device_gloo():
+    """`bench.py --gpus 2` with no launcher: the parent starts both ranks itself (here on ONE GPU over gloo — the test
+    hook for 1-GPU boxes), rank 0 prints the single JSON line with n_gpus = 2 and the comm block."""
+    out = _run_bench({"VNQA_DIST_BACKEND": "gloo", "VNQA_SINGLE_DEVICE": "1"}, ["--gpus", "2"] + SMALL)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    c = out["comm"]
+    assert c["ranks"] == 2 and c["backend"] == "gloo" and c["allreduce_alone_ms"] > 0
+    assert c["ms_per_step_without_collectives"] > 0 and "exposed_comm_ms_per_step" in c
+    assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL, one rank per GPU)")
+def test_bench_gpus2_rccl_two_gpus():
+    """Two ranks on two MI355X over RCCL through the self-spawning entry point; also A/Bs the persistent conv kernels'
+    CU reservation (VNQA_PERSISTENT_RESERVE_CUS), which exists for exactly this co-scheduling with RCCL's kernels."""
+    base = _run_bench({}, ["--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--no-parity"])
+    assert base["n_gpus"] == 2 and base["comm"]["backend"] == "rccl" and base["comm"]["ranks"] == 2
+    resv = _run_bench({"VNQA_PERSISTENT_RESERVE_CUS": "8"}, ["--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "1",
+                                                            "--no-cpu-baseline", "--no-parity"])
+    print("dp2 clips/s: reserve 0 -> %.1f, reserve 8 -> %.1f; exposed comm %.3f / %.3f ms"
+          % (base["value"], resv["value"], base["comm"]["exposed_comm_ms_per_step"], resv["comm"]["exposed_comm_ms_per_step"]))
+    assert resv["n_gpus"] == 2
