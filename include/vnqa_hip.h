@@ -103,6 +103,43 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
                              const float* post_scale, const float* post_shift, const void* border_sub,
                              void* y, void* stream);
 
+/* Fused trunk epilogues (BIAS_RELU_BNSTATS / BIAS_FILM_RELU_RES) — the same conv with the elementwise op
+ * that FOLLOWS it in the reference applied while the output tile is still in LDS:
+ *
+ *   VNQA_EPI_BNSTATS  (conv_init -> ReLU -> train-mode BatchNorm2d per frame, models/film_attn_pt_stem.py:211)
+ *     y = relu?(conv + bias) as usual, plus mean[f][c] / biased var[f][c] of y over the pixels of every frame f
+ *     (frame_of [n_img], frame_off [n_frames+1]: images of a frame are contiguous).  Each pixel tile writes per-frame
+ *     partial sums to `partial` (vnqa_conv2d_bnstats_workspace bytes) and a second tiny launch reduces them in tile
+ *     order: no atomics, run-to-run deterministic.  Returns VNQA_ERR_UNSUPPORTED when frames are too small for the tile
+ *     (workspace query < 0): the caller then uses vnqa_frame_bn_stats.
+ *   VNQA_EPI_FILM_RES (conv3x3 -> FiLM affine -> ReLU -> + residual, models/film_attn_pt_stem.py:224-241)
+ *     y  = conv + bias                                   (z: the FiLM backward needs it)
+ *     y2 = relu(gamma[n][c] * y + beta[n][c]) + res      (gamma/beta fp32 rows of stride film_ld; channels >= film_c: 0)
+ *     computed from the storage-rounded y, i.e. bit-identical to vnqa_film_relu_res_fwd applied to y.
+ * pool2 / depth / wt_tiled / post_scale are not available with a fused epilogue.
+ */
+#define VNQA_EPI_NONE 0
+#define VNQA_EPI_BNSTATS 1
+#define VNQA_EPI_FILM_RES 2
+typedef struct vnqa_conv_epilogue {
+  int32_t kind;              /* VNQA_EPI_* */
+  int32_t n_frames;          /* BNSTATS */
+  int32_t min_frame_images;  /* BNSTATS: smallest number of images in a frame (host knowledge; sizes the slot count) */
+  int32_t film_ld, film_c;   /* FILM_RES */
+  const int32_t* frame_of;   /* BNSTATS: [n_img] */
+  const int32_t* frame_off;  /* BNSTATS: [n_frames + 1] */
+  float* partial;            /* BNSTATS workspace */
+  float* mean;               /* BNSTATS out: [n_frames][c_out] */
+  float* var;                /* BNSTATS out: [n_frames][c_out], biased */
+  const float* gamma;        /* FILM_RES */
+  const float* beta;         /* FILM_RES */
+  const void* res;           /* FILM_RES: padded NHWC like y */
+  void* y2;                  /* FILM_RES: padded NHWC like y */
+} vnqa_conv_epilogue;
+int64_t vnqa_conv2d_bnstats_workspace(const vnqa_conv_desc* d, int32_t min_frame_images);
+int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
+                                const vnqa_conv_epilogue* e, void* y, void* stream);
+
 /* Operand builders of that border correction (all tensors in `dtype`, c * element size a multiple of 16 bytes; the
  * outside ring of the (h+2)x(w+2) grid is enumerated top row (w+2), bottom row (w+2), left column (h), right column (h)):
  *   vnqa_ring_im2col      : x halo-2 padded NHWC [n][h+4][w+4][c] -> [n][2(w+2)+2h][9][c], the 3x3 patches around the ring
@@ -275,6 +312,15 @@ int vnqa_film_relu_res_fwd(const void* z, const void* res, const float* gamma, c
 int vnqa_film_relu_res_bwd(const void* dout, const void* z, const float* gamma, const float* beta, void* dz,
                            float* dgamma, float* dbeta, int32_t n_img, int32_t hp, int32_t wp, int32_t c,
                            int32_t dtype, void* stream);
+/* The same two ops on gamma/beta that are COLUMN SLICES of a wider fp32 matrix (the FiLM generator's output
+ * [n_img][2*C*blocks], models/film_attn_pt_stem.py:229-233): row stride film_ld (floats), channels >= film_c are padding
+ * (gamma = beta = 0, no gradient written); dgamma/dbeta rows have stride grad_ld. */
+int vnqa_film_relu_res_fwd_ld(const void* z, const void* res, const float* gamma, const float* beta, void* out,
+                              int32_t n_img, int32_t hp, int32_t wp, int32_t c, int32_t film_ld, int32_t film_c,
+                              int32_t dtype, void* stream);
+int vnqa_film_relu_res_bwd_ld(const void* dout, const void* z, const float* gamma, const float* beta, void* dz,
+                              float* dgamma, float* dbeta, int32_t n_img, int32_t hp, int32_t wp, int32_t c,
+                              int32_t film_ld, int32_t film_c, int32_t grad_ld, int32_t dtype, void* stream);
 int vnqa_relu_bwd(const void* a, const void* b, const void* y, void* g, int64_t n, int32_t dtype, void* stream);
 
 /* Temporal softmax-attention over frames, fused (models/film_attn_pt_stem.py:268-290):

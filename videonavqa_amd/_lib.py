@@ -23,6 +23,15 @@ class ConvDesc(ctypes.Structure):
                                     "x_halo", "y_halo", "relu", "pool2", "tile", "wt_tiled", "depth")]
 
 
+class ConvEpilogue(ctypes.Structure):
+    """include/vnqa_hip.h: vnqa_conv_epilogue"""
+    _fields_ = [("kind", _i32), ("n_frames", _i32), ("min_frame_images", _i32), ("film_ld", _i32), ("film_c", _i32),
+                ("frame_of", _vp), ("frame_off", _vp), ("partial", _vp), ("mean", _vp), ("var", _vp),
+                ("gamma", _vp), ("beta", _vp), ("res", _vp), ("y2", _vp)]
+
+
+EPI_NONE, EPI_BNSTATS, EPI_FILM_RES = 0, 1, 2
+
 _SIGNATURES = {
     "vnqa_version": (ctypes.c_int, []),
     "vnqa_last_error": (ctypes.c_char_p, []),
@@ -41,6 +50,10 @@ _SIGNATURES = {
     "vnqa_frame_bn_bwd": (ctypes.c_int, [_vp] * 10 + [_i32] * 7 + [_vp]),
     "vnqa_film_relu_res_fwd": (ctypes.c_int, [_vp] * 5 + [_i32] * 5 + [_vp]),
     "vnqa_film_relu_res_bwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
+    "vnqa_film_relu_res_fwd_ld": (ctypes.c_int, [_vp] * 5 + [_i32] * 7 + [_vp]),
+    "vnqa_film_relu_res_bwd_ld": (ctypes.c_int, [_vp] * 7 + [_i32] * 8 + [_vp]),
+    "vnqa_conv2d_bnstats_workspace": (_i64, [ctypes.POINTER(ConvDesc), _i32]),
+    "vnqa_conv2d_igemm_fused_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp]),
     "vnqa_relu_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "vnqa_temporal_attn_fwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 3 + [_vp]),
     "vnqa_temporal_attn_bwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 3 + [_vp]),
@@ -128,6 +141,12 @@ def to_device_async(t, device):
     if device.type != "cuda" or t.is_cuda:
         return t.to(device)
     return t.pin_memory().to(device, non_blocking=True)
+
+
+def vptr(t):
+    """Device pointer of a (possibly strided) tensor view: the caller passes the strides to the kernel itself."""
+    assert t.is_cuda
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def stream():

@@ -21,6 +21,17 @@ struct ConvArgs {
   int slices, kt_per_slice; // split-K: K-steps [slice*kt_per_slice, ...) -> fp32 slab
   float* partial;           // [slices][M][Cout] fp32 when slices > 1
   int group_tiles;          // > 0: grouped GEMM — pixel tile t uses weight rows [(t / group_tiles) * Cout, ...) (vnqa_gemm_nt_grouped)
+  // fused epilogues of the FiLM trunk (vnqa_conv2d_igemm_fused_fwd; applied to the LDS-staged, storage-rounded tile in the
+  // store loop, so the results are bit-identical to the separate elementwise kernels):
+  int epi;                  // VNQA_EPI_NONE | VNQA_EPI_BNSTATS | VNQA_EPI_FILM_RES
+  const int* frame_of;      // BNSTATS: [n_img] frame of every image (images of a frame are contiguous)
+  float* stats_partial;     // BNSTATS: [tilesM][3][2][Cout] fp32: per pixel tile and frame slot (frame - frame of the tile's
+                            //          first pixel; a 256-pixel tile overlaps at most 3 frames), sum and sum of squares
+  const float* film_gamma;  // FILM_RES: fp32, gamma of image n / channel c at film_gamma[n * film_ld + c]
+  const float* film_beta;
+  int film_ld, film_c;      // row stride (floats); channels >= film_c (padding) get gamma = beta = 0
+  const char* res;          // FILM_RES: residual, same padded-NHWC geometry / element type as y
+  char* y2;                 // FILM_RES: second output relu(gamma*z+beta)+res (y receives z = conv + bias, needed by the backward)
   const void* border_sub;   // optional [n_img][2W + 2(H-2)][Cout] (element type of y): value SUBTRACTED from the border
                             // pixels' sums before ReLU/pool (ring order: top row, bottom row, left column, right column)
 };

@@ -552,6 +552,18 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   const int rows_out = p.pool ? BM / 4 : BM;
   const int M_out = p.pool ? (p.M >> 2) : p.M;
   const int Ho = p.pool ? (p.H >> 1) : p.H, Wo = p.pool ? (p.W >> 1) : p.W;
+  // BNSTATS: every thread keeps sum / sum of squares of ITS 16-byte channel chunk over the tile rows it stores, per frame
+  // slot (NT % CH == 0: a thread's chunk is the same on every pass of the loop)
+  constexpr bool kStatsOk = (TAG == 0) && (NT % CH == 0) && (CH <= 64) && (64 % CH == 0);   // trunk instantiations only
+  float st_s[3][EPC], st_q[3][EPC];
+  int frame0 = 0;
+  if (kStatsOk && p.epi == VNQA_EPI_BNSTATS) {
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) st_s[sl][e] = st_q[sl][e] = 0.f;
+    frame0 = p.frame_of[(tile_m * rows_out) / (Ho * Wo)];
+  }
   for (int idx = threadIdx.x; idx < rows_out * CH; idx += NT) {
     const int orow = idx / CH, c = idx - orow * CH;
     const int mo = tile_m * rows_out + orow;
@@ -584,11 +596,76 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       const int nn = n / p.D;
       oimg = (size_t)nn * (p.D + 2) + (n - nn * p.D) + 1;
     }
-    T* dst = (T*)(p.y) + ((oimg * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+    const size_t ooff = ((oimg * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+    T* dst = (T*)(p.y) + ooff;
     T out[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) out[e] = ElemOps<T>::store(v[e]);
     *(uint4*)dst = *(const uint4*)out;
+    if (kStatsOk && p.epi == VNQA_EPI_BNSTATS) {
+      const int sl = p.frame_of[n] - frame0;        // 0..2 (checked on the host: every frame holds >= BM/3 pixels)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float x = v[e];
+        if (sl == 0) { st_s[0][e] += x; st_q[0][e] += x * x; }
+        else if (sl == 1) { st_s[1][e] += x; st_q[1][e] += x * x; }
+        else { st_s[2][e] += x; st_q[2][e] += x * x; }
+      }
+    } else if (TAG == 0 && p.epi == VNQA_EPI_FILM_RES) {
+      // out2 = relu(gamma[n] * z + beta[n]) + res, from the storage-rounded z just written (film_attn_pt_stem.py:229-241)
+      float ga[EPC], be[EPC], r[EPC];
+      const float* gp = p.film_gamma + (size_t)n * p.film_ld + co0;
+      const float* bp = p.film_beta + (size_t)n * p.film_ld + co0;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const bool ok = co0 + e < p.film_c;
+        ga[e] = ok ? gp[e] : 0.f;
+        be[e] = ok ? bp[e] : 0.f;
+      }
+      const uint4 rraw = *(const uint4*)((const T*)p.res + ooff);
+      const T* rt = (const T*)&rraw;
+      T o2[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        r[e] = ElemOps<T>::load(rt[e]);
+        o2[e] = ElemOps<T>::store(fmaxf(ga[e] * v[e] + be[e], 0.f) + r[e]);
+      }
+      *(uint4*)((T*)p.y2 + ooff) = *(const uint4*)o2;
+    }
+  }
+  if (kStatsOk && p.epi == VNQA_EPI_BNSTATS) {
+    // lanes l and l ^ CH ... share a channel chunk inside a wave (64 / CH row groups): fold them with shuffles, then the
+    // waves' partials through LDS (the staged tile is dead after the barrier) in a fixed order: deterministic
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+#pragma unroll
+        for (int o = 32; o >= CH; o >>= 1) {
+          st_s[sl][e] += __shfl_xor(st_s[sl][e], o, 64);
+          st_q[sl][e] += __shfl_xor(st_q[sl][e], o, 64);
+        }
+      }
+    __syncthreads();
+    float* red = (float*)smem;                       // [NW][3][2][BN]
+    if (lane < CH) {
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          red[((wave * 3 + sl) * 2 + 0) * BN + lane * EPC + e] = st_s[sl][e];
+          red[((wave * 3 + sl) * 2 + 1) * BN + lane * EPC + e] = st_q[sl][e];
+        }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 3 * 2 * BN; o += NT) {
+      const int ch = o % BN, sq = o / BN;              // sq = slot * 2 + {sum, sumsq}
+      float acc_s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) acc_s += red[(w * 6 + sq) * BN + ch];
+      const int co = tile_n * BN + ch;
+      if (co < p.Cout) p.stats_partial[((size_t)tile_m * 6 + sq) * p.Cout + co] = acc_s;
+    }
   }
 }
 
@@ -618,16 +695,32 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   return VNQA_OK;
 }
 
-int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
+int resolve_tile(const ConvArgs& a, int dtype, int tile) {
+  if (tile != VNQA_TILE_AUTO) return tile;
   if (dtype == VNQA_BF16) {
-    if (tile == VNQA_TILE_AUTO) {
-      if (a.Cout <= 64) tile = VNQA_TILE_256x64;
-      else if (a.Cout <= 128) tile = VNQA_TILE_256x128;   // (128x128 is faster alone, slower when two streams co-run)
-      else {
-        static const int wide_tile = [] { const char* e = getenv("VNQA_AUTO_TILE_WIDE"); return e ? atoi(e) : VNQA_TILE_256x256; }();
-        tile = wide_tile;       // experiment hook for the trunk's C_out >= 256 layers (end-to-end A/B of tile shapes)
-      }
+    if (a.Cout <= 64) return VNQA_TILE_256x64;
+    if (a.Cout <= 128) return VNQA_TILE_256x128;   // (128x128 is faster alone, slower when two streams co-run)
+    static const int wide_tile = [] { const char* e = getenv("VNQA_AUTO_TILE_WIDE"); return e ? atoi(e) : VNQA_TILE_256x256; }();
+    return wide_tile;       // experiment hook for the trunk's C_out >= 256 layers (end-to-end A/B of tile shapes)
+  }
+  return a.Cout <= 64 ? VNQA_TILE_128x64 : VNQA_TILE_128x128;
+}
+
+// pixel rows of a tile id with TAG == 0 (the instantiations that carry the fused trunk epilogues); 0 = none
+int fused_tile_rows(int dtype, int tile) {
+  if (dtype == VNQA_BF16) {
+    switch (tile) {
+      case VNQA_TILE_256x256: case VNQA_TILE_256x128: case VNQA_TILE_256x64: case VNQA_TILE_256x128_W24: return 256;
+      case VNQA_TILE_128x128: case VNQA_TILE_128x64: return 128;
+      default: return 0;
     }
+  }
+  return (tile == VNQA_TILE_128x128 || tile == VNQA_TILE_128x64) ? 128 : 0;
+}
+
+int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
+  tile = resolve_tile(a, dtype, tile);
+  if (dtype == VNQA_BF16) {
     switch (tile) {
       case VNQA_TILE_256x256: return launch<vnqa_bf16, 256, 256, 2, 4>(a, st);
       case VNQA_TILE_256x128: return launch<vnqa_bf16, 256, 128, 4, 2>(a, st);
@@ -648,7 +741,6 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       default: break;
     }
   } else {
-    if (tile == VNQA_TILE_AUTO) tile = a.Cout <= 64 ? VNQA_TILE_128x64 : VNQA_TILE_128x128;
     switch (tile) {
       case VNQA_TILE_128x128: return launch<float, 128, 128, 2, 2>(a, st);
       case VNQA_TILE_128x64: return launch<float, 128, 64, 4, 1>(a, st);
@@ -674,6 +766,28 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float
     if (relu) s = fmaxf(s, 0.f);
     out[m * ldo + n] = ElemOps<T>::store(s);
   }
+}
+
+// BNSTATS epilogue, second half: per (frame, channel) sum the tile partials in tile order (deterministic) and turn them
+// into mean / biased variance.  partial [tilesM][3][2][C]; frame f covers pixels [off[f]*S, off[f+1]*S).
+__global__ void bnstats_finalize_kernel(const float* __restrict__ partial, const int* __restrict__ frame_of,
+                                        const int* __restrict__ frame_off, float* __restrict__ mean, float* __restrict__ var,
+                                        int S, int bm, int C) {
+  const int f = blockIdx.y;
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  const long long lo = (long long)frame_off[f] * S, hi = (long long)frame_off[f + 1] * S;
+  float s = 0.f, q = 0.f;
+  for (int t = (int)(lo / bm); t <= (int)((hi - 1) / bm); ++t) {
+    const int slot = f - frame_of[(int)(((long long)t * bm) / S)];
+    if (slot < 0 || slot > 2) continue;
+    s += partial[((size_t)t * 6 + slot * 2 + 0) * C + ch];
+    q += partial[((size_t)t * 6 + slot * 2 + 1) * C + ch];
+  }
+  const float n = (float)(hi - lo);
+  const float m = s / n;
+  mean[(size_t)f * C + ch] = m;
+  var[(size_t)f * C + ch] = fmaxf(q / n - m * m, 0.f);
 }
 
 }  // namespace
@@ -785,6 +899,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = relu; a.pool = 0;
   a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
   a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr; a.group_tiles = 0;
+  a.epi = VNQA_EPI_NONE;
   hipStream_t st = (hipStream_t)stream;
   // bf16: 256-row tiles unless 128-row tiles waste fewer padded rows (e.g. m = 280: 384 instead of 512)
   int tile = VNQA_TILE_128x128;
@@ -838,6 +953,7 @@ extern "C" int vnqa_gemm_nt_grouped(const void* a_gmk, const void* b_gnk, void* 
   a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = 0; a.pool = 0;
   a.M = groups * m_group; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
   a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr;
+  a.epi = VNQA_EPI_NONE;
   a.group_tiles = m_group / bm;
   int tile = dtype == VNQA_BF16 ? (n % 256 == 0 ? VNQA_TILE_256x256 : VNQA_TILE_256x128) : VNQA_TILE_128x128;
   if (const char* e = getenv("VNQA_GROUPED_TILE")) tile = atoi(e);     // experiment hook (row tile must divide m_group)
@@ -850,9 +966,9 @@ extern "C" int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, con
   return vnqa_conv2d_igemm_fwd_ex(d, x, wt, bias, post_scale, post_shift, nullptr, y, stream);
 }
 
-extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void* wt,
-                                        const float* bias, const float* post_scale, const float* post_shift,
-                                        const void* border_sub, void* y, void* stream) {
+static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
+                          const float* post_scale, const float* post_shift, const void* border_sub, void* y,
+                          ConvArgs& a) {
   VNQA_CHECK_ARG(d && x && wt && y, "conv2d_igemm_fwd: null pointer");
   VNQA_CHECK_ARG(d->dtype == VNQA_BF16 || d->dtype == VNQA_F32, "conv2d_igemm_fwd: bad dtype %d", d->dtype);
   const int bk = d->dtype == VNQA_BF16 ? 64 : 32;
@@ -873,7 +989,6 @@ extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, 
   VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv2d_igemm_fwd: post_scale/post_shift must come together");
   VNQA_CHECK_ARG((long long)d->n_img * (d->depth > 0 ? d->depth : 1) * d->h * d->w < (1ll << 31), "conv2d_igemm_fwd: too many pixels");
 
-  ConvArgs a;
   a.x = (const char*)x;
   a.wt = (const char*)wt;
   a.bias = bias;
@@ -906,6 +1021,9 @@ extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, 
   a.partial = nullptr;
   a.border_sub = border_sub;
   a.group_tiles = 0;
+  a.epi = VNQA_EPI_NONE;
+  a.frame_of = nullptr; a.stats_partial = nullptr; a.film_gamma = nullptr; a.film_beta = nullptr;
+  a.film_ld = 0; a.film_c = 0; a.res = nullptr; a.y2 = nullptr;
   VNQA_CHECK_ARG(!d->wt_tiled || (d->tile != VNQA_TILE_AUTO && d->tile != VNQA_TILE_P4_256x256 &&
                                   d->tile != VNQA_TILE_P4_256x128 && d->tile != VNQA_TILE_P4_256x64 &&
                                   d->tile != VNQA_TILE_P3_256x128),
@@ -913,5 +1031,80 @@ extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, 
   const int ho = d->pool2 ? d->h / 2 : d->h, wo = d->pool2 ? d->w / 2 : d->w;
   a.Hyp = ho + 2 * d->y_halo;
   a.Wyp = wo + 2 * d->y_halo;
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void* wt,
+                                        const float* bias, const float* post_scale, const float* post_shift,
+                                        const void* border_sub, void* y, void* stream) {
+  ConvArgs a;
+  const int rc = fill_conv_args(d, x, wt, bias, post_scale, post_shift, border_sub, y, a);
+  if (rc != VNQA_OK) return rc;
   return conv_dispatch(a, d->dtype, d->tile, (hipStream_t)stream);
+}
+
+// pixel rows per tile the fused-epilogue conv would use for this problem (0: no fused instantiation)
+static int fused_rows_for(const vnqa_conv_desc* d) {
+  ConvArgs a;
+  a.Cout = d->c_out;
+  return fused_tile_rows(d->dtype, resolve_tile(a, d->dtype, d->tile));
+}
+
+extern "C" int64_t vnqa_conv2d_bnstats_workspace(const vnqa_conv_desc* d, int32_t min_frame_images) {
+  if (!d || d->pool2 || d->depth > 0 || d->wt_tiled) return -1;
+  const int bm = fused_rows_for(d);
+  if (bm == 0) return -1;
+  // a tile may overlap at most 3 frames: two whole frames plus a pixel on either side must not fit into one tile
+  if (2ll * min_frame_images * d->h * d->w + 2 <= bm) return -1;
+  const int64_t tiles_m = ((int64_t)d->n_img * d->h * d->w + bm - 1) / bm;
+  return tiles_m * 6 * d->c_out * 4;
+}
+
+extern "C" int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
+                                           const vnqa_conv_epilogue* e, void* y, void* stream) {
+  VNQA_CHECK_ARG(e != nullptr, "conv2d_igemm_fused_fwd: null epilogue");
+  ConvArgs a;
+  const int rc = fill_conv_args(d, x, wt, bias, nullptr, nullptr, nullptr, y, a);
+  if (rc != VNQA_OK) return rc;
+  VNQA_CHECK_ARG(!d->pool2 && d->depth == 0 && !d->wt_tiled, "conv2d_igemm_fused_fwd: 2-D, un-pooled, K-major weights only");
+  const int bm = fused_rows_for(d);
+  if (bm == 0) {
+    vnqa_set_error("conv2d_igemm_fused_fwd: tile id %d has no fused-epilogue instantiation", d->tile);
+    return VNQA_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (e->kind == VNQA_EPI_BNSTATS) {
+    VNQA_CHECK_ARG(e->frame_of && e->frame_off && e->n_frames > 0 && e->partial && e->mean && e->var,
+                   "conv2d_igemm_fused_fwd(BNSTATS): null argument");
+    if (vnqa_conv2d_bnstats_workspace(d, e->min_frame_images) < 0) {
+      vnqa_set_error("conv2d_igemm_fused_fwd(BNSTATS): frames of %d image(s) x %dx%d are too small for a %d-pixel tile",
+                     e->min_frame_images, d->h, d->w, bm);
+      return VNQA_ERR_UNSUPPORTED;
+    }
+    a.epi = VNQA_EPI_BNSTATS;
+    a.frame_of = e->frame_of;
+    a.stats_partial = e->partial;
+    const int rc2 = conv_dispatch(a, d->dtype, d->tile, st);
+    if (rc2 != VNQA_OK) return rc2;
+    dim3 grid((d->c_out + 127) / 128, e->n_frames);
+    hipLaunchKernelGGL(bnstats_finalize_kernel, grid, dim3(128), 0, st, (const float*)e->partial, e->frame_of, e->frame_off,
+                       e->mean, e->var, d->h * d->w, bm, d->c_out);
+    VNQA_CHECK_LAUNCH();
+    return VNQA_OK;
+  }
+  if (e->kind == VNQA_EPI_FILM_RES) {
+    VNQA_CHECK_ARG(e->gamma && e->beta && e->res && e->y2 && e->film_ld > 0 && e->film_c > 0 && e->film_c <= d->c_out,
+                   "conv2d_igemm_fused_fwd(FILM_RES): bad argument");
+    VNQA_CHECK_ARG(!d->relu, "conv2d_igemm_fused_fwd(FILM_RES): the conv itself carries no ReLU (film_attn_pt_stem.py:224)");
+    a.epi = VNQA_EPI_FILM_RES;
+    a.film_gamma = e->gamma;
+    a.film_beta = e->beta;
+    a.film_ld = e->film_ld;
+    a.film_c = e->film_c;
+    a.res = (const char*)e->res;
+    a.y2 = (char*)e->y2;
+    return conv_dispatch(a, d->dtype, d->tile, st);
+  }
+  vnqa_set_error("conv2d_igemm_fused_fwd: unknown epilogue kind %d", e->kind);
+  return VNQA_ERR_INVALID_ARG;
 }

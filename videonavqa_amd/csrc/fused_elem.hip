@@ -235,15 +235,16 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
 template <typename T>
 __global__ void __launch_bounds__(256) film_fwd_kernel(const T* __restrict__ z, const T* __restrict__ res,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       T* __restrict__ out, int hp, int wp, int c) {
+                                                       T* __restrict__ out, int hp, int wp, int c, int ld, int film_c) {
   const int n = blockIdx.y, cg = blockIdx.x;
   const int prow = threadIdx.x >> 3, chunk = threadIdx.x & 7;
   const int c0 = cg * 64 + chunk * 8;
   float ga[8], be[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    ga[e] = gamma[(size_t)n * c + c0 + e];
-    be[e] = beta[(size_t)n * c + c0 + e];
+    const bool ok = c0 + e < film_c;
+    ga[e] = ok ? gamma[(size_t)n * ld + c0 + e] : 0.f;
+    be[e] = ok ? beta[(size_t)n * ld + c0 + e] : 0.f;
   }
   const size_t base = (size_t)n * hp * wp * c + c0;
   for (int p = prow; p < hp * wp; p += 32) {
@@ -267,7 +268,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) film_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ z,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        T* __restrict__ dz, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                       int hp, int wp, int c) {
+                                                       int hp, int wp, int c, int ld, int film_c, int ld_out) {
   __shared__ float s_red[32 * 64];
   const int n = blockIdx.y, cg = blockIdx.x;
   const int prow = threadIdx.x >> 3, chunk = threadIdx.x & 7;
@@ -275,8 +276,9 @@ __global__ void __launch_bounds__(256) film_bwd_kernel(const T* __restrict__ dou
   float ga[8], be[8], sg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    ga[e] = gamma[(size_t)n * c + c0 + e];
-    be[e] = beta[(size_t)n * c + c0 + e];
+    const bool ok = c0 + e < film_c;
+    ga[e] = ok ? gamma[(size_t)n * ld + c0 + e] : 0.f;
+    be[e] = ok ? beta[(size_t)n * ld + c0 + e] : 0.f;
   }
   const size_t base = (size_t)n * hp * wp * c + c0;
   for (int p = prow; p < hp * wp; p += 32) {
@@ -303,8 +305,10 @@ __global__ void __launch_bounds__(256) film_bwd_kernel(const T* __restrict__ dou
   if (prow == 0) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      dgamma[(size_t)n * c + c0 + e] = sg[e];
-      dbeta[(size_t)n * c + c0 + e] = sb[e];
+      if (c0 + e < film_c) {
+        dgamma[(size_t)n * ld_out + c0 + e] = sg[e];
+        dbeta[(size_t)n * ld_out + c0 + e] = sb[e];
+      }
     }
   }
 }
@@ -379,14 +383,35 @@ extern "C" int vnqa_frame_bn_bwd(const void* dy, const void* x, const int32_t* f
   return VNQA_OK;
 }
 
-extern "C" int vnqa_film_relu_res_fwd(const void* z, const void* res, const float* gamma, const float* beta, void* out,
-                                      int32_t n_img, int32_t hp, int32_t wp, int32_t c, int32_t dtype, void* stream) {
-  VNQA_CHECK_ARG(z && res && gamma && beta && out && n_img > 0 && c % 64 == 0, "film_relu_res_fwd: bad arguments");
+extern "C" int vnqa_film_relu_res_fwd_ld(const void* z, const void* res, const float* gamma, const float* beta, void* out,
+                                         int32_t n_img, int32_t hp, int32_t wp, int32_t c, int32_t film_ld, int32_t film_c,
+                                         int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(z && res && gamma && beta && out && n_img > 0 && c % 64 == 0 && film_ld > 0 && film_c > 0 && film_c <= c,
+                 "film_relu_res_fwd: bad arguments");
   dim3 grid(c / 64, n_img);
   hipStream_t st = (hipStream_t)stream;
   VNQA_ELEM_DISPATCH(dtype,
-      hipLaunchKernelGGL(film_fwd_kernel<vnqa_bf16>, grid, dim3(256), 0, st, (const vnqa_bf16*)z, (const vnqa_bf16*)res, gamma, beta, (vnqa_bf16*)out, hp, wp, c),
-      hipLaunchKernelGGL(film_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)z, (const float*)res, gamma, beta, (float*)out, hp, wp, c));
+      hipLaunchKernelGGL(film_fwd_kernel<vnqa_bf16>, grid, dim3(256), 0, st, (const vnqa_bf16*)z, (const vnqa_bf16*)res, gamma, beta, (vnqa_bf16*)out, hp, wp, c, film_ld, film_c),
+      hipLaunchKernelGGL(film_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)z, (const float*)res, gamma, beta, (float*)out, hp, wp, c, film_ld, film_c));
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_film_relu_res_fwd(const void* z, const void* res, const float* gamma, const float* beta, void* out,
+                                      int32_t n_img, int32_t hp, int32_t wp, int32_t c, int32_t dtype, void* stream) {
+  return vnqa_film_relu_res_fwd_ld(z, res, gamma, beta, out, n_img, hp, wp, c, c, c, dtype, stream);
+}
+
+extern "C" int vnqa_film_relu_res_bwd_ld(const void* dout, const void* z, const float* gamma, const float* beta, void* dz,
+                                         float* dgamma, float* dbeta, int32_t n_img, int32_t hp, int32_t wp, int32_t c,
+                                         int32_t film_ld, int32_t film_c, int32_t grad_ld, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(dout && z && gamma && beta && dz && dgamma && dbeta && n_img > 0 && c % 64 == 0 && film_ld > 0 &&
+                     grad_ld > 0 && film_c > 0 && film_c <= c, "film_relu_res_bwd: bad arguments");
+  dim3 grid(c / 64, n_img);
+  hipStream_t st = (hipStream_t)stream;
+  VNQA_ELEM_DISPATCH(dtype,
+      hipLaunchKernelGGL(film_bwd_kernel<vnqa_bf16>, grid, dim3(256), 0, st, (const vnqa_bf16*)dout, (const vnqa_bf16*)z, gamma, beta, (vnqa_bf16*)dz, dgamma, dbeta, hp, wp, c, film_ld, film_c, grad_ld),
+      hipLaunchKernelGGL(film_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)z, gamma, beta, (float*)dz, dgamma, dbeta, hp, wp, c, film_ld, film_c, grad_ld));
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
@@ -394,14 +419,7 @@ extern "C" int vnqa_film_relu_res_fwd(const void* z, const void* res, const floa
 extern "C" int vnqa_film_relu_res_bwd(const void* dout, const void* z, const float* gamma, const float* beta, void* dz,
                                       float* dgamma, float* dbeta, int32_t n_img, int32_t hp, int32_t wp, int32_t c,
                                       int32_t dtype, void* stream) {
-  VNQA_CHECK_ARG(dout && z && gamma && beta && dz && dgamma && dbeta && n_img > 0 && c % 64 == 0, "film_relu_res_bwd: bad arguments");
-  dim3 grid(c / 64, n_img);
-  hipStream_t st = (hipStream_t)stream;
-  VNQA_ELEM_DISPATCH(dtype,
-      hipLaunchKernelGGL(film_bwd_kernel<vnqa_bf16>, grid, dim3(256), 0, st, (const vnqa_bf16*)dout, (const vnqa_bf16*)z, gamma, beta, (vnqa_bf16*)dz, dgamma, dbeta, hp, wp, c),
-      hipLaunchKernelGGL(film_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)dout, (const float*)z, gamma, beta, (float*)dz, dgamma, dbeta, hp, wp, c));
-  VNQA_CHECK_LAUNCH();
-  return VNQA_OK;
+  return vnqa_film_relu_res_bwd_ld(dout, z, gamma, beta, dz, dgamma, dbeta, n_img, hp, wp, c, c, c, c, dtype, stream);
 }
 
 extern "C" int vnqa_relu_bwd(const void* a, const void* b, const void* y, void* g, int64_t n, int32_t dtype, void* stream) {

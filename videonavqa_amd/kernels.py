@@ -90,6 +90,63 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
     return out
 
 
+def _conv_desc(x, c_out, c_y, taps, relu, tile=L.TILE_AUTO):
+    N, Hp, Wp, Cin = x.shape
+    return L.ConvDesc(L.dtype_id(x.dtype), N, Hp - 2, Wp - 2, Cin, c_out, c_y, taps, 1, 1, int(relu), 0, tile, 0, 0)
+
+
+def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frames, min_frame_images):
+    """conv (+bias, +ReLU) with the per-frame BatchNorm statistics of its output taken in the epilogue
+    (vnqa_conv2d_igemm_fused_fwd, VNQA_EPI_BNSTATS).  Returns (y, mean [F,Cout], var [F,Cout]) or None when the frames are
+    too small for the tile (the caller then runs conv2d_igemm + frame_bn_stats)."""
+    N, Hp, Wp, _ = x.shape
+    c_out, taps, _ = wt.shape
+    d = _conv_desc(x, c_out, c_out, taps, relu)
+    ws_bytes = L.lib().vnqa_conv2d_bnstats_workspace(ctypes.byref(d), int(min_frame_images))
+    if ws_bytes < 0:
+        return None
+    y = empty_padded((N, Hp, Wp, c_out), x.dtype, x.device)
+    ws = workspace(ws_bytes, x.device)
+    mean = torch.empty((n_frames, c_out), dtype=torch.float32, device=x.device)
+    var = torch.empty((n_frames, c_out), dtype=torch.float32, device=x.device)
+    e = L.ConvEpilogue(kind=L.EPI_BNSTATS, n_frames=n_frames, min_frame_images=int(min_frame_images),
+                       frame_of=frame_of_i32.data_ptr(), frame_off=frame_off_i32.data_ptr(), partial=ws.data_ptr(),
+                       mean=mean.data_ptr(), var=var.data_ptr())
+    L.check(L.lib().vnqa_conv2d_igemm_fused_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), ctypes.byref(e),
+                                                L.ptr(y), L.stream()), "vnqa_conv2d_igemm_fused_fwd(BNSTATS)")
+    return y, mean, var
+
+
+def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res):
+    """z = conv(x) + bias and out = relu(gamma[n] * z + beta[n]) + res in ONE launch (VNQA_EPI_FILM_RES).  gamma / beta:
+    fp32 2-D views [n_img, >= film_c] with unit column stride (column slices of the FiLM generator's output)."""
+    N, Hp, Wp, _ = x.shape
+    c_out, taps, _ = wt.shape
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.stride(1) == 1 and beta.stride(1) == 1
+    assert gamma.stride(0) == beta.stride(0) and res.shape == (N, Hp, Wp, c_out) and res.dtype == x.dtype
+    d = _conv_desc(x, c_out, c_out, taps, False)
+    z = empty_padded((N, Hp, Wp, c_out), x.dtype, x.device)
+    out = empty_padded((N, Hp, Wp, c_out), x.dtype, x.device)
+    e = L.ConvEpilogue(kind=L.EPI_FILM_RES, film_ld=gamma.stride(0), film_c=int(film_c), gamma=gamma.data_ptr(),
+                       beta=beta.data_ptr(), res=res.data_ptr(), y2=out.data_ptr())
+    L.check(L.lib().vnqa_conv2d_igemm_fused_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), ctypes.byref(e),
+                                                L.ptr(z), L.stream()), "vnqa_conv2d_igemm_fused_fwd(FILM_RES)")
+    return z, out
+
+
+def film_relu_res_bwd_ld(dout, z, gamma, beta, film_c, dgamma, dbeta):
+    """FiLM backward on column-slice views: gamma/beta [n_img, >= film_c] (row stride = view stride), gradients written into
+    the views dgamma/dbeta (same column range of the gradient matrix)."""
+    N, hp, wp, c = z.shape
+    assert gamma.stride(1) == 1 and dgamma.stride(1) == 1 and gamma.stride(0) == beta.stride(0)
+    assert dgamma.stride(0) == dbeta.stride(0)
+    dz = torch.empty_like(z)
+    L.check(L.lib().vnqa_film_relu_res_bwd_ld(L.ptr(dout), L.ptr(z), L.vptr(gamma), L.vptr(beta), L.ptr(dz), L.vptr(dgamma),
+                                              L.vptr(dbeta), N, hp, wp, c, gamma.stride(0), int(film_c), dgamma.stride(0),
+                                              L.dtype_id(z.dtype), L.stream()), "vnqa_film_relu_res_bwd_ld")
+    return dz
+
+
 def ring_im2col(x, H, W):
     """x halo-2 padded NHWC [n,H+4,W+4,c] -> [n*(2(W+2)+2H), 9*c]: 3x3 patches around the outside-ring positions."""
     n, _, _, c = x.shape

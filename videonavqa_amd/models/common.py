@@ -290,6 +290,50 @@ class FiLMTrunkBase(nn.Module):
         self.film_hidden = (hn.detach()[perm].unsqueeze(0), cn.detach()[perm].unsqueeze(0))
 
     # ---- conv trunk on the packed image list -------------------------------------------------
+    def _trunk_fused(self, x, lay, film_specs):
+        """TRAIN-mode trunk as one autograd node with the fused conv epilogues (ops.FilmTrunkFn).
+        film_specs[k] = (FiLM matrix [n_img, ld] fp32, column of block k's gamma) — beta follows at + C."""
+        C = self.num_res_block_channels
+        uniq, film_map = [], []
+        for t, col in film_specs:
+            for i, u in enumerate(uniq):
+                if u is t:
+                    break
+            else:
+                i = len(uniq)
+                uniq.append(t)
+            film_map.append((i, int(col)))
+        uniq = [u if (u.dtype == torch.float32 and u.stride(1) == 1) else u.float().contiguous() for u in uniq]
+        meta = ops.TrunkMeta(lay, C, self.num_res_blocks, len(uniq), film_map, BN_EPS)
+        blocks = []
+        for k in range(self.num_res_blocks):
+            c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
+            blocks += [c1.weight, c1.bias, c3.weight, c3.bias]
+        bn = self.bn_init
+        x, mean, var = ops.film_trunk(x, self.conv_init.weight, self.conv_init.bias, bn.weight, bn.bias, meta, *uniq, *blocks)
+        self._advance_running_stats(bn, lay, mean, var, (x.shape[1] - 2) * (x.shape[2] - 2))
+        return x
+
+    @staticmethod
+    def _advance_running_stats(bn, lay, mean, var, S):
+        """Running statistics advanced once per frame in frame order: closed form of the per-frame EMA updates of
+        film_attn_pt_stem.py:211 (momentum 0.1, unbiased variance)."""
+        C = bn.num_features
+        with torch.no_grad():
+            T = lay.n_frames
+            cnt = (lay.cts_t * S).unsqueeze(1)
+            decay = (1.0 - BN_MOMENTUM) ** torch.arange(T - 1, -1, -1, device=mean.device, dtype=torch.float32)
+            coef = (BN_MOMENTUM * decay).unsqueeze(1)                          # weight of frame t's statistic
+            unbias = cnt / torch.clamp(cnt - 1, min=1.0)
+            keep = (1.0 - BN_MOMENTUM) ** T
+            bn.running_mean.mul_(keep).add_((coef * mean[:, :C]).sum(0))
+            bn.running_var.mul_(keep).add_((coef * (var * unbias)[:, :C]).sum(0))
+            bn.num_batches_tracked += T
+
+    def _use_fused_trunk(self):
+        import os
+        return self.training and os.environ.get("VNQA_FUSED_TRUNK", "1") != "0" and os.environ.get("VNQA_SIDE_LSTM", "0") != "1"
+
     def _trunk(self, x, lay, film_fn):
         """conv_init -> ReLU -> per-frame BN -> FiLM residual blocks.
         film_fn(k) -> (gamma [n_img,C], beta [n_img,C]) for block k."""

@@ -76,15 +76,19 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
             film = F.relu(self.film_layer[1](h_last))                   # [B, n_frames, 2*C*blocks] (:179)
             return film[lay.sample_of, lay.frame_of]                    # [n_img, 2*C*blocks]
 
-        film_img, join = self._fork_generator(generator)
-        x = self._trunk_head(x, lay)
-        join()
+        if self._use_fused_trunk():       # train mode: the conv trunk as ONE autograd node with fused conv epilogues
+            film_img = generator()
+            x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])   # :229-233
+        else:
+            film_img, join = self._fork_generator(generator)
+            x = self._trunk_head(x, lay)
+            join()
 
-        def film_fn(k):
-            s = 2 * C * k
-            return film_img[:, s:s + C], film_img[:, s + C:s + 2 * C]   # :229-233
+            def film_fn(k):
+                s = 2 * C * k
+                return film_img[:, s:s + C], film_img[:, s + C:s + 2 * C]   # :229-233
 
-        x = self._trunk_blocks(x, lay, film_fn)
+            x = self._trunk_blocks(x, lay, film_fn)
 
         # fc_embed_attn over the flattened map (:244) as one split-K GEMM for all images
         n_img, hp, wp, c_pad = x.shape

@@ -62,13 +62,17 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
             film = F.relu(self.film_layer[1](h_last))
             return film[lay.sample_of, lay.frame_of]
 
-        film_img, join = self._fork_generator(generator)
-        x = self._trunk_head(x, lay)
-        join()
+        if self._use_fused_trunk():       # train mode: the conv trunk as ONE autograd node with fused conv epilogues
+            film_img = generator()
+            x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])
+        else:
+            film_img, join = self._fork_generator(generator)
+            x = self._trunk_head(x, lay)
+            join()
 
-        def film_fn(k):
-            s = 2 * C * k
-            return film_img[:, s:s + C], film_img[:, s + C:s + 2 * C]
+            def film_fn(k):
+                s = 2 * C * k
+                return film_img[:, s:s + C], film_img[:, s + C:s + 2 * C]
 
-        x = self._trunk_blocks(x, lay, film_fn)
+            x = self._trunk_blocks(x, lay, film_fn)
         return self._gp_tail(x, lay, h, w)

@@ -75,5 +75,8 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
             fv = film_per_block[k]
             return fv[:, s:s + C], fv[:, s + C:s + 2 * C]                 # :228-230
 
-        x = self._trunk(x, lay, film_fn)
+        if self._use_fused_trunk():       # train mode: the conv trunk as ONE autograd node with fused conv epilogues
+            x = self._trunk_fused(x, lay, [(film_per_block[k], 2 * C * k) for k in range(self.num_res_blocks)])
+        else:
+            x = self._trunk(x, lay, film_fn)
         return self._gp_tail(x, lay, h, w)                                # :240-250

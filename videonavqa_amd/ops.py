@@ -119,6 +119,111 @@ class FilmReluResFn(torch.autograd.Function):
         return dz, dout, dgamma, dbeta
 
 
+class FilmTrunkFn(torch.autograd.Function):
+    """The whole conv trunk of the FiLM models in TRAIN mode as ONE autograd node (film_attn_pt_stem.py:211-241):
+
+        r   = relu(conv_init(x))          + per-frame BatchNorm statistics in the conv's epilogue  (VNQA_EPI_BNSTATS)
+        h   = bn_init(r)                  (batch statistics per frame)
+        per block k:  res = relu(conv1x1_k(h))                                         (frozen weights)
+                      z, h = conv3x3_k(res), relu(gamma_k * z + beta_k) + res          (ONE launch, VNQA_EPI_FILM_RES)
+
+    and a hand-written backward: FiLM backward (writes d gamma / d beta straight into their column range of the FiLM
+    matrix gradient), wgrad + dgrad of the 3x3 conv, the residual join and the 1x1 conv's ReLU mask in one elementwise
+    kernel, the 1x1 dgrad, BN backward with conv_init's ReLU mask, conv_init's wgrad.  Compared with one autograd node per
+    op this removes the AccumulateGrad / add kernels of the residual joins and ~30 graph nodes of host bookkeeping.
+
+    forward(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors):
+      tensors = the distinct FiLM matrices [n_img, ld] fp32 (meta.n_film of them), then (w1, b1, w3, b3) per block;
+      meta.film_map[k] = (index of block k's matrix, column of its gamma; beta follows at + C).
+    Returns (h, mean [F, Cpad], var [F, Cpad]) — the statistics for the caller's running-stat update."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, meta, *tensors):
+        lay, C, blocks = meta.layout, meta.channels, meta.blocks
+        films = tensors[:meta.n_film]
+        cdt = x.dtype
+        c_pad = L.round_up(C, 64)
+        wt0 = K.pack_conv_weight(conv_w, cdt, c_out_pad=c_pad, c_in_pad=x.shape[-1])
+        b0 = K.pad_vec(conv_b, c_pad)
+        S = (x.shape[1] - 2) * (x.shape[2] - 2)
+        fused = None
+        if cdt == torch.bfloat16:       # fp32 (parity) precision keeps the exact two-pass statistics kernel
+            fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts))
+        if fused is None:
+            r = K.conv2d_igemm(x, wt0, bias=b0, relu=True)
+            mean, var = K.frame_bn_stats(r, lay.frame_off_i32, lay.n_frames)
+        else:
+            r, mean, var = fused
+        rstd = torch.rsqrt(var + meta.eps)
+        g = K.pad_vec(bn_w, c_pad)
+        h = K.frame_bn_apply(r, lay.frame_of_i32, mean, rstd, g, K.pad_vec(bn_b, c_pad))
+        saved = [x, r, mean, rstd, g]
+        for k in range(blocks):
+            w1, b1, w3, b3 = tensors[meta.n_film + 4 * k: meta.n_film + 4 * k + 4]
+            res = K.conv2d_igemm(h, K.pack_conv_weight(w1, cdt, c_out_pad=c_pad, c_in_pad=c_pad), bias=K.pad_vec(b1, c_pad),
+                                 relu=True)
+            fi, col = meta.film_map[k]
+            film = films[fi]
+            z, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(w3, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
+                                           K.pad_vec(b3, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res)
+            saved += [res, z]
+        ctx.meta = meta
+        ctx.save_for_backward(*saved, conv_w, *tensors)
+        ctx.mark_non_differentiable(mean, var)
+        return h, mean, var
+
+    @staticmethod
+    def backward(ctx, dout, _dm, _dv):
+        meta = ctx.meta
+        lay, C, blocks, nf = meta.layout, meta.channels, meta.blocks, meta.n_film
+        sv = ctx.saved_tensors
+        x, r, mean, rstd, g = sv[:5]
+        acts = sv[5:5 + 2 * blocks]
+        conv_w = sv[5 + 2 * blocks]
+        tensors = sv[6 + 2 * blocks:]
+        films = tensors[:nf]
+        cdt = x.dtype
+        c_pad = L.round_up(C, 64)
+        dout = dout.contiguous()
+        dfilms = [torch.zeros_like(f) if ctx.needs_input_grad[6 + i] else None for i, f in enumerate(films)]
+        grads_blocks = [None] * (4 * blocks)
+        for k in reversed(range(blocks)):
+            w1, b1, w3, b3 = tensors[nf + 4 * k: nf + 4 * k + 4]
+            res, z = acts[2 * k], acts[2 * k + 1]
+            fi, col = meta.film_map[k]
+            film = films[fi]
+            dfilm = dfilms[fi] if dfilms[fi] is not None else torch.empty_like(film)
+            dz = K.film_relu_res_bwd_ld(dout, z, film[:, col:col + C], film[:, col + C:col + 2 * C], C,
+                                        dfilm[:, col:col + C], dfilm[:, col + C:col + 2 * C])
+            dwt, dbias = K.conv2d_wgrad(res, dz, 9)
+            grads_blocks[4 * k + 2] = K.unpack_conv_wgrad(dwt, C, C)
+            grads_blocks[4 * k + 3] = dbias[:C].clone()
+            dres = K.conv2d_igemm(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
+            gsum = K.relu_bwd(dres, res, dout)             # (dres + dout) * [res > 0]: residual join + the 1x1 conv's ReLU
+            # (the 1x1 convs are frozen upstream — never in parameters() — so they get no weight gradient)
+            dout = K.conv2d_igemm(gsum, K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
+        dr, s1, s2 = K.frame_bn_bwd(dout, r, lay.frame_of_i32, lay.frame_off_i32, mean, rstd, g, lay.n_frames, True)
+        dbn_w, dbn_b = s2.sum(0)[:C], s1.sum(0)[:C]
+        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9)
+        dconv_w = K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv2d_igemm(dr, K.pack_conv_weight(conv_w, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=x.shape[-1]))
+        return (dx, dconv_w, dbias0[:C].clone(), dbn_w, dbn_b, None) + tuple(dfilms) + tuple(grads_blocks)
+
+
+class TrunkMeta(object):
+    """Non-tensor arguments of FilmTrunkFn."""
+
+    def __init__(self, layout, channels, blocks, n_film, film_map, eps):
+        self.layout, self.channels, self.blocks, self.n_film, self.film_map, self.eps = \
+            layout, channels, blocks, n_film, film_map, eps
+
+
+def film_trunk(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors):
+    return FilmTrunkFn.apply(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors)
+
+
 def frame_bn_train(x, gamma, beta, frame_of_i32, frame_off_i32, n_frames, eps, relu_input=True):
     return FrameBNTrainFn.apply(x, gamma, beta, frame_of_i32, frame_off_i32, n_frames, eps, relu_input)
 
