@@ -334,6 +334,59 @@ int vnqa_temporal_attn_fwd(const float* feat, const float* valid, const float* m
 int vnqa_temporal_attn_bwd(const float* feat, const float* valid, const float* w, const float* coef,
                            const float* dctxt, float* dfeat, float* dw_part, float* db_part, int32_t b,
                            int32_t t, int32_t a, void* stream);
+/* The same op on the PACKED image list (what the product path runs): f [n_img][ld] in `dtype` is the output of the
+ * fc_embed_attn GEMM, image n = frame_off[t] + b for the valid (sample b, frame t) pairs; the zero-padded [B][T][A] tensor,
+ * the validity grid and the -(1<<31) masks of models/film_attn_pt_stem.py:245-256 are formed on the fly.  The backward
+ * writes d f [n_img][ld] in `dtype` (padding columns a..ld-1 zero), ready to be the next GEMM's operand. */
+int vnqa_temporal_attn_packed_fwd(const void* f, int32_t ld, int32_t dtype, const int32_t* frame_off, int32_t n_frames,
+                                  const float* w, const float* bias, float* coef, float* ctxt, int32_t b, int32_t t,
+                                  int32_t a, void* stream);
+int vnqa_temporal_attn_packed_bwd(const void* f, int32_t ld, int32_t dtype, const int32_t* frame_off, int32_t n_frames,
+                                  const float* w, const float* coef, const float* dctxt, void* df, float* dw_part,
+                                  float* db_part, int32_t b, int32_t t, int32_t a, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Small fp32 pieces of the question path / classifier / loss (csrc/glue.hip): with them a training step of the FiLM models
+ * enqueues no ATen / rocBLAS kernel for these ops.  All exact fp32, fixed summation order, no atomics.
+ *
+ * vnqa_sgemm: C[row_c(m)][n] = act( sum_k A'(m,k) * B(k,n) + bias[n] ) [+ C], with
+ *     A'(m,k) = A[row_a(m) * a_rs + k * a_cs] * [a_mask(same index) > 0],   B(k,n) = B[k * b_rs + n * b_cs]
+ *   (element strides: NN / NT / TN products without copies); a_rows / c_rows optional int32 [m] row maps (negative: zero
+ *   row / row not written); a_mask optional (the ReLU mask of a Linear+ReLU backward).  Replaces nn.Linear at
+ *   models/film_attn_pt_stem.py:179 (FiLM generator Linear+ReLU), :293 (LSTMCell input projection), :301 (out_linear),
+ *   models/time_multi_hop_pt_stem.py:179 (fc_attn_out) and the backward GEMMs of each.
+ * vnqa_colsum: out[n] = sum_m x[m][n] * [mask[m][n] > 0]  (bias gradients).
+ * vnqa_gather_rows: dst[r] = src[rows[r]] (negative: zeros) — the LSTM output at the last token of every repeat
+ *   (film_attn_pt_stem.py:163-171).
+ * vnqa_embed_proj_fwd: xg[b][pos] = W_ih embed[tokens[row_perm[b]][pos]] + b_ih + b_hh — nn.Embedding (:146) fused with the
+ *   input half of nn.LSTM (:160).  vnqa_token_dsum: dsum[v] = sum of d xg over the positions holding token v, from which
+ *   d embed = dsum W_ih, d W_ih = dsum^T embed, d b = colsum(dsum) (rows of equal tokens share their embedding).
+ * vnqa_lstm_fold_dxg: d xg[b][pos] = sum over the n_rep repeats of d gates (the question is re-run once per frame, :213).
+ * vnqa_lstm_wgrad_operands: the two operands of dW_hh = sum d gates^T h_prev in the GEMM's element type, one pass.
+ * vnqa_ce_loss: nn.CrossEntropyLoss(weight, reduction sum | mean) forward and d logits (eval/q_and_v_eval.py:124);
+ *   ys int64 [b] read through row_perm (the batch sort of :113-116).
+ * vnqa_bn_running_update: bn_init's running statistics advanced once per processed frame in frame order
+ *   (film_attn_pt_stem.py:211: one BatchNorm2d call per frame; momentum 0.1, unbiased variance).
+ */
+int vnqa_sgemm(const float* a, const float* b, float* c, const float* bias, const float* a_mask, const int32_t* a_rows,
+               const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int32_t ldc, int32_t m,
+               int32_t n, int32_t k, int32_t relu, int32_t accumulate, void* stream);
+int vnqa_colsum(const float* x, const float* mask, float* out, int32_t rows, int32_t cols, int32_t ld, void* stream);
+int vnqa_gather_rows(const float* src, const int32_t* rows, float* dst, int32_t n_rows, int32_t cols, void* stream);
+int vnqa_embed_proj_fwd(const int64_t* tokens, const int32_t* row_perm, const float* embed, const float* w_ih,
+                        const float* b_ih, const float* b_hh, float* xg, int32_t b, int32_t lq, int32_t e, int32_t g,
+                        int32_t vocab, void* stream);
+int vnqa_token_dsum(const int64_t* tokens, const int32_t* row_perm, const float* dxg, float* dsum, int32_t b, int32_t lq,
+                    int32_t g, int32_t vocab, void* stream);
+int vnqa_lstm_fold_dxg(const float* dgates, const int32_t* q_lens, float* dxg, int32_t b, int32_t lq, int32_t s,
+                       int32_t hidden, int32_t n_rep, void* stream);
+int vnqa_lstm_wgrad_operands(const float* dgates, const float* hs, const float* h0, void* a, void* hp, int32_t b, int32_t s,
+                             int32_t hidden, int32_t dtype, void* stream);
+int vnqa_ce_loss(const float* logits, const int64_t* ys, const int32_t* row_perm, const float* weight, float* loss,
+                 float* dlogits, int32_t b, int32_t k, int32_t mean, void* stream);
+int vnqa_bn_running_update(const float* mean, const float* var, const int32_t* frame_off, float* running_mean,
+                           float* running_var, int32_t n_frames, int32_t pixels_per_image, int32_t c, int32_t ld,
+                           float momentum, void* stream);
 
 /* Persistent LSTM over a repeated sequence (one workgroup per sample, W_hh rows in registers).
  * Replaces the per-frame packed nn.LSTM calls with carried state of compute_film_values /

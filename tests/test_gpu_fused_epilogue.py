@@ -126,6 +126,8 @@ def test_one_node_trunk_matches_op_by_op_graph(precision, kind, monkeypatch):
     assert float((a[1] - b[1]).abs().max()) <= tol * float(a[1].abs().max()) + 1e-7
     assert float((a[2] - b[2]).abs().max()) <= tol * float(a[2].abs().max()) + 1e-7
     assert set(a[3]) == set(b[3])
+    gmax = max(float(t.abs().max()) for t in a[3].values())
     for n in a[3]:
         scale = float(a[3][n].abs().max())
-        assert float((a[3][n] - b[3][n]).abs().max()) <= (1e-4 if precision == "fp32" else 3e-2) * scale + 1e-7, n
+        # (analytically zero gradients, e.g. fc_hidden_attn of the attention model, are float noise: absolute floor)
+        assert float((a[3][n] - b[3][n]).abs().max()) <= (1e-4 if precision == "fp32" else 3e-2) * scale + 1e-6 * gmax, n

@@ -57,6 +57,17 @@ _SIGNATURES = {
     "vnqa_relu_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "vnqa_temporal_attn_fwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 3 + [_vp]),
     "vnqa_temporal_attn_bwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 3 + [_vp]),
+    "vnqa_temporal_attn_packed_fwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vnqa_temporal_attn_packed_bwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vnqa_sgemm": (ctypes.c_int, [_vp] * 7 + [_i64] * 4 + [_i32] * 6 + [_vp]),
+    "vnqa_colsum": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vnqa_gather_rows": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "vnqa_embed_proj_fwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
+    "vnqa_token_dsum": (ctypes.c_int, [_vp] * 4 + [_i32] * 4 + [_vp]),
+    "vnqa_lstm_fold_dxg": (ctypes.c_int, [_vp] * 3 + [_i32] * 5 + [_vp]),
+    "vnqa_lstm_wgrad_operands": (ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_vp]),
+    "vnqa_ce_loss": (ctypes.c_int, [_vp] * 6 + [_i32] * 3 + [_vp]),
+    "vnqa_bn_running_update": (ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_f32, _vp]),
     "vnqa_lstm_seq_fwd": (ctypes.c_int, [_vp] * 9 + [_i32] * 5 + [_vp]),
     "vnqa_lstm_seq_bwd": (ctypes.c_int, [_vp] * 10 + [_i32] * 4 + [_vp]),
     "vnqa_lstm_wide_fwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
