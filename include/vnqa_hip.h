@@ -371,7 +371,8 @@ int vnqa_temporal_attn_packed_bwd(const void* f, int32_t ld, int32_t dtype, cons
 int vnqa_sgemm(const float* a, const float* b, float* c, const float* bias, const float* a_mask, const int32_t* a_rows,
                const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int32_t ldc, int32_t m,
                int32_t n, int32_t k, int32_t relu, int32_t accumulate, void* stream);
-int vnqa_colsum(const float* x, const float* mask, float* out, int32_t rows, int32_t cols, int32_t ld, void* stream);
+int vnqa_colsum(const void* x, const float* mask, float* out, int32_t rows, int32_t cols, int32_t ld, int32_t dtype,
+                void* stream);   /* x in `dtype`; a mask needs dtype == VNQA_F32 */
 int vnqa_gather_rows(const float* src, const int32_t* rows, float* dst, int32_t n_rows, int32_t cols, void* stream);
 int vnqa_embed_proj_fwd(const int64_t* tokens, const int32_t* row_perm, const float* embed, const float* w_ih,
                         const float* b_ih, const float* b_hh, float* xg, int32_t b, int32_t lq, int32_t e, int32_t g,

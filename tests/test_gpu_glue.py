@@ -1,0 +1,159 @@
+"""GPU: the small fp32 HIP ops of the question path / classifier / loss (csrc/glue.hip, packed temporal attention)
+against plain PyTorch fp32 references of the same ops."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=1e-5):
+    return float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("m,n,k", [(280, 1024, 128), (8, 70, 4480), (3, 5, 7), (130, 65, 33)])
+def test_sgemm_nt_nn_tn_bias_relu_mask_gather_scatter(m, n, k):
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(m * 7 + n)
+    x = torch.randn(m, k, generator=g).cuda()
+    w = torch.randn(n, k, generator=g).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    assert _close(K.linear_nt(x, w, bias=b, relu=True), F.relu(x @ w.t() + b))
+    assert _close(K.linear_nt(x, w), x @ w.t())
+    dy = torch.randn(m, n, generator=g).cuda()
+    mask = torch.randn(m, n, generator=g).cuda()
+    dym = dy * (mask > 0)
+    assert _close(K.matmul_nn(dy, w, a_mask=mask), dym @ w)
+    assert _close(K.matmul_tn(dy, x, a_mask=mask), dym.t() @ x)
+    assert _close(K.colsum(dy, mask), dym.sum(0)) and _close(K.colsum(dy), dy.sum(0))
+    assert _close(K.colsum(dy.bfloat16()), dy.bfloat16().float().sum(0), 1e-5)
+    # row gather on A (with a negative = zero row) and row scatter on C, accumulation
+    rows = torch.randperm(m, generator=g)[: max(m // 2, 1)].to(torch.int32)
+    rows_neg = rows.clone()
+    rows_neg[0] = -1
+    xs = x[rows.long()].clone()
+    xs[0] = 0
+    assert _close(K.linear_nt(x, w, bias=b, a_rows=rows_neg.cuda(), m=rows.numel()), xs @ w.t() + b)
+    out = torch.zeros(m, k, device="cuda")
+    K.matmul_nn(dy[: rows.numel()].contiguous(), w, out=out, c_rows=rows.cuda())
+    ref = torch.zeros(m, k, device="cuda")
+    ref[rows.long().cuda()] = dy[: rows.numel()] @ w
+    assert _close(out, ref)
+    acc = torch.ones(n, k, device="cuda")
+    K.matmul_tn(dy, x, out=acc, accumulate=True)
+    assert _close(acc, 1 + dy.t() @ x)
+    # strided operand views (column slices of wider matrices)
+    wide = torch.randn(m, k + 9, generator=g).cuda()
+    assert _close(K.linear_nt(wide[:, 4:4 + k], w), wide[:, 4:4 + k] @ w.t())
+
+
+@pytest.mark.parametrize("padding_idx", [None, 0])
+def test_embed_proj_forward_backward_vs_torch(padding_idx):
+    from videonavqa_amd import ops
+    torch.manual_seed(3)
+    V, E, H, B, Lq = 23, 12, 16, 5, 9
+    emb = nn.Embedding(V, E, padding_idx=padding_idx).cuda()
+    lstm = nn.LSTM(E, H).cuda()
+    tokens = torch.randint(0, V, (B, Lq)).cuda()
+    tokens[0, 3] = 0
+    ref = F.linear(emb(tokens), lstm.weight_ih_l0, lstm.bias_ih_l0 + lstm.bias_hh_l0)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    want = [p.grad.clone() for p in (emb.weight, lstm.weight_ih_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)]
+    for p in (emb.weight, lstm.weight_ih_l0, lstm.bias_ih_l0, lstm.bias_hh_l0):
+        p.grad = None
+    got = ops.embed_proj(tokens, emb.weight, lstm.weight_ih_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, padding_idx)
+    assert _close(got, ref)
+    got.backward(dy)
+    for p, wnt in zip((emb.weight, lstm.weight_ih_l0, lstm.bias_ih_l0, lstm.bias_hh_l0), want):
+        assert _close(p.grad, wnt, 1e-4)
+
+
+def test_linear_fn_with_row_gather_vs_torch():
+    from videonavqa_amd import ops
+    torch.manual_seed(5)
+    hs = torch.randn(40, 16, device="cuda", requires_grad=True)
+    lin = nn.Linear(16, 24).cuda()
+    rows = torch.tensor([3, 17, 39, 0, 8], dtype=torch.int32, device="cuda")
+    ref = F.relu(lin(hs[rows.long()]))
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    want = (hs.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    hs.grad = lin.weight.grad = lin.bias.grad = None
+    got = ops.linear(hs, lin.weight, lin.bias, relu=True, rows=rows)
+    assert _close(got, ref)
+    got.backward(dy)
+    for a, b in zip((hs.grad, lin.weight.grad, lin.bias.grad), want):
+        assert _close(a, b, 1e-5)
+
+
+@pytest.mark.parametrize("reduction", ["sum", "mean"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_ce_loss_vs_torch(reduction, weighted):
+    from videonavqa_amd import ops
+    torch.manual_seed(7)
+    B, Kc = 11, 70
+    logits = (torch.randn(B, Kc, device="cuda") * 3).requires_grad_(True)
+    ys = torch.randint(0, Kc, (B,), device="cuda")
+    perm = torch.randperm(B).to(torch.int32).cuda()
+    w = (torch.rand(Kc, device="cuda") + 0.2) if weighted else None
+    ref = nn.CrossEntropyLoss(weight=w, reduction=reduction)(logits, ys[perm.long()])
+    ref.backward()
+    want = logits.grad.clone()
+    logits.grad = None
+    got = ops.cross_entropy(logits, ys, row_perm=perm, weight=w, reduction=reduction)
+    assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
+    (got * 2.0).backward()
+    assert _close(logits.grad, 2.0 * want, 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_packed_temporal_attention_vs_dense_op(dtype):
+    """packed kernel (frame-major image list, validity / masks formed on the fly) == the dense [B,T,A] op it replaces,
+    ragged clips incl. frames past the longest video (un-masked on purpose)."""
+    from videonavqa_amd import ops
+    from videonavqa_amd.models.common import FrameLayout
+    torch.manual_seed(9)
+    B, T, A, ld = 4, 7, 16, 64
+    lay = FrameLayout([5, 4, 2, 2], T, "cuda")
+    f = torch.zeros(lay.n_img, ld, device="cuda")
+    f[:, :A] = torch.randn(lay.n_img, A, device="cuda")
+    f = f.to(dtype).requires_grad_(True)
+    w = torch.randn(1, A, device="cuda", requires_grad=True)
+    bias = torch.randn(1, device="cuda", requires_grad=True)
+    # dense reference path (the op-by-op model code)
+    dense = torch.zeros(B, T, A, device="cuda").index_put((lay.sample_of, lay.frame_of), f[:, :A].float())
+    valid = torch.zeros(B, T, device="cuda").index_put((lay.sample_of, lay.frame_of), torch.ones(lay.n_img, device="cuda"))
+    processed = torch.zeros(1, T, device="cuda")
+    processed[:, :lay.n_frames] = 1
+    masks = (processed - valid) * float(-(1 << 31))
+    ctxt_ref, coef_ref = ops.temporal_attention(dense, valid, masks, w, bias)
+    dctxt = torch.randn_like(ctxt_ref)
+    ctxt_ref.backward(dctxt)
+    want = (f.grad.clone(), w.grad.clone(), bias.grad.clone())
+    f.grad = w.grad = bias.grad = None
+    ctxt, coef = ops.temporal_attention_packed(f, lay.frame_off_i32, lay.n_frames, B, T, A, w, bias)
+    assert _close(ctxt, ctxt_ref, 1e-5) and _close(coef, coef_ref, 1e-5)
+    ctxt.backward(dctxt)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert _close(f.grad.float(), want[0].float(), tol) and float(f.grad[:, A:].abs().max()) == 0
+    assert _close(w.grad, want[1], 1e-4) and _close(bias.grad, want[2], 1e-4)
+
+
+def test_bn_running_update_matches_per_frame_ema():
+    from videonavqa_amd import kernels as K
+    torch.manual_seed(11)
+    Fr, C, S = 6, 70, 196
+    cts = [4, 4, 3, 3, 1, 1]
+    off = torch.tensor([0] + list(torch.tensor(cts).cumsum(0)), dtype=torch.int32, device="cuda")
+    mean = torch.randn(Fr, 128, device="cuda")
+    var = torch.rand(Fr, 128, device="cuda") + 0.1
+    rm, rv = torch.randn(C, device="cuda"), torch.rand(C, device="cuda") + 0.5
+    em, ev = rm.clone(), rv.clone()
+    for f in range(Fr):
+        n = cts[f] * S
+        em = 0.9 * em + 0.1 * mean[f, :C]
+        ev = 0.9 * ev + 0.1 * var[f, :C] * n / (n - 1)
+    K.bn_running_update(mean, var, off, Fr, S, rm, rv, 0.1)
+    assert _close(rm, em, 1e-6) and _close(rv, ev, 1e-6)

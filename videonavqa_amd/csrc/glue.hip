@@ -114,13 +114,14 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p) {
 }
 
 // out[n] = sum_m x[m*ld + n] * [mask > 0]   (one thread per column, 256 columns per block; rows in a fixed order)
-__global__ void colsum_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out, int rows,
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out, int rows,
                               int cols, int ld) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= cols) return;
   float s = 0.f;
   for (int m = 0; m < rows; ++m) {
-    const float v = x[(size_t)m * ld + n];
+    const float v = ElemOps<T>::load(x[(size_t)m * ld + n]);
     s += (mask == nullptr || mask[(size_t)m * ld + n] > 0.f) ? v : 0.f;
   }
   out[n] = s;
@@ -272,9 +273,16 @@ extern "C" int vnqa_sgemm(const float* a, const float* b, float* c, const float*
   return VNQA_OK;
 }
 
-extern "C" int vnqa_colsum(const float* x, const float* mask, float* out, int32_t rows, int32_t cols, int32_t ld, void* stream) {
+extern "C" int vnqa_colsum(const void* x, const float* mask, float* out, int32_t rows, int32_t cols, int32_t ld, int32_t dtype,
+                           void* stream) {
   VNQA_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, mask, out, rows, cols, ld);
+  VNQA_CHECK_ARG(dtype == VNQA_F32 || (dtype == VNQA_BF16 && mask == nullptr), "colsum: dtype must be f32, or bf16 without a mask");
+  if (dtype == VNQA_BF16)
+    hipLaunchKernelGGL(colsum_kernel<vnqa_bf16>, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const vnqa_bf16*)x,
+                       mask, out, rows, cols, ld);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)x, mask, out,
+                       rows, cols, ld);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

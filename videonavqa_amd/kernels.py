@@ -26,7 +26,9 @@ def pack_conv_weight(w_oihw, dtype, out_scale=None, transpose_flip=False, c_out_
 
 
 def pad_vec(v, n):
-    """fp32 per-channel vector zero-padded to n entries."""
+    """fp32 per-channel vector zero-padded to n entries (the vector itself when nothing has to change)."""
+    if v.numel() == n and v.dtype == torch.float32 and v.is_contiguous():
+        return v.detach()
     out = torch.zeros(n, dtype=torch.float32, device=v.device)
     out[: v.numel()] = v.detach().float()
     return out
@@ -574,3 +576,134 @@ def temporal_attn_bwd(feat, valid, w, coef, dctxt):
     L.check(L.lib().vnqa_temporal_attn_bwd(L.ptr(feat), L.ptr(valid), L.ptr(w), L.ptr(coef), L.ptr(dctxt), L.ptr(dfeat),
                                            L.ptr(dw_part), L.ptr(db_part), B, T, A, L.stream()), "vnqa_temporal_attn_bwd")
     return dfeat, dw_part, db_part
+
+
+# ---- csrc/glue.hip: small fp32 products and data movement of the question path / classifier / loss ---------------------
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_cuda
+    return t
+
+
+def sgemm(a, b, m, n, k, a_rs, a_cs, b_rs, b_cs, out, bias=None, relu=False, accumulate=False, a_mask=None, a_rows=None,
+          c_rows=None):
+    """out[row_c(i)][j] = act(sum_k a'[i,k] b[k,j] + bias[j]) [+ out]; element strides select NN / NT / TN (vnqa_sgemm)."""
+    assert out.dtype == torch.float32 and out.stride(-1) == 1
+    L.check(L.lib().vnqa_sgemm(L.vptr(_f32c(a)), L.vptr(_f32c(b)), L.vptr(out), L.ptr(bias),
+                               L.vptr(a_mask) if a_mask is not None else None, L.ptr(a_rows), L.ptr(c_rows),
+                               a_rs, a_cs, b_rs, b_cs, out.stride(0), m, n, k, int(relu), int(accumulate), L.stream()),
+            "vnqa_sgemm")
+    return out
+
+
+def linear_nt(x, w, bias=None, relu=False, a_rows=None, m=None):
+    """act(x_sel @ w.T + bias): x [R,K], w [N,K] fp32 (row-major, unit inner stride); a_rows gathers m rows of x."""
+    m = x.shape[0] if m is None else m
+    n, k = w.shape
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    return sgemm(x, w, m, n, k, x.stride(0), 1, 1, w.stride(0), out, bias=bias, relu=relu, a_rows=a_rows)
+
+
+def matmul_nn(a, b, a_mask=None, out=None, c_rows=None, accumulate=False):
+    """(a * [mask > 0]) @ b: a [M,K], b [K,N]; c_rows scatters the result rows into `out`."""
+    m, k = a.shape
+    n = b.shape[1]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    return sgemm(a, b, m, n, k, a.stride(0), 1, b.stride(0), 1, out, a_mask=a_mask, c_rows=c_rows, accumulate=accumulate)
+
+
+def matmul_tn(a, b, a_mask=None, out=None, accumulate=False):
+    """(a * [mask > 0]).T @ b: a [K,M], b [K,N] -> [M,N]."""
+    k, m = a.shape
+    n = b.shape[1]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    return sgemm(a, b, m, n, k, 1, a.stride(0), b.stride(0), 1, out, a_mask=a_mask, accumulate=accumulate)
+
+
+def colsum(x, mask=None):
+    """sum over the rows of a 2-D tensor (fp32, optionally only where mask > 0; or bf16 without a mask) -> fp32 [cols]."""
+    rows, cols = x.shape
+    out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vnqa_colsum(L.vptr(x), L.vptr(mask) if mask is not None else None, L.ptr(out), rows, cols,
+                                x.stride(0), L.dtype_id(x.dtype), L.stream()), "vnqa_colsum")
+    return out
+
+
+def gather_rows(src, rows):
+    """dst[r] = src[rows[r]] (zeros for negative indices); src [R,C] fp32 contiguous, rows int32."""
+    n, c = rows.numel(), src.shape[1]
+    dst = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    L.check(L.lib().vnqa_gather_rows(L.ptr(_f32c(src)), L.ptr(rows), L.ptr(dst), n, c, L.stream()), "vnqa_gather_rows")
+    return dst
+
+
+def embed_proj_fwd(tokens, row_perm, embed, w_ih, b_ih, b_hh):
+    B, Lq = tokens.shape
+    V, E = embed.shape
+    G = w_ih.shape[0]
+    xg = torch.empty((B, Lq, G), dtype=torch.float32, device=embed.device)
+    L.check(L.lib().vnqa_embed_proj_fwd(L.ptr(tokens), L.ptr(row_perm), L.ptr(embed), L.ptr(w_ih), L.ptr(b_ih), L.ptr(b_hh),
+                                        L.ptr(xg), B, Lq, E, G, V, L.stream()), "vnqa_embed_proj_fwd")
+    return xg
+
+
+def token_dsum(tokens, row_perm, dxg, vocab):
+    B, Lq, G = dxg.shape
+    dsum = torch.empty((vocab, G), dtype=torch.float32, device=dxg.device)
+    L.check(L.lib().vnqa_token_dsum(L.ptr(tokens), L.ptr(row_perm), L.ptr(dxg), L.ptr(dsum), B, Lq, G, vocab, L.stream()),
+            "vnqa_token_dsum")
+    return dsum
+
+
+def lstm_fold_dxg(dgates, q_lens_i32, Lq, n_rep):
+    B, S, G = dgates.shape
+    dxg = torch.empty((B, Lq, G), dtype=torch.float32, device=dgates.device)
+    L.check(L.lib().vnqa_lstm_fold_dxg(L.ptr(dgates), L.ptr(q_lens_i32), L.ptr(dxg), B, Lq, S, G // 4, n_rep, L.stream()),
+            "vnqa_lstm_fold_dxg")
+    return dxg
+
+
+def lstm_wgrad_operands(dgates, hs, h0, dtype):
+    B, S, G = dgates.shape
+    H = G // 4
+    a = torch.empty((B * S, G), dtype=dtype, device=dgates.device)
+    hp = torch.empty((B * S, H), dtype=dtype, device=dgates.device)
+    L.check(L.lib().vnqa_lstm_wgrad_operands(L.ptr(dgates), L.ptr(hs), L.ptr(h0), L.ptr(a), L.ptr(hp), B, S, H,
+                                             L.dtype_id(dtype), L.stream()), "vnqa_lstm_wgrad_operands")
+    return a, hp
+
+
+def ce_loss(logits, ys, row_perm, weight, mean):
+    B, Kc = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    L.check(L.lib().vnqa_ce_loss(L.ptr(logits), L.ptr(ys), L.ptr(row_perm), L.ptr(weight), L.ptr(loss), L.ptr(dlogits), B, Kc,
+                                 int(mean), L.stream()), "vnqa_ce_loss")
+    return loss, dlogits
+
+
+def bn_running_update(mean, var, frame_off_i32, n_frames, pixels_per_image, running_mean, running_var, momentum):
+    C = running_mean.numel()
+    L.check(L.lib().vnqa_bn_running_update(L.ptr(mean), L.ptr(var), L.ptr(frame_off_i32), L.ptr(running_mean),
+                                           L.ptr(running_var), n_frames, pixels_per_image, C, mean.stride(0), momentum,
+                                           L.stream()), "vnqa_bn_running_update")
+
+
+def temporal_attn_packed_fwd(f, frame_off_i32, n_frames, B, T, A, w, bias):
+    coef = torch.empty((B, T), dtype=torch.float32, device=f.device)
+    ctxt = torch.empty((B, A), dtype=torch.float32, device=f.device)
+    L.check(L.lib().vnqa_temporal_attn_packed_fwd(L.ptr(f), f.stride(0), L.dtype_id(f.dtype), L.ptr(frame_off_i32), n_frames,
+                                                  L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(ctxt), B, T, A, L.stream()),
+            "vnqa_temporal_attn_packed_fwd")
+    return coef, ctxt
+
+
+def temporal_attn_packed_bwd(f, frame_off_i32, n_frames, B, T, A, w, coef, dctxt):
+    df = torch.empty_like(f)
+    dw_part = torch.empty((B, A), dtype=torch.float32, device=f.device)
+    db_part = torch.empty((B, 1), dtype=torch.float32, device=f.device)
+    L.check(L.lib().vnqa_temporal_attn_packed_bwd(L.ptr(f), f.stride(0), L.dtype_id(f.dtype), L.ptr(frame_off_i32), n_frames,
+                                                  L.ptr(w), L.ptr(coef), L.ptr(dctxt), L.ptr(df), L.ptr(dw_part),
+                                                  L.ptr(db_part), B, T, A, L.stream()), "vnqa_temporal_attn_packed_bwd")
+    return df, dw_part, db_part

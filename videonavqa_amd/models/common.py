@@ -94,11 +94,36 @@ class FrameLayout(object):
         self.img_of = packed[:o1]
         self.frame_of_i32 = packed[o1:o2]
         self.frame_off_i32 = packed[o3:o3 + nf + 1]
-        self.frame_of = packed[o1:o2].long()
-        self.sample_of = packed[o2:o3].long()
-        self.cts_t = (packed[o3 + 1:o3 + nf + 1] - packed[o3:o3 + nf]).float()
+        self.sample_of_i32 = packed[o2:o3]
         self.uniform = all(ct == B for ct in self.cts)
-        self._device_tensors = [packed, self.frame_of, self.sample_of, self.cts_t]
+        self._device_tensors = [packed]
+        self._lazy = {}
+
+    # int64 / float forms of the tables: built on first use (the fused training path never needs them)
+    def _lazily(self, name, make):
+        t = self._lazy.get(name)
+        if t is None:
+            t = self._lazy[name] = make()
+            self._device_tensors.append(t)
+        return t
+
+    @property
+    def frame_of(self):
+        return self._lazily("frame_of", lambda: self.frame_of_i32.long())
+
+    @property
+    def sample_of(self):
+        return self._lazily("sample_of", lambda: self.sample_of_i32.long())
+
+    @property
+    def cts_t(self):
+        return self._lazily("cts_t", lambda: (self.frame_off_i32[1:] - self.frame_off_i32[:-1]).float())
+
+    def last_token_rows(self, q_lens_cpu, S):
+        """Row of the flattened LSTM output [B*S, H] holding sample b's state at the LAST token of its (t+1)-th repeat,
+        for every image n = (frame t, sample b) in packing order (film_attn_pt_stem.py:163-171 evaluated per frame)."""
+        ql = [int(v) for v in q_lens_cpu]
+        return np.asarray([b * S + (t + 1) * ql[b] - 1 for t, ct in enumerate(self.cts) for b in range(ct)], np.int32)
 
     def record_stream(self, stream):
         """The tables were allocated on the stream current at construction (the stem's side stream when prefetched);
@@ -238,8 +263,9 @@ class FiLMTrunkBase(nn.Module):
         super()._apply(fn, *args, **kwargs)
         for c in self.conv1x1_layers:
             c._apply(fn)
-        if getattr(self, "film_hidden", None) is not None:
-            self.film_hidden = tuple(fn(t) for t in self.film_hidden)
+        if self.__dict__.get("_carried") is None and self.__dict__.get("_film_hidden") is not None:
+            self.__dict__["_film_hidden"] = tuple(fn(t) for t in self.__dict__["_film_hidden"])
+        self.__dict__["_zero_state"] = None
         return self
 
     def extra_state_tensors(self):
@@ -272,12 +298,42 @@ class FiLMTrunkBase(nn.Module):
         x = K.feat_to_nhwc(v_input, lay.img_of, lay.n_img, cdt)
         return x, lay, h, w
 
+    # The carried question-LSTM state is kept lazily: the reference stores it in q_len-sorted order (:150,:160), which costs
+    # a host sort + upload + two gathers per step — paid only when somebody actually reads `film_hidden` (a test, or a
+    # caller that does NOT reset it with init_hidden() between minibatches).
+    def _get_film_hidden(self):
+        carried = self.__dict__.get("_carried")
+        if carried is not None:
+            hn, cn, ql_cpu = carried
+            perm = L.to_device_async(torch.sort(ql_cpu, dim=0, descending=True, stable=True)[1], hn.device)
+            self.__dict__["_film_hidden"] = (hn[perm].unsqueeze(0), cn[perm].unsqueeze(0))
+            self.__dict__["_carried"] = None
+        return self.__dict__.get("_film_hidden")
+
+    def _set_film_hidden(self, value):
+        self.__dict__["_film_hidden"] = value
+        self.__dict__["_carried"] = None
+
+    film_hidden = property(_get_film_hidden, _set_film_hidden)
+
+    def _zero_hidden(self, B, H, device):
+        """Cached zero state (never written in place): init_hidden() every minibatch costs no fill kernels."""
+        z = self.__dict__.get("_zero_state")
+        if z is None or z[0].shape != (1, B, H) or z[0].device != torch.device(device):
+            z = (torch.zeros(1, B, H, device=device), torch.zeros(1, B, H, device=device))
+            self.__dict__["_zero_state"] = z
+        return z
+
     def _question_state(self, B, H, q_lens, device):
         """Per-sample initial (h, c); the reference stores it in q_len-sorted order (:150,:160)."""
-        fh = getattr(self, "film_hidden", None)
-        if fh is None:
-            z = torch.zeros(B, H, device=device)
-            return z, z.clone()
+        carried = self.__dict__.get("_carried")
+        if carried is not None:           # state of the previous forward, still in sample order: use as is
+            return carried[0], carried[1]
+        fh = self.__dict__.get("_film_hidden")
+        z = self.__dict__.get("_zero_state")
+        if fh is None or (z is not None and fh[0] is z[0]):
+            z = self._zero_hidden(B, H, device)
+            return z[0][0], z[1][0]
         perm = L.to_device_async(torch.sort(q_lens.cpu(), dim=0, descending=True, stable=True)[1], device)
         h0 = torch.empty(B, H, device=device)
         c0 = torch.empty(B, H, device=device)
@@ -286,8 +342,27 @@ class FiLMTrunkBase(nn.Module):
         return h0, c0
 
     def _store_question_state(self, hn, cn, q_lens):
-        perm = L.to_device_async(torch.sort(q_lens.cpu(), dim=0, descending=True, stable=True)[1], hn.device)
-        self.film_hidden = (hn.detach()[perm].unsqueeze(0), cn.detach()[perm].unsqueeze(0))
+        self.__dict__["_carried"] = (hn.detach(), cn.detach(), q_lens.detach().cpu().long())
+
+    def question_film_values(self, lstm, proj, q_input, q_lens, lay, padding_idx=None):
+        """FiLM generator for all frames of the minibatch (film_attn_pt_stem.py:144-181 called once per frame from :213):
+        embedding + input projection (one HIP launch), the question LSTM re-run per frame with carried state as ONE
+        persistent chain, then Linear + ReLU on the state at the last token of every repeat, written per packed image.
+        Returns film [n_img, 2*C*blocks] fp32."""
+        B = q_input.shape[0]
+        H = lstm.hidden_size
+        dev = q_input.device
+        ql_cpu = q_lens.detach().cpu().long()
+        Lmax = int(ql_cpu.max())
+        S = Lmax * lay.n_frames
+        tbl = np.concatenate([ql_cpu.numpy().astype(np.int32), lay.last_token_rows(ql_cpu, S)])
+        tbl = L.to_device_async(torch.from_numpy(tbl), dev)          # ONE pinned upload for both tables
+        ql_i32, rows = tbl[:B], tbl[B:]
+        xg = ops.embed_proj(q_input, self.embed.weight, lstm.weight_ih_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, padding_idx)
+        h0, c0 = self._question_state(B, H, q_lens, dev)
+        hs, hn, cn = ops.lstm_seq(xg, lstm.weight_hh_l0, h0, c0, ql_i32, lay.n_frames, S, self.compute_dtype)
+        self._store_question_state(hn, cn, q_lens)
+        return ops.linear(hs.view(B * S, H), proj.weight, proj.bias, relu=True, rows=rows)
 
     # ---- conv trunk on the packed image list -------------------------------------------------
     def _trunk_fused(self, x, lay, film_specs):
@@ -316,19 +391,11 @@ class FiLMTrunkBase(nn.Module):
 
     @staticmethod
     def _advance_running_stats(bn, lay, mean, var, S):
-        """Running statistics advanced once per frame in frame order: closed form of the per-frame EMA updates of
-        film_attn_pt_stem.py:211 (momentum 0.1, unbiased variance)."""
-        C = bn.num_features
+        """Running statistics advanced once per processed frame in frame order (film_attn_pt_stem.py:211 calls bn_init once
+        per frame: momentum 0.1, unbiased variance) — one HIP launch."""
         with torch.no_grad():
-            T = lay.n_frames
-            cnt = (lay.cts_t * S).unsqueeze(1)
-            decay = (1.0 - BN_MOMENTUM) ** torch.arange(T - 1, -1, -1, device=mean.device, dtype=torch.float32)
-            coef = (BN_MOMENTUM * decay).unsqueeze(1)                          # weight of frame t's statistic
-            unbias = cnt / torch.clamp(cnt - 1, min=1.0)
-            keep = (1.0 - BN_MOMENTUM) ** T
-            bn.running_mean.mul_(keep).add_((coef * mean[:, :C]).sum(0))
-            bn.running_var.mul_(keep).add_((coef * (var * unbias)[:, :C]).sum(0))
-            bn.num_batches_tracked += T
+            K.bn_running_update(mean, var, lay.frame_off_i32, lay.n_frames, S, bn.running_mean, bn.running_var, BN_MOMENTUM)
+            bn.num_batches_tracked += lay.n_frames
 
     def _use_fused_trunk(self):
         import os

@@ -52,9 +52,7 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
 
     def init_hidden(self):
         """film_attn_pt_stem.py:133-138."""
-        dev = self.embed.weight.device
-        self.film_hidden = (torch.zeros(1, self.batch_size, self.hidden_size, device=dev),
-                            torch.zeros(1, self.batch_size, self.hidden_size, device=dev))
+        self.film_hidden = self._zero_hidden(self.batch_size, self.hidden_size, self.embed.weight.device)
 
     def forward(self, v_input, q_input, v_lens, q_lens):
         """v_input: fp32 [B, C_in, h, w, T] (reference layout) or NativeFeatures from the stem;
@@ -66,20 +64,21 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         B, T = lay.B, lay.T
         C = self.num_res_block_channels
 
-        # FiLM generator: question LSTM re-run per processed frame with carried state (:213) — on the side stream
-        def generator():
-            emb = self.embed(q_input)
-            h0, c0 = self._question_state(B, self.hidden_size, q_lens, dev)
-            h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
-                                                          wgrad_dtype=self.compute_dtype)
-            self._store_question_state(hn, cn, q_lens)
-            film = F.relu(self.film_layer[1](h_last))                   # [B, n_frames, 2*C*blocks] (:179)
-            return film[lay.sample_of, lay.frame_of]                    # [n_img, 2*C*blocks]
-
-        if self._use_fused_trunk():       # train mode: the conv trunk as ONE autograd node with fused conv epilogues
-            film_img = generator()
+        fused = self._use_fused_trunk()
+        if fused:       # train mode: generator and conv trunk on fused HIP ops (one autograd node for the trunk)
+            film_img = self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay)
             x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])   # :229-233
         else:
+            # FiLM generator: question LSTM re-run per processed frame with carried state (:213) — on the side stream
+            def generator():
+                emb = self.embed(q_input)
+                h0, c0 = self._question_state(B, self.hidden_size, q_lens, dev)
+                h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
+                                                              wgrad_dtype=self.compute_dtype)
+                self._store_question_state(hn, cn, q_lens)
+                film = F.relu(self.film_layer[1](h_last))                   # [B, n_frames, 2*C*blocks] (:179)
+                return film[lay.sample_of, lay.frame_of]                    # [n_img, 2*C*blocks]
+
             film_img, join = self._fork_generator(generator)
             x = self._trunk_head(x, lay)
             join()
@@ -95,6 +94,22 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         at = self.at_hidden_size
         at_pad = L.round_up(at, 64)
         f = ops.fc_native(x.view(n_img, -1), self.fc_embed_attn.weight, self.fc_embed_attn.bias, C, h, w, at_pad)
+        if fused:
+            # temporal attention (:245-290) straight from the packed GEMM output: the zero-padded [B,T,at] tensor, the
+            # validity grid and the -(1<<31) masks are formed inside the kernel.  v_i = fc_hidden_attn(h) is constant along
+            # the frame axis and softmax is shift invariant, so coefs/ctxt are identical at every step of the
+            # :283 loop and are computed once (fc_hidden_attn consequently receives a zero gradient).
+            ctxt, coefs = ops.temporal_attention_packed(f, lay.frame_off_i32, lay.n_frames, B, T, at,
+                                                        self.fc_attn_1.weight, self.fc_attn_1.bias)
+            # the 35-step LSTMCell chain on a constant input = the persistent LSTM kernel with one "token" repeated T
+            # times (:283,293-298); input projection and classifier (:301) on the fp32 HIP GEMM
+            gi = ops.linear(ctxt, self.lstm_attn.weight_ih, self.lstm_attn.bias_ih + self.lstm_attn.bias_hh)
+            z = self._zero_hidden(B, at, dev)[0][0] if at == self.hidden_size else torch.zeros(B, at, device=dev)
+            ones = self.__dict__.get("_ones_i32")
+            if ones is None or ones.numel() != B or ones.device != dev:
+                ones = self.__dict__["_ones_i32"] = torch.ones(B, dtype=torch.int32, device=dev)
+            hs, _, _ = ops.lstm_seq(gi.unsqueeze(1), self.lstm_attn.weight_hh, z, z, ones, T, T, self.compute_dtype)
+            return ops.linear(hs.view(B, T * at), self.out_linear.weight, self.out_linear.bias)      # :301
         f = f[:, :at].float()
         all_features = torch.zeros(B, T, at, device=dev).index_put((lay.sample_of, lay.frame_of), f)  # :245-256
         valid = torch.zeros(B, T, 1, device=dev).index_put(
@@ -105,13 +120,9 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         processed[:, :lay.n_frames] = 1
         masks = (processed - valid) * NEG_MASK
         # temporal attention (:268-290) as ONE fused HIP kernel: fc_attn_1 scores on the valid entries,
-        # masked softmax over frames, weighted sum.  v_i = fc_hidden_attn(h) is constant along the frame
-        # axis and softmax is shift invariant, so coefs/ctxt are identical at every step of the
-        # :283 loop and are computed once (fc_hidden_attn consequently receives a zero gradient).
+        # masked softmax over frames, weighted sum.
         ctxt, coefs = ops.temporal_attention(all_features, valid.squeeze(2), masks.squeeze(2),
                                              self.fc_attn_1.weight, self.fc_attn_1.bias)
-        # the 35-step LSTMCell chain on a constant input = the persistent LSTM kernel with
-        # one "token" repeated T times (:283,293-298)
         gi = F.linear(ctxt, self.lstm_attn.weight_ih, self.lstm_attn.bias_ih + self.lstm_attn.bias_hh)
         zeros = torch.zeros(B, at, device=dev)
         ones = torch.ones(B, dtype=torch.int32, device=dev)

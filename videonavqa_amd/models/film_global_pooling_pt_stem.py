@@ -41,9 +41,7 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
         self.init_hidden()
 
     def init_hidden(self):
-        dev = self.embed.weight.device
-        self.film_hidden = (torch.zeros(1, self.batch_size, self.hidden_size, device=dev),
-                            torch.zeros(1, self.batch_size, self.hidden_size, device=dev))
+        self.film_hidden = self._zero_hidden(self.batch_size, self.hidden_size, self.embed.weight.device)
 
     def forward(self, v_input, q_input, v_lens, q_lens):
         """film_global_pooling_pt_stem.py:180-238."""
@@ -62,8 +60,8 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
             film = F.relu(self.film_layer[1](h_last))
             return film[lay.sample_of, lay.frame_of]
 
-        if self._use_fused_trunk():       # train mode: the conv trunk as ONE autograd node with fused conv epilogues
-            film_img = generator()
+        if self._use_fused_trunk():       # train mode: generator and conv trunk on fused HIP ops
+            film_img = self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay, padding_idx=0)
             x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])
         else:
             film_img, join = self._fork_generator(generator)

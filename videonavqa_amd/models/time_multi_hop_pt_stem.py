@@ -41,9 +41,7 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
 
     def init_hidden(self):
         """time_multi_hop_pt_stem.py:111-116."""
-        dev = self.embed.weight.device
-        self.film_hidden = (torch.zeros(1, self.batch_size, self.hidden_size, device=dev),
-                            torch.zeros(1, self.batch_size, self.hidden_size, device=dev))
+        self.film_hidden = self._zero_hidden(self.batch_size, self.hidden_size, self.embed.weight.device)
         self.h = None
 
     def forward(self, v_input, q_input, v_lens, q_lens):

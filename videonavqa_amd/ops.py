@@ -197,19 +197,19 @@ class FilmTrunkFn(torch.autograd.Function):
                                         dfilm[:, col:col + C], dfilm[:, col + C:col + 2 * C])
             dwt, dbias = K.conv2d_wgrad(res, dz, 9)
             grads_blocks[4 * k + 2] = K.unpack_conv_wgrad(dwt, C, C)
-            grads_blocks[4 * k + 3] = dbias[:C].clone()
+            grads_blocks[4 * k + 3] = dbias[:C]
             dres = K.conv2d_igemm(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
             gsum = K.relu_bwd(dres, res, dout)             # (dres + dout) * [res > 0]: residual join + the 1x1 conv's ReLU
             # (the 1x1 convs are frozen upstream — never in parameters() — so they get no weight gradient)
             dout = K.conv2d_igemm(gsum, K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
         dr, s1, s2 = K.frame_bn_bwd(dout, r, lay.frame_of_i32, lay.frame_off_i32, mean, rstd, g, lay.n_frames, True)
-        dbn_w, dbn_b = s2.sum(0)[:C], s1.sum(0)[:C]
+        dbn_w, dbn_b = K.colsum(s2)[:C], K.colsum(s1)[:C]
         dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9)
         dconv_w = K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_igemm(dr, K.pack_conv_weight(conv_w, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=x.shape[-1]))
-        return (dx, dconv_w, dbias0[:C].clone(), dbn_w, dbn_b, None) + tuple(dfilms) + tuple(grads_blocks)
+        return (dx, dconv_w, dbias0[:C], dbn_w, dbn_b, None) + tuple(dfilms) + tuple(grads_blocks)
 
 
 class TrunkMeta(object):
@@ -262,17 +262,13 @@ class LstmSeqFn(torch.autograd.Function):
         dhN = None if dhN is None else dhN.float().contiguous()
         dcN = None if dcN is None else dcN.float().contiguous()
         dgates, dh0, dc0 = K.lstm_seq_bwd(w, q_lens_i32, c0, gates, dhs, dhN, dcN, n_rep)
-        # dW_hh = sum_{b,t} dgates[b,t]^T h_{t-1}[b]   (rows past a sample's last cell are zero)
-        hprev = torch.cat([h0.unsqueeze(1), hs[:, :-1]], dim=1)
-        # exact-f32 MFMA in the fp32 (parity) mode; bf16 operands / fp32 accumulation in the bf16 mode (the f32 matrix
-        # path runs at 1/16 of the bf16 rate and this GEMM sits on the trunk's dependent chain)
-        wd = ctx.wgrad_dtype
-        dw = K.gemm_tn(dgates.view(B * S, 4 * H).to(wd), hprev.reshape(B * S, H).to(wd).contiguous())
+        # dW_hh = sum_{b,t} dgates[b,t]^T h_{t-1}[b]   (rows past a sample's last cell are zero): both operands produced in
+        # the GEMM's element type by one kernel.  Exact-f32 MFMA in the fp32 (parity) mode; bf16 operands / fp32 accumulation
+        # in the bf16 mode (the f32 matrix path runs at 1/16 of the bf16 rate and this GEMM sits on the trunk's dependent chain)
+        a, hprev = K.lstm_wgrad_operands(dgates, hs, h0, ctx.wgrad_dtype)
+        dw = K.gemm_tn(a, hprev)
         # dxg[b][pos] = sum over repeats of dgates at cells t with t % q_len == pos
-        ql = q_lens_i32.long().clamp(min=1).unsqueeze(1)
-        t = torch.arange(S, device=hs.device).unsqueeze(0)
-        pos = (t % ql).unsqueeze(2).expand(B, S, 4 * H)
-        dxg = torch.zeros(B, Lq, 4 * H, device=hs.device).scatter_add_(1, pos, dgates)
+        dxg = K.lstm_fold_dxg(dgates, q_lens_i32, Lq, n_rep)
         return dxg, dw, dh0, dc0, None, None, None, None
 
 
@@ -459,7 +455,7 @@ class FcNativeFn(torch.autograd.Function):
         c_pad = x.shape[1] // ((h + 2) * (w + 2))
         need_dx = ctx.needs_input_grad[0]
         nat, nat_t = K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, x.dtype, want_t=need_dx)
-        bias_p = torch.nn.functional.pad(bias.detach().float(), (0, rows_pad - rows)).contiguous()
+        bias_p = K.pad_vec(bias, rows_pad)
         out = K.gemm_nt(x.contiguous(), nat, bias=bias_p)
         ctx.save_for_backward(x, nat_t)
         ctx.geom = (rows, C, h, w, c_pad)
@@ -472,7 +468,7 @@ class FcNativeFn(torch.autograd.Function):
         dout = dout.to(x.dtype).contiguous()
         dx = K.gemm_nt(dout, nat_t) if ctx.needs_input_grad[0] else None
         dw = K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad) if ctx.needs_input_grad[1] else None
-        db = dout.float().sum(0)[:rows] if ctx.needs_input_grad[2] else None
+        db = K.colsum(dout)[:rows] if ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None, None, None
 
 
@@ -587,3 +583,118 @@ class MacCoreFn(torch.autograd.Function):
 
 def mac_core(*args):
     return MacCoreFn.apply(*args)
+
+
+# ---- question path / classifier / loss on csrc/glue.hip (no ATen / rocBLAS kernels in the step) --------------------------
+class LinearFn(torch.autograd.Function):
+    """y = act(x_sel @ w.T + b) in exact fp32 on vnqa_sgemm; `rows` (int32, optional) gathers the rows of x first —
+    the LSTM output at the last token of every repeat (film_attn_pt_stem.py:163-171) feeding the FiLM generator's
+    Linear+ReLU (:179).  Replaces nn.Linear of film_layer[1], lstm_attn's input half, out_linear and their backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu, rows):
+        x = x.float() if x.dtype != torch.float32 else x
+        assert x.dim() == 2 and x.stride(1) == 1
+        xs = K.gather_rows(x.contiguous(), rows) if rows is not None else x
+        y = K.linear_nt(xs, w, bias=b, relu=relu)
+        ctx.save_for_backward(xs, w, y if relu else None, rows)
+        ctx.relu, ctx.x_rows = relu, x.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, w, y, rows = ctx.saved_tensors
+        dy = dy.contiguous()
+        mask = y if ctx.relu else None
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if rows is not None:      # adjoint of the row gather: scatter into zeros (every source row is used at most once)
+                dx = torch.zeros((ctx.x_rows, w.shape[1]), dtype=torch.float32, device=dy.device)
+                K.matmul_nn(dy, w, a_mask=mask, out=dx, c_rows=rows)
+            else:
+                dx = K.matmul_nn(dy, w, a_mask=mask)
+        if ctx.needs_input_grad[1]:
+            dw = K.matmul_tn(dy, xs, a_mask=mask)
+        if ctx.needs_input_grad[2]:
+            db = K.colsum(dy, mask)
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b, relu=False, rows=None):
+    return LinearFn.apply(x, w, b, relu, rows)
+
+
+class EmbedProjFn(torch.autograd.Function):
+    """xg[b,pos] = W_ih embed[tokens[b,pos]] + b_ih + b_hh: nn.Embedding (film_attn_pt_stem.py:146) fused with the input half
+    of nn.LSTM (:160).  Backward through per-token sums of d xg (rows holding the same token share their embedding):
+    d embed = dsum W_ih, d W_ih = dsum^T embed, d b_ih = d b_hh = colsum(dsum); `padding_idx` row gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, tokens, embed, w_ih, b_ih, b_hh, padding_idx):
+        xg = K.embed_proj_fwd(tokens.contiguous(), None, embed, w_ih, b_ih, b_hh)
+        ctx.save_for_backward(tokens, embed, w_ih)
+        ctx.padding_idx = padding_idx
+        return xg
+
+    @staticmethod
+    def backward(ctx, dxg):
+        tokens, embed, w_ih = ctx.saved_tensors
+        V = embed.shape[0]
+        dsum = K.token_dsum(tokens.contiguous(), None, dxg.contiguous(), V)        # [V, 4H]
+        dembed = K.matmul_nn(dsum, w_ih)                                            # [V, E]
+        if ctx.padding_idx is not None:
+            dembed[ctx.padding_idx].zero_()
+        dw = K.matmul_tn(dsum, embed)                                               # [4H, E]
+        db = K.colsum(dsum)
+        return None, dembed, dw, db, db, None
+
+
+def embed_proj(tokens, embed, w_ih, b_ih, b_hh, padding_idx=None):
+    return EmbedProjFn.apply(tokens, embed, w_ih, b_ih, b_hh, padding_idx)
+
+
+class TemporalAttnPackedFn(torch.autograd.Function):
+    """ctxt, coef = temporal attention (film_attn_pt_stem.py:245-290) straight from the packed fc_embed_attn output
+    f [n_img, ld] (compute dtype): no dense [B,T,A] scatter, validity grid or mask tensors."""
+
+    @staticmethod
+    def forward(ctx, f, frame_off_i32, n_frames, B, T, A, w, bias):
+        w1 = w.reshape(-1)
+        b1 = bias.reshape(-1)
+        coef, ctxt = K.temporal_attn_packed_fwd(f, frame_off_i32, n_frames, B, T, A, w1, b1)
+        ctx.save_for_backward(f, frame_off_i32, w1, coef)
+        ctx.dims, ctx.w_shape = (n_frames, B, T, A), w.shape
+        ctx.mark_non_differentiable(coef)
+        return ctxt, coef
+
+    @staticmethod
+    def backward(ctx, dctxt, _dcoef):
+        f, frame_off_i32, w1, coef = ctx.saved_tensors
+        n_frames, B, T, A = ctx.dims
+        df, dw_part, db_part = K.temporal_attn_packed_bwd(f, frame_off_i32, n_frames, B, T, A, w1, coef, dctxt.contiguous())
+        return df, None, None, None, None, None, K.colsum(dw_part).view(ctx.w_shape), K.colsum(db_part)
+
+
+def temporal_attention_packed(f, frame_off_i32, n_frames, B, T, A, w, bias):
+    return TemporalAttnPackedFn.apply(f, frame_off_i32, n_frames, B, T, A, w, bias)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss(weight, reduction = sum | mean) of eval/q_and_v_eval.py:124 as one HIP launch producing the loss
+    and d logits; `row_perm` (int32) reads the targets through the batch sort of :113-116."""
+
+    @staticmethod
+    def forward(ctx, logits, ys, row_perm, weight, mean):
+        loss, dlogits = K.ce_loss(logits.float().contiguous(), ys, row_perm, weight, mean)
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * dloss, None, None, None, None
+
+
+def cross_entropy(logits, ys, row_perm=None, weight=None, reduction="sum"):
+    assert reduction in ("sum", "mean"), reduction
+    return CrossEntropyFn.apply(logits, ys, row_perm, weight, reduction == "mean")

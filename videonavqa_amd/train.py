@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import kernels as K
+from . import ops
 from .models.common import FrameLayout, NativeFeatures
 
 
@@ -120,7 +121,8 @@ class Trainer(object):
         self.model, self.stem = model, stem
         self.lr, self.clip = lr, clip
         self.world_size, self.rank = world_size, rank
-        self.loss_fn = nn.CrossEntropyLoss(weight=class_weights, reduction=loss_reduction)
+        self.loss_fn = nn.CrossEntropyLoss(weight=class_weights, reduction=loss_reduction)    # (eval loops use this form)
+        self.class_weights = None if class_weights is None else class_weights.detach().float().contiguous()
         self.loss_reduction = loss_reduction
         self.feature_channels = feature_channels
         collectives = world_size > 1 if collectives is None else bool(collectives)
@@ -270,11 +272,12 @@ class Trainer(object):
         self._prefetched = None
         if next_clip is not None:
             self.prefetch(next_clip, next_v_lens_cpu if next_v_lens_cpu is not None else v_lens_cpu)
-        perm_d = L.to_device_async(perm, self.stem_device)
+        perm_d = L.to_device_async(perm.to(torch.int32), self.stem_device)
         if hasattr(self.model, "init_hidden"):     # `--model mac` has none (eval/q_and_v_eval.py:119-120)
             self.model.init_hidden()
-        logits = self.model(native, q_input[perm_d], v_sorted, q_lens_cpu[perm])
-        loss = self.loss_fn(logits, ys[perm_d])
+        logits = self.model(native, q_input.index_select(0, perm_d), v_sorted, q_lens_cpu[perm])
+        # CrossEntropyLoss forward + d logits as one HIP launch; the targets are read through the batch-sort permutation
+        loss = ops.cross_entropy(logits, ys, row_perm=perm_d, weight=self.class_weights, reduction=self.loss_reduction)
         loss.backward()
         self.reducer.finish()
         clamp = getattr(self.model, "grad_clamp", None)
