@@ -359,7 +359,7 @@ int vnqa_temporal_attn_packed_bwd(const void* f, int32_t ld, int32_t dtype, cons
  * vnqa_gather_rows: dst[r] = src[rows[r]] (negative: zeros) — the LSTM output at the last token of every repeat
  *   (film_attn_pt_stem.py:163-171).
  * vnqa_embed_proj_fwd: xg[b][pos] = W_ih embed[tokens[row_perm[b]][pos]] + b_ih + b_hh — nn.Embedding (:146) fused with the
- *   input half of nn.LSTM (:160).  vnqa_token_dsum: dsum[v] = sum of d xg over the positions holding token v, from which
+ *   input half of nn.LSTM (:160): the lookup is the row gather of the GEMM's A operand.  vnqa_token_dsum: dsum[v] = sum of d xg over the positions holding token v, from which
  *   d embed = dsum W_ih, d W_ih = dsum^T embed, d b = colsum(dsum) (rows of equal tokens share their embedding).
  * vnqa_lstm_fold_dxg: d xg[b][pos] = sum over the n_rep repeats of d gates (the question is re-run once per frame, :213).
  * vnqa_lstm_wgrad_operands: the two operands of dW_hh = sum d gates^T h_prev in the GEMM's element type, one pass.
@@ -368,17 +368,20 @@ int vnqa_temporal_attn_packed_bwd(const void* f, int32_t ld, int32_t dtype, cons
  * vnqa_bn_running_update: bn_init's running statistics advanced once per processed frame in frame order
  *   (film_attn_pt_stem.py:211: one BatchNorm2d call per frame; momentum 0.1, unbiased variance).
  */
+int64_t vnqa_sgemm_workspace(int32_t m, int32_t n, int32_t k);   /* bytes of split-K scratch (0: none needed) */
 int vnqa_sgemm(const float* a, const float* b, float* c, const float* bias, const float* a_mask, const int32_t* a_rows,
                const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int32_t ldc, int32_t m,
-               int32_t n, int32_t k, int32_t relu, int32_t accumulate, void* stream);
+               int32_t n, int32_t k, int32_t relu, int32_t accumulate, void* workspace, void* stream);
+               /* workspace: vnqa_sgemm_workspace bytes (skinny outputs over a long K are split over workgroups and summed in
+                * slice order by a second launch); NULL = one pass over K */
 int vnqa_colsum(const void* x, const float* mask, float* out, int32_t rows, int32_t cols, int32_t ld, int32_t dtype,
                 void* stream);   /* x in `dtype`; a mask needs dtype == VNQA_F32 */
 int vnqa_gather_rows(const float* src, const int32_t* rows, float* dst, int32_t n_rows, int32_t cols, void* stream);
 int vnqa_embed_proj_fwd(const int64_t* tokens, const int32_t* row_perm, const float* embed, const float* w_ih,
-                        const float* b_ih, const float* b_hh, float* xg, int32_t b, int32_t lq, int32_t e, int32_t g,
-                        int32_t vocab, void* stream);
-int vnqa_token_dsum(const int64_t* tokens, const int32_t* row_perm, const float* dxg, float* dsum, int32_t b, int32_t lq,
-                    int32_t g, int32_t vocab, void* stream);
+                        const float* b_ih, const float* b_hh, float* xg, int32_t* rows, int32_t b, int32_t lq, int32_t e,
+                        int32_t g, int32_t vocab, void* stream);   /* rows: out, int32 [b*lq] token per position (kept for the backward) */
+int vnqa_token_dsum(const int32_t* rows, const float* dxg, float* dsum, int32_t n_pos, int32_t g, int32_t vocab,
+                    void* stream);
 int vnqa_lstm_fold_dxg(const float* dgates, const int32_t* q_lens, float* dxg, int32_t b, int32_t lq, int32_t s,
                        int32_t hidden, int32_t n_rep, void* stream);
 int vnqa_lstm_wgrad_operands(const float* dgates, const float* hs, const float* h0, void* a, void* hp, int32_t b, int32_t s,

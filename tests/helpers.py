@@ -37,7 +37,7 @@ def model_of_case(case):
     raise KeyError(case)
 
 
-QV_CASES = ["film_attn_full", "film_attn_ragged", "film_attn_short", "film_attn_s196",
+QV_CASES = ["film_attn_full", "film_attn_ragged", "film_attn_short", "film_attn_s196", "film_attn_b5",
             "film_gp_full", "film_gp_ragged", "tmh_full", "tmh_ragged"]
 
 
@@ -63,6 +63,9 @@ def build_product_model(case, precision):
         spatial = 130
         if case == "film_attn_s196":
             kw["num_res_blocks"] = 1
+            spatial = 196
+        if case == "film_attn_b5":          # eval.sh's depth: 5 FiLM blocks, 14x14 maps
+            kw["num_res_blocks"] = 5
             spatial = 196
         model = M.FiLMAttnPretrainedStem(spatial_size=spatial, precision=precision, **kw)
     elif case.startswith("film_gp"):

@@ -370,6 +370,8 @@ def main():
     attn_kw = dict(batch_size=B, q_embedding_size=12, nb_classes=7, num_input_channels=C_in,
                    num_res_block_channels=C, num_res_blocks=2, hidden_size=16,
                    at_hidden_size=16, max_num_frames=T, q_encoder="lstm", vocab_size=20)
+    if args.only == "film_attn_b5":
+        return main_b5(out_dir, attn_kw, B, C_in, T, L, FiLMAttnPretrainedStem)
     run_qv_case(out_dir, "film_attn_full", FiLMAttnPretrainedStem, attn_kw, B, C_in, T, L,
                 v_lens=[6, 6, 6], q_lens=[9, 5, 7], seed=11)
     run_qv_case(out_dir, "film_attn_ragged", FiLMAttnPretrainedStem, attn_kw, B, C_in, T, L,
@@ -381,6 +383,16 @@ def main():
     attn196["num_res_blocks"] = 1
     run_qv_case(out_dir, "film_attn_s196", FiLMAttnPretrainedStem, attn196, B, C_in, T, L,
                 v_lens=[6, 5, 3], q_lens=[9, 2, 7], seed=14, patch_spatial=(14, 14))
+
+    # eval.sh's depth (5 FiLM blocks, /root/reference/eval.sh:8-19) on 14x14 maps: 5 gamma/beta column pairs of the
+    # generator's output, residual joins 5 deep
+    attn_b5 = dict(attn_kw)
+    attn_b5["num_res_blocks"] = 5
+    if not args.only or args.only == "film_attn_b5":
+        run_qv_case(out_dir, "film_attn_b5", FiLMAttnPretrainedStem, attn_b5, B, C_in, T, L,
+                    v_lens=[6, 4, 3], q_lens=[5, 9, 2], seed=15, patch_spatial=(14, 14))
+    if args.only == "film_attn_b5":
+        return
 
     gp_kw = dict(batch_size=B, q_embedding_size=12, nb_classes=7, num_input_channels=C_in,
                  num_res_block_channels=C, num_tail_channels=4, num_res_blocks=2,
@@ -402,6 +414,13 @@ def main():
     run_cnn3d_case(out_dir, "cnn3d_small", seed=51)
     run_qonly_case(out_dir, "qonly_small", seed=61)
     run_mac_only(out_dir)
+
+
+def main_b5(out_dir, attn_kw, B, C_in, T, L, cls):
+    attn_b5 = dict(attn_kw)
+    attn_b5["num_res_blocks"] = 5
+    run_qv_case(out_dir, "film_attn_b5", cls, attn_b5, B, C_in, T, L, v_lens=[6, 4, 3], q_lens=[5, 9, 2], seed=15,
+                patch_spatial=(14, 14))
 
 
 def run_mac_only(out_dir):

@@ -59,11 +59,12 @@ _SIGNATURES = {
     "vnqa_temporal_attn_bwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 3 + [_vp]),
     "vnqa_temporal_attn_packed_fwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vnqa_temporal_attn_packed_bwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "vnqa_sgemm": (ctypes.c_int, [_vp] * 7 + [_i64] * 4 + [_i32] * 6 + [_vp]),
+    "vnqa_sgemm_workspace": (_i64, [_i32, _i32, _i32]),
+    "vnqa_sgemm": (ctypes.c_int, [_vp] * 7 + [_i64] * 4 + [_i32] * 6 + [_vp, _vp]),
     "vnqa_colsum": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_gather_rows": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
-    "vnqa_embed_proj_fwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
-    "vnqa_token_dsum": (ctypes.c_int, [_vp] * 4 + [_i32] * 4 + [_vp]),
+    "vnqa_embed_proj_fwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [_vp]),
+    "vnqa_token_dsum": (ctypes.c_int, [_vp] * 3 + [_i32] * 3 + [_vp]),
     "vnqa_lstm_fold_dxg": (ctypes.c_int, [_vp] * 3 + [_i32] * 5 + [_vp]),
     "vnqa_lstm_wgrad_operands": (ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_vp]),
     "vnqa_ce_loss": (ctypes.c_int, [_vp] * 6 + [_i32] * 3 + [_vp]),

@@ -23,6 +23,7 @@ struct SgemmArgs {
   const float* B;
   float* C;
   const float* bias;     // [N] or null
+  const float* bias2;    // second bias vector added like `bias` (b_ih + b_hh of an LSTM input projection); or null
   const float* a_mask;   // same indexing as A: A'(m,k) = A(m,k) * [a_mask(m,k) > 0]; or null
   const int* a_rows;     // [M]: physical row of A for logical row m (negative: a zero row); or null
   const int* c_rows;     // [M]: physical row of C for logical row m (negative: not written); or null
@@ -32,18 +33,22 @@ struct SgemmArgs {
   int relu, accumulate;
 };
 
-// 64x64 output tile, 16-deep K chunks through LDS, 256 threads x (4x4) outputs
-__global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p) {
+// 64x64 output tile, 16-deep K chunks through LDS, 256 threads x (4x4) outputs; the next chunk's global loads are issued
+// before the current chunk's FMAs (register double buffer).  gridDim.z > 1: split-K — slice z covers K range
+// [z * k_per_slice, ...) and writes its raw partial tile to `partial` [z][M][N]; sgemm_finish_kernel applies the epilogue.
+__global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __restrict__ partial, int k_per_slice) {
   __shared__ float As[16][64 + 4];
   __shared__ float Bs[16][64 + 4];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int kb = blockIdx.z * k_per_slice;
+  const int ke = (kb + k_per_slice < p.K) ? kb + k_per_slice : p.K;
   float acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  // loader roles: thread -> (k = tid & 15, 4 rows m = (tid >> 4) + 16 r) for A, (k = tid >> 4 .. , n) for B
+  // loader roles: A: k = tid & 15, rows m = (tid >> 4) + 16 r;  B: k = tid >> 4, columns n = (tid & 15) + 16 r
   const int lk = threadIdx.x & 15, lr = threadIdx.x >> 4;
   long long a_base[4];
   bool a_ok[4];
@@ -58,24 +63,34 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p) {
     }
     a_base[r] = (long long)row * p.a_rs;
   }
-  for (int k0 = 0; k0 < p.K; k0 += 16) {
+  float ra[4], rb[4];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = k0 + lk;
       float v = 0.f;
-      if (a_ok[r] && k < p.K) {
+      if (a_ok[r] && k < ke) {
         const long long off = a_base[r] + (long long)k * p.a_cs;
         v = p.A[off];
         if (p.a_mask != nullptr && !(p.a_mask[off] > 0.f)) v = 0.f;
       }
-      As[lk][lr + 16 * r] = v;
+      ra[r] = v;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = k0 + lr, n = n0 + lk + 16 * r;
-      Bs[lr][lk + 16 * r] = (k < p.K && n < p.N) ? p.B[(long long)k * p.b_rs + (long long)n * p.b_cs] : 0.f;
+      rb[r] = (k < ke && n < p.N) ? p.B[(long long)k * p.b_rs + (long long)n * p.b_cs] : 0.f;
+    }
+  };
+  fetch(kb);
+  for (int k0 = kb; k0 < ke; k0 += 16) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      As[lk][lr + 16 * r] = ra[r];
+      Bs[lr][lk + 16 * r] = rb[r];
     }
     __syncthreads();
+    if (k0 + 16 < ke) fetch(k0 + 16);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       float a[4], b[4];
@@ -94,6 +109,14 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p) {
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + ty * 4 + i;
     if (m >= p.M) continue;
+    if (partial != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + tx * 4 + j;
+        if (n < p.N) partial[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j];
+      }
+      continue;
+    }
     int row = m;
     if (p.c_rows != nullptr) {
       row = p.c_rows[m];
@@ -105,11 +128,33 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p) {
       if (n >= p.N) continue;
       float v = acc[i][j];
       if (p.bias != nullptr) v += p.bias[n];
+      if (p.bias2 != nullptr) v += p.bias2[n];
       float* dst = p.C + (long long)row * p.ldc + n;
       if (p.accumulate) v += *dst;
       if (p.relu) v = fmaxf(v, 0.f);
       *dst = v;
     }
+  }
+}
+
+// split-K second pass: sum the slices in order (deterministic), then bias / accumulate / ReLU / row scatter
+__global__ void sgemm_finish_kernel(const SgemmArgs p, const float* __restrict__ partial, int slices) {
+  const size_t total = (size_t)p.M * p.N;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / p.N), n = (int)(i - (size_t)m * p.N);
+    int row = m;
+    if (p.c_rows != nullptr) {
+      row = p.c_rows[m];
+      if (row < 0) continue;
+    }
+    float v = 0.f;
+    for (int z = 0; z < slices; ++z) v += partial[(size_t)z * total + i];
+    if (p.bias != nullptr) v += p.bias[n];
+    if (p.bias2 != nullptr) v += p.bias2[n];
+    float* dst = p.C + (long long)row * p.ldc + n;
+    if (p.accumulate) v += *dst;
+    if (p.relu) v = fmaxf(v, 0.f);
+    *dst = v;
   }
 }
 
@@ -134,37 +179,34 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int* __r
   for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(size_t)r * cols + c] = row >= 0 ? src[(size_t)row * cols + c] : 0.f;
 }
 
-// xg[b][pos][j] = b_ih[j] + b_hh[j] + sum_e W_ih[j][e] * embed[token(b,pos)][e]
-__global__ void embed_proj_fwd_kernel(const long long* __restrict__ tokens, const int* __restrict__ row_perm,
-                                      const float* __restrict__ embed, const float* __restrict__ w_ih,
-                                      const float* __restrict__ b_ih, const float* __restrict__ b_hh, float* __restrict__ xg,
-                                      int Lq, int E, int G, int V) {
-  extern __shared__ float s_e[];
-  const int b = blockIdx.y, pos = blockIdx.x;
+// rows[b*Lq + pos] = token(row_perm[b], pos) clamped to the vocabulary: the row-gather table of the embedding GEMM
+__global__ void token_rows_kernel(const long long* __restrict__ tokens, const int* __restrict__ row_perm, int* __restrict__ rows,
+                                  int B, int Lq, int V) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Lq) return;
+  const int b = i / Lq, pos = i - b * Lq;
   const int src_b = row_perm != nullptr ? row_perm[b] : b;
   long long tok = tokens[(size_t)src_b * Lq + pos];
-  tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
-  for (int e = threadIdx.x; e < E; e += blockDim.x) s_e[e] = embed[(size_t)tok * E + e];
-  __syncthreads();
-  for (int j = threadIdx.x; j < G; j += blockDim.x) {
-    const float* w = w_ih + (size_t)j * E;
-    float acc = b_ih[j] + b_hh[j];
-    for (int e = 0; e < E; ++e) acc = fmaf(w[e], s_e[e], acc);
-    xg[((size_t)b * Lq + pos) * G + j] = acc;
-  }
+  rows[i] = (int)(tok < 0 ? 0 : (tok >= V ? V - 1 : tok));
 }
 
 // dsum[v][j] = sum over the (b, pos) whose token is v of dxg[b][pos][j]   (positions in a fixed order)
-__global__ void token_dsum_kernel(const long long* __restrict__ tokens, const int* __restrict__ row_perm,
-                                  const float* __restrict__ dxg, float* __restrict__ dsum, int B, int Lq, int G) {
+__global__ void token_dsum_kernel(const int* __restrict__ rows, const float* __restrict__ dxg, float* __restrict__ dsum, int n_pos,
+                                  int G) {
+  extern __shared__ int s_hit[];              // positions holding token v, in order
+  __shared__ int s_n;
   const int v = blockIdx.x;
+  if (threadIdx.x == 0) {                     // serial compaction keeps the summation order fixed (n_pos is a few hundred)
+    int n = 0;
+    for (int i = 0; i < n_pos; ++i)
+      if (rows[i] == v) s_hit[n++] = i;
+    s_n = n;
+  }
+  __syncthreads();
+  const int n = s_n;
   for (int j = threadIdx.x; j < G; j += blockDim.x) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const int src_b = row_perm != nullptr ? row_perm[b] : b;
-      for (int pos = 0; pos < Lq; ++pos)
-        if (tokens[(size_t)src_b * Lq + pos] == v) s += dxg[((size_t)b * Lq + pos) * G + j];
-    }
+    for (int h = 0; h < n; ++h) s += dxg[(size_t)s_hit[h] * G + j];
     dsum[(size_t)v * G + j] = s;
   }
 }
@@ -259,16 +301,46 @@ __global__ void bn_running_update_kernel(const float* __restrict__ mean, const f
 
 }  // namespace
 
+// Split-K plan: few output tiles but a long K (out_linear: 8 x 70 outputs over K = 4480; the FiLM generator's d h:
+// 280 x 128 over K = 1024) would leave the chip to a handful of workgroups walking K serially at memory latency per chunk.
+static int sgemm_slices(int m, int n, int k) {
+  const int tiles = ((m + 63) / 64) * ((n + 63) / 64);
+  if (tiles >= 64 || k < 256) return 1;
+  int s = (128 + tiles - 1) / tiles;
+  const int max_s = k / 64;
+  s = s > max_s ? max_s : s;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int64_t vnqa_sgemm_workspace(int32_t m, int32_t n, int32_t k) {
+  const int s = sgemm_slices(m, n, k);
+  return s <= 1 ? 0 : (int64_t)s * m * n * 4;
+}
+
 extern "C" int vnqa_sgemm(const float* a, const float* b, float* c, const float* bias, const float* a_mask,
                           const int32_t* a_rows, const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs,
                           int64_t b_cs, int32_t ldc, int32_t m, int32_t n, int32_t k, int32_t relu, int32_t accumulate,
-                          void* stream) {
+                          void* workspace, void* stream) {
   VNQA_CHECK_ARG(a && b && c && m > 0 && n > 0 && k > 0 && ldc >= n, "sgemm: bad arguments (m=%d n=%d k=%d ldc=%d)", m, n, k, ldc);
   SgemmArgs p;
-  p.A = a; p.B = b; p.C = c; p.bias = bias; p.a_mask = a_mask; p.a_rows = a_rows; p.c_rows = c_rows;
+  p.A = a; p.B = b; p.C = c; p.bias = bias; p.bias2 = nullptr; p.a_mask = a_mask; p.a_rows = a_rows; p.c_rows = c_rows;
   p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc; p.M = m; p.N = n; p.K = k;
   p.relu = relu; p.accumulate = accumulate;
-  hipLaunchKernelGGL(sgemm_kernel, dim3((n + 63) / 64, (m + 63) / 64), dim3(256), 0, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  const int slices = workspace != nullptr ? sgemm_slices(m, n, k) : 1;     // workspace == NULL: one pass over K
+  if (slices <= 1) {
+    hipLaunchKernelGGL(sgemm_kernel, dim3((n + 63) / 64, (m + 63) / 64, 1), dim3(256), 0, st, p, (float*)nullptr, k);
+    VNQA_CHECK_LAUNCH();
+    return VNQA_OK;
+  }
+  const int kps = ((k + slices - 1) / slices + 15) / 16 * 16;
+  const int nsl = (k + kps - 1) / kps;
+  hipLaunchKernelGGL(sgemm_kernel, dim3((n + 63) / 64, (m + 63) / 64, nsl), dim3(256), 0, st, p, (float*)workspace, kps);
+  VNQA_CHECK_LAUNCH();
+  const size_t total = (size_t)m * n;
+  int g = (int)((total + 255) / 256);
+  g = g > 1024 ? 1024 : g;
+  hipLaunchKernelGGL(sgemm_finish_kernel, dim3(g), dim3(256), 0, st, p, (const float*)workspace, nsl);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
@@ -296,23 +368,30 @@ extern "C" int vnqa_gather_rows(const float* src, const int32_t* rows, float* ds
 }
 
 extern "C" int vnqa_embed_proj_fwd(const int64_t* tokens, const int32_t* row_perm, const float* embed, const float* w_ih,
-                                   const float* b_ih, const float* b_hh, float* xg, int32_t b, int32_t lq, int32_t e,
-                                   int32_t g, int32_t vocab, void* stream) {
-  VNQA_CHECK_ARG(tokens && embed && w_ih && b_ih && b_hh && xg && b > 0 && lq > 0 && e > 0 && g > 0 && vocab > 0,
+                                   const float* b_ih, const float* b_hh, float* xg, int32_t* rows, int32_t b, int32_t lq,
+                                   int32_t e, int32_t g, int32_t vocab, void* stream) {
+  VNQA_CHECK_ARG(tokens && embed && w_ih && b_ih && b_hh && xg && rows && b > 0 && lq > 0 && e > 0 && g > 0 && vocab > 0,
                  "embed_proj_fwd: bad arguments");
-  const int threads = g >= 512 ? 512 : (g + 63) / 64 * 64;
-  hipLaunchKernelGGL(embed_proj_fwd_kernel, dim3(lq, b), dim3(threads), e * sizeof(float), (hipStream_t)stream,
-                     (const long long*)tokens, row_perm, embed, w_ih, b_ih, b_hh, xg, lq, e, g, vocab);
+  hipStream_t st = (hipStream_t)stream;
+  const int n_pos = b * lq;
+  hipLaunchKernelGGL(token_rows_kernel, dim3((n_pos + 255) / 256), dim3(256), 0, st, (const long long*)tokens, row_perm, rows, b,
+                     lq, vocab);
+  VNQA_CHECK_LAUNCH();
+  // xg [n_pos][g] = embed[rows] (n_pos x e)  @  w_ih^T (e x g)  + b_ih + b_hh : the embedding lookup IS the GEMM's row gather
+  SgemmArgs p;
+  p.A = embed; p.B = w_ih; p.C = xg; p.bias = b_ih; p.bias2 = b_hh; p.a_mask = nullptr; p.a_rows = rows; p.c_rows = nullptr;
+  p.a_rs = e; p.a_cs = 1; p.b_rs = 1; p.b_cs = e; p.ldc = g; p.M = n_pos; p.N = g; p.K = e; p.relu = 0; p.accumulate = 0;
+  hipLaunchKernelGGL(sgemm_kernel, dim3((g + 63) / 64, (n_pos + 63) / 64, 1), dim3(256), 0, st, p, (float*)nullptr, e);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
 
-extern "C" int vnqa_token_dsum(const int64_t* tokens, const int32_t* row_perm, const float* dxg, float* dsum, int32_t b,
-                               int32_t lq, int32_t g, int32_t vocab, void* stream) {
-  VNQA_CHECK_ARG(tokens && dxg && dsum && b > 0 && lq > 0 && g > 0 && vocab > 0, "token_dsum: bad arguments");
+extern "C" int vnqa_token_dsum(const int32_t* rows, const float* dxg, float* dsum, int32_t n_pos, int32_t g, int32_t vocab,
+                               void* stream) {
+  VNQA_CHECK_ARG(rows && dxg && dsum && n_pos > 0 && g > 0 && vocab > 0 && n_pos <= 12288, "token_dsum: bad arguments");
   const int threads = g >= 512 ? 512 : (g + 63) / 64 * 64;
-  hipLaunchKernelGGL(token_dsum_kernel, dim3(vocab), dim3(threads), 0, (hipStream_t)stream, (const long long*)tokens, row_perm,
-                     dxg, dsum, b, lq, g);
+  hipLaunchKernelGGL(token_dsum_kernel, dim3(vocab), dim3(threads), n_pos * sizeof(int), (hipStream_t)stream, rows, dxg, dsum,
+                     n_pos, g);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -588,10 +588,12 @@ def sgemm(a, b, m, n, k, a_rs, a_cs, b_rs, b_cs, out, bias=None, relu=False, acc
           c_rows=None):
     """out[row_c(i)][j] = act(sum_k a'[i,k] b[k,j] + bias[j]) [+ out]; element strides select NN / NT / TN (vnqa_sgemm)."""
     assert out.dtype == torch.float32 and out.stride(-1) == 1
+    ws_bytes = L.lib().vnqa_sgemm_workspace(m, n, k)
+    ws = workspace(ws_bytes, out.device) if ws_bytes > 0 else None
     L.check(L.lib().vnqa_sgemm(L.vptr(_f32c(a)), L.vptr(_f32c(b)), L.vptr(out), L.ptr(bias),
                                L.vptr(a_mask) if a_mask is not None else None, L.ptr(a_rows), L.ptr(c_rows),
-                               a_rs, a_cs, b_rs, b_cs, out.stride(0), m, n, k, int(relu), int(accumulate), L.stream()),
-            "vnqa_sgemm")
+                               a_rs, a_cs, b_rs, b_cs, out.stride(0), m, n, k, int(relu), int(accumulate), L.ptr(ws),
+                               L.stream()), "vnqa_sgemm")
     return out
 
 
@@ -639,20 +641,21 @@ def gather_rows(src, rows):
 
 
 def embed_proj_fwd(tokens, row_perm, embed, w_ih, b_ih, b_hh):
+    """Returns (xg [B,Lq,4H], rows int32 [B*Lq]: the token of every position, kept for the backward)."""
     B, Lq = tokens.shape
     V, E = embed.shape
     G = w_ih.shape[0]
     xg = torch.empty((B, Lq, G), dtype=torch.float32, device=embed.device)
+    rows = torch.empty((B * Lq,), dtype=torch.int32, device=embed.device)
     L.check(L.lib().vnqa_embed_proj_fwd(L.ptr(tokens), L.ptr(row_perm), L.ptr(embed), L.ptr(w_ih), L.ptr(b_ih), L.ptr(b_hh),
-                                        L.ptr(xg), B, Lq, E, G, V, L.stream()), "vnqa_embed_proj_fwd")
-    return xg
+                                        L.ptr(xg), L.ptr(rows), B, Lq, E, G, V, L.stream()), "vnqa_embed_proj_fwd")
+    return xg, rows
 
 
-def token_dsum(tokens, row_perm, dxg, vocab):
+def token_dsum(rows, dxg, vocab):
     B, Lq, G = dxg.shape
     dsum = torch.empty((vocab, G), dtype=torch.float32, device=dxg.device)
-    L.check(L.lib().vnqa_token_dsum(L.ptr(tokens), L.ptr(row_perm), L.ptr(dxg), L.ptr(dsum), B, Lq, G, vocab, L.stream()),
-            "vnqa_token_dsum")
+    L.check(L.lib().vnqa_token_dsum(L.ptr(rows), L.ptr(dxg), L.ptr(dsum), B * Lq, G, vocab, L.stream()), "vnqa_token_dsum")
     return dsum
 
 

@@ -631,16 +631,16 @@ class EmbedProjFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tokens, embed, w_ih, b_ih, b_hh, padding_idx):
-        xg = K.embed_proj_fwd(tokens.contiguous(), None, embed, w_ih, b_ih, b_hh)
-        ctx.save_for_backward(tokens, embed, w_ih)
+        xg, rows = K.embed_proj_fwd(tokens.contiguous(), None, embed, w_ih, b_ih, b_hh)
+        ctx.save_for_backward(rows, embed, w_ih)
         ctx.padding_idx = padding_idx
         return xg
 
     @staticmethod
     def backward(ctx, dxg):
-        tokens, embed, w_ih = ctx.saved_tensors
+        rows, embed, w_ih = ctx.saved_tensors
         V = embed.shape[0]
-        dsum = K.token_dsum(tokens.contiguous(), None, dxg.contiguous(), V)        # [V, 4H]
+        dsum = K.token_dsum(rows, dxg.contiguous(), V)                              # [V, 4H]
         dembed = K.matmul_nn(dsum, w_ih)                                            # [V, E]
         if ctx.padding_idx is not None:
             dembed[ctx.padding_idx].zero_()
