@@ -158,18 +158,29 @@ __global__ void sgemm_finish_kernel(const SgemmArgs p, const float* __restrict__
   }
 }
 
-// out[n] = sum_m x[m*ld + n] * [mask > 0]   (one thread per column, 256 columns per block; rows in a fixed order)
+// out[n] = sum_m x[m*ld + n] * [mask > 0]: block = 64 columns x 16 row lanes (row lane r sums rows r, r+16, ...), the 16
+// partial sums folded through LDS in a fixed order
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out, int rows,
-                              int cols, int ld) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= cols) return;
+__global__ void __launch_bounds__(1024) colsum_kernel(const T* __restrict__ x, const float* __restrict__ mask,
+                                                      float* __restrict__ out, int rows, int cols, int ld) {
+  __shared__ float s_part[16][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
   float s = 0.f;
-  for (int m = 0; m < rows; ++m) {
-    const float v = ElemOps<T>::load(x[(size_t)m * ld + n]);
-    s += (mask == nullptr || mask[(size_t)m * ld + n] > 0.f) ? v : 0.f;
+  if (n < cols) {
+    for (int m = ry; m < rows; m += 16) {
+      const float v = ElemOps<T>::load(x[(size_t)m * ld + n]);
+      s += (mask == nullptr || mask[(size_t)m * ld + n] > 0.f) ? v : 0.f;
+    }
   }
-  out[n] = s;
+  s_part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && n < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += s_part[r][cx];
+    out[n] = t;
+  }
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, float* __restrict__ dst,
@@ -196,11 +207,17 @@ __global__ void token_dsum_kernel(const int* __restrict__ rows, const float* __r
   extern __shared__ int s_hit[];              // positions holding token v, in order
   __shared__ int s_n;
   const int v = blockIdx.x;
-  if (threadIdx.x == 0) {                     // serial compaction keeps the summation order fixed (n_pos is a few hundred)
+  if (threadIdx.x < 64) {                     // wave 0: ordered compaction, 64 positions per ballot (summation order fixed)
+    const int lane = threadIdx.x;
     int n = 0;
-    for (int i = 0; i < n_pos; ++i)
-      if (rows[i] == v) s_hit[n++] = i;
-    s_n = n;
+    for (int i0 = 0; i0 < n_pos; i0 += 64) {
+      const int i = i0 + lane;
+      const bool hit = i < n_pos && rows[i] == v;
+      const unsigned long long m = __ballot(hit);
+      if (hit) s_hit[n + __popcll(m & ((1ull << lane) - 1ull))] = i;
+      n += __popcll(m);
+    }
+    if (lane == 0) s_n = n;
   }
   __syncthreads();
   const int n = s_n;
@@ -350,10 +367,10 @@ extern "C" int vnqa_colsum(const void* x, const float* mask, float* out, int32_t
   VNQA_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad arguments");
   VNQA_CHECK_ARG(dtype == VNQA_F32 || (dtype == VNQA_BF16 && mask == nullptr), "colsum: dtype must be f32, or bf16 without a mask");
   if (dtype == VNQA_BF16)
-    hipLaunchKernelGGL(colsum_kernel<vnqa_bf16>, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const vnqa_bf16*)x,
+    hipLaunchKernelGGL(colsum_kernel<vnqa_bf16>, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const vnqa_bf16*)x,
                        mask, out, rows, cols, ld);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)x, mask, out,
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const float*)x, mask, out,
                        rows, cols, ld);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;

@@ -258,9 +258,10 @@ def pack_fc_weight(w, C, h, wd, c_pad, rows_pad, dtype, want_t=True):
     return nat, nat_t
 
 
-def unpack_fc_wgrad(dw_nat, rows, C, h, wd, c_pad):
+def unpack_fc_wgrad(dw_nat, rows, C, h, wd, c_pad, out=None):
     """fp32 gradient of the native-layout weight [rows_pad, (h+2)(wd+2)*c_pad] -> [rows, C*h*wd]."""
-    dw = torch.empty((rows, C * h * wd), dtype=torch.float32, device=dw_nat.device)
+    dw = out if out is not None else torch.empty((rows, C * h * wd), dtype=torch.float32, device=dw_nat.device)
+    assert dw.shape == (rows, C * h * wd) and dw.is_contiguous() and dw.dtype == torch.float32
     L.check(L.lib().vnqa_unpack_fc_wgrad(L.ptr(dw_nat), rows, C, h, wd, c_pad, L.ptr(dw), L.stream()),
             "vnqa_unpack_fc_wgrad")
     return dw
@@ -322,7 +323,7 @@ def workspace(nbytes, device):
     return buf
 
 
-def conv2d_wgrad(x, dy, taps, want_bias=True):
+def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None):
     """x, dy: padded NHWC (halo 1, same N/H/W). Returns (dwt fp32 [Cout][taps][Cin], dbias fp32 [Cout])."""
     N, Hp, Wp, Cin = x.shape
     Cout = dy.shape[-1]
@@ -330,17 +331,22 @@ def conv2d_wgrad(x, dy, taps, want_bias=True):
     h, w = Hp - 2, Wp - 2
     ws = workspace(L.lib().vnqa_conv2d_wgrad_workspace(N, h, w, Cin, Cout, taps), x.device)
     dwt = torch.empty((Cout, taps, Cin), dtype=torch.float32, device=x.device)
-    dbias = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    dbias = None
+    if want_bias:
+        dbias = dbias_out if (dbias_out is not None and dbias_out.numel() == Cout) else \
+            torch.empty((Cout,), dtype=torch.float32, device=x.device)
     L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwt), L.ptr(dbias), L.ptr(ws), N, h, w, Cin, Cout,
                                       taps, L.dtype_id(x.dtype), L.stream()), "vnqa_conv2d_wgrad")
     return dwt, dbias
 
 
-def unpack_conv_wgrad(dwt, c_out, c_in):
+def unpack_conv_wgrad(dwt, c_out, c_in, out=None):
     """fp32 [c_out_pad][taps][c_in_pad] -> OIHW fp32 [c_out][c_in][k][k]."""
     c_out_pad, taps, c_in_pad = dwt.shape
     shape = {1: (1, 1), 9: (3, 3), 27: (3, 3, 3)}[taps]
-    out = torch.empty((c_out, c_in) + shape, dtype=torch.float32, device=dwt.device)
+    if out is None:
+        out = torch.empty((c_out, c_in) + shape, dtype=torch.float32, device=dwt.device)
+    assert out.shape == (c_out, c_in) + shape and out.is_contiguous() and out.dtype == torch.float32
     L.check(L.lib().vnqa_unpack_conv_wgrad(L.ptr(dwt), c_out, c_in, taps, c_out_pad, c_in_pad, L.ptr(out),
                                            L.stream()), "vnqa_unpack_conv_wgrad")
     return out
@@ -362,14 +368,16 @@ def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
     return out
 
 
-def gemm_tn(a, b):
+def gemm_tn(a, b, out=None):
     """out[m][n] = sum_k a[k][m] b[k][n]; a [K,M], b [K,N] (same dtype) -> fp32 [M,N]."""
     Kd, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == Kd and a.dtype == b.dtype
     did = L.dtype_id(a.dtype)
     ws = workspace(L.lib().vnqa_gemm_tn_workspace(M, N, Kd, did), a.device)
-    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    assert out.shape == (M, N) and out.is_contiguous() and out.dtype == torch.float32
     L.check(L.lib().vnqa_gemm_tn(L.ptr(a), L.ptr(b), L.ptr(out), L.ptr(ws), M, N, Kd, did, L.stream()),
             "vnqa_gemm_tn")
     return out
@@ -623,10 +631,12 @@ def matmul_tn(a, b, a_mask=None, out=None, accumulate=False):
     return sgemm(a, b, m, n, k, 1, a.stride(0), b.stride(0), 1, out, a_mask=a_mask, accumulate=accumulate)
 
 
-def colsum(x, mask=None):
+def colsum(x, mask=None, out=None):
     """sum over the rows of a 2-D tensor (fp32, optionally only where mask > 0; or bf16 without a mask) -> fp32 [cols]."""
     rows, cols = x.shape
-    out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    assert out.numel() == cols and out.is_contiguous() and out.dtype == torch.float32
     L.check(L.lib().vnqa_colsum(L.vptr(x), L.vptr(mask) if mask is not None else None, L.ptr(out), rows, cols,
                                 x.stride(0), L.dtype_id(x.dtype), L.stream()), "vnqa_colsum")
     return out

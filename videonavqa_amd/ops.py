@@ -10,6 +10,42 @@ from . import _lib as L
 from . import kernels as K
 
 
+class GradSink(object):
+    """Where a parameter's gradient lives when the training driver owns it (train.FlatParams: a slice of the flat gradient
+    buffer, zeroed by the fused clip+Adam kernel).  A parameter carrying `_vnqa_grad_sink` has exactly ONE gradient producer
+    per backward pass, so the producing kernel writes straight into the slice and the autograd node returns None for it:
+    no temporary gradient tensor and no AccumulateGrad add kernel (for fc_embed_attn.weight that add alone moved 150 MB).
+    `on_ready` (optional) is the data-parallel reducer's hook for parameters whose all-reduce starts early."""
+
+    def __init__(self, view):
+        self.view, self.on_ready = view, None
+
+    def done(self):
+        if self.on_ready is not None:
+            self.on_ready()
+
+
+def sink_of(param):
+    """The parameter's GradSink, or None (plain autograd accumulation)."""
+    s = getattr(param, "_vnqa_grad_sink", None)
+    return s if (s is not None and param.requires_grad and torch.is_grad_enabled()) else None
+
+
+def _into(sink, shape=None):
+    """Output buffer for a gradient kernel: the sink's view (optionally reshaped) or None = allocate."""
+    if sink is None:
+        return None
+    return sink.view if shape is None else sink.view.view(shape)
+
+
+def _ret(sink, value):
+    """What the autograd node returns for a parameter: None when the kernel already wrote into the sink."""
+    if sink is None:
+        return value
+    sink.done()
+    return None
+
+
 class ConvFn(torch.autograd.Function):
     """y = [relu](conv2d(x, weight) + bias), 3x3 pad 1 or 1x1; weight/bias are the reference-layout
     fp32 parameters (OIHW).  Backward: dgrad = the same igemm on flipped weights, wgrad = MFMA
@@ -168,6 +204,10 @@ class FilmTrunkFn(torch.autograd.Function):
                                            K.pad_vec(b3, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res)
             saved += [res, z]
         ctx.meta = meta
+        # gradient sinks (FlatParams): conv_init w/b, bn w/b, then (w3, b3) per block
+        with torch.enable_grad():
+            ctx.sinks = [sink_of(t) for t in (conv_w, conv_b, bn_w, bn_b)] + \
+                        [sink_of(tensors[meta.n_film + 4 * k + i]) for k in range(blocks) for i in (2, 3)]
         ctx.save_for_backward(*saved, conv_w, *tensors)
         ctx.mark_non_differentiable(mean, var)
         return h, mean, var
@@ -195,21 +235,27 @@ class FilmTrunkFn(torch.autograd.Function):
             dfilm = dfilms[fi] if dfilms[fi] is not None else torch.empty_like(film)
             dz = K.film_relu_res_bwd_ld(dout, z, film[:, col:col + C], film[:, col + C:col + 2 * C], C,
                                         dfilm[:, col:col + C], dfilm[:, col + C:col + 2 * C])
-            dwt, dbias = K.conv2d_wgrad(res, dz, 9)
-            grads_blocks[4 * k + 2] = K.unpack_conv_wgrad(dwt, C, C)
-            grads_blocks[4 * k + 3] = dbias[:C]
+            sw, sb = ctx.sinks[4 + 2 * k], ctx.sinks[5 + 2 * k]
+            dwt, dbias = K.conv2d_wgrad(res, dz, 9, dbias_out=_into(sb))
+            grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw)))
+            direct_b = sb is not None and dbias.data_ptr() == sb.view.data_ptr()      # (only without channel padding)
+            grads_blocks[4 * k + 3] = _ret(sb if direct_b else None, dbias[:C])
             dres = K.conv2d_igemm(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
             gsum = K.relu_bwd(dres, res, dout)             # (dres + dout) * [res > 0]: residual join + the 1x1 conv's ReLU
             # (the 1x1 convs are frozen upstream — never in parameters() — so they get no weight gradient)
             dout = K.conv2d_igemm(gsum, K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
         dr, s1, s2 = K.frame_bn_bwd(dout, r, lay.frame_of_i32, lay.frame_off_i32, mean, rstd, g, lay.n_frames, True)
-        dbn_w, dbn_b = K.colsum(s2)[:C], K.colsum(s1)[:C]
-        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9)
-        dconv_w = K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1])
+        s_cw, s_cb, s_bw, s_bb = ctx.sinks[:4]
+        exact = c_pad == C
+        dbn_w = _ret(s_bw if exact else None, K.colsum(s2, out=_into(s_bw) if exact else None)[:C])
+        dbn_b = _ret(s_bb if exact else None, K.colsum(s1, out=_into(s_bb) if exact else None)[:C])
+        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None)
+        dconv_w = _ret(s_cw, K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw)))
+        dconv_b = _ret(s_cb if exact else None, dbias0[:C])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_igemm(dr, K.pack_conv_weight(conv_w, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=x.shape[-1]))
-        return (dx, dconv_w, dbias0[:C], dbn_w, dbn_b, None) + tuple(dfilms) + tuple(grads_blocks)
+        return (dx, dconv_w, dconv_b, dbn_w, dbn_b, None) + tuple(dfilms) + tuple(grads_blocks)
 
 
 class TrunkMeta(object):
@@ -251,6 +297,8 @@ class LstmSeqFn(torch.autograd.Function):
         hs, gates, hN, cN = K.lstm_seq_fwd(xg, w, q_lens_i32, h0, c0, n_rep, S)
         ctx.save_for_backward(w, h0, c0, hs, gates, q_lens_i32)
         ctx.n_rep, ctx.Lq = n_rep, xg.shape[1]
+        with torch.enable_grad():
+            ctx.sink_w = sink_of(w_hh)
         return hs, hN, cN
 
     @staticmethod
@@ -266,7 +314,7 @@ class LstmSeqFn(torch.autograd.Function):
         # the GEMM's element type by one kernel.  Exact-f32 MFMA in the fp32 (parity) mode; bf16 operands / fp32 accumulation
         # in the bf16 mode (the f32 matrix path runs at 1/16 of the bf16 rate and this GEMM sits on the trunk's dependent chain)
         a, hprev = K.lstm_wgrad_operands(dgates, hs, h0, ctx.wgrad_dtype)
-        dw = K.gemm_tn(a, hprev)
+        dw = _ret(ctx.sink_w, K.gemm_tn(a, hprev, out=_into(ctx.sink_w)))
         # dxg[b][pos] = sum over repeats of dgates at cells t with t % q_len == pos
         dxg = K.lstm_fold_dxg(dgates, q_lens_i32, Lq, n_rep)
         return dxg, dw, dh0, dc0, None, None, None, None
@@ -459,6 +507,8 @@ class FcNativeFn(torch.autograd.Function):
         out = K.gemm_nt(x.contiguous(), nat, bias=bias_p)
         ctx.save_for_backward(x, nat_t)
         ctx.geom = (rows, C, h, w, c_pad)
+        with torch.enable_grad():
+            ctx.sink_w = sink_of(weight)
         return out
 
     @staticmethod
@@ -467,7 +517,9 @@ class FcNativeFn(torch.autograd.Function):
         rows, C, h, w, c_pad = ctx.geom
         dout = dout.to(x.dtype).contiguous()
         dx = K.gemm_nt(dout, nat_t) if ctx.needs_input_grad[0] else None
-        dw = K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = _ret(ctx.sink_w, K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad, out=_into(ctx.sink_w)))
         db = K.colsum(dout)[:rows] if ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None, None, None
 
@@ -599,6 +651,8 @@ class LinearFn(torch.autograd.Function):
         y = K.linear_nt(xs, w, bias=b, relu=relu)
         ctx.save_for_backward(xs, w, y if relu else None, rows)
         ctx.relu, ctx.x_rows = relu, x.shape[0]
+        with torch.enable_grad():
+            ctx.sinks = (sink_of(w), sink_of(b) if b is not None else None)
         return y
 
     @staticmethod
@@ -613,10 +667,11 @@ class LinearFn(torch.autograd.Function):
                 K.matmul_nn(dy, w, a_mask=mask, out=dx, c_rows=rows)
             else:
                 dx = K.matmul_nn(dy, w, a_mask=mask)
+        sw, sb = ctx.sinks
         if ctx.needs_input_grad[1]:
-            dw = K.matmul_tn(dy, xs, a_mask=mask)
+            dw = _ret(sw, K.matmul_tn(dy, xs, a_mask=mask, out=_into(sw)))
         if ctx.needs_input_grad[2]:
-            db = K.colsum(dy, mask)
+            db = _ret(sb, K.colsum(dy, mask, out=_into(sb)))
         return dx, dw, db, None, None
 
 

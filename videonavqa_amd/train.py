@@ -45,6 +45,10 @@ class FlatParams(object):
             self.flat[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + k].view_as(p)
             p.grad = self.grad[off:off + k].view_as(p)
+            # the HIP ops' backward writes this parameter's gradient straight into its slice (ops.GradSink): valid because
+            # the buffer is zeroed by the fused clip+Adam kernel every step and each parameter has one gradient producer
+            if os.environ.get("VNQA_DIRECT_GRADS", "1") != "0":
+                p._vnqa_grad_sink = ops.GradSink(p.grad)
             off += k
         self.partial = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.step_count = 0
@@ -80,6 +84,9 @@ class OverlappedGradReducer(object):
             if self.enabled and k >= early_numel:
                 self.early[p] = (off, off + k)
                 p.register_post_accumulate_grad_hook(self._hook)
+                sink = getattr(p, "_vnqa_grad_sink", None)
+                if sink is not None:      # gradient written in place by its kernel: no AccumulateGrad node fires the hook
+                    sink.on_ready = (lambda q=p: self._hook(q))
             off += k
 
     def _hook(self, p):
