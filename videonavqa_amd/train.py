@@ -75,7 +75,7 @@ class OverlappedGradReducer(object):
 
     def __init__(self, fp, world_size, loss_reduction="sum", early_numel=1 << 22, active=None):
         self.fp, self.world, self.loss_reduction = fp, world_size, loss_reduction
-        self.early, self.pending, self.done_ranges = {}, [], []
+        self.early, self.pending, self.done_ranges, self._fired = {}, [], [], set()
         # active=True with world_size 1 runs the collectives on a one-rank group (RCCL code-path test on a 1-GPU box)
         self.enabled = world_size > 1 if active is None else bool(active)
         off = 0
@@ -90,8 +90,12 @@ class OverlappedGradReducer(object):
             off += k
 
     def _hook(self, p):
-        if not self.enabled:
+        # Fires once per parameter and step whichever way the gradient arrived: from autograd's AccumulateGrad node (which
+        # runs its post-accumulate hooks even when the producing node returned None because it wrote the gradient in place)
+        # or from the producing kernel's GradSink.
+        if not self.enabled or p in self._fired:
             return
+        self._fired.add(p)
         a, b = self.early[p]
         self.pending.append(dist.all_reduce(self.fp.grad[a:b], op=dist.ReduceOp.SUM, async_op=True))
         self.done_ranges.append((a, b))
@@ -99,6 +103,7 @@ class OverlappedGradReducer(object):
     def finish(self):
         """Call after backward: reduce what the hooks did not cover, wait for everything."""
         if not self.enabled:
+            self._fired.clear()
             return
         cur = 0
         for a, b in sorted(self.done_ranges) + [(self.fp.n, self.fp.n)]:
@@ -108,6 +113,7 @@ class OverlappedGradReducer(object):
         for w in self.pending:
             w.wait()
         self.pending, self.done_ranges = [], []
+        self._fired.clear()
         if self.loss_reduction != "sum":
             self.fp.grad.div_(self.world)
 
