@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--bench")
     ap.add_argument("--bench-nooverlap")
     ap.add_argument("--profiled")
-    ap.add_argument("--command", default="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline")
+    ap.add_argument("--command", default="python3 bench.py --steps 20 --warmup 5 --repeats 1 --no-parity --no-cpu-baseline")
     a = ap.parse_args()
     db = sorted(glob.glob(os.path.join(a.trace_dir, "**", "*_results.db"), recursive=True))[-1]
     c = sqlite3.connect(db)
@@ -49,7 +49,7 @@ def main():
     md = ["# Round %d — rocprofv3 --kernel-trace --stats of `%s`" % (a.round, a.command), "",
           "MI355X (gfx950), 1 GPU, bf16, B=8 clips x 35 frames x 224x224, side-stream stem pipeline on.",
           "%d steps profiled.  Raw CSV: `profiles/%s_kernel_stats.csv`; PMC HBM traffic of the dominant kernel: "
-          "`profiles/r01_pmc_traffic.json`." % (a.steps, tag), ""]
+          "`profiles/%s_pmc_traffic.json`." % (a.steps, tag, tag), ""]
 
     def line(label, path):
         d = load(path)
@@ -71,7 +71,7 @@ def main():
            "number `roofline.avg_launch_ms` must agree with (kernel durations are inflated when the trunk co-runs; the stem-alone",
            "passes bench.py runs after the timed region for `stem_alone_ms` are in this trace too).", "",
            "| kernel | calls/step | ms/step | avg µs | % GPU time |", "|---|---|---|---|---|"]
-    for n, cnt, tot, mn, mx in rows[:28]:
+    for n, cnt, tot, mn, mx in rows[:40]:
         md.append("| `%s` | %.1f | %.3f | %.1f | %.1f |" % (n[:110], cnt / a.steps, tot / a.steps / 1e6, tot / cnt / 1e3,
                                                           100.0 * tot / total))
     md.append("")
@@ -80,6 +80,19 @@ def main():
               "everything else; they do not run inside a training step.")
     md.append("Sum over all kernels: %.3f ms/step of GPU time (two streams overlap, so this exceeds the wall time per step)."
               % (total / a.steps / 1e6))
+    # framework kernels left in the step (everything that is not this library's): ATen elementwise / index / reduce kernels,
+    # rocBLAS (Cijk_*) GEMMs, runtime copies
+    fw = [(n, cnt, tot) for n, cnt, tot, mn, mx in rows if n.startswith("void at::") or n.startswith("Cijk_") or "rocclr" in n
+          or n.startswith("at::") or "at::native" in n]
+    md += ["", "## Framework (ATen / rocBLAS / runtime) kernels still launched", "",
+           "| kernel | calls/step | us/step | % GPU time |", "|---|---|---|---|"]
+    for n, cnt, tot in fw:
+        md.append("| `%s` | %.2f | %.1f | %.3f |" % (n[:100], cnt / a.steps, tot / a.steps / 1e3, 100.0 * tot / total))
+    md.append("")
+    md.append("Total framework kernels: %.1f launches/step, %.1f us/step = %.2f %% of the summed GPU kernel time (the fp64 "
+              "`Cijk_*` / `im2col` rows are the one-time stem composition at construction, see above)."
+              % (sum(c for _, c, _ in fw) / a.steps, sum(t for _, _, t in fw) / a.steps / 1e3,
+                 100.0 * sum(t for _, _, t in fw) / total))
     with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.md"), "w") as f:
         f.write("\n".join(md) + "\n")
     print("wrote", out_csv)

@@ -225,7 +225,12 @@ class FilmTrunkFn(torch.autograd.Function):
         cdt = x.dtype
         c_pad = L.round_up(C, 64)
         dout = dout.contiguous()
-        dfilms = [torch.zeros_like(f) if ctx.needs_input_grad[6 + i] else None for i, f in enumerate(films)]
+        # a FiLM matrix whose every column is some block's gamma or beta needs no zero fill (attention / pooling models:
+        # ONE matrix [n_img, 2*C*blocks]); multi-hop's per-block matrices are only partly written
+        covered = nf == 1 and films[0].shape[1] == 2 * C * blocks and \
+            sorted(c for _, c in meta.film_map) == [2 * C * k for k in range(blocks)]
+        dfilms = [(torch.empty_like(f) if covered else torch.zeros_like(f)) if ctx.needs_input_grad[6 + i] else None
+                  for i, f in enumerate(films)]
         grads_blocks = [None] * (4 * blocks)
         for k in reversed(range(blocks)):
             w1, b1, w3, b3 = tensors[nf + 4 * k: nf + 4 * k + 4]
@@ -290,6 +295,7 @@ class LstmSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xg, w_hh, h0, c0, q_lens_i32, n_rep, S, wgrad_dtype=torch.float32):
         ctx.wgrad_dtype = wgrad_dtype
+        ctx.set_materialize_grads(False)      # unused outputs (hN, cN) arrive as None instead of freshly filled zero tensors
         xg = xg.float().contiguous()
         w = w_hh.float().contiguous()
         h0 = h0.float().contiguous()
