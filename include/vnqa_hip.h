@@ -371,7 +371,8 @@ int vnqa_temporal_attn_packed_bwd(const void* f, int32_t ld, int32_t dtype, cons
 int64_t vnqa_sgemm_workspace(int32_t m, int32_t n, int32_t k);   /* bytes of split-K scratch (0: none needed) */
 int vnqa_sgemm(const float* a, const float* b, float* c, const float* bias, const float* a_mask, const int32_t* a_rows,
                const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int32_t ldc, int32_t m,
-               int32_t n, int32_t k, int32_t relu, int32_t accumulate, void* workspace, void* stream);
+               int32_t n, int32_t k, int32_t relu, int32_t accumulate, const float* addend, void* workspace, void* stream);
+               /* addend: optional fp32 matrix [m][ldc] added to the product (torch.addmm's first argument) */
                /* workspace: vnqa_sgemm_workspace bytes (skinny outputs over a long K are split over workgroups and summed in
                 * slice order by a second launch); NULL = one pass over K */
 int vnqa_colsum(const void* x, const float* mask, float* out, int32_t rows, int32_t cols, int32_t ld, int32_t dtype,
@@ -460,6 +461,37 @@ int vnqa_mac_read_bwd(const void* know, const void* pre, const float* p, const f
 int vnqa_mac_read_accum(const float* dscore, const float* p, const float* u, const float* v,
                         const float* dread, void* dknow, void* dpre, int32_t k, int32_t n, int32_t s,
                         int32_t c, int32_t ld, int32_t dtype, void* stream);
+
+/* One MAC reasoning step for all packed images (ControlUnit, ReadUnit, WriteUnit.concat of the reference's
+ * models/mac.py:28-42,53-62,82-85) as ONE call per direction: the ~11 forward / ~25 backward launches (fp32 GEMMs on
+ * vnqa_sgemm, the attention pools above, elementwise products) are enqueued from C++ instead of one by one from Python —
+ * `--model mac` was bound by the launch thread, not by the GPU.
+ *   forward : cq = control Wc^T + pq;  control' = pool(ctxw; cq * w_ca, b_ca) [* mask_c];  mem = memory Wm^T + bm;
+ *             v = control' * w_ra;  t = v W1;  u = mem * t;  read = pool(know, pre; u, v, b_ra);
+ *             concat = read Wr^T + memory Wmm^T + bw        (every intermediate is an output: the backward reads them)
+ *   backward: from d_concat and (optional) d_cnew: d_control, d_memory, d_cq, the per-step attention factors
+ *             (ds_r, d_read, ds_c, d_c — the caller stacks them over steps for vnqa_mac_read_accum) and the parameter
+ *             gradients ACCUMULATED (+=) into g_*: g_wca / g_wra are per-image [n][d] partial sums of the two attention
+ *             weight vectors' gradients (the caller sums them over images once), g_bm / g_bw vectors, the rest [d][d].
+ * All matrices fp32 row-major [n][d] unless noted; know / pre [n*s][ld] in `dtype`; ctxw fp32 [n*lq][d]; ones fp32 [n] = 1.
+ */
+typedef struct vnqa_mac_core {
+  int32_t n, d, lq, s, ld, dtype;
+  const float *control, *memory, *pq, *ctxw;
+  const void *know, *pre;
+  const float* mask_c;                                             /* [n][d] or NULL */
+  const float *wc, *w_ca, *b_ca, *wm, *bm, *w1, *w_ra, *b_ra, *wr, *wmm, *bw;
+  float *cq, *qv, *p_c, *cnew, *mem, *v, *t, *u, *p_r, *read, *concat;   /* forward outputs (p_c [n][lq], p_r [n][s]) */
+  const float *d_cnew, *d_concat;                                  /* backward inputs (d_cnew may be NULL) */
+  float *d_control, *d_memory, *d_cq;                              /* backward outputs */
+  float *ds_r, *d_read, *ds_c, *d_c, *du, *dv, *dqv, *d_mem, *d_t; /* backward factors / scratch (ds_r [n][s], ds_c [n][lq]) */
+  float *g_wc, *g_wca, *g_wm, *g_bm, *g_w1, *g_wra, *g_wr, *g_wmm, *g_bw;
+  const float* ones;
+  void* workspace;                                                 /* vnqa_mac_core_workspace(n, d) bytes, or NULL */
+} vnqa_mac_core;
+int64_t vnqa_mac_core_workspace(int32_t n, int32_t d);
+int vnqa_mac_core_fwd(const vnqa_mac_core* a, void* stream);
+int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream);
 
 /* Fused global-norm clip + Adam + zero_grad over flat fp32 buffers.
  * Replaces clip_grad_norm(model.parameters(), clip); optimizer.step(); optimizer.zero_grad()

@@ -32,6 +32,15 @@ class ConvEpilogue(ctypes.Structure):
 
 EPI_NONE, EPI_BNSTATS, EPI_FILM_RES = 0, 1, 2
 
+_MAC_PTRS = ("control memory pq ctxw know pre mask_c wc w_ca b_ca wm bm w1 w_ra b_ra wr wmm bw "
+             "cq qv p_c cnew mem v t u p_r read concat d_cnew d_concat d_control d_memory d_cq "
+             "ds_r d_read ds_c d_c du dv dqv d_mem d_t g_wc g_wca g_wm g_bm g_w1 g_wra g_wr g_wmm g_bw ones workspace").split()
+
+
+class MacCore(ctypes.Structure):
+    """include/vnqa_hip.h: vnqa_mac_core"""
+    _fields_ = [(n, _i32) for n in ("n", "d", "lq", "s", "ld", "dtype")] + [(n, _vp) for n in _MAC_PTRS]
+
 _SIGNATURES = {
     "vnqa_version": (ctypes.c_int, []),
     "vnqa_last_error": (ctypes.c_char_p, []),
@@ -60,7 +69,10 @@ _SIGNATURES = {
     "vnqa_temporal_attn_packed_fwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vnqa_temporal_attn_packed_bwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "vnqa_sgemm_workspace": (_i64, [_i32, _i32, _i32]),
-    "vnqa_sgemm": (ctypes.c_int, [_vp] * 7 + [_i64] * 4 + [_i32] * 6 + [_vp, _vp]),
+    "vnqa_sgemm": (ctypes.c_int, [_vp] * 7 + [_i64] * 4 + [_i32] * 6 + [_vp, _vp, _vp]),
+    "vnqa_mac_core_workspace": (_i64, [_i32, _i32]),
+    "vnqa_mac_core_fwd": (ctypes.c_int, [_vp, _vp]),
+    "vnqa_mac_core_bwd": (ctypes.c_int, [_vp, _vp]),
     "vnqa_colsum": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_gather_rows": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "vnqa_embed_proj_fwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [_vp]),

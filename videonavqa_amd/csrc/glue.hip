@@ -24,6 +24,7 @@ struct SgemmArgs {
   float* C;
   const float* bias;     // [N] or null
   const float* bias2;    // second bias vector added like `bias` (b_ih + b_hh of an LSTM input projection); or null
+  const float* addend;   // matrix added to the product (same rows / ldc as C, read at the LOGICAL row m); or null
   const float* a_mask;   // same indexing as A: A'(m,k) = A(m,k) * [a_mask(m,k) > 0]; or null
   const int* a_rows;     // [M]: physical row of A for logical row m (negative: a zero row); or null
   const int* c_rows;     // [M]: physical row of C for logical row m (negative: not written); or null
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __
       float v = acc[i][j];
       if (p.bias != nullptr) v += p.bias[n];
       if (p.bias2 != nullptr) v += p.bias2[n];
+      if (p.addend != nullptr) v += p.addend[(long long)m * p.ldc + n];
       float* dst = p.C + (long long)row * p.ldc + n;
       if (p.accumulate) v += *dst;
       if (p.relu) v = fmaxf(v, 0.f);
@@ -151,6 +153,7 @@ __global__ void sgemm_finish_kernel(const SgemmArgs p, const float* __restrict__
     for (int z = 0; z < slices; ++z) v += partial[(size_t)z * total + i];
     if (p.bias != nullptr) v += p.bias[n];
     if (p.bias2 != nullptr) v += p.bias2[n];
+    if (p.addend != nullptr) v += p.addend[(long long)m * p.ldc + n];
     float* dst = p.C + (long long)row * p.ldc + n;
     if (p.accumulate) v += *dst;
     if (p.relu) v = fmaxf(v, 0.f);
@@ -337,10 +340,10 @@ extern "C" int64_t vnqa_sgemm_workspace(int32_t m, int32_t n, int32_t k) {
 extern "C" int vnqa_sgemm(const float* a, const float* b, float* c, const float* bias, const float* a_mask,
                           const int32_t* a_rows, const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs,
                           int64_t b_cs, int32_t ldc, int32_t m, int32_t n, int32_t k, int32_t relu, int32_t accumulate,
-                          void* workspace, void* stream) {
+                          const float* addend, void* workspace, void* stream) {
   VNQA_CHECK_ARG(a && b && c && m > 0 && n > 0 && k > 0 && ldc >= n, "sgemm: bad arguments (m=%d n=%d k=%d ldc=%d)", m, n, k, ldc);
   SgemmArgs p;
-  p.A = a; p.B = b; p.C = c; p.bias = bias; p.bias2 = nullptr; p.a_mask = a_mask; p.a_rows = a_rows; p.c_rows = c_rows;
+  p.A = a; p.B = b; p.C = c; p.bias = bias; p.bias2 = nullptr; p.addend = addend; p.a_mask = a_mask; p.a_rows = a_rows; p.c_rows = c_rows;
   p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc; p.M = m; p.N = n; p.K = k;
   p.relu = relu; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
@@ -396,7 +399,7 @@ extern "C" int vnqa_embed_proj_fwd(const int64_t* tokens, const int32_t* row_per
   VNQA_CHECK_LAUNCH();
   // xg [n_pos][g] = embed[rows] (n_pos x e)  @  w_ih^T (e x g)  + b_ih + b_hh : the embedding lookup IS the GEMM's row gather
   SgemmArgs p;
-  p.A = embed; p.B = w_ih; p.C = xg; p.bias = b_ih; p.bias2 = b_hh; p.a_mask = nullptr; p.a_rows = rows; p.c_rows = nullptr;
+  p.A = embed; p.B = w_ih; p.C = xg; p.bias = b_ih; p.bias2 = b_hh; p.addend = nullptr; p.a_mask = nullptr; p.a_rows = rows; p.c_rows = nullptr;
   p.a_rs = e; p.a_cs = 1; p.b_rs = 1; p.b_cs = e; p.ldc = g; p.M = n_pos; p.N = g; p.K = e; p.relu = 0; p.accumulate = 0;
   hipLaunchKernelGGL(sgemm_kernel, dim3((g + 63) / 64, (n_pos + 63) / 64, 1), dim3(256), 0, st, p, (float*)nullptr, e);
   VNQA_CHECK_LAUNCH();

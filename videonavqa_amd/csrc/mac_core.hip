@@ -1,0 +1,124 @@
+// mac_core.hip — one MAC reasoning step (ControlUnit, ReadUnit, WriteUnit.concat of the reference's models/mac.py:28-42,
+// 53-62,82-85, evaluated for all packed images at once) as ONE C-ABI call per direction.
+//
+// The step is ~11 small launches forward and ~25 backward (fp32 GEMMs of [n_img, dim] x [dim, dim], the fused attention-pool
+// kernels of mac_read.hip, a few elementwise products).  Issued one by one from Python the 12 steps of a training pass cost the
+// launch thread more time than the GPU needs to run them (16.7 ms of host time against 13.8 ms of kernels per step of
+// `bench.py --model mac`); here the whole sequence is enqueued from C++.
+//
+//   cq      = control Wc^T + pq                       (pq = position_aware_i(question) Wp^T + b, hoisted by the caller)
+//   control'= pool(ctx, cq * w_ca, b_ca) [* mask]     (attention over the question words)
+//   mem     = memory Wm^T + bm ;  v = control' * w_ra ;  u = mem * (v W1)
+//   read    = pool(know, pre; u, v, b_ra)             (re-associated ReadUnit, see models/mac.py of this repo)
+//   concat  = read Wr^T + memory Wmm^T + bw
+#include "vnqa_common.h"
+
+namespace {
+
+// out[i] = (acc ? out[i] : 0) + x[i] * y[cols ? i % cols : i] (+ z[i])
+__global__ void ew_mul_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y,
+                              const float* __restrict__ z, int n, int cols, int acc) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float v = x[i] * y[cols > 0 ? i % cols : i];
+    if (z != nullptr) v += z[i];
+    if (acc) v += out[i];
+    out[i] = v;
+  }
+}
+
+int ew_mul(float* out, const float* x, const float* y, const float* z, int n, int cols, int acc, hipStream_t st) {
+  int g = (n + 255) / 256;
+  g = g > 1024 ? 1024 : g;
+  hipLaunchKernelGGL(ew_mul_kernel, dim3(g), dim3(256), 0, st, out, x, y, z, n, cols, acc);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+#define MC_TRY(call)             \
+  do {                           \
+    const int rc__ = (call);     \
+    if (rc__ != VNQA_OK) return rc__; \
+  } while (0)
+
+// C[m,n] = A[m,k] B^T (B [n,k])  + bias / addend
+// (ws: split-K scratch of vnqa_mac_core_workspace bytes — the [n_img, dim] x [dim, dim] products are 40 output tiles)
+int gemm_nt(const float* a, const float* b, float* c, const float* bias, const float* addend, int m, int n, int k, int acc,
+            void* ws, void* st) {
+  return vnqa_sgemm(a, b, c, bias, nullptr, nullptr, nullptr, k, 1, 1, k, n, m, n, k, 0, acc, addend, ws, st);
+}
+// C[m,n] = A[m,k] B (B [k,n])
+int gemm_nn(const float* a, const float* b, float* c, int m, int n, int k, int acc, void* ws, void* st) {
+  return vnqa_sgemm(a, b, c, nullptr, nullptr, nullptr, nullptr, k, 1, n, 1, n, m, n, k, 0, acc, nullptr, ws, st);
+}
+// C[m,n] (+)= A^T B (A [k,m], B [k,n])
+int gemm_tn(const float* a, const float* b, float* c, int m, int n, int k, int acc, void* ws, void* st) {
+  return vnqa_sgemm(a, b, c, nullptr, nullptr, nullptr, nullptr, 1, m, n, 1, n, m, n, k, 0, acc, nullptr, ws, st);
+}
+
+}  // namespace
+
+extern "C" int64_t vnqa_mac_core_workspace(int32_t n, int32_t d) {
+  int64_t need = vnqa_sgemm_workspace(n, d, d);
+  const int64_t b = vnqa_sgemm_workspace(d, d, n), c = vnqa_sgemm_workspace(d, 1, n);
+  need = b > need ? b : need;
+  return c > need ? c : need;
+}
+
+extern "C" int vnqa_mac_core_fwd(const vnqa_mac_core* a, void* stream) {
+  VNQA_CHECK_ARG(a != nullptr, "mac_core_fwd: null argument block");
+  VNQA_CHECK_ARG(a->control && a->memory && a->pq && a->ctxw && a->know && a->pre && a->wc && a->w_ca && a->b_ca && a->wm &&
+                     a->bm && a->w1 && a->w_ra && a->b_ra && a->wr && a->wmm && a->bw,
+                 "mac_core_fwd: null input / parameter");
+  VNQA_CHECK_ARG(a->cq && a->qv && a->p_c && a->cnew && a->mem && a->v && a->t && a->u && a->p_r && a->read && a->concat,
+                 "mac_core_fwd: null output");
+  const int N = a->n, d = a->d;
+  hipStream_t st = (hipStream_t)stream;
+  MC_TRY(gemm_nt(a->control, a->wc, a->cq, nullptr, a->pq, N, d, d, 0, a->workspace, stream));            // cq = pq + control Wc^T
+  MC_TRY(ew_mul(a->qv, a->cq, a->w_ca, nullptr, N * d, d, 0, st));                           // qv = cq * w_ca
+  MC_TRY(vnqa_mac_read_fwd(a->ctxw, nullptr, a->qv, nullptr, a->b_ca, a->p_c, a->cnew, N, a->lq, d, d, VNQA_F32, stream));
+  if (a->mask_c != nullptr) MC_TRY(ew_mul(a->cnew, a->cnew, a->mask_c, nullptr, N * d, 0, 0, st));
+  MC_TRY(gemm_nt(a->memory, a->wm, a->mem, a->bm, nullptr, N, d, d, 0, a->workspace, stream));             // mem = memory Wm^T + bm
+  MC_TRY(ew_mul(a->v, a->cnew, a->w_ra, nullptr, N * d, d, 0, st));                          // v = control' * w_ra
+  MC_TRY(gemm_nn(a->v, a->w1, a->t, N, d, d, 0, a->workspace, stream));                                     // t = v W1
+  MC_TRY(ew_mul(a->u, a->mem, a->t, nullptr, N * d, 0, 0, st));                              // u = mem * t
+  MC_TRY(vnqa_mac_read_fwd(a->know, a->pre, a->u, a->v, a->b_ra, a->p_r, a->read, N, a->s, d, a->ld, a->dtype, stream));
+  MC_TRY(gemm_nt(a->read, a->wr, a->concat, a->bw, nullptr, N, d, d, 0, a->workspace, stream));            // concat = read Wr^T + bw
+  MC_TRY(gemm_nt(a->memory, a->wmm, a->concat, nullptr, nullptr, N, d, d, 1, a->workspace, stream));       //        + memory Wmm^T
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream) {
+  VNQA_CHECK_ARG(a != nullptr, "mac_core_bwd: null argument block");
+  VNQA_CHECK_ARG(a->d_concat && a->d_control && a->d_memory && a->d_cq && a->ds_r && a->d_read && a->ds_c && a->d_c && a->du &&
+                     a->dv && a->dqv && a->d_mem && a->d_t && a->ones,
+                 "mac_core_bwd: null gradient buffer");
+  VNQA_CHECK_ARG(a->g_wc && a->g_wca && a->g_wm && a->g_bm && a->g_w1 && a->g_wra && a->g_wr && a->g_wmm && a->g_bw,
+                 "mac_core_bwd: null parameter-gradient accumulator");
+  const int N = a->n, d = a->d;
+  hipStream_t st = (hipStream_t)stream;
+  // WriteUnit.concat
+  MC_TRY(gemm_nn(a->d_concat, a->wr, a->d_read, N, d, d, 0, a->workspace, stream));
+  MC_TRY(gemm_nn(a->d_concat, a->wmm, a->d_memory, N, d, d, 0, a->workspace, stream));
+  MC_TRY(gemm_tn(a->d_concat, a->read, a->g_wr, d, d, N, 1, a->workspace, stream));
+  MC_TRY(gemm_tn(a->d_concat, a->memory, a->g_wmm, d, d, N, 1, a->workspace, stream));
+  MC_TRY(gemm_tn(a->d_concat, a->ones, a->g_bw, d, 1, N, 1, a->workspace, stream));
+  // ReadUnit attention
+  MC_TRY(vnqa_mac_read_bwd(a->know, a->pre, a->p_r, a->d_read, a->ds_r, a->du, a->dv, N, a->s, d, a->ld, a->dtype, stream));
+  MC_TRY(ew_mul(a->d_mem, a->du, a->t, nullptr, N * d, 0, 0, st));                           // d mem = du * t
+  MC_TRY(ew_mul(a->d_t, a->du, a->mem, nullptr, N * d, 0, 0, st));                           // d t   = du * mem
+  MC_TRY(gemm_nt(a->d_t, a->w1, a->dv, nullptr, nullptr, N, d, d, 1, a->workspace, stream));                // dv += d t W1^T
+  MC_TRY(gemm_tn(a->v, a->d_t, a->g_w1, d, d, N, 1, a->workspace, stream));
+  MC_TRY(ew_mul(a->g_wra, a->dv, a->cnew, nullptr, N * d, 0, 1, st));                        // per-image w_ra gradient terms
+  MC_TRY(ew_mul(a->d_c, a->dv, a->w_ra, a->d_cnew, N * d, d, 0, st));                        // d control' = dv * w_ra (+ upstream)
+  MC_TRY(gemm_nn(a->d_mem, a->wm, a->d_memory, N, d, d, 1, a->workspace, stream));                          // d memory += d mem Wm
+  MC_TRY(gemm_tn(a->d_mem, a->memory, a->g_wm, d, d, N, 1, a->workspace, stream));
+  MC_TRY(gemm_tn(a->d_mem, a->ones, a->g_bm, d, 1, N, 1, a->workspace, stream));
+  if (a->mask_c != nullptr) MC_TRY(ew_mul(a->d_c, a->d_c, a->mask_c, nullptr, N * d, 0, 0, st));
+  // ControlUnit attention
+  MC_TRY(vnqa_mac_read_bwd(a->ctxw, nullptr, a->p_c, a->d_c, a->ds_c, a->dqv, nullptr, N, a->lq, d, d, VNQA_F32, stream));
+  MC_TRY(ew_mul(a->d_cq, a->dqv, a->w_ca, nullptr, N * d, d, 0, st));                        // d cq = dqv * w_ca
+  MC_TRY(ew_mul(a->g_wca, a->dqv, a->cq, nullptr, N * d, 0, 1, st));
+  MC_TRY(gemm_nn(a->d_cq, a->wc, a->d_control, N, d, d, 0, a->workspace, stream));
+  MC_TRY(gemm_tn(a->d_cq, a->control, a->g_wc, d, d, N, 1, a->workspace, stream));
+  return VNQA_OK;
+}

@@ -600,7 +600,7 @@ def sgemm(a, b, m, n, k, a_rs, a_cs, b_rs, b_cs, out, bias=None, relu=False, acc
     ws = workspace(ws_bytes, out.device) if ws_bytes > 0 else None
     L.check(L.lib().vnqa_sgemm(L.vptr(_f32c(a)), L.vptr(_f32c(b)), L.vptr(out), L.ptr(bias),
                                L.vptr(a_mask) if a_mask is not None else None, L.ptr(a_rows), L.ptr(c_rows),
-                               a_rs, a_cs, b_rs, b_cs, out.stride(0), m, n, k, int(relu), int(accumulate), L.ptr(ws),
+                               a_rs, a_cs, b_rs, b_cs, out.stride(0), m, n, k, int(relu), int(accumulate), None, L.ptr(ws),
                                L.stream()), "vnqa_sgemm")
     return out
 
@@ -720,3 +720,12 @@ def temporal_attn_packed_bwd(f, frame_off_i32, n_frames, B, T, A, w, coef, dctxt
                                                   L.ptr(w), L.ptr(coef), L.ptr(dctxt), L.ptr(df), L.ptr(dw_part),
                                                   L.ptr(db_part), B, T, A, L.stream()), "vnqa_temporal_attn_packed_bwd")
     return df, dw_part, db_part
+
+
+def mac_core_call(direction, dims, tensors):
+    """vnqa_mac_core_fwd / _bwd: `dims` = (n, d, lq, s, ld, dtype id), `tensors` = {field name: tensor or None}."""
+    a = L.MacCore(*dims)
+    for name, t in tensors.items():
+        setattr(a, name, None if t is None else t.data_ptr())
+    fn = L.lib().vnqa_mac_core_fwd if direction == "fwd" else L.lib().vnqa_mac_core_bwd
+    L.check(fn(ctypes.byref(a), L.stream()), "vnqa_mac_core_" + direction)

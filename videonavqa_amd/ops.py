@@ -543,10 +543,111 @@ class MacCoreState(object):
         self.ctrl = []
         self.read = []
         self.grads = {}
+        self.grads_meta = {}
 
 
 class MacCoreFn(torch.autograd.Function):
     """One MAC reasoning step (ControlUnit, ReadUnit and WriteUnit.concat of models/mac.py:28-42,53-62,82-85) for all
+    packed images as ONE autograd node whose forward and backward are ONE C-ABI call each (vnqa_mac_core_fwd / _bwd,
+    csrc/mac_core.hip): the ~11 / ~25 launches of a step are enqueued from C++.  `--model mac` was bound by the launch
+    thread (16.7 ms of host time against 13.8 ms of kernels per training step), not by the GPU.
+
+      cq      = control Wc^T + pq                       (pq = position_aware_i(question) Wp^T + b, hoisted by the caller)
+      control'= pool(ctx, cq * w_ca, b_ca) [* mask]     (attention over the question words)
+      mem     = memory Wm^T + bm ;  v = control' * w_ra ;  u = mem * (v W1)
+      read    = pool(know, pre; u, v, b_ra)             (re-associated ReadUnit, see models/mac.py)
+      concat  = read Wr^T + memory Wmm^T + bw
+    Returns (control', concat); self-attention / memory gate / the memory dropout mask stay with the caller.  Parameter
+    gradients are accumulated over the steps in the shared state and handed to autograd once, by the first step's node
+    (which the engine necessarily runs last)."""
+
+    FWD = ("cq", "qv", "cnew", "mem", "v", "t", "u", "read", "concat")          # [N, d] each, then p_c [N, Lq], p_r [N, S]
+
+    @staticmethod
+    def forward(ctx_, control, memory, pq, ctxw, know, pre, mask_c, wc, w_ca, b_ca, wm, bm, w1, w_ra, b_ra, wr, wmm, bw,
+                state, Lq, S):
+        N, d = control.shape
+        dev = control.device
+        buf = torch.empty(9 * N * d + N * Lq + N * S, dtype=torch.float32, device=dev)      # ONE allocation for all outputs
+        out = {n: buf[i * N * d:(i + 1) * N * d].view(N, d) for i, n in enumerate(MacCoreFn.FWD)}
+        out["p_c"] = buf[9 * N * d: 9 * N * d + N * Lq].view(N, Lq)
+        out["p_r"] = buf[9 * N * d + N * Lq:].view(N, S)
+        if "ws" not in state.grads_meta:
+            nb = L.lib().vnqa_mac_core_workspace(N, d)
+            state.grads_meta["ws"] = K.workspace(nb, dev) if nb > 0 else None
+        f32 = lambda t: t.detach().float().contiguous()
+        inputs = dict(control=f32(control), memory=f32(memory), pq=f32(pq), ctxw=ctxw, know=know, pre=pre,
+                      mask_c=None if mask_c is None else f32(mask_c), wc=f32(wc), w_ca=f32(w_ca), b_ca=f32(b_ca), wm=f32(wm),
+                      bm=f32(bm), w1=f32(w1), w_ra=f32(w_ra), b_ra=f32(b_ra), wr=f32(wr), wmm=f32(wmm), bw=f32(bw))
+        dims = (N, d, Lq, S, know.shape[-1], L.dtype_id(know.dtype))
+        K.mac_core_call("fwd", dims, dict(inputs, workspace=state.grads_meta["ws"], **out))
+        ctx_.save_for_backward(*[inputs[k] for k in ("control", "memory", "ctxw", "know", "pre")],
+                               inputs["mask_c"], *[inputs[k] for k in ("wc", "w_ca", "b_ca", "wm", "bm", "w1", "w_ra", "b_ra",
+                                                                       "wr", "wmm", "bw")], buf)
+        ctx_.state, ctx_.dims, ctx_.index = state, dims, state.n_calls
+        state.n_calls += 1
+        return out["cnew"], out["concat"]
+
+    @staticmethod
+    def backward(ctx_, d_cnew, d_concat):
+        sv = ctx_.saved_tensors
+        control, memory, ctxw, know, pre, mask_c = sv[:6]
+        wc, w_ca, b_ca, wm, bm, w1, w_ra, b_ra, wr, wmm, bw = sv[6:17]
+        buf = sv[17]
+        N, d, Lq, S, ld, did = ctx_.dims
+        dev = control.device
+        st = ctx_.state
+        out = {n: buf[i * N * d:(i + 1) * N * d].view(N, d) for i, n in enumerate(MacCoreFn.FWD)}
+        out["p_c"] = buf[9 * N * d: 9 * N * d + N * Lq].view(N, Lq)
+        out["p_r"] = buf[9 * N * d + N * Lq:].view(N, S)
+        G = st.grads
+        if not G:
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+            # ONE zero-filled buffer for all parameter-gradient accumulators of the 12 steps
+            acc = z(6 * d * d + 2 * N * d + 2 * d)
+            o = [0]
+
+            def take(n, *shape):
+                v = acc[o[0]:o[0] + n].view(*shape)
+                o[0] += n
+                return v
+            G.update(g_wc=take(d * d, d, d), g_wm=take(d * d, d, d), g_w1=take(d * d, d, d), g_wr=take(d * d, d, d),
+                     g_wmm=take(d * d, d, d), g_wca=take(N * d, N, d), g_wra=take(N * d, N, d), g_bm=take(d, d),
+                     g_bw=take(d, d), ones=torch.ones(N, dtype=torch.float32, device=dev))
+        # per-step gradient buffers: outputs (3 x [N,d]), factors kept for the final accumulation (d_read, d_c [N,d];
+        # ds_r [N,S]; ds_c [N,Lq]) and scratch (du, dv, dqv, d_mem, d_t)
+        gb = torch.empty(10 * N * d + N * S + N * Lq, dtype=torch.float32, device=dev)
+        names = ("d_control", "d_memory", "d_cq", "d_read", "d_c", "du", "dv", "dqv", "d_mem", "d_t")
+        g = {n: gb[i * N * d:(i + 1) * N * d].view(N, d) for i, n in enumerate(names)}
+        g["ds_r"] = gb[10 * N * d:10 * N * d + N * S].view(N, S)
+        g["ds_c"] = gb[10 * N * d + N * S:].view(N, Lq)
+        args = dict(control=control, memory=memory, ctxw=ctxw, know=know, pre=pre, mask_c=mask_c, wc=wc, w_ca=w_ca, b_ca=b_ca,
+                    wm=wm, bm=bm, w1=w1, w_ra=w_ra, b_ra=b_ra, wr=wr, wmm=wmm, bw=bw,
+                    d_cnew=None if d_cnew is None else d_cnew.float().contiguous(), d_concat=d_concat.float().contiguous(),
+                    workspace=st.grads_meta.get("ws"))
+        args.update(out)
+        args.update(g)
+        args.update(G)
+        K.mac_core_call("bwd", (N, d, Lq, S, ld, did), args)
+        st.read.append((g["ds_r"], out["p_r"], out["u"], out["v"], g["d_read"]))
+        st.ctrl.append((g["ds_c"], out["p_c"], out["qv"], g["d_c"]))
+        d_ctxw = d_know = d_pre = None
+        gp = [None] * 11
+        if ctx_.index == 0:      # runs last: every later step depends on this one's outputs
+            f = [torch.stack(x) for x in zip(*st.read)]
+            d_know, d_pre = K.mac_read_accum(f[0], f[1], f[2], f[3], f[4], N, S, d, ld, know.dtype)
+            c = [torch.stack(x) for x in zip(*st.ctrl)]
+            d_ctxw, _ = K.mac_read_accum(c[0], c[1], c[2], None, c[3], N, Lq, d, ctxw.shape[-1], ctxw.dtype)
+            gp = [G["g_wc"], K.colsum(G["g_wca"]).view(1, d), c[0].sum().view(1), G["g_wm"], G["g_bm"],
+                  G["g_w1"], K.colsum(G["g_wra"]).view(1, d), f[0].sum().view(1), G["g_wr"], G["g_wmm"], G["g_bw"]]
+            st.read, st.ctrl, st.grads = [], [], {}
+        return (g["d_control"], g["d_memory"], g["d_cq"], d_ctxw, d_know, d_pre, None, gp[0], gp[1], gp[2], gp[3], gp[4],
+                gp[5], gp[6], gp[7], gp[8], gp[9], gp[10], None, None, None)
+
+
+class MacCoreTorchFn(torch.autograd.Function):
+    """(A/B reference, VNQA_MAC_CORE_TORCH=1: the same node issued op by op from Python on torch GEMMs.)
+    One MAC reasoning step (ControlUnit, ReadUnit and WriteUnit.concat of models/mac.py:28-42,53-62,82-85) for all
     packed images as ONE autograd node: inside, plain torch GEMMs and the fused attention kernels run without graph
     recording, and the backward is written out by hand.  Motivation: the MAC training step was bound by the launch
     thread (autograd bookkeeping of ~75 small ops per step and direction), not by the GPU.
@@ -640,6 +741,9 @@ class MacCoreFn(torch.autograd.Function):
 
 
 def mac_core(*args):
+    import os
+    if os.environ.get("VNQA_MAC_CORE_TORCH", "0") == "1":
+        return MacCoreTorchFn.apply(*args)
     return MacCoreFn.apply(*args)
 
 
