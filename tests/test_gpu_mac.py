@@ -9,6 +9,14 @@ from helpers import MAC_CASES, mac_case, rel_err
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["rocblas_step", "cabi_step"])
+def mac_core_impl(request, monkeypatch):
+    """Every MAC test runs with both forms of the reasoning step: the op-by-op node (default) and the one-call-per-direction
+    C-ABI form (vnqa_mac_core_fwd / _bwd, VNQA_MAC_CORE_CABI=1)."""
+    monkeypatch.setenv("VNQA_MAC_CORE_CABI", "1" if request.param == "cabi_step" else "0")
+    return request.param
+
+
 def _packed_reference(lstm, x_sorted, lens):
     """torch.nn.LSTM on a packed batch (CPU fp32) -> padded output [B,Lmax,dirs*H] with grads enabled."""
     packed = nn.utils.rnn.pack_padded_sequence(x_sorted, lens, batch_first=True)

@@ -49,13 +49,19 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  // loader roles: A: k = tid & 15, rows m = (tid >> 4) + 16 r;  B: k = tid >> 4, columns n = (tid & 15) + 16 r
-  const int lk = threadIdx.x & 15, lr = threadIdx.x >> 4;
+  // Loader roles follow the operand's contiguous direction so that a wave's loads fall into whole cache lines:
+  //   A k-contiguous (a_cs == 1: x of x W^T):  k = tid & 15, rows m = (tid >> 4) + 16 r
+  //   A m-contiguous (a_rs == 1: dY of dY^T X): m = tid & 63, k = (tid >> 6) + 4 r
+  //   B n-contiguous (b_cs == 1: W of x W):     n = tid & 63, k = (tid >> 6) + 4 r
+  //   B k-contiguous (b_rs == 1: W of x W^T):   k = tid & 15, columns n = (tid >> 4) + 16 r
+  const bool a_kfast = (p.a_cs == 1) || (p.a_rs != 1);
+  const bool b_kfast = (p.b_rs == 1) && (p.b_cs != 1);
+  const int t15 = threadIdx.x & 15, t4 = threadIdx.x >> 4, t63 = threadIdx.x & 63, t6 = threadIdx.x >> 6;
   long long a_base[4];
   bool a_ok[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int m = m0 + lr + 16 * r;
+    const int m = m0 + (a_kfast ? t4 + 16 * r : t63);
     int row = m;
     a_ok[r] = m < p.M;
     if (a_ok[r] && p.a_rows != nullptr) {
@@ -68,7 +74,7 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int k = k0 + lk;
+      const int k = k0 + (a_kfast ? t15 : t6 + 4 * r);
       float v = 0.f;
       if (a_ok[r] && k < ke) {
         const long long off = a_base[r] + (long long)k * p.a_cs;
@@ -79,7 +85,8 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int k = k0 + lr, n = n0 + lk + 16 * r;
+      const int k = k0 + (b_kfast ? t15 : t6 + 4 * r);
+      const int n = n0 + (b_kfast ? t4 + 16 * r : t63);
       rb[r] = (k < ke && n < p.N) ? p.B[(long long)k * p.b_rs + (long long)n * p.b_cs] : 0.f;
     }
   };
@@ -87,8 +94,10 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __
   for (int k0 = kb; k0 < ke; k0 += 16) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      As[lk][lr + 16 * r] = ra[r];
-      Bs[lr][lk + 16 * r] = rb[r];
+      if (a_kfast) As[t15][t4 + 16 * r] = ra[r];
+      else As[t6 + 4 * r][t63] = ra[r];
+      if (b_kfast) Bs[t15][t4 + 16 * r] = rb[r];
+      else Bs[t6 + 4 * r][t63] = rb[r];
     }
     __syncthreads();
     if (k0 + 16 < ke) fetch(k0 + 16);

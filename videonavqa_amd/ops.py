@@ -573,7 +573,8 @@ class MacCoreFn(torch.autograd.Function):
         out["p_c"] = buf[9 * N * d: 9 * N * d + N * Lq].view(N, Lq)
         out["p_r"] = buf[9 * N * d + N * Lq:].view(N, S)
         if "ws" not in state.grads_meta:
-            nb = L.lib().vnqa_mac_core_workspace(N, d)
+            import os
+            nb = L.lib().vnqa_mac_core_workspace(N, d) if os.environ.get("VNQA_MAC_SPLITK", "1") != "0" else 0
             state.grads_meta["ws"] = K.workspace(nb, dev) if nb > 0 else None
         f32 = lambda t: t.detach().float().contiguous()
         inputs = dict(control=f32(control), memory=f32(memory), pq=f32(pq), ctxw=ctxw, know=know, pre=pre,
@@ -646,7 +647,7 @@ class MacCoreFn(torch.autograd.Function):
 
 
 class MacCoreTorchFn(torch.autograd.Function):
-    """(A/B reference, VNQA_MAC_CORE_TORCH=1: the same node issued op by op from Python on torch GEMMs.)
+    """(The default of ops.mac_core: the node issued op by op from Python on torch / rocBLAS GEMMs.)
     One MAC reasoning step (ControlUnit, ReadUnit and WriteUnit.concat of models/mac.py:28-42,53-62,82-85) for all
     packed images as ONE autograd node: inside, plain torch GEMMs and the fused attention kernels run without graph
     recording, and the backward is written out by hand.  Motivation: the MAC training step was bound by the launch
@@ -741,10 +742,15 @@ class MacCoreTorchFn(torch.autograd.Function):
 
 
 def mac_core(*args):
+    """Default: the op-by-op node on rocBLAS GEMMs (MacCoreTorchFn).  VNQA_MAC_CORE_CABI=1 selects the one-call-per-direction
+    C-ABI form (MacCoreFn): same results (tests/test_gpu_mac.py runs both), ~430 fewer Python-issued launches per training
+    step, but measured 12 % SLOWER end to end (355 vs 405 clips/s, `tools/ab_mac.sh`): its 204 fp32 GEMMs of
+    [n_img, dim] x [dim, dim] run on the plain-FMA vnqa_sgemm at 19 us each against rocBLAS' 9 us, which costs more than the
+    launch thread saves.  It becomes the default once those products run on the exact-f32 MFMA GEMM with fused epilogues."""
     import os
-    if os.environ.get("VNQA_MAC_CORE_TORCH", "0") == "1":
-        return MacCoreTorchFn.apply(*args)
-    return MacCoreFn.apply(*args)
+    if os.environ.get("VNQA_MAC_CORE_CABI", "0") == "1":
+        return MacCoreFn.apply(*args)
+    return MacCoreTorchFn.apply(*args)
 
 
 # ---- question path / classifier / loss on csrc/glue.hip (no ATen / rocBLAS kernels in the step) --------------------------
