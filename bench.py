@@ -218,6 +218,31 @@ def cpu_baseline(argv, limit_s=420):
             "sample": "cpu leg produced no measurement%s: %s" % (note, (err or "").strip()[-300:])}
 
 
+def fp16_leg(args):
+    """The fp16-storage precision (libvnqa_hip_f16.so: the same kernels with IEEE fp16 as the 16-bit format, loss-scaled
+    backward) measured on the same workload in a CHILD process — one 16-bit storage format per process — after this
+    process's own measurement: throughput of a short run and its parity block against the exact-f32 precision."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--precision", "fp16", "--no-cpu-baseline", "--no-fp16-leg", "--repeats", "1",
+           "--steps", str(min(args.steps, 10)), "--warmup", "3", "--batch", str(args.batch), "--frames", str(args.frames),
+           "--height", str(args.height), "--width", str(args.width), "--blocks", str(args.blocks), "--channels", str(args.channels)]
+    env = {k: v for k, v in os.environ.items() if k not in ("VNQA_HALF",)}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        line = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+        if not line:
+            return {"error": (r.stderr or "no output").strip()[-300:]}
+        d = json.loads(line[-1])
+        p = d.get("parity", {})
+        return {"what": "bench.py --precision fp16 (fp16 storage, fp32 accumulate, backward loss scale 2^10), %d timed steps, child process"
+                        % d["steps"], "clips_per_s": d["value"], "ms_per_step": d["ms_per_step"],
+                "roofline_frac": d["roofline"]["frac"], "fp16_logits_rel_err": p.get("fp16_logits_rel_err"),
+                "argmax_equal_at_init": p.get("argmax_equal_at_init"), "loss_rel_err": p.get("loss_rel_err"),
+                "grad_rel_l2_err": p.get("grad_rel_l2_err"), "after_fit": p.get("after_fit")}
+    except subprocess.TimeoutExpired:
+        return {"error": "fp16 leg exceeded 300 s"}
+
+
 def spawn_ranks(n, argv):
     """`bench.py --gpus N` without a launcher: start N rank processes (one per GPU) from THIS process, which has not
     touched the GPU, with the torchrun environment contract; rank 0's stdout (the one JSON line) is relayed.
@@ -292,7 +317,10 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
             loss = tr.loss_fn(out, y[perm_d])
         return out, loss
 
-    for prec in ("fp32", "bf16"):
+    low = args.precision if args.precision in ("bf16", "fp16") else "bf16"      # the 16-bit precision under test
+    from videonavqa_amd import _lib as L
+    L.set_half("f16" if low == "fp16" else "bf16")       # one 16-bit storage format per process: fix it before the fp32 build
+    for prec in ("fp32", low):
         a = copy.copy(args)
         a.precision = prec
         model, stem, _, _ = build(a, device)
@@ -330,8 +358,8 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
         fit[prec] = (out.detach().float().cpu(), float(loss))
         del tr, model, stem
         torch.cuda.empty_cache()
-    rel = [float((b - f).abs().max() / f.abs().max()) for b, f in zip(logits["bf16"], logits["fp32"])]
-    same = sum(int((b.argmax(1) == f.argmax(1)).sum()) for b, f in zip(logits["bf16"], logits["fp32"]))
+    rel = [float((b - f).abs().max() / f.abs().max()) for b, f in zip(logits[low], logits["fp32"])]
+    same = sum(int((b.argmax(1) == f.argmax(1)).sum()) for b, f in zip(logits[low], logits["fp32"]))
     total = sum(f.shape[0] for f in logits["fp32"])
 
     def top2_gap(f):     # how decisive the fp32 prediction is: top-1 / top-2 logit gap relative to max |logit|
@@ -339,19 +367,20 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
         return (t[:, 0] - t[:, 1]) / f.abs().max()
 
     # samples whose bf16 argmax differs: their fp32 top-2 gap (a flip needs gap < 2 x the logits error)
-    flipped = [round(float(g), 6) for b, f in zip(logits["bf16"], logits["fp32"])
+    flipped = [round(float(g), 6) for b, f in zip(logits[low], logits["fp32"])
                for g, eq in zip(top2_gap(f), b.argmax(1) == f.argmax(1)) if not bool(eq)]
-    gf, gb = grads["fp32"], grads["bf16"]
-    ff, fb = fit["fp32"][0], fit["bf16"][0]
+    gf, gb = grads["fp32"], grads[low]
+    ff, fb = fit["fp32"][0], fit[low][0]
     return {"reference": "precision='fp32' (exact-f32 MFMA kernels; pinned <= 1e-3 to the reference goldens by tests/test_gpu_models.py)",
             "batches": "3 x (%d clips x %d frames %dx%d): full length, ragged, ragged; train-mode forward"
                        % (args.batch, args.frames, args.height, args.width),
-            "bf16_logits_rel_err": round(max(rel), 6), "bf16_logits_rel_err_per_batch": [round(r, 6) for r in rel],
+            "precision": low,
+            "%s_logits_rel_err" % low: round(max(rel), 6), "%s_logits_rel_err_per_batch" % low: [round(r, 6) for r in rel],
             "argmax_equal_at_init": "%d/%d" % (same, total), "fp32_top2_gap_rel_of_flipped_at_init": flipped,
-            "loss_rel_err": round(max(abs(b - f) / max(abs(f), 1e-9) for b, f in zip(losses["bf16"], losses["fp32"])), 6),
+            "loss_rel_err": round(max(abs(b - f) / max(abs(f), 1e-9) for b, f in zip(losses[low], losses["fp32"])), 6),
             "grad_rel_l2_err": round(float((gb - gf).norm() / gf.norm()), 6),
-            "after_fit": {"fit_steps_fp32": fit_steps, "fp32_loss": round(fit["fp32"][1], 4), "bf16_loss": round(fit["bf16"][1], 4),
-                          "bf16_logits_rel_err": round(float((fb - ff).abs().max() / ff.abs().max()), 6),
+            "after_fit": {"fit_steps_fp32": fit_steps, "fp32_loss": round(fit["fp32"][1], 4), "%s_loss" % low: round(fit[low][1], 4),
+                          "%s_logits_rel_err" % low: round(float((fb - ff).abs().max() / ff.abs().max()), 6),
                           "argmax_equal": bool((fb.argmax(1) == ff.argmax(1)).all()),
                           "fp32_min_top2_gap_rel": round(float(top2_gap(ff).min()), 6)},
             "argmax_equal": bool((fb.argmax(1) == ff.argmax(1)).all()),
@@ -365,7 +394,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=3, help="the timed K-step region is run this many times back to back; "
                     "the reported value / ms_per_step are the MEDIAN region's, all regions are listed in `repeats`")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="bf16: the benchmark precision (BASELINE.json); fp16: the fp16-storage build of the library (same MFMA "
+                         "rate, 8x finer rounding, loss-scaled backward); fp32: the exact-f32 parity precision")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=35)
     ap.add_argument("--height", type=int, default=224)
@@ -379,6 +410,8 @@ def main():
                     "and are copied to the GPU every step (on the stem stream); never the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-fp32 parity block (adds ~10 s)")
+    ap.add_argument("--parity-only", action="store_true", help="print only the parity block of --precision (no timing)")
+    ap.add_argument("--no-fp16-leg", action="store_true", help="skip the fp16-storage precision's own short run (child process)")
     ap.add_argument("--no-overlap", action="store_true", help="run the stem on the main stream (no side-stream pipeline)")
     ap.add_argument("--cpu-batch", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-steps", type=int, default=3, help=argparse.SUPPRESS)
@@ -388,6 +421,13 @@ def main():
         cpu_baseline_child(args)
         return
 
+    if args.precision == "fp16":      # the fp16-storage build of the library (one 16-bit format per process)
+        from videonavqa_amd import _lib as L
+        L.set_half("f16")
+    if args.parity_only:
+        torch.cuda.set_device(0)
+        print(json.dumps(precision_parity(args, torch.device("cuda", 0))), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus, sys.argv[1:])          # this process never touches the GPU
         return
@@ -512,7 +552,7 @@ def main():
         torch.cuda.synchronize()
         stem_ms = e0.elapsed_time(e1) / 5
     parity = None
-    if rank == 0 and not args.no_parity and args.model != "mac" and args.precision == "bf16":
+    if rank == 0 and not args.no_parity and args.model != "mac" and args.precision in ("bf16", "fp16"):
         loss = loss.clone()
         del trainer, model, stem
         torch.cuda.empty_cache()
@@ -532,7 +572,7 @@ def main():
         # algorithmic FLOPs of exactly the launches that were timed (the stem-tagged instantiation), recorded by the stem
         flops_per_launch = sum(ev[2] for ev in events) / max(len(events), 1)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_BF16_TFLOPS if args.precision in ("bf16", "fp16") else PEAK_F32_TFLOPS      # fp16 MFMA rate == bf16's
         # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
         # live; collected with rocprofv3 --pmc in separate runs, corrected per the microarch guide) — only
         # valid for the default workload the passes were taken on
@@ -556,7 +596,7 @@ def main():
             "metric": METRIC, "value": round(clips, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision], "data": "synthetic",
             "repeats": {"n": len(regions), "value_is": "median region", "clips_per_s": [round(c, 1) for c in all_clips],
                         "spread_rel": round((max(all_clips) - min(all_clips)) / clips, 4)},
             "config": {"workload": "%s training step: VGG-16[:10]+ObjDetectCNN(512) frozen stem + "
@@ -592,6 +632,8 @@ def main():
             out["comm"] = comm
         if parity is not None:
             out["parity"] = parity
+        if world == 1 and args.precision == "bf16" and not args.no_fp16_leg and not args.no_parity and args.model == "film_attn_pt":
+            out["fp16_mode"] = fp16_leg(args)
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
         print(json.dumps(out), flush=True)

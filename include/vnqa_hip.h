@@ -216,6 +216,8 @@ int vnqa_pack_conv_weight_tiled(const float* w_oihw, int32_t c_out, int32_t c_in
 /* Inverse of the above for gradients: dW (fp32, [c_out_pad][taps][c_in_pad]) -> OIHW fp32. */
 int vnqa_unpack_conv_wgrad(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps,
                            int32_t c_out_pad, int32_t c_in_pad, float* dw_oihw, void* stream);
+int vnqa_unpack_conv_wgrad_scaled(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps, int32_t c_out_pad,
+                                  int32_t c_in_pad, float* dw_oihw, float alpha, void* stream);   /* dw = alpha * un-packed */
 
 /* fc_embed_attn = nn.Linear(spatial*C -> at_hidden) applied to the NCHW-flattened feature map
  * (models/film_attn_pt_stem.py:56-57,244).  The kernels keep maps as padded NHWC, so its weight is re-laid out once
@@ -228,6 +230,8 @@ int vnqa_pack_fc_weight(const float* w, int32_t rows, int32_t c, int32_t h, int3
                         int32_t c_pad, int32_t dtype, void* nat, void* nat_t, void* stream);
 int vnqa_unpack_fc_wgrad(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad,
                          float* dw, void* stream);
+int vnqa_unpack_fc_wgrad_scaled(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad, float* dw,
+                                float alpha, void* stream);
 
 /* Layout converters between the reference's tensors and padded NHWC.
  *   vnqa_feat_to_nhwc : v fp32 [b][c][h][w][t] (the model-input layout, eval/q_and_v_eval.py:110)
@@ -343,7 +347,10 @@ int vnqa_temporal_attn_packed_fwd(const void* f, int32_t ld, int32_t dtype, cons
                                   int32_t a, void* stream);
 int vnqa_temporal_attn_packed_bwd(const void* f, int32_t ld, int32_t dtype, const int32_t* frame_off, int32_t n_frames,
                                   const float* w, const float* coef, const float* dctxt, void* df, float* dw_part,
-                                  float* db_part, int32_t b, int32_t t, int32_t a, void* stream);
+                                  float* db_part, int32_t b, int32_t t, int32_t a, float grad_scale, void* stream);
+                                  /* grad_scale: d f is multiplied by it BEFORE rounding to `dtype` — the loss scale of the
+                                   * fp16 storage build (activation gradients of 1e-5..1e-7 would sit in fp16's subnormal
+                                   * range); the consumers divide their fp32 results by it (…_scaled un-pack entry points) */
 
 /* ---------------------------------------------------------------------------------------
  * Small fp32 pieces of the question path / classifier / loss (csrc/glue.hip): with them a training step of the FiLM models

@@ -9,6 +9,31 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VNQA_LIB", os.path.join(_HERE, "lib", "libvnqa_hip.so"))
+LIB_PATH_F16 = os.path.join(_HERE, "lib", "libvnqa_hip_f16.so")
+
+# The library's 16-bit storage format is a BUILD property (csrc/vnqa_common.h): libvnqa_hip.so stores bf16,
+# libvnqa_hip_f16.so IEEE fp16 (same MFMA rate, 8x finer rounding, +-65504 range).  One format per process: it is fixed by
+# the first model / stem built (precision 'bf16' | 'fp16'; 'fp32' works with either) or by VNQA_HALF=bf16|f16.
+_half = os.environ.get("VNQA_HALF")          # None until somebody needs a 16-bit format
+
+
+def set_half(fmt):
+    """Select the process's 16-bit storage format ('bf16' | 'f16').  Raises if the other library is already in use."""
+    global _half
+    assert fmt in ("bf16", "f16"), fmt
+    if _half is not None and _half != fmt and _lib is not None:
+        raise VnqaError("this process already runs the %s build of the HIP library; precision '%s' needs the other one — "
+                        "one 16-bit storage format per process (use a separate process, or VNQA_HALF)" % (_half, fmt))
+    _half = fmt
+
+
+def half_dtype():
+    """torch dtype of the library's 16-bit storage format."""
+    return torch.float16 if _half == "f16" else torch.bfloat16
+
+
+def is_half(dt):
+    return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
@@ -67,7 +92,9 @@ _SIGNATURES = {
     "vnqa_temporal_attn_fwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 3 + [_vp]),
     "vnqa_temporal_attn_bwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 3 + [_vp]),
     "vnqa_temporal_attn_packed_fwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "vnqa_temporal_attn_packed_bwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "vnqa_temporal_attn_packed_bwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "vnqa_unpack_conv_wgrad_scaled": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _vp]),
+    "vnqa_unpack_fc_wgrad_scaled": (ctypes.c_int, [_vp] + [_i32] * 5 + [_vp, _f32, _vp]),
     "vnqa_sgemm_workspace": (_i64, [_i32, _i32, _i32]),
     "vnqa_sgemm": (ctypes.c_int, [_vp] * 7 + [_i64] * 4 + [_i32] * 6 + [_vp, _vp, _vp]),
     "vnqa_mac_core_workspace": (_i64, [_i32, _i32]),
@@ -121,19 +148,22 @@ class VnqaError(RuntimeError):
 
 def lib():
     """Load (once) and return the CDLL; raises if the HIP library has not been built."""
-    global _lib
+    global _lib, _half
     if _lib is None:
+        if _half is None:
+            _half = "bf16"
+        path = LIB_PATH_F16 if (_half == "f16" and "VNQA_LIB" not in os.environ) else LIB_PATH
         if "VNQA_LIB" not in os.environ and os.path.exists("/opt/rocm/bin/hipcc") \
                 and os.environ.get("VNQA_NO_REBUILD", "0") != "1":
             # not a fallback: (re)build the HIP library itself when it is missing OR older than its sources (the digest
             # check is cheap; build() takes a file lock, so torchrun ranks do not compile over each other)
             from .build import build as _build
-            _build(verbose=False)
-        if not os.path.exists(LIB_PATH):
+            _build(verbose=False, variant=_half)
+        if not os.path.exists(path):
             raise VnqaError(
-                "libvnqa_hip.so not found at %s — build it with `python -m videonavqa_amd.build` "
-                "(there is no CPU/PyTorch fallback for the HIP path)" % LIB_PATH)
-        _lib = ctypes.CDLL(LIB_PATH)
+                "%s not found — build it with `python -m videonavqa_amd.build` "
+                "(there is no CPU/PyTorch fallback for the HIP path)" % path)
+        _lib = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(_lib, name)  # AttributeError if the symbol is missing: fail loudly
             fn.restype = res
@@ -178,8 +208,13 @@ def stream():
 
 
 def dtype_id(dt):
-    if dt == torch.bfloat16:
-        return BF16
+    if dt in (torch.bfloat16, torch.float16):
+        if _lib is None:
+            set_half("f16" if dt == torch.float16 else "bf16")
+        if dt != half_dtype():
+            raise VnqaError("%s tensor handed to the %s build of the HIP library (one 16-bit storage format per process)"
+                            % (dt, _half))
+        return BF16          # "the library's 16-bit format"
     if dt == torch.float32:
         return F32
     raise VnqaError("unsupported dtype %s" % dt)

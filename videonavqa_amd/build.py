@@ -12,6 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvnqa_hip.so")
+# The same sources with -DVNQA_H16_IS_F16: the library's 16-bit storage format is IEEE fp16 instead of bf16
+# (csrc/vnqa_common.h); selected by precision='fp16' / VNQA_HALF=f16 on the Python side.
+LIB_F16 = os.path.join(LIBDIR, "libvnqa_hip_f16.so")
+VARIANTS = {"bf16": (LIB, [], "libvnqa_hip"), "f16": (LIB_F16, ["-DVNQA_H16_IS_F16"], "libvnqa_hip_f16")}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = (["-DVNQA_DIAG_SKIP_DMA"] if os.environ.get("VNQA_DIAG") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
@@ -21,25 +25,29 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
-def _digest():
+def _digest(extra=()):
     h = hashlib.sha256()
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     for f in sources() + headers + [os.path.join(HERE, "..", "include", "vnqa_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + list(extra)).encode())
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
-    """Compile every source and link libvnqa_hip.so unless the source digest matches the stamp.  Safe to call from several
+def build(force=False, verbose=True, variant="bf16"):
+    """Compile every source and link the library (variant 'bf16': libvnqa_hip.so, 'f16': libvnqa_hip_f16.so, 'all': both)
+    unless the source digest matches the stamp.  Safe to call from several
     processes at once (torchrun ranks): an exclusive file lock serialises them, the winners of later turns find the stamp
     up to date, and objects / the library are written to temporary names and renamed into place."""
     import fcntl
     import tempfile
+    if variant == "all":
+        return [build(force, verbose, v) for v in ("bf16", "f16")]
+    LIB, extra, stem_name = VARIANTS[variant]
     os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "libvnqa_hip.stamp")
-    dig = _digest()
+    stamp = os.path.join(LIBDIR, stem_name + ".stamp")
+    dig = _digest(extra)
 
     def fresh():
         return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig
@@ -56,16 +64,17 @@ def build(force=False, verbose=True):
                 objs, procs = [], []
                 for src in sources():
                     obj = os.path.join(tmpdir, os.path.basename(src) + ".o")
-                    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+                    cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
                     procs.append((src, subprocess.Popen(cmd)))
                     objs.append(obj)
                 failed = [src for src, p in procs if p.wait() != 0]
                 if failed:
                     raise RuntimeError("hipcc failed on %s" % ", ".join(failed))
-                tmp_lib = os.path.join(tmpdir, "libvnqa_hip.so")
+                tmp_lib = os.path.join(tmpdir, stem_name + ".so")
                 subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs)
-                for obj in objs:               # keep the objects next to the library (inspection: llvm-objdump)
-                    os.replace(obj, os.path.join(LIBDIR, os.path.basename(obj)))
+                if variant == "bf16":
+                    for obj in objs:           # keep the objects next to the library (inspection: llvm-objdump)
+                        os.replace(obj, os.path.join(LIBDIR, os.path.basename(obj)))
                 os.replace(tmp_lib, LIB)
                 with open(stamp + ".tmp", "w") as fh:
                     fh.write(dig)
@@ -81,4 +90,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, variant="all")

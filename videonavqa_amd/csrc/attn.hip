@@ -157,7 +157,7 @@ template <typename T>
 __global__ void temporal_attn_packed_bwd_kernel(const T* __restrict__ f, int ld, const int* __restrict__ frame_off, int n_frames,
                                                 const float* __restrict__ w, const float* __restrict__ coef,
                                                 const float* __restrict__ dctxt, T* __restrict__ df, float* __restrict__ dw_part,
-                                                float* __restrict__ db_part, int Tn, int A) {
+                                                float* __restrict__ db_part, int Tn, int A, float grad_scale) {
   extern __shared__ float s_mem[];            // [T] g / dscore*valid, [T] coef, [16] scratch
   float* s_g = s_mem;
   float* s_c = s_mem + Tn;
@@ -197,7 +197,7 @@ __global__ void temporal_attn_packed_bwd_kernel(const T* __restrict__ f, int ld,
     const size_t row = (size_t)(frame_off[t] + b) * ld;
     if (a < A) {
       const float fv = ElemOps<T>::load(f[row + a]);
-      df[row + a] = ElemOps<T>::store(s_c[t] * da + s_g[t] * wa);
+      df[row + a] = ElemOps<T>::store(grad_scale * (s_c[t] * da + s_g[t] * wa));
       dwa = fmaf(s_g[t], fv, dwa);
     }
     for (int c = A + a; c < ld; c += blockDim.x) df[row + c] = ElemOps<T>::store(0.f);     // padding columns of the GEMM operand
@@ -232,7 +232,8 @@ extern "C" int vnqa_temporal_attn_packed_fwd(const void* f, int32_t ld, int32_t 
 
 extern "C" int vnqa_temporal_attn_packed_bwd(const void* f, int32_t ld, int32_t dtype, const int32_t* frame_off,
                                              int32_t n_frames, const float* w, const float* coef, const float* dctxt, void* df,
-                                             float* dw_part, float* db_part, int32_t b, int32_t t, int32_t a, void* stream) {
+                                             float* dw_part, float* db_part, int32_t b, int32_t t, int32_t a, float grad_scale,
+                                             void* stream) {
   VNQA_CHECK_ARG(f && frame_off && w && coef && dctxt && df && dw_part && db_part, "temporal_attn_packed_bwd: null pointer");
   VNQA_CHECK_ARG(b > 0 && t > 0 && a > 0 && a <= 1024 && ld >= a && n_frames > 0 && n_frames <= t,
                  "temporal_attn_packed_bwd: need 0 < a <= 1024, ld >= a, 0 < n_frames <= t");
@@ -241,10 +242,10 @@ extern "C" int vnqa_temporal_attn_packed_bwd(const void* f, int32_t ld, int32_t 
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VNQA_BF16)
     hipLaunchKernelGGL(temporal_attn_packed_bwd_kernel<vnqa_bf16>, dim3(b), dim3(threads), lds, st, (const vnqa_bf16*)f, ld,
-                       frame_off, n_frames, w, coef, dctxt, (vnqa_bf16*)df, dw_part, db_part, t, a);
+                       frame_off, n_frames, w, coef, dctxt, (vnqa_bf16*)df, dw_part, db_part, t, a, grad_scale);
   else if (dtype == VNQA_F32)
     hipLaunchKernelGGL(temporal_attn_packed_bwd_kernel<float>, dim3(b), dim3(threads), lds, st, (const float*)f, ld, frame_off,
-                       n_frames, w, coef, dctxt, (float*)df, dw_part, db_part, t, a);
+                       n_frames, w, coef, dctxt, (float*)df, dw_part, db_part, t, a, grad_scale);
   else {
     vnqa_set_error("temporal_attn_packed_bwd: bad dtype %d", dtype);
     return VNQA_ERR_INVALID_ARG;

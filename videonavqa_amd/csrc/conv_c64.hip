@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         vnqa_f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
-        a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[j], xb, a1, 0, 0, 0);
+        a1 = VNQA_MFMA_16x16x32(w1f[j], xb, a1);
         uint2 pk = make_uint2(0u, 0u);
         if (inside) {
           pk.x = (unsigned)f32_to_bf16(fmaxf(a1[0] + b1r[j][0], 0.f)) | ((unsigned)f32_to_bf16(fmaxf(a1[1] + b1r[j][1], 0.f)) << 16);
@@ -273,8 +273,8 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vnqa_bf16x8, wfb[k & 1][j]),
-                                                             __builtin_bit_cast(vnqa_bf16x8, xfb[k & 1][i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = VNQA_MFMA_16x16x32(__builtin_bit_cast(vnqa_bf16x8, wfb[k & 1][j]),
+                                                             __builtin_bit_cast(vnqa_bf16x8, xfb[k & 1][i]), acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
           const unsigned w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[2 * e] = fmaxf(v[2 * e], __uint_as_float(w4[e] << 16));
-            v[2 * e + 1] = fmaxf(v[2 * e + 1], __uint_as_float(w4[e] & 0xffff0000u));
+            v[2 * e] = fmaxf(v[2 * e], h16_lo(w4[e]));
+            v[2 * e + 1] = fmaxf(v[2 * e + 1], h16_hi(w4[e]));
           }
         }
       } else {
@@ -333,8 +333,8 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
         const unsigned w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[2 * e] = __uint_as_float(w4[e] << 16);
-          v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+          v[2 * e] = h16_lo(w4[e]);
+          v[2 * e + 1] = h16_hi(w4[e]);
         }
       }
       const int co0 = nsl * 64 + c * 8;
@@ -495,14 +495,14 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
 #pragma unroll
       for (int gi = 0; gi < 5; ++gi) {
         const vnqa_f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        a1[gi][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xa[gi], z, 0, 0, 0);
+        a1[gi][j] = VNQA_MFMA_16x16x32(wf, xa[gi], z);
       }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int gi = 0; gi < 5; ++gi)
-        a1[gi][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(w1b[j], xb[gi], a1[gi][j], 0, 0, 0);
+        a1[gi][j] = VNQA_MFMA_16x16x16(w1b[j], xb[gi], a1[gi][j]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 bb = *(const float4*)(ldsB1 + 16 * j + 4 * fh);
@@ -571,8 +571,8 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vnqa_bf16x8, wf[j]),
-                                                             __builtin_bit_cast(vnqa_bf16x8, xf[i]), acc[i][j], 0, 0, 0);
+          acc[i][j] = VNQA_MFMA_16x16x32(__builtin_bit_cast(vnqa_bf16x8, wf[j]),
+                                                             __builtin_bit_cast(vnqa_bf16x8, xf[i]), acc[i][j]);
     };
     load_step(0, wfa, xfa);
     __builtin_amdgcn_s_setprio(1);
@@ -704,8 +704,8 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
         float v[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[2 * e] = __uint_as_float(w4[e] << 16);
-          v[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+          v[2 * e] = h16_lo(w4[e]);
+          v[2 * e + 1] = h16_hi(w4[e]);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];

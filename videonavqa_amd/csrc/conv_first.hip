@@ -107,8 +107,8 @@ __global__ void __launch_bounds__(256) conv_first_kernel(const FirstArgs p) {
         vnqa_f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tn][0], xb[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tn][1], xb[1], acc, 0, 0, 0);
+        acc = VNQA_MFMA_32x32x16(wa[tn][0], xb[0], acc);
+        acc = VNQA_MFMA_32x32x16(wa[tn][1], xb[1], acc);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           uint2 pk;

@@ -34,12 +34,12 @@ template <typename T> struct Mma;
 template <> struct Mma<vnqa_bf16> {
   static constexpr int MT = kBf16Mt;
   static __device__ __forceinline__ void run(const vnqa_f32x4& a, const vnqa_f32x4& b, vnqa_f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(vnqa_bf16x8, a),
-                                                __builtin_bit_cast(vnqa_bf16x8, b), c, 0, 0, 0);
+    c = VNQA_MFMA_32x32x16(__builtin_bit_cast(vnqa_bf16x8, a),
+                                                __builtin_bit_cast(vnqa_bf16x8, b), c);
   }
   static __device__ __forceinline__ void run(const vnqa_f32x4& a, const vnqa_f32x4& b, vnqa_f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vnqa_bf16x8, a),
-                                                __builtin_bit_cast(vnqa_bf16x8, b), c, 0, 0, 0);
+    c = VNQA_MFMA_16x16x32(__builtin_bit_cast(vnqa_bf16x8, a),
+                                                __builtin_bit_cast(vnqa_bf16x8, b), c);
   }
 };
 template <int MT> struct AccOf { typedef vnqa_f32x16 type; };
@@ -504,10 +504,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
-            sub[j][g][0] = __uint_as_float(raw[j][g].x << 16);
-            sub[j][g][1] = __uint_as_float(raw[j][g].x & 0xffff0000u);
-            sub[j][g][2] = __uint_as_float(raw[j][g].y << 16);
-            sub[j][g][3] = __uint_as_float(raw[j][g].y & 0xffff0000u);
+            sub[j][g][0] = h16_lo(raw[j][g].x);
+            sub[j][g][1] = h16_hi(raw[j][g].x);
+            sub[j][g][2] = h16_lo(raw[j][g].y);
+            sub[j][g][3] = h16_hi(raw[j][g].y);
           }
       } else {
 #pragma unroll

@@ -40,8 +40,7 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ void mma16(const vnqa_f32x4& a, const vnqa_f32x4& b, vnqa_f32x4& c) {
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vnqa_bf16x8, a), __builtin_bit_cast(vnqa_bf16x8, b), c,
-                                              0, 0, 0);
+  c = VNQA_MFMA_16x16x32(__builtin_bit_cast(vnqa_bf16x8, a), __builtin_bit_cast(vnqa_bf16x8, b), c);
 }
 
 template <int TC, int TAG>

@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
           for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s & 1][i], bf[s & 1][j], acc16[i][j], 0, 0, 0);
+              acc16[i][j] = VNQA_MFMA_16x16x32(af[s & 1][i], bf[s & 1][j], acc16[i][j]);
         }
 #elif defined(VNQA_WGRAD_TR_BUILTIN) || !defined(VNQA_WGRAD_ROLLING)
 #pragma unroll
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
           for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc16[i][j], 0, 0, 0);
+              acc16[i][j] = VNQA_MFMA_16x16x32(af[i], bf[j], acc16[i][j]);
         }
 #else
         // (-DVNQA_WGRAD_ROLLING, measured +-2 % for look-aheads 2..5 and left off: the loop is bound by its LDS-DMA, not by
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
             const vnqa_bf16x8 af = vnqa_bf16x8{alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[j], acc16[i][j], 0, 0, 0);
+              acc16[i][j] = VNQA_MFMA_16x16x32(af, bf[j], acc16[i][j]);
             __builtin_amdgcn_sched_barrier(0);     // keep request i+3 behind these MFMAs in program order
           }
         }
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = VNQA_MFMA_32x32x16(af[i], bf[j], acc[i][j]);
         }
       } else {
 #pragma unroll 4
@@ -465,10 +465,10 @@ __device__ __forceinline__ void cs_load8(const T* p, float v[8]);
 template <>
 __device__ __forceinline__ void cs_load8<vnqa_bf16>(const vnqa_bf16* p, float v[8]) {
   const uint4 u = *(const uint4*)p;
-  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
-  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+  v[0] = h16_lo(u.x); v[1] = h16_hi(u.x);
+  v[2] = h16_lo(u.y); v[3] = h16_hi(u.y);
+  v[4] = h16_lo(u.z); v[5] = h16_hi(u.z);
+  v[6] = h16_lo(u.w); v[7] = h16_hi(u.w);
 }
 template <>
 __device__ __forceinline__ void cs_load8<float>(const float* p, float v[8]) {

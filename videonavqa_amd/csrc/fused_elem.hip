@@ -17,10 +17,10 @@ __device__ __forceinline__ void load8(const T* p, float v[8]);
 template <>
 __device__ __forceinline__ void load8<vnqa_bf16>(const vnqa_bf16* p, float v[8]) {
   const uint4 u = *(const uint4*)p;
-  v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
-  v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
-  v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
-  v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+  v[0] = h16_lo(u.x); v[1] = h16_hi(u.x);
+  v[2] = h16_lo(u.y); v[3] = h16_hi(u.y);
+  v[4] = h16_lo(u.z); v[5] = h16_hi(u.z);
+  v[6] = h16_lo(u.w); v[7] = h16_hi(u.w);
 }
 template <>
 __device__ __forceinline__ void load8<float>(const float* p, float v[8]) {

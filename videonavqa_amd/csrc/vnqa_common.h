@@ -35,6 +35,34 @@ typedef __attribute__((ext_vector_type(4))) float vnqa_f32x4;
 typedef __attribute__((ext_vector_type(16))) float vnqa_f32x16;
 typedef unsigned short vnqa_bf16;  // raw bits
 
+// ---- the library's 16-bit storage format -----------------------------------------------------------------------------
+// Every kernel treats its 16-bit elements through the helpers below (conversion, unpacking of two packed elements, the
+// three MFMA shapes), so ONE compile-time switch selects the format of the whole library:
+//   default            bf16  (8 exponent bits / 8 significand bits: the fp32 range, 2^-9 relative rounding)
+//   -DVNQA_H16_IS_F16  IEEE fp16 (5 / 11 bits: 2^-12 relative rounding — 8x finer — at the same MFMA rate; finite range
+//                      +-65504: conversions saturate instead of producing inf).  Built as libvnqa_hip_f16.so, selected by
+//                      precision='fp16' on the Python side; VNQA_BF16 then means "the library's 16-bit format".
+// (Names keep the historical `bf16`: f32_to_bf16 = fp32 -> storage format.)
+#ifdef VNQA_H16_IS_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 vnqa_f16x8_;
+typedef __attribute__((ext_vector_type(4))) _Float16 vnqa_f16x4_;
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);     // round-to-nearest-even, saturating
+  return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float h16_lo(unsigned w) { return bf16_to_f32((unsigned short)(w & 0xffffu)); }
+__device__ __forceinline__ float h16_hi(unsigned w) { return bf16_to_f32((unsigned short)(w >> 16)); }
+__device__ __forceinline__ vnqa_f32x4 VNQA_MFMA_16x16x32(vnqa_bf16x8 a, vnqa_bf16x8 b, vnqa_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vnqa_f16x8_, a), __builtin_bit_cast(vnqa_f16x8_, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ vnqa_f32x16 VNQA_MFMA_32x32x16(vnqa_bf16x8 a, vnqa_bf16x8 b, vnqa_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vnqa_f16x8_, a), __builtin_bit_cast(vnqa_f16x8_, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ vnqa_f32x4 VNQA_MFMA_16x16x16(vnqa_bf16x4 a, vnqa_bf16x4 b, vnqa_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(vnqa_f16x4_, a), __builtin_bit_cast(vnqa_f16x4_, b), c, 0, 0, 0);
+}
+#else
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
   return __uint_as_float(((unsigned)b) << 16);
 }
@@ -43,6 +71,19 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(unsigned short, h);
 }
+// the two elements packed in a 32-bit word
+__device__ __forceinline__ float h16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ vnqa_f32x4 VNQA_MFMA_16x16x32(vnqa_bf16x8 a, vnqa_bf16x8 b, vnqa_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ vnqa_f32x16 VNQA_MFMA_32x32x16(vnqa_bf16x8 a, vnqa_bf16x8 b, vnqa_f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ vnqa_f32x4 VNQA_MFMA_16x16x16(vnqa_bf16x4 a, vnqa_bf16x4 b, vnqa_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+#endif
 
 template <typename T> struct ElemOps;
 template <> struct ElemOps<vnqa_bf16> {

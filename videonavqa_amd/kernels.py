@@ -50,7 +50,7 @@ def pack_conv_weight_tiled(w_oihw, dtype, tile, out_scale=None, c_out_pad=None, 
     did = L.dtype_id(dtype)
     nbytes = L.lib().vnqa_conv_weight_tiled_bytes(c_out_pad, c_in_pad, taps, tile, did)
     assert nbytes > 0, "tile %d has no tiled weight layout" % tile
-    buf = torch.empty(nbytes // (2 if dtype == torch.bfloat16 else 4), dtype=dtype, device=w.device)
+    buf = torch.empty(nbytes // (2 if L.is_half(dtype) else 4), dtype=dtype, device=w.device)
     sc = out_scale.detach().float().contiguous() if out_scale is not None else None
     L.check(L.lib().vnqa_pack_conv_weight_tiled(L.ptr(w), c_out, c_in, taps, c_in_pad, L.ptr(sc), tile, did,
                                                 L.ptr(buf), L.stream()), "vnqa_pack_conv_weight_tiled")
@@ -206,7 +206,7 @@ def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2, Wp - 2
     c_out, taps, cin_w = wt.shape
-    assert Cin == 64 and cin_w == 64 and taps == 9 and x.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16
+    assert Cin == 64 and cin_w == 64 and taps == 9 and L.is_half(x.dtype) and wt.dtype == x.dtype
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
@@ -221,7 +221,7 @@ def clip_to_nhwc4(clip, img_of, n_img, out=None):
     B, C, H, W, T = clip.shape
     assert C == 3 and clip.dtype == torch.float32
     if out is None:
-        out = torch.zeros((n_img, H + 4, W + 4, 4), dtype=torch.bfloat16, device=clip.device)
+        out = torch.zeros((n_img, H + 4, W + 4, 4), dtype=L.half_dtype(), device=clip.device)
     L.check(L.lib().vnqa_clip_to_nhwc4(L.ptr(clip.contiguous()), L.ptr(img_of), L.ptr(out), B, T, H, W, L.stream()),
             "vnqa_clip_to_nhwc4")
     return out
@@ -233,7 +233,7 @@ def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_sc
     N, Hp4, Wp4, c4 = img4.shape
     H, W = Hp4 - 4, Wp4 - 4
     c_out, taps, cin_w = wt.shape
-    assert c4 == 4 and cin_w == 64 and taps == 9 and img4.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16
+    assert c4 == 4 and cin_w == 64 and taps == 9 and L.is_half(img4.dtype) and wt.dtype == img4.dtype
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=img4.dtype, device=img4.device)
@@ -258,11 +258,11 @@ def pack_fc_weight(w, C, h, wd, c_pad, rows_pad, dtype, want_t=True):
     return nat, nat_t
 
 
-def unpack_fc_wgrad(dw_nat, rows, C, h, wd, c_pad, out=None):
+def unpack_fc_wgrad(dw_nat, rows, C, h, wd, c_pad, out=None, alpha=1.0):
     """fp32 gradient of the native-layout weight [rows_pad, (h+2)(wd+2)*c_pad] -> [rows, C*h*wd]."""
     dw = out if out is not None else torch.empty((rows, C * h * wd), dtype=torch.float32, device=dw_nat.device)
     assert dw.shape == (rows, C * h * wd) and dw.is_contiguous() and dw.dtype == torch.float32
-    L.check(L.lib().vnqa_unpack_fc_wgrad(L.ptr(dw_nat), rows, C, h, wd, c_pad, L.ptr(dw), L.stream()),
+    L.check(L.lib().vnqa_unpack_fc_wgrad_scaled(L.ptr(dw_nat), rows, C, h, wd, c_pad, L.ptr(dw), float(alpha), L.stream()),
             "vnqa_unpack_fc_wgrad")
     return dw
 
@@ -340,15 +340,15 @@ def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None):
     return dwt, dbias
 
 
-def unpack_conv_wgrad(dwt, c_out, c_in, out=None):
+def unpack_conv_wgrad(dwt, c_out, c_in, out=None, alpha=1.0):
     """fp32 [c_out_pad][taps][c_in_pad] -> OIHW fp32 [c_out][c_in][k][k]."""
     c_out_pad, taps, c_in_pad = dwt.shape
     shape = {1: (1, 1), 9: (3, 3), 27: (3, 3, 3)}[taps]
     if out is None:
         out = torch.empty((c_out, c_in) + shape, dtype=torch.float32, device=dwt.device)
     assert out.shape == (c_out, c_in) + shape and out.is_contiguous() and out.dtype == torch.float32
-    L.check(L.lib().vnqa_unpack_conv_wgrad(L.ptr(dwt), c_out, c_in, taps, c_out_pad, c_in_pad, L.ptr(out),
-                                           L.stream()), "vnqa_unpack_conv_wgrad")
+    L.check(L.lib().vnqa_unpack_conv_wgrad_scaled(L.ptr(dwt), c_out, c_in, taps, c_out_pad, c_in_pad, L.ptr(out),
+                                                  float(alpha), L.stream()), "vnqa_unpack_conv_wgrad")
     return out
 
 
@@ -712,13 +712,14 @@ def temporal_attn_packed_fwd(f, frame_off_i32, n_frames, B, T, A, w, bias):
     return coef, ctxt
 
 
-def temporal_attn_packed_bwd(f, frame_off_i32, n_frames, B, T, A, w, coef, dctxt):
+def temporal_attn_packed_bwd(f, frame_off_i32, n_frames, B, T, A, w, coef, dctxt, grad_scale=1.0):
     df = torch.empty_like(f)
     dw_part = torch.empty((B, A), dtype=torch.float32, device=f.device)
     db_part = torch.empty((B, 1), dtype=torch.float32, device=f.device)
     L.check(L.lib().vnqa_temporal_attn_packed_bwd(L.ptr(f), f.stride(0), L.dtype_id(f.dtype), L.ptr(frame_off_i32), n_frames,
                                                   L.ptr(w), L.ptr(coef), L.ptr(dctxt), L.ptr(df), L.ptr(dw_part),
-                                                  L.ptr(db_part), B, T, A, L.stream()), "vnqa_temporal_attn_packed_bwd")
+                                                  L.ptr(db_part), B, T, A, float(grad_scale), L.stream()),
+            "vnqa_temporal_attn_packed_bwd")
     return df, dw_part, db_part
 
 

@@ -27,10 +27,24 @@ BN_MOMENTUM = 0.1
 
 def compute_dtype(precision):
     if precision in ("bf16", torch.bfloat16):
+        L.set_half("bf16")
         return torch.bfloat16
+    if precision in ("fp16", "f16", torch.float16):      # the fp16-storage build of the library (csrc/vnqa_common.h)
+        L.set_half("f16")
+        return torch.float16
     if precision in ("fp32", "f32", torch.float32):
         return torch.float32
-    raise ValueError("precision must be 'bf16' or 'fp32' (got %r)" % (precision,))
+    raise ValueError("precision must be 'bf16', 'fp16' or 'fp32' (got %r)" % (precision,))
+
+
+# Loss scale of the fp16-storage precision: the activation gradients that enter the conv trunk from the attention tail are
+# 1e-5 .. 1e-7 here — at or below fp16's normal range (6.1e-5) — so the tail's backward kernel emits them multiplied by
+# 2^10 (exact) and every fp32 result computed from them (weight / bias / gamma / beta gradients) is divided by it again.
+FP16_GRAD_SCALE = 1024.0
+
+
+def grad_scale_of(dtype):
+    return FP16_GRAD_SCALE if dtype == torch.float16 else 1.0
 
 
 def reference_init_(module):
@@ -360,7 +374,7 @@ class FiLMTrunkBase(nn.Module):
         ql_i32, rows = tbl[:B], tbl[B:]
         xg = ops.embed_proj(q_input, self.embed.weight, lstm.weight_ih_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, padding_idx)
         h0, c0 = self._question_state(B, H, q_lens, dev)
-        hs, hn, cn = ops.lstm_seq(xg, lstm.weight_hh_l0, h0, c0, ql_i32, lay.n_frames, S, self.compute_dtype)
+        hs, hn, cn = ops.lstm_seq(xg, lstm.weight_hh_l0, h0, c0, ql_i32, lay.n_frames, S, self._lstm_wgrad_dtype())
         self._store_question_state(hn, cn, q_lens)
         return ops.linear(hs.view(B * S, H), proj.weight, proj.bias, relu=True, rows=rows)
 
@@ -379,7 +393,8 @@ class FiLMTrunkBase(nn.Module):
                 uniq.append(t)
             film_map.append((i, int(col)))
         uniq = [u if (u.dtype == torch.float32 and u.stride(1) == 1) else u.float().contiguous() for u in uniq]
-        meta = ops.TrunkMeta(lay, C, self.num_res_blocks, len(uniq), film_map, BN_EPS)
+        meta = ops.TrunkMeta(lay, C, self.num_res_blocks, len(uniq), film_map, BN_EPS,
+                             grad_scale=getattr(self, "_trunk_grad_scale", 1.0))
         blocks = []
         for k in range(self.num_res_blocks):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
@@ -396,6 +411,10 @@ class FiLMTrunkBase(nn.Module):
         with torch.no_grad():
             K.bn_running_update(mean, var, lay.frame_off_i32, lay.n_frames, S, bn.running_mean, bn.running_var, BN_MOMENTUM)
             bn.num_batches_tracked += lay.n_frames
+
+    def _lstm_wgrad_dtype(self):
+        """Operand type of the LSTMs' dW_hh GEMM: the compute dtype, except fp16 (gate gradients underflow it: exact f32)."""
+        return torch.float32 if self.compute_dtype == torch.float16 else self.compute_dtype
 
     def _use_fused_trunk(self):
         import os

@@ -5,7 +5,7 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from .. import ops
-from .common import (FiLMTrunkBase, NativeFeatures, compute_dtype, repeated_question_lstm)
+from .common import (FiLMTrunkBase, NativeFeatures, compute_dtype, grad_scale_of, repeated_question_lstm)
 
 NEG_MASK = float(-(1 << 31))  # film_attn_pt_stem.py:251
 
@@ -65,6 +65,9 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         C = self.num_res_block_channels
 
         fused = self._use_fused_trunk()
+        # fp16 storage: the tail's backward emits d f times 2^10, FcNativeFn / FilmTrunkFn divide their fp32 results by it
+        gscale = grad_scale_of(self.compute_dtype) if fused else 1.0
+        self._trunk_grad_scale = gscale
         if fused:       # train mode: generator and conv trunk on fused HIP ops (one autograd node for the trunk)
             film_img = self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay)
             x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])   # :229-233
@@ -74,7 +77,7 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
                 emb = self.embed(q_input)
                 h0, c0 = self._question_state(B, self.hidden_size, q_lens, dev)
                 h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
-                                                              wgrad_dtype=self.compute_dtype)
+                                                              wgrad_dtype=self._lstm_wgrad_dtype())
                 self._store_question_state(hn, cn, q_lens)
                 film = F.relu(self.film_layer[1](h_last))                   # [B, n_frames, 2*C*blocks] (:179)
                 return film[lay.sample_of, lay.frame_of]                    # [n_img, 2*C*blocks]
@@ -93,14 +96,14 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         n_img, hp, wp, c_pad = x.shape
         at = self.at_hidden_size
         at_pad = L.round_up(at, 64)
-        f = ops.fc_native(x.view(n_img, -1), self.fc_embed_attn.weight, self.fc_embed_attn.bias, C, h, w, at_pad)
+        f = ops.fc_native(x.view(n_img, -1), self.fc_embed_attn.weight, self.fc_embed_attn.bias, C, h, w, at_pad, gscale)
         if fused:
             # temporal attention (:245-290) straight from the packed GEMM output: the zero-padded [B,T,at] tensor, the
             # validity grid and the -(1<<31) masks are formed inside the kernel.  v_i = fc_hidden_attn(h) is constant along
             # the frame axis and softmax is shift invariant, so coefs/ctxt are identical at every step of the
             # :283 loop and are computed once (fc_hidden_attn consequently receives a zero gradient).
             ctxt, coefs = ops.temporal_attention_packed(f, lay.frame_off_i32, lay.n_frames, B, T, at,
-                                                        self.fc_attn_1.weight, self.fc_attn_1.bias)
+                                                        self.fc_attn_1.weight, self.fc_attn_1.bias, gscale)
             # the 35-step LSTMCell chain on a constant input = the persistent LSTM kernel with one "token" repeated T
             # times (:283,293-298); input projection and classifier (:301) on the fp32 HIP GEMM
             gi = ops.linear(ctxt, self.lstm_attn.weight_ih, self.lstm_attn.bias_ih + self.lstm_attn.bias_hh)
@@ -108,7 +111,7 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
             ones = self.__dict__.get("_ones_i32")
             if ones is None or ones.numel() != B or ones.device != dev:
                 ones = self.__dict__["_ones_i32"] = torch.ones(B, dtype=torch.int32, device=dev)
-            hs, _, _ = ops.lstm_seq(gi.unsqueeze(1), self.lstm_attn.weight_hh, z, z, ones, T, T, self.compute_dtype)
+            hs, _, _ = ops.lstm_seq(gi.unsqueeze(1), self.lstm_attn.weight_hh, z, z, ones, T, T, self._lstm_wgrad_dtype())
             return ops.linear(hs.view(B, T * at), self.out_linear.weight, self.out_linear.bias)      # :301
         f = f[:, :at].float()
         all_features = torch.zeros(B, T, at, device=dev).index_put((lay.sample_of, lay.frame_of), f)  # :245-256

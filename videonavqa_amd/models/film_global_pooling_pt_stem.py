@@ -55,7 +55,7 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
             emb = self.embed(q_input)
             h0, c0 = self._question_state(lay.B, self.hidden_size, q_lens, dev)
             h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
-                                                          wgrad_dtype=self.compute_dtype)
+                                                          wgrad_dtype=self._lstm_wgrad_dtype())
             self._store_question_state(hn, cn, q_lens)
             film = F.relu(self.film_layer[1](h_last))
             return film[lay.sample_of, lay.frame_of]

@@ -55,7 +55,7 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
         emb = self.embed(q_input)
         h0, c0 = self._question_state(B, Hq, q_lens, x.device)
         h_last, states, (hn, cn) = repeated_question_lstm(self.q_encoder, emb, q_lens, Fn, h0, c0,
-                                                          want_states=True, wgrad_dtype=self.compute_dtype)
+                                                          want_states=True, wgrad_dtype=self._lstm_wgrad_dtype())
         self._store_question_state(hn, cn, q_lens)
         enc = self.encoder_norm(h_last)                                   # [B,F,H]   :148
         # per-image context, reset at every frame (:157-158); the hop chain runs over blocks

@@ -183,7 +183,7 @@ class FilmTrunkFn(torch.autograd.Function):
         b0 = K.pad_vec(conv_b, c_pad)
         S = (x.shape[1] - 2) * (x.shape[2] - 2)
         fused = None
-        if cdt == torch.bfloat16:       # fp32 (parity) precision keeps the exact two-pass statistics kernel
+        if L.is_half(cdt):              # fp32 (parity) precision keeps the exact two-pass statistics kernel
             fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts))
         if fused is None:
             r = K.conv2d_igemm(x, wt0, bias=b0, relu=True)
@@ -225,6 +225,9 @@ class FilmTrunkFn(torch.autograd.Function):
         cdt = x.dtype
         c_pad = L.round_up(C, 64)
         dout = dout.contiguous()
+        inv = 1.0 / meta.grad_scale
+        scaled = meta.grad_scale != 1.0
+        sinks = [None] * len(ctx.sinks) if scaled else ctx.sinks      # (scaled small vectors go through a temporary)
         # a FiLM matrix whose every column is some block's gamma or beta needs no zero fill (attention / pooling models:
         # ONE matrix [n_img, 2*C*blocks]); multi-hop's per-block matrices are only partly written
         covered = nf == 1 and films[0].shape[1] == 2 * C * blocks and \
@@ -240,23 +243,27 @@ class FilmTrunkFn(torch.autograd.Function):
             dfilm = dfilms[fi] if dfilms[fi] is not None else torch.empty_like(film)
             dz = K.film_relu_res_bwd_ld(dout, z, film[:, col:col + C], film[:, col + C:col + 2 * C], C,
                                         dfilm[:, col:col + C], dfilm[:, col + C:col + 2 * C])
-            sw, sb = ctx.sinks[4 + 2 * k], ctx.sinks[5 + 2 * k]
+            sw, sb = ctx.sinks[4 + 2 * k], sinks[5 + 2 * k]
             dwt, dbias = K.conv2d_wgrad(res, dz, 9, dbias_out=_into(sb))
-            grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw)))
+            grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw), alpha=inv))
             direct_b = sb is not None and dbias.data_ptr() == sb.view.data_ptr()      # (only without channel padding)
-            grads_blocks[4 * k + 3] = _ret(sb if direct_b else None, dbias[:C])
+            grads_blocks[4 * k + 3] = _ret(sb if direct_b else None, dbias[:C] * inv if scaled else dbias[:C])
             dres = K.conv2d_igemm(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
             gsum = K.relu_bwd(dres, res, dout)             # (dres + dout) * [res > 0]: residual join + the 1x1 conv's ReLU
             # (the 1x1 convs are frozen upstream — never in parameters() — so they get no weight gradient)
             dout = K.conv2d_igemm(gsum, K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
         dr, s1, s2 = K.frame_bn_bwd(dout, r, lay.frame_of_i32, lay.frame_off_i32, mean, rstd, g, lay.n_frames, True)
-        s_cw, s_cb, s_bw, s_bb = ctx.sinks[:4]
+        s_cw = ctx.sinks[0]
+        s_cb, s_bw, s_bb = sinks[1:4]
         exact = c_pad == C
         dbn_w = _ret(s_bw if exact else None, K.colsum(s2, out=_into(s_bw) if exact else None)[:C])
         dbn_b = _ret(s_bb if exact else None, K.colsum(s1, out=_into(s_bb) if exact else None)[:C])
         dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None)
-        dconv_w = _ret(s_cw, K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw)))
+        dconv_w = _ret(s_cw, K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw), alpha=inv))
         dconv_b = _ret(s_cb if exact else None, dbias0[:C])
+        if scaled:
+            dbn_w, dbn_b, dconv_b = dbn_w * inv, dbn_b * inv, dconv_b * inv
+            dfilms = [None if t is None else t.mul_(inv) for t in dfilms]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_igemm(dr, K.pack_conv_weight(conv_w, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=x.shape[-1]))
@@ -266,9 +273,12 @@ class FilmTrunkFn(torch.autograd.Function):
 class TrunkMeta(object):
     """Non-tensor arguments of FilmTrunkFn."""
 
-    def __init__(self, layout, channels, blocks, n_film, film_map, eps):
+    def __init__(self, layout, channels, blocks, n_film, film_map, eps, grad_scale=1.0):
         self.layout, self.channels, self.blocks, self.n_film, self.film_map, self.eps = \
             layout, channels, blocks, n_film, film_map, eps
+        # incoming d(out) is `grad_scale` times the true gradient (fp16 loss scale): every fp32 parameter / FiLM gradient
+        # leaving the node is divided by it, the activation gradients inside stay scaled
+        self.grad_scale = float(grad_scale)
 
 
 def film_trunk(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors):
@@ -504,7 +514,8 @@ class FcNativeFn(torch.autograd.Function):
     weight gradient returns to the parameter layout in one kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, C, h, w, rows_pad):
+    def forward(ctx, x, weight, bias, C, h, w, rows_pad, grad_scale=1.0):
+        ctx.grad_scale = float(grad_scale)      # d(out) arrives multiplied by this (fp16 loss scale): dW, db are divided by it
         rows = weight.shape[0]
         c_pad = x.shape[1] // ((h + 2) * (w + 2))
         need_dx = ctx.needs_input_grad[0]
@@ -525,13 +536,16 @@ class FcNativeFn(torch.autograd.Function):
         dx = K.gemm_nt(dout, nat_t) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = _ret(ctx.sink_w, K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad, out=_into(ctx.sink_w)))
+            dw = _ret(ctx.sink_w, K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad, out=_into(ctx.sink_w),
+                                                    alpha=1.0 / ctx.grad_scale))
         db = K.colsum(dout)[:rows] if ctx.needs_input_grad[2] else None
-        return dx, dw, db, None, None, None, None
+        if db is not None and ctx.grad_scale != 1.0:
+            db = db * (1.0 / ctx.grad_scale)
+        return dx, dw, db, None, None, None, None, None
 
 
-def fc_native(x, weight, bias, C, h, w, rows_pad):
-    return FcNativeFn.apply(x, weight, bias, C, h, w, rows_pad)
+def fc_native(x, weight, bias, C, h, w, rows_pad, grad_scale=1.0):
+    return FcNativeFn.apply(x, weight, bias, C, h, w, rows_pad, grad_scale)
 
 
 class MacCoreState(object):
@@ -829,7 +843,8 @@ class TemporalAttnPackedFn(torch.autograd.Function):
     f [n_img, ld] (compute dtype): no dense [B,T,A] scatter, validity grid or mask tensors."""
 
     @staticmethod
-    def forward(ctx, f, frame_off_i32, n_frames, B, T, A, w, bias):
+    def forward(ctx, f, frame_off_i32, n_frames, B, T, A, w, bias, grad_scale=1.0):
+        ctx.grad_scale = float(grad_scale)      # d f leaves the backward kernel multiplied by this (fp16 loss scale)
         w1 = w.reshape(-1)
         b1 = bias.reshape(-1)
         coef, ctxt = K.temporal_attn_packed_fwd(f, frame_off_i32, n_frames, B, T, A, w1, b1)
@@ -842,12 +857,13 @@ class TemporalAttnPackedFn(torch.autograd.Function):
     def backward(ctx, dctxt, _dcoef):
         f, frame_off_i32, w1, coef = ctx.saved_tensors
         n_frames, B, T, A = ctx.dims
-        df, dw_part, db_part = K.temporal_attn_packed_bwd(f, frame_off_i32, n_frames, B, T, A, w1, coef, dctxt.contiguous())
-        return df, None, None, None, None, None, K.colsum(dw_part).view(ctx.w_shape), K.colsum(db_part)
+        df, dw_part, db_part = K.temporal_attn_packed_bwd(f, frame_off_i32, n_frames, B, T, A, w1, coef, dctxt.contiguous(),
+                                                          ctx.grad_scale)
+        return df, None, None, None, None, None, K.colsum(dw_part).view(ctx.w_shape), K.colsum(db_part), None
 
 
-def temporal_attention_packed(f, frame_off_i32, n_frames, B, T, A, w, bias):
-    return TemporalAttnPackedFn.apply(f, frame_off_i32, n_frames, B, T, A, w, bias)
+def temporal_attention_packed(f, frame_off_i32, n_frames, B, T, A, w, bias, grad_scale=1.0):
+    return TemporalAttnPackedFn.apply(f, frame_off_i32, n_frames, B, T, A, w, bias, grad_scale)
 
 
 class CrossEntropyFn(torch.autograd.Function):

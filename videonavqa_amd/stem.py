@@ -76,7 +76,8 @@ class FrozenStem(object):
     """Execution plan (packed weights + persistent activation buffers) for the frozen stem."""
 
     def __init__(self, vgg, objdet, precision='bf16'):
-        self.cdt = torch.bfloat16 if precision in ("bf16", torch.bfloat16) else torch.float32
+        from .models.common import compute_dtype
+        self.cdt = compute_dtype(precision)
         self.vgg, self.objdet = vgg, objdet
         self.layers_vgg, self.layers_od = [], []
         self.composed = None
@@ -121,7 +122,7 @@ class FrozenStem(object):
         if bn is not None:
             scale, shift = _fold_bn(bn)
             b = b * scale + shift
-        bf16 = self.cdt == torch.bfloat16
+        bf16 = L.is_half(self.cdt)      # 16-bit storage (bf16 or, in the fp16 build, fp16): the MFMA fast path
         if bf16 and c_in_pad == 64:
             tile = None                      # conv_c64 direct kernel (row layout, LDS-resident weights)
         elif bf16:
@@ -165,7 +166,7 @@ class FrozenStem(object):
         bc = b2 + w2.sum((2, 3)) @ b1
         co, ci, cm = wc.shape[0], wc.shape[1], w1.shape[0]
         co_pad, ci_pad, cm_pad = L.round_up(co, 64), L.round_up(ci, 64), L.round_up(cm, 64)
-        bf16 = self.cdt == torch.bfloat16
+        bf16 = L.is_half(self.cdt)
         tile = L.TILE_STEM_256x256 if (bf16 and co_pad >= 256) else (L.TILE_AUTO if bf16 else L.TILE_128x128)
         if bf16 and os.environ.get("VNQA_STEM_COMPOSE_TILE"):
             tile = int(os.environ["VNQA_STEM_COMPOSE_TILE"])      # A/B hook
@@ -263,7 +264,7 @@ class FrozenStem(object):
         assert self.vgg is not None and self.objdet is not None
         B, _, H, W, T = clip.shape
         ly = self.layers_vgg[0]
-        if self.cdt == torch.bfloat16 and ly["tile"] is None and os.environ.get("VNQA_FUSE_FIRST", "1") != "0":
+        if L.is_half(self.cdt) and ly["tile"] is None and os.environ.get("VNQA_FUSE_FIRST", "1") != "0":
             # conv1_1 evaluated inside the conv1_2 kernel from a 4-channel bf16 image list: its 64-channel output
             # (1.8 GB at 280 x 224 x 224) never goes to HBM
             img4 = self._buf(("img4", H, W), (n_img, H + 4, W + 4, 4))
