@@ -623,8 +623,9 @@ def main():
                                                                  / 1e12 / peak, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "kernel": "conv_igemm_kernel<bf16,256,256,2,4,TAG=1> (frozen-stem igemm on v_mfma_f32_16x16x32_bf16: "
-                                   "the C_out=512 layers; FLOPs = those its launches execute)",
+                         "kernel": "conv_igemm_kernel<%s,256,256,2,4,TAG=1> (frozen-stem igemm on v_mfma_f32_16x16x32_%s: "
+                                   "the C_out=512 layers; FLOPs = those its launches execute)"
+                                   % (("f16", "f16") if args.precision == "fp16" else ("bf16", "bf16")),
                          "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
                          "gflop_per_launch": round(flops_per_launch / 1e9, 1)},
         }

@@ -197,8 +197,8 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
         a1 = VNQA_MFMA_16x16x32(w1f[j], xb, a1);
         uint2 pk = make_uint2(0u, 0u);
         if (inside) {
-          pk.x = (unsigned)f32_to_bf16(fmaxf(a1[0] + b1r[j][0], 0.f)) | ((unsigned)f32_to_bf16(fmaxf(a1[1] + b1r[j][1], 0.f)) << 16);
-          pk.y = (unsigned)f32_to_bf16(fmaxf(a1[2] + b1r[j][2], 0.f)) | ((unsigned)f32_to_bf16(fmaxf(a1[3] + b1r[j][3], 0.f)) << 16);
+          pk.x = pack2_h16(fmaxf(a1[0] + b1r[j][0], 0.f), fmaxf(a1[1] + b1r[j][1], 0.f));
+          pk.y = pack2_h16(fmaxf(a1[2] + b1r[j][2], 0.f), fmaxf(a1[3] + b1r[j][3], 0.f));
         }
         if (pr < PROWS)
           *(uint2*)(ldsP + pr * 128 + (((2 * j + (fh >> 1)) ^ swz128(pr)) << 4) + ((fh & 1) << 3)) = pk;
@@ -295,8 +295,8 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
           if (p.relu) v[e] = fmaxf(v[e], 0.f);
         }
         uint2 pk;
-        pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        pk.x = pack2_h16(v[0], v[1]);
+        pk.y = pack2_h16(v[2], v[3]);
         *(uint2*)(ldsC + m * CROW + (wn * 32 + 16 * j + 4 * fh) * 2) = pk;
       }
     }
@@ -343,10 +343,10 @@ __global__ void __launch_bounds__(NW * 64) conv_c64_kernel(const C64Args p) {
         for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
       }
       uint4 o;
-      o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-      o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-      o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-      o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+      o.x = pack2_h16(v[0], v[1]);
+      o.y = pack2_h16(v[2], v[3]);
+      o.z = pack2_h16(v[4], v[5]);
+      o.w = pack2_h16(v[6], v[7]);
       unsigned short* dst = (unsigned short*)p.y +
                             (((size_t)n * p.Hyp + oy + 1) * p.Wyp + ox + 1) * (size_t)p.Cy + co0;
       *(uint4*)dst = o;
@@ -510,8 +510,8 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
       for (int gi = 0; gi < 5; ++gi) {
         uint2 pk = make_uint2(0u, 0u);
         if (ins[gi]) {
-          pk.x = (unsigned)f32_to_bf16(fmaxf(a1[gi][j][0] + bb.x, 0.f)) | ((unsigned)f32_to_bf16(fmaxf(a1[gi][j][1] + bb.y, 0.f)) << 16);
-          pk.y = (unsigned)f32_to_bf16(fmaxf(a1[gi][j][2] + bb.z, 0.f)) | ((unsigned)f32_to_bf16(fmaxf(a1[gi][j][3] + bb.w, 0.f)) << 16);
+          pk.x = pack2_h16(fmaxf(a1[gi][j][0] + bb.x, 0.f), fmaxf(a1[gi][j][1] + bb.y, 0.f));
+          pk.y = pack2_h16(fmaxf(a1[gi][j][2] + bb.z, 0.f), fmaxf(a1[gi][j][3] + bb.w, 0.f));
         }
         const int pr = prs[gi];
         if (pr < PROWS_W)
@@ -642,8 +642,8 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
             for (int e = 0; e < 4; ++e)
               v[e] = bf16_to_f32(f32_to_bf16(v[e])) * p.post_scale[co + e] + p.post_shift[co + e];
           }
-          P[j].x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-          P[j].y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          P[j].x = pack2_h16(v[0], v[1]);
+          P[j].y = pack2_h16(v[2], v[3]);
         }
         // this lane stores j = 2 hp + q; its partner lane ^ 16 stores j = 2 (1 - hp) + q and needs this lane's group of it
         const uint2 lo = q ? P[1] : P[0], hi = q ? P[3] : P[2];
@@ -677,8 +677,8 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
           }
           uint2 pk;
-          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          pk.x = pack2_h16(v[0], v[1]);
+          pk.y = pack2_h16(v[2], v[3]);
           *(uint2*)(ldsC + m * CROW + (16 * j + 4 * fh) * 2) = pk;
         }
       }
@@ -709,10 +709,10 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
-        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-        o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-        o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+        o.x = pack2_h16(v[0], v[1]);
+        o.y = pack2_h16(v[2], v[3]);
+        o.z = pack2_h16(v[4], v[5]);
+        o.w = pack2_h16(v[6], v[7]);
       }
       unsigned short* dst = (unsigned short*)p.y + (((size_t)n * p.Hyp + oy + 1) * p.Wyp + ox + 1) * (size_t)p.Cy + co0;
       *(uint4*)dst = o;
@@ -741,7 +741,7 @@ __global__ void __launch_bounds__(256) clip_to_nhwc4_kernel(const float* __restr
     const int img = img_of[b * T + t];
     if (img < 0) continue;
     uint2 o;
-    o.x = (unsigned)f32_to_bf16(stage[px * T + t]) | ((unsigned)f32_to_bf16(stage[32 * T + px * T + t]) << 16);
+    o.x = pack2_h16(stage[px * T + t], stage[32 * T + px * T + t]);
     o.y = (unsigned)f32_to_bf16(stage[2 * 32 * T + px * T + t]);
     *(uint2*)(out + ((((size_t)img * (H + 4)) + y + 2) * (W + 4) + x0 + px + 2) * 4) = o;
   }

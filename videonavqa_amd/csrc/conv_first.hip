@@ -116,8 +116,8 @@ __global__ void __launch_bounds__(256) conv_first_kernel(const FirstArgs p) {
           const float v1 = fmaxf(acc[4 * g + 1] + bias4[tn][g][1], 0.f);
           const float v2 = fmaxf(acc[4 * g + 2] + bias4[tn][g][2], 0.f);
           const float v3 = fmaxf(acc[4 * g + 3] + bias4[tn][g][3], 0.f);
-          pk.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
-          pk.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+          pk.x = pack2_h16(v0, v1);
+          pk.y = pack2_h16(v2, v3);
           *(uint2*)(ctile + col * 144 + (tn * 32 + 8 * g + 4 * h) * 2) = pk;
         }
       }

@@ -536,8 +536,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
         char* dst = smem + prow * CROW + col * ES;
         if constexpr (ES == 2) {
           uint2 pk;
-          pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-          pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+          pk.x = pack2_h16(v[0], v[1]);
+          pk.y = pack2_h16(v[2], v[3]);
           *(uint2*)dst = pk;
         } else {
           *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);

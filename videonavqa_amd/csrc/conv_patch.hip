@@ -231,8 +231,8 @@ __global__ void __launch_bounds__(NT) conv_patch_kernel(const ConvArgs p) {
         if (p.relu) v[e] = fmaxf(v[e], 0.f);
       }
       uint2 pk;
-      pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-      pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+      pk.x = pack2_h16(v[0], v[1]);
+      pk.y = pack2_h16(v[2], v[3]);
       *(uint2*)(smem + prow * CROW + col * 2) = pk;
     }
   }

@@ -36,10 +36,10 @@ template <> struct Row8<vnqa_bf16> {
   }
   static __device__ __forceinline__ void store(vnqa_bf16* p, const float v[8]) {
     uint4 u;
-    u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-    u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-    u.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-    u.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    u.x = pack2_h16(v[0], v[1]);
+    u.y = pack2_h16(v[2], v[3]);
+    u.z = pack2_h16(v[4], v[5]);
+    u.w = pack2_h16(v[6], v[7]);
     *(uint4*)p = u;
   }
 };

@@ -40,7 +40,7 @@ typedef unsigned short vnqa_bf16;  // raw bits
 // three MFMA shapes), so ONE compile-time switch selects the format of the whole library:
 //   default            bf16  (8 exponent bits / 8 significand bits: the fp32 range, 2^-9 relative rounding)
 //   -DVNQA_H16_IS_F16  IEEE fp16 (5 / 11 bits: 2^-12 relative rounding — 8x finer — at the same MFMA rate; finite range
-//                      +-65504: conversions saturate instead of producing inf).  Built as libvnqa_hip_f16.so, selected by
+//                      +-65504; larger magnitudes become inf, as in any IEEE fp16 pipeline).  Built as libvnqa_hip_f16.so, selected by
 //                      precision='fp16' on the Python side; VNQA_BF16 then means "the library's 16-bit format".
 // (Names keep the historical `bf16`: f32_to_bf16 = fp32 -> storage format.)
 #ifdef VNQA_H16_IS_F16
@@ -48,8 +48,14 @@ typedef __attribute__((ext_vector_type(8))) _Float16 vnqa_f16x8_;
 typedef __attribute__((ext_vector_type(4))) _Float16 vnqa_f16x4_;
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  const _Float16 h = (_Float16)__builtin_amdgcn_fmed3f(f, -65504.f, 65504.f);     // round-to-nearest-even, saturating
-  return __builtin_bit_cast(unsigned short, h);
+  return __builtin_bit_cast(unsigned short, (_Float16)f);          // round-to-nearest-even; |f| > 65504 -> inf (IEEE)
+}
+// two elements -> one 32-bit word (low half = a): one packed conversion instead of two conversions + a pack
+typedef __attribute__((ext_vector_type(2))) _Float16 vnqa_f16x2_;
+typedef __attribute__((ext_vector_type(2))) float vnqa_f32x2_;
+__device__ __forceinline__ unsigned pack2_h16(float a, float b) {
+  const vnqa_f32x2_ v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, vnqa_f16x2_));
 }
 __device__ __forceinline__ float h16_lo(unsigned w) { return bf16_to_f32((unsigned short)(w & 0xffffu)); }
 __device__ __forceinline__ float h16_hi(unsigned w) { return bf16_to_f32((unsigned short)(w >> 16)); }
@@ -70,6 +76,9 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ unsigned pack2_h16(float a, float b) {
+  return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);      // (the compiler fuses this into v_cvt_pk_bf16_f32)
 }
 // the two elements packed in a 32-bit word
 __device__ __forceinline__ float h16_lo(unsigned w) { return __uint_as_float(w << 16); }
