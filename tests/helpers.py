@@ -6,6 +6,12 @@ import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+# The 16-bit precision the GPU tests exercise next to fp32: 'bf16' (libvnqa_hip.so) by default; VNQA_TEST_LOW_PRECISION=fp16
+# re-runs the very same tests on the fp16-storage build (libvnqa_hip_f16.so) — one 16-bit storage format per process, so that
+# run is a separate pytest process (tests/test_gpu_fp16.py starts it).
+LOW = os.environ.get("VNQA_TEST_LOW_PRECISION", "bf16")
+LOW_DTYPE = torch.float16 if LOW == "fp16" else torch.bfloat16
+
 
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))

@@ -4,11 +4,13 @@ summation order differs); bf16 path is checked against the reference evaluated o
 bf16-rounded operands, 1e-2 relative (bf16 output rounding = 2^-9)."""
 import pytest
 import torch
+
+from helpers import LOW, LOW_DTYPE
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, LOW_DTYPE]
 
 
 def _tol(dt):
@@ -72,7 +74,7 @@ def test_conv_igemm_tiles_agree(tile):
     N, H, W, Cin, Cout = 4, 14, 14, 128, 256
     x = torch.randn(N, Cin, H, W, generator=g).cuda()
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
-    dt = torch.bfloat16
+    dt = LOW_DTYPE
     ref = F.relu(F.conv2d(_q(x, dt), _q(w, dt), None, padding=1))
     y = K.conv2d_igemm(K.nchw_to_nhwc(x, dt, c_pad=Cin), K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=Cin),
                        relu=True, tile=tile)
@@ -201,7 +203,7 @@ def test_conv_igemm_ring_pipeline(tile, cfg):
     """4-stage ring / counted-vmcnt main loop: short K loops (1..3 stages), pooling, 1x1, ragged tiles."""
     from videonavqa_amd import kernels as K
     N, H, W, Cin, Cout, taps, relu, pool = cfg
-    dt = torch.bfloat16
+    dt = LOW_DTYPE
     g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]) + tile)
     k = 3 if taps == 9 else 1
     x = torch.randn(N, Cin, H, W, generator=g).cuda()
@@ -229,7 +231,7 @@ def test_conv_igemm_ring_pipeline(tile, cfg):
 def test_conv_c64_direct_vs_torch(cfg, shape4):
     from videonavqa_amd import kernels as K
     N, H, W, Cout, relu, pool, post = cfg
-    dt = torch.bfloat16
+    dt = LOW_DTYPE
     g = torch.Generator(device="cpu").manual_seed(sum(cfg[:4]))
     x = torch.randn(N, 64, H, W, generator=g).cuda()
     w = (torch.randn(Cout, 64, 3, 3, generator=g) / 24.0).cuda()
@@ -283,7 +285,7 @@ def test_conv_patch_tile_vs_torch(tile, cfg):
     """LDS-resident activation patch igemm (conv_patch.hip) vs torch on the same bf16-rounded operands."""
     from videonavqa_amd import kernels as K
     N, H, W, Cin, Cout, relu, pool, post = cfg
-    dt = torch.bfloat16
+    dt = LOW_DTYPE
     g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]) + tile)
     x = torch.randn(N, Cin, H, W, generator=g).cuda()
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
@@ -315,7 +317,7 @@ def test_conv_patch_tile_vs_torch(tile, cfg):
 def test_conv_patch_tile_rejects_unsupported_geometry():
     from videonavqa_amd import kernels as K
     from videonavqa_amd._lib import VnqaError
-    dt = torch.bfloat16
+    dt = LOW_DTYPE
     x = torch.zeros(2, 12, 15, 64, dtype=dt, device="cuda")      # 10x13 maps: width not a multiple of 14
     wt = torch.zeros(64, 9, 64, dtype=dt, device="cuda")
     with pytest.raises(VnqaError):
@@ -333,7 +335,7 @@ def test_conv_first_fused_into_c64(cfg):
     torch on the same bf16-rounded operands, and vs the two-launch HIP path."""
     from videonavqa_amd import kernels as K
     B, T, H, W, Cout, pool, ragged = cfg
-    dt = torch.bfloat16
+    dt = LOW_DTYPE
     g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]))
     clip = torch.rand(B, 3, H, W, T, generator=g).cuda()
     w1 = (torch.randn(64, 3, 3, 3, generator=g) * 0.3).cuda()
@@ -404,7 +406,7 @@ def test_composed_conv_pair_matches_two_step(dt, cfg):
     x = torch.randn(N, Ci, H, W).cuda()
     with torch.no_grad():
         ref = F.max_pool2d(F.relu(bn(c2(c1(x)))), 2, 2)
-    stem = FrozenStem(None, None, "bf16" if dt == torch.bfloat16 else "fp32")
+    stem = FrozenStem(None, None, LOW if dt == LOW_DTYPE else "fp32")
     stem.composed = stem._compose_pair(c1, c2, bn)
     xn = F.pad(K.nchw_to_nhwc(x, dt, c_pad=Ci), (0, 0, 1, 1, 1, 1))          # halo 2
     with torch.no_grad():

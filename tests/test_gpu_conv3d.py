@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from helpers import load_golden, rel_err, weights_from
+from helpers import load_golden, rel_err, weights_from, LOW, LOW_DTYPE
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,7 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.float32, LOW_DTYPE])
 @pytest.mark.parametrize("cfg", [(2, 4, 10, 12, 64, 64), (1, 6, 8, 8, 128, 192), (3, 3, 14, 6, 64, 128)])
 def test_conv3d_fwd_dgrad_wgrad_vs_torch(dt, cfg):
     from videonavqa_amd import ops
@@ -49,7 +49,7 @@ def test_conv3d_fwd_dgrad_wgrad_vs_torch(dt, cfg):
     assert _rel(bp.grad, br.grad) < gt
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", LOW])
 def test_video_only_cnn3d_features_vs_reference_golden(precision):
     from videonavqa_amd.models import VideoOnlyCNN3D
     g = load_golden("cnn3d_small")

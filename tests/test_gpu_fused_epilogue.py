@@ -5,6 +5,8 @@ import os
 import pytest
 import torch
 
+from helpers import LOW, LOW_DTYPE
+
 pytestmark = pytest.mark.gpu
 
 
@@ -15,7 +17,7 @@ def _padded(n, h, w, c, dtype, seed, scale=1.0):
     return x.to(dtype).cuda()
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [LOW_DTYPE, torch.float32])
 @pytest.mark.parametrize("geom", [(8, 14, 14, [3, 2, 2, 1]), (5, 10, 13, [1, 1, 1, 1, 1]), (12, 14, 14, [8, 4])])
 def test_conv_bnstats_epilogue_matches_separate_stats(dtype, geom):
     """conv + ReLU with the per-frame statistics taken in the epilogue: output bit-identical to the plain conv, mean/var
@@ -48,14 +50,14 @@ def test_conv_bnstats_epilogue_matches_separate_stats(dtype, geom):
 
 def test_conv_bnstats_reports_unsupported_for_tiny_frames():
     from videonavqa_amd import kernels as K
-    x = _padded(6, 4, 6, 64, torch.bfloat16, 1)              # 24 pixels per image: a 256-pixel tile would span > 3 frames
-    wt = K.pack_conv_weight(torch.randn(64, 64, 3, 3).cuda(), torch.bfloat16)
+    x = _padded(6, 4, 6, 64, LOW_DTYPE, 1)              # 24 pixels per image: a 256-pixel tile would span > 3 frames
+    wt = K.pack_conv_weight(torch.randn(64, 64, 3, 3).cuda(), LOW_DTYPE)
     frame_of = torch.arange(6, dtype=torch.int32, device="cuda")
     frame_off = torch.arange(7, dtype=torch.int32, device="cuda")
     assert K.conv2d_igemm_bnstats(x, wt, None, True, frame_of, frame_off, 6, 1) is None
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype", [LOW_DTYPE, torch.float32])
 @pytest.mark.parametrize("C", [128, 40])
 def test_conv_film_res_epilogue_is_bit_identical_to_separate_kernels(dtype, C):
     """3x3 conv + FiLM affine + ReLU + residual in one launch vs conv then vnqa_film_relu_res_fwd; gamma/beta are column
@@ -88,7 +90,7 @@ def test_conv_film_res_epilogue_is_bit_identical_to_separate_kernels(dtype, C):
     assert float(dfilm[:, :2 * C].abs().max()) == 0 and float(dfilm[:, 4 * C:].abs().max()) == 0
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", LOW])
 @pytest.mark.parametrize("kind", ["film_attn", "tmh"])
 def test_one_node_trunk_matches_op_by_op_graph(precision, kind, monkeypatch):
     """Same model, same inputs: VNQA_FUSED_TRUNK=1 (ops.FilmTrunkFn, fused epilogues) vs =0 (one autograd node per op).

@@ -2,6 +2,8 @@
 against plain PyTorch fp32 references of the same ops."""
 import pytest
 import torch
+
+from helpers import LOW, LOW_DTYPE
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -27,7 +29,7 @@ def test_sgemm_nt_nn_tn_bias_relu_mask_gather_scatter(m, n, k):
     assert _close(K.matmul_nn(dy, w, a_mask=mask), dym @ w)
     assert _close(K.matmul_tn(dy, x, a_mask=mask), dym.t() @ x)
     assert _close(K.colsum(dy, mask), dym.sum(0)) and _close(K.colsum(dy), dy.sum(0))
-    assert _close(K.colsum(dy.bfloat16()), dy.bfloat16().float().sum(0), 1e-5)
+    assert _close(K.colsum(dy.to(LOW_DTYPE)), dy.to(LOW_DTYPE).float().sum(0), 1e-5)
     # row gather on A (with a negative = zero row) and row scatter on C, accumulation
     rows = torch.randperm(m, generator=g)[: max(m // 2, 1)].to(torch.int32)
     rows_neg = rows.clone()
@@ -108,7 +110,7 @@ def test_ce_loss_vs_torch(reduction, weighted):
     assert _close(logits.grad, 2.0 * want, 1e-5)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, LOW_DTYPE])
 def test_packed_temporal_attention_vs_dense_op(dtype):
     """packed kernel (frame-major image list, validity / masks formed on the fly) == the dense [B,T,A] op it replaces,
     ragged clips incl. frames past the longest video (un-masked on purpose)."""

@@ -4,7 +4,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from helpers import MAC_CASES, mac_case, rel_err
+from helpers import MAC_CASES, mac_case, rel_err, LOW, LOW_DTYPE
 
 pytestmark = pytest.mark.gpu
 
@@ -125,7 +125,7 @@ def test_mac_train_forward_backward_fp32(case, tag):
 
 @pytest.mark.parametrize("case", MAC_CASES)
 def test_mac_bf16_close_to_reference(case):
-    model, g, (v, q, vl, ql, y), _ = _product(case, "bf16")
+    model, g, (v, q, vl, ql, y), _ = _product(case, LOW)
     model.eval()
     with torch.no_grad():
         out = model(v, q, vl, ql)
@@ -192,7 +192,7 @@ def test_mac_full_size_batch_independence_and_training():
     torch.manual_seed(5)
     dev = torch.device("cuda")
     B, T = 8, 35
-    model = M.MACNetwork(n_vocab=134, dim=512, embed_hidden=128, classes=70, precision="bf16").to(dev)
+    model = M.MACNetwork(n_vocab=134, dim=512, embed_hidden=128, classes=70, precision=LOW).to(dev)
     v = torch.rand(B, 512, 14, 14, T, device=dev)
     v_lens = torch.tensor([35, 35, 30, 22, 22, 9, 4, 3])
     q_lens = torch.tensor([25, 19, 19, 12, 9, 7, 6, 5])
@@ -207,7 +207,7 @@ def test_mac_full_size_batch_independence_and_training():
     y = torch.randint(0, 70, (B,), device=dev)
     trainer = Trainer(model, stem=None, lr=1e-4, clip=1.0, feature_channels=512)
     lay = FrameLayout(v_lens, T, dev)
-    native = NativeFeatures(K.feat_to_nhwc(v, lay.img_of, lay.n_img, torch.bfloat16), lay, 512, 14, 14)
+    native = NativeFeatures(K.feat_to_nhwc(v, lay.img_of, lay.n_img, LOW_DTYPE), lay, 512, 14, 14)
     trainer.extract_features = lambda clip, v_lens_cpu, slot=0: (native, v_lens, torch.arange(B))
     model.mac.dropout = 0.0
     losses = [float(trainer.step(v, q, v_lens, q_lens, y)[0]) for _ in range(4)]

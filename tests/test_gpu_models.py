@@ -12,18 +12,18 @@ import pytest
 import torch
 import torch.nn as nn
 
-from helpers import QV_CASES, build_product_model, load_golden, rel_err, weights_from
+from helpers import QV_CASES, build_product_model, load_golden, rel_err, weights_from, LOW, LOW_DTYPE
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = {"fp32": 1e-3, "bf16": 6e-2}
+LOGIT_TOL = {"fp32": 1e-3, "bf16": 6e-2, "fp16": 1e-2}
 
 
 def _inputs(g):
     return tuple(torch.from_numpy(g[k]).cuda() for k in ("v", "q", "v_lens", "q_lens", "y"))
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", LOW])
 @pytest.mark.parametrize("case", QV_CASES)
 def test_eval_logits_vs_reference_golden(case, precision):
     model, g = build_product_model(case, precision)
@@ -39,7 +39,7 @@ def test_eval_logits_vs_reference_golden(case, precision):
         assert (got.argmax(1) == g["eval_logits"].argmax(1)).all()
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", LOW])
 @pytest.mark.parametrize("case", QV_CASES)
 def test_train_forward_backward_vs_reference_golden(case, precision):
     model, g = build_product_model(case, precision)
@@ -112,7 +112,7 @@ def test_training_trajectory_vs_reference_golden(case):
     assert rel_err(logits, g["traj_final_eval_logits"]) < 5e-3
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", LOW])
 def test_obj_detect_cnn_vs_reference_golden(precision):
     from videonavqa_amd.models import ObjDetectCNN
     g = load_golden("objdet_f16")
@@ -125,7 +125,7 @@ def test_obj_detect_cnn_vs_reference_golden(precision):
     assert rel_err(y, g["y"]) < (1e-4 if precision == "fp32" else 3e-2), rel_err(y, g["y"])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", LOW])
 def test_fused_stem_vs_oracle(precision):
     """clip [B,3,H,W,T] -> packed native features, against the oracle's per-frame stem loop
     (eval/q_and_v_eval.py:102-110) with seeded synthetic weights; ragged frame validity."""

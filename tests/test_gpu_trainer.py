@@ -2,6 +2,8 @@
 fused clip+Adam kernel vs torch.optim.Adam + clip_grad_norm_."""
 import pytest
 import torch
+
+from helpers import LOW, LOW_DTYPE
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
@@ -93,7 +95,7 @@ def test_bf16_and_fp32_paths_train_alike():
     the exact-f32 parity precision: both must fit the batch and their loss curves must stay close."""
     curves = {}
     from videonavqa_amd.train import Trainer
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", LOW):
         model, stem, batches = _setup(prec, seed=3)
         trainer = Trainer(model, stem, lr=3e-4)
         losses = []
@@ -102,7 +104,7 @@ def test_bf16_and_fp32_paths_train_alike():
             losses.append(float(loss))
         assert all(l == l and l < 1e4 for l in losses), losses        # finite
         curves[prec] = losses
-    f, b = curves["fp32"], curves["bf16"]
+    f, b = curves["fp32"], curves[LOW]
     assert f[-1] < 0.6 * f[0] and b[-1] < 0.6 * b[0], (f[0], f[-1], b[0], b[-1])
     assert abs(b[0] - f[0]) < 0.05 * abs(f[0]) + 0.05
     rel = [abs(x - y) / max(abs(y), 1e-3) for x, y in zip(b[:20], f[:20])]

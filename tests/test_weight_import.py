@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import LOW, LOW_DTYPE
+
 # torchvision VGG-16 'D' conv positions inside `features` and their (c_out, c_in)
 VGG16_CONVS = {0: (64, 3), 2: (64, 64), 5: (128, 64), 7: (128, 128), 10: (256, 128), 12: (256, 256), 14: (256, 256),
                17: (512, 256), 19: (512, 512), 21: (512, 512), 24: (512, 512), 26: (512, 512), 28: (512, 512)}
@@ -84,7 +86,7 @@ def test_loaders_read_reference_style_files(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", LOW])
 def test_stem_from_imported_files_vs_oracle(tmp_path, precision):
     """Files -> loaders -> FrozenStem (composed conv11.conv12, folded BN, 512 filters) on the reference's own 160x208
     clip geometry (10x13 maps) against the oracle's per-frame loop on the same tensors."""
