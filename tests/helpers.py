@@ -11,6 +11,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # run is a separate pytest process (tests/test_gpu_fp16.py starts it).
 LOW = os.environ.get("VNQA_TEST_LOW_PRECISION", "bf16")
 LOW_DTYPE = torch.float16 if LOW == "fp16" else torch.bfloat16
+if LOW == "fp16":
+    os.environ.setdefault("VNQA_HALF", "f16")      # read by videonavqa_amd._lib when it is first imported
 
 
 def load_golden(name):

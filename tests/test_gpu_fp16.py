@@ -19,7 +19,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def _run(args, timeout):
     if os.environ.get("VNQA_TEST_LOW_PRECISION") == "fp16":
         pytest.skip("already inside the fp16 child run")
-    env = dict(os.environ, VNQA_TEST_LOW_PRECISION="fp16")
+    env = dict(os.environ, VNQA_TEST_LOW_PRECISION="fp16", VNQA_HALF="f16")      # (the fp32-only tests of the child load the f16 build too)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=timeout)
     tail = "\n".join(r.stdout.strip().splitlines()[-25:])
