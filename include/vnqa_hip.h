@@ -148,6 +148,10 @@ int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* x, const vo
  *                           its three outside neighbours (zeros where a corner belongs to the top/bottom group);
  *   vnqa_ring_assemble    : the four edge GEMM results [n][w|h][c] -> border_sub [n][2w+2(h-2)][c] (corners summed).
  */
+/* vnqa_conv2d_ring_fwd: y1 [n][2(w+2)+2h][c_out] = conv3x3(x, wt) + bias evaluated AT the outside-ring positions, as an
+ * implicit GEMM straight from the halo-2 image (replaces vnqa_ring_im2col + vnqa_gemm_nt: no [n*ring, 9*c_in] matrix). */
+int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* bias, void* y1, int32_t n_img, int32_t h, int32_t w,
+                         int32_t c_in, int32_t c_out, int32_t dtype, void* stream);
 int vnqa_ring_im2col(const void* x, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype,
                      void* stream);
 int vnqa_ring_edge_gather(const void* y1, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t edge,

@@ -443,3 +443,29 @@ def test_grouped_gemm_and_all_edge_gather_match_per_edge_calls(dt):
         assert torch.equal(res[e, :n * ln], ref)
         exact = one.float() @ wts[e].float().t()
         assert _rel(res[e, :n * ln].float(), exact) < _tol(dt)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_ring_conv_implicit_gemm_matches_im2col_gemm(dt):
+    """conv3x3 at the outside-ring positions of halo-2 images (the first operand of the composed conv's border correction):
+    the implicit-GEMM form (vnqa_conv2d_ring_fwd) against the materialised im2col + GEMM it replaces."""
+    from videonavqa_amd import kernels as K
+    torch.manual_seed(3)
+    n, H, W, ci, co = 5, 10, 14, 128, 192
+    x = torch.zeros(n, H + 4, W + 4, ci)
+    x[:, 2:-2, 2:-2] = torch.randn(n, H, W, ci)
+    x = x.to(dt).cuda()
+    w = (torch.randn(co, ci, 3, 3) * 0.05).cuda()
+    b = torch.randn(co).cuda()
+    wt = K.pack_conv_weight(w, dt)                                   # [co][9][ci]
+    ref = K.gemm_nt(K.ring_im2col(x, H, W), wt.view(co, -1), bias=b, split_k=False).float()
+    got = K.conv2d_ring(x, wt, b, H, W).float()
+    assert got.shape == ref.shape == (n * (2 * (W + 2) + 2 * H), co)
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    assert float((got - ref).abs().max()) <= tol * float(ref.abs().max())
+    # and against torch: conv evaluated on the (H+2)x(W+2) grid, ring positions picked out
+    xin = x[:, 1:-1, 1:-1].float().permute(0, 3, 1, 2)              # halo-1 view: a 'valid' conv gives the (H+2)x(W+2)... no:
+    full = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.to(dt).float(), b)   # valid conv over the halo-2 image: [n,co,H+2,W+2]
+    ring = torch.cat([full[:, :, 0, :], full[:, :, -1, :], full[:, :, 1:-1, 0], full[:, :, 1:-1, -1]], 2)   # top, bottom, left, right
+    ring = ring.permute(0, 2, 1).reshape(-1, co)
+    assert float((got - ring).abs().max()) <= (1e-4 if dt == torch.float32 else 2e-2) * float(ring.abs().max())

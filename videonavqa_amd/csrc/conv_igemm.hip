@@ -158,7 +158,22 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     int m = tile_m * BM + row;
     m = m < p.M ? m : p.M - 1;
     int n, y, x;
-    decode_pixel(m, p.H, p.W, p.pool, n, y, x);
+    if (p.ring_h > 0) {
+      // ring position q = (qy, qx), qy in [-1, H], qx in [-1, W] (top row, bottom row, left column, right column); its 3x3
+      // window's top-left tap sits at (qy + 1, qx + 1) of the halo-2 padded image
+      const int R = 2 * (p.ring_w + 2) + 2 * p.ring_h;
+      n = m / R;
+      const int r = m - n * R;
+      int qy, qx;
+      if (r < p.ring_w + 2) { qy = -1; qx = r - 1; }
+      else if (r < 2 * (p.ring_w + 2)) { qy = p.ring_h; qx = r - (p.ring_w + 2) - 1; }
+      else if (r < 2 * (p.ring_w + 2) + p.ring_h) { qy = r - 2 * (p.ring_w + 2); qx = -1; }
+      else { qy = r - 2 * (p.ring_w + 2) - p.ring_h; qx = p.ring_w; }
+      y = qy + 1;
+      x = qx + 1;
+    } else {
+      decode_pixel(m, p.H, p.W, p.pool, n, y, x);
+    }
     size_t img = n;
     if (p.D > 0) {   // depth slice (nn, d): top-front-left tap sits at padded depth d
       const int nn = n / p.D;
@@ -899,7 +914,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = relu; a.pool = 0;
   a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
   a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr; a.group_tiles = 0;
-  a.epi = VNQA_EPI_NONE;
+  a.epi = VNQA_EPI_NONE; a.ring_h = 0; a.ring_w = 0;
   hipStream_t st = (hipStream_t)stream;
   // bf16: 256-row tiles unless 128-row tiles waste fewer padded rows (e.g. m = 280: 384 instead of 512)
   int tile = VNQA_TILE_128x128;
@@ -953,7 +968,7 @@ extern "C" int vnqa_gemm_nt_grouped(const void* a_gmk, const void* b_gnk, void* 
   a.taps = 1; a.x_halo = 0; a.y_halo = 0; a.relu = 0; a.pool = 0;
   a.M = groups * m_group; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
   a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr;
-  a.epi = VNQA_EPI_NONE;
+  a.epi = VNQA_EPI_NONE; a.ring_h = 0; a.ring_w = 0;
   a.group_tiles = m_group / bm;
   int tile = dtype == VNQA_BF16 ? (n % 256 == 0 ? VNQA_TILE_256x256 : VNQA_TILE_256x128) : VNQA_TILE_128x128;
   if (const char* e = getenv("VNQA_GROUPED_TILE")) tile = atoi(e);     // experiment hook (row tile must divide m_group)
@@ -1022,6 +1037,7 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
   a.border_sub = border_sub;
   a.group_tiles = 0;
   a.epi = VNQA_EPI_NONE;
+  a.ring_h = 0; a.ring_w = 0;
   a.frame_of = nullptr; a.stats_partial = nullptr; a.film_gamma = nullptr; a.film_beta = nullptr;
   a.film_ld = 0; a.film_c = 0; a.res = nullptr; a.y2 = nullptr;
   VNQA_CHECK_ARG(!d->wt_tiled || (d->tile != VNQA_TILE_AUTO && d->tile != VNQA_TILE_P4_256x256 &&
@@ -1041,6 +1057,38 @@ extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, 
   const int rc = fill_conv_args(d, x, wt, bias, post_scale, post_shift, border_sub, y, a);
   if (rc != VNQA_OK) return rc;
   return conv_dispatch(a, d->dtype, d->tile, (hipStream_t)stream);
+}
+
+// conv11 evaluated at the OUTSIDE-RING positions of halo-2 images, straight from the image (implicit GEMM: the ring position
+// decides the nine tap addresses) — the first operand of the composed conv's border correction (vnqa_conv2d_igemm_fwd_ex)
+// without materialising the [n*R, 9*c_in] im2col matrix vnqa_ring_im2col + vnqa_gemm_nt needed (147 MB written and read
+// back per 280-frame stem pass).  x: [n_img][h+4][w+4][c_in]; wt: [c_out][9][c_in]; y1: [n_img][R][c_out], R = 2(w+2) + 2h.
+extern "C" int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* bias, void* y1, int32_t n_img, int32_t h,
+                                    int32_t w, int32_t c_in, int32_t c_out, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(x && wt && y1 && n_img > 0 && h >= 2 && w >= 2, "conv2d_ring_fwd: bad arguments");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv2d_ring_fwd: bad dtype %d", dtype);
+  const int bk = dtype == VNQA_BF16 ? 64 : 32;
+  VNQA_CHECK_ARG(c_in > 0 && c_in % bk == 0 && c_out > 0 && c_out % 8 == 0, "conv2d_ring_fwd: c_in %% %d, c_out %% 8", bk);
+  const int R = 2 * (w + 2) + 2 * h;
+  VNQA_CHECK_ARG((long long)n_img * R < (1ll << 31), "conv2d_ring_fwd: too many ring positions");
+  vnqa_conv_desc d;
+  d.dtype = dtype; d.n_img = n_img; d.h = 1; d.w = R; d.c_in = c_in; d.c_out = c_out; d.c_y = c_out; d.taps = 9;
+  d.x_halo = 1; d.y_halo = 0; d.relu = 0; d.pool2 = 0; d.tile = VNQA_TILE_AUTO; d.wt_tiled = 0; d.depth = 0;
+  ConvArgs a;
+  const int rc = fill_conv_args(&d, x, wt, bias, nullptr, nullptr, nullptr, y1, a);
+  if (rc != VNQA_OK) return rc;
+  a.ring_h = h;
+  a.ring_w = w;
+  a.Hp = h + 4;        // the INPUT is the halo-2 image list; the output is [n_img][1][R] (fill_conv_args: Hyp = 1, Wyp = R)
+  a.Wp = w + 4;
+  // one pass over K in a fixed order whatever n_img is (a frame's features must not depend on the launch's other frames)
+  int tile = VNQA_TILE_128x128;
+  if (dtype == VNQA_BF16) {
+    const long long m = (long long)n_img * R;
+    const long long pad256 = (m + 255) / 256 * 256, pad128 = (m + 127) / 128 * 128;
+    tile = pad128 >= pad256 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+  }
+  return conv_dispatch(a, dtype, tile, (hipStream_t)stream);
 }
 
 // pixel rows per tile the fused-epilogue conv would use for this problem (0: no fused instantiation)

@@ -149,6 +149,18 @@ def film_relu_res_bwd_ld(dout, z, gamma, beta, film_c, dgamma, dbeta):
     return dz
 
 
+def conv2d_ring(x, wt, bias, H, W):
+    """conv3x3 (weights wt [c_out][9][c_in], K-major) + bias at the outside-ring positions of halo-2 images
+    x [n, H+4, W+4, c_in] -> y1 [n * (2(W+2) + 2H), c_out]; implicit GEMM (vnqa_conv2d_ring_fwd)."""
+    n, _, _, c_in = x.shape
+    c_out = wt.shape[0]
+    R = 2 * (W + 2) + 2 * H
+    y1 = torch.empty((n * R, c_out), dtype=x.dtype, device=x.device)
+    L.check(L.lib().vnqa_conv2d_ring_fwd(L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(y1), n, H, W, c_in, c_out,
+                                         L.dtype_id(x.dtype), L.stream()), "vnqa_conv2d_ring_fwd")
+    return y1
+
+
 def ring_im2col(x, H, W):
     """x halo-2 padded NHWC [n,H+4,W+4,c] -> [n*(2(W+2)+2H), 9*c]: 3x3 patches around the outside-ring positions."""
     n, _, _, c = x.shape

@@ -195,7 +195,10 @@ class FrozenStem(object):
         H, W = hp - 4, wp - 4
         cm = cp["c_mid_pad"]
         # conv1 (+ b1) at the outside-ring positions, then the four edge GEMMs of conv2's outside taps -> ring of R[p]
-        y1 = K.gemm_nt(K.ring_im2col(x, H, W), cp["w1m"], bias=cp["b1"], split_k=False)        # [n*ring, cm_pad]
+        if os.environ.get("VNQA_RING_IM2COL", "0") == "1":      # A/B: materialise the [n*ring, 9*ci] matrix, then a plain GEMM
+            y1 = K.gemm_nt(K.ring_im2col(x, H, W), cp["w1m"], bias=cp["b1"], split_k=False)    # [n*ring, cm_pad]
+        else:                                                    # implicit GEMM straight from the halo-2 image
+            y1 = K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W)
         if os.environ.get("VNQA_RING_GROUPED", "0") != "0":
             # the four edge products as ONE grouped GEMM on 256x256 tiles: 164 -> 110 us alone and the stem alone 1 % faster,
             # but END TO END the four small launches on 128x128 tiles (two workgroups per CU) interleave better with the
