@@ -151,7 +151,14 @@ int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* x, const vo
 /* vnqa_conv2d_ring_fwd: y1 [n][2(w+2)+2h][c_out] = conv3x3(x, wt) + bias evaluated AT the outside-ring positions, as an
  * implicit GEMM straight from the halo-2 image (replaces vnqa_ring_im2col + vnqa_gemm_nt: no [n*ring, 9*c_in] matrix). */
 int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* bias, void* y1, int32_t n_img, int32_t h, int32_t w,
-                         int32_t c_in, int32_t c_out, int32_t dtype, void* stream);
+                         int32_t c_in, int32_t c_out, int32_t padded, int32_t dtype, void* stream);
+/* padded = 1: y1 is [n][R + 4][c_out] with the rows laid out top (w+2) | bottom (w+2) | 0 | left (h) | 0 | 0 | right (h) | 0; the
+ * four zero rows are NEVER written (the caller zeroes the buffer once) and stand in for the corner neighbours that belong to
+ * the top / bottom group when vnqa_ring_edge_conv_fwd slides its 1x3 window along the left / right columns:
+ *   out[n][j][co] = sum_{slot < 3, c} y1p[n][base(edge) + j + slot][c] * wt[co][slot][c]      (edge 0/1/2/3 = top/bottom/left/right)
+ * — the edge products of the border correction without vnqa_ring_edge_gather's [n*len, 3*c_mid] operands. */
+int vnqa_ring_edge_conv_fwd(const void* y1p, const void* wt, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c_mid,
+                            int32_t c_out, int32_t edge, int32_t dtype, void* stream);
 int vnqa_ring_im2col(const void* x, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype,
                      void* stream);
 int vnqa_ring_edge_gather(const void* y1, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t edge,

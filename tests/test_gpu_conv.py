@@ -469,3 +469,33 @@ def test_ring_conv_implicit_gemm_matches_im2col_gemm(dt):
     ring = torch.cat([full[:, :, 0, :], full[:, :, -1, :], full[:, :, 1:-1, 0], full[:, :, 1:-1, -1]], 2)   # top, bottom, left, right
     ring = ring.permute(0, 2, 1).reshape(-1, co)
     assert float((got - ring).abs().max()) <= (1e-4 if dt == torch.float32 else 2e-2) * float(ring.abs().max())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_ring_edge_convs_match_gathered_edge_gemms(dt):
+    """The four edge products of the border correction as implicit 1x3 convs along the zero-separated ring layout against
+    the gathered-operand GEMMs they replace (incl. the corner slots that must read zeros on the left / right columns)."""
+    from videonavqa_amd import kernels as K
+    torch.manual_seed(4)
+    n, H, W, ci, cm, co = 3, 6, 10, 64, 128, 64
+    x = torch.zeros(n, H + 4, W + 4, ci)
+    x[:, 2:-2, 2:-2] = torch.randn(n, H, W, ci)
+    x = x.to(dt).cuda()
+    wt = K.pack_conv_weight((torch.randn(cm, ci, 3, 3) * 0.1).cuda(), dt)
+    b = torch.randn(cm).cuda()
+    R = 2 * (W + 2) + 2 * H
+    y1 = K.conv2d_ring(x, wt, b, H, W)                                           # [n*R, cm]
+    y1p = torch.zeros(n, R + 4, cm, dtype=dt, device="cuda")
+    K.conv2d_ring(x, wt, b, H, W, out_padded=y1p)
+    flat = y1.view(n, R, cm)
+    assert torch.equal(y1p[:, :2 * (W + 2)], flat[:, :2 * (W + 2)])
+    assert torch.equal(y1p[:, 2 * (W + 2) + 1:2 * (W + 2) + 1 + H], flat[:, 2 * (W + 2):2 * (W + 2) + H])
+    assert torch.equal(y1p[:, 2 * (W + 2) + H + 3:2 * (W + 2) + 2 * H + 3], flat[:, 2 * (W + 2) + H:])
+    for z in (2 * (W + 2), 2 * (W + 2) + H + 1, 2 * (W + 2) + H + 2, R + 3):
+        assert float(y1p[:, z].abs().max()) == 0                                # separator rows never written
+    for e in range(4):
+        we = (torch.randn(co, 3 * cm) * 0.05).to(dt).cuda()
+        ref = K.gemm_nt(K.ring_edge_gather(y1, n, H, W, e), we, split_k=False).float()
+        got = K.ring_edge_conv(y1p, we, H, W, e).float()
+        tol = 1e-5 if dt == torch.float32 else 1e-2
+        assert got.shape == ref.shape and float((got - ref).abs().max()) <= tol * float(ref.abs().max()), e

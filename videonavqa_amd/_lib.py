@@ -113,7 +113,8 @@ _SIGNATURES = {
     "vnqa_lstm_wide_fwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
     "vnqa_lstm_wide_bwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
     "vnqa_conv2d_igemm_fwd_ex": (ctypes.c_int, [_vp] * 9),
-    "vnqa_conv2d_ring_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 6 + [_vp]),
+    "vnqa_conv2d_ring_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 7 + [_vp]),
+    "vnqa_ring_edge_conv_fwd": (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 7 + [_vp]),
     "vnqa_ring_im2col": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_ring_edge_gather": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_ring_edge_gather_all": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

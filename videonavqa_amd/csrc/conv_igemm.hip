@@ -210,6 +210,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       const int rs = tap - 9 * q;
       r = rs / 3;
       s = rs - 3 * r;
+    } else if (p.taps == 3) {        // 1x3 window along a row (vnqa_ring_edge_conv_fwd)
+      r = 0;
+      s = tap;
     } else {
       r = p.x_halo;
       s = p.x_halo;
@@ -605,7 +608,13 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     }
     const int n = mo / (Ho * Wo);
     const int rem = mo - n * (Ho * Wo);
-    const int yo = rem / Wo, xo = rem - yo * Wo;
+    const int yo = rem / Wo;
+    int xo = rem - yo * Wo;
+    if (p.ring_h > 0 && p.Wyp > Wo) {
+      // padded ring layout: top (W+2) | bottom (W+2) | 0 | left (H) | 0 | 0 | right (H) | 0 — the zero rows (never written) are
+      // what the 1x3 edge windows read in place of the corner neighbours that belong to the top / bottom group
+      xo += (xo >= 2 * (p.ring_w + 2) ? 1 : 0) + (xo >= 2 * (p.ring_w + 2) + p.ring_h ? 2 : 0);
+    }
     size_t oimg = n;
     if (p.D > 0) {   // output depth slices carry a depth halo of 1 as well
       const int nn = n / p.D;
@@ -1064,7 +1073,7 @@ extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, 
 // without materialising the [n*R, 9*c_in] im2col matrix vnqa_ring_im2col + vnqa_gemm_nt needed (147 MB written and read
 // back per 280-frame stem pass).  x: [n_img][h+4][w+4][c_in]; wt: [c_out][9][c_in]; y1: [n_img][R][c_out], R = 2(w+2) + 2h.
 extern "C" int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* bias, void* y1, int32_t n_img, int32_t h,
-                                    int32_t w, int32_t c_in, int32_t c_out, int32_t dtype, void* stream) {
+                                    int32_t w, int32_t c_in, int32_t c_out, int32_t padded, int32_t dtype, void* stream) {
   VNQA_CHECK_ARG(x && wt && y1 && n_img > 0 && h >= 2 && w >= 2, "conv2d_ring_fwd: bad arguments");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv2d_ring_fwd: bad dtype %d", dtype);
   const int bk = dtype == VNQA_BF16 ? 64 : 32;
@@ -1081,11 +1090,46 @@ extern "C" int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* 
   a.ring_w = w;
   a.Hp = h + 4;        // the INPUT is the halo-2 image list; the output is [n_img][1][R] (fill_conv_args: Hyp = 1, Wyp = R)
   a.Wp = w + 4;
+  if (padded) a.Wyp = R + 4;     // [n_img][R + 4]: zero separator rows around the left / right columns (see the store loop)
   // one pass over K in a fixed order whatever n_img is (a frame's features must not depend on the launch's other frames)
   int tile = VNQA_TILE_128x128;
   if (dtype == VNQA_BF16) {
     const long long m = (long long)n_img * R;
     const long long pad256 = (m + 255) / 256 * 256, pad128 = (m + 127) / 128 * 128;
+    tile = pad128 >= pad256 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+  }
+  return conv_dispatch(a, dtype, tile, (hipStream_t)stream);
+}
+
+// One edge product of the border correction as an implicit 1x3 conv along the padded ring rows of y1p [n][R+4][c_mid]
+// (vnqa_conv2d_ring_fwd(padded = 1)): out[n][j][co] = sum_{slot, c} y1p[n][base(edge) + j + slot][c] * wt[co][slot][c],
+// edge 0/1/2/3 = top / bottom / left / right, j = x (top, bottom: w outputs) or y (left, right: h outputs).  Replaces
+// vnqa_ring_edge_gather + vnqa_gemm_nt (no [n*len, 3*c_mid] operand).
+extern "C" int vnqa_ring_edge_conv_fwd(const void* y1p, const void* wt, void* out, int32_t n_img, int32_t h, int32_t w,
+                                       int32_t c_mid, int32_t c_out, int32_t edge, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(y1p && wt && out && n_img > 0 && h >= 2 && w >= 2 && edge >= 0 && edge < 4, "ring_edge_conv_fwd: bad arguments");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "ring_edge_conv_fwd: bad dtype %d", dtype);
+  const int bk = dtype == VNQA_BF16 ? 64 : 32, es = dtype == VNQA_BF16 ? 2 : 4;
+  VNQA_CHECK_ARG(c_mid > 0 && c_mid % bk == 0 && c_out > 0 && c_out % 8 == 0, "ring_edge_conv_fwd: c_mid %% %d, c_out %% 8", bk);
+  const int R = 2 * (w + 2) + 2 * h, Rp = R + 4;
+  const int len = edge < 2 ? w : h;
+  const int base = edge == 0 ? 0 : (edge == 1 ? w + 2 : (edge == 2 ? 2 * (w + 2) : 2 * (w + 2) + h + 2));
+  ConvArgs a;
+  a.x = (const char*)y1p + (size_t)base * c_mid * es;
+  a.wt = (const char*)wt;
+  a.bias = nullptr; a.post_scale = nullptr; a.post_shift = nullptr;
+  a.y = (char*)out;
+  a.n_img = n_img; a.H = 1; a.W = len; a.Hp = 1; a.Wp = Rp;
+  a.Cin = c_mid; a.Cout = c_out; a.Cy = c_out;
+  a.taps = 3; a.x_halo = 0; a.y_halo = 0; a.relu = 0; a.pool = 0;
+  a.M = n_img * len; a.tilesN = 0; a.Hyp = 1; a.Wyp = len; a.wt_tiled = 0; a.D = 0;
+  a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr; a.group_tiles = 0;
+  a.epi = VNQA_EPI_NONE; a.ring_h = 0; a.ring_w = 0;
+  a.frame_of = nullptr; a.stats_partial = nullptr; a.film_gamma = nullptr; a.film_beta = nullptr;
+  a.film_ld = 0; a.film_c = 0; a.res = nullptr; a.y2 = nullptr;
+  int tile = VNQA_TILE_128x128;
+  if (dtype == VNQA_BF16) {
+    const int pad256 = (a.M + 255) / 256 * 256, pad128 = (a.M + 127) / 128 * 128;
     tile = pad128 >= pad256 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
   }
   return conv_dispatch(a, dtype, tile, (hipStream_t)stream);

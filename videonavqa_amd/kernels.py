@@ -149,16 +149,34 @@ def film_relu_res_bwd_ld(dout, z, gamma, beta, film_c, dgamma, dbeta):
     return dz
 
 
-def conv2d_ring(x, wt, bias, H, W):
+def conv2d_ring(x, wt, bias, H, W, out_padded=None):
     """conv3x3 (weights wt [c_out][9][c_in], K-major) + bias at the outside-ring positions of halo-2 images
-    x [n, H+4, W+4, c_in] -> y1 [n * (2(W+2) + 2H), c_out]; implicit GEMM (vnqa_conv2d_ring_fwd)."""
+    x [n, H+4, W+4, c_in] -> y1 [n * (2(W+2) + 2H), c_out]; implicit GEMM (vnqa_conv2d_ring_fwd).
+    out_padded: a ZEROED buffer [n, R+4, c_out] whose four separator rows are never written (see ring_edge_conv)."""
     n, _, _, c_in = x.shape
     c_out = wt.shape[0]
     R = 2 * (W + 2) + 2 * H
-    y1 = torch.empty((n * R, c_out), dtype=x.dtype, device=x.device)
+    if out_padded is not None:
+        assert out_padded.shape == (n, R + 4, c_out) and out_padded.dtype == x.dtype and out_padded.is_contiguous()
+        y1 = out_padded
+    else:
+        y1 = torch.empty((n * R, c_out), dtype=x.dtype, device=x.device)
     L.check(L.lib().vnqa_conv2d_ring_fwd(L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(y1), n, H, W, c_in, c_out,
-                                         L.dtype_id(x.dtype), L.stream()), "vnqa_conv2d_ring_fwd")
+                                         1 if out_padded is not None else 0, L.dtype_id(x.dtype), L.stream()),
+            "vnqa_conv2d_ring_fwd")
     return y1
+
+
+def ring_edge_conv(y1p, wt_edge, H, W, edge):
+    """One edge product of the border correction as an implicit 1x3 conv along the padded ring rows (vnqa_ring_edge_conv_fwd):
+    y1p [n, R+4, cm], wt_edge [co, 3*cm] -> [n * (W | H), co]."""
+    n, _, cm = y1p.shape
+    co = wt_edge.shape[0]
+    ln = W if edge < 2 else H
+    out = torch.empty((n * ln, co), dtype=y1p.dtype, device=y1p.device)
+    L.check(L.lib().vnqa_ring_edge_conv_fwd(L.ptr(y1p), L.ptr(wt_edge), L.ptr(out), n, H, W, cm, co, edge,
+                                            L.dtype_id(y1p.dtype), L.stream()), "vnqa_ring_edge_conv_fwd")
+    return out
 
 
 def ring_im2col(x, H, W):

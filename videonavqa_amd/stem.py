@@ -195,19 +195,30 @@ class FrozenStem(object):
         H, W = hp - 4, wp - 4
         cm = cp["c_mid_pad"]
         # conv1 (+ b1) at the outside-ring positions, then the four edge GEMMs of conv2's outside taps -> ring of R[p]
-        if os.environ.get("VNQA_RING_IM2COL", "0") == "1":      # A/B: materialise the [n*ring, 9*ci] matrix, then a plain GEMM
-            y1 = K.gemm_nt(K.ring_im2col(x, H, W), cp["w1m"], bias=cp["b1"], split_k=False)    # [n*ring, cm_pad]
-        else:                                                    # implicit GEMM straight from the halo-2 image
-            y1 = K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W)
-        if os.environ.get("VNQA_RING_GROUPED", "0") != "0":
-            # the four edge products as ONE grouped GEMM on 256x256 tiles: 164 -> 110 us alone and the stem alone 1 % faster,
-            # but END TO END the four small launches on 128x128 tiles (two workgroups per CU) interleave better with the
-            # co-running trunk: same-box A/B 836 vs 830 clips/s at 224x224, 1013 vs 982 at 160x208 — so this is opt-in
-            res = K.gemm_nt_grouped(K.ring_edge_gather_all(y1, n, H, W), cp["edges_all"])
-            part = [res[0, :n * W], res[1, :n * W], res[2, :n * H], res[3, :n * H]]
-        else:
-            part = [K.gemm_nt(K.ring_edge_gather(y1, n, H, W, e), cp["edges"][name], split_k=False)
+        mode = os.environ.get("VNQA_RING_MODE", "implicit")
+        if mode == "implicit":
+            # both correction operands as implicit GEMMs: conv11 at the ring positions straight from the halo-2 image, written
+            # into a zero-separated ring layout; the four edge products as 1x3 convs along its rows (no im2col matrix, no
+            # gathered edge operands: 147 + 4 x 48 MB less written and read back per 280-frame pass)
+            R = 2 * (W + 2) + 2 * H
+            y1p = self._buf(key + ("y1p", H, W), (n, R + 4, cm))
+            K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W, out_padded=y1p)
+            part = [K.ring_edge_conv(y1p, cp["edges"][name], H, W, e)
                     for e, name in enumerate(("top", "bottom", "left", "right"))]
+        else:
+            if mode == "im2col":      # A/B: materialise the [n*ring, 9*ci] matrix, then a plain GEMM
+                y1 = K.gemm_nt(K.ring_im2col(x, H, W), cp["w1m"], bias=cp["b1"], split_k=False)    # [n*ring, cm_pad]
+            else:                     # "gather": implicit ring GEMM, gathered edge operands
+                y1 = K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W)
+            if os.environ.get("VNQA_RING_GROUPED", "0") != "0":
+                # the four edge products as ONE grouped GEMM on 256x256 tiles: 164 -> 110 us alone and the stem alone 1 % faster,
+                # but END TO END the four small launches on 128x128 tiles (two workgroups per CU) interleave better with the
+                # co-running trunk: same-box A/B 836 vs 830 clips/s at 224x224, 1013 vs 982 at 160x208 — so this is opt-in
+                res = K.gemm_nt_grouped(K.ring_edge_gather_all(y1, n, H, W), cp["edges_all"])
+                part = [res[0, :n * W], res[1, :n * W], res[2, :n * H], res[3, :n * H]]
+            else:
+                part = [K.gemm_nt(K.ring_edge_gather(y1, n, H, W, e), cp["edges"][name], split_k=False)
+                        for e, name in enumerate(("top", "bottom", "left", "right"))]
         ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
         out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
