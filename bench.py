@@ -224,7 +224,7 @@ def fp16_leg(args):
     process's own measurement: throughput of a short run and its parity block against the exact-f32 precision."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--precision", "fp16", "--no-cpu-baseline", "--no-fp16-leg", "--repeats", "1",
-           "--steps", str(min(args.steps, 10)), "--warmup", "3", "--batch", str(args.batch), "--frames", str(args.frames),
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch), "--frames", str(args.frames),
            "--height", str(args.height), "--width", str(args.width), "--blocks", str(args.blocks), "--channels", str(args.channels)]
     env = {k: v for k, v in os.environ.items() if k not in ("VNQA_HALF",)}
     try:
