@@ -89,10 +89,15 @@ def main():
     for n, cnt, tot in fw:
         md.append("| `%s` | %.2f | %.1f | %.3f |" % (n[:100], cnt / a.steps, tot / a.steps / 1e3, 100.0 * tot / total))
     md.append("")
-    md.append("Total framework kernels: %.1f launches/step, %.1f us/step = %.2f %% of the summed GPU kernel time (the fp64 "
-              "`Cijk_*` / `im2col` rows are the one-time stem composition at construction, see above)."
-              % (sum(c for _, c, _ in fw) / a.steps, sum(t for _, _, t in fw) / a.steps / 1e3,
-                 100.0 * sum(t for _, _, t in fw) / total))
+    once = [r for r in fw if "double" in r[0] or "_DB_" in r[0]]        # fp64: the one-time composition of conv11 . conv12
+    steady = [r for r in fw if r not in once]
+    md.append("Framework kernels excluding the one-time fp64 stem composition (`Cijk_*_DB_*`, `*<double>*`: model construction): "
+              "%.1f launches/step, %.1f us/step = %.2f %% of the summed GPU kernel time — this still includes the fills / copies of "
+              "model construction and of bench.py's warm-up allocation (the whole process is traced); the per-step list of the "
+              "steady state is `profiles/%s_trunk_timeline.txt` (rocprofv3 trace of one training step's trunk chain: ~20 framework "
+              "launches, ~100 us of its 4.6 ms)."
+              % (sum(c for _, c, _ in steady) / a.steps, sum(t for _, _, t in steady) / a.steps / 1e3,
+                 100.0 * sum(t for _, _, t in steady) / total, tag))
     with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.md"), "w") as f:
         f.write("\n".join(md) + "\n")
     print("wrote", out_csv)

@@ -6,14 +6,19 @@ import time
 
 import torch
 
-import bench as B
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench as B          # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     a = ap.parse_args()
-    args = argparse.Namespace(precision="bf16", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
+    args = argparse.Namespace(precision=a.precision, batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
                               model="film_attn_pt")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)

@@ -399,10 +399,26 @@ class FiLMTrunkBase(nn.Module):
         for k in range(self.num_res_blocks):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
             blocks += [c1.weight, c1.bias, c3.weight, c3.bias]
+        meta.c1_packs = self._frozen_c1_packs(x.dtype, L.round_up(C, 64))
         bn = self.bn_init
         x, mean, var = ops.film_trunk(x, self.conv_init.weight, self.conv_init.bias, bn.weight, bn.bias, meta, *uniq, *blocks)
         self._advance_running_stats(bn, lay, mean, var, (x.shape[1] - 2) * (x.shape[2] - 2))
         return x
+
+    def _frozen_c1_packs(self, cdt, c_pad):
+        """K-major packs (forward, flipped for dgrad) of the frozen 1x1 conv weights, re-made only when a weight was modified
+        in place (tensor._version: load_reference_tensors, checkpoint restore, .to()).  Trainable weights are never cached —
+        the fused Adam kernel updates them through the flat buffer without touching their version counter."""
+        if any(c.weight.requires_grad for c in self.conv1x1_layers):
+            return None
+        key = (cdt, c_pad, tuple((c.weight._version, c.weight.data_ptr()) for c in self.conv1x1_layers))
+        cached = self.__dict__.get("_c1_pack_cache")
+        if cached is None or cached[0] != key:
+            packs = [(K.pack_conv_weight(c.weight, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
+                      K.pack_conv_weight(c.weight, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
+                     for c in self.conv1x1_layers]
+            cached = self.__dict__["_c1_pack_cache"] = (key, packs)
+        return cached[1]
 
     @staticmethod
     def _advance_running_stats(bn, lay, mean, var, S):

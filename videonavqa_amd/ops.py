@@ -196,8 +196,8 @@ class FilmTrunkFn(torch.autograd.Function):
         saved = [x, r, mean, rstd, g]
         for k in range(blocks):
             w1, b1, w3, b3 = tensors[meta.n_film + 4 * k: meta.n_film + 4 * k + 4]
-            res = K.conv2d_igemm(h, K.pack_conv_weight(w1, cdt, c_out_pad=c_pad, c_in_pad=c_pad), bias=K.pad_vec(b1, c_pad),
-                                 relu=True)
+            wt1 = meta.c1_packs[k][0] if meta.c1_packs else K.pack_conv_weight(w1, cdt, c_out_pad=c_pad, c_in_pad=c_pad)
+            res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(b1, c_pad), relu=True)
             fi, col = meta.film_map[k]
             film = films[fi]
             z, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(w3, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
@@ -251,7 +251,9 @@ class FilmTrunkFn(torch.autograd.Function):
             dres = K.conv2d_igemm(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
             gsum = K.relu_bwd(dres, res, dout)             # (dres + dout) * [res > 0]: residual join + the 1x1 conv's ReLU
             # (the 1x1 convs are frozen upstream — never in parameters() — so they get no weight gradient)
-            dout = K.conv2d_igemm(gsum, K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
+            wt1d = meta.c1_packs[k][1] if meta.c1_packs else \
+                K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad)
+            dout = K.conv2d_igemm(gsum, wt1d)
         dr, s1, s2 = K.frame_bn_bwd(dout, r, lay.frame_of_i32, lay.frame_off_i32, mean, rstd, g, lay.n_frames, True)
         s_cw = ctx.sinks[0]
         s_cb, s_bw, s_bb = sinks[1:4]
@@ -279,6 +281,8 @@ class TrunkMeta(object):
         # incoming d(out) is `grad_scale` times the true gradient (fp16 loss scale): every fp32 parameter / FiLM gradient
         # leaving the node is divided by it, the activation gradients inside stay scaled
         self.grad_scale = float(grad_scale)
+        # per block (forward pack, dgrad pack) of the FROZEN 1x1 conv weights, cached by the model across steps; None = pack here
+        self.c1_packs = None
 
 
 def film_trunk(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors):
