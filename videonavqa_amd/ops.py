@@ -530,6 +530,7 @@ class FcNativeFn(torch.autograd.Function):
         ctx.geom = (rows, C, h, w, c_pad)
         with torch.enable_grad():
             ctx.sink_w = sink_of(weight)
+            ctx.sink_b = sink_of(bias) if rows == rows_pad else None
         return out
 
     @staticmethod
@@ -542,9 +543,12 @@ class FcNativeFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = _ret(ctx.sink_w, K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad, out=_into(ctx.sink_w),
                                                     alpha=1.0 / ctx.grad_scale))
-        db = K.colsum(dout)[:rows] if ctx.needs_input_grad[2] else None
-        if db is not None and ctx.grad_scale != 1.0:
-            db = db * (1.0 / ctx.grad_scale)
+        db = None
+        if ctx.needs_input_grad[2]:
+            sb = ctx.sink_b if ctx.grad_scale == 1.0 else None
+            db = _ret(sb, K.colsum(dout, out=_into(sb))[:rows])
+            if ctx.grad_scale != 1.0:
+                db = db * (1.0 / ctx.grad_scale)
         return dx, dw, db, None, None, None, None, None
 
 
@@ -823,19 +827,23 @@ class EmbedProjFn(torch.autograd.Function):
         xg, rows = K.embed_proj_fwd(tokens.contiguous(), None, embed, w_ih, b_ih, b_hh)
         ctx.save_for_backward(rows, embed, w_ih)
         ctx.padding_idx = padding_idx
+        with torch.enable_grad():
+            ctx.sinks = [sink_of(t) for t in (embed, w_ih, b_ih, b_hh)]
         return xg
 
     @staticmethod
     def backward(ctx, dxg):
         rows, embed, w_ih = ctx.saved_tensors
         V = embed.shape[0]
+        se, sw, sb1, sb2 = ctx.sinks
         dsum = K.token_dsum(rows, dxg.contiguous(), V)                              # [V, 4H]
-        dembed = K.matmul_nn(dsum, w_ih)                                            # [V, E]
+        dembed = K.matmul_nn(dsum, w_ih, out=_into(se))                             # [V, E]
         if ctx.padding_idx is not None:
             dembed[ctx.padding_idx].zero_()
-        dw = K.matmul_tn(dsum, embed)                                               # [4H, E]
-        db = K.colsum(dsum)
-        return None, dembed, dw, db, db, None
+        dw = K.matmul_tn(dsum, embed, out=_into(sw))                                # [4H, E]
+        db1 = K.colsum(dsum, out=_into(sb1))
+        db2 = K.colsum(dsum, out=_into(sb2)) if sb2 is not None else db1
+        return None, _ret(se, dembed), _ret(sw, dw), _ret(sb1, db1), _ret(sb2, db2), None
 
 
 def embed_proj(tokens, embed, w_ih, b_ih, b_hh, padding_idx=None):
@@ -854,6 +862,8 @@ class TemporalAttnPackedFn(torch.autograd.Function):
         coef, ctxt = K.temporal_attn_packed_fwd(f, frame_off_i32, n_frames, B, T, A, w1, b1)
         ctx.save_for_backward(f, frame_off_i32, w1, coef)
         ctx.dims, ctx.w_shape = (n_frames, B, T, A), w.shape
+        with torch.enable_grad():
+            ctx.sinks = (sink_of(w), sink_of(bias))
         ctx.mark_non_differentiable(coef)
         return ctxt, coef
 
@@ -863,7 +873,10 @@ class TemporalAttnPackedFn(torch.autograd.Function):
         n_frames, B, T, A = ctx.dims
         df, dw_part, db_part = K.temporal_attn_packed_bwd(f, frame_off_i32, n_frames, B, T, A, w1, coef, dctxt.contiguous(),
                                                           ctx.grad_scale)
-        return df, None, None, None, None, None, K.colsum(dw_part).view(ctx.w_shape), K.colsum(db_part), None
+        sw, sb = ctx.sinks
+        dw = K.colsum(dw_part, out=None if sw is None else sw.view.view(-1)).view(ctx.w_shape)
+        db = K.colsum(db_part, out=None if sb is None else sb.view.view(-1))
+        return df, None, None, None, None, None, _ret(sw, dw), _ret(sb, db), None
 
 
 def temporal_attention_packed(f, frame_off_i32, n_frames, B, T, A, w, bias, grad_scale=1.0):
