@@ -31,7 +31,8 @@ def _digest(extra=()):
     for f in sources() + headers + [os.path.join(HERE, "..", "include", "vnqa_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS + list(extra)).encode())
+    # (flags hashed with the checkout path stripped: the same tree at another location — a gpurun box — must not rebuild)
+    h.update(" ".join(FLAGS + list(extra)).replace(os.path.join(HERE, ".."), "<root>").replace(HERE, "<pkg>").encode())
     return h.hexdigest()
 
 
