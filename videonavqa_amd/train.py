@@ -67,13 +67,14 @@ def sync_replicas(tensors, src=0):
 class OverlappedGradReducer(object):
     """SUM all-reduce of the flat gradient buffer, overlapped with backward.
 
-    Big parameters (>= `early_numel` elements; for FiLM-attn that is fc_embed_attn.weight = 51 MB of
-    the 56 MB payload, whose gradient is complete early in backward) are reduced asynchronously from
-    a post-accumulate-grad hook, each as its own contiguous slice of the flat buffer; `finish()` reduces
-    the remaining ranges and waits for the early ones.  xGMI rings are per-link bound, so few large
+    Big parameters (>= `early_numel` elements; for FiLM-attn at 224x224 that is fc_embed_attn.weight = 51 MB of
+    the 73 MB payload, whose gradient is complete early in backward, and the two 9.4 MB conv weights) are reduced
+    asynchronously as soon as their gradient kernel has been enqueued (ops.GradSink notification / post-accumulate-grad
+    hook), each as its own contiguous slice of the flat buffer; `finish()` reduces the remaining ranges (~1.5 MB of
+    biases, LSTM and classifier weights) and waits for the early ones.  xGMI rings are per-link bound, so few large
     transfers beat many small buckets here."""
 
-    def __init__(self, fp, world_size, loss_reduction="sum", early_numel=1 << 22, active=None):
+    def __init__(self, fp, world_size, loss_reduction="sum", early_numel=1 << 20, active=None):
         self.fp, self.world, self.loss_reduction = fp, world_size, loss_reduction
         self.early, self.pending, self.done_ranges, self._fired = {}, [], [], set()
         # active=True with world_size 1 runs the collectives on a one-rank group (RCCL code-path test on a 1-GPU box)
