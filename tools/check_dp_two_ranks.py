@@ -1,7 +1,11 @@
+#!/usr/bin/env python3
+"""GPU diagnostic: two gloo ranks on one GPU, early-hook gradient all-reduce on — prints, per parameter, the reduced
+gradient against the sum of the two ranks' own gradients (and against the patterns a double / mismatched all-reduce would
+give) plus the slice contents at hook time.  This is what located the double-firing reducer hook of round 2."""
 import os, sys, torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
-ROOT = "/root/repo"
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
 def worker(rank, world, port):
     sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")

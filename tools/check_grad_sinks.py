@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""GPU diagnostic: one training step with the gradient sinks on (VNQA_DIRECT_GRADS=1: kernels write parameter gradients
+straight into the flat buffer) and off (autograd AccumulateGrad) from identical weights — prints the per-parameter
+difference of the flat gradient (expected: exactly 0 everywhere)."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_gpu_trainer import _setup
 from videonavqa_amd.train import Trainer
 import videonavqa_amd.train as T
