@@ -495,11 +495,12 @@ class FiLMTrunkBase(nn.Module):
     def _gp_tail(self, x, lay, h, w):
         """relu(c1x1_tail) -> zero-padded stack over frames -> max over frames -> out_linear
         (film_global_pooling_pt_stem.py:228-238)."""
-        t = ops.conv(x, self.c1x1_tail.weight, self.c1x1_tail.bias, relu=True)     # [n_img,hp,wp,tail_pad]
+        gs = getattr(self, "_trunk_grad_scale", 1.0)      # fp16 storage: the tail conv and the trunk see scaled gradients
+        t = ops.conv(x, self.c1x1_tail.weight, self.c1x1_tail.bias, relu=True, grad_scale=gs)     # [n_img,hp,wp,tail_pad]
         n_img, hp, wp, tp = t.shape
         tail = self.c1x1_tail.out_channels
         dense = torch.zeros(lay.n_frames, lay.B, hp, wp, tp, device=t.device, dtype=torch.float32)
-        dense = dense.index_put((lay.frame_of, lay.sample_of), t.float())
+        dense = dense.index_put((lay.frame_of, lay.sample_of), ops.scale_grad(t.float(), gs))
         pooled = dense.max(dim=0)[0].reshape(lay.B, -1)
         w_nat = self._fc_native_weight(self.out_linear.weight, tail, h, w, tp, self.out_linear.out_features)
         return pooled @ w_nat.t() + self.out_linear.bias

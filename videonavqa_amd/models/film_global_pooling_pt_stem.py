@@ -3,7 +3,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .common import FiLMTrunkBase, compute_dtype, repeated_question_lstm
+from .common import FiLMTrunkBase, compute_dtype, grad_scale_of, repeated_question_lstm
 
 
 class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
@@ -60,6 +60,7 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
             film = F.relu(self.film_layer[1](h_last))
             return film[lay.sample_of, lay.frame_of]
 
+        self._trunk_grad_scale = grad_scale_of(self.compute_dtype) if self._use_fused_trunk() else 1.0
         if self._use_fused_trunk():       # train mode: generator and conv trunk on fused HIP ops
             film_img = self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay, padding_idx=0)
             x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])

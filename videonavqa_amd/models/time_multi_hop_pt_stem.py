@@ -3,7 +3,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .common import FiLMTrunkBase, compute_dtype, repeated_question_lstm
+from .common import FiLMTrunkBase, compute_dtype, grad_scale_of, repeated_question_lstm
 
 
 class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
@@ -73,6 +73,7 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
             fv = film_per_block[k]
             return fv[:, s:s + C], fv[:, s + C:s + 2 * C]                 # :228-230
 
+        self._trunk_grad_scale = grad_scale_of(self.compute_dtype) if self._use_fused_trunk() else 1.0
         if self._use_fused_trunk():       # train mode: the conv trunk as ONE autograd node with fused conv epilogues
             x = self._trunk_fused(x, lay, [(film_per_block[k], 2 * C * k) for k in range(self.num_res_blocks)])
         else:

@@ -52,7 +52,8 @@ class ConvFn(torch.autograd.Function):
     split-K kernel.  Replaces nn.Conv2d at models/film_attn_pt_stem.py:211,219,224."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, mask_in_backward=True):
+    def forward(ctx, x, weight, bias, relu, mask_in_backward=True, grad_scale=1.0):
+        ctx.grad_scale = float(grad_scale)      # d y arrives multiplied by this (fp16 loss scale): dW, db are divided by it
         c_out, c_in, k, _ = weight.shape
         cdt = x.dtype
         c_in_pad = x.shape[-1]
@@ -73,13 +74,14 @@ class ConvFn(torch.autograd.Function):
             dy = K.relu_bwd(dy, y)
         dx = dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            inv = 1.0 / ctx.grad_scale
             dwt, dbias = K.conv2d_wgrad(x, dy, k * k)
-            dw = K.unpack_conv_wgrad(dwt, c_out, c_in)
-            db = dbias[:c_out].clone()
+            dw = K.unpack_conv_wgrad(dwt, c_out, c_in, alpha=inv)
+            db = dbias[:c_out].clone() if inv == 1.0 else dbias[:c_out] * inv
         if ctx.needs_input_grad[0]:
             wt_d = K.pack_conv_weight(weight, dy.dtype, transpose_flip=True, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
             dx = K.conv2d_igemm(dy, wt_d)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class LinearNTFn(torch.autograd.Function):
@@ -108,8 +110,27 @@ class LinearNTFn(torch.autograd.Function):
         return dx, dw, db
 
 
-def conv(x, weight, bias, relu=False, mask_in_backward=True):
-    return ConvFn.apply(x, weight, bias, relu, mask_in_backward)
+def conv(x, weight, bias, relu=False, mask_in_backward=True, grad_scale=1.0):
+    return ConvFn.apply(x, weight, bias, relu, mask_in_backward, grad_scale)
+
+
+class ScaleGradFn(torch.autograd.Function):
+    """Identity whose backward multiplies the gradient by `scale` — the entry point of the fp16 loss scale where the
+    gradient is still fp32 (placed right after the `.float()` of a 16-bit activation: the cast's backward then rounds
+    scale * g, not g, to fp16)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = float(scale)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None
+
+
+def scale_grad(x, scale):
+    return x if scale == 1.0 else ScaleGradFn.apply(x, scale)
 
 
 class FrameBNTrainFn(torch.autograd.Function):
