@@ -4,9 +4,9 @@ summation order differs); bf16 path is checked against the reference evaluated o
 bf16-rounded operands, 1e-2 relative (bf16 output rounding = 2^-9)."""
 import pytest
 import torch
+import torch.nn.functional as F
 
 from helpers import LOW, LOW_DTYPE
-import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 

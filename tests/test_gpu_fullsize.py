@@ -7,10 +7,10 @@
 """
 import pytest
 import torch
-
-from helpers import LOW, LOW_DTYPE
 import torch.nn as nn
 import torch.nn.functional as F
+
+from helpers import LOW, LOW_DTYPE
 
 pytestmark = pytest.mark.gpu
 

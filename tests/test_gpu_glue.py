@@ -2,10 +2,10 @@
 against plain PyTorch fp32 references of the same ops."""
 import pytest
 import torch
-
-from helpers import LOW, LOW_DTYPE
 import torch.nn as nn
 import torch.nn.functional as F
+
+from helpers import LOW, LOW_DTYPE
 
 pytestmark = pytest.mark.gpu
 

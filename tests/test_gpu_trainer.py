@@ -2,9 +2,9 @@
 fused clip+Adam kernel vs torch.optim.Adam + clip_grad_norm_."""
 import pytest
 import torch
+import torch.nn as nn
 
 from helpers import LOW, LOW_DTYPE
-import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
 
