@@ -121,6 +121,9 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
 #define VNQA_EPI_NONE 0
 #define VNQA_EPI_BNSTATS 1
 #define VNQA_EPI_FILM_RES 2
+#define VNQA_EPI_ADD_MASK 3     /* y = (conv + res) * [y2 > 0]  (y2 is READ: the tensor whose sign is the mask) — the FiLM block's
+                                 * backward: dgrad of the 3x3 conv + the residual branch's gradient, masked by the 1x1 conv's
+                                 * ReLU (models/film_attn_pt_stem.py:219-241 differentiated); bit-identical to vnqa_relu_bwd(a, b, y) */
 typedef struct vnqa_conv_epilogue {
   int32_t kind;              /* VNQA_EPI_* */
   int32_t n_frames;          /* BNSTATS */

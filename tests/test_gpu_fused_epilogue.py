@@ -133,3 +133,19 @@ def test_one_node_trunk_matches_op_by_op_graph(precision, kind, monkeypatch):
         scale = float(a[3][n].abs().max())
         # (analytically zero gradients, e.g. fc_hidden_attn of the attention model, are float noise: absolute floor)
         assert float((a[3][n] - b[3][n]).abs().max()) <= (1e-4 if precision == "fp32" else 3e-2) * scale + 1e-6 * gmax, n
+
+
+@pytest.mark.parametrize("dtype", [LOW_DTYPE, torch.float32])
+def test_conv_add_mask_epilogue_is_bit_identical_to_conv_plus_relu_bwd(dtype):
+    """dgrad + residual join + ReLU mask in one launch (VNQA_EPI_ADD_MASK) vs conv2d_igemm followed by relu_bwd(a, y, b)."""
+    from videonavqa_amd import kernels as K
+    n_img, h, w, C = 7, 14, 14, 128
+    dz = _padded(n_img, h, w, C, dtype, 11)
+    dout = _padded(n_img, h, w, C, dtype, 12)
+    res = _padded(n_img, h, w, C, dtype, 13).relu()
+    g = torch.Generator().manual_seed(14)
+    wt = K.pack_conv_weight((torch.randn(C, C, 3, 3, generator=g) * 0.05).cuda(), dtype, transpose_flip=True)
+    ref = K.relu_bwd(K.conv2d_igemm(dz, wt), res, dout)
+    got = K.conv2d_igemm_add_mask(dz, wt, dout, res)
+    assert torch.equal(got, ref)
+    assert float(got[:, 0].abs().max()) == 0 and float(got[:, :, -1].abs().max()) == 0

@@ -55,7 +55,7 @@ class ConvEpilogue(ctypes.Structure):
                 ("gamma", _vp), ("beta", _vp), ("res", _vp), ("y2", _vp)]
 
 
-EPI_NONE, EPI_BNSTATS, EPI_FILM_RES = 0, 1, 2
+EPI_NONE, EPI_BNSTATS, EPI_FILM_RES, EPI_ADD_MASK = 0, 1, 2, 3
 
 _MAC_PTRS = ("control memory pq ctxw know pre mask_c wc w_ca b_ca wm bm w1 w_ra b_ra wr wmm bw "
              "cq qv p_c cnew mem v t u p_r read concat d_cnew d_concat d_control d_memory d_cq "

@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     T out[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) out[e] = ElemOps<T>::store(v[e]);
-    *(uint4*)dst = *(const uint4*)out;
+    if (!(TAG == 0 && p.epi == VNQA_EPI_ADD_MASK)) *(uint4*)dst = *(const uint4*)out;
     if (kStatsOk && p.epi == VNQA_EPI_BNSTATS) {
       const int sl = p.frame_of[n] - frame0;        // 0..2 (checked on the host: every frame holds >= BM/3 pixels)
 #pragma unroll
@@ -655,6 +655,18 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
         o2[e] = ElemOps<T>::store(fmaxf(ga[e] * v[e] + be[e], 0.f) + r[e]);
       }
       *(uint4*)((T*)p.y2 + ooff) = *(const uint4*)o2;
+    } else if (TAG == 0 && p.epi == VNQA_EPI_ADD_MASK) {
+      // y = (conv + add) * [mask > 0]: the residual join and the ReLU mask of the FiLM block's backward on the dgrad's
+      // storage-rounded output (`out`: exactly what the plain conv would have stored)
+      const uint4 araw = *(const uint4*)((const T*)p.res + ooff);
+      const uint4 mraw = *(const uint4*)((const T*)p.y2 + ooff);
+      const T* at = (const T*)&araw;
+      const T* mt = (const T*)&mraw;
+      T o2[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e)
+        o2[e] = ElemOps<T>::store(ElemOps<T>::load(mt[e]) > 0.f ? ElemOps<T>::load(out[e]) + ElemOps<T>::load(at[e]) : 0.f);
+      *(uint4*)dst = *(const uint4*)o2;
     }
   }
   if (kStatsOk && p.epi == VNQA_EPI_BNSTATS) {
@@ -1195,6 +1207,14 @@ extern "C" int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* 
     a.film_c = e->film_c;
     a.res = (const char*)e->res;
     a.y2 = (char*)e->y2;
+    return conv_dispatch(a, d->dtype, d->tile, st);
+  }
+  if (e->kind == VNQA_EPI_ADD_MASK) {
+    VNQA_CHECK_ARG(e->res && e->y2, "conv2d_igemm_fused_fwd(ADD_MASK): res (the addend) and y2 (the mask source) are required");
+    VNQA_CHECK_ARG(!d->relu && bias == nullptr, "conv2d_igemm_fused_fwd(ADD_MASK): no bias / ReLU on the conv itself");
+    a.epi = VNQA_EPI_ADD_MASK;
+    a.res = (const char*)e->res;
+    a.y2 = (char*)e->y2;          // read-only here: the tensor whose sign is the mask
     return conv_dispatch(a, d->dtype, d->tile, st);
   }
   vnqa_set_error("conv2d_igemm_fused_fwd: unknown epilogue kind %d", e->kind);

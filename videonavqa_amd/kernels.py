@@ -136,6 +136,20 @@ def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res):
     return z, out
 
 
+def conv2d_igemm_add_mask(x, wt, add, mask_src):
+    """(conv(x) + add) * [mask_src > 0] in ONE launch (VNQA_EPI_ADD_MASK): the dgrad of the FiLM block's 3x3 conv joined with the
+    residual branch's gradient and masked by the 1x1 conv's ReLU."""
+    N, Hp, Wp, _ = x.shape
+    c_out, taps, _ = wt.shape
+    assert add.shape == (N, Hp, Wp, c_out) and mask_src.shape == add.shape and add.dtype == x.dtype == mask_src.dtype
+    d = _conv_desc(x, c_out, c_out, taps, False)
+    y = empty_padded((N, Hp, Wp, c_out), x.dtype, x.device)
+    e = L.ConvEpilogue(kind=L.EPI_ADD_MASK, res=add.data_ptr(), y2=mask_src.data_ptr())
+    L.check(L.lib().vnqa_conv2d_igemm_fused_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), None, ctypes.byref(e), L.ptr(y),
+                                                L.stream()), "vnqa_conv2d_igemm_fused_fwd(ADD_MASK)")
+    return y
+
+
 def film_relu_res_bwd_ld(dout, z, gamma, beta, film_c, dgamma, dbeta):
     """FiLM backward on column-slice views: gamma/beta [n_img, >= film_c] (row stride = view stride), gradients written into
     the views dgamma/dbeta (same column range of the gradient matrix)."""

@@ -269,8 +269,10 @@ class FilmTrunkFn(torch.autograd.Function):
             grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw), alpha=inv))
             direct_b = sb is not None and dbias.data_ptr() == sb.view.data_ptr()      # (only without channel padding)
             grads_blocks[4 * k + 3] = _ret(sb if direct_b else None, dbias[:C] * inv if scaled else dbias[:C])
-            dres = K.conv2d_igemm(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
-            gsum = K.relu_bwd(dres, res, dout)             # (dres + dout) * [res > 0]: residual join + the 1x1 conv's ReLU
+            # (dgrad(dz) + dout) * [res > 0]: the 3x3 conv's dgrad with the residual join and the 1x1 conv's ReLU mask in its
+            # epilogue (VNQA_EPI_ADD_MASK; bit-identical to conv2d_igemm followed by relu_bwd(dres, res, dout))
+            gsum = K.conv2d_igemm_add_mask(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad),
+                                           dout, res)
             # (the 1x1 convs are frozen upstream — never in parameters() — so they get no weight gradient)
             wt1d = meta.c1_packs[k][1] if meta.c1_packs else \
                 K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad)
