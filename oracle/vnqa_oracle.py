@@ -200,6 +200,26 @@ def _film_values_lstm(W, q_input, q_lens, hidden, ct_B):
     return F.relu(last @ W["film_layer.1.weight"].t() + W["film_layer.1.bias"]), hidden
 
 
+def _film_values_bow(W, q_input, ct_B):
+    """compute_film_values, bag-of-words encoder (film_attn_pt_stem.py:145,171-181; the pooling model's is the same,
+    film_global_pooling_pt_stem.py:138,164-174): Linear over every token position of the UNSORTED padded question, summed over
+    positions (padding tokens included); the division by the question length at :175-176 discards its result, so the
+    sum stands.  No carried state."""
+    x = F.embedding(q_input, W["embed.weight"], padding_idx=W.get("_embed_padding_idx", None))
+    x = (x @ W["film_layer.0.weight"].t() + W["film_layer.0.bias"]).sum(dim=1)[:ct_B]
+    return F.relu(x @ W["film_layer.1.weight"].t() + W["film_layer.1.bias"])
+
+
+def _is_bow(W):
+    return "film_layer.0.weight" in W
+
+
+def _film_values(W, q_input, q_lens, hidden, ct_B):
+    if _is_bow(W):
+        return _film_values_bow(W, q_input, ct_B), hidden
+    return _film_values_lstm(W, q_input, q_lens, hidden, ct_B)
+
+
 # --------------------------------------------------------------------------
 # FiLMAttnPretrainedStem.forward
 # --------------------------------------------------------------------------
@@ -208,7 +228,7 @@ def film_attn_forward(W, v_input, q_input, v_lens, q_lens, training=True, aux=No
     v_input [B,C_in,h,w,T]; v_lens sorted descending.  Returns logits [B,nb_classes].
     `aux` (dict) receives BN running stats, the carried LSTM state and intermediates."""
     B, T = v_input.shape[0], v_input.shape[-1]
-    Hq = W["film_layer.0.weight_hh_l0"].shape[1]
+    Hq = W["film_layer.1.weight"].shape[1]
     at = W["fc_attn_1.weight"].shape[1]
     nblocks = _num_blocks(W)
     hidden = (v_input.new_zeros(B, Hq), v_input.new_zeros(B, Hq))           # init_hidden :133-138
@@ -221,7 +241,7 @@ def film_attn_forward(W, v_input, q_input, v_lens, q_lens, training=True, aux=No
         x = v_input[:ct, :, :, :, i]                                        # :210
         x = F.relu(F.conv2d(x, W["conv_init.weight"], W["conv_init.bias"], padding=1))
         x = bn_train_frame(x, W["bn_init.weight"], W["bn_init.bias"], bn)   # :211
-        film_values, hidden = _film_values_lstm(W, q_input, q_lens, hidden, ct)  # :213
+        film_values, hidden = _film_values(W, q_input, q_lens, hidden, ct)  # :213
         film_per_frame.append(film_values)
         s = 0
         for k in range(nblocks):                                            # :217-241
@@ -273,7 +293,7 @@ def film_gp_forward(W, v_input, q_input, v_lens, q_lens, training=True, aux=None
     """FiLMGlobalPoolingPretrainedStem.forward (film_global_pooling_pt_stem.py:180-238);
     embedding has padding_idx=0 (:34) which only matters for the gradient."""
     B, T = v_input.shape[0], v_input.shape[-1]
-    Hq = W["film_layer.0.weight_hh_l0"].shape[1]
+    Hq = W["film_layer.1.weight"].shape[1]
     nblocks = _num_blocks(W)
     W = dict(W)
     W["_embed_padding_idx"] = 0
@@ -284,7 +304,7 @@ def film_gp_forward(W, v_input, q_input, v_lens, q_lens, training=True, aux=None
         x = v_input[:ct, :, :, :, i]
         x = F.relu(F.conv2d(x, W["conv_init.weight"], W["conv_init.bias"], padding=1))
         x = bn_train_frame(x, W["bn_init.weight"], W["bn_init.bias"], bn)   # :196
-        film_values, hidden = _film_values_lstm(W, q_input, q_lens, hidden, ct)  # :198
+        film_values, hidden = _film_values(W, q_input, q_lens, hidden, ct)  # :198
         s = 0
         for k in range(nblocks):
             x, s = film_res_block(x, film_values, s, W, k)

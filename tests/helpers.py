@@ -45,8 +45,8 @@ def model_of_case(case):
     raise KeyError(case)
 
 
-QV_CASES = ["film_attn_full", "film_attn_ragged", "film_attn_short", "film_attn_s196", "film_attn_b5",
-            "film_gp_full", "film_gp_ragged", "tmh_full", "tmh_ragged"]
+QV_CASES = ["film_attn_full", "film_attn_ragged", "film_attn_short", "film_attn_s196", "film_attn_b5", "film_attn_bow",
+            "film_gp_full", "film_gp_ragged", "film_gp_bow", "tmh_full", "tmh_ragged"]
 
 
 # constructor arguments used by tools/capture_goldens.py for each golden case
@@ -75,9 +75,12 @@ def build_product_model(case, precision):
         if case == "film_attn_b5":          # eval.sh's depth: 5 FiLM blocks, 14x14 maps
             kw["num_res_blocks"] = 5
             spatial = 196
+        if case == "film_attn_bow":         # q_encoder='bow' (film_attn_pt_stem.py:75-77,171-177)
+            kw["q_encoder"] = "bow"
         model = M.FiLMAttnPretrainedStem(spatial_size=spatial, precision=precision, **kw)
     elif case.startswith("film_gp"):
-        model = M.FiLMGlobalPoolingPretrainedStem(spatial_size=130, precision=precision, **GP_KW)
+        kw = dict(GP_KW, q_encoder="bow") if case == "film_gp_bow" else GP_KW
+        model = M.FiLMGlobalPoolingPretrainedStem(spatial_size=130, precision=precision, **kw)
     else:
         model = M.TimeMultiHopFiLMPretrainedStem(spatial_size=130, precision=precision, **TMH_KW)
     model = model.cuda()

@@ -58,7 +58,8 @@ def test_train_forward_backward_vs_reference_golden(case, precision):
     assert rel_err(model.bn_init.running_mean.cpu().numpy(), g["bn_running_mean_after"]) < tol
     assert rel_err(model.bn_init.running_var.cpu().numpy(), g["bn_running_var_after"]) < tol
     # carried LSTM state is kept in q_len-sorted order like the reference (ties: stable order)
-    assert rel_err(model.film_hidden[0][0].cpu().numpy(), g["film_hidden_h_after"][0]) < tol
+    if "film_hidden_h_after" in g:          # (the bag-of-words encoder carries no state)
+        assert rel_err(model.film_hidden[0][0].cpu().numpy(), g["film_hidden_h_after"][0]) < tol
     # fp32: every element within 2e-3 of the tensor's max |grad|.  bf16 (stated, looser): ReLU/FiLM
     # masks of near-zero activations may flip under bf16 rounding, so single elements can move a
     # lot on these tiny nets; bound the relative L2 error per tensor and the worst element.

@@ -43,8 +43,9 @@ def test_train_forward_backward(case):
     assert rel_err(aux["bn"]["running_var"].numpy(), g["bn_running_var_after"]) < 1e-5
     # the reference keeps the carried state in q_len-sorted order (film_attn_pt_stem.py:150,160)
     perm = ql.sort(0, descending=True)[1]
-    assert rel_err(aux["hidden"][0].detach()[perm].numpy(), g["film_hidden_h_after"][0]) < 2e-5
-    assert rel_err(aux["hidden"][1].detach()[perm].numpy(), g["film_hidden_c_after"][0]) < 2e-5
+    if "film_hidden_h_after" in g:          # the bag-of-words encoder carries no state
+        assert rel_err(aux["hidden"][0].detach()[perm].numpy(), g["film_hidden_h_after"][0]) < 2e-5
+        assert rel_err(aux["hidden"][1].detach()[perm].numpy(), g["film_hidden_c_after"][0]) < 2e-5
     checked = 0
     for k, gr in zip(names, grads):
         ref = g["grad/" + k]

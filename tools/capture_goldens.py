@@ -101,7 +101,7 @@ def make_inputs(rng, B, C_in, h, w, T, L, vocab, nb_classes, v_lens, q_lens):
 
 
 def run_qv_case(out_dir, name, cls, ctor_kwargs, B, C_in, T, L, v_lens, q_lens, seed,
-                spatial=(10, 13), train_steps=3, lr=1e-3, patch_spatial=None):
+                spatial=(10, 13), train_steps=3, lr=1e-3, patch_spatial=None, post_fill=None):
     """Forward/backward/trajectory for one of the three FiLM models."""
     torch.manual_seed(0)
     model = cls(**ctor_kwargs)
@@ -117,6 +117,8 @@ def run_qv_case(out_dir, name, cls, ctor_kwargs, B, C_in, T, L, v_lens, q_lens, 
         else:
             model.out_linear = nn.Linear(S * ctor_kwargs["num_tail_channels"], model.nb_classes)
     seeded_fill(model, seed)
+    if post_fill is not None:
+        post_fill(model)
     rng = np.random.RandomState(seed + 1)
     vocab = ctor_kwargs["vocab_size"]
     nb_classes = ctor_kwargs["nb_classes"]
@@ -150,8 +152,9 @@ def run_qv_case(out_dir, name, cls, ctor_kwargs, B, C_in, T, L, v_lens, q_lens, 
         rec["grad/" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
     rec["bn_running_mean_after"] = model.bn_init.running_mean.numpy().copy()
     rec["bn_running_var_after"] = model.bn_init.running_var.numpy().copy()
-    rec["film_hidden_h_after"] = model.film_hidden[0].detach().numpy().copy()
-    rec["film_hidden_c_after"] = model.film_hidden[1].detach().numpy().copy()
+    if getattr(model, "q_encoder", "lstm") != "bow":          # the bag-of-words encoder carries no state (:133-138)
+        rec["film_hidden_h_after"] = model.film_hidden[0].detach().numpy().copy()
+        rec["film_hidden_c_after"] = model.film_hidden[1].detach().numpy().copy()
 
     # ---- short training trajectory: clip 1.0 + Adam over REGISTERED params
     #      (q_and_v_eval.py:136-139, :333) ----
@@ -372,6 +375,8 @@ def main():
                    at_hidden_size=16, max_num_frames=T, q_encoder="lstm", vocab_size=20)
     if args.only == "film_attn_b5":
         return main_b5(out_dir, attn_kw, B, C_in, T, L, FiLMAttnPretrainedStem)
+    if args.only == "bow":
+        return main_bow(out_dir, attn_kw, B, C_in, T, L, FiLMAttnPretrainedStem, FiLMGlobalPoolingPretrainedStem)
     run_qv_case(out_dir, "film_attn_full", FiLMAttnPretrainedStem, attn_kw, B, C_in, T, L,
                 v_lens=[6, 6, 6], q_lens=[9, 5, 7], seed=11)
     run_qv_case(out_dir, "film_attn_ragged", FiLMAttnPretrainedStem, attn_kw, B, C_in, T, L,
@@ -410,6 +415,7 @@ def main():
     run_qv_case(out_dir, "tmh_ragged", TimeMultiHopFiLMPretrainedStem, tmh_kw, B, C_in, T, L,
                 v_lens=[6, 4, 2], q_lens=[4, 9, 6], seed=32)
 
+    main_bow(out_dir, attn_kw, B, C_in, T, L, FiLMAttnPretrainedStem, FiLMGlobalPoolingPretrainedStem)
     run_objdet_case(out_dir, "objdet_f16", num_filters=16, N=2, H=16, W=24, seed=41)
     run_cnn3d_case(out_dir, "cnn3d_small", seed=51)
     run_qonly_case(out_dir, "qonly_small", seed=61)
@@ -421,6 +427,28 @@ def main_b5(out_dir, attn_kw, B, C_in, T, L, cls):
     attn_b5["num_res_blocks"] = 5
     run_qv_case(out_dir, "film_attn_b5", cls, attn_b5, B, C_in, T, L, v_lens=[6, 4, 3], q_lens=[5, 9, 2], seed=15,
                 patch_spatial=(14, 14))
+
+
+def main_bow(out_dir, attn_kw, B, C_in, T, L, attn_cls, gp_cls):
+    """q_encoder='bow' (film_attn_pt_stem.py:75-77,171-177).  Upstream names `torch.cuda.FloatTensor` in a statement whose
+    result it discards (:176); on this CUDA-less box the name is pointed at the CPU tensor type for the capture so that the
+    statement stays the no-op it is on a GPU.  Nothing else is touched."""
+    torch.cuda.FloatTensor = torch.FloatTensor
+    kw = dict(attn_kw)
+    kw["q_encoder"] = "bow"
+
+    def calm(model):
+        # the encoder's output is SUMMED over the 9 token positions: keep the FiLM gammas O(1) like the LSTM cases'
+        with torch.no_grad():
+            model.film_layer[0].weight.mul_(0.3)
+            model.film_layer[0].bias.mul_(0.1)
+
+    run_qv_case(out_dir, "film_attn_bow", attn_cls, kw, B, C_in, T, L, v_lens=[6, 4, 2], q_lens=[4, 9, 6], seed=16,
+                post_fill=calm)
+    gp_kw = dict(batch_size=B, q_embedding_size=12, nb_classes=7, num_input_channels=C_in, num_res_block_channels=8,
+                 num_tail_channels=4, num_res_blocks=2, hidden_size=16, q_encoder="bow", vocab_size=20)
+    run_qv_case(out_dir, "film_gp_bow", gp_cls, gp_kw, B, C_in, T, L, v_lens=[6, 5, 3], q_lens=[9, 2, 7], seed=23,
+                post_fill=calm)
 
 
 def run_mac_only(out_dir):

@@ -378,6 +378,17 @@ class FiLMTrunkBase(nn.Module):
         self._store_question_state(hn, cn, q_lens)
         return ops.linear(hs.view(B * S, H), proj.weight, proj.bias, relu=True, rows=rows)
 
+    def bow_film_values(self, enc, proj, q_input, lay):
+        """FiLM generator with q_encoder='bow' (film_attn_pt_stem.py:75-77,171-181 / film_global_pooling_pt_stem.py:164-174):
+        nn.Linear over every position of the padded question, summed over positions (padding tokens included — upstream's
+        division by the question length at :175-176 discards its result), then Linear + ReLU.  No carried state, the same
+        values for every frame; both products on the fp32 HIP GEMM.  Returns film [n_img, 2*C*blocks] fp32."""
+        B, Lq = q_input.shape
+        emb = self.embed(q_input)
+        pooled = ops.linear(emb.reshape(B * Lq, -1), enc.weight, enc.bias).view(B, Lq, -1).sum(1)
+        film = ops.linear(pooled, proj.weight, proj.bias, relu=True)
+        return film.index_select(0, lay.sample_of)
+
     # ---- conv trunk on the packed image list -------------------------------------------------
     def _trunk_fused(self, x, lay, film_specs):
         """TRAIN-mode trunk as one autograd node with the fused conv epilogues (ops.FilmTrunkFn).

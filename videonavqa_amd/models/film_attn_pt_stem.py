@@ -21,9 +21,6 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
                  precision='bf16'):
         super(FiLMAttnPretrainedStem, self).__init__()
         assert q_encoder.lower() in ['lstm', 'bow'], "Invalid question encoder! ('lstm', 'bow')"
-        if q_encoder.lower() != 'lstm':
-            # the reference's BoW branch is CUDA-only and discards its division (:173-177); not built
-            raise NotImplementedError("q_encoder='bow' is not implemented on the MI355X path")
         self.q_encoder = q_encoder
         self.nb_classes = nb_classes
         self.batch_size = batch_size
@@ -36,7 +33,9 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         self.embed = nn.Embedding(vocab_size, q_embedding_size)                       # :37
         self._build_trunk_head(num_input_channels, num_res_block_channels)             # :39-44
         total_out_size = 2 * num_res_block_channels * num_res_blocks
-        self.film_layer = nn.ModuleList([nn.LSTM(q_embedding_size, hidden_size),      # :51,75-87 (GPU flavour)
+        encoder = nn.LSTM(q_embedding_size, hidden_size) if q_encoder == 'lstm' else \
+            nn.Linear(q_embedding_size, hidden_size)                                   # :75-77 (compared as given, like upstream)
+        self.film_layer = nn.ModuleList([encoder,                                      # :51,75-87 (GPU flavour)
                                          nn.Linear(hidden_size, total_out_size),
                                          nn.ReLU(inplace=True)])
         self._build_film_pipeline(num_res_block_channels, num_res_blocks)              # :52,93-108
@@ -51,8 +50,9 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         self.init_hidden()
 
     def init_hidden(self):
-        """film_attn_pt_stem.py:133-138."""
-        self.film_hidden = self._zero_hidden(self.batch_size, self.hidden_size, self.embed.weight.device)
+        """film_attn_pt_stem.py:133-138 (the bag-of-words encoder carries no state)."""
+        if self.q_encoder == 'lstm':
+            self.film_hidden = self._zero_hidden(self.batch_size, self.hidden_size, self.embed.weight.device)
 
     def forward(self, v_input, q_input, v_lens, q_lens):
         """v_input: fp32 [B, C_in, h, w, T] (reference layout) or NativeFeatures from the stem;
@@ -68,12 +68,16 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         # fp16 storage: the tail's backward emits d f times 2^10, FcNativeFn / FilmTrunkFn divide their fp32 results by it
         gscale = grad_scale_of(self.compute_dtype) if fused else 1.0
         self._trunk_grad_scale = gscale
+        bow = not isinstance(self.film_layer[0], nn.LSTM)                    # :158
         if fused:       # train mode: generator and conv trunk on fused HIP ops (one autograd node for the trunk)
-            film_img = self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay)
+            film_img = self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay) if bow else \
+                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay)
             x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])   # :229-233
         else:
             # FiLM generator: question LSTM re-run per processed frame with carried state (:213) — on the side stream
             def generator():
+                if bow:
+                    return self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay)
                 emb = self.embed(q_input)
                 h0, c0 = self._question_state(B, self.hidden_size, q_lens, dev)
                 h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,

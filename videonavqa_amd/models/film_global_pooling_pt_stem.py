@@ -14,8 +14,6 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
                  q_encoder='lstm', vocab_size=134, *, spatial_size=130, precision='bf16'):
         super(FiLMGlobalPoolingPretrainedStem, self).__init__()
         assert q_encoder.lower() in ['lstm', 'bow'], "Invalid question encoder! ('lstm', 'bow')"
-        if q_encoder.lower() != 'lstm':
-            raise NotImplementedError("q_encoder='bow' is not implemented on the MI355X path")
         self.q_encoder = q_encoder
         self.nb_classes = nb_classes
         self.batch_size = batch_size
@@ -27,7 +25,9 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
         self.embed = nn.Embedding(vocab_size, q_embedding_size, padding_idx=0)        # :34
         self._build_trunk_head(num_input_channels, num_res_block_channels)             # :38-41
         total_out_size = 2 * num_res_block_channels * num_res_blocks
-        self.film_layer = nn.ModuleList([nn.LSTM(q_embedding_size, hidden_size),      # :48
+        encoder = nn.LSTM(q_embedding_size, hidden_size) if q_encoder == 'lstm' else \
+            nn.Linear(q_embedding_size, hidden_size)                                   # :69-71
+        self.film_layer = nn.ModuleList([encoder,                                      # :48
                                          nn.Linear(hidden_size, total_out_size),
                                          nn.ReLU(inplace=True)])
         self._build_film_pipeline(num_res_block_channels, num_res_blocks)              # :49
@@ -41,7 +41,8 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
         self.init_hidden()
 
     def init_hidden(self):
-        self.film_hidden = self._zero_hidden(self.batch_size, self.hidden_size, self.embed.weight.device)
+        if self.q_encoder == 'lstm':          # :125-130 (the bag-of-words encoder carries no state)
+            self.film_hidden = self._zero_hidden(self.batch_size, self.hidden_size, self.embed.weight.device)
 
     def forward(self, v_input, q_input, v_lens, q_lens):
         """film_global_pooling_pt_stem.py:180-238."""
@@ -51,7 +52,11 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
         C = self.num_res_block_channels
         dev = x.device
 
+        bow = not isinstance(self.film_layer[0], nn.LSTM)                    # :150
+
         def generator():     # question LSTM + FiLM projection on the side stream (common.FiLMTrunkBase._fork_generator)
+            if bow:
+                return self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay)
             emb = self.embed(q_input)
             h0, c0 = self._question_state(lay.B, self.hidden_size, q_lens, dev)
             h_last, _, (hn, cn) = repeated_question_lstm(self.film_layer[0], emb, q_lens, lay.n_frames, h0, c0,
@@ -62,7 +67,8 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
 
         self._trunk_grad_scale = grad_scale_of(self.compute_dtype) if self._use_fused_trunk() else 1.0
         if self._use_fused_trunk():       # train mode: generator and conv trunk on fused HIP ops
-            film_img = self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay, padding_idx=0)
+            film_img = self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay) if bow else \
+                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay, padding_idx=0)
             x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])
         else:
             film_img, join = self._fork_generator(generator)
