@@ -440,8 +440,8 @@ def main_bow(out_dir, attn_kw, B, C_in, T, L, attn_cls, gp_cls):
     def calm(model):
         # the encoder's output is SUMMED over the 9 token positions: keep the FiLM gammas O(1) like the LSTM cases'
         with torch.no_grad():
-            model.film_layer[0].weight.mul_(0.3)
-            model.film_layer[0].bias.mul_(0.1)
+            model.film_layer[0].weight.mul_(0.2)
+            model.film_layer[0].bias.mul_(0.05)
 
     run_qv_case(out_dir, "film_attn_bow", attn_cls, kw, B, C_in, T, L, v_lens=[6, 4, 2], q_lens=[4, 9, 6], seed=16,
                 post_fill=calm)
