@@ -1,0 +1,11 @@
+#!/bin/bash
+# Same-box interleaved A/B of environment knobs on the headline bench:
+#   tools/ab_env.sh [rounds] "VAR=1" "OTHER=2 THIRD=3" ...     (the empty setting "" = defaults is always included)
+# prints clips/s and stem_alone_ms per run.
+R=${1:-2}; shift
+for i in $(seq $R); do
+  for S in "" "$@"; do
+    V=$(env $S timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-fp16-leg --repeats 1 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["config"]["stem_alone_ms"])')
+    echo "[${S:-default}] $V"
+  done
+done
