@@ -35,6 +35,15 @@ constexpr int CROW = BN * 2 + 16;
 static_assert(BM * CROW <= LDS_BYTES, "epilogue tile must fit");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
 
+// XOR swizzle of the PATCH rows (16-byte chunk ^= pswz(row)).  The tap shifts start a pixel fragment at any patch row, and a
+// ds_read_b128 is served in non-contiguous 16-lane groups: `row & 6` is conflict-free for every start row (see conv_c64.hip,
+// tools/lds_swizzle_check.py); the weight slab, whose fragments start at multiples of 16, keeps (row >> 1) & 7.
+#ifdef VNQA_PATCH_OLD_SWIZZLE
+__device__ __forceinline__ int pswz(int row) { return (row >> 1) & 7; }
+#else
+__device__ __forceinline__ int pswz(int row) { return row & 6; }
+#endif
+
 __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -88,7 +97,7 @@ __global__ void __launch_bounds__(NT) conv_patch_kernel(const ConvArgs p) {
     int lin = (wave + NW * j) * 8 + (lane >> 3);
     lin = lin < n_lin ? lin : n_lin - 1;  // rows past the patch are never read; keep the address in bounds
     const int i = lin / PW, jj = lin - i * PW;
-    const int chunk = (lane & 7) ^ ((lin >> 1) & 7);
+    const int chunk = (lane & 7) ^ pswz((wave + NW * j) * 8 + (lane >> 3));      // keyed on the LDS row (before the clamp)
     a_off[j] = ((size_t)(pr_first + i) * p.Wp + cb * TC + jj) * cin_b + (size_t)chunk * 16;
   }
   size_t b_off[B_PER_WAVE];
@@ -163,7 +172,7 @@ __global__ void __launch_bounds__(NT) conv_patch_kernel(const ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int lin = x_lin[i] + tapoff;
-      xf[i] = *(const vnqa_f32x4*)(pb + lin * 128 + (((4 * s + fh) ^ ((lin >> 1) & 7)) << 4));
+      xf[i] = *(const vnqa_f32x4*)(pb + lin * 128 + (((4 * s + fh) ^ pswz(lin)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) wf[j] = *(const vnqa_f32x4*)(bb + (w_rd[j] ^ (s << 6)));
