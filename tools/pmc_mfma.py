@@ -78,7 +78,7 @@ def main():
                     "effective_clock = active_cycles / duration; wait/issue/active fractions are of SQ_WAVE_CYCLES; "
                     "lds_bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE",
         "note": "profiled passes run at a lower clock than un-profiled ones (guide: DVFS give-back); durations here are the profiled ones",
-        "kernels": rows[:12]}, indent=1))
+        "kernels": rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 12]}, indent=1))
 
 
 if __name__ == "__main__":

@@ -788,19 +788,42 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
 }
 
 
-// out[m][n] = act( sum_s slab[s][m][n] + bias[n] ), fixed summation order (deterministic)
+// out[m][n] = act( sum_s slab[s][m][n] + bias[n] ), fixed summation order (deterministic).
+// A 256-thread block owns 16 groups of 4 consecutive outputs: thread (g = tid & 15, q = tid >> 4) sums the slices
+// q, q + 16, q + 32, ... of its group with 16-byte loads (16 independent streams per output instead of one thread walking
+// all slices at load latency: 62 -> 15 us for fc_embed_attn's 256 x [280 x 128] partials), then the 16 partial sums are
+// added in the order q = 0..15 through LDS.
 template <typename T>
-__global__ void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias, T* __restrict__ out,
-                                     int M, int N, int ldo, int slices, int relu) {
-  const size_t total = (size_t)M * N;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                            T* __restrict__ out, int M, int N, int ldo, int slices, int relu) {
+  __shared__ float4 part[16][16];
+  const size_t total = (size_t)M * N;                 // N % 8 == 0, so groups of 4 never straddle a row
+  const int g = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const size_t i = ((size_t)blockIdx.x * 16 + g) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < total) {
+    for (int k = q; k < slices; k += 16) {
+      const float4 v = *(const float4*)(slab + (size_t)k * total + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  part[q][g] = s;
+  __syncthreads();
+  if (q == 0 && i < total) {
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+      const float4 v = part[r][g];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
     const int n = (int)(i % N);
     const size_t m = i / N;
-    float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += slab[(size_t)k * total + i];
-    if (bias) s += bias[n];
-    if (relu) s = fmaxf(s, 0.f);
-    out[m * ldo + n] = ElemOps<T>::store(s);
+    float o[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (bias) o[e] += bias[n + e];
+      if (relu) o[e] = fmaxf(o[e], 0.f);
+      out[m * ldo + n + e] = ElemOps<T>::store(o[e]);
+    }
   }
 }
 
@@ -955,8 +978,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
     const int rc = conv_dispatch(a, dtype, tile, st);
     if (rc != VNQA_OK) return rc;
     const size_t total = (size_t)m * n;
-    int g = (int)((total + 255) / 256);
-    g = g > 2048 ? 2048 : g;
+    const int g = (int)((total / 4 + 15) / 16);
     if (dtype == VNQA_BF16)
       hipLaunchKernelGGL(splitk_reduce_kernel<vnqa_bf16>, dim3(g), dim3(256), 0, st, (const float*)workspace, bias,
                          (vnqa_bf16*)out, m, n, ldo, a.slices, relu);
