@@ -17,6 +17,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-prefetch", action="store_true", help="run each step's stem inline instead of under the previous trunk")
+    ap.add_argument("--every", type=int, default=25, help="print every N steps")
     a = ap.parse_args()
     args = argparse.Namespace(precision=a.precision, batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
                               model="film_attn_pt")
@@ -41,8 +43,11 @@ def main():
         cur, nxt = pool[i % 6], pool[(i + 1) % 6]
         c, n = q
         q[0], q[1] = n, tr.upload(pool[(i + 2) % 6][0])
-        loss, _ = tr.step(c, cur[1], cur[2], cur[3], cur[4], next_clip=n, next_v_lens_cpu=nxt[2])
-        if i % 25 == 24:
+        if a.no_prefetch:
+            loss, _ = tr.step(c, cur[1], cur[2], cur[3], cur[4])
+        else:
+            loss, _ = tr.step(c, cur[1], cur[2], cur[3], cur[4], next_clip=n, next_v_lens_cpu=nxt[2])
+        if i % a.every == a.every - 1:
             losses.append(float(loss))
             mem = torch.cuda.memory_allocated() / 2**30
             rsv = torch.cuda.memory_reserved() / 2**30

@@ -227,6 +227,9 @@ class Trainer(object):
             self._up_bufs[i] = torch.empty(clip_host.shape, dtype=clip_host.dtype, device=self.stem_device)
         buf = self._up_bufs[i]
         self.copy_stream.wait_stream(self.stem_stream)       # the stem that last read this buffer is long queued
+        # ... or it ran inline on the caller's stream (a step whose clip was not prefetched): the buffer was handed out three
+        # uploads ago, so waiting for what that stream holds NOW costs no overlap — this copy still runs under the next step
+        self.copy_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.copy_stream):
             buf.copy_(clip_host, non_blocking=True)
             ev = torch.cuda.Event()
