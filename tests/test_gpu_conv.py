@@ -385,6 +385,30 @@ def test_fc_weight_pack_unpack(dt, cfg):
     assert torch.equal(back, ref_b)
 
 
+@pytest.mark.parametrize("cfg", [(280, 256 * 512), (7, 128), (320, 5 * 128), (33, 300 * 128)])
+def test_fc_dx_matches_generic_gemm(cfg):
+    """vnqa_fc_dx (dX of fc_embed_attn from the forward operand, resident dout + transposed LDS reads) against the generic
+    path it replaces (vnqa_gemm_nt on the transposed copy: same 16-bit operands, fp32 accumulation over 128 terms, one
+    rounding) and against torch's fp32 product of the same rounded operands."""
+    from videonavqa_amd import kernels as K
+    from helpers import LOW_DTYPE
+    m, kn = cfg
+    g = torch.Generator(device="cpu").manual_seed(m + kn)
+    dout = torch.randn(m, 128, generator=g).cuda().to(LOW_DTYPE)
+    nat = (torch.randn(128, kn, generator=g) * 0.1).cuda().to(LOW_DTYPE)
+    assert K.fc_dx_supported(m, 128, kn, LOW_DTYPE)
+    dx = K.fc_dx(dout, nat)
+    ref = dout.float() @ nat.float()
+    assert dx.shape == ref.shape
+    assert _rel(dx.float(), ref) < 6e-3, _rel(dx.float(), ref)
+    old = K.gemm_nt(dout, nat.t().contiguous())
+    # both accumulate the same 128 products in fp32 (in different orders) and round once: at most one ulp apart
+    ulp = 2.0 ** -7 if LOW_DTYPE == torch.bfloat16 else 2.0 ** -10
+    assert float(((dx.float() - old.float()).abs() / (ref.abs() + 1e-3)).max()) <= 2 * ulp
+    assert not K.fc_dx_supported(321, 128, kn, LOW_DTYPE) and not K.fc_dx_supported(m, 64, kn, LOW_DTYPE)
+    assert not K.fc_dx_supported(m, 128, kn, torch.float32)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 6, 8, 64, 128, 192), (3, 14, 12, 128, 512, 512), (1, 4, 4, 64, 64, 64)])
 def test_composed_conv_pair_matches_two_step(dt, cfg):

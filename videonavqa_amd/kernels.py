@@ -302,6 +302,21 @@ def pack_fc_weight(w, C, h, wd, c_pad, rows_pad, dtype, want_t=True):
     return nat, nat_t
 
 
+def fc_dx_supported(m, rows_pad, kn, dtype):
+    """vnqa_fc_dx's shapes: 16-bit storage, contraction 128, at most 320 rows, a whole number of 128-column slabs."""
+    return L.is_half(dtype) and rows_pad == 128 and 0 < m <= 320 and kn % 128 == 0
+
+
+def fc_dx(dout, nat):
+    """dx [m, kn] = dout [m, 128] @ nat [128, kn] (16-bit): the Linear's input gradient from its forward operand."""
+    m, r = dout.shape
+    kn = nat.shape[1]
+    assert nat.shape[0] == r and dout.dtype == nat.dtype and dout.is_contiguous() and nat.is_contiguous()
+    dx = torch.empty((m, kn), dtype=dout.dtype, device=dout.device)
+    L.check(L.lib().vnqa_fc_dx(L.ptr(dout), L.ptr(nat), L.ptr(dx), m, r, kn, L.dtype_id(dout.dtype), L.stream()), "vnqa_fc_dx")
+    return dx
+
+
 def unpack_fc_wgrad(dw_nat, rows, C, h, wd, c_pad, out=None, alpha=1.0):
     """fp32 gradient of the native-layout weight [rows_pad, (h+2)(wd+2)*c_pad] -> [rows, C*h*wd]."""
     dw = out if out is not None else torch.empty((rows, C * h * wd), dtype=torch.float32, device=dw_nat.device)

@@ -4,6 +4,8 @@ Activations are padded-NHWC tensors [N, H+2, W+2, Cpad] in the compute dtype (bf
 a ZERO halo; every op here preserves that invariant (gradients included), because the conv
 kernels get their zero padding — and wgrad its summation domain — from it.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -546,10 +548,13 @@ class FcNativeFn(torch.autograd.Function):
         rows = weight.shape[0]
         c_pad = x.shape[1] // ((h + 2) * (w + 2))
         need_dx = ctx.needs_input_grad[0]
-        nat, nat_t = K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, x.dtype, want_t=need_dx)
+        # dX from the forward operand alone (vnqa_fc_dx) where its shapes allow: no transposed weight copy per step
+        ctx.direct_dx = need_dx and K.fc_dx_supported(x.shape[0], rows_pad, x.shape[1], x.dtype) and \
+            os.environ.get("VNQA_FC_DX", "1") != "0"
+        nat, nat_t = K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, x.dtype, want_t=need_dx and not ctx.direct_dx)
         bias_p = K.pad_vec(bias, rows_pad)
         out = K.gemm_nt(x.contiguous(), nat, bias=bias_p)
-        ctx.save_for_backward(x, nat_t)
+        ctx.save_for_backward(x, nat if ctx.direct_dx else nat_t)
         ctx.geom = (rows, C, h, w, c_pad)
         with torch.enable_grad():
             ctx.sink_w = sink_of(weight)
@@ -561,7 +566,9 @@ class FcNativeFn(torch.autograd.Function):
         x, nat_t = ctx.saved_tensors
         rows, C, h, w, c_pad = ctx.geom
         dout = dout.to(x.dtype).contiguous()
-        dx = K.gemm_nt(dout, nat_t) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.fc_dx(dout, nat_t) if ctx.direct_dx else K.gemm_nt(dout, nat_t)     # (direct: the saved tensor is `nat`)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _ret(ctx.sink_w, K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad, out=_into(ctx.sink_w),
