@@ -246,8 +246,8 @@ int vnqa_unpack_fc_wgrad(const float* dw_nat, int32_t rows, int32_t c, int32_t h
                          float* dw, void* stream);
 /* Input gradient of that Linear from the FORWARD operand alone (round 2; replaces torch's `grad_output @ weight` of
  * models/film_attn_pt_stem.py:244 in backward):  dx[m][k] = sum_r dout[m][r] * nat[r][k],  dout [m][r], nat [r][k],
- * dx [m][k], all in the library's 16-bit format (dtype VNQA_BF16), r == 128, m <= 320, k % 128 == 0.  dout stays in LDS, `nat`
- * is streamed once in [128][128] slabs read through the transposed LDS read, dx is written once — no `nat_t` needed.
+ * dx [m][k], all in the library's 16-bit format (dtype VNQA_BF16), r == 128, k % 128 == 0.  Per 320 rows of dout (kept in LDS)
+ * `nat` is streamed once in [128][128] slabs read through the transposed LDS read and dx is written once — no `nat_t` needed.
  */
 int vnqa_fc_dx(const void* dout, const void* nat, void* dx, int32_t m, int32_t r, int32_t k, int32_t dtype, void* stream);
 int vnqa_unpack_fc_wgrad_scaled(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad, float* dw,

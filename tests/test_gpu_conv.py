@@ -385,7 +385,7 @@ def test_fc_weight_pack_unpack(dt, cfg):
     assert torch.equal(back, ref_b)
 
 
-@pytest.mark.parametrize("cfg", [(280, 256 * 512), (7, 128), (320, 5 * 128), (33, 300 * 128)])
+@pytest.mark.parametrize("cfg", [(280, 256 * 512), (7, 128), (320, 5 * 128), (33, 300 * 128), (321, 3 * 128), (1120, 40 * 128)])
 def test_fc_dx_matches_generic_gemm(cfg):
     """vnqa_fc_dx (dX of fc_embed_attn from the forward operand, resident dout + transposed LDS reads) against the generic
     path it replaces (vnqa_gemm_nt on the transposed copy: same 16-bit operands, fp32 accumulation over 128 terms, one
@@ -405,7 +405,7 @@ def test_fc_dx_matches_generic_gemm(cfg):
     # both accumulate the same 128 products in fp32 (in different orders) and round once: at most one ulp apart
     ulp = 2.0 ** -7 if LOW_DTYPE == torch.bfloat16 else 2.0 ** -10
     assert float(((dx.float() - old.float()).abs() / (ref.abs() + 1e-3)).max()) <= 2 * ulp
-    assert not K.fc_dx_supported(321, 128, kn, LOW_DTYPE) and not K.fc_dx_supported(m, 64, kn, LOW_DTYPE)
+    assert not K.fc_dx_supported(m, 64, kn, LOW_DTYPE) and not K.fc_dx_supported(m, 128, kn + 64, LOW_DTYPE)
     assert not K.fc_dx_supported(m, 128, kn, torch.float32)
 
 

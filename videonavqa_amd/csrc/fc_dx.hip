@@ -1,6 +1,6 @@
 // fc_dx.hip — input gradient of a wide nn.Linear whose weight is held in the FORWARD layout only (gfx950).
 //
-//   dx[m][k] = sum_r dout[m][r] * nat[r][k]        m < M <= 320 rows,  r < R = 128,  k < K (K % 128 == 0, here 131 072)
+//   dx[m][k] = sum_r dout[m][r] * nat[r][k]        m < M (320 rows per launch),  r < R = 128,  k < K (K % 128 == 0, here 131 072)
 //
 // fc_embed_attn (film_attn_pt_stem.py:56-57,244) maps the flattened [S*C] feature map of every packed image to 128
 // attention features; its dX is a GEMM with a tiny contraction (128) and a huge output (280 x 131 072 x 2 B = 73 MB), i.e.
@@ -170,18 +170,25 @@ extern "C" int vnqa_fc_dx(const void* dout, const void* nat, void* dx, int32_t m
   VNQA_CHECK_ARG(dout && nat && dx, "fc_dx: null pointer");
   VNQA_CHECK_ARG(dtype == VNQA_BF16, "fc_dx: 16-bit storage only (dtype %d)", dtype);
   VNQA_CHECK_ARG(r == R, "fc_dx: contraction length %d (this kernel is built for %d)", r, R);
-  VNQA_CHECK_ARG(m > 0 && m <= MPAD, "fc_dx: %d rows (1..%d supported)", m, MPAD);
+  VNQA_CHECK_ARG(m > 0, "fc_dx: %d rows", m);
   VNQA_CHECK_ARG(k > 0 && k % TK == 0, "fc_dx: k=%d must be a positive multiple of %d", k, TK);
   static std::atomic<bool> attr_set{false};
   if (!attr_set.load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute((const void*)fc_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set.store(true, std::memory_order_release);
   }
-  FcDxArgs a;
-  a.dout = (const char*)dout; a.nat = (const char*)nat; a.dx = (char*)dx;
-  a.M = m; a.K = k; a.tiles = k / TK;
-  const int grid = a.tiles < 256 ? a.tiles : 256;
-  hipLaunchKernelGGL(fc_dx_kernel, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
-  VNQA_CHECK_LAUNCH();
+  // more than 320 rows (minibatches above 9 full-length clips): one launch per 320-row block of dout; `nat` (33 MB at the
+  // headline size) is re-streamed per block from the Infinity Cache
+  for (int m0 = 0; m0 < m; m0 += MPAD) {
+    FcDxArgs a;
+    a.dout = (const char*)dout + (size_t)m0 * R * 2;
+    a.nat = (const char*)nat;
+    a.dx = (char*)dx + (size_t)m0 * k * 2;
+    a.M = (m - m0) < MPAD ? (m - m0) : MPAD;
+    a.K = k; a.tiles = k / TK;
+    const int grid = a.tiles < 256 ? a.tiles : 256;
+    hipLaunchKernelGGL(fc_dx_kernel, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+    VNQA_CHECK_LAUNCH();
+  }
   return VNQA_OK;
 }

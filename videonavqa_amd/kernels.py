@@ -303,8 +303,8 @@ def pack_fc_weight(w, C, h, wd, c_pad, rows_pad, dtype, want_t=True):
 
 
 def fc_dx_supported(m, rows_pad, kn, dtype):
-    """vnqa_fc_dx's shapes: 16-bit storage, contraction 128, at most 320 rows, a whole number of 128-column slabs."""
-    return L.is_half(dtype) and rows_pad == 128 and 0 < m <= 320 and kn % 128 == 0
+    """vnqa_fc_dx's shapes: 16-bit storage, contraction 128, a whole number of 128-column slabs."""
+    return L.is_half(dtype) and rows_pad == 128 and m > 0 and kn % 128 == 0
 
 
 def fc_dx(dout, nat):
