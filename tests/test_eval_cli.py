@@ -91,6 +91,28 @@ def test_cli_synthetic_train_val_checkpoint_resume(model, tmp_path, capsys):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model", ["film_attn_pt", "film_gp_pt"])
+def test_cli_bag_of_words_question_encoder(model, tmp_path, capsys):
+    """--q_encoder bow (eval/q_and_v_eval.py:35; film_attn_pt_stem.py:75-77): one epoch, checkpoint, resume.  The encoder
+    is an nn.Linear, so the checkpoint carries film_layer.0.weight / .bias instead of the LSTM's four tensors."""
+    from videonavqa_amd.eval import q_and_v_eval as E
+    os.chdir(tmp_path)
+    argv = ["--model", model, "--q_encoder", "bow", "--synthetic", "4", "--batch_size", "2", "--num_workers", "0",
+            "--height", "64", "--width", "96", "--num_res_block_channels", "64", "--hidden_size", "16", "--at_hidden_size", "16",
+            "--embed_size", "16", "--checkpoint_path", "bow.pt", "--stats_after_every", "1"]
+    E.main(argv)
+    out = capsys.readouterr().out
+    assert "Train Epoch: 0" in out and "Validation:" in out
+    ck = torch.load(tmp_path / "e0_bow.pt", map_location="cpu")
+    keys = set(ck["state_dict"])
+    assert {"film_layer.0.weight", "film_layer.0.bias", "film_layer.1.weight"} <= keys
+    assert not any(k.startswith("film_layer.0.weight_hh") for k in keys)
+    os.replace(tmp_path / "e0_bow.pt", tmp_path / "bow.pt")
+    E.main(argv)
+    assert "Restored checkpoint bow.pt (epoch 1)" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
 def test_checkpoint_restores_frozen_conv1x1_layers(tmp_path, capsys):
     """A checkpoint written from a model whose frozen conv1x1_layers do NOT come from seed 0 must evaluate identically
     after q_and_v_test restores it: the 1x1 convs travel in the 'extra_state' key."""
