@@ -552,7 +552,8 @@ def main():
         torch.cuda.synchronize()
         stem_ms = e0.elapsed_time(e1) / 5
     parity = None
-    if rank == 0 and not args.no_parity and args.model != "mac" and args.precision in ("bf16", "fp16"):
+    # (single-GPU runs only: at N > 1 the other ranks would sit in the barrier below for the minute this takes)
+    if world == 1 and not args.no_parity and args.model != "mac" and args.precision in ("bf16", "fp16"):
         loss = loss.clone()
         del trainer, model, stem
         torch.cuda.empty_cache()
