@@ -86,6 +86,8 @@ typedef struct vnqa_conv_desc {
 #define VNQA_TILE_512x128 15 /* 512 pixels x 128 couts, 4x2 waves (128x64 wave tiles as the 256x256 tile; 160 KiB of LDS) */
 #define VNQA_TILE_P3_256x128 16 /* 256x128, 4x2 waves, ring of three 32-channel stages: 72 KiB of LDS, two workgroups per CU */
 #define VNQA_TILE_STEM_256x256 6 /* 256x256 geometry, own kernel symbol for the frozen stem (bf16) */
+#define VNQA_TILE_320x128 17 /* 320 rows x 128 couts, 4x2 waves (80x64 wave tiles): skinny GEMMs whose 257..320 rows would waste half of
+                                  a second 256-row tile (fc_embed_attn forward at 280 packed images) */
 
 int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
                           const float* bias, const float* post_scale, const float* post_shift,

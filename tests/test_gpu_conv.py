@@ -170,7 +170,7 @@ def test_feat_to_nhwc_roundtrip():
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("mnk", [(18, 64, 4096), (280, 128, 8192), (300, 192, 64), (5, 64, 64)])
+@pytest.mark.parametrize("mnk", [(18, 64, 4096), (280, 128, 8192), (300, 192, 64), (5, 64, 64), (320, 128, 4096), (257, 64, 2048)])
 def test_gemm_nt(dt, mnk):
     from videonavqa_amd import kernels as K
     M, N, Kd = mnk

@@ -772,6 +772,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_256x128_W16: return launch<vnqa_bf16, 256, 128, 4, 4, 2>(a, st);
       case VNQA_TILE_512x128: return launch<vnqa_bf16, 512, 128, 4, 2, 2>(a, st);
       case VNQA_TILE_P3_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, 2, 3>(a, st);
+      case VNQA_TILE_320x128: return launch<vnqa_bf16, 320, 128, 4, 2, 2>(a, st);
       case VNQA_TILE_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 0, st);
       case VNQA_TILE_STEM_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 1, st);
       default: break;
@@ -965,6 +966,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   if (dtype == VNQA_BF16) {
     const int pad256 = (m + 255) / 256 * 256, pad128 = (m + 127) / 128 * 128;
     tile = (ws > 0 || pad128 >= pad256) ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+    if (ws > 0 && m > 256 && m <= 320 && n <= 128) tile = VNQA_TILE_320x128;     // one row tile instead of two half-empty ones
     // (256x256 tiles for wide outputs — the stem's ring GEMM alone 112 -> 90 us — were measured and dropped: neutral end to
     // end at 224x224, -9 % at 160x208 where 412 such tiles fill 1.6 rounds of the chip)
   }
