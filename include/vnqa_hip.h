@@ -66,7 +66,11 @@ typedef struct vnqa_conv_desc {
   int32_t wt_tiled; /* 0: wt is [c_out][taps][c_in]; 1: wt comes from vnqa_pack_conv_weight_tiled for THIS tile id */
   int32_t depth;   /* 0: 2-D conv.  > 0: 3-D conv (nn.Conv3d k=3 pad=1, models/v_only_cnn3d.py:13-26) with taps == 27:
                     * x is [n_img][depth+2][h+2][w+2][c_in], y is [n_img][depth+2][ho+2][wo+2][c_y]; pool2 pools (1,2,2) */
+  int32_t flags;   /* VNQA_CONV_ZERO_HALO: the kernel also writes ZEROS to the 1-pixel halo ring of y (channels < c_out), so y
+                    * may be an uninitialised buffer — 2-D convs with y_halo == 1 on the igemm tiles (not the 224-pixel patch
+                    * tiles 11 / 12); round 2: replaces a separate halo-zeroing launch per fresh conv output */
 } vnqa_conv_desc;
+#define VNQA_CONV_ZERO_HALO 1
 
 #define VNQA_TILE_AUTO 0
 #define VNQA_TILE_256x256 1

@@ -149,3 +149,31 @@ def test_conv_add_mask_epilogue_is_bit_identical_to_conv_plus_relu_bwd(dtype):
     got = K.conv2d_igemm_add_mask(dz, wt, dout, res)
     assert torch.equal(got, ref)
     assert float(got[:, 0].abs().max()) == 0 and float(got[:, :, -1].abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [LOW_DTYPE, torch.float32])
+@pytest.mark.parametrize("cfg", [(5, 14, 14, 64, 128, 9, False), (3, 10, 13, 64, 64, 1, False), (4, 12, 16, 64, 192, 9, True),
+                                 (7, 6, 6, 128, 64, 9, False)])
+def test_conv_zeroes_the_halo_of_a_poisoned_output_buffer(dt, cfg):
+    """VNQA_CONV_ZERO_HALO: fresh conv outputs come from torch.empty and the kernel writes the halo ring itself.  The caching
+    allocator is primed with NaN-filled blocks of exactly the output's size, so a halo position the kernel misses shows up as
+    NaN; interior values must equal the same conv into a pre-zeroed buffer (the path without the flag)."""
+    from videonavqa_amd import kernels as K
+    N, H, W, Cin, Cout, taps, pool = cfg
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]))
+    x = torch.zeros(N, H + 2, W + 2, Cin, dtype=dt, device="cuda")
+    x[:, 1:-1, 1:-1] = torch.randn(N, H, W, Cin, generator=g).cuda().to(dt)
+    k = 3 if taps == 9 else 1
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.1).cuda()
+    wt = K.pack_conv_weight(w, dt)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    ref = K.conv2d_igemm(x, wt, relu=True, pool2=pool, out=torch.zeros(N, Ho + 2, Wo + 2, Cout, dtype=dt, device="cuda"))
+    for _ in range(3):
+        junk = [torch.full((N, Ho + 2, Wo + 2, Cout), float("nan"), dtype=dt, device="cuda") for _ in range(2)]
+        del junk
+        y = K.conv2d_igemm(x, wt, relu=True, pool2=pool)
+        assert torch.isfinite(y.float()).all()
+        assert torch.equal(y, ref)
+        assert float(y[:, 0].abs().max()) == 0 and float(y[:, -1].abs().max()) == 0
+        assert float(y[:, :, 0].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0

@@ -45,7 +45,10 @@ _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, _i32) for n in ("dtype", "n_img", "h", "w", "c_in", "c_out", "c_y", "taps",
-                                    "x_halo", "y_halo", "relu", "pool2", "tile", "wt_tiled", "depth")]
+                                    "x_halo", "y_halo", "relu", "pool2", "tile", "wt_tiled", "depth", "flags")]
+
+
+CONV_ZERO_HALO = 1      # vnqa_conv_desc.flags
 
 
 class ConvEpilogue(ctypes.Structure):

@@ -21,6 +21,7 @@ struct ConvArgs {
   int slices, kt_per_slice; // split-K: K-steps [slice*kt_per_slice, ...) -> fp32 slab
   float* partial;           // [slices][M][Cout] fp32 when slices > 1
   int group_tiles;          // > 0: grouped GEMM — pixel tile t uses weight rows [(t / group_tiles) * Cout, ...) (vnqa_gemm_nt_grouped)
+  int zero_halo = 0;        // 1: the store loop also writes zeros to y's (and y2's) 1-pixel halo ring (vnqa_conv_desc.flags)
   int ring_h, ring_w;       // > 0: the "pixels" are the outside-ring positions of the (ring_h+2) x (ring_w+2) grid of halo-2 images
                             // (vnqa_conv2d_ring_fwd): pixel m = image m / R, ring position m % R, R = 2(ring_w+2) + 2 ring_h
   // fused epilogues of the FiLM trunk (vnqa_conv2d_igemm_fused_fwd; applied to the LDS-staged, storage-rounded tile in the

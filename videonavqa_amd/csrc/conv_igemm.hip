@@ -626,6 +626,33 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
 #pragma unroll
     for (int e = 0; e < EPC; ++e) out[e] = ElemOps<T>::store(v[e]);
     if (!(TAG == 0 && p.epi == VNQA_EPI_ADD_MASK)) *(uint4*)dst = *(const uint4*)out;
+    if (p.zero_halo) {
+      // the halo ring of a fresh output buffer: every border pixel's thread also zeroes the halo positions next to it
+      // (corners by the corner pixels) for its 16-byte channel chunk — for y and, with FILM_RES, for the second output
+      const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
+      const long long rs = (long long)p.Wyp * p.Cy, cs = p.Cy;
+      const bool x0 = xo == 0, x1 = xo == Wo - 1, y0 = yo == 0, y1 = yo == Ho - 1;
+      if (x0 | x1 | y0 | y1) {
+        T* const second = (TAG == 0 && p.epi == VNQA_EPI_FILM_RES) ? (T*)p.y2 + ooff : nullptr;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          T* b = which == 0 ? dst : second;
+          if (b == nullptr) continue;
+          if (x0) *(uint4*)(b - cs) = zz;
+          if (x1) *(uint4*)(b + cs) = zz;
+          if (y0) {
+            *(uint4*)(b - rs) = zz;
+            if (x0) *(uint4*)(b - rs - cs) = zz;
+            if (x1) *(uint4*)(b - rs + cs) = zz;
+          }
+          if (y1) {
+            *(uint4*)(b + rs) = zz;
+            if (x0) *(uint4*)(b + rs - cs) = zz;
+            if (x1) *(uint4*)(b + rs + cs) = zz;
+          }
+        }
+      }
+    }
     if (kStatsOk && p.epi == VNQA_EPI_BNSTATS) {
       const int sl = p.frame_of[n] - frame0;        // 0..2 (checked on the host: every frame holds >= BM/3 pixels)
 #pragma unroll
@@ -773,8 +800,13 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_512x128: return launch<vnqa_bf16, 512, 128, 4, 2, 2>(a, st);
       case VNQA_TILE_P3_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, 2, 3>(a, st);
       case VNQA_TILE_320x128: return launch<vnqa_bf16, 320, 128, 4, 2, 2>(a, st);
-      case VNQA_TILE_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 0, st);
-      case VNQA_TILE_STEM_PATCH_224x256: return vnqa_conv_patch_dispatch(a, 1, st);
+      case VNQA_TILE_PATCH_224x256:
+      case VNQA_TILE_STEM_PATCH_224x256:
+        if (a.zero_halo) {
+          vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_ZERO_HALO is not available on the 224-pixel patch tiles");
+          return VNQA_ERR_UNSUPPORTED;
+        }
+        return vnqa_conv_patch_dispatch(a, tile == VNQA_TILE_PATCH_224x256 ? 0 : 1, st);
       default: break;
     }
   } else {
@@ -1067,6 +1099,9 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
   a.x_halo = d->x_halo;
   a.y_halo = d->y_halo;
   a.relu = d->relu;
+  VNQA_CHECK_ARG(!(d->flags & VNQA_CONV_ZERO_HALO) || (d->y_halo == 1 && d->depth == 0),
+                 "conv2d_igemm_fwd: VNQA_CONV_ZERO_HALO needs a 2-D conv with y_halo == 1");
+  a.zero_halo = (d->flags & VNQA_CONV_ZERO_HALO) ? 1 : 0;
   a.pool = d->pool2;
   a.M = d->n_img * d->h * d->w;
   a.tilesN = 0;
@@ -1118,7 +1153,7 @@ extern "C" int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* 
   VNQA_CHECK_ARG((long long)n_img * R < (1ll << 31), "conv2d_ring_fwd: too many ring positions");
   vnqa_conv_desc d;
   d.dtype = dtype; d.n_img = n_img; d.h = 1; d.w = R; d.c_in = c_in; d.c_out = c_out; d.c_y = c_out; d.taps = 9;
-  d.x_halo = 1; d.y_halo = 0; d.relu = 0; d.pool2 = 0; d.tile = VNQA_TILE_AUTO; d.wt_tiled = 0; d.depth = 0;
+  d.x_halo = 1; d.y_halo = 0; d.relu = 0; d.pool2 = 0; d.tile = VNQA_TILE_AUTO; d.wt_tiled = 0; d.depth = 0; d.flags = 0;
   ConvArgs a;
   const int rc = fill_conv_args(&d, x, wt, bias, nullptr, nullptr, nullptr, y1, a);
   if (rc != VNQA_OK) return rc;

@@ -79,13 +79,18 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
         c_out, taps, cin_w = wt.shape
     assert cin_w == Cin and wt.dtype == x.dtype, (cin_w, x.shape, wt.dtype, x.dtype)
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
+    flags = 0
     if out is None:
-        if y_halo == 1 and c_out % 8 == 0:
+        if y_halo == 1 and c_out % 8 == 0 and tile not in (11, 12):
+            # fresh output: the kernel zeroes the halo ring itself (VNQA_CONV_ZERO_HALO), no fill / halo launch
+            out = torch.empty((N, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
+            flags = L.CONV_ZERO_HALO
+        elif y_halo == 1 and c_out % 8 == 0:
             out = empty_padded((N, Ho + 2, Wo + 2, c_out), x.dtype, x.device)
         else:
             out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], taps, x_halo, y_halo,
-                   int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0, 0)
+                   int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0, 0, flags)
     L.check(L.lib().vnqa_conv2d_igemm_fwd_ex(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                              L.ptr(post_shift), L.ptr(border_sub), L.ptr(out), L.stream()),
             "vnqa_conv2d_igemm_fwd")
@@ -94,7 +99,9 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
 
 def _conv_desc(x, c_out, c_y, taps, relu, tile=L.TILE_AUTO):
     N, Hp, Wp, Cin = x.shape
-    return L.ConvDesc(L.dtype_id(x.dtype), N, Hp - 2, Wp - 2, Cin, c_out, c_y, taps, 1, 1, int(relu), 0, tile, 0, 0)
+    # (fused trunk convs write fresh outputs: the kernel zeroes their halo ring, VNQA_CONV_ZERO_HALO)
+    return L.ConvDesc(L.dtype_id(x.dtype), N, Hp - 2, Wp - 2, Cin, c_out, c_y, taps, 1, 1, int(relu), 0, tile, 0, 0,
+                      L.CONV_ZERO_HALO)
 
 
 def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frames, min_frame_images):
@@ -107,7 +114,7 @@ def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frame
     ws_bytes = L.lib().vnqa_conv2d_bnstats_workspace(ctypes.byref(d), int(min_frame_images))
     if ws_bytes < 0:
         return None
-    y = empty_padded((N, Hp, Wp, c_out), x.dtype, x.device)
+    y = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
     ws = workspace(ws_bytes, x.device)
     mean = torch.empty((n_frames, c_out), dtype=torch.float32, device=x.device)
     var = torch.empty((n_frames, c_out), dtype=torch.float32, device=x.device)
@@ -127,8 +134,8 @@ def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res):
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.stride(1) == 1 and beta.stride(1) == 1
     assert gamma.stride(0) == beta.stride(0) and res.shape == (N, Hp, Wp, c_out) and res.dtype == x.dtype
     d = _conv_desc(x, c_out, c_out, taps, False)
-    z = empty_padded((N, Hp, Wp, c_out), x.dtype, x.device)
-    out = empty_padded((N, Hp, Wp, c_out), x.dtype, x.device)
+    z = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
+    out = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
     e = L.ConvEpilogue(kind=L.EPI_FILM_RES, film_ld=gamma.stride(0), film_c=int(film_c), gamma=gamma.data_ptr(),
                        beta=beta.data_ptr(), res=res.data_ptr(), y2=out.data_ptr())
     L.check(L.lib().vnqa_conv2d_igemm_fused_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), ctypes.byref(e),
@@ -143,7 +150,7 @@ def conv2d_igemm_add_mask(x, wt, add, mask_src):
     c_out, taps, _ = wt.shape
     assert add.shape == (N, Hp, Wp, c_out) and mask_src.shape == add.shape and add.dtype == x.dtype == mask_src.dtype
     d = _conv_desc(x, c_out, c_out, taps, False)
-    y = empty_padded((N, Hp, Wp, c_out), x.dtype, x.device)
+    y = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
     e = L.ConvEpilogue(kind=L.EPI_ADD_MASK, res=add.data_ptr(), y2=mask_src.data_ptr())
     L.check(L.lib().vnqa_conv2d_igemm_fused_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), None, ctypes.byref(e), L.ptr(y),
                                                 L.stream()), "vnqa_conv2d_igemm_fused_fwd(ADD_MASK)")
