@@ -185,6 +185,19 @@ int vnqa_ring_assemble(const void* top, const void* bottom, const void* left, co
 int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
                         const float* post_scale, const float* post_shift, void* y, void* stream);
 
+/* Weights-stationary-in-REGISTERS persistent direct 3x3 conv (bf16 / the library's 16-bit format) for the short-K layers
+ * of the VGG front (get_frcnn_feature_extractor features[2], [5], [7]; call sites eval/q_and_v_eval.py:106): 4 waves per
+ * workgroup, one per SIMD, each keeping its slice of the weights in 288 of its SIMD's 512 registers for the whole
+ * launch; only the activation patch goes through LDS (csrc/conv_wreg.hip).  Same tensors and epilogue contract as
+ * vnqa_conv2d_igemm_fwd (bias -> ReLU -> 2x2 max-pool -> per-channel affine; y_halo 1 or 2) for exactly these geometries:
+ *   c_in 128 -> c_out 128 with pool2 (conv2_2), c_in 64 -> c_out 128 without pool2 (conv2_1), c_in 64 -> c_out 64 with
+ *   pool2 (conv1_2); w % 16 == 0, h % 8 == 0 (conv1_2: h % 16 == 0).
+ * vnqa_conv2d_wreg_supported returns 1 when a descriptor qualifies (callers fall back to the igemm / c64 kernels).
+ */
+int vnqa_conv2d_wreg_supported(const vnqa_conv_desc* d);
+int vnqa_conv2d_wreg_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
+                         const float* post_scale, const float* post_shift, void* y, void* stream);
+
 /* conv1_1 + conv1_2 of the VGG front in ONE launch (get_frcnn_feature_extractor, features[0:4]; call sites
  * eval/q_and_v_eval.py:106): the 3 -> 64 conv + ReLU is evaluated inside the c_in == 64 direct kernel for the
  * 18x18 patch each 16x16 output tile needs, so its 64-channel output never goes to HBM.

@@ -523,3 +523,60 @@ def test_ring_edge_convs_match_gathered_edge_gemms(dt):
         got = K.ring_edge_conv(y1p, we, H, W, e).float()
         tol = 1e-5 if dt == torch.float32 else 1e-2
         assert got.shape == ref.shape and float((got - ref).abs().max()) <= tol * float(ref.abs().max()), e
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, pool, post, y_halo      (the three geometries vnqa_conv2d_wreg_fwd serves)
+    (3, 16, 32, 128, 128, True, True, 2),       # conv2_2 (+ bn_input affine, halo-2 output for the composed 5x5 conv)
+    (2, 8, 16, 128, 128, True, False, 1),
+    (5, 24, 48, 64, 128, False, False, 1),      # conv2_1
+    (3, 32, 32, 64, 64, True, False, 1),        # conv1_2
+    (70, 16, 16, 128, 128, True, True, 1),      # more tiles than one round of workgroups... 
+    (300, 16, 32, 64, 128, False, True, 1),     # several rounds: the patch double buffer wraps many times
+    (150, 32, 32, 64, 64, True, True, 1),
+])
+def test_conv_wreg_vs_torch(cfg):
+    """weights-in-registers persistent direct conv (csrc/conv_wreg.hip) vs torch on the same storage-rounded operands, and
+    bit-for-bit against the implicit-GEMM kernel (same products, fp32 accumulation order differs only inside the MFMA K)"""
+    from videonavqa_amd import kernels as K
+    N, H, W, Cin, Cout, pool, post, yh = cfg
+    dt = LOW_DTYPE
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]) + yh)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda() * 0.1
+    sc = ((torch.rand(Cout, generator=g) + 0.5) * torch.where(torch.rand(Cout, generator=g) > 0.3, 1.0, -1.0)).cuda()
+    sh = torch.randn(Cout, generator=g).cuda() * 0.2
+    ref = F.relu(F.conv2d(_q(x, dt), _q(w, dt), b, padding=1))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    if post:
+        ref = ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    xn = K.nchw_to_nhwc(x, dt, c_pad=Cin)
+    wt = K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=Cin)
+    assert K.conv2d_wreg_supported(xn, wt, pool2=pool, y_halo=yh)
+    y = K.conv2d_wreg(xn, wt, bias=b, relu=True, pool2=pool, post_scale=sc if post else None,
+                      post_shift=sh if post else None, y_halo=yh)
+    inner = y[:, yh - 1:y.shape[1] - (yh - 1), yh - 1:y.shape[2] - (yh - 1)].contiguous()
+    got = K.nhwc_to_nchw(inner, Cout)
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 1e-2, _rel(got, ref)
+    # the halo ring is never written
+    assert float(y[:, :yh].abs().max()) == 0 and float(y[:, -yh:].abs().max()) == 0
+    assert float(y[:, :, :yh].abs().max()) == 0 and float(y[:, :, -yh:].abs().max()) == 0
+    # against the igemm kernel on the same packed operands (halo 1 form)
+    y2 = K.conv2d_igemm(xn, wt, bias=b, relu=True, pool2=pool, post_scale=sc if post else None,
+                        post_shift=sh if post else None)
+    d = (inner.float() - y2.float()).abs().max() / (y2.float().abs().max() + 1e-12)
+    assert float(d) < 4e-3, float(d)
+
+
+def test_conv_wreg_unsupported_geometry_is_refused():
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd import _lib as L
+    dt = LOW_DTYPE
+    x = torch.zeros(1, 12, 22, 128, dtype=dt, device="cuda")       # 10 x 20: not whole 8 x 16 tiles
+    wt = torch.zeros(128, 9, 128, dtype=dt, device="cuda")
+    assert not K.conv2d_wreg_supported(x, wt, pool2=True)
+    with pytest.raises(L.VnqaError):
+        K.conv2d_wreg(x, wt, relu=True, pool2=True)

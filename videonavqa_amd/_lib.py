@@ -74,6 +74,8 @@ _SIGNATURES = {
     "vnqa_last_error": (ctypes.c_char_p, []),
     "vnqa_conv2d_igemm_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_conv2d_c64_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vnqa_conv2d_wreg_supported": (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),
+    "vnqa_conv2d_wreg_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_conv_first_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_pack_conv_weight": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "vnqa_conv_weight_tiled_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),

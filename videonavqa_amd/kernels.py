@@ -267,6 +267,36 @@ def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_
     return out
 
 
+def _wreg_desc(x, wt, pool2, relu, out_c, y_halo):
+    N, Hp, Wp, Cin = x.shape
+    return L.ConvDesc(L.BF16, N, Hp - 2, Wp - 2, Cin, wt.shape[0], out_c, 9, 1, y_halo, int(relu), 1 if pool2 else 0, 0, 0, 0)
+
+
+def conv2d_wreg_supported(x, wt, pool2=False, y_halo=1):
+    """True when the weights-in-registers direct conv (vnqa_conv2d_wreg_fwd) serves this layer."""
+    if not (L.is_half(x.dtype) and wt.dim() == 3 and wt.shape[1] == 9 and wt.shape[2] == x.shape[-1]):
+        return False
+    d = _wreg_desc(x, wt, pool2, False, wt.shape[0], y_halo)
+    return bool(L.lib().vnqa_conv2d_wreg_supported(ctypes.byref(d)))
+
+
+def conv2d_wreg(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None, y_halo=1):
+    """Weights-stationary-in-registers persistent direct 3x3 conv (csrc/conv_wreg.hip): same tensors as conv2d_igemm
+    (x padded NHWC halo 1, wt [c_out, 9, c_in] K-major), for conv1_2 / conv2_1 / conv2_2 shaped layers."""
+    N, Hp, Wp, Cin = x.shape
+    H, W = Hp - 2, Wp - 2
+    c_out = wt.shape[0]
+    assert wt.shape[1] == 9 and wt.shape[2] == Cin and L.is_half(x.dtype) and wt.dtype == x.dtype
+    Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
+    if out is None:
+        out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
+    assert out.shape[:3] == (N, Ho + 2 * y_halo, Wo + 2 * y_halo)
+    d = _wreg_desc(x, wt, pool2, relu, out.shape[-1], y_halo)
+    L.check(L.lib().vnqa_conv2d_wreg_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
+                                         L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_wreg_fwd")
+    return out
+
+
 def clip_to_nhwc4(clip, img_of, n_img, out=None):
     """clip fp32 [B,3,H,W,T] (frames last) -> image list bf16 [n_img,H+4,W+4,4] (halo 2 and channel 3 zero)."""
     B, C, H, W, T = clip.shape
