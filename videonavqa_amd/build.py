@@ -21,6 +21,12 @@ FLAGS = (["-DVNQA_DIAG_SKIP_DMA"] if os.environ.get("VNQA_DIAG") else []) + ["--
          "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
 
 
+# per-source extra flags.  conv_wreg.hip: its tile loop is ONE fully unrolled instruction stream (hand-placed MFMA / LDS read /
+# DMA / epilogue interleave); before constant folding the body exceeds LLVM's default pragma-unroll budget, and a loop
+# left rolled would index register arrays at run time (scratch): make that a build error, never a slow kernel.
+PER_FILE_FLAGS = {"conv_wreg.hip": ["-mllvm", "-pragma-unroll-threshold=4000000", "-Werror=pass-failed"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -32,6 +38,7 @@ def _digest(extra=()):
         with open(f, "rb") as fh:
             h.update(fh.read())
     # (flags hashed with the checkout path stripped: the same tree at another location — a gpurun box — must not rebuild)
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())
     h.update(" ".join(FLAGS + list(extra)).replace(os.path.join(HERE, ".."), "<root>").replace(HERE, "<pkg>").encode())
     return h.hexdigest()
 
@@ -65,7 +72,8 @@ def build(force=False, verbose=True, variant="bf16"):
                 objs, procs = [], []
                 for src in sources():
                     obj = os.path.join(tmpdir, os.path.basename(src) + ".o")
-                    cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+                    cmd = [HIPCC] + FLAGS + extra + PER_FILE_FLAGS.get(os.path.basename(src), []) + \
+                        (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
                     procs.append((src, subprocess.Popen(cmd)))
                     objs.append(obj)
                 failed = [src for src, p in procs if p.wait() != 0]

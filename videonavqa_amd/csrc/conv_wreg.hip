@@ -54,9 +54,39 @@ __device__ __forceinline__ void glds16_asm(const char* sbase, unsigned voff, uns
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 
+// MFMAs issued from inline asm so that the weight fragment's register FILE is ours to choose: 64 of a wave's 72 fragments
+// are pinned in the 256 accumulation registers (constraint "a") and read by the MFMA directly as its A operand, 8 live in
+// ordinary VGPRs.  Left to the register allocator, ~35 fragments are parked in AGPRs and copied back to VGPRs
+// (4 v_accvgpr_read + wait states) in front of every use: ~0.85 VALU instructions per MFMA, in bursts that stall the pipe.
+// Hazards (hipcc pads nothing inside asm): A/B operands come from ds_read (s_waitcnt, inserted by hipcc for asm operands) or
+// are written once before the tile loop; an accumulator is re-used as C by a later MFMA of the same shape (accumulate
+// chain: 0 wait states); VALU readers of an accumulator sit behind mfma_fence()'s wait states.
+#ifdef VNQA_H16_IS_F16
+#define VNQA_MFMA16_MNEMONIC "v_mfma_f32_16x16x32_f16"
+#else
+#define VNQA_MFMA16_MNEMONIC "v_mfma_f32_16x16x32_bf16"
+#endif
+template <bool IN_AGPR, bool FIRST>
+__device__ __forceinline__ void mfma_asm(vnqa_f32x4& acc, const vnqa_bf16x8& w, const vnqa_bf16x8& x) {
+  if constexpr (FIRST) {
+    if constexpr (IN_AGPR) asm volatile(VNQA_MFMA16_MNEMONIC " %0, %1, %2, 0" : "=&v"(acc) : "a"(w), "v"(x));
+    else asm volatile(VNQA_MFMA16_MNEMONIC " %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(x));
+  } else {
+    if constexpr (IN_AGPR) asm volatile(VNQA_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+    else asm volatile(VNQA_MFMA16_MNEMONIC " %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+  }
+}
+
 template <int CIN> __device__ __forceinline__ int wreg_swz(int px) { return CIN == 64 ? (px & 6) : 2 * (px & 7); }
 
-template <int CIN, int COUT, int NCG, int TH, int HR, bool POOL>
+// single-instruction max (fmaxf on a value hipcc cannot prove quiet costs an extra canonicalising v_max per operand)
+__device__ __forceinline__ float vmax1(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <int CIN, int COUT, int NCG, int TH, int HR, bool POOL, bool POST>
 __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
   constexpr int NPG = 4 / NCG;                 // pixel groups (waves that share a cout slice split the tile rows)
   constexpr int RW = TH / NPG, NP = RW / HR;   // conv rows per wave; a wave works through them in NP parts of HR rows
@@ -64,11 +94,16 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
   constexpr int PIXB = CIN * 2, CPP = PIXB / 16, PPI = 1024 / PIXB;
   constexpr int PW = 18, PH = TH + 2, NPIX = PH * PW;
   constexpr int NI = (NPIX * PIXB + 1023) / 1024, SLOT = NI * 1024;
+  constexpr int NDMA = (NI + 3) / 4;           // DMA instructions per wave and patch (the last one may be missing)
   constexpr int NGRP = 3 * KS;                 // fragment groups (column shift s, k-step ks) per part
   constexpr int NR = HR + 2;                   // patch rows a part touches
+  constexpr int NSTEP = NP * NGRP;
+  constexpr int SPS = 3 * HR;                  // filler slots per step: one behind every (patch row, tap row) MFMA group
+  constexpr int SPP = NGRP * SPS;              // ... per part
   static_assert(NJ * 9 * KS == 72, "a wave's weight slice must be 72 fragments (288 registers)");
   static_assert(RW % HR == 0 && NP % 2 == 0 && (!POOL || HR % 2 == 0), "parts must hold whole pooling windows");
   static_assert(POOL ? ((HR / 2) * NJ == 4 || (HR / 2) * NJ == 2) : (NJ % 2 == 0), "epilogue store grouping");
+  static_assert(NSTEP % 2 == 0 && NGRP % 2 == 0, "steps come in Xa / Xb pairs");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const ldsPar = (float*)(smem + 2 * SLOT);     // bias[COUT], post_scale[COUT], post_shift[COUT]
@@ -108,23 +143,24 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
     x0 = (r - ty * p.tilesX) * 16;
   };
 
-  // patch DMA: instruction q writes LDS bytes [q*1024, q*1024+1024) of the slot = PPI consecutive patch pixels
-  auto issue_patch = [&](int t, int slot) {
+  // patch DMA: instruction q = wave + 4 k writes LDS bytes [q*1024, q*1024+1024) of the slot = PPI consecutive patch pixels;
+  // the lane's source offset relative to the patch origin does not depend on the tile: computed once
+  unsigned dma_off[NDMA];
+#pragma unroll
+  for (int k = 0; k < NDMA; ++k) {
+    int pix = (wave + 4 * k) * PPI + lane / CPP;
+    pix = pix < NPIX ? pix : NPIX - 1;
+    const int py = pix / PW, px = pix - py * PW;
+    dma_off[k] = (unsigned)((py * p.Wp + px) * PIXB + (((lane % CPP) ^ wreg_swz<CIN>(px)) << 4));
+  }
+  auto patch_src = [&](int t) {
     int n, y0, x0;
     tile_origin(t, n, y0, x0);
-    const char* src0 = p.x + (((size_t)n * p.Hp + y0) * p.Wp + x0) * PIXB;
-    asm volatile("s_nop 4" ::: "memory");   // (SGPR operands below may come fresh from VALU lane reads)
-#pragma unroll
-    for (int k = 0; k < (NI + 3) / 4; ++k) {
-      const int q = wave + 4 * k;
-      if (q < NI) {      // wave-uniform
-        int pix = q * PPI + lane / CPP;
-        pix = pix < NPIX ? pix : NPIX - 1;
-        const int py = pix / PW, px = pix - py * PW;
-        const int sc = (lane % CPP) ^ wreg_swz<CIN>(px);
-        glds16_asm(src0, (unsigned)((py * p.Wp + px) * PIXB + sc * 16), __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + q * 1024));
-      }
-    }
+    return p.x + (((size_t)n * p.Hp + y0) * p.Wp + x0) * PIXB;
+  };
+  auto issue_dma = [&](const char* src0, int slot, int k) {
+    if (wave + 4 * k < NI)      // wave-uniform
+      glds16_asm(src0, dma_off[k], __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + (wave + 4 * k) * 1024));
   };
 
   // per-lane fragment bases: pixel column fr + s, k-chunk 4 ks + fh (swizzled); the row offset is an immediate
@@ -136,11 +172,17 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
       fbase[s][ks] = (fr + s) * PIXB + (((4 * ks + fh) ^ wreg_swz<CIN>(fr + s)) << 4);
 
   int t = per_round_base;
-  if (t < p.n_tiles) issue_patch(t, 0);
+  if (t < p.n_tiles) {
+    const char* src0 = patch_src(t);
+    asm volatile("s_nop 4" ::: "memory");   // (SGPR operands of the DMA may come fresh from VALU lane reads)
+#pragma unroll
+    for (int k = 0; k < NDMA; ++k) issue_dma(src0, 0, k);
+  }
 
-  // 16-byte stores per lane and tile (every lane executes every store: tiles are always whole)
+  // 16-byte stores per lane and tile (every lane executes every store instruction: tiles are always whole)
   constexpr int NST = NP * (POOL ? 1 : HR * NJ / 2);
-  const int hp = fh & 1;
+  const int hp = fh & 1, q2 = fr & 1;
+  const float relu_floor = p.relu ? 0.f : -INFINITY;
 
   for (int it = 0; t < p.n_tiles; t += G, ++it) {
     const int slot = it & 1;
@@ -149,14 +191,129 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
     if (it > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // patch visible to all waves; everyone is done reading the other slot
-    if (t + G < p.n_tiles) issue_patch(t + G, slot ^ 1);
 
+    const bool have_next = t + G < p.n_tiles;
+    const char* next_src = have_next ? patch_src(t + G) : p.x;
     int n, y0, x0;
     tile_origin(t, n, y0, x0);
     const char* const ldsP = smem + slot * SLOT + (pg * RW) * PW * PIXB;
 
-    vnqa_f32x4 acc[2][HR][NJ];       // parts alternate between the two sets: the epilogue of part k runs under part k + 1's MFMAs
-    // Step k = (half h, group g = (s, ks)).  The NR patch-row fragments of a group are read ONCE and serve all three tap
+    vnqa_f32x4 acc[2][HR][NJ];       // parts alternate between the two sets: the epilogue of part h runs under part h + 1's MFMAs
+
+    // ---- epilogue of part h in small pieces (VALU only, no barrier): lane holds couts cout0 + 16 j + 4 fh + e of pixel
+    //      column fr.  Piece 0 fetches the per-channel parameters, value pieces apply bias / ReLU / pool / affine, store
+    //      pieces exchange 8-byte groups between the fh-pair lanes (v_permlane16_swap) and store 16 bytes per lane. ----
+    constexpr int HRP = POOL ? HR / 2 : HR;                 // output rows of a part
+    constexpr int NVAL = HRP * NJ * 4;                      // values per lane and part
+    constexpr int VPP = NJ == 2 ? 1 : (POOL ? 2 : 4);       // values per value piece (what fits behind NJ MFMAs)
+    constexpr int NVP = NVAL / VPP;                         // value pieces
+    constexpr int NSP = POOL ? 1 : HR * NJ / 2;             // store pieces
+    constexpr int NPIECE = 1 + NVP + NSP;
+    float4 pb[NJ], ps[NJ], ph[NJ];
+    float ev[HRP][NJ][4];
+    auto epi_piece = [&](int h, int m) {
+      if (m == 0) {
+        // wait states between the part's last MFMA and the first VALU read of its accumulators (8-pass XDL: 12+)
+#pragma unroll
+        for (int i = 0; i < HR; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[h & 1][i][j]));
+        asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < HR; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[h & 1][i][j]));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int co = cout0 + 16 * j + 4 * fh;
+          pb[j] = *(const float4*)(ldsPar + co);
+          if constexpr (POST) {
+            ps[j] = *(const float4*)(ldsPar + COUT + co);
+            ph[j] = *(const float4*)(ldsPar + 2 * COUT + co);
+          }
+        }
+      } else if (m <= NVP) {
+#pragma unroll
+        for (int vi = (m - 1) * VPP; vi < m * VPP; ++vi) {
+          const int e = vi & 3, j = (vi >> 2) % NJ, ro = vi / (4 * NJ);
+          const float b = e == 0 ? pb[j].x : e == 1 ? pb[j].y : e == 2 ? pb[j].z : pb[j].w;
+          float u;
+          if constexpr (POOL) {
+            u = vmax1(acc[h & 1][2 * ro][j][e], acc[h & 1][2 * ro + 1][j][e]);         // rows 2 ro, 2 ro + 1
+            // columns fr and fr ^ 1: DPP quad_perm [1,0,3,2]
+            u = vmax1(u, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0xB1, 0xF, 0xF, true)));
+            u = vmax1(u + b, relu_floor);                                             // (bias commutes with the max)
+          } else {
+            u = vmax1(acc[h & 1][ro][j][e] + b, relu_floor);
+          }
+          if constexpr (POST) {   // affine on the storage-rounded value, as the LDS-staged kernels do
+            const float sc = e == 0 ? ps[j].x : e == 1 ? ps[j].y : e == 2 ? ps[j].z : ps[j].w;
+            const float sh = e == 0 ? ph[j].x : e == 1 ? ph[j].y : e == 2 ? ph[j].z : ph[j].w;
+            u = bf16_to_f32(f32_to_bf16(u)) * sc + sh;
+          }
+          ev[ro][j][e] = u;
+        }
+      } else {
+        const int sp = m - 1 - NVP;
+        auto pk = [&](int ro, int j) { return make_uint2(pack2_h16(ev[ro][j][0], ev[ro][j][1]), pack2_h16(ev[ro][j][2], ev[ro][j][3])); };
+        if constexpr (POOL) {
+          // 4 (pooled row, cout block) combinations per lane quad (fr parity q2, fh parity hp): q2 picks the pair, the
+          // fh-pair lanes trade one 8-byte group so that each lane owns 8 consecutive couts of ONE combination
+          uint2 lo, hi;
+          int pr_st, j_lo, j_hi;
+          bool st = true;
+          if constexpr (NJ == 2 && HRP == 2) {        // q2 = pooled row, hp = cout block
+            const uint2 a0 = pk(0, 0), a1 = pk(HRP - 1, 0), b0 = pk(0, NJ - 1), b1 = pk(HRP - 1, NJ - 1);
+            lo = q2 ? a1 : a0;
+            hi = q2 ? b1 : b0;
+            pr_st = q2; j_lo = 0; j_hi = 1;
+          } else if constexpr (NJ == 2) {             // HRP == 1: two combinations only — the odd column of a pair does not store
+            lo = pk(0, 0);
+            hi = pk(0, NJ - 1);
+            pr_st = 0; j_lo = 0; j_hi = 1;
+            st = q2 == 0;
+          } else {                                    // NJ == 4, HRP == 1: block = 2 hp + q2
+            const uint2 a0 = pk(0, 0), a1 = pk(0, 1), b0 = pk(0, NJ - 2), b1 = pk(0, NJ - 1);
+            lo = q2 ? a1 : a0;
+            hi = q2 ? b1 : b0;
+            pr_st = 0; j_lo = q2; j_hi = 2 + q2;
+          }
+          const auto sx = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
+          const int oy = ((y0 + pg * RW + h * HR) >> 1) + pr_st, ox = (x0 >> 1) + (fr >> 1);
+          const int co = cout0 + 16 * (hp ? j_hi : j_lo) + 8 * (fh >> 1);
+          unsigned short* dst = (unsigned short*)p.y +
+                                (((size_t)n * p.Hyp + oy + p.y_halo) * p.Wyp + ox + p.y_halo) * (size_t)p.Cy + co;
+          if (st) *(uint4*)dst = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        } else {
+          // un-pooled: per conv row i and pair of cout blocks (2 mm, 2 mm + 1) one 16-byte store per lane
+          const int i = sp / (NJ / 2), mm = sp % (NJ / 2);
+          const uint2 a = pk(i, 2 * mm), b = pk(i, 2 * mm + 1);
+          const auto sx = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+          const auto sy = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+          const int oy = y0 + pg * RW + h * HR + i, ox = x0 + fr;
+          unsigned short* dst = (unsigned short*)p.y +
+                                (((size_t)n * p.Hyp + oy + p.y_halo) * p.Wyp + ox + p.y_halo) * (size_t)p.Cy + cout0 +
+                                8 * (fh >> 1) + 16 * (2 * mm + hp);
+          *(uint4*)dst = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      }
+    };
+
+    // filler behind MFMA group `pos` of step k: spreads everything that is not an MFMA or a fragment read over the
+    // tile — the next patch's DMA instructions over part 0, the epilogue pieces of part h - 1 over part h
+    constexpr int DMA_STRIDE = SPP / NDMA, EPI_STRIDE = (SPP - 2) / NPIECE > 0 ? (SPP - 2) / NPIECE : 1;
+    static_assert(DMA_STRIDE >= 1 && NPIECE <= SPP - 2, "fillers must fit their part");
+    auto filler = [&](int k, int pos) {
+      const int h = k / NGRP, u = (k - h * NGRP) * SPS + pos;
+      if (h == 0) {
+        if (u % DMA_STRIDE == DMA_STRIDE - 1 && u / DMA_STRIDE < NDMA && have_next) issue_dma(next_src, slot ^ 1, u / DMA_STRIDE);
+      } else {
+        if (u >= 2 && (u - 2) % EPI_STRIDE == 0 && (u - 2) / EPI_STRIDE < NPIECE) epi_piece(h - 1, (u - 2) / EPI_STRIDE);
+      }
+    };
+
+    // Step k = (part h, group g = (s, ks)).  The NR patch-row fragments of a group are read ONCE and serve all three tap
     // rows r (output row i = R - r): NR reads per 3 HR NJ MFMAs.  The reads of step k + 1 are issued in the middle of step
     // k's MFMAs (register double buffer Xa / Xb), so that the wait in front of a step never covers reads younger than its own.
     auto load_step = [&](int k, vnqa_bf16x8* X) {
@@ -174,106 +331,26 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
         for (int r = 0; r < 3; ++r) {
           const int i = R - r;
           if (i < 0 || i >= HR) continue;
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            if (g == 0 && r == 0) acc[h & 1][i][j] = vnqa_f32x4{0.f, 0.f, 0.f, 0.f};      // first product of this accumulator
-            acc[h & 1][i][j] = VNQA_MFMA_16x16x32(Wf[3 * r + s][ks][j], X[R], acc[h & 1][i][j]);
-          }
-        }
-    };
-    // ---- epilogue of half tile h, from registers: lane holds couts cout0 + 16 j + 4 fh + e of pixel column fr ----
-    auto epilogue = [&](int h) {
-      if constexpr (POOL) {
-        constexpr int HRP = HR / 2;
-        uint2 P[HRP][NJ];
-#pragma unroll
-        for (int pr = 0; pr < HRP; ++pr)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const int co = cout0 + 16 * j + 4 * fh;
-            const float4 bb = *(const float4*)(ldsPar + co);
-            const float4 sc = *(const float4*)(ldsPar + COUT + co);
-            const float4 sh = *(const float4*)(ldsPar + 2 * COUT + co);
-            const float b4[4] = {bb.x, bb.y, bb.z, bb.w}, s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float u = fmaxf(acc[h & 1][2 * pr][j][e], acc[h & 1][2 * pr + 1][j][e]) + b4[e];      // rows 2pr, 2pr+1 (bias commutes with max)
-              if (p.relu) u = fmaxf(u, 0.f);
-              // columns fr and fr ^ 1: DPP quad_perm [1,0,3,2]
-              u = fmaxf(u, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0xB1, 0xF, 0xF, true)));
-              // affine on the storage-rounded value, as the LDS-staged kernels do (scale 1 / shift 0 = identity)
-              v[e] = p.post_scale ? bf16_to_f32(f32_to_bf16(u)) * s4[e] + h4[e] : u;
+          // position of this (R, r) group among the step's 3 HR groups (execution order: R ascending, r ascending)
+          int pos = 0;
+          for (int RR = 0; RR <= R; ++RR)
+            for (int rr = 0; rr < 3; ++rr) {
+              const int ii = RR - rr;
+              if (ii < 0 || ii >= HR) continue;
+              if (RR < R || rr < r) ++pos;
             }
-            P[pr][j].x = pack2_h16(v[0], v[1]);
-            P[pr][j].y = pack2_h16(v[2], v[3]);
-          }
-        // 4 (pooled row, cout block) combinations per lane quad (fr parity q, fh parity hp): q picks the pair, the fh-pair
-        // lanes trade one 8-byte group (v_permlane16_swap) so that each lane owns 8 consecutive couts of ONE combination
-        const int q = fr & 1;
-        uint2 lo, hi;
-        int pr_st, j_lo, j_hi;
-        bool st = true;
-        if constexpr (NJ == 2 && HRP == 2) {        // q = pooled row, hp = cout block
-          lo = q ? P[HRP - 1][0] : P[0][0];
-          hi = q ? P[HRP - 1][NJ - 1] : P[0][NJ - 1];
-          pr_st = q; j_lo = 0; j_hi = 1;
-        } else if constexpr (NJ == 2) {             // HRP == 1: two combinations only — the odd column of a pair does not store
-          lo = P[0][0];
-          hi = P[0][NJ - 1];
-          pr_st = 0; j_lo = 0; j_hi = 1;
-          st = q == 0;
-        } else {                                    // NJ == 4, HRP == 1: block = 2 hp + q
-          lo = q ? P[0][1] : P[0][0];
-          hi = q ? P[0][NJ - 1] : P[0][NJ - 2];
-          pr_st = 0; j_lo = q; j_hi = 2 + q;
-        }
-        const auto sx = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
-        const auto sy = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
-        const uint4 o = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-        const int oy = ((y0 + pg * RW + h * HR) >> 1) + pr_st, ox = (x0 >> 1) + (fr >> 1);
-        const int co = cout0 + 16 * (hp ? j_hi : j_lo) + 8 * (fh >> 1);
-        unsigned short* dst = (unsigned short*)p.y +
-                              (((size_t)n * p.Hyp + oy + p.y_halo) * p.Wyp + ox + p.y_halo) * (size_t)p.Cy + co;
-        if (st) *(uint4*)dst = o;
-      } else {
-        // un-pooled: per conv row and pair of cout blocks (2m, 2m+1) one 16-byte store per lane
-#pragma unroll
-        for (int i = 0; i < HR; ++i) {
-          uint2 P[NJ];
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
-            const int co = cout0 + 16 * j + 4 * fh;
-            const float4 bb = *(const float4*)(ldsPar + co);
-            const float4 sc = *(const float4*)(ldsPar + COUT + co);
-            const float4 sh = *(const float4*)(ldsPar + 2 * COUT + co);
-            const float b4[4] = {bb.x, bb.y, bb.z, bb.w}, s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float u = acc[h & 1][i][j][e] + b4[e];
-              if (p.relu) u = fmaxf(u, 0.f);
-              v[e] = p.post_scale ? bf16_to_f32(f32_to_bf16(u)) * s4[e] + h4[e] : u;
-            }
-            P[j].x = pack2_h16(v[0], v[1]);
-            P[j].y = pack2_h16(v[2], v[3]);
+            const bool first = g == 0 && r == 0;         // first product of this accumulator: C = 0
+            const bool in_a = 3 * r + s < 8;             // tap 8's fragments live in VGPRs, taps 0..7 in AGPRs
+            if (first) { if (in_a) mfma_asm<true, true>(acc[h & 1][i][j], Wf[3 * r + s][ks][j], X[R]); else mfma_asm<false, true>(acc[h & 1][i][j], Wf[3 * r + s][ks][j], X[R]); }
+            else { if (in_a) mfma_asm<true, false>(acc[h & 1][i][j], Wf[3 * r + s][ks][j], X[R]); else mfma_asm<false, false>(acc[h & 1][i][j], Wf[3 * r + s][ks][j], X[R]); }
           }
-          const int oy = y0 + pg * RW + h * HR + i, ox = x0 + fr;
-          unsigned short* dst0 = (unsigned short*)p.y +
-                                 (((size_t)n * p.Hyp + oy + p.y_halo) * p.Wyp + ox + p.y_halo) * (size_t)p.Cy + cout0 + 8 * (fh >> 1);
-#pragma unroll
-          for (int m = 0; m < NJ / 2; ++m) {
-            const auto sx = __builtin_amdgcn_permlane16_swap(P[2 * m].x, P[2 * m + 1].x, false, false);
-            const auto sy = __builtin_amdgcn_permlane16_swap(P[2 * m].y, P[2 * m + 1].y, false, false);
-            *(uint4*)(dst0 + 16 * (2 * m + hp)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-          }
+          filler(k, pos);
         }
-      }
     };
 
     constexpr int SPLIT = NR >= 6 ? 2 : 1;     // patch rows whose MFMAs run before the next step's reads are issued
-    constexpr int NSTEP = NP * NGRP;
-    static_assert(NSTEP % 2 == 0 && NGRP % 2 == 0, "steps come in Xa / Xb pairs");
     vnqa_bf16x8 Xa[NR], Xb[NR];
     load_step(0, Xa);
 #pragma unroll
@@ -285,8 +362,6 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
       load_step(k + 1, Xb);
       __builtin_amdgcn_sched_barrier(0);
       mma_rows(k, Xa, SPLIT, NR);
-      if (k >= NGRP && k % NGRP == 0) epilogue(k / NGRP - 1);   // previous part is complete: its VALU-only epilogue shares
-                                                                // a region with this part's MFMAs
       __builtin_amdgcn_sched_barrier(0);
       // odd step
       mma_rows(k + 1, Xb, 0, SPLIT);
@@ -296,12 +371,13 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
       mma_rows(k + 1, Xb, SPLIT, NR);
     }
     __builtin_amdgcn_sched_barrier(0);
-    epilogue(NP - 1);
+#pragma unroll
+    for (int m = 0; m < NPIECE; ++m) epi_piece(NP - 1, m);
   }
 }
 
-template <int CIN, int COUT, int NCG, int TH, int HR, bool POOL>
-int wreg_launch(WregArgs a, hipStream_t stream) {
+template <int CIN, int COUT, int NCG, int TH, int HR, bool POOL, bool POST>
+int wreg_launch_(WregArgs a, hipStream_t stream) {
   constexpr int PIXB = CIN * 2;
   constexpr int NI = ((TH + 2) * 18 * PIXB + 1023) / 1024;
   constexpr int LDS = 2 * NI * 1024 + 3 * COUT * 4;
@@ -309,7 +385,7 @@ int wreg_launch(WregArgs a, hipStream_t stream) {
   a.tilesX = a.W / 16;
   a.tilesY = a.H / TH;
   a.n_tiles = a.n_img * a.tilesX * a.tilesY;
-  auto kern = conv_wreg_kernel<CIN, COUT, NCG, TH, HR, POOL>;
+  auto kern = conv_wreg_kernel<CIN, COUT, NCG, TH, HR, POOL, POST>;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
@@ -325,6 +401,12 @@ int wreg_launch(WregArgs a, hipStream_t stream) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, a);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
+}
+
+template <int CIN, int COUT, int NCG, int TH, int HR, bool POOL>
+int wreg_launch(const WregArgs& a, hipStream_t stream) {
+  return a.post_scale ? wreg_launch_<CIN, COUT, NCG, TH, HR, POOL, true>(a, stream)
+                      : wreg_launch_<CIN, COUT, NCG, TH, HR, POOL, false>(a, stream);
 }
 
 }  // namespace
