@@ -171,174 +171,188 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
     for (int ks = 0; ks < KS; ++ks)
       fbase[s][ks] = (fr + s) * PIXB + (((4 * ks + fh) ^ wreg_swz<CIN>(fr + s)) << 4);
 
+  struct TileAt { int n, y0, x0; };
   int t = per_round_base;
+  TileAt cur = {0, 0, 0}, prev = {0, 0, 0}, nxt = {0, 0, 0};
+  const char* next_src = p.x;            // patch origin of tile t + G (valid while t + G < n_tiles)
   if (t < p.n_tiles) {
-    const char* src0 = patch_src(t);
+    tile_origin(t, cur.n, cur.y0, cur.x0);
+    const char* src0 = p.x + (((size_t)cur.n * p.Hp + cur.y0) * p.Wp + cur.x0) * PIXB;
+    if (t + G < p.n_tiles) {
+      tile_origin(t + G, nxt.n, nxt.y0, nxt.x0);
+      next_src = p.x + (((size_t)nxt.n * p.Hp + nxt.y0) * p.Wp + nxt.x0) * PIXB;
+    }
     asm volatile("s_nop 4" ::: "memory");   // (SGPR operands of the DMA may come fresh from VALU lane reads)
 #pragma unroll
     for (int k = 0; k < NDMA; ++k) issue_dma(src0, 0, k);
   }
 
-  // 16-byte stores per lane and tile (every lane executes every store instruction: tiles are always whole)
-  constexpr int NST = NP * (POOL ? 1 : HR * NJ / 2);
+  // 16-byte stores per lane: NSTP per part, every lane executes every store instruction (tiles are always whole)
+  constexpr int NSTP = POOL ? 1 : HR * NJ / 2;
   const int hp = fh & 1, q2 = fr & 1;
   const float relu_floor = p.relu ? 0.f : -INFINITY;
 
+  vnqa_f32x4 acc[2][HR][NJ];       // parts alternate between the two sets: the epilogue of a part runs under the NEXT part's
+                                   // MFMAs — the last part's under part 0 of the next tile (set 1 is idle there: NP is even)
+  // ---- epilogue of a part in small pieces (VALU only, no barrier): lane holds couts cout0 + 16 j + 4 fh + e of pixel
+  //      column fr.  Piece 0 fetches the per-channel parameters, value pieces apply bias / ReLU / pool / affine, store
+  //      pieces exchange 8-byte groups between the fh-pair lanes (v_permlane16_swap) and store 16 bytes per lane. ----
+  constexpr int HRP = POOL ? HR / 2 : HR;                 // output rows of a part
+  constexpr int NVAL = HRP * NJ * 4;                      // values per lane and part
+  constexpr int VPP = NJ == 2 ? 1 : (POOL ? 2 : 4);       // values per value piece (what fits behind NJ MFMAs)
+  constexpr int NVP = NVAL / VPP;                         // value pieces
+  constexpr int NPIECE = 1 + NVP + NSTP;
+  float4 pb[NJ], ps[NJ], ph[NJ];
+  float ev[HRP][NJ][4];
+  auto epi_piece = [&](int h, int m, const TileAt& ta, bool fence = false) {
+    if (m == 0) {
+      // wait states between the part's last MFMA and the first VALU read of its accumulators (8-pass XDL: 12+)
+#pragma unroll
+      for (int i = 0; i < HR; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[h & 1][i][j]));
+      if (fence) asm volatile("s_nop 15" ::: "memory");      // (interleaved pieces run several MFMA groups later anyway)
+#pragma unroll
+      for (int i = 0; i < HR; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[h & 1][i][j]));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int co = cout0 + 16 * j + 4 * fh;
+        pb[j] = *(const float4*)(ldsPar + co);
+        if constexpr (POST) {
+          ps[j] = *(const float4*)(ldsPar + COUT + co);
+          ph[j] = *(const float4*)(ldsPar + 2 * COUT + co);
+        }
+      }
+    } else if (m <= NVP) {
+#pragma unroll
+      for (int vi = (m - 1) * VPP; vi < m * VPP; ++vi) {
+        const int e = vi & 3, j = (vi >> 2) % NJ, ro = vi / (4 * NJ);
+        const float b = e == 0 ? pb[j].x : e == 1 ? pb[j].y : e == 2 ? pb[j].z : pb[j].w;
+        float u;
+        if constexpr (POOL) {
+          u = vmax1(acc[h & 1][2 * ro][j][e], acc[h & 1][2 * ro + 1][j][e]);         // rows 2 ro, 2 ro + 1
+          // columns fr and fr ^ 1: DPP quad_perm [1,0,3,2]
+          u = vmax1(u, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0xB1, 0xF, 0xF, true)));
+          u = vmax1(u + b, relu_floor);                                             // (bias commutes with the max)
+        } else {
+          u = vmax1(acc[h & 1][ro][j][e] + b, relu_floor);
+        }
+        if constexpr (POST) {   // affine on the storage-rounded value, as the LDS-staged kernels do
+          const float sc = e == 0 ? ps[j].x : e == 1 ? ps[j].y : e == 2 ? ps[j].z : ps[j].w;
+          const float sh = e == 0 ? ph[j].x : e == 1 ? ph[j].y : e == 2 ? ph[j].z : ph[j].w;
+          u = bf16_to_f32(f32_to_bf16(u)) * sc + sh;
+        }
+        ev[ro][j][e] = u;
+      }
+    } else {
+      const int sp = m - 1 - NVP;
+      auto pk = [&](int ro, int j) { return make_uint2(pack2_h16(ev[ro][j][0], ev[ro][j][1]), pack2_h16(ev[ro][j][2], ev[ro][j][3])); };
+      if constexpr (POOL) {
+        // 4 (pooled row, cout block) combinations per lane quad (fr parity q2, fh parity hp): q2 picks the pair, the
+        // fh-pair lanes trade one 8-byte group so that each lane owns 8 consecutive couts of ONE combination
+        uint2 lo, hi;
+        int pr_st, j_lo, j_hi;
+        bool st = true;
+        if constexpr (NJ == 2 && HRP == 2) {        // q2 = pooled row, hp = cout block
+          const uint2 a0 = pk(0, 0), a1 = pk(HRP - 1, 0), b0 = pk(0, NJ - 1), b1 = pk(HRP - 1, NJ - 1);
+          lo = q2 ? a1 : a0;
+          hi = q2 ? b1 : b0;
+          pr_st = q2; j_lo = 0; j_hi = 1;
+        } else if constexpr (NJ == 2) {             // HRP == 1: two combinations only — the odd column of a pair does not store
+          lo = pk(0, 0);
+          hi = pk(0, NJ - 1);
+          pr_st = 0; j_lo = 0; j_hi = 1;
+          st = q2 == 0;
+        } else {                                    // NJ == 4, HRP == 1: block = 2 hp + q2
+          const uint2 a0 = pk(0, 0), a1 = pk(0, 1), b0 = pk(0, NJ - 2), b1 = pk(0, NJ - 1);
+          lo = q2 ? a1 : a0;
+          hi = q2 ? b1 : b0;
+          pr_st = 0; j_lo = q2; j_hi = 2 + q2;
+        }
+        const auto sx = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
+        const int oy = ((ta.y0 + pg * RW + h * HR) >> 1) + pr_st, ox = (ta.x0 >> 1) + (fr >> 1);
+        const int co = cout0 + 16 * (hp ? j_hi : j_lo) + 8 * (fh >> 1);
+        unsigned short* dst = (unsigned short*)p.y +
+                              (((size_t)ta.n * p.Hyp + oy + p.y_halo) * p.Wyp + ox + p.y_halo) * (size_t)p.Cy + co;
+        if (st) *(uint4*)dst = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      } else {
+        // un-pooled: per conv row i and pair of cout blocks (2 mm, 2 mm + 1) one 16-byte store per lane
+        const int i = sp / (NJ / 2), mm = sp % (NJ / 2);
+        const uint2 a = pk(i, 2 * mm), b = pk(i, 2 * mm + 1);
+        const auto sx = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+        const int oy = ta.y0 + pg * RW + h * HR + i, ox = ta.x0 + fr;
+        unsigned short* dst = (unsigned short*)p.y +
+                              (((size_t)ta.n * p.Hyp + oy + p.y_halo) * p.Wyp + ox + p.y_halo) * (size_t)p.Cy + cout0 +
+                              8 * (fh >> 1) + 16 * (2 * mm + hp);
+        *(uint4*)dst = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      }
+    }
+  };
+
   for (int it = 0; t < p.n_tiles; t += G, ++it) {
     const int slot = it & 1;
-    // This tile's patch was issued a whole tile ago (before that tile's NST stores): all but those stores must be done.
+    // This tile's patch was issued during part 0 of the previous tile; the only vector-memory instructions this wave has
+    // issued since are the stores of that tile's parts 0 .. NP-2 (the deferred store of its last part is issued below) and
+    // possibly the deferred store of the tile before: all but the youngest (NP - 1) NSTP must be done.
     // First tile: everything (the patch, and the parameter table written above).
-    if (it > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    if (it > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP - 1) * NSTP) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // patch visible to all waves; everyone is done reading the other slot
 
     const bool have_next = t + G < p.n_tiles;
-    const char* next_src = have_next ? patch_src(t + G) : p.x;
-    int n, y0, x0;
-    tile_origin(t, n, y0, x0);
+    const char* const dma_src = next_src;
     const char* const ldsP = smem + slot * SLOT + (pg * RW) * PW * PIXB;
 
-    vnqa_f32x4 acc[2][HR][NJ];       // parts alternate between the two sets: the epilogue of part h runs under part h + 1's MFMAs
-
-    // ---- epilogue of part h in small pieces (VALU only, no barrier): lane holds couts cout0 + 16 j + 4 fh + e of pixel
-    //      column fr.  Piece 0 fetches the per-channel parameters, value pieces apply bias / ReLU / pool / affine, store
-    //      pieces exchange 8-byte groups between the fh-pair lanes (v_permlane16_swap) and store 16 bytes per lane. ----
-    constexpr int HRP = POOL ? HR / 2 : HR;                 // output rows of a part
-    constexpr int NVAL = HRP * NJ * 4;                      // values per lane and part
-    constexpr int VPP = NJ == 2 ? 1 : (POOL ? 2 : 4);       // values per value piece (what fits behind NJ MFMAs)
-    constexpr int NVP = NVAL / VPP;                         // value pieces
-    constexpr int NSP = POOL ? 1 : HR * NJ / 2;             // store pieces
-    constexpr int NPIECE = 1 + NVP + NSP;
-    float4 pb[NJ], ps[NJ], ph[NJ];
-    float ev[HRP][NJ][4];
-    auto epi_piece = [&](int h, int m) {
-      if (m == 0) {
-        // wait states between the part's last MFMA and the first VALU read of its accumulators (8-pass XDL: 12+)
-#pragma unroll
-        for (int i = 0; i < HR; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[h & 1][i][j]));
-        asm volatile("s_nop 15" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < HR; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[h & 1][i][j]));
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int co = cout0 + 16 * j + 4 * fh;
-          pb[j] = *(const float4*)(ldsPar + co);
-          if constexpr (POST) {
-            ps[j] = *(const float4*)(ldsPar + COUT + co);
-            ph[j] = *(const float4*)(ldsPar + 2 * COUT + co);
-          }
-        }
-      } else if (m <= NVP) {
-#pragma unroll
-        for (int vi = (m - 1) * VPP; vi < m * VPP; ++vi) {
-          const int e = vi & 3, j = (vi >> 2) % NJ, ro = vi / (4 * NJ);
-          const float b = e == 0 ? pb[j].x : e == 1 ? pb[j].y : e == 2 ? pb[j].z : pb[j].w;
-          float u;
-          if constexpr (POOL) {
-            u = vmax1(acc[h & 1][2 * ro][j][e], acc[h & 1][2 * ro + 1][j][e]);         // rows 2 ro, 2 ro + 1
-            // columns fr and fr ^ 1: DPP quad_perm [1,0,3,2]
-            u = vmax1(u, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u), 0xB1, 0xF, 0xF, true)));
-            u = vmax1(u + b, relu_floor);                                             // (bias commutes with the max)
-          } else {
-            u = vmax1(acc[h & 1][ro][j][e] + b, relu_floor);
-          }
-          if constexpr (POST) {   // affine on the storage-rounded value, as the LDS-staged kernels do
-            const float sc = e == 0 ? ps[j].x : e == 1 ? ps[j].y : e == 2 ? ps[j].z : ps[j].w;
-            const float sh = e == 0 ? ph[j].x : e == 1 ? ph[j].y : e == 2 ? ph[j].z : ph[j].w;
-            u = bf16_to_f32(f32_to_bf16(u)) * sc + sh;
-          }
-          ev[ro][j][e] = u;
-        }
-      } else {
-        const int sp = m - 1 - NVP;
-        auto pk = [&](int ro, int j) { return make_uint2(pack2_h16(ev[ro][j][0], ev[ro][j][1]), pack2_h16(ev[ro][j][2], ev[ro][j][3])); };
-        if constexpr (POOL) {
-          // 4 (pooled row, cout block) combinations per lane quad (fr parity q2, fh parity hp): q2 picks the pair, the
-          // fh-pair lanes trade one 8-byte group so that each lane owns 8 consecutive couts of ONE combination
-          uint2 lo, hi;
-          int pr_st, j_lo, j_hi;
-          bool st = true;
-          if constexpr (NJ == 2 && HRP == 2) {        // q2 = pooled row, hp = cout block
-            const uint2 a0 = pk(0, 0), a1 = pk(HRP - 1, 0), b0 = pk(0, NJ - 1), b1 = pk(HRP - 1, NJ - 1);
-            lo = q2 ? a1 : a0;
-            hi = q2 ? b1 : b0;
-            pr_st = q2; j_lo = 0; j_hi = 1;
-          } else if constexpr (NJ == 2) {             // HRP == 1: two combinations only — the odd column of a pair does not store
-            lo = pk(0, 0);
-            hi = pk(0, NJ - 1);
-            pr_st = 0; j_lo = 0; j_hi = 1;
-            st = q2 == 0;
-          } else {                                    // NJ == 4, HRP == 1: block = 2 hp + q2
-            const uint2 a0 = pk(0, 0), a1 = pk(0, 1), b0 = pk(0, NJ - 2), b1 = pk(0, NJ - 1);
-            lo = q2 ? a1 : a0;
-            hi = q2 ? b1 : b0;
-            pr_st = 0; j_lo = q2; j_hi = 2 + q2;
-          }
-          const auto sx = __builtin_amdgcn_permlane16_swap(lo.x, hi.x, false, false);
-          const auto sy = __builtin_amdgcn_permlane16_swap(lo.y, hi.y, false, false);
-          const int oy = ((y0 + pg * RW + h * HR) >> 1) + pr_st, ox = (x0 >> 1) + (fr >> 1);
-          const int co = cout0 + 16 * (hp ? j_hi : j_lo) + 8 * (fh >> 1);
-          unsigned short* dst = (unsigned short*)p.y +
-                                (((size_t)n * p.Hyp + oy + p.y_halo) * p.Wyp + ox + p.y_halo) * (size_t)p.Cy + co;
-          if (st) *(uint4*)dst = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-        } else {
-          // un-pooled: per conv row i and pair of cout blocks (2 mm, 2 mm + 1) one 16-byte store per lane
-          const int i = sp / (NJ / 2), mm = sp % (NJ / 2);
-          const uint2 a = pk(i, 2 * mm), b = pk(i, 2 * mm + 1);
-          const auto sx = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
-          const auto sy = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
-          const int oy = y0 + pg * RW + h * HR + i, ox = x0 + fr;
-          unsigned short* dst = (unsigned short*)p.y +
-                                (((size_t)n * p.Hyp + oy + p.y_halo) * p.Wyp + ox + p.y_halo) * (size_t)p.Cy + cout0 +
-                                8 * (fh >> 1) + 16 * (2 * mm + hp);
-          *(uint4*)dst = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-        }
-      }
-    };
-
-    // filler behind MFMA group `pos` of step k: spreads everything that is not an MFMA or a fragment read over the
-    // tile — the next patch's DMA instructions over part 0, the epilogue pieces of part h - 1 over part h
-    constexpr int DMA_STRIDE = SPP / NDMA, EPI_STRIDE = (SPP - 2) / NPIECE > 0 ? (SPP - 2) / NPIECE : 1;
-    static_assert(DMA_STRIDE >= 1 && NPIECE <= SPP - 2, "fillers must fit their part");
+    // Fillers: everything that is neither an MFMA nor a fragment read is cut into pieces of a few instructions, one piece
+    // behind one (patch row, tap row) MFMA group.  Part 0: the next patch's DMA instructions (even slots) and the epilogue of
+    // the PREVIOUS tile's last part (odd slots).  Part h >= 1: the epilogue of part h - 1; the last part also carries the
+    // scalar address arithmetic of the tiles to come.
+    constexpr int DMA_STRIDE = (SPP / 2) / NDMA, EPI0_STRIDE = (SPP / 2) / NPIECE, EPI_STRIDE = (SPP - 2) / NPIECE;
+    static_assert(DMA_STRIDE >= 1 && EPI0_STRIDE >= 1 && EPI_STRIDE >= 1, "fillers must fit their part");
+    TileAt nn = nxt;
+    const char* nn_src = next_src;
     auto filler = [&](int k, int pos) {
       const int h = k / NGRP, u = (k - h * NGRP) * SPS + pos;
       if (h == 0) {
-        if (u % DMA_STRIDE == DMA_STRIDE - 1 && u / DMA_STRIDE < NDMA && have_next) issue_dma(next_src, slot ^ 1, u / DMA_STRIDE);
+        const int v = u >> 1;
+        if ((u & 1) == 0) {
+          if (v % DMA_STRIDE == 0 && v / DMA_STRIDE < NDMA && have_next) issue_dma(dma_src, slot ^ 1, v / DMA_STRIDE);
+        } else {
+          if (v % EPI0_STRIDE == 0 && v / EPI0_STRIDE < NPIECE && it > 0) epi_piece(NP - 1, v / EPI0_STRIDE, prev);
+        }
       } else {
-        if (u >= 2 && (u - 2) % EPI_STRIDE == 0 && (u - 2) / EPI_STRIDE < NPIECE) epi_piece(h - 1, (u - 2) / EPI_STRIDE);
+        if (u >= 2 && (u - 2) % EPI_STRIDE == 0 && (u - 2) / EPI_STRIDE < NPIECE) epi_piece(h - 1, (u - 2) / EPI_STRIDE, cur);
+        if (h == NP - 1 && u == 1) {               // coordinates of tile t + G (its patch is in flight), patch origin of tile t + 2G
+          nn = nxt;
+          if (t + 2 * G < p.n_tiles) tile_origin(t + 2 * G, nxt.n, nxt.y0, nxt.x0);
+        }
+        if (h == NP - 1 && u == SPS + 1)
+          nn_src = p.x + (((size_t)nxt.n * p.Hp + nxt.y0) * p.Wp + nxt.x0) * PIXB;
       }
     };
 
     // Step k = (part h, group g = (s, ks)).  The NR patch-row fragments of a group are read ONCE and serve all three tap
-    // rows r (output row i = R - r): NR reads per 3 HR NJ MFMAs.  The reads of step k + 1 are issued in the middle of step
-    // k's MFMAs (register double buffer Xa / Xb), so that the wait in front of a step never covers reads younger than its own.
-    auto load_step = [&](int k, vnqa_bf16x8* X) {
+    // rows r (output row i = R - r): NR reads per 3 HR NJ MFMAs.  Fragment R of step k + 1 is read behind MFMA group R of
+    // step k (register double buffer Xa / Xb): one ds_read_b128 per gap, a whole step ahead of its first use.
+    auto load_frag = [&](int k, vnqa_bf16x8* X, int R) {
       const int h = k / NGRP, g = k - h * NGRP;
       const int s = g / KS, ks = g - s * KS;
-#pragma unroll
-      for (int R = 0; R < NR; ++R) X[R] = *(const vnqa_bf16x8*)(ldsP + fbase[s][ks] + (h * HR + R) * PW * PIXB);
+      X[R] = *(const vnqa_bf16x8*)(ldsP + fbase[s][ks] + (h * HR + R) * PW * PIXB);
     };
-    auto mma_rows = [&](int k, const vnqa_bf16x8* X, int R0, int R1) {
+    auto step = [&](int k, const vnqa_bf16x8* X, vnqa_bf16x8* Xn) {
       const int h = k / NGRP, g = k - h * NGRP;
       const int s = g / KS, ks = g - s * KS;
+      int pos = 0;
 #pragma unroll
-      for (int R = R0; R < R1; ++R)
+      for (int R = 0; R < NR; ++R)
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
           const int i = R - r;
           if (i < 0 || i >= HR) continue;
-          // position of this (R, r) group among the step's 3 HR groups (execution order: R ascending, r ascending)
-          int pos = 0;
-          for (int RR = 0; RR <= R; ++RR)
-            for (int rr = 0; rr < 3; ++rr) {
-              const int ii = RR - rr;
-              if (ii < 0 || ii >= HR) continue;
-              if (RR < R || rr < r) ++pos;
-            }
 #pragma unroll
           for (int j = 0; j < NJ; ++j) {
             const bool first = g == 0 && r == 0;         // first product of this accumulator: C = 0
@@ -346,34 +360,29 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
             if (first) { if (in_a) mfma_asm<true, true>(acc[h & 1][i][j], Wf[3 * r + s][ks][j], X[R]); else mfma_asm<false, true>(acc[h & 1][i][j], Wf[3 * r + s][ks][j], X[R]); }
             else { if (in_a) mfma_asm<true, false>(acc[h & 1][i][j], Wf[3 * r + s][ks][j], X[R]); else mfma_asm<false, false>(acc[h & 1][i][j], Wf[3 * r + s][ks][j], X[R]); }
           }
+          if (pos < NR && k + 1 < NSTEP) load_frag(k + 1, Xn, pos);
           filler(k, pos);
+          __builtin_amdgcn_sched_barrier(0);
+          ++pos;
         }
     };
 
-    constexpr int SPLIT = NR >= 6 ? 2 : 1;     // patch rows whose MFMAs run before the next step's reads are issued
     vnqa_bf16x8 Xa[NR], Xb[NR];
-    load_step(0, Xa);
 #pragma unroll
-    for (int k = 0; k < NSTEP; k += 2) {
-      // even step: fragments in Xa, next step's into Xb
-      __builtin_amdgcn_sched_barrier(0);
-      mma_rows(k, Xa, 0, SPLIT);
-      __builtin_amdgcn_sched_barrier(0);
-      load_step(k + 1, Xb);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_rows(k, Xa, SPLIT, NR);
-      __builtin_amdgcn_sched_barrier(0);
-      // odd step
-      mma_rows(k + 1, Xb, 0, SPLIT);
-      __builtin_amdgcn_sched_barrier(0);
-      if (k + 2 < NSTEP) load_step(k + 2, Xa);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_rows(k + 1, Xb, SPLIT, NR);
-    }
+    for (int R = 0; R < NR; ++R) load_frag(0, Xa, R);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int m = 0; m < NPIECE; ++m) epi_piece(NP - 1, m);
+    for (int k = 0; k < NSTEP; k += 2) {
+      step(k, Xa, Xb);
+      step(k + 1, Xb, Xa);
+    }
+    prev = cur;
+    cur = nn;
+    next_src = nn_src;
   }
+  // the last tile's last part (every workgroup has processed at least one tile: grid <= n_tiles)
+#pragma unroll
+  for (int m = 0; m < NPIECE; ++m) epi_piece(NP - 1, m, prev, true);
 }
 
 template <int CIN, int COUT, int NCG, int TH, int HR, bool POOL, bool POST>
