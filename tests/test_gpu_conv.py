@@ -67,7 +67,7 @@ def test_conv_igemm_vs_torch(dt, cfg):
     assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19])
 def test_conv_igemm_tiles_agree(tile):
     from videonavqa_amd import kernels as K
     g = torch.Generator(device="cpu").manual_seed(tile)
@@ -196,7 +196,7 @@ def test_gemm_tn(dt, mnk):
     assert _rel(out, ref) < 5e-5
 
 
-@pytest.mark.parametrize("tile", [7, 8, 9])
+@pytest.mark.parametrize("tile", [7, 8, 9, 18])
 @pytest.mark.parametrize("cfg", [(3, 10, 13, 64, 64, 9, True, False), (2, 16, 12, 64, 128, 9, True, True),
                                  (5, 14, 14, 128, 320, 1, True, False), (9, 28, 28, 64, 64, 9, False, True)])
 def test_conv_igemm_ring_pipeline(tile, cfg):
@@ -255,7 +255,7 @@ def test_conv_c64_direct_vs_torch(cfg, shape4):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 15])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 15, 18, 19])
 def test_conv_igemm_pretiled_weights(dt, tile):
     """pre-tiled (LDS-image) weight layout gives the same result as the row layout"""
     from videonavqa_amd import kernels as K

@@ -14,7 +14,7 @@ os.makedirs(out_dir, exist_ok=True)
 procs, objs = [], []
 for src in B.sources():
     obj = os.path.join(out_dir, os.path.basename(src) + ".o")
-    cmd = [B.HIPCC] + extra + B.FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
+    cmd = [B.HIPCC] + extra + B.FLAGS + B.PER_FILE_FLAGS.get(os.path.basename(src), []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]
     procs.append((src, subprocess.Popen(cmd, stderr=subprocess.DEVNULL)))
     objs.append(obj)
 for src, p in procs:

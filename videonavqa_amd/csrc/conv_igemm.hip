@@ -57,6 +57,14 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// LDS-DMA from inline asm (64-bit per-lane source address, wave-uniform LDS destination): invisible to hipcc's wait-count
+// bookkeeping, so it can stay in flight across raw barriers and next to LDS reads; every wait for it is hand-placed
+// (PIPE == 5 main loop).  M0 is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16_asm64(const char* src, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_addr) : "memory");
+}
 // Rejected experiment, kept for A/B: non-temporal (aux = 2) weight-tile DMA measured -8 % on conv12/conv22
 // (every CU re-reads the weight tiles from L2; nt gives that reuse up).
 #ifdef VNQA_NT_WEIGHTS
@@ -95,6 +103,9 @@ __device__ __forceinline__ void decode_pixel(int m, int H, int W, int pool, int&
 //
 // PIPE selects the main-loop structure:
 //   PIPE == 2 : two 128-byte-row stages, __syncthreads() (drains the DMA) once per 64-channel K-step;
+//   PIPE == 5 : two 128-byte-row stages like PIPE == 2, but software-pipelined by hand (see the branch below): one raw
+//               barrier per K-step placed BETWEEN its two k-substeps, DMA two stages ahead issued piece by piece between
+//               MFMA groups, fragment reads one substep ahead, one per MFMA gap; no wave stagger.
 //   PIPE == 4 : a ring of four 64-byte-row stages (32 channels each); the DMA of three stages stays in
 //               flight ACROSS the workgroup barriers: counted s_waitcnt vmcnt(N) + raw s_barrier, one
 //               barrier per stage, a slot is refilled right after the barrier that retires its readers.
@@ -109,7 +120,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   constexpr int NG = NR / 4;                  // groups of 4 consecutive couts per lane and tile
   constexpr int CPS = MT == 32 ? 2 : 4;       // 16-byte chunks one k-substep spans (lane takes chunk fh of them)
   constexpr int ES = (int)sizeof(T);
-  constexpr int ROWB = PIPE >= 3 ? 64 : 128;  // bytes of one tile row per stage
+  constexpr int ROWB = (PIPE == 3 || PIPE == 4) ? 64 : 128;  // bytes of one tile row per stage
   constexpr int BK = ROWB / ES;               // channels per stage
   constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
   constexpr int RPI = 1024 / ROWB;            // rows covered by one wave-level DMA instruction
@@ -122,7 +133,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   constexpr int CROW = BN * ES + 16;          // epilogue LDS row stride (bytes)
   static_assert((BM / RPI) % NW == 0 && (BN / RPI) % NW == 0, "tile/wave mismatch");
   static_assert(TM >= 1 && TN >= 1, "wave tile too small");
-  static_assert(PIPE == 2 || PIPE == 3 || PIPE == 4, "PIPE must be 2, 3 or 4");
+  static_assert(PIPE == 2 || PIPE == 3 || PIPE == 4 || PIPE == 5, "PIPE must be 2, 3, 4 or 5");
   // swizzle: spread the 16 rows a ds_read_b128 lane group touches over all 16 slots of a 256-B bank row
   auto swz = [](int row) { return ROWB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
@@ -379,6 +390,119 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       }
       mma_sub(xf1, wf1);
     }
+  } else if constexpr (PIPE == 5) {
+    // Hand-pipelined loop (256x256 tile, 8 waves, 128x64 wave tiles, 16x16x32 MFMA).  Per K-step kt and wave:
+    //   phase 0: the 32 MFMAs of k-substep 0 (fragments already in registers), the 12 fragment reads of substep 1 behind them;
+    //   --- s_waitcnt vmcnt(0) [stage kt+1, issued a whole K-step ago, has landed] + lgkmcnt(0) [every fragment of stage kt is
+    //       in registers], raw s_barrier: slot kt%2 is free, slot (kt+1)%2 is visible ---
+    //   phase 1: the 32 MFMAs of substep 1; behind them the 8 DMA instructions of stage kt+2 (into the slot just freed) and
+    //            the 12 fragment reads of stage kt+1 / substep 0.
+    // A DMA thus has a full K-step to land and its wait never stalls; a barrier never has a DMA burst or a fragment-read
+    // burst behind it; the matrix pipe always has queued work while this wave issues an expensive instruction.
+    static_assert(NSUB == 2 && NW == 8 && MT == 16 && TM == LPS, "PIPE 5 is laid out for the 256x256 tile");
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // K position of a stage (tap = (q, r, sx) window coordinates, kc = 64-channel chunk), advanced incrementally: the
+    // per-stage offsets cost a handful of scalar instructions instead of a division chain behind the barrier
+    const int kw = (p.taps == 9 || p.taps == 27 || p.taps == 3) ? 3 : (p.taps == 25 ? 5 : 1);
+    const int kh = (p.taps == 9 || p.taps == 27) ? 3 : (p.taps == 25 ? 5 : 1);
+    const int r_base = (p.taps == 9 || p.taps == 25 || p.taps == 27 || p.taps == 3) ? 0 : p.x_halo;   // 1x1: the centre tap
+    struct KPos { int tap, kc, q, r, sx; };
+    auto kpos_at = [&](int kt) {
+      KPos k;
+      k.kc = kt / p.taps;
+      k.tap = kt - k.kc * p.taps;
+      k.q = k.tap / (kw * kh);
+      const int rs = k.tap - k.q * (kw * kh);
+      k.r = rs / kw;
+      k.sx = rs - k.r * kw;
+      return k;
+    };
+    auto kpos_next = [&](KPos& k) {
+      ++k.tap;
+      if (++k.sx == kw) { k.sx = 0; if (++k.r == kh) { k.r = 0; ++k.q; } }
+      if (k.tap == p.taps) { k.tap = 0; k.sx = 0; k.r = 0; k.q = 0; ++k.kc; }
+    };
+    auto stage_off = [&](const KPos& k, size_t& tapoff, size_t& woff) {
+      tapoff = ((((size_t)k.q * p.Hp + (k.r + r_base)) * p.Wp + (k.sx + r_base)) * p.Cin + (size_t)k.kc * BK) * ES;
+      woff = ((size_t)k.tap * p.Cin + (size_t)k.kc * BK) * ES;
+    };
+    auto dma_piece = [&](size_t tapoff, size_t woff, int kt, int buf, int j) {
+      if (j < A_PER_WAVE) {
+        glds16_asm64(p.x + a_off[j < A_PER_WAVE ? j : 0] + tapoff,
+                     __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + (wave * A_PER_WAVE + j) * 1024));
+      } else {
+        const int jj = j - A_PER_WAVE;
+        const char* src = p.wt_tiled ? p.wt + ((size_t)tile_n * KT + kt) * B_BYTES + (size_t)lane * 16 + (wave * B_PER_WAVE + jj) * 1024
+                                     : p.wt + b_off[jj >= 0 && jj < B_PER_WAVE ? jj : 0] + woff;
+        glds16_asm64(src, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE_BYTES + A_BYTES + (wave * B_PER_WAVE + jj) * 1024));
+      }
+    };
+    // fragment read idx (0 .. TM+TN-1) of substep s: pixel fragments first, then weight fragments
+    auto read_frag = [&](const char* lds, int s, int idx, vnqa_f32x4* xf, vnqa_f32x4* wf) {
+      if (idx < TM) xf[idx] = *(const vnqa_f32x4*)(lds + x_rd[idx] + (((CPS * s + fh) ^ x_sw[idx]) << 4));
+      else wf[idx - TM] = *(const vnqa_f32x4*)(lds + w_rd[idx - TM] + (((CPS * s + fh) ^ w_sw[idx - TM]) << 4));
+    };
+    // the 12 reads behind the 8 MFMA groups of a phase: two behind each of the first four groups, one behind the others
+    auto reads_behind = [&](const char* lds, int s, int g, vnqa_f32x4* xf, vnqa_f32x4* wf) {
+      if (g < 4) { read_frag(lds, s, 2 * g, xf, wf); read_frag(lds, s, 2 * g + 1, xf, wf); }
+      else read_frag(lds, s, 4 + g, xf, wf);
+    };
+    size_t tapoff, woff;
+    KPos kp = kpos_at(kt0);
+    stage_off(kp, tapoff, woff);
+    asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < LPS; ++j) dma_piece(tapoff, woff, kt0, 0, j);
+    kpos_next(kp);
+    if (kt0 + 1 < kt1) {
+      stage_off(kp, tapoff, woff);
+#pragma unroll
+      for (int j = 0; j < LPS; ++j) dma_piece(tapoff, woff, kt0 + 1, 1, j);
+    }
+    kpos_next(kp);                       // kp = position of stage kt + 2 from here on
+    stage_off(kp, tapoff, woff);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    vnqa_f32x4 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+#pragma unroll
+    for (int idx = 0; idx < TM + TN; ++idx) read_frag(smem, 0, idx, xf0, wf0);
+    // timing-only diagnostics of this loop (compile-time, so that the rest of the code is generated as in the product build):
+    // -DVNQA_P5_DIAG=<bits>: 1 = no pixel DMA, 2 = no weight DMA, 4 = no fragment reads, 8 = no barrier, 16 = no MFMAs
+#ifndef VNQA_P5_DIAG
+#define VNQA_P5_DIAG 0
+#endif
+    constexpr bool dgA = VNQA_P5_DIAG & 1, dgB = VNQA_P5_DIAG & 2, dgR = VNQA_P5_DIAG & 4, dgBar = VNQA_P5_DIAG & 8, dgM = VNQA_P5_DIAG & 16;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      const char* lds = smem + cur * STAGE_BYTES;
+      const char* ldn = smem + (cur ^ 1) * STAGE_BYTES;
+      const bool has1 = kt + 1 < kt1 && !dgR, has2 = kt + 2 < kt1;
+      // ---- phase 0 ----
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) if (!dgM) Mma<T>::run(wf0[j], xf0[i], acc[i][j]);
+        if (!dgR) reads_behind(lds, 1, i, xf1, wf1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stage kt+1 (issued during phase 1 of K-step kt-1) has landed
+      __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): all of stage kt's fragments are in registers
+      if (!dgBar) __builtin_amdgcn_s_barrier();
+      // ---- phase 1 ----
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) if (!dgM) Mma<T>::run(wf1[j], xf1[i], acc[i][j]);
+        if (has2 && !(i < A_PER_WAVE ? dgA : dgB)) dma_piece(tapoff, woff, kt + 2, cur, i);
+        if (has1) reads_behind(ldn, 0, i, xf0, wf0);
+      }
+      kpos_next(kp);
+      stage_off(kp, tapoff, woff);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_barrier();     // every wave is done with its fragment reads before the epilogue reuses the LDS
   } else if constexpr (PIPE == 2) {
     stage(kt0, 0);
     __syncthreads();
@@ -736,9 +860,10 @@ template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int TAG = 0, int
 int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int ES = (int)sizeof(T);
-  constexpr int STAGE = (BM + BN) * (PIPE >= 3 ? 64 : 128);
+  constexpr int STAGE = (BM + BN) * ((PIPE == 3 || PIPE == 4) ? 64 : 128);
   constexpr int CT = BM * (BN * ES + 16);
-  constexpr int LDS = (PIPE * STAGE > CT) ? PIPE * STAGE : CT;
+  constexpr int NSTAGE = PIPE == 5 ? 2 : PIPE;
+  constexpr int LDS = (NSTAGE * STAGE > CT) ? NSTAGE * STAGE : CT;
   static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
   ConvArgs p = a;
   const int tilesM = (p.M + BM - 1) / BM;
@@ -773,7 +898,8 @@ int resolve_tile(const ConvArgs& a, int dtype, int tile) {
 int fused_tile_rows(int dtype, int tile) {
   if (dtype == VNQA_BF16) {
     switch (tile) {
-      case VNQA_TILE_256x256: case VNQA_TILE_256x128: case VNQA_TILE_256x64: case VNQA_TILE_256x128_W24: return 256;
+      case VNQA_TILE_256x256: case VNQA_TILE_256x128: case VNQA_TILE_256x64: case VNQA_TILE_256x128_W24:
+      case VNQA_TILE_I5_256x256: return 256;
       case VNQA_TILE_128x128: case VNQA_TILE_128x64: return 128;
       default: return 0;
     }
@@ -800,6 +926,8 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_512x128: return launch<vnqa_bf16, 512, 128, 4, 2, 2>(a, st);
       case VNQA_TILE_P3_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, 2, 3>(a, st);
       case VNQA_TILE_320x128: return launch<vnqa_bf16, 320, 128, 4, 2, 2>(a, st);
+      case VNQA_TILE_I5_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, 0, 5>(a, st);
+      case VNQA_TILE_STEM_I5_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, 1, 5>(a, st);
       case VNQA_TILE_PATCH_224x256:
       case VNQA_TILE_STEM_PATCH_224x256:
         if (a.zero_halo) {
@@ -888,7 +1016,7 @@ namespace {
 
 int tile_bn(int tile) {
   switch (tile) {
-    case VNQA_TILE_256x256: case VNQA_TILE_STEM_256x256: return 256;
+    case VNQA_TILE_256x256: case VNQA_TILE_STEM_256x256: case VNQA_TILE_I5_256x256: case VNQA_TILE_STEM_I5_256x256: return 256;
     case VNQA_TILE_256x128: case VNQA_TILE_128x128: case VNQA_TILE_256x128_W24: case VNQA_TILE_512x128:
     case VNQA_TILE_P3_256x128: return 128;
     case VNQA_TILE_256x64: case VNQA_TILE_128x64: return 64;

@@ -144,8 +144,15 @@ class FrozenStem(object):
             wt = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         else:   # frozen weights: pre-tiled once into the exact LDS images the igemm DMA consumes
             wt = K.pack_conv_weight_tiled(w, self.cdt, tile, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
-        return dict(wt=wt, bias=K.pad_vec(b, c_out_pad), relu=relu, pool=pool, post=None,
-                    c_out=c_out, c_in=c_in, c_out_pad=c_out_pad, tile=tile)
+        ly = dict(wt=wt, bias=K.pad_vec(b, c_out_pad), relu=relu, pool=pool, post=None,
+                  c_out=c_out, c_in=c_in, c_out_pad=c_out_pad, tile=tile)
+        # short-K layers of the VGG front (conv1_2 / conv2_1 / conv2_2 shapes): weights-stationary-in-registers direct conv
+        # (csrc/conv_wreg.hip) when the run-time geometry has whole tiles; it reads the K-major row pack
+        if bf16 and relu and (c_in_pad, c_out_pad, bool(pool)) in ((64, 64, True), (64, 128, False), (128, 128, True)) \
+                and os.environ.get("VNQA_STEM_WREG", "1") != "0":
+            ly["wt_rows"] = wt if tile is None else K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad,
+                                                                       c_in_pad=c_in_pad)
+        return ly
 
     def _compose_pair(self, c1, c2, bn):
         """Two stacked linear convs with frozen weights as ONE conv.
@@ -171,7 +178,7 @@ class FrozenStem(object):
         if bf16 and os.environ.get("VNQA_STEM_COMPOSE_TILE"):
             tile = int(os.environ["VNQA_STEM_COMPOSE_TILE"])      # A/B hook
         wcf = wc.float().contiguous()
-        if tile == L.TILE_STEM_256x256 and os.environ.get("VNQA_STEM_TILED", "1") != "0":
+        if tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256) and os.environ.get("VNQA_STEM_TILED", "1") != "0":
             wt = K.pack_conv_weight_tiled(wcf, self.cdt, tile, c_out_pad=co_pad, c_in_pad=ci_pad)
         else:
             wt = K.pack_conv_weight(wcf, self.cdt, c_out_pad=co_pad, c_in_pad=ci_pad)
@@ -222,7 +229,7 @@ class FrozenStem(object):
         ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
         out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
-        timed = self.timing is not None and cp["tile"] == L.TILE_STEM_256x256
+        timed = self.timing is not None and cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256)
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -251,11 +258,15 @@ class FrozenStem(object):
             out = self._buf(key, (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
             post = ly["post"]
             tile = ly["tile"]
-            timed = self.timing is not None and tile == L.TILE_STEM_256x256
+            timed = self.timing is not None and tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256)
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            if tile is None:
+            if "wt_rows" in ly and K.conv2d_wreg_supported(x, ly["wt_rows"], pool2=ly["pool"], y_halo=yh):
+                x = K.conv2d_wreg(x, ly["wt_rows"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
+                                  post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+                                  out=out, y_halo=yh)
+            elif tile is None:
                 # C_in = 64 layers (conv1_2, conv2_1): persistent direct conv with LDS-resident weights
                 x = K.conv2d_c64(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                  post_scale=post[0] if post else None, post_shift=post[1] if post else None, out=out)
