@@ -143,3 +143,48 @@ def test_overlapped_reducer_on_one_rank_rccl_group():
     d = (w0 - w1).abs()                      # same tolerances as the pipeline test above (Adam on noise-level gradients)
     assert float(d.max()) < 6e-3
     assert float(torch.quantile(d[:1000000], 0.999)) < 1e-5
+
+
+def _two_backwards(direct):
+    """flat gradient after TWO backward passes (different minibatches) without an optimizer step in between"""
+    import os
+    from videonavqa_amd.train import Trainer
+    from videonavqa_amd import ops
+    old = os.environ.get("VNQA_DIRECT_GRADS")
+    os.environ["VNQA_DIRECT_GRADS"] = "1" if direct else "0"
+    try:
+        model, stem, batches = _setup(seed=3)
+        tr = Trainer(model, stem, lr=1e-3)
+    finally:
+        if old is None:
+            os.environ.pop("VNQA_DIRECT_GRADS", None)
+        else:
+            os.environ["VNQA_DIRECT_GRADS"] = old
+    model.train()
+    grads = []
+    for b in batches[:2]:
+        clip, q, v_lens, q_lens, y = b
+        native, v_sorted, perm = tr.extract_features(clip, v_lens)
+        perm_d = perm.cuda()
+        model.init_hidden()
+        logits = model(native, q.index_select(0, perm_d), v_sorted, q_lens[perm])
+        loss = ops.cross_entropy(logits, y, row_perm=perm_d.to(torch.int32), reduction="sum")
+        loss.backward()
+        grads.append(tr.fp.grad.clone())
+    torch.cuda.synchronize()
+    return grads
+
+
+def test_grad_sinks_accumulate_over_two_backward_passes():
+    """a second backward before the buffer is zeroed must ADD to the flat gradient (as p.grad does), not
+    overwrite the first pass's slice — the sink hands its slice out once per zeroing, later producers go through
+    AccumulateGrad."""
+    g_ref = _two_backwards(False)
+    g_dir = _two_backwards(True)
+    for a, b in zip(g_ref, g_dir):
+        scale = float(a.abs().max())
+        assert scale > 0
+        # (torch's scatter / index_put backward use float atomics: last-bit noise between two runs)
+        assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+    # and the second pass really added something
+    assert float((g_dir[1] - g_dir[0]).abs().max()) > 1e-6 * float(g_dir[0].abs().max())

@@ -14,13 +14,18 @@ from . import kernels as K
 
 class GradSink(object):
     """Where a parameter's gradient lives when the training driver owns it (train.FlatParams: a slice of the flat gradient
-    buffer, zeroed by the fused clip+Adam kernel).  A parameter carrying `_vnqa_grad_sink` has exactly ONE gradient producer
-    per backward pass, so the producing kernel writes straight into the slice and the autograd node returns None for it:
-    no temporary gradient tensor and no AccumulateGrad add kernel (for fc_embed_attn.weight that add alone moved 150 MB).
-    `on_ready` (optional) is the data-parallel reducer's hook for parameters whose all-reduce starts early."""
+    buffer, zeroed by the fused clip+Adam kernel).  The FIRST gradient producer of a parameter after the buffer was zeroed
+    writes straight into the slice and its autograd node returns None: no temporary gradient tensor and no AccumulateGrad
+    add kernel (for fc_embed_attn.weight that add alone moved 150 MB).  Any FURTHER producer before the next zeroing — a
+    second backward pass without an optimizer step (gradient accumulation, gradient checks on a Trainer-owned model), or a
+    weight shared by two ops — finds `written` set and takes the ordinary route (temporary + AccumulateGrad add), so the
+    slice accumulates exactly as `p.grad` would.  `train.FlatParams.mark_zeroed()` clears the flag wherever the buffer is
+    zeroed.  `on_ready` (optional) is the data-parallel reducer's hook for parameters whose all-reduce starts early."""
 
     def __init__(self, view):
         self.view, self.on_ready = view, None
+        self.written = False      # the slice already holds a gradient of the current accumulation window
+        self._handed = False      # _into() gave the view to a kernel whose _ret() has not run yet
 
     def done(self):
         if self.on_ready is not None:
@@ -28,22 +33,32 @@ class GradSink(object):
 
 
 def sink_of(param):
-    """The parameter's GradSink, or None (plain autograd accumulation)."""
+    """The parameter's GradSink, or None (plain autograd accumulation).  None as well when `param.grad` is no longer the
+    sink's slice (e.g. a stock optimizer's zero_grad(set_to_none=True)): writing there would lose the gradient."""
     s = getattr(param, "_vnqa_grad_sink", None)
-    return s if (s is not None and param.requires_grad and torch.is_grad_enabled()) else None
+    if s is None or not param.requires_grad or not torch.is_grad_enabled():
+        return None
+    g = param.grad
+    if g is None or g.data_ptr() != s.view.data_ptr():
+        return None
+    return s
 
 
 def _into(sink, shape=None):
-    """Output buffer for a gradient kernel: the sink's view (optionally reshaped) or None = allocate."""
-    if sink is None:
+    """Output buffer for a gradient kernel: the sink's view (optionally reshaped), or None = allocate (no sink, or the
+    slice already holds a gradient: the value then goes through AccumulateGrad)."""
+    if sink is None or sink.written:
         return None
+    sink._handed = True
     return sink.view if shape is None else sink.view.view(shape)
 
 
 def _ret(sink, value):
-    """What the autograd node returns for a parameter: None when the kernel already wrote into the sink."""
-    if sink is None:
+    """What the autograd node returns for a parameter: None when the kernel wrote into the sink, else the value."""
+    if sink is None or not sink._handed:
         return value
+    sink._handed = False
+    sink.written = True
     sink.done()
     return None
 

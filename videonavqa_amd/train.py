@@ -55,6 +55,16 @@ class FlatParams(object):
 
     def zero_grad(self):
         self.grad.zero_()
+        self.mark_zeroed()
+
+    def mark_zeroed(self):
+        """The flat gradient buffer has just been zeroed (fused clip+Adam kernel, zero_grad): the next gradient producer of
+        every parameter may write its slice in place again (ops.GradSink)."""
+        for p in self.params:
+            s = getattr(p, "_vnqa_grad_sink", None)
+            if s is not None:
+                s.written = False
+                s._handed = False
 
 
 def sync_replicas(tensors, src=0):
@@ -303,6 +313,7 @@ class Trainer(object):
         self.fp.step_count += 1
         K.clip_adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.fp.partial,
                          self.fp.step_count, self.lr, self.clip)
+        self.fp.mark_zeroed()        # (the kernel zeroes the gradient buffer)
         ev = torch.cuda.Event()
         ev.record(main)
         self._trunk_done[self._slot] = ev
