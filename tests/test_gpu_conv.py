@@ -272,7 +272,7 @@ def test_conv_igemm_pretiled_weights(dt, tile):
     assert _rel(K.nhwc_to_nchw(y, Cout), ref) < _tol(dt)
 
 
-@pytest.mark.parametrize("tile", [11, 12])
+@pytest.mark.parametrize("tile", [11, 12, 20, 21])
 @pytest.mark.parametrize("cfg", [
     # N, H, W, Cin, Cout, relu, pool, post
     (3, 28, 28, 128, 512, True, True, True),      # 8x28 tiles straddle image boundaries (28 = 3.5 x 8)

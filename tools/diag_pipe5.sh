@@ -1,5 +1,5 @@
 #!/bin/bash
-# timing-only ablations of the PIPE 5 igemm main loop (tools/build_igemm_variant.sh p5d<bits> -DVNQA_P5_DIAG=<bits>):
+# timing-only ablations of the PIPE 5 igemm main loop (tools/build_one_variant.sh p5d<bits> conv_igemm.hip -DVNQA_P5_DIAG=<bits>):
 # bits 1 = no pixel DMA, 2 = no weight DMA, 4 = no fragment reads, 8 = no barrier, 16 = no MFMAs
 export PYTHONPATH=. VNQA_NO_REBUILD=1
 for L in conv21 conv12; do

@@ -39,6 +39,7 @@ BF16, F32 = 0, 1
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
+TILE_PS_224x256, TILE_STEM_PS_224x256 = 20, 21     # patch-stationary 3x3 conv (csrc/conv_ps.hip)
 TILE_P4_256x256, TILE_P4_256x128, TILE_P4_256x64, TILE_256x128_W24 = 7, 8, 9, 10
 
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float

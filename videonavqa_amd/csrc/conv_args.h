@@ -42,3 +42,6 @@ struct ConvArgs {
 // conv_patch.hip: 224-pixel 2-D tiles, activation patch DMA'd once per 64-channel chunk (bf16, 3x3, 2-D only).
 // Returns VNQA_ERR_UNSUPPORTED (with the reason in vnqa_last_error) when the geometry does not fit.
 int vnqa_conv_patch_dispatch(const ConvArgs& a, int tag, hipStream_t st);
+
+// conv_ps.hip: patch-stationary 3x3 conv, 4 waves / 512 registers each, hand-placed main loop (bf16, 3x3, 2-D, plain epilogue).
+int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st);

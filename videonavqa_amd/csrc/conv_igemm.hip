@@ -935,6 +935,9 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
           return VNQA_ERR_UNSUPPORTED;
         }
         return vnqa_conv_patch_dispatch(a, tile == VNQA_TILE_PATCH_224x256 ? 0 : 1, st);
+      case VNQA_TILE_PS_224x256:
+      case VNQA_TILE_STEM_PS_224x256:
+        return vnqa_conv_ps_dispatch(a, tile == VNQA_TILE_PS_224x256 ? 0 : 1, st);
       default: break;
     }
   } else {

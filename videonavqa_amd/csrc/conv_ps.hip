@@ -1,0 +1,377 @@
+// conv_ps.hip — "patch-stationary" 3x3 implicit-GEMM conv for the wide layers (C_in % 64 == 0, C_out tiles of 256): the
+// activation patch stays in LDS across the 9 taps, the weights stream through LDS, ONE wave per SIMD owns all 512 registers
+// of its SIMD, and every instruction of the main loop is placed by hand.
+//
+// Why (measured): conv_igemm.hip moves 64 KiB of operands into LDS per 64-channel K-step and CU.  With
+// its MFMAs compiled out the same loop still takes 61 % of its time: the L2 -> LDS DMA path delivers ~70 GB/s per CU
+// (~33 B/clk), which is what 64 KiB per 2048 MFMA cycles asks for — the kernel is co-limited by the DMA path and the matrix
+// pipe, and the two overlap badly because a wave that waits to issue a DMA cannot issue its MFMAs (two waves of a SIMD hit
+// their DMA bursts together).  This kernel asks the DMA path for 45 % less: the nine taps of a 64-channel chunk re-read the
+// SAME halo'd pixel patch from LDS (fetched once per chunk), only the 32 KiB weight slab is fetched per tap.  The freed
+// margin is what lets 4 waves (one per SIMD, 112 px x 128 cout wave tiles, 224 accumulator registers in the AGPR half of the
+// register file) keep the matrix pipe fed: 15 fragment reads per 56 MFMAs instead of 12 per 32, one barrier per K-step placed
+// BETWEEN its two k-substeps, DMA two K-steps ahead, one filler (fragment read, DMA instruction, address arithmetic) behind
+// every group of four MFMAs.
+//
+// Geometry (as conv_patch.hip): a workgroup owns 224 conv-output pixels = TR image rows x TC columns (8 x 28 or 16 x 14) of
+// the global (image, row) list — tiles may straddle images, the patch is the contiguous range of PADDED rows between the
+// first and the last row's halos — and 256 output channels.
+//   D[cout][pixel] += W[tap][cout][chunk] . patch[pixel + tap][chunk]       (weights = MFMA A operand, pixels = B operand)
+// Patch swizzle: 16-byte chunk ^= (col + 4 row) & 6 (TC = 28: conflict-free ds_read_b128 for every fragment, wrap position
+// and tap under gfx950's lane groups; TC = 14: (col + 2 row) & 6, the best linear form, 2-way on half of the wrapped reads).
+// Epilogue: bias, ReLU, 2x2 max-pool, per-channel affine through LDS, 16-byte NHWC stores (same contract as
+// vnqa_conv2d_igemm_fwd).  bf16 / fp16 storage only.
+#include "conv_args.h"
+
+namespace {
+
+namespace ps {
+constexpr int BM = 224, BN = 256, NW = 4, NT = 256;
+constexpr int WTM = 112, WTN = 128, TM = 7, TN = 8;
+constexpr int PATCH_ROWS = 360, PATCH_BYTES = PATCH_ROWS * 128, B_BYTES = BN * 128;
+constexpr int PATCH_INSTR = PATCH_ROWS / 8;                 // 45 wave-level DMA instructions cover a patch
+constexpr int PIW = (PATCH_INSTR + NW - 1) / NW;            // <= 12 of them per wave
+constexpr int WPW = (BN / 8) / NW;                          // 8 weight DMA instructions per wave and K-step
+constexpr int LDS_BYTES = 2 * PATCH_BYTES + 2 * B_BYTES;    // 157696
+constexpr int CROW = BN * 2 + 16;
+static_assert(BM * CROW <= LDS_BYTES, "epilogue tile must fit");
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
+}  // namespace ps
+
+#ifdef VNQA_H16_IS_F16
+#define VNQA_PS_MFMA "v_mfma_f32_16x16x32_f16"
+#else
+#define VNQA_PS_MFMA "v_mfma_f32_16x16x32_bf16"
+#endif
+
+// accumulators live in AGPRs ("a"): with 224 of them per lane the VGPR half stays free for two fragment sets
+template <bool FIRST>
+__device__ __forceinline__ void ps_mfma(vnqa_f32x4& acc, const vnqa_f32x4& w, const vnqa_f32x4& x) {
+  if constexpr (FIRST) asm volatile(VNQA_PS_MFMA " %0, %1, %2, 0" : "=&a"(acc) : "v"(w), "v"(x));
+  else asm volatile(VNQA_PS_MFMA " %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(x));
+}
+
+// LDS-DMA from inline asm (invisible to hipcc's wait counting; every wait is hand-placed): wave-uniform base + 32-bit lane offset
+__device__ __forceinline__ void ps_glds(const char* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+
+template <int TC> __device__ __forceinline__ int ps_swz(int row, int col) { return TC == 14 ? ((col + 2 * row) & 6) : ((col + 4 * row) & 6); }
+
+template <int TC, int TAG>
+__global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
+  using namespace ps;
+  constexpr int TR = BM / TC, PW = TC + 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  constexpr int WOFF = 2 * PATCH_BYTES;        // weight slabs behind the two patch buffers
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fh = lane >> 4;
+
+  // XCD-aware bijective remap (as conv_igemm.hip): an XCD gets a contiguous run of tiles, n-tile fastest
+  int tile_m, tile_n;
+  {
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tile_n = t % p.tilesN;
+    tile_m = t / p.tilesN;
+  }
+  const int CB = p.W / TC;
+  const int rt = tile_m / CB, cb = tile_m - rt * CB;
+  const int total_rows = p.n_img * p.H;
+  const int g0 = rt * TR;
+  auto padrow = [&](int g) {
+    const int n = g / p.H;
+    return n * p.Hp + (g - n * p.H) + 1;
+  };
+  const int g_last = min(g0 + TR - 1, total_rows - 1);
+  const int pr_first = padrow(g0) - 1;
+  const int n_lin = (padrow(g_last) + 1 - pr_first + 1) * PW;      // patch pixels (rows of 128 B) actually needed
+  const int n_instr = (n_lin + 7) >> 3;
+
+  const int kchunks = p.Cin >> 6;
+  const unsigned cin_b = (unsigned)p.Cin * 2;
+
+  // ---- per-lane DMA source offsets (32-bit, relative to wave-uniform bases) ----
+  const char* const x_base = p.x + ((size_t)pr_first * p.Wp + (size_t)cb * TC) * cin_b;
+  unsigned a_off[PIW];                    // patch instruction q = wave + 4 j: LDS pixels 8q .. 8q+7
+#pragma unroll
+  for (int j = 0; j < PIW; ++j) {
+    const int lin0 = (wave + NW * j) * 8 + (lane >> 3);
+    const int i0 = lin0 / PW, c0 = lin0 - i0 * PW;                 // LDS position (keys the swizzle, before the clamp)
+    const int lin = lin0 < n_lin ? lin0 : n_lin - 1;               // pixels past the patch are never read; keep the address in bounds
+    const int i = lin / PW, jj = lin - i * PW;
+    a_off[j] = (unsigned)(i * p.Wp + jj) * cin_b + (unsigned)(((lane & 7) ^ ps_swz<TC>(i0, c0)) << 4);
+  }
+  unsigned b_off[WPW];
+  const unsigned w_row_bytes = 9u * cin_b;
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) {
+    const int row = (wave * WPW + j) * 8 + (lane >> 3);
+    int co = tile_n * BN + row;
+    co = co < p.Cout ? co : p.Cout - 1;
+    b_off[j] = (unsigned)co * w_row_bytes + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+  }
+  auto dma_patch_piece = [&](int kc, int j) {      // j-th instruction of this wave, chunk kc (wave-uniform predicate)
+    if (wave + NW * j < n_instr)
+      ps_glds(x_base + (size_t)kc * 128, a_off[j],
+              __builtin_amdgcn_readfirstlane(lds0 + (kc & 1) * PATCH_BYTES + (wave + NW * j) * 1024));
+  };
+  auto dma_weight_piece = [&](int kc, int tap, int slab, int j) {
+    ps_glds(p.wt + ((size_t)tap * p.Cin + (size_t)kc * 64) * 2, b_off[j],
+            __builtin_amdgcn_readfirstlane(lds0 + WOFF + slab * B_BYTES + (wave * WPW + j) * 1024));
+  };
+
+  // ---- fragment addressing ----
+  // weights: row = wn*128 + 16 j + fr, its swizzle (row >> 1) & 7 = (fr >> 1) & 7 for every j: one base per k-substep + immediates
+  const int w_rd0 = WOFF + (wn * WTN + fr) * 128 + ((fh ^ ((fr >> 1) & 7)) << 4);
+  // pixels: patch position of (pixel, tap (0,0)); tap (r, s) adds r PW + s pixels and (s + 4 r [2 r]) to the swizzle key
+  int x_lin128[TM], x_key16[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int ml = wm * WTM + i * 16 + fr;
+    const int tr = ml / TC, tc = ml - tr * TC;
+    const int g = min(g0 + tr, total_rows - 1);
+    const int R0 = padrow(g) - pr_first - 1;
+    x_lin128[i] = (R0 * PW + tc) * 128 + (fh << 4);
+    x_key16[i] = (tc + (TC == 14 ? 2 : 4) * R0) << 4;
+  }
+
+  vnqa_f32x4 acc[TM][TN];          // zeroed here, long before the first MFMA reads them as C (no wait states needed there)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = vnqa_f32x4{0.f, 0.f, 0.f, 0.f};
+  vnqa_f32x4 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
+
+  // ---- prologue: the whole patch of chunk 0, weights of K-steps 0 and 1 ----
+  asm volatile("s_nop 4" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < PIW; ++j) dma_patch_piece(0, j);
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) dma_weight_piece(0, 0, 0, j);
+#pragma unroll
+  for (int j = 0; j < WPW; ++j) dma_weight_piece(0, 1, 1, j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // x fragment address of pixel fragment i for the tap whose (pixel offset, swizzle key offset) are compile-time constants
+  auto x_addr = [&](int i, int pbuf_off, int tap) {
+    const int r = tap / 3, s = tap - 3 * r;
+    const int key = ((x_key16[i] + ((s + (TC == 14 ? 2 : 4) * r) << 4)) & 0x60);
+    return (x_lin128[i] ^ key) + pbuf_off + (r * PW + s) * 128;      // (the XOR only touches the chunk bits of the pixel's 128 bytes)
+  };
+  // first fragments: K-step 0, substep 0
+#pragma unroll
+  for (int i = 0; i < TM; ++i) xf0[i] = *(const vnqa_f32x4*)(smem + x_addr(i, 0, 0));
+#pragma unroll
+  for (int j = 0; j < TN; ++j) wf0[j] = *(const vnqa_f32x4*)(smem + w_rd0 + j * 2048);
+
+  int slab = 0;                                  // slab of the current K-step's weights = kt & 1
+  for (int kc = 0; kc < kchunks; ++kc) {
+    const int pbuf = (kc & 1) * PATCH_BYTES;
+    const bool more_chunks = kc + 1 < kchunks;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // position of the K-steps to come
+      const int tap1 = tap == 8 ? 0 : tap + 1;                          // K-step kt + 1
+      const int tap2 = tap >= 7 ? tap - 7 : tap + 2;                    // K-step kt + 2
+      const bool has1 = tap < 8 || more_chunks;
+      const int kc1 = tap == 8 ? kc + 1 : kc;
+      const int kc2 = tap >= 7 ? kc + 1 : kc;
+      const bool do2 = kc2 < kchunks;
+      const int pbuf1 = (kc1 & 1) * PATCH_BYTES;
+      // ---- phase 0: substep 0 MFMAs; behind them the 15 fragment reads of substep 1 ----
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 4 * h; j < 4 * h + 4; ++j) ps_mfma<false>(acc[i][j], wf0[j], xf0[i]);
+          const int slot = 2 * i + h;
+          if (h == 0) xf1[i] = *(const vnqa_f32x4*)(smem + (x_addr(i, pbuf, tap) ^ 64));
+          else wf1[i] = *(const vnqa_f32x4*)(smem + (w_rd0 ^ 64) + slab * B_BYTES + i * 2048);
+          if (slot == 13) wf1[7] = *(const vnqa_f32x4*)(smem + (w_rd0 ^ 64) + slab * B_BYTES + 7 * 2048);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // weights of K-step kt+1 and any patch piece issued a K-step ago have landed
+      __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): every fragment of this K-step is in registers
+      __builtin_amdgcn_s_barrier();                        // slab (kt & 1) is free; slab ((kt+1) & 1) / the next patch are visible
+      // ---- phase 1: substep 1 MFMAs; behind them the weight DMA of K-step kt+2, patch pieces of the next chunk, and the
+      //      fragment reads of K-step kt+1 / substep 0 ----
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 4 * h; j < 4 * h + 4; ++j) ps_mfma<false>(acc[i][j], wf1[j], xf1[i]);
+          const int slot = 2 * i + h;
+          if (h == 0) {
+            if (do2) dma_weight_piece(kc2, tap2, slab, i);              // 7 of the 8 weight pieces behind the even slots
+            if (has1) wf0[i] = *(const vnqa_f32x4*)(smem + w_rd0 + (slab ^ 1) * B_BYTES + i * 2048);
+          } else {
+            if (slot == 13 && do2) dma_weight_piece(kc2, tap2, slab, 7);
+            // patch pieces of chunk kc+1: two per tap during taps 0..5
+            if (more_chunks && tap < 6 && (slot == 1 || slot == 3)) dma_patch_piece(kc + 1, 2 * tap + (slot >> 1));
+            if (has1) xf0[i] = *(const vnqa_f32x4*)(smem + x_addr(i, pbuf1, tap1));
+            if (slot == 13 && has1) wf0[7] = *(const vnqa_f32x4*)(smem + w_rd0 + (slab ^ 1) * B_BYTES + 7 * 2048);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      slab ^= 1;
+    }
+  }
+  // wait states between the last MFMAs and the first read of an accumulator (8-pass XDL: 12+), then free the LDS
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+a"(acc[i][j]));
+  asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+a"(acc[i][j]));
+  __builtin_amdgcn_s_barrier();      // every wave is done reading fragments: the LDS becomes the epilogue tile
+
+  // ---------------- epilogue ----------------
+  // acc[i][j][e]: pixel = wm*112 + i*16 + fr ; cout = wn*128 + j*16 + 4*fh + e
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = wn * WTN + j * 16 + 4 * fh;
+    const int co = tile_n * BN + col;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b4[e] = (co + e < p.Cout) ? p.bias[co + e] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int prow = wm * WTM + i * 16 + fr;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = acc[i][j][e] + b4[e];
+        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+      }
+      uint2 pk;
+      pk.x = pack2_h16(v[0], v[1]);
+      pk.y = pack2_h16(v[2], v[3]);
+      *(uint2*)(smem + prow * CROW + col * 2) = pk;
+    }
+  }
+  __syncthreads();
+
+  constexpr int CH = BN * 2 / 16;       // 16-byte chunks per tile row
+  const bool has_post = (p.post_scale != nullptr);
+  const int rows_out = p.pool ? BM / 4 : BM;
+  const int OC = p.pool ? TC / 2 : TC;  // output columns per tile row
+  for (int idx = threadIdx.x; idx < rows_out * CH; idx += NT) {
+    const int orow = idx / CH, c = idx - orow * CH;
+    const int co0 = tile_n * BN + c * 8;
+    const int orr = orow / OC, occ = orow - orr * OC;
+    const int g = g0 + (p.pool ? 2 * orr : orr);
+    if (g >= total_rows || co0 >= p.Cout) continue;
+    float v[8];
+    if (p.pool) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = -INFINITY;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int ml = (2 * orr + (d >> 1)) * TC + 2 * occ + (d & 1);
+        const uint4 u = *(const uint4*)(smem + ml * CROW + c * 16);
+        const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] = fmaxf(v[2 * e], h16_lo(w4[e]));
+          v[2 * e + 1] = fmaxf(v[2 * e + 1], h16_hi(w4[e]));
+        }
+      }
+    } else {
+      const uint4 u = *(const uint4*)(smem + orow * CROW + c * 16);
+      const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = h16_lo(w4[e]);
+        v[2 * e + 1] = h16_hi(w4[e]);
+      }
+    }
+    if (has_post) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
+    }
+    const int n = g / p.H;
+    const int y = g - n * p.H;
+    const int yo = p.pool ? (y >> 1) : y;
+    const int xo = (p.pool ? (cb * TC) >> 1 : cb * TC) + occ;
+    vnqa_bf16* dst = (vnqa_bf16*)(p.y) + (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+    uint4 o;
+    o.x = pack2_h16(v[0], v[1]);
+    o.y = pack2_h16(v[2], v[3]);
+    o.z = pack2_h16(v[4], v[5]);
+    o.w = pack2_h16(v[6], v[7]);
+    *(uint4*)dst = o;
+  }
+}
+
+template <int TC, int TAG>
+int launch_ps(const ConvArgs& a, hipStream_t stream) {
+  using namespace ps;
+  constexpr int TR = BM / TC;
+  ConvArgs p = a;
+  const int rows = p.n_img * p.H;
+  const int tilesM = ((rows + TR - 1) / TR) * (p.W / TC);
+  p.tilesN = (p.Cout + BN - 1) / BN;
+  auto kern = conv_ps_kernel<TC, TAG>;
+  static std::atomic<bool> attr_set{false};   // idempotent attribute call: a race only repeats it
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) {
+      vnqa_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", LDS_BYTES, hipGetErrorString(e));
+      return VNQA_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tilesM * p.tilesN), dim3(NT), LDS_BYTES, stream, p);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+}  // namespace
+
+int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
+  using namespace ps;
+  if (a.taps != 9 || a.D != 0 || a.x_halo != 1 || a.wt_tiled || a.partial != nullptr || a.Cin % 64 != 0 || a.Cin < 64 ||
+      a.border_sub != nullptr || a.group_tiles != 0 || a.ring_h != 0 || a.epi != VNQA_EPI_NONE || a.zero_halo) {
+    vnqa_set_error("conv patch-stationary tile: needs a plain bf16 3x3 2-D conv, x_halo 1, c_in %% 64 == 0, K-major weights");
+    return VNQA_ERR_UNSUPPORTED;
+  }
+  const int tc = a.W % 28 == 0 ? 28 : (a.W % 14 == 0 ? 14 : 0);
+  if (tc == 0) {
+    vnqa_set_error("conv patch-stationary tile: width %d is not a multiple of 14", a.W);
+    return VNQA_ERR_UNSUPPORTED;
+  }
+  const int tr = BM / tc;
+  // patch rows needed at worst: tile rows + 2 halo rows + 2 per image boundary the tile can straddle
+  const int max_cross = (tr - 1 + a.H - 1) / a.H;
+  if ((tr + 2 + 2 * max_cross) * (tc + 2) > PATCH_ROWS || (a.pool && (a.H % 2 != 0 || a.W % 2 != 0))) {
+    vnqa_set_error("conv patch-stationary tile: %dx%d images do not fit the %d-pixel LDS patch", a.H, a.W, PATCH_ROWS);
+    return VNQA_ERR_UNSUPPORTED;
+  }
+  if ((size_t)(a.Hp + 2) * a.Wp * a.Cin * 2 * 4 >= (1ull << 32) || (size_t)a.Cout * 9 * a.Cin * 2 >= (1ull << 32)) {
+    vnqa_set_error("conv patch-stationary tile: tensor too large for its 32-bit DMA offsets");
+    return VNQA_ERR_UNSUPPORTED;
+  }
+  if (tc == 28) return tag ? launch_ps<28, 1>(a, st) : launch_ps<28, 0>(a, st);
+  return tag ? launch_ps<14, 1>(a, st) : launch_ps<14, 0>(a, st);
+}

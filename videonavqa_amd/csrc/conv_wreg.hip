@@ -158,9 +158,15 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
     tile_origin(t, n, y0, x0);
     return p.x + (((size_t)n * p.Hp + y0) * p.Wp + x0) * PIXB;
   };
+#ifndef VNQA_WREG_DMA_REPEAT      // timing-only experiment: every DMA instruction issued this many times (cost of one issue)
+#define VNQA_WREG_DMA_REPEAT 1
+#endif
   auto issue_dma = [&](const char* src0, int slot, int k) {
-    if (wave + 4 * k < NI)      // wave-uniform
-      glds16_asm(src0, dma_off[k], __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + (wave + 4 * k) * 1024));
+    if (wave + 4 * k < NI) {    // wave-uniform
+#pragma unroll
+      for (int rep = 0; rep < VNQA_WREG_DMA_REPEAT; ++rep)
+        glds16_asm(src0, dma_off[k], __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + (wave + 4 * k) * 1024));
+    }
   };
 
   // per-lane fragment bases: pixel column fr + s, k-chunk 4 ks + fh (swizzled); the row offset is an immediate

@@ -81,7 +81,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     flags = 0
     if out is None:
-        if y_halo == 1 and c_out % 8 == 0 and tile not in (11, 12):
+        if y_halo == 1 and c_out % 8 == 0 and tile not in (11, 12, 20, 21):
             # fresh output: the kernel zeroes the halo ring itself (VNQA_CONV_ZERO_HALO), no fill / halo launch
             out = torch.empty((N, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
             flags = L.CONV_ZERO_HALO
