@@ -184,7 +184,8 @@ def test_grad_sinks_accumulate_over_two_backward_passes():
     for a, b in zip(g_ref, g_dir):
         scale = float(a.abs().max())
         assert scale > 0
-        # (torch's scatter / index_put backward use float atomics: last-bit noise between two runs)
-        assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+        # (two separately built runs: float atomics in torch's scatter / index_put backward and split-K slab orders give
+        # noise up to ~1e-3 of the largest gradient; an overwrite instead of an accumulation would be O(1) off)
+        assert float((a - b).abs().max()) <= 5e-3 * scale, float((a - b).abs().max()) / scale
     # and the second pass really added something
     assert float((g_dir[1] - g_dir[0]).abs().max()) > 1e-6 * float(g_dir[0].abs().max())

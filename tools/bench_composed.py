@@ -25,7 +25,7 @@ def timed(fn, it=5):
     return e0.elapsed_time(e1) / it
 
 for rep in range(2):
-    for tile, tiled in ((6, True), (6, False), (1, False), (13, False)):
+    for tile, tiled in ((6, True), (21, False), (19, True)):
         wt = K.pack_conv_weight_tiled(w, dt, tile, c_out_pad=Co, c_in_pad=Ci) if tiled else K.pack_conv_weight(w, dt, c_out_pad=Co, c_in_pad=Ci)
         for sub in (ring, None):
             ms = timed(lambda: K.conv2d_igemm(x, wt, bias=b, relu=True, pool2=True, x_halo=2, y_halo=1, out=out, tile=tile, border_sub=sub))

@@ -6,7 +6,7 @@ N=$1; SRC=$2; shift 2
 D=videonavqa_amd
 mkdir -p /tmp/build/$N
 PF=""
-if [ "$SRC" = "conv_wreg.hip" ]; then PF="-mllvm -pragma-unroll-threshold=4000000 -Werror=pass-failed"; fi
+if [ "$SRC" = "conv_wreg.hip" ] || [ "$SRC" = "conv_ps.hip" ]; then PF="-mllvm -pragma-unroll-threshold=4000000 -Werror=pass-failed"; fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -I include $PF "$@" -c $D/csrc/$SRC -o /tmp/build/$N/$SRC.o
 OBJS=$(ls $D/lib/*.o | grep -v "/$SRC.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/lib/libvnqa_$N.so /tmp/build/$N/$SRC.o $OBJS

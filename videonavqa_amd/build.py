@@ -21,10 +21,11 @@ FLAGS = (["-DVNQA_DIAG_SKIP_DMA"] if os.environ.get("VNQA_DIAG") else []) + ["--
          "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
 
 
-# per-source extra flags.  conv_wreg.hip: its tile loop is ONE fully unrolled instruction stream (hand-placed MFMA / LDS read /
+# per-source extra flags.  conv_wreg.hip / conv_ps.hip: their main loops are ONE fully unrolled instruction stream (hand-placed MFMA / LDS read /
 # DMA / epilogue interleave); before constant folding the body exceeds LLVM's default pragma-unroll budget, and a loop
 # left rolled would index register arrays at run time (scratch): make that a build error, never a slow kernel.
-PER_FILE_FLAGS = {"conv_wreg.hip": ["-mllvm", "-pragma-unroll-threshold=4000000", "-Werror=pass-failed"]}
+_UNROLL_ALL = ["-mllvm", "-pragma-unroll-threshold=4000000", "-Werror=pass-failed"]
+PER_FILE_FLAGS = {"conv_wreg.hip": _UNROLL_ALL, "conv_ps.hip": _UNROLL_ALL}
 
 
 def sources():

@@ -28,14 +28,12 @@ namespace {
 namespace ps {
 constexpr int BM = 224, BN = 256, NW = 4, NT = 256;
 constexpr int WTM = 112, WTN = 128, TM = 7, TN = 8;
-constexpr int PATCH_ROWS = 360, PATCH_BYTES = PATCH_ROWS * 128, B_BYTES = BN * 128;
-constexpr int PATCH_INSTR = PATCH_ROWS / 8;                 // 45 wave-level DMA instructions cover a patch
-constexpr int PIW = (PATCH_INSTR + NW - 1) / NW;            // <= 12 of them per wave
+constexpr int B_BYTES = BN * 128;
+// patch pixels (rows of 128 B) an LDS patch buffer holds: 3x3 — up to 360 (tiles may straddle images); 5x5 — (TR + 4) (TC + 4)
+// <= 384 (tiles never straddle images: h %% TR == 0 is required), which with two 32 KiB weight slabs is exactly 160 KiB
+constexpr int patch_rows(int halo) { return halo == 1 ? 360 : 384; }
 constexpr int WPW = (BN / 8) / NW;                          // 8 weight DMA instructions per wave and K-step
-constexpr int LDS_BYTES = 2 * PATCH_BYTES + 2 * B_BYTES;    // 157696
 constexpr int CROW = BN * 2 + 16;
-static_assert(BM * CROW <= LDS_BYTES, "epilogue tile must fit");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
 }  // namespace ps
 
 #ifdef VNQA_H16_IS_F16
@@ -58,12 +56,18 @@ __device__ __forceinline__ void ps_glds(const char* sbase, unsigned voff, unsign
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
 
-template <int TC> __device__ __forceinline__ int ps_swz(int row, int col) { return TC == 14 ? ((col + 2 * row) & 6) : ((col + 4 * row) & 6); }
+// row multiplier of the patch swizzle key (col + RM row) & 6: exhaustive search per geometry (tools/lds_swizzle_check.py)
+template <int TC, int HALO> constexpr int ps_rm() { return TC == 14 ? (HALO == 1 ? 2 : 6) : 4; }
+template <int TC, int HALO> __device__ __forceinline__ int ps_swz(int row, int col) { return (col + ps_rm<TC, HALO>() * row) & 6; }
 
-template <int TC, int TAG>
+template <int TC, int HALO, int TAG>
 __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   using namespace ps;
-  constexpr int TR = BM / TC, PW = TC + 2;
+  constexpr int TR = BM / TC, PW = TC + 2 * HALO, KW = 2 * HALO + 1, NTAPS = KW * KW;
+  constexpr int PATCH_ROWS = patch_rows(HALO), PATCH_BYTES = PATCH_ROWS * 128;
+  constexpr int PATCH_INSTR = PATCH_ROWS / 8, PIW = (PATCH_INSTR + NW - 1) / NW;      // patch DMA instructions: all / per wave
+  constexpr int RM = ps_rm<TC, HALO>();
+  static_assert(BM * CROW <= 2 * PATCH_BYTES + 2 * B_BYTES && 2 * PATCH_BYTES + 2 * B_BYTES <= 160 * 1024, "LDS budget");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   constexpr int WOFF = 2 * PATCH_BYTES;        // weight slabs behind the two patch buffers
@@ -89,11 +93,11 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   const int g0 = rt * TR;
   auto padrow = [&](int g) {
     const int n = g / p.H;
-    return n * p.Hp + (g - n * p.H) + 1;
+    return n * p.Hp + (g - n * p.H) + HALO;
   };
   const int g_last = min(g0 + TR - 1, total_rows - 1);
-  const int pr_first = padrow(g0) - 1;
-  const int n_lin = (padrow(g_last) + 1 - pr_first + 1) * PW;      // patch pixels (rows of 128 B) actually needed
+  const int pr_first = padrow(g0) - HALO;
+  const int n_lin = (padrow(g_last) + HALO - pr_first + 1) * PW;   // patch pixels (rows of 128 B) actually needed
   const int n_instr = (n_lin + 7) >> 3;
 
   const int kchunks = p.Cin >> 6;
@@ -108,10 +112,10 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     const int i0 = lin0 / PW, c0 = lin0 - i0 * PW;                 // LDS position (keys the swizzle, before the clamp)
     const int lin = lin0 < n_lin ? lin0 : n_lin - 1;               // pixels past the patch are never read; keep the address in bounds
     const int i = lin / PW, jj = lin - i * PW;
-    a_off[j] = (unsigned)(i * p.Wp + jj) * cin_b + (unsigned)(((lane & 7) ^ ps_swz<TC>(i0, c0)) << 4);
+    a_off[j] = (unsigned)(i * p.Wp + jj) * cin_b + (unsigned)(((lane & 7) ^ ps_swz<TC, HALO>(i0, c0)) << 4);
   }
   unsigned b_off[WPW];
-  const unsigned w_row_bytes = 9u * cin_b;
+  const unsigned w_row_bytes = (unsigned)NTAPS * cin_b;
 #pragma unroll
   for (int j = 0; j < WPW; ++j) {
     const int row = (wave * WPW + j) * 8 + (lane >> 3);
@@ -139,9 +143,9 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     const int ml = wm * WTM + i * 16 + fr;
     const int tr = ml / TC, tc = ml - tr * TC;
     const int g = min(g0 + tr, total_rows - 1);
-    const int R0 = padrow(g) - pr_first - 1;
+    const int R0 = padrow(g) - pr_first - HALO;
     x_lin128[i] = (R0 * PW + tc) * 128 + (fh << 4);
-    x_key16[i] = (tc + (TC == 14 ? 2 : 4) * R0) << 4;
+    x_key16[i] = (tc + RM * R0) << 4;
   }
 
   vnqa_f32x4 acc[TM][TN];          // zeroed here, long before the first MFMA reads them as C (no wait states needed there)
@@ -164,8 +168,8 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
 
   // x fragment address of pixel fragment i for the tap whose (pixel offset, swizzle key offset) are compile-time constants
   auto x_addr = [&](int i, int pbuf_off, int tap) {
-    const int r = tap / 3, s = tap - 3 * r;
-    const int key = ((x_key16[i] + ((s + (TC == 14 ? 2 : 4) * r) << 4)) & 0x60);
+    const int r = tap / KW, s = tap - KW * r;
+    const int key = ((x_key16[i] + ((s + RM * r) << 4)) & 0x60);
     return (x_lin128[i] ^ key) + pbuf_off + (r * PW + s) * 128;      // (the XOR only touches the chunk bits of the pixel's 128 bytes)
   };
   // first fragments: K-step 0, substep 0
@@ -175,57 +179,53 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   for (int j = 0; j < TN; ++j) wf0[j] = *(const vnqa_f32x4*)(smem + w_rd0 + j * 2048);
 
   int slab = 0;                                  // slab of the current K-step's weights = kt & 1
+  constexpr int PPT = (PIW + NTAPS - 4) / (NTAPS - 3);     // patch pieces of the next chunk issued per tap (taps 0 .. NTAPS-4)
   for (int kc = 0; kc < kchunks; ++kc) {
     const int pbuf = (kc & 1) * PATCH_BYTES;
     const bool more_chunks = kc + 1 < kchunks;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < NTAPS; ++tap) {
       // position of the K-steps to come
-      const int tap1 = tap == 8 ? 0 : tap + 1;                          // K-step kt + 1
-      const int tap2 = tap >= 7 ? tap - 7 : tap + 2;                    // K-step kt + 2
-      const bool has1 = tap < 8 || more_chunks;
-      const int kc1 = tap == 8 ? kc + 1 : kc;
-      const int kc2 = tap >= 7 ? kc + 1 : kc;
+      const int tap1 = tap == NTAPS - 1 ? 0 : tap + 1;                          // K-step kt + 1
+      const int tap2 = tap >= NTAPS - 2 ? tap - (NTAPS - 2) : tap + 2;          // K-step kt + 2
+      const bool has1 = tap < NTAPS - 1 || more_chunks;
+      const int kc1 = tap == NTAPS - 1 ? kc + 1 : kc;
+      const int kc2 = tap >= NTAPS - 2 ? kc + 1 : kc;
       const bool do2 = kc2 < kchunks;
       const int pbuf1 = (kc1 & 1) * PATCH_BYTES;
-      // ---- phase 0: substep 0 MFMAs; behind them the 15 fragment reads of substep 1 ----
+      // ---- phase 0: substep 0 MFMAs; behind the first eight groups the 15 fragment reads of substep 1 (the last six groups
+      //      cover their latency) ----
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int slot = 0; slot < 14; ++slot) {
+        const int i = slot >> 1, h = slot & 1;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 4 * h; j < 4 * h + 4; ++j) ps_mfma<false>(acc[i][j], wf0[j], xf0[i]);
-          const int slot = 2 * i + h;
-          if (h == 0) xf1[i] = *(const vnqa_f32x4*)(smem + (x_addr(i, pbuf, tap) ^ 64));
-          else wf1[i] = *(const vnqa_f32x4*)(smem + (w_rd0 ^ 64) + slab * B_BYTES + i * 2048);
-          if (slot == 13) wf1[7] = *(const vnqa_f32x4*)(smem + (w_rd0 ^ 64) + slab * B_BYTES + 7 * 2048);
-        }
+        for (int j = 4 * h; j < 4 * h + 4; ++j) ps_mfma<false>(acc[i][j], wf0[j], xf0[i]);
+        if (slot < TM) xf1[slot] = *(const vnqa_f32x4*)(smem + (x_addr(slot, pbuf, tap) ^ 64));
+        if (slot < TN) wf1[slot] = *(const vnqa_f32x4*)(smem + (w_rd0 ^ 64) + slab * B_BYTES + slot * 2048);
       }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // weights of K-step kt+1 and any patch piece issued a K-step ago have landed
       __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): every fragment of this K-step is in registers
       __builtin_amdgcn_s_barrier();                        // slab (kt & 1) is free; slab ((kt+1) & 1) / the next patch are visible
-      // ---- phase 1: substep 1 MFMAs; behind them the weight DMA of K-step kt+2, patch pieces of the next chunk, and the
-      //      fragment reads of K-step kt+1 / substep 0 ----
+      // ---- phase 1: substep 1 MFMAs; behind them the 15 fragment reads of K-step kt+1 / substep 0 (groups 0..7), the 8
+      //      weight DMA instructions of K-step kt+2 and the patch pieces of the next chunk ----
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int slot = 0; slot < 14; ++slot) {
+        const int i = slot >> 1, h = slot & 1;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          __builtin_amdgcn_sched_barrier(0);
+        for (int j = 4 * h; j < 4 * h + 4; ++j) ps_mfma<false>(acc[i][j], wf1[j], xf1[i]);
+        if (has1 && slot < TM) xf0[slot] = *(const vnqa_f32x4*)(smem + x_addr(slot, pbuf1, tap1));
+        if (has1 && slot < TN) wf0[slot] = *(const vnqa_f32x4*)(smem + w_rd0 + (slab ^ 1) * B_BYTES + slot * 2048);
+        // weight pieces behind groups 0,1,3,5,7,8,10,12; patch pieces behind groups 9 and 11
+        constexpr int wslot[8] = {0, 1, 3, 5, 7, 8, 10, 12};
 #pragma unroll
-          for (int j = 4 * h; j < 4 * h + 4; ++j) ps_mfma<false>(acc[i][j], wf1[j], xf1[i]);
-          const int slot = 2 * i + h;
-          if (h == 0) {
-            if (do2) dma_weight_piece(kc2, tap2, slab, i);              // 7 of the 8 weight pieces behind the even slots
-            if (has1) wf0[i] = *(const vnqa_f32x4*)(smem + w_rd0 + (slab ^ 1) * B_BYTES + i * 2048);
-          } else {
-            if (slot == 13 && do2) dma_weight_piece(kc2, tap2, slab, 7);
-            // patch pieces of chunk kc+1: two per tap during taps 0..5
-            if (more_chunks && tap < 6 && (slot == 1 || slot == 3)) dma_patch_piece(kc + 1, 2 * tap + (slot >> 1));
-            if (has1) xf0[i] = *(const vnqa_f32x4*)(smem + x_addr(i, pbuf1, tap1));
-            if (slot == 13 && has1) wf0[7] = *(const vnqa_f32x4*)(smem + w_rd0 + (slab ^ 1) * B_BYTES + 7 * 2048);
-          }
+        for (int q = 0; q < 8; ++q)
+          if (slot == wslot[q] && do2) dma_weight_piece(kc2, tap2, slab, q);
+        if (more_chunks && tap < NTAPS - 3 && (slot == 9 || slot == 11)) {
+          const int pj = tap * PPT + (slot == 11 ? 1 : 0);
+          if ((slot == 9 || PPT > 1) && pj < PIW) dma_patch_piece(kc + 1, pj);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -246,6 +246,27 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
 
   // ---------------- epilogue ----------------
   // acc[i][j][e]: pixel = wm*112 + i*16 + fr ; cout = wn*128 + j*16 + 4*fh + e
+  // composed-conv border correction (vnqa_conv2d_igemm_fwd_ex): row of the correction tensor for each of this lane's pixels
+  // (-1: interior pixel or no correction); ring order: top row, bottom row, left column, right column
+  int ring_row[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    ring_row[i] = -1;
+    if (p.border_sub != nullptr) {
+      const int ml = wm * WTM + i * 16 + fr;
+      const int tr = ml / TC, tc = ml - tr * TC;
+      const int g = g0 + tr;
+      if (g < total_rows) {
+        const int n = g / p.H, y = g - n * p.H, x = cb * TC + tc;
+        int ring = -1;
+        if (y == 0) ring = x;
+        else if (y == p.H - 1) ring = p.W + x;
+        else if (x == 0) ring = 2 * p.W + (y - 1);
+        else if (x == p.W - 1) ring = 2 * p.W + (p.H - 2) + (y - 1);
+        if (ring >= 0) ring_row[i] = n * (2 * p.W + 2 * (p.H - 2)) + ring;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = wn * WTN + j * 16 + 4 * fh;
@@ -258,10 +279,15 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int prow = wm * WTM + i * 16 + fr;
+      float sub[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ring_row[i] >= 0 && co + 3 < p.Cout) {
+        const uint2 raw = *(const uint2*)((const char*)p.border_sub + ((size_t)ring_row[i] * p.Cout + co) * 2);
+        sub[0] = h16_lo(raw.x); sub[1] = h16_hi(raw.x); sub[2] = h16_lo(raw.y); sub[3] = h16_hi(raw.y);
+      }
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = acc[i][j][e] + b4[e];
+        v[e] = acc[i][j][e] + b4[e] - sub[e];
         if (p.relu) v[e] = fmaxf(v[e], 0.f);
       }
       uint2 pk;
@@ -324,15 +350,16 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   }
 }
 
-template <int TC, int TAG>
+template <int TC, int HALO, int TAG>
 int launch_ps(const ConvArgs& a, hipStream_t stream) {
   using namespace ps;
   constexpr int TR = BM / TC;
+  constexpr int LDS_BYTES = 2 * patch_rows(HALO) * 128 + 2 * B_BYTES;
   ConvArgs p = a;
   const int rows = p.n_img * p.H;
   const int tilesM = ((rows + TR - 1) / TR) * (p.W / TC);
   p.tilesN = (p.Cout + BN - 1) / BN;
-  auto kern = conv_ps_kernel<TC, TAG>;
+  auto kern = conv_ps_kernel<TC, HALO, TAG>;
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: a race only repeats it
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -351,9 +378,11 @@ int launch_ps(const ConvArgs& a, hipStream_t stream) {
 
 int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
   using namespace ps;
-  if (a.taps != 9 || a.D != 0 || a.x_halo != 1 || a.wt_tiled || a.partial != nullptr || a.Cin % 64 != 0 || a.Cin < 64 ||
-      a.border_sub != nullptr || a.group_tiles != 0 || a.ring_h != 0 || a.epi != VNQA_EPI_NONE || a.zero_halo) {
-    vnqa_set_error("conv patch-stationary tile: needs a plain bf16 3x3 2-D conv, x_halo 1, c_in %% 64 == 0, K-major weights");
+  const int halo = a.taps == 25 ? 2 : 1;
+  if ((a.taps != 9 && a.taps != 25) || a.D != 0 || a.x_halo != halo || a.wt_tiled || a.partial != nullptr || a.Cin % 64 != 0 ||
+      a.Cin < 64 || a.group_tiles != 0 || a.ring_h != 0 || a.epi != VNQA_EPI_NONE || a.zero_halo ||
+      (a.border_sub != nullptr && a.Cout % 4 != 0)) {
+    vnqa_set_error("conv patch-stationary tile: needs a plain bf16 3x3 / 5x5 2-D conv, x_halo = 1 / 2, c_in %% 64 == 0, K-major weights");
     return VNQA_ERR_UNSUPPORTED;
   }
   const int tc = a.W % 28 == 0 ? 28 : (a.W % 14 == 0 ? 14 : 0);
@@ -362,16 +391,32 @@ int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
     return VNQA_ERR_UNSUPPORTED;
   }
   const int tr = BM / tc;
-  // patch rows needed at worst: tile rows + 2 halo rows + 2 per image boundary the tile can straddle
-  const int max_cross = (tr - 1 + a.H - 1) / a.H;
-  if ((tr + 2 + 2 * max_cross) * (tc + 2) > PATCH_ROWS || (a.pool && (a.H % 2 != 0 || a.W % 2 != 0))) {
-    vnqa_set_error("conv patch-stationary tile: %dx%d images do not fit the %d-pixel LDS patch", a.H, a.W, PATCH_ROWS);
+  if (halo == 2) {
+    // 5x5: the (tr + 4) x (tc + 4) patch fills the buffer exactly: tiles must not straddle images
+    if (a.H % tr != 0) {
+      vnqa_set_error("conv patch-stationary tile (5x5): height %d is not a multiple of the %d tile rows", a.H, tr);
+      return VNQA_ERR_UNSUPPORTED;
+    }
+  } else {
+    // patch rows needed at worst: tile rows + 2 halo rows + 2 per image boundary the tile can straddle
+    const int max_cross = (tr - 1 + a.H - 1) / a.H;
+    if ((tr + 2 + 2 * max_cross) * (tc + 2) > patch_rows(1)) {
+      vnqa_set_error("conv patch-stationary tile: %dx%d images do not fit the %d-pixel LDS patch", a.H, a.W, patch_rows(1));
+      return VNQA_ERR_UNSUPPORTED;
+    }
+  }
+  if (a.pool && (a.H % 2 != 0 || a.W % 2 != 0)) {
+    vnqa_set_error("conv patch-stationary tile: pool2 needs even h, w");
     return VNQA_ERR_UNSUPPORTED;
   }
-  if ((size_t)(a.Hp + 2) * a.Wp * a.Cin * 2 * 4 >= (1ull << 32) || (size_t)a.Cout * 9 * a.Cin * 2 >= (1ull << 32)) {
+  if ((size_t)(a.Hp + 4) * a.Wp * a.Cin * 2 * 4 >= (1ull << 32) || (size_t)a.Cout * a.taps * a.Cin * 2 >= (1ull << 32)) {
     vnqa_set_error("conv patch-stationary tile: tensor too large for its 32-bit DMA offsets");
     return VNQA_ERR_UNSUPPORTED;
   }
-  if (tc == 28) return tag ? launch_ps<28, 1>(a, st) : launch_ps<28, 0>(a, st);
-  return tag ? launch_ps<14, 1>(a, st) : launch_ps<14, 0>(a, st);
+  if (halo == 1) {
+    if (tc == 28) return tag ? launch_ps<28, 1, 1>(a, st) : launch_ps<28, 1, 0>(a, st);
+    return tag ? launch_ps<14, 1, 1>(a, st) : launch_ps<14, 1, 0>(a, st);
+  }
+  if (tc == 28) return tag ? launch_ps<28, 2, 1>(a, st) : launch_ps<28, 2, 0>(a, st);
+  return tag ? launch_ps<14, 2, 1>(a, st) : launch_ps<14, 2, 0>(a, st);
 }

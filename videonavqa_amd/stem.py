@@ -83,7 +83,7 @@ class FrozenStem(object):
         self.composed = None
         self.first = None
         self._bufs = {}
-        self.timing = None   # bench hook: list collecting (start, end) events around stem-tagged launches
+        self.timing = None   # bench hook: list collecting (start event, end event, FLOPs, kernel) of the C_out = 512 stem launches
         if vgg is not None:
             f = vgg.features
             dev = f["0"].weight.device
@@ -140,7 +140,8 @@ class FrozenStem(object):
                 tile = L.TILE_256x256_W16
         else:
             tile = L.TILE_128x64 if c_out_pad <= 64 else L.TILE_128x128
-        if tile is None or tile == L.TILE_256x256_W16 or os.environ.get("VNQA_STEM_TILED", "1") == "0":
+        if tile is None or tile in (L.TILE_256x256_W16, L.TILE_PS_224x256, L.TILE_STEM_PS_224x256) or \
+                os.environ.get("VNQA_STEM_TILED", "1") == "0":
             wt = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         else:   # frozen weights: pre-tiled once into the exact LDS images the igemm DMA consumes
             wt = K.pack_conv_weight_tiled(w, self.cdt, tile, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
@@ -152,7 +153,21 @@ class FrozenStem(object):
                 and os.environ.get("VNQA_STEM_WREG", "1") != "0":
             ly["wt_rows"] = wt if tile is None else K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad,
                                                                        c_in_pad=c_in_pad)
+        # wide 3x3 layers (conv21 .. conv32): patch-stationary kernel (csrc/conv_ps.hip, K-major weights) when the run-time
+        # geometry qualifies (_ps_ok); the implicit-GEMM tile above stays as the fallback
+        if bf16 and tile == L.TILE_STEM_256x256 and w.shape[2] == 3 and os.environ.get("VNQA_STEM_PS", "1") != "0":
+            ly["wt_ps"] = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         return ly
+
+    @staticmethod
+    def _ps_ok(h, w, pool):
+        """vnqa_conv_ps_dispatch's geometry conditions for a 3x3 layer on h x w maps (224-pixel tiles of 8 x 28 or 16 x 14)."""
+        tc = 28 if w % 28 == 0 else (14 if w % 14 == 0 else 0)
+        if tc == 0 or (pool and (h % 2 or w % 2)):
+            return False
+        tr = 224 // tc
+        max_cross = (tr - 1 + h - 1) // h
+        return (tr + 2 + 2 * max_cross) * (tc + 2) <= 360
 
     def _compose_pair(self, c1, c2, bn):
         """Two stacked linear convs with frozen weights as ONE conv.
@@ -229,7 +244,7 @@ class FrozenStem(object):
         ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
         out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
-        timed = self.timing is not None and cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256)
+        timed = self.timing is not None and cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256)
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -237,7 +252,8 @@ class FrozenStem(object):
                            tile=cp["tile"], border_sub=ring)
         if timed:
             ev1.record()
-            self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25))
+            self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25,
+                                "conv_ps_kernel" if cp["tile"] == L.TILE_STEM_PS_224x256 else "conv_igemm_kernel"))
         return y
 
     def _buf(self, key, shape):
@@ -258,7 +274,8 @@ class FrozenStem(object):
             out = self._buf(key, (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
             post = ly["post"]
             tile = ly["tile"]
-            timed = self.timing is not None and tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256)
+            timed = self.timing is not None and tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256)      # (C_out = 512 layers, whichever kernel serves them)
+            kname = "conv_igemm_kernel"
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
@@ -266,6 +283,11 @@ class FrozenStem(object):
                 x = K.conv2d_wreg(x, ly["wt_rows"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                   post_scale=post[0] if post else None, post_shift=post[1] if post else None,
                                   out=out, y_halo=yh)
+            elif "wt_ps" in ly and yh == 1 and self._ps_ok(h, w, ly["pool"]):
+                kname = "conv_ps_kernel"
+                x = K.conv2d_igemm(x, ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
+                                   post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+                                   out=out, tile=L.TILE_STEM_PS_224x256, y_halo=yh)
             elif tile is None:
                 # C_in = 64 layers (conv1_2, conv2_1): persistent direct conv with LDS-resident weights
                 x = K.conv2d_c64(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
@@ -276,7 +298,7 @@ class FrozenStem(object):
                                    out=out, tile=tile, y_halo=yh)
             if timed:
                 ev1.record()
-                self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9))
+                self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9, kname))
         return x
 
     # ---- fused fast path: clip -> packed native features ------------------------------------
