@@ -189,6 +189,20 @@ int vnqa_ring_assemble(const void* top, const void* bottom, const void* left, co
 int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
                         const float* post_scale, const float* post_shift, void* y, void* stream);
 
+/* Tail of the global-max-pooling models (models/film_global_pooling_pt_stem.py:228-238, models/time_multi_hop_pt_stem.py:240-250:
+ * relu(c1x1_tail) per frame -> zero-padded stack over frames -> max over frames -> out_linear) on the PACKED image list:
+ *   maps      [n_img][h+2][w+2][c_pad] relu'd tail maps (16-bit storage or f32, zero halo), images frame-major:
+ *             image of (frame t, sorted sample b) = frame_off[t] + b for b < frame_off[t+1] - frame_off[t]
+ *   pooled    fp32 [batch][tail*h*w] in the reference's NCHW-flattened order (= the column order of out_linear.weight)
+ *   argmax    int32, same shape: the image that supplied the maximum, -1 where every frame is <= 0 (no gradient either way)
+ * vnqa_frame_max_bwd writes the WHOLE gradient tensor d maps (zero halo / padding channels included):
+ *   d maps[img][y][x][c] = scale * d pooled[sample_of[img]][c*h*w + y*w + x] where argmax == img, else 0.
+ */
+int vnqa_frame_max_fwd(const void* maps, const int32_t* frame_off, float* pooled, int32_t* argmax, int32_t batch,
+                       int32_t n_frames, int32_t h, int32_t w, int32_t c_pad, int32_t tail, int32_t dtype, void* stream);
+int vnqa_frame_max_bwd(const float* dpooled, const int32_t* argmax, const int32_t* sample_of, void* dmaps, int32_t n_img,
+                       int32_t h, int32_t w, int32_t c_pad, int32_t tail, float scale, int32_t dtype, void* stream);
+
 /* Weights-stationary-in-REGISTERS persistent direct 3x3 conv (bf16 / the library's 16-bit format) for the short-K layers
  * of the VGG front (get_frcnn_feature_extractor features[2], [5], [7]; call sites eval/q_and_v_eval.py:106): 4 waves per
  * workgroup, one per SIMD, each keeping its slice of the weights in 288 of its SIMD's 512 registers for the whole

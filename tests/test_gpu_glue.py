@@ -159,3 +159,52 @@ def test_bn_running_update_matches_per_frame_ema():
         ev = 0.9 * ev + 0.1 * var[f, :C] * n / (n - 1)
     K.bn_running_update(mean, var, off, Fr, S, rm, rv, 0.1)
     assert _close(rm, em, 1e-6) and _close(rv, ev, 1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, LOW_DTYPE])
+@pytest.mark.parametrize("v_lens,T,tail,h,w", [([5, 5, 5], 5, 16, 4, 6), ([6, 4, 4, 1], 6, 32, 3, 5), ([3, 2], 7, 8, 14, 14)])
+def test_frame_max_tail_vs_dense_stack(dt, v_lens, T, tail, h, w):
+    """segmented max over frames from the packed image list (vnqa_frame_max_fwd / _bwd, csrc/pool_tail.hip) against the
+    reference's dense zero-padded [T, B, ...] stack + max(dim=0) (film_global_pooling_pt_stem.py:230-235) and its autograd"""
+    from videonavqa_amd import ops
+    from videonavqa_amd.models.common import FrameLayout
+    lay = FrameLayout(v_lens, T, "cuda")
+    B, c_pad = len(v_lens), 64
+    g = torch.Generator().manual_seed(sum(v_lens) + tail)
+    maps = torch.zeros(lay.n_img, h + 2, w + 2, c_pad)
+    vals = torch.relu(torch.randn(lay.n_img, h, w, tail, generator=g))
+    vals[:, 0, 0, :] = 0.0                                    # a position where every frame is zero: no gradient, argmax -1
+    vals[:, 1, 1, 0] = 0.7                                    # an exact tie between all frames: the FIRST frame wins
+    maps[:, 1:-1, 1:-1, :tail] = vals
+    maps = maps.cuda().to(dt).requires_grad_(True)
+    pooled, argmax = ops.frame_max(maps, lay, tail, 2.0)
+    # reference: dense stack, rows of absent (frame, sample) pairs stay zero
+    mref = maps.detach().float().requires_grad_(True)
+    dense = torch.zeros(lay.n_frames, B, h + 2, w + 2, c_pad, device="cuda")
+    dense = dense.index_put((lay.frame_of, lay.sample_of), mref)
+    ref = dense.max(dim=0)[0][:, 1:-1, 1:-1, :tail].permute(0, 3, 1, 2).reshape(B, -1)       # NCHW-flattened
+    assert pooled.shape == ref.shape and torch.equal(pooled, ref)
+    dp = torch.randn(pooled.shape, generator=g).cuda()
+    pooled.backward(dp)
+    ref.backward(dp)
+    assert maps.grad.shape == maps.shape
+    gref = 2.0 * mref.grad.to(dt).float()
+    got = maps.grad.float().clone()
+    # Where a sample's maximum is 0 every frame ties with the zero padding rows: torch routes the gradient to one of those
+    # zeros (the relu backward of the real model then zeroes it), this kernel routes none — compare where the maximum is
+    # positive, require zero elsewhere.  The forced 0.7 tie: the whole gradient goes to exactly one frame either way.
+    pos = (ref.detach().view(B, tail, h, w) > 0).permute(0, 2, 3, 1)[lay.sample_of]         # [n_img, h, w, tail]
+    gi, ri = got[:, 1:-1, 1:-1, :tail], gref[:, 1:-1, 1:-1, :tail]
+    assert float((gi * (~pos)).abs().max()) == 0
+    tie_got, tie_ref = gi[:, 1, 1, 0].clone(), ri[:, 1, 1, 0].clone()
+    gi[:, 1, 1, 0] = 0
+    ri[:, 1, 1, 0] = 0
+    assert _close(gi * pos, ri * pos, 1e-6 if dt == torch.float32 else 1e-2)
+    for b in range(B):
+        sel = lay.sample_of == b
+        assert abs(float(tie_got[sel].sum()) - float(tie_ref[sel].sum())) <= 1e-2 * abs(float(tie_ref[sel].sum())) + 1e-6
+        assert int((tie_got[sel] != 0).sum()) <= 1
+    assert float(maps.grad[:, 0].abs().max()) == 0 and float(maps.grad[..., tail:].abs().max()) == 0
+    am = argmax.view(B, tail, h, w)
+    assert int(am[:, :, 0, 0].max()) == -1                    # all-zero position
+    assert torch.equal(am[:, 0, 1, 1], lay.frame_off_i32[0] + torch.arange(B, device="cuda", dtype=torch.int32))   # tie -> frame 0

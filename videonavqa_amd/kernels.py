@@ -297,6 +297,28 @@ def conv2d_wreg(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post
     return out
 
 
+def frame_max_fwd(maps, frame_off_i32, batch, n_frames, tail):
+    """max over a sample's frames of the packed relu'd tail maps [n_img, h+2, w+2, c_pad] -> (pooled fp32 [batch, tail*h*w] in
+    NCHW-flattened order, argmax int32) — vnqa_frame_max_fwd."""
+    n_img, hp, wp, c_pad = maps.shape
+    h, w = hp - 2, wp - 2
+    pooled = torch.empty((batch, tail * h * w), dtype=torch.float32, device=maps.device)
+    argmax = torch.empty((batch, tail * h * w), dtype=torch.int32, device=maps.device)
+    L.check(L.lib().vnqa_frame_max_fwd(L.ptr(maps.contiguous()), L.ptr(frame_off_i32), L.ptr(pooled), L.ptr(argmax), batch,
+                                       n_frames, h, w, c_pad, tail, L.dtype_id(maps.dtype), L.stream()), "vnqa_frame_max_fwd")
+    return pooled, argmax
+
+
+def frame_max_bwd(dpooled, argmax, sample_of_i32, shape, dtype, tail, scale=1.0):
+    """gradient of frame_max_fwd w.r.t. the packed maps: the whole padded NHWC tensor `shape` = [n_img, h+2, w+2, c_pad]."""
+    n_img, hp, wp, c_pad = shape
+    dmaps = torch.empty(shape, dtype=dtype, device=dpooled.device)
+    L.check(L.lib().vnqa_frame_max_bwd(L.ptr(dpooled.contiguous()), L.ptr(argmax), L.ptr(sample_of_i32), L.ptr(dmaps), n_img,
+                                       hp - 2, wp - 2, c_pad, tail, float(scale), L.dtype_id(dtype), L.stream()),
+            "vnqa_frame_max_bwd")
+    return dmaps
+
+
 def clip_to_nhwc4(clip, img_of, n_img, out=None):
     """clip fp32 [B,3,H,W,T] (frames last) -> image list bf16 [n_img,H+4,W+4,4] (halo 2 and channel 3 zero)."""
     B, C, H, W, T = clip.shape

@@ -13,6 +13,8 @@ per-frame loop necessary is re-expressed on the packed list:
                                        n_frames times), outputs sampled at each repeat's end.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -508,8 +510,13 @@ class FiLMTrunkBase(nn.Module):
         (film_global_pooling_pt_stem.py:228-238)."""
         gs = getattr(self, "_trunk_grad_scale", 1.0)      # fp16 storage: the tail conv and the trunk see scaled gradients
         t = ops.conv(x, self.c1x1_tail.weight, self.c1x1_tail.bias, relu=True, grad_scale=gs)     # [n_img,hp,wp,tail_pad]
-        n_img, hp, wp, tp = t.shape
         tail = self.c1x1_tail.out_channels
+        if t.is_cuda and os.environ.get("VNQA_GP_TAIL_TORCH", "0") != "1":
+            # HIP tail: segmented max over each sample's frames straight from the packed image list, written in the reference's
+            # NCHW-flattened order, then out_linear on the fp32 GEMM (no dense [T, B, ...] stack, no weight re-layout)
+            pooled, self._gp_argmax = ops.frame_max(t, lay, tail, gs)
+            return ops.linear(pooled, self.out_linear.weight, self.out_linear.bias)
+        n_img, hp, wp, tp = t.shape
         dense = torch.zeros(lay.n_frames, lay.B, hp, wp, tp, device=t.device, dtype=torch.float32)
         dense = dense.index_put((lay.frame_of, lay.sample_of), ops.scale_grad(t.float(), gs))
         pooled = dense.max(dim=0)[0].reshape(lay.B, -1)

@@ -862,6 +862,30 @@ def linear(x, w, b, relu=False, rows=None):
     return LinearFn.apply(x, w, b, relu, rows)
 
 
+class FrameMaxFn(torch.autograd.Function):
+    """max over a sample's frames of the relu'd tail maps, straight from the packed image list (the reference's zero-padded
+    [T, B, ...] stack + max(dim=0), film_global_pooling_pt_stem.py:230-235): (pooled, argmax) = vnqa_frame_max_fwd; the backward
+    routes d pooled to the arg-max image (x `grad_scale`, the fp16 loss scale of the maps' gradient)."""
+
+    @staticmethod
+    def forward(ctx, maps, lay, tail, grad_scale):
+        pooled, argmax = K.frame_max_fwd(maps, lay.frame_off_i32, lay.B, lay.n_frames, tail)
+        ctx.save_for_backward(argmax)
+        ctx.lay, ctx.shape, ctx.dtype, ctx.tail, ctx.gs = lay, tuple(maps.shape), maps.dtype, tail, float(grad_scale)
+        ctx.mark_non_differentiable(argmax)
+        return pooled, argmax
+
+    @staticmethod
+    def backward(ctx, dpooled, _dargmax):
+        (argmax,) = ctx.saved_tensors
+        dmaps = K.frame_max_bwd(dpooled.float(), argmax, ctx.lay.sample_of_i32, ctx.shape, ctx.dtype, ctx.tail, ctx.gs)
+        return dmaps, None, None, None
+
+
+def frame_max(maps, lay, tail, grad_scale=1.0):
+    return FrameMaxFn.apply(maps, lay, tail, grad_scale)
+
+
 class EmbedProjFn(torch.autograd.Function):
     """xg[b,pos] = W_ih embed[tokens[b,pos]] + b_ih + b_hh: nn.Embedding (film_attn_pt_stem.py:146) fused with the input half
     of nn.LSTM (:160).  Backward through per-token sums of d xg (rows holding the same token share their embedding):
