@@ -100,10 +100,12 @@ def build(args, device):
                            precision=prec)
     elif args.model == "film_gp_pt":       # BASELINE.json config 3
         model = FiLMGlobalPoolingPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
-                                                num_res_block_channels=args.channels, spatial_size=S, precision=prec)
+                                                num_res_block_channels=args.channels, spatial_size=S, precision=prec,
+                                                **({"num_tail_channels": args.tail_channels} if getattr(args, "tail_channels", 0) else {}))
     else:                                  # BASELINE.json config 5 (use --frames 70)
         model = TimeMultiHopFiLMPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
-                                               num_res_block_channels=args.channels, spatial_size=S, precision=prec)
+                                               num_res_block_channels=args.channels, spatial_size=S, precision=prec,
+                                               **({"num_tail_channels": args.tail_channels} if getattr(args, "tail_channels", 0) else {}))
     vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
     stem = FrozenStem(vgg, od, prec)
     COMPOSED_STEM[0] = stem.composed is not None
@@ -305,7 +307,7 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
     import copy
     from videonavqa_amd.train import Trainer
     batches = parity_batches(args, device)
-    logits, losses, grads, speed, fit = {}, {}, {}, {}, {}
+    logits, losses, grads, speed, fit, names, gp = {}, {}, {}, {}, {}, {}, {}
     trained = None
 
     def forward(tr, batch, grad=False):
@@ -334,6 +336,23 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
                 loss.backward()
                 grads[prec] = tr.fp.grad.clone()
                 tr.fp.zero_grad()
+                names[prec] = [(n, p.numel()) for n, p in model.named_parameters() if p.requires_grad]
+                am = getattr(model, "_gp_argmax", None)       # pooling heads: which frame supplied every pooled feature
+                if am is not None:
+                    if prec == "fp32":
+                        gp["ref_argmax"] = am.clone()
+                    else:
+                        # the same backward with the gradient ROUTED by the fp32 run's arg-max frames: what is left of the
+                        # gradient error once max-over-frames picks the same frames
+                        ref_am = gp["ref_argmax"]
+                        live = ref_am >= 0
+                        gp["flip_frac"] = float(((am != ref_am) & live).sum()) / max(float(live.sum()), 1.0)
+                        model._gp_route = ref_am
+                        out2, loss2 = forward(tr, batch, grad=True)
+                        loss2.backward()
+                        gp["routed_grad"] = tr.fp.grad.clone()
+                        tr.fp.zero_grad()
+                        model._gp_route = None
             lg.append(out.detach().float().cpu())
             ls.append(float(loss.detach()))
         logits[prec], losses[prec] = lg, ls
@@ -372,6 +391,30 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
                for g, eq in zip(top2_gap(f), b.argmax(1) == f.argmax(1)) if not bool(eq)]
     gf, gb = grads["fp32"], grads[low]
     ff, fb = fit["fp32"][0], fit[low][0]
+
+    def per_param(g_low):
+        """the parameters that carry the flat-gradient error: (name, own relative L2 error, share of the squared error)"""
+        rows, off, tot = [], 0, float((g_low - gf).pow(2).sum())
+        for n, k in names["fp32"]:
+            d, r = g_low[off:off + k] - gf[off:off + k], gf[off:off + k]
+            rows.append((n, float(d.norm() / (r.norm() + 1e-30)), float(d.pow(2).sum()) / max(tot, 1e-30)))
+            off += k
+        rows.sort(key=lambda t: -t[2])
+        return [{"param": n, "rel_l2_err": round(e, 5), "share_of_sq_err": round(sh, 4)} for n, e, sh in rows[:5]]
+
+    pooling = None
+    if "routed_grad" in gp:
+        gr = gp["routed_grad"]
+        pooling = {"argmax_frame_flip_frac": round(gp["flip_frac"], 5),
+                   "grad_rel_l2_err_routed_by_fp32_argmax": round(float((gr - gf).norm() / gf.norm()), 6),
+                   "grad_err_by_param_routed": per_param(gr),
+                   "note": "max over frames hands each pooled feature's WHOLE gradient to ONE frame: where two frames are within "
+                           "rounding of each other the 16-bit run picks the other one (argmax_frame_flip_frac) and that feature's "
+                           "gradient moves to another image's activations — a discontinuity of the model, not a kernel error. "
+                           "Routing the 16-bit backward by the fp32 run's frames removes that part; what remains sits in "
+                           "conv_init.weight, whose gradient is a sum over the SPARSE set of (frame, pixel) positions the max "
+                           "selected (no averaging over frames as in the attention model) and scales with the storage "
+                           "format's rounding (bf16 -> fp16: 2.7x smaller)"}
     return {"reference": "precision='fp32' (exact-f32 MFMA kernels; pinned <= 1e-3 to the reference goldens by tests/test_gpu_models.py)",
             "batches": "3 x (%d clips x %d frames %dx%d): full length, ragged, ragged; train-mode forward"
                        % (args.batch, args.frames, args.height, args.width),
@@ -380,6 +423,7 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
             "argmax_equal_at_init": "%d/%d" % (same, total), "fp32_top2_gap_rel_of_flipped_at_init": flipped,
             "loss_rel_err": round(max(abs(b - f) / max(abs(f), 1e-9) for b, f in zip(losses[low], losses["fp32"])), 6),
             "grad_rel_l2_err": round(float((gb - gf).norm() / gf.norm()), 6),
+            "grad_err_by_param": per_param(gb), "pooling_head": pooling,
             "after_fit": {"fit_steps_fp32": fit_steps, "fp32_loss": round(fit["fp32"][1], 4), "%s_loss" % low: round(fit[low][1], 4),
                           "%s_logits_rel_err" % low: round(float((fb - ff).abs().max() / ff.abs().max()), 6),
                           "argmax_equal": bool((fb.argmax(1) == ff.argmax(1)).all()),
@@ -404,6 +448,8 @@ def main():
     ap.add_argument("--width", type=int, default=224)
     ap.add_argument("--blocks", type=int, default=1)
     ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--tail-channels", type=int, default=0, help="num_tail_channels of the pooling models (0 = the "
+                    "constructor default: 16 / 32; eval.sh passes 32 for film_gp_pt and 64 for time_multi_hop)")
     ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop", "mac"],
                     help="film_attn_pt is the metric's model; film_gp_pt / time_multi_hop are BASELINE.json's ladder "
                          "configs 3 and 5, mac is the remaining stem-consuming model of the same CLI")

@@ -83,7 +83,8 @@ def test_full_size_stem_vs_torch_reference_and_batch_independence(B):
 
 def _bench_args(**kw):
     import argparse
-    d = dict(precision=LOW, batch=8, frames=35, height=224, width=224, blocks=1, channels=512, model="film_attn_pt")
+    d = dict(precision=LOW, batch=8, frames=35, height=224, width=224, blocks=1, channels=512, model="film_attn_pt",
+             tail_channels=0)
     d.update(kw)
     return argparse.Namespace(**d)
 
@@ -94,8 +95,8 @@ FULL_SIZE_CONFIGS = {
     "config3_film_gp": dict(model="film_gp_pt"),
     "config5_time_multi_hop_T70": dict(model="time_multi_hop", frames=70),
     "evalsh_film_attn_5x1024_bs32": dict(blocks=5, channels=1024, batch=32),
-    "evalsh_film_gp_4x1024_bs32": dict(model="film_gp_pt", blocks=4, channels=1024, batch=32),
-    "evalsh_time_multi_hop_3x1024_bs16": dict(model="time_multi_hop", blocks=3, channels=1024, batch=16),
+    "evalsh_film_gp_4x1024_bs32": dict(model="film_gp_pt", blocks=4, channels=1024, batch=32, tail_channels=32),   # eval.sh:30-31
+    "evalsh_time_multi_hop_3x1024_bs16": dict(model="time_multi_hop", blocks=3, channels=1024, batch=16, tail_channels=64),   # eval.sh:10-13,24
 }
 
 
@@ -158,6 +159,18 @@ def test_bf16_vs_fp32_mode_logits_argmax_at_full_size(name):
     if fit["fp32_min_top2_gap_rel"] > 2 * tol:
         assert fit["argmax_equal"], res
     assert abs(fit[LOW + "_loss"] - fit["fp32_loss"]) < 5 * tol * max(1.0, fit["fp32_loss"]), res
+    # flat-gradient error of one backward pass at initialisation.  Attention models: 5 % (measured 2.2 % /
+    # 0.8 %).  Max-pooling heads: each pooled feature's whole gradient goes to ONE frame and ~10 % of the features pick another
+    # frame under bf16 rounding (1.3 % under fp16): stated 0.5 (measured 0.13 - 0.40 bf16, 0.075 fp16 at config 3), and
+    # routing the backward by the fp32 run's arg-max frames must not make it worse.
+    gtol = 0.05 if "film_attn" in name else 0.5
+    if LOW == "fp16":
+        gtol = gtol / 2.5
+    assert res["grad_rel_l2_err"] < gtol, res
+    if res.get("pooling_head"):
+        ph = res["pooling_head"]
+        assert ph["grad_rel_l2_err_routed_by_fp32_argmax"] <= res["grad_rel_l2_err"] * 1.02, res
+        assert ph["argmax_frame_flip_frac"] < (0.25 if LOW == "bf16" else 0.05), res
 
 
 def test_full_size_trunk_wgrad_vs_torch_and_additivity():

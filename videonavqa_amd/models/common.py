@@ -514,7 +514,7 @@ class FiLMTrunkBase(nn.Module):
         if t.is_cuda and os.environ.get("VNQA_GP_TAIL_TORCH", "0") != "1":
             # HIP tail: segmented max over each sample's frames straight from the packed image list, written in the reference's
             # NCHW-flattened order, then out_linear on the fp32 GEMM (no dense [T, B, ...] stack, no weight re-layout)
-            pooled, self._gp_argmax = ops.frame_max(t, lay, tail, gs)
+            pooled, self._gp_argmax = ops.frame_max(t, lay, tail, gs, getattr(self, "_gp_route", None))
             return ops.linear(pooled, self.out_linear.weight, self.out_linear.bias)
         n_img, hp, wp, tp = t.shape
         dense = torch.zeros(lay.n_frames, lay.B, hp, wp, tp, device=t.device, dtype=torch.float32)

@@ -868,9 +868,10 @@ class FrameMaxFn(torch.autograd.Function):
     routes d pooled to the arg-max image (x `grad_scale`, the fp16 loss scale of the maps' gradient)."""
 
     @staticmethod
-    def forward(ctx, maps, lay, tail, grad_scale):
+    def forward(ctx, maps, lay, tail, grad_scale, route=None):
         pooled, argmax = K.frame_max_fwd(maps, lay.frame_off_i32, lay.B, lay.n_frames, tail)
-        ctx.save_for_backward(argmax)
+        # `route` (diagnostics, bench.precision_parity): arg-max table of ANOTHER run to route the gradient by
+        ctx.save_for_backward(argmax if route is None else route)
         ctx.lay, ctx.shape, ctx.dtype, ctx.tail, ctx.gs = lay, tuple(maps.shape), maps.dtype, tail, float(grad_scale)
         ctx.mark_non_differentiable(argmax)
         return pooled, argmax
@@ -879,11 +880,11 @@ class FrameMaxFn(torch.autograd.Function):
     def backward(ctx, dpooled, _dargmax):
         (argmax,) = ctx.saved_tensors
         dmaps = K.frame_max_bwd(dpooled.float(), argmax, ctx.lay.sample_of_i32, ctx.shape, ctx.dtype, ctx.tail, ctx.gs)
-        return dmaps, None, None, None
+        return dmaps, None, None, None, None
 
 
-def frame_max(maps, lay, tail, grad_scale=1.0):
-    return FrameMaxFn.apply(maps, lay, tail, grad_scale)
+def frame_max(maps, lay, tail, grad_scale=1.0, route=None):
+    return FrameMaxFn.apply(maps, lay, tail, grad_scale, route)
 
 
 class EmbedProjFn(torch.autograd.Function):
