@@ -203,6 +203,32 @@ int vnqa_frame_max_fwd(const void* maps, const int32_t* frame_off, float* pooled
 int vnqa_frame_max_bwd(const float* dpooled, const int32_t* argmax, const int32_t* sample_of, void* dmaps, int32_t n_img,
                        int32_t h, int32_t w, int32_t c_pad, int32_t tail, float scale, int32_t dtype, void* stream);
 
+/* Multi-hop FiLM generator of TimeMultiHopFiLMPretrainedStem (models/time_multi_hop_pt_stem.py:124-184), fp32, packed image list.
+ *   vnqa_layernorm_fwd : y[r] = LayerNorm(x[rows ? rows[r] : r]) * gamma + beta over the last dimension n (nn.LayerNorm, biased
+ *                        variance; encoder_norm :148, decoder_norm :184); saves mean / rstd per row
+ *   vnqa_layernorm_bwd : dx [n_rows][n] (dense, NOT scattered through `rows`; may be NULL) and d gamma / d beta (per-column sums
+ *                        over the rows in row order; `accumulate` != 0 adds to them; may be NULL together)
+ *   vnqa_scatter_add_rows : dst[rows[r]] += src[r] for unique rows (adjoint of the row gather)
+ *   vnqa_hop_fwd       : decode_to_film_values' attention (:165-176) for every image: p = hv (.) states, coefs =
+ *                        softmax_words(p . w + bias) over lmax words (padding words NOT masked, as upstream), hv_out = coefs^T p.
+ *                        states of image i = rows base_row[i] .. base_row[i] + qlen[i] - 1 of hs [*, hidden] (the persistent
+ *                        LSTM chain's output), zero beyond; coefs [n_img][lmax] is kept for the backward
+ *   vnqa_hop_bwd       : d hv, d hs (ACCUMULATED into the caller's zero-initialised / running buffer), per-image d w rows
+ *                        [n_img][hidden] (the caller sums them over images); d bias is identically 0 (softmax shift invariance)
+ * hidden <= 256, lmax <= 64.
+ */
+int vnqa_layernorm_fwd(const float* x, const int32_t* rows, const float* gamma, const float* beta, float* y, float* mean,
+                       float* rstd, int32_t n_rows, int32_t n, float eps, void* stream);
+int vnqa_layernorm_bwd(const float* dy, const float* x, const int32_t* rows, const float* mean, const float* rstd,
+                       const float* gamma, float* dx, float* dgamma, float* dbeta, int32_t n_rows, int32_t n,
+                       int32_t accumulate, void* stream);
+int vnqa_scatter_add_rows(float* dst, const int32_t* rows, const float* src, int32_t n_rows, int32_t n, void* stream);
+int vnqa_hop_fwd(const float* hv, const float* hs, const int32_t* base_row, const int32_t* qlen, const float* w,
+                 const float* bias, float* hv_out, float* coefs, int32_t n_img, int32_t lmax, int32_t hidden, void* stream);
+int vnqa_hop_bwd(const float* dout, const float* hv, const float* hs, const int32_t* base_row, const int32_t* qlen,
+                 const float* w, const float* coefs, float* dhv, float* dhs, float* dw_img, int32_t n_img, int32_t lmax,
+                 int32_t hidden, void* stream);
+
 /* Weights-stationary-in-REGISTERS persistent direct 3x3 conv (bf16 / the library's 16-bit format) for the short-K layers
  * of the VGG front (get_frcnn_feature_extractor features[2], [5], [7]; call sites eval/q_and_v_eval.py:106): 4 waves per
  * workgroup, one per SIMD, each keeping its slice of the weights in 288 of its SIMD's 512 registers for the whole

@@ -208,3 +208,46 @@ def test_frame_max_tail_vs_dense_stack(dt, v_lens, T, tail, h, w):
     am = argmax.view(B, tail, h, w)
     assert int(am[:, :, 0, 0].max()) == -1                    # all-zero position
     assert torch.equal(am[:, 0, 1, 1], lay.frame_off_i32[0] + torch.arange(B, device="cuda", dtype=torch.int32))   # tie -> frame 0
+
+
+@pytest.mark.parametrize("hidden", [128, 16, 64])
+@pytest.mark.parametrize("v_lens,q_lens,blocks", [([4, 4, 4], [5, 3, 7], 2), ([6, 3, 1, 1], [2, 9, 4, 4], 3), ([2], [11], 1)])
+def test_multi_hop_generator_hip_vs_torch(v_lens, q_lens, blocks, hidden):
+    """the multi-hop FiLM generator on HIP kernels (csrc/hop_gen.hip + vnqa_sgemm, one autograd node) against the same
+    generator op by op on stock torch (models/time_multi_hop_pt_stem.py:124-184): FiLM matrices and every gradient"""
+    from videonavqa_amd.models import TimeMultiHopFiLMPretrainedStem
+    from videonavqa_amd.models.common import FrameLayout
+    B, T, C, H = len(v_lens), max(v_lens) + 1, 16, hidden
+    torch.manual_seed(sum(q_lens) + blocks)
+    model = TimeMultiHopFiLMPretrainedStem(B, 24, 7, num_input_channels=64, num_res_block_channels=C, num_res_blocks=blocks,
+                                           num_tail_channels=8, hidden_size=H, vocab_size=30, spatial_size=12,
+                                           precision="fp32").cuda()
+    with torch.no_grad():
+        for p in (model.encoder_norm.weight, model.decoder_norm.weight):
+            p.uniform_(0.5, 1.5)
+        for p in (model.encoder_norm.bias, model.decoder_norm.bias, model.fc_hidden_attn.bias):
+            p.normal_(0, 0.3)
+        model.fc_hidden_attn.weight.normal_(0, 0.5)
+    lay = FrameLayout(v_lens, T, "cuda")
+    ql = torch.tensor(q_lens)
+    q = torch.randint(1, 30, (B, max(q_lens) + 2))
+    q = (q * (torch.arange(q.shape[1]).unsqueeze(0) < ql.unsqueeze(1))).cuda()
+    outs, grads = {}, {}
+    for mode in ("hip", "torch"):
+        model.zero_grad(set_to_none=True)
+        model.init_hidden()
+        films = model._generator_hip(q, ql, lay) if mode == "hip" else model._generator_torch(q, ql, lay)
+        g = torch.Generator().manual_seed(3)
+        loss = sum((f * torch.randn(f.shape, generator=g).cuda()).sum() for f in films)
+        loss.backward()
+        outs[mode] = [f.detach().clone() for f in films]
+        grads[mode] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    for a, b in zip(outs["hip"], outs["torch"]):
+        assert a.shape == b.shape and _close(a, b, 2e-5)
+    assert set(grads["hip"]) == set(grads["torch"])
+    for n in grads["torch"]:
+        ref = grads["torch"][n]
+        if n == "fc_hidden_attn.bias":             # identically 0 (softmax shift invariance); torch returns rounding noise
+            assert float(grads["hip"][n].abs().max()) < 1e-4 and float(ref.abs().max()) < 1e-3, n
+            continue
+        assert _close(grads["hip"][n], ref, 3e-4), (n, float((grads["hip"][n] - ref).abs().max()), float(ref.abs().max()))

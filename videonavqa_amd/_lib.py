@@ -76,6 +76,11 @@ _SIGNATURES = {
     "vnqa_last_error": (ctypes.c_char_p, []),
     "vnqa_conv2d_igemm_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_conv2d_c64_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vnqa_layernorm_fwd": (ctypes.c_int, [_vp] * 7 + [_i32, _i32, _f32, _vp]),
+    "vnqa_layernorm_bwd": (ctypes.c_int, [_vp] * 9 + [_i32, _i32, _i32, _vp]),
+    "vnqa_scatter_add_rows": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "vnqa_hop_fwd": (ctypes.c_int, [_vp] * 8 + [_i32, _i32, _i32, _vp]),
+    "vnqa_hop_bwd": (ctypes.c_int, [_vp] * 10 + [_i32, _i32, _i32, _vp]),
     "vnqa_frame_max_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 7 + [_vp]),
     "vnqa_frame_max_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 5 + [_f32, _i32, _vp]),
     "vnqa_conv2d_wreg_supported": (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),

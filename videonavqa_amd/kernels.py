@@ -297,6 +297,62 @@ def conv2d_wreg(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post
     return out
 
 
+def layernorm_fwd(x, gamma, beta, eps, rows=None):
+    """LayerNorm over the last dimension of fp32 rows (optionally gathered: row r of the result normalises x[rows[r]]).
+    Returns (y, mean, rstd)."""
+    n = x.shape[-1]
+    n_rows = rows.numel() if rows is not None else x.numel() // n
+    y = torch.empty((n_rows, n), dtype=torch.float32, device=x.device)
+    mean = torch.empty((n_rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((n_rows,), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vnqa_layernorm_fwd(L.ptr(_f32c(x)), L.ptr(rows), L.ptr(_f32c(gamma)), L.ptr(_f32c(beta)), L.ptr(y), L.ptr(mean),
+                                       L.ptr(rstd), n_rows, n, float(eps), L.stream()), "vnqa_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, rows=None, dgamma=None, dbeta=None, accumulate=False, need_dx=True):
+    """Returns (dx [n_rows, n] or None, dgamma, dbeta); dgamma / dbeta are written (or accumulated) in place when given."""
+    n_rows, n = dy.shape
+    dx = torch.empty((n_rows, n), dtype=torch.float32, device=dy.device) if need_dx else None
+    if dgamma is None:
+        dgamma = torch.empty((n,), dtype=torch.float32, device=dy.device)
+        dbeta = torch.empty((n,), dtype=torch.float32, device=dy.device)
+        accumulate = False
+    L.check(L.lib().vnqa_layernorm_bwd(L.ptr(_f32c(dy)), L.ptr(_f32c(x)), L.ptr(rows), L.ptr(mean), L.ptr(rstd), L.ptr(_f32c(gamma)),
+                                       L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), n_rows, n, 1 if accumulate else 0, L.stream()),
+            "vnqa_layernorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def scatter_add_rows(dst, rows, src):
+    """dst[rows[r]] += src[r] (unique rows; fp32 2-D, contiguous)."""
+    n_rows, n = src.shape
+    assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.shape[-1] == n
+    L.check(L.lib().vnqa_scatter_add_rows(L.ptr(dst), L.ptr(rows), L.ptr(_f32c(src)), n_rows, n, L.stream()), "vnqa_scatter_add_rows")
+    return dst
+
+
+def hop_fwd(hv, hs, base_row, qlen, w, bias, lmax):
+    """one hop of the multi-hop FiLM generator for every image (vnqa_hop_fwd): returns (hv_out [n_img, H], coefs [n_img, lmax])."""
+    n_img, H = hv.shape
+    out = torch.empty((n_img, H), dtype=torch.float32, device=hv.device)
+    coefs = torch.empty((n_img, lmax), dtype=torch.float32, device=hv.device)
+    L.check(L.lib().vnqa_hop_fwd(L.ptr(_f32c(hv)), L.ptr(_f32c(hs)), L.ptr(base_row), L.ptr(qlen), L.ptr(_f32c(w.reshape(-1))),
+                                 L.ptr(_f32c(bias.reshape(-1))), L.ptr(out), L.ptr(coefs), n_img, lmax, H, L.stream()), "vnqa_hop_fwd")
+    return out, coefs
+
+
+def hop_bwd(dout, hv, hs, base_row, qlen, w, coefs, dhs):
+    """backward of hop_fwd: returns (d hv [n_img, H], per-image d w rows [n_img, H]); d hs is ACCUMULATED into `dhs`."""
+    n_img, H = hv.shape
+    dhv = torch.empty((n_img, H), dtype=torch.float32, device=hv.device)
+    dw_img = torch.empty((n_img, H), dtype=torch.float32, device=hv.device)
+    L.check(L.lib().vnqa_hop_bwd(L.ptr(_f32c(dout)), L.ptr(_f32c(hv)), L.ptr(_f32c(hs)), L.ptr(base_row), L.ptr(qlen),
+                                 L.ptr(_f32c(w.reshape(-1))), L.ptr(coefs), L.ptr(dhv), L.ptr(dhs), L.ptr(dw_img), n_img,
+                                 coefs.shape[1], H, L.stream()), "vnqa_hop_bwd")
+    return dhv, dw_img
+
+
 def frame_max_fwd(maps, frame_off_i32, batch, n_frames, tail):
     """max over a sample's frames of the packed relu'd tail maps [n_img, h+2, w+2, c_pad] -> (pooled fp32 [batch, tail*h*w] in
     NCHW-flattened order, argmax int32) — vnqa_frame_max_fwd."""

@@ -1,8 +1,13 @@
 """TimeMultiHopFiLMPretrainedStem — drop-in for models/time_multi_hop_pt_stem.py."""
+import os
+
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import _lib as L
+from .. import ops
 from .common import FiLMTrunkBase, compute_dtype, grad_scale_of, repeated_question_lstm
 
 
@@ -44,16 +49,35 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
         self.film_hidden = self._zero_hidden(self.batch_size, self.hidden_size, self.embed.weight.device)
         self.h = None
 
-    def forward(self, v_input, q_input, v_lens, q_lens):
-        """time_multi_hop_pt_stem.py:191-250 with compute_film_encoding (:124-158) and
-        decode_to_film_values (:165-184) evaluated for all frames at once."""
-        x, lay, h, w = self._prepare_input(v_input, v_lens)
-        assert lay.B == self.batch_size
-        assert h * w == self.spatial_size
+    def _generator_hip(self, q_input, q_lens, lay):
+        """compute_film_encoding + decode_to_film_values (:124-184) for all frames at once on HIP kernels: embedding + input
+        projection (one launch), the question LSTM re-run per frame with carried state as ONE persistent chain, then the
+        multi-hop attention read straight from the chain's output rows (ops.MultiHopGenFn)."""
+        B, H, dev = q_input.shape[0], self.hidden_size, q_input.device
+        ql_cpu = q_lens.detach().cpu().long()
+        Lmax = int(ql_cpu.max())
+        S = Lmax * lay.n_frames
+        ql = [int(v) for v in ql_cpu]
+        pairs = [(t, b) for t, ct in enumerate(lay.cts) for b in range(ct)]
+        base = np.asarray([b * S + t * ql[b] for t, b in pairs], np.int32)
+        qimg = np.asarray([ql[b] for _, b in pairs], np.int32)
+        tbl = np.concatenate([ql_cpu.numpy().astype(np.int32), lay.last_token_rows(ql_cpu, S), base, qimg])
+        tbl = L.to_device_async(torch.from_numpy(tbl), dev)          # ONE pinned upload for all tables
+        n = lay.n_img
+        ql_i32, last_rows, base_row, qlen = tbl[:B], tbl[B:B + n], tbl[B + n:B + 2 * n], tbl[B + 2 * n:]
+        lstm = self.q_encoder
+        xg = ops.embed_proj(q_input, self.embed.weight, lstm.weight_ih_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, 0)
+        h0, c0 = self._question_state(B, H, q_lens, dev)
+        hs, hn, cn = ops.lstm_seq(xg, lstm.weight_hh_l0, h0, c0, ql_i32, lay.n_frames, S, self._lstm_wgrad_dtype())
+        self._store_question_state(hn, cn, q_lens)
+        return list(ops.multi_hop_generator(hs.view(B * S, H), (last_rows, base_row, qlen), Lmax, self.num_res_blocks,
+                                            self.encoder_norm, self.fc_hidden_attn, self.fc_attn_out, self.decoder_norm))
+
+    def _generator_torch(self, q_input, q_lens, lay):
+        """the same generator op by op on stock torch (CPU / VNQA_HOP_TORCH=1 cross-check)"""
         B, Fn, Hq = lay.B, lay.n_frames, self.hidden_size
-        C = self.num_res_block_channels
         emb = self.embed(q_input)
-        h0, c0 = self._question_state(B, Hq, q_lens, x.device)
+        h0, c0 = self._question_state(B, Hq, q_lens, q_input.device)
         h_last, states, (hn, cn) = repeated_question_lstm(self.q_encoder, emb, q_lens, Fn, h0, c0,
                                                           want_states=True, wgrad_dtype=self._lstm_wgrad_dtype())
         self._store_question_state(hn, cn, q_lens)
@@ -67,6 +91,20 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
             coefs = torch.softmax(self.fc_hidden_attn(prod), dim=1)       # unmasked over words :171-172
             hv = torch.bmm(coefs.permute(0, 2, 1), prod).squeeze(1)       # :175-176
             film_per_block.append(self.decoder_norm(self.fc_attn_out(hv)))  # :179,184
+        return film_per_block
+
+    def forward(self, v_input, q_input, v_lens, q_lens):
+        """time_multi_hop_pt_stem.py:191-250 with compute_film_encoding (:124-158) and
+        decode_to_film_values (:165-184) evaluated for all frames at once."""
+        x, lay, h, w = self._prepare_input(v_input, v_lens)
+        assert lay.B == self.batch_size
+        assert h * w == self.spatial_size
+        B, Fn, Hq = lay.B, lay.n_frames, self.hidden_size
+        C = self.num_res_block_channels
+        if x.is_cuda and os.environ.get("VNQA_HOP_TORCH", "0") != "1":
+            film_per_block = self._generator_hip(q_input, q_lens, lay)
+        else:
+            film_per_block = self._generator_torch(q_input, q_lens, lay)
 
         def film_fn(k):
             s = 2 * C * k

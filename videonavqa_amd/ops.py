@@ -862,6 +862,86 @@ def linear(x, w, b, relu=False, rows=None):
     return LinearFn.apply(x, w, b, relu, rows)
 
 
+class MultiHopGenFn(torch.autograd.Function):
+    """The multi-hop FiLM generator (time_multi_hop_pt_stem.py:146-184) for every packed image as ONE autograd node on the HIP
+    kernels of csrc/hop_gen.hip + vnqa_sgemm:
+        enc = encoder_norm(hs[last_rows]);  per block: hv = hop(hv, states) ; film_k = decoder_norm(fc_attn_out(hv))
+    hs [B*S, H] is the persistent LSTM chain's output; image i's word states are its rows base_row[i] .. + qlen[i] - 1.
+    Returns one FiLM matrix [n_img, N] per block.  The backward accumulates d hs in ONE buffer (no per-use gradient tensors)."""
+
+    @staticmethod
+    def forward(ctx, hs, tables, lmax, blocks, eps_enc, eps_dec, enc_g, enc_b, w_att, b_att, w_out, b_out, dec_g, dec_b):
+        last_rows, base_row, qlen = tables
+        enc, m0, r0 = K.layernorm_fwd(hs, enc_g, enc_b, eps_enc, rows=last_rows)
+        hv, saved, films = enc, [], []
+        for _ in range(blocks):
+            hv_next, coefs = K.hop_fwd(hv, hs, base_row, qlen, w_att, b_att, lmax)
+            y = K.linear_nt(hv_next, w_out, bias=b_out)
+            film, m, r = K.layernorm_fwd(y, dec_g, dec_b, eps_dec)
+            saved += [hv, coefs, hv_next, y, m, r]
+            films.append(film)
+            hv = hv_next
+        ctx.save_for_backward(hs, last_rows, base_row, qlen, m0, r0, enc_g, w_att, w_out, dec_g, *saved)
+        ctx.blocks = blocks
+        with torch.enable_grad():
+            ctx.sinks = [sink_of(t) for t in (enc_g, enc_b, w_att, w_out, b_out, dec_g, dec_b)]
+        return tuple(films)
+
+    @staticmethod
+    def backward(ctx, *dfilms):
+        hs, last_rows, base_row, qlen, m0, r0, enc_g, w_att, w_out, dec_g = ctx.saved_tensors[:10]
+        saved = ctx.saved_tensors[10:]
+        s_eg, s_eb, s_wa, s_wo, s_bo, s_dg, s_db = ctx.sinks
+        dev, H, N = hs.device, hs.shape[1], w_out.shape[0]
+        n_img = last_rows.numel()
+        dhs = torch.zeros_like(hs)
+        ones = torch.ones((n_img, 1), dtype=torch.float32, device=dev)
+        def pair(a, b):       # gamma / beta gradients are written by ONE kernel: both in place or both through temporaries
+            return a is not None and b is not None and not a.written and not b.written
+        if pair(s_dg, s_db):
+            d_dec_g, d_dec_b = _into(s_dg), _into(s_db)
+        else:
+            d_dec_g = torch.empty((N,), dtype=torch.float32, device=dev)
+            d_dec_b = torch.empty((N,), dtype=torch.float32, device=dev)
+            s_dg = s_db = None
+        d_wo = _into(s_wo)
+        d_wo = d_wo if d_wo is not None else torch.empty((N, H), dtype=torch.float32, device=dev)
+        d_bo = _into(s_bo)
+        d_bo = d_bo if d_bo is not None else torch.empty((N,), dtype=torch.float32, device=dev)
+        d_wa = _into(s_wa, (1, H))
+        d_wa = d_wa if d_wa is not None else torch.empty((1, H), dtype=torch.float32, device=dev)
+        carry, first = None, True
+        for k in reversed(range(ctx.blocks)):
+            hv_in, coefs, hv_next, y, m, r = saved[6 * k: 6 * k + 6]
+            df = dfilms[k]
+            if df is None:
+                df = torch.zeros((n_img, N), dtype=torch.float32, device=dev)
+            dy, _, _ = K.layernorm_bwd(df.float().contiguous(), y, m, r, dec_g, dgamma=d_dec_g, dbeta=d_dec_b, accumulate=not first)
+            K.matmul_tn(dy, hv_next, out=d_wo, accumulate=not first)                       # d W_out += dy^T hv
+            K.matmul_tn(ones, dy, out=d_bo.view(1, N), accumulate=not first)               # d b_out += colsum(dy)
+            if carry is None:
+                carry = K.matmul_nn(dy, w_out)                                             # d hv_next (last block: nothing carried)
+            else:
+                K.matmul_nn(dy, w_out, out=carry, accumulate=True)                         # + the next hop's d hv_in
+            carry, dw_img = K.hop_bwd(carry, hv_in, hs, base_row, qlen, w_att, coefs, dhs)
+            K.matmul_tn(ones, dw_img, out=d_wa, accumulate=not first)
+            first = False
+        both_e = pair(s_eg, s_eb)
+        dx_enc, d_enc_g, d_enc_b = K.layernorm_bwd(carry, hs, m0, r0, enc_g, rows=last_rows,
+                                                   dgamma=_into(s_eg) if both_e else None, dbeta=_into(s_eb) if both_e else None)
+        K.scatter_add_rows(dhs, last_rows, dx_enc)
+        return (dhs, None, None, None, None, None,
+                _ret(s_eg if both_e else None, d_enc_g), _ret(s_eb if both_e else None, d_enc_b),
+                _ret(s_wa, d_wa), torch.zeros((1,), dtype=torch.float32, device=dev),          # d b_att == 0 (softmax shift invariance)
+                _ret(s_wo, d_wo), _ret(s_bo, d_bo), _ret(s_dg, d_dec_g), _ret(s_db, d_dec_b))
+
+
+def multi_hop_generator(hs, tables, lmax, blocks, enc_norm, fc_hidden_attn, fc_attn_out, dec_norm):
+    return MultiHopGenFn.apply(hs, tables, lmax, blocks, enc_norm.eps, dec_norm.eps, enc_norm.weight, enc_norm.bias,
+                               fc_hidden_attn.weight, fc_hidden_attn.bias, fc_attn_out.weight, fc_attn_out.bias,
+                               dec_norm.weight, dec_norm.bias)
+
+
 class FrameMaxFn(torch.autograd.Function):
     """max over a sample's frames of the relu'd tail maps, straight from the packed image list (the reference's zero-padded
     [T, B, ...] stack + max(dim=0), film_global_pooling_pt_stem.py:230-235): (pooled, argmax) = vnqa_frame_max_fwd; the backward
