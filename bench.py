@@ -590,7 +590,15 @@ def main():
         trainer.reducer.enabled = False
         dt_nc = timed_region()[0]
         trainer.reducer.enabled = True
-        comm = {"ranks": world, "backend": "rccl" if backend == "nccl" else backend,
+        rccl_ver = None
+        try:
+            rccl_ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        comm = {"ranks": world, "backend": "rccl" if backend == "nccl" else backend, "rccl_version": rccl_ver,
+                # RCCL picks algorithm / protocol per call from its tuner unless pinned by the environment; what this run used:
+                "rccl_algo": os.environ.get("NCCL_ALGO", "tuner default (NCCL_ALGO unset)"),
+                "rccl_proto": os.environ.get("NCCL_PROTO", "tuner default (NCCL_PROTO unset)"),
                 "allreduce_payload_mb": round(trainer.fp.n * 4 / 1e6, 1), "allreduce_alone_ms": round(ar_ms, 3),
                 "allreduce_alone_busbw_gbs": round(2 * (world - 1) / world * trainer.fp.n * 4 / (ar_ms * 1e-3) / 1e9, 1),
                 "ms_per_step_without_collectives": round(dt_nc / args.steps * 1e3, 3),

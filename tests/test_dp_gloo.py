@@ -102,3 +102,77 @@ def test_flat_params_alias_model_parameters():
     assert float(fp.grad.abs().sum()) > 0      # autograd accumulated INTO the flat buffer
     fp.zero_grad()
     assert all(float(p.grad.abs().max()) == 0 for p in model.parameters())
+
+
+class _Scrambled(nn.Module):
+    """three big layers REGISTERED in the order (c, a, b) but USED as a -> b -> c: their gradients arrive c, b, a — out of
+    order with respect to their slices of the flat buffer (c, a, b)"""
+
+    def __init__(self, seed):
+        super(_Scrambled, self).__init__()
+        torch.manual_seed(seed)
+        self.c = nn.Linear(32, 5)
+        self.a = nn.Linear(12, 32)
+        self.b = nn.Linear(32, 32)
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+
+
+def _worker_mean(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    from videonavqa_amd.train import FlatParams, OverlappedGradReducer, sync_replicas
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _Scrambled(seed=200 + rank)
+    sync_replicas(list(model.state_dict().values()))
+    fp = FlatParams(model.parameters())
+    reducer = OverlappedGradReducer(fp, world, "mean", early_numel=100)      # the Trainer's own reducer class
+    assert len(reducer.early) == 3                                            # a.weight, b.weight, c.weight
+    fired = []
+    orig = reducer._hook
+    reducer._hook = lambda p: (fired.append(p), orig(p))[1]
+    for p in reducer.early:                  # (re-register through the recording wrapper)
+        p._post_accumulate_grad_hooks.clear()
+        p.register_post_accumulate_grad_hook(reducer._hook)
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(8, 12, generator=g)
+    Y = torch.randint(0, 5, (8,), generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    loss_fn = nn.CrossEntropyLoss(reduction="mean")
+    for it in range(3):
+        fired.clear()
+        loss_fn(model(xs), ys).backward()
+        # arrival order c, b, a  !=  buffer order c, a, b; each early parameter fired exactly once
+        offs = [reducer.early[p][0] for p in fired]
+        assert len(fired) == 3 and len(set(id(p) for p in fired)) == 3 and offs != sorted(offs), offs
+        reducer.finish()
+        _adam_step(fp, 1e-2)
+    gathered = [torch.zeros_like(fp.flat) for _ in range(world)]
+    dist.all_gather(gathered, fp.flat)
+    assert torch.equal(gathered[0], gathered[1])
+    if rank == 0:
+        torch.save(fp.flat.clone(), out_path)
+    dist.destroy_process_group()
+
+
+def test_reducer_three_early_parameters_out_of_order_mean_loss(tmp_path):
+    """the Trainer's reducer with >= 3 early (hook-reduced) parameters whose gradients arrive out of buffer
+    order, loss_reduction='mean': two ranks x bs 4 == one process on the global batch of 8 with a mean loss."""
+    sys.path.insert(0, ROOT)
+    from videonavqa_amd.train import FlatParams
+    out = str(tmp_path / "w_mean.pt")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_mean, args=(2, port, out), nprocs=2, join=True)
+    w_dp = torch.load(out)
+    model = _Scrambled(seed=200)
+    fp = FlatParams(model.parameters())
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(8, 12, generator=g)
+    Y = torch.randint(0, 5, (8,), generator=g)
+    loss_fn = nn.CrossEntropyLoss(reduction="mean")
+    for _ in range(3):
+        loss_fn(model(X), Y).backward()
+        _adam_step(fp, 1e-2)
+    assert torch.allclose(w_dp, fp.flat, rtol=1e-5, atol=1e-6), float((w_dp - fp.flat).abs().max())

@@ -68,6 +68,15 @@ def _worker(rank, world, port, out_dir):
     dist.all_gather(flat1, tr.fp.flat)
     assert torch.equal(flat1[0], flat1[1])
     assert bool(torch.isfinite(tr.fp.flat).all())
+    # 4) BatchNorm running statistics are RANK-LOCAL (the reference has no SyncBN: every rank normalises with its own
+    #    minibatch): after a step on different minibatches they differ between ranks, nothing reduces them, and
+    #    the checkpoint policy is "rank 0's copy" — model.state_dict() on rank 0 holds exactly rank 0's buffers
+    rm = model.bn_init.running_mean.detach().clone()
+    rms = [torch.zeros_like(rm) for _ in range(world)]
+    dist.all_gather(rms, rm)
+    assert not torch.equal(rms[0], rms[1])
+    if rank == 0:
+        assert torch.equal(model.state_dict()["bn_init.running_mean"], rms[0])
     open(os.path.join(out_dir, "ok%d" % rank), "w").write("%g" % err)
     dist.destroy_process_group()
 
