@@ -32,6 +32,10 @@ extern "C" {
 #define VNQA_ERR_HIP (-2)
 #define VNQA_ERR_UNSUPPORTED (-3)
 
+/* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
+ * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
+ * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
+#define VNQA_ABI_VERSION 300
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 

@@ -110,3 +110,54 @@ def test_mac_edge_batches_vs_oracle(name, v_lens, q_lens):
     assert torch.isfinite(got).all()
     assert rel_err(got.numpy(), ref.numpy()) < 1e-3, name
     assert (got.argmax(1) == ref.argmax(1)).all()
+
+
+def test_carried_question_state_follows_the_sorted_order_between_batches():
+    """two consecutive forwards WITHOUT init_hidden() whose q_len sort permutations differ.  Upstream carries
+    film_hidden in q_len-sorted order, so sorted slot i of the new batch inherits sorted slot i of the old one
+    (film_attn_pt_stem.py:150,160).  The lazily kept sample-order state must give exactly what the materialised
+    sorted-order state (the `film_hidden` getter) gives."""
+    import videonavqa_amd.models as M
+    torch.manual_seed(3)
+    B = 3
+    model = M.FiLMAttnPretrainedStem(batch_size=B, q_embedding_size=12, nb_classes=K, num_input_channels=CIN,
+                                     num_res_block_channels=C, num_res_blocks=1, hidden_size=16, at_hidden_size=16,
+                                     max_num_frames=T, vocab_size=V, spatial_size=130, precision="fp32").cuda().eval()
+    b1 = _batch(21, [6, 5, 4], [9, 2, 5])          # sorted order of the questions: samples 0, 2, 1
+    b2 = _batch(22, [6, 6, 3], [3, 8, 4])          # ... then 1, 2, 0
+    outs = []
+    for materialise in (False, True):
+        model.init_hidden()
+        with torch.no_grad():
+            model(b1[0].cuda(), b1[1].cuda(), b1[2], b1[3])
+            if materialise:
+                fh = model.film_hidden              # sorted-order form, drops the lazily kept sample-order state
+                assert fh[0].shape == (1, B, 16)
+            outs.append(model(b2[0].cuda(), b2[1].cuda(), b2[2], b2[3]).cpu())
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    # and the state really is carried: a reset in between changes the second batch's logits
+    model.init_hidden()
+    with torch.no_grad():
+        fresh = model(b2[0].cuda(), b2[1].cuda(), b2[2], b2[3]).cpu()
+    assert float((fresh - outs[0]).abs().max()) > 1e-6
+
+
+def test_ce_loss_ignores_out_of_range_targets_like_ignore_index():
+    """vnqa_ce_loss must not index out of bounds on a target outside [0, K); such rows are ignored (zero weight,
+    zero gradient), which is what nn.CrossEntropyLoss does for ignore_index = -100."""
+    from videonavqa_amd import ops
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(6, K, generator=g).cuda().requires_grad_(True)
+    ys = torch.tensor([1, -100, 3, 0, K - 1, 2]).cuda()
+    w = (torch.rand(K, generator=g) + 0.5).cuda()
+    for reduction in ("sum", "mean"):
+        for weight in (None, w):
+            lg = logits.detach().clone().requires_grad_(True)
+            loss = ops.cross_entropy(lg, ys, weight=weight, reduction=reduction)
+            loss.backward()
+            ref_l = logits.detach().clone().requires_grad_(True)
+            ref = torch.nn.functional.cross_entropy(ref_l, ys, weight=weight, reduction=reduction, ignore_index=-100)
+            ref.backward()
+            assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+            assert float((lg.grad - ref_l.grad).abs().max()) <= 1e-6
+            assert float(lg.grad[1].abs().max()) == 0.0

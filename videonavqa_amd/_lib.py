@@ -36,6 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
+ABI_VERSION = 300          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -175,16 +176,30 @@ def lib():
             # not a fallback: (re)build the HIP library itself when it is missing OR older than its sources (the digest
             # check is cheap; build() takes a file lock, so torchrun ranks do not compile over each other)
             from .build import build as _build
-            _build(verbose=False, variant=_half)
+            try:
+                _build(verbose=False, variant=_half)
+            except (OSError, RuntimeError) as e:      # read-only / NFS install, lock failure, compiler error
+                if not os.path.exists(path):
+                    raise VnqaError("cannot build %s (%s) — run `python -m videonavqa_amd.build` where the tree is "
+                                    "writable" % (path, e))
+                import warnings
+                warnings.warn("HIP library may be stale: the implicit rebuild failed (%s); run `python -m "
+                              "videonavqa_amd.build`" % e)
         if not os.path.exists(path):
             raise VnqaError(
                 "%s not found — build it with `python -m videonavqa_amd.build` "
                 "(there is no CPU/PyTorch fallback for the HIP path)" % path)
-        _lib = ctypes.CDLL(path)
+        cdll = ctypes.CDLL(path)
+        cdll.vnqa_version.restype = ctypes.c_int
+        got = cdll.vnqa_version()
+        if got != ABI_VERSION:
+            raise VnqaError("%s reports ABI version %d, this binding needs %d — stale library: rebuild it with `python -m "
+                            "videonavqa_amd.build`" % (path, got, ABI_VERSION))
         for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(_lib, name)  # AttributeError if the symbol is missing: fail loudly
+            fn = getattr(cdll, name)  # AttributeError if the symbol is missing: fail loudly
             fn.restype = res
             fn.argtypes = args
+        _lib = cdll
     return _lib
 
 

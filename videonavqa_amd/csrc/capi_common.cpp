@@ -12,4 +12,4 @@ void vnqa_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vnqa_last_error(void) { return g_err; }
-extern "C" int vnqa_version(void) { return 100; }
+extern "C" int vnqa_version(void) { return VNQA_ABI_VERSION; }

@@ -865,6 +865,18 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   constexpr int NSTAGE = PIPE == 5 ? 2 : PIPE;
   constexpr int LDS = (NSTAGE * STAGE > CT) ? NSTAGE * STAGE : CT;
   static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
+  // the BNSTATS epilogue is compiled into an instantiation only where the kernel's own predicate (kStatsOk) holds: refuse the
+  // request here instead of launching a kernel that would leave the statistics workspace unwritten
+  constexpr bool kStatsOk = (TAG == 0) && (NT % (BN * ES / 16) == 0) && (BN * ES / 16 <= 64) && (64 % (BN * ES / 16) == 0);
+  if (a.epi == VNQA_EPI_BNSTATS && !kStatsOk) {
+    vnqa_set_error("conv2d_igemm_fused_fwd: the BNSTATS epilogue is not available on this tile (%dx%d, %d threads, tag %d)",
+                   BM, BN, NT, TAG);
+    return VNQA_ERR_UNSUPPORTED;
+  }
+  if ((a.epi == VNQA_EPI_FILM_RES || a.epi == VNQA_EPI_ADD_MASK) && TAG != 0) {
+    vnqa_set_error("conv2d_igemm_fused_fwd: fused trunk epilogues are compiled into the TAG 0 instantiations only");
+    return VNQA_ERR_UNSUPPORTED;
+  }
   ConvArgs p = a;
   const int tilesM = (p.M + BM - 1) / BM;
   p.tilesN = (p.Cout + BN - 1) / BN;

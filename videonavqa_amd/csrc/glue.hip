@@ -284,13 +284,16 @@ __global__ void ce_loss_kernel(const float* __restrict__ logits, const long long
     for (int k = lane; k < K; k += 64) den += expf(lg[k] - mx);
     den = wave_reduce_sum(den);
     const long long y = ys[row_perm != nullptr ? row_perm[b] : b];
-    const float wy = weight != nullptr ? weight[y] : 1.f;
+    // a target outside [0, K) is IGNORED (zero weight, zero gradient) — nn.CrossEntropyLoss's ignore_index = -100 lands here;
+    // it never indexes weight[] / the logits row out of bounds
+    const bool valid = y >= 0 && y < K;
+    const float wy = !valid ? 0.f : (weight != nullptr ? weight[y] : 1.f);
     const float lse = mx + logf(den);
     for (int k = lane; k < K; k += 64) {
       const float pk = expf(lg[k] - lse);
       dlogits[(size_t)b * K + k] = wy * (pk - (k == y ? 1.f : 0.f));      // scaled by 1 / sum(w) below for 'mean'
     }
-    if (lane == 0) {
+    if (lane == 0 && valid) {
       my_loss += wy * (lse - lg[y]);
       my_w += wy;
     }

@@ -863,6 +863,9 @@ def lstm_wgrad_operands(dgates, hs, h0, dtype):
 
 def ce_loss(logits, ys, row_perm, weight, mean):
     B, Kc = logits.shape
+    assert ys.dtype == torch.int64 and ys.is_contiguous() and ys.numel() >= B, "ce_loss: targets must be contiguous int64"
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    assert row_perm is None or (row_perm.dtype == torch.int32 and row_perm.is_contiguous())
     loss = torch.empty((), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty_like(logits)
     L.check(L.lib().vnqa_ce_loss(L.ptr(logits), L.ptr(ys), L.ptr(row_perm), L.ptr(weight), L.ptr(loss), L.ptr(dlogits), B, Kc,

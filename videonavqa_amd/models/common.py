@@ -279,7 +279,10 @@ class FiLMTrunkBase(nn.Module):
         super()._apply(fn, *args, **kwargs)
         for c in self.conv1x1_layers:
             c._apply(fn)
-        if self.__dict__.get("_carried") is None and self.__dict__.get("_film_hidden") is not None:
+        carried = self.__dict__.get("_carried")
+        if carried is not None:          # the lazily kept state follows the module to its new device / dtype
+            self.__dict__["_carried"] = (fn(carried[0]), fn(carried[1]), carried[2])
+        elif self.__dict__.get("_film_hidden") is not None:
             self.__dict__["_film_hidden"] = tuple(fn(t) for t in self.__dict__["_film_hidden"])
         self.__dict__["_zero_state"] = None
         return self
@@ -343,8 +346,22 @@ class FiLMTrunkBase(nn.Module):
     def _question_state(self, B, H, q_lens, device):
         """Per-sample initial (h, c); the reference stores it in q_len-sorted order (:150,:160)."""
         carried = self.__dict__.get("_carried")
-        if carried is not None:           # state of the previous forward, still in sample order: use as is
-            return carried[0], carried[1]
+        if carried is not None:
+            # State of the previous forward, kept in SAMPLE order.  Upstream stores it in q_len-sorted order and hands sorted
+            # slot i of the old batch to sorted slot i of the new one (:150,:160): identical to "use as is" when the two
+            # batches sort the same way (always, when the caller resets with init_hidden() or repeats a batch); otherwise
+            # sample perm_new[i] inherits the state of sample perm_old[i]
+            hn, cn, ql_old = carried
+            ql_new = q_lens.detach().cpu().long()
+            if ql_old.shape == ql_new.shape and not torch.equal(ql_old, ql_new):
+                perm_old = torch.sort(ql_old, dim=0, descending=True, stable=True)[1]
+                perm_new = torch.sort(ql_new, dim=0, descending=True, stable=True)[1]
+                if not torch.equal(perm_old, perm_new):
+                    src = torch.empty_like(perm_old)
+                    src[perm_new] = perm_old
+                    src = L.to_device_async(src, hn.device)
+                    return hn.index_select(0, src), cn.index_select(0, src)
+            return hn, cn
         fh = self.__dict__.get("_film_hidden")
         z = self.__dict__.get("_zero_state")
         if fh is None or (z is not None and fh[0] is z[0]):
