@@ -124,10 +124,12 @@ def test_full_size_training_steps_are_sane(name):
 # logits within 1e-3 relative with the answer-class argmax bit-exact; the fp32 mode itself is pinned <= 1e-3 to the
 # reference goldens in tests/test_gpu_models.py).  Error = max |logit_bf16 - logit_fp32| / max |logit_fp32| over a
 # minibatch, worst of three minibatches (full-length and ragged), train-mode forward.
-# The attention models average frame features (errors of independent frames partly cancel): 1e-2.  The global-max-pooling
+# The attention models average frame features (errors of independent frames partly cancel): stated 1.2e-2 — measured 0.0091
+# worst of three minibatches at the headline config (round 3; 0.0095 in round 2: the figure moves by a few % whenever a kernel
+# change reorders roundings, so the stated tolerance keeps a 30 % margin instead of round 2's 5 %).  The global-max-pooling
 # heads (film_gp_pt, time_multi_hop) pick ONE frame per feature, so a near-tie between frames that flips under bf16
 # rounding moves that feature by the whole difference: stated looser, 3e-2.
-BF16_FULL_SIZE_LOGIT_TOL = {"config4_film_attn": 1e-2, "evalsh_film_attn_5x1024_bs32": 1e-2,
+BF16_FULL_SIZE_LOGIT_TOL = {"config4_film_attn": 1.2e-2, "evalsh_film_attn_5x1024_bs32": 1.2e-2,
                             "config3_film_gp": 3e-2, "config5_time_multi_hop_T70": 3e-2,
                             "evalsh_film_gp_4x1024_bs32": 3e-2, "evalsh_time_multi_hop_3x1024_bs16": 3e-2}
 
@@ -145,8 +147,8 @@ def test_bf16_vs_fp32_mode_logits_argmax_at_full_size(name):
         json.dump(res, fh, indent=1)
     print(name, json.dumps(res))
     tol = BF16_FULL_SIZE_LOGIT_TOL[name]
-    if LOW == "fp16":        # 11 significand bits instead of 8: an eighth of the bf16 error (measured 1.2e-3 at the headline config)
-        tol = tol / 4
+    if LOW == "fp16":        # 11 significand bits instead of 8: an eighth of the bf16 error (measured 1.3e-3 at the headline
+        tol = tol / 6        # config -> stated 2e-3 for the attention models, 5e-3 for the pooling heads)
     err = res[LOW + "_logits_rel_err"]
     assert err < tol, res
     assert res["loss_rel_err"] < tol, res
