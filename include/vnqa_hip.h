@@ -35,9 +35,19 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 300
+#define VNQA_ABI_VERSION 302
 int vnqa_version(void);
 const char* vnqa_last_error(void);
+
+/* CU partition for a software pipeline of full-chip kernels (the frozen stem) against a latency-bound chain of small kernels or a
+ * collective on another stream.  vnqa_stream_create_reserved: a HIP stream (hipStream_t in *stream; the caller destroys it with
+ * hipStreamDestroy) whose kernels never run on `reserve_cus` of the device's CUs (a multiple of n_cu / 8, spread evenly over the
+ * XCDs; 0 = an ordinary stream).  vnqa_set_persistent_reserve(n): the persistent one-workgroup-per-CU conv kernels size their
+ * grids for n_cu - n CUs (initial value: env VNQA_PERSISTENT_RESERVE_CUS, default 0); vnqa_persistent_reserve() reads it back. */
+int vnqa_stream_create_reserved(int32_t reserve_cus, void** stream);
+int vnqa_stream_create_masked(const uint32_t* host_mask, int32_t words, void** stream);   /* explicit mask, bit i = CU i usable */
+void vnqa_set_persistent_reserve(int32_t n);
+int32_t vnqa_persistent_reserve(void);
 
 /* ---------------------------------------------------------------------------------------
  * conv2d, stride 1, 'same' (3x3 pad 1 or 1x1), implicit GEMM on MFMA.
@@ -582,10 +592,26 @@ typedef struct vnqa_mac_core {
   float *g_wc, *g_wca, *g_wm, *g_bm, *g_w1, *g_wra, *g_wr, *g_wmm, *g_bw;
   const float* ones;
   void* workspace;                                                 /* vnqa_mac_core_workspace(n, d) bytes, or NULL */
+  int32_t defer_wgrad;   /* != 0: _bwd leaves every g_* untouched (they may be NULL); the caller keeps the per-step factors stacked
+                          * step-major and forms all parameter gradients with ONE vnqa_mac_core_wgrad call after the last step */
 } vnqa_mac_core;
 int64_t vnqa_mac_core_workspace(int32_t n, int32_t d);
 int vnqa_mac_core_fwd(const vnqa_mac_core* a, void* stream);
 int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream);
+
+/* Parameter gradients of all reasoning steps in one call (the deferred form of vnqa_mac_core_bwd's g_* accumulation; same
+ * reference lines, mac.py:28-42,53-62,82-85).  Every factor is the per-step [n][d] fp32 matrix stacked over the steps to
+ * [rows = steps * n][d] (any consistent step order).  Outputs are WRITTEN: g_wr = d_concat^T read, g_wmm = d_concat^T memory,
+ * g_w1 = v^T d_t, g_wm = d_mem^T memory, g_wc = d_cq^T control ([d][d]); g_bw / g_bm = column sums of d_concat / d_mem;
+ * g_wra[j] = sum_r dv*cnew, g_wca[j] = sum_r dqv*cq ([d]). */
+typedef struct vnqa_mac_wgrad {
+  int32_t rows, d;
+  const float *d_concat, *read, *memory, *v, *d_t, *d_mem, *d_cq, *control, *dv, *cnew, *dqv, *cq;
+  float *g_wc, *g_wca, *g_wm, *g_bm, *g_w1, *g_wra, *g_wr, *g_wmm, *g_bw;
+  void* workspace;                                                 /* vnqa_mac_core_wgrad_workspace(rows, d) bytes, or NULL */
+} vnqa_mac_wgrad;
+int64_t vnqa_mac_core_wgrad_workspace(int32_t rows, int32_t d);
+int vnqa_mac_core_wgrad(const vnqa_mac_wgrad* w, void* stream);
 
 /* Fused global-norm clip + Adam + zero_grad over flat fp32 buffers.
  * Replaces clip_grad_norm(model.parameters(), clip); optimizer.step(); optimizer.zero_grad()

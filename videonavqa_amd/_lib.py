@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 300          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 302          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -70,11 +70,25 @@ _MAC_PTRS = ("control memory pq ctxw know pre mask_c wc w_ca b_ca wm bm w1 w_ra 
 
 class MacCore(ctypes.Structure):
     """include/vnqa_hip.h: vnqa_mac_core"""
-    _fields_ = [(n, _i32) for n in ("n", "d", "lq", "s", "ld", "dtype")] + [(n, _vp) for n in _MAC_PTRS]
+    _fields_ = ([(n, _i32) for n in ("n", "d", "lq", "s", "ld", "dtype")] + [(n, _vp) for n in _MAC_PTRS]
+                + [("defer_wgrad", _i32)])
+
+
+_MAC_WGRAD_PTRS = ("d_concat read memory v d_t d_mem d_cq control dv cnew dqv cq "
+                   "g_wc g_wca g_wm g_bm g_w1 g_wra g_wr g_wmm g_bw workspace").split()
+
+
+class MacWgrad(ctypes.Structure):
+    """include/vnqa_hip.h: vnqa_mac_wgrad"""
+    _fields_ = [("rows", _i32), ("d", _i32)] + [(n, _vp) for n in _MAC_WGRAD_PTRS]
 
 _SIGNATURES = {
     "vnqa_version": (ctypes.c_int, []),
     "vnqa_last_error": (ctypes.c_char_p, []),
+    "vnqa_stream_create_reserved": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_void_p)]),
+    "vnqa_stream_create_masked": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(ctypes.c_void_p)]),
+    "vnqa_set_persistent_reserve": (None, [_i32]),
+    "vnqa_persistent_reserve": (_i32, []),
     "vnqa_conv2d_igemm_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_conv2d_c64_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_layernorm_fwd": (ctypes.c_int, [_vp] * 7 + [_i32, _i32, _f32, _vp]),
@@ -115,6 +129,8 @@ _SIGNATURES = {
     "vnqa_mac_core_workspace": (_i64, [_i32, _i32]),
     "vnqa_mac_core_fwd": (ctypes.c_int, [_vp, _vp]),
     "vnqa_mac_core_bwd": (ctypes.c_int, [_vp, _vp]),
+    "vnqa_mac_core_wgrad_workspace": (_i64, [_i32, _i32]),
+    "vnqa_mac_core_wgrad": (ctypes.c_int, [_vp, _vp]),
     "vnqa_colsum": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_gather_rows": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "vnqa_embed_proj_fwd": (ctypes.c_int, [_vp] * 8 + [_i32] * 5 + [_vp]),
@@ -237,6 +253,18 @@ def vptr(t):
 
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def reserved_stream(reserve_cus, device=None):
+    """A torch stream whose kernels never run on `reserve_cus` of the chip's CUs (vnqa_stream_create_reserved; a multiple of 32 on
+    MI355X), with the persistent conv kernels' grids sized to match.  For the frozen stem when the trunk on the other stream is
+    a latency-bound chain of small kernels (MACNetwork) or a collective must start at once (N > 1)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(dev):
+        out = ctypes.c_void_p()
+        check(lib().vnqa_stream_create_reserved(int(reserve_cus), ctypes.byref(out)), "vnqa_stream_create_reserved")
+        lib().vnqa_set_persistent_reserve(int(reserve_cus))
+        return torch.cuda.ExternalStream(out.value, device=dev)
 
 
 def dtype_id(dt):

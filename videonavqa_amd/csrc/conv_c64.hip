@@ -803,8 +803,7 @@ long long c64_grid(const C64Args& a) {
   // one persistent workgroup per CU.  VNQA_PERSISTENT_RESERVE_CUS=n leaves n CUs to the other streams for the whole
   // life of the kernel (1.0 / 0.6 ms): a knob for multi-GPU runs, where an RCCL all-reduce launched meanwhile would
   // otherwise wait for a persistent workgroup to retire before it gets its first CU.
-  static const int reserve = [] { const char* e = getenv("VNQA_PERSISTENT_RESERVE_CUS"); const int v = e ? atoi(e) : 0;
-                                  return v < 0 ? 0 : (v > 128 ? 128 : v); }();
+  const int reserve = vnqa_persistent_reserve();
   long long grid = 256 - reserve;
   grid = grid / a.nsplit * a.nsplit;
   if (grid > a.n_work) grid = (a.n_work / a.nsplit) * a.nsplit;

@@ -409,8 +409,7 @@ int wreg_launch_(WregArgs a, hipStream_t stream) {
     }
     attr_set = true;
   }
-  static const int reserve = [] { const char* e = getenv("VNQA_PERSISTENT_RESERVE_CUS"); const int v = e ? atoi(e) : 0;
-                                  return v < 0 ? 0 : (v > 128 ? 128 : v); }();
+  const int reserve = vnqa_persistent_reserve();
   int grid = (256 - reserve) & ~7;
   if (grid > a.n_tiles) grid = a.n_tiles;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, a);

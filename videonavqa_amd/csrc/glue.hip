@@ -14,6 +14,8 @@
 //   bn_running_update   the per-frame running-statistics EMA of bn_init (:211), frame by frame as the reference does
 //
 // All of it is latency-class work (a few microseconds per launch); plain FMA, exact fp32, fixed summation orders.
+#include <cstdlib>
+
 #include "vnqa_common.h"
 
 namespace {
@@ -146,6 +148,168 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __
       *dst = v;
     }
   }
+}
+
+// The same GEMM on the exact-f32 matrix core (v_mfma_f32_32x32x2_f32: each product is an fmaf into the fp32 accumulator, no
+// reduced-precision step anywhere).  Made for the products this library actually issues — [a few hundred rows] x [512] over
+// K = 512 (MACNetwork's reasoning step: 216 of them per training step), out_linear, the FiLM generators — which are latency
+// problems, not throughput problems: a workgroup is 8 waves laid out WM x WN x WK; every wave owns one 32 x 32 output tile
+// over 1/WK of the K range, loads its operands straight from L2 into the MFMA register layout (float4 along K where the
+// operand is K-contiguous — any permutation of K is valid as long as A and B use the same one), and the WK partial tiles
+// are summed through LDS in a fixed order (deterministic).  <1,1,8>: 32 x 32 tile, K split 8 ways — [280,512]x[512,512] is
+// 144 workgroups of 8 waves with 64 K-values each, i.e. the whole chip for ~32 MFMAs per wave.  <2,2,2>: 64 x 64 tiles for
+// larger outputs.  Same SgemmArgs contract / epilogue / split-K partial mode as sgemm_kernel.
+template <int WM, int WN, int WK>
+__global__ void __launch_bounds__(512) sgemm_mfma_kernel(const SgemmArgs p, float* __restrict__ partial, int k_per_slice,
+                                                         int a_vec, int b_vec) {
+  static_assert(WM * WN * WK == 8, "8 waves");
+  constexpr int TILE = 32 * 33;
+  __shared__ float red[WK * WM * WN * TILE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.y * (32 * WM), n0 = blockIdx.x * (32 * WN);
+  const int ks = blockIdx.z * k_per_slice;
+  const int kse = (ks + k_per_slice < p.K) ? ks + k_per_slice : p.K;
+  const int kper = (((kse - ks) + WK - 1) / WK + 7) / 8 * 8;
+  const int kb = ks + wk * kper;
+  const int ke = (kb + kper < kse) ? kb + kper : kse;
+  const int am = m0 + wm * 32 + r;
+  bool a_ok = am < p.M;
+  long long arow = am;
+  if (a_ok && p.a_rows != nullptr) {
+    arow = p.a_rows[am];
+    a_ok = arow >= 0;
+  }
+  const float* Ap = p.A + arow * p.a_rs;
+  const float* Mp = p.a_mask != nullptr ? p.a_mask + arow * p.a_rs : nullptr;
+  const int bn = n0 + wn * 32 + r;
+  const bool b_ok = bn < p.N;
+  const float* Bp = p.B + (long long)bn * p.b_cs;
+  auto load_a = [&](int k, float (&a)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = 0.f;
+    if (!a_ok || k >= ke) return;
+    if (a_vec && k + 3 < ke) {
+      const float4 v = *reinterpret_cast<const float4*>(Ap + k);
+      a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+      if (Mp != nullptr) {
+        const float4 q = *reinterpret_cast<const float4*>(Mp + k);
+        if (!(q.x > 0.f)) a[0] = 0.f;
+        if (!(q.y > 0.f)) a[1] = 0.f;
+        if (!(q.z > 0.f)) a[2] = 0.f;
+        if (!(q.w > 0.f)) a[3] = 0.f;
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k + j < ke) {
+        const long long off = (long long)(k + j) * p.a_cs;
+        float v = Ap[off];
+        if (Mp != nullptr && !(Mp[off] > 0.f)) v = 0.f;
+        a[j] = v;
+      }
+  };
+  auto load_b = [&](int k, float (&b)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = 0.f;
+    if (!b_ok || k >= ke) return;
+    if (b_vec && k + 3 < ke) {
+      const float4 v = *reinterpret_cast<const float4*>(Bp + k);
+      b[0] = v.x; b[1] = v.y; b[2] = v.z; b[3] = v.w;
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k + j < ke) b[j] = Bp[(long long)(k + j) * p.b_rs];
+  };
+  vnqa_f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  constexpr int U = 4;                       // chunks of 8 K-values per stage; the next stage's loads fly under this stage's MFMAs
+  float a0[U][4], b0[U][4], a1[U][4], b1[U][4];
+#pragma unroll
+  for (int c = 0; c < U; ++c) {
+    load_a(kb + 8 * c + 4 * h, a0[c]);
+    load_b(kb + 8 * c + 4 * h, b0[c]);
+  }
+  for (int k0 = kb; k0 < ke; k0 += 16 * U) {
+#pragma unroll
+    for (int c = 0; c < U; ++c) {
+      load_a(k0 + 8 * (U + c) + 4 * h, a1[c]);
+      load_b(k0 + 8 * (U + c) + 4 * h, b1[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < U; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c][j], b0[c][j], acc, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < U; ++c) {
+      load_a(k0 + 8 * (2 * U + c) + 4 * h, a0[c]);
+      load_b(k0 + 8 * (2 * U + c) + 4 * h, b0[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < U; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c][j], b1[c][j], acc, 0, 0, 0);
+  }
+  // accumulator element i of a lane: row 8 (i / 4) + 4 h + i % 4, column r
+  float* mine = red + (size_t)((wm * WN + wn) * WK + wk) * TILE;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mine[(8 * (i >> 2) + 4 * h + (i & 3)) * 33 + r] = acc[i];
+  __syncthreads();
+  for (int e = threadIdx.x; e < WM * WN * 1024; e += 512) {
+    const int t = e >> 10, idx = e & 1023, row = idx >> 5, col = idx & 31;
+    const int m = m0 + (t / WN) * 32 + row, n = n0 + (t % WN) * 32 + col;
+    if (m >= p.M || n >= p.N) continue;
+    const float* src = red + (size_t)t * WK * TILE + row * 33 + col;
+    float v = 0.f;
+#pragma unroll
+    for (int z = 0; z < WK; ++z) v += src[z * TILE];
+    if (partial != nullptr) {
+      partial[((size_t)blockIdx.z * p.M + m) * p.N + n] = v;
+      continue;
+    }
+    int orow = m;
+    if (p.c_rows != nullptr) {
+      orow = p.c_rows[m];
+      if (orow < 0) continue;
+    }
+    if (p.bias != nullptr) v += p.bias[n];
+    if (p.bias2 != nullptr) v += p.bias2[n];
+    if (p.addend != nullptr) v += p.addend[(long long)m * p.ldc + n];
+    float* dst = p.C + (long long)orow * p.ldc + n;
+    if (p.accumulate) v += *dst;
+    if (p.relu) v = fmaxf(v, 0.f);
+    *dst = v;
+  }
+}
+
+// one launch of the GEMM proper (z = split-K slices): the MFMA form unless VNQA_SGEMM_FMA=1 asks for the FMA kernel
+static bool sgemm_use_fma() {
+  static const int v = [] {
+    const char* e = getenv("VNQA_SGEMM_FMA");
+    return (e != nullptr && e[0] == '1') ? 1 : 0;
+  }();
+  return v != 0;
+}
+
+static void sgemm_launch(const SgemmArgs& p, float* partial, int kps, int nsl, hipStream_t st) {
+  if (sgemm_use_fma()) {
+    hipLaunchKernelGGL(sgemm_kernel, dim3((p.N + 63) / 64, (p.M + 63) / 64, nsl), dim3(256), 0, st, p, partial, kps);
+    return;
+  }
+  const int a_vec = (p.a_cs == 1 && p.a_rs % 4 == 0 && ((uintptr_t)p.A & 15) == 0 && kps % 8 == 0 &&
+                     (p.a_mask == nullptr || ((uintptr_t)p.a_mask & 15) == 0)) ? 1 : 0;
+  const int b_vec = (p.b_rs == 1 && p.b_cs % 4 == 0 && ((uintptr_t)p.B & 15) == 0 && kps % 8 == 0) ? 1 : 0;
+  const long long tiles32 = (long long)((p.M + 31) / 32) * ((p.N + 31) / 32);
+  if (tiles32 <= 1024)
+    hipLaunchKernelGGL((sgemm_mfma_kernel<1, 1, 8>), dim3((p.N + 31) / 32, (p.M + 31) / 32, nsl), dim3(512), 0, st, p, partial, kps,
+                       a_vec, b_vec);
+  else
+    hipLaunchKernelGGL((sgemm_mfma_kernel<2, 2, 2>), dim3((p.N + 63) / 64, (p.M + 63) / 64, nsl), dim3(512), 0, st, p, partial, kps,
+                       a_vec, b_vec);
 }
 
 // split-K second pass: sum the slices in order (deterministic), then bias / accumulate / ReLU / row scatter
@@ -336,6 +500,16 @@ __global__ void bn_running_update_kernel(const float* __restrict__ mean, const f
 // Split-K plan: few output tiles but a long K (out_linear: 8 x 70 outputs over K = 4480; the FiLM generator's d h:
 // 280 x 128 over K = 1024) would leave the chip to a handful of workgroups walking K serially at memory latency per chunk.
 static int sgemm_slices(int m, int n, int k) {
+  if (!sgemm_use_fma()) {
+    // MFMA form: a workgroup already splits its K range over 8 waves; more slices only when the output has too few
+    // 32 x 32 tiles to occupy the chip AND every slice still gets >= 128 K-values (16 per wave)
+    const long long tiles = (long long)((m + 31) / 32) * ((n + 31) / 32);
+    if (tiles >= 96 || k < 512) return 1;
+    int s = (int)((192 + tiles - 1) / tiles);
+    const int max_s = k / 128;
+    s = s > max_s ? max_s : s;
+    return s < 1 ? 1 : s;
+  }
   const int tiles = ((m + 63) / 64) * ((n + 63) / 64);
   if (tiles >= 64 || k < 256) return 1;
   int s = (128 + tiles - 1) / tiles;
@@ -361,13 +535,13 @@ extern "C" int vnqa_sgemm(const float* a, const float* b, float* c, const float*
   hipStream_t st = (hipStream_t)stream;
   const int slices = workspace != nullptr ? sgemm_slices(m, n, k) : 1;     // workspace == NULL: one pass over K
   if (slices <= 1) {
-    hipLaunchKernelGGL(sgemm_kernel, dim3((n + 63) / 64, (m + 63) / 64, 1), dim3(256), 0, st, p, (float*)nullptr, k);
+    sgemm_launch(p, nullptr, (k + 15) / 16 * 16, 1, st);
     VNQA_CHECK_LAUNCH();
     return VNQA_OK;
   }
   const int kps = ((k + slices - 1) / slices + 15) / 16 * 16;
   const int nsl = (k + kps - 1) / kps;
-  hipLaunchKernelGGL(sgemm_kernel, dim3((n + 63) / 64, (m + 63) / 64, nsl), dim3(256), 0, st, p, (float*)workspace, kps);
+  sgemm_launch(p, (float*)workspace, kps, nsl, st);
   VNQA_CHECK_LAUNCH();
   const size_t total = (size_t)m * n;
   int g = (int)((total + 255) / 256);
@@ -413,7 +587,7 @@ extern "C" int vnqa_embed_proj_fwd(const int64_t* tokens, const int32_t* row_per
   SgemmArgs p;
   p.A = embed; p.B = w_ih; p.C = xg; p.bias = b_ih; p.bias2 = b_hh; p.addend = nullptr; p.a_mask = nullptr; p.a_rows = rows; p.c_rows = nullptr;
   p.a_rs = e; p.a_cs = 1; p.b_rs = 1; p.b_cs = e; p.ldc = g; p.M = n_pos; p.N = g; p.K = e; p.relu = 0; p.accumulate = 0;
-  hipLaunchKernelGGL(sgemm_kernel, dim3((g + 63) / 64, (n_pos + 63) / 64, 1), dim3(256), 0, st, p, (float*)nullptr, e);
+  sgemm_launch(p, nullptr, (e + 15) / 16 * 16, 1, st);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -34,6 +34,25 @@ int ew_mul(float* out, const float* x, const float* y, const float* z, int n, in
   return VNQA_OK;
 }
 
+// out[j] = sum_r x[r][j] * y[r][j]: 64 columns x 16 row lanes per block, partial sums folded through LDS in a fixed order
+__global__ void __launch_bounds__(1024) dot_colsum_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          float* __restrict__ out, int rows, int cols) {
+  __shared__ float s_part[16][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
+  float s = 0.f;
+  if (n < cols)
+    for (int m = ry; m < rows; m += 16) s = fmaf(x[(size_t)m * cols + n], y[(size_t)m * cols + n], s);
+  s_part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && n < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += s_part[r][cx];
+    out[n] = t;
+  }
+}
+
 #define MC_TRY(call)             \
   do {                           \
     const int rc__ = (call);     \
@@ -90,35 +109,69 @@ extern "C" int vnqa_mac_core_fwd(const vnqa_mac_core* a, void* stream) {
 extern "C" int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream) {
   VNQA_CHECK_ARG(a != nullptr, "mac_core_bwd: null argument block");
   VNQA_CHECK_ARG(a->d_concat && a->d_control && a->d_memory && a->d_cq && a->ds_r && a->d_read && a->ds_c && a->d_c && a->du &&
-                     a->dv && a->dqv && a->d_mem && a->d_t && a->ones,
+                     a->dv && a->dqv && a->d_mem && a->d_t && (a->ones || a->defer_wgrad),
                  "mac_core_bwd: null gradient buffer");
-  VNQA_CHECK_ARG(a->g_wc && a->g_wca && a->g_wm && a->g_bm && a->g_w1 && a->g_wra && a->g_wr && a->g_wmm && a->g_bw,
+  const bool defer = a->defer_wgrad != 0;      // parameter gradients come from ONE vnqa_mac_core_wgrad call over all steps instead
+  VNQA_CHECK_ARG(defer || (a->g_wc && a->g_wca && a->g_wm && a->g_bm && a->g_w1 && a->g_wra && a->g_wr && a->g_wmm && a->g_bw),
                  "mac_core_bwd: null parameter-gradient accumulator");
   const int N = a->n, d = a->d;
   hipStream_t st = (hipStream_t)stream;
   // WriteUnit.concat
   MC_TRY(gemm_nn(a->d_concat, a->wr, a->d_read, N, d, d, 0, a->workspace, stream));
   MC_TRY(gemm_nn(a->d_concat, a->wmm, a->d_memory, N, d, d, 0, a->workspace, stream));
-  MC_TRY(gemm_tn(a->d_concat, a->read, a->g_wr, d, d, N, 1, a->workspace, stream));
-  MC_TRY(gemm_tn(a->d_concat, a->memory, a->g_wmm, d, d, N, 1, a->workspace, stream));
-  MC_TRY(gemm_tn(a->d_concat, a->ones, a->g_bw, d, 1, N, 1, a->workspace, stream));
+  if (!defer) {
+    MC_TRY(gemm_tn(a->d_concat, a->read, a->g_wr, d, d, N, 1, a->workspace, stream));
+    MC_TRY(gemm_tn(a->d_concat, a->memory, a->g_wmm, d, d, N, 1, a->workspace, stream));
+    MC_TRY(gemm_tn(a->d_concat, a->ones, a->g_bw, d, 1, N, 1, a->workspace, stream));
+  }
   // ReadUnit attention
   MC_TRY(vnqa_mac_read_bwd(a->know, a->pre, a->p_r, a->d_read, a->ds_r, a->du, a->dv, N, a->s, d, a->ld, a->dtype, stream));
   MC_TRY(ew_mul(a->d_mem, a->du, a->t, nullptr, N * d, 0, 0, st));                           // d mem = du * t
   MC_TRY(ew_mul(a->d_t, a->du, a->mem, nullptr, N * d, 0, 0, st));                           // d t   = du * mem
   MC_TRY(gemm_nt(a->d_t, a->w1, a->dv, nullptr, nullptr, N, d, d, 1, a->workspace, stream));                // dv += d t W1^T
-  MC_TRY(gemm_tn(a->v, a->d_t, a->g_w1, d, d, N, 1, a->workspace, stream));
-  MC_TRY(ew_mul(a->g_wra, a->dv, a->cnew, nullptr, N * d, 0, 1, st));                        // per-image w_ra gradient terms
+  if (!defer) {
+    MC_TRY(gemm_tn(a->v, a->d_t, a->g_w1, d, d, N, 1, a->workspace, stream));
+    MC_TRY(ew_mul(a->g_wra, a->dv, a->cnew, nullptr, N * d, 0, 1, st));                      // per-image w_ra gradient terms
+  }
   MC_TRY(ew_mul(a->d_c, a->dv, a->w_ra, a->d_cnew, N * d, d, 0, st));                        // d control' = dv * w_ra (+ upstream)
   MC_TRY(gemm_nn(a->d_mem, a->wm, a->d_memory, N, d, d, 1, a->workspace, stream));                          // d memory += d mem Wm
-  MC_TRY(gemm_tn(a->d_mem, a->memory, a->g_wm, d, d, N, 1, a->workspace, stream));
-  MC_TRY(gemm_tn(a->d_mem, a->ones, a->g_bm, d, 1, N, 1, a->workspace, stream));
+  if (!defer) {
+    MC_TRY(gemm_tn(a->d_mem, a->memory, a->g_wm, d, d, N, 1, a->workspace, stream));
+    MC_TRY(gemm_tn(a->d_mem, a->ones, a->g_bm, d, 1, N, 1, a->workspace, stream));
+  }
   if (a->mask_c != nullptr) MC_TRY(ew_mul(a->d_c, a->d_c, a->mask_c, nullptr, N * d, 0, 0, st));
   // ControlUnit attention
   MC_TRY(vnqa_mac_read_bwd(a->ctxw, nullptr, a->p_c, a->d_c, a->ds_c, a->dqv, nullptr, N, a->lq, d, d, VNQA_F32, stream));
   MC_TRY(ew_mul(a->d_cq, a->dqv, a->w_ca, nullptr, N * d, d, 0, st));                        // d cq = dqv * w_ca
-  MC_TRY(ew_mul(a->g_wca, a->dqv, a->cq, nullptr, N * d, 0, 1, st));
+  if (!defer) MC_TRY(ew_mul(a->g_wca, a->dqv, a->cq, nullptr, N * d, 0, 1, st));
   MC_TRY(gemm_nn(a->d_cq, a->wc, a->d_control, N, d, d, 0, a->workspace, stream));
-  MC_TRY(gemm_tn(a->d_cq, a->control, a->g_wc, d, d, N, 1, a->workspace, stream));
+  if (!defer) MC_TRY(gemm_tn(a->d_cq, a->control, a->g_wc, d, d, N, 1, a->workspace, stream));
+  return VNQA_OK;
+}
+
+// Parameter gradients of ALL reasoning steps at once: every factor is the per-step [n][d] matrices stacked to [rows = steps * n][d]
+// (the caller keeps them step-major in one slab), so each weight gradient is ONE product over K = rows instead of `steps`
+// accumulating products on the backward pass's dependent chain (12 steps x 9 launches off that chain).
+extern "C" int64_t vnqa_mac_core_wgrad_workspace(int32_t rows, int32_t d) { return vnqa_sgemm_workspace(d, d, rows); }
+
+extern "C" int vnqa_mac_core_wgrad(const vnqa_mac_wgrad* w, void* stream) {
+  VNQA_CHECK_ARG(w != nullptr && w->rows > 0 && w->d > 0, "mac_wgrad: bad argument block");
+  VNQA_CHECK_ARG(w->d_concat && w->read && w->memory && w->v && w->d_t && w->d_mem && w->d_cq && w->control && w->dv && w->cnew &&
+                     w->dqv && w->cq, "mac_wgrad: null factor");
+  VNQA_CHECK_ARG(w->g_wc && w->g_wca && w->g_wm && w->g_bm && w->g_w1 && w->g_wra && w->g_wr && w->g_wmm && w->g_bw,
+                 "mac_wgrad: null output");
+  const int R = w->rows, d = w->d;
+  hipStream_t st = (hipStream_t)stream;
+  MC_TRY(gemm_tn(w->d_concat, w->read, w->g_wr, d, d, R, 0, w->workspace, stream));
+  MC_TRY(gemm_tn(w->d_concat, w->memory, w->g_wmm, d, d, R, 0, w->workspace, stream));
+  MC_TRY(gemm_tn(w->v, w->d_t, w->g_w1, d, d, R, 0, w->workspace, stream));
+  MC_TRY(gemm_tn(w->d_mem, w->memory, w->g_wm, d, d, R, 0, w->workspace, stream));
+  MC_TRY(gemm_tn(w->d_cq, w->control, w->g_wc, d, d, R, 0, w->workspace, stream));
+  MC_TRY(vnqa_colsum(w->d_concat, nullptr, w->g_bw, R, d, d, VNQA_F32, stream));
+  MC_TRY(vnqa_colsum(w->d_mem, nullptr, w->g_bm, R, d, d, VNQA_F32, stream));
+  hipLaunchKernelGGL(dot_colsum_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, w->dv, w->cnew, w->g_wra, R, d);
+  VNQA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dot_colsum_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, w->dqv, w->cq, w->g_wca, R, d);
+  VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -900,10 +900,20 @@ def temporal_attn_packed_bwd(f, frame_off_i32, n_frames, B, T, A, w, coef, dctxt
     return df, dw_part, db_part
 
 
-def mac_core_call(direction, dims, tensors):
+def mac_wgrad(rows, d, tensors):
+    """vnqa_mac_core_wgrad: every parameter gradient of the MAC reasoning steps from the step-stacked [rows, d] factors."""
+    a = L.MacWgrad(rows, d)
+    for name, t in tensors.items():
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous()), name
+        setattr(a, name, None if t is None else t.data_ptr())
+    L.check(L.lib().vnqa_mac_core_wgrad(ctypes.byref(a), L.stream()), "vnqa_mac_core_wgrad")
+
+
+def mac_core_call(direction, dims, tensors, defer_wgrad=False):
     """vnqa_mac_core_fwd / _bwd: `dims` = (n, d, lq, s, ld, dtype id), `tensors` = {field name: tensor or None}."""
     a = L.MacCore(*dims)
     for name, t in tensors.items():
         setattr(a, name, None if t is None else t.data_ptr())
+    a.defer_wgrad = 1 if defer_wgrad else 0
     fn = L.lib().vnqa_mac_core_fwd if direction == "fwd" else L.lib().vnqa_mac_core_bwd
     L.check(fn(ctypes.byref(a), L.stream()), "vnqa_mac_core_" + direction)

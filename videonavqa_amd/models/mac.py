@@ -70,6 +70,12 @@ def _write_unit(dim, self_attention, memory_gate):   # mac.py:66-80
 class MACNetwork(nn.Module):
     """Positional signature and defaults of mac.py:169-171; keyword-only extras: precision."""
 
+    # train.Trainer can keep this many CUs free of the frozen stem's kernels (CU-masked stem stream).  Measured for this model's
+    # ~1 000-launch reasoning chain (tools/ab_mac.sh): 0 -> 414 clips/s, 32 -> 286, 64 -> 280 — the chain's workgroups are dealt
+    # to ALL CUs whatever the stem leaves free, so they still queue behind stem workgroups, and the stem itself loses 1/8 of
+    # the chip.  Hence 0: stem and chain run back to back (6.6 + 11.3 ms).
+    stem_reserve_cus = 0
+
     def __init__(self, n_vocab, dim, embed_hidden=300, max_step=12, self_attention=False, memory_gate=False,
                  classes=28, dropout=0.15, max_num_frames=35, *, precision='bf16'):
         super(MACNetwork, self).__init__()
@@ -180,7 +186,7 @@ class MACNetwork(nn.Module):
         # step-invariant half of ReadUnit.concat on the MFMA GEMM: know W2^T + b (kept in the compute dtype)
         w2 = F.pad(m.read.concat.weight[:, dim:], (0, c_pad - dim, 0, c_pad - dim))
         pre = ops.linear_nt(kd, w2, F.pad(m.read.concat.bias, (0, c_pad - dim)))
-        state = ops.MacCoreState()
+        state = ops.MacCoreState(self.max_step)
         wc, w1 = wcq[:, :dim], m.read.concat.weight[:, :dim]
         wr, wmm = m.write.concat.weight[:, :dim], m.write.concat.weight[:, dim:]
         masks = self._masks(n_img, dev)

@@ -602,47 +602,62 @@ def fc_native(x, weight, bias, C, h, w, rows_pad, grad_scale=1.0):
 
 
 class MacCoreState(object):
-    """Shared by the MacCoreFn nodes of one forward: per-step factors of the two attention pools (question words,
-    knowledge base) whose [N, positions, C] gradients are formed once, in the first step's backward (see MacReadFn)."""
+    """Shared by the MacCoreFn nodes of one forward.  `n_steps` (the number of reasoning steps that will be issued) lets the
+    C-ABI node keep every per-step matrix STEP-STACKED in two slabs (forward factors, backward factors): field f of step i
+    lives at slab[f][i], so [n_steps * N, d] views of a field are free and the last node to run forms all parameter
+    gradients (vnqa_mac_core_wgrad) and the [N, positions, C] attention-pool gradients (mac_read_accum) in one call each."""
 
-    def __init__(self):
+    def __init__(self, n_steps=None):
+        self.n_steps = n_steps
         self.n_calls = 0
         self.ctrl = []
         self.read = []
         self.grads = {}
         self.grads_meta = {}
+        self.fwd = None          # {field: [n_steps, N, width]} views of the forward slab
+        self.bwd = None
+        self.outer = {}          # step index -> (control, memory, d_concat): the factors that arrive from outside the node
 
 
 class MacCoreFn(torch.autograd.Function):
     """One MAC reasoning step (ControlUnit, ReadUnit and WriteUnit.concat of models/mac.py:28-42,53-62,82-85) for all
     packed images as ONE autograd node whose forward and backward are ONE C-ABI call each (vnqa_mac_core_fwd / _bwd,
-    csrc/mac_core.hip): the ~11 / ~25 launches of a step are enqueued from C++.  `--model mac` was bound by the launch
-    thread (16.7 ms of host time against 13.8 ms of kernels per training step), not by the GPU.
+    csrc/mac_core.hip): the launches of a step are enqueued from C++, its [N, d] x [d, d] products run on the exact-f32 MFMA
+    GEMM, and the parameter gradients of all steps are formed once, after the last step's backward, from step-stacked
+    factors (vnqa_mac_core_wgrad: one product over K = steps * N per weight instead of `steps` products on the dependent chain).
 
       cq      = control Wc^T + pq                       (pq = position_aware_i(question) Wp^T + b, hoisted by the caller)
       control'= pool(ctx, cq * w_ca, b_ca) [* mask]     (attention over the question words)
       mem     = memory Wm^T + bm ;  v = control' * w_ra ;  u = mem * (v W1)
       read    = pool(know, pre; u, v, b_ra)             (re-associated ReadUnit, see models/mac.py)
       concat  = read Wr^T + memory Wmm^T + bw
-    Returns (control', concat); self-attention / memory gate / the memory dropout mask stay with the caller.  Parameter
-    gradients are accumulated over the steps in the shared state and handed to autograd once, by the first step's node
-    (which the engine necessarily runs last)."""
+    Returns (control', concat); self-attention / memory gate / the memory dropout mask stay with the caller."""
 
     FWD = ("cq", "qv", "cnew", "mem", "v", "t", "u", "read", "concat")          # [N, d] each, then p_c [N, Lq], p_r [N, S]
+    BWD = ("d_control", "d_memory", "d_cq", "d_read", "d_c", "du", "dv", "dqv", "d_mem", "d_t")   # then ds_r [N,S], ds_c [N,Lq]
+
+    @staticmethod
+    def _slab(names, widths, n_steps, N, dev):
+        total = sum(widths)
+        buf = torch.empty(n_steps * N * total, dtype=torch.float32, device=dev)      # ONE allocation, field-major
+        out, o = {}, 0
+        for n, wd in zip(names, widths):
+            out[n] = buf[o:o + n_steps * N * wd].view(n_steps, N, wd)
+            o += n_steps * N * wd
+        return out
 
     @staticmethod
     def forward(ctx_, control, memory, pq, ctxw, know, pre, mask_c, wc, w_ca, b_ca, wm, bm, w1, w_ra, b_ra, wr, wmm, bw,
                 state, Lq, S):
         N, d = control.shape
         dev = control.device
-        buf = torch.empty(9 * N * d + N * Lq + N * S, dtype=torch.float32, device=dev)      # ONE allocation for all outputs
-        out = {n: buf[i * N * d:(i + 1) * N * d].view(N, d) for i, n in enumerate(MacCoreFn.FWD)}
-        out["p_c"] = buf[9 * N * d: 9 * N * d + N * Lq].view(N, Lq)
-        out["p_r"] = buf[9 * N * d + N * Lq:].view(N, S)
-        if "ws" not in state.grads_meta:
-            import os
-            nb = L.lib().vnqa_mac_core_workspace(N, d) if os.environ.get("VNQA_MAC_SPLITK", "1") != "0" else 0
+        assert state.n_steps is not None and state.n_calls < state.n_steps, "MacCoreState(n_steps) too small for this forward"
+        if state.fwd is None:
+            state.fwd = MacCoreFn._slab(MacCoreFn.FWD + ("p_c", "p_r"), [d] * 9 + [Lq, S], state.n_steps, N, dev)
+            nb = L.lib().vnqa_mac_core_workspace(N, d)
             state.grads_meta["ws"] = K.workspace(nb, dev) if nb > 0 else None
+        i = state.n_calls
+        out = {n: v[i] for n, v in state.fwd.items()}
         f32 = lambda t: t.detach().float().contiguous()
         inputs = dict(control=f32(control), memory=f32(memory), pq=f32(pq), ctxw=ctxw, know=know, pre=pre,
                       mask_c=None if mask_c is None else f32(mask_c), wc=f32(wc), w_ca=f32(w_ca), b_ca=f32(b_ca), wm=f32(wm),
@@ -651,8 +666,8 @@ class MacCoreFn(torch.autograd.Function):
         K.mac_core_call("fwd", dims, dict(inputs, workspace=state.grads_meta["ws"], **out))
         ctx_.save_for_backward(*[inputs[k] for k in ("control", "memory", "ctxw", "know", "pre")],
                                inputs["mask_c"], *[inputs[k] for k in ("wc", "w_ca", "b_ca", "wm", "bm", "w1", "w_ra", "b_ra",
-                                                                       "wr", "wmm", "bw")], buf)
-        ctx_.state, ctx_.dims, ctx_.index = state, dims, state.n_calls
+                                                                       "wr", "wmm", "bw")])
+        ctx_.state, ctx_.dims, ctx_.index = state, dims, i
         state.n_calls += 1
         return out["cnew"], out["concat"]
 
@@ -661,60 +676,55 @@ class MacCoreFn(torch.autograd.Function):
         sv = ctx_.saved_tensors
         control, memory, ctxw, know, pre, mask_c = sv[:6]
         wc, w_ca, b_ca, wm, bm, w1, w_ra, b_ra, wr, wmm, bw = sv[6:17]
-        buf = sv[17]
         N, d, Lq, S, ld, did = ctx_.dims
         dev = control.device
-        st = ctx_.state
-        out = {n: buf[i * N * d:(i + 1) * N * d].view(N, d) for i, n in enumerate(MacCoreFn.FWD)}
-        out["p_c"] = buf[9 * N * d: 9 * N * d + N * Lq].view(N, Lq)
-        out["p_r"] = buf[9 * N * d + N * Lq:].view(N, S)
-        G = st.grads
-        if not G:
-            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-            # ONE zero-filled buffer for all parameter-gradient accumulators of the 12 steps
-            acc = z(6 * d * d + 2 * N * d + 2 * d)
-            o = [0]
-
-            def take(n, *shape):
-                v = acc[o[0]:o[0] + n].view(*shape)
-                o[0] += n
-                return v
-            G.update(g_wc=take(d * d, d, d), g_wm=take(d * d, d, d), g_w1=take(d * d, d, d), g_wr=take(d * d, d, d),
-                     g_wmm=take(d * d, d, d), g_wca=take(N * d, N, d), g_wra=take(N * d, N, d), g_bm=take(d, d),
-                     g_bw=take(d, d), ones=torch.ones(N, dtype=torch.float32, device=dev))
-        # per-step gradient buffers: outputs (3 x [N,d]), factors kept for the final accumulation (d_read, d_c [N,d];
-        # ds_r [N,S]; ds_c [N,Lq]) and scratch (du, dv, dqv, d_mem, d_t)
-        gb = torch.empty(10 * N * d + N * S + N * Lq, dtype=torch.float32, device=dev)
-        names = ("d_control", "d_memory", "d_cq", "d_read", "d_c", "du", "dv", "dqv", "d_mem", "d_t")
-        g = {n: gb[i * N * d:(i + 1) * N * d].view(N, d) for i, n in enumerate(names)}
-        g["ds_r"] = gb[10 * N * d:10 * N * d + N * S].view(N, S)
-        g["ds_c"] = gb[10 * N * d + N * S:].view(N, Lq)
+        st, i = ctx_.state, ctx_.index
+        n_used = st.n_calls
+        if st.bwd is None:
+            st.bwd = MacCoreFn._slab(MacCoreFn.BWD + ("ds_r", "ds_c"), [d] * 10 + [S, Lq], n_used, N, dev)
+        out = {n: v[i] for n, v in st.fwd.items()}
+        g = {n: v[i] for n, v in st.bwd.items()}
+        d_concat = d_concat.float().contiguous()
         args = dict(control=control, memory=memory, ctxw=ctxw, know=know, pre=pre, mask_c=mask_c, wc=wc, w_ca=w_ca, b_ca=b_ca,
                     wm=wm, bm=bm, w1=w1, w_ra=w_ra, b_ra=b_ra, wr=wr, wmm=wmm, bw=bw,
-                    d_cnew=None if d_cnew is None else d_cnew.float().contiguous(), d_concat=d_concat.float().contiguous(),
+                    d_cnew=None if d_cnew is None else d_cnew.float().contiguous(), d_concat=d_concat,
                     workspace=st.grads_meta.get("ws"))
         args.update(out)
         args.update(g)
-        args.update(G)
-        K.mac_core_call("bwd", (N, d, Lq, S, ld, did), args)
-        st.read.append((g["ds_r"], out["p_r"], out["u"], out["v"], g["d_read"]))
-        st.ctrl.append((g["ds_c"], out["p_c"], out["qv"], g["d_c"]))
+        K.mac_core_call("bwd", (N, d, Lq, S, ld, did), args, defer_wgrad=True)
+        st.outer[i] = (control, memory, d_concat)
         d_ctxw = d_know = d_pre = None
         gp = [None] * 11
-        if ctx_.index == 0:      # runs last: every later step depends on this one's outputs
-            f = [torch.stack(x) for x in zip(*st.read)]
-            d_know, d_pre = K.mac_read_accum(f[0], f[1], f[2], f[3], f[4], N, S, d, ld, know.dtype)
-            c = [torch.stack(x) for x in zip(*st.ctrl)]
-            d_ctxw, _ = K.mac_read_accum(c[0], c[1], c[2], None, c[3], N, Lq, d, ctxw.shape[-1], ctxw.dtype)
-            gp = [G["g_wc"], K.colsum(G["g_wca"]).view(1, d), c[0].sum().view(1), G["g_wm"], G["g_bm"],
-                  G["g_w1"], K.colsum(G["g_wra"]).view(1, d), f[0].sum().view(1), G["g_wr"], G["g_wmm"], G["g_bw"]]
-            st.read, st.ctrl, st.grads = [], [], {}
+        if i == 0:               # runs last: every later step depends on this one's outputs
+            F_, B_ = st.fwd, st.bwd
+            used = lambda t: t[:n_used]
+            d_know, d_pre = K.mac_read_accum(used(B_["ds_r"]), used(F_["p_r"]), used(F_["u"]), used(F_["v"]), used(B_["d_read"]),
+                                             N, S, d, ld, know.dtype)
+            d_ctxw, _ = K.mac_read_accum(used(B_["ds_c"]), used(F_["p_c"]), used(F_["qv"]), None, used(B_["d_c"]), N, Lq, d,
+                                         ctxw.shape[-1], ctxw.dtype)
+            rows = n_used * N
+            order = range(n_used)
+            stack = lambda k: torch.stack([st.outer[j][k] for j in order]).view(rows, d)
+            flat = lambda t: used(t).reshape(rows, d)
+            gw = torch.empty(5 * d * d + 4 * d, dtype=torch.float32, device=dev)
+            names = ("g_wc", "g_wm", "g_w1", "g_wr", "g_wmm")
+            G = {n: gw[k * d * d:(k + 1) * d * d].view(d, d) for k, n in enumerate(names)}
+            for k, n in enumerate(("g_wca", "g_wra", "g_bm", "g_bw")):
+                G[n] = gw[5 * d * d + k * d: 5 * d * d + (k + 1) * d]
+            nb = L.lib().vnqa_mac_core_wgrad_workspace(rows, d)
+            K.mac_wgrad(rows, d, dict(d_concat=stack(2), read=flat(F_["read"]), memory=stack(1), v=flat(F_["v"]),
+                                      d_t=flat(B_["d_t"]), d_mem=flat(B_["d_mem"]), d_cq=flat(B_["d_cq"]), control=stack(0),
+                                      dv=flat(B_["dv"]), cnew=flat(F_["cnew"]), dqv=flat(B_["dqv"]), cq=flat(F_["cq"]),
+                                      workspace=K.workspace(nb, dev) if nb > 0 else None, **G))
+            gp = [G["g_wc"], G["g_wca"].view(1, d), used(B_["ds_c"]).sum().view(1), G["g_wm"], G["g_bm"],
+                  G["g_w1"], G["g_wra"].view(1, d), used(B_["ds_r"]).sum().view(1), G["g_wr"], G["g_wmm"], G["g_bw"]]
+            st.outer, st.fwd, st.bwd = {}, None, None
         return (g["d_control"], g["d_memory"], g["d_cq"], d_ctxw, d_know, d_pre, None, gp[0], gp[1], gp[2], gp[3], gp[4],
                 gp[5], gp[6], gp[7], gp[8], gp[9], gp[10], None, None, None)
 
 
 class MacCoreTorchFn(torch.autograd.Function):
-    """(The default of ops.mac_core: the node issued op by op from Python on torch / rocBLAS GEMMs.)
+    """(VNQA_MAC_CORE_TORCH=1: the node issued op by op from Python on torch / rocBLAS GEMMs; the A/B partner of MacCoreFn.)
     One MAC reasoning step (ControlUnit, ReadUnit and WriteUnit.concat of models/mac.py:28-42,53-62,82-85) for all
     packed images as ONE autograd node: inside, plain torch GEMMs and the fused attention kernels run without graph
     recording, and the backward is written out by hand.  Motivation: the MAC training step was bound by the launch
@@ -809,15 +819,13 @@ class MacCoreTorchFn(torch.autograd.Function):
 
 
 def mac_core(*args):
-    """Default: the op-by-op node on rocBLAS GEMMs (MacCoreTorchFn).  VNQA_MAC_CORE_CABI=1 selects the one-call-per-direction
-    C-ABI form (MacCoreFn): same results (tests/test_gpu_mac.py runs both), ~430 fewer Python-issued launches per training
-    step, but measured 12 % SLOWER end to end (355 vs 405 clips/s, `tools/ab_mac.sh`): its 204 fp32 GEMMs of
-    [n_img, dim] x [dim, dim] run on the plain-FMA vnqa_sgemm at 19 us each against rocBLAS' 9 us, which costs more than the
-    launch thread saves.  It becomes the default once those products run on the exact-f32 MFMA GEMM with fused epilogues."""
+    """Default: the C-ABI node (MacCoreFn: one call per direction, exact-f32 MFMA products, parameter gradients deferred to
+    one vnqa_mac_core_wgrad call).  VNQA_MAC_CORE_TORCH=1 selects the op-by-op node on torch / rocBLAS GEMMs (MacCoreTorchFn) for
+    the A/B (`tools/ab_mac.sh`); tests/test_gpu_mac.py runs both against the reference goldens."""
     import os
-    if os.environ.get("VNQA_MAC_CORE_CABI", "0") == "1":
-        return MacCoreFn.apply(*args)
-    return MacCoreTorchFn.apply(*args)
+    if os.environ.get("VNQA_MAC_CORE_TORCH", "0") == "1" or os.environ.get("VNQA_MAC_CORE_CABI", "1") == "0":
+        return MacCoreTorchFn.apply(*args)
+    return MacCoreFn.apply(*args)
 
 
 # ---- question path / classifier / loss on csrc/glue.hip (no ATen / rocBLAS kernels in the step) --------------------------

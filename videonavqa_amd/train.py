@@ -159,7 +159,18 @@ class Trainer(object):
         self.stem_device = self.fp.flat.device
         self.copy_stream = None
         prio = int(os.environ.get("VNQA_STEM_PRIO", "0"))
-        self.stem_stream = torch.cuda.Stream(priority=prio)
+        # CU partition: a model whose trunk is a long dependent chain of SMALL kernels (MACNetwork: ~1 000 launches per step)
+        # cannot overlap with full-chip stem kernels that own every CU's LDS — each small kernel would wait for stem workgroups to
+        # retire.  Such a model asks for `stem_reserve_cus` CUs the stem stream never touches (its own attribute; env
+        # VNQA_STEM_RESERVE_CUS overrides, 0 = off): the chain runs there at once, the stem on the rest.
+        reserve = os.environ.get("VNQA_STEM_RESERVE_CUS")
+        reserve = int(reserve) if reserve is not None else int(getattr(model, "stem_reserve_cus", 0))
+        self.stem_reserve_cus = reserve if (stem is not None and self.fp.flat.is_cuda) else 0
+        if self.stem_reserve_cus > 0:
+            from . import _lib as L
+            self.stem_stream = L.reserved_stream(self.stem_reserve_cus, self.stem_device)
+        else:
+            self.stem_stream = torch.cuda.Stream(priority=prio)
         tprio = os.environ.get("VNQA_TRUNK_PRIO")
         self.trunk_stream = torch.cuda.Stream(priority=int(tprio)) if tprio is not None else None
         self._prefetched = None          # (key, NativeFeatures, v_sorted, perm, done_event)
