@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 302
+#define VNQA_ABI_VERSION 303
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -626,6 +626,59 @@ int vnqa_l2norm_partial(const float* g, int64_t n, float* partial, void* stream)
 int vnqa_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const float* partial,
                    int32_t n_partial, float clip, float lr, float beta1, float beta2, float eps,
                    int32_t step, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * VideoOnlyCNN3D (models/v_only_cnn3d.py:13-37,59-81) — csrc/cnn3d.hip.  16-bit storage format only.
+ *
+ * BatchNorm in train mode is three steps: partial (sum, sum of squares) per block -> vnqa_bn_finalize (mean, rstd, running
+ * statistics with the unbiased variance, momentum as nn.BatchNorm) -> apply.  Partials are [blocks][c][2] fp32 and are produced
+ * by vnqa_c3d_stats_ncdhw (fp32 [n][c][s] input, blocks = n * chunks), vnqa_c3d_stats_rows (dense [rows][c],
+ * blocks = vnqa_c3d_stats_blocks(rows)), vnqa_c3d_conv1_fwd (blocks = vnqa_c3d_conv1_fwd_blocks) and vnqa_pool444_fwd
+ * (blocks = vnqa_pool444_blocks).
+ *
+ * vnqa_view5: where element (n, d, h, w, c) of a tensor lives, in ELEMENTS: base + n sn + d sd + h sh + w sw + c sc; the row index
+ * of the dense operand runs over (n, d, h, w) with extents d, h, w.  Serves padded NDHWC (the next conv's input), dense rows and
+ * the NC(DHW)-flattened fp32 feature matrix alike.
+ *   vnqa_bn_rows_apply : out(view) = gamma (x - mean) rstd + beta, x dense [rows][c]
+ *   vnqa_bn_rows_bwd   : dx dense [rows][c] = gamma rstd (dy - mean(dy) - x^ mean(dy x^)), dgamma = sum dy x^ / grad_scale,
+ *                        dbeta = sum dy / grad_scale; workspace (vnqa_c3d_stats_blocks(rows) * c * 2 + 2 c) floats
+ *   vnqa_pool444_fwd/bwd : MaxPool3d(4,4,4) of a padded NDHWC conv output y (ReLU already applied) -> p dense
+ *                        [n][d/4][h/4][w/4][c] + arg-max bytes (255: maximum not positive) + statistics of p; backward writes the
+ *                        whole interior of the padded dy (zero where not an arg-max), never the halo
+ *   vnqa_c3d_conv1_fwd : p = MaxPool3d(1,2,2)(relu(conv3d(bn_input(x), weight) + bias)) straight from the fp32 [n][3][d][h][w]
+ *                        clip: p dense [n][d][h/2][w/2][64], idx = arg-max 0..3 in (h, w) order (+4: not positive), statistics of p.
+ *                        h, w multiples of 16 (vnqa_c3d_conv1_supported)
+ *   vnqa_c3d_conv1_bwd : from dp (gradient wrt p): dweight [64][3][27], dbias [64], and bn_input's dgamma / dbeta [3], all
+ *                        divided by grad_scale; partial: (vnqa_c3d_conv1_bwd_blocks + 16) * 64 * 112 floats
+ */
+typedef struct vnqa_view5 {
+  int64_t base, sn, sd, sh, sw, sc;
+  int32_t d, h, w;
+} vnqa_view5;
+int32_t vnqa_c3d_stats_blocks(int64_t rows);
+int vnqa_c3d_stats_ncdhw(const float* x, float* partial, int32_t n, int32_t c, int64_t s, int32_t chunks, void* stream);
+int vnqa_c3d_stats_rows(const void* x, float* partial, int64_t rows, int32_t c, int32_t dtype, void* stream);
+int vnqa_bn_finalize(const float* partial, int32_t nblk, int32_t c, double count, float eps, float momentum, float* mean,
+                     float* rstd, float* running_mean, float* running_var, void* stream);
+int vnqa_bn_rows_apply(const void* x, int32_t x_dtype, void* out, int32_t out_dtype, const vnqa_view5* out_view, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta, int64_t rows, int32_t c, void* stream);
+int vnqa_bn_rows_bwd(const void* dy, int32_t dy_dtype, const vnqa_view5* dy_view, const void* x, int32_t x_dtype, void* dx,
+                     int32_t dx_dtype, const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta,
+                     float* workspace, float grad_scale, int64_t rows, int32_t c, void* stream);
+int32_t vnqa_pool444_blocks(int32_t n, int32_t d, int32_t h, int32_t w, int32_t c);
+int vnqa_pool444_fwd(const void* y, void* p, uint8_t* idx, float* partial, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                     void* stream);
+int vnqa_pool444_bwd(const void* dp, const uint8_t* idx, void* dy, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                     void* stream);
+int vnqa_c3d_conv1_supported(int32_t n, int32_t d, int32_t h, int32_t w);
+int32_t vnqa_c3d_conv1_fwd_blocks(int32_t n, int32_t h, int32_t w);
+int32_t vnqa_c3d_conv1_bwd_blocks(int32_t n, int32_t h, int32_t w);
+int vnqa_c3d_conv1_fwd(const float* x, const float* weight, const float* bias, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, void* p, uint8_t* idx, float* partial, int32_t n, int32_t d,
+                       int32_t h, int32_t w, void* stream);
+int vnqa_c3d_conv1_bwd(const float* x, const float* weight, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const void* dp, const uint8_t* idx, float* partial, float grad_scale, float* dweight,
+                       float* dbias, float* dgamma, float* dbeta, int32_t n, int32_t d, int32_t h, int32_t w, void* stream);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 302          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 303          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -76,6 +76,11 @@ class MacCore(ctypes.Structure):
 
 _MAC_WGRAD_PTRS = ("d_concat read memory v d_t d_mem d_cq control dv cnew dqv cq "
                    "g_wc g_wca g_wm g_bm g_w1 g_wra g_wr g_wmm g_bw workspace").split()
+
+
+class View5(ctypes.Structure):
+    """include/vnqa_hip.h: vnqa_view5 (element strides of an (n, d, h, w, c)-indexed tensor)"""
+    _fields_ = [(n, _i64) for n in ("base", "sn", "sd", "sh", "sw", "sc")] + [(n, _i32) for n in ("d", "h", "w")]
 
 
 class MacWgrad(ctypes.Structure):
@@ -129,6 +134,21 @@ _SIGNATURES = {
     "vnqa_mac_core_workspace": (_i64, [_i32, _i32]),
     "vnqa_mac_core_fwd": (ctypes.c_int, [_vp, _vp]),
     "vnqa_mac_core_bwd": (ctypes.c_int, [_vp, _vp]),
+    "vnqa_c3d_stats_blocks": (_i32, [_i64]),
+    "vnqa_c3d_stats_ncdhw": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _vp]),
+    "vnqa_c3d_stats_rows": (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "vnqa_bn_finalize": (ctypes.c_int, [_vp, _i32, _i32, ctypes.c_double, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "vnqa_bn_rows_apply": (ctypes.c_int, [_vp, _i32, _vp, _i32, ctypes.POINTER(View5), _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "vnqa_bn_rows_bwd": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(View5), _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _f32, _i64, _i32, _vp]),
+    "vnqa_pool444_blocks": (_i32, [_i32] * 5),
+    "vnqa_pool444_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 5 + [_vp]),
+    "vnqa_pool444_bwd": (ctypes.c_int, [_vp, _vp, _vp] + [_i32] * 5 + [_vp]),
+    "vnqa_c3d_conv1_supported": (ctypes.c_int, [_i32] * 4),
+    "vnqa_c3d_conv1_fwd_blocks": (_i32, [_i32] * 3),
+    "vnqa_c3d_conv1_bwd_blocks": (_i32, [_i32] * 3),
+    "vnqa_c3d_conv1_fwd": (ctypes.c_int, [_vp] * 10 + [_i32] * 4 + [_vp]),
+    "vnqa_c3d_conv1_bwd": (ctypes.c_int, [_vp] * 9 + [_f32] + [_vp] * 4 + [_i32] * 4 + [_vp]),
     "vnqa_mac_core_wgrad_workspace": (_i64, [_i32, _i32]),
     "vnqa_mac_core_wgrad": (ctypes.c_int, [_vp, _vp]),
     "vnqa_colsum": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -32,6 +32,7 @@ struct WgradArgs {
   int Cin, Cout, taps;
   int tilesCo, tilesCi;
   int ksteps_total, ksteps_per_slice, slices;
+  int taps_real;    // SMALL form: `taps` counts tap GROUPS of 256 / Cin taps; this is the conv's tap count (27)
 };
 
 __device__ __forceinline__ void glds16w(const char* src, char* lds_wave_base) {
@@ -70,8 +71,13 @@ __device__ __forceinline__ void lds_tr_wait() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ int swz_tr(int row) { return ((row & 3) << 2) | (((row >> 3) & 1) << 1); }
 
 // BM = BN = 256 channels, 8 waves as 2 (co) x 4 (ci): wave tile 128 co x 64 ci.
-template <typename T>
+// SMALL (bf16, C_out <= 128, C_in = 64 or 128 — the Conv3d layers of v_only_cnn3d): the 256 "ci" columns of a tile are
+// 256 / C_in TAPS side by side (each its own row shift of X), and the two co halves of the wave grid, which would be idle,
+// take the two 32-pixel substeps of a K-step instead (two partial slabs per slice): a tile is 128 co x (4 taps x 64 ci) at
+// the full kernel's MFMA : LDS ratio, where the plain tiling would use 1/8 of its 256 x 256 tile.
+template <typename T, bool SMALL = false>
 __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
+  static_assert(!SMALL || sizeof(T) == 2, "the small-channel form is 16-bit only");
   constexpr int ES = (int)sizeof(T);
   constexpr int BCH = 256;                 // channels per tile side
   constexpr int RB = BCH * ES;             // LDS row bytes
@@ -106,7 +112,12 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
   const int slice = bid;
 
   int dtap = 0;
-  if (p.taps == 9) {
+  auto tap_shift3d = [&](int t) {
+    const int q = t / 9, rs = t - 9 * q, r = rs / 3, s = rs - 3 * r;
+    return ((q - 1) * p.Hp + (r - 1)) * p.Wp + (s - 1);
+  };
+  if constexpr (SMALL) {
+  } else if (p.taps == 9) {
     const int r = tap / 3, s = tap - 3 * r;
     dtap = (r - 1) * p.Wp + (s - 1);
   } else if (p.taps == 27) {
@@ -115,7 +126,8 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
   }
 
   // ---- per-lane staging geometry: instruction q = wave*4 + j covers 1 KiB of the tile ----
-  int st_row[4], st_coff_a[4], st_coff_b[4];
+  int st_row[4], st_coff_a[4], st_coff_b[4], st_dtap[4];
+  bool st_tap_ok[4], st_a_ok[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int lin = (wave * 4 + j) * 64 + lane;   // 16-byte chunk index within the tile
@@ -129,6 +141,16 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
     cb = cb < p.Cin ? cb : p.Cin - (16 / ES);
     st_coff_a[j] = ca * ES;
     st_coff_b[j] = cb * ES;
+    st_dtap[j] = dtap;
+    st_tap_ok[j] = true;
+    st_a_ok[j] = !SMALL || logical * (16 / ES) < p.Cout;     // SMALL: the tile's co columns past C_out are never read
+    if constexpr (SMALL) {
+      const int cpt = p.Cin >> 3;                         // 16-byte chunks per tap
+      const int sub = logical / cpt, tapid = tap * (32 / cpt) + sub;
+      st_tap_ok[j] = tapid < p.taps_real;
+      st_dtap[j] = st_tap_ok[j] ? tap_shift3d(tapid) : 0;
+      st_coff_b[j] = (logical - sub * cpt) * 16;
+    }
   }
   const size_t rowA = (size_t)p.Cout * ES, rowB = (size_t)p.Cin * ES;
 
@@ -165,14 +187,15 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
         const unsigned y = __umulhi(rem, p.vw_magic);
         pa += (long long)(y * (unsigned)p.Wp + (rem - y * (unsigned)p.vw));
       }
-      long long pb = pa + dtap;
+      long long pb = pa + st_dtap[j];
       pb = pb < 0 ? 0 : (pb < p.Ptot ? pb : p.Ptot - 1);
       const char* srcA = st_v[j] < p.Vtot ? p.dy + (size_t)pa * rowA + st_coff_a[j] : (const char*)vnqa_zero_page;
 #ifndef VNQA_WGRAD_DIAG_NO_A
-      glds16w(srcA, lds + (wave * 4 + j) * 1024);
+      if (st_a_ok[j]) glds16w(srcA, lds + (wave * 4 + j) * 1024);
 #endif
 #ifndef VNQA_WGRAD_DIAG_NO_B
-      glds16w(p.x + (size_t)pb * rowB + st_coff_b[j], lds + TILE_BYTES + (wave * 4 + j) * 1024);
+      glds16w(st_tap_ok[j] ? p.x + (size_t)pb * rowB + st_coff_b[j] : (const char*)vnqa_zero_page,
+              lds + TILE_BYTES + (wave * 4 + j) * 1024);
 #endif
       st_v[j] += KP;
       if (p.vrow > 0) {
@@ -220,6 +243,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
     __builtin_amdgcn_s_barrier();
   };
 
+  const int wmA = SMALL ? 0 : wm * 128;                   // first co column of this wave's fragments
   // fragment-read lane geometry
   const int g = lane >> 4, il = lane & 15, q4 = il >> 2, pp = il & 3;  // tr-read roles
   const int fh = lane >> 5, fr = lane & 31;                            // mfma roles
@@ -246,7 +270,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
 #ifdef VNQA_WGRAD_TR_BUILTIN
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const int off = ((((wm * 128 + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4;
+            const int off = ((((wmA + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4;
             const s16x4 lo = lds_tr_read(ldsA + row0 * RB + off + sub);
             const s16x4 hi = lds_tr_read(ldsA + (row0 + 4) * RB + off + sub);
             af[i] = vnqa_bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -263,7 +287,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
           s16x4 alo[8], ahi[8], blo[4], bhi[4];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const unsigned a = baseA + (((((wm * 128 + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
+            const unsigned a = baseA + (((((wmA + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
             alo[i] = lds_tr_read_asm<0>(a);
             ahi[i] = lds_tr_read_asm<4 * RB>(a);
           }
@@ -302,6 +326,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
 #elif defined(VNQA_WGRAD_TR_BUILTIN) || !defined(VNQA_WGRAD_ROLLING)
 #pragma unroll
         for (int s = 0; s < KP / 32; ++s) {
+          if (SMALL && s != wm) continue;                 // SMALL: this wave's co half is a pixel half instead
           vnqa_bf16x8 af[8], bf[4];
           load16(s, af, bf);
 #pragma unroll
@@ -325,7 +350,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
           const unsigned baseA = lds_addr(ldsA) + row0 * RB + sub, baseB = lds_addr(ldsB) + row0 * RB + sub;
           s16x4 alo[8], ahi[8], blo[4], bhi[4];
           auto req_a = [&](int i) {
-            const unsigned a = baseA + (((((wm * 128 + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
+            const unsigned a = baseA + (((((wmA + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
             alo[i] = lds_tr_read_asm<0>(a);
             ahi[i] = lds_tr_read_asm<4 * RB>(a);
           };
@@ -421,6 +446,26 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
 
   // ---- store the partial tile: D[co][ci], co = (reg&3)+8(reg>>2)+4 fh, ci = fr ----
   float* slab = p.out + (size_t)slice * p.Cout * p.taps * p.Cin;
+  if constexpr (SMALL) {
+    // D[co = 16 i + 4 (lane>>4) + e][column = 64 wn + 16 j + (lane&15)] of pixel half wm; column -> (tap, ci)
+    const int r16 = lane & 15, h16 = lane >> 4;
+    slab = p.out + (size_t)(slice * 2 + wm) * p.Cout * p.taps_real * p.Cin;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = wn * 64 + j * 16 + r16;
+      const int sub = col / p.Cin, ci = col - sub * p.Cin;
+      const int tapid = tap * (256 / p.Cin) + sub;
+      if (tapid >= p.taps_real) continue;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = i * 16 + 4 * h16 + e;
+          if (co < p.Cout) slab[((size_t)co * p.taps_real + tapid) * p.Cin + ci] = acc16[i][j][e];
+        }
+    }
+    return;
+  }
   if constexpr (kMma16) {
     // D[co = 16 i + 4 (lane>>4) + e][ci = 16 j + (lane&15)]
     const int r16 = lane & 15, h16 = lane >> 4;
@@ -581,10 +626,36 @@ extern "C" int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t
 }
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
-                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h = 0);
+                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h = 0,
+                     bool small = false);
+
+// the small-channel form's plan: tap groups x slices, two partial slabs per slice
+static bool small3d_ok(int c_in, int c_out, int dtype) {
+#ifdef VNQA_WGRAD_NO_SMALL
+  return false;
+#else
+  return dtype == VNQA_BF16 && c_out <= 128 && (c_in == 64 || c_in == 128);
+#endif
+}
+static Plan small3d_plan(long long Ptot, int c_in) {
+  Plan pl = make_plan_k(Ptot, 256, 256, 1, VNQA_BF16);
+  const int groups = (27 + 256 / c_in - 1) / (256 / c_in);
+  int slices = 512 / groups;                                      // one workgroup per CU (128 KiB LDS): two FULL rounds of 256
+  const int max_slices = pl.ksteps_total / 8 > 0 ? pl.ksteps_total / 8 : 1;
+  slices = slices > max_slices ? max_slices : slices;
+  pl.ksteps_per_slice = (pl.ksteps_total + slices - 1) / slices;
+  pl.slices = (pl.ksteps_total + pl.ksteps_per_slice - 1) / pl.ksteps_per_slice;
+  long long cb = Ptot / 2048;
+  pl.colsum_blocks = (int)(cb < 1 ? 1 : (cb > 1024 ? 1024 : cb));
+  return pl;
+}
 
 extern "C" int64_t vnqa_conv3d_wgrad_workspace(int32_t n_img, int32_t d, int32_t h, int32_t w, int32_t c_in, int32_t c_out) {
   int64_t need = 0;
+  if (small3d_ok(c_in, c_out, VNQA_BF16)) {
+    const Plan pl = small3d_plan((long long)n_img * (d + 2) * (h + 2) * (w + 2), c_in);
+    need = ((int64_t)2 * pl.slices * c_out * 27 * c_in + (int64_t)pl.colsum_blocks * c_out) * 4;
+  }
   for (int dt = 0; dt < 2; ++dt) {
     const Plan pl = make_plan_k((long long)n_img * (d + 2) * (h + 2) * (w + 2), c_in, c_out, 27, dt);
     const int64_t b = ((int64_t)pl.slices * c_out * 27 * c_in + (int64_t)pl.colsum_blocks * c_out) * 4;
@@ -599,6 +670,10 @@ extern "C" int vnqa_conv3d_wgrad(const void* x, const void* dy, float* dwt, floa
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv3d_wgrad: bad dtype %d", dtype);
   VNQA_CHECK_ARG(c_in % 8 == 0 && c_out % 8 == 0 && c_in >= 8 && c_out >= 8, "conv3d_wgrad: channels must be multiples of 8");
   VNQA_CHECK_ARG(n_img > 0 && d > 0 && h > 0 && w > 0, "conv3d_wgrad: empty problem");
+  if (small3d_ok(c_in, c_out, dtype)) {
+    const Plan pl = small3d_plan((long long)n_img * (d + 2) * (h + 2) * (w + 2), c_in);
+    return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, 27, dtype, stream, h, true);
+  }
   const Plan pl = make_plan_k((long long)n_img * (d + 2) * (h + 2) * (w + 2), c_in, c_out, 27, dtype);
   return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, 27, dtype, stream, h);
 }
@@ -632,7 +707,7 @@ extern "C" int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void
 }
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
-                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h) {
+                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h, bool small) {
   hipStream_t st = (hipStream_t)stream;
   WgradArgs a;
   a.x = (const char*)x;
@@ -654,10 +729,30 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   a.ksteps_total = pl.ksteps_total;
   a.ksteps_per_slice = pl.ksteps_per_slice;
   a.slices = pl.slices;
+  a.taps_real = taps;
   const int lds = 2 * 65536;
-  const int grid = pl.slices * pl.tilesCo * taps * pl.tilesCi;
+  int grid = pl.slices * pl.tilesCo * taps * pl.tilesCi;
+  int n_slabs = pl.slices;
+  if (small) {
+    a.taps = (taps + 256 / c_in - 1) / (256 / c_in);          // tap groups
+    a.tilesCo = a.tilesCi = 1;
+    a.out = (float*)workspace;
+    grid = pl.slices * a.taps;
+    n_slabs = 2 * pl.slices;
+  }
   static std::atomic<bool> attr_done[2] = {{false}, {false}};   // idempotent attribute call: a race only repeats it
-  if (dtype == VNQA_BF16) {
+  if (small) {
+    auto kern = conv_wgrad_kernel<vnqa_bf16, true>;
+    static std::atomic<bool> small_done{false};
+    if (!small_done) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        vnqa_set_error("conv3d_wgrad: cannot reserve %d B of LDS", lds);
+        return VNQA_ERR_HIP;
+      }
+      small_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+  } else if (dtype == VNQA_BF16) {
     auto kern = conv_wgrad_kernel<vnqa_bf16>;
     if (!attr_done[0]) {
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -680,14 +775,14 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   }
   VNQA_CHECK_LAUNCH();
   const size_t n = (size_t)c_out * taps * c_in;
-  if (pl.slices > 1) {
+  if (n_slabs > 1) {
     int g = (int)((n + 255) / 256);
     g = g > 2048 ? 2048 : g;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(g), dim3(256), 0, st, (const float*)workspace, dwt, n, pl.slices);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(g), dim3(256), 0, st, (const float*)workspace, dwt, n, n_slabs);
     VNQA_CHECK_LAUNCH();
   }
   if (dbias != nullptr) {
-    float* partial = (float*)workspace + (size_t)pl.slices * n;
+    float* partial = (float*)workspace + (size_t)n_slabs * n;
     const long long rpb = (pl.Ptot + pl.colsum_blocks - 1) / pl.colsum_blocks;
     if (dtype == VNQA_BF16)
       hipLaunchKernelGGL(colsum_partial_kernel<vnqa_bf16>, dim3((c_out + 63) / 64, pl.colsum_blocks), dim3(256), 0, st,

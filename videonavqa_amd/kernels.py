@@ -917,3 +917,127 @@ def mac_core_call(direction, dims, tensors, defer_wgrad=False):
     a.defer_wgrad = 1 if defer_wgrad else 0
     fn = L.lib().vnqa_mac_core_fwd if direction == "fwd" else L.lib().vnqa_mac_core_bwd
     L.check(fn(ctypes.byref(a), L.stream()), "vnqa_mac_core_" + direction)
+
+
+# ---- csrc/cnn3d.hip: VideoOnlyCNN3D's first conv, BatchNorm over channel-last rows, MaxPool3d(4,4,4) ------------------------
+def view_padded_ndhwc(D, H, W, C):
+    """element (n, d, h, w, c) of a padded NDHWC tensor [N, D+2, H+2, W+2, C] (interior only)"""
+    sh = (W + 2) * C
+    sd = (H + 2) * sh
+    return L.View5(sd + sh + C, (D + 2) * sd, sd, sh, C, 1, D, H, W)
+
+
+def view_dense(D, H, W, C):
+    return L.View5(0, D * H * W * C, H * W * C, W * C, C, 1, D, H, W)
+
+
+def view_nc_flat(D, H, W, C):
+    """[N, C*D*H*W] in NCDHW order (what .view(N, -1) of an NCDHW tensor gives: v_only_cnn3d.py:74)"""
+    return L.View5(0, C * D * H * W, H * W, W, 1, D * H * W, D, H, W)
+
+
+def bn_finalize(partial, count, eps, momentum=0.0, running_mean=None, running_var=None):
+    """partial fp32 [blocks, C, 2] -> (mean, rstd) fp32 [C]; running statistics updated in place when given."""
+    nblk, C, _ = partial.shape
+    mean = torch.empty((C,), dtype=torch.float32, device=partial.device)
+    rstd = torch.empty_like(mean)
+    L.check(L.lib().vnqa_bn_finalize(L.ptr(partial), nblk, C, float(count), float(eps), float(momentum), L.ptr(mean), L.ptr(rstd),
+                                     L.ptr(running_mean), L.ptr(running_var), L.stream()), "vnqa_bn_finalize")
+    return mean, rstd
+
+
+def c3d_stats_ncdhw(x):
+    """fp32 [N, C, ...] -> partial statistics [blocks, C, 2]"""
+    N, C = x.shape[0], x.shape[1]
+    S = x[0, 0].numel()
+    chunks = max(1, min(64, S // 16384))
+    partial = torch.empty((N * chunks, C, 2), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vnqa_c3d_stats_ncdhw(L.ptr(_f32c(x)), L.ptr(partial), N, C, S, chunks, L.stream()), "vnqa_c3d_stats_ncdhw")
+    return partial
+
+
+def c3d_stats_rows(x):
+    """dense [R, C] (fp32 or 16-bit) -> partial statistics [blocks, C, 2]"""
+    R, C = x.shape
+    assert x.is_contiguous()
+    nb = L.lib().vnqa_c3d_stats_blocks(R)
+    partial = torch.empty((nb, C, 2), dtype=torch.float32, device=x.device)
+    L.check(L.lib().vnqa_c3d_stats_rows(L.vptr(x), L.ptr(partial), R, C, L.dtype_id(x.dtype), L.stream()), "vnqa_c3d_stats_rows")
+    return partial
+
+
+def bn_rows_apply(x, out, view, mean, rstd, gamma, beta):
+    """out(view) = gamma (x - mean) rstd + beta; x dense [R, C]"""
+    R, C = x.shape
+    assert x.is_contiguous() and out.is_contiguous()
+    L.check(L.lib().vnqa_bn_rows_apply(L.vptr(x), L.dtype_id(x.dtype), L.vptr(out), L.dtype_id(out.dtype), ctypes.byref(view),
+                                       L.ptr(mean), L.ptr(rstd), L.ptr(_f32c(gamma)), L.ptr(_f32c(beta)), R, C, L.stream()),
+            "vnqa_bn_rows_apply")
+    return out
+
+
+def bn_rows_bwd(dy, dy_view, x, dx_dtype, mean, rstd, gamma, grad_scale=1.0):
+    """train-mode BatchNorm backward over rows: returns (dx dense [R, C] in dx_dtype, dgamma, dbeta)."""
+    R, C = x.shape
+    assert x.is_contiguous() and dy.is_contiguous()
+    nb = L.lib().vnqa_c3d_stats_blocks(R)
+    ws = workspace((nb * C * 2 + 2 * C) * 4, x.device)
+    dx = torch.empty((R, C), dtype=dx_dtype, device=x.device)
+    dg = torch.empty((C,), dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dg)
+    L.check(L.lib().vnqa_bn_rows_bwd(L.vptr(dy), L.dtype_id(dy.dtype), ctypes.byref(dy_view), L.vptr(x), L.dtype_id(x.dtype),
+                                     L.vptr(dx), L.dtype_id(dx_dtype), L.ptr(mean), L.ptr(rstd), L.ptr(_f32c(gamma)), L.ptr(dg),
+                                     L.ptr(db), L.ptr(ws), float(grad_scale), R, C, L.stream()), "vnqa_bn_rows_bwd")
+    return dx, dg, db
+
+
+def pool444_fwd(y):
+    """y padded NDHWC [N, D+2, H+2, W+2, C] (16-bit, ReLU applied) -> (p dense [N, D/4, H/4, W/4, C], idx uint8, partial stats)"""
+    N, Dp, Hp, Wp, C = y.shape
+    D, H, W = Dp - 2, Hp - 2, Wp - 2
+    p = torch.empty((N, D // 4, H // 4, W // 4, C), dtype=y.dtype, device=y.device)
+    idx = torch.empty(p.shape, dtype=torch.uint8, device=y.device)
+    nb = L.lib().vnqa_pool444_blocks(N, D, H, W, C)
+    partial = torch.empty((nb, C, 2), dtype=torch.float32, device=y.device)
+    L.check(L.lib().vnqa_pool444_fwd(L.ptr(y), L.ptr(p), L.vptr(idx), L.ptr(partial), N, D, H, W, C, L.stream()), "vnqa_pool444_fwd")
+    return p, idx, partial
+
+
+def pool444_bwd(dp, idx, dy):
+    """dy (padded NDHWC, zero halo kept) <- dp routed to the arg-max positions, zeros elsewhere in the interior"""
+    N, Dp, Hp, Wp, C = dy.shape
+    assert dp.is_contiguous() and idx.is_contiguous() and dp.dtype == dy.dtype
+    L.check(L.lib().vnqa_pool444_bwd(L.ptr(dp), L.vptr(idx), L.ptr(dy), N, Dp - 2, Hp - 2, Wp - 2, C, L.stream()), "vnqa_pool444_bwd")
+    return dy
+
+
+def c3d_conv1_supported(N, D, H, W):
+    return bool(L.lib().vnqa_c3d_conv1_supported(N, D, H, W))
+
+
+def c3d_conv1_fwd(x, weight, bias, mean, rstd, gamma, beta, dtype):
+    """fp32 clip [N,3,D,H,W] -> (p dense [N,D,H/2,W/2,64] in `dtype`, idx uint8, partial stats of p)"""
+    N, _, D, H, W = x.shape
+    p = torch.empty((N, D, H // 2, W // 2, 64), dtype=dtype, device=x.device)
+    idx = torch.empty(p.shape, dtype=torch.uint8, device=x.device)
+    partial = torch.empty((L.lib().vnqa_c3d_conv1_fwd_blocks(N, H, W), 64, 2), dtype=torch.float32, device=x.device)
+    L.dtype_id(dtype)
+    L.check(L.lib().vnqa_c3d_conv1_fwd(L.ptr(_f32c(x)), L.ptr(_f32c(weight)), L.ptr(_f32c(bias)), L.ptr(mean), L.ptr(rstd),
+                                       L.ptr(_f32c(gamma)), L.ptr(_f32c(beta)), L.ptr(p), L.vptr(idx), L.ptr(partial), N, D, H, W,
+                                       L.stream()), "vnqa_c3d_conv1_fwd")
+    return p, idx, partial
+
+
+def c3d_conv1_bwd(x, weight, mean, rstd, gamma, beta, dp, idx, grad_scale=1.0):
+    """-> (dweight [64,3,3,3,3], dbias [64], bn_input dgamma [3], dbeta [3])"""
+    N, _, D, H, W = x.shape
+    ws = workspace((L.lib().vnqa_c3d_conv1_bwd_blocks(N, H, W) + 16) * 64 * 112 * 4, x.device)
+    dw = torch.empty((64, 3, 3, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((64,), dtype=torch.float32, device=x.device)
+    dg = torch.empty((3,), dtype=torch.float32, device=x.device)
+    dbt = torch.empty((3,), dtype=torch.float32, device=x.device)
+    assert dp.is_contiguous() and idx.is_contiguous()
+    L.check(L.lib().vnqa_c3d_conv1_bwd(L.ptr(_f32c(x)), L.ptr(_f32c(weight)), L.ptr(mean), L.ptr(rstd), L.ptr(_f32c(gamma)),
+                                       L.ptr(_f32c(beta)), L.ptr(dp), L.vptr(idx), L.ptr(ws), float(grad_scale), L.ptr(dw), L.ptr(db),
+                                       L.ptr(dg), L.ptr(dbt), N, D, H, W, L.stream()), "vnqa_c3d_conv1_bwd")
+    return dw, db, dg, dbt

@@ -1,10 +1,14 @@
 """VideoOnlyCNN3D — C3D-like video-only baseline (config 2: 3-D conv HIP kernel bring-up; drop-in for
 models/v_only_cnn3d.py)."""
+import os
+
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import kernels as K
 from .. import ops
-from .common import compute_dtype, reference_init_
+from .common import compute_dtype, grad_scale_of, reference_init_
 
 # conv stage = (conv attr, bn attr, pool attr, C_in, C_out, pool kernel == stride)   (v_only_cnn3d.py:16-26)
 _STAGES = (("conv1", "bn1", "pool1", 3, 64, (1, 2, 2)),
@@ -17,9 +21,12 @@ _HEAD = (("fc6", "bn6", 2048), ("fc7", "bn7", 128), ("fc8", None, None))
 class VideoOnlyCNN3D(nn.Module):
     """`VideoOnlyCNN3D(nb_classes)` as upstream; `fc6_in_features` parameterises the hard-coded 7680
     (= 128*10*6*1 for the reference's [B,3,160,208,35] clips, where Conv3d sees (D,H,W) = (H,W,T); 1152 for
-    the 16x3x112x112 config-2 clips).  The three Conv3d layers (forward, dgrad, wgrad) run on the MFMA
-    igemm / wgrad kernels through a 27-tap table over padded NDHWC; the BatchNorm3d / MaxPool3d / FC glue
-    of this bring-up rung is stock PyTorch-ROCm."""
+    the 16x3x112x112 config-2 clips).  16-bit precisions with H, W multiples of 16 and pool-divisible extents (config 2) run the
+    whole feature extractor as ONE autograd node on csrc/cnn3d.hip (ops.Cnn3dFeaturesFn: conv1 straight from the fp32 clip with
+    bn_input / pool1 / bn1's statistics fused, pools with arg-max bytes, BatchNorm written into the next conv's padded input)
+    plus the 27-tap igemm / small-channel wgrad kernels, and the classifier on vnqa_sgemm + the same BatchNorm kernels.
+    precision='fp32' and other geometries (the reference's 160x208x35 clips: W = 35) take the generic path: convs on the
+    igemm / wgrad kernels through padded NDHWC, BatchNorm3d / MaxPool3d / FC on stock PyTorch-ROCm."""
 
     def __init__(self, nb_classes, *, fc6_in_features=7680, precision='bf16'):
         super(VideoOnlyCNN3D, self).__init__()
@@ -39,9 +46,25 @@ class VideoOnlyCNN3D(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.apply(reference_init_)          # upstream's rule tests Conv2d, not Conv3d (:41): convs keep default init
 
+    def _fast_ok(self, inputs):
+        if self.compute_dtype == torch.float32 or os.environ.get("VNQA_CNN3D_GENERIC", "0") == "1":
+            return False
+        N, C, D, H, W = inputs.shape
+        if C != 3 or not K.c3d_conv1_supported(N, D, H, W):
+            return False
+        return D % 4 == 0 and (H // 2) % 4 == 0 and (W // 2) % 4 == 0 and D // 4 >= 4 and H // 8 >= 4 and W // 8 >= 4
+
     def features(self, inputs):
-        """bn_input -> 3 x [relu(conv3d) on the HIP kernels -> MaxPool3d -> BatchNorm3d]  (v_only_cnn3d.py:60-72)."""
+        """bn_input -> 3 x [relu(conv3d) on the HIP kernels -> MaxPool3d -> BatchNorm3d]  (v_only_cnn3d.py:60-72).
+        Returns NCDHW fp32."""
         assert inputs.is_cuda, "the HIP path needs device tensors (no CPU fallback)"
+        if self._fast_ok(inputs):
+            if self.training:
+                with torch.no_grad():
+                    for bn in (self.bn_input, self.bn1, self.bn2, self.bn3):
+                        bn.num_batches_tracked += 1
+            return ops.cnn3d_features(inputs, self.bn_input, self.conv1, self.bn1, self.conv2, self.bn2, self.conv3a, self.bn3,
+                                      self.training, self.compute_dtype, grad_scale_of(self.compute_dtype))
         h = self.bn_input(inputs.float())
         for conv_name, bn_name, pool_name, _, cout, _ in _STAGES:
             conv = getattr(self, conv_name)
@@ -52,7 +75,15 @@ class VideoOnlyCNN3D(nn.Module):
 
     def forward(self, inputs):
         """inputs fp32 [B,3,D,H,W] -> logits [B,nb_classes] (v_only_cnn3d.py:59-81)."""
+        fast = self._fast_ok(inputs)
         h = self.features(inputs).flatten(1)
+        if fast:                                  # classifier on vnqa_sgemm + the channel-last BatchNorm kernels
+            for fc, bn in ((self.fc6, self.bn6), (self.fc7, self.bn7)):
+                if self.training:
+                    with torch.no_grad():
+                        bn.num_batches_tracked += 1
+                h = ops.batch_norm_rows(ops.linear(h, fc.weight, fc.bias, relu=True), bn, self.training)
+            return ops.linear(h, self.fc8.weight, self.fc8.bias)
         h = self.bn6(F.relu(self.fc6(h)))
         h = self.bn7(F.relu(self.fc7(h)))
         return self.fc8(h)

@@ -435,6 +435,168 @@ def ndhwc_padded_to_ncdhw(x, C):
     return x[:, 1:-1, 1:-1, 1:-1, :C].permute(0, 4, 1, 2, 3).float()
 
 
+class _HaloPool(object):
+    """Zero-halo padded NDHWC buffers handed out to the 3-D conv pipeline and returned after use: the kernels write interiors
+    only, so a returned buffer is a ready zero-halo buffer again (no per-step memset of ~1 GB activations)."""
+
+    def __init__(self):
+        self.free = {}
+
+    def get(self, shape, dtype, device):
+        key = (tuple(shape), dtype, str(device), torch.cuda.current_stream().cuda_stream)
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        return torch.zeros(shape, dtype=dtype, device=device)
+
+    def put(self, t):
+        key = (tuple(t.shape), t.dtype, str(t.device), torch.cuda.current_stream().cuda_stream)
+        lst = self.free.setdefault(key, [])
+        if len(lst) < 2:
+            lst.append(t)
+
+
+_HALO_POOL = _HaloPool()
+
+
+class Cnn3dFeaturesFn(torch.autograd.Function):
+    """bn_input -> 3 x [relu(conv3d) -> MaxPool3d -> BatchNorm3d] -> flatten (v_only_cnn3d.py:60-74) as ONE autograd node on
+    csrc/cnn3d.hip + the 27-tap igemm / small-channel wgrad kernels, 16-bit storage:
+      conv1 reads the fp32 clip directly (bn_input folded into its patch load and weights, pool(1,2,2) + bn1 statistics in its
+      epilogue); every BatchNorm writes straight into the next conv's padded NDHWC input; the pools keep an arg-max byte per
+      output (ReLU mask included) and the backward pool writes the conv's whole padded dY; conv1's backward is one split-K
+      GEMM that also yields bn_input's parameter gradients.
+    `bns` = the four BatchNorm3d modules (running statistics / momentum / eps live there), `training` selects batch statistics."""
+
+    @staticmethod
+    def forward(ctx, x, g0, b0, w1, c1b, g1, b1, w2, c2b, g2, b2, w3, c3b, g3, b3, bns, training, cdt, grad_scale):
+        N, _, D, H, W = x.shape
+        dev = x.device
+        x = x.detach().float().contiguous()
+        f = lambda t: t.detach().float().contiguous()
+        g0, b0, w1, c1b, g1, b1, g2, b2, g3, b3 = [f(t) for t in (g0, b0, w1, c1b, g1, b1, g2, b2, g3, b3)]
+
+        def stats(bn, partial, count):
+            if training:
+                return K.bn_finalize(partial, count, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                     bn.running_mean, bn.running_var)
+            return bn.running_mean.detach().float().contiguous(), torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+
+        mean0, rstd0 = stats(bns[0], K.c3d_stats_ncdhw(x) if training else None, N * D * H * W)
+        p1, idx1, part1 = K.c3d_conv1_fwd(x, w1, c1b, mean0, rstd0, g0, b0, cdt)
+        H1, W1 = H // 2, W // 2
+        mean1, rstd1 = stats(bns[1], part1, N * D * H1 * W1)
+        a1 = _HALO_POOL.get((N, D + 2, H1 + 2, W1 + 2, 64), cdt, dev)
+        K.bn_rows_apply(p1.view(-1, 64), a1, K.view_padded_ndhwc(D, H1, W1, 64), mean1, rstd1, g1, b1)
+        c2 = w2.shape[0]
+        wt2 = K.pack_conv_weight(w2, cdt, c_out_pad=c2, c_in_pad=64)
+        y2 = _HALO_POOL.get((N, D + 2, H1 + 2, W1 + 2, c2), cdt, dev)
+        K.conv3d_igemm(a1, wt2, bias=f(c2b), relu=True, out=y2)
+        p2, idx2, part2 = K.pool444_fwd(y2)
+        _HALO_POOL.put(y2)                       # the ReLU mask travels in idx2: y2 itself is not needed again
+        D2, H2, W2 = D // 4, H1 // 4, W1 // 4
+        mean2, rstd2 = stats(bns[2], part2, N * D2 * H2 * W2)
+        a2 = _HALO_POOL.get((N, D2 + 2, H2 + 2, W2 + 2, c2), cdt, dev)
+        K.bn_rows_apply(p2.view(-1, c2), a2, K.view_padded_ndhwc(D2, H2, W2, c2), mean2, rstd2, g2, b2)
+        c3 = w3.shape[0]
+        wt3 = K.pack_conv_weight(w3, cdt, c_out_pad=c3, c_in_pad=c2)
+        y3 = _HALO_POOL.get((N, D2 + 2, H2 + 2, W2 + 2, c3), cdt, dev)
+        K.conv3d_igemm(a2, wt3, bias=f(c3b), relu=True, out=y3)
+        p3, idx3, part3 = K.pool444_fwd(y3)
+        _HALO_POOL.put(y3)
+        D3, H3, W3 = D2 // 4, H2 // 4, W2 // 4
+        mean3, rstd3 = stats(bns[3], part3, N * D3 * H3 * W3)
+        feat = torch.empty((N, c3 * D3 * H3 * W3), dtype=torch.float32, device=dev)
+        K.bn_rows_apply(p3.view(-1, c3), feat, K.view_nc_flat(D3, H3, W3, c3), mean3, rstd3, g3, b3)
+        ctx.save_for_backward(x, g0, b0, w1, g1, g2, g3, w2, w3, mean0, rstd0, mean1, rstd1, mean2, rstd2, mean3, rstd3,
+                              p1, idx1, a1, p2, idx2, a2, p3, idx3)
+        ctx.meta = (cdt, float(grad_scale), training)
+        if not any(ctx.needs_input_grad):         # no backward will come for them: the padded inputs go back to the pool now
+            _HALO_POOL.put(a1)
+            _HALO_POOL.put(a2)
+        return feat.view(N, c3, D3, H3, W3)
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        (x, g0, b0, w1, g1, g2, g3, w2, w3, mean0, rstd0, mean1, rstd1, mean2, rstd2, mean3, rstd3,
+         p1, idx1, a1, p2, idx2, a2, p3, idx3) = ctx.saved_tensors
+        cdt, gs, training = ctx.meta
+        if not training:
+            raise NotImplementedError("VideoOnlyCNN3D: backward through eval-mode BatchNorm is not part of the reference path")
+        N, D1, H1, W1, _ = p1.shape
+        _, D2, H2, W2, c2 = p2.shape
+        _, D3, H3, W3, c3 = p3.shape
+        dev = x.device
+        dfeat = dfeat.reshape(N, -1)
+        dfeat = (dfeat.float() * gs).contiguous() if gs != 1.0 else dfeat.float().contiguous()
+        # stage 3
+        dp3, dg3, db3 = K.bn_rows_bwd(dfeat, K.view_nc_flat(D3, H3, W3, c3), p3.view(-1, c3), cdt, mean3, rstd3, g3, gs)
+        dy3 = _HALO_POOL.get((N, D2 + 2, H2 + 2, W2 + 2, c3), cdt, dev)
+        K.pool444_bwd(dp3.view(p3.shape), idx3, dy3)
+        dwt3, dbias3 = K.conv3d_wgrad(a2, dy3)
+        dw3 = K.unpack_conv_wgrad(dwt3, c3, c2, alpha=1.0 / gs)
+        da2 = _HALO_POOL.get((N, D2 + 2, H2 + 2, W2 + 2, c2), cdt, dev)
+        K.conv3d_igemm(dy3, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c3, c_in_pad=c2), out=da2)
+        _HALO_POOL.put(dy3)
+        # stage 2
+        dp2, dg2, db2 = K.bn_rows_bwd(da2, K.view_padded_ndhwc(D2, H2, W2, c2), p2.view(-1, c2), cdt, mean2, rstd2, g2, gs)
+        _HALO_POOL.put(da2)
+        dy2 = _HALO_POOL.get((N, D1 + 2, H1 + 2, W1 + 2, c2), cdt, dev)
+        K.pool444_bwd(dp2.view(p2.shape), idx2, dy2)
+        dwt2, dbias2 = K.conv3d_wgrad(a1, dy2)
+        dw2 = K.unpack_conv_wgrad(dwt2, c2, 64, alpha=1.0 / gs)
+        da1 = _HALO_POOL.get((N, D1 + 2, H1 + 2, W1 + 2, 64), cdt, dev)
+        K.conv3d_igemm(dy2, K.pack_conv_weight(w2, cdt, transpose_flip=True, c_out_pad=c2, c_in_pad=64), out=da1)
+        _HALO_POOL.put(dy2)
+        # stage 1
+        dp1, dg1, db1 = K.bn_rows_bwd(da1, K.view_padded_ndhwc(D1, H1, W1, 64), p1.view(-1, 64), cdt, mean1, rstd1, g1, gs)
+        _HALO_POOL.put(da1)
+        dw1, dc1b, dg0, db0 = K.c3d_conv1_bwd(x, w1, mean0, rstd0, g0, b0, dp1, idx1, gs)
+        _HALO_POOL.put(a1)
+        _HALO_POOL.put(a2)
+        inv = 1.0 / gs
+        return (None, dg0, db0, dw1, dc1b, dg1, db1, dw2, dbias2[:c2] * inv if gs != 1.0 else dbias2[:c2].clone(), dg2, db2,
+                dw3, dbias3[:c3] * inv if gs != 1.0 else dbias3[:c3].clone(), dg3, db3, None, None, None, None)
+
+
+def cnn3d_features(x, bn_input, conv1, bn1, conv2, bn2, conv3, bn3, training, cdt, grad_scale=1.0):
+    return Cnn3dFeaturesFn.apply(x, bn_input.weight, bn_input.bias, conv1.weight, conv1.bias, bn1.weight, bn1.bias, conv2.weight,
+                                 conv2.bias, bn2.weight, bn2.bias, conv3.weight, conv3.bias, bn3.weight, bn3.bias,
+                                 (bn_input, bn1, bn2, bn3), training, cdt, grad_scale)
+
+
+class BatchNormRowsFn(torch.autograd.Function):
+    """nn.BatchNorm1d over dense fp32 rows [R, C] (bn6 / bn7 of v_only_cnn3d.py:76-79) on the channel-last BatchNorm kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, training):
+        x = x.contiguous()
+        R, C = x.shape
+        if training:
+            mean, rstd = K.bn_finalize(K.c3d_stats_rows(x), R, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                       bn.running_mean, bn.running_var)
+        else:
+            mean, rstd = bn.running_mean.detach().float().contiguous(), torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        y = torch.empty_like(x)
+        g = gamma.detach().float().contiguous()
+        K.bn_rows_apply(x, y, K.view_dense(1, 1, 1, C), mean, rstd, g, beta.detach().float().contiguous())
+        ctx.save_for_backward(x, g, mean, rstd)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the reference path")
+        dx, dg, db = K.bn_rows_bwd(dy.contiguous(), K.view_dense(1, 1, 1, x.shape[1]), x, torch.float32, mean, rstd, g)
+        return dx, dg, db, None, None
+
+
+def batch_norm_rows(x, bn, training):
+    return BatchNormRowsFn.apply(x, bn.weight, bn.bias, bn, training)
+
+
 class TemporalAttnFn(torch.autograd.Function):
     """ctxt, coef = fused temporal attention (film_attn_pt_stem.py:268-290): fc_attn_1 scores on the valid
     (sample, frame) entries, -(1<<31) masks, softmax over frames, weighted sum of the frame features."""
