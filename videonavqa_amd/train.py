@@ -171,8 +171,13 @@ class Trainer(object):
             self.stem_stream = L.reserved_stream(self.stem_reserve_cus, self.stem_device)
         else:
             self.stem_stream = torch.cuda.Stream(priority=prio)
-        tprio = os.environ.get("VNQA_TRUNK_PRIO")
-        self.trunk_stream = torch.cuda.Stream(priority=int(tprio)) if tprio is not None else None
+        # The trunk (the step's dependent chain: question LSTMs, FiLM blocks, attention tail, backward, Adam) runs on its own
+        # HIGH-priority stream by default: its kernels are dispatched ahead of the co-running stem's whenever both have
+        # workgroups pending, so the chain finishes sooner and the stem fills what is left (same-box A/B, 4 rounds each:
+        # 846 -> 876 clips/s, +3.5 %).  VNQA_TRUNK_PRIO=none: the caller's stream, as before; any integer: that priority.
+        tprio = os.environ.get("VNQA_TRUNK_PRIO", "-1")
+        use_ts = tprio.lower() != "none" and self.fp.flat.is_cuda
+        self.trunk_stream = torch.cuda.Stream(priority=int(tprio)) if use_ts else None
         self._prefetched = None          # (key, NativeFeatures, v_sorted, perm, done_event)
         self._slot = 0
         self._trunk_done = [None, None]  # event per slot: last trunk pass that read that slot
@@ -288,6 +293,9 @@ class Trainer(object):
         with torch.cuda.stream(self.trunk_stream):
             out = self._step(clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip, next_v_lens_cpu)
         outer.wait_stream(self.trunk_stream)
+        for t in out:                 # (allocated on the trunk stream, consumed by the caller on its own)
+            if torch.is_tensor(t):
+                t.record_stream(outer)
         return out
 
     def _step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
