@@ -681,7 +681,10 @@ def main():
         for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tfile = os.path.join(ROOT, "profiles", tname)
             if default_cfg and os.path.exists(tfile):
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic = (tj.get("kernels", {}).get(dom) or {}).get("hbm_bytes_per_launch", tj.get("hbm_bytes_per_launch") if dom == "conv_igemm_kernel" else None)
+                if traffic is None:
+                    continue
                 traffic_src = "profiles/%s (separate rocprofv3 --pmc passes over this workload's stem; not measured live)" % tname
                 break
         S = (H // 16) * (W // 16)

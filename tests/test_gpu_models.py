@@ -3,9 +3,11 @@
 
 Tolerances (north star: logits within 1e-3 relative of the reference, argmax bit-exact):
   precision='fp32' (exact-f32 MFMA path): logits 1e-3 * max|logits|, gradients 2e-3 * max|grad|
-  precision='bf16' (bf16 storage, fp32 accumulate): logits 6e-2 * max|logits| (stated, looser);
-                   gradients of these 8-channel nets: relative L2 error < 0.3 per tensor (BN backward
-                   cancels large terms, bf16 activations carry 2^-9 relative noise each).
+  precision='bf16' (bf16 storage, fp32 accumulate): logits 2.5e-2 * max|logits| (measured worst over all cases 1.26e-2,
+                   tools/measure_smallnet_tol.py; round 2 stated 6e-2);
+                   gradients of these 8-channel nets: relative L2 error < 0.3 per tensor and worst element <= 0.6 max|grad|
+                   (measured worst 0.296 / 0.53, both on the bag-of-words max-pooling case: a frame arg-max that flips
+                   under rounding moves a whole feature's gradient; BN backward cancels large terms).
 """
 import numpy as np
 import pytest
@@ -16,7 +18,7 @@ from helpers import QV_CASES, build_product_model, load_golden, rel_err, weights
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = {"fp32": 1e-3, "bf16": 6e-2, "fp16": 1e-2}
+LOGIT_TOL = {"fp32": 1e-3, "bf16": 2.5e-2, "fp16": 1e-2}
 
 
 def _inputs(g):

@@ -22,7 +22,39 @@ def extra_cycles(swz, starts):
     return total
 
 
+def ps_extra_cycles(TC, HALO, RM):
+    """csrc/conv_ps.hip pixel-fragment reads: lane (fr, fh) of pixel fragment i (wave row wm) reads, for tap (r, s) and K substep
+    ks, the 16-byte chunk (4 ks + fh) ^ ((tc + RM R0 + s + RM r) & 6) of patch pixel (R0 + r) PW + tc + s, where pixel
+    ml = 112 wm + 16 i + fr sits at tile row R0 = ml // TC, column tc = ml % TC and PW = TC + 2 HALO (pixels are 128-byte rows).
+    Returns (extra cycles, group accesses) over every wm, i, tap and substep."""
+    PW, KW = TC + 2 * HALO, 2 * HALO + 1
+    extra = n = 0
+    for wm in (0, 1):
+        for i in range(7):
+            for r in range(KW):
+                for s_ in range(KW):
+                    for ks in (0, 1):
+                        for g in G:
+                            seen = {}
+                            for lane in g:
+                                fr, fh = lane & 15, lane >> 4
+                                ml = 112 * wm + 16 * i + fr
+                                R0, tc = divmod(ml, TC)
+                                px = (R0 + r) * PW + tc + s_
+                                chunk = (4 * ks + fh) ^ ((tc + RM * R0 + s_ + RM * r) & 6)
+                                slot = ((px & 1) << 3) | chunk
+                                seen[slot] = seen.get(slot, 0) + 1
+                            extra += max(seen.values()) - 1
+                            n += 1
+    return extra, n
+
+
 if __name__ == "__main__":
+    for TC, HALO, RM in ((28, 1, 4), (14, 1, 2), (14, 2, 6), (28, 2, 4)):
+        best = min(range(8), key=lambda m: ps_extra_cycles(TC, HALO, m)[0])
+        e, n_ = ps_extra_cycles(TC, HALO, RM)
+        print("conv_ps TC=%d %dx%d key (col + %d row) & 6: %d extra cycles over %d group accesses (best multiplier %d: %d)"
+              % (TC, 2 * HALO + 1, 2 * HALO + 1, RM, e, n_, best, ps_extra_cycles(TC, HALO, best)[0]))
     n = 64 * 2 * 4
     print("old (row >> 1) & 7: %d extra cycles over %d group accesses" % (extra_cycles(lambda r: (r >> 1) & 7, range(64)), n))
     new = extra_cycles(lambda r: r & 6, range(64))

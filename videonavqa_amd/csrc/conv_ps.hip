@@ -18,7 +18,9 @@
 // first and the last row's halos — and 256 output channels.
 //   D[cout][pixel] += W[tap][cout][chunk] . patch[pixel + tap][chunk]       (weights = MFMA A operand, pixels = B operand)
 // Patch swizzle: 16-byte chunk ^= (col + 4 row) & 6 (TC = 28: conflict-free ds_read_b128 for every fragment, wrap position
-// and tap under gfx950's lane groups; TC = 14: (col + 2 row) & 6, the best linear form, 2-way on half of the wrapped reads).
+// and tap under gfx950's lane groups; TC = 14: (col + 6 row) & 6 — with the two extra halo rows a 16-row tile crosses at every
+// image boundary of 14 x 14 maps, multiplier 2 put 31 % of the kernel's LDS cycles into bank conflicts (PMC), 6 leaves 5 %;
+// tools/lds_swizzle_check.py enumerates every fragment, tap and boundary phase).
 // Epilogue: bias, ReLU, 2x2 max-pool, per-channel affine through LDS, 16-byte NHWC stores (same contract as
 // vnqa_conv2d_igemm_fwd).  bf16 / fp16 storage only.
 #include "conv_args.h"
@@ -57,7 +59,10 @@ __device__ __forceinline__ void ps_glds(const char* sbase, unsigned voff, unsign
 }
 
 // row multiplier of the patch swizzle key (col + RM row) & 6: exhaustive search per geometry (tools/lds_swizzle_check.py)
-template <int TC, int HALO> constexpr int ps_rm() { return TC == 14 ? (HALO == 1 ? 2 : 6) : 4; }
+#ifndef VNQA_PS_RM14
+#define VNQA_PS_RM14 6
+#endif
+template <int TC, int HALO> constexpr int ps_rm() { return TC == 14 ? (HALO == 1 ? VNQA_PS_RM14 : 6) : 4; }
 template <int TC, int HALO> __device__ __forceinline__ int ps_swz(int row, int col) { return (col + ps_rm<TC, HALO>() * row) & 6; }
 
 template <int TC, int HALO, int TAG>
