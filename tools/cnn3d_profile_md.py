@@ -34,8 +34,9 @@ for label, sub in (("forward", "conv_igemm_kernel<unsigned short, 256, 128"), ("
                    ("wgrad", "conv_wgrad_kernel<unsigned short, true>")):
     for r in find(sub):
         mx = float(r.get("MaxNs", r["AverageNs"])) / 1e3
+        tf = conv2 / mx * 1e3                      # GFLOP / us = PFLOP/s
         print("| %s | `%s` | %.0f | %.0f | %.3f |" % (label, r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")[:60], mx,
-                                                      conv2 / mx * 1e3 / 1e3, conv2 / mx / PEAK))
+                                                      tf, tf / PEAK))
 print("\n(the same kernels also serve conv3a's 22-GFLOP passes; the largest launch of each name is conv2's)\n")
 foreign = [r for r in rows if r["Name"].lstrip().startswith(("void at::native", "at::native", "Cijk_", "MIOpen", "void at::cuda"))]
 ft = sum(float(r["TotalDurationNs"]) for r in foreign) / 1e6 / steps

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: the trunk's weight-gradient launch alone (tools/bench_wgrad.py) under rocprofv3 -> kernel-only time
-# next to the whole op's (kernel + slab reduce + bias column sums) -> gpurun_out/r02_wgrad.txt
+# next to the whole op's (kernel + slab reduce + bias column sums) -> gpurun_out/r03_wgrad.txt
 ROOT=$PWD; export PYTHONPATH=$ROOT
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/wg
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/wg -- python3 $ROOT/tools/bench_wgrad.py > /tmp/wg.out 2>/dev/null
@@ -16,5 +16,5 @@ for r in csv.DictReader(open(sys.argv[1])):
         us = float(r["AverageNs"]) / 1e3
         print("conv_wgrad_kernel alone: %.1f us = %.0f TFLOP/s on valid pixels" % (us, 2.0 * 280 * 196 * 512 * 512 * 9 / us / 1e6))
 PY
-} > gpurun_out/r02_wgrad.txt
-cat gpurun_out/r02_wgrad.txt
+} > gpurun_out/r03_wgrad.txt
+cat gpurun_out/r03_wgrad.txt

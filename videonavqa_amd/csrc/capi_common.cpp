@@ -28,13 +28,13 @@ extern "C" int32_t vnqa_persistent_reserve(void) {
   if (v < 0) {
     const char* e = getenv("VNQA_PERSISTENT_RESERVE_CUS");
     v = e ? atoi(e) : 0;
-    v = v < 0 ? 0 : (v > 128 ? 128 : v);
+    v = v < 0 ? 0 : (v > 224 ? 224 : v);
     g_reserve.store(v);
   }
   return v;
 }
 
-extern "C" void vnqa_set_persistent_reserve(int32_t n) { g_reserve.store(n < 0 ? 0 : (n > 128 ? 128 : n)); }
+extern "C" void vnqa_set_persistent_reserve(int32_t n) { g_reserve.store(n < 0 ? 0 : (n > 224 ? 224 : n)); }
 
 extern "C" int vnqa_stream_create_reserved(int32_t reserve_cus, void** stream) {
   int dev = 0, n_cu = 0;
@@ -44,8 +44,8 @@ extern "C" int vnqa_stream_create_reserved(int32_t reserve_cus, void** stream) {
   }
   VNQA_CHECK_ARG(n_cu % 64 == 0 && n_cu <= 512, "stream_create_reserved: unexpected CU count %d", n_cu);
   const int cls = n_cu / 8;                                    // CUs per residue class below
-  VNQA_CHECK_ARG(stream != nullptr && reserve_cus >= 0 && reserve_cus % cls == 0 && reserve_cus <= n_cu / 2,
-                 "stream_create_reserved: reserve_cus must be a multiple of %d in [0, %d] (got %d)", cls, n_cu / 2, reserve_cus);
+  VNQA_CHECK_ARG(stream != nullptr && reserve_cus >= 0 && reserve_cus % cls == 0 && reserve_cus <= n_cu - cls,
+                 "stream_create_reserved: reserve_cus must be a multiple of %d in [0, %d] (got %d)", cls, n_cu - cls, reserve_cus);
   // Measured on MI355X (tools/probe_cu_mask.py, the whole frozen stem on the masked stream): mask bit i is CU i / 8 of XCD i % 8,
   // and inside an XCD consecutive indices fall on different shader engines.  Workgroups are dealt round-robin to XCDs and to
   // the engines of an XCD regardless of the mask, so the slowest XCD / engine sets the kernel's time: one missing CU in ONE XCD

@@ -70,11 +70,13 @@ def _write_unit(dim, self_attention, memory_gate):   # mac.py:66-80
 class MACNetwork(nn.Module):
     """Positional signature and defaults of mac.py:169-171; keyword-only extras: precision."""
 
-    # train.Trainer can keep this many CUs free of the frozen stem's kernels (CU-masked stem stream).  Measured for this model's
-    # ~1 000-launch reasoning chain (tools/ab_mac.sh): 0 -> 414 clips/s, 32 -> 286, 64 -> 280 — the chain's workgroups are dealt
-    # to ALL CUs whatever the stem leaves free, so they still queue behind stem workgroups, and the stem itself loses 1/8 of
-    # the chip.  Hence 0: stem and chain run back to back (6.6 + 11.3 ms).
-    stem_reserve_cus = 0
+    # train.Trainer keeps this many CUs free of the frozen stem's kernels (CU-masked stem stream, 16 CUs of every XCD): this
+    # model's trunk is a ~1 000-launch dependent chain of small kernels that otherwise queue behind stem workgroups owning a
+    # whole CU's LDS, so stem (6.6 ms) and chain (11.3 ms) ran back to back.  With the chain on the Trainer's high-priority
+    # stream AND half the chip to itself they overlap: `tools/ab_mac_reserve.sh`, same box — reserve 0: 413 clips/s, 96: 492,
+    # 128: 503-505, 160: 445, 192: 316 (the masked stem alone takes 13 ms at 128, the chain 11.3 + contention).  Without the
+    # high-priority trunk stream a reservation makes things worse (64 CUs: 275), which is what round 3 measured first.
+    stem_reserve_cus = 128
 
     def __init__(self, n_vocab, dim, embed_hidden=300, max_step=12, self_attention=False, memory_gate=False,
                  classes=28, dropout=0.15, max_num_frames=35, *, precision='bf16'):

@@ -179,11 +179,14 @@ class FrozenStem(object):
         i.e. one small GEMM for Y1 (ring im2col x W1) and four edge GEMMs (top / bottom / left / right, K = 3 c_mid);
         the composed kernel subtracts R from the border pixels' sums before ReLU and pooling."""
         dev = c1.weight.device
-        w1, b1 = c1.weight.detach().double(), c1.bias.detach().double()
-        w2, b2 = c2.weight.detach().double(), c2.bias.detach().double()
+        # composed once, in fp64, on the HOST (a one-off 2-GFLOP product: keeps fp64 rocBLAS / im2col kernels out of the device
+        # traces and costs ~0.3 s at construction)
+        w1, b1 = c1.weight.detach().double().cpu(), c1.bias.detach().double().cpu()
+        w2, b2 = c2.weight.detach().double().cpu(), c2.bias.detach().double().cpu()
         scale, shift = _fold_bn(bn)
-        w2 = w2 * scale.double().view(-1, 1, 1, 1)
-        b2 = b2 * scale.double() + shift.double()
+        scale, shift = scale.double().cpu(), shift.double().cpu()
+        w2 = w2 * scale.view(-1, 1, 1, 1)
+        b2 = b2 * scale + shift
         wc = torch.nn.functional.conv2d(w1.permute(1, 0, 2, 3), w2.flip(2, 3), padding=2).permute(1, 0, 2, 3)   # [co,ci,5,5]
         bc = b2 + w2.sum((2, 3)) @ b1
         co, ci, cm = wc.shape[0], wc.shape[1], w1.shape[0]
@@ -192,21 +195,21 @@ class FrozenStem(object):
         tile = L.TILE_STEM_256x256 if (bf16 and co_pad >= 256) else (L.TILE_AUTO if bf16 else L.TILE_128x128)
         if bf16 and os.environ.get("VNQA_STEM_COMPOSE_TILE"):
             tile = int(os.environ["VNQA_STEM_COMPOSE_TILE"])      # A/B hook
-        wcf = wc.float().contiguous()
+        wcf = wc.float().contiguous().to(dev)
         if tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256) and os.environ.get("VNQA_STEM_TILED", "1") != "0":
             wt = K.pack_conv_weight_tiled(wcf, self.cdt, tile, c_out_pad=co_pad, c_in_pad=ci_pad)
         else:
             wt = K.pack_conv_weight(wcf, self.cdt, c_out_pad=co_pad, c_in_pad=ci_pad)
         # ring GEMM operand: W1 K-major [cm_pad][9*ci_pad]; edge operands: (s W2) slices [co_pad][3*cm_pad]
-        w1m = K.pack_conv_weight(w1.float().contiguous(), self.cdt, c_out_pad=cm_pad, c_in_pad=ci_pad).view(cm_pad, -1)
+        w1m = K.pack_conv_weight(w1.float().contiguous().to(dev), self.cdt, c_out_pad=cm_pad, c_in_pad=ci_pad).view(cm_pad, -1)
 
         def edge(sel):      # sel: [co,cm,3] -> [co_pad, 3*cm_pad] (slot-major, channels fastest)
-            e = torch.zeros(co_pad, 3, cm_pad, dtype=torch.float64, device=dev)
+            e = torch.zeros(co_pad, 3, cm_pad, dtype=torch.float64)
             e[:co, :, :cm] = sel.permute(0, 2, 1)
-            return e.view(co_pad, -1).to(self.cdt).contiguous()
+            return e.view(co_pad, -1).to(dev).to(self.cdt).contiguous()
         edges = dict(top=edge(w2[:, :, 0, :]), bottom=edge(w2[:, :, 2, :]), left=edge(w2[:, :, :, 0]), right=edge(w2[:, :, :, 2]))
         edges_all = torch.stack([edges[k] for k in ("top", "bottom", "left", "right")]).contiguous()   # [4, co_pad, 3*cm_pad]
-        return dict(wt=wt, bias=K.pad_vec(bc.float(), co_pad), b1=K.pad_vec(b1.float(), cm_pad), w1m=w1m, edges=edges,
+        return dict(wt=wt, bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges,
                     edges_all=edges_all,
                     c_in=ci, c_out=co, c_out_pad=co_pad, c_mid_pad=cm_pad, tile=tile, taps=25)
 

@@ -167,10 +167,11 @@ class Trainer(object):
         reserve = int(reserve) if reserve is not None else int(getattr(model, "stem_reserve_cus", 0))
         self.stem_reserve_cus = reserve if (stem is not None and self.fp.flat.is_cuda) else 0
         if self.stem_reserve_cus > 0:
-            from . import _lib as L
             self.stem_stream = L.reserved_stream(self.stem_reserve_cus, self.stem_device)
         else:
             self.stem_stream = torch.cuda.Stream(priority=prio)
+            if stem is not None and self.fp.flat.is_cuda:
+                L.lib().vnqa_set_persistent_reserve(0)       # (process-wide: the most recently built Trainer's setting holds)
         # The trunk (the step's dependent chain: question LSTMs, FiLM blocks, attention tail, backward, Adam) runs on its own
         # HIGH-priority stream by default: its kernels are dispatched ahead of the co-running stem's whenever both have
         # workgroups pending, so the chain finishes sooner and the stem fills what is left (same-box A/B, 4 rounds each:
