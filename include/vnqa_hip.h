@@ -608,7 +608,7 @@ typedef struct vnqa_mac_wgrad {
   int32_t rows, d;
   const float *d_concat, *read, *memory, *v, *d_t, *d_mem, *d_cq, *control, *dv, *cnew, *dqv, *cq;
   float *g_wc, *g_wca, *g_wm, *g_bm, *g_w1, *g_wra, *g_wr, *g_wmm, *g_bw;
-  void* workspace;                                                 /* vnqa_mac_core_wgrad_workspace(rows, d) bytes, or NULL */
+  void* workspace;                                                 /* vnqa_mac_core_wgrad_workspace(rows, d) bytes (required) */
 } vnqa_mac_wgrad;
 int64_t vnqa_mac_core_wgrad_workspace(int32_t rows, int32_t d);
 int vnqa_mac_core_wgrad(const vnqa_mac_wgrad* w, void* stream);

@@ -227,7 +227,11 @@ __global__ void __launch_bounds__(512) sgemm_mfma_kernel(const SgemmArgs p, floa
   vnqa_f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  constexpr int U = 4;                       // chunks of 8 K-values per stage; the next stage's loads fly under this stage's MFMAs
+  // chunks of 8 K-values (lane half h takes k0 + 4 h .. + 3 of each, so the two halves of a row read ADJACENT 16 bytes and one load
+  // instruction touches 32 lines); the next stage's loads fly under this stage's MFMAs.  (Measured and dropped: giving each
+  // half 32 consecutive K-values, so that a lane's eight loads walk one 128-byte line — 64 lines per instruction instead of
+  // 32 — made the [280,512]x[512,512] product slower, 11.9 -> 15.4 us: the address coalescer, not L1 reuse, is the limit.)
+  constexpr int U = 4;
   float a0[U][4], b0[U][4], a1[U][4], b1[U][4];
 #pragma unroll
   for (int c = 0; c < U; ++c) {

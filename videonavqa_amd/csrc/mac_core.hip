@@ -34,23 +34,39 @@ int ew_mul(float* out, const float* x, const float* y, const float* z, int n, in
   return VNQA_OK;
 }
 
-// out[j] = sum_r x[r][j] * y[r][j]: 64 columns x 16 row lanes per block, partial sums folded through LDS in a fixed order
+// partial[z][j] = sum over row share z of x[r][j] * (y ? y[r][j] : 1): 64 columns x 16 row lanes per block, grid (cols / 64, shares);
+// fold_shares_kernel sums the shares in order (deterministic)
+constexpr int MC_SHARES = 32;
 __global__ void __launch_bounds__(1024) dot_colsum_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                          float* __restrict__ out, int rows, int cols) {
+                                                          float* __restrict__ partial, int rows, int cols) {
   __shared__ float s_part[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + cx;
+  const int per = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * per;
+  int r1 = r0 + per;
+  r1 = r1 < rows ? r1 : rows;
   float s = 0.f;
-  if (n < cols)
-    for (int m = ry; m < rows; m += 16) s = fmaf(x[(size_t)m * cols + n], y[(size_t)m * cols + n], s);
+  if (n < cols) {
+    if (y != nullptr)
+      for (int m = r0 + ry; m < r1; m += 16) s = fmaf(x[(size_t)m * cols + n], y[(size_t)m * cols + n], s);
+    else
+      for (int m = r0 + ry; m < r1; m += 16) s += x[(size_t)m * cols + n];
+  }
   s_part[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && n < cols) {
     float t = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t += s_part[r][cx];
-    out[n] = t;
+    partial[(size_t)blockIdx.y * cols + n] = t;
   }
+}
+__global__ void fold_shares_kernel(const float* __restrict__ partial, float* __restrict__ out, int shares, int cols) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= cols) return;
+  float t = 0.f;
+  for (int z = 0; z < shares; ++z) t += partial[(size_t)z * cols + n];
+  out[n] = t;
 }
 
 #define MC_TRY(call)             \
@@ -152,7 +168,9 @@ extern "C" int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream) {
 // Parameter gradients of ALL reasoning steps at once: every factor is the per-step [n][d] matrices stacked to [rows = steps * n][d]
 // (the caller keeps them step-major in one slab), so each weight gradient is ONE product over K = rows instead of `steps`
 // accumulating products on the backward pass's dependent chain (12 steps x 9 launches off that chain).
-extern "C" int64_t vnqa_mac_core_wgrad_workspace(int32_t rows, int32_t d) { return vnqa_sgemm_workspace(d, d, rows); }
+extern "C" int64_t vnqa_mac_core_wgrad_workspace(int32_t rows, int32_t d) {
+  return vnqa_sgemm_workspace(d, d, rows) + (int64_t)MC_SHARES * d * 4;      // split-K scratch, then the column sums' row shares
+}
 
 extern "C" int vnqa_mac_core_wgrad(const vnqa_mac_wgrad* w, void* stream) {
   VNQA_CHECK_ARG(w != nullptr && w->rows > 0 && w->d > 0, "mac_wgrad: bad argument block");
@@ -167,11 +185,16 @@ extern "C" int vnqa_mac_core_wgrad(const vnqa_mac_wgrad* w, void* stream) {
   MC_TRY(gemm_tn(w->v, w->d_t, w->g_w1, d, d, R, 0, w->workspace, stream));
   MC_TRY(gemm_tn(w->d_mem, w->memory, w->g_wm, d, d, R, 0, w->workspace, stream));
   MC_TRY(gemm_tn(w->d_cq, w->control, w->g_wc, d, d, R, 0, w->workspace, stream));
-  MC_TRY(vnqa_colsum(w->d_concat, nullptr, w->g_bw, R, d, d, VNQA_F32, stream));
-  MC_TRY(vnqa_colsum(w->d_mem, nullptr, w->g_bm, R, d, d, VNQA_F32, stream));
-  hipLaunchKernelGGL(dot_colsum_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, w->dv, w->cnew, w->g_wra, R, d);
-  VNQA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dot_colsum_kernel, dim3((d + 63) / 64), dim3(1024), 0, st, w->dqv, w->cq, w->g_wca, R, d);
+  VNQA_CHECK_ARG(w->workspace != nullptr, "mac_wgrad: workspace required (vnqa_mac_core_wgrad_workspace bytes)");
+  float* shares = (float*)((char*)w->workspace + vnqa_sgemm_workspace(d, d, R));
+  auto colsum2 = [&](const float* x, const float* y, float* out) {
+    hipLaunchKernelGGL(dot_colsum_kernel, dim3((d + 63) / 64, MC_SHARES), dim3(1024), 0, st, x, y, shares, R, d);
+    hipLaunchKernelGGL(fold_shares_kernel, dim3((d + 255) / 256), dim3(256), 0, st, (const float*)shares, out, MC_SHARES, d);
+  };
+  colsum2(w->d_concat, nullptr, w->g_bw);
+  colsum2(w->d_mem, nullptr, w->g_bm);
+  colsum2(w->dv, w->cnew, w->g_wra);
+  colsum2(w->dqv, w->cq, w->g_wca);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -877,7 +877,7 @@ class MacCoreFn(torch.autograd.Function):
             K.mac_wgrad(rows, d, dict(d_concat=stack(2), read=flat(F_["read"]), memory=stack(1), v=flat(F_["v"]),
                                       d_t=flat(B_["d_t"]), d_mem=flat(B_["d_mem"]), d_cq=flat(B_["d_cq"]), control=stack(0),
                                       dv=flat(B_["dv"]), cnew=flat(F_["cnew"]), dqv=flat(B_["dqv"]), cq=flat(F_["cq"]),
-                                      workspace=K.workspace(nb, dev) if nb > 0 else None, **G))
+                                      workspace=K.workspace(nb, dev), **G))
             gp = [G["g_wc"], G["g_wca"].view(1, d), used(B_["ds_c"]).sum().view(1), G["g_wm"], G["g_bm"],
                   G["g_w1"], G["g_wra"].view(1, d), used(B_["ds_r"]).sum().view(1), G["g_wr"], G["g_wmm"], G["g_bw"]]
             st.outer, st.fwd, st.bwd = {}, None, None
