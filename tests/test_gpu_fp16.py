@@ -29,7 +29,7 @@ def _run(args, timeout):
 
 def test_kernel_and_model_suites_on_the_fp16_storage_build():
     tail = _run(["tests/test_gpu_conv.py", "tests/test_gpu_fused_epilogue.py", "tests/test_gpu_glue.py", "tests/test_gpu_models.py",
-                 "tests/test_gpu_trainer.py", "tests/test_weight_import.py", "tests/test_gpu_edge_cases.py"], 1500)
+                 "tests/test_gpu_trainer.py", "tests/test_weight_import.py", "tests/test_gpu_edge_cases.py", "tests/test_gpu_conv3d.py"], 1500)
     assert " passed" in tail, tail
 
 
