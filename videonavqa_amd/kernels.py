@@ -3,6 +3,7 @@
 Activations are "padded NHWC" tensors [N, H+2, W+2, C] (zero halo) — see include/vnqa_hip.h.
 """
 import ctypes
+import os
 
 import torch
 
@@ -720,8 +721,10 @@ def conv3d_igemm(x, wt, bias=None, relu=False, pool2=False, out=None):
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Dp, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
+    # 128-cout 3-D convs (VideoOnlyCNN3D conv2 / conv3a): the 512 x 128 tile (tools/ab_c3d_tiles.sh: config 2 +1.5 % over the 256 x 128 default)
+    tile = int(os.environ.get("VNQA_C3D_TILE_%d" % c_out, 15 if c_out == 128 else L.TILE_AUTO)) if L.is_half(x.dtype) else L.TILE_AUTO
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], 27, 1, 1, int(relu), 1 if pool2 else 0,
-                   L.TILE_AUTO, 0, D)
+                   tile, 0, D)
     L.check(L.lib().vnqa_conv2d_igemm_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), None, None, L.ptr(out),
                                           L.stream()), "vnqa_conv2d_igemm_fwd(3d)")
     return out
