@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 303
+#define VNQA_ABI_VERSION 304
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -476,6 +476,12 @@ int64_t vnqa_sgemm_workspace(int32_t m, int32_t n, int32_t k);   /* bytes of spl
 int vnqa_sgemm(const float* a, const float* b, float* c, const float* bias, const float* a_mask, const int32_t* a_rows,
                const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int32_t ldc, int32_t m,
                int32_t n, int32_t k, int32_t relu, int32_t accumulate, const float* addend, void* workspace, void* stream);
+/* vnqa_sgemm (no gather / scatter / mask / accumulate / ReLU) with a SECOND output written by the same epilogue:
+ * out2[m][n] = C[m][n] * out2_col[n] * out2_mul[m][n] (either factor may be NULL; out2 / out2_mul rows of ldc floats) — the
+ * elementwise products that follow MACNetwork's reasoning-step projections (mac.py:33,57-58). */
+int vnqa_sgemm2(const float* a, const float* b, float* c, const float* bias, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs,
+                int32_t ldc, int32_t m, int32_t n, int32_t k, const float* addend, float* out2, const float* out2_col,
+                const float* out2_mul, void* workspace, void* stream);
                /* addend: optional fp32 matrix [m][ldc] added to the product (torch.addmm's first argument) */
                /* workspace: vnqa_sgemm_workspace bytes (skinny outputs over a long K are split over workgroups and summed in
                 * slice order by a second launch); NULL = one pass over K */

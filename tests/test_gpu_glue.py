@@ -275,3 +275,18 @@ def test_reserved_cu_stream_runs_kernels_and_sets_persistent_grids():
     with pytest.raises(L.VnqaError):
         L.reserved_stream(8)            # not a whole share of every XCD's shader engines
     L.lib().vnqa_set_persistent_reserve(0)
+
+
+@pytest.mark.parametrize("shape", [(280, 512, 512), (37, 70, 200), (8, 70, 4480)])
+def test_sgemm2_second_output_from_the_same_epilogue(shape):
+    """vnqa_sgemm2: y = x w^T + addend and y2 = y * col[n] * mul[m, n] (with and without split-K slices)."""
+    from videonavqa_amd import kernels as K
+    m, n, k = shape
+    g = torch.Generator().manual_seed(m + n + k)
+    x, w = torch.randn(m, k, generator=g).cuda(), torch.randn(n, k, generator=g).cuda()
+    add, col, mul = torch.randn(m, n, generator=g).cuda(), torch.randn(n, generator=g).cuda(), torch.randn(m, n, generator=g).cuda()
+    ref = x.double() @ w.double().t() + add.double()
+    for c_, m_ in ((col, None), (None, mul), (col, mul)):
+        y, y2 = K.linear_nt2(x, w, addend=add, out2_col=c_, out2_mul=m_)
+        r2 = ref * (1 if c_ is None else c_.double()) * (1 if m_ is None else m_.double())
+        assert _close(y, ref.float(), 2e-5) and _close(y2, r2.float(), 2e-5)

@@ -14,6 +14,8 @@
 //
 // The pixel dimension is split over workgroups (split-K); partial tiles go to fp32 slabs in a
 // caller-provided workspace and a second kernel sums them in a fixed order (deterministic).
+#include <cstdlib>
+
 #include "vnqa_common.h"
 
 namespace {
@@ -33,7 +35,12 @@ struct WgradArgs {
   int tilesCo, tilesCi;
   int ksteps_total, ksteps_per_slice, slices;
   int taps_real;    // SMALL form: `taps` counts tap GROUPS of 256 / Cin taps; this is the conv's tap count (27)
+  float* final;     // != NULL: the LAST workgroup to finish a tile folds the slices' partial tiles into `final` (no reduce launch)
 };
+
+// arrival counters of the fused slab reduce, one per output tile, self-resetting (the last arriver writes 0 back).  Process-wide:
+// two weight-gradient launches must not be in flight at once on different streams (they never are: the trunk is one stream).
+__device__ int g_wgrad_arrivals[8192];
 
 __device__ __forceinline__ void glds16w(const char* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -480,6 +487,35 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
           if (co < p.Cout && ci < p.Cin) slab[((size_t)co * p.taps + tap) * p.Cin + ci] = acc16[i][j][e];
         }
       }
+    if (p.final != nullptr) {
+      // Fused slab reduce: release this workgroup's partial tile, count arrivals; whoever arrives last acquires the others'
+      // tiles and sums them IN SLICE ORDER (the result does not depend on which workgroup that is).
+      __shared__ int s_last;
+      __threadfence();
+      __syncthreads();
+      const int tile_id = (tile_co * p.taps + tap) * p.tilesCi + tile_ci;
+      if (threadIdx.x == 0) {
+        const int old = atomicAdd(&g_wgrad_arrivals[tile_id], 1);
+        s_last = old == p.slices - 1;
+        if (s_last) g_wgrad_arrivals[tile_id] = 0;
+      }
+      __syncthreads();
+      if (s_last) {
+        __threadfence();
+        const size_t n_all = (size_t)p.Cout * p.taps * p.Cin;
+        for (int e = threadIdx.x; e < BCH * (BCH / 4); e += 512) {
+          const int co = tile_co * BCH + e / (BCH / 4), ci = tile_ci * BCH + (e % (BCH / 4)) * 4;
+          if (co >= p.Cout || ci >= p.Cin) continue;
+          const size_t off = ((size_t)co * p.taps + tap) * p.Cin + ci;
+          float4 acc4 = *(const float4*)(p.out + off);
+          for (int z = 1; z < p.slices; ++z) {
+            const float4 v = *(const float4*)(p.out + (size_t)z * n_all + off);
+            acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w;
+          }
+          *(float4*)(p.final + off) = acc4;
+        }
+      }
+    }
     return;
   }
 #pragma unroll
@@ -730,6 +766,14 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   a.ksteps_per_slice = pl.ksteps_per_slice;
   a.slices = pl.slices;
   a.taps_real = taps;
+  a.final = nullptr;
+  // (opt-in: measured SLOWER end to end — same-box A/B 845 vs 869 clips/s over three rounds: the agent-scope release / acquire
+  // fences write back and invalidate L2 lines across the 8 XCDs for every workgroup, which costs more than the 20 us reduce
+  // launches it saves)
+  static const bool fuse_reduce = [] { const char* e = getenv("VNQA_WGRAD_FUSED_REDUCE"); return e != nullptr && e[0] == '1'; }();
+  if (fuse_reduce && !small && dtype == VNQA_BF16 && pl.slices > 1 && c_in % 4 == 0 &&
+      (long long)pl.tilesCo * taps * pl.tilesCi <= 8192)
+    a.final = dwt;
   const int lds = 2 * 65536;
   int grid = pl.slices * pl.tilesCo * taps * pl.tilesCi;
   int n_slabs = pl.slices;
@@ -775,7 +819,7 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   }
   VNQA_CHECK_LAUNCH();
   const size_t n = (size_t)c_out * taps * c_in;
-  if (n_slabs > 1) {
+  if (n_slabs > 1 && a.final == nullptr) {
     int g = (int)((n + 255) / 256);
     g = g > 2048 ? 2048 : g;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(g), dim3(256), 0, st, (const float*)workspace, dwt, n, n_slabs);

@@ -26,6 +26,9 @@ struct SgemmArgs {
   float* C;
   const float* bias;     // [N] or null
   const float* bias2;    // second bias vector added like `bias` (b_ih + b_hh of an LSTM input projection); or null
+  float* out2;           // optional second output (rows / ldc as C): out2 = result * out2_col[n] * out2_mul(m, n); or null
+  const float* out2_col; // [N] or null
+  const float* out2_mul; // matrix indexed like `addend` (logical row m, ldc) or null
   const float* addend;   // matrix added to the product (same rows / ldc as C, read at the LOGICAL row m); or null
   const float* a_mask;   // same indexing as A: A'(m,k) = A(m,k) * [a_mask(m,k) > 0]; or null
   const int* a_rows;     // [M]: physical row of A for logical row m (negative: a zero row); or null
@@ -146,6 +149,12 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __
       if (p.accumulate) v += *dst;
       if (p.relu) v = fmaxf(v, 0.f);
       *dst = v;
+      if (p.out2 != nullptr) {
+        float w = v;
+        if (p.out2_col != nullptr) w *= p.out2_col[n];
+        if (p.out2_mul != nullptr) w *= p.out2_mul[(long long)m * p.ldc + n];
+        p.out2[(long long)row * p.ldc + n] = w;
+      }
     }
   }
 }
@@ -287,6 +296,12 @@ __global__ void __launch_bounds__(512) sgemm_mfma_kernel(const SgemmArgs p, floa
     if (p.accumulate) v += *dst;
     if (p.relu) v = fmaxf(v, 0.f);
     *dst = v;
+    if (p.out2 != nullptr) {
+      float w = v;
+      if (p.out2_col != nullptr) w *= p.out2_col[n];
+      if (p.out2_mul != nullptr) w *= p.out2_mul[(long long)m * p.ldc + n];
+      p.out2[(long long)orow * p.ldc + n] = w;
+    }
   }
 }
 
@@ -335,6 +350,12 @@ __global__ void sgemm_finish_kernel(const SgemmArgs p, const float* __restrict__
     if (p.accumulate) v += *dst;
     if (p.relu) v = fmaxf(v, 0.f);
     *dst = v;
+    if (p.out2 != nullptr) {
+      float w = v;
+      if (p.out2_col != nullptr) w *= p.out2_col[n];
+      if (p.out2_mul != nullptr) w *= p.out2_mul[(long long)m * p.ldc + n];
+      p.out2[(long long)row * p.ldc + n] = w;
+    }
   }
 }
 
@@ -527,13 +548,35 @@ extern "C" int64_t vnqa_sgemm_workspace(int32_t m, int32_t n, int32_t k) {
   return s <= 1 ? 0 : (int64_t)s * m * n * 4;
 }
 
+static int sgemm_run(const float* a, const float* b, float* c, const float* bias, const float* a_mask, const int32_t* a_rows,
+                     const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int32_t ldc, int32_t m,
+                     int32_t n, int32_t k, int32_t relu, int32_t accumulate, const float* addend, void* workspace, void* stream,
+                     float* out2, const float* out2_col, const float* out2_mul);
+
 extern "C" int vnqa_sgemm(const float* a, const float* b, float* c, const float* bias, const float* a_mask,
                           const int32_t* a_rows, const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs,
                           int64_t b_cs, int32_t ldc, int32_t m, int32_t n, int32_t k, int32_t relu, int32_t accumulate,
                           const float* addend, void* workspace, void* stream) {
+  return sgemm_run(a, b, c, bias, a_mask, a_rows, c_rows, a_rs, a_cs, b_rs, b_cs, ldc, m, n, k, relu, accumulate, addend, workspace,
+                   stream, nullptr, nullptr, nullptr);
+}
+
+// vnqa_sgemm with a second output written by the same epilogue: out2 = C_result * out2_col[n] * out2_mul(m, n)
+extern "C" int vnqa_sgemm2(const float* a, const float* b, float* c, const float* bias, int64_t a_rs, int64_t a_cs, int64_t b_rs,
+                           int64_t b_cs, int32_t ldc, int32_t m, int32_t n, int32_t k, const float* addend, float* out2,
+                           const float* out2_col, const float* out2_mul, void* workspace, void* stream) {
+  VNQA_CHECK_ARG(out2 != nullptr, "sgemm2: out2 required");
+  return sgemm_run(a, b, c, bias, nullptr, nullptr, nullptr, a_rs, a_cs, b_rs, b_cs, ldc, m, n, k, 0, 0, addend, workspace, stream,
+                   out2, out2_col, out2_mul);
+}
+
+static int sgemm_run(const float* a, const float* b, float* c, const float* bias, const float* a_mask, const int32_t* a_rows,
+                     const int32_t* c_rows, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs, int32_t ldc, int32_t m,
+                     int32_t n, int32_t k, int32_t relu, int32_t accumulate, const float* addend, void* workspace, void* stream,
+                     float* out2, const float* out2_col, const float* out2_mul) {
   VNQA_CHECK_ARG(a && b && c && m > 0 && n > 0 && k > 0 && ldc >= n, "sgemm: bad arguments (m=%d n=%d k=%d ldc=%d)", m, n, k, ldc);
   SgemmArgs p;
-  p.A = a; p.B = b; p.C = c; p.bias = bias; p.bias2 = nullptr; p.addend = addend; p.a_mask = a_mask; p.a_rows = a_rows; p.c_rows = c_rows;
+  p.A = a; p.B = b; p.C = c; p.bias = bias; p.bias2 = nullptr; p.out2 = out2; p.out2_col = out2_col; p.out2_mul = out2_mul; p.addend = addend; p.a_mask = a_mask; p.a_rows = a_rows; p.c_rows = c_rows;
   p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc; p.M = m; p.N = n; p.K = k;
   p.relu = relu; p.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
@@ -589,7 +632,7 @@ extern "C" int vnqa_embed_proj_fwd(const int64_t* tokens, const int32_t* row_per
   VNQA_CHECK_LAUNCH();
   // xg [n_pos][g] = embed[rows] (n_pos x e)  @  w_ih^T (e x g)  + b_ih + b_hh : the embedding lookup IS the GEMM's row gather
   SgemmArgs p;
-  p.A = embed; p.B = w_ih; p.C = xg; p.bias = b_ih; p.bias2 = b_hh; p.addend = nullptr; p.a_mask = nullptr; p.a_rows = rows; p.c_rows = nullptr;
+  p.A = embed; p.B = w_ih; p.C = xg; p.bias = b_ih; p.bias2 = b_hh; p.out2 = nullptr; p.out2_col = nullptr; p.out2_mul = nullptr; p.addend = nullptr; p.a_mask = nullptr; p.a_rows = rows; p.c_rows = nullptr;
   p.a_rs = e; p.a_cs = 1; p.b_rs = 1; p.b_cs = e; p.ldc = g; p.M = n_pos; p.N = g; p.K = e; p.relu = 0; p.accumulate = 0;
   sgemm_launch(p, nullptr, (e + 15) / 16 * 16, 1, st);
   VNQA_CHECK_LAUNCH();

@@ -69,6 +69,16 @@ __global__ void fold_shares_kernel(const float* __restrict__ partial, float* __r
   out[n] = t;
 }
 
+// o1 = x * y1, o2 = x * y2 (the two products of one backward factor in one launch)
+__global__ void ew_mul2_kernel(float* __restrict__ o1, float* __restrict__ o2, const float* __restrict__ x,
+                               const float* __restrict__ y1, const float* __restrict__ y2, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float v = x[i];
+    o1[i] = v * y1[i];
+    o2[i] = v * y2[i];
+  }
+}
+
 #define MC_TRY(call)             \
   do {                           \
     const int rc__ = (call);     \
@@ -80,6 +90,15 @@ __global__ void fold_shares_kernel(const float* __restrict__ partial, float* __r
 int gemm_nt(const float* a, const float* b, float* c, const float* bias, const float* addend, int m, int n, int k, int acc,
             void* ws, void* st) {
   return vnqa_sgemm(a, b, c, bias, nullptr, nullptr, nullptr, k, 1, 1, k, n, m, n, k, 0, acc, addend, ws, st);
+}
+// C = A B^T + addend and, from the same epilogue, out2 = C * colscale[n]
+int gemm_nt_scaled(const float* a, const float* b, float* c, const float* addend, float* out2, const float* colscale, int m, int n,
+                   int k, void* ws, void* st) {
+  return vnqa_sgemm2(a, b, c, nullptr, k, 1, 1, k, n, m, n, k, addend, out2, colscale, nullptr, ws, st);
+}
+// C = A B and out2 = C * mul (elementwise matrix)
+int gemm_nn_mul(const float* a, const float* b, float* c, float* out2, const float* mul, int m, int n, int k, void* ws, void* st) {
+  return vnqa_sgemm2(a, b, c, nullptr, k, 1, n, 1, n, m, n, k, nullptr, out2, nullptr, mul, ws, st);
 }
 // C[m,n] = A[m,k] B (B [k,n])
 int gemm_nn(const float* a, const float* b, float* c, int m, int n, int k, int acc, void* ws, void* st) {
@@ -108,14 +127,12 @@ extern "C" int vnqa_mac_core_fwd(const vnqa_mac_core* a, void* stream) {
                  "mac_core_fwd: null output");
   const int N = a->n, d = a->d;
   hipStream_t st = (hipStream_t)stream;
-  MC_TRY(gemm_nt(a->control, a->wc, a->cq, nullptr, a->pq, N, d, d, 0, a->workspace, stream));            // cq = pq + control Wc^T
-  MC_TRY(ew_mul(a->qv, a->cq, a->w_ca, nullptr, N * d, d, 0, st));                           // qv = cq * w_ca
+  MC_TRY(gemm_nt_scaled(a->control, a->wc, a->cq, a->pq, a->qv, a->w_ca, N, d, d, a->workspace, stream));   // cq = pq + control Wc^T; qv = cq * w_ca
   MC_TRY(vnqa_mac_read_fwd(a->ctxw, nullptr, a->qv, nullptr, a->b_ca, a->p_c, a->cnew, N, a->lq, d, d, VNQA_F32, stream));
   if (a->mask_c != nullptr) MC_TRY(ew_mul(a->cnew, a->cnew, a->mask_c, nullptr, N * d, 0, 0, st));
   MC_TRY(gemm_nt(a->memory, a->wm, a->mem, a->bm, nullptr, N, d, d, 0, a->workspace, stream));             // mem = memory Wm^T + bm
   MC_TRY(ew_mul(a->v, a->cnew, a->w_ra, nullptr, N * d, d, 0, st));                          // v = control' * w_ra
-  MC_TRY(gemm_nn(a->v, a->w1, a->t, N, d, d, 0, a->workspace, stream));                                     // t = v W1
-  MC_TRY(ew_mul(a->u, a->mem, a->t, nullptr, N * d, 0, 0, st));                              // u = mem * t
+  MC_TRY(gemm_nn_mul(a->v, a->w1, a->t, a->u, a->mem, N, d, d, a->workspace, stream));                      // t = v W1; u = mem * t
   MC_TRY(vnqa_mac_read_fwd(a->know, a->pre, a->u, a->v, a->b_ra, a->p_r, a->read, N, a->s, d, a->ld, a->dtype, stream));
   MC_TRY(gemm_nt(a->read, a->wr, a->concat, a->bw, nullptr, N, d, d, 0, a->workspace, stream));            // concat = read Wr^T + bw
   MC_TRY(gemm_nt(a->memory, a->wmm, a->concat, nullptr, nullptr, N, d, d, 1, a->workspace, stream));       //        + memory Wmm^T
@@ -142,8 +159,13 @@ extern "C" int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream) {
   }
   // ReadUnit attention
   MC_TRY(vnqa_mac_read_bwd(a->know, a->pre, a->p_r, a->d_read, a->ds_r, a->du, a->dv, N, a->s, d, a->ld, a->dtype, stream));
-  MC_TRY(ew_mul(a->d_mem, a->du, a->t, nullptr, N * d, 0, 0, st));                           // d mem = du * t
-  MC_TRY(ew_mul(a->d_t, a->du, a->mem, nullptr, N * d, 0, 0, st));                           // d t   = du * mem
+  {                                                                                          // d mem = du * t, d t = du * mem
+    int g = (N * d + 255) / 256;
+    g = g > 1024 ? 1024 : g;
+    hipLaunchKernelGGL(ew_mul2_kernel, dim3(g), dim3(256), 0, st, a->d_mem, a->d_t, (const float*)a->du, (const float*)a->t,
+                       (const float*)a->mem, N * d);
+    VNQA_CHECK_LAUNCH();
+  }
   MC_TRY(gemm_nt(a->d_t, a->w1, a->dv, nullptr, nullptr, N, d, d, 1, a->workspace, stream));                // dv += d t W1^T
   if (!defer) {
     MC_TRY(gemm_tn(a->v, a->d_t, a->g_w1, d, d, N, 1, a->workspace, stream));

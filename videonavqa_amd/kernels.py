@@ -782,6 +782,19 @@ def sgemm(a, b, m, n, k, a_rs, a_cs, b_rs, b_cs, out, bias=None, relu=False, acc
     return out
 
 
+def linear_nt2(x, w, addend=None, out2_col=None, out2_mul=None):
+    """(y, y2) with y = x @ w.T (+ addend) and, from the same epilogue, y2 = y * out2_col[n] * out2_mul[m, n] (vnqa_sgemm2)."""
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    y2 = torch.empty_like(y)
+    ws_bytes = L.lib().vnqa_sgemm_workspace(m, n, k)
+    ws = workspace(ws_bytes, x.device) if ws_bytes > 0 else None
+    L.check(L.lib().vnqa_sgemm2(L.vptr(_f32c(x)), L.vptr(_f32c(w)), L.ptr(y), None, x.stride(0), 1, 1, w.stride(0), n, m, n, k,
+                                L.ptr(addend), L.ptr(y2), L.ptr(out2_col), L.ptr(out2_mul), L.ptr(ws), L.stream()), "vnqa_sgemm2")
+    return y, y2
+
+
 def linear_nt(x, w, bias=None, relu=False, a_rows=None, m=None):
     """act(x_sel @ w.T + bias): x [R,K], w [N,K] fp32 (row-major, unit inner stride); a_rows gathers m rows of x."""
     m = x.shape[0] if m is None else m
