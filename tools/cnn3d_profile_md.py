@@ -30,7 +30,7 @@ def find(sub):
 
 print("## roofline of the three conv2 GEMMs (64 -> 128 channels on 32 x 16 x 56 x 56 positions, %.0f GFLOP each)\n" % conv2)
 print("| pass | kernel | avg launch µs (largest launch) | TFLOP/s | fraction of 2.5 PF |\n|---|---|---|---|---|")
-for label, sub in (("forward", "conv_igemm_kernel<unsigned short, 256, 128"), ("dgrad", "conv_igemm_kernel<unsigned short, 256, 64"),
+for label, sub in (("forward", "conv_igemm_kernel<unsigned short, 512, 128"), ("dgrad", "conv_igemm_kernel<unsigned short, 256, 64"),
                    ("wgrad", "conv_wgrad_kernel<unsigned short, true>")):
     for r in find(sub):
         mx = float(r.get("MaxNs", r["AverageNs"])) / 1e3
