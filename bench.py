@@ -727,12 +727,13 @@ def main():
                                                                  / 1e12 / peak, 4)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": {"conv_igemm_kernel": "conv_igemm_kernel<%s,256,256,2,4,TAG=1> (frozen-stem implicit GEMM on "
-                                                         "v_mfma_f32_16x16x32: the composed 5x5 conv11.conv12 and any C_out=512 layer "
-                                                         "the patch-stationary kernel does not serve; FLOPs = those its launches execute)",
-                                    "conv_ps_kernel": "conv_ps_kernel<TC,1,TAG=1> (patch-stationary 3x3 conv, 4 waves x 512 registers: "
-                                                      "conv21, conv22, conv31, conv32; FLOPs = those its launches execute)"}[dom]
-                                   % ((("f16" if args.precision == "fp16" else "bf16"),) if dom == "conv_igemm_kernel" else ()),
+                         "kernel": {"conv_igemm_kernel": "conv_igemm_kernel<%s,256,256,2,4,TAG=1> (frozen-stem implicit GEMM on v_mfma_f32_16x16x32: "
+                                                         "the composed 5x5 conv11.conv12 and any C_out=512 layer the patch-stationary "
+                                                         "kernel does not serve; FLOPs = those its launches execute)"
+                                                         % ("f16" if args.precision == "fp16" else "bf16"),
+                                    "conv_ps_kernel<28>": "conv_ps_kernel<28,1,TAG=1> (patch-stationary 3x3 conv, 4 waves x 512 registers: conv21, "
+                                                          "conv22 on 28x28 maps; FLOPs = those its launches execute)",
+                                    "conv_ps_kernel<14>": "conv_ps_kernel<14,1,TAG=1> (patch-stationary 3x3 conv: conv31, conv32 on 14x14 maps)"}.get(dom, dom),
                          "measured": "HIP events around every launch of this kernel in the timed region, while the trunk stream "
                                      "co-runs on the same chip (see stem_alone_* for the kernel with the chip to itself)",
                          # the same kernel's launches with no other stream on the chip (stem-alone pass after the timed region):

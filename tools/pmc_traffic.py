@@ -13,12 +13,13 @@ import sys
 
 KERNELS = {"conv_igemm_kernel": ("conv_igemm_kernel<unsigned short, 256, 256, 2, 4, 1, 2>",
                                  "frozen-stem igemm: the composed conv11.conv12 (5x5, 128 -> 512 on 56x56 maps, pool)"),
-           "conv_ps_kernel": ("conv_ps_kernel<", "patch-stationary 3x3 conv: conv21, conv22 (28x28 maps), conv31, conv32 (14x14)")}
-# unique bytes one 280-frame launch must move (padded 16-bit inputs + weights + outputs), by grid size where a name serves several layers
+           "conv_ps_kernel<28>": ("conv_ps_kernel<28,", "patch-stationary 3x3 conv: conv21, conv22 (28x28 maps, conv22 pooled)"),
+           "conv_ps_kernel<14>": ("conv_ps_kernel<14,", "patch-stationary 3x3 conv: conv31, conv32 (14x14 maps)")}
+# unique bytes one 280-frame launch must move (padded 16-bit inputs + weights + outputs), averaged over the layers a symbol serves
 N = 280
 ALGO = {"conv_igemm_kernel": N * 60 * 60 * 128 * 2 + 512 * 25 * 128 * 2 + N * 30 * 30 * 512 * 2,
-        "conv_ps_kernel": (2 * (N * 30 * 30 * 512 * 2 + 512 * 9 * 512 * 2) + N * 30 * 30 * 512 * 2 + N * 16 * 16 * 512 * 2      # conv21, conv22 (pooled)
-                           + 2 * (N * 16 * 16 * 512 * 2 + 512 * 9 * 512 * 2) + 2 * N * 16 * 16 * 512 * 2) / 4.0}
+        "conv_ps_kernel<28>": (2 * (N * 30 * 30 * 512 * 2 + 512 * 9 * 512 * 2) + N * 30 * 30 * 512 * 2 + N * 16 * 16 * 512 * 2) / 2.0,
+        "conv_ps_kernel<14>": (2 * (N * 16 * 16 * 512 * 2 + 512 * 9 * 512 * 2) + 2 * N * 16 * 16 * 512 * 2) / 2.0}
 
 
 def per_dispatch(d, counter, pat):

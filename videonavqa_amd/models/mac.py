@@ -184,7 +184,7 @@ class MACNetwork(nn.Module):
         pb = torch.stack([l.bias for l in m.control.position_aware])              # [steps,dim]
         pa_all = torch.matmul(hq, pw.transpose(1, 2)) + pb.unsqueeze(1)           # [steps,B,dim]
         wcq = m.control.control_question.weight
-        pq_all = (torch.matmul(pa_all, wcq[:, dim:].t()) + m.control.control_question.bias)[:, so]   # [steps,N,dim]
+        pq_all = (torch.matmul(pa_all, wcq[:, dim:].t()) + m.control.control_question.bias)[:, so].contiguous()   # [steps,N,dim]
         # step-invariant half of ReadUnit.concat on the MFMA GEMM: know W2^T + b (kept in the compute dtype)
         w2 = F.pad(m.read.concat.weight[:, dim:], (0, c_pad - dim, 0, c_pad - dim))
         pre = ops.linear_nt(kd, w2, F.pad(m.read.concat.bias, (0, c_pad - dim)))
@@ -200,7 +200,7 @@ class MACNetwork(nn.Module):
         for i in range(self.max_step):
             # ControlUnit + ReadUnit + WriteUnit.concat as ONE autograd node (ops.MacCoreFn)
             prev = memories[-1]
-            control, concat = ops.mac_core(control.contiguous(), prev.contiguous(), pq_all[i], ctx, kd, pre,
+            control, concat = ops.mac_core(control.contiguous(), prev.contiguous(), pq_all, i, ctx, kd, pre,
                                            None if masks is None else masks[0], wc, m.control.attn.weight,
                                            m.control.attn.bias, m.read.mem.weight, m.read.mem.bias, w1,
                                            m.read.attn.weight, m.read.attn.bias, wr, wmm, m.write.concat.bias,

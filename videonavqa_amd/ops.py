@@ -810,10 +810,18 @@ class MacCoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx_, control, memory, pq, ctxw, know, pre, mask_c, wc, w_ca, b_ca, wm, bm, w1, w_ra, b_ra, wr, wmm, bw,
-                state, Lq, S):
+                state, Lq, S, step=None):
         N, d = control.shape
         dev = control.device
         assert state.n_steps is not None and state.n_calls < state.n_steps, "MacCoreState(n_steps) too small for this forward"
+        # `pq` may be the [steps, N, d] tensor of ALL steps' position-aware terms with `step` selecting this node's slice: its
+        # gradient is then the backward slab's d_cq field, handed to autograd ONCE by the node that runs last, instead of twelve
+        # slice-backward zero-fills + adds of the whole [steps, N, d] tensor
+        ctx_.pq_all_shape = None
+        if step is not None:
+            assert pq.dim() == 3 and pq.is_contiguous()
+            ctx_.pq_all_shape = tuple(pq.shape)
+            pq = pq[step]
         if state.fwd is None:
             state.fwd = MacCoreFn._slab(MacCoreFn.FWD + ("p_c", "p_r"), [d] * 9 + [Lq, S], state.n_steps, N, dev)
             nb = L.lib().vnqa_mac_core_workspace(N, d)
@@ -855,10 +863,11 @@ class MacCoreFn(torch.autograd.Function):
         args.update(g)
         K.mac_core_call("bwd", (N, d, Lq, S, ld, did), args, defer_wgrad=True)
         st.outer[i] = (control, memory, d_concat)
-        d_ctxw = d_know = d_pre = None
+        d_ctxw = d_know = d_pre = d_cq_all = None
         gp = [None] * 11
         if i == 0:               # runs last: every later step depends on this one's outputs
             F_, B_ = st.fwd, st.bwd
+            d_cq_all = B_["d_cq"][:n_used]
             used = lambda t: t[:n_used]
             d_know, d_pre = K.mac_read_accum(used(B_["ds_r"]), used(F_["p_r"]), used(F_["u"]), used(F_["v"]), used(B_["d_read"]),
                                              N, S, d, ld, know.dtype)
@@ -881,8 +890,14 @@ class MacCoreFn(torch.autograd.Function):
             gp = [G["g_wc"], G["g_wca"].view(1, d), used(B_["ds_c"]).sum().view(1), G["g_wm"], G["g_bm"],
                   G["g_w1"], G["g_wra"].view(1, d), used(B_["ds_r"]).sum().view(1), G["g_wr"], G["g_wmm"], G["g_bw"]]
             st.outer, st.fwd, st.bwd = {}, None, None
-        return (g["d_control"], g["d_memory"], g["d_cq"], d_ctxw, d_know, d_pre, None, gp[0], gp[1], gp[2], gp[3], gp[4],
-                gp[5], gp[6], gp[7], gp[8], gp[9], gp[10], None, None, None)
+        d_pq = g["d_cq"]
+        if ctx_.pq_all_shape is not None:        # whole-tensor form: only the last node to run returns it (None = zero elsewhere)
+            d_pq = None
+            if i == 0:
+                assert ctx_.pq_all_shape[0] == n_used, "pq_all must hold exactly the steps that were run"
+                d_pq = d_cq_all
+        return (g["d_control"], g["d_memory"], d_pq, d_ctxw, d_know, d_pre, None, gp[0], gp[1], gp[2], gp[3], gp[4],
+                gp[5], gp[6], gp[7], gp[8], gp[9], gp[10], None, None, None, None)
 
 
 class MacCoreTorchFn(torch.autograd.Function):
@@ -980,14 +995,16 @@ class MacCoreTorchFn(torch.autograd.Function):
                 g[8], g[9], g[10], None, None, None)
 
 
-def mac_core(*args):
-    """Default: the C-ABI node (MacCoreFn: one call per direction, exact-f32 MFMA products, parameter gradients deferred to
-    one vnqa_mac_core_wgrad call).  VNQA_MAC_CORE_TORCH=1 selects the op-by-op node on torch / rocBLAS GEMMs (MacCoreTorchFn) for
-    the A/B (`tools/ab_mac.sh`); tests/test_gpu_mac.py runs both against the reference goldens."""
+def mac_core(control, memory, pq_all, step, *rest):
+    """One reasoning step; `pq_all` [steps, N, d] holds every step's position-aware term and `step` selects this one.
+    Default: the C-ABI node (MacCoreFn: one call per direction, exact-f32 MFMA products with the elementwise products in their
+    epilogues, parameter gradients deferred to one vnqa_mac_core_wgrad call).  VNQA_MAC_CORE_TORCH=1 selects the op-by-op node on
+    torch / rocBLAS GEMMs (MacCoreTorchFn) for the A/B (`tools/ab_mac.sh`); tests/test_gpu_mac.py runs both against the
+    reference goldens."""
     import os
     if os.environ.get("VNQA_MAC_CORE_TORCH", "0") == "1" or os.environ.get("VNQA_MAC_CORE_CABI", "1") == "0":
-        return MacCoreTorchFn.apply(*args)
-    return MacCoreFn.apply(*args)
+        return MacCoreTorchFn.apply(control, memory, pq_all[step], *rest)
+    return MacCoreFn.apply(control, memory, pq_all, *rest, step)
 
 
 # ---- question path / classifier / loss on csrc/glue.hip (no ATen / rocBLAS kernels in the step) --------------------------

@@ -287,7 +287,7 @@ class FrozenStem(object):
                                   post_scale=post[0] if post else None, post_shift=post[1] if post else None,
                                   out=out, y_halo=yh)
             elif "wt_ps" in ly and yh == 1 and self._ps_ok(h, w, ly["pool"]):
-                kname = "conv_ps_kernel"
+                kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)      # (one entry per kernel SYMBOL, as rocprofv3 lists them)
                 x = K.conv2d_igemm(x, ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                    post_scale=post[0] if post else None, post_shift=post[1] if post else None,
                                    out=out, tile=L.TILE_STEM_PS_224x256, y_halo=yh)
