@@ -251,6 +251,65 @@ def fp16_leg(args):
         return {"error": "fp16 leg exceeded 300 s"}
 
 
+def bench_cnn3d(args):
+    """BASELINE config 2 (`--model v_only_cnn3d`): VideoOnlyCNN3D on 1 MI355X, synthetic 16x3x112x112 clips, bs = 32 unless --batch is
+    given explicitly, forward + backward + fused clip+Adam over the flat parameter buffer; one JSON line in the same schema.
+    Single GPU only; `roofline` prices the whole step's algorithmic conv FLOPs (per-kernel figures: profiles/r03_cnn3d.md)."""
+    from videonavqa_amd import kernels as K, ops
+    from videonavqa_amd.models import VideoOnlyCNN3D
+    from videonavqa_amd.train import FlatParams
+    assert args.gpus == 1, "config 2 is a single-GPU ladder rung"
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    B = 32 if args.batch == 8 else args.batch
+    D, H, W = 16, 112, 112
+    torch.manual_seed(0)
+    model = VideoOnlyCNN3D(70, fc6_in_features=128 * (D // 16) * (H // 32) * (W // 32), precision=args.precision).to(dev).train()
+    fp = FlatParams(model.parameters())
+    g = torch.Generator().manual_seed(7)
+    batches = [(torch.rand(B, 3, D, H, W, generator=g).to(dev), torch.randint(0, 70, (B,), generator=g).to(dev))
+               for _ in range(max(args.minibatches, 1))]
+
+    def step(i):
+        x, y = batches[i % len(batches)]
+        loss = ops.cross_entropy(model(x), y, reduction="sum")
+        loss.backward()
+        fp.step_count += 1
+        K.clip_adam_step(fp.flat, fp.grad, fp.m, fp.v, fp.partial, fp.step_count, 1e-4, 1e30)
+        fp.mark_zeroed()
+        return loss
+    for i in range(args.warmup):
+        step(i)
+    regions = []
+    for _ in range(args.repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = step(i)
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+    dt = sorted(regions)[len(regions) // 2]
+    conv = 3 * B * (2.0 * D * H * W * 3 * 64 * 27 + 2.0 * D * (H // 2) * (W // 2) * 64 * 128 * 27
+                    + 2.0 * (D // 4) * (H // 8) * (W // 8) * 128 * 128 * 27)
+    peak = PEAK_BF16_TFLOPS if args.precision in ("bf16", "fp16") else PEAK_F32_TFLOPS
+    tf = conv * args.steps / dt / 1e12
+    print(json.dumps({
+        "metric": "v_only_cnn3d clips/sec (16x3x112x112 clips) fwd+bwd+Adam, 1 MI355X (BASELINE config 2)", "value": round(B * args.steps / dt, 1),
+        "unit": "clips/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision], "data": "synthetic",
+        "repeats": {"n": len(regions), "value_is": "median region", "clips_per_s": [round(B * args.steps / r, 1) for r in regions]},
+        "config": {"workload": "VideoOnlyCNN3D training step (bn_input, 3 x [Conv3d, ReLU, MaxPool3d, BatchNorm3d], 3 FC + 2 BatchNorm1d), "
+                               "bs=%d, %dx3x%dx%d clips; %s" % (B, D, H, W, "fused 16-bit path (csrc/cnn3d.hip)" if model._fast_ok(batches[0][0])
+                                                                 else "generic path"),
+                   "global_batch": B, "minibatches_rotated": len(batches), "final_loss": round(float(loss), 4),
+                   "gflop_per_clip": round(conv / B / 1e9, 1)},
+        "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+                     "kernel": "whole step: algorithmic FLOPs of the three Conv3d layers (forward + dgrad + wgrad) / step time; the three "
+                               "conv2 GEMMs are the MFMA-bound part, the rest is HBM-bound passes (per-kernel split: profiles/r03_cnn3d.md)"},
+        "cpu_baseline": None}), flush=True)
+
+
 def spawn_ranks(n, argv):
     """`bench.py --gpus N` without a launcher: start N rank processes (one per GPU) from THIS process, which has not
     touched the GPU, with the torchrun environment contract; rank 0's stdout (the one JSON line) is relayed.
@@ -455,7 +514,7 @@ def main():
     ap.add_argument("--channels", type=int, default=512)
     ap.add_argument("--tail-channels", type=int, default=0, help="num_tail_channels of the pooling models (0 = the "
                     "constructor default: 16 / 32; eval.sh passes 32 for film_gp_pt and 64 for time_multi_hop)")
-    ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop", "mac"],
+    ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop", "mac", "v_only_cnn3d"],
                     help="film_attn_pt is the metric's model; film_gp_pt / time_multi_hop are BASELINE.json's ladder "
                          "configs 3 and 5, mac is the remaining stem-consuming model of the same CLI")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: clips start in pinned host memory "
@@ -479,6 +538,9 @@ def main():
     if args.precision == "fp16":      # the fp16-storage build of the library (one 16-bit format per process)
         from videonavqa_amd import _lib as L
         L.set_half("f16")
+    if args.model == "v_only_cnn3d":
+        bench_cnn3d(args)
+        return
     if args.parity_only:
         torch.cuda.set_device(0)
         print(json.dumps(precision_parity(args, torch.device("cuda", 0))), flush=True)
