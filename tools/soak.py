@@ -19,9 +19,10 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-prefetch", action="store_true", help="run each step's stem inline instead of under the previous trunk")
     ap.add_argument("--every", type=int, default=25, help="print every N steps")
+    ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop", "mac"])
     a = ap.parse_args()
     args = argparse.Namespace(precision=a.precision, batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
-                              model="film_attn_pt")
+                              model=a.model, tail_channels=0)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     from videonavqa_amd.train import Trainer
