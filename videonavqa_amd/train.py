@@ -167,8 +167,13 @@ class Trainer(object):
         reserve = int(reserve) if reserve is not None else int(getattr(model, "stem_reserve_cus", 0))
         self.stem_reserve_cus = reserve if (stem is not None and self.fp.flat.is_cuda) else 0
         if self.stem_reserve_cus > 0:
-            self.stem_stream = L.reserved_stream(self.stem_reserve_cus, self.stem_device)
-        else:
+            try:
+                self.stem_stream = L.reserved_stream(self.stem_reserve_cus, self.stem_device)
+            except L.VnqaError as e:          # (a device whose CU count the mask layout was not measured on: run un-partitioned)
+                import warnings
+                warnings.warn("stem CU reservation unavailable (%s): the stem runs on an ordinary stream" % e)
+                self.stem_reserve_cus = 0
+        if self.stem_reserve_cus == 0:
             self.stem_stream = torch.cuda.Stream(priority=prio)
             if stem is not None and self.fp.flat.is_cuda:
                 L.lib().vnqa_set_persistent_reserve(0)       # (process-wide: the most recently built Trainer's setting holds)
