@@ -241,7 +241,12 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VNQA_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            # RCCL's kernels on a high-priority stream: they are dispatched ahead of the co-running stem's workgroups, like the trunk's
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, pg_options=opts)
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
