@@ -409,10 +409,19 @@ class FiLMTrunkBase(nn.Module):
         return film.index_select(0, lay.sample_of)
 
     # ---- conv trunk on the packed image list -------------------------------------------------
-    def _trunk_fused(self, x, lay, film_specs):
-        """TRAIN-mode trunk as one autograd node with the fused conv epilogues (ops.FilmTrunkFn).
-        film_specs[k] = (FiLM matrix [n_img, ld] fp32, column of block k's gamma) — beta follows at + C."""
+    def _trunk_fused(self, x, lay, film_specs, join=None):
+        """TRAIN-mode trunk on the fused conv epilogues as two autograd nodes (ops.FilmTrunkHeadFn: conv_init + BatchNorm, which
+        needs nothing from the question; ops.FilmTrunkBlocksFn: the FiLM residual blocks).  film_specs[k] = (FiLM matrix
+        [n_img, ld] fp32, column of block k's gamma) — beta follows at + C.  `join` (from _fork_generator) is called between the
+        two nodes: the FiLM matrices may still be in flight on the generator's side stream until then."""
         C = self.num_res_block_channels
+        meta = ops.TrunkMeta(lay, C, self.num_res_blocks, 0, [], BN_EPS, grad_scale=getattr(self, "_trunk_grad_scale", 1.0))
+        bn = self.bn_init
+        S = (x.shape[1] - 2) * (x.shape[2] - 2)
+        h, mean, var = ops.FilmTrunkHeadFn.apply(x, self.conv_init.weight, self.conv_init.bias, bn.weight, bn.bias, meta)
+        self._advance_running_stats(bn, lay, mean, var, S)
+        if join is not None:
+            join()
         uniq, film_map = [], []
         for t, col in film_specs:
             for i, u in enumerate(uniq):
@@ -423,17 +432,13 @@ class FiLMTrunkBase(nn.Module):
                 uniq.append(t)
             film_map.append((i, int(col)))
         uniq = [u if (u.dtype == torch.float32 and u.stride(1) == 1) else u.float().contiguous() for u in uniq]
-        meta = ops.TrunkMeta(lay, C, self.num_res_blocks, len(uniq), film_map, BN_EPS,
-                             grad_scale=getattr(self, "_trunk_grad_scale", 1.0))
+        meta.n_film, meta.film_map = len(uniq), film_map
         blocks = []
         for k in range(self.num_res_blocks):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
             blocks += [c1.weight, c1.bias, c3.weight, c3.bias]
         meta.c1_packs = self._frozen_c1_packs(x.dtype, L.round_up(C, 64))
-        bn = self.bn_init
-        x, mean, var = ops.film_trunk(x, self.conv_init.weight, self.conv_init.bias, bn.weight, bn.bias, meta, *uniq, *blocks)
-        self._advance_running_stats(bn, lay, mean, var, (x.shape[1] - 2) * (x.shape[2] - 2))
-        return x
+        return ops.FilmTrunkBlocksFn.apply(h, meta, *uniq, *blocks)
 
     def _frozen_c1_packs(self, cdt, c_pad):
         """K-major packs (forward, flipped for dgrad) of the frozen 1x1 conv weights, re-made only when a weight was modified
@@ -464,7 +469,7 @@ class FiLMTrunkBase(nn.Module):
 
     def _use_fused_trunk(self):
         import os
-        return self.training and os.environ.get("VNQA_FUSED_TRUNK", "1") != "0" and os.environ.get("VNQA_SIDE_LSTM", "0") != "1"
+        return self.training and os.environ.get("VNQA_FUSED_TRUNK", "1") != "0"
 
     def _trunk(self, x, lay, film_fn):
         """conv_init -> ReLU -> per-frame BN -> FiLM residual blocks.
@@ -488,21 +493,22 @@ class FiLMTrunkBase(nn.Module):
         return x
 
     # ---- FiLM generator on a side stream ---------------------------------------------------------
-    # The question LSTM chain (~800 dependent cells) needs nothing from the video: forked onto its own stream it
-    # runs beside conv_init / BN in forward, and — autograd replays every backward op on its forward's stream —
-    # its BPTT runs beside BN-backward / conv_init's wgrad in backward.  Opt-in (VNQA_SIDE_LSTM=1): measured +-0 at both
-    # 224x224 and 160x208 once the LSTM chain was shortened — the step is bound by the SUM of stem and trunk kernel work,
-    # not by the trunk's dependent chain, so taking the chain off the critical path buys nothing.
+    # The question LSTM chain (~800 dependent cells, 0.8 ms forward / 0.95 ms BPTT on 8 CUs) needs nothing from the video: forked
+    # onto its own high-priority stream it runs beside conv_init / BN in forward, and — autograd replays every backward op on
+    # its forward's stream — its BPTT runs beside BN-backward / conv_init's wgrad in backward.  Default ON since round 3
+    # (VNQA_SIDE_LSTM=0: same stream): in the pipelined step the stem of minibatch i+2 may not start before the trunk of
+    # minibatch i has released its feature slot, so the trunk's dependent-chain LATENCY under contention — not only the summed
+    # kernel work — sets the step; same-box A/B +6.5 % (877-897 -> 940-956 clips/s) even on the un-fused graph.
     def _fork_generator(self, fn):
         """Run fn() (returns a tensor or tuple of tensors) on the side stream; returns (result, join) where join()
         makes the current stream wait for it and registers the cross-stream use with the caching allocator."""
         import os
-        if not torch.cuda.is_available() or os.environ.get("VNQA_SIDE_LSTM", "0") != "1":
+        if not torch.cuda.is_available() or os.environ.get("VNQA_SIDE_LSTM", "1") == "0" or not torch.is_grad_enabled():
             return fn(), (lambda: None)
         main = torch.cuda.current_stream()
         side = getattr(self, "_gen_stream", None)
         if side is None:
-            side = self._gen_stream = torch.cuda.Stream()
+            side = self._gen_stream = torch.cuda.Stream(priority=-1)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             out = fn()

@@ -70,9 +70,11 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         self._trunk_grad_scale = gscale
         bow = not isinstance(self.film_layer[0], nn.LSTM)                    # :158
         if fused:       # train mode: generator and conv trunk on fused HIP ops (one autograd node for the trunk)
-            film_img = self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay) if bow else \
-                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay)
-            x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])   # :229-233
+            # the FiLM generator (question LSTM re-run per frame, :213) on the side stream, joined after conv_init + BatchNorm
+            film_img, join = self._fork_generator(
+                lambda: self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay) if bow else
+                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay))
+            x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)], join)   # :229-233
         else:
             # FiLM generator: question LSTM re-run per processed frame with carried state (:213) — on the side stream
             def generator():

@@ -67,9 +67,10 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
 
         self._trunk_grad_scale = grad_scale_of(self.compute_dtype) if self._use_fused_trunk() else 1.0
         if self._use_fused_trunk():       # train mode: generator and conv trunk on fused HIP ops
-            film_img = self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay) if bow else \
-                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay, padding_idx=0)
-            x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)])
+            film_img, join = self._fork_generator(
+                lambda: self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay) if bow else
+                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay, padding_idx=0))
+            x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)], join)
         else:
             film_img, join = self._fork_generator(generator)
             x = self._trunk_head(x, lay)

@@ -101,19 +101,22 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
         assert h * w == self.spatial_size
         B, Fn, Hq = lay.B, lay.n_frames, self.hidden_size
         C = self.num_res_block_channels
-        if x.is_cuda and os.environ.get("VNQA_HOP_TORCH", "0") != "1":
-            film_per_block = self._generator_hip(q_input, q_lens, lay)
+        fused = self._use_fused_trunk()
+        gen = self._generator_hip if (x.is_cuda and os.environ.get("VNQA_HOP_TORCH", "0") != "1") else self._generator_torch
+        join = None
+        if fused:       # the generator (question LSTM chain + hop attention) on the side stream, joined after conv_init + BatchNorm
+            film_per_block, join = self._fork_generator(lambda: tuple(gen(q_input, q_lens, lay)))
         else:
-            film_per_block = self._generator_torch(q_input, q_lens, lay)
+            film_per_block = gen(q_input, q_lens, lay)
 
         def film_fn(k):
             s = 2 * C * k
             fv = film_per_block[k]
             return fv[:, s:s + C], fv[:, s + C:s + 2 * C]                 # :228-230
 
-        self._trunk_grad_scale = grad_scale_of(self.compute_dtype) if self._use_fused_trunk() else 1.0
-        if self._use_fused_trunk():       # train mode: the conv trunk as ONE autograd node with fused conv epilogues
-            x = self._trunk_fused(x, lay, [(film_per_block[k], 2 * C * k) for k in range(self.num_res_blocks)])
+        self._trunk_grad_scale = grad_scale_of(self.compute_dtype) if fused else 1.0
+        if fused:       # train mode: the conv trunk on fused conv epilogues (two autograd nodes around the generator's join)
+            x = self._trunk_fused(x, lay, [(film_per_block[k], 2 * C * k) for k in range(self.num_res_blocks)], join)
         else:
             x = self._trunk(x, lay, film_fn)
         return self._gp_tail(x, lay, h, w)                                # :240-250

@@ -193,33 +193,24 @@ class FilmReluResFn(torch.autograd.Function):
         return dz, dout, dgamma, dbeta
 
 
-class FilmTrunkFn(torch.autograd.Function):
-    """The whole conv trunk of the FiLM models in TRAIN mode as ONE autograd node (film_attn_pt_stem.py:211-241):
+class FilmTrunkHeadFn(torch.autograd.Function):
+    """First half of the TRAIN-mode conv trunk (film_attn_pt_stem.py:211) — the part that needs nothing from the question:
 
-        r   = relu(conv_init(x))          + per-frame BatchNorm statistics in the conv's epilogue  (VNQA_EPI_BNSTATS)
-        h   = bn_init(r)                  (batch statistics per frame)
-        per block k:  res = relu(conv1x1_k(h))                                         (frozen weights)
-                      z, h = conv3x3_k(res), relu(gamma_k * z + beta_k) + res          (ONE launch, VNQA_EPI_FILM_RES)
+        r = relu(conv_init(x))      + per-frame BatchNorm statistics in the conv's epilogue  (VNQA_EPI_BNSTATS)
+        h = bn_init(r)              (batch statistics per frame)
 
-    and a hand-written backward: FiLM backward (writes d gamma / d beta straight into their column range of the FiLM
-    matrix gradient), wgrad + dgrad of the 3x3 conv, the residual join and the 1x1 conv's ReLU mask in one elementwise
-    kernel, the 1x1 dgrad, BN backward with conv_init's ReLU mask, conv_init's wgrad.  Compared with one autograd node per
-    op this removes the AccumulateGrad / add kernels of the residual joins and ~30 graph nodes of host bookkeeping.
-
-    forward(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors):
-      tensors = the distinct FiLM matrices [n_img, ld] fp32 (meta.n_film of them), then (w1, b1, w3, b3) per block;
-      meta.film_map[k] = (index of block k's matrix, column of its gamma; beta follows at + C).
+    Its own autograd node so that the question side (the FiLM generator's LSTM chain, forked onto a side stream by the models)
+    overlaps it in BOTH directions: forward, the chain runs beside conv_init / BN; backward, FilmTrunkBlocksFn hands d gamma /
+    d beta to the generator's BPTT first and this node's BN backward + conv_init wgrad run beside it.
     Returns (h, mean [F, Cpad], var [F, Cpad]) — the statistics for the caller's running-stat update."""
 
     @staticmethod
-    def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, meta, *tensors):
-        lay, C, blocks = meta.layout, meta.channels, meta.blocks
-        films = tensors[:meta.n_film]
+    def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, meta):
+        lay, C = meta.layout, meta.channels
         cdt = x.dtype
         c_pad = L.round_up(C, 64)
         wt0 = K.pack_conv_weight(conv_w, cdt, c_out_pad=c_pad, c_in_pad=x.shape[-1])
         b0 = K.pad_vec(conv_b, c_pad)
-        S = (x.shape[1] - 2) * (x.shape[2] - 2)
         fused = None
         if L.is_half(cdt):              # fp32 (parity) precision keeps the exact two-pass statistics kernel
             fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts))
@@ -231,7 +222,62 @@ class FilmTrunkFn(torch.autograd.Function):
         rstd = torch.rsqrt(var + meta.eps)
         g = K.pad_vec(bn_w, c_pad)
         h = K.frame_bn_apply(r, lay.frame_of_i32, mean, rstd, g, K.pad_vec(bn_b, c_pad))
-        saved = [x, r, mean, rstd, g]
+        ctx.meta = meta
+        with torch.enable_grad():       # gradient sinks (FlatParams): conv_init w/b, bn w/b
+            ctx.sinks = [sink_of(t) for t in (conv_w, conv_b, bn_w, bn_b)]
+        ctx.save_for_backward(x, r, mean, rstd, g, conv_w)
+        ctx.mark_non_differentiable(mean, var)
+        return h, mean, var
+
+    @staticmethod
+    def backward(ctx, dout, _dm, _dv):
+        meta = ctx.meta
+        lay, C = meta.layout, meta.channels
+        x, r, mean, rstd, g, conv_w = ctx.saved_tensors
+        cdt = x.dtype
+        c_pad = L.round_up(C, 64)
+        dout = dout.contiguous()
+        inv = 1.0 / meta.grad_scale
+        scaled = meta.grad_scale != 1.0
+        sinks = [None] * 4 if scaled else ctx.sinks      # (scaled small vectors go through a temporary)
+        dr, s1, s2 = K.frame_bn_bwd(dout, r, lay.frame_of_i32, lay.frame_off_i32, mean, rstd, g, lay.n_frames, True)
+        s_cw = ctx.sinks[0]
+        s_cb, s_bw, s_bb = sinks[1:4]
+        exact = c_pad == C
+        dbn_w = _ret(s_bw if exact else None, K.colsum(s2, out=_into(s_bw) if exact else None)[:C])
+        dbn_b = _ret(s_bb if exact else None, K.colsum(s1, out=_into(s_bb) if exact else None)[:C])
+        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None)
+        dconv_w = _ret(s_cw, K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw), alpha=inv))
+        dconv_b = _ret(s_cb if exact else None, dbias0[:C])
+        if scaled:
+            dbn_w, dbn_b, dconv_b = dbn_w * inv, dbn_b * inv, dconv_b * inv
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv2d_igemm(dr, K.pack_conv_weight(conv_w, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=x.shape[-1]))
+        return dx, dconv_w, dconv_b, dbn_w, dbn_b, None
+
+
+class FilmTrunkBlocksFn(torch.autograd.Function):
+    """Second half of the TRAIN-mode conv trunk (film_attn_pt_stem.py:224-241), one autograd node for all FiLM residual blocks:
+
+        per block k:  res = relu(conv1x1_k(h))                                         (frozen weights)
+                      z, h = conv3x3_k(res), relu(gamma_k * z + beta_k) + res          (ONE launch, VNQA_EPI_FILM_RES)
+
+    and a hand-written backward: FiLM backward (writes d gamma / d beta straight into their column range of the FiLM matrix
+    gradient), wgrad + dgrad of the 3x3 conv with the residual join and the 1x1 conv's ReLU mask in the dgrad's epilogue
+    (VNQA_EPI_ADD_MASK), the 1x1 dgrad.  Compared with one autograd node per op this removes the AccumulateGrad / add kernels
+    of the residual joins and ~30 graph nodes of host bookkeeping.
+
+    forward(h, meta, *tensors): tensors = the distinct FiLM matrices [n_img, ld] fp32 (meta.n_film of them), then
+    (w1, b1, w3, b3) per block; meta.film_map[k] = (index of block k's matrix, column of its gamma; beta follows at + C)."""
+
+    @staticmethod
+    def forward(ctx, h, meta, *tensors):
+        C, blocks = meta.channels, meta.blocks
+        films = tensors[:meta.n_film]
+        cdt = h.dtype
+        c_pad = L.round_up(C, 64)
+        saved = []
         for k in range(blocks):
             w1, b1, w3, b3 = tensors[meta.n_film + 4 * k: meta.n_film + 4 * k + 4]
             wt1 = meta.c1_packs[k][0] if meta.c1_packs else K.pack_conv_weight(w1, cdt, c_out_pad=c_pad, c_in_pad=c_pad)
@@ -242,25 +288,20 @@ class FilmTrunkFn(torch.autograd.Function):
                                            K.pad_vec(b3, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res)
             saved += [res, z]
         ctx.meta = meta
-        # gradient sinks (FlatParams): conv_init w/b, bn w/b, then (w3, b3) per block
-        with torch.enable_grad():
-            ctx.sinks = [sink_of(t) for t in (conv_w, conv_b, bn_w, bn_b)] + \
-                        [sink_of(tensors[meta.n_film + 4 * k + i]) for k in range(blocks) for i in (2, 3)]
-        ctx.save_for_backward(*saved, conv_w, *tensors)
-        ctx.mark_non_differentiable(mean, var)
-        return h, mean, var
+        with torch.enable_grad():       # gradient sinks (FlatParams): (w3, b3) per block
+            ctx.sinks = [sink_of(tensors[meta.n_film + 4 * k + i]) for k in range(blocks) for i in (2, 3)]
+        ctx.save_for_backward(*saved, *tensors)
+        return h
 
     @staticmethod
-    def backward(ctx, dout, _dm, _dv):
+    def backward(ctx, dout):
         meta = ctx.meta
-        lay, C, blocks, nf = meta.layout, meta.channels, meta.blocks, meta.n_film
+        C, blocks, nf = meta.channels, meta.blocks, meta.n_film
         sv = ctx.saved_tensors
-        x, r, mean, rstd, g = sv[:5]
-        acts = sv[5:5 + 2 * blocks]
-        conv_w = sv[5 + 2 * blocks]
-        tensors = sv[6 + 2 * blocks:]
+        acts = sv[:2 * blocks]
+        tensors = sv[2 * blocks:]
         films = tensors[:nf]
-        cdt = x.dtype
+        cdt = acts[0].dtype
         c_pad = L.round_up(C, 64)
         dout = dout.contiguous()
         inv = 1.0 / meta.grad_scale
@@ -270,7 +311,7 @@ class FilmTrunkFn(torch.autograd.Function):
         # ONE matrix [n_img, 2*C*blocks]); multi-hop's per-block matrices are only partly written
         covered = nf == 1 and films[0].shape[1] == 2 * C * blocks and \
             sorted(c for _, c in meta.film_map) == [2 * C * k for k in range(blocks)]
-        dfilms = [(torch.empty_like(f) if covered else torch.zeros_like(f)) if ctx.needs_input_grad[6 + i] else None
+        dfilms = [(torch.empty_like(f) if covered else torch.zeros_like(f)) if ctx.needs_input_grad[2 + i] else None
                   for i, f in enumerate(films)]
         grads_blocks = [None] * (4 * blocks)
         for k in reversed(range(blocks)):
@@ -281,7 +322,7 @@ class FilmTrunkFn(torch.autograd.Function):
             dfilm = dfilms[fi] if dfilms[fi] is not None else torch.empty_like(film)
             dz = K.film_relu_res_bwd_ld(dout, z, film[:, col:col + C], film[:, col + C:col + 2 * C], C,
                                         dfilm[:, col:col + C], dfilm[:, col + C:col + 2 * C])
-            sw, sb = ctx.sinks[4 + 2 * k], sinks[5 + 2 * k]
+            sw, sb = ctx.sinks[2 * k], sinks[2 * k + 1]
             dwt, dbias = K.conv2d_wgrad(res, dz, 9, dbias_out=_into(sb))
             grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw), alpha=inv))
             direct_b = sb is not None and dbias.data_ptr() == sb.view.data_ptr()      # (only without channel padding)
@@ -294,22 +335,9 @@ class FilmTrunkFn(torch.autograd.Function):
             wt1d = meta.c1_packs[k][1] if meta.c1_packs else \
                 K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad)
             dout = K.conv2d_igemm(gsum, wt1d)
-        dr, s1, s2 = K.frame_bn_bwd(dout, r, lay.frame_of_i32, lay.frame_off_i32, mean, rstd, g, lay.n_frames, True)
-        s_cw = ctx.sinks[0]
-        s_cb, s_bw, s_bb = sinks[1:4]
-        exact = c_pad == C
-        dbn_w = _ret(s_bw if exact else None, K.colsum(s2, out=_into(s_bw) if exact else None)[:C])
-        dbn_b = _ret(s_bb if exact else None, K.colsum(s1, out=_into(s_bb) if exact else None)[:C])
-        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None)
-        dconv_w = _ret(s_cw, K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw), alpha=inv))
-        dconv_b = _ret(s_cb if exact else None, dbias0[:C])
         if scaled:
-            dbn_w, dbn_b, dconv_b = dbn_w * inv, dbn_b * inv, dconv_b * inv
             dfilms = [None if t is None else t.mul_(inv) for t in dfilms]
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = K.conv2d_igemm(dr, K.pack_conv_weight(conv_w, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=x.shape[-1]))
-        return (dx, dconv_w, dconv_b, dbn_w, dbn_b, None) + tuple(dfilms) + tuple(grads_blocks)
+        return (dout, None) + tuple(dfilms) + tuple(grads_blocks)
 
 
 class TrunkMeta(object):
@@ -325,8 +353,14 @@ class TrunkMeta(object):
         self.c1_packs = None
 
 
-def film_trunk(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors):
-    return FilmTrunkFn.apply(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors)
+def film_trunk(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors, join=None):
+    """The TRAIN-mode conv trunk as two autograd nodes (FilmTrunkHeadFn, FilmTrunkBlocksFn).  `join` (optional callable) is
+    invoked between them: the point where a FiLM generator forked onto a side stream must have delivered `tensors[:n_film]`.
+    Returns (h, mean, var)."""
+    h, mean, var = FilmTrunkHeadFn.apply(x, conv_w, conv_b, bn_w, bn_b, meta)
+    if join is not None:
+        join()
+    return FilmTrunkBlocksFn.apply(h, meta, *tensors), mean, var
 
 
 def frame_bn_train(x, gamma, beta, frame_of_i32, frame_off_i32, n_frames, eps, relu_input=True):
