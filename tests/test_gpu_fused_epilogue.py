@@ -177,3 +177,34 @@ def test_conv_zeroes_the_halo_of_a_poisoned_output_buffer(dt, cfg):
         assert torch.equal(y, ref)
         assert float(y[:, 0].abs().max()) == 0 and float(y[:, -1].abs().max()) == 0
         assert float(y[:, :, 0].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [(9, 14, 14, 256), (5, 28, 28, 256), (35, 14, 14, 512)])
+def test_patch_stationary_tile_carries_film_res_and_add_mask(geom):
+    """The FiLM block's two fused 3x3 launches on the patch-stationary kernel (tile id 20, what the train-mode trunk uses at
+    14x14 / 28x28 maps): bit-identical to the igemm forms — z, the FiLM+ReLU+residual output, the masked dgrad sum — and the halo
+    ring of the torch.empty outputs is zeroed (allocator primed with NaN blocks of the same size)."""
+    from videonavqa_amd import _lib as L, kernels as K
+    if not L.is_half(LOW_DTYPE):
+        pytest.skip("16-bit storage only")
+    n_img, h, w, C = geom
+    res = _padded(n_img, h, w, C, LOW_DTYPE, 3).relu()
+    g = torch.Generator().manual_seed(4)
+    wt = K.pack_conv_weight(torch.randn(C, C, 3, 3, generator=g).cuda() * 0.03, LOW_DTYPE)
+    b = torch.randn(C, generator=g).cuda()
+    film = torch.randn(n_img, 4 * C, generator=g).cuda().relu()
+    gamma, beta = film[:, C:2 * C], film[:, 2 * C:3 * C]
+    assert K.ps_fused_tile(res) == L.TILE_PS_224x256
+    z_ref, out_ref = K.conv2d_igemm_film_res(res, wt, b, gamma, beta, C, res)
+    dz = _padded(n_img, h, w, C, LOW_DTYPE, 11)
+    dout = _padded(n_img, h, w, C, LOW_DTYPE, 12)
+    sum_ref = K.conv2d_igemm_add_mask(dz, wt, dout, res)
+    poison = [torch.full_like(res, float("nan")) for _ in range(4)]
+    del poison
+    z, out = K.conv2d_igemm_film_res(res, wt, b, gamma, beta, C, res, tile=L.TILE_PS_224x256)
+    got = K.conv2d_igemm_add_mask(dz, wt, dout, res, tile=L.TILE_PS_224x256)
+    assert torch.equal(z, z_ref) and torch.equal(out, out_ref) and torch.equal(got, sum_ref)
+    for t in (z, out, got):
+        assert float(t[:, 0].abs().max()) == 0 and float(t[:, -1].abs().max()) == 0
+        assert float(t[:, :, 0].abs().max()) == 0 and float(t[:, :, -1].abs().max()) == 0

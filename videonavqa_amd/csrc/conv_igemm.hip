@@ -1373,7 +1373,9 @@ extern "C" int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* 
   const int rc = fill_conv_args(d, x, wt, bias, nullptr, nullptr, nullptr, y, a);
   if (rc != VNQA_OK) return rc;
   VNQA_CHECK_ARG(!d->pool2 && d->depth == 0 && !d->wt_tiled, "conv2d_igemm_fused_fwd: 2-D, un-pooled, K-major weights only");
-  const int bm = fused_rows_for(d);
+  // (the patch-stationary kernel carries FILM_RES and ADD_MASK in its own store loop: conv_ps.hip)
+  const bool ps_tile = d->tile == VNQA_TILE_PS_224x256 && (e->kind == VNQA_EPI_FILM_RES || e->kind == VNQA_EPI_ADD_MASK);
+  const int bm = ps_tile ? 224 : fused_rows_for(d);
   if (bm == 0) {
     vnqa_set_error("conv2d_igemm_fused_fwd: tile id %d has no fused-epilogue instantiation", d->tile);
     return VNQA_ERR_UNSUPPORTED;

@@ -345,13 +345,73 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     const int y = g - n * p.H;
     const int yo = p.pool ? (y >> 1) : y;
     const int xo = (p.pool ? (cb * TC) >> 1 : cb * TC) + occ;
-    vnqa_bf16* dst = (vnqa_bf16*)(p.y) + (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+    const size_t ooff = (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+    vnqa_bf16* dst = (vnqa_bf16*)(p.y) + ooff;
     uint4 o;
-    o.x = pack2_h16(v[0], v[1]);
-    o.y = pack2_h16(v[2], v[3]);
-    o.z = pack2_h16(v[4], v[5]);
-    o.w = pack2_h16(v[6], v[7]);
+    if (TAG == 0 && p.epi == VNQA_EPI_ADD_MASK) {
+      // y = (conv + add) * [mask > 0] on the storage-rounded conv output (v holds exactly the 16-bit values staged in LDS):
+      // the FiLM block's dgrad joined with the residual branch's gradient and masked by the 1x1 conv's ReLU
+      const uint4 araw = *(const uint4*)((const vnqa_bf16*)p.res + ooff);
+      const uint4 mraw = *(const uint4*)((const vnqa_bf16*)p.y2 + ooff);
+      const unsigned aw[4] = {araw.x, araw.y, araw.z, araw.w}, mw[4] = {mraw.x, mraw.y, mraw.z, mraw.w};
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        w[2 * e] = h16_lo(mw[e]) > 0.f ? v[2 * e] + h16_lo(aw[e]) : 0.f;
+        w[2 * e + 1] = h16_hi(mw[e]) > 0.f ? v[2 * e + 1] + h16_hi(aw[e]) : 0.f;
+      }
+      o.x = pack2_h16(w[0], w[1]); o.y = pack2_h16(w[2], w[3]); o.z = pack2_h16(w[4], w[5]); o.w = pack2_h16(w[6], w[7]);
+    } else {
+      o.x = pack2_h16(v[0], v[1]); o.y = pack2_h16(v[2], v[3]); o.z = pack2_h16(v[4], v[5]); o.w = pack2_h16(v[6], v[7]);
+    }
     *(uint4*)dst = o;
+    vnqa_bf16* second = nullptr;
+    if (TAG == 0 && p.epi == VNQA_EPI_FILM_RES) {
+      // out2 = relu(gamma[n] * z + beta[n]) + res from the storage-rounded z just written (film_attn_pt_stem.py:229-241)
+      const float* gp = p.film_gamma + (size_t)n * p.film_ld + co0;
+      const float* bp = p.film_beta + (size_t)n * p.film_ld + co0;
+      const uint4 rraw = *(const uint4*)((const vnqa_bf16*)p.res + ooff);
+      const unsigned rw[4] = {rraw.x, rraw.y, rraw.z, rraw.w};
+      float w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool ok = co0 + e < p.film_c;
+        const float ga = ok ? gp[e] : 0.f, be = ok ? bp[e] : 0.f;
+        const float r = (e & 1) ? h16_hi(rw[e >> 1]) : h16_lo(rw[e >> 1]);
+        w[e] = fmaxf(ga * v[e] + be, 0.f) + r;
+      }
+      uint4 o2;
+      o2.x = pack2_h16(w[0], w[1]); o2.y = pack2_h16(w[2], w[3]); o2.z = pack2_h16(w[4], w[5]); o2.w = pack2_h16(w[6], w[7]);
+      second = (vnqa_bf16*)p.y2 + ooff;
+      *(uint4*)second = o2;
+    }
+    if (p.zero_halo) {
+      // the halo ring of a fresh output buffer: every border pixel's thread also zeroes the halo positions next to it (corners
+      // by the corner pixels) for its 16-byte channel chunk — for y and, with FILM_RES, for the second output
+      const int Ho = p.pool ? p.H >> 1 : p.H, Wo = p.pool ? p.W >> 1 : p.W;
+      const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
+      const long long rs = (long long)p.Wyp * p.Cy, cs = p.Cy;
+      const bool x0 = xo == 0, x1 = xo == Wo - 1, y0 = yo == 0, y1 = yo == Ho - 1;
+      if (x0 | x1 | y0 | y1) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+          vnqa_bf16* b = which == 0 ? dst : second;
+          if (b == nullptr) continue;
+          if (x0) *(uint4*)(b - cs) = zz;
+          if (x1) *(uint4*)(b + cs) = zz;
+          if (y0) {
+            *(uint4*)(b - rs) = zz;
+            if (x0) *(uint4*)(b - rs - cs) = zz;
+            if (x1) *(uint4*)(b - rs + cs) = zz;
+          }
+          if (y1) {
+            *(uint4*)(b + rs) = zz;
+            if (x0) *(uint4*)(b + rs - cs) = zz;
+            if (x1) *(uint4*)(b + rs + cs) = zz;
+          }
+        }
+      }
+    }
   }
 }
 
@@ -385,9 +445,11 @@ int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
   using namespace ps;
   const int halo = a.taps == 25 ? 2 : 1;
   if ((a.taps != 9 && a.taps != 25) || a.D != 0 || a.x_halo != halo || a.wt_tiled || a.partial != nullptr || a.Cin % 64 != 0 ||
-      a.Cin < 64 || a.group_tiles != 0 || a.ring_h != 0 || a.epi != VNQA_EPI_NONE || a.zero_halo ||
-      (a.border_sub != nullptr && a.Cout % 4 != 0)) {
-    vnqa_set_error("conv patch-stationary tile: needs a plain bf16 3x3 / 5x5 2-D conv, x_halo = 1 / 2, c_in %% 64 == 0, K-major weights");
+      a.Cin < 64 || a.group_tiles != 0 || a.ring_h != 0 || (a.border_sub != nullptr && a.Cout % 4 != 0) ||
+      !(a.epi == VNQA_EPI_NONE || ((a.epi == VNQA_EPI_FILM_RES || a.epi == VNQA_EPI_ADD_MASK) && tag == 0 && !a.pool && a.y_halo == 1)) ||
+      (a.zero_halo && a.y_halo != 1)) {
+    vnqa_set_error("conv patch-stationary tile: needs a bf16 3x3 / 5x5 2-D conv, x_halo = 1 / 2, c_in %% 64 == 0, K-major weights; of the "
+                   "fused epilogues FILM_RES and ADD_MASK (un-pooled, y_halo = 1, trunk tag)");
     return VNQA_ERR_UNSUPPORTED;
   }
   const int tc = a.W % 28 == 0 ? 28 : (a.W % 14 == 0 ? 14 : 0);

@@ -127,14 +127,29 @@ def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frame
     return y, mean, var
 
 
-def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res):
+def ps_fused_tile(x):
+    """TILE_PS_224x256 when the patch-stationary kernel can run a 3x3 conv with a fused FILM_RES / ADD_MASK epilogue on this
+    padded-NHWC input (16-bit storage, width a multiple of 14, its LDS patch fits), else TILE_AUTO.  VNQA_TRUNK_PS=0 disables."""
+    if os.environ.get("VNQA_TRUNK_PS", "1") == "0" or not L.is_half(x.dtype):
+        return L.TILE_AUTO
+    N, Hp, Wp, C = x.shape
+    h, w = Hp - 2, Wp - 2
+    tc = 28 if w % 28 == 0 else (14 if w % 14 == 0 else 0)
+    if tc == 0 or C % 64 != 0:
+        return L.TILE_AUTO
+    tr = 224 // tc
+    max_cross = (tr - 1 + h - 1) // h
+    return L.TILE_PS_224x256 if (tr + 2 + 2 * max_cross) * (tc + 2) <= 360 else L.TILE_AUTO
+
+
+def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res, tile=L.TILE_AUTO):
     """z = conv(x) + bias and out = relu(gamma[n] * z + beta[n]) + res in ONE launch (VNQA_EPI_FILM_RES).  gamma / beta:
     fp32 2-D views [n_img, >= film_c] with unit column stride (column slices of the FiLM generator's output)."""
     N, Hp, Wp, _ = x.shape
     c_out, taps, _ = wt.shape
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.stride(1) == 1 and beta.stride(1) == 1
     assert gamma.stride(0) == beta.stride(0) and res.shape == (N, Hp, Wp, c_out) and res.dtype == x.dtype
-    d = _conv_desc(x, c_out, c_out, taps, False)
+    d = _conv_desc(x, c_out, c_out, taps, False, tile if taps == 9 else L.TILE_AUTO)
     z = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
     out = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
     e = L.ConvEpilogue(kind=L.EPI_FILM_RES, film_ld=gamma.stride(0), film_c=int(film_c), gamma=gamma.data_ptr(),
@@ -144,13 +159,13 @@ def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res):
     return z, out
 
 
-def conv2d_igemm_add_mask(x, wt, add, mask_src):
+def conv2d_igemm_add_mask(x, wt, add, mask_src, tile=L.TILE_AUTO):
     """(conv(x) + add) * [mask_src > 0] in ONE launch (VNQA_EPI_ADD_MASK): the dgrad of the FiLM block's 3x3 conv joined with the
     residual branch's gradient and masked by the 1x1 conv's ReLU."""
     N, Hp, Wp, _ = x.shape
     c_out, taps, _ = wt.shape
     assert add.shape == (N, Hp, Wp, c_out) and mask_src.shape == add.shape and add.dtype == x.dtype == mask_src.dtype
-    d = _conv_desc(x, c_out, c_out, taps, False)
+    d = _conv_desc(x, c_out, c_out, taps, False, tile if taps == 9 else L.TILE_AUTO)
     y = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
     e = L.ConvEpilogue(kind=L.EPI_ADD_MASK, res=add.data_ptr(), y2=mask_src.data_ptr())
     L.check(L.lib().vnqa_conv2d_igemm_fused_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), None, ctypes.byref(e), L.ptr(y),

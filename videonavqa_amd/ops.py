@@ -285,7 +285,8 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
             fi, col = meta.film_map[k]
             film = films[fi]
             z, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(w3, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
-                                           K.pad_vec(b3, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res)
+                                           K.pad_vec(b3, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res,
+                                           tile=K.ps_fused_tile(res))
             saved += [res, z]
         ctx.meta = meta
         with torch.enable_grad():       # gradient sinks (FlatParams): (w3, b3) per block
@@ -330,7 +331,7 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
             # (dgrad(dz) + dout) * [res > 0]: the 3x3 conv's dgrad with the residual join and the 1x1 conv's ReLU mask in its
             # epilogue (VNQA_EPI_ADD_MASK; bit-identical to conv2d_igemm followed by relu_bwd(dres, res, dout))
             gsum = K.conv2d_igemm_add_mask(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad),
-                                           dout, res)
+                                           dout, res, tile=K.ps_fused_tile(dz))
             # (the 1x1 convs are frozen upstream — never in parameters() — so they get no weight gradient)
             wt1d = meta.c1_packs[k][1] if meta.c1_packs else \
                 K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad)
