@@ -676,7 +676,9 @@ static bool small3d_ok(int c_in, int c_out, int dtype) {
 static Plan small3d_plan(long long Ptot, int c_in) {
   Plan pl = make_plan_k(Ptot, 256, 256, 1, VNQA_BF16);
   const int groups = (27 + 256 / c_in - 1) / (256 / c_in);
-  int slices = 512 / groups;                                      // one workgroup per CU (128 KiB LDS): two FULL rounds of 256
+  static const int target_wgs = [] { const char* e = getenv("VNQA_WGRAD_SMALL_WGS"); const int v = e ? atoi(e) : 256; return v < 32 ? 32 : v; }();
+  int slices = target_wgs / groups;                               // one workgroup per CU (128 KiB LDS): ONE full round of 256 (two rounds: the
+                                                                  // slab reduce reads twice the partials for nothing; config 2 -1.2 %)
   const int max_slices = pl.ksteps_total / 8 > 0 ? pl.ksteps_total / 8 : 1;
   slices = slices > max_slices ? max_slices : slices;
   pl.ksteps_per_slice = (pl.ksteps_total + slices - 1) / slices;
