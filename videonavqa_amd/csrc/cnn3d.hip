@@ -718,21 +718,21 @@ __global__ void __launch_bounds__(256) c3d_fold_kernel(const float* __restrict__
 
 // G = sum of the partials; dW[co][c][tap] = gamma_c G[co][tap][c] + beta_c G[co][tap][3]; db[co] = G[co][13][3];
 // d gamma_c = sum W[co][c][tap] G[co][tap][c];  d beta_c = sum W[co][c][tap] G[co][tap][3]      (one workgroup)
-__global__ void __launch_bounds__(256) c3d_conv1_bwd_finalize_kernel(const float* __restrict__ partial, int nblk,
+__global__ void __launch_bounds__(1024) c3d_conv1_bwd_finalize_kernel(const float* __restrict__ partial, int nblk,
                                                                      const float* __restrict__ w, const float* __restrict__ gamma,
                                                                      const float* __restrict__ beta, float inv_scale,
                                                                      float* __restrict__ dw, float* __restrict__ db,
                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float s_g[C1_CO * 112];
-  __shared__ float s_red[6][256];
-  for (int i = threadIdx.x; i < C1_CO * 112; i += 256) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)partial[(size_t)b * C1_CO * 112 + i];
-    s_g[i] = (float)(s * inv_scale);
+  __shared__ float s_red[6][1024];
+  for (int i = threadIdx.x; i < C1_CO * 112; i += 1024) {
+    float s = 0.f;                                           // (<= 16 shares, already folded in order by c3d_fold_kernel)
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * C1_CO * 112 + i];
+    s_g[i] = s * inv_scale;
   }
   __syncthreads();
   float r[6] = {0, 0, 0, 0, 0, 0};
-  for (int i = threadIdx.x; i < C1_CO * 27; i += 256) {
+  for (int i = threadIdx.x; i < C1_CO * 27; i += 1024) {
     const int co = i / 27, t = i - co * 27;
     const float g3 = s_g[co * 112 + t * 4 + 3];
 #pragma unroll
@@ -749,7 +749,7 @@ __global__ void __launch_bounds__(256) c3d_conv1_bwd_finalize_kernel(const float
   __syncthreads();
   if (threadIdx.x < 6) {
     double s = 0.0;
-    for (int i = 0; i < 256; ++i) s += (double)s_red[threadIdx.x][i];
+    for (int i = 0; i < 1024; ++i) s += (double)s_red[threadIdx.x][i];
     if (threadIdx.x < 3) dgamma[threadIdx.x] = (float)s;
     else dbeta[threadIdx.x - 3] = (float)s;
   }
@@ -946,7 +946,7 @@ extern "C" int vnqa_c3d_conv1_bwd(const float* x, const float* weight, const flo
   hipLaunchKernelGGL(c3d_fold_kernel, dim3((n_el + 255) / 256, shares), dim3(256), 0, st, (const float*)partial, folded, grid, n_el,
                      shares);
   VNQA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(c3d_conv1_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)folded, shares, weight, gamma, beta,
+  hipLaunchKernelGGL(c3d_conv1_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)folded, shares, weight, gamma, beta,
                      1.0f / grad_scale, dweight, dbias, dgamma, dbeta);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
