@@ -655,7 +655,7 @@ int vnqa_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const floa
  *                        clip: p dense [n][d][h/2][w/2][64], idx = arg-max 0..3 in (h, w) order (+4: not positive), statistics of p.
  *                        h, w multiples of 16 (vnqa_c3d_conv1_supported)
  *   vnqa_c3d_conv1_bwd : from dp (gradient wrt p): dweight [64][3][27], dbias [64], and bn_input's dgamma / dbeta [3], all
- *                        divided by grad_scale; partial: (vnqa_c3d_conv1_bwd_blocks + 16) * 64 * 112 floats
+ *                        divided by grad_scale; partial: (2 * vnqa_c3d_conv1_bwd_blocks + 16) * 64 * 112 floats
  */
 typedef struct vnqa_view5 {
   int64_t base, sn, sd, sh, sw, sc;

@@ -605,9 +605,15 @@ __global__ void __launch_bounds__(256) c3d_conv1_bwd_kernel(const C1Args a, int 
   int bkd[C1B_NT], boff[C1B_NT];
 #pragma unroll
   for (int nt = 0; nt < C1B_NT; ++nt) c1_tap(4 * nt + pp, bkd[nt], boff[nt]);
-  vnqa_f32x4 acc[C1B_NT];
+  // wave = (co half ch: 32 output channels = two M-tiles, pixel half ph: K-steps 4 ph .. 4 ph + 3 of every plane): one im2col
+  // fragment feeds two MFMAs (18 transposed reads per 14 MFMAs instead of 16 per 7); the two pixel halves are separate partial
+  // sums, folded with the other workgroups' by c3d_fold_kernel
+  const int ch = wave & 1, ph = wave >> 1;
+  vnqa_f32x4 acc[2][C1B_NT];
 #pragma unroll
-  for (int nt = 0; nt < C1B_NT; ++nt) acc[nt] = vnqa_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C1B_NT; ++nt) acc[mt][nt] = vnqa_f32x4{0.f, 0.f, 0.f, 0.f};
   const int Ho = a.H / 2, Wo = a.W / 2;
 
   for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
@@ -665,12 +671,18 @@ __global__ void __launch_bounds__(256) c3d_conv1_bwd_kernel(const C1Args a, int 
                                      c3_lds_addr(s_patch) + (unsigned)((d % 3) * C1_PLANE),
                                      c3_lds_addr(s_patch) + (unsigned)(((d + 1) % 3) * C1_PLANE)};
       const unsigned zero_addr = c3_lds_addr(s_patch) + 3 * C1_PLANE;
-      const unsigned dy_base = c3_lds_addr(s_dy) + (unsigned)((2 * wave + (pp >> 1)) * 16 + ((pp & 1) << 3));
+      const unsigned dy_base = c3_lds_addr(s_dy) + (unsigned)((4 * ch + (pp >> 1)) * 16 + ((pp & 1) << 3));
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {                          // K-step: pixels 32 s .. + 31 = tile rows 2 s, 2 s + 1
-        // A: dY^T, lane group g supplies pixels 32 s + 8 g .. + 7 of channels 16 wave .. + 15
+      for (int s4 = 0; s4 < 4; ++s4) {                       // K-step: pixels 32 s .. + 31 = tile rows 2 s, 2 s + 1
+        const int s = 4 * ph + s4;
+        // A: dY^T, lane group g supplies pixels 32 s + 8 g .. + 7 of channels 32 ch + 16 mt .. + 15
         const unsigned arow = (unsigned)((32 * s + 8 * g + q4) * (C1_CO * 2));
-        const c3_s16x4 alo = c3_tr_read(dy_base + arow), ahi = c3_tr_read(dy_base + arow + 4 * C1_CO * 2);
+        c3_s16x4 alo[2], ahi[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          alo[mt] = c3_tr_read(dy_base + arow + mt * 32);
+          ahi[mt] = c3_tr_read(dy_base + arow + mt * 32 + 4 * C1_CO * 2);
+        }
         // B: pixels (row 2 s + (g >> 1), columns 8 (g & 1) + q4 [+ 4]) of 4 taps x 4 channels per N-tile
         const unsigned prow = (unsigned)(((2 * s + (g >> 1)) * C1_PW + 8 * (g & 1) + q4) * 8);
         c3_s16x4 blo[C1B_NT], bhi[C1B_NT];
@@ -682,25 +694,32 @@ __global__ void __launch_bounds__(256) c3d_conv1_bwd_kernel(const C1Args a, int 
           bhi[nt] = c3_tr_read(kd < 0 ? zero_addr : base + 4 * 8);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        c3_s16x4 alo2 = alo, ahi2 = ahi;
-        asm volatile("" : "+v"(alo2), "+v"(ahi2));
-        const vnqa_bf16x8 af = vnqa_bf16x8{alo2[0], alo2[1], alo2[2], alo2[3], ahi2[0], ahi2[1], ahi2[2], ahi2[3]};
+        vnqa_bf16x8 af[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          asm volatile("" : "+v"(alo[mt]), "+v"(ahi[mt]));
+          af[mt] = vnqa_bf16x8{alo[mt][0], alo[mt][1], alo[mt][2], alo[mt][3], ahi[mt][0], ahi[mt][1], ahi[mt][2], ahi[mt][3]};
+        }
 #pragma unroll
         for (int nt = 0; nt < C1B_NT; ++nt) {
           asm volatile("" : "+v"(blo[nt]), "+v"(bhi[nt]));
           const vnqa_bf16x8 bf = vnqa_bf16x8{blo[nt][0], blo[nt][1], blo[nt][2], blo[nt][3], bhi[nt][0], bhi[nt][1], bhi[nt][2], bhi[nt][3]};
-          acc[nt] = VNQA_MFMA_16x16x32(af, bf, acc[nt]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = VNQA_MFMA_16x16x32(af[mt], bf, acc[mt][nt]);
         }
       }
       __syncthreads();
     }
   }
-  // D[co = 16 wave + 4 (lane >> 4) + e][k = 16 nt + (lane & 15)]
+  // D[co = 32 ch + 16 mt + 4 (lane >> 4) + e][k = 16 nt + (lane & 15)] of pixel half ph -> partial set 2 blockIdx + ph
 #pragma unroll
-  for (int nt = 0; nt < C1B_NT; ++nt)
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      a.partial[((size_t)blockIdx.x * C1_CO + 16 * wave + 4 * (lane >> 4) + e) * (16 * C1B_NT) + 16 * nt + (lane & 15)] = acc[nt][e];
+    for (int nt = 0; nt < C1B_NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        a.partial[((size_t)(2 * blockIdx.x + ph) * C1_CO + 32 * ch + 16 * mt + 4 * (lane >> 4) + e) * (16 * C1B_NT) + 16 * nt + (lane & 15)] =
+            acc[mt][nt][e];
 }
 
 // first fold of the split-K partials: out[z][i] = sum of partial[b][i] over the z-th share of the blocks
@@ -940,10 +959,10 @@ extern "C" int vnqa_c3d_conv1_bwd(const float* x, const float* weight, const flo
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(c3d_conv1_bwd_kernel, dim3(grid), dim3(256), 0, st, a, n * (h / 16) * (w / 16));
   VNQA_CHECK_LAUNCH();
-  // partials [grid][64][112] -> 16 shares (second part of the workspace) -> the one-workgroup finalize
-  const int n_el = C1_CO * 112, shares = grid < 16 ? grid : 16;
-  float* folded = partial + (size_t)grid * n_el;
-  hipLaunchKernelGGL(c3d_fold_kernel, dim3((n_el + 255) / 256, shares), dim3(256), 0, st, (const float*)partial, folded, grid, n_el,
+  // partials [2 grid][64][112] (two pixel halves per workgroup) -> 16 shares (behind them in the workspace) -> the one-workgroup finalize
+  const int n_el = C1_CO * 112, n_sets = 2 * grid, shares = n_sets < 16 ? n_sets : 16;
+  float* folded = partial + (size_t)n_sets * n_el;
+  hipLaunchKernelGGL(c3d_fold_kernel, dim3((n_el + 255) / 256, shares), dim3(256), 0, st, (const float*)partial, folded, n_sets, n_el,
                      shares);
   VNQA_CHECK_LAUNCH();
   hipLaunchKernelGGL(c3d_conv1_bwd_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float*)folded, shares, weight, gamma, beta,

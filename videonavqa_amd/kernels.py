@@ -1062,7 +1062,7 @@ def c3d_conv1_fwd(x, weight, bias, mean, rstd, gamma, beta, dtype):
 def c3d_conv1_bwd(x, weight, mean, rstd, gamma, beta, dp, idx, grad_scale=1.0):
     """-> (dweight [64,3,3,3,3], dbias [64], bn_input dgamma [3], dbeta [3])"""
     N, _, D, H, W = x.shape
-    ws = workspace((L.lib().vnqa_c3d_conv1_bwd_blocks(N, H, W) + 16) * 64 * 112 * 4, x.device)
+    ws = workspace((2 * L.lib().vnqa_c3d_conv1_bwd_blocks(N, H, W) + 16) * 64 * 112 * 4, x.device)
     dw = torch.empty((64, 3, 3, 3, 3), dtype=torch.float32, device=x.device)
     db = torch.empty((64,), dtype=torch.float32, device=x.device)
     dg = torch.empty((3,), dtype=torch.float32, device=x.device)
