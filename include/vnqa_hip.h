@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 304
+#define VNQA_ABI_VERSION 305
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -547,6 +547,20 @@ int vnqa_lstm_wide_fwd(const float* xg, const float* w_hh, const float* h0, cons
 int vnqa_lstm_wide_bwd(const float* w_hh_t, const float* c0, const int32_t* batch_sizes_host,
                        const float* gates, const float* cs, const float* dhs, float* dgates,
                        float* dc_work, int32_t t, int32_t b, int32_t hidden, int32_t reverse, void* stream);
+
+/* Both directions of a bidirectional packed LSTM from zero states (models/mac.py:185,210-213: the question encoder) with
+ * chain position i of the forward direction (step i) and of the reverse direction (step t-1-i) in ONE launch: t launches
+ * instead of 2 t on the dependent chain.  Buffers as vnqa_lstm_wide_fwd / _bwd, one set per direction (`_f` walks 0..t-1,
+ * `_r` walks t-1..0); dc_work_f / dc_work_r are two distinct zeroed [b][hidden] scratch buffers.  Results are bit-identical
+ * to two single-direction calls.
+ */
+int vnqa_lstm_wide_bidir_fwd(const float* xg_f, const float* xg_r, const float* w_hh_f, const float* w_hh_r,
+                             const int32_t* batch_sizes_host, float* hs_f, float* hs_r, float* cs_f, float* cs_r,
+                             float* gates_f, float* gates_r, int32_t t, int32_t b, int32_t hidden, void* stream);
+int vnqa_lstm_wide_bidir_bwd(const float* w_hh_t_f, const float* w_hh_t_r, const int32_t* batch_sizes_host,
+                             const float* gates_f, const float* gates_r, const float* cs_f, const float* cs_r,
+                             const float* dhs_f, const float* dhs_r, float* dgates_f, float* dgates_r,
+                             float* dc_work_f, float* dc_work_r, int32_t t, int32_t b, int32_t hidden, void* stream);
 
 /* Fused ReadUnit attention of MACNetwork (models/mac.py:53-62; replaces, per reasoning step, the Linear(2d->d)
  * over [mem*know ; know] at every position, the control-weighted Linear(d->1), the softmax over positions and the

@@ -64,6 +64,35 @@ def test_lstm_wide_matches_torch_packed_bidirectional(B, E, H, lens):
         assert rel_err(bias.grad.cpu().numpy(), getattr(lstm, "bias_ih_l0" + sfx).grad.numpy()) < 2e-4, sfx
 
 
+@pytest.mark.parametrize("B,H,lens", [(5, 16, [9, 7, 7, 3, 1]), (11, 48, [6, 6, 5, 5, 5, 4, 3, 3, 2, 1, 1]), (3, 512, [13, 9, 4]),
+                                      (8, 1536, [7, 7, 6, 4, 4, 2, 1, 1])])
+def test_lstm_wide_bidir_is_two_single_direction_calls(B, H, lens):
+    """ops.lstm_wide_bidir (chain position i of both directions in one launch) vs two ops.lstm_wide nodes: outputs and every
+    gradient bit-identical (same arithmetic, only the launches are shared)."""
+    from videonavqa_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    T = lens[0]
+    bsz = ops.packed_batch_sizes(lens)
+    xg = [(torch.randn(T, B, 4 * H, device=dev) * 0.3).requires_grad_(True) for _ in range(4)]
+    w = [(torch.randn(4 * H, H, device=dev) / H ** 0.5).requires_grad_(True) for _ in range(2)]
+    w2 = [t.detach().clone().requires_grad_(True) for t in w]
+    with torch.no_grad():
+        xg[2].copy_(xg[0]); xg[3].copy_(xg[1])
+    valid = torch.zeros(T, B, 1, device=dev)
+    for b, l in enumerate(lens):
+        valid[:l, b] = 1
+    gf, gr = torch.randn(T, B, H, device=dev) * valid, torch.randn(T, B, H, device=dev) * valid
+    a_f, a_r = ops.lstm_wide(xg[0], w[0], bsz, False), ops.lstm_wide(xg[1], w[1], bsz, True)
+    ((a_f * gf).sum() + (a_r * gr).sum()).backward()
+    b_f, b_r = ops.lstm_wide_bidir(xg[2], xg[3], w2[0], w2[1], bsz)
+    ((b_f * gf).sum() + (b_r * gr).sum()).backward()
+    assert torch.equal(a_f, b_f) and torch.equal(a_r, b_r)
+    assert torch.equal(xg[0].grad, xg[2].grad) and torch.equal(xg[1].grad, xg[3].grad)
+    assert torch.equal(w[0].grad, w2[0].grad) and torch.equal(w[1].grad, w2[1].grad)
+    assert float(a_f.abs().sum()) > 0 and float(xg[1].grad.abs().sum()) > 0
+
+
 def test_lstm_wide_rejects_bad_batch_sizes():
     from videonavqa_amd import kernels as K
     from videonavqa_amd._lib import VnqaError

@@ -640,6 +640,37 @@ def lstm_wide_bwd(w_hh_t, batch_sizes, gates, cs, dhs, reverse=False, c0=None):
     return dgates
 
 
+def lstm_wide_bidir_fwd(xg_f, xg_r, w_hh_f, w_hh_r, batch_sizes):
+    """Both directions of a bidirectional packed LSTM from zero states, one launch per chain position
+    (vnqa_lstm_wide_bidir_fwd).  Returns ((hs_f, hs_r), (cs_f, cs_r), (gates_f, gates_r)); bit-identical to two
+    lstm_wide_fwd calls."""
+    T, B, H4 = xg_f.shape
+    H = H4 // 4
+    dev = xg_f.device
+    assert xg_r.shape == xg_f.shape and w_hh_f.shape == w_hh_r.shape == (H4, H)
+    bs = (ctypes.c_int32 * T)(*[int(v) for v in batch_sizes])
+    hs = torch.zeros((2, T, B, H), dtype=torch.float32, device=dev)
+    cs = torch.zeros((2, T, B, H), dtype=torch.float32, device=dev)
+    gates = torch.zeros((2, T, B, H4), dtype=torch.float32, device=dev)
+    L.check(L.lib().vnqa_lstm_wide_bidir_fwd(L.ptr(xg_f), L.ptr(xg_r), L.ptr(w_hh_f), L.ptr(w_hh_r), bs, L.ptr(hs[0]),
+                                             L.ptr(hs[1]), L.ptr(cs[0]), L.ptr(cs[1]), L.ptr(gates[0]), L.ptr(gates[1]),
+                                             T, B, H, L.stream()), "vnqa_lstm_wide_bidir_fwd")
+    return (hs[0], hs[1]), (cs[0], cs[1]), (gates[0], gates[1])
+
+
+def lstm_wide_bidir_bwd(w_hh_t_f, w_hh_t_r, batch_sizes, gates_f, gates_r, cs_f, cs_r, dhs_f, dhs_r):
+    """BPTT of lstm_wide_bidir_fwd.  Returns (dgates_f, dgates_r), each [T,B,4H] (= d xg of its direction)."""
+    T, B, H = cs_f.shape
+    dev = cs_f.device
+    bs = (ctypes.c_int32 * T)(*[int(v) for v in batch_sizes])
+    dgates = torch.zeros((2, T, B, 4 * H), dtype=torch.float32, device=dev)
+    dc = torch.zeros((2, B, H), dtype=torch.float32, device=dev)
+    L.check(L.lib().vnqa_lstm_wide_bidir_bwd(L.ptr(w_hh_t_f), L.ptr(w_hh_t_r), bs, L.ptr(gates_f), L.ptr(gates_r), L.ptr(cs_f),
+                                             L.ptr(cs_r), L.ptr(dhs_f), L.ptr(dhs_r), L.ptr(dgates[0]), L.ptr(dgates[1]),
+                                             L.ptr(dc[0]), L.ptr(dc[1]), T, B, H, L.stream()), "vnqa_lstm_wide_bidir_bwd")
+    return dgates[0], dgates[1]
+
+
 def mac_read_fwd(know, pre, u, v, bias, n, s, c):
     """Fused ReadUnit attention.  know/pre [n*s, ld] (compute dtype), u/v fp32 [n,c] -> p [n,s], read [n,c] fp32."""
     ld = know.shape[-1]

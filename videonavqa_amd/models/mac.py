@@ -132,14 +132,14 @@ class MACNetwork(nn.Module):
         emb = F.embedding(question[:B], self.embed.weight, padding_idx=0)[perm_d][:, :Lmax]
         bsz = ops.packed_batch_sizes(lens_sorted)
         H = self.dim
-        outs, finals = [], []
-        for sfx, rev in (("", False), ("_reverse", True)):
-            w_ih, w_hh = getattr(self.lstm, "weight_ih_l0" + sfx), getattr(self.lstm, "weight_hh_l0" + sfx)
+        xgs = []
+        for sfx in ("", "_reverse"):
+            w_ih = getattr(self.lstm, "weight_ih_l0" + sfx)
             bias = getattr(self.lstm, "bias_ih_l0" + sfx) + getattr(self.lstm, "bias_hh_l0" + sfx)
-            xg = F.linear(emb, w_ih, bias).transpose(0, 1).contiguous()          # [Lmax,B,4H]
-            hs = ops.lstm_wide(xg, w_hh, bsz, rev)                                # [Lmax,B,H]
-            outs.append(hs)
-            finals.append(hs[0] if rev else hs[L.to_device_async(lens_sorted - 1, dev), torch.arange(B, device=dev)])
+            xgs.append(F.linear(emb, w_ih, bias).transpose(0, 1).contiguous())   # [Lmax,B,4H]
+        # both directions' chains share their launches (ops.LstmWideBidirFn)
+        outs = ops.lstm_wide_bidir(xgs[0], xgs[1], self.lstm.weight_hh_l0, self.lstm.weight_hh_l0_reverse, bsz)   # 2 x [Lmax,B,H]
+        finals = [outs[0][L.to_device_async(lens_sorted - 1, dev), torch.arange(B, device=dev)], outs[1][0]]
         lstm_out = torch.cat(outs, 2).transpose(0, 1)                             # [B,Lmax,2H] sorted order
         inv = L.to_device_async(torch.sort(perm, dim=0)[1], dev)
         context = self.lstm_proj(lstm_out[inv])                                   # :217-220 (pad rows -> bias)
@@ -189,8 +189,10 @@ class MACNetwork(nn.Module):
         w2 = F.pad(m.read.concat.weight[:, dim:], (0, c_pad - dim, 0, c_pad - dim))
         pre = ops.linear_nt(kd, w2, F.pad(m.read.concat.bias, (0, c_pad - dim)))
         state = ops.MacCoreState(self.max_step)
-        wc, w1 = wcq[:, :dim], m.read.concat.weight[:, :dim]
-        wr, wmm = m.write.concat.weight[:, :dim], m.write.concat.weight[:, dim:]
+        # contiguous halves of the [dim, 2 dim] weights ONCE (autograd-tracked copies): the node's `.contiguous()` of a column
+        # slice otherwise copies 4 x 1 MB per reasoning step (48 launches per forward on the dependent chain)
+        wc, w1 = wcq[:, :dim].contiguous(), m.read.concat.weight[:, :dim].contiguous()
+        wr, wmm = m.write.concat.weight[:, :dim].contiguous(), m.write.concat.weight[:, dim:].contiguous()
         masks = self._masks(n_img, dev)
         control = m.control_0.expand(n_img, dim)
         memory = m.mem_0.expand(n_img, dim)

@@ -691,6 +691,39 @@ def lstm_wide(xg, w_hh, batch_sizes, reverse=False):
     return LstmWideFn.apply(xg, w_hh, batch_sizes, reverse)
 
 
+class LstmWideBidirFn(torch.autograd.Function):
+    """(hs_f, hs_r) = both directions of a bidirectional packed LSTM (MACNetwork's question encoder, models/mac.py:185,
+    210-213) with the two independent chains sharing their launches: chain position i of either direction runs in one
+    launch, forward and backward — half the launches of two LstmWideFn nodes on the model's dependent chain, same bits."""
+
+    @staticmethod
+    def forward(ctx, xg_f, xg_r, w_hh_f, w_hh_r, batch_sizes):
+        xg_f, xg_r = xg_f.float().contiguous(), xg_r.float().contiguous()
+        wf, wr = w_hh_f.float().contiguous(), w_hh_r.float().contiguous()
+        hs, cs, gates = K.lstm_wide_bidir_fwd(xg_f, xg_r, wf, wr, batch_sizes)
+        ctx.save_for_backward(wf, wr, hs[0], hs[1], cs[0], cs[1], gates[0], gates[1])
+        ctx.batch_sizes = tuple(batch_sizes)
+        return hs[0], hs[1]
+
+    @staticmethod
+    def backward(ctx, dhs_f, dhs_r):
+        wf, wr, hs_f, hs_r, cs_f, cs_r, gates_f, gates_r = ctx.saved_tensors
+        T, B, H = hs_f.shape
+        zf = lambda d, ref: torch.zeros_like(ref) if d is None else d.float().contiguous()
+        dg_f, dg_r = K.lstm_wide_bidir_bwd(wf.t().contiguous(), wr.t().contiguous(), ctx.batch_sizes, gates_f, gates_r, cs_f,
+                                           cs_r, zf(dhs_f, hs_f), zf(dhs_r, hs_r))
+        zero = torch.zeros(1, B, H, device=hs_f.device)
+        hp_f = torch.cat([zero, hs_f[:-1]], 0)           # h of each step's predecessor in its chain
+        hp_r = torch.cat([hs_r[1:], zero], 0)
+        dw_f = K.gemm_tn(dg_f.reshape(T * B, 4 * H), hp_f.reshape(T * B, H).contiguous())
+        dw_r = K.gemm_tn(dg_r.reshape(T * B, 4 * H), hp_r.reshape(T * B, H).contiguous())
+        return dg_f, dg_r, dw_f, dw_r, None
+
+
+def lstm_wide_bidir(xg_f, xg_r, w_hh_f, w_hh_r, batch_sizes):
+    return LstmWideBidirFn.apply(xg_f, xg_r, w_hh_f, w_hh_r, batch_sizes)
+
+
 def packed_batch_sizes(lens_sorted, n_steps=None):
     """PackedSequence.batch_sizes of host lengths sorted descending."""
     lens = [int(v) for v in lens_sorted]
