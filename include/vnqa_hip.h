@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 305
+#define VNQA_ABI_VERSION 306
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -482,6 +482,26 @@ int vnqa_sgemm(const float* a, const float* b, float* c, const float* bias, cons
 int vnqa_sgemm2(const float* a, const float* b, float* c, const float* bias, int64_t a_rs, int64_t a_cs, int64_t b_rs, int64_t b_cs,
                 int32_t ldc, int32_t m, int32_t n, int32_t k, const float* addend, float* out2, const float* out2_col,
                 const float* out2_mul, void* workspace, void* stream);
+
+/* Up to VNQA_SGEMM_BATCH_MAX independent vnqa_sgemm / vnqa_sgemm2 products in ONE launch (one pass over K each, no row
+ * gather / scatter / operand mask): the small fp32 products of a MACNetwork reasoning step that do not depend on each other
+ * (models/mac.py:31-32 with :55 and :84; their gradients) cost the step's dependent chain one launch instead of two or three.
+ * Every field as the same-named argument of vnqa_sgemm / vnqa_sgemm2; results are bit-identical to separate calls without a
+ * workspace.  Problems whose outputs exceed 1024 tiles of 32 x 32 are run one after the other instead. */
+typedef struct vnqa_sgemm_problem {
+  const float* a;
+  const float* b;
+  float* c;
+  const float* bias;
+  const float* addend;
+  float* out2;
+  const float* out2_col;
+  const float* out2_mul;
+  int64_t a_rs, a_cs, b_rs, b_cs;
+  int32_t ldc, m, n, k, relu, accumulate;
+} vnqa_sgemm_problem;
+#define VNQA_SGEMM_BATCH_MAX 4
+int vnqa_sgemm_batch(const vnqa_sgemm_problem* problems, int32_t count, void* stream);
                /* addend: optional fp32 matrix [m][ldc] added to the product (torch.addmm's first argument) */
                /* workspace: vnqa_sgemm_workspace bytes (skinny outputs over a long K are split over workgroups and summed in
                 * slice order by a second launch); NULL = one pass over K */

@@ -290,3 +290,29 @@ def test_sgemm2_second_output_from_the_same_epilogue(shape):
         y, y2 = K.linear_nt2(x, w, addend=add, out2_col=c_, out2_mul=m_)
         r2 = ref * (1 if c_ is None else c_.double()) * (1 if m_ is None else m_.double())
         assert _close(y, ref.float(), 2e-5) and _close(y2, r2.float(), 2e-5)
+
+
+def test_sgemm_batch_is_the_separate_calls():
+    """vnqa_sgemm_batch: three independent products of different shapes / forms (x w^T + addend with a scaled second output,
+    x w^T + bias, accumulating x w with a ReLU) in one launch vs float64 references; the nt form bit-identical to
+    K.linear_nt2 (same kernel body, one pass over K)."""
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    r = lambda *sh: torch.randn(*sh, generator=g).cuda()
+    m, d = 280, 512
+    x1, w1, add1, col1 = r(m, d), r(d, d), r(m, d), r(d)
+    x2, w2, b2 = r(m, d), r(200, d), r(200)
+    x3, w3, c3 = r(70, 96), r(96, 40), r(70, 40)
+    c1, o1, c2 = torch.empty(m, d).cuda(), torch.empty(m, d).cuda(), torch.empty(m, 200).cuda()
+    c3_ref = torch.relu(c3.double() + x3.double() @ w3.double())
+    K.sgemm_batch([
+        dict(a=x1, b=w1, c=c1, addend=add1, out2=o1, out2_col=col1, a_rs=d, a_cs=1, b_rs=1, b_cs=d, ldc=d, m=m, n=d, k=d),
+        dict(a=x2, b=w2, c=c2, bias=b2, a_rs=d, a_cs=1, b_rs=1, b_cs=d, ldc=200, m=m, n=200, k=d),
+        dict(a=x3, b=w3, c=c3, a_rs=96, a_cs=1, b_rs=40, b_cs=1, ldc=40, m=70, n=40, k=96, relu=1, accumulate=1)])
+    y, y2 = K.linear_nt2(x1, w1, addend=add1, out2_col=col1)
+    assert torch.equal(c1, y) and torch.equal(o1, y2)
+    assert _close(c1, (x1.double() @ w1.double().t() + add1.double()).float(), 2e-5)
+    assert _close(c2, (x2.double() @ w2.double().t() + b2.double()).float(), 2e-5)
+    assert _close(c3, c3_ref.float(), 2e-5)
+    with pytest.raises(RuntimeError):
+        K.sgemm_batch([dict(a=x1, b=w1, c=c1, a_rs=d, a_cs=1, b_rs=1, b_cs=d, ldc=d, m=m, n=d, k=d)] * 5)

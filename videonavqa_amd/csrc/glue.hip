@@ -169,8 +169,8 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __
 // 144 workgroups of 8 waves with 64 K-values each, i.e. the whole chip for ~32 MFMAs per wave.  <2,2,2>: 64 x 64 tiles for
 // larger outputs.  Same SgemmArgs contract / epilogue / split-K partial mode as sgemm_kernel.
 template <int WM, int WN, int WK>
-__global__ void __launch_bounds__(512) sgemm_mfma_kernel(const SgemmArgs p, float* __restrict__ partial, int k_per_slice,
-                                                         int a_vec, int b_vec) {
+__device__ __forceinline__ void sgemm_mfma_body(const SgemmArgs& p, float* __restrict__ partial, int k_per_slice, int slice,
+                                                int a_vec, int b_vec) {
   static_assert(WM * WN * WK == 8, "8 waves");
   constexpr int TILE = 32 * 33;
   __shared__ float red[WK * WM * WN * TILE];
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(512) sgemm_mfma_kernel(const SgemmArgs p, floa
   const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.y * (32 * WM), n0 = blockIdx.x * (32 * WN);
-  const int ks = blockIdx.z * k_per_slice;
+  const int ks = slice * k_per_slice;
   const int kse = (ks + k_per_slice < p.K) ? ks + k_per_slice : p.K;
   const int kper = (((kse - ks) + WK - 1) / WK + 7) / 8 * 8;
   const int kb = ks + wk * kper;
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(512) sgemm_mfma_kernel(const SgemmArgs p, floa
 #pragma unroll
     for (int z = 0; z < WK; ++z) v += src[z * TILE];
     if (partial != nullptr) {
-      partial[((size_t)blockIdx.z * p.M + m) * p.N + n] = v;
+      partial[((size_t)slice * p.M + m) * p.N + n] = v;
       continue;
     }
     int orow = m;
@@ -305,6 +305,26 @@ __global__ void __launch_bounds__(512) sgemm_mfma_kernel(const SgemmArgs p, floa
   }
 }
 
+template <int WM, int WN, int WK>
+__global__ void __launch_bounds__(512) sgemm_mfma_kernel(const SgemmArgs p, float* __restrict__ partial, int k_per_slice,
+                                                         int a_vec, int b_vec) {
+  sgemm_mfma_body<WM, WN, WK>(p, partial, k_per_slice, blockIdx.z, a_vec, b_vec);
+}
+
+// Up to SGEMM_BATCH independent products in ONE launch (blockIdx.z = problem; one pass over K each): MACNetwork's reasoning
+// step issues small products that do not depend on each other back to back — each launch costs the dependent chain ~5.5 us
+// before any work starts, about what the product itself takes.
+constexpr int SGEMM_BATCH = 4;
+struct SgemmBatchArgs {
+  SgemmArgs a[SGEMM_BATCH];
+  int a_vec[SGEMM_BATCH], b_vec[SGEMM_BATCH];
+};
+__global__ void __launch_bounds__(512) sgemm_mfma_batch_kernel(const SgemmBatchArgs pp) {
+  const SgemmArgs& p = pp.a[blockIdx.z];
+  if ((int)blockIdx.y * 32 >= p.M || (int)blockIdx.x * 32 >= p.N) return;      // grid = the largest problem's (workgroup-uniform)
+  sgemm_mfma_body<1, 1, 8>(p, nullptr, (p.K + 15) / 16 * 16, 0, pp.a_vec[blockIdx.z], pp.b_vec[blockIdx.z]);
+}
+
 // one launch of the GEMM proper (z = split-K slices): the MFMA form unless VNQA_SGEMM_FMA=1 asks for the FMA kernel
 static bool sgemm_use_fma() {
   static const int v = [] {
@@ -314,14 +334,21 @@ static bool sgemm_use_fma() {
   return v != 0;
 }
 
+// float4 operand loads along K: contiguous K, 16-byte aligned rows
+static int sgemm_a_vec(const SgemmArgs& p, int kps) {
+  return (p.a_cs == 1 && p.a_rs % 4 == 0 && ((uintptr_t)p.A & 15) == 0 && kps % 8 == 0 &&
+          (p.a_mask == nullptr || ((uintptr_t)p.a_mask & 15) == 0)) ? 1 : 0;
+}
+static int sgemm_b_vec(const SgemmArgs& p, int kps) {
+  return (p.b_rs == 1 && p.b_cs % 4 == 0 && ((uintptr_t)p.B & 15) == 0 && kps % 8 == 0) ? 1 : 0;
+}
+
 static void sgemm_launch(const SgemmArgs& p, float* partial, int kps, int nsl, hipStream_t st) {
   if (sgemm_use_fma()) {
     hipLaunchKernelGGL(sgemm_kernel, dim3((p.N + 63) / 64, (p.M + 63) / 64, nsl), dim3(256), 0, st, p, partial, kps);
     return;
   }
-  const int a_vec = (p.a_cs == 1 && p.a_rs % 4 == 0 && ((uintptr_t)p.A & 15) == 0 && kps % 8 == 0 &&
-                     (p.a_mask == nullptr || ((uintptr_t)p.a_mask & 15) == 0)) ? 1 : 0;
-  const int b_vec = (p.b_rs == 1 && p.b_cs % 4 == 0 && ((uintptr_t)p.B & 15) == 0 && kps % 8 == 0) ? 1 : 0;
+  const int a_vec = sgemm_a_vec(p, kps), b_vec = sgemm_b_vec(p, kps);
   const long long tiles32 = (long long)((p.M + 31) / 32) * ((p.N + 31) / 32);
   if (tiles32 <= 1024)
     hipLaunchKernelGGL((sgemm_mfma_kernel<1, 1, 8>), dim3((p.N + 31) / 32, (p.M + 31) / 32, nsl), dim3(512), 0, st, p, partial, kps,
@@ -594,6 +621,46 @@ static int sgemm_run(const float* a, const float* b, float* c, const float* bias
   int g = (int)((total + 255) / 256);
   g = g > 1024 ? 1024 : g;
   hipLaunchKernelGGL(sgemm_finish_kernel, dim3(g), dim3(256), 0, st, p, (const float*)workspace, nsl);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_sgemm_batch(const vnqa_sgemm_problem* problems, int32_t count, void* stream) {
+  VNQA_CHECK_ARG(problems != nullptr && count >= 1 && count <= VNQA_SGEMM_BATCH_MAX, "sgemm_batch: 1..%d problems", VNQA_SGEMM_BATCH_MAX);
+  static_assert(VNQA_SGEMM_BATCH_MAX == SGEMM_BATCH, "header and kernel batch limits");
+  bool one_launch = !sgemm_use_fma() && count > 1;
+  int gx = 0, gy = 0;
+  for (int i = 0; i < count; ++i) {
+    const vnqa_sgemm_problem& q = problems[i];
+    VNQA_CHECK_ARG(q.a && q.b && q.c && q.m > 0 && q.n > 0 && q.k > 0 && q.ldc >= q.n,
+                   "sgemm_batch: bad problem %d (m=%d n=%d k=%d ldc=%d)", i, q.m, q.n, q.k, q.ldc);
+    const int tx = (q.n + 31) / 32, ty = (q.m + 31) / 32;
+    if ((long long)tx * ty > 1024) one_launch = false;        // large outputs take the 64 x 64 tile form: run them one by one
+    gx = tx > gx ? tx : gx;
+    gy = ty > gy ? ty : gy;
+  }
+  if (!one_launch) {
+    for (int i = 0; i < count; ++i) {
+      const vnqa_sgemm_problem& q = problems[i];
+      const int rc = sgemm_run(q.a, q.b, q.c, q.bias, nullptr, nullptr, nullptr, q.a_rs, q.a_cs, q.b_rs, q.b_cs, q.ldc, q.m, q.n, q.k,
+                               q.relu, q.accumulate, q.addend, nullptr, stream, q.out2, q.out2_col, q.out2_mul);
+      if (rc != VNQA_OK) return rc;
+    }
+    return VNQA_OK;
+  }
+  SgemmBatchArgs pp;
+  for (int i = 0; i < SGEMM_BATCH; ++i) {
+    const vnqa_sgemm_problem& q = problems[i < count ? i : 0];
+    SgemmArgs& p = pp.a[i];
+    p.A = q.a; p.B = q.b; p.C = q.c; p.bias = q.bias; p.bias2 = nullptr; p.out2 = q.out2; p.out2_col = q.out2_col;
+    p.out2_mul = q.out2_mul; p.addend = q.addend; p.a_mask = nullptr; p.a_rows = nullptr; p.c_rows = nullptr;
+    p.a_rs = q.a_rs; p.a_cs = q.a_cs; p.b_rs = q.b_rs; p.b_cs = q.b_cs; p.ldc = q.ldc; p.M = q.m; p.N = q.n; p.K = q.k;
+    p.relu = q.relu; p.accumulate = q.accumulate;
+    const int kps = (q.k + 15) / 16 * 16;
+    pp.a_vec[i] = sgemm_a_vec(p, kps);
+    pp.b_vec[i] = sgemm_b_vec(p, kps);
+  }
+  hipLaunchKernelGGL(sgemm_mfma_batch_kernel, dim3(gx, gy, count), dim3(512), 0, (hipStream_t)stream, pp);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -1,7 +1,7 @@
 // mac_core.hip — one MAC reasoning step (ControlUnit, ReadUnit, WriteUnit.concat of the reference's models/mac.py:28-42,
 // 53-62,82-85, evaluated for all packed images at once) as ONE C-ABI call per direction.
 //
-// The step is ~11 small launches forward and ~25 backward (fp32 GEMMs of [n_img, dim] x [dim, dim], the fused attention-pool
+// The step is 7 small launches forward and 9 backward (25 with per-step weight gradients) (fp32 GEMMs of [n_img, dim] x [dim, dim], the fused attention-pool
 // kernels of mac_read.hip, a few elementwise products).  Issued one by one from Python the 12 steps of a training pass cost the
 // launch thread more time than the GPU needs to run them (16.7 ms of host time against 13.8 ms of kernels per step of
 // `bench.py --model mac`); here the whole sequence is enqueued from C++.
@@ -109,6 +109,17 @@ int gemm_tn(const float* a, const float* b, float* c, int m, int n, int k, int a
   return vnqa_sgemm(a, b, c, nullptr, nullptr, nullptr, nullptr, 1, m, n, 1, n, m, n, k, 0, acc, nullptr, ws, st);
 }
 
+// problem descriptors of vnqa_sgemm_batch in the forms used here
+vnqa_sgemm_problem prob_nt(const float* a, const float* b, float* c, const float* bias, const float* addend, int m, int n, int k,
+                           int acc) {                                   // C (+)= A B^T (+ bias / addend), B [n,k]
+  vnqa_sgemm_problem q = {a, b, c, bias, addend, nullptr, nullptr, nullptr, k, 1, 1, k, n, m, n, k, 0, acc};
+  return q;
+}
+vnqa_sgemm_problem prob_nn(const float* a, const float* b, float* c, int m, int n, int k, int acc) {     // C (+)= A B, B [k,n]
+  vnqa_sgemm_problem q = {a, b, c, nullptr, nullptr, nullptr, nullptr, nullptr, k, 1, n, 1, n, m, n, k, 0, acc};
+  return q;
+}
+
 }  // namespace
 
 extern "C" int64_t vnqa_mac_core_workspace(int32_t n, int32_t d) {
@@ -127,15 +138,22 @@ extern "C" int vnqa_mac_core_fwd(const vnqa_mac_core* a, void* stream) {
                  "mac_core_fwd: null output");
   const int N = a->n, d = a->d;
   hipStream_t st = (hipStream_t)stream;
-  MC_TRY(gemm_nt_scaled(a->control, a->wc, a->cq, a->pq, a->qv, a->w_ca, N, d, d, a->workspace, stream));   // cq = pq + control Wc^T; qv = cq * w_ca
+  {
+    // the three products that only need the step's inputs, in ONE launch: cq = pq + control Wc^T (and qv = cq * w_ca from
+    // the same epilogue), mem = memory Wm^T + bm, concat = memory Wmm^T + bw (read Wr^T is added at the end)
+    vnqa_sgemm_problem q[3] = {prob_nt(a->control, a->wc, a->cq, nullptr, a->pq, N, d, d, 0),
+                               prob_nt(a->memory, a->wm, a->mem, a->bm, nullptr, N, d, d, 0),
+                               prob_nt(a->memory, a->wmm, a->concat, a->bw, nullptr, N, d, d, 0)};
+    q[0].out2 = a->qv;
+    q[0].out2_col = a->w_ca;
+    MC_TRY(vnqa_sgemm_batch(q, 3, stream));
+  }
   MC_TRY(vnqa_mac_read_fwd(a->ctxw, nullptr, a->qv, nullptr, a->b_ca, a->p_c, a->cnew, N, a->lq, d, d, VNQA_F32, stream));
   if (a->mask_c != nullptr) MC_TRY(ew_mul(a->cnew, a->cnew, a->mask_c, nullptr, N * d, 0, 0, st));
-  MC_TRY(gemm_nt(a->memory, a->wm, a->mem, a->bm, nullptr, N, d, d, 0, a->workspace, stream));             // mem = memory Wm^T + bm
   MC_TRY(ew_mul(a->v, a->cnew, a->w_ra, nullptr, N * d, d, 0, st));                          // v = control' * w_ra
   MC_TRY(gemm_nn_mul(a->v, a->w1, a->t, a->u, a->mem, N, d, d, a->workspace, stream));                      // t = v W1; u = mem * t
   MC_TRY(vnqa_mac_read_fwd(a->know, a->pre, a->u, a->v, a->b_ra, a->p_r, a->read, N, a->s, d, a->ld, a->dtype, stream));
-  MC_TRY(gemm_nt(a->read, a->wr, a->concat, a->bw, nullptr, N, d, d, 0, a->workspace, stream));            // concat = read Wr^T + bw
-  MC_TRY(gemm_nt(a->memory, a->wmm, a->concat, nullptr, nullptr, N, d, d, 1, a->workspace, stream));       //        + memory Wmm^T
+  MC_TRY(gemm_nt(a->read, a->wr, a->concat, nullptr, nullptr, N, d, d, 1, a->workspace, stream));          // concat += read Wr^T
   return VNQA_OK;
 }
 
@@ -150,8 +168,10 @@ extern "C" int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream) {
   const int N = a->n, d = a->d;
   hipStream_t st = (hipStream_t)stream;
   // WriteUnit.concat
-  MC_TRY(gemm_nn(a->d_concat, a->wr, a->d_read, N, d, d, 0, a->workspace, stream));
-  MC_TRY(gemm_nn(a->d_concat, a->wmm, a->d_memory, N, d, d, 0, a->workspace, stream));
+  {
+    vnqa_sgemm_problem q[2] = {prob_nn(a->d_concat, a->wr, a->d_read, N, d, d, 0), prob_nn(a->d_concat, a->wmm, a->d_memory, N, d, d, 0)};
+    MC_TRY(vnqa_sgemm_batch(q, 2, stream));
+  }
   if (!defer) {
     MC_TRY(gemm_tn(a->d_concat, a->read, a->g_wr, d, d, N, 1, a->workspace, stream));
     MC_TRY(gemm_tn(a->d_concat, a->memory, a->g_wmm, d, d, N, 1, a->workspace, stream));
@@ -166,13 +186,15 @@ extern "C" int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream) {
                        (const float*)a->mem, N * d);
     VNQA_CHECK_LAUNCH();
   }
-  MC_TRY(gemm_nt(a->d_t, a->w1, a->dv, nullptr, nullptr, N, d, d, 1, a->workspace, stream));                // dv += d t W1^T
+  {                                                                  // dv += d t W1^T and d memory += d mem Wm in one launch
+    vnqa_sgemm_problem q[2] = {prob_nt(a->d_t, a->w1, a->dv, nullptr, nullptr, N, d, d, 1), prob_nn(a->d_mem, a->wm, a->d_memory, N, d, d, 1)};
+    MC_TRY(vnqa_sgemm_batch(q, 2, stream));
+  }
   if (!defer) {
     MC_TRY(gemm_tn(a->v, a->d_t, a->g_w1, d, d, N, 1, a->workspace, stream));
     MC_TRY(ew_mul(a->g_wra, a->dv, a->cnew, nullptr, N * d, 0, 1, st));                      // per-image w_ra gradient terms
   }
   MC_TRY(ew_mul(a->d_c, a->dv, a->w_ra, a->d_cnew, N * d, d, 0, st));                        // d control' = dv * w_ra (+ upstream)
-  MC_TRY(gemm_nn(a->d_mem, a->wm, a->d_memory, N, d, d, 1, a->workspace, stream));                          // d memory += d mem Wm
   if (!defer) {
     MC_TRY(gemm_tn(a->d_mem, a->memory, a->g_wm, d, d, N, 1, a->workspace, stream));
     MC_TRY(gemm_tn(a->d_mem, a->ones, a->g_bm, d, 1, N, 1, a->workspace, stream));

@@ -640,6 +640,20 @@ def lstm_wide_bwd(w_hh_t, batch_sizes, gates, cs, dhs, reverse=False, c0=None):
     return dgates
 
 
+def sgemm_batch(problems):
+    """vnqa_sgemm_batch: up to 4 independent fp32 products in one launch.  Each problem is a dict with tensors a, b, c and
+    optional bias / addend / out2 / out2_col / out2_mul, the element strides a_rs, a_cs, b_rs, b_cs and ldc, m, n, k, relu,
+    accumulate (the arguments of vnqa_sgemm / vnqa_sgemm2)."""
+    arr = (L.SgemmProblem * len(problems))()
+    for q, d in zip(arr, problems):
+        for n in ("a", "b", "c", "bias", "addend", "out2", "out2_col", "out2_mul"):
+            setattr(q, n, L.ptr(d.get(n)))
+        for n in ("a_rs", "a_cs", "b_rs", "b_cs", "ldc", "m", "n", "k"):
+            setattr(q, n, int(d[n]))
+        q.relu, q.accumulate = int(d.get("relu", 0)), int(d.get("accumulate", 0))
+    L.check(L.lib().vnqa_sgemm_batch(ctypes.cast(arr, ctypes.c_void_p), len(problems), L.stream()), "vnqa_sgemm_batch")
+
+
 def lstm_wide_bidir_fwd(xg_f, xg_r, w_hh_f, w_hh_r, batch_sizes):
     """Both directions of a bidirectional packed LSTM from zero states, one launch per chain position
     (vnqa_lstm_wide_bidir_fwd).  Returns ((hs_f, hs_r), (cs_f, cs_r), (gates_f, gates_r)); bit-identical to two

@@ -74,9 +74,10 @@ class MACNetwork(nn.Module):
     # model's trunk is a ~1 000-launch dependent chain of small kernels that otherwise queue behind stem workgroups owning a
     # whole CU's LDS, so stem (6.6 ms) and chain (11.3 ms) ran back to back.  With the chain on the Trainer's high-priority
     # stream AND half the chip to itself they overlap: `tools/ab_mac_reserve.sh`, same box — reserve 0: 413 clips/s, 96: 492,
-    # 128: 503-505, 160: 445, 192: 316 (the masked stem alone takes 13 ms at 128, the chain 11.3 + contention).  Without the
+    # 128: 503-505, 160: 445, 192: 316 (the masked stem alone takes 8.5 ms at 128, the chain 11.3 + contention).  Without the
     # high-priority trunk stream a reservation makes things worse (64 CUs: 275), which is what round 3 measured first.
-    stem_reserve_cus = 128
+    # With the chain 1.9 ms shorter (wide-LSTM rewrite, question directions sharing launches): 64: 542, 96: 574, 128: 561-564.
+    stem_reserve_cus = 96
 
     def __init__(self, n_vocab, dim, embed_hidden=300, max_step=12, self_attention=False, memory_gate=False,
                  classes=28, dropout=0.15, max_num_frames=35, *, precision='bf16'):
