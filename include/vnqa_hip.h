@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 306
+#define VNQA_ABI_VERSION 307
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -602,6 +602,20 @@ int vnqa_mac_read_fwd(const void* know, const void* pre, const float* u, const f
 int vnqa_mac_read_bwd(const void* know, const void* pre, const float* p, const float* dread, float* dscore,
                       float* du, float* dv, int32_t n, int32_t s, int32_t c, int32_t ld, int32_t dtype,
                       void* stream);
+/* The same two kernels with the elementwise steps that sit between them in a reasoning step folded in (models/mac.py:36-42
+ * with :57-58: control' = pool(...) [* dropout mask], v = control' * w_attn and their gradients):
+ *   _fwd_scaled : read = pool * out_mask (fp32 [n][c], or NULL);  out2 = read * out2_col[c] (fp32 [n][c] / [c]; both or neither)
+ *   _bwd_fused  : pro_x != NULL: dread is an OUTPUT first — dread = (pro_x * pro_col[c] + pro_add) * pro_mask, with
+ *                 pro_x / pro_add / pro_mask fp32 [n][c] (the latter two may be NULL), pro_col fp32 [c] — and then used as
+ *                 in vnqa_mac_read_bwd;  du2 = du * du2_col[c] (both or neither).
+ */
+int vnqa_mac_read_fwd_scaled(const void* know, const void* pre, const float* u, const float* v, const float* bias, float* p,
+                             float* read, const float* out_mask, float* out2, const float* out2_col, int32_t n, int32_t s,
+                             int32_t c, int32_t ld, int32_t dtype, void* stream);
+int vnqa_mac_read_bwd_fused(const void* know, const void* pre, const float* p, float* dread, const float* pro_x,
+                            const float* pro_col, const float* pro_add, const float* pro_mask, float* dscore, float* du,
+                            float* dv, float* du2, const float* du2_col, int32_t n, int32_t s, int32_t c, int32_t ld,
+                            int32_t dtype, void* stream);
 int vnqa_mac_read_accum(const float* dscore, const float* p, const float* u, const float* v,
                         const float* dread, void* dknow, void* dpre, int32_t k, int32_t n, int32_t s,
                         int32_t c, int32_t ld, int32_t dtype, void* stream);

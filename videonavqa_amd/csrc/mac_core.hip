@@ -1,7 +1,7 @@
 // mac_core.hip — one MAC reasoning step (ControlUnit, ReadUnit, WriteUnit.concat of the reference's models/mac.py:28-42,
 // 53-62,82-85, evaluated for all packed images at once) as ONE C-ABI call per direction.
 //
-// The step is 7 small launches forward and 9 backward (25 with per-step weight gradients) (fp32 GEMMs of [n_img, dim] x [dim, dim], the fused attention-pool
+// The step is 5 launches forward and 6 backward (plus 9 with per-step weight gradients) (fp32 GEMMs of [n_img, dim] x [dim, dim], the fused attention-pool
 // kernels of mac_read.hip, a few elementwise products).  Issued one by one from Python the 12 steps of a training pass cost the
 // launch thread more time than the GPU needs to run them (16.7 ms of host time against 13.8 ms of kernels per step of
 // `bench.py --model mac`); here the whole sequence is enqueued from C++.
@@ -137,7 +137,6 @@ extern "C" int vnqa_mac_core_fwd(const vnqa_mac_core* a, void* stream) {
   VNQA_CHECK_ARG(a->cq && a->qv && a->p_c && a->cnew && a->mem && a->v && a->t && a->u && a->p_r && a->read && a->concat,
                  "mac_core_fwd: null output");
   const int N = a->n, d = a->d;
-  hipStream_t st = (hipStream_t)stream;
   {
     // the three products that only need the step's inputs, in ONE launch: cq = pq + control Wc^T (and qv = cq * w_ca from
     // the same epilogue), mem = memory Wm^T + bm, concat = memory Wmm^T + bw (read Wr^T is added at the end)
@@ -148,9 +147,9 @@ extern "C" int vnqa_mac_core_fwd(const vnqa_mac_core* a, void* stream) {
     q[0].out2_col = a->w_ca;
     MC_TRY(vnqa_sgemm_batch(q, 3, stream));
   }
-  MC_TRY(vnqa_mac_read_fwd(a->ctxw, nullptr, a->qv, nullptr, a->b_ca, a->p_c, a->cnew, N, a->lq, d, d, VNQA_F32, stream));
-  if (a->mask_c != nullptr) MC_TRY(ew_mul(a->cnew, a->cnew, a->mask_c, nullptr, N * d, 0, 0, st));
-  MC_TRY(ew_mul(a->v, a->cnew, a->w_ra, nullptr, N * d, d, 0, st));                          // v = control' * w_ra
+  // control' = pool(ctx, qv) [* mask] and v = control' * w_ra from the pool kernel's epilogue
+  MC_TRY(vnqa_mac_read_fwd_scaled(a->ctxw, nullptr, a->qv, nullptr, a->b_ca, a->p_c, a->cnew, a->mask_c, a->v, a->w_ra, N, a->lq,
+                                  d, d, VNQA_F32, stream));
   MC_TRY(gemm_nn_mul(a->v, a->w1, a->t, a->u, a->mem, N, d, d, a->workspace, stream));                      // t = v W1; u = mem * t
   MC_TRY(vnqa_mac_read_fwd(a->know, a->pre, a->u, a->v, a->b_ra, a->p_r, a->read, N, a->s, d, a->ld, a->dtype, stream));
   MC_TRY(gemm_nt(a->read, a->wr, a->concat, nullptr, nullptr, N, d, d, 1, a->workspace, stream));          // concat += read Wr^T
@@ -194,15 +193,14 @@ extern "C" int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream) {
     MC_TRY(gemm_tn(a->v, a->d_t, a->g_w1, d, d, N, 1, a->workspace, stream));
     MC_TRY(ew_mul(a->g_wra, a->dv, a->cnew, nullptr, N * d, 0, 1, st));                      // per-image w_ra gradient terms
   }
-  MC_TRY(ew_mul(a->d_c, a->dv, a->w_ra, a->d_cnew, N * d, d, 0, st));                        // d control' = dv * w_ra (+ upstream)
   if (!defer) {
     MC_TRY(gemm_tn(a->d_mem, a->memory, a->g_wm, d, d, N, 1, a->workspace, stream));
     MC_TRY(gemm_tn(a->d_mem, a->ones, a->g_bm, d, 1, N, 1, a->workspace, stream));
   }
-  if (a->mask_c != nullptr) MC_TRY(ew_mul(a->d_c, a->d_c, a->mask_c, nullptr, N * d, 0, 0, st));
-  // ControlUnit attention
-  MC_TRY(vnqa_mac_read_bwd(a->ctxw, nullptr, a->p_c, a->d_c, a->ds_c, a->dqv, nullptr, N, a->lq, d, d, VNQA_F32, stream));
-  MC_TRY(ew_mul(a->d_cq, a->dqv, a->w_ca, nullptr, N * d, d, 0, st));                        // d cq = dqv * w_ca
+  // ControlUnit attention; its prologue forms d control' = (dv * w_ra + upstream) [* mask] (kept in d_c for the gradient
+  // factors), its epilogue d cq = dqv * w_ca
+  MC_TRY(vnqa_mac_read_bwd_fused(a->ctxw, nullptr, a->p_c, a->d_c, a->dv, a->w_ra, a->d_cnew, a->mask_c, a->ds_c, a->dqv, nullptr,
+                                 a->d_cq, a->w_ca, N, a->lq, d, d, VNQA_F32, stream));
   if (!defer) MC_TRY(ew_mul(a->g_wca, a->dqv, a->cq, nullptr, N * d, 0, 1, st));
   MC_TRY(gemm_nn(a->d_cq, a->wc, a->d_control, N, d, d, 0, a->workspace, stream));
   if (!defer) MC_TRY(gemm_tn(a->d_cq, a->control, a->g_wc, d, d, N, 1, a->workspace, stream));

@@ -22,7 +22,10 @@
 
 namespace {
 
-constexpr int NTH = 256, NWV = 4;
+// 16 waves per image: a wave has two 1-KiB row loads in flight per position, and one workgroup per image is all the
+// parallelism there is (280 images on 256 CUs) — with 4 waves the knowledge-base sweeps ran at 2.2 TB/s, bound by the
+// latency of their own loads
+constexpr int NTH = 1024, NWV = NTH / 64;
 constexpr int MAX_S = 1024;
 
 template <typename T> struct Row8;
@@ -65,14 +68,20 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float m = red[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) m = fmaxf(m, red[w]);
+  return m;
 }
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_reduce_sum(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return red[0] + red[1] + red[2] + red[3];
+  float t = red[0];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) t += red[w];
+  return t;
 }
 
 // t[s] = sum_c a[s][c] x[c] (+ b[s][c] y[c]) for every position s of image n -> LDS t[]
@@ -101,10 +110,13 @@ __device__ __forceinline__ void rows_dot(const T* a, const T* b, const float* x,
   }
 }
 
-// out[c] = sum_s w[s] a[s][c]: thread = (8-channel group cg = tid % 64, row phase tid / 64); partials over the 4 row
-// phases are summed through LDS (red8: [4][64][8] floats)
+// out[c] = sum_s w[s] a[s][c]: thread = (8-channel group cg = tid % 64, row phase tid / 64); partials over the NWV row
+// phases are summed in order through LDS (red8: [NWV][64][8] floats)
+// Optional epilogue: out = sum * omask[c] (omask per image, or null), out2[c] = out[c] * out2_col[c] (out2 null: none).
 template <typename T>
-__device__ __forceinline__ void weighted_colsum(const T* a, const float* w, int S, int C, int ld, float* red8, float* out) {
+__device__ __forceinline__ void weighted_colsum(const T* a, const float* w, int S, int C, int ld, float* red8, float* out,
+                                                const float* omask = nullptr, float* out2 = nullptr,
+                                                const float* out2_col = nullptr) {
   const int cg = threadIdx.x & 63, ph = threadIdx.x >> 6;
   for (int c0 = 0; c0 < C; c0 += 512) {
     const int c = c0 + cg * 8;
@@ -122,10 +134,18 @@ __device__ __forceinline__ void weighted_colsum(const T* a, const float* w, int 
 #pragma unroll
     for (int e = 0; e < 8; ++e) red8[(ph * 64 + cg) * 8 + e] = acc[e];
     __syncthreads();
-    if (ph == 0 && c < C) {
+    // 512 threads fold: thread (cg, e) sums element e of channel group cg over the phases
+    if (threadIdx.x < 512) {
+      const int g = threadIdx.x >> 3, e = threadIdx.x & 7;
+      if (c0 + g * 8 < C) {
+        float t = red8[g * 8 + e];
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        out[c + e] = red8[cg * 8 + e] + red8[(64 + cg) * 8 + e] + red8[(128 + cg) * 8 + e] + red8[(192 + cg) * 8 + e];
+        for (int w = 1; w < NWV; ++w) t += red8[(w * 64 + g) * 8 + e];
+        const int cc = c0 + g * 8 + e;
+        if (omask != nullptr) t *= omask[cc];
+        out[cc] = t;
+        if (out2 != nullptr) out2[cc] = t * out2_col[cc];
+      }
     }
   }
 }
@@ -134,7 +154,9 @@ template <typename T>
 __global__ void __launch_bounds__(NTH) mac_read_fwd_kernel(const T* __restrict__ kn, const T* __restrict__ pre,
                                                            const float* __restrict__ u, const float* __restrict__ v,
                                                            const float* __restrict__ bias, float* __restrict__ p,
-                                                           float* __restrict__ read, int S, int C, int ld) {
+                                                           float* __restrict__ read, const float* __restrict__ out_mask,
+                                                           float* __restrict__ out2, const float* __restrict__ out2_col,
+                                                           int S, int C, int ld) {
   __shared__ float sc[MAX_S];
   __shared__ float red[NWV];
   __shared__ float red8[NWV * 64 * 8];
@@ -163,19 +185,38 @@ __global__ void __launch_bounds__(NTH) mac_read_fwd_kernel(const T* __restrict__
     p[(size_t)n * S + s] = pr;
   }
   __syncthreads();
-  weighted_colsum<T>(a, sc, S, C, ld, red8, read + (size_t)n * C);
+  weighted_colsum<T>(a, sc, S, C, ld, red8, read + (size_t)n * C, out_mask ? out_mask + (size_t)n * C : nullptr,
+                     out2 ? out2 + (size_t)n * C : nullptr, out2_col);
 }
 
+// Optional prologue (pro_x != null): this image's dread row is first FORMED here and written out,
+//   dread[c] = (pro_x[c] * pro_col[c] + pro_add[c]) * pro_mask[c]        (pro_add / pro_mask per image, or null)
+// — the elementwise steps between two attention backward passes of a MAC reasoning step.  Optional epilogue: du2 = du * du2_col.
+// (dread is deliberately neither const nor restrict: it is written and then read through the same pointer.)
 template <typename T>
 __global__ void __launch_bounds__(NTH) mac_read_bwd_kernel(const T* __restrict__ kn, const T* __restrict__ pre,
-                                                           const float* __restrict__ p, const float* __restrict__ dread,
+                                                           const float* __restrict__ p, float* dread,
                                                            float* __restrict__ dscore, float* __restrict__ du,
-                                                           float* __restrict__ dv, int S, int C, int ld) {
+                                                           float* __restrict__ dv, const float* __restrict__ pro_x,
+                                                           const float* __restrict__ pro_col, const float* __restrict__ pro_add,
+                                                           const float* __restrict__ pro_mask, float* __restrict__ du2,
+                                                           const float* __restrict__ du2_col, int S, int C, int ld) {
   __shared__ float ds[MAX_S];
   __shared__ float red[NWV];
   __shared__ float red8[NWV * 64 * 8];
   const int n = blockIdx.x;
   const T* a = kn + (size_t)n * S * ld;
+  if (pro_x != nullptr) {
+    for (int c = threadIdx.x; c < C; c += NTH) {
+      const size_t i = (size_t)n * C + c;
+      float t = pro_x[i] * pro_col[c];
+      if (pro_add != nullptr) t += pro_add[i];
+      if (pro_mask != nullptr) t *= pro_mask[i];
+      dread[i] = t;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
   rows_dot<T, false>(a, nullptr, dread + (size_t)n * C, nullptr, S, C, ld, ds);      // dp[s]
   __syncthreads();
   float dot = 0.f;
@@ -187,7 +228,7 @@ __global__ void __launch_bounds__(NTH) mac_read_bwd_kernel(const T* __restrict__
     dscore[(size_t)n * S + s] = g;
   }
   __syncthreads();
-  weighted_colsum<T>(a, ds, S, C, ld, red8, du + (size_t)n * C);
+  weighted_colsum<T>(a, ds, S, C, ld, red8, du + (size_t)n * C, nullptr, du2 ? du2 + (size_t)n * C : nullptr, du2_col);
   if (pre != nullptr) weighted_colsum<T>(pre + (size_t)n * S * ld, ds, S, C, ld, red8, dv + (size_t)n * C);
 }
 
@@ -251,20 +292,49 @@ __global__ void __launch_bounds__(NTH) mac_read_accum_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int vnqa_mac_read_fwd(const void* know, const void* pre, const float* u, const float* v, const float* bias,
-                                 float* p, float* read, int32_t n, int32_t s, int32_t c, int32_t ld, int32_t dtype,
-                                 void* stream) {
+extern "C" int vnqa_mac_read_fwd_scaled(const void* know, const void* pre, const float* u, const float* v, const float* bias,
+                                        float* p, float* read, const float* out_mask, float* out2, const float* out2_col,
+                                        int32_t n, int32_t s, int32_t c, int32_t ld, int32_t dtype, void* stream) {
   VNQA_CHECK_ARG(know && u && p && read && (pre == nullptr) == (v == nullptr), "mac_read_fwd: null pointer (pre and v come together)");
+  VNQA_CHECK_ARG((out2 == nullptr) == (out2_col == nullptr), "mac_read_fwd: out2 and out2_col come together");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "mac_read_fwd: bad dtype %d", dtype);
   VNQA_CHECK_ARG(n > 0 && s > 0 && s <= MAX_S, "mac_read_fwd: positions per image must be in 1..%d (got %d)", MAX_S, s);
   VNQA_CHECK_ARG(c > 0 && c % 8 == 0 && ld >= c && ld % 8 == 0, "mac_read_fwd: c=%d ld=%d must be multiples of 8, ld>=c", c, ld);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == VNQA_BF16)
     hipLaunchKernelGGL(mac_read_fwd_kernel<vnqa_bf16>, dim3(n), dim3(NTH), 0, st, (const vnqa_bf16*)know,
-                       (const vnqa_bf16*)pre, u, v, bias, p, read, s, c, ld);
+                       (const vnqa_bf16*)pre, u, v, bias, p, read, out_mask, out2, out2_col, s, c, ld);
   else
     hipLaunchKernelGGL(mac_read_fwd_kernel<float>, dim3(n), dim3(NTH), 0, st, (const float*)know, (const float*)pre, u, v,
-                       bias, p, read, s, c, ld);
+                       bias, p, read, out_mask, out2, out2_col, s, c, ld);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_mac_read_fwd(const void* know, const void* pre, const float* u, const float* v, const float* bias,
+                                 float* p, float* read, int32_t n, int32_t s, int32_t c, int32_t ld, int32_t dtype,
+                                 void* stream) {
+  return vnqa_mac_read_fwd_scaled(know, pre, u, v, bias, p, read, nullptr, nullptr, nullptr, n, s, c, ld, dtype, stream);
+}
+
+extern "C" int vnqa_mac_read_bwd_fused(const void* know, const void* pre, const float* p, float* dread, const float* pro_x,
+                                       const float* pro_col, const float* pro_add, const float* pro_mask, float* dscore,
+                                       float* du, float* dv, float* du2, const float* du2_col, int32_t n, int32_t s, int32_t c,
+                                       int32_t ld, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(know && p && dread && dscore && du && (pre == nullptr) == (dv == nullptr), "mac_read_bwd: null pointer (pre and dv come together)");
+  VNQA_CHECK_ARG((pro_x == nullptr) == (pro_col == nullptr) && (pro_x != nullptr || (pro_add == nullptr && pro_mask == nullptr)),
+                 "mac_read_bwd: prologue needs pro_x and pro_col");
+  VNQA_CHECK_ARG((du2 == nullptr) == (du2_col == nullptr), "mac_read_bwd: du2 and du2_col come together");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "mac_read_bwd: bad dtype %d", dtype);
+  VNQA_CHECK_ARG(n > 0 && s > 0 && s <= MAX_S, "mac_read_bwd: positions per image must be in 1..%d (got %d)", MAX_S, s);
+  VNQA_CHECK_ARG(c > 0 && c % 8 == 0 && ld >= c && ld % 8 == 0, "mac_read_bwd: c=%d ld=%d must be multiples of 8, ld>=c", c, ld);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == VNQA_BF16)
+    hipLaunchKernelGGL(mac_read_bwd_kernel<vnqa_bf16>, dim3(n), dim3(NTH), 0, st, (const vnqa_bf16*)know,
+                       (const vnqa_bf16*)pre, p, dread, dscore, du, dv, pro_x, pro_col, pro_add, pro_mask, du2, du2_col, s, c, ld);
+  else
+    hipLaunchKernelGGL(mac_read_bwd_kernel<float>, dim3(n), dim3(NTH), 0, st, (const float*)know, (const float*)pre, p,
+                       dread, dscore, du, dv, pro_x, pro_col, pro_add, pro_mask, du2, du2_col, s, c, ld);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
@@ -272,19 +342,8 @@ extern "C" int vnqa_mac_read_fwd(const void* know, const void* pre, const float*
 extern "C" int vnqa_mac_read_bwd(const void* know, const void* pre, const float* p, const float* dread, float* dscore,
                                  float* du, float* dv, int32_t n, int32_t s, int32_t c, int32_t ld, int32_t dtype,
                                  void* stream) {
-  VNQA_CHECK_ARG(know && p && dread && dscore && du && (pre == nullptr) == (dv == nullptr), "mac_read_bwd: null pointer (pre and dv come together)");
-  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "mac_read_bwd: bad dtype %d", dtype);
-  VNQA_CHECK_ARG(n > 0 && s > 0 && s <= MAX_S, "mac_read_bwd: positions per image must be in 1..%d (got %d)", MAX_S, s);
-  VNQA_CHECK_ARG(c > 0 && c % 8 == 0 && ld >= c && ld % 8 == 0, "mac_read_bwd: c=%d ld=%d must be multiples of 8, ld>=c", c, ld);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == VNQA_BF16)
-    hipLaunchKernelGGL(mac_read_bwd_kernel<vnqa_bf16>, dim3(n), dim3(NTH), 0, st, (const vnqa_bf16*)know,
-                       (const vnqa_bf16*)pre, p, dread, dscore, du, dv, s, c, ld);
-  else
-    hipLaunchKernelGGL(mac_read_bwd_kernel<float>, dim3(n), dim3(NTH), 0, st, (const float*)know, (const float*)pre, p,
-                       dread, dscore, du, dv, s, c, ld);
-  VNQA_CHECK_LAUNCH();
-  return VNQA_OK;
+  return vnqa_mac_read_bwd_fused(know, pre, p, const_cast<float*>(dread), nullptr, nullptr, nullptr, nullptr, dscore, du, dv,
+                                 nullptr, nullptr, n, s, c, ld, dtype, stream);
 }
 
 extern "C" int vnqa_mac_read_accum(const float* dscore, const float* p, const float* u, const float* v,
