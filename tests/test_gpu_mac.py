@@ -93,6 +93,44 @@ def test_lstm_wide_bidir_is_two_single_direction_calls(B, H, lens):
     assert float(a_f.abs().sum()) > 0 and float(xg[1].grad.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(5, 14, 14, 64, 256), (3, 10, 12, 64, 128), (2, 28, 28, 128, 512)])
+def test_conv_elu_epilogue_matches_elu_after_conv(n, h, w, cin, cout):
+    """ops.conv(relu=2): ELU in the conv epilogue (igemm and patch-stationary tiles) vs F.elu applied to the plain conv's
+    output, forward and all gradients, and vs an fp32 torch reference of conv -> ELU."""
+    from videonavqa_amd import ops
+    from helpers import LOW_DTYPE
+    dev = torch.device("cuda")
+    torch.manual_seed(n + h + cout)
+    x = torch.zeros(n, h + 2, w + 2, cin, device=dev)
+    x[:, 1:-1, 1:-1] = torch.randn(n, h, w, cin, device=dev)
+    wgt = (torch.randn(cout, cin, 3, 3, device=dev) / (9 * cin) ** 0.5 * 1.5)
+    b = torch.randn(cout, device=dev) * 0.2
+    g = torch.zeros(n, h + 2, w + 2, cout, device=dev)
+    g[:, 1:-1, 1:-1] = torch.randn(n, h, w, cout, device=dev)
+    outs = []
+    for fused in (True, False):
+        xx = x.to(LOW_DTYPE).requires_grad_(True)
+        ww, bb = wgt.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.conv(xx, ww, bb, relu=2) if fused else torch.nn.functional.elu(ops.conv(xx, ww, bb, relu=False))
+        y.backward(g.to(LOW_DTYPE))
+        outs.append((y.detach().float(), xx.grad.float(), ww.grad, bb.grad))
+    xr = x[:, 1:-1, 1:-1].permute(0, 3, 1, 2).to(LOW_DTYPE).float().requires_grad_(True)
+    wr, br = wgt.to(LOW_DTYPE).float().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.elu(torch.nn.functional.conv2d(xr, wr, br, padding=1))
+    yr.backward(g[:, 1:-1, 1:-1].permute(0, 3, 1, 2).to(LOW_DTYPE).float())
+    y_f, dx_f, dw_f, db_f = outs[0]
+    assert float(y_f[:, 0].abs().max()) == 0 and float(y_f[:, :, -1].abs().max()) == 0          # halo stays zero
+    assert float((y_f < 0).float().mean()) > 0.2                                                  # the negative branch is exercised
+    ref = yr.detach().permute(0, 2, 3, 1)
+    assert rel_err(y_f[:, 1:-1, 1:-1].cpu().numpy(), ref.cpu().numpy()) < 6e-3
+    assert rel_err(outs[1][0][:, 1:-1, 1:-1].cpu().numpy(), ref.cpu().numpy()) < 8e-3          # the two-rounding form it replaces
+    assert rel_err(dx_f[:, 1:-1, 1:-1].cpu().numpy(), xr.grad.permute(0, 2, 3, 1).cpu().numpy()) < 1.5e-2
+    assert rel_err(dw_f.cpu().numpy(), wr.grad.cpu().numpy()) < 1.5e-2
+    assert rel_err(db_f.cpu().numpy(), br.grad.cpu().numpy()) < 1.5e-2
+    for a, c in zip(outs[0][1:], outs[1][1:]):
+        assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1.5e-2
+
+
 def test_lstm_wide_rejects_bad_batch_sizes():
     from videonavqa_amd import kernels as K
     from videonavqa_amd._lib import VnqaError

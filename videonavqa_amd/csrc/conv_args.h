@@ -2,6 +2,14 @@
 #pragma once
 #include "vnqa_common.h"
 
+// activation of the plain epilogue (vnqa_conv_desc.relu): 0 none, 1 ReLU, 2 ELU(alpha = 1) — only conv_igemm_kernel and
+// conv_ps_kernel implement 2 (the entry points of the other kernels reject it); internal experiment bits >= 256 mean ReLU
+#define VNQA_ACT_ELU 2
+__device__ __forceinline__ float vnqa_conv_act(float v, int mode) {
+  if (mode == VNQA_ACT_ELU) return v > 0.f ? v : expm1f(v);
+  return mode ? fmaxf(v, 0.f) : v;
+}
+
 struct ConvArgs {
   const char* x;
   const char* wt;

@@ -785,6 +785,7 @@ int c64_fill(const vnqa_conv_desc* d, const void* x, const void* wt, const float
   a.Wp = d->w + 2;
   a.Cout = d->c_out;
   a.Cy = d->c_y;
+  VNQA_CHECK_ARG(d->relu == 0 || d->relu == 1, "conv (direct kernels): relu must be 0 or 1 (the ELU epilogue lives on the implicit-GEMM tiles)");
   a.relu = d->relu;
   a.pool = d->pool2;
   a.tilesX = (d->w + TS - 1) / TS;

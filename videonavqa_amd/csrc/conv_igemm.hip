@@ -672,8 +672,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = acc[i][j][4 * g + e] + bias_r[j][g][e] - sub[j][g][e];
-          if (p.relu) v[e] = fmaxf(v[e], 0.f);
+          v[e] = vnqa_conv_act(acc[i][j][4 * g + e] + bias_r[j][g][e] - sub[j][g][e], p.relu);
         }
         char* dst = smem + prow * CROW + col * ES;
         if constexpr (ES == 2) {
@@ -942,6 +941,10 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_STEM_I5_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, 1, 5>(a, st);
       case VNQA_TILE_PATCH_224x256:
       case VNQA_TILE_STEM_PATCH_224x256:
+        if (a.relu == VNQA_ACT_ELU) {
+          vnqa_set_error("conv2d_igemm_fwd: the ELU epilogue is not available on the 224-pixel patch tiles");
+          return VNQA_ERR_UNSUPPORTED;
+        }
         if (a.zero_halo) {
           vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_ZERO_HALO is not available on the 224-pixel patch tiles");
           return VNQA_ERR_UNSUPPORTED;
@@ -1242,6 +1245,8 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
   a.x_halo = d->x_halo;
   a.y_halo = d->y_halo;
   a.relu = d->relu;
+  VNQA_CHECK_ARG(d->relu >= 0 && d->relu <= 2 && (d->relu != VNQA_ACT_ELU || !d->pool2),
+                 "conv2d_igemm_fwd: relu must be 0 (none), 1 (ReLU) or 2 (ELU; not with pooling)");
   VNQA_CHECK_ARG(!(d->flags & VNQA_CONV_ZERO_HALO) || (d->y_halo == 1 && d->depth == 0),
                  "conv2d_igemm_fwd: VNQA_CONV_ZERO_HALO needs a 2-D conv with y_halo == 1");
   a.zero_halo = (d->flags & VNQA_CONV_ZERO_HALO) ? 1 : 0;

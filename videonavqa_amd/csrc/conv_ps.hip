@@ -292,8 +292,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = acc[i][j][e] + b4[e] - sub[e];
-        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        v[e] = vnqa_conv_act(acc[i][j][e] + b4[e] - sub[e], p.relu);
       }
       uint2 pk;
       pk.x = pack2_h16(v[0], v[1]);

@@ -457,6 +457,7 @@ extern "C" int vnqa_conv2d_wreg_fwd(const vnqa_conv_desc* d, const void* x, cons
   a.Hp = d->h + 2;
   a.Wp = d->w + 2;
   a.Cy = d->c_y;
+  VNQA_CHECK_ARG(d->relu == 0 || d->relu == 1, "conv (direct kernels): relu must be 0 or 1 (the ELU epilogue lives on the implicit-GEMM tiles)");
   a.relu = d->relu;
   const int ho = d->pool2 ? d->h / 2 : d->h, wo = d->pool2 ? d->w / 2 : d->w;
   a.y_halo = d->y_halo;

@@ -18,6 +18,7 @@ how the work is laid out for the MI355X:
   * both nn.LSTMs (bidirectional question encoder, 3*dim tail) run on the step-wise wide-LSTM HIP
     kernels (ops.lstm_wide) directly on PackedSequence batch sizes.
 """
+import os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -160,7 +161,10 @@ class MACNetwork(nn.Module):
     def _knowledge(self, x):
         """conv -> ELU three times (mac.py:174-179,236); returns the dense interior [n_img*S, c_pad]."""
         for k in (0, 2, 4):
-            x = F.elu(ops.conv(x, self.conv[k].weight, self.conv[k].bias, relu=False))   # elu(0)=0 keeps the halo
+            if os.environ.get("VNQA_MAC_ELU_FUSED", "1") == "0":
+                x = F.elu(ops.conv(x, self.conv[k].weight, self.conv[k].bias, relu=False))
+                continue
+            x = ops.conv(x, self.conv[k].weight, self.conv[k].bias, relu=2)     # ELU in the conv epilogue; elu(0)=0 keeps the halo
         n_img, hp, wp, c_pad = x.shape
         return x[:, 1:-1, 1:-1, :].reshape(n_img * (hp - 2) * (wp - 2), c_pad), n_img, (hp - 2) * (wp - 2), c_pad
 

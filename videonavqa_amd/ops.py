@@ -63,9 +63,18 @@ def _ret(sink, value):
     return None
 
 
+def _ps_plain_tile(x, k, c_out_pad):
+    """The patch-stationary kernel for a plain 3x3 conv (or its dgrad) on 14 / 28 wide maps with 256-multiple output channels
+    (MACNetwork's conv stack: 219-224 us against 257 on the 256 x 256 igemm tile), else the library's own choice."""
+    if os.environ.get("VNQA_PLAIN_PS", "0") != "1":
+        return L.TILE_AUTO
+    return K.ps_fused_tile(x) if k == 3 and c_out_pad % 256 == 0 else L.TILE_AUTO
+
+
 class ConvFn(torch.autograd.Function):
-    """y = [relu](conv2d(x, weight) + bias), 3x3 pad 1 or 1x1; weight/bias are the reference-layout
-    fp32 parameters (OIHW).  Backward: dgrad = the same igemm on flipped weights, wgrad = MFMA
+    """y = act(conv2d(x, weight) + bias), 3x3 pad 1 or 1x1; weight/bias are the reference-layout
+    fp32 parameters (OIHW).  relu: False / True, or 2 = ELU in the conv's epilogue (MACNetwork, models/mac.py:174-179;
+    computed on the fp32 accumulator, rounded once).  Backward: dgrad = the same igemm on flipped weights, wgrad = MFMA
     split-K kernel.  Replaces nn.Conv2d at models/film_attn_pt_stem.py:211,219,224."""
 
     @staticmethod
@@ -76,10 +85,11 @@ class ConvFn(torch.autograd.Function):
         c_in_pad = x.shape[-1]
         c_out_pad = L.round_up(c_out, 64)
         wt = K.pack_conv_weight(weight, cdt, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
-        y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu)
-        ctx.relu = relu and mask_in_backward   # False: the consumer's backward applies the ReLU mask
+        y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu, tile=_ps_plain_tile(x, k, c_out_pad))
+        ctx.elu = relu is not True and relu == 2
+        ctx.relu = bool(relu) and not ctx.elu and mask_in_backward   # False: the consumer's backward applies the ReLU mask
         ctx.dims = (c_out, c_in, k, c_out_pad, c_in_pad)
-        ctx.save_for_backward(x, weight, y if ctx.relu else None)
+        ctx.save_for_backward(x, weight, y if (ctx.relu or ctx.elu) else None)
         return y
 
     @staticmethod
@@ -89,6 +99,8 @@ class ConvFn(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.relu:
             dy = K.relu_bwd(dy, y)
+        elif ctx.elu:                          # d/dv elu(v) from the result: 1 where y > 0, else y + 1
+            dy = torch.ops.aten.elu_backward(dy, 1.0, 1.0, 1.0, True, y)
         dx = dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             inv = 1.0 / ctx.grad_scale
@@ -97,7 +109,7 @@ class ConvFn(torch.autograd.Function):
             db = dbias[:c_out].clone() if inv == 1.0 else dbias[:c_out] * inv
         if ctx.needs_input_grad[0]:
             wt_d = K.pack_conv_weight(weight, dy.dtype, transpose_flip=True, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
-            dx = K.conv2d_igemm(dy, wt_d)
+            dx = K.conv2d_igemm(dy, wt_d, tile=_ps_plain_tile(dy, k, c_in_pad))
         return dx, dw, db, None, None, None
 
 
