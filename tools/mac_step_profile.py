@@ -51,7 +51,7 @@ def main():
             pr = cProfile.Profile(); pr.enable()
             for i in range(3): step(i)
             pr.disable(); torch.cuda.synchronize()
-            pstats.Stats(pr).sort_stats("tottime").print_stats(8)
+            pstats.Stats(pr).sort_stats("tottime").print_stats(28)
 
 if __name__ == "__main__":
     main()
