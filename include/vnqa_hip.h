@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 308
+#define VNQA_ABI_VERSION 309
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -653,6 +653,23 @@ typedef struct vnqa_mac_core {
 int64_t vnqa_mac_core_workspace(int32_t n, int32_t d);
 int vnqa_mac_core_fwd(const vnqa_mac_core* a, void* stream);
 int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream);
+
+/* All `n_steps` reasoning steps in one call per direction, for MACNetwork without self-attention and memory gate (the reference's
+ * defaults, models/mac.py:131-155 with :86-105 skipped):
+ *     step i: (control_i, memory_i) -> vnqa_mac_core_fwd -> (cnew_i, concat_i);  control_{i+1} = cnew_i;
+ *             memory_{i+1} = concat_i * mask_m       (mask_m fp32 [n][d], the memory dropout mask of :125-129, or NULL)
+ * `step0` describes step 0 as for vnqa_mac_core_fwd / _bwd; every per-step buffer of step i lies i * (step 0's rows) further on —
+ * [n][d] buffers i*n*d floats, p_c / ds_c i*n*lq, p_r / ds_r i*n*s, pq i*n*d: the caller's STEP-STACKED slabs, which are what
+ * vnqa_mac_core_wgrad and vnqa_mac_read_accum take afterwards.  step0->memory is not read: memory_i = memories[i],
+ *   memories : fp32 [n_steps + 1][n][d], memories[0] = the initial memory (in), memories[i + 1] written by step i; memories[n_steps]
+ *              is the result.  control_0 = step0->control; control_i = cnew of step i - 1.
+ * backward (defer_wgrad must be set): d_memory_out fp32 [n][d] = gradient on memories[n_steps];
+ *   d_concat : fp32 [n_steps][n][d] out (d_concat_i = d memory_{i+1} * mask_m: a factor of vnqa_mac_core_wgrad);
+ *   step0->d_control / d_memory slabs [n_steps][n][d]: entry 0 = the gradients on the initial control / memory.
+ * step0->d_concat / d_cnew are ignored.  Results are bit-identical to n_steps vnqa_mac_core calls with the elementwise products between. */
+int vnqa_mac_chain_fwd(const vnqa_mac_core* step0, int32_t n_steps, float* memories, const float* mask_m, void* stream);
+int vnqa_mac_chain_bwd(const vnqa_mac_core* step0, int32_t n_steps, const float* memories, const float* mask_m,
+                       const float* d_memory_out, float* d_concat, void* stream);
 
 /* Parameter gradients of all reasoning steps in one call (the deferred form of vnqa_mac_core_bwd's g_* accumulation; same
  * reference lines, mac.py:28-42,53-62,82-85).  Every factor is the per-step [n][d] fp32 matrix stacked over the steps to

@@ -9,11 +9,12 @@ from helpers import MAC_CASES, mac_case, rel_err, LOW, LOW_DTYPE
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["rocblas_step", "cabi_step"])
+@pytest.fixture(autouse=True, params=["rocblas_step", "cabi_step", "cabi_chain"])
 def mac_core_impl(request, monkeypatch):
-    """Every MAC test runs with both forms of the reasoning step: the op-by-op node (default) and the one-call-per-direction
-    C-ABI form (vnqa_mac_core_fwd / _bwd, VNQA_MAC_CORE_CABI=1)."""
-    monkeypatch.setenv("VNQA_MAC_CORE_CABI", "1" if request.param == "cabi_step" else "0")
+    """Every MAC test runs with all three forms of the reasoning steps: the op-by-op node on torch / rocBLAS GEMMs, one C-ABI
+    node per step (vnqa_mac_core_fwd / _bwd) and — the default — all steps as one node (vnqa_mac_chain_fwd / _bwd)."""
+    monkeypatch.setenv("VNQA_MAC_CORE_CABI", "0" if request.param == "rocblas_step" else "1")
+    monkeypatch.setenv("VNQA_MAC_CHAIN", "1" if request.param == "cabi_chain" else "0")
     return request.param
 
 
@@ -188,6 +189,27 @@ def test_mac_train_forward_backward_fp32(case, tag):
         assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max() + 2e-6, (k, np.abs(got - ref).max(), np.abs(ref).max())
         checked += 1
     assert checked >= 30
+
+
+@pytest.mark.parametrize("case", MAC_CASES)
+def test_mac_chain_node_is_the_per_step_nodes(case, mac_core_impl, monkeypatch):
+    """All steps as one autograd node (ops.MacChainFn) vs one node per step (ops.MacCoreFn): logits and every parameter gradient
+    bit-identical — the same kernels in the same order, only the loop over steps moved into C++."""
+    if mac_core_impl != "cabi_chain":
+        pytest.skip("one comparison is enough")
+    res = []
+    for chain in ("1", "0"):
+        monkeypatch.setenv("VNQA_MAC_CHAIN", chain)
+        model, g, (v, q, vl, ql, y), masks = _product(case, LOW)
+        model.train()
+        model.dropout_masks = (torch.cat([m[0] for m in masks]).cuda(), torch.cat([m[1] for m in masks]).cuda())
+        logits = model(v, q, vl, ql)
+        nn.functional.cross_entropy(logits, y, reduction="sum").backward()
+        res.append((logits.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) >= 30
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
 @pytest.mark.parametrize("case", MAC_CASES)

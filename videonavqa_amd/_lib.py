@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 308          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 309          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -158,6 +158,8 @@ _SIGNATURES = {
     "vnqa_c3d_conv1_bwd": (ctypes.c_int, [_vp] * 9 + [_f32] + [_vp] * 4 + [_i32] * 4 + [_vp]),
     "vnqa_sgemm2": (ctypes.c_int, [_vp] * 4 + [_i64] * 4 + [_i32] * 4 + [_vp] * 6),
     "vnqa_sgemm_batch": (ctypes.c_int, [_vp, _i32, _vp]),
+    "vnqa_mac_chain_fwd": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp]),
+    "vnqa_mac_chain_bwd": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_mac_core_wgrad_workspace": (_i64, [_i32, _i32]),
     "vnqa_mac_core_wgrad": (ctypes.c_int, [_vp, _vp]),
     "vnqa_colsum": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

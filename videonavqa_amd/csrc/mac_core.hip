@@ -207,6 +207,75 @@ extern "C" int vnqa_mac_core_bwd(const vnqa_mac_core* a, void* stream) {
   return VNQA_OK;
 }
 
+// ---- all reasoning steps in one call per direction (no self-attention, no memory gate: the reference's defaults) ----------------
+// With the step a single launch sequence, what is left of a training pass's cost is the HOST: 24 autograd-node invocations of
+// ~90 us of Python each plus the ATen launches between them (mask multiplies, gradient sums) — the chain ran at the speed of
+// the launch thread (the same trunk on a quarter of the frames took as long).  Here the loop over steps is in C++.
+namespace {
+
+// o = x * y, or a copy when y == null
+__global__ void mul_or_copy_kernel(float* __restrict__ o, const float* __restrict__ x, const float* __restrict__ y, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) o[i] = y != nullptr ? x[i] * y[i] : x[i];
+}
+void mul_or_copy(float* o, const float* x, const float* y, int n, hipStream_t st) {
+  int g = (n + 255) / 256;
+  g = g > 1024 ? 1024 : g;
+  hipLaunchKernelGGL(mul_or_copy_kernel, dim3(g), dim3(256), 0, st, o, x, y, n);
+}
+
+// step i's argument block: every per-step buffer sits i * (rows of step 0) further on in the caller's step-stacked slabs
+vnqa_mac_core step_args(const vnqa_mac_core* a0, int i, const float* memories) {
+  vnqa_mac_core a = *a0;
+  const size_t nd = (size_t)a.n * a.d, nl = (size_t)a.n * a.lq, ns = (size_t)a.n * a.s;
+  auto at = [&](float* p, size_t per) { return p ? p + i * per : nullptr; };
+  a.control = i == 0 ? a0->control : a0->cnew + (size_t)(i - 1) * nd;
+  a.memory = memories + (size_t)i * nd;
+  a.pq = a0->pq + i * nd;
+  a.cq = at(a0->cq, nd); a.qv = at(a0->qv, nd); a.p_c = at(a0->p_c, nl); a.cnew = at(a0->cnew, nd); a.mem = at(a0->mem, nd);
+  a.v = at(a0->v, nd); a.t = at(a0->t, nd); a.u = at(a0->u, nd); a.p_r = at(a0->p_r, ns); a.read = at(a0->read, nd);
+  a.concat = at(a0->concat, nd);
+  a.d_control = at(a0->d_control, nd); a.d_memory = at(a0->d_memory, nd); a.d_cq = at(a0->d_cq, nd);
+  a.ds_r = at(a0->ds_r, ns); a.d_read = at(a0->d_read, nd); a.ds_c = at(a0->ds_c, nl); a.d_c = at(a0->d_c, nd);
+  a.du = at(a0->du, nd); a.dv = at(a0->dv, nd); a.dqv = at(a0->dqv, nd); a.d_mem = at(a0->d_mem, nd); a.d_t = at(a0->d_t, nd);
+  return a;
+}
+
+}  // namespace
+
+extern "C" int vnqa_mac_chain_fwd(const vnqa_mac_core* step0, int32_t n_steps, float* memories, const float* mask_m, void* stream) {
+  VNQA_CHECK_ARG(step0 != nullptr && n_steps > 0 && memories != nullptr, "mac_chain_fwd: null argument / no steps");
+  VNQA_CHECK_ARG(step0->pq && step0->cnew && step0->concat, "mac_chain_fwd: null slab");
+  const size_t nd = (size_t)step0->n * step0->d;
+  for (int i = 0; i < n_steps; ++i) {
+    const vnqa_mac_core a = step_args(step0, i, memories);
+    MC_TRY(vnqa_mac_core_fwd(&a, stream));
+    mul_or_copy(memories + (size_t)(i + 1) * nd, a.concat, mask_m, (int)nd, (hipStream_t)stream);      // memory_{i+1} = concat_i [* mask]
+  }
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_mac_chain_bwd(const vnqa_mac_core* step0, int32_t n_steps, const float* memories, const float* mask_m,
+                                  const float* d_memory_out, float* d_concat, void* stream) {
+  VNQA_CHECK_ARG(step0 != nullptr && n_steps > 0 && memories != nullptr && d_memory_out != nullptr && d_concat != nullptr,
+                 "mac_chain_bwd: null argument / no steps");
+  VNQA_CHECK_ARG(step0->defer_wgrad != 0, "mac_chain_bwd: parameter gradients come from vnqa_mac_core_wgrad (defer_wgrad = 1)");
+  VNQA_CHECK_ARG(step0->d_control && step0->d_memory, "mac_chain_bwd: null slab");
+  const size_t nd = (size_t)step0->n * step0->d;
+  for (int i = n_steps - 1; i >= 0; --i) {
+    vnqa_mac_core a = step_args(step0, i, memories);
+    const bool last = i == n_steps - 1;
+    float* dc = d_concat + (size_t)i * nd;
+    // the step's concat fed memory_{i+1} = concat [* mask] only; its control' fed step i+1's control only
+    mul_or_copy(dc, last ? d_memory_out : step0->d_memory + (size_t)(i + 1) * nd, mask_m, (int)nd, (hipStream_t)stream);
+    a.d_concat = dc;
+    a.d_cnew = last ? nullptr : step0->d_control + (size_t)(i + 1) * nd;
+    MC_TRY(vnqa_mac_core_bwd(&a, stream));
+  }
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
 // Parameter gradients of ALL reasoning steps at once: every factor is the per-step [n][d] matrices stacked to [rows = steps * n][d]
 // (the caller keeps them step-major in one slab), so each weight gradient is ONE product over K = rows instead of `steps`
 // accumulating products on the backward pass's dependent chain (12 steps x 9 launches off that chain).

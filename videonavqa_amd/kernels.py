@@ -995,6 +995,19 @@ def mac_core_call(direction, dims, tensors, defer_wgrad=False):
     L.check(fn(ctypes.byref(a), L.stream()), "vnqa_mac_core_" + direction)
 
 
+def mac_chain_call(direction, dims, n_steps, tensors, memories, mask_m, d_memory_out=None, d_concat=None):
+    """vnqa_mac_chain_fwd / _bwd: `tensors` describe STEP 0 (views of the step-stacked slabs), see include/vnqa_hip.h."""
+    a = L.MacCore(*dims)
+    for name, t in tensors.items():
+        setattr(a, name, None if t is None else t.data_ptr())
+    a.defer_wgrad = 1
+    if direction == "fwd":
+        L.check(L.lib().vnqa_mac_chain_fwd(ctypes.byref(a), n_steps, L.ptr(memories), L.ptr(mask_m), L.stream()), "vnqa_mac_chain_fwd")
+    else:
+        L.check(L.lib().vnqa_mac_chain_bwd(ctypes.byref(a), n_steps, L.ptr(memories), L.ptr(mask_m), L.ptr(d_memory_out),
+                                           L.ptr(d_concat), L.stream()), "vnqa_mac_chain_bwd")
+
+
 # ---- csrc/cnn3d.hip: VideoOnlyCNN3D's first conv, BatchNorm over channel-last rows, MaxPool3d(4,4,4) ------------------------
 def view_padded_ndhwc(D, H, W, C):
     """element (n, d, h, w, c) of a padded NDHWC tensor [N, D+2, H+2, W+2, C] (interior only)"""

@@ -203,6 +203,13 @@ class MACNetwork(nn.Module):
         memory = m.mem_0.expand(n_img, dim)
         if masks is not None:
             control, memory = control * masks[0], memory * masks[1]
+        if (not self.self_attention and not self.memory_gate and os.environ.get("VNQA_MAC_CHAIN", "1") != "0"
+                and os.environ.get("VNQA_MAC_CORE_TORCH", "0") != "1" and os.environ.get("VNQA_MAC_CORE_CABI", "1") != "0"):
+            # the reference's default configuration: all steps as ONE autograd node (ops.MacChainFn), the loop over steps in C++
+            return ops.mac_chain(control.contiguous(), memory.contiguous(), pq_all, ctx, kd, pre,
+                                 None if masks is None else masks[0], None if masks is None else masks[1], wc,
+                                 m.control.attn.weight, m.control.attn.bias, m.read.mem.weight, m.read.mem.bias, w1,
+                                 m.read.attn.weight, m.read.attn.bias, wr, wmm, m.write.concat.bias, Lq, S)
         controls, memories = [control], [memory]
         for i in range(self.max_step):
             # ControlUnit + ReadUnit + WriteUnit.concat as ONE autograd node (ops.MacCoreFn)

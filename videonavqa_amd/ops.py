@@ -980,6 +980,81 @@ class MacCoreFn(torch.autograd.Function):
                 gp[5], gp[6], gp[7], gp[8], gp[9], gp[10], None, None, None, None)
 
 
+class MacChainFn(torch.autograd.Function):
+    """ALL reasoning steps of MACNetwork without self-attention / memory gate (the reference's defaults, models/mac.py:131-155)
+    as ONE autograd node: forward and backward are one C-ABI call each (vnqa_mac_chain_fwd / _bwd loop over the steps in C++,
+    csrc/mac_core.hip), then vnqa_mac_read_accum x 2 and vnqa_mac_core_wgrad over the step-stacked slabs as in MacCoreFn.
+    With the step itself down to 5 + 6 launches the per-step nodes had become host-bound — 24 node invocations of ~90 us of
+    Python each, the mask multiplies and gradient sums between them; this node is bit-identical to that chain.
+
+      memory_{i+1} = concat_i * mask_m,  control_{i+1} = control'_i;   returns memory_{n_steps}."""
+
+    @staticmethod
+    def forward(ctx_, control, memory, pq_all, ctxw, know, pre, mask_c, mask_m, wc, w_ca, b_ca, wm, bm, w1, w_ra, b_ra, wr, wmm, bw,
+                Lq, S):
+        N, d = control.shape
+        n_steps = pq_all.shape[0]
+        dev = control.device
+        f32 = lambda t: None if t is None else t.detach().float().contiguous()
+        F_ = MacCoreFn._slab(MacCoreFn.FWD + ("p_c", "p_r"), [d] * 9 + [Lq, S], n_steps, N, dev)
+        # control_i = entry i of `ctl` (entry 0 = the initial control, control'_i written to entry i + 1); likewise the memories
+        ctl = torch.empty((n_steps + 1, N, d), dtype=torch.float32, device=dev)
+        mems = torch.empty((n_steps + 1, N, d), dtype=torch.float32, device=dev)
+        ctl[0].copy_(control)
+        mems[0].copy_(memory)
+        F_["cnew"] = ctl[1:]
+        nb = L.lib().vnqa_mac_core_workspace(N, d)
+        ws = K.workspace(nb, dev) if nb > 0 else None
+        par = dict(ctxw=ctxw, know=know, pre=pre, mask_c=f32(mask_c), wc=f32(wc), w_ca=f32(w_ca), b_ca=f32(b_ca), wm=f32(wm),
+                   bm=f32(bm), w1=f32(w1), w_ra=f32(w_ra), b_ra=f32(b_ra), wr=f32(wr), wmm=f32(wmm), bw=f32(bw))
+        pq_all = f32(pq_all)
+        mask_m = f32(mask_m)
+        dims = (N, d, Lq, S, know.shape[-1], L.dtype_id(know.dtype))
+        step0 = dict(par, control=ctl[0], memory=mems[0], pq=pq_all[0], workspace=ws, **{n: v[0] for n, v in F_.items()})
+        K.mac_chain_call("fwd", dims, n_steps, step0, mems, mask_m)
+        ctx_.save_for_backward(ctxw, know, pre, par["mask_c"], mask_m, pq_all, ctl, mems,
+                               *[par[k] for k in ("wc", "w_ca", "b_ca", "wm", "bm", "w1", "w_ra", "b_ra", "wr", "wmm", "bw")])
+        ctx_.fwd, ctx_.dims, ctx_.ws = F_, dims, ws
+        return mems[n_steps]
+
+    @staticmethod
+    def backward(ctx_, d_out):
+        sv = ctx_.saved_tensors
+        ctxw, know, pre, mask_c, mask_m, pq_all, ctl, mems = sv[:8]
+        names = ("wc", "w_ca", "b_ca", "wm", "bm", "w1", "w_ra", "b_ra", "wr", "wmm", "bw")
+        par = dict(zip(names, sv[8:19]))
+        N, d, Lq, S, ld, did = ctx_.dims
+        n_steps = pq_all.shape[0]
+        dev = ctl.device
+        F_ = ctx_.fwd
+        B_ = MacCoreFn._slab(MacCoreFn.BWD + ("ds_r", "ds_c", "d_concat"), [d] * 10 + [S, Lq, d], n_steps, N, dev)
+        step0 = dict(par, ctxw=ctxw, know=know, pre=pre, mask_c=mask_c, control=ctl[0], memory=mems[0], pq=pq_all[0],
+                     workspace=ctx_.ws, **{n: v[0] for n, v in F_.items()})
+        step0.update({n: v[0] for n, v in B_.items() if n != "d_concat"})
+        K.mac_chain_call("bwd", (N, d, Lq, S, ld, did), n_steps, step0, mems, mask_m, d_out.float().contiguous(), B_["d_concat"])
+        d_know, d_pre = K.mac_read_accum(B_["ds_r"], F_["p_r"], F_["u"], F_["v"], B_["d_read"], N, S, d, ld, know.dtype)
+        d_ctxw, _ = K.mac_read_accum(B_["ds_c"], F_["p_c"], F_["qv"], None, B_["d_c"], N, Lq, d, ctxw.shape[-1], ctxw.dtype)
+        rows = n_steps * N
+        flat = lambda t: t.reshape(rows, d)
+        gw = torch.empty(5 * d * d + 4 * d, dtype=torch.float32, device=dev)
+        G = {n: gw[k * d * d:(k + 1) * d * d].view(d, d) for k, n in enumerate(("g_wc", "g_wm", "g_w1", "g_wr", "g_wmm"))}
+        for k, n in enumerate(("g_wca", "g_wra", "g_bm", "g_bw")):
+            G[n] = gw[5 * d * d + k * d: 5 * d * d + (k + 1) * d]
+        nb = L.lib().vnqa_mac_core_wgrad_workspace(rows, d)
+        K.mac_wgrad(rows, d, dict(d_concat=flat(B_["d_concat"]), read=flat(F_["read"]), memory=flat(mems[:n_steps]), v=flat(F_["v"]),
+                                  d_t=flat(B_["d_t"]), d_mem=flat(B_["d_mem"]), d_cq=flat(B_["d_cq"]), control=flat(ctl[:n_steps]),
+                                  dv=flat(B_["dv"]), cnew=flat(ctl[1:]), dqv=flat(B_["dqv"]), cq=flat(F_["cq"]),
+                                  workspace=K.workspace(nb, dev), **G))
+        ctx_.fwd = None
+        return (B_["d_control"][0], B_["d_memory"][0], B_["d_cq"], d_ctxw, d_know, d_pre, None, None,
+                G["g_wc"], G["g_wca"].view(1, d), B_["ds_c"].sum().view(1), G["g_wm"], G["g_bm"], G["g_w1"], G["g_wra"].view(1, d),
+                B_["ds_r"].sum().view(1), G["g_wr"], G["g_wmm"], G["g_bw"], None, None)
+
+
+def mac_chain(control, memory, pq_all, ctxw, know, pre, mask_c, mask_m, *weights_and_dims):
+    return MacChainFn.apply(control, memory, pq_all, ctxw, know, pre, mask_c, mask_m, *weights_and_dims)
+
+
 class MacCoreTorchFn(torch.autograd.Function):
     """(VNQA_MAC_CORE_TORCH=1: the node issued op by op from Python on torch / rocBLAS GEMMs; the A/B partner of MacCoreFn.)
     One MAC reasoning step (ControlUnit, ReadUnit and WriteUnit.concat of models/mac.py:28-42,53-62,82-85) for all
