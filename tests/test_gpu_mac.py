@@ -91,7 +91,7 @@ def test_lstm_wide_bidir_is_two_single_direction_calls(B, H, lens):
     assert torch.equal(a_f, b_f) and torch.equal(a_r, b_r)
     assert torch.equal(xg[0].grad, xg[2].grad) and torch.equal(xg[1].grad, xg[3].grad)
     assert torch.equal(w[0].grad, w2[0].grad) and torch.equal(w[1].grad, w2[1].grad)
-    assert float(a_f.abs().sum()) > 0 and float(xg[1].grad.abs().sum()) > 0
+    assert float(a_f.detach().abs().sum()) > 0 and float(xg[1].grad.abs().sum()) > 0
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(5, 14, 14, 64, 256), (3, 10, 12, 64, 128), (2, 28, 28, 128, 512)])
