@@ -75,7 +75,7 @@ typedef struct vnqa_conv_desc {
   int32_t x_halo;  /* 1 for taps==9; 0 or 1 for taps==1 */
   int32_t y_halo;  /* 0 or 1 */
   int32_t relu;    /* activation after conv + bias: 0 none, 1 ReLU, 2 ELU(alpha 1) (MACNetwork's conv stack, models/mac.py:174-179;
-                    * vnqa_conv2d_igemm_fwd[_ex] on the implicit-GEMM and patch-stationary tiles only, no pooling) */
+                    * vnqa_conv2d_igemm_fwd[_ex] with tile = VNQA_TILE_AUTO or the plain tile it resolves to, no pooling) */
   int32_t pool2;   /* requires h, w even */
   int32_t tile;    /* 0 = auto, else a VNQA_TILE_* id */
   int32_t wt_tiled; /* 0: wt is [c_out][taps][c_in]; 1: wt comes from vnqa_pack_conv_weight_tiled for THIS tile id */

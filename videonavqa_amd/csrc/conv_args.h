@@ -2,12 +2,16 @@
 #pragma once
 #include "vnqa_common.h"
 
-// activation of the plain epilogue (vnqa_conv_desc.relu): 0 none, 1 ReLU, 2 ELU(alpha = 1) — only conv_igemm_kernel and
-// conv_ps_kernel implement 2 (the entry points of the other kernels reject it); internal experiment bits >= 256 mean ReLU
+// activation of the plain epilogue (vnqa_conv_desc.relu): 0 none, 1 ReLU, 2 ELU(alpha = 1).  ELU lives in its OWN kernel
+// instantiations (conv_igemm_kernel<..., TAG = VNQA_TAG_ELU>): as a runtime branch in the shared epilogue it cost the frozen
+// stem's kernels 5.5 % end to end (same-box A/B 888 vs 938 clips/s: the inlined expm1f at every store site changed the
+// register allocation and code layout of kernels that never take it).  Internal experiment bits >= 256 in `relu` mean ReLU.
 #define VNQA_ACT_ELU 2
+#define VNQA_TAG_ELU 3
+template <int TAG>
 __device__ __forceinline__ float vnqa_conv_act(float v, int mode) {
-  if (mode == VNQA_ACT_ELU) return v > 0.f ? v : expm1f(v);
-  return mode ? fmaxf(v, 0.f) : v;
+  if constexpr (TAG == VNQA_TAG_ELU) return v > 0.f ? v : expm1f(v);
+  else return mode ? fmaxf(v, 0.f) : v;
 }
 
 struct ConvArgs {

@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          v[e] = vnqa_conv_act(acc[i][j][4 * g + e] + bias_r[j][g][e] - sub[j][g][e], p.relu);
+          v[e] = vnqa_conv_act<TAG>(acc[i][j][4 * g + e] + bias_r[j][g][e] - sub[j][g][e], p.relu);
         }
         char* dst = smem + prow * CROW + col * ES;
         if constexpr (ES == 2) {
@@ -920,6 +920,28 @@ int fused_tile_rows(int dtype, int tile) {
 
 int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
   tile = resolve_tile(a, dtype, tile);
+  if (a.relu == VNQA_ACT_ELU) {        // own instantiations of the plain tiles (conv_args.h: why not a runtime branch)
+    if (a.epi != VNQA_EPI_NONE || a.partial != nullptr || a.pool) {
+      vnqa_set_error("conv2d_igemm_fwd: the ELU epilogue comes without pooling, split-K and fused trunk epilogues");
+      return VNQA_ERR_UNSUPPORTED;
+    }
+    if (dtype == VNQA_BF16) {
+      switch (tile) {
+        case VNQA_TILE_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, VNQA_TAG_ELU>(a, st);
+        case VNQA_TILE_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, VNQA_TAG_ELU>(a, st);
+        case VNQA_TILE_256x64: return launch<vnqa_bf16, 256, 64, 8, 1, VNQA_TAG_ELU>(a, st);
+        default: break;
+      }
+    } else {
+      switch (tile) {
+        case VNQA_TILE_128x128: return launch<float, 128, 128, 2, 2, VNQA_TAG_ELU>(a, st);
+        case VNQA_TILE_128x64: return launch<float, 128, 64, 4, 1, VNQA_TAG_ELU>(a, st);
+        default: break;
+      }
+    }
+    vnqa_set_error("conv2d_igemm_fwd: the ELU epilogue is built for the automatic tiles only (256x256 / 256x128 / 256x64; f32 128x128 / 128x64), not tile %d", tile);
+    return VNQA_ERR_UNSUPPORTED;
+  }
   if (dtype == VNQA_BF16) {
     switch (tile) {
       case VNQA_TILE_256x256: return launch<vnqa_bf16, 256, 256, 2, 4>(a, st);
@@ -941,10 +963,6 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       case VNQA_TILE_STEM_I5_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, 1, 5>(a, st);
       case VNQA_TILE_PATCH_224x256:
       case VNQA_TILE_STEM_PATCH_224x256:
-        if (a.relu == VNQA_ACT_ELU) {
-          vnqa_set_error("conv2d_igemm_fwd: the ELU epilogue is not available on the 224-pixel patch tiles");
-          return VNQA_ERR_UNSUPPORTED;
-        }
         if (a.zero_halo) {
           vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_ZERO_HALO is not available on the 224-pixel patch tiles");
           return VNQA_ERR_UNSUPPORTED;

@@ -292,7 +292,8 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[e] = vnqa_conv_act(acc[i][j][e] + b4[e] - sub[e], p.relu);
+        v[e] = acc[i][j][e] + b4[e] - sub[e];
+        if (p.relu) v[e] = fmaxf(v[e], 0.f);
       }
       uint2 pk;
       pk.x = pack2_h16(v[0], v[1]);
@@ -446,7 +447,7 @@ int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
   if ((a.taps != 9 && a.taps != 25) || a.D != 0 || a.x_halo != halo || a.wt_tiled || a.partial != nullptr || a.Cin % 64 != 0 ||
       a.Cin < 64 || a.group_tiles != 0 || a.ring_h != 0 || (a.border_sub != nullptr && a.Cout % 4 != 0) ||
       !(a.epi == VNQA_EPI_NONE || ((a.epi == VNQA_EPI_FILM_RES || a.epi == VNQA_EPI_ADD_MASK) && tag == 0 && !a.pool && a.y_halo == 1)) ||
-      (a.zero_halo && a.y_halo != 1)) {
+      (a.zero_halo && a.y_halo != 1) || a.relu == 2) {
     vnqa_set_error("conv patch-stationary tile: needs a bf16 3x3 / 5x5 2-D conv, x_halo = 1 / 2, c_in %% 64 == 0, K-major weights; of the "
                    "fused epilogues FILM_RES and ADD_MASK (un-pooled, y_halo = 1, trunk tag)");
     return VNQA_ERR_UNSUPPORTED;

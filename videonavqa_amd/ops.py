@@ -85,8 +85,9 @@ class ConvFn(torch.autograd.Function):
         c_in_pad = x.shape[-1]
         c_out_pad = L.round_up(c_out, 64)
         wt = K.pack_conv_weight(weight, cdt, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
-        y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu, tile=_ps_plain_tile(x, k, c_out_pad))
         ctx.elu = relu is not True and relu == 2
+        y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu,
+                           tile=L.TILE_AUTO if ctx.elu else _ps_plain_tile(x, k, c_out_pad))   # (the ELU epilogue: igemm tiles only)
         ctx.relu = bool(relu) and not ctx.elu and mask_in_backward   # False: the consumer's backward applies the ReLU mask
         ctx.dims = (c_out, c_in, k, c_out_pad, c_in_pad)
         ctx.save_for_backward(x, weight, y if (ctx.relu or ctx.elu) else None)
