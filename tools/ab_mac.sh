@@ -8,6 +8,7 @@ echo "torch / rocBLAS step                    :"; VNQA_MAC_CORE_TORCH=1 run
 echo "torch / rocBLAS step, 64 CUs            :"; VNQA_MAC_CORE_TORCH=1 VNQA_STEM_RESERVE_CUS=64 run
 echo "C-ABI, FMA sgemm                        :"; VNQA_SGEMM_FMA=1 run
 echo "C-ABI, no overlap                       :"; run --no-overlap
+echo "question encoder on the caller's stream :"; VNQA_MAC_SIDE_QUESTION=0 run
 echo "ELUs as separate passes                 :"; VNQA_MAC_ELU_FUSED=0 run
 echo "plain convs on the patch-stationary tile:"; VNQA_PLAIN_PS=1 run
 echo "C-ABI step (default) again              :"; run

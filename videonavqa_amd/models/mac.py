@@ -176,13 +176,14 @@ class MACNetwork(nn.Module):
         keep = 1.0 - self.mac.dropout                                                 # mac.py:125-129
         return tuple(torch.empty(n_img, self.dim, device=dev).bernoulli_(keep) / keep for _ in range(2))
 
-    def _reason(self, context, hq, kd, n_img, S, c_pad, lay):
-        """MACUnit.forward for every image at once (mac.py:131-155 with the units at :28-42,53-62,82-105)."""
+    def _question_terms(self, question, question_len, lay, dev):
+        """Everything of the forward that depends on the question only: the encoder (mac.py:203-221), the per-image context
+        rows and all steps' position-aware terms.  forward() runs it on a side stream next to the conv stack."""
         dim, m = self.dim, self.mac
-        dev = kd.device
+        context, hq = self._encode_question(question, question_len, lay.B, dev)
         so = lay.sample_of
         Lq = context.shape[1]
-        ctx = context[so].reshape(n_img * Lq, dim).contiguous()                   # [N*L,dim] fp32
+        ctx = context[so].reshape(lay.n_img * Lq, dim).contiguous()               # [N*L,dim] fp32
         # all position_aware projections (one per reasoning step, mac.py:29) and their share of control_question
         # (:31-32: Linear([control ; position_aware])) in two batched products, hoisted out of the step loop
         pw = torch.stack([l.weight for l in m.control.position_aware])            # [steps,dim,2dim]
@@ -190,6 +191,13 @@ class MACNetwork(nn.Module):
         pa_all = torch.matmul(hq, pw.transpose(1, 2)) + pb.unsqueeze(1)           # [steps,B,dim]
         wcq = m.control.control_question.weight
         pq_all = (torch.matmul(pa_all, wcq[:, dim:].t()) + m.control.control_question.bias)[:, so].contiguous()   # [steps,N,dim]
+        return hq, ctx, pq_all, Lq
+
+    def _reason(self, ctx, pq_all, Lq, kd, n_img, S, c_pad, lay):
+        """MACUnit.forward for every image at once (mac.py:131-155 with the units at :28-42,53-62,82-105)."""
+        dim, m = self.dim, self.mac
+        dev = kd.device
+        wcq = m.control.control_question.weight
         # step-invariant half of ReadUnit.concat on the MFMA GEMM: know W2^T + b (kept in the compute dtype)
         w2 = F.pad(m.read.concat.weight[:, dim:], (0, c_pad - dim, 0, c_pad - dim))
         pre = ops.linear_nt(kd, w2, F.pad(m.read.concat.bias, (0, c_pad - dim)))
@@ -241,9 +249,25 @@ class MACNetwork(nn.Module):
         x, lay, h, w = self._prepare_input(images, v_lens)
         dev = x.device
         B = lay.B
-        context, hq = self._encode_question(question, question_len, B, dev)
-        kd, n_img, S, c_pad = self._knowledge(x)
-        memory = self._reason(context, hq, kd, n_img, S, c_pad, lay)
+        if torch.is_grad_enabled() and x.is_cuda and os.environ.get("VNQA_MAC_SIDE_QUESTION", "1") != "0":
+            # the question side (embedding, bidirectional LSTM = 24 dependent launches, projections) has no input from the conv
+            # stack: it runs on its own high-priority stream next to the three convs, and autograd runs its backward there too,
+            # next to the convs' backward — both off the model's dependent chain
+            main = torch.cuda.current_stream()
+            side = getattr(self, "_q_stream", None)
+            if side is None:
+                side = self._q_stream = torch.cuda.Stream(priority=-1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                hq, ctx, pq_all, Lq = self._question_terms(question, question_len, lay, dev)
+            kd, n_img, S, c_pad = self._knowledge(x)
+            main.wait_stream(side)
+            for t in (hq, ctx, pq_all):
+                t.record_stream(main)
+        else:
+            hq, ctx, pq_all, Lq = self._question_terms(question, question_len, lay, dev)
+            kd, n_img, S, c_pad = self._knowledge(x)
+        memory = self._reason(ctx, pq_all, Lq, kd, n_img, S, c_pad, lay)
         out = torch.cat([memory, hq[lay.sample_of]], 1)                            # :240
         outs = torch.zeros(lay.n_frames, B, 3 * self.dim, device=dev).index_put((lay.frame_of, lay.sample_of), out)
         t = self.lstm_tail
