@@ -257,6 +257,9 @@ class MACNetwork(nn.Module):
             side = getattr(self, "_q_stream", None)
             if side is None:
                 side = self._q_stream = torch.cuda.Stream(priority=-1)
+                # (the question encoder's parameters accumulate their gradients on this stream by design)
+                if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+                    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 hq, ctx, pq_all, Lq = self._question_terms(question, question_len, lay, dev)
