@@ -705,6 +705,108 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       for (int e = 0; e < EPC; ++e) st_s[sl][e] = st_q[sl][e] = 0.f;
     frame0 = p.frame_of[(tile_m * rows_out) / (Ho * Wo)];
   }
+#ifndef VNQA_EPI_UNBATCHED        // (tools/build_variant.py unbatched -DVNQA_EPI_UNBATCHED -DVNQA_PS_EPI_UNBATCHED: the A/B partner)
+  if constexpr (TAG == 0) {
+    // FILM_RES / ADD_MASK (2-D, un-pooled, y_halo = 1, no ring): the arithmetic of the generic loop below with a thread's chunks
+    // taken UN at a time and ALL their global operands (res / add / mask, gamma / beta rows) requested before the first is
+    // used — chunk by chunk every iteration waited ~1.7 us for its own loads (conv_ps.hip has the same loop and the numbers).
+    if ((p.epi == VNQA_EPI_FILM_RES || p.epi == VNQA_EPI_ADD_MASK) && !p.pool && p.ring_h == 0 && p.D == 0) {
+      constexpr int UN = 4;
+      const bool film = p.epi == VNQA_EPI_FILM_RES;
+      for (int idx0 = threadIdx.x; idx0 < rows_out * CH; idx0 += UN * NT) {
+        size_t ooff[UN];
+        bool ok[UN];
+        int xo_[UN], yo_[UN];
+        uint4 ra[UN], rb[UN];
+        float ga[UN][EPC], be[UN][EPC];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int idx = idx0 + u * NT;
+          const int orow = idx / CH, c = idx - orow * CH;
+          const int mo = tile_m * rows_out + orow;
+          const int co0 = tile_n * BN + c * EPC;
+          ok[u] = idx < rows_out * CH && mo < M_out && co0 < p.Cout;
+          const int mm = ok[u] ? mo : 0;
+          const int n = mm / (Ho * Wo);
+          const int rem = mm - n * (Ho * Wo);
+          yo_[u] = rem / Wo;
+          xo_[u] = rem - yo_[u] * Wo;
+          ooff[u] = (((size_t)n * p.Hyp + yo_[u] + p.y_halo) * p.Wyp + xo_[u] + p.y_halo) * (size_t)p.Cy + co0;
+          ra[u] = rb[u] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) ga[u][e] = be[u][e] = 0.f;
+          if (ok[u]) {
+            ra[u] = *(const uint4*)((const T*)p.res + ooff[u]);
+            if (!film) rb[u] = *(const uint4*)((const T*)p.y2 + ooff[u]);
+            else {
+              const float* gp = p.film_gamma + (size_t)n * p.film_ld + co0;
+              const float* bp = p.film_beta + (size_t)n * p.film_ld + co0;
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) {
+                const bool in = co0 + e < p.film_c;
+                ga[u][e] = in ? gp[e] : 0.f;
+                be[u][e] = in ? bp[e] : 0.f;
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          if (!ok[u]) continue;
+          const int idx = idx0 + u * NT;
+          const int orow = idx / CH, c = idx - orow * CH;
+          const uint4 staged = *(const uint4*)(smem + orow * CROW + c * 16);
+          const T* src = (const T*)&staged;
+          T* dst = (T*)(p.y) + ooff[u];
+          T* second = nullptr;
+          T o2[EPC];
+          if (film) {
+            *(uint4*)dst = staged;                               // z: exactly the storage-rounded values staged in LDS
+            const T* rt = (const T*)&ra[u];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+              o2[e] = ElemOps<T>::store(fmaxf(ga[u][e] * ElemOps<T>::load(src[e]) + be[u][e], 0.f) + ElemOps<T>::load(rt[e]));
+            second = (T*)p.y2 + ooff[u];
+            *(uint4*)second = *(const uint4*)o2;
+          } else {
+            const T* at = (const T*)&ra[u];
+            const T* mt = (const T*)&rb[u];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+              o2[e] = ElemOps<T>::store(ElemOps<T>::load(mt[e]) > 0.f ? ElemOps<T>::load(src[e]) + ElemOps<T>::load(at[e]) : 0.f);
+            *(uint4*)dst = *(const uint4*)o2;
+          }
+          if (p.zero_halo) {
+            const int xo = xo_[u], yo = yo_[u];
+            const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
+            const long long rs = (long long)p.Wyp * p.Cy, cs = p.Cy;
+            const bool x0 = xo == 0, x1 = xo == Wo - 1, y0 = yo == 0, y1 = yo == Ho - 1;
+            if (x0 | x1 | y0 | y1) {
+#pragma unroll
+              for (int which = 0; which < 2; ++which) {
+                T* b = which == 0 ? dst : second;
+                if (b == nullptr) continue;
+                if (x0) *(uint4*)(b - cs) = zz;
+                if (x1) *(uint4*)(b + cs) = zz;
+                if (y0) {
+                  *(uint4*)(b - rs) = zz;
+                  if (x0) *(uint4*)(b - rs - cs) = zz;
+                  if (x1) *(uint4*)(b - rs + cs) = zz;
+                }
+                if (y1) {
+                  *(uint4*)(b + rs) = zz;
+                  if (x0) *(uint4*)(b + rs - cs) = zz;
+                  if (x1) *(uint4*)(b + rs + cs) = zz;
+                }
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
+#endif
   for (int idx = threadIdx.x; idx < rows_out * CH; idx += NT) {
     const int orow = idx / CH, c = idx - orow * CH;
     const int mo = tile_m * rows_out + orow;
