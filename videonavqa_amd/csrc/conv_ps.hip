@@ -311,7 +311,10 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     // before the first is used.  One chunk at a time, every iteration waited for its own loads: ~1.7 us x 28 per tile —
     // FILM_RES cost a C = 1024 conv +31 % (3.83 vs 2.92 ms) for 0.9 GB of extra traffic worth 0.2 ms.
     if (p.epi == VNQA_EPI_FILM_RES || p.epi == VNQA_EPI_ADD_MASK) {
-      constexpr int UN = 4;
+#ifndef VNQA_PS_EPI_UN      // batch size of the fused store loop (kernel alone, FILM_RES at C = 1024: 2: 3.24 ms, 4: 3.21, 7: 3.21)
+#define VNQA_PS_EPI_UN 4
+#endif
+      constexpr int UN = VNQA_PS_EPI_UN;
       const bool film = p.epi == VNQA_EPI_FILM_RES;
       const int c = threadIdx.x % CH;                       // NT % CH == 0: a thread keeps its channel chunk
       const int co0 = tile_n * BN + c * 8;
