@@ -250,7 +250,8 @@ int vnqa_hop_bwd(const float* dout, const float* hv, const float* hs, const int3
  * launch; only the activation patch goes through LDS (csrc/conv_wreg.hip).  Same tensors and epilogue contract as
  * vnqa_conv2d_igemm_fwd (bias -> ReLU -> 2x2 max-pool -> per-channel affine; y_halo 1 or 2) for exactly these geometries:
  *   c_in 128 -> c_out 128 with pool2 (conv2_2), c_in 64 -> c_out 128 without pool2 (conv2_1), c_in 64 -> c_out 64 with
- *   pool2 (conv1_2); w % 16 == 0, h % 8 == 0 (conv1_2: h % 16 == 0).
+ *   pool2 (conv1_2); w >= 16 and even (a width that is not a multiple of 16 costs one overlapping 16-pixel tile per
+ *   row: the 80 x 104 maps of the reference's 160 x 208 frames), h % 8 == 0 (conv1_2: h % 16 == 0).
  * vnqa_conv2d_wreg_supported returns 1 when a descriptor qualifies (callers fall back to the igemm / c64 kernels).
  */
 int vnqa_conv2d_wreg_supported(const vnqa_conv_desc* d);

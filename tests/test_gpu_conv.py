@@ -534,6 +534,14 @@ def test_ring_edge_convs_match_gathered_edge_gemms(dt):
     (70, 16, 16, 128, 128, True, True, 1),      # more tiles than one round of workgroups... 
     (300, 16, 32, 64, 128, False, True, 1),     # several rounds: the patch double buffer wraps many times
     (150, 32, 32, 64, 64, True, True, 1),
+    # widths that are not a multiple of 16: the last tile of a row overlaps its neighbour (80 x 104 = the reference's 160 x 208 frames)
+    (6, 16, 104, 128, 128, True, True, 2),
+    (5, 16, 104, 64, 128, False, True, 1),
+    (4, 16, 24, 128, 128, True, False, 1),
+    (3, 8, 40, 64, 128, False, False, 1),
+    (3, 32, 40, 64, 64, True, False, 1),
+    (2, 8, 18, 64, 128, False, False, 1),
+    (40, 80, 104, 64, 128, False, False, 1),
 ])
 def test_conv_wreg_vs_torch(cfg):
     """weights-in-registers persistent direct conv (csrc/conv_wreg.hip) vs torch on the same storage-rounded operands, and

@@ -140,7 +140,9 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
     const int r = t - n * per_img;
     const int ty = r / p.tilesX;
     y0 = ty * TH;
-    x0 = (r - ty * p.tilesX) * 16;
+    // widths that are not a multiple of 16 (the reference's 160 x 208 frames give 80 x 104 maps): the last tile of a row
+    // starts at W - 16 and overlaps its neighbour — the shared columns are computed twice to the same bits, no masking
+    x0 = min((r - ty * p.tilesX) * 16, p.W - 16);
   };
 
   // patch DMA: instruction q = wave + 4 k writes LDS bytes [q*1024, q*1024+1024) of the slot = PPI consecutive patch pixels;
@@ -397,7 +399,7 @@ int wreg_launch_(WregArgs a, hipStream_t stream) {
   constexpr int NI = ((TH + 2) * 18 * PIXB + 1023) / 1024;
   constexpr int LDS = 2 * NI * 1024 + 3 * COUT * 4;
   static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
-  a.tilesX = a.W / 16;
+  a.tilesX = (a.W + 15) / 16;
   a.tilesY = a.H / TH;
   a.n_tiles = a.n_img * a.tilesX * a.tilesY;
   auto kern = conv_wreg_kernel<CIN, COUT, NCG, TH, HR, POOL, POST>;
@@ -428,7 +430,7 @@ int wreg_launch(const WregArgs& a, hipStream_t stream) {
 // 1 when vnqa_conv2d_wreg_fwd serves this geometry (the caller falls back to the igemm / c64 kernels otherwise)
 extern "C" int vnqa_conv2d_wreg_supported(const vnqa_conv_desc* d) {
   if (!d || d->dtype != VNQA_BF16 || d->taps != 9 || d->x_halo != 1 || d->depth != 0) return 0;
-  if (d->w % 16 != 0 || d->h % 8 != 0 || d->c_y % 8 != 0) return 0;
+  if (d->w < 16 || d->w % 2 != 0 || d->h % 8 != 0 || d->c_y % 8 != 0) return 0;     // (w % 16 != 0: overlapping last tile)
   if (d->c_in == 128 && d->c_out == 128 && d->pool2) return 1;
   if (d->c_in == 64 && d->c_out == 128 && !d->pool2) return 1;
   if (d->c_in == 64 && d->c_out == 64 && d->pool2 && d->h % 16 == 0) return 1;
