@@ -107,7 +107,8 @@ typedef struct vnqa_conv_desc {
 #define VNQA_TILE_STEM_256x256 6 /* 256x256 geometry, own kernel symbol for the frozen stem (bf16) */
 #define VNQA_TILE_I5_256x256 18  /* 256x256, 8 waves, hand-pipelined main loop (PIPE 5: mid-K-step barrier, DMA two stages ahead, one filler per MFMA group) */
 #define VNQA_TILE_STEM_I5_256x256 19 /* same kernel, own symbol for the frozen stem */
-#define VNQA_TILE_PS_224x256 20  /* patch-stationary 3x3 conv (csrc/conv_ps.hip): 224 px x 256 couts, 4 waves x 512 registers, hand-placed loop */
+#define VNQA_TILE_PS_224x256 20  /* patch-stationary 3x3 conv (csrc/conv_ps.hip): 224 px x 256 couts, 4 waves x 512 registers, hand-placed loop;
+                                    8 x 28 tiles for w % 28 == 0, else 16 x 14 for any even w >= 14 (last column block overlaps its neighbour) */
 #define VNQA_TILE_STEM_PS_224x256 21 /* same kernel, own symbol for the frozen stem */
 #define VNQA_TILE_320x128 17 /* 320 rows x 128 couts, 4x2 waves (80x64 wave tiles): skinny GEMMs whose 257..320 rows would waste half of
                                   a second 256-row tile (fc_embed_attn forward at 280 packed images) */

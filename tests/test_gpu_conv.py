@@ -314,6 +314,42 @@ def test_conv_patch_tile_vs_torch(tile, cfg):
     assert _rel(y.float(), y1.float()) < 1e-2
 
 
+@pytest.mark.parametrize("tile", [20, 21])
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, relu, pool, post: widths that are not a multiple of 14 — the last column block overlaps its neighbour
+    (7, 20, 26, 256, 256, True, True, True),      # the reference's 160 x 208 frames: ObjDetectCNN's 20 x 26 maps
+    (5, 20, 26, 128, 256, True, False, False),
+    (3, 14, 16, 64, 64, False, False, False),     # overlap of 12 columns
+    (2, 28, 40, 64, 320, True, True, False),      # three column blocks, the last two overlap by 2
+])
+def test_conv_ps_tile_overlapping_column_blocks(tile, cfg):
+    """conv_ps.hip on widths its 14-column tiles do not divide: vs torch, halo untouched, and against the row-tile igemm."""
+    from videonavqa_amd import kernels as K
+    N, H, W, Cin, Cout, relu, pool, post = cfg
+    dt = LOW_DTYPE
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg[:5]) + tile)
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5).cuda()
+    b = torch.randn(Cout, generator=g).cuda() * 0.1
+    sc = (torch.rand(Cout, generator=g) + 0.5).cuda() * torch.where(torch.rand(Cout, generator=g) > 0.3, 1.0, -1.0).cuda()
+    sh = torch.randn(Cout, generator=g).cuda() * 0.2
+    ref = F.conv2d(_q(x, dt), _q(w, dt), b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    if post:
+        ref = ref * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    xn, wt = K.nchw_to_nhwc(x, dt, c_pad=Cin), K.pack_conv_weight(w, dt, c_out_pad=Cout, c_in_pad=Cin)
+    kw = dict(bias=b, relu=relu, pool2=pool, post_scale=sc if post else None, post_shift=sh if post else None)
+    y = K.conv2d_igemm(xn, wt, tile=tile, **kw)
+    got = K.nhwc_to_nchw(y, Cout)
+    assert got.shape == ref.shape and _rel(got, ref) < 1e-2, _rel(got, ref)
+    assert float(y[:, 0].abs().max()) == 0 and float(y[:, :, 0].abs().max()) == 0
+    assert float(y[:, -1].abs().max()) == 0 and float(y[:, :, -1].abs().max()) == 0
+    assert _rel(y.float(), K.conv2d_igemm(xn, wt, tile=1, **kw).float()) < 1e-2
+
+
 def test_conv_patch_tile_rejects_unsupported_geometry():
     from videonavqa_amd import kernels as K
     from videonavqa_amd._lib import VnqaError

@@ -180,7 +180,7 @@ def test_conv_zeroes_the_halo_of_a_poisoned_output_buffer(dt, cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("geom", [(9, 14, 14, 256), (5, 28, 28, 256), (35, 14, 14, 512)])
+@pytest.mark.parametrize("geom", [(9, 14, 14, 256), (5, 28, 28, 256), (35, 14, 14, 512), (6, 20, 26, 256)])
 def test_patch_stationary_tile_carries_film_res_and_add_mask(geom):
     """The FiLM block's two fused 3x3 launches on the patch-stationary kernel (tile id 20, what the train-mode trunk uses at
     14x14 / 28x28 maps): bit-identical to the igemm forms — z, the FiLM+ReLU+residual output, the masked dgrad sum — and the halo

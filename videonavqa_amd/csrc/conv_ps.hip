@@ -92,8 +92,11 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     tile_n = t % p.tilesN;
     tile_m = t / p.tilesN;
   }
-  const int CB = p.W / TC;
+  // column blocks: widths that are not a multiple of TC (26-wide maps of the reference's 160 x 208 frames) put the last block at
+  // W - TC, overlapping its neighbour — the shared columns are computed twice to the same bits, no masking
+  const int CB = (p.W + TC - 1) / TC;
   const int rt = tile_m / CB, cb = tile_m - rt * CB;
+  const int xb = min(cb * TC, p.W - TC);       // first image column of this tile
   const int total_rows = p.n_img * p.H;
   const int g0 = rt * TR;
   auto padrow = [&](int g) {
@@ -109,7 +112,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   const unsigned cin_b = (unsigned)p.Cin * 2;
 
   // ---- per-lane DMA source offsets (32-bit, relative to wave-uniform bases) ----
-  const char* const x_base = p.x + ((size_t)pr_first * p.Wp + (size_t)cb * TC) * cin_b;
+  const char* const x_base = p.x + ((size_t)pr_first * p.Wp + (size_t)xb) * cin_b;
   unsigned a_off[PIW];                    // patch instruction q = wave + 4 j: LDS pixels 8q .. 8q+7
 #pragma unroll
   for (int j = 0; j < PIW; ++j) {
@@ -262,7 +265,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
       const int tr = ml / TC, tc = ml - tr * TC;
       const int g = g0 + tr;
       if (g < total_rows) {
-        const int n = g / p.H, y = g - n * p.H, x = cb * TC + tc;
+        const int n = g / p.H, y = g - n * p.H, x = xb + tc;
         int ring = -1;
         if (y == 0) ring = x;
         else if (y == p.H - 1) ring = p.W + x;
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
           const int gg = ok[u] ? g : g0;
           const int n = gg / p.H, y = gg - n * p.H;
           nn[u] = n;
-          ooff[u] = (((size_t)n * p.Hyp + y + 1) * p.Wyp + cb * TC + occ + 1) * (size_t)p.Cy + co0;
+          ooff[u] = (((size_t)n * p.Hyp + y + 1) * p.Wyp + xb + occ + 1) * (size_t)p.Cy + co0;
           ra[u] = rb[u] = make_uint4(0u, 0u, 0u, 0u);
           g0v[u] = g1v[u] = b0v[u] = b1v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (ok[u]) {
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
           if (p.zero_halo) {
             const int orr = orow / TC, occ = orow - orr * TC;
             const int gg = g0 + orr;
-            const int yo = gg - nn[u] * p.H, xo = cb * TC + occ;
+            const int yo = gg - nn[u] * p.H, xo = xb + occ;
             const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
             const long long rs = (long long)p.Wyp * p.Cy, cs = p.Cy;
             const bool x0 = xo == 0, x1 = xo == p.W - 1, y0 = yo == 0, y1 = yo == p.H - 1;
@@ -472,7 +475,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     const int n = g / p.H;
     const int y = g - n * p.H;
     const int yo = p.pool ? (y >> 1) : y;
-    const int xo = (p.pool ? (cb * TC) >> 1 : cb * TC) + occ;
+    const int xo = (p.pool ? xb >> 1 : xb) + occ;
     const size_t ooff = (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
     vnqa_bf16* dst = (vnqa_bf16*)(p.y) + ooff;
     uint4 o;
@@ -550,7 +553,7 @@ int launch_ps(const ConvArgs& a, hipStream_t stream) {
   constexpr int LDS_BYTES = 2 * patch_rows(HALO) * 128 + 2 * B_BYTES;
   ConvArgs p = a;
   const int rows = p.n_img * p.H;
-  const int tilesM = ((rows + TR - 1) / TR) * (p.W / TC);
+  const int tilesM = ((rows + TR - 1) / TR) * ((p.W + TC - 1) / TC);
   p.tilesN = (p.Cout + BN - 1) / BN;
   auto kern = conv_ps_kernel<TC, HALO, TAG>;
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: a race only repeats it
@@ -580,9 +583,10 @@ int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
                    "fused epilogues FILM_RES and ADD_MASK (un-pooled, y_halo = 1, trunk tag)");
     return VNQA_ERR_UNSUPPORTED;
   }
-  const int tc = a.W % 28 == 0 ? 28 : (a.W % 14 == 0 ? 14 : 0);
+  // 28-wide tiles for widths that are multiples of 28, else 14-wide ones (any even width >= 14: the last column block overlaps)
+  const int tc = a.W % 28 == 0 ? 28 : ((a.W >= 14 && (a.W % 14 == 0 || a.W % 2 == 0)) ? 14 : 0);
   if (tc == 0) {
-    vnqa_set_error("conv patch-stationary tile: width %d is not a multiple of 14", a.W);
+    vnqa_set_error("conv patch-stationary tile: width %d must be even and >= 14 (or a multiple of 14)", a.W);
     return VNQA_ERR_UNSUPPORTED;
   }
   const int tr = BM / tc;

@@ -129,12 +129,12 @@ def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frame
 
 def ps_fused_tile(x):
     """TILE_PS_224x256 when the patch-stationary kernel can run a 3x3 conv with a fused FILM_RES / ADD_MASK epilogue on this
-    padded-NHWC input (16-bit storage, width a multiple of 14, its LDS patch fits), else TILE_AUTO.  VNQA_TRUNK_PS=0 disables."""
+    padded-NHWC input (16-bit storage, width a multiple of 14 or any even width >= 14, its LDS patch fits), else TILE_AUTO.  VNQA_TRUNK_PS=0 disables."""
     if os.environ.get("VNQA_TRUNK_PS", "1") == "0" or not L.is_half(x.dtype):
         return L.TILE_AUTO
     N, Hp, Wp, C = x.shape
     h, w = Hp - 2, Wp - 2
-    tc = 28 if w % 28 == 0 else (14 if w % 14 == 0 else 0)
+    tc = 28 if w % 28 == 0 else (14 if (w >= 14 and (w % 14 == 0 or w % 2 == 0)) else 0)      # (else: overlapping last column block)
     if tc == 0 or C % 64 != 0:
         return L.TILE_AUTO
     tr = 224 // tc

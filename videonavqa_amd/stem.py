@@ -162,7 +162,7 @@ class FrozenStem(object):
     @staticmethod
     def _ps_ok(h, w, pool):
         """vnqa_conv_ps_dispatch's geometry conditions for a 3x3 layer on h x w maps (224-pixel tiles of 8 x 28 or 16 x 14)."""
-        tc = 28 if w % 28 == 0 else (14 if w % 14 == 0 else 0)
+        tc = 28 if w % 28 == 0 else (14 if (w >= 14 and (w % 14 == 0 or w % 2 == 0)) else 0)     # (else: overlapping last block)
         if tc == 0 or (pool and (h % 2 or w % 2)):
             return False
         tr = 224 // tc
