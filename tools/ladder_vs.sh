@@ -16,8 +16,11 @@ case "$1" in
     git worktree remove --force _old; git worktree prune; sed -i '/^_old\/$/d' .git/info/exclude ;;
   run)
     R=$PWD
-    B="--steps 20 --warmup 5 --repeats 1 --no-parity --no-cpu-baseline --no-fp16-leg"
-    one() { (cd $1 && PYTHONPATH=$1 python bench.py $B "${@:2}" 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("%8.1f" % d["value"])'); }
+    B="--steps 20 --warmup 5 --repeats 1 --no-parity --no-cpu-baseline"
+    grep -q -- "--no-fp16-leg" _old/bench.py && B="$B --no-fp16-leg"
+    one() { (cd $1 && PYTHONPATH=$1 python bench.py $B $([ $1 = $R ] && echo --no-fp16-leg) "${@:2}" 2>/dev/null | tail -1 | python -c 'import sys,json
+try: print("%8.1f" % json.loads(sys.stdin.read())["value"])
+except Exception: print("nan")'); }       # (nan: the older tree's bench.py does not know the row's flags)
     row() { name=$1; shift; a=$(one $R "$@"); b=$(one $R/_old "$@"); a2=$(one $R "$@"); b2=$(one $R/_old "$@")
             python3 -c "import sys; n,a,b,a2,b2=sys.argv[1:]; a,b,a2,b2=map(float,(a,b,a2,b2)); print('%-22s new %8.1f %8.1f   old %8.1f %8.1f   new/old %.3f' % (n,a,a2,b,b2,(a+a2)/(b+b2)))" "$name" $a $b $a2 $b2; }
     row headline
