@@ -266,7 +266,6 @@ __global__ void __launch_bounds__(256) ring_edge_gather_kernel(const uint4* __re
   if (group_rows > 0) edge = blockIdx.z;
   const int len = edge < 2 ? W : H;
   if (j >= len) return;
-  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
   uint4* dst = out + ((size_t)(group_rows > 0 ? edge * group_rows : 0) + (size_t)n * len + j) * 3 * c16;
   for (int i = threadIdx.x; i < 3 * c16; i += 256) {
     const int slot = i / c16, k = i - slot * c16;
@@ -277,7 +276,9 @@ __global__ void __launch_bounds__(256) ring_edge_gather_kernel(const uint4* __re
       const int yy = j + slot - 1;                                  // q = (yy, -1 | W); corners (yy = -1, H) excluded
       if (yy >= 0 && yy < H) r = 2 * (W + 2) + (edge == 3 ? H : 0) + yy;
     }
-    dst[i] = r >= 0 ? y1[((size_t)n * R + r) * c16 + k] : z;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);       // (a ternary between a load and the constant kept `z` in scratch)
+    if (r >= 0) v = y1[((size_t)n * R + r) * c16 + k];
+    dst[i] = v;
   }
 }
 
