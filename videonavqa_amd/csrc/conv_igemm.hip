@@ -709,7 +709,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   // (Only on the two large tiles: the batch's operand registers are the high-water mark of the small-tile instantiations —
   // 256 x 64 went from 116 to 133 VGPRs, i.e. from two workgroups per CU to one, and VideoOnlyCNN3D's conv2 dgrad on that
   // tile from 0.88 to 1.31 ms, although it never takes this path.)
-  if constexpr (TAG == 0 && BM * BN >= 256 * 128) {
+  if constexpr (TAG == 0 && BM * BN >= 256 * 128 && (PIPE == 2 || PIPE == 5 || BN == 256)) {     // (not the 4-stage 256 x 128 ring: 119 -> 147 VGPRs)
     // FILM_RES / ADD_MASK (2-D, un-pooled, y_halo = 1, no ring): the arithmetic of the generic loop below with a thread's chunks
     // taken UN at a time and ALL their global operands (res / add / mask, gamma / beta rows) requested before the first is
     // used — chunk by chunk every iteration waited ~1.7 us for its own loads (conv_ps.hip has the same loop and the numbers).
