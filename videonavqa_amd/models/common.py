@@ -499,15 +499,17 @@ class FiLMTrunkBase(nn.Module):
     # (VNQA_SIDE_LSTM=0: same stream): in the pipelined step the stem of minibatch i+2 may not start before the trunk of
     # minibatch i has released its feature slot, so the trunk's dependent-chain LATENCY under contention — not only the summed
     # kernel work — sets the step; same-box A/B +6.5 % (877-897 -> 940-956 clips/s) even on the un-fused graph.
-    def _fork_generator(self, fn):
+    def _fork_generator(self, fn, n_img=None):
         """Run fn() (returns a tensor or tuple of tensors) on the side stream; returns (result, join) where join()
         makes the current stream wait for it and registers the cross-stream use with the caching allocator.
-        VNQA_SIDE_LSTM: 1 always, 0 never, default `auto` = for minibatches of up to 16 clips (same-box A/B, on / off:
-        bs 8 +2.9 .. +6.5 %, bs 16 +-0, bs 32 -5.5 % — there the trunk's kernels are four times longer, its chain latency no longer
-        sets the step, and the chain's 32 persistent high-priority workgroups only take CUs from the convs)."""
+        VNQA_SIDE_LSTM: 1 always, 0 never, default `auto` = for minibatches of up to 420 frames (n_img; without it: up to 16
+        clips).  Same-box A/B, on / off: 8 x 35 frames +2.9 .. +6.5 %, 16 x 35 -0.5 %, 8 x 70 (multi-hop) -0.9 %, 32 x 35 -5.5 % —
+        with more frames the trunk's kernels are longer, its chain latency no longer sets the step, and the chain's persistent
+        high-priority workgroups only take CUs from the convs."""
         import os
         mode = os.environ.get("VNQA_SIDE_LSTM", "auto")
-        on = mode == "1" or (mode != "0" and getattr(self, "batch_size", 8) <= 16)
+        small = (n_img <= 420) if n_img is not None else getattr(self, "batch_size", 8) <= 16
+        on = mode == "1" or (mode != "0" and small)
         if not torch.cuda.is_available() or not on or not torch.is_grad_enabled():
             return fn(), (lambda: None)
         main = torch.cuda.current_stream()

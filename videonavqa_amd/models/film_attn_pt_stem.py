@@ -73,7 +73,7 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
             # the FiLM generator (question LSTM re-run per frame, :213) on the side stream, joined after conv_init + BatchNorm
             film_img, join = self._fork_generator(
                 lambda: self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay) if bow else
-                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay))
+                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay), n_img=lay.n_img)
             x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)], join)   # :229-233
         else:
             # FiLM generator: question LSTM re-run per processed frame with carried state (:213) — on the side stream
@@ -88,7 +88,7 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
                 film = F.relu(self.film_layer[1](h_last))                   # [B, n_frames, 2*C*blocks] (:179)
                 return film[lay.sample_of, lay.frame_of]                    # [n_img, 2*C*blocks]
 
-            film_img, join = self._fork_generator(generator)
+            film_img, join = self._fork_generator(generator, n_img=lay.n_img)
             x = self._trunk_head(x, lay)
             join()
 

@@ -69,10 +69,10 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
         if self._use_fused_trunk():       # train mode: generator and conv trunk on fused HIP ops
             film_img, join = self._fork_generator(
                 lambda: self.bow_film_values(self.film_layer[0], self.film_layer[1], q_input, lay) if bow else
-                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay, padding_idx=0))
+                self.question_film_values(self.film_layer[0], self.film_layer[1], q_input, q_lens, lay, padding_idx=0), n_img=lay.n_img)
             x = self._trunk_fused(x, lay, [(film_img, 2 * C * k) for k in range(self.num_res_blocks)], join)
         else:
-            film_img, join = self._fork_generator(generator)
+            film_img, join = self._fork_generator(generator, n_img=lay.n_img)
             x = self._trunk_head(x, lay)
             join()
 

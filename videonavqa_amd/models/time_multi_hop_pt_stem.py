@@ -105,7 +105,7 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
         gen = self._generator_hip if (x.is_cuda and os.environ.get("VNQA_HOP_TORCH", "0") != "1") else self._generator_torch
         join = None
         if fused:       # the generator (question LSTM chain + hop attention) on the side stream, joined after conv_init + BatchNorm
-            film_per_block, join = self._fork_generator(lambda: tuple(gen(q_input, q_lens, lay)))
+            film_per_block, join = self._fork_generator(lambda: tuple(gen(q_input, q_lens, lay)), n_img=lay.n_img)
         else:
             film_per_block = gen(q_input, q_lens, lay)
 
