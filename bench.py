@@ -125,17 +125,10 @@ def synth_batch(args, rank, device, index=0):
     return clip.to(device), q.to(device), v_lens, q_lens, y.to(device)
 
 
-def cpu_baseline_child(args):
-    """Runs in a CPU-only child process (`bench.py --cpu-baseline-only`): the oracle — a CPU
-    restatement of the reference, kind 'port' — timed on this host's cores on the metric's own minibatch
-    (SURVEY 8d: B = 8 clips x T frames, 1 warm-up + 3 timed full steps: stem fwd + FiLM-attn fwd/bwd + clip + Adam).
-    A cumulative JSON line is printed after every timed step, so a parent that runs out of patience still has a
-    measurement of the steps completed so far."""
-    from oracle import vnqa_oracle as O
-    import torch.nn as nn
-    torch.manual_seed(0)
-    nthreads = torch.get_num_threads()
-    Bs = args.cpu_batch
+def oracle_workload(args, Bs):
+    """Weights (reference GPU-flavour state_dict names, fp32, seeded) and ONE minibatch of the metric's shape for the CPU leg.
+    Pure tensor generation (no oracle import): the GPU parent regenerates the identical dictionaries from the same seed to
+    run its exact-f32 precision on them (`parity.oracle_full_size_*`), the CPU child feeds them to the oracle."""
     S = (args.height // 16) * (args.width // 16)
     C = args.channels
     g = torch.Generator(device="cpu").manual_seed(99)
@@ -178,7 +171,32 @@ def cpu_baseline_child(args):
     q = torch.randint(1, 134, (Bs, 56), generator=g)
     v_lens = torch.full((Bs,), args.frames, dtype=torch.long)
     y = torch.randint(0, 70, (Bs,), generator=g)
+    return W_vgg, W_od, W, (clip, q, v_lens, q_lens, y)
+
+
+def cpu_baseline_child(args):
+    """Runs in a CPU-only child process (`bench.py --cpu-baseline-only`): the oracle — a CPU
+    restatement of the reference, kind 'port' — timed on this host's cores on the metric's own minibatch
+    (SURVEY 8d: B = 8 clips x T frames, 1 warm-up + 3 timed full steps: stem fwd + FiLM-attn fwd/bwd + clip + Adam).
+    A cumulative JSON line is printed after every timed step, so a parent that runs out of patience still has a
+    measurement of the steps completed so far.  With --cpu-logits-out the oracle's train-mode forward logits on the
+    initial weights (the first thing the warm-up step computes anyway) are written there for the parent's
+    HIP-vs-oracle comparison at the benchmark's own size."""
+    from oracle import vnqa_oracle as O
+    torch.manual_seed(0)
+    nthreads = torch.get_num_threads()
+    Bs = args.cpu_batch
+    W_vgg, W_od, W, (clip, q, v_lens, q_lens, y) = oracle_workload(args, Bs)
     adam = O.AdamState(list(W))
+
+    if args.cpu_logits_out:
+        with torch.no_grad():
+            feats = O.stem_forward(clip, W_vgg, W_od)
+            v2, q2, vl2, ql2, y2, _perm = O.sort_batch(feats, q, v_lens, q_lens, y)
+            W0 = {k: v.clone() for k, v in W.items()}          # (train-mode BN advances the running statistics in place)
+            logits = O.film_attn_forward(W0, v2, q2, vl2, ql2, training=True)
+        torch.save({"logits": logits.detach().clone(), "batch": Bs, "perm": _perm.clone()}, args.cpu_logits_out)
+        del feats, v2, W0
 
     def one():
         feats = O.stem_forward(clip, W_vgg, W_od)
@@ -196,14 +214,16 @@ def cpu_baseline_child(args):
                                     % (Bs, args.frames, args.height, args.width, n, nthreads)}), flush=True)
 
 
-def cpu_baseline(argv, limit_s=420):
+def cpu_baseline(argv, limit_s=420, logits_out=None):
     """Launch the CPU leg as a child process BEFORE this process touches the GPU; bounded by a timeout.  The child
-    prints a cumulative line after every timed step: on a timeout the last complete line is what is reported."""
+    prints a cumulative line after every timed step: on a timeout the last complete line is what is reported.
+    `logits_out`: file the child writes the oracle's forward logits of its minibatch to (parity.oracle_full_size_*)."""
     import subprocess
     env = dict(os.environ)
     env["HIP_VISIBLE_DEVICES"] = ""
     env["CUDA_VISIBLE_DEVICES"] = ""
-    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"] + argv, env=env,
+    extra = ["--cpu-logits-out", logits_out] if logits_out else []
+    proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"] + argv + extra, env=env,
                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     note = ""
     try:
@@ -357,6 +377,55 @@ def parity_batches(args, device):
         y = torch.randint(0, 70, (B,), generator=g)
         out.append((clip.to(device), q.to(device), v_lens, q_lens, y.to(device)))
     return out
+
+
+def oracle_full_size(args, device, dump_path):
+    """HIP path vs the CPU oracle at the BENCHMARK'S OWN SIZE: the exact-f32 precision of the product (stem +
+    FiLM-attn, train-mode forward through the C ABI) on the very weights and minibatch the CPU leg ran
+    (`oracle_workload`, regenerated from the same seed), against the logits the oracle computed there.  The oracle runs
+    only in the CPU child; this function reads its dumped logits."""
+    import copy
+    import torch.nn as nn
+    from videonavqa_amd.models import FiLMAttnPretrainedStem, ObjDetectCNN
+    from videonavqa_amd.models.common import FrameLayout, NativeFeatures
+    from videonavqa_amd.stem import FrozenStem, VGGFront
+    if not dump_path or not os.path.exists(dump_path) or args.model != "film_attn_pt":
+        return None
+    d = torch.load(dump_path)
+    ref, Bs, perm_o = d["logits"].float(), int(d["batch"]), d["perm"].long()
+    W_vgg, W_od, W, (clip, q, v_lens, q_lens, y) = oracle_workload(args, Bs)
+    S = (args.height // 16) * (args.width // 16)
+    vgg = VGGFront("fp32")
+    od = ObjDetectCNN(27, 512, 1024, 0, True, True, precision="fp32")
+    vgg.load_state_dict(W_vgg)
+    od.load_state_dict(W_od, strict=False)          # (the unused classifier tail / num_batches_tracked are not in the dict)
+    model = FiLMAttnPretrainedStem(Bs, 128, 70, num_res_blocks=args.blocks, num_res_block_channels=args.channels,
+                                   max_num_frames=args.frames, spatial_size=S, precision="fp32")
+    vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
+    model.load_reference_tensors(W)
+    stem = FrozenStem(vgg, od, "fp32")
+    v_sorted, perm = torch.sort(v_lens, dim=0, descending=True, stable=True)
+    lay = FrameLayout(v_sorted, args.frames, device, perm=perm)
+    feats = stem.forward_clip(clip.to(device), lay.img_of, lay.n_img)
+    native = NativeFeatures(feats, lay, 512, args.height // 16, args.width // 16)
+    model.train()
+    model.init_hidden()
+    with torch.no_grad():
+        out = model(native, q.to(device)[perm.to(device)], v_sorted, q_lens[perm]).float().cpu()
+    # rows: product row j = original sample perm[j]; oracle row i = original sample perm_o[i]
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(len(perm))
+    out_o = out[inv[perm_o]]
+    err = float((out_o - ref).abs().max() / ref.abs().max())
+    l2 = float((out_o - ref).norm() / ref.norm())
+    del model, stem, vgg, od, feats
+    torch.cuda.empty_cache()
+    return {"oracle_full_size_rel_err": round(err, 9), "oracle_full_size_rel_l2_err": round(l2, 9),
+            "oracle_full_size_argmax_equal": bool((out_o.argmax(1) == ref.argmax(1)).all()),
+            "oracle_full_size_what": "precision='fp32' HIP path (stem + FiLM-attn train-mode forward) vs oracle/vnqa_oracle.py "
+                                     "(stem_forward + film_attn_forward, run in the CPU child) on identical weights and the CPU "
+                                     "leg's minibatch: %d clips x %d frames %dx%d; max|d logit| / max|logit|"
+                                     % (Bs, args.frames, args.height, args.width)}
 
 
 def precision_parity(args, device, speed_steps=5, fit_steps=12):
@@ -530,6 +599,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-steps", type=int, default=3, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-logits-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         cpu_baseline_child(args)
@@ -553,10 +623,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    cpu_leg = None
+    cpu_leg, oracle_dump = None, None
     if world == 1 and not args.no_cpu_baseline:
+        import tempfile
         fwd = [a for a in sys.argv[1:] if a not in ("--no-cpu-baseline",)]
-        cpu_leg = cpu_baseline(fwd)          # child process, before any GPU initialisation here
+        if args.model == "film_attn_pt" and not args.no_parity:
+            oracle_dump = os.path.join(tempfile.mkdtemp(prefix="vnqa_bench_"), "oracle_logits.pt")
+        cpu_leg = cpu_baseline(fwd, logits_out=oracle_dump)          # child process, before any GPU initialisation here
     import torch.distributed as dist
     # test hook: VNQA_DIST_BACKEND=gloo VNQA_SINGLE_DEVICE=1 runs N ranks on ONE GPU to exercise the multi-rank
     # code path where only one GPU exists (never a benchmark configuration)
@@ -703,6 +776,9 @@ def main():
         del trainer, model, stem
         torch.cuda.empty_cache()
         parity = precision_parity(args, device)
+        full = oracle_full_size(args, device, oracle_dump)
+        if full is not None:
+            parity.update(full)
     if world > 1:
         dist.barrier()
 

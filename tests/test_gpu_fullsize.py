@@ -195,3 +195,59 @@ def test_full_size_trunk_wgrad_vs_torch_and_additivity():
     a, _ = K.conv2d_wgrad(xn[:100].contiguous(), dyn[:100].contiguous(), 9)
     b, _ = K.conv2d_wgrad(xn[100:].contiguous(), dyn[100:].contiguous(), 9)
     assert float((a + b - dwt).abs().max()) < 2e-4 * scale
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_hip_fp32_vs_oracle_at_baseline_geometry(ragged):
+    """the HIP path against the ORACLE ITSELF at BASELINE.json's geometry — 35 frames of 224 x 224 through the
+    full-width stem (VGG-16[:10] + ObjDetectCNN(512)) and the default FiLM-attn model — on B = 2 clips (what the oracle
+    finishes in seconds on the host cores).  precision='fp32' through the C ABI vs oracle.stem_forward + film_attn_forward:
+    stem features <= 1e-3 of their max, logits <= 1e-3 of max |logit|, answer classes identical (north star's tolerance)."""
+    import argparse
+    import bench as Bn
+    from oracle import vnqa_oracle as O
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd.models import FiLMAttnPretrainedStem, ObjDetectCNN
+    from videonavqa_amd.models.common import FrameLayout, NativeFeatures
+    from videonavqa_amd.stem import FrozenStem, VGGFront
+    B, T, H, Wd = 2, 35, 224, 224
+    args = argparse.Namespace(height=H, width=Wd, frames=T, channels=512, blocks=1)
+    W_vgg, W_od, W, (clip, q, v_lens, q_lens, y) = Bn.oracle_workload(args, B)
+    if ragged:
+        v_lens = torch.tensor([T, 11])
+        clip = clip * (torch.arange(T).view(1, 1, 1, 1, T) < v_lens.view(B, 1, 1, 1, 1)).float()
+    # ---- oracle (CPU, fp32) ----
+    with torch.no_grad():
+        feats_o = O.stem_forward(clip, W_vgg, W_od)                       # [B,512,14,14,T]
+        v2, q2, vl2, ql2, y2, perm_o = O.sort_batch(feats_o, q, v_lens, q_lens, y)
+        ref = O.film_attn_forward({k: v.clone() for k, v in W.items()}, v2, q2, vl2, ql2, training=True)
+    # ---- product (HIP, exact-f32 precision) ----
+    dev = torch.device("cuda", 0)
+    vgg, od = VGGFront("fp32"), ObjDetectCNN(27, 512, 1024, 0, True, True, precision="fp32")
+    vgg.load_state_dict(W_vgg)
+    od.load_state_dict(W_od, strict=False)
+    model = FiLMAttnPretrainedStem(B, 128, 70, max_num_frames=T, spatial_size=196, precision="fp32")
+    vgg, od, model = vgg.to(dev).eval(), od.to(dev).eval(), model.to(dev).train()
+    model.load_reference_tensors(W)
+    stem = FrozenStem(vgg, od, "fp32")
+    v_sorted, perm = torch.sort(v_lens, dim=0, descending=True, stable=True)
+    lay = FrameLayout(v_sorted, T, dev, perm=perm)
+    feats = stem.forward_clip(clip.to(dev), lay.img_of, lay.n_img)
+    # stem features of the first and the last valid image against the oracle's
+    for b, t in ((0, 0), (int(perm[0]), T - 1)):
+        n = int(lay.img_of[b * T + t])
+        got = K.nhwc_to_nchw(feats[n:n + 1].contiguous(), 512)[0].cpu()
+        want = feats_o[b, :, :, :, t]
+        assert float((got - want).abs().max() / want.abs().max()) < 1e-3
+    model.init_hidden()
+    with torch.no_grad():
+        out = model(NativeFeatures(feats, lay, 512, H // 16, Wd // 16), q.to(dev)[perm.to(dev)], v_sorted, q_lens[perm])
+    out_s = out.float().cpu()
+    out, ref_s = torch.empty_like(out_s), ref
+    out[perm] = out_s                                       # both back to the ORIGINAL sample order (the oracle's sort is
+    ref = torch.empty_like(ref_s)                           # not stable: equal lengths may come out in another order)
+    ref[perm_o] = ref_s
+    err = float((out - ref).abs().max() / ref.abs().max())
+    print("HIP fp32 vs oracle at 2 x 35 x 224 x 224 (ragged=%s): logits rel err %.3g" % (ragged, err))
+    assert err < 1e-3, err                                  # north star: logits within 1e-3 rel of reference
+    assert torch.equal(out.argmax(1), ref.argmax(1))        # answer-class argmax bit-exact

@@ -189,3 +189,37 @@ def test_grad_sinks_accumulate_over_two_backward_passes():
         assert float((a - b).abs().max()) <= 5e-3 * scale, float((a - b).abs().max()) / scale
     # and the second pass really added something
     assert float((g_dir[1] - g_dir[0]).abs().max()) > 1e-6 * float(g_dir[0].abs().max())
+
+
+def _first_steps(env_prio, monkeypatch, direct_prefetch=False):
+    """Losses of steps 0..3 where step 0's clip was NOT prefetched (its stem runs inline on the trunk stream) and step 0
+    immediately prefetches step 1's clip on the stem stream: the two stem passes share every intermediate buffer."""
+    from videonavqa_amd.train import Trainer
+    if env_prio is None:
+        monkeypatch.delenv("VNQA_TRUNK_PRIO", raising=False)
+    else:
+        monkeypatch.setenv("VNQA_TRUNK_PRIO", env_prio)
+    model, stem, batches = _setup()
+    tr = Trainer(model, stem, lr=1e-3)
+    losses = []
+    for i in range(4):
+        b, nb = batches[i % 3], batches[(i + 1) % 3]
+        if direct_prefetch and i == 2:
+            # a caller that prefetches by itself between steps, then hands step() a DIFFERENT clip: the stale prefetch is
+            # discarded and the inline stem must wait for it
+            tr.prefetch(batches[0][0], batches[0][2])
+        loss, _ = tr.step(*b, next_clip=nb[0], next_v_lens_cpu=nb[2])
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    return losses
+
+
+@pytest.mark.parametrize("direct", [False, True])
+def test_inline_first_step_then_prefetch_shares_no_buffers_in_flight(monkeypatch, direct):
+    """ADVICE r3 (train.py: two stems at once on shared intermediate buffers): with the trunk on its own stream the stem
+    stream used to wait only for the caller's stream, not for the stem that step 0 runs INLINE — so step 1's prefetched stem
+    overwrote step 0's intermediates.  Pipelined losses must equal the single-stream run's."""
+    ref = _first_steps("none", monkeypatch, direct)
+    for _ in range(3):          # a race shows up intermittently: repeat
+        got = _first_steps(None, monkeypatch, direct)
+        assert all(abs(a - b) <= 1e-5 * max(1.0, abs(a)) for a, b in zip(ref, got)), (ref, got)

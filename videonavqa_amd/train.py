@@ -197,6 +197,8 @@ class Trainer(object):
         self._slot = 0
         self._trunk_done = [None] * self._n_slots  # event per slot: last trunk pass that read that slot
         self._inputs_ready = None        # recorded on the CALLER's stream at step() entry: clips / labels produced so far
+        self._in_step = False            # prefetch() called from inside step() (current stream = the trunk stream) or by the caller
+        self._inline_stem_done = None    # event after a stem pass that ran INLINE on the trunk / caller's stream (shared buffers)
 
     def sync_replicas(self):
         """Rank 0's weights everywhere, INCLUDING the frozen unregistered conv1x1 layers
@@ -288,10 +290,16 @@ class Trainer(object):
         """Start the stem of an upcoming minibatch on the side stream (returns immediately)."""
         slot = (self._slot + 1) % self._n_slots
         main = torch.cuda.current_stream()
-        if self._inputs_ready is not None and self.trunk_stream is not None:
+        if self._in_step and self._inputs_ready is not None and self.trunk_stream is not None:
             self.stem_stream.wait_event(self._inputs_ready)  # the caller's stream up to this step() call (NOT the trunk stream: the
         else:                                                # stem must not wait for the previous minibatch's trunk)
-            self.stem_stream.wait_stream(main)               # clip / layout uploads issued so far
+            self.stem_stream.wait_stream(main)               # clip / layout uploads issued so far (also: prefetch() called directly)
+        if self._inline_stem_done is not None:
+            # A stem pass ran inline on the trunk stream (a step whose clip had not been prefetched: first step of an epoch,
+            # bench priming).  Only the last layer's output is per slot — every other stem buffer is shared — so this pass
+            # must not start before that one has finished.
+            self.stem_stream.wait_event(self._inline_stem_done)
+            self._inline_stem_done = None
         if self._trunk_done[slot] is not None:
             self.stem_stream.wait_event(self._trunk_done[slot])   # that slot's previous reader
         with torch.cuda.stream(self.stem_stream):
@@ -312,7 +320,11 @@ class Trainer(object):
         self._inputs_ready.record(outer)
         self.trunk_stream.wait_stream(outer)
         with torch.cuda.stream(self.trunk_stream):
-            out = self._step(clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip, next_v_lens_cpu)
+            self._in_step = True
+            try:
+                out = self._step(clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip, next_v_lens_cpu)
+            finally:
+                self._in_step = False
         outer.wait_stream(self.trunk_stream)
         for t in out:                 # (allocated on the trunk stream, consumed by the caller on its own)
             if torch.is_tensor(t):
@@ -335,7 +347,12 @@ class Trainer(object):
             if not clip.is_cuda:
                 clip = clip.to(self.stem_device, non_blocking=True)
             self._wait_upload(clip)
+            # inline stem: a discarded / stale prefetch may still be running on the stem stream and shares every intermediate
+            # buffer with this pass — wait for it, and make the next prefetch wait for this pass (event below)
+            main.wait_stream(self.stem_stream)
             native, v_sorted, perm = self.extract_features(clip, v_lens_cpu, slot=self._slot)
+            self._inline_stem_done = torch.cuda.Event()
+            self._inline_stem_done.record(main)
         self._prefetched = None
         if next_clip is not None:
             self.prefetch(next_clip, next_v_lens_cpu if next_v_lens_cpu is not None else v_lens_cpu)
