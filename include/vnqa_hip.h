@@ -35,19 +35,18 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 309
+#define VNQA_ABI_VERSION 400
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
 /* CU partition for a software pipeline of full-chip kernels (the frozen stem) against a latency-bound chain of small kernels or a
  * collective on another stream.  vnqa_stream_create_reserved: a HIP stream (hipStream_t in *stream; the caller destroys it with
  * hipStreamDestroy) whose kernels never run on `reserve_cus` of the device's CUs (a multiple of n_cu / 8, spread evenly over the
- * XCDs; 0 = an ordinary stream).  vnqa_set_persistent_reserve(n): the persistent one-workgroup-per-CU conv kernels size their
- * grids for n_cu - n CUs (initial value: env VNQA_PERSISTENT_RESERVE_CUS, default 0); vnqa_persistent_reserve() reads it back. */
+ * XCDs; 0 = an ordinary stream).  The persistent one-workgroup-per-CU conv kernels (vnqa_conv2d_c64_fwd, vnqa_conv_first_c64_fwd,
+ * vnqa_conv2d_wreg_fwd) size their grids for n_cu - n CUs when the call's descriptor carries VNQA_CONV_RESERVE_CUS(n) in `flags`:
+ * a per-call argument — the library keeps NO mutable process-wide state and reads NO environment variable. */
 int vnqa_stream_create_reserved(int32_t reserve_cus, void** stream);
 int vnqa_stream_create_masked(const uint32_t* host_mask, int32_t words, void** stream);   /* explicit mask, bit i = CU i usable */
-void vnqa_set_persistent_reserve(int32_t n);
-int32_t vnqa_persistent_reserve(void);
 
 /* ---------------------------------------------------------------------------------------
  * conv2d, stride 1, 'same' (3x3 pad 1 or 1x1), implicit GEMM on MFMA.
@@ -86,6 +85,9 @@ typedef struct vnqa_conv_desc {
                     * tiles 11 / 12); round 2: replaces a separate halo-zeroing launch per fresh conv output */
 } vnqa_conv_desc;
 #define VNQA_CONV_ZERO_HALO 1
+/* bits 8..15 of flags: the persistent conv kernels leave n CUs (a multiple of 8, <= 224) to the other streams of the process */
+#define VNQA_CONV_RESERVE_CUS(n) ((((n) < 0 ? 0 : ((n) > 224 ? 224 : (n))) / 8) << 8)
+#define VNQA_CONV_RESERVE_OF(flags) ((((flags) >> 8) & 0xff) * 8)
 
 #define VNQA_TILE_AUTO 0
 #define VNQA_TILE_256x256 1
@@ -358,7 +360,10 @@ int vnqa_zero_halo(void* y, int32_t n_img, int32_t hp, int32_t wp, int32_t c, in
  *   dbias[o]       = sum_{n,y,x} dy[n,y,x,o]                            (fp32, nullable)
  * x : padded NHWC [n_img][h+2][w+2][c_in] (halo 1), dy : padded NHWC [n_img][h+2][w+2][c_out]
  * (halo 1, ZERO halo).  workspace: fp32, vnqa_conv2d_wgrad_workspace() bytes.
+ * dtype may carry the option bit VNQA_WGRAD_FUSED_REDUCE: the last-arriving workgroup of every output tile folds the split-K
+ * slabs itself (no reduce launch; bf16, <= 8192 tiles — measured slower end to end, DESIGN 5: an A/B option, off by default).
  */
+#define VNQA_WGRAD_FUSED_REDUCE 0x100
 int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t w, int32_t c_in,
                                     int32_t c_out, int32_t taps);
 int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace,

@@ -253,28 +253,28 @@ def test_multi_hop_generator_hip_vs_torch(v_lens, q_lens, blocks, hidden):
         assert _close(grads["hip"][n], ref, 3e-4), (n, float((grads["hip"][n] - ref).abs().max()), float(ref.abs().max()))
 
 
-def test_reserved_cu_stream_runs_kernels_and_sets_persistent_grids():
+def test_reserved_cu_stream_runs_kernels_and_persistent_grids_follow_per_call():
     """vnqa_stream_create_reserved: a CU-masked stream (32 CUs left to other streams) computes the same conv as the default
-    stream; the persistent kernels' grid reservation follows and resets."""
+    stream; the persistent kernels take their CU reservation PER CALL (VNQA_CONV_RESERVE_CUS in the descriptor's flags — the
+    library keeps no process-wide setting) and compute the same result with a smaller grid."""
     from videonavqa_amd import _lib as L, kernels as K
     x = torch.zeros(2, 18, 18, 64, device="cuda", dtype=L.half_dtype())
     x[:, 1:-1, 1:-1] = torch.randn(2, 16, 16, 64, device="cuda").to(x.dtype)
     w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
     wt = K.pack_conv_weight(w, x.dtype)
     ref = K.conv2d_igemm(x, wt, relu=True)
+    assert not hasattr(L.lib(), "vnqa_set_persistent_reserve_") and L.conv_reserve_flags(32) == 4 << 8
     st = L.reserved_stream(32)
-    try:
-        assert L.lib().vnqa_persistent_reserve() == 32
-        st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            got = K.conv2d_igemm(x, wt, relu=True)
-        st.synchronize()
-        assert torch.equal(got, ref)
-    finally:
-        L.lib().vnqa_set_persistent_reserve(0)
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        got = K.conv2d_igemm(x, wt, relu=True)
+        got_c64 = K.conv2d_c64(x, wt, relu=True, reserve_cus=32)          # persistent direct conv, grid of 224 workgroups
+    st.synchronize()
+    assert torch.equal(got, ref)
+    plain_c64 = K.conv2d_c64(x, wt, relu=True)
+    assert torch.equal(got_c64, plain_c64)
     with pytest.raises(L.VnqaError):
         L.reserved_stream(8)            # not a whole share of every XCD's shader engines
-    L.lib().vnqa_set_persistent_reserve(0)
 
 
 @pytest.mark.parametrize("shape", [(280, 512, 512), (37, 70, 200), (8, 70, 4480)])

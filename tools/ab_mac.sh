@@ -6,7 +6,6 @@ for n in 0 32 64 96 128 160; do echo "C-ABI step, stem leaves $n CUs          :"
 echo "C-ABI step, 64 CUs, trunk on caller stream:"; VNQA_STEM_RESERVE_CUS=64 VNQA_TRUNK_PRIO=none run
 echo "torch / rocBLAS step                    :"; VNQA_MAC_CORE_TORCH=1 run
 echo "torch / rocBLAS step, 64 CUs            :"; VNQA_MAC_CORE_TORCH=1 VNQA_STEM_RESERVE_CUS=64 run
-echo "C-ABI, FMA sgemm                        :"; VNQA_SGEMM_FMA=1 run
 echo "C-ABI, no overlap                       :"; run --no-overlap
 echo "question encoder on the caller's stream :"; VNQA_MAC_SIDE_QUESTION=0 run
 echo "ELUs as separate passes                 :"; VNQA_MAC_ELU_FUSED=0 run

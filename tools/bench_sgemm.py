@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """vnqa_sgemm on the shapes the library issues (MAC reasoning step, out_linear, FiLM generator) against torch.matmul (rocBLAS):
-per-call time of a back-to-back chain of 200 calls.  VNQA_SGEMM_FMA=1 selects the plain-FMA kernel for the A/B."""
+per-call time of a back-to-back chain of 200 calls.  (the round-2 plain-FMA kernel it replaced was removed in round 4)."""
 import torch
 from videonavqa_amd import kernels as K
 

@@ -21,8 +21,9 @@ def run(stream, n=10):
 print("plain stream            : %.2f ms" % run(torch.cuda.Stream()))
 for r in (0, 32, 64):
     st = L.reserved_stream(r)
-    print("masked stream, reserve %2d (persistent grids %d): %.2f ms" % (r, 256 - L.lib().vnqa_persistent_reserve(), run(st)))
-L.lib().vnqa_set_persistent_reserve(0)
+    stem.reserve_cus = r          # (per-call descriptor field of the persistent kernels: the library keeps no global setting)
+    print("masked stream, reserve %2d (persistent grids %d): %.2f ms" % (r, 256 - r, run(st)))
+stem.reserve_cus = 0
 print("plain stream again      : %.2f ms" % run(torch.cuda.Stream()))
 
 import ctypes
@@ -37,9 +38,9 @@ for name, clr in (("bit 0", [0]), ("bits 0-7", range(8)), ("bits 0-31", range(32
                   ("i%16==15 (16)", [i for i in range(256) if i % 16 == 15]), ("i%32>=28 (32)", [i for i in range(256) if i % 32 >= 28]),
                   ("i%64>=56 (32)", [i for i in range(256) if i % 64 >= 56]), ("bits 0-127", range(128))):
     clr = list(clr)
-    L.lib().vnqa_set_persistent_reserve(0)
+    stem.reserve_cus = 0
     t_full = run(masked(clr))
-    L.lib().vnqa_set_persistent_reserve((len(clr) + 7) // 8 * 8)
+    stem.reserve_cus = (len(clr) + 7) // 8 * 8
     t_fit = run(masked(clr))
     print("cleared %-16s (%3d CUs): %.2f ms with 256-WG persistent grids, %.2f ms with fitted grids" % (name, len(clr), t_full, t_fit))
-L.lib().vnqa_set_persistent_reserve(0)
+stem.reserve_cus = 0

@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 309          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 400          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -52,6 +52,14 @@ class ConvDesc(ctypes.Structure):
 
 
 CONV_ZERO_HALO = 1      # vnqa_conv_desc.flags
+WGRAD_FUSED_REDUCE = 0x100     # option bit of vnqa_conv2d_wgrad's dtype argument
+
+
+def conv_reserve_flags(reserve_cus):
+    """VNQA_CONV_RESERVE_CUS(n): bits 8..15 of vnqa_conv_desc.flags — the persistent conv kernels leave n CUs (multiple of 8,
+    <= 224) to the other streams.  A per-call argument: the library keeps no process-wide setting."""
+    n = max(0, min(224, int(reserve_cus)))
+    return (n // 8) << 8
 
 
 class ConvEpilogue(ctypes.Structure):
@@ -99,8 +107,6 @@ _SIGNATURES = {
     "vnqa_last_error": (ctypes.c_char_p, []),
     "vnqa_stream_create_reserved": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_void_p)]),
     "vnqa_stream_create_masked": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(ctypes.c_void_p)]),
-    "vnqa_set_persistent_reserve": (None, [_i32]),
-    "vnqa_persistent_reserve": (_i32, []),
     "vnqa_conv2d_igemm_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_conv2d_c64_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_layernorm_fwd": (ctypes.c_int, [_vp] * 7 + [_i32, _i32, _f32, _vp]),
@@ -292,13 +298,12 @@ def stream():
 
 def reserved_stream(reserve_cus, device=None):
     """A torch stream whose kernels never run on `reserve_cus` of the chip's CUs (vnqa_stream_create_reserved; a multiple of 32 on
-    MI355X), with the persistent conv kernels' grids sized to match.  For the frozen stem when the trunk on the other stream is
+    MI355X).  The persistent conv kernels' grids are sized to match per call (FrozenStem.reserve_cus -> conv_reserve_flags).  For the frozen stem when the trunk on the other stream is
     a latency-bound chain of small kernels (MACNetwork) or a collective must start at once (N > 1)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     with torch.cuda.device(dev):
         out = ctypes.c_void_p()
         check(lib().vnqa_stream_create_reserved(int(reserve_cus), ctypes.byref(out)), "vnqa_stream_create_reserved")
-        lib().vnqa_set_persistent_reserve(int(reserve_cus))
         return torch.cuda.ExternalStream(out.value, device=dev)
 
 

@@ -2,7 +2,6 @@
 #include "vnqa_common.h"
 #include <string.h>
 #include <stdlib.h>
-#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -19,22 +18,9 @@ extern "C" int vnqa_version(void) { return VNQA_ABI_VERSION; }
 // ---- CU partition between the full-chip stem kernels and a latency-bound chain of small kernels on another stream ----------
 // A stream created by vnqa_stream_create_reserved(n) never runs on n of the chip's CUs (4 per XCD for n = 32): kernels on other
 // streams (MACNetwork's ~1 000 dependent small launches per step, an RCCL all-reduce) find those CUs free at once instead of
-// waiting for a stem workgroup that owns a whole CU's LDS / registers to retire.  vnqa_set_persistent_reserve(n) sizes the
-// persistent one-workgroup-per-CU kernels' grids to match (256 - n).
-static std::atomic<int> g_reserve{-1};
-
-extern "C" int32_t vnqa_persistent_reserve(void) {
-  int v = g_reserve.load();
-  if (v < 0) {
-    const char* e = getenv("VNQA_PERSISTENT_RESERVE_CUS");
-    v = e ? atoi(e) : 0;
-    v = v < 0 ? 0 : (v > 224 ? 224 : v);
-    g_reserve.store(v);
-  }
-  return v;
-}
-
-extern "C" void vnqa_set_persistent_reserve(int32_t n) { g_reserve.store(n < 0 ? 0 : (n > 224 ? 224 : n)); }
+// waiting for a stem workgroup that owns a whole CU's LDS / registers to retire.  The persistent one-workgroup-per-CU conv kernels
+// size their grids to match through a PER-CALL descriptor field (VNQA_CONV_RESERVE_CUS in vnqa_conv_desc.flags): the library keeps
+// no mutable global state and reads no environment variable.
 
 extern "C" int vnqa_stream_create_reserved(int32_t reserve_cus, void** stream) {
   int dev = 0, n_cu = 0;

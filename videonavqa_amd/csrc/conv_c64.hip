@@ -50,6 +50,7 @@ struct C64Args {
   // fused conv1_1 (FUSE variant): x = image as [n][H+4][W+4][4] bf16 (zero halo of 2, channel 3 zero)
   const float* w1;              // [64][27] fp32 (OIHW flattened)
   const float* b1;              // [64]
+  int reserve_cus;              // CUs the persistent grid leaves to other streams (VNQA_CONV_RESERVE_CUS in vnqa_conv_desc.flags)
 };
 
 __device__ __forceinline__ void glds16c(const char* src, char* lds_wave_base) {
@@ -787,6 +788,7 @@ int c64_fill(const vnqa_conv_desc* d, const void* x, const void* wt, const float
   a.Cy = d->c_y;
   VNQA_CHECK_ARG(d->relu == 0 || d->relu == 1, "conv (direct kernels): relu must be 0 or 1 (the ELU epilogue lives on the implicit-GEMM tiles)");
   a.relu = d->relu;
+  a.reserve_cus = VNQA_CONV_RESERVE_OF(d->flags);
   a.pool = d->pool2;
   a.tilesX = (d->w + TS - 1) / TS;
   a.tilesY = (d->h + TS - 1) / TS;
@@ -801,11 +803,10 @@ int c64_fill(const vnqa_conv_desc* d, const void* x, const void* wt, const float
 }
 
 long long c64_grid(const C64Args& a) {
-  // one persistent workgroup per CU.  VNQA_PERSISTENT_RESERVE_CUS=n leaves n CUs to the other streams for the whole
-  // life of the kernel (1.0 / 0.6 ms): a knob for multi-GPU runs, where an RCCL all-reduce launched meanwhile would
+  // one persistent workgroup per CU.  VNQA_CONV_RESERVE_CUS(n) in the descriptor's flags leaves n CUs to the other streams for
+  // the whole life of the kernel (1.0 / 0.6 ms): a knob for multi-GPU runs, where an RCCL all-reduce launched meanwhile would
   // otherwise wait for a persistent workgroup to retire before it gets its first CU.
-  const int reserve = vnqa_persistent_reserve();
-  long long grid = 256 - reserve;
+  long long grid = 256 - a.reserve_cus;
   grid = grid / a.nsplit * a.nsplit;
   if (grid > a.n_work) grid = (a.n_work / a.nsplit) * a.nsplit;
   if (grid < a.nsplit) grid = a.nsplit;

@@ -1004,8 +1004,7 @@ int resolve_tile(const ConvArgs& a, int dtype, int tile) {
   if (dtype == VNQA_BF16) {
     if (a.Cout <= 64) return VNQA_TILE_256x64;
     if (a.Cout <= 128) return VNQA_TILE_256x128;   // (128x128 is faster alone, slower when two streams co-run)
-    static const int wide_tile = [] { const char* e = getenv("VNQA_AUTO_TILE_WIDE"); return e ? atoi(e) : VNQA_TILE_256x256; }();
-    return wide_tile;       // experiment hook for the trunk's C_out >= 256 layers (end-to-end A/B of tile shapes)
+    return VNQA_TILE_256x256;       // (callers A/B other shapes through vnqa_conv_desc.tile: the library reads no environment)
   }
   return a.Cout <= 64 ? VNQA_TILE_128x64 : VNQA_TILE_128x128;
 }
@@ -1317,7 +1316,6 @@ extern "C" int vnqa_gemm_nt_grouped(const void* a_gmk, const void* b_gnk, void* 
   a.epi = VNQA_EPI_NONE; a.ring_h = 0; a.ring_w = 0;
   a.group_tiles = m_group / bm;
   int tile = dtype == VNQA_BF16 ? (n % 256 == 0 ? VNQA_TILE_256x256 : VNQA_TILE_256x128) : VNQA_TILE_128x128;
-  if (const char* e = getenv("VNQA_GROUPED_TILE")) tile = atoi(e);     // experiment hook (row tile must divide m_group)
   return conv_dispatch(a, dtype, tile, (hipStream_t)stream);
 }
 

@@ -683,7 +683,7 @@ extern "C" int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
                      int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h = 0,
-                     bool small = false);
+                     bool small = false, bool fuse_reduce = false);
 
 // the small-channel form's plan: tap groups x slices, two partial slabs per slice
 static bool small3d_ok(int c_in, int c_out, int dtype) {
@@ -696,7 +696,7 @@ static bool small3d_ok(int c_in, int c_out, int dtype) {
 static Plan small3d_plan(long long Ptot, int c_in) {
   Plan pl = make_plan_k(Ptot, 256, 256, 1, VNQA_BF16);
   const int groups = (27 + 256 / c_in - 1) / (256 / c_in);
-  static const int target_wgs = [] { const char* e = getenv("VNQA_WGRAD_SMALL_WGS"); const int v = e ? atoi(e) : 256; return v < 32 ? 32 : v; }();
+  const int target_wgs = 256;
   int slices = target_wgs / groups;                               // one workgroup per CU (128 KiB LDS): ONE full round of 256 (two rounds: the
                                                                   // slab reduce reads twice the partials for nothing; config 2 -1.2 %)
   const int max_slices = pl.ksteps_total / 8 > 0 ? pl.ksteps_total / 8 : 1;
@@ -739,6 +739,8 @@ extern "C" int vnqa_conv3d_wgrad(const void* x, const void* dy, float* dwt, floa
 extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace,
                                  int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
                                  int32_t taps, int32_t dtype, void* stream) {
+  const bool fuse_reduce = (dtype & VNQA_WGRAD_FUSED_REDUCE) != 0;      // per-call option bit (the library reads no environment)
+  dtype &= ~VNQA_WGRAD_FUSED_REDUCE;
   VNQA_CHECK_ARG(x && dy && dwt && workspace, "conv2d_wgrad: null pointer");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv2d_wgrad: bad dtype %d", dtype);
   VNQA_CHECK_ARG(taps == 9 || taps == 1, "conv2d_wgrad: taps must be 9 or 1");
@@ -746,7 +748,7 @@ extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, floa
   VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0, "conv2d_wgrad: empty problem");
   VNQA_CHECK_ARG((long long)n_img * (h + 2) * (w + 2) < (1ll << 31), "conv2d_wgrad: too many pixels");
   const Plan pl = make_plan(n_img, h, w, c_in, c_out, taps, dtype);
-  return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, taps, dtype, stream);
+  return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, taps, dtype, stream, 0, false, fuse_reduce);
 }
 
 extern "C" int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype) {
@@ -765,7 +767,8 @@ extern "C" int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void
 }
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
-                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h, bool small) {
+                     int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h, bool small,
+                     bool fuse_reduce) {
   hipStream_t st = (hipStream_t)stream;
   WgradArgs a;
   a.x = (const char*)x;
@@ -789,10 +792,9 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   a.slices = pl.slices;
   a.taps_real = taps;
   a.final = nullptr;
-  // (opt-in: measured SLOWER end to end — same-box A/B 845 vs 869 clips/s over three rounds: the agent-scope release / acquire
+  // (opt-in through the VNQA_WGRAD_FUSED_REDUCE bit of vnqa_conv2d_wgrad's dtype argument: measured SLOWER end to end — same-box A/B 845 vs 869 clips/s over three rounds: the agent-scope release / acquire
   // fences write back and invalidate L2 lines across the 8 XCDs for every workgroup, which costs more than the 20 us reduce
   // launches it saves)
-  static const bool fuse_reduce = [] { const char* e = getenv("VNQA_WGRAD_FUSED_REDUCE"); return e != nullptr && e[0] == '1'; }();
   if (fuse_reduce && !small && dtype == VNQA_BF16 && pl.slices > 1 && c_in % 4 == 0 &&
       (long long)pl.tilesCo * taps * pl.tilesCi <= 8192)
     a.final = dwt;

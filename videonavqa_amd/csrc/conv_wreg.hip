@@ -42,6 +42,7 @@ struct WregArgs {
   int tilesX, tilesY;
   int n_tiles;
   int Hyp, Wyp, y_halo;
+  int reserve_cus;     // CUs the persistent grid leaves to other streams (VNQA_CONV_RESERVE_CUS in vnqa_conv_desc.flags)
 };
 
 // LDS-DMA issued from inline asm: hipcc does not see it, so it neither drains it with a vmcnt(0) in front of unrelated LDS
@@ -411,8 +412,7 @@ int wreg_launch_(WregArgs a, hipStream_t stream) {
     }
     attr_set = true;
   }
-  const int reserve = vnqa_persistent_reserve();
-  int grid = (256 - reserve) & ~7;
+  int grid = (256 - a.reserve_cus) & ~7;
   if (grid > a.n_tiles) grid = a.n_tiles;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, a);
   VNQA_CHECK_LAUNCH();
@@ -463,6 +463,7 @@ extern "C" int vnqa_conv2d_wreg_fwd(const vnqa_conv_desc* d, const void* x, cons
   a.relu = d->relu;
   const int ho = d->pool2 ? d->h / 2 : d->h, wo = d->pool2 ? d->w / 2 : d->w;
   a.y_halo = d->y_halo;
+  a.reserve_cus = VNQA_CONV_RESERVE_OF(d->flags);
   a.Hyp = ho + 2 * d->y_halo;
   a.Wyp = wo + 2 * d->y_halo;
   hipStream_t st = (hipStream_t)stream;

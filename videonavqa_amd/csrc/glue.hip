@@ -39,127 +39,7 @@ struct SgemmArgs {
   int relu, accumulate;
 };
 
-// 64x64 output tile, 16-deep K chunks through LDS, 256 threads x (4x4) outputs; the next chunk's global loads are issued
-// before the current chunk's FMAs (register double buffer).  gridDim.z > 1: split-K — slice z covers K range
-// [z * k_per_slice, ...) and writes its raw partial tile to `partial` [z][M][N]; sgemm_finish_kernel applies the epilogue.
-__global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __restrict__ partial, int k_per_slice) {
-  __shared__ float As[16][64 + 4];
-  __shared__ float Bs[16][64 + 4];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const int kb = blockIdx.z * k_per_slice;
-  const int ke = (kb + k_per_slice < p.K) ? kb + k_per_slice : p.K;
-  float acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  // Loader roles follow the operand's contiguous direction so that a wave's loads fall into whole cache lines:
-  //   A k-contiguous (a_cs == 1: x of x W^T):  k = tid & 15, rows m = (tid >> 4) + 16 r
-  //   A m-contiguous (a_rs == 1: dY of dY^T X): m = tid & 63, k = (tid >> 6) + 4 r
-  //   B n-contiguous (b_cs == 1: W of x W):     n = tid & 63, k = (tid >> 6) + 4 r
-  //   B k-contiguous (b_rs == 1: W of x W^T):   k = tid & 15, columns n = (tid >> 4) + 16 r
-  const bool a_kfast = (p.a_cs == 1) || (p.a_rs != 1);
-  const bool b_kfast = (p.b_rs == 1) && (p.b_cs != 1);
-  const int t15 = threadIdx.x & 15, t4 = threadIdx.x >> 4, t63 = threadIdx.x & 63, t6 = threadIdx.x >> 6;
-  long long a_base[4];
-  bool a_ok[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = m0 + (a_kfast ? t4 + 16 * r : t63);
-    int row = m;
-    a_ok[r] = m < p.M;
-    if (a_ok[r] && p.a_rows != nullptr) {
-      row = p.a_rows[m];
-      a_ok[r] = row >= 0;
-    }
-    a_base[r] = (long long)row * p.a_rs;
-  }
-  float ra[4], rb[4];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = k0 + (a_kfast ? t15 : t6 + 4 * r);
-      float v = 0.f;
-      if (a_ok[r] && k < ke) {
-        const long long off = a_base[r] + (long long)k * p.a_cs;
-        v = p.A[off];
-        if (p.a_mask != nullptr && !(p.a_mask[off] > 0.f)) v = 0.f;
-      }
-      ra[r] = v;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = k0 + (b_kfast ? t15 : t6 + 4 * r);
-      const int n = n0 + (b_kfast ? t4 + 16 * r : t63);
-      rb[r] = (k < ke && n < p.N) ? p.B[(long long)k * p.b_rs + (long long)n * p.b_cs] : 0.f;
-    }
-  };
-  fetch(kb);
-  for (int k0 = kb; k0 < ke; k0 += 16) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (a_kfast) As[t15][t4 + 16 * r] = ra[r];
-      else As[t6 + 4 * r][t63] = ra[r];
-      if (b_kfast) Bs[t15][t4 + 16 * r] = rb[r];
-      else Bs[t6 + 4 * r][t63] = rb[r];
-    }
-    __syncthreads();
-    if (k0 + 16 < ke) fetch(k0 + 16);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= p.M) continue;
-    if (partial != nullptr) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + tx * 4 + j;
-        if (n < p.N) partial[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[i][j];
-      }
-      continue;
-    }
-    int row = m;
-    if (p.c_rows != nullptr) {
-      row = p.c_rows[m];
-      if (row < 0) continue;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= p.N) continue;
-      float v = acc[i][j];
-      if (p.bias != nullptr) v += p.bias[n];
-      if (p.bias2 != nullptr) v += p.bias2[n];
-      if (p.addend != nullptr) v += p.addend[(long long)m * p.ldc + n];
-      float* dst = p.C + (long long)row * p.ldc + n;
-      if (p.accumulate) v += *dst;
-      if (p.relu) v = fmaxf(v, 0.f);
-      *dst = v;
-      if (p.out2 != nullptr) {
-        float w = v;
-        if (p.out2_col != nullptr) w *= p.out2_col[n];
-        if (p.out2_mul != nullptr) w *= p.out2_mul[(long long)m * p.ldc + n];
-        p.out2[(long long)row * p.ldc + n] = w;
-      }
-    }
-  }
-}
-
-// The same GEMM on the exact-f32 matrix core (v_mfma_f32_32x32x2_f32: each product is an fmaf into the fp32 accumulator, no
+// The fp32 GEMM on the exact-f32 matrix core (v_mfma_f32_32x32x2_f32: each product is an fmaf into the fp32 accumulator, no
 // reduced-precision step anywhere).  Made for the products this library actually issues — [a few hundred rows] x [512] over
 // K = 512 (MACNetwork's reasoning step: 216 of them per training step), out_linear, the FiLM generators — which are latency
 // problems, not throughput problems: a workgroup is 8 waves laid out WM x WN x WK; every wave owns one 32 x 32 output tile
@@ -167,7 +47,8 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SgemmArgs p, float* __
 // operand is K-contiguous — any permutation of K is valid as long as A and B use the same one), and the WK partial tiles
 // are summed through LDS in a fixed order (deterministic).  <1,1,8>: 32 x 32 tile, K split 8 ways — [280,512]x[512,512] is
 // 144 workgroups of 8 waves with 64 K-values each, i.e. the whole chip for ~32 MFMAs per wave.  <2,2,2>: 64 x 64 tiles for
-// larger outputs.  Same SgemmArgs contract / epilogue / split-K partial mode as sgemm_kernel.
+// larger outputs.  gridDim.z > 1: split-K — slice z covers K range [z * k_per_slice, ...) and writes its raw partial tile to
+// `partial` [z][M][N]; sgemm_finish_kernel applies the epilogue.
 template <int WM, int WN, int WK>
 __device__ __forceinline__ void sgemm_mfma_body(const SgemmArgs& p, float* __restrict__ partial, int k_per_slice, int slice,
                                                 int a_vec, int b_vec) {
@@ -325,15 +206,6 @@ __global__ void __launch_bounds__(512) sgemm_mfma_batch_kernel(const SgemmBatchA
   sgemm_mfma_body<1, 1, 8>(p, nullptr, (p.K + 15) / 16 * 16, 0, pp.a_vec[blockIdx.z], pp.b_vec[blockIdx.z]);
 }
 
-// one launch of the GEMM proper (z = split-K slices): the MFMA form unless VNQA_SGEMM_FMA=1 asks for the FMA kernel
-static bool sgemm_use_fma() {
-  static const int v = [] {
-    const char* e = getenv("VNQA_SGEMM_FMA");
-    return (e != nullptr && e[0] == '1') ? 1 : 0;
-  }();
-  return v != 0;
-}
-
 // float4 operand loads along K: contiguous K, 16-byte aligned rows
 static int sgemm_a_vec(const SgemmArgs& p, int kps) {
   return (p.a_cs == 1 && p.a_rs % 4 == 0 && ((uintptr_t)p.A & 15) == 0 && kps % 8 == 0 &&
@@ -343,11 +215,8 @@ static int sgemm_b_vec(const SgemmArgs& p, int kps) {
   return (p.b_rs == 1 && p.b_cs % 4 == 0 && ((uintptr_t)p.B & 15) == 0 && kps % 8 == 0) ? 1 : 0;
 }
 
+// one launch of the GEMM proper (z = split-K slices)
 static void sgemm_launch(const SgemmArgs& p, float* partial, int kps, int nsl, hipStream_t st) {
-  if (sgemm_use_fma()) {
-    hipLaunchKernelGGL(sgemm_kernel, dim3((p.N + 63) / 64, (p.M + 63) / 64, nsl), dim3(256), 0, st, p, partial, kps);
-    return;
-  }
   const int a_vec = sgemm_a_vec(p, kps), b_vec = sgemm_b_vec(p, kps);
   const long long tiles32 = (long long)((p.M + 31) / 32) * ((p.N + 31) / 32);
   if (tiles32 <= 1024)
@@ -552,20 +421,12 @@ __global__ void bn_running_update_kernel(const float* __restrict__ mean, const f
 // Split-K plan: few output tiles but a long K (out_linear: 8 x 70 outputs over K = 4480; the FiLM generator's d h:
 // 280 x 128 over K = 1024) would leave the chip to a handful of workgroups walking K serially at memory latency per chunk.
 static int sgemm_slices(int m, int n, int k) {
-  if (!sgemm_use_fma()) {
-    // MFMA form: a workgroup already splits its K range over 8 waves; more slices only when the output has too few
-    // 32 x 32 tiles to occupy the chip AND every slice still gets >= 128 K-values (16 per wave)
-    const long long tiles = (long long)((m + 31) / 32) * ((n + 31) / 32);
-    if (tiles >= 96 || k < 512) return 1;
-    int s = (int)((192 + tiles - 1) / tiles);
-    const int max_s = k / 128;
-    s = s > max_s ? max_s : s;
-    return s < 1 ? 1 : s;
-  }
-  const int tiles = ((m + 63) / 64) * ((n + 63) / 64);
-  if (tiles >= 64 || k < 256) return 1;
-  int s = (128 + tiles - 1) / tiles;
-  const int max_s = k / 64;
+  // a workgroup already splits its K range over 8 waves; more slices only when the output has too few 32 x 32 tiles to occupy
+  // the chip AND every slice still gets >= 128 K-values (16 per wave)
+  const long long tiles = (long long)((m + 31) / 32) * ((n + 31) / 32);
+  if (tiles >= 96 || k < 512) return 1;
+  int s = (int)((192 + tiles - 1) / tiles);
+  const int max_s = k / 128;
   s = s > max_s ? max_s : s;
   return s < 1 ? 1 : s;
 }
@@ -628,7 +489,7 @@ static int sgemm_run(const float* a, const float* b, float* c, const float* bias
 extern "C" int vnqa_sgemm_batch(const vnqa_sgemm_problem* problems, int32_t count, void* stream) {
   VNQA_CHECK_ARG(problems != nullptr && count >= 1 && count <= VNQA_SGEMM_BATCH_MAX, "sgemm_batch: 1..%d problems", VNQA_SGEMM_BATCH_MAX);
   static_assert(VNQA_SGEMM_BATCH_MAX == SGEMM_BATCH, "header and kernel batch limits");
-  bool one_launch = !sgemm_use_fma() && count > 1;
+  bool one_launch = count > 1;
   int gx = 0, gy = 0;
   for (int i = 0; i < count; ++i) {
     const vnqa_sgemm_problem& q = problems[i];

@@ -268,7 +268,8 @@ def ring_assemble(top, bottom, left, right, n, H, W):
     return ring
 
 
-def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None, shape4=False):
+def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None, shape4=False,
+               reserve_cus=0):
     """Persistent direct conv for Cin == 64 (bf16, 3x3): same tensors as conv2d_igemm."""
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2, Wp - 2
@@ -277,15 +278,17 @@ def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
-    d = L.ConvDesc(L.BF16, N, H, W, Cin, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 2 if shape4 else 0, 0, 0)
+    d = L.ConvDesc(L.BF16, N, H, W, Cin, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 2 if shape4 else 0, 0, 0,
+                   L.conv_reserve_flags(reserve_cus))
     L.check(L.lib().vnqa_conv2d_c64_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                         L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_c64_fwd")
     return out
 
 
-def _wreg_desc(x, wt, pool2, relu, out_c, y_halo):
+def _wreg_desc(x, wt, pool2, relu, out_c, y_halo, reserve_cus=0):
     N, Hp, Wp, Cin = x.shape
-    return L.ConvDesc(L.BF16, N, Hp - 2, Wp - 2, Cin, wt.shape[0], out_c, 9, 1, y_halo, int(relu), 1 if pool2 else 0, 0, 0, 0)
+    return L.ConvDesc(L.BF16, N, Hp - 2, Wp - 2, Cin, wt.shape[0], out_c, 9, 1, y_halo, int(relu), 1 if pool2 else 0, 0, 0, 0,
+                      L.conv_reserve_flags(reserve_cus))
 
 
 def conv2d_wreg_supported(x, wt, pool2=False, y_halo=1):
@@ -296,7 +299,8 @@ def conv2d_wreg_supported(x, wt, pool2=False, y_halo=1):
     return bool(L.lib().vnqa_conv2d_wreg_supported(ctypes.byref(d)))
 
 
-def conv2d_wreg(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None, y_halo=1):
+def conv2d_wreg(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None, y_halo=1,
+                reserve_cus=0):
     """Weights-stationary-in-registers persistent direct 3x3 conv (csrc/conv_wreg.hip): same tensors as conv2d_igemm
     (x padded NHWC halo 1, wt [c_out, 9, c_in] K-major), for conv1_2 / conv2_1 / conv2_2 shaped layers."""
     N, Hp, Wp, Cin = x.shape
@@ -307,7 +311,7 @@ def conv2d_wreg(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post
     if out is None:
         out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
     assert out.shape[:3] == (N, Ho + 2 * y_halo, Wo + 2 * y_halo)
-    d = _wreg_desc(x, wt, pool2, relu, out.shape[-1], y_halo)
+    d = _wreg_desc(x, wt, pool2, relu, out.shape[-1], y_halo, reserve_cus)
     L.check(L.lib().vnqa_conv2d_wreg_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                          L.ptr(post_shift), L.ptr(out), L.stream()), "vnqa_conv2d_wreg_fwd")
     return out
@@ -402,7 +406,8 @@ def clip_to_nhwc4(clip, img_of, n_img, out=None):
     return out
 
 
-def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None):
+def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None,
+                   reserve_cus=0):
     """conv(3->64)+ReLU fused into the following C_in = 64 conv (see vnqa_conv_first_c64_fwd).  img4 from clip_to_nhwc4;
     w1/b1 the first conv's fp32 OIHW weights and bias; wt/bias/... as conv2d_c64."""
     N, Hp4, Wp4, c4 = img4.shape
@@ -412,7 +417,8 @@ def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_sc
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=img4.dtype, device=img4.device)
-    d = L.ConvDesc(L.BF16, N, H, W, 64, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0, 0)
+    d = L.ConvDesc(L.BF16, N, H, W, 64, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0, 0,
+                   L.conv_reserve_flags(reserve_cus))
     L.check(L.lib().vnqa_conv_first_c64_fwd(ctypes.byref(d), L.ptr(img4), L.ptr(w1.detach().float().contiguous()),
                                             L.ptr(b1.detach().float().contiguous()), L.ptr(wt), L.ptr(bias),
                                             L.ptr(post_scale), L.ptr(post_shift), L.ptr(out), L.stream()),
@@ -513,6 +519,11 @@ def workspace(nbytes, device):
     return buf
 
 
+# A/B option of the weight-gradient kernel, passed PER CALL in its dtype argument (the library itself reads no environment):
+# VNQA_WGRAD_FUSED_REDUCE=1 folds the split-K slabs in the kernel's tail instead of a reduce launch (-2.5 % end to end)
+_WGRAD_OPTS = L.WGRAD_FUSED_REDUCE if os.environ.get("VNQA_WGRAD_FUSED_REDUCE", "0") == "1" else 0
+
+
 def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None):
     """x, dy: padded NHWC (halo 1, same N/H/W). Returns (dwt fp32 [Cout][taps][Cin], dbias fp32 [Cout])."""
     N, Hp, Wp, Cin = x.shape
@@ -526,7 +537,7 @@ def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None):
         dbias = dbias_out if (dbias_out is not None and dbias_out.numel() == Cout) else \
             torch.empty((Cout,), dtype=torch.float32, device=x.device)
     L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwt), L.ptr(dbias), L.ptr(ws), N, h, w, Cin, Cout,
-                                      taps, L.dtype_id(x.dtype), L.stream()), "vnqa_conv2d_wgrad")
+                                      taps, L.dtype_id(x.dtype) | _WGRAD_OPTS, L.stream()), "vnqa_conv2d_wgrad")
     return dwt, dbias
 
 

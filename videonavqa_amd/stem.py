@@ -83,6 +83,10 @@ class FrozenStem(object):
         self.composed = None
         self.first = None
         self._bufs = {}
+        # CUs the persistent one-workgroup-per-CU kernels (fused conv1, C_in = 64 direct conv, weights-in-registers conv) leave to
+        # other streams, passed with every call (vnqa_conv_desc.flags): the Trainer sets it to its stem stream's CU reservation;
+        # VNQA_PERSISTENT_RESERVE_CUS is the stand-alone A/B knob (8: -12 % on one GPU; multi-GPU investigation)
+        self.reserve_cus = int(os.environ.get("VNQA_PERSISTENT_RESERVE_CUS", "0"))
         self.timing = None   # bench hook: list collecting (start event, end event, FLOPs, kernel) of the C_out = 512 stem launches
         if vgg is not None:
             f = vgg.features
@@ -285,7 +289,7 @@ class FrozenStem(object):
             if "wt_rows" in ly and K.conv2d_wreg_supported(x, ly["wt_rows"], pool2=ly["pool"], y_halo=yh):
                 x = K.conv2d_wreg(x, ly["wt_rows"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                   post_scale=post[0] if post else None, post_shift=post[1] if post else None,
-                                  out=out, y_halo=yh)
+                                  out=out, y_halo=yh, reserve_cus=self.reserve_cus)
             elif "wt_ps" in ly and yh == 1 and self._ps_ok(h, w, ly["pool"]):
                 kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)      # (one entry per kernel SYMBOL, as rocprofv3 lists them)
                 x = K.conv2d_igemm(x, ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
@@ -294,7 +298,8 @@ class FrozenStem(object):
             elif tile is None:
                 # C_in = 64 layers (conv1_2, conv2_1): persistent direct conv with LDS-resident weights
                 x = K.conv2d_c64(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
-                                 post_scale=post[0] if post else None, post_shift=post[1] if post else None, out=out)
+                                 post_scale=post[0] if post else None, post_shift=post[1] if post else None, out=out,
+                                 reserve_cus=self.reserve_cus)
             else:
                 x = K.conv2d_igemm(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                    post_scale=post[0] if post else None, post_shift=post[1] if post else None,
@@ -327,7 +332,7 @@ class FrozenStem(object):
             for n0 in range(0, n_img, step):
                 K.conv_first_c64(img4[n0:n0 + step], self.first[0], self.first[1], ly["wt"], bias=ly["bias"], relu=ly["relu"],
                                  pool2=ly["pool"], post_scale=post[0] if post else None,
-                                 post_shift=post[1] if post else None, out=out[n0:n0 + step])
+                                 post_shift=post[1] if post else None, out=out[n0:n0 + step], reserve_cus=self.reserve_cus)
             x = out
             x = self._run(x, self.layers_vgg[1:], "vgg", first_index=1)
         else:

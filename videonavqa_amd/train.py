@@ -175,8 +175,9 @@ class Trainer(object):
                 self.stem_reserve_cus = 0
         if self.stem_reserve_cus == 0:
             self.stem_stream = torch.cuda.Stream(priority=prio)
-            if stem is not None and self.fp.flat.is_cuda:
-                L.lib().vnqa_set_persistent_reserve(0)       # (process-wide: the most recently built Trainer's setting holds)
+        elif stem is not None:
+            # the persistent conv kernels size their grids for the masked stream's CUs: a per-call descriptor field of THIS stem
+            stem.reserve_cus = max(int(getattr(stem, "reserve_cus", 0)), self.stem_reserve_cus)
         # The trunk (the step's dependent chain: question LSTMs, FiLM blocks, attention tail, backward, Adam) runs on its own
         # HIGH-priority stream by default: its kernels are dispatched ahead of the co-running stem's whenever both have
         # workgroups pending, so the chain finishes sooner and the stem fills what is left (same-box A/B, 4 rounds each:
