@@ -294,9 +294,7 @@ def bench_cnn3d(args):
         x, y = batches[i % len(batches)]
         loss = ops.cross_entropy(model(x), y, reduction="sum")
         loss.backward()
-        fp.step_count += 1
-        K.clip_adam_step(fp.flat, fp.grad, fp.m, fp.v, fp.partial, fp.step_count, 1e-4, 1e30)
-        fp.mark_zeroed()
+        fp.clip_adam_step(1e-4, 1e30)
         return loss
     for i in range(args.warmup):
         step(i)

@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 400
+#define VNQA_ABI_VERSION 401
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -699,12 +699,15 @@ int vnqa_mac_core_wgrad(const vnqa_mac_wgrad* w, void* stream);
  *                         vnqa_l2norm_blocks(n)); deterministic two-stage reduction
  *   vnqa_clip_adam      : coef = min(1, clip/(sqrt(sum partial)+1e-6)); g*=coef; Adam update of
  *                         p, m, v; g = 0.  step = 1-based step count (bias correction).
+ *                         overflow_count (optional device int32): loss-scaled training (fp16 storage) — when the gradient
+ *                         norm is not finite the update is SKIPPED (p, m, v untouched, g zeroed) and *overflow_count is
+ *                         incremented; the caller reads it back asynchronously to lower its loss scale.
  */
 int32_t vnqa_l2norm_blocks(int64_t n);
 int vnqa_l2norm_partial(const float* g, int64_t n, float* partial, void* stream);
 int vnqa_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const float* partial,
                    int32_t n_partial, float clip, float lr, float beta1, float beta2, float eps,
-                   int32_t step, void* stream);
+                   int32_t step, int32_t* overflow_count, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * VideoOnlyCNN3D (models/v_only_cnn3d.py:13-37,59-81) — csrc/cnn3d.hip.  16-bit storage format only.

@@ -223,3 +223,48 @@ def test_inline_first_step_then_prefetch_shares_no_buffers_in_flight(monkeypatch
     for _ in range(3):          # a race shows up intermittently: repeat
         got = _first_steps(None, monkeypatch, direct)
         assert all(abs(a - b) <= 1e-5 * max(1.0, abs(a)) for a, b in zip(ref, got)), (ref, got)
+
+
+def test_clip_adam_skips_non_finite_gradients_and_counts_them():
+    """Loss-scaled (fp16 storage) training: with an overflow counter the fused kernel skips an update whose gradient norm is
+    not finite — parameters and moments untouched, gradients zeroed, counter incremented — and behaves as before otherwise."""
+    from videonavqa_amd import kernels as K
+    torch.manual_seed(2)
+    n = 50000
+    p, g = torch.randn(n, device="cuda"), torch.randn(n, device="cuda")
+    m, v, partial = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(1024, device="cuda")
+    count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    p0 = p.clone()
+    for bad in (float("inf"), float("nan")):
+        g.normal_()
+        g[1234] = bad
+        K.clip_adam_step(p, g, m, v, partial, 1, 1e-3, 1.0, overflow_count=count)
+        assert torch.equal(p, p0) and float(m.abs().max()) == 0 and float(v.abs().max()) == 0
+        assert float(g.abs().max()) == 0
+    assert int(count) == 2
+    g.normal_()
+    ref_p, ref_g, ref_m, ref_v = p.clone(), g.clone(), m.clone(), v.clone()
+    K.clip_adam_step(ref_p, ref_g, ref_m, ref_v, partial, 1, 1e-3, 1.0)               # no counter: the plain kernel
+    K.clip_adam_step(p, g, m, v, partial, 1, 1e-3, 1.0, overflow_count=count)
+    assert torch.equal(p, ref_p) and torch.equal(m, ref_m) and torch.equal(v, ref_v) and int(count) == 2
+
+
+def test_dynamic_loss_scale_halves_after_overflow_and_grows_when_clean():
+    from videonavqa_amd.models import common as C
+    from videonavqa_amd.train import DynamicLossScale
+    try:
+        s = DynamicLossScale("cuda", init=1024.0, growth_interval=3)
+        assert C.grad_scale_of(torch.float16) == 1024.0 and C.grad_scale_of(torch.bfloat16) == 1.0
+        s.count += 1                       # what the kernel does on an overflowed step
+        seen = 0
+        for _ in range(4):                 # the read-back is asynchronous: observed within a couple of steps
+            torch.cuda.synchronize()
+            seen += s.after_step()
+        assert seen == 1 and s.skipped_steps == 1
+        assert s.scale in (512.0, 1024.0)  # halved once, possibly doubled again by 3 clean steps since
+        for _ in range(8):
+            torch.cuda.synchronize()
+            s.after_step()
+        assert s.scale >= 1024.0 and C.grad_scale_of(torch.float16) == s.scale
+    finally:
+        C.set_fp16_loss_scale(C.FP16_GRAD_SCALE)

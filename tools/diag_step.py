@@ -39,9 +39,7 @@ def main():
         loss = tr.loss_fn(logits, y[perm.to(dev)])
         loss.backward()
         tick("step %d: backward done" % it, t0)
-        tr.fp.step_count += 1
-        from videonavqa_amd import kernels as K
-        K.clip_adam_step(tr.fp.flat, tr.fp.grad, tr.fp.m, tr.fp.v, tr.fp.partial, tr.fp.step_count, 1e-4, 1.0)
+        tr.fp.clip_adam_step(1e-4, 1.0)          # (clip + Adam + zero_grad AND the gradient sinks' reset)
         tick("step %d: adam done, loss %.4f" % (it, float(loss)), t0)
 
 

@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 400          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 401          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -202,7 +202,7 @@ _SIGNATURES = {
     "vnqa_mac_read_accum": (ctypes.c_int, [_vp] * 7 + [_i32] * 6 + [_vp]),
     "vnqa_l2norm_blocks": (_i32, [_i64]),
     "vnqa_l2norm_partial": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
-    "vnqa_clip_adam": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp]),
+    "vnqa_clip_adam": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "vnqa_conv3d_wgrad_workspace": (_i64, [_i32] * 6),
     "vnqa_conv3d_wgrad": (ctypes.c_int, [_vp] * 5 + [_i32] * 7 + [_vp]),
     "vnqa_gemm_nt_workspace": (_i64, [_i32, _i32, _i32, _i32]),

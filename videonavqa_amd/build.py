@@ -15,7 +15,24 @@ LIB = os.path.join(LIBDIR, "libvnqa_hip.so")
 # The same sources with -DVNQA_H16_IS_F16: the library's 16-bit storage format is IEEE fp16 instead of bf16
 # (csrc/vnqa_common.h); selected by precision='fp16' / VNQA_HALF=f16 on the Python side.
 LIB_F16 = os.path.join(LIBDIR, "libvnqa_hip_f16.so")
-VARIANTS = {"bf16": (LIB, [], "libvnqa_hip"), "f16": (LIB_F16, ["-DVNQA_H16_IS_F16"], "libvnqa_hip_f16")}
+# Host-side AddressSanitizer build (sanitizer row): the same sources with -fsanitize=address on the HOST code only
+# (-fno-gpu-sanitize: device code is compiled as usual — GPU ASan / xnack+ code objects are not available on this pool);
+# tests/test_capi_asan.py drives every entry point's argument checks through it on the CPU box.  Never loaded by the product.
+LIB_ASAN = os.path.join(LIBDIR, "libvnqa_hip_asan.so")
+VARIANTS = {"bf16": (LIB, [], "libvnqa_hip"), "f16": (LIB_F16, ["-DVNQA_H16_IS_F16"], "libvnqa_hip_f16"),
+            "asan": (LIB_ASAN, ["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan", "-g", "-fno-omit-frame-pointer"],
+                     "libvnqa_hip_asan")}
+
+
+def asan_runtime():
+    """Path of the shared ASan runtime the 'asan' variant links against (LD_PRELOAD it into the test interpreter)."""
+    out = subprocess.check_output([os.path.join(os.path.dirname(HIPCC), "..", "lib", "llvm", "bin", "clang"),
+                                   "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    if not os.path.isabs(out):
+        import glob
+        cand = glob.glob("/opt/rocm*/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
+        out = cand[0] if cand else out
+    return out
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = (["-DVNQA_DIAG_SKIP_DMA"] if os.environ.get("VNQA_DIAG") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-Wno-unused-result", "-I", os.path.join(HERE, "..", "include")]
@@ -81,7 +98,8 @@ def build(force=False, verbose=True, variant="bf16"):
                 if failed:
                     raise RuntimeError("hipcc failed on %s" % ", ".join(failed))
                 tmp_lib = os.path.join(tmpdir, stem_name + ".so")
-                subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs)
+                link_extra = ["-fsanitize=address", "-fno-gpu-sanitize", "-shared-libsan"] if variant == "asan" else []
+                subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + link_extra + objs)
                 if variant == "bf16":
                     for obj in objs:           # keep the objects next to the library (inspection: llvm-objdump)
                         os.replace(obj, os.path.join(LIBDIR, os.path.basename(obj)))

@@ -1224,6 +1224,7 @@ extern "C" int vnqa_pack_conv_weight_tiled(const float* w_oihw, int32_t c_out, i
 }
 
 extern "C" int64_t vnqa_gemm_nt_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
   const int bk = dtype == VNQA_BF16 ? 64 : 32;
   const int bm = dtype == VNQA_BF16 ? 256 : 128;
   const int tiles = ((m + bm - 1) / bm) * ((n + 127) / 128);

@@ -671,6 +671,7 @@ Plan make_plan_k(long long Ptot, int c_in, int c_out, int taps, int dtype, long 
 
 extern "C" int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t w, int32_t c_in,
                                                int32_t c_out, int32_t taps) {
+  if (n_img <= 0 || h <= 0 || w <= 0 || c_in <= 0 || c_out <= 0 || taps <= 0) return 0;     // (empty problem: the call itself is rejected)
   // sized for the larger (f32: smaller K-step -> never fewer slices than bf16) of both dtypes
   int64_t need = 0;
   for (int dt = 0; dt < 2; ++dt) {
@@ -709,6 +710,7 @@ static Plan small3d_plan(long long Ptot, int c_in) {
 }
 
 extern "C" int64_t vnqa_conv3d_wgrad_workspace(int32_t n_img, int32_t d, int32_t h, int32_t w, int32_t c_in, int32_t c_out) {
+  if (n_img <= 0 || d <= 0 || h <= 0 || w <= 0 || c_in <= 0 || c_out <= 0) return 0;
   int64_t need = 0;
   if (small3d_ok(c_in, c_out, VNQA_BF16)) {
     const Plan pl = small3d_plan((long long)n_img * (d + 2) * (h + 2) * (w + 2), c_in);
@@ -752,6 +754,7 @@ extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, floa
 }
 
 extern "C" int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype) {
+  if (m <= 0 || n <= 0 || k <= 0) return 0;
   const Plan pl = make_plan_k(k, n, m, 1, dtype);
   return ((int64_t)pl.slices * m * n + (int64_t)pl.colsum_blocks * m) * 4;
 }

@@ -30,7 +30,8 @@ __global__ void l2norm_partial_kernel(const float* __restrict__ g, long long n, 
 
 __global__ void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, long long n, const float* __restrict__ partial, int n_partial,
-                                 float clip, float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2) {
+                                 float clip, float step_size, float beta1, float beta2, float eps, float inv_sqrt_bc2,
+                                 int* __restrict__ overflow_count) {
   __shared__ float s_coef;
   if (threadIdx.x < 64) {
     float t = 0.f;
@@ -38,11 +39,18 @@ __global__ void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g, f
     t = wave_reduce_sum(t);
     if (threadIdx.x == 0) {
       const float c = clip / (sqrtf(t) + 1e-6f);
-      s_coef = c < 1.f ? c : 1.f;
+      // loss-scaled (fp16 storage) training: a non-finite gradient norm means the scale overflowed somewhere in the backward
+      // pass — every block sees the same partials and takes the same decision: SKIP the update (coef = -1), still zero g
+      s_coef = (overflow_count != nullptr && !(t <= 3.0e38f)) ? -1.f : (c < 1.f ? c : 1.f);
     }
   }
   __syncthreads();
   const float coef = s_coef;
+  if (coef < 0.f) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(overflow_count, 1);      // the host reads it back asynchronously
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) g[i] = 0.f;
+    return;
+  }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
@@ -74,14 +82,14 @@ extern "C" int vnqa_l2norm_partial(const float* g, int64_t n, float* partial, vo
 
 extern "C" int vnqa_clip_adam(float* p, float* g, float* m, float* v, int64_t n, const float* partial,
                               int32_t n_partial, float clip, float lr, float beta1, float beta2, float eps,
-                              int32_t step, void* stream) {
+                              int32_t step, int32_t* overflow_count, void* stream) {
   VNQA_CHECK_ARG(p && g && m && v && partial && n > 0 && n_partial > 0 && step >= 1, "clip_adam: bad arguments");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   long long blocks = (n + 255) / 256;
   blocks = blocks > 4096 ? 4096 : blocks;
   hipLaunchKernelGGL(clip_adam_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n,
-                     partial, n_partial, clip, (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)));
+                     partial, n_partial, clip, (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), (int*)overflow_count);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -584,14 +584,15 @@ def gemm_tn(a, b, out=None):
     return out
 
 
-def clip_adam_step(p, g, m, v, partial, step, lr, clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
-    """Fused clip_grad_norm + Adam + zero_grad on flat fp32 buffers (in place)."""
+def clip_adam_step(p, g, m, v, partial, step, lr, clip=1.0, beta1=0.9, beta2=0.999, eps=1e-8, overflow_count=None):
+    """Fused clip_grad_norm + Adam + zero_grad on flat fp32 buffers (in place).  overflow_count (device int32 [1], loss-scaled
+    fp16 training): a non-finite gradient norm skips the update on the device and increments it."""
     n = p.numel()
     nb = L.lib().vnqa_l2norm_blocks(n)
     assert partial.numel() >= nb
     L.check(L.lib().vnqa_l2norm_partial(L.ptr(g), n, L.ptr(partial), L.stream()), "vnqa_l2norm_partial")
     L.check(L.lib().vnqa_clip_adam(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), n, L.ptr(partial), nb, clip, lr,
-                                   beta1, beta2, eps, step, L.stream()), "vnqa_clip_adam")
+                                   beta1, beta2, eps, step, L.ptr(overflow_count), L.stream()), "vnqa_clip_adam")
 
 
 def lstm_seq_fwd(xg, w_hh, q_lens_i32, h0, c0, n_rep, S):

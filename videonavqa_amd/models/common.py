@@ -42,11 +42,19 @@ def compute_dtype(precision):
 # Loss scale of the fp16-storage precision: the activation gradients that enter the conv trunk from the attention tail are
 # 1e-5 .. 1e-7 here — at or below fp16's normal range (6.1e-5) — so the tail's backward kernel emits them multiplied by
 # 2^10 (exact) and every fp32 result computed from them (weight / bias / gamma / beta gradients) is divided by it again.
+# 2^10 is the INITIAL value: train.DynamicLossScale (owned by the Trainer) halves it when the fused clip+Adam kernel reports a
+# non-finite gradient norm (that step's update is skipped on the device) and doubles it after a run of clean steps.
 FP16_GRAD_SCALE = 1024.0
+_LOSS_SCALE = {"fp16": FP16_GRAD_SCALE}
 
 
 def grad_scale_of(dtype):
-    return FP16_GRAD_SCALE if dtype == torch.float16 else 1.0
+    return _LOSS_SCALE["fp16"] if dtype == torch.float16 else 1.0
+
+
+def set_fp16_loss_scale(value):
+    """The loss scale the NEXT forward/backward of the fp16-storage models uses (a power of two: exact scaling)."""
+    _LOSS_SCALE["fp16"] = float(value)
 
 
 def reference_init_(module):

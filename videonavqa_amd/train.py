@@ -57,6 +57,16 @@ class FlatParams(object):
         self.grad.zero_()
         self.mark_zeroed()
 
+    def clip_adam_step(self, lr, clip=1.0, overflow_count=None):
+        """Global-norm clip + Adam + zero_grad over the flat buffers (two HIP launches) AND the gradient sinks' reset that must
+        go with every zeroing of the gradient buffer — one call, so that no training loop can forget the second half
+        (a loop calling K.clip_adam_step alone left the sinks `written`, and every later backward silently took
+        the temporary + AccumulateGrad route)."""
+        self.step_count += 1
+        K.clip_adam_step(self.flat, self.grad, self.m, self.v, self.partial, self.step_count, lr, clip,
+                         overflow_count=overflow_count)
+        self.mark_zeroed()
+
     def mark_zeroed(self):
         """The flat gradient buffer has just been zeroed (fused clip+Adam kernel, zero_grad): the next gradient producer of
         every parameter may write its slice in place again (ops.GradSink)."""
@@ -65,6 +75,59 @@ class FlatParams(object):
             if s is not None:
                 s.written = False
                 s._handed = False
+
+
+class DynamicLossScale(object):
+    """Loss scale of the fp16-storage precision, adjusted like torch.amp.GradScaler but WITHOUT a host sync in the step:
+    the fused clip+Adam kernel itself skips an update whose gradient norm is not finite and counts it in a device int32; the
+    host copies that counter into pinned memory asynchronously after every step and looks at the copy that has ARRIVED at the
+    next one — an overflow halves the scale one or two steps late (those steps are skipped on the device too if they
+    overflow), `growth_interval` clean steps double it (cap 2^24).  Powers of two only: scaling is exact."""
+
+    def __init__(self, device, init=None, growth_interval=200, max_scale=2.0 ** 24, min_scale=1.0):
+        from .models import common as C
+        self._C = C
+        self.scale = float(C.FP16_GRAD_SCALE if init is None else init)
+        self.growth_interval, self.max_scale, self.min_scale = int(growth_interval), float(max_scale), float(min_scale)
+        self.count = torch.zeros(1, dtype=torch.int32, device=device)
+        self._host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.device(device).type == "cuda" else None
+        self._event, self._seen, self._clean = None, 0, 0
+        self.skipped_steps = 0
+        C.set_fp16_loss_scale(self.scale)
+
+    def after_step(self):
+        """Call right after the clip+Adam launch: consume the previous read-back, start the next one.  Returns the number of
+        newly observed skipped steps (the caller takes them off its Adam step count)."""
+        new = 0
+        if self._host is not None:
+            if self._event is not None and self._event.query():
+                seen = int(self._host[0])
+                new = seen - self._seen
+                self._seen = seen
+                self._event = None
+            if self._event is None:
+                self._host.copy_(self.count, non_blocking=True)
+                self._event = torch.cuda.Event()
+                self._event.record()
+        if new > 0:
+            self.skipped_steps += new
+            self.scale = max(self.scale * 0.5 ** new, self.min_scale)
+            self._clean = 0
+        else:
+            self._clean += 1
+            if self._clean >= self.growth_interval:
+                self.scale = min(self.scale * 2.0, self.max_scale)
+                self._clean = 0
+        self._C.set_fp16_loss_scale(self.scale)
+        return new
+
+    def state_dict(self):
+        return {"scale": self.scale, "clean_steps": self._clean, "skipped_steps": self.skipped_steps}
+
+    def load_state_dict(self, d):
+        self.scale, self._clean = float(d.get("scale", self.scale)), int(d.get("clean_steps", 0))
+        self.skipped_steps = int(d.get("skipped_steps", 0))
+        self._C.set_fp16_loss_scale(self.scale)
 
 
 def sync_replicas(tensors, src=0):
@@ -198,6 +261,12 @@ class Trainer(object):
         self._slot = 0
         self._trunk_done = [None] * self._n_slots  # event per slot: last trunk pass that read that slot
         self._inputs_ready = None        # recorded on the CALLER's stream at step() entry: clips / labels produced so far
+        # fp16 storage: dynamic loss scale (VNQA_FP16_LOSS_SCALE=<value> pins it: no adjustment, the round-2/3 behaviour)
+        self.loss_scaler = None
+        if getattr(model, "compute_dtype", None) == torch.float16 and self.fp.flat.is_cuda:
+            pinned = os.environ.get("VNQA_FP16_LOSS_SCALE")
+            self.loss_scaler = DynamicLossScale(self.fp.flat.device, init=float(pinned) if pinned else None,
+                                                growth_interval=(1 << 62) if pinned else 200)
         self._in_step = False            # prefetch() called from inside step() (current stream = the trunk stream) or by the caller
         self._inline_stem_done = None    # event after a stem pass that ran INLINE on the trunk / caller's stream (shared buffers)
 
@@ -368,10 +437,10 @@ class Trainer(object):
         clamp = getattr(self.model, "grad_clamp", None)
         if clamp:    # MACNetwork: per-parameter gradient clamp hooks (eval/q_and_v_eval.py:348-351), on the reduced gradient
             self.fp.grad.clamp_(-clamp, clamp)
-        self.fp.step_count += 1
-        K.clip_adam_step(self.fp.flat, self.fp.grad, self.fp.m, self.fp.v, self.fp.partial,
-                         self.fp.step_count, self.lr, self.clip)
-        self.fp.mark_zeroed()        # (the kernel zeroes the gradient buffer)
+        self.fp.clip_adam_step(self.lr, self.clip,        # (the kernel zeroes the gradient buffer; the sinks are reset with it)
+                               overflow_count=None if self.loss_scaler is None else self.loss_scaler.count)
+        if self.loss_scaler is not None:      # updates skipped on the device (overflow) do not count as Adam steps
+            self.fp.step_count = max(self.fp.step_count - self.loss_scaler.after_step(), 0)
         ev = torch.cuda.Event()
         ev.record(main)
         self._trunk_done[self._slot] = ev
