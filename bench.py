@@ -116,7 +116,12 @@ def synth_batch(args, rank, device, index=0):
     """Synthetic minibatch `index` of rank `rank` (SURVEY 8d inputs; index 0 keeps the round-1/2 seed 1234 + rank)."""
     g = torch.Generator(device="cpu").manual_seed(1234 + rank + 7919 * index)
     B, T = args.batch, args.frames
-    clip = torch.rand(B, 3, args.height, args.width, T, generator=g)
+    if getattr(args, "clip_dtype", "f32") == "u8":
+        # raw 8-bit pixels k, valued float32(k / 255.0) like the reference's loader forms them (eval/dataset.py:91): what
+        # VNQADataset(uint8_video=True) delivers — a quarter of the bytes per clip
+        clip = torch.randint(0, 256, (B, 3, args.height, args.width, T), generator=g, dtype=torch.uint8)
+    else:
+        clip = torch.rand(B, 3, args.height, args.width, T, generator=g)
     q_lens = torch.randint(5, 26, (B,), generator=g)
     q = torch.randint(1, 134, (B, 56), generator=g)
     q = q * (torch.arange(56).unsqueeze(0) < q_lens.unsqueeze(1)).long()
@@ -586,6 +591,8 @@ def main():
                          "configs 3 and 5, mac is the remaining stem-consuming model of the same CLI")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: clips start in pinned host memory "
                     "and are copied to the GPU every step (on the stem stream); never the headline value")
+    ap.add_argument("--clip-dtype", default="f32", choices=["f32", "u8"], help="u8: synthetic clips are RAW 8-bit pixels (value "
+                    "k / 255 as eval/dataset.py:91 forms it; VNQADataset(uint8_video=True)) — with --h2d a quarter of the PCIe bytes")
     ap.add_argument("--minibatches", type=int, default=4, help="distinct HBM-resident minibatches (own clips, questions, "
                     "labels) the steps rotate through, so that the timed region does not fit ONE batch to loss 1e-3 and "
                     "run its backward kernels on collapsed gradients")
@@ -855,7 +862,8 @@ def main():
                        "whole_step_tflops_algorithmic": round(clips * flops_clip / 1e12, 1),
                        "gflop_per_clip_executed": round(flops_clip_exec / 1e9, 1),
                        "whole_step_tflops_executed": round(clips * flops_clip_exec / 1e12, 1),
-                       "final_loss": round(float(loss), 4), "minibatches_rotated": NB, "inputs": "pinned host memory, H2D every step" if args.h2d else "resident in HBM",
+                       "final_loss": round(float(loss), 4), "minibatches_rotated": NB, "inputs": ("pinned host memory, H2D every step" if args.h2d else "resident in HBM") +
+                                 (", raw uint8 pixels (k / 255 formed on the device)" if args.clip_dtype == "u8" else ""),
                        "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
                        "stem_alone_ms": round(stem_ms, 3),
                        # whole frozen stem alone on the chip: EXECUTED FLOPs / time / peak (hardware utilisation) and the

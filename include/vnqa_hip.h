@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 401
+#define VNQA_ABI_VERSION 402
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -273,6 +273,12 @@ int vnqa_conv2d_wreg_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
  */
 int vnqa_clip_to_nhwc4(const float* clip, const int32_t* img_of, void* img4, int32_t b, int32_t t, int32_t h,
                        int32_t w, void* stream);
+/* vnqa_clip_u8_to_nhwc4: the same image list from RAW 8-bit pixels [b][3][h][w][t] (what cv2 decodes, eval/dataset.py:66-77)
+ * and the caller's table lut[256] = float32(k / 255.0) evaluated in double precision — bit for bit the value
+ * `clip / 255.0` (dataset.py:91, float64) takes after `.float()` (eval/q_and_v_eval.py:92) — so the host uploads a quarter of
+ * the reference's bytes per clip and the device sees identical inputs. */
+int vnqa_clip_u8_to_nhwc4(const uint8_t* clip, const float* lut, const int32_t* img_of, void* img4, int32_t b, int32_t t,
+                          int32_t h, int32_t w, void* stream);
 int vnqa_conv_first_c64_fwd(const vnqa_conv_desc* d, const void* img4, const float* w1, const float* b1,
                             const void* wt, const float* bias, const float* post_scale,
                             const float* post_shift, void* y, void* stream);

@@ -216,3 +216,32 @@ def test_vnqa_dataset_contract_with_stubbed_decoder(tmp_path, monkeypatch):
     qs = D.VNQADataset(q_dir=str(qd), v_dir=str(vd), filenames=["clip0"], labels={"clip0": 3}, q_only=True)[0][0]
     vs = D.VNQADataset(q_dir=str(qd), v_dir=str(vd), filenames=["clip0"], labels={"clip0": 3}, v_only=True)[0][0]
     assert set(qs) == {"question", "q_len"} and set(vs) == {"video", "v_len"}
+
+
+def test_uint8_video_option_is_bit_identical_to_the_float64_path(tmp_path, monkeypatch):
+    """VNQADataset(uint8_video=True) hands out the RAW 8-bit clip; the pixel table the stem applies to it
+    (kernels.pixel_lut: float32(k / 255.0), division in float64) reproduces the default path's `clip / 255.0` on float64
+    followed by the training loop's `.float()` (eval/dataset.py:91, eval/q_and_v_eval.py:92) BIT FOR BIT, for all 256 pixel
+    values — so uploading a quarter of the bytes changes nothing downstream."""
+    import random
+    import numpy as np
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd.eval import dataset as D, utils as U
+    qd, vd = tmp_path / "q", tmp_path / "v"
+    qd.mkdir()
+    vd.mkdir()
+    np.save(qd / "c.npy", np.array([5, 9, 2], dtype=np.int64))
+    rng = np.random.RandomState(0)
+    frames = [rng.randint(0, 256, (U.VID_HEIGHT, U.VID_WIDTH, 3)).astype(np.uint8) for _ in range(37)]
+    frames[0][:2, :128, 0] = np.arange(256).reshape(2, 128)            # every pixel value occurs
+    monkeypatch.setattr(D, "_read_frames", lambda path: frames)
+    kw = dict(q_dir=str(qd), v_dir=str(vd), filenames=["c"], labels={"c": 1})
+    random.seed(11)
+    Xf, _ = D.VNQADataset(**kw)[0]
+    random.seed(11)                                    # the same 1-in-4 frame draw
+    Xu, _ = D.VNQADataset(uint8_video=True, **kw)[0]
+    assert Xu["video"].dtype == torch.uint8 and Xu["video"].shape == Xf["video"].shape and Xu["v_len"] == Xf["v_len"]
+    lut = K.pixel_lut("cpu")
+    assert lut.dtype == torch.float32 and lut.shape == (256,)
+    assert torch.equal(lut[Xu["video"].long()], Xf["video"].float())       # bit-exact, padding frames included
+    assert torch.equal(lut, (torch.arange(256, dtype=torch.float64) / 255.0).float())

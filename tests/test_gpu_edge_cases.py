@@ -161,3 +161,35 @@ def test_ce_loss_ignores_out_of_range_targets_like_ignore_index():
             assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
             assert float((lg.grad - ref_l.grad).abs().max()) <= 1e-6
             assert float(lg.grad[1].abs().max()) == 0.0
+
+
+def test_uint8_clip_gives_bit_identical_stem_input_and_features():
+    """raw 8-bit pixels + the 256-entry table float32(k / 255.0) (division in float64, eval/dataset.py:91)
+    give the stem bit for bit what the fp32 clip gives — the 4-channel image list of the fused first conv, and the features
+    of the whole stem (16-bit fused path and exact-f32 path)."""
+    import torch.nn as nn
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd.models import ObjDetectCNN
+    from videonavqa_amd.models.common import FrameLayout
+    from videonavqa_amd.stem import FrozenStem, VGGFront
+    from helpers import LOW
+    g = torch.Generator().manual_seed(3)
+    B, T, H, W = 2, 5, 32, 48
+    u8 = torch.randint(0, 256, (B, 3, H, W, T), generator=g, dtype=torch.uint8)
+    u8[0, 0, 0, :, 0] = torch.arange(W, dtype=torch.uint8)
+    f32 = (u8.double() / 255.0).float()                      # the reference loader's values (dataset.py:91, q_and_v_eval.py:92)
+    lay = FrameLayout([T, 3], T, "cuda")
+    a = K.clip_to_nhwc4(u8.cuda(), lay.img_of, lay.n_img)
+    b = K.clip_to_nhwc4(f32.cuda(), lay.img_of, lay.n_img)
+    assert torch.equal(a, b)
+    assert torch.equal(K.expand_u8_clip(u8.cuda()).cpu(), f32)
+    for prec in (LOW, "fp32"):
+        torch.manual_seed(0)
+        vgg, od = VGGFront(prec), ObjDetectCNN(5, 64, 8, 0, True, True, precision=prec)
+        with torch.no_grad():
+            for conv in vgg.features.values():
+                nn.init.kaiming_uniform_(conv.weight, a=1.0)
+        stem = FrozenStem(vgg.cuda().eval(), od.cuda().eval(), prec)
+        fa = stem.forward_clip(u8.cuda(), lay.img_of, lay.n_img).clone()
+        fb = stem.forward_clip(f32.cuda(), lay.img_of, lay.n_img)
+        assert torch.equal(fa, fb), prec

@@ -737,24 +737,36 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
 // clip fp32 [B][3][H][W][T] (frames last) -> image list [n_img][H+4][W+4][4] bf16 (halo 2 and channel 3 stay zero:
 // the caller zeroes the buffer once).  One workgroup per (32-pixel run, row, sample): the 3 x 32 x T floats are read
 // as three contiguous runs, transposed through LDS, and every frame writes 32 x 8 contiguous bytes.
-__global__ void __launch_bounds__(256) clip_to_nhwc4_kernel(const float* __restrict__ clip, const int* __restrict__ img_of,
+template <typename SRC>
+__global__ void __launch_bounds__(256) clip_to_nhwc4_kernel(const SRC* __restrict__ clip, const float* __restrict__ lut,
+                                                            const int* __restrict__ img_of,
                                                             unsigned short* __restrict__ out, int T, int H, int W) {
-  extern __shared__ __attribute__((aligned(16))) float stage[];     // [3][32][T]
+  // SRC = float: the clip's values as they are.  SRC = unsigned char: raw 8-bit pixels k, valued lut[k] — the caller's table of
+  // float32(k / 255.0) evaluated in double (eval/dataset.py:91 followed by q_and_v_eval.py:92's .float()), so both sources
+  // give the same bits while the upload moves a quarter of the bytes.
+  extern __shared__ __attribute__((aligned(16))) float stage_f[];     // [3][32][T] SRC elements (+ 256 floats of LUT)
+  SRC* stage = (SRC*)stage_f;
+  float* s_lut = stage_f + (3 * 32 * T * sizeof(SRC) + 3) / 4;
   const int x0 = blockIdx.x * 32, y = blockIdx.y, b = blockIdx.z;
   const int nx = min(32, W - x0);
   const int run = nx * T;
+  if constexpr (sizeof(SRC) == 1) s_lut[threadIdx.x] = lut[threadIdx.x];
   for (int c = 0; c < 3; ++c) {
-    const float* src = clip + ((((size_t)b * 3 + c) * H + y) * W + x0) * (size_t)T;
+    const SRC* src = clip + ((((size_t)b * 3 + c) * H + y) * W + x0) * (size_t)T;
     for (int i = threadIdx.x; i < run; i += 256) stage[c * 32 * T + i] = src[i];
   }
   __syncthreads();
+  auto val = [&](int idx) -> float {
+    if constexpr (sizeof(SRC) == 1) return s_lut[stage[idx]];
+    else return stage[idx];
+  };
   for (int i = threadIdx.x; i < T * nx; i += 256) {
     const int t = i / nx, px = i - t * nx;
     const int img = img_of[b * T + t];
     if (img < 0) continue;
     uint2 o;
-    o.x = pack2_h16(stage[px * T + t], stage[32 * T + px * T + t]);
-    o.y = (unsigned)f32_to_bf16(stage[2 * 32 * T + px * T + t]);
+    o.x = pack2_h16(val(px * T + t), val(32 * T + px * T + t));
+    o.y = (unsigned)f32_to_bf16(val(2 * 32 * T + px * T + t));
     *(uint2*)(out + ((((size_t)img * (H + 4)) + y + 2) * (W + 4) + x0 + px + 2) * 4) = o;
   }
 }
@@ -881,8 +893,22 @@ extern "C" int vnqa_clip_to_nhwc4(const float* clip, const int32_t* img_of, void
   VNQA_CHECK_ARG(b > 0 && t > 0 && h > 0 && w > 0, "clip_to_nhwc4: empty problem");
   const size_t lds = (size_t)3 * 32 * t * sizeof(float);
   VNQA_CHECK_ARG(lds <= 64 * 1024, "clip_to_nhwc4: t=%d frames do not fit the LDS stage", t);
-  hipLaunchKernelGGL(clip_to_nhwc4_kernel, dim3((w + 31) / 32, h, b), dim3(256), lds, (hipStream_t)stream, clip, img_of,
-                     (unsigned short*)img4, t, h, w);
+  hipLaunchKernelGGL(clip_to_nhwc4_kernel<float>, dim3((w + 31) / 32, h, b), dim3(256), lds, (hipStream_t)stream, clip,
+                     (const float*)nullptr, img_of, (unsigned short*)img4, t, h, w);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+// The same layout kernel fed with RAW 8-bit pixels (the frames cv2 decodes, eval/dataset.py:66-77) and the caller's 256-entry
+// table of their float values: a quarter of the PCIe bytes of the fp32 clip the reference uploads (q_and_v_eval.py:92-99).
+extern "C" int vnqa_clip_u8_to_nhwc4(const uint8_t* clip, const float* lut, const int32_t* img_of, void* img4, int32_t b,
+                                     int32_t t, int32_t h, int32_t w, void* stream) {
+  VNQA_CHECK_ARG(clip && lut && img_of && img4, "clip_u8_to_nhwc4: null pointer");
+  VNQA_CHECK_ARG(b > 0 && t > 0 && h > 0 && w > 0, "clip_u8_to_nhwc4: empty problem");
+  const size_t lds = ((size_t)3 * 32 * t + 3) / 4 * 4 + 256 * sizeof(float);
+  VNQA_CHECK_ARG(lds <= 64 * 1024, "clip_u8_to_nhwc4: t=%d frames do not fit the LDS stage", t);
+  hipLaunchKernelGGL(clip_to_nhwc4_kernel<unsigned char>, dim3((w + 31) / 32, h, b), dim3(256), lds, (hipStream_t)stream, clip,
+                     lut, img_of, (unsigned short*)img4, t, h, w);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

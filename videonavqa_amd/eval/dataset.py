@@ -47,7 +47,12 @@ class VNQADataset(Dataset):
     """Constructor arguments as in the reference (eval/dataset.py:18-27)."""
 
     def __init__(self, q_dir, v_dir, filenames, labels, q_only=False, v_only=False, max_q_len=None,
-                 num_classes=None, q_metadata=False):
+                 num_classes=None, q_metadata=False, uint8_video=False):
+        """uint8_video (keyword, not upstream): item['video'] is the RAW 8-bit clip [3, H, W, 35] (zero padded) instead of
+        float64 pixels / 255 — a quarter of the fp32 bytes over PCIe; the stem turns pixel k into float32(k / 255.0)
+        (division in float64: kernels.pixel_lut), bit for bit what `clip / 255.0` + `.float()` gives (dataset.py:91,
+        q_and_v_eval.py:92)."""
+        self.uint8_video = uint8_video
         if q_only and v_only:
             raise AssertionError("Can't have both question- and video-only modes!")
         for d, what in ((q_dir, "question"), (v_dir, "video")):
@@ -68,6 +73,11 @@ class VNQADataset(Dataset):
     def _video(self, name):
         frames = _read_frames(os.path.join(self.v_dir, name + '.mp4'))
         keep = subsample_indices(len(frames))[:U.MAX_ALLOWED_NUM_FRAMES_DROPPING]
+        if self.uint8_video:
+            clip = torch.zeros(3, U.VID_HEIGHT, U.VID_WIDTH, U.MAX_ALLOWED_NUM_FRAMES_DROPPING, dtype=torch.uint8)
+            for slot, idx in enumerate(keep):
+                clip[..., slot] = torch.from_numpy(frames[idx]).permute(2, 0, 1)
+            return clip, len(keep)
         clip = torch.zeros(3, U.VID_HEIGHT, U.VID_WIDTH, U.MAX_ALLOWED_NUM_FRAMES_DROPPING, dtype=torch.float64)
         for slot, idx in enumerate(keep):
             clip[..., slot] = torch.from_numpy(frames[idx]).permute(2, 0, 1).double()

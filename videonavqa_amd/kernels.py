@@ -395,12 +395,35 @@ def frame_max_bwd(dpooled, argmax, sample_of_i32, shape, dtype, tail, scale=1.0)
     return dmaps
 
 
+_PIXEL_LUT = {}
+
+
+def pixel_lut(device):
+    """lut[k] = float32(k / 255.0) with the division in float64: exactly the value a raw pixel k has after the reference's
+    `clip / 255.0` on a float64 tensor (eval/dataset.py:91) and the training loop's `.float()` (eval/q_and_v_eval.py:92)."""
+    key = str(device)
+    t = _PIXEL_LUT.get(key)
+    if t is None:
+        t = _PIXEL_LUT[key] = (torch.arange(256, dtype=torch.float64) / 255.0).float().to(device)
+    return t
+
+
+def expand_u8_clip(clip):
+    """uint8 clip -> the fp32 clip the reference's loader would have produced (device-side table lookup)."""
+    return pixel_lut(clip.device)[clip.long()]
+
+
 def clip_to_nhwc4(clip, img_of, n_img, out=None):
-    """clip fp32 [B,3,H,W,T] (frames last) -> image list bf16 [n_img,H+4,W+4,4] (halo 2 and channel 3 zero)."""
+    """clip fp32 — or RAW uint8 pixels valued k / 255 — [B,3,H,W,T] (frames last) -> image list bf16 [n_img,H+4,W+4,4]
+    (halo 2 and channel 3 zero)."""
     B, C, H, W, T = clip.shape
-    assert C == 3 and clip.dtype == torch.float32
+    assert C == 3 and clip.dtype in (torch.float32, torch.uint8)
     if out is None:
         out = torch.zeros((n_img, H + 4, W + 4, 4), dtype=L.half_dtype(), device=clip.device)
+    if clip.dtype == torch.uint8:
+        L.check(L.lib().vnqa_clip_u8_to_nhwc4(L.ptr(clip.contiguous()), L.ptr(pixel_lut(clip.device)), L.ptr(img_of), L.ptr(out),
+                                              B, T, H, W, L.stream()), "vnqa_clip_u8_to_nhwc4")
+        return out
     L.check(L.lib().vnqa_clip_to_nhwc4(L.ptr(clip.contiguous()), L.ptr(img_of), L.ptr(out), B, T, H, W, L.stream()),
             "vnqa_clip_to_nhwc4")
     return out

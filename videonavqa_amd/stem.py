@@ -312,7 +312,8 @@ class FrozenStem(object):
     # ---- fused fast path: clip -> packed native features ------------------------------------
     @torch.no_grad()
     def forward_clip(self, clip, img_of, n_img, slot=0):
-        """clip fp32 [B,3,H,W,T] on the GPU; img_of int32 [B*T] (image index or -1).
+        """clip fp32 [B,3,H,W,T] on the GPU — or uint8 raw pixels k, meaning k / 255 exactly as the reference's loader forms it
+        (eval/dataset.py:91; VNQADataset(uint8_video=True)) —; img_of int32 [B*T] (image index or -1).
         Returns padded NHWC [n_img, H/16+2, W/16+2, Cpad] in the compute dtype.
         `slot` selects one of several OUTPUT buffers (the intermediates are shared), so that the
         features of step i stay alive for its backward while step i+1's stem already runs."""
@@ -336,6 +337,8 @@ class FrozenStem(object):
             x = out
             x = self._run(x, self.layers_vgg[1:], "vgg", first_index=1)
         else:
+            if clip.dtype == torch.uint8:        # raw pixels: the un-fused first conv reads the fp32 clip
+                clip = K.expand_u8_clip(clip)
             a = self._buf(("first", H, W), (n_img, H + 2, W + 2, 64))
             K.conv_first(clip, self.first[0], self.first[1], img_of, n_img, self.cdt, out=a)
             x = self._run(a, self.layers_vgg, "vgg")
