@@ -596,6 +596,8 @@ def main():
     ap.add_argument("--minibatches", type=int, default=4, help="distinct HBM-resident minibatches (own clips, questions, "
                     "labels) the steps rotate through, so that the timed region does not fit ONE batch to loss 1e-3 and "
                     "run its backward kernels on collapsed gradients")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"], help="eval: time the INFERENCE path (Trainer.eval_step: "
+                    "val_epoch / test of the reference, forward only) instead of the training step; never the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-fp32 parity block (adds ~10 s)")
     ap.add_argument("--parity-only", action="store_true", help="print only the parity block of --precision (no timing)")
@@ -719,9 +721,40 @@ def main():
             dt = float(t.item())
         return dt, t_enq, ev, loss
 
+    if args.mode == "eval":
+        # inference (val_epoch / test, eval/q_and_v_eval.py:159-224, eval/q_and_v_test.py:64-142): the SAME timed-region protocol
+        # with Trainer.eval_step — forward-only fused trunk, stem of the next minibatch on the stem stream
+        def run_step():       # noqa: F811
+            i = step_no[0]
+            step_no[0] += 1
+            b, bn = batches[i % NB], batches[(i + 1) % NB]
+            if args.no_overlap:
+                return trainer.eval_step(*b)[:2]
+            return trainer.eval_step(*b, next_clip=bn[0], next_v_lens_cpu=bn[2])[:2]
+        for _ in range(3 + args.warmup):
+            run_step()
     regions = [timed_region() for _ in range(max(args.repeats, 1))]
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     dt, t_enqueue, events, loss = regions[order[len(order) // 2]]          # the MEDIAN region is the reported one
+
+    # the inference path's throughput next to the training headline (same protocol, same resident minibatches, one region)
+    eval_mode = None
+    if args.mode == "train" and world == 1 and not args.h2d and args.model != "mac":
+        train_step = run_step
+
+        def run_step():       # noqa: F811
+            i = step_no[0]
+            step_no[0] += 1
+            b, bn = batches[i % NB], batches[(i + 1) % NB]
+            return trainer.eval_step(*b, next_clip=bn[0], next_v_lens_cpu=bn[2])[:2]
+        for _ in range(3):
+            run_step()
+        e_dt = timed_region()[0]
+        eval_mode = {"what": "Trainer.eval_step (model.eval() under no_grad: forward-only fused trunk, BatchNorm running statistics "
+                             "folded into conv_init's epilogue, stem of the next minibatch on the stem stream), %d timed steps, same "
+                             "resident minibatches; `bench.py --mode eval` prints this as its own line" % args.steps,
+                     "value": round(args.batch * args.steps / e_dt, 1), "unit": "clips/s", "ms_per_step": round(e_dt / args.steps * 1e3, 3)}
+        run_step = train_step
 
     # (N > 1) what the gradient all-reduce costs: the flat buffer's all-reduce alone, and the step WITHOUT collectives
     # (replicas diverge from here on: after the measurement) -> exposed communication per step
@@ -892,6 +925,11 @@ def main():
                          "launches_per_step": launches_per_step, "avg_launch_ms": round(avg_ms, 4),
                          "gflop_per_launch": round(flops_per_launch / 1e9, 1)},
         }
+        if args.mode == "eval":
+            out["metric"] = METRIC.replace("fwd+bwd", "forward only (inference: val_epoch / test)")
+            out["config"]["workload"] = out["config"]["workload"].replace("training step", "INFERENCE step (eval mode, no backward / optimizer)")
+        if eval_mode is not None:
+            out["eval_mode"] = eval_mode
         if comm is not None:
             out["comm"] = comm
         if parity is not None:

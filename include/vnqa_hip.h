@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 402
+#define VNQA_ABI_VERSION 403
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -144,6 +144,8 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
  *     y  = conv + bias                                   (z: the FiLM backward needs it)
  *     y2 = relu(gamma[n][c] * y + beta[n][c]) + res      (gamma/beta fp32 rows of stride film_ld; channels >= film_c: 0)
  *     computed from the storage-rounded y, i.e. bit-identical to vnqa_film_relu_res_fwd applied to y.
+ *     y == NULL (this epilogue only): forward-only form for inference (eval/q_and_v_eval.py:159-224, eval/q_and_v_test.py:64-142)
+ *     — z is not stored, y2 is identical to the two-output call's.
  * pool2 / depth / wt_tiled / post_scale are not available with a fused epilogue.
  */
 #define VNQA_EPI_NONE 0

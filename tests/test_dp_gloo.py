@@ -176,3 +176,47 @@ def test_reducer_three_early_parameters_out_of_order_mean_loss(tmp_path):
         loss_fn(model(X), Y).backward()
         _adam_step(fp, 1e-2)
     assert torch.allclose(w_dp, fp.flat, rtol=1e-5, atol=1e-6), float((w_dp - fp.flat).abs().max())
+
+
+def _eval_shard_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    from videonavqa_amd.eval.q_and_v_eval import ShardedBatchSampler, gather_eval_shards
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_items, bs = 23, 4                      # 5 full batches + a short one (dropped by val_epoch)
+    sampler = ShardedBatchSampler(n_items, bs, rank, world)
+    per_batch, loss, n = [], 0.0, 0
+    for gi, idx in zip(sampler.global_index, sampler):
+        idx = np.asarray(idx)
+        # stand-ins for one batch's (targets, predictions): functions of the item index only
+        per_batch.append((gi, idx % 7, (idx * 3) % 7))
+        loss += float(idx.sum())
+        n += len(idx)
+    (y_t, y_p), tot_loss, tot_n = gather_eval_shards(per_batch, loss, n, world)
+    torch.save({"y_t": y_t, "y_p": y_p, "loss": tot_loss, "n": tot_n, "own": len(per_batch)}, out_path % rank)
+    dist.destroy_process_group()
+
+
+def test_validation_sharded_over_two_ranks_merges_to_the_single_process_order(tmp_path):
+    """validation sharded over ranks with ONE gather — rank r evaluates full batches r, r + world, ...; the
+    merged targets / predictions come back in the single-process loop's order on every rank, losses and counts add up."""
+    import numpy as np
+    world = 2
+    port = 29500 + (os.getpid() % 2000) + 7
+    out = str(tmp_path / "shard_%d.pt")
+    mp.spawn(_eval_shard_worker, args=(world, port, out), nprocs=world, join=True)
+    items = np.arange(20)                                           # 5 full batches of 4: item 20..22 are the dropped short batch
+    res = [torch.load(out % r, weights_only=False) for r in range(world)]
+    assert [r["own"] for r in res] == [3, 2]                        # batches 0, 2, 4 / 1, 3
+    for r in res:
+        assert np.array_equal(r["y_t"], (items % 7).astype(np.float64))
+        assert np.array_equal(r["y_p"], ((items * 3) % 7).astype(np.float64))
+        assert r["loss"] == float(items.sum()) and r["n"] == 20
+    # world 1: the same helper is the identity
+    from videonavqa_amd.eval.q_and_v_eval import ShardedBatchSampler, gather_eval_shards
+    s1 = ShardedBatchSampler(23, 4)
+    assert len(s1) == 5 and s1.global_index == [0, 1, 2, 3, 4] and len(ShardedBatchSampler(23, 4, keep_short=True)) == 6
+    (a, b), l, n = gather_eval_shards([(1, [3.0], [4.0]), (0, [1.0], [2.0])], 5.0, 2, 1)
+    assert a.tolist() == [1.0, 3.0] and b.tolist() == [2.0, 4.0] and (l, n) == (5.0, 2)

@@ -25,13 +25,20 @@ def _inputs(g):
     return tuple(torch.from_numpy(g[k]).cuda() for k in ("v", "q", "v_lens", "q_lens", "y"))
 
 
+@pytest.mark.parametrize("fused_eval", [True, False])
 @pytest.mark.parametrize("precision", ["fp32", LOW])
 @pytest.mark.parametrize("case", QV_CASES)
-def test_eval_logits_vs_reference_golden(case, precision):
+def test_eval_logits_vs_reference_golden(case, precision, fused_eval, monkeypatch):
+    """Eval-mode logits against the reference's own (tests/golden): on the round-4 inference path (forward-only fused trunk:
+    eval BatchNorm folded into conv_init's epilogue, FILM_RES without the z output, packed tails — the default under
+    no_grad) and on the op-by-op eval graph (VNQA_FUSED_EVAL=0), same tolerance."""
+    monkeypatch.setenv("VNQA_FUSED_EVAL", "1" if fused_eval else "0")
     model, g = build_product_model(case, precision)
     v, q, vl, ql, y = _inputs(g)
     model.eval()
+    assert model._use_fused_trunk() is False            # eval mode with autograd on: the op-by-op graph
     with torch.no_grad():
+        assert model._use_fused_trunk() is fused_eval
         model.init_hidden()
         logits = model(v, q, vl, ql)
     got = logits.float().cpu().numpy()

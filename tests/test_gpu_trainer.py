@@ -268,3 +268,39 @@ def test_dynamic_loss_scale_halves_after_overflow_and_grows_when_clean():
         assert s.scale >= 1024.0 and C.grad_scale_of(torch.float16) == s.scale
     finally:
         C.set_fp16_loss_scale(C.FP16_GRAD_SCALE)
+
+
+def test_eval_step_pipeline_matches_plain_per_batch_evaluation(monkeypatch):
+    """Trainer.eval_step (inference path: forward-only fused trunk, next batch's stem prefetched on the stem stream, loss on the
+    device) against the plain evaluation of every batch by itself on the op-by-op eval graph (VNQA_FUSED_EVAL=0, no
+    pipeline): same logits (fp32: 1e-5), same losses, n_real slicing as q_and_v_test.py:123."""
+    from videonavqa_amd.train import Trainer
+    model, stem, batches = _setup()
+    tr = Trainer(model, stem)
+    model.bn_init.running_mean.normal_(0, 0.3)           # non-trivial running statistics to fold
+    model.bn_init.running_var.uniform_(0.5, 1.5)
+    ref = []
+    monkeypatch.setenv("VNQA_FUSED_EVAL", "0")
+    model.eval()
+    with torch.no_grad():
+        for clip, q, v_lens, q_lens, y in batches:
+            native, v_sorted, perm = tr.extract_features(clip, v_lens)
+            pd = perm.cuda()
+            model.init_hidden()
+            out = model(native, q[pd], v_sorted, q_lens[perm])
+            ref.append((out.clone(), float(nn.CrossEntropyLoss(reduction="sum")(out, y[pd])),
+                        float(nn.CrossEntropyLoss(reduction="sum")(out[:2], y[pd][:2]))))
+    monkeypatch.setenv("VNQA_FUSED_EVAL", "1")
+    for rounds in range(2):
+        for i, (clip, q, v_lens, q_lens, y) in enumerate(batches):
+            nb = batches[(i + 1) % 3]
+            loss, out, perm_d = tr.eval_step(clip, q, v_lens, q_lens, y, next_clip=nb[0], next_v_lens_cpu=nb[2])
+            assert not model.training and out.shape == ref[i][0].shape
+            assert float((out - ref[i][0]).abs().max()) < 1e-5 * max(1.0, float(ref[i][0].abs().max()))
+            assert abs(float(loss) - ref[i][1]) < 1e-4 * max(1.0, abs(ref[i][1]))
+            assert torch.equal(perm_d.long().cpu(), torch.sort(v_lens, descending=True, stable=True)[1])
+    loss2, _, _ = tr.eval_step(*batches[0], n_real=2)        # padded last batch: loss over the first 2 sorted rows only
+    assert abs(float(loss2) - ref[0][2]) < 1e-4 * max(1.0, abs(ref[0][2]))
+    # training still works after evaluation on the same Trainer (model back in train mode, prefetch state consistent)
+    l0, _ = tr.step(*batches[0], next_clip=batches[1][0], next_v_lens_cpu=batches[1][2])
+    assert model.training and float(l0) == float(l0)

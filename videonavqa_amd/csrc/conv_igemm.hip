@@ -760,11 +760,11 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
           const int orow = idx / CH, c = idx - orow * CH;
           const uint4 staged = *(const uint4*)(smem + orow * CROW + c * 16);
           const T* src = (const T*)&staged;
-          T* dst = (T*)(p.y) + ooff[u];
+          T* dst = p.y != nullptr ? (T*)(p.y) + ooff[u] : nullptr;      // (FILM_RES with y == NULL: forward-only, z is not kept)
           T* second = nullptr;
           T o2[EPC];
           if (film) {
-            *(uint4*)dst = staged;                               // z: exactly the storage-rounded values staged in LDS
+            if (dst != nullptr) *(uint4*)dst = staged;           // z: exactly the storage-rounded values staged in LDS
             const T* rt = (const T*)&ra[u];
 #pragma unroll
             for (int e = 0; e < EPC; ++e)
@@ -849,11 +849,12 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       oimg = (size_t)nn * (p.D + 2) + (n - nn * p.D) + 1;
     }
     const size_t ooff = ((oimg * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
-    T* dst = (T*)(p.y) + ooff;
+    const bool no_z = TAG == 0 && p.epi == VNQA_EPI_FILM_RES && p.y == nullptr;     // forward-only FiLM block: z is not kept
+    T* dst = no_z ? nullptr : (T*)(p.y) + ooff;
     T out[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) out[e] = ElemOps<T>::store(v[e]);
-    if (!(TAG == 0 && p.epi == VNQA_EPI_ADD_MASK)) *(uint4*)dst = *(const uint4*)out;
+    if (!(TAG == 0 && p.epi == VNQA_EPI_ADD_MASK) && !no_z) *(uint4*)dst = *(const uint4*)out;
     if (p.zero_halo) {
       // the halo ring of a fresh output buffer: every border pixel's thread also zeroes the halo positions next to it
       // (corners by the corner pixels) for its 16-byte channel chunk — for y and, with FILM_RES, for the second output
@@ -1497,8 +1498,11 @@ extern "C" int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* 
                                            const vnqa_conv_epilogue* e, void* y, void* stream) {
   VNQA_CHECK_ARG(e != nullptr, "conv2d_igemm_fused_fwd: null epilogue");
   ConvArgs a;
-  const int rc = fill_conv_args(d, x, wt, bias, nullptr, nullptr, nullptr, y, a);
+  // FILM_RES with y == NULL: forward-only (inference) form — the conv output z is needed by the BACKWARD only and is not stored
+  const bool film_no_z = e->kind == VNQA_EPI_FILM_RES && y == nullptr && e->y2 != nullptr;
+  const int rc = fill_conv_args(d, x, wt, bias, nullptr, nullptr, nullptr, film_no_z ? e->y2 : y, a);
   if (rc != VNQA_OK) return rc;
+  if (film_no_z) a.y = nullptr;
   VNQA_CHECK_ARG(!d->pool2 && d->depth == 0 && !d->wt_tiled, "conv2d_igemm_fused_fwd: 2-D, un-pooled, K-major weights only");
   // (the patch-stationary kernel carries FILM_RES and ADD_MASK in its own store loop: conv_ps.hip)
   const bool ps_tile = d->tile == VNQA_TILE_PS_224x256 && (e->kind == VNQA_EPI_FILM_RES || e->kind == VNQA_EPI_ADD_MASK);

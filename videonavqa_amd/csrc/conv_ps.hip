@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
             v[2 * e] = h16_lo(w4[e]);
             v[2 * e + 1] = h16_hi(w4[e]);
           }
-          vnqa_bf16* dst = (vnqa_bf16*)(p.y) + ooff[u];
+          vnqa_bf16* dst = p.y != nullptr ? (vnqa_bf16*)(p.y) + ooff[u] : nullptr;      // (FILM_RES with y == NULL: z is not kept)
           vnqa_bf16* second = nullptr;
           const unsigned aw[4] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w};
           if (!film) {
@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
             o.x = pack2_h16(w[0], w[1]); o.y = pack2_h16(w[2], w[3]); o.z = pack2_h16(w[4], w[5]); o.w = pack2_h16(w[6], w[7]);
             *(uint4*)dst = o;
           } else {
-            *(uint4*)dst = uu;                               // z, exactly the 16-bit values staged in LDS
+            if (dst != nullptr) *(uint4*)dst = uu;           // z, exactly the 16-bit values staged in LDS
             const float ga[8] = {g0v[u].x, g0v[u].y, g0v[u].z, g0v[u].w, g1v[u].x, g1v[u].y, g1v[u].z, g1v[u].w};
             const float be[8] = {b0v[u].x, b0v[u].y, b0v[u].z, b0v[u].w, b1v[u].x, b1v[u].y, b1v[u].z, b1v[u].w};
             float w[8];
@@ -477,7 +477,8 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     const int yo = p.pool ? (y >> 1) : y;
     const int xo = (p.pool ? xb >> 1 : xb) + occ;
     const size_t ooff = (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
-    vnqa_bf16* dst = (vnqa_bf16*)(p.y) + ooff;
+    const bool no_z = TAG == 0 && p.epi == VNQA_EPI_FILM_RES && p.y == nullptr;     // forward-only FiLM block: z is not kept
+    vnqa_bf16* dst = no_z ? nullptr : (vnqa_bf16*)(p.y) + ooff;
     uint4 o;
     if (TAG == 0 && p.epi == VNQA_EPI_ADD_MASK) {
       // y = (conv + add) * [mask > 0] on the storage-rounded conv output (v holds exactly the 16-bit values staged in LDS):
@@ -495,7 +496,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     } else {
       o.x = pack2_h16(v[0], v[1]); o.y = pack2_h16(v[2], v[3]); o.z = pack2_h16(v[4], v[5]); o.w = pack2_h16(v[6], v[7]);
     }
-    *(uint4*)dst = o;
+    if (!no_z) *(uint4*)dst = o;
     vnqa_bf16* second = nullptr;
     if (TAG == 0 && p.epi == VNQA_EPI_FILM_RES) {
       // out2 = relu(gamma[n] * z + beta[n]) + res from the storage-rounded z just written (film_attn_pt_stem.py:229-241)

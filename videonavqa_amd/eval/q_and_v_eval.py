@@ -116,7 +116,9 @@ def _staged_batches(args, trainer, data_loader, device):
     frozen stem overlap the current minibatch's trunk pass (Trainer.upload / Trainer.step(next_clip=...))."""
     def stage(item):
         i, (Xs, ys) = item
-        clip = Xs['video'].float()
+        clip = Xs['video']
+        if clip.dtype != torch.uint8:          # (VNQADataset(uint8_video=True) hands out raw pixels: uploaded as they are)
+            clip = clip.float()
         clip = trainer.upload(clip.pin_memory() if not clip.is_pinned() else clip)
         return i, (clip, Xs['question'].to(device, non_blocking=True), Xs['v_len'].long().cpu(),
                    Xs['q_len'].long().cpu(), ys.to(device, non_blocking=True))
@@ -185,34 +187,75 @@ def train_epoch(epoch, args, trainer, data_loader, device, rank=0):
     return avg_loss / max(num_examples, 1)
 
 
-def val_epoch(args, trainer, data_loader, device, rank=0):
-    """q_and_v_eval.py:159-224."""
+class ShardedBatchSampler(object):
+    """Batch sampler of the validation / test split for data-parallel evaluation: the split's FULL batches in order
+    (val_epoch skips a short last batch, q_and_v_eval.py:188-189), batch i evaluated by rank i % world only — every rank
+    decodes and evaluates 1 / world of the split instead of all of it.  keep_short=True also yields the short last batch
+    (the test script pads it, q_and_v_test.py:80-87)."""
+
+    def __init__(self, n_items, batch_size, rank=0, world=1, keep_short=False):
+        n_batches = n_items // batch_size + (1 if (keep_short and n_items % batch_size) else 0)
+        self.batches = [list(range(i * batch_size, min((i + 1) * batch_size, n_items)))
+                        for i in range(n_batches) if i % world == rank]
+        self.global_index = [i for i in range(n_batches) if i % world == rank]
+        self.n_batches_total = n_batches
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def gather_eval_shards(per_batch, loss_sum, n_examples, world, device=None):
+    """Merge the ranks' evaluation shards with ONE collective (all_gather_object).  per_batch: this rank's list of
+    (global batch index, 1-D float64 arrays...) — e.g. (i, y_target, y_pred) — in any order.  Returns (list of merged
+    arrays, concatenated in global batch order — exactly the single-process loop's order —, total loss, total examples);
+    identical on every rank."""
+    import torch.distributed as dist
+    shards = [(per_batch, float(loss_sum), int(n_examples))]
+    if world > 1 and dist.is_available() and dist.is_initialized():
+        out = [None] * world
+        dist.all_gather_object(out, shards[0])
+        shards = out
+    rows = sorted((item for sh in shards for item in sh[0]), key=lambda it: it[0])
+    n_arrays = len(rows[0]) - 1 if rows else 0
+    merged = [np.concatenate([np.asarray(r[1 + k], dtype=np.float64) for r in rows]) if rows else np.array([])
+              for k in range(max(n_arrays, 2))]
+    return merged, sum(sh[1] for sh in shards), sum(sh[2] for sh in shards)
+
+
+def val_epoch(args, trainer, data_loader, device, rank=0, world=1):
+    """q_and_v_eval.py:159-224 on the inference path: Trainer.eval_step (forward-only fused trunk, the stem of the NEXT
+    minibatch and its H2D copy overlapping this minibatch's trunk, as in training), loss / predictions / targets kept on the
+    device for the whole epoch and read back ONCE; with world > 1 the loader hands this rank only its share of the batches
+    (ShardedBatchSampler) and the shards are merged by one gather."""
     from sklearn.metrics import f1_score
-    model = trainer.model
-    model.eval()
-    val_loss, hit, num_examples = 0.0, 0, 0
-    y_pred, y_target = np.array([]), np.array([])
-    with torch.no_grad():
-        for Xs, ys in data_loader:
-            if len(ys) < args.batch_size:
-                continue
-            num_examples += len(ys)
-            clip, q, v_lens, q_lens, ys = _to_device(Xs, ys, device)
-            native, v_sorted, perm = trainer.extract_features(clip, v_lens)
-            perm_d = perm.to(device)
-            if args.model != 'mac':                                     # :204-205
-                model.init_hidden()
-            output = model(native, q[perm_d], v_sorted, q_lens[perm])
-            ys_sorted = ys[perm_d]
-            y_target = np.append(y_target, ys_sorted.cpu().numpy())
-            val_loss += float(trainer.loss_fn(output, ys_sorted))
-            pred_class = output.max(1)[1]
-            y_pred = np.append(y_pred, pred_class.cpu().numpy())
-            hit += int((pred_class == ys_sorted).sum())
+    trainer.model.eval()
+    num_examples = 0
+    loss_acc = torch.zeros((), dtype=torch.float64, device=device)
+    preds, targets = [], []
+    for i, batch, nxt in _staged_batches(args, trainer, data_loader, device):
+        clip, q, v_lens, q_lens, ys = batch
+        num_examples += len(ys)
+        ahead = dict(next_clip=nxt[0], next_v_lens_cpu=nxt[2]) if nxt is not None else {}
+        loss, output, perm_d = trainer.eval_step(clip, q, v_lens, q_lens, ys, **ahead)
+        loss_acc += loss
+        targets.append(ys.index_select(0, perm_d))                      # sorted order, as the logits (:195-199)
+        preds.append(output.max(1)[1])
+    sampler = getattr(data_loader, "batch_sampler", None)
+    index = getattr(sampler, "global_index", None) or list(range(len(preds)))
+    if preds:      # the epoch's ONE read-back
+        P = torch.stack(preds).cpu().numpy().astype(np.float64)
+        T = torch.stack(targets).cpu().numpy().astype(np.float64)
+        per_batch = [(index[k], T[k], P[k]) for k in range(len(preds))]
+    else:
+        per_batch = []
+    (y_target, y_pred), val_loss, num_examples = gather_eval_shards(per_batch, float(loss_acc), num_examples, world, device)
+    hit = int((y_pred == y_target).sum())
     accs = U.per_class_accuracies(y_target, y_pred, args.num_classes)
     f1_w = f1_score(y_target, y_pred, average='weighted') if num_examples else 0.0
     f1_micro = f1_score(y_target, y_pred, average='micro') if num_examples else 0.0
-    # (every rank evaluates the whole validation split: nothing to aggregate)
     if rank == 0:
         pp.pprint({i: accs[i] for i in np.nonzero(accs)[0].tolist()})
         print('Validation:\tAverage loss: {:.6f}, Accuracy: {}/{}, F1: w{:.4f}, micro{:.4f}\n'.format(
@@ -267,8 +310,9 @@ def main(argv=None):
     tr_sampler = DistributedSampler(train_data, world, rank, shuffle=True) if world > 1 else None
     train_loader = DataLoader(dataset=train_data, batch_size=args.batch_size, shuffle=tr_sampler is None,
                               sampler=tr_sampler, num_workers=args.num_workers, drop_last=False)
-    val_loader = DataLoader(dataset=val_data, batch_size=args.batch_size, shuffle=False,
-                            num_workers=args.num_workers)
+    # validation is sharded over the ranks by BATCH (rank r evaluates batches r, r + world, ...) and merged by one gather
+    val_loader = DataLoader(dataset=val_data, num_workers=args.num_workers,
+                            batch_sampler=ShardedBatchSampler(len(val_data), args.batch_size, rank, world))
 
     spatial = (args.height // 16) * (args.width // 16)
     torch.manual_seed(0)
@@ -314,7 +358,7 @@ def main(argv=None):
             trainer.lr = args.l_rate / 10. if epoch == 0 else args.l_rate   # rate drops to l_rate/10 for one epoch
             if rank == 0:
                 print('learning rate %.5f' % trainer.lr)
-        val_epoch(args, trainer, val_loader, device, rank)
+        val_epoch(args, trainer, val_loader, device, rank, world)
     if world > 1:
         dist.destroy_process_group()
 

@@ -21,42 +21,65 @@ from . import utils as U
 from .q_and_v_eval import build_model, build_parser
 
 
+def _padded(args, Xs, ys):
+    """The last short batch PADDED to batch_size (q_and_v_test.py:80-87): questions 0 / q_len 1 / zero video / v_len 1 /
+    q_id 35 / label 0.  Returns (Xs, ys, q_ids, number of real examples)."""
+    num_real = ys.size(0)
+    q_ids = Xs.get('q_id', torch.zeros(num_real, dtype=torch.long))
+    if num_real < args.batch_size:
+        padded = args.batch_size - num_real
+        Xs = dict(Xs)
+        Xs['question'] = F.pad(Xs['question'], (0, 0, 0, padded), 'constant', 0)
+        Xs['q_len'] = F.pad(Xs['q_len'], (0, padded), 'constant', 1)
+        Xs['video'] = F.pad(Xs['video'], (0, 0, 0, 0, 0, 0, 0, 0, 0, padded), 'constant', 0)
+        Xs['v_len'] = F.pad(Xs['v_len'], (0, padded), 'constant', 1)
+        q_ids = F.pad(q_ids, (0, padded), 'constant', 35)
+        ys = F.pad(ys, (0, padded), 'constant', 0)
+    return Xs, ys, q_ids, num_real
+
+
 def test(args, model, trainer, data_loader, loss_fn, device):
-    """q_and_v_test.py:64-142."""
+    """q_and_v_test.py:64-142 on the inference path (Trainer.eval_step: forward-only fused trunk; the stem and the H2D copy
+    of the NEXT batch overlap this batch's trunk); loss, predictions, targets and question ids stay on the device and are
+    read back once after the last batch."""
     from sklearn.metrics import f1_score
     model.eval()
-    test_loss, hit, num_examples = 0.0, 0, 0
-    y_pred, y_target, qs = np.array([]), np.array([]), np.array([])
-    with torch.no_grad():
-        for Xs, ys in data_loader:
-            num_examples += len(ys)
-            num_real = ys.size(0)
-            q_ids = Xs.get('q_id', torch.zeros(num_real, dtype=torch.long))
-            if len(ys) < args.batch_size:                                                   # :80-87
-                padded = args.batch_size - ys.size(0)
-                Xs['question'] = F.pad(Xs['question'], (0, 0, 0, padded), 'constant', 0)
-                Xs['q_len'] = F.pad(Xs['q_len'], (0, padded), 'constant', 1)
-                Xs['video'] = F.pad(Xs['video'], (0, 0, 0, 0, 0, 0, 0, 0, 0, padded), 'constant', 0)
-                Xs['v_len'] = F.pad(Xs['v_len'], (0, padded), 'constant', 1)
-                q_ids = F.pad(q_ids, (0, padded), 'constant', 35)
-                ys = F.pad(ys, (0, padded), 'constant', 0)
-            clip = Xs['video'].float().to(device)
-            q = Xs['question'].to(device)
-            v_lens, q_lens = Xs['v_len'].long().cpu(), Xs['q_len'].long().cpu()
-            ys = ys.to(device)
-            native, v_sorted, perm = trainer.extract_features(clip, v_lens)                 # stem + sort (:101-116)
-            perm_d = perm.to(device)
-            ys_s, qid_s = ys[perm_d], q_ids[perm]
-            y_target = np.append(y_target, ys_s[:num_real].cpu().numpy())                   # :117-118
-            qs = np.append(qs, qid_s[:num_real].cpu().numpy())
-            if args.model != 'mac':                                                         # :121-122
-                model.init_hidden()
-            output = model(native, q[perm_d], v_sorted, q_lens[perm])[:num_real]            # :122-123
-            ys_s = ys_s[:num_real]
-            test_loss += float(loss_fn(output, ys_s))
-            pred_class = output.max(1)[1]
-            y_pred = np.append(y_pred, pred_class.cpu().numpy())
-            hit += int((pred_class == ys_s).sum())
+    num_examples = 0
+    loss_acc = torch.zeros((), dtype=torch.float64, device=device)
+    preds, targets, qids, reals = [], [], [], []
+
+    def stage(item):
+        Xs, ys, q_ids, num_real = _padded(args, *item)
+        clip = Xs['video'] if Xs['video'].dtype == torch.uint8 else Xs['video'].float()
+        clip = trainer.upload(clip.pin_memory() if not clip.is_pinned() else clip)
+        return (clip, Xs['question'].to(device, non_blocking=True), Xs['v_len'].long().cpu(), Xs['q_len'].long().cpu(),
+                ys.to(device, non_blocking=True), q_ids.to(device, non_blocking=True), num_real)
+
+    it = iter(data_loader)
+    cur = next(it, None)
+    cur = stage(cur) if cur is not None else None
+    while cur is not None:
+        nxt = next(it, None)
+        nxt = stage(nxt) if nxt is not None else None
+        clip, q, v_lens, q_lens, ys, q_ids, num_real = cur
+        num_examples += num_real
+        ahead = dict(next_clip=nxt[0], next_v_lens_cpu=nxt[2]) if nxt is not None else {}
+        loss, output, perm_d = trainer.eval_step(clip, q, v_lens, q_lens, ys, n_real=num_real, **ahead)   # stem + sort + forward (:101-123)
+        loss_acc += loss
+        targets.append(ys.index_select(0, perm_d))                                          # :117-118 (sorted order)
+        qids.append(q_ids.index_select(0, perm_d))
+        preds.append(output.max(1)[1])
+        reals.append(num_real)
+        cur = nxt
+    if preds:       # the ONE read-back
+        P, T, Q = (torch.stack(t).cpu().numpy() for t in (preds, targets, qids))
+        y_pred = np.concatenate([P[k][:n] for k, n in enumerate(reals)]).astype(np.float64)     # :123 the first num_real sorted rows
+        y_target = np.concatenate([T[k][:n] for k, n in enumerate(reals)]).astype(np.float64)
+        qs = np.concatenate([Q[k][:n] for k, n in enumerate(reals)]).astype(np.float64)
+    else:
+        y_pred, y_target, qs = np.array([]), np.array([]), np.array([])
+    test_loss = float(loss_acc)
+    hit = int((y_pred == y_target).sum())
     accs = U.per_class_accuracies(y_target, y_pred, args.num_classes)
     pp.pprint({i: accs[i] for i in np.nonzero(accs)[0].tolist()})
     f1_w = f1_score(y_target, y_pred, average='weighted')

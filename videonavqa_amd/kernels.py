@@ -142,15 +142,16 @@ def ps_fused_tile(x):
     return L.TILE_PS_224x256 if (tr + 2 + 2 * max_cross) * (tc + 2) <= 360 else L.TILE_AUTO
 
 
-def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res, tile=L.TILE_AUTO):
+def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res, tile=L.TILE_AUTO, keep_z=True):
     """z = conv(x) + bias and out = relu(gamma[n] * z + beta[n]) + res in ONE launch (VNQA_EPI_FILM_RES).  gamma / beta:
-    fp32 2-D views [n_img, >= film_c] with unit column stride (column slices of the FiLM generator's output)."""
+    fp32 2-D views [n_img, >= film_c] with unit column stride (column slices of the FiLM generator's output).
+    keep_z=False (inference): z, which only the backward reads, is not stored; returns (None, out)."""
     N, Hp, Wp, _ = x.shape
     c_out, taps, _ = wt.shape
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.stride(1) == 1 and beta.stride(1) == 1
     assert gamma.stride(0) == beta.stride(0) and res.shape == (N, Hp, Wp, c_out) and res.dtype == x.dtype
     d = _conv_desc(x, c_out, c_out, taps, False, tile if taps == 9 else L.TILE_AUTO)
-    z = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
+    z = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device) if keep_z else None
     out = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
     e = L.ConvEpilogue(kind=L.EPI_FILM_RES, film_ld=gamma.stride(0), film_c=int(film_c), gamma=gamma.data_ptr(),
                        beta=beta.data_ptr(), res=res.data_ptr(), y2=out.data_ptr())

@@ -422,6 +422,8 @@ class FiLMTrunkBase(nn.Module):
         needs nothing from the question; ops.FilmTrunkBlocksFn: the FiLM residual blocks).  film_specs[k] = (FiLM matrix
         [n_img, ld] fp32, column of block k's gamma) — beta follows at + C.  `join` (from _fork_generator) is called between the
         two nodes: the FiLM matrices may still be in flight on the generator's side stream until then."""
+        if not self.training:
+            return self._trunk_infer(x, lay, film_specs, join)
         C = self.num_res_block_channels
         meta = ops.TrunkMeta(lay, C, self.num_res_blocks, 0, [], BN_EPS, grad_scale=getattr(self, "_trunk_grad_scale", 1.0))
         bn = self.bn_init
@@ -476,8 +478,50 @@ class FiLMTrunkBase(nn.Module):
         return torch.float32 if self.compute_dtype == torch.float16 else self.compute_dtype
 
     def _use_fused_trunk(self):
+        """The fused conv-trunk path: train mode (two autograd nodes on the fused epilogues), and — round 4 — eval mode under
+        torch.no_grad() (val_epoch / test, eval/q_and_v_eval.py:159-224, eval/q_and_v_test.py:64-142): the forward-only
+        form of the same kernels (_trunk_infer).  Eval mode WITH autograd enabled keeps the op-by-op graph."""
         import os
-        return self.training and os.environ.get("VNQA_FUSED_TRUNK", "1") != "0"
+        if self.training:
+            return os.environ.get("VNQA_FUSED_TRUNK", "1") != "0"
+        return self._use_fused_eval()
+
+    def _use_fused_eval(self):
+        import os
+        return (not self.training) and (not torch.is_grad_enabled()) and os.environ.get("VNQA_FUSED_EVAL", "1") != "0"
+
+    def _trunk_infer(self, x, lay, film_specs, join=None):
+        """Forward-only conv trunk for inference (model.eval() under no_grad): three launches per FiLM block-model instead of
+        the op-by-op graph's seven —
+          conv_init -> ReLU -> eval-mode BatchNorm (film_attn_pt_stem.py:211 with running statistics): ONE conv launch, the
+            BatchNorm folded into the epilogue's per-channel affine (scale = gamma * rsqrt(running_var + eps), shift = beta -
+            running_mean * scale, applied to the fp32 accumulator after the ReLU, rounded once);
+          per block: the frozen 1x1 conv + ReLU, then conv3x3 -> FiLM -> ReLU -> + residual as one launch WITHOUT the z
+            output (VNQA_EPI_FILM_RES, y = NULL: only the backward reads z).
+        No autograd nodes, no statistics, no saved activations."""
+        C = self.num_res_block_channels
+        cdt = x.dtype
+        c_pad = L.round_up(C, 64)
+        bn = self.bn_init
+        scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + BN_EPS)
+        shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+        wt0 = K.pack_conv_weight(self.conv_init.weight, cdt, c_out_pad=c_pad, c_in_pad=x.shape[-1])
+        h = K.conv2d_igemm(x, wt0, bias=K.pad_vec(self.conv_init.bias, c_pad), relu=True,
+                           post_scale=K.pad_vec(scale, c_pad), post_shift=K.pad_vec(shift, c_pad))
+        if join is not None:
+            join()
+        packs = self._frozen_c1_packs(cdt, c_pad)
+        for k in range(self.num_res_blocks):
+            c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
+            wt1 = packs[k][0] if packs else K.pack_conv_weight(c1.weight, cdt, c_out_pad=c_pad, c_in_pad=c_pad)
+            res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(c1.bias, c_pad), relu=True)
+            film, col = film_specs[k]
+            if not (film.dtype == torch.float32 and film.stride(1) == 1):
+                film = film.float().contiguous()
+            _, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(c3.weight, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
+                                           K.pad_vec(c3.bias, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res,
+                                           tile=K.ps_fused_tile(res), keep_z=False)
+        return h
 
     def _trunk(self, x, lay, film_fn):
         """conv_init -> ReLU -> per-frame BN -> FiLM residual blocks.
@@ -518,7 +562,8 @@ class FiLMTrunkBase(nn.Module):
         mode = os.environ.get("VNQA_SIDE_LSTM", "auto")
         small = (n_img <= 420) if n_img is not None else getattr(self, "batch_size", 8) <= 16
         on = mode == "1" or (mode != "0" and small)
-        if not torch.cuda.is_available() or not on or not torch.is_grad_enabled():
+        # (under no_grad only the fused inference path forks: the op-by-op eval graph keeps everything on one stream)
+        if not torch.cuda.is_available() or not on or not (torch.is_grad_enabled() or self._use_fused_eval()):
             return fn(), (lambda: None)
         main = torch.cuda.current_stream()
         side = getattr(self, "_gen_stream", None)

@@ -382,9 +382,10 @@ class Trainer(object):
             done.record(self.stem_stream)
         self._prefetched = (key, native, v_sorted, perm, done, slot)
 
-    def step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
+    def _on_trunk_stream(self, fn, *args, **kw):
+        """Run fn on the trunk's own high-priority stream, ordered after the caller's stream and joined back to it."""
         if self.trunk_stream is None:
-            return self._step(clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip, next_v_lens_cpu)
+            return fn(*args, **kw)
         outer = torch.cuda.current_stream()
         self._inputs_ready = torch.cuda.Event()
         self._inputs_ready.record(outer)
@@ -392,7 +393,7 @@ class Trainer(object):
         with torch.cuda.stream(self.trunk_stream):
             self._in_step = True
             try:
-                out = self._step(clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip, next_v_lens_cpu)
+                out = fn(*args, **kw)
             finally:
                 self._in_step = False
         outer.wait_stream(self.trunk_stream)
@@ -401,13 +402,20 @@ class Trainer(object):
                 t.record_stream(outer)
         return out
 
-    def _step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
-        """One optimisation step.  v_lens_cpu / q_lens_cpu are host int64 tensors (as a DataLoader
-        delivers them); clip, q_input, ys are on the GPU.  If `next_clip` is given, its stem is
-        launched on the side stream so that it overlaps this step's trunk.  Returns (loss, logits) —
-        logits rows in length-sorted order like the reference (:121-130)."""
-        self.model.train()
-        main = torch.cuda.current_stream()
+    def step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
+        return self._on_trunk_stream(self._step, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip, next_v_lens_cpu)
+
+    def eval_step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None, n_real=None):
+        """Forward-only counterpart of step() for val_epoch / test (eval/q_and_v_eval.py:188-213, eval/q_and_v_test.py:
+        100-131): model.eval() under no_grad on the inference path (fused forward-only trunk), with the SAME software pipeline
+        as training — the frozen stem of `next_clip` runs on the stem stream beside this minibatch's trunk — and nothing
+        read back: returns (loss, logits, perm_d) as device tensors (logits rows in length-sorted order, perm_d the sort
+        permutation; loss over the first `n_real` sorted rows — q_and_v_test.py:123 slices a padded last batch that way)."""
+        return self._on_trunk_stream(self._eval_step, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip, next_v_lens_cpu,
+                                     n_real)
+
+    def _features_for(self, clip, v_lens_cpu, main):
+        """This minibatch's stem output: the prefetched one when `clip` is what prefetch() was given, else computed inline."""
         if self._prefetched is not None and self._prefetched[0] == clip.data_ptr():
             _, native, v_sorted, perm, done, slot = self._prefetched
             main.wait_event(done)
@@ -424,6 +432,35 @@ class Trainer(object):
             self._inline_stem_done = torch.cuda.Event()
             self._inline_stem_done.record(main)
         self._prefetched = None
+        return native, v_sorted, perm
+
+    def _eval_step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None, n_real=None):
+        self.model.eval()
+        main = torch.cuda.current_stream()
+        with torch.no_grad():
+            native, v_sorted, perm = self._features_for(clip, v_lens_cpu, main)
+            if next_clip is not None:
+                self.prefetch(next_clip, next_v_lens_cpu if next_v_lens_cpu is not None else v_lens_cpu)
+            perm_d = L.to_device_async(perm.to(torch.int32), self.stem_device)
+            if hasattr(self.model, "init_hidden"):
+                self.model.init_hidden()
+            logits = self.model(native, q_input.index_select(0, perm_d), v_sorted, q_lens_cpu[perm])
+            n = logits.shape[0] if n_real is None else int(n_real)
+            loss = ops.cross_entropy(logits[:n], ys, row_perm=perm_d[:n], weight=self.class_weights,
+                                     reduction=self.loss_reduction)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._trunk_done[self._slot] = ev
+        return loss.detach(), logits, perm_d
+
+    def _step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
+        """One optimisation step.  v_lens_cpu / q_lens_cpu are host int64 tensors (as a DataLoader
+        delivers them); clip, q_input, ys are on the GPU.  If `next_clip` is given, its stem is
+        launched on the side stream so that it overlaps this step's trunk.  Returns (loss, logits) —
+        logits rows in length-sorted order like the reference (:121-130)."""
+        self.model.train()
+        main = torch.cuda.current_stream()
+        native, v_sorted, perm = self._features_for(clip, v_lens_cpu, main)
         if next_clip is not None:
             self.prefetch(next_clip, next_v_lens_cpu if next_v_lens_cpu is not None else v_lens_cpu)
         perm_d = L.to_device_async(perm.to(torch.int32), self.stem_device)
