@@ -246,34 +246,40 @@ def cpu_baseline(argv, limit_s=420, logits_out=None):
             "sample": "cpu leg produced no measurement%s: %s" % (note, (err or "").strip()[-300:])}
 
 
-def fp16_leg(args):
+def fp16_leg(args, precision="fp16"):
     """The fp16-storage precision (libvnqa_hip_f16.so: the same kernels with IEEE fp16 as the 16-bit format, loss-scaled
     backward) measured on the same workload in a CHILD process — one 16-bit storage format per process — after this
     process's own measurement: throughput of a short run and its parity block against the exact-f32 precision."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--precision", "fp16", "--no-cpu-baseline", "--no-fp16-leg", "--repeats", "1",
+    cmd = [sys.executable, os.path.abspath(__file__), "--precision", precision, "--no-cpu-baseline", "--no-fp16-leg", "--repeats", "1",
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch), "--frames", str(args.frames),
            "--height", str(args.height), "--width", str(args.width), "--blocks", str(args.blocks), "--channels", str(args.channels)]
     env = {k: v for k, v in os.environ.items() if k not in ("VNQA_HALF",)}
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
         line = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
         if not line:
             return {"error": (r.stderr or "no output").strip()[-300:]}
         d = json.loads(line[-1])
         p = d.get("parity", {})
-        return {"what": "bench.py --precision fp16 (fp16 storage, fp32 accumulate, backward loss scale 2^10), %d timed steps, child process"
-                        % d["steps"],
+        what = ("bench.py --precision fp16 (fp16 storage, fp32 accumulate, dynamic loss scale from 2^10), %d timed steps, child process"
+                if precision == "fp16" else
+                "bench.py --precision fp16x: the TOLERANCE-COMPLIANT 16-bit-MFMA mode — fp32 storage, every forward conv / GEMM of the "
+                "stem and the trunk as three fp16-half products (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate) on the fp16 matrix "
+                "cores, exact-f32 backward; %d timed steps, child process") % d["steps"]
+        key = precision + "_logits_rel_err"
+        return {"what": what, "precision": precision,
                 # the precision's own full line: the same fields the top-level line carries, measured the same way
                 "metric": d["metric"], "value": d["value"], "unit": d["unit"], "dtype": d["dtype"], "steps": d["steps"],
                 "warmup": d["warmup"], "ms_per_step": d["ms_per_step"], "roofline": d["roofline"],
                 "stem_alone_ms": d["config"].get("stem_alone_ms"), "stem_alone_mfma_util": d["config"].get("stem_alone_mfma_util"),
                 "clips_per_s": d["value"], "roofline_frac": d["roofline"]["frac"],
-                "fp16_logits_rel_err": p.get("fp16_logits_rel_err"),
+                key: p.get(key), key + "_per_batch": p.get(key + "_per_batch"),
+                precision + "_logits_rel_l2_err_per_batch": p.get(precision + "_logits_rel_l2_err_per_batch"),
                 "argmax_equal_at_init": p.get("argmax_equal_at_init"), "loss_rel_err": p.get("loss_rel_err"),
                 "grad_rel_l2_err": p.get("grad_rel_l2_err"), "after_fit": p.get("after_fit")}
     except subprocess.TimeoutExpired:
-        return {"error": "fp16 leg exceeded 300 s"}
+        return {"error": "%s leg exceeded 420 s" % precision}
 
 
 def bench_cnn3d(args):
@@ -456,9 +462,9 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
             loss = tr.loss_fn(out, y[perm_d])
         return out, loss
 
-    low = args.precision if args.precision in ("bf16", "fp16") else "bf16"      # the 16-bit precision under test
+    low = args.precision if args.precision in ("bf16", "fp16", "fp16x") else "bf16"      # the 16-bit precision under test
     from videonavqa_amd import _lib as L
-    L.set_half("f16" if low == "fp16" else "bf16")       # one 16-bit storage format per process: fix it before the fp32 build
+    L.set_half("f16" if low in ("fp16", "fp16x") else "bf16")       # one 16-bit storage format per process: fix it before the fp32 build
     for prec in ("fp32", low):
         a = copy.copy(args)
         a.precision = prec
@@ -515,6 +521,7 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
         del tr, model, stem
         torch.cuda.empty_cache()
     rel = [float((b - f).abs().max() / f.abs().max()) for b, f in zip(logits[low], logits["fp32"])]
+    rel_l2 = [float((b - f).norm() / f.norm()) for b, f in zip(logits[low], logits["fp32"])]
     same = sum(int((b.argmax(1) == f.argmax(1)).sum()) for b, f in zip(logits[low], logits["fp32"]))
     total = sum(f.shape[0] for f in logits["fp32"])
 
@@ -555,7 +562,9 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
             "batches": "3 x (%d clips x %d frames %dx%d): full length, ragged, ragged; train-mode forward"
                        % (args.batch, args.frames, args.height, args.width),
             "precision": low,
-            "%s_logits_rel_err" % low: round(max(rel), 6), "%s_logits_rel_err_per_batch" % low: [round(r, 6) for r in rel],
+            "%s_logits_rel_err" % low: round(max(rel), 8), "%s_logits_rel_err_per_batch" % low: [round(r, 8) for r in rel],
+            # the same comparison as a relative L2 norm over the minibatch's logits (the max-norm figure above is the strict one)
+            "%s_logits_rel_l2_err_per_batch" % low: [round(r, 8) for r in rel_l2],
             "argmax_equal_at_init": "%d/%d" % (same, total), "fp32_top2_gap_rel_of_flipped_at_init": flipped,
             "loss_rel_err": round(max(abs(b - f) / max(abs(f), 1e-9) for b, f in zip(losses[low], losses["fp32"])), 6),
             "grad_rel_l2_err": round(float((gb - gf).norm() / gf.norm()), 6),
@@ -575,9 +584,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=3, help="the timed K-step region is run this many times back to back; "
                     "the reported value / ms_per_step are the MEDIAN region's, all regions are listed in `repeats`")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp16x", "fp32"],
                     help="bf16: the benchmark precision (BASELINE.json); fp16: the fp16-storage build of the library (same MFMA "
-                         "rate, 8x finer rounding, loss-scaled backward); fp32: the exact-f32 parity precision")
+                         "rate, 8x finer rounding, loss-scaled backward); fp16x: fp32 storage, forward contractions as three "
+                         "fp16-half products on the 16-bit matrix cores (the tolerance-compliant mode: logits within 1e-3 of "
+                         "exact fp32); fp32: the exact-f32 parity precision")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--frames", type=int, default=35)
     ap.add_argument("--height", type=int, default=224)
@@ -612,7 +623,7 @@ def main():
         cpu_baseline_child(args)
         return
 
-    if args.precision == "fp16":      # the fp16-storage build of the library (one 16-bit format per process)
+    if args.precision in ("fp16", "fp16x"):      # the fp16-storage build of the library (one 16-bit format per process)
         from videonavqa_amd import _lib as L
         L.set_half("f16")
     if args.model == "v_only_cnn3d":
@@ -809,7 +820,7 @@ def main():
         alone_events, stem.timing = stem.timing, None
     parity = None
     # (single-GPU runs only: at N > 1 the other ranks would sit in the barrier below for the minute this takes)
-    if world == 1 and not args.no_parity and args.model != "mac" and args.precision in ("bf16", "fp16"):
+    if world == 1 and not args.no_parity and args.model != "mac" and args.precision in ("bf16", "fp16", "fp16x"):
         loss = loss.clone()
         del trainer, model, stem
         torch.cuda.empty_cache()
@@ -854,6 +865,8 @@ def main():
         flops_per_launch = dstat["gflop_per_launch"] * 1e9
         achieved = dstat["achieved_tflops"]
         peak = PEAK_BF16_TFLOPS if args.precision in ("bf16", "fp16") else PEAK_F32_TFLOPS      # fp16 MFMA rate == bf16's
+        if args.precision == "fp16x":      # 3 fp16 MFMA products per algorithmic multiply-add: priced on the algorithmic FLOPs
+            peak = PEAK_BF16_TFLOPS / 3.0
         # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
         # live; collected with rocprofv3 --pmc in separate runs, corrected per the microarch guide) — only
         # valid for the default workload the passes were taken on
@@ -881,7 +894,7 @@ def main():
             "metric": METRIC, "value": round(clips, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp16x": "f16 x3 (forward contractions as three fp16-half MFMA products, fp32 storage / accumulate)", "fp32": "f32"}[args.precision], "data": "synthetic",
             "repeats": {"n": len(regions), "value_is": "median region", "clips_per_s": [round(c, 1) for c in all_clips],
                         "spread_rel": round((max(all_clips) - min(all_clips)) / clips, 4)},
             "config": {"workload": "%s training step: VGG-16[:10]+ObjDetectCNN(512) frozen stem + "
@@ -936,6 +949,8 @@ def main():
             out["parity"] = parity
         if world == 1 and args.precision == "bf16" and not args.no_fp16_leg and not args.no_parity and args.model == "film_attn_pt":
             out["fp16_mode"] = fp16_leg(args)
+            # the mode that meets north star's 1e-3 logits tolerance on all parity batches, with its own value / roofline
+            out["tolerance_mode"] = fp16_leg(args, "fp16x")
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
         print(json.dumps(out), flush=True)

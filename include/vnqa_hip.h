@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 403
+#define VNQA_ABI_VERSION 404
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -130,6 +130,28 @@ int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt
 int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
                              const float* post_scale, const float* post_shift, const void* border_sub,
                              void* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * precision='fp16x': fp32 contractions on the 16-bit matrix cores as three products of fp16 halves (csrc/split3.hip),
+ *      x . w = x_hi . w_hi + x_lo . w_hi + x_hi . w_lo,   v_hi = fp16(v), v_lo = fp16(v - v_hi),   fp32 accumulation:
+ * the same nn.Conv2d / nn.Linear call sites as vnqa_conv2d_igemm_fwd / vnqa_gemm_nt, for callers that need the reference's
+ * fp32 results to north star's 1e-3 (measured ~1e-5) but not bit-exactness, at 3/16 of the exact-f32 matrix path's cost.
+ *   vnqa_split3_f32     : rows x c fp32 (row stride src_ld) -> hi, lo and (optional, may be NULL) a second copy of hi, each
+ *                         rows x c in the library's 16-bit format with row stride dst_ld.  Channel-concatenated operand
+ *                         [hi | lo | hi]: (base, base + c, base + 2c), dst_ld = 3c.
+ *   vnqa_conv2d_igemm_raw : the 16-bit conv's raw fp32 accumulators [n_img*h*w][c_out] (d: dtype VNQA_BF16, c_in = the
+ *                         concatenated channel count, relu = pool2 = flags = 0, an implicit-GEMM tile id or VNQA_TILE_AUTO).
+ *   vnqa_x3_post        : y = post( pool2?( relu?( raw - border_sub + bias ) ) ) in fp32 -> padded NHWC fp32 interior
+ *                         (the epilogue contract of vnqa_conv2d_igemm_fwd_ex; border_sub fp32 [n][2w + 2(h-2)][c_out]).
+ *   vnqa_gemm_nt with dtype = VNQA_BF16 | VNQA_GEMM_OUT_F32 : 16-bit operands, fp32 `out` (workspace >= m*n*4 bytes required).
+ */
+int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld, int64_t dst_ld,
+                    void* stream);
+int vnqa_conv2d_igemm_raw(const vnqa_conv_desc* d, const void* x, const void* wt, float* raw, void* stream);
+int vnqa_x3_post(const float* raw, const float* bias, const float* post_scale, const float* post_shift, const float* border_sub,
+                 float* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y, int32_t y_halo, int32_t relu,
+                 int32_t pool2, void* stream);
+#define VNQA_GEMM_OUT_F32 0x200
 
 /* Fused trunk epilogues (BIAS_RELU_BNSTATS / BIAS_FILM_RELU_RES) — the same conv with the elementwise op
  * that FOLLOWS it in the reference applied while the output tile is still in LDS:

@@ -36,3 +36,10 @@ def test_kernel_and_model_suites_on_the_fp16_storage_build():
 def test_full_size_parity_of_the_headline_config_on_the_fp16_storage_build():
     tail = _run(["tests/test_gpu_fullsize.py", "-k", "config4_film_attn or stem_vs_torch"], 1500)
     assert " passed" in tail, tail
+
+
+def test_x3_products_and_the_fp16x_precision_on_the_fp16_build():
+    """precision='fp16x' (tests/test_gpu_x3.py): three-product fp16 MFMA contractions vs the exact-f32 path, the reference goldens,
+    and north star's 1e-3 on all three full-size parity batches — needs the fp16 build, hence this child run."""
+    tail = _run(["tests/test_gpu_x3.py"], 1500)
+    assert " passed" in tail and "skipped" not in tail.splitlines()[-1], tail

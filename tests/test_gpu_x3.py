@@ -1,0 +1,160 @@
+"""GPU: precision='fp16x' — fp32 contractions as three fp16-half products on the 16-bit matrix cores (csrc/split3.hip,
+kernels.f32_conv_mode) against the exact-f32 matrix path of the same library and against the reference's goldens.
+
+Runs in the fp16 build of the library (one 16-bit storage format per process): this module is collected only when the process's
+format is f16 (VNQA_TEST_LOW_PRECISION=fp16: tests/test_gpu_fp16.py starts that pytest run), or when no format is fixed yet."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import LOW, QV_CASES, build_product_model, load_golden, rel_err
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(LOW != "fp16", reason="x3 products need the fp16 build of the library: run with "
+                                                       "VNQA_TEST_LOW_PRECISION=fp16 (tests/test_gpu_fp16.py does)")]
+
+
+def _padded(n, h, w, c, seed, halo=1, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.zeros(n, h + 2 * halo, w + 2 * halo, c)
+    x[:, halo:halo + h, halo:halo + w] = torch.randn(n, h, w, c, generator=g) * scale
+    return x.cuda()
+
+
+def test_split3_halves_reconstruct_22_bits():
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(1000, 64, generator=g) * torch.logspace(-3, 2, 64)).cuda()
+    s = K.split3(x)
+    hi, lo, hi2 = s[:, :64].float(), s[:, 64:128].float(), s[:, 128:].float()
+    assert torch.equal(hi, hi2) and torch.equal(hi, x.half().float())
+    err = ((hi + lo) - x).abs()
+    assert float((err / x.abs().clamp_min(1e-3)).max()) < 2.0 ** -20          # 22 significand bits (fp16 subnormal floor below 1e-3)
+    assert float(K.split3(torch.zeros(8, 64, device="cuda")).abs().max()) == 0
+
+
+@pytest.mark.parametrize("cfg", [dict(cin=64, cout=64, taps=9, relu=True, pool=True),
+                                 dict(cin=128, cout=512, taps=9, relu=False, pool=False, post=True),
+                                 dict(cin=512, cout=512, taps=9, relu=True, pool=True),
+                                 dict(cin=512, cout=512, taps=1, relu=True, pool=False),
+                                 dict(cin=128, cout=256, taps=25, relu=True, pool=True, border=True)])
+def test_x3_conv_matches_exact_f32_conv(cfg):
+    """The x3 product against the exact-f32 MFMA conv of the same library on identical fp32 operands: <= 2e-5 of the output's
+    max (x_lo . w_lo is dropped: 2^-22 per product), with every epilogue piece (bias, ReLU, 2x2 pool, affine, border correction)."""
+    from videonavqa_amd import kernels as K
+    cin, cout, taps = cfg["cin"], cfg["cout"], cfg["taps"]
+    halo = 2 if taps == 25 else 1
+    n, h, w = 3, 12, 16
+    x = _padded(n, h, w, cin, 1, halo)
+    g = torch.Generator().manual_seed(2)
+    k = {9: 3, 1: 1, 25: 5}[taps]
+    wt = K.pack_conv_weight((torch.randn(cout, cin, k, k, generator=g) / (cin * taps) ** 0.5).cuda(), torch.float32)
+    bias = torch.randn(cout, generator=g).cuda() * 0.1
+    post = (torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda() * 0.1) if cfg.get("post") else (None, None)
+    ring = torch.randn(n, 2 * w + 2 * (h - 2), cout, generator=g).cuda() * 0.05 if cfg.get("border") else None
+    kw = dict(bias=bias, relu=cfg["relu"], pool2=cfg["pool"], post_scale=post[0], post_shift=post[1], x_halo=halo, border_sub=ring)
+    ref = K.conv2d_igemm(x, wt, **kw)
+    with K.f32_conv_mode("x3"):
+        got = K.conv2d_igemm(x, wt, **kw)
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    assert float(got[:, 0].abs().max()) == 0 and float(got[:, :, -1].abs().max()) == 0          # zero halo
+    assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    with K.f32_conv_mode("x3"):          # into a caller-provided buffer (the stem's persistent activations)
+        out = torch.zeros_like(ref)
+        K.conv2d_igemm(x, wt, out=out, **kw)
+    assert torch.equal(out, got)
+
+
+def test_x3_gemm_nt_matches_exact_f32():
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(280, 2048, generator=g).cuda()
+    b = (torch.randn(128, 2048, generator=g) / 45.0).cuda()
+    bias = torch.randn(128, generator=g).cuda()
+    ref = K.gemm_nt(a, b, bias=bias)
+    with K.f32_conv_mode("x3"):
+        got = K.gemm_nt(a, b, bias=bias)
+    assert got.dtype == torch.float32
+    assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert float((got - (a @ b.t() + bias)).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("case", QV_CASES)
+def test_fp16x_models_vs_reference_golden(case):
+    """precision='fp16x' on the reference's goldens: eval logits and train logits within 1e-3 (north star's tolerance; the
+    exact-f32 precision measures ~3e-7 here, this mode must stay in the same class), answer classes identical."""
+    import torch.nn as nn
+    model, g = build_product_model(case, "fp16x")
+    assert model.x3 and model.compute_dtype == torch.float32
+    v, q, vl, ql, y = (torch.from_numpy(g[k]).cuda() for k in ("v", "q", "v_lens", "q_lens", "y"))
+    model.eval()
+    with torch.no_grad():
+        model.init_hidden()
+        got = model(v, q, vl, ql).float().cpu().numpy()
+    assert rel_err(got, g["eval_logits"]) < 1e-4, rel_err(got, g["eval_logits"])
+    assert (got.argmax(1) == g["eval_logits"].argmax(1)).all()
+    model.train()
+    model.init_hidden()
+    logits = model(v, q, vl, ql)
+    loss = nn.CrossEntropyLoss(reduction="sum")(logits, y)
+    loss.backward()
+    got = logits.detach().float().cpu().numpy()
+    assert rel_err(got, g["train_logits"]) < 1e-4, rel_err(got, g["train_logits"])
+    assert (got.argmax(1) == g["train_logits"].argmax(1)).all()
+    assert abs(float(loss) - float(g["train_loss"])) < 1e-3 * max(1.0, abs(float(g["train_loss"])))
+    for name, p in model.named_parameters():          # exact-f32 backward on x3-forward activations
+        key = "grad/" + name
+        if key in g and p.grad is not None:
+            assert rel_err(p.grad.cpu().numpy(), g[key]) < 2e-3, name
+
+
+def test_fp16x_stem_vs_exact_f32_stem():
+    """The frozen stem (composed 5x5 pair included) in fp16x against the exact-f32 stem on the same weights and clip."""
+    import torch.nn as nn
+    from videonavqa_amd.models import ObjDetectCNN
+    from videonavqa_amd.models.common import FrameLayout
+    from videonavqa_amd.stem import FrozenStem, VGGFront
+    feats = {}
+    g = torch.Generator().manual_seed(5)
+    clip = torch.rand(2, 3, 64, 96, 3, generator=g).cuda()
+    for prec in ("fp32", "fp16x"):
+        torch.manual_seed(0)
+        vgg, od = VGGFront(prec), ObjDetectCNN(5, 512, 8, 0, True, True, precision=prec)
+        with torch.no_grad():
+            for conv in vgg.features.values():
+                nn.init.kaiming_uniform_(conv.weight, a=1.0)
+            for m in od.modules():
+                if isinstance(m, nn.Conv2d):
+                    nn.init.kaiming_uniform_(m.weight, a=1.0)
+                if isinstance(m, nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.1)
+                    m.running_var.uniform_(0.8, 1.2)
+        stem = FrozenStem(vgg.cuda().eval(), od.cuda().eval(), prec)
+        assert stem.composed is not None
+        lay = FrameLayout([3, 2], 3, "cuda")
+        feats[prec] = stem.forward_clip(clip, lay.img_of, lay.n_img).clone()
+    a, b = feats["fp16x"], feats["fp32"]
+    assert a.dtype == torch.float32 and float((a - b).abs().max()) < 5e-5 * float(b.abs().max())
+
+
+def test_fp16x_meets_1e3_on_all_three_full_size_parity_batches():
+    """the tolerance-compliant 16-bit-MFMA mode at BASELINE.json's full size (8 clips x 35 frames x 224 x 224, default
+    FiLM-attn model): logits within 1e-3 of the exact-f32 precision on ALL THREE parity minibatches (north star's tolerance —
+    asserted as stated, not a looser self-declared one), answer classes identical on all 24 samples."""
+    import argparse
+    import json
+    import bench as Bn
+    args = argparse.Namespace(precision="fp16x", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
+                              model="film_attn_pt", tail_channels=0)
+    res = Bn.precision_parity(args, torch.device("cuda", 0), speed_steps=2, fit_steps=6)
+    out_dir = os.path.join(os.path.dirname(os.path.abspath(Bn.__file__)), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_config4_film_attn_fp16x.json"), "w") as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res))
+    assert all(e <= 1e-3 for e in res["fp16x_logits_rel_err_per_batch"]), res
+    assert res["argmax_equal_at_init"] == "24/24", res
+    assert res["loss_rel_err"] < 1e-3 and res["grad_rel_l2_err"] < 1e-2, res
+    assert res["after_fit"]["fp16x_logits_rel_err"] <= 1e-3 and res["after_fit"]["argmax_equal"], res

@@ -1241,8 +1241,12 @@ extern "C" int64_t vnqa_gemm_nt_workspace(int32_t m, int32_t n, int32_t k, int32
 extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bias, void* out, void* workspace,
                             int32_t m, int32_t n, int32_t k, int32_t ldo, int32_t relu, int32_t dtype,
                             void* stream) {
+  const bool out_f32 = (dtype & VNQA_GEMM_OUT_F32) != 0;       // 16-bit operands, fp32 output (x3 products): per-call option bit
+  dtype &= ~VNQA_GEMM_OUT_F32;
   VNQA_CHECK_ARG(a_mk && b_nk && out, "gemm_nt: null pointer");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "gemm_nt: bad dtype %d", dtype);
+  VNQA_CHECK_ARG(!out_f32 || (dtype == VNQA_BF16 && workspace != nullptr),
+                 "gemm_nt: VNQA_GEMM_OUT_F32 needs 16-bit operands and a workspace of max(vnqa_gemm_nt_workspace, m*n*4) bytes");
   const int bk = dtype == VNQA_BF16 ? 64 : 32;
   VNQA_CHECK_ARG(m > 0 && n > 0 && k > 0 && k % bk == 0, "gemm_nt: k=%d must be a positive multiple of %d", k, bk);
   VNQA_CHECK_ARG(n % 8 == 0 && ldo >= n && ldo % 8 == 0, "gemm_nt: n=%d ldo=%d must be multiples of 8", n, ldo);
@@ -1272,8 +1276,8 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
     // (256x256 tiles for wide outputs — the stem's ring GEMM alone 112 -> 90 us — were measured and dropped: neutral end to
     // end at 224x224, -9 % at 160x208 where 412 such tiles fill 1.6 rounds of the chip)
   }
-  if (ws > 0) {
-    const int slices_req = (int)(ws / ((int64_t)m * n * 4));
+  if (ws > 0 || out_f32) {
+    const int slices_req = ws > 0 ? (int)(ws / ((int64_t)m * n * 4)) : 1;
     const int kt = k / bk;
     a.kt_per_slice = (kt + slices_req - 1) / slices_req;
     a.slices = (kt + a.kt_per_slice - 1) / a.kt_per_slice;
@@ -1283,7 +1287,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
     if (rc != VNQA_OK) return rc;
     const size_t total = (size_t)m * n;
     const int g = (int)((total / 4 + 15) / 16);
-    if (dtype == VNQA_BF16)
+    if (dtype == VNQA_BF16 && !out_f32)
       hipLaunchKernelGGL(splitk_reduce_kernel<vnqa_bf16>, dim3(g), dim3(256), 0, st, (const float*)workspace, bias,
                          (vnqa_bf16*)out, m, n, ldo, a.slices, relu);
     else
@@ -1492,6 +1496,25 @@ extern "C" int64_t vnqa_conv2d_bnstats_workspace(const vnqa_conv_desc* d, int32_
   if (2ll * min_frame_images * d->h * d->w + 2 <= bm) return -1;
   const int64_t tiles_m = ((int64_t)d->n_img * d->h * d->w + bm - 1) / bm;
   return tiles_m * 6 * d->c_out * 4;
+}
+
+// The conv's RAW fp32 accumulators [n_img * h * w][c_out] (dense, pixel-major, no bias / activation / pooling / halo): the
+// 16-bit implicit GEMM as a building block of the x3 products (csrc/split3.hip) — the operands are fp16 halves concatenated
+// along K (c_in = 3 x the layer's channels), the caller finishes the sums in fp32 (vnqa_x3_post).
+extern "C" int vnqa_conv2d_igemm_raw(const vnqa_conv_desc* d, const void* x, const void* wt, float* raw, void* stream) {
+  ConvArgs a;
+  const int rc = fill_conv_args(d, x, wt, nullptr, nullptr, nullptr, nullptr, raw, a);
+  if (rc != VNQA_OK) return rc;
+  VNQA_CHECK_ARG(d->dtype == VNQA_BF16 && !d->pool2 && d->depth == 0 && !d->wt_tiled && d->relu == 0 && d->flags == 0,
+                 "conv2d_igemm_raw: a plain 16-bit 2-D conv (no pooling / activation / pre-tiled weights / flags)");
+  VNQA_CHECK_ARG(d->c_out % 4 == 0 && ((uintptr_t)raw & 15) == 0, "conv2d_igemm_raw: c_out %% 4 == 0 and a 16-byte aligned output");
+  VNQA_CHECK_ARG(d->tile != VNQA_TILE_PATCH_224x256 && d->tile != VNQA_TILE_STEM_PATCH_224x256 && d->tile != VNQA_TILE_PS_224x256 &&
+                     d->tile != VNQA_TILE_STEM_PS_224x256,
+                 "conv2d_igemm_raw: implicit-GEMM tiles only (the patch kernels have no raw output)");
+  a.partial = raw;          // slice 0 of a one-slice split-K: the kernel's raw-accumulator store
+  a.slices = 1;
+  a.y = nullptr;
+  return conv_dispatch(a, d->dtype, d->tile, (hipStream_t)stream);
 }
 
 extern "C" int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,

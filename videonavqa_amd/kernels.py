@@ -67,9 +67,108 @@ def empty_padded(shape, dtype, device):
     return out
 
 
+# ---- precision='fp16x': fp32 contractions as three fp16-half products on the 16-bit matrix cores (csrc/split3.hip) --------------
+# While the mode is on (f32_conv_mode("x3"): the FORWARD passes of the fp16x models / stem), convs and GEMMs handed fp32 tensors run
+#   split (fp32 -> [hi | lo | hi] 16-bit, one pass) -> the 16-bit implicit GEMM over K' = 3K with raw fp32 accumulators out
+#   -> vnqa_x3_post (bias / ReLU / pool / affine / border correction in fp32)
+# instead of the exact-f32 matrix path (1/16 of the 16-bit MFMA rate).  Everything else of the fp32 precision — statistics, FiLM,
+# LSTMs, the backward pass — is unchanged, so the mode differs from exact fp32 by ~1e-6 per product (x_lo . w_lo dropped).
+_F32_CONV_MODE = ["exact"]
+
+
+class f32_conv_mode(object):
+    """Context manager: how convs / GEMMs on fp32 tensors are evaluated inside it — 'x3' or 'exact' (the default)."""
+
+    def __init__(self, mode):
+        assert mode in ("x3", "exact")
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = _F32_CONV_MODE[0]
+        _F32_CONV_MODE[0] = self.mode
+
+    def __exit__(self, *exc):
+        _F32_CONV_MODE[0] = self.prev
+        return False
+
+
+def x3_active(t):
+    return _F32_CONV_MODE[0] == "x3" and t.dtype == torch.float32 and t.is_cuda
+
+
+_X3_WS = {}
+
+
+def _x3_buffer(name, numel, dtype, device):
+    """Reusable scratch per (stream, role): the x3 operand and raw-accumulator buffers of consecutive layers on one stream."""
+    key = (name, str(device), torch.cuda.current_stream().cuda_stream, dtype)
+    buf = _X3_WS.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = _X3_WS[key] = torch.empty(int(numel), dtype=dtype, device=device)
+    return buf[:numel]
+
+
+def split3(x2d, out=None, layout="channels"):
+    """fp32 [rows, c] -> 16-bit halves.  layout 'channels': [rows, 3c] = [hi | lo | hi] (the activation operand of an x3 product)."""
+    rows, c = x2d.shape
+    assert x2d.dtype == torch.float32 and x2d.stride(1) == 1 and c % 8 == 0
+    half = L.half_dtype()
+    if out is None:
+        out = torch.empty((rows, 3 * c), dtype=half, device=x2d.device)
+    assert out.shape == (rows, 3 * c) and out.is_contiguous()
+    base, es = out.data_ptr(), out.element_size()
+    L.check(L.lib().vnqa_split3_f32(L.vptr(x2d), ctypes.c_void_p(base), ctypes.c_void_p(base + c * es),
+                                    ctypes.c_void_p(base + 2 * c * es), rows, c, x2d.stride(0), 3 * c, L.stream()), "vnqa_split3_f32")
+    return out
+
+
+def x3_weight(wt):
+    """fp32 K-major weights [n][...][k] -> 16-bit [n][...][3k] = [w_hi | w_hi | w_lo] along the innermost (contraction) axis, cached
+    on the tensor object for weights that persist (the frozen stem's packs; re-made when the tensor was modified in place)."""
+    cached = getattr(wt, "_vnqa_x3", None)
+    if cached is not None and cached[0] == wt._version:
+        return cached[1]
+    half = L.half_dtype()
+    hi = wt.to(half)
+    lo = (wt - hi.float()).to(half)
+    w3 = torch.cat([hi, hi, lo], dim=-1).contiguous()
+    try:
+        wt._vnqa_x3 = (wt._version, w3)
+    except (AttributeError, RuntimeError):
+        pass
+    return w3
+
+
+def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub):
+    N, Hp, Wp, Cin = x.shape
+    H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
+    c_out, taps, cin_w = wt.shape
+    assert cin_w == Cin and wt.dtype == torch.float32 and x.is_contiguous()
+    w3 = x3_weight(wt).view(c_out, taps, 3 * Cin)
+    half = L.half_dtype()
+    x3 = _x3_buffer("x3in", N * Hp * Wp * 3 * Cin, half, x.device).view(N * Hp * Wp, 3 * Cin)
+    split3(x.view(N * Hp * Wp, Cin), out=x3)
+    raw = _x3_buffer("raw", N * H * W * c_out, torch.float32, x.device)
+    tile = L.TILE_AUTO        # (the caller's tile id belongs to the exact-f32 kernels: the 16-bit product picks its own)
+    d = L.ConvDesc(L.BF16, N, H, W, 3 * Cin, c_out, c_out, taps, x_halo, 0, 0, 0, tile, 0, 0, 0)
+    L.check(L.lib().vnqa_conv2d_igemm_raw(ctypes.byref(d), L.ptr(x3), L.ptr(w3), L.ptr(raw), L.stream()), "vnqa_conv2d_igemm_raw")
+    Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
+    if out is None:
+        shape = (N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out)
+        out = empty_padded(shape, torch.float32, x.device) if y_halo == 1 else torch.zeros(shape, dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.shape[:3] == (N, Ho + 2 * y_halo, Wo + 2 * y_halo)
+    bs = None if border_sub is None else border_sub.float().contiguous()
+    L.check(L.lib().vnqa_x3_post(L.ptr(raw), L.ptr(bias), L.ptr(post_scale), L.ptr(post_shift), L.ptr(bs), L.ptr(out), N, H, W,
+                                 c_out, out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, L.stream()), "vnqa_x3_post")
+    return out
+
+
 def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
                  x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output."""
+    if x3_active(x) and not isinstance(wt, TiledWeight) and relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 \
+            and x.shape[-1] % 64 == 0:
+        return _conv2d_x3(x, wt, bias, bool(relu), pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub)
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
     tiled = isinstance(wt, TiledWeight)
@@ -150,6 +249,12 @@ def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res, tile=L.TILE_AUT
     c_out, taps, _ = wt.shape
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.stride(1) == 1 and beta.stride(1) == 1
     assert gamma.stride(0) == beta.stride(0) and res.shape == (N, Hp, Wp, c_out) and res.dtype == x.dtype
+    if x3_active(x):       # the conv as an x3 product, the FiLM affine + ReLU + residual as the separate fp32 kernel
+        z = conv2d_igemm(x, wt, bias=bias, x_halo=1 if taps == 9 else 1)
+        g = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
+        b = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
+        g[:, :film_c], b[:, :film_c] = gamma[:, :film_c], beta[:, :film_c]
+        return (z if keep_z else None), film_relu_res_fwd(z, res, g, b)
     d = _conv_desc(x, c_out, c_out, taps, False, tile if taps == 9 else L.TILE_AUTO)
     z = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device) if keep_z else None
     out = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
@@ -583,6 +688,18 @@ def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
     M, Kd = a.shape
     N = b.shape[0]
     assert b.shape[1] == Kd and a.dtype == b.dtype
+    if x3_active(a) and Kd % 64 == 0 and a.is_contiguous():
+        # x3 product: [a_hi | a_lo | a_hi] . [b_hi | b_hi | b_lo]^T on the 16-bit GEMM with an fp32 output
+        a3 = split3(a, out=_x3_buffer("x3in", M * 3 * Kd, L.half_dtype(), a.device).view(M, 3 * Kd))
+        b3 = x3_weight(b)
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        assert out.dtype == torch.float32
+        ws_bytes = max(L.lib().vnqa_gemm_nt_workspace(M, N, 3 * Kd, L.BF16) if split_k else 0, M * N * 4)
+        ws = workspace(ws_bytes, a.device)
+        L.check(L.lib().vnqa_gemm_nt(L.ptr(a3), L.ptr(b3), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, 3 * Kd, out.stride(0),
+                                     1 if relu else 0, L.BF16 | L.GEMM_OUT_F32, L.stream()), "vnqa_gemm_nt(x3)")
+        return out
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
     did = L.dtype_id(a.dtype)

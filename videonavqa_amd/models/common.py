@@ -36,7 +36,17 @@ def compute_dtype(precision):
         return torch.float16
     if precision in ("fp32", "f32", torch.float32):
         return torch.float32
-    raise ValueError("precision must be 'bf16', 'fp16' or 'fp32' (got %r)" % (precision,))
+    if precision == "fp16x":
+        # fp32 storage and elementwise work as in 'fp32', but the FORWARD contractions run on the fp16 matrix cores as three
+        # products of fp16 halves with fp32 accumulation (kernels.f32_conv_mode / csrc/split3.hip): the tolerance-compliant
+        # 16-bit-MFMA precision — logits within north star's 1e-3 of exact fp32 (measured ~1e-5) at a multiple of its speed
+        L.set_half("f16")
+        return torch.float32
+    raise ValueError("precision must be 'bf16', 'fp16', 'fp16x' or 'fp32' (got %r)" % (precision,))
+
+
+def is_x3(precision):
+    return precision == "fp16x"
 
 
 # Loss scale of the fp16-storage precision: the activation gradients that enter the conv trunk from the attention tail are
@@ -254,6 +264,14 @@ class FiLMTrunkBase(nn.Module):
     stock torch.nn modules so that names, shapes, init and state_dict match the reference
     (GPU flavour: film_layer registered, conv1x1_layers a plain list — SURVEY §0.5/0.6);
     their forward() is never called: compute goes through videonavqa_amd.ops."""
+
+    def __call__(self, *args, **kwargs):
+        # precision='fp16x' (self.x3): convs / GEMMs on fp32 tensors inside this forward run as x3 products; the backward pass,
+        # which runs after this context has closed, keeps the exact-f32 matrix path
+        if self.__dict__.get("x3", False):
+            with K.f32_conv_mode("x3"):
+                return super().__call__(*args, **kwargs)
+        return super().__call__(*args, **kwargs)
 
     def _build_trunk_head(self, num_input_channels, num_res_block_channels):
         """relu / conv_init / bn_init — registered first, as upstream (film_attn_pt_stem.py:39-42)."""

@@ -78,6 +78,7 @@ class FrozenStem(object):
     def __init__(self, vgg, objdet, precision='bf16'):
         from .models.common import compute_dtype
         self.cdt = compute_dtype(precision)
+        self.x3 = precision == "fp16x"       # fp32 storage, contractions as three fp16-half products (kernels.f32_conv_mode)
         self.vgg, self.objdet = vgg, objdet
         self.layers_vgg, self.layers_od = [], []
         self.composed = None
@@ -144,8 +145,8 @@ class FrozenStem(object):
                 tile = L.TILE_256x256_W16
         else:
             tile = L.TILE_128x64 if c_out_pad <= 64 else L.TILE_128x128
-        if tile is None or tile in (L.TILE_256x256_W16, L.TILE_PS_224x256, L.TILE_STEM_PS_224x256) or \
-                os.environ.get("VNQA_STEM_TILED", "1") == "0":
+        if tile is None or tile in (L.TILE_256x256_W16, L.TILE_PS_224x256, L.TILE_STEM_PS_224x256) or self.x3 or \
+                os.environ.get("VNQA_STEM_TILED", "1") == "0":      # (x3 products read the K-major pack)
             wt = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         else:   # frozen weights: pre-tiled once into the exact LDS images the igemm DMA consumes
             wt = K.pack_conv_weight_tiled(w, self.cdt, tile, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
@@ -200,7 +201,7 @@ class FrozenStem(object):
         if bf16 and os.environ.get("VNQA_STEM_COMPOSE_TILE"):
             tile = int(os.environ["VNQA_STEM_COMPOSE_TILE"])      # A/B hook
         wcf = wc.float().contiguous().to(dev)
-        if tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256) and os.environ.get("VNQA_STEM_TILED", "1") != "0":
+        if tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256) and os.environ.get("VNQA_STEM_TILED", "1") != "0" and not self.x3:
             wt = K.pack_conv_weight_tiled(wcf, self.cdt, tile, c_out_pad=co_pad, c_in_pad=ci_pad)
         else:
             wt = K.pack_conv_weight(wcf, self.cdt, c_out_pad=co_pad, c_in_pad=ci_pad)
@@ -281,8 +282,9 @@ class FrozenStem(object):
             out = self._buf(key, (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
             post = ly["post"]
             tile = ly["tile"]
-            timed = self.timing is not None and tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256)      # (C_out = 512 layers, whichever kernel serves them)
-            kname = "conv_igemm_kernel"
+            timed = self.timing is not None and (tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256) or
+                                                 (self.x3 and ly["c_out_pad"] >= 256))      # (C_out = 512 layers, whichever kernel serves them)
+            kname = "conv_igemm_kernel" if not self.x3 else "x3 product (split + conv_igemm_kernel raw + post)"
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
@@ -318,6 +320,9 @@ class FrozenStem(object):
         `slot` selects one of several OUTPUT buffers (the intermediates are shared), so that the
         features of step i stay alive for its backward while step i+1's stem already runs."""
         assert self.vgg is not None and self.objdet is not None
+        if self.x3 and K._F32_CONV_MODE[0] != "x3":
+            with K.f32_conv_mode("x3"):
+                return self.forward_clip(clip, img_of, n_img, slot)
         B, _, H, W, T = clip.shape
         ly = self.layers_vgg[0]
         if L.is_half(self.cdt) and ly["tile"] is None and os.environ.get("VNQA_FUSE_FIRST", "1") != "0":

@@ -334,16 +334,20 @@ class Trainer(object):
         stem(i+1) and trunk(i) run, the copy engine, the stem and the trunk form a 3-stage pipeline."""
         if self.copy_stream is None:
             self.copy_stream = torch.cuda.Stream()
-            self._up_bufs, self._up_idx, self._up_events = [None, None, None], 0, {}
+            self._up_bufs, self._up_idx, self._up_events, self._up_read_done = [None, None, None], 0, {}, {}
         i = self._up_idx
         self._up_idx = (i + 1) % 3
         if self._up_bufs[i] is None or self._up_bufs[i].shape != clip_host.shape:
             self._up_bufs[i] = torch.empty(clip_host.shape, dtype=clip_host.dtype, device=self.stem_device)
         buf = self._up_bufs[i]
-        self.copy_stream.wait_stream(self.stem_stream)       # the stem that last read this buffer is long queued
-        # ... or it ran inline on the caller's stream (a step whose clip was not prefetched): the buffer was handed out three
-        # uploads ago, so waiting for what that stream holds NOW costs no overlap — this copy still runs under the next step
-        self.copy_stream.wait_stream(torch.cuda.current_stream())
+        # The copy may overwrite this buffer once the stem pass that last READ it has finished — an event recorded right after
+        # that pass on whichever stream ran it (_mark_clip_read).  Rounds 1-3 made the copy wait for the whole stem stream
+        # instead, i.e. for stem(i+1), which had just been enqueued: the copy of clip i+2 then started only when stem(i+1)
+        # ended and stem(i+2) waited for the copy — the stem stream, the pipeline's bottleneck, idled for the length of every
+        # copy (-4 % with fp32 clips AND with uint8 clips a quarter the size: profiles/r04_h2d.txt).
+        ev = self._up_read_done.get(buf.data_ptr())
+        if ev is not None:
+            self.copy_stream.wait_event(ev)
         with torch.cuda.stream(self.copy_stream):
             buf.copy_(clip_host, non_blocking=True)
             ev = torch.cuda.Event()
@@ -355,6 +359,14 @@ class Trainer(object):
         ev = self._up_events.get(clip.data_ptr()) if self.copy_stream is not None else None
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
+
+    def _mark_clip_read(self, clip):
+        """Right after a stem pass over `clip` on the current stream: if it is one of upload()'s rotating buffers, record that its
+        last reader is done (the next copy into that buffer waits for exactly this)."""
+        if self.copy_stream is not None and clip.is_cuda and clip.data_ptr() in self._up_events:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._up_read_done[clip.data_ptr()] = ev
 
     def prefetch(self, clip, v_lens_cpu):
         """Start the stem of an upcoming minibatch on the side stream (returns immediately)."""
@@ -378,6 +390,7 @@ class Trainer(object):
                 clip = clip.to(self.stem_device, non_blocking=True)
             self._wait_upload(clip)
             native, v_sorted, perm = self.extract_features(clip, v_lens_cpu, slot=slot)
+            self._mark_clip_read(clip)
             done = torch.cuda.Event()
             done.record(self.stem_stream)
         self._prefetched = (key, native, v_sorted, perm, done, slot)
@@ -429,6 +442,7 @@ class Trainer(object):
             # buffer with this pass — wait for it, and make the next prefetch wait for this pass (event below)
             main.wait_stream(self.stem_stream)
             native, v_sorted, perm = self.extract_features(clip, v_lens_cpu, slot=self._slot)
+            self._mark_clip_read(clip)
             self._inline_stem_done = torch.cuda.Event()
             self._inline_stem_done.record(main)
         self._prefetched = None
