@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 404
+#define VNQA_ABI_VERSION 405
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -142,15 +142,17 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
  *   vnqa_conv2d_igemm_raw : the 16-bit conv's raw fp32 accumulators [n_img*h*w][c_out] (d: dtype VNQA_BF16, c_in = the
  *                         concatenated channel count, relu = pool2 = flags = 0, an implicit-GEMM tile id or VNQA_TILE_AUTO).
  *   vnqa_x3_post        : y = post( pool2?( relu?( raw - border_sub + bias ) ) ) in fp32 -> padded NHWC fp32 interior
- *                         (the epilogue contract of vnqa_conv2d_igemm_fwd_ex; border_sub fp32 [n][2w + 2(h-2)][c_out]).
+ *                         (the epilogue contract of vnqa_conv2d_igemm_fwd_ex; border_sub fp32 [n][2w + 2(h-2)][c_out]);
+ *                         out_x3 != 0: y is 16-bit [..][c_y >= 3 c_out] and receives the halves [hi | lo | hi] instead — the
+ *                         next x3 product's operand, no fp32 round trip between consecutive layers.
  *   vnqa_gemm_nt with dtype = VNQA_BF16 | VNQA_GEMM_OUT_F32 : 16-bit operands, fp32 `out` (workspace >= m*n*4 bytes required).
  */
 int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld, int64_t dst_ld,
                     void* stream);
 int vnqa_conv2d_igemm_raw(const vnqa_conv_desc* d, const void* x, const void* wt, float* raw, void* stream);
 int vnqa_x3_post(const float* raw, const float* bias, const float* post_scale, const float* post_shift, const float* border_sub,
-                 float* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y, int32_t y_halo, int32_t relu,
-                 int32_t pool2, void* stream);
+                 void* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y, int32_t y_halo, int32_t relu,
+                 int32_t pool2, int32_t out_x3, void* stream);
 #define VNQA_GEMM_OUT_F32 0x200
 
 /* Fused trunk epilogues (BIAS_RELU_BNSTATS / BIAS_FILM_RELU_RES) — the same conv with the elementwise op

@@ -31,7 +31,10 @@ def test_split3_halves_reconstruct_22_bits():
     hi, lo, hi2 = s[:, :64].float(), s[:, 64:128].float(), s[:, 128:].float()
     assert torch.equal(hi, hi2) and torch.equal(hi, x.half().float())
     err = ((hi + lo) - x).abs()
-    assert float((err / x.abs().clamp_min(1e-3)).max()) < 2.0 ** -20          # 22 significand bits (fp16 subnormal floor below 1e-3)
+    # 22 significand bits, down to the absolute floor of fp16's subnormal spacing (2^-24) for the low half of small values
+    assert bool((err <= 2.0 ** -25 + 2.0 ** -22 * x.abs()).all())
+    big = x.abs() >= 0.25
+    assert float((err[big] / x.abs()[big]).max()) < 2.0 ** -21
     assert float(K.split3(torch.zeros(8, 64, device="cuda")).abs().max()) == 0
 
 
@@ -103,15 +106,20 @@ def test_fp16x_models_vs_reference_golden(case):
     got = logits.detach().float().cpu().numpy()
     assert rel_err(got, g["train_logits"]) < 1e-4, rel_err(got, g["train_logits"])
     assert (got.argmax(1) == g["train_logits"].argmax(1)).all()
-    assert abs(float(loss) - float(g["train_loss"])) < 1e-3 * max(1.0, abs(float(g["train_loss"])))
+    assert abs(float(loss.detach()) - float(g["train_loss"])) < 1e-3 * max(1.0, abs(float(g["train_loss"])))
     for name, p in model.named_parameters():          # exact-f32 backward on x3-forward activations
         key = "grad/" + name
-        if key in g and p.grad is not None:
-            assert rel_err(p.grad.cpu().numpy(), g[key]) < 2e-3, name
+        if key in g and p.grad is not None:          # (as the fp32 precision's test: within 2e-3 of the tensor's max, +1e-6 for
+            ref, got_g = g[key], p.grad.cpu().numpy()    # gradients that are analytically zero)
+            assert np.abs(got_g - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-6, name
 
 
-def test_fp16x_stem_vs_exact_f32_stem():
-    """The frozen stem (composed 5x5 pair included) in fp16x against the exact-f32 stem on the same weights and clip."""
+@pytest.mark.parametrize("plain_first", [False, True])
+def test_fp16x_stem_vs_exact_f32_stem(plain_first, monkeypatch):
+    """The frozen stem (composed 5x5 pair included) in fp16x against the exact-f32 stem on the same weights and clip: every layer
+    as an x3 product (VNQA_X3_PLAIN_FIRST=0: 5e-5 of the features' max), and the default with conv1_1 + conv1_2 on the plain fp16
+    fused kernel (five fp16 roundings: stated 3e-3 on the features)."""
+    monkeypatch.setenv("VNQA_X3_PLAIN_FIRST", "1" if plain_first else "0")
     import torch.nn as nn
     from videonavqa_amd.models import ObjDetectCNN
     from videonavqa_amd.models.common import FrameLayout
@@ -136,7 +144,7 @@ def test_fp16x_stem_vs_exact_f32_stem():
         lay = FrameLayout([3, 2], 3, "cuda")
         feats[prec] = stem.forward_clip(clip, lay.img_of, lay.n_img).clone()
     a, b = feats["fp16x"], feats["fp32"]
-    assert a.dtype == torch.float32 and float((a - b).abs().max()) < 5e-5 * float(b.abs().max())
+    assert a.dtype == torch.float32 and float((a - b).abs().max()) < (3e-3 if plain_first else 5e-5) * float(b.abs().max())
 
 
 def test_fp16x_meets_1e3_on_all_three_full_size_parity_batches():

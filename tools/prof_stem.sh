@@ -2,7 +2,7 @@
 # ON THE GPU BOX: per-kernel split of the frozen stem alone (tools/stem_only.py under rocprofv3 --kernel-trace --stats)
 R=$PWD; export PYTHONPATH=$R
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ps
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -- python3 $R/tools/stem_only.py --iters 20 > /tmp/ps.out 2> /tmp/ps.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -- python3 $R/tools/stem_only.py --iters 20 $STEM_ARGS > /tmp/ps.out 2> /tmp/ps.err
 cd $R
 F=$(find /tmp/ps -name '*kernel_stats.csv' | head -1)
 tail -1 /tmp/ps.out

@@ -20,8 +20,12 @@ def main():
     ap.add_argument("--height", type=int, default=224)
     ap.add_argument("--width", type=int, default=224)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--precision", default="bf16")
     a = ap.parse_args()
-    a.precision, a.model, a.blocks, a.channels, a.tail_channels = "bf16", "film_attn_pt", 1, 512, 0
+    a.model, a.blocks, a.channels, a.tail_channels = "film_attn_pt", 1, 512, 0
+    if a.precision in ("fp16", "fp16x"):
+        from videonavqa_amd import _lib as L
+        L.set_half("f16")
     stem = bench.build(a, torch.device("cuda"))[1]
     clip = torch.randn(a.batch, 3, a.height, a.width, a.frames, device="cuda")
     lay = FrameLayout([a.frames] * a.batch, a.frames, "cuda")

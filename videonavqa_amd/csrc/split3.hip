@@ -48,6 +48,8 @@ struct PostArgs {
   const float* post_shift;
   const float* border_sub;  // [n][2w + 2(h-2)][c_out] fp32 or null
   float* y;                 // padded NHWC [n][ho + 2 yh][wo + 2 yh][c_y] fp32, interior written
+  unsigned short* y16;      // != null: the output as the NEXT x3 product's operand instead — 16-bit [..][c_y], channels
+                            // [hi | lo | hi] at c, c_out + c, 2 c_out + c (c_y >= 3 c_out): no fp32 round trip between layers
   int n, h, w, c_out, c_y, y_halo, relu, pool;
 };
 
@@ -98,7 +100,21 @@ __global__ void __launch_bounds__(256) x3_post_kernel(const PostArgs p) {
       const float4 s = *(const float4*)(p.post_scale + c), t = *(const float4*)(p.post_shift + c);
       v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
     }
-    *(float4*)(p.y + (((size_t)n * hyp + yo + p.y_halo) * wyp + xo + p.y_halo) * p.c_y + c) = v;
+    const size_t pix = (((size_t)n * hyp + yo + p.y_halo) * wyp + xo + p.y_halo) * p.c_y;
+    if (p.y16 == nullptr) {
+      *(float4*)(p.y + pix + c) = v;
+    } else {
+      uint2 h, l;
+      h.x = pack2_h16(v.x, v.y);
+      h.y = pack2_h16(v.z, v.w);
+      const float r0 = v.x - h16_lo(h.x), r1 = v.y - h16_hi(h.x), r2 = v.z - h16_lo(h.y), r3 = v.w - h16_hi(h.y);
+      l.x = pack2_h16(r0 == r0 ? r0 : 0.f, r1 == r1 ? r1 : 0.f);
+      l.y = pack2_h16(r2 == r2 ? r2 : 0.f, r3 == r3 ? r3 : 0.f);
+      unsigned short* o = p.y16 + pix + c;
+      *(uint2*)o = h;
+      *(uint2*)(o + p.c_out) = l;
+      *(uint2*)(o + 2 * p.c_out) = h;
+    }
   }
 }
 
@@ -123,17 +139,19 @@ extern "C" int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, in
 }
 
 extern "C" int vnqa_x3_post(const float* raw, const float* bias, const float* post_scale, const float* post_shift,
-                            const float* border_sub, float* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y,
-                            int32_t y_halo, int32_t relu, int32_t pool2, void* stream) {
+                            const float* border_sub, void* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y,
+                            int32_t y_halo, int32_t relu, int32_t pool2, int32_t out_x3, void* stream) {
   VNQA_CHECK_ARG(raw && y, "x3_post: null pointer");
-  VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0 && c_out > 0 && c_out % 4 == 0 && c_y >= c_out && c_y % 4 == 0,
+  VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0 && c_out > 0 && c_out % 4 == 0 && c_y >= (out_x3 ? 3 : 1) * c_out && c_y % 4 == 0,
                  "x3_post: bad geometry n=%d h=%d w=%d c_out=%d c_y=%d", n_img, h, w, c_out, c_y);
   VNQA_CHECK_ARG(y_halo >= 0 && y_halo <= 2 && (relu == 0 || relu == 1), "x3_post: y_halo in 0..2, relu in 0..1");
   VNQA_CHECK_ARG(!pool2 || (h % 2 == 0 && w % 2 == 0), "x3_post: pool2 needs even h, w");
   VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "x3_post: post_scale / post_shift come together");
   VNQA_CHECK_ARG(border_sub == nullptr || (h >= 2 && w >= 2), "x3_post: border_sub needs h, w >= 2");
   PostArgs p;
-  p.raw = raw; p.bias = bias; p.post_scale = post_scale; p.post_shift = post_shift; p.border_sub = border_sub; p.y = y;
+  p.raw = raw; p.bias = bias; p.post_scale = post_scale; p.post_shift = post_shift; p.border_sub = border_sub;
+  p.y = out_x3 ? nullptr : (float*)y;
+  p.y16 = out_x3 ? (unsigned short*)y : nullptr;
   p.n = n_img; p.h = h; p.w = w; p.c_out = c_out; p.c_y = c_y; p.y_halo = y_halo; p.relu = relu; p.pool = pool2 ? 1 : 0;
   const long long total = (long long)n_img * (pool2 ? h / 2 : h) * (pool2 ? w / 2 : w) * (c_out / 4);
   hipLaunchKernelGGL(x3_post_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);

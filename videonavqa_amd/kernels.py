@@ -139,36 +139,81 @@ def x3_weight(wt):
     return w3
 
 
-def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub):
-    N, Hp, Wp, Cin = x.shape
-    H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
-    c_out, taps, cin_w = wt.shape
-    assert cin_w == Cin and wt.dtype == torch.float32 and x.is_contiguous()
-    w3 = x3_weight(wt).view(c_out, taps, 3 * Cin)
+def x3_weight2(wt):
+    """[w_hi | w_lo] along the contraction axis: the weight operand for an input that is ALREADY 16-bit (nothing to split on the
+    activation side: two products instead of three)."""
+    cached = getattr(wt, "_vnqa_x2", None)
+    if cached is not None and cached[0] == wt._version:
+        return cached[1]
     half = L.half_dtype()
-    x3 = _x3_buffer("x3in", N * Hp * Wp * 3 * Cin, half, x.device).view(N * Hp * Wp, 3 * Cin)
-    split3(x.view(N * Hp * Wp, Cin), out=x3)
+    hi = wt.to(half)
+    w2 = torch.cat([hi, (wt - hi.float()).to(half)], dim=-1).contiguous()
+    try:
+        wt._vnqa_x2 = (wt._version, w2)
+    except (AttributeError, RuntimeError):
+        pass
+    return w2
+
+
+def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub, x3_out=False):
+    """One conv as an x3 product.  x: fp32 [.., C] (split here), or 16-bit [.., 3C] already in the [hi | lo | hi] operand layout
+    (the previous layer's x3_out), or 16-bit [.., C] (a plain 16-bit activation: [x | x] against [w_hi | w_lo], two products).
+    Output: fp32 padded NHWC, or with x3_out the next layer's 16-bit operand [.., 3 c_out]."""
+    N, Hp, Wp, Cx = x.shape
+    H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
+    c_out, taps, Cin = wt.shape
+    assert wt.dtype == torch.float32 and x.is_contiguous()
+    half = L.half_dtype()
+    if x.dtype == torch.float32:
+        assert Cx == Cin
+        k = 3 * Cin
+        w3 = x3_weight(wt).view(c_out, taps, k)
+        xin = _x3_buffer("x3in", N * Hp * Wp * k, half, x.device).view(N * Hp * Wp, k)
+        split3(x.view(N * Hp * Wp, Cin), out=xin)
+    elif Cx == 3 * Cin:
+        assert x.dtype == half
+        k, xin = 3 * Cin, x
+        w3 = x3_weight(wt).view(c_out, taps, k)
+    else:
+        assert x.dtype == half and Cx == Cin
+        k = 2 * Cin
+        w3 = x3_weight2(wt).view(c_out, taps, k)
+        xin = _x3_buffer("x3in", N * Hp * Wp * k, half, x.device).view(N, Hp, Wp, k)
+        torch.cat([x, x], dim=-1, out=xin)
     raw = _x3_buffer("raw", N * H * W * c_out, torch.float32, x.device)
-    tile = L.TILE_AUTO        # (the caller's tile id belongs to the exact-f32 kernels: the 16-bit product picks its own)
-    d = L.ConvDesc(L.BF16, N, H, W, 3 * Cin, c_out, c_out, taps, x_halo, 0, 0, 0, tile, 0, 0, 0)
-    L.check(L.lib().vnqa_conv2d_igemm_raw(ctypes.byref(d), L.ptr(x3), L.ptr(w3), L.ptr(raw), L.stream()), "vnqa_conv2d_igemm_raw")
+    d = L.ConvDesc(L.BF16, N, H, W, k, c_out, c_out, taps, x_halo, 0, 0, 0, L.TILE_AUTO, 0, 0, 0)      # (the 16-bit product picks its own tile)
+    L.check(L.lib().vnqa_conv2d_igemm_raw(ctypes.byref(d), L.ptr(xin), L.ptr(w3), L.ptr(raw), L.stream()), "vnqa_conv2d_igemm_raw")
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
+    odt, oc = (half, 3 * c_out) if x3_out else (torch.float32, c_out)
     if out is None:
-        shape = (N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out)
-        out = empty_padded(shape, torch.float32, x.device) if y_halo == 1 else torch.zeros(shape, dtype=torch.float32, device=x.device)
-    assert out.dtype == torch.float32 and out.shape[:3] == (N, Ho + 2 * y_halo, Wo + 2 * y_halo)
+        shape = (N, Ho + 2 * y_halo, Wo + 2 * y_halo, oc)
+        out = empty_padded(shape, odt, x.device) if y_halo == 1 else torch.zeros(shape, dtype=odt, device=x.device)
+    assert out.dtype == odt and out.shape[:3] == (N, Ho + 2 * y_halo, Wo + 2 * y_halo) and out.shape[-1] >= oc
     bs = None if border_sub is None else border_sub.float().contiguous()
     L.check(L.lib().vnqa_x3_post(L.ptr(raw), L.ptr(bias), L.ptr(post_scale), L.ptr(post_shift), L.ptr(bs), L.ptr(out), N, H, W,
-                                 c_out, out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, L.stream()), "vnqa_x3_post")
+                                 c_out, out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, 1 if x3_out else 0, L.stream()),
+            "vnqa_x3_post")
+    return out
+
+
+def x3_post_again(out, n, h, w, c_out, y_halo, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None):
+    """The raw sums of the x3 product that JUST ran on this stream (still in its scratch buffer), finished once more as fp32 into
+    `out` — for a layer whose output is needed both as the next product's 16-bit operand and as an fp32 tensor."""
+    raw = _x3_buffer("raw", n * h * w * c_out, torch.float32, out.device)
+    assert out.dtype == torch.float32
+    L.check(L.lib().vnqa_x3_post(L.ptr(raw), L.ptr(bias), L.ptr(post_scale), L.ptr(post_shift), None, L.ptr(out), n, h, w, c_out,
+                                 out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, 0, L.stream()), "vnqa_x3_post")
     return out
 
 
 def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
-                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None):
-    """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output."""
-    if x3_active(x) and not isinstance(wt, TiledWeight) and relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 \
-            and x.shape[-1] % 64 == 0:
-        return _conv2d_x3(x, wt, bias, bool(relu), pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub)
+                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False):
+    """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
+    (x3_out: only inside f32_conv_mode("x3") — the output as the next x3 product's 16-bit operand, see _conv2d_x3.)"""
+    if _F32_CONV_MODE[0] == "x3" and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
+            relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 and x.shape[-1] % 64 == 0:
+        return _conv2d_x3(x, wt, bias, bool(relu), pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub, x3_out)
+    assert not x3_out, "x3_out needs f32_conv_mode('x3') and fp32 K-major weights"
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
     tiled = isinstance(wt, TiledWeight)

@@ -49,8 +49,8 @@ class VGGFront(nn.Module):
         return out
 
     def forward(self, x):
-        if self._plan is None:
-            self._plan = FrozenStem(self, None, self.precision)
+        if self._plan is None:      # (the per-module drop-in path of fp16x runs on the exact-f32 kernels: an API path, not the fast one)
+            self._plan = FrozenStem(self, None, "fp32" if self.precision == "fp16x" else self.precision)
         return self._plan.vgg_nchw(x)
 
 
@@ -93,7 +93,11 @@ class FrozenStem(object):
             f = vgg.features
             dev = f["0"].weight.device
             self.first = (f["0"].weight.detach().float().contiguous(), f["0"].bias.detach().float().contiguous())
-            self.layers_vgg = [self._layer(f["2"], relu=True, pool=True),
+            # fp16x: conv1_1 + conv1_2 — 3.6 GB of fp32 activations each at 280 frames, HBM-bound as x3 products (8.4 of the all-x3
+            # stem's 32 ms) — run as the plain fp16 fused kernel by default (1.05 ms): five fp16 roundings (clip, two weight sets,
+            # two activations) stay in the forward pass, ~0.5e-3 of logits error instead of ~1e-5 (VNQA_X3_PLAIN_FIRST=0: all x3)
+            self.x3_plain_first = self.x3 and os.environ.get("VNQA_X3_PLAIN_FIRST", "1") != "0"
+            self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=L.half_dtype() if self.x3_plain_first else None),
                                self._layer(f["5"], relu=True, pool=False),
                                self._layer(f["7"], relu=True, pool=True)]
         if objdet is not None:
@@ -117,8 +121,18 @@ class FrozenStem(object):
                 self.layers_vgg[-1]["post"] = (K.pad_vec(s, 128), K.pad_vec(t, 128))
                 if self.composed is not None:
                     self.layers_vgg[-1]["y_halo"] = 2        # the composed 5x5 conv reads a halo-2 image
+                    self.layers_vgg[-1]["dual"] = self.x3    # (x3: its output also as fp32, for the exact-f32 border-correction GEMMs)
 
-    def _layer(self, conv, bn=None, relu=False, pool=False):
+    def _layer(self, conv, bn=None, relu=False, pool=False, cdt=None):
+        if cdt is not None:          # a layer in another storage dtype than the stem's (fp16x: the plain fp16 first layer)
+            keep, keep_x3 = self.cdt, self.x3
+            self.cdt, self.x3 = cdt, False
+            try:
+                ly = self._layer(conv, bn, relu, pool)
+            finally:
+                self.cdt, self.x3 = keep, keep_x3
+            ly["cdt"] = cdt
+            return ly
         w = conv.weight.detach().float()
         b = conv.bias.detach().float()
         c_out, c_in = w.shape[0], w.shape[1]
@@ -221,6 +235,9 @@ class FrozenStem(object):
     def _run_composed(self, x, key, slot=0, use_slot=False):
         """x: halo-2 padded NHWC [n, H+4, W+4, ci_pad] -> relu/pool'ed output of the composed pair (halo 1)."""
         cp = self.composed
+        xc = x                       # the composed conv's input
+        if self.x3 and x.dtype != torch.float32:
+            x = self._x3_side        # (fp16x: the border-correction GEMMs read the fp32 copy, the 5x5 conv the x3 operand)
         n, hp, wp, ci_pad = x.shape
         H, W = hp - 4, wp - 4
         cm = cp["c_mid_pad"]
@@ -251,35 +268,48 @@ class FrozenStem(object):
                         for e, name in enumerate(("top", "bottom", "left", "right"))]
         ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
-        out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
-        timed = self.timing is not None and cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256)
+        if self.x3:
+            out = self._buf(key + (ho, wo, "x3"), (n, ho + 2, wo + 2, 3 * cp["c_out_pad"]), dtype=L.half_dtype())
+        else:
+            out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
+        timed = self.timing is not None and (self.x3 or cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256))
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        y = K.conv2d_igemm(x, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
-                           tile=cp["tile"], border_sub=ring)
+        y = K.conv2d_igemm(xc, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
+                           tile=cp["tile"], border_sub=ring, x3_out=self.x3)
         if timed:
             ev1.record()
             self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25,
-                                "conv_ps_kernel" if cp["tile"] == L.TILE_STEM_PS_224x256 else "conv_igemm_kernel"))
+                                "x3 product (split + conv_igemm_kernel raw + post)" if self.x3 else
+                                ("conv_ps_kernel" if cp["tile"] == L.TILE_STEM_PS_224x256 else "conv_igemm_kernel")))
         return y
 
-    def _buf(self, key, shape):
+    def _buf(self, key, shape, dtype=None):
         """Persistent zero-halo activation buffer, grown (never shrunk) along the image axis."""
+        dtype = self.cdt if dtype is None else dtype
+        key = key + (str(dtype),) if dtype != self.cdt else key
         cap = self._bufs.get(key)
         if cap is None or cap.shape[0] < shape[0] or tuple(cap.shape[1:]) != tuple(shape[1:]):
-            cap = torch.zeros(shape, dtype=self.cdt, device="cuda")
+            cap = torch.zeros(shape, dtype=dtype, device="cuda")
             self._bufs[key] = cap
         return cap[:shape[0]]
 
-    def _run(self, x, layers, tag, last_slot=0, first_index=0):
+    def _run(self, x, layers, tag, last_slot=0, first_index=0, final=True):
         for i, ly in enumerate(layers, first_index):
             n, hp, wp, _ = x.shape
             h, w = hp - 2, wp - 2
             ho, wo = (h // 2, w // 2) if ly["pool"] else (h, w)
             yh = ly.get("y_halo", 1)
-            key = (tag, i, ho, wo) if i + 1 < len(layers) + first_index else (tag, i, ho, wo, last_slot)
-            out = self._buf(key, (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
+            last = not (i + 1 < len(layers) + first_index)
+            key = (tag, i, ho, wo) if not last else (tag, i, ho, wo, last_slot)
+            # fp16x: consecutive layers hand each other the 16-bit x3 operand [hi | lo | hi] (no fp32 round trip); the chain's
+            # last layer (`final`) writes fp32
+            x3_out = self.x3 and K._F32_CONV_MODE[0] == "x3" and not (last and final)
+            if x3_out:
+                out = self._buf(key + ("x3",), (n, ho + 2 * yh, wo + 2 * yh, 3 * ly["c_out_pad"]), dtype=L.half_dtype())
+            else:
+                out = self._buf(key, (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
             post = ly["post"]
             tile = ly["tile"]
             timed = self.timing is not None and (tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256) or
@@ -305,7 +335,13 @@ class FrozenStem(object):
             else:
                 x = K.conv2d_igemm(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                    post_scale=post[0] if post else None, post_shift=post[1] if post else None,
-                                   out=out, tile=tile, y_halo=yh)
+                                   out=out, tile=tile, y_halo=yh, x3_out=x3_out)
+                if x3_out and ly.get("dual"):
+                    # the same raw sums once more as fp32 (still in the x3 scratch of this stream): the composed pair's border
+                    # correction runs on the exact-f32 GEMMs
+                    self._x3_side = K.x3_post_again(self._buf(key + ("f32side",), (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"])),
+                                                    n, h, w, ly["c_out_pad"], yh, bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
+                                                    post_scale=post[0] if post else None, post_shift=post[1] if post else None)
             if timed:
                 ev1.record()
                 self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9, kname))
@@ -325,13 +361,14 @@ class FrozenStem(object):
                 return self.forward_clip(clip, img_of, n_img, slot)
         B, _, H, W, T = clip.shape
         ly = self.layers_vgg[0]
-        if L.is_half(self.cdt) and ly["tile"] is None and os.environ.get("VNQA_FUSE_FIRST", "1") != "0":
+        if L.is_half(ly.get("cdt", self.cdt)) and ly["tile"] is None and os.environ.get("VNQA_FUSE_FIRST", "1") != "0":
             # conv1_1 evaluated inside the conv1_2 kernel from a 4-channel bf16 image list: its 64-channel output
             # (1.8 GB at 280 x 224 x 224) never goes to HBM
-            img4 = self._buf(("img4", H, W), (n_img, H + 4, W + 4, 4))
+            hdt = ly.get("cdt", self.cdt)
+            img4 = self._buf(("img4", H, W), (n_img, H + 4, W + 4, 4), dtype=hdt)
             K.clip_to_nhwc4(clip, img_of, n_img, out=img4)
             ho, wo = (H // 2, W // 2) if ly["pool"] else (H, W)
-            out = self._buf(("vgg", 0, ho, wo), (n_img, ho + 2, wo + 2, ly["c_out_pad"]))
+            out = self._buf(("vgg", 0, ho, wo), (n_img, ho + 2, wo + 2, ly["c_out_pad"]), dtype=hdt)
             post = ly["post"]
             split = int(os.environ.get("VNQA_C64_SPLIT", "1"))     # A/B hook: the persistent kernel as several shorter launches
             step = (n_img + split - 1) // split
@@ -340,13 +377,13 @@ class FrozenStem(object):
                                  pool2=ly["pool"], post_scale=post[0] if post else None,
                                  post_shift=post[1] if post else None, out=out[n0:n0 + step], reserve_cus=self.reserve_cus)
             x = out
-            x = self._run(x, self.layers_vgg[1:], "vgg", first_index=1)
+            x = self._run(x, self.layers_vgg[1:], "vgg", first_index=1, final=False)
         else:
             if clip.dtype == torch.uint8:        # raw pixels: the un-fused first conv reads the fp32 clip
                 clip = K.expand_u8_clip(clip)
             a = self._buf(("first", H, W), (n_img, H + 2, W + 2, 64))
             K.conv_first(clip, self.first[0], self.first[1], img_of, n_img, self.cdt, out=a)
-            x = self._run(a, self.layers_vgg, "vgg")
+            x = self._run(a, self.layers_vgg, "vgg", final=False)
         return self._run_od(x, "od", slot)
 
     def _run_od(self, x, tag, slot=0):
