@@ -694,9 +694,12 @@ def main():
             i = step_no[0]
             step_no[0] += 1
             cur, nx = queue
-            queue[0], queue[1] = nx, trainer.upload(batches[(i + 2) % NB][0])
             b, bn = batches[i % NB], batches[(i + 1) % NB]
-            return trainer.step(cur, *b[1:], next_clip=nx, next_v_lens_cpu=bn[2])
+            out = trainer.step(cur, *b[1:], next_clip=nx, next_v_lens_cpu=bn[2])
+            # the copy of clip i+2 is enqueued AFTER step i (its consumer, stem(i+2), is enqueued by step i+1): the launch thread
+            # hands the GPU this step's kernels first
+            queue[0], queue[1] = nx, trainer.upload(batches[(i + 2) % NB][0])
+            return out
     else:
         def run_step():
             i = step_no[0]
