@@ -875,7 +875,7 @@ def main():
         # valid for the default workload the passes were taken on
         traffic, traffic_src = None, None
         default_cfg = (args.precision == "bf16" and (B, T, H, W) == (8, 35, 224, 224))
-        for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tfile = os.path.join(ROOT, "profiles", tname)
             if default_cfg and os.path.exists(tfile):
                 tj = json.load(open(tfile))

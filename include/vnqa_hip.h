@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 405
+#define VNQA_ABI_VERSION 406
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -85,6 +85,8 @@ typedef struct vnqa_conv_desc {
                     * tiles 11 / 12); round 2: replaces a separate halo-zeroing launch per fresh conv output */
 } vnqa_conv_desc;
 #define VNQA_CONV_ZERO_HALO 1
+#define VNQA_CONV_XCD_SPLIT_N 2   /* stem-tagged implicit-GEMM tiles with exactly two cout tiles (the composed 5x5 conv, c_out 512 on
+                                   * 256-cout tiles): every XCD computes ONE cout half, so its 4 MiB L2 holds half of the weight set */
 /* bits 8..15 of flags: the persistent conv kernels leave n CUs (a multiple of 8, <= 224) to the other streams of the process */
 #define VNQA_CONV_RESERVE_CUS(n) ((((n) < 0 ? 0 : ((n) > 224 ? 224 : (n))) / 8) << 8)
 #define VNQA_CONV_RESERVE_OF(flags) ((((flags) >> 8) & 0xff) * 8)

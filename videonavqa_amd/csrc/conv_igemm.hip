@@ -154,6 +154,20 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     tile_n = swz % p.tilesN;
     tile_m = swz / p.tilesN;
+    if constexpr (TAG == 1) {
+      // VNQA_CONV_XCD_SPLIT_N (stem launches with two cout tiles: the composed 5x5 conv): XCD x owns cout half x & 1 ONLY, the pixel
+      // tiles of that half dealt to the four XCDs of its parity in contiguous runs.  An XCD's L2 (4 MiB) then holds ONE half of the
+      // weight set (1.65 of the composed conv's 3.3 MB) next to its 32 tiles' activation windows instead of thrashing on both
+      // halves; the price is that each activation window is fetched by two XCDs.  Bijective: hardware deals block b to XCD b % 8,
+      // so the XCDs of one parity hold 4q + r/2 = nwg/2 blocks (nwg = 2 tilesM is even, hence r is).
+      if (p.xcd_split && p.tilesN == 2 && (nwg & 1) == 0) {
+        const int par = xcd & 1, j = xcd >> 1;
+        int off = 0;
+        for (int i = 0; i < j; ++i) off += q + ((2 * i + par) < r ? 1 : 0);
+        tile_n = par;
+        tile_m = off + (bid >> 3);
+      }
+    }
   }
 
   const int kchunks = p.Cin / BK;
@@ -1377,6 +1391,7 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
   VNQA_CHECK_ARG(!(d->flags & VNQA_CONV_ZERO_HALO) || (d->y_halo == 1 && d->depth == 0),
                  "conv2d_igemm_fwd: VNQA_CONV_ZERO_HALO needs a 2-D conv with y_halo == 1");
   a.zero_halo = (d->flags & VNQA_CONV_ZERO_HALO) ? 1 : 0;
+  a.xcd_split = (d->flags & VNQA_CONV_XCD_SPLIT_N) ? 1 : 0;
   a.pool = d->pool2;
   a.M = d->n_img * d->h * d->w;
   a.tilesN = 0;

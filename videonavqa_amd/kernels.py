@@ -207,7 +207,7 @@ def x3_post_again(out, n, h, w, c_out, y_halo, bias=None, relu=False, pool2=Fals
 
 
 def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
-                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False):
+                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False, desc_flags=0):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
     (x3_out: only inside f32_conv_mode("x3") — the output as the next x3 product's 16-bit operand, see _conv2d_x3.)"""
     if _F32_CONV_MODE[0] == "x3" and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
@@ -235,7 +235,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
         else:
             out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], taps, x_halo, y_halo,
-                   int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0, 0, flags)
+                   int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0, 0, flags | int(desc_flags))
     L.check(L.lib().vnqa_conv2d_igemm_fwd_ex(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                              L.ptr(post_shift), L.ptr(border_sub), L.ptr(out), L.stream()),
             "vnqa_conv2d_igemm_fwd")

@@ -276,8 +276,11 @@ class FrozenStem(object):
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        # every XCD computes ONE cout half of the composed conv (its L2 then holds 1.65 instead of 3.3 MB of weights): fabric-side reads
+        # 1 022 -> 831 MB per launch (profiles/r04_pmc_traffic*.json), time unchanged (2.166 vs 2.161 ms; end to end 941-943 either way)
+        xcd = L.CONV_XCD_SPLIT_N if (not self.x3 and os.environ.get("VNQA_STEM_XCD_SPLIT", "1") == "1") else 0
         y = K.conv2d_igemm(xc, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
-                           tile=cp["tile"], border_sub=ring, x3_out=self.x3)
+                           tile=cp["tile"], border_sub=ring, x3_out=self.x3, desc_flags=xcd)
         if timed:
             ev1.record()
             self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25,
