@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 406
+#define VNQA_ABI_VERSION 407
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -150,11 +150,13 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
  *   vnqa_gemm_nt with dtype = VNQA_BF16 | VNQA_GEMM_OUT_F32 : 16-bit operands, fp32 `out` (workspace >= m*n*4 bytes required).
  */
 int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld, int64_t dst_ld,
-                    void* stream);
+                    const float* scale, void* stream);   /* scale: optional DEVICE scalar (a power of two) applied before the split:
+                                                          * gradient operands are lifted into fp16's normal range */
 int vnqa_conv2d_igemm_raw(const vnqa_conv_desc* d, const void* x, const void* wt, float* raw, void* stream);
 int vnqa_x3_post(const float* raw, const float* bias, const float* post_scale, const float* post_shift, const float* border_sub,
                  void* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y, int32_t y_halo, int32_t relu,
-                 int32_t pool2, int32_t out_x3, void* stream);
+                 int32_t pool2, int32_t out_x3, const float* raw_scale, void* stream);   /* raw_scale: optional DEVICE scalar
+                                                          * multiplied into the raw sums first (1 / the operand's split scale) */
 #define VNQA_GEMM_OUT_F32 0x200
 
 /* Fused trunk epilogues (BIAS_RELU_BNSTATS / BIAS_FILM_RELU_RES) — the same conv with the elementwise op

@@ -18,14 +18,18 @@ namespace {
 // rows x c fp32 (row stride src_ld) -> three 16-bit destinations with row stride dst_ld: hi, lo and (optional) a second copy of hi
 __global__ void __launch_bounds__(256) split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
                                                      unsigned short* __restrict__ lo, unsigned short* __restrict__ hi2,
-                                                     long long rows, int c8, long long src_ld, long long dst_ld) {
+                                                     long long rows, int c8, long long src_ld, long long dst_ld,
+                                                     const float* __restrict__ scale) {
+  // scale (optional, DEVICE scalar, a power of two): the values are multiplied by it before they are split — gradients (1e-5 .. 1e-8
+  // here) are lifted into fp16's normal range first; the consumer multiplies its fp32 result by 1 / scale
+  const float sc = scale != nullptr ? *scale : 1.f;
   const long long total = rows * c8;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const long long r = i / c8;
     const int j = (int)(i - r * c8) * 8;
     const float4 a = *(const float4*)(x + r * src_ld + j);
     const float4 b = *(const float4*)(x + r * src_ld + j + 4);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const float v[8] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc, b.x * sc, b.y * sc, b.z * sc, b.w * sc};
     unsigned h[4], l[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -48,6 +52,7 @@ struct PostArgs {
   const float* post_shift;
   const float* border_sub;  // [n][2w + 2(h-2)][c_out] fp32 or null
   float* y;                 // padded NHWC [n][ho + 2 yh][wo + 2 yh][c_y] fp32, interior written
+  const float* raw_scale;   // optional DEVICE scalar: raw sums are multiplied by it first (1 / the operand's split scale)
   unsigned short* y16;      // != null: the output as the NEXT x3 product's operand instead — 16-bit [..][c_y], channels
                             // [hi | lo | hi] at c, c_out + c, 2 c_out + c (c_y >= 3 c_out): no fp32 round trip between layers
   int n, h, w, c_out, c_y, y_halo, relu, pool;
@@ -55,6 +60,10 @@ struct PostArgs {
 
 __device__ __forceinline__ float4 post_one(const PostArgs& p, int n, int y, int x, int c, const float4 bias) {
   float4 v = *(const float4*)(p.raw + (((size_t)n * p.h + y) * p.w + x) * p.c_out + c);
+  if (p.raw_scale != nullptr) {
+    const float rs = *p.raw_scale;
+    v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs;
+  }
   if (p.border_sub != nullptr) {
     int ring = -1;
     if (y == 0) ring = x;
@@ -126,21 +135,21 @@ int grid_for(long long total) {
 }  // namespace
 
 extern "C" int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld,
-                               int64_t dst_ld, void* stream) {
+                               int64_t dst_ld, const float* scale, void* stream) {
   VNQA_CHECK_ARG(x && hi && lo, "split3_f32: null pointer");
   VNQA_CHECK_ARG(rows > 0 && c > 0 && c % 8 == 0 && src_ld >= c && src_ld % 4 == 0 && dst_ld >= c && dst_ld % 8 == 0,
                  "split3_f32: rows=%lld c=%d src_ld=%lld dst_ld=%lld (c %% 8, src_ld %% 4, dst_ld %% 8 must be 0)",
                  (long long)rows, c, (long long)src_ld, (long long)dst_ld);
   VNQA_CHECK_ARG((((uintptr_t)x | (uintptr_t)hi | (uintptr_t)lo | (uintptr_t)hi2) & 15) == 0, "split3_f32: 16-byte alignment");
   hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (c / 8))), dim3(256), 0, (hipStream_t)stream, x, (unsigned short*)hi,
-                     (unsigned short*)lo, (unsigned short*)hi2, (long long)rows, c / 8, (long long)src_ld, (long long)dst_ld);
+                     (unsigned short*)lo, (unsigned short*)hi2, (long long)rows, c / 8, (long long)src_ld, (long long)dst_ld, scale);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
 
 extern "C" int vnqa_x3_post(const float* raw, const float* bias, const float* post_scale, const float* post_shift,
                             const float* border_sub, void* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y,
-                            int32_t y_halo, int32_t relu, int32_t pool2, int32_t out_x3, void* stream) {
+                            int32_t y_halo, int32_t relu, int32_t pool2, int32_t out_x3, const float* raw_scale, void* stream) {
   VNQA_CHECK_ARG(raw && y, "x3_post: null pointer");
   VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0 && c_out > 0 && c_out % 4 == 0 && c_y >= (out_x3 ? 3 : 1) * c_out && c_y % 4 == 0,
                  "x3_post: bad geometry n=%d h=%d w=%d c_out=%d c_y=%d", n_img, h, w, c_out, c_y);
@@ -150,6 +159,7 @@ extern "C" int vnqa_x3_post(const float* raw, const float* bias, const float* po
   VNQA_CHECK_ARG(border_sub == nullptr || (h >= 2 && w >= 2), "x3_post: border_sub needs h, w >= 2");
   PostArgs p;
   p.raw = raw; p.bias = bias; p.post_scale = post_scale; p.post_shift = post_shift; p.border_sub = border_sub;
+  p.raw_scale = raw_scale;
   p.y = out_x3 ? nullptr : (float*)y;
   p.y16 = out_x3 ? (unsigned short*)y : nullptr;
   p.n = n_img; p.h = h; p.w = w; p.c_out = c_out; p.c_y = c_y; p.y_halo = y_halo; p.relu = relu; p.pool = pool2 ? 1 : 0;

@@ -80,7 +80,10 @@ class f32_conv_mode(object):
     """Context manager: how convs / GEMMs on fp32 tensors are evaluated inside it — 'x3' or 'exact' (the default)."""
 
     def __init__(self, mode):
-        assert mode in ("x3", "exact")
+        # 'x3g': x3 products whose ACTIVATION-side operand is a gradient tensor (the backward pass): it is multiplied by a
+        # per-tensor power of two chosen on the device (its max lands in [2^12, 2^13)) before the fp16 split — gradients are
+        # 1e-5 .. 1e-8 here, below fp16's normal range — and the fp32 result is divided by it again
+        assert mode in ("x3", "x3g", "exact")
         self.mode = mode
 
     def __enter__(self):
@@ -93,7 +96,19 @@ class f32_conv_mode(object):
 
 
 def x3_active(t):
-    return _F32_CONV_MODE[0] == "x3" and t.dtype == torch.float32 and t.is_cuda
+    return _F32_CONV_MODE[0] in ("x3", "x3g") and t.dtype == torch.float32 and t.is_cuda
+
+
+def x3_mode():
+    return _F32_CONV_MODE[0]
+
+
+def grad_split_scale(t):
+    """(scale, 1 / scale) as 0-dim device tensors: the power of two that lifts max |t| into [2^12, 2^13) (1 for an all-zero tensor)."""
+    amax = t.abs().amax().float()
+    e = torch.clamp(torch.floor(torch.log2(torch.clamp(amax, min=1e-35))), min=-100.0)     # (scale stays a finite fp32 power of two)
+    scale = torch.where(amax > 0, torch.exp2(12.0 - e), torch.ones_like(amax))
+    return scale, 1.0 / scale
 
 
 _X3_WS = {}
@@ -108,8 +123,9 @@ def _x3_buffer(name, numel, dtype, device):
     return buf[:numel]
 
 
-def split3(x2d, out=None, layout="channels"):
-    """fp32 [rows, c] -> 16-bit halves.  layout 'channels': [rows, 3c] = [hi | lo | hi] (the activation operand of an x3 product)."""
+def split3(x2d, out=None, scale=None):
+    """fp32 [rows, c] -> 16-bit halves, channel-concatenated [rows, 3c] = [hi | lo | hi] (the activation operand of an x3 product).
+    scale: optional 0-dim device tensor multiplied in before the split (grad_split_scale)."""
     rows, c = x2d.shape
     assert x2d.dtype == torch.float32 and x2d.stride(1) == 1 and c % 8 == 0
     half = L.half_dtype()
@@ -118,7 +134,21 @@ def split3(x2d, out=None, layout="channels"):
     assert out.shape == (rows, 3 * c) and out.is_contiguous()
     base, es = out.data_ptr(), out.element_size()
     L.check(L.lib().vnqa_split3_f32(L.vptr(x2d), ctypes.c_void_p(base), ctypes.c_void_p(base + c * es),
-                                    ctypes.c_void_p(base + 2 * c * es), rows, c, x2d.stride(0), 3 * c, L.stream()), "vnqa_split3_f32")
+                                    ctypes.c_void_p(base + 2 * c * es), rows, c, x2d.stride(0), 3 * c, L.ptr(scale), L.stream()),
+            "vnqa_split3_f32")
+    return out
+
+
+def split3_rows(x2d, order, scale=None, name="x3rows"):
+    """fp32 [rows, c] -> 16-bit [3 * rows, c]: the three halves stacked along the ROWS (the contraction axis of a weight-gradient
+    product), in `order`: 'hhl' = [hi; hi; lo] (the activation operand), 'hlh' = [hi; lo; hi] (the gradient operand)."""
+    rows, c = x2d.shape
+    assert x2d.dtype == torch.float32 and x2d.is_contiguous() and c % 8 == 0 and order in ("hhl", "hlh")
+    out = _x3_buffer(name + order, 3 * rows * c, L.half_dtype(), x2d.device).view(3 * rows, c)
+    base, blk = out.data_ptr(), rows * c * out.element_size()
+    hi, lo, hi2 = (base, base + 2 * blk, base + blk) if order == "hhl" else (base, base + blk, base + 2 * blk)
+    L.check(L.lib().vnqa_split3_f32(L.ptr(x2d), ctypes.c_void_p(hi), ctypes.c_void_p(lo), ctypes.c_void_p(hi2), rows, c, c, c,
+                                    L.ptr(scale), L.stream()), "vnqa_split3_f32")
     return out
 
 
@@ -164,12 +194,16 @@ def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo,
     c_out, taps, Cin = wt.shape
     assert wt.dtype == torch.float32 and x.is_contiguous()
     half = L.half_dtype()
+    inv = None
     if x.dtype == torch.float32:
         assert Cx == Cin
         k = 3 * Cin
         w3 = x3_weight(wt).view(c_out, taps, k)
         xin = _x3_buffer("x3in", N * Hp * Wp * k, half, x.device).view(N * Hp * Wp, k)
-        split3(x.view(N * Hp * Wp, Cin), out=xin)
+        scale = None
+        if _F32_CONV_MODE[0] == "x3g":          # a gradient tensor on the activation side (dgrad): lift it into fp16's range
+            scale, inv = grad_split_scale(x)
+        split3(x.view(N * Hp * Wp, Cin), out=xin, scale=scale)
     elif Cx == 3 * Cin:
         assert x.dtype == half
         k, xin = 3 * Cin, x
@@ -191,8 +225,8 @@ def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo,
     assert out.dtype == odt and out.shape[:3] == (N, Ho + 2 * y_halo, Wo + 2 * y_halo) and out.shape[-1] >= oc
     bs = None if border_sub is None else border_sub.float().contiguous()
     L.check(L.lib().vnqa_x3_post(L.ptr(raw), L.ptr(bias), L.ptr(post_scale), L.ptr(post_shift), L.ptr(bs), L.ptr(out), N, H, W,
-                                 c_out, out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, 1 if x3_out else 0, L.stream()),
-            "vnqa_x3_post")
+                                 c_out, out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, 1 if x3_out else 0, L.ptr(inv),
+                                 L.stream()), "vnqa_x3_post")
     return out
 
 
@@ -202,7 +236,7 @@ def x3_post_again(out, n, h, w, c_out, y_halo, bias=None, relu=False, pool2=Fals
     raw = _x3_buffer("raw", n * h * w * c_out, torch.float32, out.device)
     assert out.dtype == torch.float32
     L.check(L.lib().vnqa_x3_post(L.ptr(raw), L.ptr(bias), L.ptr(post_scale), L.ptr(post_shift), None, L.ptr(out), n, h, w, c_out,
-                                 out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, 0, L.stream()), "vnqa_x3_post")
+                                 out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, 0, None, L.stream()), "vnqa_x3_post")
     return out
 
 
@@ -210,7 +244,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
                  x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False, desc_flags=0):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
     (x3_out: only inside f32_conv_mode("x3") — the output as the next x3 product's 16-bit operand, see _conv2d_x3.)"""
-    if _F32_CONV_MODE[0] == "x3" and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
+    if _F32_CONV_MODE[0] in ("x3", "x3g") and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
             relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 and x.shape[-1] % 64 == 0:
         return _conv2d_x3(x, wt, bias, bool(relu), pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub, x3_out)
     assert not x3_out, "x3_out needs f32_conv_mode('x3') and fp32 K-major weights"
@@ -316,6 +350,8 @@ def conv2d_igemm_add_mask(x, wt, add, mask_src, tile=L.TILE_AUTO):
     N, Hp, Wp, _ = x.shape
     c_out, taps, _ = wt.shape
     assert add.shape == (N, Hp, Wp, c_out) and mask_src.shape == add.shape and add.dtype == x.dtype == mask_src.dtype
+    if x3_active(x):       # the dgrad as an x3 product, the residual join + ReLU mask as the separate fp32 kernel
+        return relu_bwd(conv2d_igemm(x, wt), mask_src, add)
     d = _conv_desc(x, c_out, c_out, taps, False, tile if taps == 9 else L.TILE_AUTO)
     y = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
     e = L.ConvEpilogue(kind=L.EPI_ADD_MASK, res=add.data_ptr(), y2=mask_src.data_ptr())
@@ -704,6 +740,22 @@ def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None):
     Cout = dy.shape[-1]
     assert dy.shape[:3] == x.shape[:3] and dy.dtype == x.dtype
     h, w = Hp - 2, Wp - 2
+    if x3_active(x) and Cin % 8 == 0 and Cout % 8 == 0 and x.is_contiguous() and dy.is_contiguous() and \
+            3 * N * Hp * Wp < (1 << 31):
+        # x3 product over the pixels: dW = sum_p dY[p] X[p + tap]  with  X' = [x_hi; x_hi; x_lo], dY' = s [dy_hi; dy_lo; dy_hi] stacked
+        # along the IMAGE axis — the 16-bit weight-gradient kernel on 3 N images computes exactly the three products' sum
+        scale, inv = grad_split_scale(dy)
+        x3 = split3_rows(x.view(N * Hp * Wp, Cin), "hhl").view(3 * N, Hp, Wp, Cin)
+        dy3 = split3_rows(dy.view(N * Hp * Wp, Cout), "hlh", scale=scale, name="x3rowsdy").view(3 * N, Hp, Wp, Cout)
+        ws = workspace(L.lib().vnqa_conv2d_wgrad_workspace(3 * N, h, w, Cin, Cout, taps), x.device)
+        dwt = torch.empty((Cout, taps, Cin), dtype=torch.float32, device=x.device)
+        L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x3), L.ptr(dy3), L.ptr(dwt), None, L.ptr(ws), 3 * N, h, w, Cin, Cout, taps,
+                                          L.BF16, L.stream()), "vnqa_conv2d_wgrad(x3)")
+        dwt.mul_(inv)
+        dbias = None
+        if want_bias:
+            dbias = colsum(dy.view(N * Hp * Wp, Cout), out=dbias_out if (dbias_out is not None and dbias_out.numel() == Cout) else None)
+        return dwt, dbias
     ws = workspace(L.lib().vnqa_conv2d_wgrad_workspace(N, h, w, Cin, Cout, taps), x.device)
     dwt = torch.empty((Cout, taps, Cin), dtype=torch.float32, device=x.device)
     dbias = None
@@ -735,7 +787,11 @@ def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
     assert b.shape[1] == Kd and a.dtype == b.dtype
     if x3_active(a) and Kd % 64 == 0 and a.is_contiguous():
         # x3 product: [a_hi | a_lo | a_hi] . [b_hi | b_hi | b_lo]^T on the 16-bit GEMM with an fp32 output
-        a3 = split3(a, out=_x3_buffer("x3in", M * 3 * Kd, L.half_dtype(), a.device).view(M, 3 * Kd))
+        scale = inv = None
+        if _F32_CONV_MODE[0] == "x3g":          # `a` is a gradient (dX = dOut . W): lifted into fp16's range, divided out below
+            assert bias is None and not relu
+            scale, inv = grad_split_scale(a)
+        a3 = split3(a, out=_x3_buffer("x3in", M * 3 * Kd, L.half_dtype(), a.device).view(M, 3 * Kd), scale=scale)
         b3 = x3_weight(b)
         if out is None:
             out = torch.empty((M, N), dtype=torch.float32, device=a.device)
@@ -744,6 +800,8 @@ def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
         ws = workspace(ws_bytes, a.device)
         L.check(L.lib().vnqa_gemm_nt(L.ptr(a3), L.ptr(b3), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, 3 * Kd, out.stride(0),
                                      1 if relu else 0, L.BF16 | L.GEMM_OUT_F32, L.stream()), "vnqa_gemm_nt(x3)")
+        if inv is not None:
+            out.mul_(inv)
         return out
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
@@ -760,6 +818,18 @@ def gemm_tn(a, b, out=None):
     Kd, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == Kd and a.dtype == b.dtype
+    if x3_active(a) and M % 8 == 0 and N % 8 == 0 and a.is_contiguous() and b.is_contiguous():
+        # x3 product over K (the rows): A' = s [a_hi; a_lo; a_hi] (a: the gradient operand), B' = [b_hi; b_hi; b_lo]
+        scale, inv = grad_split_scale(a)
+        a3 = split3_rows(a, "hlh", scale=scale, name="x3rowsdy")
+        b3 = split3_rows(b, "hhl")
+        ws = workspace(L.lib().vnqa_gemm_tn_workspace(M, N, 3 * Kd, L.BF16), a.device)
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+        assert out.shape == (M, N) and out.is_contiguous() and out.dtype == torch.float32
+        L.check(L.lib().vnqa_gemm_tn(L.ptr(a3), L.ptr(b3), L.ptr(out), L.ptr(ws), M, N, 3 * Kd, L.BF16, L.stream()), "vnqa_gemm_tn(x3)")
+        out.mul_(inv)
+        return out
     did = L.dtype_id(a.dtype)
     ws = workspace(L.lib().vnqa_gemm_tn_workspace(M, N, Kd, did), a.device)
     if out is None:

@@ -4,12 +4,24 @@ Activations are padded-NHWC tensors [N, H+2, W+2, Cpad] in the compute dtype (bf
 a ZERO halo; every op here preserves that invariant (gradients included), because the conv
 kernels get their zero padding — and wgrad its summation domain — from it.
 """
+import contextlib
 import os
 
 import torch
 
 from . import _lib as L
 from . import kernels as K
+
+
+def _x3_forward(ctx):
+    """precision='fp16x': remember that this node's forward ran its contractions as x3 products (kernels.f32_conv_mode) ..."""
+    ctx.x3 = K.x3_mode() == "x3"
+
+
+def _x3_backward(ctx):
+    """... so that its backward — which autograd runs after the forward's context has closed, on its own thread — runs them as x3
+    products too, with the gradient operands scaled into fp16's range ('x3g')."""
+    return K.f32_conv_mode("x3g") if getattr(ctx, "x3", False) else contextlib.nullcontext()
 
 
 class GradSink(object):
@@ -79,6 +91,7 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu, mask_in_backward=True, grad_scale=1.0):
+        _x3_forward(ctx)
         ctx.grad_scale = float(grad_scale)      # d y arrives multiplied by this (fp16 loss scale): dW, db are divided by it
         c_out, c_in, k, _ = weight.shape
         cdt = x.dtype
@@ -95,6 +108,11 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with _x3_backward(ctx):
+            return ConvFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         c_out, c_in, k, c_out_pad, c_in_pad = ctx.dims
         dy = dy.contiguous()
@@ -121,6 +139,7 @@ class LinearNTFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias):
+        _x3_forward(ctx)
         wc = w.to(x.dtype).contiguous()
         out = K.gemm_nt(x.contiguous(), wc, bias=bias.float().contiguous())
         ctx.save_for_backward(x, wc)
@@ -128,6 +147,11 @@ class LinearNTFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        with _x3_backward(ctx):
+            return LinearNTFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         x, wc = ctx.saved_tensors
         dout = dout.to(x.dtype).contiguous()
         dx = dw = db = None
@@ -219,6 +243,7 @@ class FilmTrunkHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, meta):
+        _x3_forward(ctx)
         lay, C = meta.layout, meta.channels
         cdt = x.dtype
         c_pad = L.round_up(C, 64)
@@ -244,6 +269,11 @@ class FilmTrunkHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dm, _dv):
+        with _x3_backward(ctx):
+            return FilmTrunkHeadFn._backward(ctx, dout, _dm, _dv)
+
+    @staticmethod
+    def _backward(ctx, dout, _dm, _dv):
         meta = ctx.meta
         lay, C = meta.layout, meta.channels
         x, r, mean, rstd, g, conv_w = ctx.saved_tensors
@@ -286,6 +316,7 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, meta, *tensors):
+        _x3_forward(ctx)
         C, blocks = meta.channels, meta.blocks
         films = tensors[:meta.n_film]
         cdt = h.dtype
@@ -309,6 +340,11 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        with _x3_backward(ctx):
+            return FilmTrunkBlocksFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         meta = ctx.meta
         C, blocks, nf = meta.channels, meta.blocks, meta.n_film
         sv = ctx.saved_tensors
@@ -802,6 +838,7 @@ class FcNativeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, C, h, w, rows_pad, grad_scale=1.0):
+        _x3_forward(ctx)
         ctx.grad_scale = float(grad_scale)      # d(out) arrives multiplied by this (fp16 loss scale): dW, db are divided by it
         rows = weight.shape[0]
         c_pad = x.shape[1] // ((h + 2) * (w + 2))
@@ -821,6 +858,11 @@ class FcNativeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        with _x3_backward(ctx):
+            return FcNativeFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         x, nat_t = ctx.saved_tensors
         rows, C, h, w, c_pad = ctx.geom
         dout = dout.to(x.dtype).contiguous()
