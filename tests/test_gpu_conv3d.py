@@ -273,3 +273,31 @@ def test_video_only_cnn3d_config2_batch32_trains():
         losses.append(float(loss))
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
+
+
+def test_fused_cnn3d_pooled_buffers_are_returned_once_and_a_second_backward_is_refused():
+    """the fused 3-D path keeps two pooled (~GB-scale at config 2) padded activations as saved tensors.  They return to
+    the pool exactly once — after the backward, or when a grad-enabled forward's graph is dropped without a backward — and a
+    second backward over a retained graph raises instead of reading recycled buffers."""
+    import gc
+    from videonavqa_amd import ops
+    from videonavqa_amd.models import VideoOnlyCNN3D
+    torch.manual_seed(0)
+    m = VideoOnlyCNN3D(70, fc6_in_features=128 * 1 * 1 * 1, precision=LOW).cuda().train()
+    x = torch.rand(2, 3, 16, 48, 48, device="cuda")
+    if not m._fast_ok(x):
+        pytest.skip("geometry not on the fused path")
+    y = torch.randint(0, 70, (2,), device="cuda")
+    count = lambda: sum(len(v) for v in ops._HALO_POOL.free.values())
+    loss = F.cross_entropy(m(x), y, reduction="sum")
+    loss.backward(retain_graph=True)
+    after_bwd = count()
+    with pytest.raises(RuntimeError, match="second backward"):
+        loss.backward()
+    assert count() == after_bwd                       # nothing returned twice
+    del loss
+    out = m(x)                                        # grad-enabled forward, never followed by a backward
+    held = count()
+    del out
+    gc.collect()
+    assert count() >= held                            # its lease went back when the graph was freed (pool keeps at most 2 per shape)

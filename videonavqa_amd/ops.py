@@ -543,6 +543,29 @@ class _HaloPool(object):
 _HALO_POOL = _HaloPool()
 
 
+class _PoolLease(object):
+    """Owner of pooled buffers that an autograd node keeps as saved tensors: they go back to the pool exactly ONCE — when the
+    node's backward has consumed them (release()), or, for a grad-enabled forward that is never followed by a backward, when the
+    graph is freed (the node's ctx drops this object).  A second backward over a retained graph would read buffers a later
+    forward may already have rewritten: it is refused with a clear error instead."""
+
+    def __init__(self, pool, *buffers):
+        self.pool, self.buffers, self.released = pool, list(buffers), False
+
+    def release(self):
+        if not self.released:
+            self.released = True
+            for b in self.buffers:
+                self.pool.put(b)
+            self.buffers = []
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:      # interpreter shutdown
+            pass
+
+
 class Cnn3dFeaturesFn(torch.autograd.Function):
     """bn_input -> 3 x [relu(conv3d) -> MaxPool3d -> BatchNorm3d] -> flatten (v_only_cnn3d.py:60-74) as ONE autograd node on
     csrc/cnn3d.hip + the 27-tap igemm / small-channel wgrad kernels, 16-bit storage:
@@ -595,9 +618,9 @@ class Cnn3dFeaturesFn(torch.autograd.Function):
         ctx.save_for_backward(x, g0, b0, w1, g1, g2, g3, w2, w3, mean0, rstd0, mean1, rstd1, mean2, rstd2, mean3, rstd3,
                               p1, idx1, a1, p2, idx2, a2, p3, idx3)
         ctx.meta = (cdt, float(grad_scale), training)
+        ctx.lease = _PoolLease(_HALO_POOL, a1, a2)
         if not any(ctx.needs_input_grad):         # no backward will come for them: the padded inputs go back to the pool now
-            _HALO_POOL.put(a1)
-            _HALO_POOL.put(a2)
+            ctx.lease.release()
         return feat.view(N, c3, D3, H3, W3)
 
     @staticmethod
@@ -607,6 +630,10 @@ class Cnn3dFeaturesFn(torch.autograd.Function):
         cdt, gs, training = ctx.meta
         if not training:
             raise NotImplementedError("VideoOnlyCNN3D: backward through eval-mode BatchNorm is not part of the reference path")
+        if ctx.lease.released:
+            raise RuntimeError("VideoOnlyCNN3D features: this graph's pooled activation buffers were already returned (a second "
+                               "backward over a retained graph is not supported on the fused 3-D path; VNQA_CNN3D_GENERIC=1 "
+                               "keeps ordinary autograd semantics)")
         N, D1, H1, W1, _ = p1.shape
         _, D2, H2, W2, c2 = p2.shape
         _, D3, H3, W3, c3 = p3.shape
@@ -636,8 +663,7 @@ class Cnn3dFeaturesFn(torch.autograd.Function):
         dp1, dg1, db1 = K.bn_rows_bwd(da1, K.view_padded_ndhwc(D1, H1, W1, 64), p1.view(-1, 64), cdt, mean1, rstd1, g1, gs)
         _HALO_POOL.put(da1)
         dw1, dc1b, dg0, db0 = K.c3d_conv1_bwd(x, w1, mean0, rstd0, g0, b0, dp1, idx1, gs)
-        _HALO_POOL.put(a1)
-        _HALO_POOL.put(a2)
+        ctx.lease.release()
         inv = 1.0 / gs
         return (None, dg0, db0, dw1, dc1b, dg1, db1, dw2, dbias2[:c2] * inv if gs != 1.0 else dbias2[:c2].clone(), dg2, db2,
                 dw3, dbias3[:c3] * inv if gs != 1.0 else dbias3[:c3].clone(), dg3, db3, None, None, None, None)
