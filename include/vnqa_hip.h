@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 407
+#define VNQA_ABI_VERSION 408
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -288,6 +288,10 @@ int vnqa_hop_bwd(const float* dout, const float* hv, const float* hs, const int3
  * vnqa_conv2d_wreg_supported returns 1 when a descriptor qualifies (callers fall back to the igemm / c64 kernels).
  */
 int vnqa_conv2d_wreg_supported(const vnqa_conv_desc* d);
+/* 1 when the patch-stationary tiles (VNQA_TILE_PS_224x256 / VNQA_TILE_STEM_PS_224x256 of vnqa_conv2d_igemm_fwd[_ex] and the fused
+ * FILM_RES / ADD_MASK calls) serve this descriptor's geometry: 16-bit 3x3 / 5x5 2-D conv, c_in % 64 == 0, even width >= 14, the
+ * LDS patch and the 32-bit DMA offsets fit.  The library's own dispatch uses the same test. */
+int vnqa_conv_ps_supported(const vnqa_conv_desc* d);
 int vnqa_conv2d_wreg_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
                          const float* post_scale, const float* post_shift, void* y, void* stream);
 

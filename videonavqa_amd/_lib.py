@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 407          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 408          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -122,6 +122,7 @@ _SIGNATURES = {
     "vnqa_frame_max_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 7 + [_vp]),
     "vnqa_frame_max_bwd": (ctypes.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 5 + [_f32, _i32, _vp]),
     "vnqa_conv2d_wreg_supported": (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),
+    "vnqa_conv_ps_supported": (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),
     "vnqa_conv2d_wreg_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_conv_first_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_pack_conv_weight": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),

@@ -573,6 +573,54 @@ int launch_ps(const ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
+// Geometry the patch-stationary tiles serve (the ONE copy of the test: vnqa_conv_ps_dispatch and the exported predicate
+// vnqa_conv_ps_supported both call it).  tc: 28-wide tiles for widths that are multiples of 28, else 14-wide ones (any even width
+// >= 14: the last column block overlaps its neighbour).
+static int ps_geometry(int H, int W, int Cin, int Cout, int taps, int pool, int& tc) {
+  using namespace ps;
+  const int halo = taps == 25 ? 2 : 1;
+  tc = W % 28 == 0 ? 28 : ((W >= 14 && (W % 14 == 0 || W % 2 == 0)) ? 14 : 0);
+  if (tc == 0) {
+    vnqa_set_error("conv patch-stationary tile: width %d must be even and >= 14 (or a multiple of 14)", W);
+    return VNQA_ERR_UNSUPPORTED;
+  }
+  const int tr = BM / tc;
+  if (halo == 2) {
+    // 5x5: the (tr + 4) x (tc + 4) patch fills the buffer exactly: tiles must not straddle images
+    if (H % tr != 0) {
+      vnqa_set_error("conv patch-stationary tile (5x5): height %d is not a multiple of the %d tile rows", H, tr);
+      return VNQA_ERR_UNSUPPORTED;
+    }
+  } else {
+    // patch rows needed at worst: tile rows + 2 halo rows + 2 per image boundary the tile can straddle
+    const int max_cross = (tr - 1 + H - 1) / H;
+    if ((tr + 2 + 2 * max_cross) * (tc + 2) > patch_rows(1)) {
+      vnqa_set_error("conv patch-stationary tile: %dx%d images do not fit the %d-pixel LDS patch", H, W, patch_rows(1));
+      return VNQA_ERR_UNSUPPORTED;
+    }
+  }
+  if (pool && (H % 2 != 0 || W % 2 != 0)) {
+    vnqa_set_error("conv patch-stationary tile: pool2 needs even h, w");
+    return VNQA_ERR_UNSUPPORTED;
+  }
+  const int Hp = H + 2 * halo, Wp = W + 2 * halo;
+  if ((size_t)(Hp + 4) * Wp * Cin * 2 * 4 >= (1ull << 32) || (size_t)Cout * taps * Cin * 2 >= (1ull << 32)) {
+    vnqa_set_error("conv patch-stationary tile: tensor too large for its 32-bit DMA offsets");
+    return VNQA_ERR_UNSUPPORTED;
+  }
+  return VNQA_OK;
+}
+
+// 1 when the patch-stationary tiles (VNQA_TILE_PS_224x256 / VNQA_TILE_STEM_PS_224x256) serve this descriptor's conv — callers
+// choose between them and the implicit-GEMM tiles with it instead of restating the geometry test (the reason is left in
+// vnqa_last_error when the answer is 0)
+extern "C" int vnqa_conv_ps_supported(const vnqa_conv_desc* d) {
+  if (!d || d->dtype != VNQA_BF16 || (d->taps != 9 && d->taps != 25) || d->depth != 0 || d->wt_tiled || d->relu == 2) return 0;
+  if (d->x_halo != (d->taps == 25 ? 2 : 1) || d->c_in < 64 || d->c_in % 64 != 0 || d->h <= 0 || d->w <= 0 || d->n_img <= 0) return 0;
+  int tc = 0;
+  return ps_geometry(d->h, d->w, d->c_in, d->c_out, d->taps, d->pool2, tc) == VNQA_OK ? 1 : 0;
+}
+
 int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
   using namespace ps;
   const int halo = a.taps == 25 ? 2 : 1;
@@ -584,35 +632,9 @@ int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
                    "fused epilogues FILM_RES and ADD_MASK (un-pooled, y_halo = 1, trunk tag)");
     return VNQA_ERR_UNSUPPORTED;
   }
-  // 28-wide tiles for widths that are multiples of 28, else 14-wide ones (any even width >= 14: the last column block overlaps)
-  const int tc = a.W % 28 == 0 ? 28 : ((a.W >= 14 && (a.W % 14 == 0 || a.W % 2 == 0)) ? 14 : 0);
-  if (tc == 0) {
-    vnqa_set_error("conv patch-stationary tile: width %d must be even and >= 14 (or a multiple of 14)", a.W);
-    return VNQA_ERR_UNSUPPORTED;
-  }
-  const int tr = BM / tc;
-  if (halo == 2) {
-    // 5x5: the (tr + 4) x (tc + 4) patch fills the buffer exactly: tiles must not straddle images
-    if (a.H % tr != 0) {
-      vnqa_set_error("conv patch-stationary tile (5x5): height %d is not a multiple of the %d tile rows", a.H, tr);
-      return VNQA_ERR_UNSUPPORTED;
-    }
-  } else {
-    // patch rows needed at worst: tile rows + 2 halo rows + 2 per image boundary the tile can straddle
-    const int max_cross = (tr - 1 + a.H - 1) / a.H;
-    if ((tr + 2 + 2 * max_cross) * (tc + 2) > patch_rows(1)) {
-      vnqa_set_error("conv patch-stationary tile: %dx%d images do not fit the %d-pixel LDS patch", a.H, a.W, patch_rows(1));
-      return VNQA_ERR_UNSUPPORTED;
-    }
-  }
-  if (a.pool && (a.H % 2 != 0 || a.W % 2 != 0)) {
-    vnqa_set_error("conv patch-stationary tile: pool2 needs even h, w");
-    return VNQA_ERR_UNSUPPORTED;
-  }
-  if ((size_t)(a.Hp + 4) * a.Wp * a.Cin * 2 * 4 >= (1ull << 32) || (size_t)a.Cout * a.taps * a.Cin * 2 >= (1ull << 32)) {
-    vnqa_set_error("conv patch-stationary tile: tensor too large for its 32-bit DMA offsets");
-    return VNQA_ERR_UNSUPPORTED;
-  }
+  int tc = 0;
+  const int rc = ps_geometry(a.H, a.W, a.Cin, a.Cout, a.taps, a.pool, tc);
+  if (rc != VNQA_OK) return rc;
   if (halo == 1) {
     if (tc == 28) return tag ? launch_ps<28, 1, 1>(a, st) : launch_ps<28, 1, 0>(a, st);
     return tag ? launch_ps<14, 1, 1>(a, st) : launch_ps<14, 1, 0>(a, st);

@@ -305,19 +305,19 @@ def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frame
     return y, mean, var
 
 
+def conv_ps_supported(n, h, w, c_in, c_out, taps=9, pool2=False):
+    """The library's own answer (vnqa_conv_ps_supported) to: do the patch-stationary tiles serve this 16-bit conv geometry?"""
+    d = L.ConvDesc(L.BF16, n, h, w, c_in, c_out, c_out, taps, 2 if taps == 25 else 1, 1, 0, 1 if pool2 else 0, L.TILE_PS_224x256, 0, 0, 0)
+    return bool(L.lib().vnqa_conv_ps_supported(ctypes.byref(d)))
+
+
 def ps_fused_tile(x):
     """TILE_PS_224x256 when the patch-stationary kernel can run a 3x3 conv with a fused FILM_RES / ADD_MASK epilogue on this
-    padded-NHWC input (16-bit storage, width a multiple of 14 or any even width >= 14, its LDS patch fits), else TILE_AUTO.  VNQA_TRUNK_PS=0 disables."""
+    padded-NHWC input (asked of the library: vnqa_conv_ps_supported), else TILE_AUTO.  VNQA_TRUNK_PS=0 disables."""
     if os.environ.get("VNQA_TRUNK_PS", "1") == "0" or not L.is_half(x.dtype):
         return L.TILE_AUTO
     N, Hp, Wp, C = x.shape
-    h, w = Hp - 2, Wp - 2
-    tc = 28 if w % 28 == 0 else (14 if (w >= 14 and (w % 14 == 0 or w % 2 == 0)) else 0)      # (else: overlapping last column block)
-    if tc == 0 or C % 64 != 0:
-        return L.TILE_AUTO
-    tr = 224 // tc
-    max_cross = (tr - 1 + h - 1) // h
-    return L.TILE_PS_224x256 if (tr + 2 + 2 * max_cross) * (tc + 2) <= 360 else L.TILE_AUTO
+    return L.TILE_PS_224x256 if (C % 64 == 0 and conv_ps_supported(N, Hp - 2, Wp - 2, C, C)) else L.TILE_AUTO
 
 
 def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res, tile=L.TILE_AUTO, keep_z=True):

@@ -173,20 +173,10 @@ class FrozenStem(object):
             ly["wt_rows"] = wt if tile is None else K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad,
                                                                        c_in_pad=c_in_pad)
         # wide 3x3 layers (conv21 .. conv32): patch-stationary kernel (csrc/conv_ps.hip, K-major weights) when the run-time
-        # geometry qualifies (_ps_ok); the implicit-GEMM tile above stays as the fallback
+        # geometry qualifies (vnqa_conv_ps_supported); the implicit-GEMM tile above stays as the fallback
         if bf16 and tile == L.TILE_STEM_256x256 and w.shape[2] == 3 and os.environ.get("VNQA_STEM_PS", "1") != "0":
             ly["wt_ps"] = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         return ly
-
-    @staticmethod
-    def _ps_ok(h, w, pool):
-        """vnqa_conv_ps_dispatch's geometry conditions for a 3x3 layer on h x w maps (224-pixel tiles of 8 x 28 or 16 x 14)."""
-        tc = 28 if w % 28 == 0 else (14 if (w >= 14 and (w % 14 == 0 or w % 2 == 0)) else 0)     # (else: overlapping last block)
-        if tc == 0 or (pool and (h % 2 or w % 2)):
-            return False
-        tr = 224 // tc
-        max_cross = (tr - 1 + h - 1) // h
-        return (tr + 2 + 2 * max_cross) * (tc + 2) <= 360
 
     def _compose_pair(self, c1, c2, bn):
         """Two stacked linear convs with frozen weights as ONE conv.
@@ -325,7 +315,7 @@ class FrozenStem(object):
                 x = K.conv2d_wreg(x, ly["wt_rows"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                   post_scale=post[0] if post else None, post_shift=post[1] if post else None,
                                   out=out, y_halo=yh, reserve_cus=self.reserve_cus)
-            elif "wt_ps" in ly and yh == 1 and self._ps_ok(h, w, ly["pool"]):
+            elif "wt_ps" in ly and yh == 1 and K.conv_ps_supported(n, h, w, x.shape[-1], ly["c_out_pad"], 9, ly["pool"]):
                 kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)      # (one entry per kernel SYMBOL, as rocprofv3 lists them)
                 x = K.conv2d_igemm(x, ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                    post_scale=post[0] if post else None, post_shift=post[1] if post else None,
