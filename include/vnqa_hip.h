@@ -146,7 +146,8 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
  *   vnqa_x3_post        : y = post( pool2?( relu?( raw - border_sub + bias ) ) ) in fp32 -> padded NHWC fp32 interior
  *                         (the epilogue contract of vnqa_conv2d_igemm_fwd_ex; border_sub fp32 [n][2w + 2(h-2)][c_out]);
  *                         out_x3 != 0: y is 16-bit [..][c_y >= 3 c_out] and receives the halves [hi | lo | hi] instead — the
- *                         next x3 product's operand, no fp32 round trip between consecutive layers.
+ *                         next x3 product's operand, no fp32 round trip between consecutive layers; out_x3 == 2: [hi | hi]
+ *                         (c_y >= 2 c_out) for a two-product consumer — this output then carries ONE fp16 rounding.
  *   vnqa_gemm_nt with dtype = VNQA_BF16 | VNQA_GEMM_OUT_F32 : 16-bit operands, fp32 `out` (workspace >= m*n*4 bytes required).
  */
 int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld, int64_t dst_ld,

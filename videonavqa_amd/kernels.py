@@ -188,7 +188,8 @@ def x3_weight2(wt):
 def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub, x3_out=False):
     """One conv as an x3 product.  x: fp32 [.., C] (split here), or 16-bit [.., 3C] already in the [hi | lo | hi] operand layout
     (the previous layer's x3_out), or 16-bit [.., C] (a plain 16-bit activation: [x | x] against [w_hi | w_lo], two products).
-    Output: fp32 padded NHWC, or with x3_out the next layer's 16-bit operand [.., 3 c_out]."""
+    Output: fp32 padded NHWC, or with x3_out = 1 the next layer's 16-bit operand [.., 3 c_out] = [hi | lo | hi], x3_out = 2 its
+    two-product operand [.., 2 c_out] = [hi | hi] (the output rounded to fp16 once)."""
     N, Hp, Wp, Cx = x.shape
     H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
     c_out, taps, Cin = wt.shape
@@ -208,6 +209,10 @@ def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo,
         assert x.dtype == half
         k, xin = 3 * Cin, x
         w3 = x3_weight(wt).view(c_out, taps, k)
+    elif Cx == 2 * Cin:          # [x | x] written by the producer (x3_out=2): two products, nothing to prepare
+        assert x.dtype == half
+        k, xin = 2 * Cin, x
+        w3 = x3_weight2(wt).view(c_out, taps, k)
     else:
         assert x.dtype == half and Cx == Cin
         k = 2 * Cin
@@ -218,14 +223,14 @@ def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo,
     d = L.ConvDesc(L.BF16, N, H, W, k, c_out, c_out, taps, x_halo, 0, 0, 0, L.TILE_AUTO, 0, 0, 0)      # (the 16-bit product picks its own tile)
     L.check(L.lib().vnqa_conv2d_igemm_raw(ctypes.byref(d), L.ptr(xin), L.ptr(w3), L.ptr(raw), L.stream()), "vnqa_conv2d_igemm_raw")
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
-    odt, oc = (half, 3 * c_out) if x3_out else (torch.float32, c_out)
+    odt, oc = (half, (3 if int(x3_out) == 1 else 2) * c_out) if x3_out else (torch.float32, c_out)
     if out is None:
         shape = (N, Ho + 2 * y_halo, Wo + 2 * y_halo, oc)
         out = empty_padded(shape, odt, x.device) if y_halo == 1 else torch.zeros(shape, dtype=odt, device=x.device)
     assert out.dtype == odt and out.shape[:3] == (N, Ho + 2 * y_halo, Wo + 2 * y_halo) and out.shape[-1] >= oc
     bs = None if border_sub is None else border_sub.float().contiguous()
     L.check(L.lib().vnqa_x3_post(L.ptr(raw), L.ptr(bias), L.ptr(post_scale), L.ptr(post_shift), L.ptr(bs), L.ptr(out), N, H, W,
-                                 c_out, out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, 1 if x3_out else 0, L.ptr(inv),
+                                 c_out, out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, int(x3_out), L.ptr(inv),
                                  L.stream()), "vnqa_x3_post")
     return out
 

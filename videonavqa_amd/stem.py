@@ -97,6 +97,10 @@ class FrozenStem(object):
             # stem's 32 ms) — run as the plain fp16 fused kernel by default (1.05 ms): five fp16 roundings (clip, two weight sets,
             # two activations) stay in the forward pass, ~0.5e-3 of logits error instead of ~1e-5 (VNQA_X3_PLAIN_FIRST=0: all x3)
             self.x3_plain_first = self.x3 and os.environ.get("VNQA_X3_PLAIN_FIRST", "1") != "0"
+            # VNQA_X3_ROUND=n (default 0): the INPUT of the n heaviest x3 layers (composed 5x5, conv22, conv21, conv2_2 — in that order)
+            # is kept as ONE rounded fp16 tensor: two products instead of three on that layer (a third of its matrix work) for one
+            # more fp16 rounding (~0.26e-3 of logits error each, in quadrature) — the speed / tolerance curve of the mode
+            self.x3_round = set(("composed", "od3", "od2", "vgg2")[:int(os.environ.get("VNQA_X3_ROUND", "0"))]) if self.x3 else set()
             self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=L.half_dtype() if self.x3_plain_first else None),
                                self._layer(f["5"], relu=True, pool=False),
                                self._layer(f["7"], relu=True, pool=True)]
@@ -258,8 +262,9 @@ class FrozenStem(object):
                         for e, name in enumerate(("top", "bottom", "left", "right"))]
         ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
+        x3o = (2 if "od2" in self.x3_round else 1) if self.x3 else 0
         if self.x3:
-            out = self._buf(key + (ho, wo, "x3"), (n, ho + 2, wo + 2, 3 * cp["c_out_pad"]), dtype=L.half_dtype())
+            out = self._buf(key + (ho, wo, "x3"), (n, ho + 2, wo + 2, (4 - x3o) * cp["c_out_pad"]), dtype=L.half_dtype())
         else:
             out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
         timed = self.timing is not None and (self.x3 or cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256))
@@ -270,7 +275,7 @@ class FrozenStem(object):
         # 1 022 -> 831 MB per launch (profiles/r04_pmc_traffic*.json), time unchanged (2.166 vs 2.161 ms; end to end 941-943 either way)
         xcd = L.CONV_XCD_SPLIT_N if (not self.x3 and os.environ.get("VNQA_STEM_XCD_SPLIT", "1") == "1") else 0
         y = K.conv2d_igemm(xc, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
-                           tile=cp["tile"], border_sub=ring, x3_out=self.x3, desc_flags=xcd)
+                           tile=cp["tile"], border_sub=ring, x3_out=x3o, desc_flags=xcd)
         if timed:
             ev1.record()
             self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25,
@@ -300,7 +305,9 @@ class FrozenStem(object):
             # last layer (`final`) writes fp32
             x3_out = self.x3 and K._F32_CONV_MODE[0] == "x3" and not (last and final)
             if x3_out:
-                out = self._buf(key + ("x3",), (n, ho + 2 * yh, wo + 2 * yh, 3 * ly["c_out_pad"]), dtype=L.half_dtype())
+                nxt = ("%s%d" % (tag, i + 1)) if not last else ("composed" if (tag == "vgg" and self.composed is not None) else "od0")
+                x3_out = 2 if nxt in self.x3_round else 1
+                out = self._buf(key + ("x3",), (n, ho + 2 * yh, wo + 2 * yh, (4 - x3_out) * ly["c_out_pad"]), dtype=L.half_dtype())
             else:
                 out = self._buf(key, (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
             post = ly["post"]
