@@ -266,8 +266,9 @@ def fp16_leg(args, precision="fp16"):
                 if precision == "fp16" else
                 "bench.py --precision fp16x: the TOLERANCE-COMPLIANT 16-bit-MFMA mode — fp32 storage, every conv / GEMM of the stem "
                 "(from conv2_1 on; conv1_1 + conv1_2 on the plain fp16 fused kernel) and of the trunk, forward AND backward, as three "
-                "fp16-half products (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate) on the fp16 matrix cores, gradient operands "
-                "scaled by a device-chosen power of two; %d timed steps, child process") % d["steps"]
+                "fp16-half products (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; two products where the input is kept as one "
+                "rounded fp16 tensor: the four heaviest stem layers, VNQA_X3_ROUND) on the fp16 matrix cores, gradient operands scaled by "
+                "a device-chosen power of two; %d timed steps, child process") % d["steps"]
         key = precision + "_logits_rel_err"
         return {"what": what, "precision": precision,
                 # the precision's own full line: the same fields the top-level line carries, measured the same way
