@@ -464,9 +464,9 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
             loss = tr.loss_fn(out, y[perm_d])
         return out, loss
 
-    low = args.precision if args.precision in ("bf16", "fp16", "fp16x") else "bf16"      # the 16-bit precision under test
+    low = args.precision if args.precision in ("bf16", "fp16", "fp16w", "fp16x") else "bf16"      # the 16-bit precision under test
     from videonavqa_amd import _lib as L
-    L.set_half("f16" if low in ("fp16", "fp16x") else "bf16")       # one 16-bit storage format per process: fix it before the fp32 build
+    L.set_half("f16" if low in ("fp16", "fp16w", "fp16x") else "bf16")       # one 16-bit storage format per process: fix it before the fp32 build
     for prec in ("fp32", low):
         a = copy.copy(args)
         a.precision = prec
@@ -586,7 +586,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=3, help="the timed K-step region is run this many times back to back; "
                     "the reported value / ms_per_step are the MEDIAN region's, all regions are listed in `repeats`")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp16x", "fp32"],
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp16w", "fp16x", "fp32"],
                     help="bf16: the benchmark precision (BASELINE.json); fp16: the fp16-storage build of the library (same MFMA "
                          "rate, 8x finer rounding, loss-scaled backward); fp16x: fp32 storage, forward contractions as three "
                          "fp16-half products on the 16-bit matrix cores (the tolerance-compliant mode: logits within 1e-3 of "
@@ -628,7 +628,7 @@ def main():
         cpu_baseline_child(args)
         return
 
-    if args.precision in ("fp16", "fp16x"):      # the fp16-storage build of the library (one 16-bit format per process)
+    if args.precision in ("fp16", "fp16w", "fp16x"):      # the fp16-storage build of the library (one 16-bit format per process)
         from videonavqa_amd import _lib as L
         L.set_half("f16")
     if args.model == "v_only_cnn3d":
@@ -828,7 +828,7 @@ def main():
         alone_events, stem.timing = stem.timing, None
     parity = None
     # (single-GPU runs only: at N > 1 the other ranks would sit in the barrier below for the minute this takes)
-    if world == 1 and not args.no_parity and args.model != "mac" and args.precision in ("bf16", "fp16", "fp16x"):
+    if world == 1 and not args.no_parity and args.model != "mac" and args.precision in ("bf16", "fp16", "fp16w", "fp16x"):
         loss = loss.clone()
         del trainer, model, stem
         torch.cuda.empty_cache()
@@ -873,6 +873,8 @@ def main():
         flops_per_launch = dstat["gflop_per_launch"] * 1e9
         achieved = dstat["achieved_tflops"]
         peak = PEAK_BF16_TFLOPS if args.precision in ("bf16", "fp16") else PEAK_F32_TFLOPS      # fp16 MFMA rate == bf16's
+        if args.precision == "fp16w":      # 2 fp16 MFMA products per algorithmic multiply-add in the forward pass
+            peak = PEAK_BF16_TFLOPS / 2.0
         if args.precision == "fp16x":      # 3 fp16 MFMA products per algorithmic multiply-add: priced on the algorithmic FLOPs
             peak = PEAK_BF16_TFLOPS / 3.0
         # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
@@ -902,7 +904,7 @@ def main():
             "metric": METRIC, "value": round(clips, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp16": "f16", "fp16x": "f16 x3 (forward contractions as three fp16-half MFMA products, fp32 storage / accumulate)", "fp32": "f32"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp16w": "f16 storage, forward contractions x . w_hi + x . w_lo (split weights, two fp16 MFMA products)", "fp16x": "f16 x3 (forward contractions as three fp16-half MFMA products, fp32 storage / accumulate)", "fp32": "f32"}[args.precision], "data": "synthetic",
             "repeats": {"n": len(regions), "value_is": "median region", "clips_per_s": [round(c, 1) for c in all_clips],
                         "spread_rel": round((max(all_clips) - min(all_clips)) / clips, 4)},
             "config": {"workload": "%s training step: VGG-16[:10]+ObjDetectCNN(512) frozen stem + "

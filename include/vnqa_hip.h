@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 408
+#define VNQA_ABI_VERSION 409
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -87,6 +87,9 @@ typedef struct vnqa_conv_desc {
 #define VNQA_CONV_ZERO_HALO 1
 #define VNQA_CONV_XCD_SPLIT_N 2   /* stem-tagged implicit-GEMM tiles with exactly two cout tiles (the composed 5x5 conv, c_out 512 on
                                    * 256-cout tiles): every XCD computes ONE cout half, so its 4 MiB L2 holds half of the weight set */
+#define VNQA_CONV_X_WRAP2 4       /* x has c_in / 2 PHYSICAL channels and is read twice along K against wt = [w_hi | w_lo] ([c_out][taps][c_in]):
+                                   * the two-product form x . w_hi + x . w_lo of a 16-bit activation with split weights (precision 'fp16w');
+                                   * plain epilogues, tiles 256x256 / 256x128 / 256x64 / 512x128 / 320x128 or AUTO; c_in % 128 == 0 */
 /* bits 8..15 of flags: the persistent conv kernels leave n CUs (a multiple of 8, <= 224) to the other streams of the process */
 #define VNQA_CONV_RESERVE_CUS(n) ((((n) < 0 ? 0 : ((n) > 224 ? 224 : (n))) / 8) << 8)
 #define VNQA_CONV_RESERVE_OF(flags) ((((flags) >> 8) & 0xff) * 8)
@@ -159,6 +162,7 @@ int vnqa_x3_post(const float* raw, const float* bias, const float* post_scale, c
                  int32_t pool2, int32_t out_x3, const float* raw_scale, void* stream);   /* raw_scale: optional DEVICE scalar
                                                           * multiplied into the raw sums first (1 / the operand's split scale) */
 #define VNQA_GEMM_OUT_F32 0x200
+#define VNQA_GEMM_X_WRAP2 0x400   /* vnqa_gemm_nt: a has k / 2 physical columns (row stride k / 2), read twice against b = [b_hi | b_lo] */
 
 /* Fused trunk epilogues (BIAS_RELU_BNSTATS / BIAS_FILM_RELU_RES) — the same conv with the elementwise op
  * that FOLLOWS it in the reference applied while the output tile is still in LDS:

@@ -84,6 +84,80 @@ def test_x3_gemm_nt_matches_exact_f32():
     assert float((got - (a @ b.t() + bias)).abs().max()) < 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("cfg", [dict(cin=64, cout=128, taps=9, relu=True, pool=False, tile=15),
+                                 dict(cin=128, cout=128, taps=9, relu=True, pool=True, tile=15, post=True, y_halo=2),
+                                 dict(cin=512, cout=512, taps=9, relu=False, pool=False, tile=0),
+                                 dict(cin=512, cout=512, taps=1, relu=True, pool=False, tile=0),
+                                 dict(cin=128, cout=512, taps=25, relu=True, pool=True, tile=1, border=True)])
+def test_w2_two_product_conv_removes_the_weight_rounding(cfg):
+    """precision 'fp16w': the conv with a plain fp16 activation read twice along K against [w_hi | w_lo] (igemm TAG 4,
+    VNQA_CONV_X_WRAP2).  Against the exact fp32 conv of the SAME fp16-valued activation with the fp32 weights: only the output's own
+    fp16 rounding is left (<= 2^-11 relative to the value), whereas the plain fp16 conv also carries the weight rounding."""
+    from videonavqa_amd import kernels as K
+    cin, cout, taps = cfg["cin"], cfg["cout"], cfg["taps"]
+    halo = 2 if taps == 25 else 1
+    n, h, w = 3, 12, 16
+    x16 = _padded(n, h, w, cin, 21, halo).half()
+    g = torch.Generator().manual_seed(22)
+    k = {9: 3, 1: 1, 25: 5}[taps]
+    wf = (torch.randn(cout, cin, k, k, generator=g) / (cin * taps) ** 0.5).cuda()
+    wt32 = K.pack_conv_weight(wf, torch.float32)
+    bias = torch.randn(cout, generator=g).cuda() * 0.1
+    post = (torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda() * 0.1) if cfg.get("post") else (None, None)
+    ring32 = torch.randn(n, 2 * w + 2 * (h - 2), cout, generator=g).cuda() * 0.05 if cfg.get("border") else None
+    yh = cfg.get("y_halo", 1)
+    kw = dict(bias=bias, relu=cfg["relu"], pool2=cfg["pool"], post_scale=post[0], post_shift=post[1], x_halo=halo, y_halo=yh)
+    ref = K.conv2d_igemm(x16.float(), wt32, border_sub=ring32, **kw)                         # exact fp32 on the same values
+    ring16 = None if ring32 is None else ring32.half()
+    if ring16 is not None:
+        ref = K.conv2d_igemm(x16.float(), wt32, border_sub=ring16.float(), **kw)
+    plain = K.conv2d_igemm(x16, K.pack_conv_weight(wf, torch.float16), border_sub=ring16, **kw)
+    with K.f32_conv_mode("w2"):
+        got = K.conv2d_igemm(x16, wt32, border_sub=ring16, tile=cfg["tile"], **kw)
+    assert got.dtype == torch.float16 and got.shape == plain.shape
+    scale = float(ref.abs().max())
+    e_w2, e_plain = float((got.float() - ref).abs().max()) / scale, float((plain.float() - ref).abs().max()) / scale
+    assert e_w2 < 6e-4, (e_w2, e_plain)                                    # the output's own rounding
+    assert float((got.float() - ref).norm()) < 0.8 * float((plain.float() - ref).norm()), (e_w2, e_plain)
+    assert float(got[:, 0].float().abs().max()) == 0                       # zero halo kept
+
+
+def test_w2_gemm_nt_matches_exact_f32_up_to_output_rounding():
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(23)
+    a = torch.randn(280, 4096, generator=g).cuda().half()
+    b = (torch.randn(128, 4096, generator=g) / 64.0).cuda()
+    bias = torch.randn(128, generator=g).cuda()
+    ref = a.float() @ b.t() + bias
+    with K.f32_conv_mode("w2"):
+        got = K.gemm_nt(a, b, bias=bias)
+    plain = K.gemm_nt(a, b.half(), bias=bias)
+    assert got.dtype == torch.float16
+    assert float((got.float() - ref).abs().max()) < 6e-4 * float(ref.abs().max())
+    assert float((got.float() - ref).norm()) < 0.8 * float((plain.float() - ref).norm())
+
+
+@pytest.mark.parametrize("case", ["film_attn_ragged", "film_attn_s196", "film_gp_full", "tmh_ragged"])
+def test_fp16w_models_vs_reference_golden(case):
+    """precision='fp16w' (fp16 storage, split weights in every forward contraction) on the reference's goldens: eval and train
+    logits at least as close as the fp16 precision's stated 1e-2, finite gradients through the plain fp16 backward."""
+    import torch.nn as nn
+    model, g = build_product_model(case, "fp16w")
+    assert model.w2 and model.compute_dtype == torch.float16
+    v, q, vl, ql, y = (torch.from_numpy(g[k]).cuda() for k in ("v", "q", "v_lens", "q_lens", "y"))
+    model.eval()
+    with torch.no_grad():
+        model.init_hidden()
+        got = model(v, q, vl, ql).float().cpu().numpy()
+    assert rel_err(got, g["eval_logits"]) < 1e-2, rel_err(got, g["eval_logits"])
+    model.train()
+    model.init_hidden()
+    logits = model(v, q, vl, ql)
+    nn.CrossEntropyLoss(reduction="sum")(logits, y).backward()
+    assert rel_err(logits.detach().float().cpu().numpy(), g["train_logits"]) < 1e-2
+    assert all(bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.grad is not None)
+
+
 @pytest.mark.parametrize("mag", [1.0, 1e-6, 3e-9])
 def test_x3g_backward_products_match_exact_f32_for_tiny_gradients(mag):
     """The backward's x3 products ('x3g': the gradient operand scaled by a device-chosen power of two before the fp16 split, the

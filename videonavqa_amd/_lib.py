@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 408          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 409          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -53,6 +53,8 @@ class ConvDesc(ctypes.Structure):
 
 CONV_ZERO_HALO = 1      # vnqa_conv_desc.flags
 CONV_XCD_SPLIT_N = 2
+CONV_X_WRAP2 = 4
+GEMM_X_WRAP2 = 0x400
 WGRAD_FUSED_REDUCE = 0x100     # option bit of vnqa_conv2d_wgrad's dtype argument
 GEMM_OUT_F32 = 0x200           # option bit of vnqa_gemm_nt's dtype argument: 16-bit operands, fp32 output
 

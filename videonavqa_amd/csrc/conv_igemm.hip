@@ -172,6 +172,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
 
   const int kchunks = p.Cin / BK;
   const int KT = p.taps * kchunks;
+  // TAG 4 (VNQA_CONV_X_WRAP2): the activation tensor has Cin / 2 PHYSICAL channels and is read twice along K — channel chunks
+  // [0, Cin/2) and [Cin/2, Cin) of the contraction both come from it, against a weight operand [w_hi | w_lo]: the two-product form
+  // x . w_hi + x . w_lo of a 16-bit activation with split weights (precision 'fp16w'), with no duplicated copy of x in memory.
+  const int CX = TAG == 4 ? p.Cin / 2 : p.Cin;          // pixel stride of x in elements
   const size_t w_row_bytes = (size_t)p.taps * p.Cin * ES;
 
   // ---- per-lane source offsets (constant over the K loop) ----
@@ -205,7 +209,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       img = (size_t)nn * (p.D + 2) + (n - nn * p.D);
     }
     const int lc = (lane % CPR) ^ swz(row);
-    a_off[j] = ((img * p.Hp + y) * p.Wp + x) * (size_t)p.Cin * ES + (size_t)lc * 16;
+    a_off[j] = ((img * p.Hp + y) * p.Wp + x) * (size_t)CX * ES + (size_t)lc * 16;
   }
 #pragma unroll
   for (int j = 0; j < B_PER_WAVE; ++j) {
@@ -242,7 +246,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       r = p.x_halo;
       s = p.x_halo;
     }
-    const size_t tapoff = ((((size_t)q * p.Hp + r) * p.Wp + s) * p.Cin + (size_t)kc * BK) * ES;
+    const int kcx = (TAG == 4 && kc >= (kchunks >> 1)) ? kc - (kchunks >> 1) : kc;
+    const size_t tapoff = ((((size_t)q * p.Hp + r) * p.Wp + s) * CX + (size_t)kcx * BK) * ES;
     const size_t woff = ((size_t)tap * p.Cin + (size_t)kc * BK) * ES;
     char* lds = smem + buf * STAGE_BYTES;
 #ifdef VNQA_DIAG_SKIP_DMA   // timing-only diagnostic build: drop one operand's DMA after the first stage
@@ -1061,6 +1066,22 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
     vnqa_set_error("conv2d_igemm_fwd: the ELU epilogue is built for the automatic tiles only (256x256 / 256x128 / 256x64; f32 128x128 / 128x64), not tile %d", tile);
     return VNQA_ERR_UNSUPPORTED;
   }
+  if (a.x_wrap2) {          // two-product form: x read twice along K (TAG 4 instantiations of the plain tiles)
+    if (dtype != VNQA_BF16 || a.epi != VNQA_EPI_NONE || a.wt_tiled || a.D != 0 || a.ring_h != 0 || a.group_tiles != 0 || a.Cin % 128 != 0) {
+      vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_X_WRAP2 needs a plain 16-bit 2-D conv / GEMM with c_in %% 128 == 0 and K-major weights");
+      return VNQA_ERR_UNSUPPORTED;
+    }
+    switch (tile) {
+      case VNQA_TILE_256x256: case VNQA_TILE_STEM_256x256: return launch<vnqa_bf16, 256, 256, 2, 4, 4>(a, st);
+      case VNQA_TILE_256x128: return launch<vnqa_bf16, 256, 128, 4, 2, 4>(a, st);
+      case VNQA_TILE_256x64: return launch<vnqa_bf16, 256, 64, 8, 1, 4>(a, st);
+      case VNQA_TILE_512x128: return launch<vnqa_bf16, 512, 128, 4, 2, 4>(a, st);
+      case VNQA_TILE_320x128: return launch<vnqa_bf16, 320, 128, 4, 2, 4>(a, st);
+      default:
+        vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_X_WRAP2 is available on tiles 256x256, 256x128, 256x64, 512x128, 320x128 (got %d)", tile);
+        return VNQA_ERR_UNSUPPORTED;
+    }
+  }
   if (dtype == VNQA_BF16) {
     switch (tile) {
       case VNQA_TILE_256x256: return launch<vnqa_bf16, 256, 256, 2, 4>(a, st);
@@ -1256,7 +1277,8 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
                             int32_t m, int32_t n, int32_t k, int32_t ldo, int32_t relu, int32_t dtype,
                             void* stream) {
   const bool out_f32 = (dtype & VNQA_GEMM_OUT_F32) != 0;       // 16-bit operands, fp32 output (x3 products): per-call option bit
-  dtype &= ~VNQA_GEMM_OUT_F32;
+  const bool wrap2 = (dtype & VNQA_GEMM_X_WRAP2) != 0;         // a has k / 2 physical columns, read twice against b = [b_hi | b_lo]
+  dtype &= ~(VNQA_GEMM_OUT_F32 | VNQA_GEMM_X_WRAP2);
   VNQA_CHECK_ARG(a_mk && b_nk && out, "gemm_nt: null pointer");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "gemm_nt: bad dtype %d", dtype);
   VNQA_CHECK_ARG(!out_f32 || (dtype == VNQA_BF16 && workspace != nullptr),
@@ -1280,6 +1302,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
   a.M = m; a.tilesN = 0; a.Hyp = 1; a.Wyp = 1; a.wt_tiled = 0; a.D = 0;
   a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr; a.group_tiles = 0;
   a.epi = VNQA_EPI_NONE; a.ring_h = 0; a.ring_w = 0;
+  a.x_wrap2 = wrap2 ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   // bf16: 256-row tiles unless 128-row tiles waste fewer padded rows (e.g. m = 280: 384 instead of 512)
   int tile = VNQA_TILE_128x128;
@@ -1287,6 +1310,7 @@ extern "C" int vnqa_gemm_nt(const void* a_mk, const void* b_nk, const float* bia
     const int pad256 = (m + 255) / 256 * 256, pad128 = (m + 127) / 128 * 128;
     tile = (ws > 0 || pad128 >= pad256) ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
     if (ws > 0 && m > 256 && m <= 320 && n <= 128) tile = VNQA_TILE_320x128;     // one row tile instead of two half-empty ones
+    if (wrap2 && tile == VNQA_TILE_128x128) tile = VNQA_TILE_256x128;
     // (256x256 tiles for wide outputs — the stem's ring GEMM alone 112 -> 90 us — were measured and dropped: neutral end to
     // end at 224x224, -9 % at 160x208 where 412 such tiles fill 1.6 rounds of the chip)
   }
@@ -1392,6 +1416,7 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
                  "conv2d_igemm_fwd: VNQA_CONV_ZERO_HALO needs a 2-D conv with y_halo == 1");
   a.zero_halo = (d->flags & VNQA_CONV_ZERO_HALO) ? 1 : 0;
   a.xcd_split = (d->flags & VNQA_CONV_XCD_SPLIT_N) ? 1 : 0;
+  a.x_wrap2 = (d->flags & VNQA_CONV_X_WRAP2) ? 1 : 0;
   a.pool = d->pool2;
   a.M = d->n_img * d->h * d->w;
   a.tilesN = 0;

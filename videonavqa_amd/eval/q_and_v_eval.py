@@ -65,7 +65,7 @@ def build_parser():
     parser.add_argument('--best_acc', type=float, default=0)          # passed by eval.sh:57, unused upstream
     # additions
     parser.add_argument('--synthetic', type=int, default=0)
-    parser.add_argument('--precision', type=str, choices=['bf16', 'fp16', 'fp16x', 'fp32'], default='bf16')
+    parser.add_argument('--precision', type=str, choices=['bf16', 'fp16', 'fp16w', 'fp16x', 'fp32'], default='bf16')
     parser.add_argument('--height', type=int, default=U.VID_HEIGHT)
     parser.add_argument('--width', type=int, default=U.VID_WIDTH)
     return parser

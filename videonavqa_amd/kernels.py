@@ -83,7 +83,10 @@ class f32_conv_mode(object):
         # 'x3g': x3 products whose ACTIVATION-side operand is a gradient tensor (the backward pass): it is multiplied by a
         # per-tensor power of two chosen on the device (its max lands in [2^12, 2^13)) before the fp16 split — gradients are
         # 1e-5 .. 1e-8 here, below fp16's normal range — and the fp32 result is divided by it again
-        assert mode in ("x3", "x3g", "exact")
+        # 'w2' (precision 'fp16w'): convs / GEMMs with a 16-bit activation and fp32 K-major weights run as the TWO-product form
+        # x . w_hi + x . w_lo — the weight rounding is removed, the activations stay plain fp16 tensors (read twice along K by the
+        # igemm's wrap variant, VNQA_CONV_X_WRAP2: no copy, fused epilogues as usual)
+        assert mode in ("x3", "x3g", "w2", "exact")
         self.mode = mode
 
     def __enter__(self):
@@ -101,6 +104,16 @@ def x3_active(t):
 
 def x3_mode():
     return _F32_CONV_MODE[0]
+
+
+def w2_active(t):
+    return _F32_CONV_MODE[0] == "w2" and L.is_half(t.dtype) and t.is_cuda
+
+
+def fwd_pack_dtype(x):
+    """dtype in which a forward pass packs its weights for activation x: fp32 in the two-product mode (the conv / GEMM wrappers
+    split them into [w_hi | w_lo] themselves), else the activation's own."""
+    return torch.float32 if w2_active(x) else x.dtype
 
 
 def grad_split_scale(t):
@@ -256,12 +269,19 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
     tiled = isinstance(wt, TiledWeight)
+    w2 = w2_active(x) and not tiled and wt.dtype == torch.float32
+    if w2:          # two products: x read twice along K against [w_hi | w_lo] (VNQA_CONV_X_WRAP2)
+        assert wt.shape[2] == Cin and Cin % 64 == 0
+        wt = x3_weight2(wt)
+        desc_flags = int(desc_flags) | L.CONV_X_WRAP2
+        if tile not in (L.TILE_AUTO, L.TILE_256x256, L.TILE_256x128, L.TILE_256x64, L.TILE_STEM_256x256, 15, 17):
+            tile = L.TILE_AUTO
     if tiled:
         c_out, taps, cin_w, tile = wt.c_out, wt.taps, wt.c_in_pad, wt.tile
         wt = wt.data
     else:
         c_out, taps, cin_w = wt.shape
-    assert cin_w == Cin and wt.dtype == x.dtype, (cin_w, x.shape, wt.dtype, x.dtype)
+    assert cin_w == (2 * Cin if w2 else Cin) and wt.dtype == x.dtype, (cin_w, x.shape, wt.dtype, x.dtype)
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     flags = 0
     if out is None:
@@ -273,7 +293,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
             out = empty_padded((N, Ho + 2, Wo + 2, c_out), x.dtype, x.device)
         else:
             out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
-    d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], taps, x_halo, y_halo,
+    d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, cin_w, c_out, out.shape[-1], taps, x_halo, y_halo,
                    int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0, 0, flags | int(desc_flags))
     L.check(L.lib().vnqa_conv2d_igemm_fwd_ex(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),
                                              L.ptr(post_shift), L.ptr(border_sub), L.ptr(out), L.stream()),
@@ -333,8 +353,9 @@ def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res, tile=L.TILE_AUT
     c_out, taps, _ = wt.shape
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.stride(1) == 1 and beta.stride(1) == 1
     assert gamma.stride(0) == beta.stride(0) and res.shape == (N, Hp, Wp, c_out) and res.dtype == x.dtype
-    if x3_active(x):       # the conv as an x3 product, the FiLM affine + ReLU + residual as the separate fp32 kernel
-        z = conv2d_igemm(x, wt, bias=bias, x_halo=1 if taps == 9 else 1)
+    if x3_active(x) or (w2_active(x) and wt.dtype == torch.float32):
+        # the conv as an x3 / two-product conv, the FiLM affine + ReLU + residual as the separate elementwise kernel
+        z = conv2d_igemm(x, wt, bias=bias)
         g = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
         b = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
         g[:, :film_c], b[:, :film_c] = gamma[:, :film_c], beta[:, :film_c]
@@ -789,7 +810,18 @@ def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
     split_k=False: one pass over K in a fixed order (result independent of M's tiling)."""
     M, Kd = a.shape
     N = b.shape[0]
-    assert b.shape[1] == Kd and a.dtype == b.dtype
+    assert b.shape[1] == Kd and (a.dtype == b.dtype or (w2_active(a) and b.dtype == torch.float32))
+    if w2_active(a) and b.dtype == torch.float32 and Kd % 64 == 0 and a.is_contiguous():
+        # two products: a read twice along K against [b_hi | b_lo] (VNQA_GEMM_X_WRAP2)
+        b2 = x3_weight2(b)
+        if out is None:
+            out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+        did = L.dtype_id(a.dtype)
+        ws_bytes = L.lib().vnqa_gemm_nt_workspace(M, N, 2 * Kd, did) if split_k else 0
+        ws = workspace(ws_bytes, a.device) if ws_bytes > 0 else None
+        L.check(L.lib().vnqa_gemm_nt(L.ptr(a), L.ptr(b2), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, 2 * Kd, out.stride(0),
+                                     1 if relu else 0, did | L.GEMM_X_WRAP2, L.stream()), "vnqa_gemm_nt(w2)")
+        return out
     if x3_active(a) and Kd % 64 == 0 and a.is_contiguous():
         # x3 product: [a_hi | a_lo | a_hi] . [b_hi | b_hi | b_lo]^T on the 16-bit GEMM with an fp32 output
         scale = inv = None

@@ -42,7 +42,12 @@ def compute_dtype(precision):
         # 16-bit-MFMA precision — logits within north star's 1e-3 of exact fp32 (measured ~1e-5) at a multiple of its speed
         L.set_half("f16")
         return torch.float32
-    raise ValueError("precision must be 'bf16', 'fp16', 'fp16x' or 'fp32' (got %r)" % (precision,))
+    if precision == "fp16w":
+        # fp16 storage like 'fp16', but every FORWARD conv / GEMM runs the two-product form x . w_hi + x . w_lo (split weights, the
+        # activation read twice along K): the 14 weight roundings of the fp16 precision are removed, its 15 activation roundings stay
+        L.set_half("f16")
+        return torch.float16
+    raise ValueError("precision must be 'bf16', 'fp16', 'fp16w', 'fp16x' or 'fp32' (got %r)" % (precision,))
 
 
 def is_x3(precision):
@@ -268,8 +273,9 @@ class FiLMTrunkBase(nn.Module):
     def __call__(self, *args, **kwargs):
         # precision='fp16x' (self.x3): convs / GEMMs on fp32 tensors inside this forward run as x3 products; the backward pass,
         # which runs after this context has closed, keeps the exact-f32 matrix path
-        if self.__dict__.get("x3", False):
-            with K.f32_conv_mode("x3"):
+        mode = "x3" if self.__dict__.get("x3", False) else ("w2" if self.__dict__.get("w2", False) else None)
+        if mode is not None:
+            with K.f32_conv_mode(mode):
                 return super().__call__(*args, **kwargs)
         return super().__call__(*args, **kwargs)
 
@@ -523,7 +529,8 @@ class FiLMTrunkBase(nn.Module):
         bn = self.bn_init
         scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + BN_EPS)
         shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
-        wt0 = K.pack_conv_weight(self.conv_init.weight, cdt, c_out_pad=c_pad, c_in_pad=x.shape[-1])
+        fdt = K.fwd_pack_dtype(x)          # (fp32 packs in the two-product precision: the conv wrapper splits them)
+        wt0 = K.pack_conv_weight(self.conv_init.weight, fdt, c_out_pad=c_pad, c_in_pad=x.shape[-1])
         h = K.conv2d_igemm(x, wt0, bias=K.pad_vec(self.conv_init.bias, c_pad), relu=True,
                            post_scale=K.pad_vec(scale, c_pad), post_shift=K.pad_vec(shift, c_pad))
         if join is not None:
@@ -531,12 +538,12 @@ class FiLMTrunkBase(nn.Module):
         packs = self._frozen_c1_packs(cdt, c_pad)
         for k in range(self.num_res_blocks):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
-            wt1 = packs[k][0] if packs else K.pack_conv_weight(c1.weight, cdt, c_out_pad=c_pad, c_in_pad=c_pad)
+            wt1 = packs[k][0] if (packs and fdt == cdt) else K.pack_conv_weight(c1.weight, fdt, c_out_pad=c_pad, c_in_pad=c_pad)
             res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(c1.bias, c_pad), relu=True)
             film, col = film_specs[k]
             if not (film.dtype == torch.float32 and film.stride(1) == 1):
                 film = film.float().contiguous()
-            _, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(c3.weight, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
+            _, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(c3.weight, fdt, c_out_pad=c_pad, c_in_pad=c_pad),
                                            K.pad_vec(c3.bias, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res,
                                            tile=K.ps_fused_tile(res), keep_z=False)
         return h

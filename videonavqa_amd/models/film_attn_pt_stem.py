@@ -30,6 +30,7 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         self.spatial_size = spatial_size
         self.compute_dtype = compute_dtype(precision)
         self.x3 = precision == "fp16x"       # forward contractions as three fp16-half products (common.compute_dtype)
+        self.w2 = precision == "fp16w"       # fp16 storage, forward contractions with split weights (two products)
 
         self.embed = nn.Embedding(vocab_size, q_embedding_size)                       # :37
         self._build_trunk_head(num_input_channels, num_res_block_channels)             # :39-44

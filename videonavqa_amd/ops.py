@@ -97,7 +97,7 @@ class ConvFn(torch.autograd.Function):
         cdt = x.dtype
         c_in_pad = x.shape[-1]
         c_out_pad = L.round_up(c_out, 64)
-        wt = K.pack_conv_weight(weight, cdt, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+        wt = K.pack_conv_weight(weight, K.fwd_pack_dtype(x), c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         ctx.elu = relu is not True and relu == 2
         y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu,
                            tile=L.TILE_AUTO if ctx.elu else _ps_plain_tile(x, k, c_out_pad))   # (the ELU epilogue: igemm tiles only)
@@ -247,10 +247,10 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         lay, C = meta.layout, meta.channels
         cdt = x.dtype
         c_pad = L.round_up(C, 64)
-        wt0 = K.pack_conv_weight(conv_w, cdt, c_out_pad=c_pad, c_in_pad=x.shape[-1])
+        wt0 = K.pack_conv_weight(conv_w, K.fwd_pack_dtype(x), c_out_pad=c_pad, c_in_pad=x.shape[-1])
         b0 = K.pad_vec(conv_b, c_pad)
         fused = None
-        if L.is_half(cdt):              # fp32 (parity) precision keeps the exact two-pass statistics kernel
+        if L.is_half(cdt) and not K.w2_active(x):     # fp32 (parity) and the two-product precision keep the two-pass statistics kernel
             fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts))
         if fused is None:
             r = K.conv2d_igemm(x, wt0, bias=b0, relu=True)
@@ -324,11 +324,12 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
         saved = []
         for k in range(blocks):
             w1, b1, w3, b3 = tensors[meta.n_film + 4 * k: meta.n_film + 4 * k + 4]
-            wt1 = meta.c1_packs[k][0] if meta.c1_packs else K.pack_conv_weight(w1, cdt, c_out_pad=c_pad, c_in_pad=c_pad)
+            fdt = K.fwd_pack_dtype(h)
+            wt1 = meta.c1_packs[k][0] if (meta.c1_packs and fdt == cdt) else K.pack_conv_weight(w1, fdt, c_out_pad=c_pad, c_in_pad=c_pad)
             res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(b1, c_pad), relu=True)
             fi, col = meta.film_map[k]
             film = films[fi]
-            z, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(w3, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
+            z, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(w3, fdt, c_out_pad=c_pad, c_in_pad=c_pad),
                                            K.pad_vec(b3, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res,
                                            tile=K.ps_fused_tile(res))
             saved += [res, z]
@@ -874,7 +875,10 @@ class FcNativeFn(torch.autograd.Function):
             os.environ.get("VNQA_FC_DX", "1") != "0"
         nat, nat_t = K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, x.dtype, want_t=need_dx and not ctx.direct_dx)
         bias_p = K.pad_vec(bias, rows_pad)
-        out = K.gemm_nt(x.contiguous(), nat, bias=bias_p)
+        if K.w2_active(x):      # two-product forward: the fp32 operand (split into [hi | lo] by the GEMM wrapper); `nat` serves the backward
+            out = K.gemm_nt(x.contiguous(), K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, torch.float32, want_t=False)[0], bias=bias_p)
+        else:
+            out = K.gemm_nt(x.contiguous(), nat, bias=bias_p)
         ctx.save_for_backward(x, nat if ctx.direct_dx else nat_t)
         ctx.geom = (rows, C, h, w, c_pad)
         with torch.enable_grad():

@@ -50,7 +50,7 @@ class VGGFront(nn.Module):
 
     def forward(self, x):
         if self._plan is None:      # (the per-module drop-in path of fp16x runs on the exact-f32 kernels: an API path, not the fast one)
-            self._plan = FrozenStem(self, None, "fp32" if self.precision == "fp16x" else self.precision)
+            self._plan = FrozenStem(self, None, {"fp16x": "fp32", "fp16w": "fp16"}.get(self.precision, self.precision))
         return self._plan.vgg_nchw(x)
 
 
@@ -79,6 +79,7 @@ class FrozenStem(object):
         from .models.common import compute_dtype
         self.cdt = compute_dtype(precision)
         self.x3 = precision == "fp16x"       # fp32 storage, contractions as three fp16-half products (kernels.f32_conv_mode)
+        self.w2 = precision == "fp16w"       # fp16 storage, every layer after the fused conv1 with split weights (two products)
         self.vgg, self.objdet = vgg, objdet
         self.layers_vgg, self.layers_od = [], []
         self.composed = None
@@ -102,7 +103,7 @@ class FrozenStem(object):
             # more fp16 rounding.  The mode's speed / tolerance curve at the headline size, worst of the three parity batches
             # (profiles/r04_fp16x_curve.txt): PLAIN_FIRST=0 ~1e-5 at 245 clips/s; n = 0: 0.48e-3 at 277; 2: 0.56e-3 at 306; 4: 0.60e-3 at 325
             self.x3_round = set(("composed", "od3", "od2", "vgg2")[:int(os.environ.get("VNQA_X3_ROUND", "4"))]) if self.x3 else set()
-            self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=L.half_dtype() if self.x3_plain_first else None),
+            self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=L.half_dtype() if (self.x3_plain_first or self.w2) else None),
                                self._layer(f["5"], relu=True, pool=False),
                                self._layer(f["7"], relu=True, pool=True)]
         if objdet is not None:
@@ -171,6 +172,8 @@ class FrozenStem(object):
             wt = K.pack_conv_weight_tiled(w, self.cdt, tile, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         ly = dict(wt=wt, bias=K.pad_vec(b, c_out_pad), relu=relu, pool=pool, post=None,
                   c_out=c_out, c_in=c_in, c_out_pad=c_out_pad, tile=tile)
+        if self.w2:      # the fp32 K-major pack: the conv wrapper splits it into [w_hi | w_lo] once (cached on the tensor)
+            ly["wt32"] = K.pack_conv_weight(w, torch.float32, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         # short-K layers of the VGG front (conv1_2 / conv2_1 / conv2_2 shapes): weights-stationary-in-registers direct conv
         # (csrc/conv_wreg.hip) when the run-time geometry has whole tiles; it reads the K-major row pack
         if bf16 and relu and (c_in_pad, c_out_pad, bool(pool)) in ((64, 64, True), (64, 128, False), (128, 128, True)) \
@@ -223,7 +226,8 @@ class FrozenStem(object):
             return e.view(co_pad, -1).to(dev).to(self.cdt).contiguous()
         edges = dict(top=edge(w2[:, :, 0, :]), bottom=edge(w2[:, :, 2, :]), left=edge(w2[:, :, :, 0]), right=edge(w2[:, :, :, 2]))
         edges_all = torch.stack([edges[k] for k in ("top", "bottom", "left", "right")]).contiguous()   # [4, co_pad, 3*cm_pad]
-        return dict(wt=wt, bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges,
+        return dict(wt=wt, wt32=K.pack_conv_weight(wcf, torch.float32, c_out_pad=co_pad, c_in_pad=ci_pad) if self.w2 else None,
+                    bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges,
                     edges_all=edges_all,
                     c_in=ci, c_out=co, c_out_pad=co_pad, c_mid_pad=cm_pad, tile=tile, taps=25)
 
@@ -268,19 +272,21 @@ class FrozenStem(object):
             out = self._buf(key + (ho, wo, "x3"), (n, ho + 2, wo + 2, (4 - x3o) * cp["c_out_pad"]), dtype=L.half_dtype())
         else:
             out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
-        timed = self.timing is not None and (self.x3 or cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256))
+        timed = self.timing is not None and (self.x3 or self.w2 or cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256))
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         # every XCD computes ONE cout half of the composed conv (its L2 then holds 1.65 instead of 3.3 MB of weights): fabric-side reads
         # 1 022 -> 831 MB per launch (profiles/r04_pmc_traffic*.json), time unchanged (2.166 vs 2.161 ms; end to end 941-943 either way)
         xcd = L.CONV_XCD_SPLIT_N if (not self.x3 and os.environ.get("VNQA_STEM_XCD_SPLIT", "1") == "1") else 0
-        y = K.conv2d_igemm(xc, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
-                           tile=cp["tile"], border_sub=ring, x3_out=x3o, desc_flags=xcd)
+        w2 = self.w2 and K.x3_mode() == "w2"
+        y = K.conv2d_igemm(xc, cp["wt32"] if w2 else cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
+                           tile=L.TILE_256x256 if w2 else cp["tile"], border_sub=ring, x3_out=x3o, desc_flags=0 if w2 else xcd)
         if timed:
             ev1.record()
             self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25,
                                 "x3 product (split + conv_igemm_kernel raw + post)" if self.x3 else
+                                "conv_igemm_kernel<..., TAG 4> (two products, x read twice along K)" if self.w2 else
                                 ("conv_ps_kernel" if cp["tile"] == L.TILE_STEM_PS_224x256 else "conv_igemm_kernel")))
         return y
 
@@ -314,12 +320,18 @@ class FrozenStem(object):
             post = ly["post"]
             tile = ly["tile"]
             timed = self.timing is not None and (tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256) or
-                                                 (self.x3 and ly["c_out_pad"] >= 256))      # (C_out = 512 layers, whichever kernel serves them)
+                                                 ((self.x3 or self.w2) and ly["c_out_pad"] >= 256))      # (C_out = 512 layers, whichever kernel serves them)
             kname = "conv_igemm_kernel" if not self.x3 else "x3 product (split + conv_igemm_kernel raw + post)"
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            if "wt_rows" in ly and K.conv2d_wreg_supported(x, ly["wt_rows"], pool2=ly["pool"], y_halo=yh):
+            if self.w2 and "wt32" in ly and ly.get("cdt") is None and K.x3_mode() == "w2":
+                # two products on the igemm's wrap variant: 512 x 128 tiles for the C_out = 128 layers, 256 x 256 for C_out = 512
+                kname = "conv_igemm_kernel<..., TAG 4> (two products, x read twice along K)"
+                x = K.conv2d_igemm(x, ly["wt32"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
+                                   post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+                                   out=out, tile=15 if ly["c_out_pad"] == 128 else L.TILE_AUTO, y_halo=yh)
+            elif "wt_rows" in ly and K.conv2d_wreg_supported(x, ly["wt_rows"], pool2=ly["pool"], y_halo=yh):
                 x = K.conv2d_wreg(x, ly["wt_rows"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                   post_scale=post[0] if post else None, post_shift=post[1] if post else None,
                                   out=out, y_halo=yh, reserve_cus=self.reserve_cus)
@@ -357,8 +369,9 @@ class FrozenStem(object):
         `slot` selects one of several OUTPUT buffers (the intermediates are shared), so that the
         features of step i stay alive for its backward while step i+1's stem already runs."""
         assert self.vgg is not None and self.objdet is not None
-        if self.x3 and K._F32_CONV_MODE[0] != "x3":
-            with K.f32_conv_mode("x3"):
+        mode = "x3" if self.x3 else ("w2" if self.w2 else None)
+        if mode is not None and K._F32_CONV_MODE[0] != mode:
+            with K.f32_conv_mode(mode):
                 return self.forward_clip(clip, img_of, n_img, slot)
         B, _, H, W, T = clip.shape
         ly = self.layers_vgg[0]
