@@ -269,6 +269,10 @@ def fp16_leg(args, precision="fp16"):
                 "fp16-half products (x_hi w_hi + x_lo w_hi + x_hi w_lo, fp32 accumulate; two products where the input is kept as one "
                 "rounded fp16 tensor: the four heaviest stem layers, VNQA_X3_ROUND) on the fp16 matrix cores, gradient operands scaled by "
                 "a device-chosen power of two; %d timed steps, child process") % d["steps"]
+        if precision == "fp16w":
+            what = ("bench.py --precision fp16w: fp16 storage (the fp16 precision's kernels, epilogues and backward), every FORWARD conv / GEMM after "
+                    "the fused conv1 as two fp16 MFMA products x w_hi + x w_lo (split weights; the activation is read twice along K by the "
+                    "implicit GEMM, no copy): the weight roundings are gone, the activation roundings stay; %d timed steps, child process") % d["steps"]
         key = precision + "_logits_rel_err"
         return {"what": what, "precision": precision,
                 # the precision's own full line: the same fields the top-level line carries, measured the same way
@@ -961,6 +965,8 @@ def main():
             out["fp16_mode"] = fp16_leg(args)
             # the mode that meets north star's 1e-3 logits tolerance on all parity batches, with its own value / roofline
             out["tolerance_mode"] = fp16_leg(args, "fp16x")
+            # ... and the fastest precision that stays within 1e-3 on these three batches (thin margin on the worst one: not the robust choice)
+            out["fp16w_mode"] = fp16_leg(args, "fp16w")
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
         print(json.dumps(out), flush=True)
