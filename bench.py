@@ -616,6 +616,8 @@ def main():
                     "run its backward kernels on collapsed gradients")
     ap.add_argument("--mode", default="train", choices=["train", "eval"], help="eval: time the INFERENCE path (Trainer.eval_step: "
                     "val_epoch / test of the reference, forward only) instead of the training step; never the headline metric")
+    ap.add_argument("--no-eval-leg", action="store_true", help="skip the inference path's region (`eval_mode` block) after the training "
+                    "regions — for kernel traces of the training step alone")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-fp32 parity block (adds ~10 s)")
     ap.add_argument("--parity-only", action="store_true", help="print only the parity block of --precision (no timing)")
@@ -762,7 +764,7 @@ def main():
 
     # the inference path's throughput next to the training headline (same protocol, same resident minibatches, one region)
     eval_mode = None
-    if args.mode == "train" and world == 1 and not args.h2d and args.model != "mac":
+    if args.mode == "train" and world == 1 and not args.h2d and args.model != "mac" and not args.no_eval_leg:
         train_step = run_step
 
         def run_step():       # noqa: F811

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash tools/refresh_profiles.sh'): regenerates everything under profiles/ for round $1
 # (default 1) from the current build and leaves copies in gpurun_out/ for the merge back.  ~6 minutes.
 #   bench.py default / --no-overlap / layer-by-layer stem, rocprofv3 kernel trace of the bench, two PMC passes.
-R=${1:-3}; TAG=$(printf "r%02d" $R)
+R=${1:-4}; TAG=$(printf "r%02d" $R)
 ROOT=$PWD; export PYTHONPATH=$ROOT
 mkdir -p gpurun_out profiles
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/bench.err
@@ -10,7 +10,7 @@ python bench.py --no-overlap --no-cpu-baseline --no-parity > gpurun_out/${TAG}_b
 VNQA_STEM_COMPOSE=0 python bench.py --no-cpu-baseline --no-parity > gpurun_out/${TAG}_bench_layer_by_layer_stem.json 2>> gpurun_out/bench.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof /tmp/pmcF /tmp/pmcW
-rocprofv3 --kernel-trace --stats -d /tmp/prof -- python3 $ROOT/bench.py --steps 20 --warmup 5 --repeats 1 --no-parity --no-cpu-baseline > $ROOT/gpurun_out/prof_bench.json 2> $ROOT/gpurun_out/prof_bench.err
+rocprofv3 --kernel-trace --stats -d /tmp/prof -- python3 $ROOT/bench.py --steps 20 --warmup 5 --repeats 1 --no-parity --no-cpu-baseline --no-eval-leg > $ROOT/gpurun_out/prof_bench.json 2> $ROOT/gpurun_out/prof_bench.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -- python3 $ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-parity --no-cpu-baseline --no-overlap > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -- python3 $ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-parity --no-cpu-baseline --no-overlap > /dev/null 2>&1
 rm -rf /tmp/pmcM /tmp/pmcS
