@@ -145,12 +145,13 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
  *                         rows x c in the library's 16-bit format with row stride dst_ld.  Channel-concatenated operand
  *                         [hi | lo | hi]: (base, base + c, base + 2c), dst_ld = 3c.
  *   vnqa_conv2d_igemm_raw : the 16-bit conv's raw fp32 accumulators [n_img*h*w][c_out] (d: dtype VNQA_BF16, c_in = the
- *                         concatenated channel count, relu = pool2 = flags = 0, an implicit-GEMM tile id or VNQA_TILE_AUTO).
+ *                         concatenated channel count, relu = pool2 = 0, flags = 0 or VNQA_CONV_X_WRAP2 (a plain 16-bit input read
+ *                         twice against [w_hi | w_lo]), an implicit-GEMM tile id or VNQA_TILE_AUTO).
  *   vnqa_x3_post        : y = post( pool2?( relu?( raw - border_sub + bias ) ) ) in fp32 -> padded NHWC fp32 interior
  *                         (the epilogue contract of vnqa_conv2d_igemm_fwd_ex; border_sub fp32 [n][2w + 2(h-2)][c_out]);
  *                         out_x3 != 0: y is 16-bit [..][c_y >= 3 c_out] and receives the halves [hi | lo | hi] instead — the
- *                         next x3 product's operand, no fp32 round trip between consecutive layers; out_x3 == 2: [hi | hi]
- *                         (c_y >= 2 c_out) for a two-product consumer — this output then carries ONE fp16 rounding.
+ *                         next x3 product's operand, no fp32 round trip between consecutive layers; out_x3 == 2: the plain 16-bit
+ *                         tensor (one fp16 rounding) for a two-product consumer, which reads it twice (VNQA_CONV_X_WRAP2).
  *   vnqa_gemm_nt with dtype = VNQA_BF16 | VNQA_GEMM_OUT_F32 : 16-bit operands, fp32 `out` (workspace >= m*n*4 bytes required).
  */
 int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld, int64_t dst_ld,

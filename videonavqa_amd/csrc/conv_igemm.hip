@@ -1545,8 +1545,9 @@ extern "C" int vnqa_conv2d_igemm_raw(const vnqa_conv_desc* d, const void* x, con
   ConvArgs a;
   const int rc = fill_conv_args(d, x, wt, nullptr, nullptr, nullptr, nullptr, raw, a);
   if (rc != VNQA_OK) return rc;
-  VNQA_CHECK_ARG(d->dtype == VNQA_BF16 && !d->pool2 && d->depth == 0 && !d->wt_tiled && d->relu == 0 && d->flags == 0,
-                 "conv2d_igemm_raw: a plain 16-bit 2-D conv (no pooling / activation / pre-tiled weights / flags)");
+  VNQA_CHECK_ARG(d->dtype == VNQA_BF16 && !d->pool2 && d->depth == 0 && !d->wt_tiled && d->relu == 0 &&
+                     (d->flags & ~VNQA_CONV_X_WRAP2) == 0,
+                 "conv2d_igemm_raw: a plain 16-bit 2-D conv (no pooling / activation / pre-tiled weights; flags: VNQA_CONV_X_WRAP2 only)");
   VNQA_CHECK_ARG(d->c_out % 4 == 0 && ((uintptr_t)raw & 15) == 0, "conv2d_igemm_raw: c_out %% 4 == 0 and a 16-byte aligned output");
   VNQA_CHECK_ARG(d->tile != VNQA_TILE_PATCH_224x256 && d->tile != VNQA_TILE_STEM_PATCH_224x256 && d->tile != VNQA_TILE_PS_224x256 &&
                      d->tile != VNQA_TILE_STEM_PS_224x256,

@@ -121,8 +121,7 @@ __global__ void __launch_bounds__(256) x3_post_kernel(const PostArgs p) {
       l.y = pack2_h16(r2 == r2 ? r2 : 0.f, r3 == r3 ? r3 : 0.f);
       unsigned short* o = p.y16 + pix + c;
       *(uint2*)o = h;
-      if (p.two) {                            // [hi | hi]: the operand of a TWO-product consumer (this output is rounded to fp16)
-        *(uint2*)(o + p.c_out) = h;
+      if (p.two) {                            // plain fp16 output: the consumer reads it twice along K (two products, VNQA_CONV_X_WRAP2)
       } else {
         *(uint2*)(o + p.c_out) = l;
         *(uint2*)(o + 2 * p.c_out) = h;
@@ -155,9 +154,8 @@ extern "C" int vnqa_x3_post(const float* raw, const float* bias, const float* po
                             const float* border_sub, void* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y,
                             int32_t y_halo, int32_t relu, int32_t pool2, int32_t out_x3, const float* raw_scale, void* stream) {
   VNQA_CHECK_ARG(raw && y, "x3_post: null pointer");
-  VNQA_CHECK_ARG(out_x3 >= 0 && out_x3 <= 2, "x3_post: out_x3 must be 0 (fp32), 1 ([hi | lo | hi]) or 2 ([hi | hi])");
-  VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0 && c_out > 0 && c_out % 4 == 0 && c_y >= (out_x3 == 1 ? 3 : (out_x3 == 2 ? 2 : 1)) * c_out &&
-                     c_y % 4 == 0,
+  VNQA_CHECK_ARG(out_x3 >= 0 && out_x3 <= 2, "x3_post: out_x3 must be 0 (fp32), 1 (16-bit [hi | lo | hi]) or 2 (plain 16-bit)");
+  VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0 && c_out > 0 && c_out % 4 == 0 && c_y >= (out_x3 == 1 ? 3 : 1) * c_out && c_y % 4 == 0,
                  "x3_post: bad geometry n=%d h=%d w=%d c_out=%d c_y=%d", n_img, h, w, c_out, c_y);
   VNQA_CHECK_ARG(y_halo >= 0 && y_halo <= 2 && (relu == 0 || relu == 1), "x3_post: y_halo in 0..2, relu in 0..1");
   VNQA_CHECK_ARG(!pool2 || (h % 2 == 0 && w % 2 == 0), "x3_post: pool2 needs even h, w");

@@ -201,14 +201,14 @@ def x3_weight2(wt):
 def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub, x3_out=False):
     """One conv as an x3 product.  x: fp32 [.., C] (split here), or 16-bit [.., 3C] already in the [hi | lo | hi] operand layout
     (the previous layer's x3_out), or 16-bit [.., C] (a plain 16-bit activation: [x | x] against [w_hi | w_lo], two products).
-    Output: fp32 padded NHWC, or with x3_out = 1 the next layer's 16-bit operand [.., 3 c_out] = [hi | lo | hi], x3_out = 2 its
-    two-product operand [.., 2 c_out] = [hi | hi] (the output rounded to fp16 once)."""
+    Output: fp32 padded NHWC, or with x3_out = 1 the next layer's 16-bit operand [.., 3 c_out] = [hi | lo | hi], x3_out = 2 the
+    plain 16-bit tensor [.., c_out] (the output rounded to fp16 once; its consumer runs two products)."""
     N, Hp, Wp, Cx = x.shape
     H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
     c_out, taps, Cin = wt.shape
     assert wt.dtype == torch.float32 and x.is_contiguous()
     half = L.half_dtype()
-    inv = None
+    inv, wrap = None, 0
     if x.dtype == torch.float32:
         assert Cx == Cin
         k = 3 * Cin
@@ -222,21 +222,16 @@ def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo,
         assert x.dtype == half
         k, xin = 3 * Cin, x
         w3 = x3_weight(wt).view(c_out, taps, k)
-    elif Cx == 2 * Cin:          # [x | x] written by the producer (x3_out=2): two products, nothing to prepare
-        assert x.dtype == half
+    else:                        # a plain 16-bit activation: two products, read twice along K by the kernel itself (no copy)
+        assert x.dtype == half and Cx == Cin and Cin % 64 == 0
         k, xin = 2 * Cin, x
         w3 = x3_weight2(wt).view(c_out, taps, k)
-    else:
-        assert x.dtype == half and Cx == Cin
-        k = 2 * Cin
-        w3 = x3_weight2(wt).view(c_out, taps, k)
-        xin = _x3_buffer("x3in", N * Hp * Wp * k, half, x.device).view(N, Hp, Wp, k)
-        torch.cat([x, x], dim=-1, out=xin)
+        wrap = L.CONV_X_WRAP2
     raw = _x3_buffer("raw", N * H * W * c_out, torch.float32, x.device)
-    d = L.ConvDesc(L.BF16, N, H, W, k, c_out, c_out, taps, x_halo, 0, 0, 0, L.TILE_AUTO, 0, 0, 0)      # (the 16-bit product picks its own tile)
+    d = L.ConvDesc(L.BF16, N, H, W, k, c_out, c_out, taps, x_halo, 0, 0, 0, L.TILE_AUTO, 0, 0, wrap)      # (the 16-bit product picks its own tile)
     L.check(L.lib().vnqa_conv2d_igemm_raw(ctypes.byref(d), L.ptr(xin), L.ptr(w3), L.ptr(raw), L.stream()), "vnqa_conv2d_igemm_raw")
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
-    odt, oc = (half, (3 if int(x3_out) == 1 else 2) * c_out) if x3_out else (torch.float32, c_out)
+    odt, oc = (half, (3 if int(x3_out) == 1 else 1) * c_out) if x3_out else (torch.float32, c_out)
     if out is None:
         shape = (N, Ho + 2 * y_halo, Wo + 2 * y_halo, oc)
         out = empty_padded(shape, odt, x.device) if y_halo == 1 else torch.zeros(shape, dtype=odt, device=x.device)
@@ -262,14 +257,18 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
                  x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False, desc_flags=0):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
     (x3_out: only inside f32_conv_mode("x3") — the output as the next x3 product's 16-bit operand, see _conv2d_x3.)"""
-    if _F32_CONV_MODE[0] in ("x3", "x3g") and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
-            relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 and x.shape[-1] % 64 == 0:
+    x3m = _F32_CONV_MODE[0] in ("x3", "x3g") and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
+        relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 and x.shape[-1] % 64 == 0
+    # inside the x3 mode a layer with a plain 16-bit input AND a rounded (plain 16-bit) output is exactly the two-product conv of
+    # precision 'fp16w': one launch of the wrap variant with its fused epilogue instead of raw sums + a post pass
+    fused_w2 = x3m and int(x3_out) == 2 and L.is_half(x.dtype) and x.shape[-1] == wt.shape[2]
+    if x3m and not fused_w2:
         return _conv2d_x3(x, wt, bias, bool(relu), pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub, x3_out)
-    assert not x3_out, "x3_out needs f32_conv_mode('x3') and fp32 K-major weights"
+    assert fused_w2 or not x3_out, "x3_out needs f32_conv_mode('x3') and fp32 K-major weights"
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
     tiled = isinstance(wt, TiledWeight)
-    w2 = w2_active(x) and not tiled and wt.dtype == torch.float32
+    w2 = (w2_active(x) or fused_w2) and not tiled and wt.dtype == torch.float32
     if w2:          # two products: x read twice along K against [w_hi | w_lo] (VNQA_CONV_X_WRAP2)
         assert wt.shape[2] == Cin and Cin % 64 == 0
         wt = x3_weight2(wt)

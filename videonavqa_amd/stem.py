@@ -269,7 +269,7 @@ class FrozenStem(object):
         ho, wo = H // 2, W // 2
         x3o = (2 if "od2" in self.x3_round else 1) if self.x3 else 0
         if self.x3:
-            out = self._buf(key + (ho, wo, "x3"), (n, ho + 2, wo + 2, (4 - x3o) * cp["c_out_pad"]), dtype=L.half_dtype())
+            out = self._buf(key + (ho, wo, "x3", x3o), (n, ho + 2, wo + 2, (3 if x3o == 1 else 1) * cp["c_out_pad"]), dtype=L.half_dtype())
         else:
             out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
         timed = self.timing is not None and (self.x3 or self.w2 or cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256))
@@ -314,7 +314,8 @@ class FrozenStem(object):
             if x3_out:
                 nxt = ("%s%d" % (tag, i + 1)) if not last else ("composed" if (tag == "vgg" and self.composed is not None) else "od0")
                 x3_out = 2 if nxt in self.x3_round else 1
-                out = self._buf(key + ("x3",), (n, ho + 2 * yh, wo + 2 * yh, (4 - x3_out) * ly["c_out_pad"]), dtype=L.half_dtype())
+                out = self._buf(key + ("x3", x3_out), (n, ho + 2 * yh, wo + 2 * yh, (3 if x3_out == 1 else 1) * ly["c_out_pad"]),
+                                dtype=L.half_dtype())
             else:
                 out = self._buf(key, (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
             post = ly["post"]
@@ -346,15 +347,23 @@ class FrozenStem(object):
                                  post_scale=post[0] if post else None, post_shift=post[1] if post else None, out=out,
                                  reserve_cus=self.reserve_cus)
             else:
+                # (x3 mode: a plain 16-bit input with a rounded output runs as ONE fused two-product launch, no raw sums)
+                fused_w2 = x3_out == 2 and L.is_half(x.dtype) and x.shape[-1] == ly["wt"].shape[2]
                 x = K.conv2d_igemm(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                    post_scale=post[0] if post else None, post_shift=post[1] if post else None,
                                    out=out, tile=tile, y_halo=yh, x3_out=x3_out)
                 if x3_out and ly.get("dual"):
-                    # the same raw sums once more as fp32 (still in the x3 scratch of this stream): the composed pair's border
-                    # correction runs on the exact-f32 GEMMs
-                    self._x3_side = K.x3_post_again(self._buf(key + ("f32side",), (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"])),
-                                                    n, h, w, ly["c_out_pad"], yh, bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
-                                                    post_scale=post[0] if post else None, post_shift=post[1] if post else None)
+                    # the composed pair's border correction runs on the exact-f32 GEMMs: this layer's output once more as fp32 —
+                    # the rounded tensor itself when it is what the 5x5 conv reads, else the raw sums (still in this stream's
+                    # x3 scratch) finished a second time
+                    side = self._buf(key + ("f32side",), (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
+                    if x3_out == 2:
+                        side.copy_(x)
+                        self._x3_side = side
+                    else:
+                        self._x3_side = K.x3_post_again(side, n, h, w, ly["c_out_pad"], yh, bias=ly["bias"], relu=ly["relu"],
+                                                        pool2=ly["pool"], post_scale=post[0] if post else None,
+                                                        post_shift=post[1] if post else None)
             if timed:
                 ev1.record()
                 self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9, kname))
