@@ -273,6 +273,8 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
         assert wt.shape[2] == Cin and Cin % 64 == 0
         wt = x3_weight2(wt)
         desc_flags = int(desc_flags) | L.CONV_X_WRAP2
+        if border_sub is not None and border_sub.dtype != x.dtype:       # (the kernel subtracts it in the output's element type)
+            border_sub = border_sub.to(x.dtype).contiguous()
         if tile not in (L.TILE_AUTO, L.TILE_256x256, L.TILE_256x128, L.TILE_256x64, L.TILE_STEM_256x256, 15, 17):
             tile = L.TILE_AUTO
     if tiled:
