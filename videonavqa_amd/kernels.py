@@ -261,7 +261,8 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
         relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 and x.shape[-1] % 64 == 0
     # inside the x3 mode a layer with a plain 16-bit input AND a rounded (plain 16-bit) output is exactly the two-product conv of
     # precision 'fp16w': one launch of the wrap variant with its fused epilogue instead of raw sums + a post pass
-    fused_w2 = x3m and int(x3_out) == 2 and L.is_half(x.dtype) and x.shape[-1] == wt.shape[2]
+    # (not with a border correction: the composed pair keeps its fp32 correction term on the raw-sums path)
+    fused_w2 = x3m and int(x3_out) == 2 and L.is_half(x.dtype) and x.shape[-1] == wt.shape[2] and border_sub is None
     if x3m and not fused_w2:
         return _conv2d_x3(x, wt, bias, bool(relu), pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub, x3_out)
     assert fused_w2 or not x3_out, "x3_out needs f32_conv_mode('x3') and fp32 K-major weights"
