@@ -102,7 +102,7 @@ class FrozenStem(object):
             # is kept as ONE rounded fp16 tensor: two products instead of three on that layer (a third of its matrix work) for one
             # more fp16 rounding.  The mode's speed / tolerance curve at the headline size, worst of the three parity batches
             # (profiles/r04_fp16x_curve.txt): PLAIN_FIRST=0 ~1e-5 at 245 clips/s; n = 0: 0.48e-3 at 277; 4: 0.68e-3 at 362 (those layers run as fused two-product launches)
-            self.x3_round = set(("composed", "od3", "od2", "vgg2")[:int(os.environ.get("VNQA_X3_ROUND", "4"))]) if self.x3 else set()
+            self.x3_round = set(("composed", "od3", "od2", "vgg2", "od4", "od5")[:int(os.environ.get("VNQA_X3_ROUND", "4"))]) if self.x3 else set()
             self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=L.half_dtype() if (self.x3_plain_first or self.w2) else None),
                                self._layer(f["5"], relu=True, pool=False),
                                self._layer(f["7"], relu=True, pool=True)]
