@@ -41,3 +41,42 @@ def test_gpus_n_without_launcher_refuses_when_gpus_are_missing():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "only 0 GPU(s) visible" in r.stderr and "{" not in r.stdout
+
+
+def test_cpu_child_dumps_the_oracle_logits_of_a_reproducible_workload(tmp_path):
+    """Round 4: the CPU leg writes the oracle's forward logits of its minibatch; the GPU parent regenerates the SAME
+    weights and minibatch from the seed (bench.oracle_workload, no oracle import) to run the HIP path on them."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench as Bn
+    out = str(tmp_path / "logits.pt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline-only", "--cpu-batch", "2", "--frames", "3",
+                        "--height", "32", "--width", "48", "--cpu-steps", "1", "--cpu-logits-out", out], env=ENV,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    d = torch.load(out)
+    assert d["logits"].shape == (2, 70) and d["batch"] == 2 and sorted(d["perm"].tolist()) == [0, 1]
+    assert bool(torch.isfinite(d["logits"]).all())
+    a = argparse.Namespace(height=32, width=48, frames=3, channels=512, blocks=1)
+    w1 = Bn.oracle_workload(a, 2)
+    w2 = Bn.oracle_workload(a, 2)
+    for x, y in zip(w1[:3], w2[:3]):                       # the three weight dictionaries, bit for bit
+        assert x.keys() == y.keys() and all(torch.equal(x[k], y[k]) for k in x)
+    assert all(torch.equal(p, q) for p, q in zip(w1[3], w2[3]))
+    assert w1[2]["fc_embed_attn.weight"].shape == (128, (32 // 16) * (48 // 16) * 512)
+    # the oracle run on the regenerated workload reproduces the child's logits (same process-independent arithmetic)
+    from oracle import vnqa_oracle as O
+    W_vgg, W_od, W, (clip, q, v_lens, q_lens, y) = w1
+    with torch.no_grad():
+        feats = O.stem_forward(clip, W_vgg, W_od)
+        v2, q2, vl2, ql2, _, perm = O.sort_batch(feats, q, v_lens, q_lens, y)
+        ref = O.film_attn_forward({k: v.clone() for k, v in W.items()}, v2, q2, vl2, ql2, training=True)
+    assert torch.equal(perm, d["perm"]) and float((ref - d["logits"]).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+def test_bench_parser_knows_the_round4_modes():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], env=ENV, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    for token in ("--mode", "fp16x", "fp16w", "--clip-dtype", "--no-eval-leg"):
+        assert token in r.stdout, token
