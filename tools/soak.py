@@ -16,7 +16,7 @@ import bench as B          # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp16w", "fp16x", "fp32"])
     ap.add_argument("--no-prefetch", action="store_true", help="run each step's stem inline instead of under the previous trunk")
     ap.add_argument("--every", type=int, default=25, help="print every N steps")
     ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop", "mac"])
@@ -25,6 +25,9 @@ def main():
                               model=a.model, tail_channels=0)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if a.precision in ("fp16", "fp16w", "fp16x"):
+        from videonavqa_amd import _lib as L
+        L.set_half("f16")
     from videonavqa_amd.train import Trainer
     model, stem, _, _ = B.build(args, dev)
     tr = Trainer(model, stem, lr=1e-4)
@@ -54,8 +57,11 @@ def main():
             rsv = torch.cuda.memory_reserved() / 2**30
             if peak0 is None:
                 peak0 = rsv
-            print("step %4d  loss %.4f  allocated %.2f GiB  reserved %.2f GiB  %.1f clips/s" %
-                  (i + 1, losses[-1], mem, rsv, 8 * (i + 1) / (time.time() - t0)), flush=True)
+            ls = tr.loss_scaler
+            print("step %4d  loss %.4f  allocated %.2f GiB  reserved %.2f GiB  %.1f clips/s%s" %
+                  (i + 1, losses[-1], mem, rsv, 8 * (i + 1) / (time.time() - t0),
+                   "" if ls is None else "  loss scale 2^%d, %d step(s) skipped, Adam step %d" % (
+                       round(__import__("math").log2(ls.scale)), ls.skipped_steps, tr.fp.step_count)), flush=True)
             assert losses[-1] == losses[-1] and abs(losses[-1]) < 1e4, "non-finite loss"
     rsv = torch.cuda.memory_reserved() / 2**30
     assert rsv < peak0 * 1.5 + 1.0, "memory footprint grew: %.2f -> %.2f GiB" % (peak0, rsv)
