@@ -126,3 +126,67 @@ def test_bench_gpus2_rccl_two_gpus():
     print("dp2 clips/s: reserve 0 -> %.1f, reserve 8 -> %.1f; exposed comm %.3f / %.3f ms"
           % (base["value"], resv["value"], base["comm"]["exposed_comm_ms_per_step"], resv["comm"]["exposed_comm_ms_per_step"]))
     assert resv["n_gpus"] == 2
+
+
+def _val_worker(rank, world, port, out_dir):
+    """val_epoch on `world` gloo ranks sharing cuda:0: every rank evaluates its share of the split (ShardedBatchSampler), the
+    shards are merged by one gather; the returned average loss and the merged predictions must equal the single-process run's."""
+    import io
+    import contextlib
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch.nn as nn
+    from torch.utils.data import DataLoader
+    from videonavqa_amd.eval import q_and_v_eval as E
+    from videonavqa_amd.eval.dataset import SyntheticVNQADataset
+    from videonavqa_amd.models import FiLMAttnPretrainedStem, ObjDetectCNN
+    from videonavqa_amd.stem import FrozenStem, VGGFront
+    from videonavqa_amd.train import Trainer
+    torch.manual_seed(0)
+    B, H, W, T = 2, 64, 96, 35
+    vgg, od = VGGFront("fp32"), ObjDetectCNN(5, 64, 8, 0, True, True, precision="fp32")
+    with torch.no_grad():
+        for conv in vgg.features.values():
+            nn.init.kaiming_uniform_(conv.weight, a=1.0)
+    model = FiLMAttnPretrainedStem(B, 16, 70, num_input_channels=64, num_res_block_channels=64, hidden_size=16, at_hidden_size=16,
+                                   max_num_frames=T, vocab_size=134, spatial_size=(H // 16) * (W // 16), precision="fp32").cuda()
+    stem = FrozenStem(vgg.cuda().eval(), od.cuda().eval(), "fp32")
+    tr = Trainer(model, stem, world_size=world, rank=rank, feature_channels=64, collectives=False)
+    data = SyntheticVNQADataset(11, H, W, seed=99)                        # 5 full batches of 2 + one short batch (dropped)
+    loader = DataLoader(data, num_workers=0, batch_sampler=E.ShardedBatchSampler(len(data), B, rank, world))
+    args = E.build_parser().parse_args(["--model", "film_attn_pt", "--batch_size", str(B), "--num_classes", "70"])
+    captured = {}
+    real = E.gather_eval_shards
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        captured["merged"] = out
+        return out
+    E.gather_eval_shards = spy
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        avg = E.val_epoch(args, tr, loader, torch.device("cuda", 0), rank, world)
+    (y_t, y_p), loss, n = captured["merged"]
+    torch.save({"avg": avg, "y_t": y_t, "y_p": y_p, "loss": loss, "n": n, "own": len(loader), "printed": buf.getvalue()},
+               os.path.join(out_dir, "val_w%d_r%d.pt" % (world, rank)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_sharded_validation_on_two_ranks_equals_the_single_process_run(tmp_path):
+    import numpy as np
+    port = 29900 + (os.getpid() % 1000)
+    _val_worker(0, 1, port, str(tmp_path))                                 # the single-process reference, in this process
+    mp.spawn(_val_worker, args=(2, port + 1, str(tmp_path)), nprocs=2, join=True)
+    one = torch.load(tmp_path / "val_w1_r0.pt", weights_only=False)
+    assert one["n"] == 10 and one["own"] == 5 and "Validation:" in one["printed"]
+    r0, r1 = (torch.load(tmp_path / ("val_w2_r%d.pt" % r), weights_only=False) for r in (0, 1))
+    assert (r0["own"], r1["own"]) == (3, 2)                                # batches 0, 2, 4 / 1, 3: nobody evaluates the whole split
+    for r in (r0, r1):
+        assert r["n"] == 10 and np.array_equal(r["y_t"], one["y_t"]) and np.array_equal(r["y_p"], one["y_p"])
+        assert abs(r["avg"] - one["avg"]) < 1e-5 * max(1.0, abs(one["avg"]))
+    assert "Validation:" in r0["printed"] and "Validation:" not in r1["printed"]      # rank 0 prints the epoch line
