@@ -118,7 +118,8 @@ def fwd_pack_dtype(x):
 
 def grad_split_scale(t):
     """(scale, 1 / scale) as 0-dim device tensors: the power of two that lifts max |t| into [2^12, 2^13) (1 for an all-zero tensor)."""
-    amax = t.abs().amax().float()
+    lo, hi = torch.aminmax(t)                  # one pass, no |t| temporary (these tensors are 50 - 150 MB)
+    amax = torch.maximum(hi, -lo).float()
     e = torch.clamp(torch.floor(torch.log2(torch.clamp(amax, min=1e-35))), min=-100.0)     # (scale stays a finite fp32 power of two)
     scale = torch.where(amax > 0, torch.exp2(12.0 - e), torch.ones_like(amax))
     return scale, 1.0 / scale
@@ -781,8 +782,10 @@ def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None):
                                           L.BF16, L.stream()), "vnqa_conv2d_wgrad(x3)")
         dwt.mul_(inv)
         dbias = None
-        if want_bias:
-            dbias = colsum(dy.view(N * Hp * Wp, Cout), out=dbias_out if (dbias_out is not None and dbias_out.numel() == Cout) else None)
+        if want_bias:       # (a plain reduction over the 50 - 150 MB gradient: vnqa_colsum is laid out for the small fp32 matrices of the tails)
+            dbias = dbias_out if (dbias_out is not None and dbias_out.numel() == Cout) else \
+                torch.empty((Cout,), dtype=torch.float32, device=x.device)
+            torch.sum(dy.view(N * Hp * Wp, Cout), dim=0, out=dbias)
         return dwt, dbias
     ws = workspace(L.lib().vnqa_conv2d_wgrad_workspace(N, h, w, Cin, Cout, taps), x.device)
     dwt = torch.empty((Cout, taps, Cin), dtype=torch.float32, device=x.device)
