@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 409
+#define VNQA_ABI_VERSION 410
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -163,7 +163,9 @@ int vnqa_x3_post(const float* raw, const float* bias, const float* post_scale, c
                  int32_t pool2, int32_t out_x3, const float* raw_scale, void* stream);   /* raw_scale: optional DEVICE scalar
                                                           * multiplied into the raw sums first (1 / the operand's split scale) */
 #define VNQA_GEMM_OUT_F32 0x200
-#define VNQA_GEMM_X_WRAP2 0x400   /* vnqa_gemm_nt: a has k / 2 physical columns (row stride k / 2), read twice against b = [b_hi | b_lo] */
+#define VNQA_GEMM_X_WRAP2 0x400   /* vnqa_gemm_nt: a has k / 2 physical columns (row stride k / 2), read twice against b = [b_hi | b_lo];
+                                   * also accepted in the dtype of vnqa_conv2d_ring_fwd / vnqa_ring_edge_conv_fwd (c_in / c_mid = the contraction's
+                                   * channel count, twice the tensor's) */
 
 /* Fused trunk epilogues (BIAS_RELU_BNSTATS / BIAS_FILM_RELU_RES) — the same conv with the elementwise op
  * that FOLLOWS it in the reference applied while the output tile is still in LDS:

@@ -1067,7 +1067,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
     return VNQA_ERR_UNSUPPORTED;
   }
   if (a.x_wrap2) {          // two-product form: x read twice along K (TAG 4 instantiations of the plain tiles)
-    if (dtype != VNQA_BF16 || a.epi != VNQA_EPI_NONE || a.wt_tiled || a.D != 0 || a.ring_h != 0 || a.group_tiles != 0 || a.Cin % 128 != 0) {
+    if (dtype != VNQA_BF16 || a.epi != VNQA_EPI_NONE || a.wt_tiled || a.D != 0 || a.group_tiles != 0 || a.Cin % 128 != 0) {
       vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_X_WRAP2 needs a plain 16-bit 2-D conv / GEMM with c_in %% 128 == 0 and K-major weights");
       return VNQA_ERR_UNSUPPORTED;
     }
@@ -1460,15 +1460,19 @@ extern "C" int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, 
 // back per 280-frame stem pass).  x: [n_img][h+4][w+4][c_in]; wt: [c_out][9][c_in]; y1: [n_img][R][c_out], R = 2(w+2) + 2h.
 extern "C" int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* bias, void* y1, int32_t n_img, int32_t h,
                                     int32_t w, int32_t c_in, int32_t c_out, int32_t padded, int32_t dtype, void* stream) {
+  const bool wrap2 = (dtype & VNQA_GEMM_X_WRAP2) != 0;      // x has c_in / 2 physical channels, read twice against wt = [w_hi | w_lo]
+  dtype &= ~VNQA_GEMM_X_WRAP2;
   VNQA_CHECK_ARG(x && wt && y1 && n_img > 0 && h >= 2 && w >= 2, "conv2d_ring_fwd: bad arguments");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv2d_ring_fwd: bad dtype %d", dtype);
+  VNQA_CHECK_ARG(!wrap2 || dtype == VNQA_BF16, "conv2d_ring_fwd: VNQA_GEMM_X_WRAP2 needs the 16-bit format");
   const int bk = dtype == VNQA_BF16 ? 64 : 32;
   VNQA_CHECK_ARG(c_in > 0 && c_in % bk == 0 && c_out > 0 && c_out % 8 == 0, "conv2d_ring_fwd: c_in %% %d, c_out %% 8", bk);
   const int R = 2 * (w + 2) + 2 * h;
   VNQA_CHECK_ARG((long long)n_img * R < (1ll << 31), "conv2d_ring_fwd: too many ring positions");
   vnqa_conv_desc d;
   d.dtype = dtype; d.n_img = n_img; d.h = 1; d.w = R; d.c_in = c_in; d.c_out = c_out; d.c_y = c_out; d.taps = 9;
-  d.x_halo = 1; d.y_halo = 0; d.relu = 0; d.pool2 = 0; d.tile = VNQA_TILE_AUTO; d.wt_tiled = 0; d.depth = 0; d.flags = 0;
+  d.x_halo = 1; d.y_halo = 0; d.relu = 0; d.pool2 = 0; d.tile = VNQA_TILE_AUTO; d.wt_tiled = 0; d.depth = 0;
+  d.flags = wrap2 ? VNQA_CONV_X_WRAP2 : 0;
   ConvArgs a;
   const int rc = fill_conv_args(&d, x, wt, bias, nullptr, nullptr, nullptr, y1, a);
   if (rc != VNQA_OK) return rc;
@@ -1482,7 +1486,7 @@ extern "C" int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* 
   if (dtype == VNQA_BF16) {
     const long long m = (long long)n_img * R;
     const long long pad256 = (m + 255) / 256 * 256, pad128 = (m + 127) / 128 * 128;
-    tile = pad128 >= pad256 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+    tile = (pad128 >= pad256 || wrap2) ? VNQA_TILE_256x128 : VNQA_TILE_128x128;      // (the wrap variant exists on the 256-row tiles)
   }
   return conv_dispatch(a, dtype, tile, (hipStream_t)stream);
 }
@@ -1493,15 +1497,21 @@ extern "C" int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* 
 // vnqa_ring_edge_gather + vnqa_gemm_nt (no [n*len, 3*c_mid] operand).
 extern "C" int vnqa_ring_edge_conv_fwd(const void* y1p, const void* wt, void* out, int32_t n_img, int32_t h, int32_t w,
                                        int32_t c_mid, int32_t c_out, int32_t edge, int32_t dtype, void* stream) {
+  const bool wrap2 = (dtype & VNQA_GEMM_X_WRAP2) != 0;      // c_mid counts the CONTRACTION channels: y1p has c_mid / 2 of them physically
+  dtype &= ~VNQA_GEMM_X_WRAP2;
   VNQA_CHECK_ARG(y1p && wt && out && n_img > 0 && h >= 2 && w >= 2 && edge >= 0 && edge < 4, "ring_edge_conv_fwd: bad arguments");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "ring_edge_conv_fwd: bad dtype %d", dtype);
+  VNQA_CHECK_ARG(!wrap2 || (dtype == VNQA_BF16 && c_mid % 128 == 0), "ring_edge_conv_fwd: VNQA_GEMM_X_WRAP2 needs the 16-bit format, c_mid %% 128 == 0");
   const int bk = dtype == VNQA_BF16 ? 64 : 32, es = dtype == VNQA_BF16 ? 2 : 4;
   VNQA_CHECK_ARG(c_mid > 0 && c_mid % bk == 0 && c_out > 0 && c_out % 8 == 0, "ring_edge_conv_fwd: c_mid %% %d, c_out %% 8", bk);
   const int R = 2 * (w + 2) + 2 * h, Rp = R + 4;
   const int len = edge < 2 ? w : h;
   const int base = edge == 0 ? 0 : (edge == 1 ? w + 2 : (edge == 2 ? 2 * (w + 2) : 2 * (w + 2) + h + 2));
   ConvArgs a;
-  a.x = (const char*)y1p + (size_t)base * c_mid * es;
+  a.x = (const char*)y1p + (size_t)base * (wrap2 ? c_mid / 2 : c_mid) * es;
+  a.x_wrap2 = wrap2 ? 1 : 0;
+  a.xcd_split = 0;
+  a.zero_halo = 0;
   a.wt = (const char*)wt;
   a.bias = nullptr; a.post_scale = nullptr; a.post_shift = nullptr;
   a.y = (char*)out;
@@ -1516,7 +1526,7 @@ extern "C" int vnqa_ring_edge_conv_fwd(const void* y1p, const void* wt, void* ou
   int tile = VNQA_TILE_128x128;
   if (dtype == VNQA_BF16) {
     const int pad256 = (a.M + 255) / 256 * 256, pad128 = (a.M + 127) / 128 * 128;
-    tile = pad128 >= pad256 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+    tile = (pad128 >= pad256 || wrap2) ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
   }
   return conv_dispatch(a, dtype, tile, (hipStream_t)stream);
 }

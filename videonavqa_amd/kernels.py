@@ -409,13 +409,16 @@ def conv2d_ring(x, wt, bias, H, W, out_padded=None):
     n, _, _, c_in = x.shape
     c_out = wt.shape[0]
     R = 2 * (W + 2) + 2 * H
+    opt = 0
+    if w2_active(x) and wt.dtype == torch.float32:       # two products: x read twice against [w_hi | w_lo]
+        wt, c_in, opt = x3_weight2(wt), 2 * c_in, L.GEMM_X_WRAP2
     if out_padded is not None:
         assert out_padded.shape == (n, R + 4, c_out) and out_padded.dtype == x.dtype and out_padded.is_contiguous()
         y1 = out_padded
     else:
         y1 = torch.empty((n * R, c_out), dtype=x.dtype, device=x.device)
     L.check(L.lib().vnqa_conv2d_ring_fwd(L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(y1), n, H, W, c_in, c_out,
-                                         1 if out_padded is not None else 0, L.dtype_id(x.dtype), L.stream()),
+                                         1 if out_padded is not None else 0, L.dtype_id(x.dtype) | opt, L.stream()),
             "vnqa_conv2d_ring_fwd")
     return y1
 
@@ -426,9 +429,14 @@ def ring_edge_conv(y1p, wt_edge, H, W, edge):
     n, _, cm = y1p.shape
     co = wt_edge.shape[0]
     ln = W if edge < 2 else H
+    opt = 0
+    if w2_active(y1p) and wt_edge.dtype == torch.float32:
+        # two products per slot: wt_edge [co, 3 * cm] -> [co, 3, 2 cm] = per slot [w_hi | w_lo], y1p read twice
+        wt_edge = x3_weight2(wt_edge.view(co, 3, cm)).view(co, 6 * cm)
+        cm, opt = 2 * cm, L.GEMM_X_WRAP2
     out = torch.empty((n * ln, co), dtype=y1p.dtype, device=y1p.device)
     L.check(L.lib().vnqa_ring_edge_conv_fwd(L.ptr(y1p), L.ptr(wt_edge), L.ptr(out), n, H, W, cm, co, edge,
-                                            L.dtype_id(y1p.dtype), L.stream()), "vnqa_ring_edge_conv_fwd")
+                                            L.dtype_id(y1p.dtype) | opt, L.stream()), "vnqa_ring_edge_conv_fwd")
     return out
 
 

@@ -225,9 +225,19 @@ class FrozenStem(object):
             e[:co, :, :cm] = sel.permute(0, 2, 1)
             return e.view(co_pad, -1).to(dev).to(self.cdt).contiguous()
         edges = dict(top=edge(w2[:, :, 0, :]), bottom=edge(w2[:, :, 2, :]), left=edge(w2[:, :, :, 0]), right=edge(w2[:, :, :, 2]))
+        w1m32 = edges32 = None
+        if self.x3 or self.w2:       # fp32 operands of the two-product border GEMMs (split into [w_hi | w_lo] on first use, cached)
+            w1m32 = K.pack_conv_weight(w1.float().contiguous().to(dev), torch.float32, c_out_pad=cm_pad, c_in_pad=ci_pad).view(cm_pad, -1)
+
+            def edge32(sel):
+                e = torch.zeros(co_pad, 3, cm_pad, dtype=torch.float64)
+                e[:co, :, :cm] = sel.permute(0, 2, 1)
+                return e.view(co_pad, -1).float().to(dev).contiguous()
+            edges32 = dict(top=edge32(w2[:, :, 0, :]), bottom=edge32(w2[:, :, 2, :]), left=edge32(w2[:, :, :, 0]), right=edge32(w2[:, :, :, 2]))
         edges_all = torch.stack([edges[k] for k in ("top", "bottom", "left", "right")]).contiguous()   # [4, co_pad, 3*cm_pad]
         return dict(wt=wt, wt32=K.pack_conv_weight(wcf, torch.float32, c_out_pad=co_pad, c_in_pad=ci_pad) if self.w2 else None,
                     bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges,
+                    w1m32=w1m32, edges32=edges32,
                     edges_all=edges_all,
                     c_in=ci, c_out=co, c_out_pad=co_pad, c_mid_pad=cm_pad, tile=tile, taps=25)
 
@@ -235,14 +245,27 @@ class FrozenStem(object):
         """x: halo-2 padded NHWC [n, H+4, W+4, ci_pad] -> relu/pool'ed output of the composed pair (halo 1)."""
         cp = self.composed
         xc = x                       # the composed conv's input
-        if self.x3 and x.dtype != torch.float32:
+        # fp16x with a ROUNDED composed input (a plain fp16 tensor, the default) and fp16w: the border-correction GEMMs as
+        # two-product launches too — conv11 at the ring positions from the fp16 input against [w_hi | w_lo], the four edge products
+        # likewise from its fp16 output (that intermediate touches border pixels only) — instead of the exact-f32 matrix path
+        # (1.5 of the fp16x stem's 15.5 ms)
+        ring_w2 = cp.get("w1m32") is not None and L.is_half(x.dtype) and x.shape[-1] == cp["w1m32"].shape[1] // 9 and \
+            (self.w2 or self.x3) and K.x3_mode() in ("w2", "x3") and os.environ.get("VNQA_RING_W2", "1") != "0"
+        if self.x3 and x.dtype != torch.float32 and not ring_w2:
             x = self._x3_side        # (fp16x: the border-correction GEMMs read the fp32 copy, the 5x5 conv the x3 operand)
         n, hp, wp, ci_pad = x.shape
         H, W = hp - 4, wp - 4
         cm = cp["c_mid_pad"]
         # conv1 (+ b1) at the outside-ring positions, then the four edge GEMMs of conv2's outside taps -> ring of R[p]
         mode = os.environ.get("VNQA_RING_MODE", "implicit")
-        if mode == "implicit":
+        if ring_w2:
+            R = 2 * (W + 2) + 2 * H
+            y1p = self._buf(key + ("y1p", H, W, "w2"), (n, R + 4, cm), dtype=L.half_dtype())
+            with K.f32_conv_mode("w2"):
+                K.conv2d_ring(x, cp["w1m32"].view(cm, 9, ci_pad), cp["b1"], H, W, out_padded=y1p)
+                part = [K.ring_edge_conv(y1p, cp["edges32"][name], H, W, e)
+                        for e, name in enumerate(("top", "bottom", "left", "right"))]
+        elif mode == "implicit":
             # both correction operands as implicit GEMMs: conv11 at the ring positions straight from the halo-2 image, written
             # into a zero-separated ring layout; the four edge products as 1x3 convs along its rows (no im2col matrix, no
             # gathered edge operands: 147 + 4 x 48 MB less written and read back per 280-frame pass)
@@ -358,7 +381,8 @@ class FrozenStem(object):
                     # x3 scratch) finished a second time
                     side = self._buf(key + ("f32side",), (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]))
                     if x3_out == 2:
-                        side.copy_(x)
+                        if os.environ.get("VNQA_RING_W2", "1") == "0":       # (else the border GEMMs read the fp16 tensor itself)
+                            side.copy_(x)
                         self._x3_side = side
                     else:
                         self._x3_side = K.x3_post_again(side, n, h, w, ly["c_out_pad"], yh, bias=ly["bias"], relu=ly["relu"],
