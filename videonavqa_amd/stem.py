@@ -101,7 +101,7 @@ class FrozenStem(object):
             # VNQA_X3_ROUND=n (default 4): the INPUT of the n heaviest x3 layers (composed 5x5, conv22, conv21, conv2_2 — in that order)
             # is kept as ONE rounded fp16 tensor: two products instead of three on that layer (a third of its matrix work) for one
             # more fp16 rounding.  The mode's speed / tolerance curve at the headline size, worst of the three parity batches
-            # (profiles/r04_fp16x_curve.txt): PLAIN_FIRST=0 ~1e-5 at 245 clips/s; n = 0: 0.48e-3 at 277; 4: 0.68e-3 at 362 (those layers run as fused two-product launches)
+            # (profiles/r04_fp16x_curve.txt): PLAIN_FIRST=0 ~1e-5 at 245 clips/s; n = 0: 0.48e-3 at 277; 4: 0.73e-3 at 392 (those layers run as fused two-product launches)
             self.x3_round = set(("composed", "od3", "od2", "vgg2", "od4", "od5")[:int(os.environ.get("VNQA_X3_ROUND", "4"))]) if self.x3 else set()
             self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=L.half_dtype() if (self.x3_plain_first or self.w2) else None),
                                self._layer(f["5"], relu=True, pool=False),
@@ -226,7 +226,7 @@ class FrozenStem(object):
             return e.view(co_pad, -1).to(dev).to(self.cdt).contiguous()
         edges = dict(top=edge(w2[:, :, 0, :]), bottom=edge(w2[:, :, 2, :]), left=edge(w2[:, :, :, 0]), right=edge(w2[:, :, :, 2]))
         w1m32 = edges32 = None
-        if self.x3 or self.w2:       # fp32 operands of the two-product border GEMMs (split into [w_hi | w_lo] on first use, cached)
+        if self.x3:                  # fp32 operands of the two-product border GEMMs (split into [w_hi | w_lo] on first use, cached)
             w1m32 = K.pack_conv_weight(w1.float().contiguous().to(dev), torch.float32, c_out_pad=cm_pad, c_in_pad=ci_pad).view(cm_pad, -1)
 
             def edge32(sel):
@@ -245,12 +245,12 @@ class FrozenStem(object):
         """x: halo-2 padded NHWC [n, H+4, W+4, ci_pad] -> relu/pool'ed output of the composed pair (halo 1)."""
         cp = self.composed
         xc = x                       # the composed conv's input
-        # fp16x with a ROUNDED composed input (a plain fp16 tensor, the default) and fp16w: the border-correction GEMMs as
-        # two-product launches too — conv11 at the ring positions from the fp16 input against [w_hi | w_lo], the four edge products
+        # fp16x with a ROUNDED composed input (a plain fp16 tensor, the default): the border-correction GEMMs as two-product
+        # launches too (fp16w keeps them on the plain fp16 kernels: measured 0.3 ms faster there at the same 0.95e-3) — conv11 at the ring positions from the fp16 input against [w_hi | w_lo], the four edge products
         # likewise from its fp16 output (that intermediate touches border pixels only) — instead of the exact-f32 matrix path
         # (1.5 of the fp16x stem's 15.5 ms)
         ring_w2 = cp.get("w1m32") is not None and L.is_half(x.dtype) and x.shape[-1] == cp["w1m32"].shape[1] // 9 and \
-            (self.w2 or self.x3) and K.x3_mode() in ("w2", "x3") and os.environ.get("VNQA_RING_W2", "1") != "0"
+            self.x3 and K.x3_mode() == "x3" and os.environ.get("VNQA_RING_W2", "1") != "0"
         if self.x3 and x.dtype != torch.float32 and not ring_w2:
             x = self._x3_side        # (fp16x: the border-correction GEMMs read the fp32 copy, the 5x5 conv the x3 operand)
         n, hp, wp, ci_pad = x.shape
