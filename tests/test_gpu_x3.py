@@ -219,13 +219,14 @@ def test_fp16x_models_vs_reference_golden(case):
             assert np.abs(got_g - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-6, name
 
 
-@pytest.mark.parametrize("plain_first,round_n", [(False, 0), (True, 0), (True, 4)])
-def test_fp16x_stem_vs_exact_f32_stem(plain_first, round_n, monkeypatch):
+@pytest.mark.parametrize("plain_first,round_n,prefix", [(False, 0, 0), (True, 0, 1), (True, 4, 1), (True, 4, 3), (True, 4, 5), (True, 0, 7)])
+def test_fp16x_stem_vs_exact_f32_stem(plain_first, round_n, prefix, monkeypatch):
     """The frozen stem (composed 5x5 pair included) in fp16x against the exact-f32 stem on the same weights and clip: every layer
     as an x3 product (VNQA_X3_PLAIN_FIRST=0: 5e-5 of the features' max), and the default with conv1_1 + conv1_2 on the plain fp16
     fused kernel (five fp16 roundings: stated 3e-3 on the features)."""
     monkeypatch.setenv("VNQA_X3_PLAIN_FIRST", "1" if plain_first else "0")
     monkeypatch.setenv("VNQA_X3_ROUND", str(round_n))      # (4: the inputs of conv2_2, the composed pair, conv21, conv22 as two-product operands)
+    monkeypatch.setenv("VNQA_X3_PLAIN_PREFIX", str(prefix))  # (k leading layers exactly as precision 'fp16' runs them: 5 = through conv21)
     import torch.nn as nn
     from videonavqa_amd.models import ObjDetectCNN
     from videonavqa_amd.models.common import FrameLayout
@@ -250,7 +251,7 @@ def test_fp16x_stem_vs_exact_f32_stem(plain_first, round_n, monkeypatch):
         lay = FrameLayout([3, 2], 3, "cuda")
         feats[prec] = stem.forward_clip(clip, lay.img_of, lay.n_img).clone()
     a, b = feats["fp16x"], feats["fp32"]
-    assert a.dtype == torch.float32 and float((a - b).abs().max()) < (3e-3 if plain_first else 5e-5) * float(b.abs().max())
+    assert a.dtype == torch.float32 and float((a - b).abs().max()) < ((3e-3 if prefix <= 1 else 6e-3) if plain_first else 5e-5) * float(b.abs().max())
 
 
 def test_fp16x_meets_1e3_on_all_three_full_size_parity_batches():

@@ -103,15 +103,24 @@ class FrozenStem(object):
             # more fp16 rounding.  The mode's speed / tolerance curve at the headline size, worst of the three parity batches
             # (profiles/r04_fp16x_curve.txt): PLAIN_FIRST=0 ~1e-5 at 245 clips/s; n = 0: 0.48e-3 at 277; 4: 0.73e-3 at 392 (those layers run as fused two-product launches)
             self.x3_round = set(("composed", "od3", "od2", "vgg2", "od4", "od5")[:int(os.environ.get("VNQA_X3_ROUND", "4"))]) if self.x3 else set()
-            self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=L.half_dtype() if (self.x3_plain_first or self.w2) else None),
-                               self._layer(f["5"], relu=True, pool=False),
-                               self._layer(f["7"], relu=True, pool=True)]
+            # VNQA_X3_PLAIN_PREFIX=k (fp16x): the first k stem layers — in the order fused conv1, conv2_1, conv2_2, the composed pair,
+            # conv21, conv22, conv31 — run EXACTLY as in precision 'fp16' (plain storage, ONE product, the fast kernels: weights in
+            # registers, composed 5x5 with its fp16 border GEMMs, patch-stationary); the layers after the prefix are x3 products (the
+            # first of them with two products: its input is the prefix's rounded fp16 output).  Measured (profiles/r04_fp16x_curve.txt):
+            # the early / middle layers' weight roundings cost far less logits error than their 2 - 3 x matrix work buys.
+            self.x3_prefix = max(1 if self.x3_plain_first else 0, int(os.environ.get("VNQA_X3_PLAIN_PREFIX", "1"))) if self.x3 else 0
+            hp = lambda i: L.half_dtype() if (i < self.x3_prefix or (self.w2 and i == 0)) else None
+            self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=hp(0)),
+                               self._layer(f["5"], relu=True, pool=False, cdt=hp(1)),
+                               self._layer(f["7"], relu=True, pool=True, cdt=hp(2))]
         if objdet is not None:
             od = objdet
             self.bn_input = _fold_bn(od.bn_input)
-            self.layers_od = [self._layer(od.conv11), self._layer(od.conv12, bn=od.bn1, relu=True, pool=True),
-                              self._layer(od.conv21), self._layer(od.conv22, bn=od.bn2, relu=True, pool=True),
-                              self._layer(od.conv31), self._layer(od.conv32, bn=od.bn3, relu=True, pool=False)]
+            pre = getattr(self, "x3_prefix", 0)
+            hq = lambda i: L.half_dtype() if i < pre else None       # (stem layer index: 3 = the conv11 / conv12 pair, 4 = conv21, ...)
+            self.layers_od = [self._layer(od.conv11, cdt=hq(3)), self._layer(od.conv12, bn=od.bn1, relu=True, pool=True, cdt=hq(3)),
+                              self._layer(od.conv21, cdt=hq(4)), self._layer(od.conv22, bn=od.bn2, relu=True, pool=True, cdt=hq(5)),
+                              self._layer(od.conv31, cdt=hq(6)), self._layer(od.conv32, bn=od.bn3, relu=True, pool=False)]
             # conv12 is applied straight to conv11's output (obj_detector.py:72: no nonlinearity between the two convs of
             # a pair) and both are frozen: when the pair's 3x3 (c_in -> c_mid) . 3x3 (c_mid -> c_out) costs more than one
             # 5x5 (c_in -> c_out) — 9*c_in + 9*c_mid > 25*c_in, true for 128 -> 512 -> 512 only — it is evaluated as the
@@ -119,7 +128,16 @@ class FrozenStem(object):
             self.composed = None
             ci, cm = od.conv11.in_channels, od.conv11.out_channels
             if os.environ.get("VNQA_STEM_COMPOSE", "1") != "0" and 9 * ci + 9 * cm > 25 * ci:
-                self.composed = self._compose_pair(od.conv11, od.conv12, od.bn1)
+                if pre >= 4:         # the pair inside the plain fp16 prefix: built exactly as precision 'fp16' builds it
+                    keep = (self.cdt, self.x3)
+                    self.cdt, self.x3 = L.half_dtype(), False
+                    try:
+                        self.composed = self._compose_pair(od.conv11, od.conv12, od.bn1)
+                    finally:
+                        self.cdt, self.x3 = keep
+                    self.composed["cdt"] = L.half_dtype()
+                else:
+                    self.composed = self._compose_pair(od.conv11, od.conv12, od.bn1)
             self.out_channels = od.conv32.out_channels
             if vgg is not None:
                 # bn_input becomes the post-affine of the last VGG layer's epilogue
@@ -127,7 +145,8 @@ class FrozenStem(object):
                 self.layers_vgg[-1]["post"] = (K.pad_vec(s, 128), K.pad_vec(t, 128))
                 if self.composed is not None:
                     self.layers_vgg[-1]["y_halo"] = 2        # the composed 5x5 conv reads a halo-2 image
-                    self.layers_vgg[-1]["dual"] = self.x3    # (x3: its output also as fp32, for the exact-f32 border-correction GEMMs)
+                    # (x3 conv2_2: its output also as fp32, for the exact-f32 border-correction GEMMs)
+                    self.layers_vgg[-1]["dual"] = self.x3 and self.layers_vgg[-1].get("cdt") is None
 
     def _layer(self, conv, bn=None, relu=False, pool=False, cdt=None):
         if cdt is not None:          # a layer in another storage dtype than the stem's (fp16x: the plain fp16 first layer)
@@ -249,9 +268,9 @@ class FrozenStem(object):
         # launches too (fp16w keeps them on the plain fp16 kernels: measured 0.3 ms faster there at the same 0.95e-3) — conv11 at the ring positions from the fp16 input against [w_hi | w_lo], the four edge products
         # likewise from its fp16 output (that intermediate touches border pixels only) — instead of the exact-f32 matrix path
         # (1.5 of the fp16x stem's 15.5 ms)
-        ring_w2 = cp.get("w1m32") is not None and L.is_half(x.dtype) and x.shape[-1] == cp["w1m32"].shape[1] // 9 and \
+        ring_w2 = cp.get("cdt") is None and cp.get("w1m32") is not None and L.is_half(x.dtype) and x.shape[-1] == cp["w1m32"].shape[1] // 9 and \
             self.x3 and K.x3_mode() == "x3" and os.environ.get("VNQA_RING_W2", "1") != "0"
-        if self.x3 and x.dtype != torch.float32 and not ring_w2:
+        if self.x3 and cp.get("cdt") is None and x.dtype != torch.float32 and not ring_w2:
             x = self._x3_side        # (fp16x: the border-correction GEMMs read the fp32 copy, the 5x5 conv the x3 operand)
         n, hp, wp, ci_pad = x.shape
         H, W = hp - 4, wp - 4
@@ -270,7 +289,7 @@ class FrozenStem(object):
             # into a zero-separated ring layout; the four edge products as 1x3 convs along its rows (no im2col matrix, no
             # gathered edge operands: 147 + 4 x 48 MB less written and read back per 280-frame pass)
             R = 2 * (W + 2) + 2 * H
-            y1p = self._buf(key + ("y1p", H, W), (n, R + 4, cm))
+            y1p = self._buf(key + ("y1p", H, W), (n, R + 4, cm), dtype=cp.get("cdt"))
             K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W, out_padded=y1p)
             part = [K.ring_edge_conv(y1p, cp["edges"][name], H, W, e)
                     for e, name in enumerate(("top", "bottom", "left", "right"))]
@@ -290,18 +309,21 @@ class FrozenStem(object):
                         for e, name in enumerate(("top", "bottom", "left", "right"))]
         ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
-        x3o = (2 if "od2" in self.x3_round else 1) if self.x3 else 0
-        if self.x3:
+        plain = cp.get("cdt") is not None                     # the pair inside the plain fp16 prefix of an fp16x stem
+        x3o = ((2 if "od2" in self.x3_round else 1) if self.x3 else 0) if not plain else 0
+        if plain:
+            out = self._buf(key + (ho, wo, "h16"), (n, ho + 2, wo + 2, cp["c_out_pad"]), dtype=cp["cdt"])
+        elif self.x3:
             out = self._buf(key + (ho, wo, "x3", x3o), (n, ho + 2, wo + 2, (3 if x3o == 1 else 1) * cp["c_out_pad"]), dtype=L.half_dtype())
         else:
             out = self._buf(key + (ho, wo) + ((slot,) if use_slot else ()), (n, ho + 2, wo + 2, cp["c_out_pad"]))
-        timed = self.timing is not None and (self.x3 or self.w2 or cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256))
+        timed = self.timing is not None and ((self.x3 and not plain) or self.w2 or cp["tile"] in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256))
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         # every XCD computes ONE cout half of the composed conv (its L2 then holds 1.65 instead of 3.3 MB of weights): fabric-side reads
         # 1 022 -> 831 MB per launch (profiles/r04_pmc_traffic*.json), time unchanged (2.166 vs 2.161 ms; end to end 941-943 either way)
-        xcd = L.CONV_XCD_SPLIT_N if (not self.x3 and os.environ.get("VNQA_STEM_XCD_SPLIT", "1") == "1") else 0
+        xcd = L.CONV_XCD_SPLIT_N if ((not self.x3 or plain) and os.environ.get("VNQA_STEM_XCD_SPLIT", "1") == "1") else 0
         w2 = self.w2 and K.x3_mode() == "w2"
         if self.x3 and x3o == 2 and L.is_half(xc.dtype) and os.environ.get("VNQA_X3_COMPOSED_PLAIN", "0") == "1":
             # experiment: the composed pair as ONE plain fp16 product (its weight rounding stays): the layer at a third of its x3 cost
@@ -316,7 +338,7 @@ class FrozenStem(object):
         if timed:
             ev1.record()
             self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25,
-                                "x3 product (split + conv_igemm_kernel raw + post)" if self.x3 else
+                                "x3 product (split + conv_igemm_kernel raw + post)" if (self.x3 and not plain) else
                                 "conv_igemm_kernel<..., TAG 4> (two products, x read twice along K)" if self.w2 else
                                 ("conv_ps_kernel" if cp["tile"] == L.TILE_STEM_PS_224x256 else "conv_igemm_kernel")))
         return y
@@ -341,8 +363,11 @@ class FrozenStem(object):
             key = (tag, i, ho, wo) if not last else (tag, i, ho, wo, last_slot)
             # fp16x: consecutive layers hand each other the 16-bit x3 operand [hi | lo | hi] (no fp32 round trip); the chain's
             # last layer (`final`) writes fp32
-            x3_out = self.x3 and K._F32_CONV_MODE[0] == "x3" and not (last and final)
-            if x3_out:
+            plain = ly.get("cdt") is not None                 # a layer of the plain 16-bit prefix inside the fp16x stem
+            x3_out = self.x3 and not plain and K._F32_CONV_MODE[0] == "x3" and not (last and final)
+            if plain:
+                out = self._buf(key + ("h16",), (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]), dtype=ly["cdt"])
+            elif x3_out:
                 nxt = ("%s%d" % (tag, i + 1)) if not last else ("composed" if (tag == "vgg" and self.composed is not None) else "od0")
                 x3_out = 2 if nxt in self.x3_round else 1
                 out = self._buf(key + ("x3", x3_out), (n, ho + 2 * yh, wo + 2 * yh, (3 if x3_out == 1 else 1) * ly["c_out_pad"]),
@@ -353,7 +378,7 @@ class FrozenStem(object):
             tile = ly["tile"]
             timed = self.timing is not None and (tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256, L.TILE_STEM_PS_224x256) or
                                                  ((self.x3 or self.w2) and ly["c_out_pad"] >= 256))      # (C_out = 512 layers, whichever kernel serves them)
-            kname = "conv_igemm_kernel" if not self.x3 else "x3 product (split + conv_igemm_kernel raw + post)"
+            kname = "conv_igemm_kernel" if (not self.x3 or ly.get("cdt") is not None) else "x3 product (split + conv_igemm_kernel raw + post)"
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
