@@ -77,6 +77,8 @@ def build(args, device):
     import torch.nn as nn
     torch.manual_seed(0)     # identical replicas on every rank
     prec = args.precision
+    # experiment hook (fp16x): the trunk behind the x3 stem in another storage — "w2" = precision 'fp16w', "plain" = 'fp16'
+    mprec = {"w2": "fp16w", "plain": "fp16"}.get(os.environ.get("VNQA_X3_TRUNK", "x3"), prec) if prec == "fp16x" else prec
     vgg = VGGFront(prec)
     od = ObjDetectCNN(27, 512, 1024, 0, True, True, precision=prec)   # eval/utils.py:43-48
     with torch.no_grad():
@@ -93,21 +95,21 @@ def build(args, device):
     if args.model == "film_attn_pt":
         model = FiLMAttnPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
                                        num_res_block_channels=args.channels, max_num_frames=args.frames,
-                                       spatial_size=S, precision=prec)
+                                       spatial_size=S, precision=mprec)
     elif args.model == "mac":              # MACNetwork on the same stem (eval/q_and_v_eval.py:288-293)
         from videonavqa_amd.models import MACNetwork
         model = MACNetwork(n_vocab=134, dim=args.channels, embed_hidden=128, classes=70, max_num_frames=args.frames,
-                           precision=prec)
+                           precision=mprec)
     elif args.model == "film_gp_pt":       # BASELINE.json config 3
         model = FiLMGlobalPoolingPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
-                                                num_res_block_channels=args.channels, spatial_size=S, precision=prec,
+                                                num_res_block_channels=args.channels, spatial_size=S, precision=mprec,
                                                 **({"num_tail_channels": args.tail_channels} if getattr(args, "tail_channels", 0) else {}))
     else:                                  # BASELINE.json config 5 (use --frames 70)
         model = TimeMultiHopFiLMPretrainedStem(args.batch, 128, 70, num_res_blocks=args.blocks,
-                                               num_res_block_channels=args.channels, spatial_size=S, precision=prec,
+                                               num_res_block_channels=args.channels, spatial_size=S, precision=mprec,
                                                **({"num_tail_channels": args.tail_channels} if getattr(args, "tail_channels", 0) else {}))
     vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
-    stem = FrozenStem(vgg, od, prec)
+    stem = FrozenStem(vgg, od, prec, out_half=(mprec != prec))
     COMPOSED_STEM[0] = stem.composed is not None
     return model, stem, vgg, od
 

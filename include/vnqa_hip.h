@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 410
+#define VNQA_ABI_VERSION 411
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -141,7 +141,8 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
  *      x . w = x_hi . w_hi + x_lo . w_hi + x_hi . w_lo,   v_hi = fp16(v), v_lo = fp16(v - v_hi),   fp32 accumulation:
  * the same nn.Conv2d / nn.Linear call sites as vnqa_conv2d_igemm_fwd / vnqa_gemm_nt, for callers that need the reference's
  * fp32 results to north star's 1e-3 (measured ~1e-5) but not bit-exactness, at 3/16 of the exact-f32 matrix path's cost.
- *   vnqa_split3_f32     : rows x c fp32 (row stride src_ld) -> hi, lo and (optional, may be NULL) a second copy of hi, each
+ *   vnqa_split3_f32     : rows x c fp32 (row stride src_ld) -> hi, lo (may be NULL: the scaled fp32 -> 16-bit cast of a ONE-product
+ *                         backward operand) and (optional, may be NULL) a second copy of hi, each
  *                         rows x c in the library's 16-bit format with row stride dst_ld.  Channel-concatenated operand
  *                         [hi | lo | hi]: (base, base + c, base + 2c), dst_ld = 3c.
  *   vnqa_conv2d_igemm_raw : the 16-bit conv's raw fp32 accumulators [n_img*h*w][c_out] (d: dtype VNQA_BF16, c_in = the

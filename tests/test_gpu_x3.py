@@ -189,6 +189,35 @@ def test_x3g_backward_products_match_exact_f32_for_tiny_gradients(mag):
         assert float(K.conv2d_igemm(torch.zeros_like(dy), wt_d).abs().max()) == 0
 
 
+@pytest.mark.parametrize("mag", [1.0, 1e-6, 3e-9])
+def test_x1g_backward_products_are_the_fp16_backward_on_fp32_tensors(mag):
+    """The ONE-product backward ('x1g': both operands rounded to fp16 once, the gradient operand scaled first): the same four
+    products against the exact-f32 path — fp16-operand accuracy (2^-11 per operand, averaged over K), for gradients down to 3e-9."""
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(7)
+    n, h, w, c = 5, 14, 14, 128
+    x = _padded(n, h, w, c, 11)
+    dy = _padded(n, h, w, 256, 12, scale=mag)
+    wgt = (torch.randn(256, c, 3, 3, generator=g) / (c * 9) ** 0.5).cuda()
+    wt_d = K.pack_conv_weight(wgt, torch.float32, transpose_flip=True)
+    ref_dx = K.conv2d_igemm(dy, wt_d)
+    ref_dw, ref_db = K.conv2d_wgrad(x, dy, 9)
+    a = (torch.randn(280, 128, generator=g) * mag).cuda()
+    b = torch.randn(280, 512, generator=g).cuda()
+    wnk = (torch.randn(512, 128, generator=g) / 11.0).cuda()
+    ref_tn, ref_nt = K.gemm_tn(a, b), K.gemm_nt(a, wnk)
+    with K.f32_conv_mode("x1g"):
+        dx = K.conv2d_igemm(dy, wt_d)
+        dw, db = K.conv2d_wgrad(x, dy, 9)
+        tn, nt = K.gemm_tn(a, b), K.gemm_nt(a, wnk)
+        assert float(K.conv2d_igemm(torch.zeros_like(dy), wt_d).abs().max()) == 0
+    for got, ref, name in ((dx, ref_dx, "dgrad"), (dw, ref_dw, "wgrad"), (db, ref_db, "dbias"), (tn, ref_tn, "gemm_tn"), (nt, ref_nt, "gemm_nt")):
+        assert got.dtype == torch.float32 and got.shape == ref.shape, name
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-3, (name, mag, err)
+        assert name == "dbias" or err > 1e-6, (name, "one product expected, not three")
+
+
 @pytest.mark.parametrize("case", QV_CASES)
 def test_fp16x_models_vs_reference_golden(case):
     """precision='fp16x' on the reference's goldens: eval logits and train logits within 1e-3 (north star's tolerance; the

@@ -15,7 +15,8 @@
 
 namespace {
 
-// rows x c fp32 (row stride src_ld) -> three 16-bit destinations with row stride dst_ld: hi, lo and (optional) a second copy of hi
+// rows x c fp32 (row stride src_ld) -> three 16-bit destinations with row stride dst_ld: hi, (optional) lo and (optional) a second
+// copy of hi; with lo == hi2 == null it is the scaled fp32 -> 16-bit cast of the one-product backward ('x1g')
 __global__ void __launch_bounds__(256) split3_kernel(const float* __restrict__ x, unsigned short* __restrict__ hi,
                                                      unsigned short* __restrict__ lo, unsigned short* __restrict__ hi2,
                                                      long long rows, int c8, long long src_ld, long long dst_ld,
@@ -40,7 +41,7 @@ __global__ void __launch_bounds__(256) split3_kernel(const float* __restrict__ x
     }
     const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]);
     *(uint4*)(hi + r * dst_ld + j) = hv;
-    *(uint4*)(lo + r * dst_ld + j) = make_uint4(l[0], l[1], l[2], l[3]);
+    if (lo != nullptr) *(uint4*)(lo + r * dst_ld + j) = make_uint4(l[0], l[1], l[2], l[3]);
     if (hi2 != nullptr) *(uint4*)(hi2 + r * dst_ld + j) = hv;
   }
 }
@@ -139,7 +140,7 @@ int grid_for(long long total) {
 
 extern "C" int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld,
                                int64_t dst_ld, const float* scale, void* stream) {
-  VNQA_CHECK_ARG(x && hi && lo, "split3_f32: null pointer");
+  VNQA_CHECK_ARG(x && hi, "split3_f32: null pointer");
   VNQA_CHECK_ARG(rows > 0 && c > 0 && c % 8 == 0 && src_ld >= c && src_ld % 4 == 0 && dst_ld >= c && dst_ld % 8 == 0,
                  "split3_f32: rows=%lld c=%d src_ld=%lld dst_ld=%lld (c %% 8, src_ld %% 4, dst_ld %% 8 must be 0)",
                  (long long)rows, c, (long long)src_ld, (long long)dst_ld);

@@ -86,7 +86,9 @@ class f32_conv_mode(object):
         # 'w2' (precision 'fp16w'): convs / GEMMs with a 16-bit activation and fp32 K-major weights run as the TWO-product form
         # x . w_hi + x . w_lo — the weight rounding is removed, the activations stay plain fp16 tensors (read twice along K by the
         # igemm's wrap variant, VNQA_CONV_X_WRAP2: no copy, fused epilogues as usual)
-        assert mode in ("x3", "x3g", "w2", "exact")
+        # 'x1g': the backward pass as ONE fp16 product per contraction (both operands rounded once, the gradient operand scaled like
+        # 'x3g'): the fp16 precision's backward arithmetic on the fp32-stored tensors of precision 'fp16x' — a third of x3g's matrix work
+        assert mode in ("x3", "x3g", "x1g", "w2", "exact")
         self.mode = mode
 
     def __enter__(self):
@@ -99,7 +101,7 @@ class f32_conv_mode(object):
 
 
 def x3_active(t):
-    return _F32_CONV_MODE[0] in ("x3", "x3g") and t.dtype == torch.float32 and t.is_cuda
+    return _F32_CONV_MODE[0] in ("x3", "x3g", "x1g") and t.dtype == torch.float32 and t.is_cuda
 
 
 def x3_mode():
@@ -151,6 +153,29 @@ def split3(x2d, out=None, scale=None):
                                     ctypes.c_void_p(base + 2 * c * es), rows, c, x2d.stride(0), 3 * c, L.ptr(scale), L.stream()),
             "vnqa_split3_f32")
     return out
+
+
+def cast_hi(x2d, scale=None, name="x1in"):
+    """fp32 [rows, c] -> 16-bit [rows, c] = fp16(scale * x): the operand of a ONE-product backward contraction ('x1g')."""
+    rows, c = x2d.shape
+    assert x2d.dtype == torch.float32 and x2d.stride(1) == 1 and c % 8 == 0
+    out = _x3_buffer(name, rows * c, L.half_dtype(), x2d.device).view(rows, c)
+    L.check(L.lib().vnqa_split3_f32(L.vptr(x2d), L.ptr(out), None, None, rows, c, x2d.stride(0), c, L.ptr(scale), L.stream()),
+            "vnqa_split3_f32(hi only)")
+    return out
+
+
+def x1_weight(wt):
+    """fp32 weights rounded once to the 16-bit format (cached on the tensor object like x3_weight)."""
+    cached = getattr(wt, "_vnqa_x1", None)
+    if cached is not None and cached[0] == wt._version:
+        return cached[1]
+    w1 = wt.to(L.half_dtype()).contiguous()
+    try:
+        wt._vnqa_x1 = (wt._version, w1)
+    except (AttributeError, RuntimeError):
+        pass
+    return w1
 
 
 def split3_rows(x2d, order, scale=None, name="x3rows"):
@@ -210,7 +235,13 @@ def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo,
     assert wt.dtype == torch.float32 and x.is_contiguous()
     half = L.half_dtype()
     inv, wrap = None, 0
-    if x.dtype == torch.float32:
+    if x.dtype == torch.float32 and _F32_CONV_MODE[0] == "x1g":      # one product: fp16(s * dy) against fp16(w)
+        assert Cx == Cin
+        k = Cin
+        w3 = x1_weight(wt).view(c_out, taps, k)
+        scale, inv = grad_split_scale(x)
+        xin = cast_hi(x.view(N * Hp * Wp, Cin), scale=scale)
+    elif x.dtype == torch.float32:
         assert Cx == Cin
         k = 3 * Cin
         w3 = x3_weight(wt).view(c_out, taps, k)
@@ -258,7 +289,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
                  x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False, desc_flags=0):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
     (x3_out: only inside f32_conv_mode("x3") — the output as the next x3 product's 16-bit operand, see _conv2d_x3.)"""
-    x3m = _F32_CONV_MODE[0] in ("x3", "x3g") and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
+    x3m = _F32_CONV_MODE[0] in ("x3", "x3g", "x1g") and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
         relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 and x.shape[-1] % 64 == 0
     # inside the x3 mode a layer with a plain 16-bit input AND a rounded (plain 16-bit) output is exactly the two-product conv of
     # precision 'fp16w': one launch of the wrap variant with its fused epilogue instead of raw sums + a post pass
@@ -782,11 +813,17 @@ def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None):
         # x3 product over the pixels: dW = sum_p dY[p] X[p + tap]  with  X' = [x_hi; x_hi; x_lo], dY' = s [dy_hi; dy_lo; dy_hi] stacked
         # along the IMAGE axis — the 16-bit weight-gradient kernel on 3 N images computes exactly the three products' sum
         scale, inv = grad_split_scale(dy)
-        x3 = split3_rows(x.view(N * Hp * Wp, Cin), "hhl").view(3 * N, Hp, Wp, Cin)
-        dy3 = split3_rows(dy.view(N * Hp * Wp, Cout), "hlh", scale=scale, name="x3rowsdy").view(3 * N, Hp, Wp, Cout)
-        ws = workspace(L.lib().vnqa_conv2d_wgrad_workspace(3 * N, h, w, Cin, Cout, taps), x.device)
+        if _F32_CONV_MODE[0] == "x1g":      # one product: fp16(x) and fp16(s * dy), N images
+            nn = N
+            x3 = cast_hi(x.view(N * Hp * Wp, Cin), name="x1rows").view(N, Hp, Wp, Cin)
+            dy3 = cast_hi(dy.view(N * Hp * Wp, Cout), scale=scale, name="x1rowsdy").view(N, Hp, Wp, Cout)
+        else:
+            nn = 3 * N
+            x3 = split3_rows(x.view(N * Hp * Wp, Cin), "hhl").view(3 * N, Hp, Wp, Cin)
+            dy3 = split3_rows(dy.view(N * Hp * Wp, Cout), "hlh", scale=scale, name="x3rowsdy").view(3 * N, Hp, Wp, Cout)
+        ws = workspace(L.lib().vnqa_conv2d_wgrad_workspace(nn, h, w, Cin, Cout, taps), x.device)
         dwt = torch.empty((Cout, taps, Cin), dtype=torch.float32, device=x.device)
-        L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x3), L.ptr(dy3), L.ptr(dwt), None, L.ptr(ws), 3 * N, h, w, Cin, Cout, taps,
+        L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x3), L.ptr(dy3), L.ptr(dwt), None, L.ptr(ws), nn, h, w, Cin, Cout, taps,
                                           L.BF16, L.stream()), "vnqa_conv2d_wgrad(x3)")
         dwt.mul_(inv)
         dbias = None
@@ -838,17 +875,21 @@ def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
     if x3_active(a) and Kd % 64 == 0 and a.is_contiguous():
         # x3 product: [a_hi | a_lo | a_hi] . [b_hi | b_hi | b_lo]^T on the 16-bit GEMM with an fp32 output
         scale = inv = None
-        if _F32_CONV_MODE[0] == "x3g":          # `a` is a gradient (dX = dOut . W): lifted into fp16's range, divided out below
+        if _F32_CONV_MODE[0] in ("x3g", "x1g"):   # `a` is a gradient (dX = dOut . W): lifted into fp16's range, divided out below
             assert bias is None and not relu
             scale, inv = grad_split_scale(a)
-        a3 = split3(a, out=_x3_buffer("x3in", M * 3 * Kd, L.half_dtype(), a.device).view(M, 3 * Kd), scale=scale)
-        b3 = x3_weight(b)
+        if _F32_CONV_MODE[0] == "x1g":            # one product
+            kk, a3, b3 = Kd, cast_hi(a, scale=scale), x1_weight(b)
+        else:
+            kk = 3 * Kd
+            a3 = split3(a, out=_x3_buffer("x3in", M * 3 * Kd, L.half_dtype(), a.device).view(M, 3 * Kd), scale=scale)
+            b3 = x3_weight(b)
         if out is None:
             out = torch.empty((M, N), dtype=torch.float32, device=a.device)
         assert out.dtype == torch.float32
-        ws_bytes = max(L.lib().vnqa_gemm_nt_workspace(M, N, 3 * Kd, L.BF16) if split_k else 0, M * N * 4)
+        ws_bytes = max(L.lib().vnqa_gemm_nt_workspace(M, N, kk, L.BF16) if split_k else 0, M * N * 4)
         ws = workspace(ws_bytes, a.device)
-        L.check(L.lib().vnqa_gemm_nt(L.ptr(a3), L.ptr(b3), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, 3 * Kd, out.stride(0),
+        L.check(L.lib().vnqa_gemm_nt(L.ptr(a3), L.ptr(b3), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, kk, out.stride(0),
                                      1 if relu else 0, L.BF16 | L.GEMM_OUT_F32, L.stream()), "vnqa_gemm_nt(x3)")
         if inv is not None:
             out.mul_(inv)
@@ -871,13 +912,17 @@ def gemm_tn(a, b, out=None):
     if x3_active(a) and M % 8 == 0 and N % 8 == 0 and a.is_contiguous() and b.is_contiguous():
         # x3 product over K (the rows): A' = s [a_hi; a_lo; a_hi] (a: the gradient operand), B' = [b_hi; b_hi; b_lo]
         scale, inv = grad_split_scale(a)
-        a3 = split3_rows(a, "hlh", scale=scale, name="x3rowsdy")
-        b3 = split3_rows(b, "hhl")
-        ws = workspace(L.lib().vnqa_gemm_tn_workspace(M, N, 3 * Kd, L.BF16), a.device)
+        if _F32_CONV_MODE[0] == "x1g":            # one product
+            kk, a3, b3 = Kd, cast_hi(a, scale=scale, name="x1rowsdy"), cast_hi(b, name="x1rows")
+        else:
+            kk = 3 * Kd
+            a3 = split3_rows(a, "hlh", scale=scale, name="x3rowsdy")
+            b3 = split3_rows(b, "hhl")
+        ws = workspace(L.lib().vnqa_gemm_tn_workspace(M, N, kk, L.BF16), a.device)
         if out is None:
             out = torch.empty((M, N), dtype=torch.float32, device=a.device)
         assert out.shape == (M, N) and out.is_contiguous() and out.dtype == torch.float32
-        L.check(L.lib().vnqa_gemm_tn(L.ptr(a3), L.ptr(b3), L.ptr(out), L.ptr(ws), M, N, 3 * Kd, L.BF16, L.stream()), "vnqa_gemm_tn(x3)")
+        L.check(L.lib().vnqa_gemm_tn(L.ptr(a3), L.ptr(b3), L.ptr(out), L.ptr(ws), M, N, kk, L.BF16, L.stream()), "vnqa_gemm_tn(x3)")
         out.mul_(inv)
         return out
     did = L.dtype_id(a.dtype)

@@ -75,10 +75,13 @@ def _fold_bn(bn):
 class FrozenStem(object):
     """Execution plan (packed weights + persistent activation buffers) for the frozen stem."""
 
-    def __init__(self, vgg, objdet, precision='bf16'):
+    def __init__(self, vgg, objdet, precision='bf16', out_half=False):
         from .models.common import compute_dtype
         self.cdt = compute_dtype(precision)
         self.x3 = precision == "fp16x"       # fp32 storage, contractions as three fp16-half products (kernels.f32_conv_mode)
+        # fp16x with a 16-bit-storage trunk behind it (precision 'fp16' / 'fp16w' models): the LAST layer's output rounded once to
+        # fp16 instead of written as fp32
+        self.out_half = bool(out_half) and self.x3
         self.w2 = precision == "fp16w"       # fp16 storage, every layer after the fused conv1 with split weights (two products)
         self.vgg, self.objdet = vgg, objdet
         self.layers_vgg, self.layers_od = [], []
@@ -108,7 +111,7 @@ class FrozenStem(object):
             # registers, composed 5x5 with its fp16 border GEMMs, patch-stationary); the layers after the prefix are x3 products (the
             # first of them with two products: its input is the prefix's rounded fp16 output).  Measured (profiles/r04_fp16x_curve.txt):
             # the early / middle layers' weight roundings cost far less logits error than their 2 - 3 x matrix work buys.
-            self.x3_prefix = max(1 if self.x3_plain_first else 0, int(os.environ.get("VNQA_X3_PLAIN_PREFIX", "1"))) if self.x3 else 0
+            self.x3_prefix = max(1 if self.x3_plain_first else 0, int(os.environ.get("VNQA_X3_PLAIN_PREFIX", "4"))) if self.x3 else 0
             hp = lambda i: L.half_dtype() if (i < self.x3_prefix or (self.w2 and i == 0)) else None
             self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=hp(0)),
                                self._layer(f["5"], relu=True, pool=False, cdt=hp(1)),
@@ -364,12 +367,12 @@ class FrozenStem(object):
             # fp16x: consecutive layers hand each other the 16-bit x3 operand [hi | lo | hi] (no fp32 round trip); the chain's
             # last layer (`final`) writes fp32
             plain = ly.get("cdt") is not None                 # a layer of the plain 16-bit prefix inside the fp16x stem
-            x3_out = self.x3 and not plain and K._F32_CONV_MODE[0] == "x3" and not (last and final)
+            x3_out = self.x3 and not plain and K._F32_CONV_MODE[0] == "x3" and (not (last and final) or self.out_half)
             if plain:
                 out = self._buf(key + ("h16",), (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]), dtype=ly["cdt"])
             elif x3_out:
                 nxt = ("%s%d" % (tag, i + 1)) if not last else ("composed" if (tag == "vgg" and self.composed is not None) else "od0")
-                x3_out = 2 if nxt in self.x3_round else 1
+                x3_out = 2 if (nxt in self.x3_round or (last and final)) else 1
                 out = self._buf(key + ("x3", x3_out), (n, ho + 2 * yh, wo + 2 * yh, (3 if x3_out == 1 else 1) * ly["c_out_pad"]),
                                 dtype=L.half_dtype())
             else:
