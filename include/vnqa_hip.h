@@ -155,6 +155,12 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
  *                         tensor (one fp16 rounding) for a two-product consumer, which reads it twice (VNQA_CONV_X_WRAP2).
  *   vnqa_gemm_nt with dtype = VNQA_BF16 | VNQA_GEMM_OUT_F32 : 16-bit operands, fp32 `out` (workspace >= m*n*4 bytes required).
  */
+/* The split scale of a gradient tensor (the backward operands of precision 'fp16x': gradients are 1e-5 .. 1e-8, below fp16's normal
+ * range) in ONE launch: state = 16 bytes on the device, ZERO on first use (the call leaves words 0 and 3 zero again):
+ *   ((float*)state)[1] = s = the power of two that lifts max |x| into [2^12, 2^13)  (1 for an all-zero or non-finite tensor, never
+ *   above 2^112), ((float*)state)[2] = 1 / s — the `scale` of vnqa_split3_f32 and the `raw_scale` of vnqa_x3_post. */
+int vnqa_grad_split_scale(const float* x, int64_t n, void* state, void* stream);
+
 int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld, int64_t dst_ld,
                     const float* scale, void* stream);   /* scale: optional DEVICE scalar (a power of two) applied before the split:
                                                           * gradient operands are lifted into fp16's normal range */

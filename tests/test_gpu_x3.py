@@ -189,6 +189,28 @@ def test_x3g_backward_products_match_exact_f32_for_tiny_gradients(mag):
         assert float(K.conv2d_igemm(torch.zeros_like(dy), wt_d).abs().max()) == 0
 
 
+def test_grad_split_scale_single_launch_matches_its_definition():
+    """vnqa_grad_split_scale: the power of two lifting max |t| into [2^12, 2^13), 1 for all-zero / non-finite tensors, for sizes that
+    are not multiples of 4 or of the grid, reused states (a ring per stream) and 40 consecutive calls."""
+    import math
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    for i, (n, mag) in enumerate([(1, 1.0), (3, 5e-7), (4, 2.0 ** -20), (1027, 3e-9), (280 * 196 * 128 + 5, 1e-5), (5_000_003, 70000.0)] * 7):
+        t = (torch.randn(n, generator=g) * mag).cuda()
+        amax = float(t.abs().max())
+        scale, inv = K.grad_split_scale(t)
+        want = 2.0 ** (12 - math.floor(math.log2(amax)))
+        assert float(scale) == want and float(inv) == 1.0 / want, (i, n, mag, float(scale), want)
+        assert 4096.0 <= amax * float(scale) < 8192.0
+    z = torch.zeros(777, device="cuda")
+    assert [float(v) for v in K.grad_split_scale(z)] == [1.0, 1.0]
+    z[5] = float("inf")
+    assert [float(v) for v in K.grad_split_scale(z)] == [1.0, 1.0]
+    z[5], z[6] = float("nan"), 3e-40            # (NaNs are skipped; a subnormal maximum keeps a finite scale)
+    s, i = K.grad_split_scale(z)
+    assert float(s) == 2.0 ** 112 and float(i) == 2.0 ** -112
+
+
 @pytest.mark.parametrize("mag", [1.0, 1e-6, 3e-9])
 def test_x1g_backward_products_are_the_fp16_backward_on_fp32_tensors(mag):
     """The ONE-product backward ('x1g': both operands rounded to fp16 once, the gradient operand scaled first): the same four

@@ -1,0 +1,7 @@
+#!/bin/bash
+# ON THE GPU BOX: one overlapped training step of precision PREC (default fp16x), kernel by kernel with queues (tools/step_streams.py)
+R=$PWD; export PYTHONPATH=$R; PREC=${PREC:-fp16x}
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/ps
+rocprofv3 --kernel-trace -d /tmp/ps -- python3 $R/bench.py --precision $PREC --steps 6 --warmup 3 --repeats 1 --no-parity --no-cpu-baseline --no-eval-leg --no-fp16-leg > /tmp/ps.out 2> /tmp/ps.err
+cd $R
+python3 tools/step_streams.py /tmp/ps 3

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""From a rocprofv3 --kernel-trace database of an OVERLAPPED bench.py run: every kernel of ONE training step (between two clip_adam
+launches) in start order with its queue, start offset and duration — where the trunk's chain waits while the stem co-runs."""
+import glob
+import re
+import sqlite3
+import sys
+
+db = sorted(glob.glob(sys.argv[1] + '/**/*_results.db', recursive=True))[-1]
+c = sqlite3.connect(db)
+tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+kd = [t for t in tabs if 'kernel_dispatch' in t][0]
+ks = [t for t in tabs if 'kernel_symbol' in t][0]
+cols = [r[1] for r in c.execute("pragma table_info(%s)" % kd)]
+q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+rows = c.execute("select d.start, d.end, s.kernel_name, d.%s from %s d join %s s on d.kernel_id=s.id order by d.start" % (q, kd, ks)).fetchall()
+adam = [i for i, r in enumerate(rows) if 'clip_adam' in r[2]]
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+step = rows[adam[-back] + 1:adam[-back + 1] + 1]
+t0 = step[0][0]
+qs = sorted(set(r[3] for r in step))
+print("step %.3f ms, %d kernels, queues %s" % ((step[-1][1] - t0) / 1e6, len(step), qs))
+busy = dict((k, 0.0) for k in qs)
+for s, e, n, k in step:
+    busy[k] += (e - s) / 1e3
+    name = re.sub(r"^_ZN\d+_GLOBAL__N_1\d+", "", n)
+    name = re.sub(r"^_ZN2at6native\d*", "at::", name)[:70]
+    print("q%-3s %9.1f +%8.1f us  %s" % (qs.index(k), (s - t0) / 1e3, (e - s) / 1e3, name))
+print("busy us per queue:", dict((qs.index(k), round(v, 1)) for k, v in busy.items()))

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "vnqa_stream_create_reserved": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_void_p)]),
     "vnqa_stream_create_masked": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(ctypes.c_void_p)]),
     "vnqa_conv2d_igemm_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vnqa_grad_split_scale": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "vnqa_split3_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp]),
     "vnqa_conv2d_igemm_raw": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "vnqa_x3_post": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _vp]),

@@ -151,6 +151,61 @@ extern "C" int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, in
   return VNQA_OK;
 }
 
+// The split scale of a gradient tensor in ONE launch: state = {bits of max |x| (uint), scale, 1 / scale, blocks done (uint)}.  Every
+// block folds its maximum into state[0] (non-negative floats order like their bit patterns); the last block to finish turns it into the
+// power of two that lifts max |x| into [2^12, 2^13) (1 for an all-zero or non-finite tensor), writes scale and 1 / scale, and clears the
+// two words for the next call on the same state.
+__global__ void __launch_bounds__(256) grad_scale_kernel(const float* __restrict__ x, long long n4, long long n, unsigned* __restrict__ state) {
+  float m = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = *(const float4*)(x + 4 * i);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));
+  unsigned bits = __float_as_uint(m);          // (fmaxf drops NaNs; an inf stays the maximum)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)bits, off, 64);
+    bits = o > bits ? o : bits;
+  }
+  __shared__ unsigned part[4];
+  __shared__ int last;
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = bits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned b = part[0];
+    for (int i = 1; i < 4; ++i) b = part[i] > b ? part[i] : b;
+    atomicMax(&state[0], b);
+    __threadfence();
+    last = atomicAdd(&state[3], 1u) == gridDim.x - 1;
+    if (last) {
+      const float amax = __uint_as_float(atomicMax(&state[0], 0u));
+      float scale = 1.f;
+      if (amax > 0.f && amax < __builtin_inff()) {
+        int e = ilogbf(amax);
+        e = e < -100 ? -100 : e;
+        scale = ldexpf(1.f, 12 - e);
+      }
+      ((float*)state)[1] = scale;
+      ((float*)state)[2] = 1.f / scale;
+      __threadfence();
+      state[0] = 0u;
+      state[3] = 0u;
+    }
+  }
+}
+
+extern "C" int vnqa_grad_split_scale(const float* x, int64_t n, void* state, void* stream) {
+  VNQA_CHECK_ARG(x && state && n > 0, "grad_split_scale: null pointer or n <= 0");
+  VNQA_CHECK_ARG((((uintptr_t)x | (uintptr_t)state) & 15) == 0, "grad_split_scale: 16-byte alignment");
+  const long long n4 = n / 4;
+  long long blocks = (n4 + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  hipLaunchKernelGGL(grad_scale_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n4, (long long)n, (unsigned*)state);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
 extern "C" int vnqa_x3_post(const float* raw, const float* bias, const float* post_scale, const float* post_shift,
                             const float* border_sub, void* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y,
                             int32_t y_halo, int32_t relu, int32_t pool2, int32_t out_x3, const float* raw_scale, void* stream) {

@@ -118,13 +118,22 @@ def fwd_pack_dtype(x):
     return torch.float32 if w2_active(x) else x.dtype
 
 
+_SCALE_STATES = {}
+
+
 def grad_split_scale(t):
-    """(scale, 1 / scale) as 0-dim device tensors: the power of two that lifts max |t| into [2^12, 2^13) (1 for an all-zero tensor)."""
-    lo, hi = torch.aminmax(t)                  # one pass, no |t| temporary (these tensors are 50 - 150 MB)
-    amax = torch.maximum(hi, -lo).float()
-    e = torch.clamp(torch.floor(torch.log2(torch.clamp(amax, min=1e-35))), min=-100.0)     # (scale stays a finite fp32 power of two)
-    scale = torch.where(amax > 0, torch.exp2(12.0 - e), torch.ones_like(amax))
-    return scale, 1.0 / scale
+    """(scale, 1 / scale) as 0-dim device tensors: the power of two that lifts max |t| into [2^12, 2^13) (1 for an all-zero tensor).
+    ONE launch (vnqa_grad_split_scale) on a 16-byte state from a ring of 32 per stream (a scale is consumed by the next few launches
+    of its own stream: the split, the product's finishing pass, the gradient's un-scaling)."""
+    assert t.dtype == torch.float32 and t.is_contiguous()
+    key = (str(t.device), torch.cuda.current_stream().cuda_stream)
+    ring = _SCALE_STATES.get(key)
+    if ring is None:
+        ring = _SCALE_STATES[key] = [torch.zeros((32, 4), dtype=torch.float32, device=t.device), 0]
+    st = ring[0][ring[1] % 32]
+    ring[1] += 1
+    L.check(L.lib().vnqa_grad_split_scale(L.ptr(t), t.numel(), L.ptr(st), L.stream()), "vnqa_grad_split_scale")
+    return st[1], st[2]
 
 
 _X3_WS = {}
@@ -191,16 +200,27 @@ def split3_rows(x2d, order, scale=None, name="x3rows"):
     return out
 
 
+def _split_weight(wt, parts):
+    """fp32 K-major weights [..][k] -> 16-bit [..][len(parts) * k], the halves named in `parts` ('h' / 'l') along the innermost axis,
+    in ONE pass (vnqa_split3_f32)."""
+    k = wt.shape[-1]
+    assert wt.dtype == torch.float32 and wt.is_contiguous() and k % 8 == 0 and parts in ("hhl", "hl")
+    rows = wt.numel() // k
+    out = torch.empty(wt.shape[:-1] + (len(parts) * k,), dtype=L.half_dtype(), device=wt.device)
+    base, es = out.data_ptr(), out.element_size()
+    hi, hi2, lo = (base, base + k * es, base + 2 * k * es) if parts == "hhl" else (base, None, base + k * es)
+    L.check(L.lib().vnqa_split3_f32(L.ptr(wt), ctypes.c_void_p(hi), ctypes.c_void_p(lo), ctypes.c_void_p(hi2) if hi2 else None,
+                                    rows, k, k, len(parts) * k, None, L.stream()), "vnqa_split3_f32(weights)")
+    return out
+
+
 def x3_weight(wt):
     """fp32 K-major weights [n][...][k] -> 16-bit [n][...][3k] = [w_hi | w_hi | w_lo] along the innermost (contraction) axis, cached
     on the tensor object for weights that persist (the frozen stem's packs; re-made when the tensor was modified in place)."""
     cached = getattr(wt, "_vnqa_x3", None)
     if cached is not None and cached[0] == wt._version:
         return cached[1]
-    half = L.half_dtype()
-    hi = wt.to(half)
-    lo = (wt - hi.float()).to(half)
-    w3 = torch.cat([hi, hi, lo], dim=-1).contiguous()
+    w3 = _split_weight(wt, "hhl")
     try:
         wt._vnqa_x3 = (wt._version, w3)
     except (AttributeError, RuntimeError):
@@ -214,9 +234,7 @@ def x3_weight2(wt):
     cached = getattr(wt, "_vnqa_x2", None)
     if cached is not None and cached[0] == wt._version:
         return cached[1]
-    half = L.half_dtype()
-    hi = wt.to(half)
-    w2 = torch.cat([hi, (wt - hi.float()).to(half)], dim=-1).contiguous()
+    w2 = _split_weight(wt, "hl")
     try:
         wt._vnqa_x2 = (wt._version, w2)
     except (AttributeError, RuntimeError):
@@ -390,9 +408,12 @@ def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res, tile=L.TILE_AUT
     if x3_active(x) or (w2_active(x) and wt.dtype == torch.float32):
         # the conv as an x3 / two-product conv, the FiLM affine + ReLU + residual as the separate elementwise kernel
         z = conv2d_igemm(x, wt, bias=bias)
-        g = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
-        b = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
-        g[:, :film_c], b[:, :film_c] = gamma[:, :film_c], beta[:, :film_c]
+        if film_c == c_out:
+            g, b = gamma[:, :c_out].contiguous(), beta[:, :c_out].contiguous()
+        else:
+            g = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
+            b = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
+            g[:, :film_c], b[:, :film_c] = gamma[:, :film_c], beta[:, :film_c]
         return (z if keep_z else None), film_relu_res_fwd(z, res, g, b)
     d = _conv_desc(x, c_out, c_out, taps, False, tile if taps == 9 else L.TILE_AUTO)
     z = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device) if keep_z else None
