@@ -472,7 +472,7 @@ class FiLMTrunkBase(nn.Module):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
             blocks += [c1.weight, c1.bias, c3.weight, c3.bias]
         meta.c1_packs = self._frozen_c1_packs(x.dtype, L.round_up(C, 64))
-        return ops.FilmTrunkBlocksFn.apply(h, meta, *uniq, *blocks)
+        return ops.film_trunk_blocks(h, meta, uniq, blocks)
 
     def _frozen_c1_packs(self, cdt, c_pad):
         """K-major packs (forward, flipped for dgrad) of the frozen 1x1 conv weights, re-made only when a weight was modified
