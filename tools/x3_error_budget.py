@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""ON THE GPU BOX: the logits error of precision 'fp16x' against precision 'fp32' (identical weights, train-mode forward at the
+headline size) for a LIST of knob settings, on N seeded minibatches (default 12: one full-length, the rest ragged) — the error
+budget behind the mode's defaults.  One fp32 pass, then one fp16x build + pass per setting; per setting: the maximum over the
+minibatches (the test's criterion), their RMS and mean, and how many answers differ.
+
+  python tools/x3_error_budget.py [--batches 12] "PREFIX=4 ROUND=6" "PREFIX=5 ROUND=6 TRUNK_FWD=x2" ...
+(each word KEY=VALUE sets VNQA_X3_KEY=VALUE for that setting; PLAIN_PREFIX is spelled PREFIX)"""
+import argparse
+import copy
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+
+KEYS = {"PREFIX": "VNQA_X3_PLAIN_PREFIX", "ROUND": "VNQA_X3_ROUND", "TRUNK_FWD": "VNQA_X3_TRUNK_FWD", "TRUNK": "VNQA_X3_TRUNK",
+        "RING_W2": "VNQA_RING_W2", "COH": "VNQA_COHERENT_ROUND"}
+
+
+def batches(args, device, n):
+    out = []
+    for i in range(n):
+        g = torch.Generator(device="cpu").manual_seed(777 + i)
+        B, T = args.batch, args.frames
+        clip = torch.rand(B, 3, args.height, args.width, T, generator=g)
+        q_lens = torch.randint(5, 26, (B,), generator=g)
+        q = torch.randint(1, 134, (B, 56), generator=g)
+        q = q * (torch.arange(56).unsqueeze(0) < q_lens.unsqueeze(1)).long()
+        v_lens = torch.full((B,), T, dtype=torch.long) if i == 0 else torch.randint(3, T + 1, (B,), generator=g)
+        if i > 0:
+            v_lens[0] = T
+            clip = clip * (torch.arange(T).view(1, 1, 1, 1, T) < v_lens.view(B, 1, 1, 1, 1)).float()
+        out.append((clip, q, v_lens, q_lens))
+    return out
+
+
+def run(args, prec, device, data):
+    from videonavqa_amd.train import Trainer
+    a = copy.copy(args)
+    a.precision = prec
+    model, stem, _, _ = bench.build(a, device)
+    tr = Trainer(model, stem, lr=1e-4, clip=1.0, loss_reduction="sum")
+    model.train()
+    res = []
+    with torch.no_grad():
+        for clip, q, v_lens, q_lens in data:
+            native, v_sorted, perm = tr.extract_features(clip.to(device), v_lens)
+            model.init_hidden()
+            out = model(native, q.to(device)[perm.to(device)], v_sorted, q_lens[perm])
+            res.append(out.float().cpu())
+    del tr, model, stem
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batches", type=int, default=12)
+    ap.add_argument("--precision", default="fp16x", help="the precision under test (fp16x, fp16w, fp16)")
+    ap.add_argument("settings", nargs="*", default=["PREFIX=4 ROUND=6"])
+    o = ap.parse_args()
+    args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
+                              tail_channels=0)
+    from videonavqa_amd import _lib as L
+    L.set_half("f16")
+    device = torch.device("cuda", 0)
+    data = batches(args, device, o.batches)
+    ref = run(args, "fp32", device, data)
+    print("%-44s %8s %8s %8s  %s   per batch (x 1e-3)" % ("setting", "max", "rms", "mean", "flips"), flush=True)
+    for s in o.settings:
+        saved = {}
+        for word in s.split():
+            k, v = word.split("=")
+            k = KEYS.get(k, k)
+            saved[k] = os.environ.get(k)
+            os.environ[k] = v
+        got = run(args, o.precision, device, data)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k)
+            else:
+                os.environ[k] = v
+        rel = [float((g - r).abs().max() / r.abs().max()) * 1e3 for g, r in zip(got, ref)]
+        flips = sum(int((g.argmax(1) != r.argmax(1)).sum()) for g, r in zip(got, ref))
+        rms = (sum(x * x for x in rel) / len(rel)) ** 0.5
+        print("%-44s %8.3f %8.3f %8.3f  %d/%d   %s" % (s, max(rel), rms, sum(rel) / len(rel), flips, 8 * len(rel),
+                                                    " ".join("%.2f" % x for x in rel)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

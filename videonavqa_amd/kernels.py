@@ -88,7 +88,9 @@ class f32_conv_mode(object):
         # igemm's wrap variant, VNQA_CONV_X_WRAP2: no copy, fused epilogues as usual)
         # 'x1g': the backward pass as ONE fp16 product per contraction (both operands rounded once, the gradient operand scaled like
         # 'x3g'): the fp16 precision's backward arithmetic on the fp32-stored tensors of precision 'fp16x' — a third of x3g's matrix work
-        assert mode in ("x3", "x3g", "x1g", "w2", "exact")
+        # 'x2': forward products with the fp32 activation rounded ONCE to fp16 against [w_hi | w_lo] — two products instead of three
+        # for one more fp16 rounding per layer input (the trunk's VNQA_X3_TRUNK_FWD=x2 option)
+        assert mode in ("x3", "x2", "x3g", "x1g", "w2", "exact")
         self.mode = mode
 
     def __enter__(self):
@@ -101,7 +103,7 @@ class f32_conv_mode(object):
 
 
 def x3_active(t):
-    return _F32_CONV_MODE[0] in ("x3", "x3g", "x1g") and t.dtype == torch.float32 and t.is_cuda
+    return _F32_CONV_MODE[0] in ("x3", "x2", "x3g", "x1g") and t.dtype == torch.float32 and t.is_cuda
 
 
 def x3_mode():
@@ -259,6 +261,12 @@ def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo,
         w3 = x1_weight(wt).view(c_out, taps, k)
         scale, inv = grad_split_scale(x)
         xin = cast_hi(x.view(N * Hp * Wp, Cin), scale=scale)
+    elif x.dtype == torch.float32 and _F32_CONV_MODE[0] == "x2" and Cin % 64 == 0:   # two products: fp16(x) read twice against [w_hi | w_lo]
+        assert Cx == Cin
+        k = 2 * Cin
+        w3 = x3_weight2(wt).view(c_out, taps, k)
+        xin = cast_hi(x.view(N * Hp * Wp, Cin), name="x2in")
+        wrap = L.CONV_X_WRAP2
     elif x.dtype == torch.float32:
         assert Cx == Cin
         k = 3 * Cin
@@ -307,7 +315,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
                  x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False, desc_flags=0):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
     (x3_out: only inside f32_conv_mode("x3") — the output as the next x3 product's 16-bit operand, see _conv2d_x3.)"""
-    x3m = _F32_CONV_MODE[0] in ("x3", "x3g", "x1g") and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
+    x3m = _F32_CONV_MODE[0] in ("x3", "x2", "x3g", "x1g") and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
         relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 and x.shape[-1] % 64 == 0
     # inside the x3 mode a layer with a plain 16-bit input AND a rounded (plain 16-bit) output is exactly the two-product conv of
     # precision 'fp16w': one launch of the wrap variant with its fused epilogue instead of raw sums + a post pass
@@ -899,8 +907,12 @@ def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
         if _F32_CONV_MODE[0] in ("x3g", "x1g"):   # `a` is a gradient (dX = dOut . W): lifted into fp16's range, divided out below
             assert bias is None and not relu
             scale, inv = grad_split_scale(a)
+        gflags = L.BF16 | L.GEMM_OUT_F32
         if _F32_CONV_MODE[0] == "x1g":            # one product
             kk, a3, b3 = Kd, cast_hi(a, scale=scale), x1_weight(b)
+        elif _F32_CONV_MODE[0] == "x2":           # two products: fp16(a) read twice against [b_hi | b_lo]
+            kk, a3, b3 = 2 * Kd, cast_hi(a, name="x2in"), x3_weight2(b)
+            gflags |= L.GEMM_X_WRAP2
         else:
             kk = 3 * Kd
             a3 = split3(a, out=_x3_buffer("x3in", M * 3 * Kd, L.half_dtype(), a.device).view(M, 3 * Kd), scale=scale)
@@ -911,7 +923,7 @@ def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
         ws_bytes = max(L.lib().vnqa_gemm_nt_workspace(M, N, kk, L.BF16) if split_k else 0, M * N * 4)
         ws = workspace(ws_bytes, a.device)
         L.check(L.lib().vnqa_gemm_nt(L.ptr(a3), L.ptr(b3), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, kk, out.stride(0),
-                                     1 if relu else 0, L.BF16 | L.GEMM_OUT_F32, L.stream()), "vnqa_gemm_nt(x3)")
+                                     1 if relu else 0, gflags, L.stream()), "vnqa_gemm_nt(x3)")
         if inv is not None:
             out.mul_(inv)
         return out

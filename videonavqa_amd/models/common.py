@@ -273,7 +273,8 @@ class FiLMTrunkBase(nn.Module):
     def __call__(self, *args, **kwargs):
         # precision='fp16x' (self.x3): convs / GEMMs on fp32 tensors inside this forward run as x3 products; the backward pass,
         # which runs after this context has closed, keeps the exact-f32 matrix path
-        mode = "x3" if self.__dict__.get("x3", False) else ("w2" if self.__dict__.get("w2", False) else None)
+        # (VNQA_X3_TRUNK_FWD=x2: two products per contraction, the layer inputs rounded once to fp16)
+        mode = os.environ.get("VNQA_X3_TRUNK_FWD", "x3") if self.__dict__.get("x3", False) else ("w2" if self.__dict__.get("w2", False) else None)
         if mode is not None:
             with K.f32_conv_mode(mode):
                 return super().__call__(*args, **kwargs)

@@ -21,7 +21,7 @@ assert _X3_BWD_MODE in ("x3g", "x1g")
 
 def _x3_forward(ctx):
     """precision='fp16x': remember that this node's forward ran its contractions as x3 products (kernels.f32_conv_mode) ..."""
-    ctx.x3 = K.x3_mode() == "x3"
+    ctx.x3 = K.x3_mode() in ("x3", "x2")
 
 
 def _x3_backward(ctx):

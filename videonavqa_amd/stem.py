@@ -66,6 +66,82 @@ def get_frcnn_feature_extractor(path=None, precision='bf16'):
     return m.eval()
 
 
+def coherent_round(w, m, dtype):
+    """Weights w [c_out, c_in, kh, kw] (fp32) rounded to `dtype` (a 16-bit format) so that the rounding errors of each OUTPUT channel
+    cancel against the mean input:  sum_{c_in, taps} m[c_in] * (w16 - w) ~ 0  instead of a random walk of c_in * taps half-ulps.
+    Round-to-nearest everywhere, then per output channel the few weights nearest to a rounding midpoint (cheapest to move) whose
+    flip to the OTHER neighbour moves the weighted residual towards zero are flipped, as many as minimise |residual|.
+    The coherent part of a frozen layer's weight-rounding error — a constant offset per output channel wherever the input has its
+    usual mean, which no later spatial / temporal averaging removes — goes; the incoherent part (zero-mean over pixels) grows by the
+    few flipped weights only.  Returns fp32 values that are exactly representable in `dtype`."""
+    co = w.shape[0]
+    wf = w.detach().float().reshape(co, w.shape[1], -1)
+    r = wf.to(dtype)
+    bits = r.view(torch.int16).to(torch.int32)
+    rf = r.float()
+    up = rf < wf                                   # the other neighbour lies above (towards +inf) / below the nearest one
+    mag_up = (rf > 0) | ((rf == 0) & up)           # moving towards +inf grows the magnitude of a positive value (bits + 1) ...
+    step = torch.where(up == mag_up, torch.ones_like(bits), -torch.ones_like(bits))
+    ob = bits + step
+    # (crossing zero: the neighbour of +-0 is the smallest subnormal of the other sign's direction)
+    zero = rf == 0
+    ob = torch.where(zero, torch.where(up, torch.ones_like(bits), torch.full_like(bits, -32767)), ob)      # 0x0001 / 0x8001
+    other = ob.to(torch.int16).view(dtype).float()
+    exact = rf == wf
+    d0, d1 = rf - wf, other - wf
+    mm = m.detach().float().view(1, -1, 1).to(wf.device).expand_as(wf)
+    R = (mm * d0).sum((1, 2))                                            # [co] weighted residual of round-to-nearest
+    delta = (mm * (d1 - d0)).reshape(co, -1)                             # change of R when element j flips
+    cost = (d1.abs() - d0.abs()).reshape(co, -1)
+    ok = (delta * R.view(-1, 1) < 0) & ~exact.reshape(co, -1) & torch.isfinite(other).reshape(co, -1)
+    cost = torch.where(ok, cost, torch.full_like(cost, float("inf")))
+    order = cost.argsort(dim=1)
+    dsort = torch.gather(torch.where(ok, delta, torch.zeros_like(delta)), 1, order)
+    csum = torch.cumsum(dsort, 1)
+    resid = torch.cat([R.view(-1, 1), R.view(-1, 1) + csum], 1).abs()    # residual after flipping the k cheapest candidates
+    k = resid.argmin(1)                                                  # [co]
+    rank = torch.empty_like(order)
+    rank.scatter_(1, order, torch.arange(order.shape[1], device=order.device).view(1, -1).expand_as(order))
+    flip = (rank < k.view(-1, 1)) & ok
+    out = torch.where(flip.view_as(rf), other, rf)
+    return out.view_as(w)
+
+
+@torch.no_grad()
+def calibration_means(vgg, od, frames=4, height=224, width=224, seed=4242):
+    """Per-input-channel mean activation at every stem layer's input, from an fp32 torch pass of `frames` calibration frames
+    (uniform noise, like the benchmark's synthetic clips; a deployment would pass real frames): what coherent_round cancels against."""
+    import torch.nn.functional as F
+    f = vgg.features
+    dev = f["0"].weight.device
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(frames, 3, height, width, generator=g).to(dev)
+    mean = lambda t: t.float().mean((0, 2, 3)).cpu()
+    conv = lambda t, c: F.conv2d(t, c.weight.float(), c.bias.float(), padding=1)
+    bn = lambda t, b: F.batch_norm(t, b.running_mean.float(), b.running_var.float(), b.weight.float(), b.bias.float(), False, 0.0, BN_EPS)
+    m = {"first": mean(x)}
+    a = F.relu(conv(x, f["0"]))
+    m["vgg0"] = mean(a)
+    a = F.max_pool2d(F.relu(conv(a, f["2"])), 2)
+    m["vgg1"] = mean(a)
+    a = F.relu(conv(a, f["5"]))
+    m["vgg2"] = mean(a)
+    a = F.max_pool2d(F.relu(conv(a, f["7"])), 2)
+    a = bn(a, od.bn_input)
+    m["od0"] = mean(a)
+    a = conv(a, od.conv11)
+    m["od1"] = mean(a)
+    a = F.max_pool2d(F.relu(bn(conv(a, od.conv12), od.bn1)), 2)
+    m["od2"] = mean(a)
+    a = conv(a, od.conv21)
+    m["od3"] = mean(a)
+    a = F.max_pool2d(F.relu(bn(conv(a, od.conv22), od.bn2)), 2)
+    m["od4"] = mean(a)
+    a = conv(a, od.conv31)
+    m["od5"] = mean(a)
+    return m
+
+
 def _fold_bn(bn):
     scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + BN_EPS)
     shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
@@ -93,10 +169,19 @@ class FrozenStem(object):
         # VNQA_PERSISTENT_RESERVE_CUS is the stand-alone A/B knob (8: -12 % on one GPU; multi-GPU investigation)
         self.reserve_cus = int(os.environ.get("VNQA_PERSISTENT_RESERVE_CUS", "0"))
         self.timing = None   # bench hook: list collecting (start event, end event, FLOPs, kernel) of the C_out = 512 stem launches
+        # VNQA_COHERENT_ROUND=1 (experiment): the frozen 16-bit weights rounded so that each output channel's rounding errors cancel
+        # against the mean input activation (coherent_round; means from an fp32 calibration pass) instead of round-to-nearest
+        self.calib = None
+        if os.environ.get("VNQA_COHERENT_ROUND", "0") == "1" and vgg is not None and objdet is not None and precision not in ("fp32",):
+            self.calib = calibration_means(vgg, objdet)
+        cm = lambda k: None if self.calib is None else self.calib[k]
         if vgg is not None:
             f = vgg.features
             dev = f["0"].weight.device
-            self.first = (f["0"].weight.detach().float().contiguous(), f["0"].bias.detach().float().contiguous())
+            w0 = f["0"].weight.detach().float().contiguous()
+            if self.calib is not None and (precision != "fp16x" or os.environ.get("VNQA_X3_PLAIN_FIRST", "1") != "0"):
+                w0 = coherent_round(w0, cm("first"), L.half_dtype()).contiguous()
+            self.first = (w0, f["0"].bias.detach().float().contiguous())
             # fp16x: conv1_1 + conv1_2 — 3.6 GB of fp32 activations each at 280 frames, HBM-bound as x3 products (8.4 of the all-x3
             # stem's 32 ms) — run as the plain fp16 fused kernel by default (1.05 ms): five fp16 roundings (clip, two weight sets,
             # two activations) stay in the forward pass, ~0.5e-3 of logits error instead of ~1e-5 (VNQA_X3_PLAIN_FIRST=0: all x3)
@@ -113,17 +198,20 @@ class FrozenStem(object):
             # the early / middle layers' weight roundings cost far less logits error than their 2 - 3 x matrix work buys.
             self.x3_prefix = max(1 if self.x3_plain_first else 0, int(os.environ.get("VNQA_X3_PLAIN_PREFIX", "4"))) if self.x3 else 0
             hp = lambda i: L.half_dtype() if (i < self.x3_prefix or (self.w2 and i == 0)) else None
-            self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=hp(0)),
-                               self._layer(f["5"], relu=True, pool=False, cdt=hp(1)),
-                               self._layer(f["7"], relu=True, pool=True, cdt=hp(2))]
+            self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=hp(0), m=cm("vgg0")),
+                               self._layer(f["5"], relu=True, pool=False, cdt=hp(1), m=cm("vgg1")),
+                               self._layer(f["7"], relu=True, pool=True, cdt=hp(2), m=cm("vgg2"))]
         if objdet is not None:
             od = objdet
             self.bn_input = _fold_bn(od.bn_input)
             pre = getattr(self, "x3_prefix", 0)
             hq = lambda i: L.half_dtype() if i < pre else None       # (stem layer index: 3 = the conv11 / conv12 pair, 4 = conv21, ...)
-            self.layers_od = [self._layer(od.conv11, cdt=hq(3)), self._layer(od.conv12, bn=od.bn1, relu=True, pool=True, cdt=hq(3)),
-                              self._layer(od.conv21, cdt=hq(4)), self._layer(od.conv22, bn=od.bn2, relu=True, pool=True, cdt=hq(5)),
-                              self._layer(od.conv31, cdt=hq(6)), self._layer(od.conv32, bn=od.bn3, relu=True, pool=False)]
+            self.layers_od = [self._layer(od.conv11, cdt=hq(3), m=cm("od0")),
+                              self._layer(od.conv12, bn=od.bn1, relu=True, pool=True, cdt=hq(3), m=cm("od1")),
+                              self._layer(od.conv21, cdt=hq(4), m=cm("od2")),
+                              self._layer(od.conv22, bn=od.bn2, relu=True, pool=True, cdt=hq(5), m=cm("od3")),
+                              self._layer(od.conv31, cdt=hq(6), m=cm("od4")),
+                              self._layer(od.conv32, bn=od.bn3, relu=True, pool=False, m=cm("od5"))]
             # conv12 is applied straight to conv11's output (obj_detector.py:72: no nonlinearity between the two convs of
             # a pair) and both are frozen: when the pair's 3x3 (c_in -> c_mid) . 3x3 (c_mid -> c_out) costs more than one
             # 5x5 (c_in -> c_out) — 9*c_in + 9*c_mid > 25*c_in, true for 128 -> 512 -> 512 only — it is evaluated as the
@@ -151,12 +239,12 @@ class FrozenStem(object):
                     # (x3 conv2_2: its output also as fp32, for the exact-f32 border-correction GEMMs)
                     self.layers_vgg[-1]["dual"] = self.x3 and self.layers_vgg[-1].get("cdt") is None
 
-    def _layer(self, conv, bn=None, relu=False, pool=False, cdt=None):
+    def _layer(self, conv, bn=None, relu=False, pool=False, cdt=None, m=None):
         if cdt is not None:          # a layer in another storage dtype than the stem's (fp16x: the plain fp16 first layer)
             keep, keep_x3 = self.cdt, self.x3
             self.cdt, self.x3 = cdt, False
             try:
-                ly = self._layer(conv, bn, relu, pool)
+                ly = self._layer(conv, bn, relu, pool, m=m)
             finally:
                 self.cdt, self.x3 = keep, keep_x3
             ly["cdt"] = cdt
@@ -170,6 +258,11 @@ class FrozenStem(object):
             scale, shift = _fold_bn(bn)
             b = b * scale + shift
         bf16 = L.is_half(self.cdt)      # 16-bit storage (bf16 or, in the fp16 build, fp16): the MFMA fast path
+        w32, scale32 = w, scale
+        if m is not None and bf16 and not self.x3:
+            # (the BN scale folded first: the values the kernel multiplies with are the ones rounded)
+            w = coherent_round(w if scale is None else w * scale.view(-1, 1, 1, 1), m, self.cdt)
+            scale = None
         if bf16 and c_in_pad == 64:
             tile = None                      # conv_c64 direct kernel (row layout, LDS-resident weights)
         elif bf16:
@@ -195,7 +288,7 @@ class FrozenStem(object):
         ly = dict(wt=wt, bias=K.pad_vec(b, c_out_pad), relu=relu, pool=pool, post=None,
                   c_out=c_out, c_in=c_in, c_out_pad=c_out_pad, tile=tile)
         if self.w2:      # the fp32 K-major pack: the conv wrapper splits it into [w_hi | w_lo] once (cached on the tensor)
-            ly["wt32"] = K.pack_conv_weight(w, torch.float32, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+            ly["wt32"] = K.pack_conv_weight(w32, torch.float32, out_scale=scale32, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         # short-K layers of the VGG front (conv1_2 / conv2_1 / conv2_2 shapes): weights-stationary-in-registers direct conv
         # (csrc/conv_wreg.hip) when the run-time geometry has whole tiles; it reads the K-major row pack
         if bf16 and relu and (c_in_pad, c_out_pad, bool(pool)) in ((64, 64, True), (64, 128, False), (128, 128, True)) \
@@ -235,6 +328,9 @@ class FrozenStem(object):
         if bf16 and os.environ.get("VNQA_STEM_COMPOSE_TILE"):
             tile = int(os.environ["VNQA_STEM_COMPOSE_TILE"])      # A/B hook
         wcf = wc.float().contiguous().to(dev)
+        wcf32 = wcf
+        if getattr(self, "calib", None) is not None and bf16 and not self.x3:
+            wcf = coherent_round(wcf, self.calib["od0"], self.cdt).contiguous()
         if tile in (L.TILE_STEM_256x256, L.TILE_STEM_I5_256x256) and os.environ.get("VNQA_STEM_TILED", "1") != "0" and not self.x3:
             wt = K.pack_conv_weight_tiled(wcf, self.cdt, tile, c_out_pad=co_pad, c_in_pad=ci_pad)
         else:
@@ -257,7 +353,7 @@ class FrozenStem(object):
                 return e.view(co_pad, -1).float().to(dev).contiguous()
             edges32 = dict(top=edge32(w2[:, :, 0, :]), bottom=edge32(w2[:, :, 2, :]), left=edge32(w2[:, :, :, 0]), right=edge32(w2[:, :, :, 2]))
         edges_all = torch.stack([edges[k] for k in ("top", "bottom", "left", "right")]).contiguous()   # [4, co_pad, 3*cm_pad]
-        return dict(wt=wt, wt32=K.pack_conv_weight(wcf, torch.float32, c_out_pad=co_pad, c_in_pad=ci_pad) if self.w2 else None,
+        return dict(wt=wt, wt32=K.pack_conv_weight(wcf32, torch.float32, c_out_pad=co_pad, c_in_pad=ci_pad) if self.w2 else None,
                     bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges,
                     w1m32=w1m32, edges32=edges32,
                     edges_all=edges_all,
