@@ -1,0 +1,57 @@
+"""CPU: coherent rounding of frozen 16-bit weights (videonavqa_amd.stem.coherent_round) — pure tensor arithmetic, no GPU:
+every weight stays one of the two 16-bit neighbours of its fp32 value, and each output channel's rounding errors cancel against
+the mean input activation."""
+import pytest
+import torch
+
+from videonavqa_amd.stem import coherent_round
+
+
+def _neighbours(w, dt):
+    r = w.to(dt).float()
+    step = torch.where(r < w, torch.full_like(w, float("inf")), torch.full_like(w, float("-inf")))
+    other = torch.nextafter(r.to(dt), step.to(dt)).float()
+    return r, other
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(128, 64, 3, 3), (64, 3, 3, 3), (32, 128, 5, 5)])
+def test_coherent_round_properties(dt, shape):
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(shape, generator=g) / (shape[1] * shape[2] * shape[3]) ** 0.5
+    w[0, :, 0, 0] = 0.0                                     # exact zeros (channel padding) ...
+    w[1] = w[1].to(dt).float()                              # ... and exactly representable rows stay as they are
+    m = torch.rand(shape[1], generator=g) + 0.1
+    q = coherent_round(w, m, dt)
+    assert q.shape == w.shape and q.dtype == torch.float32
+    assert (q.to(dt).float() == q).all()                    # representable
+    near, other = _neighbours(w, dt)
+    assert ((q == near) | (q == other)).all()               # one of the two neighbours: element-wise error below one ulp
+    assert (q[0, :, 0, 0] == 0).all() and (q[1] == w[1]).all()
+    mm = m.view(1, -1, 1, 1)
+    r_rtn = ((near - w) * mm).sum((1, 2, 3))
+    r_coh = ((q - w) * mm).sum((1, 2, 3))
+    small = shape[1] * shape[2] * shape[3] < 100          # conv1_1's 27 weights per channel: few candidates, coarser cancellation
+    assert float(r_coh.pow(2).mean().sqrt()) < (0.3 if small else 0.15) * float(r_rtn.pow(2).mean().sqrt())
+    assert (r_coh.abs() <= r_rtn.abs() + 1e-12).all()       # never worse than round-to-nearest on any channel
+    # the price: the few flipped weights (near a rounding midpoint) add < 2 % to the element-wise rms error
+    assert float((q - w).pow(2).mean().sqrt()) < (1.25 if small else 1.02) * float((near - w).pow(2).mean().sqrt())
+    assert float((q != near).float().mean()) < (0.2 if small else 0.08)
+
+
+def test_coherent_round_output_error_on_positive_inputs():
+    """What it buys: on inputs with a positive mean (post-ReLU activations) the MEAN over pixels of a conv's output error — the part
+    later pooling cannot average away — drops by > 5x on fresh data; the total rms error does not grow."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(2)
+    C = 32
+    w = torch.randn(64, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    calib = torch.relu(torch.randn(4, C, 24, 24, generator=g) + 0.5)
+    fresh = torch.relu(torch.randn(8, C, 24, 24, generator=g) + 0.5)
+    q = coherent_round(w, calib.mean((0, 2, 3)), torch.float16)
+    ref = F.conv2d(fresh.double(), w.double())
+    e_rtn = F.conv2d(fresh.double(), w.half().double()) - ref
+    e_coh = F.conv2d(fresh.double(), q.double()) - ref
+    coh = lambda e: float(e.mean((0, 2, 3)).pow(2).mean().sqrt())
+    assert coh(e_coh) < 0.2 * coh(e_rtn)
+    assert float(e_coh.pow(2).mean().sqrt()) < float(e_rtn.pow(2).mean().sqrt())

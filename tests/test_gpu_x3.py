@@ -305,6 +305,98 @@ def test_fp16x_stem_vs_exact_f32_stem(plain_first, round_n, prefix, monkeypatch)
     assert a.dtype == torch.float32 and float((a - b).abs().max()) < ((3e-3 if prefix <= 1 else 6e-3) if plain_first else 5e-5) * float(b.abs().max())
 
 
+def _random_stem(prec, filters=512):
+    import torch.nn as nn
+    from videonavqa_amd.models import ObjDetectCNN
+    from videonavqa_amd.stem import VGGFront
+    torch.manual_seed(0)
+    vgg, od = VGGFront(prec), ObjDetectCNN(5, filters, 8, 0, True, True, precision=prec)
+    with torch.no_grad():
+        for conv in vgg.features.values():
+            nn.init.kaiming_uniform_(conv.weight, a=1.0)
+        for m in od.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1.0)
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.8, 1.2)
+    return vgg.cuda().eval(), od.cuda().eval()
+
+
+def test_calibration_means_match_a_torch_fp32_pass():
+    """stem.calibration_means (the library's exact-f32 stem with tapped layer outputs) against the same means from torch fp32
+    convolutions of the reference layer sequence (VGG-16 features[0:10]; models/obj_detector.py:69-86 in eval mode)."""
+    import torch.nn.functional as F
+    from videonavqa_amd.stem import BN_EPS, calibration_means
+    torch.set_grad_enabled(False)
+    vgg, od = _random_stem("fp32")
+    frames = torch.rand(3, 3, 64, 96, generator=torch.Generator().manual_seed(9))
+    got = calibration_means(vgg, od, frames)
+    f = vgg.features
+    conv = lambda t, c: F.conv2d(t, c.weight.float(), c.bias.float(), padding=1)
+    bn = lambda t, b: F.batch_norm(t, b.running_mean, b.running_var, b.weight, b.bias, False, 0.0, BN_EPS)
+    mean = lambda t: t.double().mean((0, 2, 3)).float().cpu()
+    x = frames.cuda()
+    want = {"first": mean(x)}
+    a = F.relu(conv(x, f["0"])); want["vgg0"] = mean(a)
+    a = F.max_pool2d(F.relu(conv(a, f["2"])), 2); want["vgg1"] = mean(a)
+    a = F.relu(conv(a, f["5"])); want["vgg2"] = mean(a)
+    a = bn(F.max_pool2d(F.relu(conv(a, f["7"])), 2), od.bn_input); want["od0"] = mean(a)
+    a = conv(a, od.conv11)                                    # (od1 is formed analytically from od0: exact away from the border)
+    a = F.max_pool2d(F.relu(bn(conv(a, od.conv12), od.bn1)), 2); want["od2"] = mean(a)
+    a = conv(a, od.conv21); want["od3"] = mean(a)
+    a = F.max_pool2d(F.relu(bn(conv(a, od.conv22), od.bn2)), 2); want["od4"] = mean(a)
+    a = conv(a, od.conv31); want["od5"] = mean(a)
+    for k, w in want.items():
+        assert got[k].shape == w.shape, k
+        assert float((got[k] - w).abs().max()) < 2e-4 * max(float(w.abs().max()), 1e-3), (k, float((got[k] - w).abs().max()))
+    assert got["od1"].shape == (od.conv11.out_channels,)
+    torch.set_grad_enabled(True)
+
+
+def test_coherent_rounding_removes_the_per_channel_offset_of_the_fp16_stem():
+    """The fp16-storage stem with coherently rounded weights (calibration on noise frames) against round-to-nearest, both compared
+    with the exact-f32 stem on a DIFFERENT clip: the per-channel mean of the feature error (what pooling cannot average away) drops
+    by more than 2x; the weights differ in a few percent of the entries only."""
+    from videonavqa_amd.models.common import FrameLayout
+    from videonavqa_amd.stem import FrozenStem
+    clip = torch.rand(2, 3, 64, 96, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    lay = FrameLayout([3, 2], 3, "cuda")
+    feats = {}
+    for name, prec, cal in (("ref", "fp32", None), ("rtn", "fp16", None), ("coh", "fp16", "noise")):
+        vgg, od = _random_stem(prec)
+        stem = FrozenStem(vgg, od, prec, calibration=cal)
+        assert (stem.calib is not None) == (cal is not None)
+        feats[name] = stem.forward_clip(clip, lay.img_of, lay.n_img).float()[:, 1:-1, 1:-1, :512].clone()
+    off = lambda k: float((feats[k] - feats["ref"]).mean((0, 1, 2)).pow(2).mean().sqrt())
+    rms = lambda k: float((feats[k] - feats["ref"]).pow(2).mean().sqrt())
+    assert off("coh") < 0.5 * off("rtn"), (off("coh"), off("rtn"))
+    assert rms("coh") < 1.05 * rms("rtn"), (rms("coh"), rms("rtn"))
+
+
+def test_fp16x_default_meets_1e3_on_twelve_full_size_minibatches():
+    """The tolerance mode's DEFAULT setting on twelve seeded minibatches of BASELINE.json's size (one full-length, eleven ragged;
+    tools/x3_error_budget.py): max |d logit| / max |logit| against the exact-f32 precision <= 1e-3 on every one of them (the
+    three-minibatch parity block of bench.py under-samples the maximum: with round-to-nearest stem weights the same setting reads
+    0.95 / 1.00 / 1.20 x 1e-3 on three of these twelve), all 96 answer classes equal."""
+    import argparse
+    import importlib.util
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    spec = importlib.util.spec_from_file_location("x3_error_budget", os.path.join(root, "tools", "x3_error_budget.py"))
+    eb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(eb)
+    args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
+                              tail_channels=0)
+    dev = torch.device("cuda", 0)
+    data = eb.batches(args, dev, 12)
+    ref = eb.run(args, "fp32", dev, data)
+    got = eb.run(args, "fp16x", dev, data)
+    rel = [float((g - r).abs().max() / r.abs().max()) for g, r in zip(got, ref)]
+    assert max(rel) <= 1e-3, rel
+    assert all(bool((g.argmax(1) == r.argmax(1)).all()) for g, r in zip(got, ref))
+    assert (sum(x * x for x in rel) / len(rel)) ** 0.5 < 0.8e-3, rel
+
+
 def test_fp16x_meets_1e3_on_all_three_full_size_parity_batches():
     """the tolerance-compliant 16-bit-MFMA mode at BASELINE.json's full size (8 clips x 35 frames x 224 x 224, default
     FiLM-attn model): logits within 1e-3 of the exact-f32 precision on ALL THREE parity minibatches (north star's tolerance —

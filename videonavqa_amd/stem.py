@@ -108,37 +108,35 @@ def coherent_round(w, m, dtype):
 
 
 @torch.no_grad()
-def calibration_means(vgg, od, frames=4, height=224, width=224, seed=4242):
-    """Per-input-channel mean activation at every stem layer's input, from an fp32 torch pass of `frames` calibration frames
-    (uniform noise, like the benchmark's synthetic clips; a deployment would pass real frames): what coherent_round cancels against."""
-    import torch.nn.functional as F
-    f = vgg.features
-    dev = f["0"].weight.device
-    g = torch.Generator().manual_seed(seed)
-    x = torch.rand(frames, 3, height, width, generator=g).to(dev)
-    mean = lambda t: t.float().mean((0, 2, 3)).cpu()
-    conv = lambda t, c: F.conv2d(t, c.weight.float(), c.bias.float(), padding=1)
-    bn = lambda t, b: F.batch_norm(t, b.running_mean.float(), b.running_var.float(), b.weight.float(), b.bias.float(), False, 0.0, BN_EPS)
-    m = {"first": mean(x)}
-    a = F.relu(conv(x, f["0"]))
-    m["vgg0"] = mean(a)
-    a = F.max_pool2d(F.relu(conv(a, f["2"])), 2)
-    m["vgg1"] = mean(a)
-    a = F.relu(conv(a, f["5"]))
-    m["vgg2"] = mean(a)
-    a = F.max_pool2d(F.relu(conv(a, f["7"])), 2)
-    a = bn(a, od.bn_input)
-    m["od0"] = mean(a)
-    a = conv(a, od.conv11)
-    m["od1"] = mean(a)
-    a = F.max_pool2d(F.relu(bn(conv(a, od.conv12), od.bn1)), 2)
-    m["od2"] = mean(a)
-    a = conv(a, od.conv21)
-    m["od3"] = mean(a)
-    a = F.max_pool2d(F.relu(bn(conv(a, od.conv22), od.bn2)), 2)
-    m["od4"] = mean(a)
-    a = conv(a, od.conv31)
-    m["od5"] = mean(a)
+def calibration_means(vgg, od, frames=None, n_frames=4, height=224, width=224, seed=4242):
+    """Per-input-channel mean activation at every stem layer's input — what coherent_round cancels against — from ONE pass of
+    calibration frames [N, 3, H, W] (values in [0, 1]) through the library's own exact-f32 stem (a FrozenStem of precision 'fp32'
+    with its layer outputs tapped).  Default frames: seeded uniform noise, the benchmark's kind of data; a deployment passes
+    frames of its own videos.  Keys: first = conv1_1's input, vgg0 / vgg1 / vgg2 = conv1_2 / conv2_1 / conv2_2, od0 = conv11 (and
+    the composed 5x5 pair), od1 = conv12, od2 .. od5 = conv21 .. conv32."""
+    dev = vgg.features["0"].weight.device
+    if frames is None:
+        frames = torch.rand(n_frames, 3, height, width, generator=torch.Generator().manual_seed(seed))
+    frames = frames.float().to(dev)
+    N, _, H, W = frames.shape
+    ref = FrozenStem(vgg, od, "fp32")
+    ref._tap = {}
+    clip = frames.permute(1, 2, 3, 0).unsqueeze(0).contiguous()                  # [1, 3, H, W, T]
+    ref.forward_clip(clip, torch.arange(N, dtype=torch.int32, device=dev), N)
+
+    def mean(key, c):
+        t = ref._tap[key]                                                        # padded NHWC fp32, zero halo
+        halo = 2 if key == ("vgg", 2) and ref.composed is not None else 1
+        n, hp, wp, _ = t.shape
+        return (t.double().sum((0, 1, 2)) / (n * (hp - 2 * halo) * (wp - 2 * halo)))[:c].float().cpu()
+    m = {"first": frames.double().mean((0, 2, 3)).float().cpu(),
+         "vgg0": mean("first", 64), "vgg1": mean(("vgg", 0), 64), "vgg2": mean(("vgg", 1), 128), "od0": mean(("vgg", 2), 128)}
+    # conv12's input is conv11's output, a linear function of od0 (no nonlinearity inside a pair): its mean follows analytically
+    w11, b11 = od.conv11.weight.detach().double().cpu(), od.conv11.bias.detach().double().cpu()
+    m["od1"] = (w11.sum((2, 3)) @ m["od0"].double() + b11).float()
+    c = od.conv12.out_channels
+    m["od2"] = mean(("od", "c") if ref.composed is not None else ("od", 1), c)
+    m["od3"], m["od4"], m["od5"] = mean(("od", 2), od.conv21.out_channels), mean(("od", 3), c), mean(("od", 4), od.conv31.out_channels)
     return m
 
 
@@ -151,7 +149,7 @@ def _fold_bn(bn):
 class FrozenStem(object):
     """Execution plan (packed weights + persistent activation buffers) for the frozen stem."""
 
-    def __init__(self, vgg, objdet, precision='bf16', out_half=False):
+    def __init__(self, vgg, objdet, precision='bf16', out_half=False, calibration="auto"):
         from .models.common import compute_dtype
         self.cdt = compute_dtype(precision)
         self.x3 = precision == "fp16x"       # fp32 storage, contractions as three fp16-half products (kernels.f32_conv_mode)
@@ -169,11 +167,20 @@ class FrozenStem(object):
         # VNQA_PERSISTENT_RESERVE_CUS is the stand-alone A/B knob (8: -12 % on one GPU; multi-GPU investigation)
         self.reserve_cus = int(os.environ.get("VNQA_PERSISTENT_RESERVE_CUS", "0"))
         self.timing = None   # bench hook: list collecting (start event, end event, FLOPs, kernel) of the C_out = 512 stem launches
-        # VNQA_COHERENT_ROUND=1 (experiment): the frozen 16-bit weights rounded so that each output channel's rounding errors cancel
-        # against the mean input activation (coherent_round; means from an fp32 calibration pass) instead of round-to-nearest
+        # calibration: how the frozen 16-bit weights are rounded.  None = round-to-nearest; "noise" or a tensor of frames
+        # [N, 3, H, W] = coherent_round against the mean input activations measured on those frames (calibration_means): each output
+        # channel's rounding errors cancel against the mean input, the part of the weight-rounding error that is a constant offset
+        # per channel and survives every later pooling.  Same kernels, same bytes; measured at the headline size on 12 minibatches
+        # (profiles/r04_x3_error_budget_*.txt): whole-fp16 stem + x3 trunk 1.06e-3 -> 0.62e-3 rms logits error, the fp16 precision
+        # 1.21e-3 -> 0.88e-3.  "auto" = "noise" for precision 'fp16x' (the tolerance mode), None otherwise; VNQA_COHERENT_ROUND=0/1
+        # overrides the default.
         self.calib = None
-        if os.environ.get("VNQA_COHERENT_ROUND", "0") == "1" and vgg is not None and objdet is not None and precision not in ("fp32",):
-            self.calib = calibration_means(vgg, objdet)
+        self._tap = None             # calibration hook: {layer key: output tensor} filled by _run / _run_composed
+        if isinstance(calibration, str) and calibration == "auto":
+            env = os.environ.get("VNQA_COHERENT_ROUND")
+            calibration = "noise" if (env == "1" or (env is None and precision == "fp16x")) else None
+        if calibration is not None and vgg is not None and objdet is not None and precision != "fp32":
+            self.calib = calibration_means(vgg, objdet, None if isinstance(calibration, str) else calibration)
         cm = lambda k: None if self.calib is None else self.calib[k]
         if vgg is not None:
             f = vgg.features
@@ -186,17 +193,19 @@ class FrozenStem(object):
             # stem's 32 ms) — run as the plain fp16 fused kernel by default (1.05 ms): five fp16 roundings (clip, two weight sets,
             # two activations) stay in the forward pass, ~0.5e-3 of logits error instead of ~1e-5 (VNQA_X3_PLAIN_FIRST=0: all x3)
             self.x3_plain_first = self.x3 and os.environ.get("VNQA_X3_PLAIN_FIRST", "1") != "0"
-            # VNQA_X3_ROUND=n (default 4): the INPUT of the n heaviest x3 layers (composed 5x5, conv22, conv21, conv2_2 — in that order)
-            # is kept as ONE rounded fp16 tensor: two products instead of three on that layer (a third of its matrix work) for one
-            # more fp16 rounding.  The mode's speed / tolerance curve at the headline size, worst of the three parity batches
-            # (profiles/r04_fp16x_curve.txt): PLAIN_FIRST=0 ~1e-5 at 245 clips/s; n = 0: 0.48e-3 at 277; 4: 0.73e-3 at 392 (those layers run as fused two-product launches)
-            self.x3_round = set(("composed", "od3", "od2", "vgg2", "od4", "od5")[:int(os.environ.get("VNQA_X3_ROUND", "4"))]) if self.x3 else set()
+            # VNQA_X3_ROUND=n (default 6): the INPUT of the n heaviest x3 layers (composed 5x5, conv22, conv21, conv2_2, conv31, conv32 —
+            # in that order) is kept as ONE rounded fp16 tensor: two products instead of three on that layer (a third of its matrix
+            # work) for one more fp16 rounding (those layers run as fused two-product launches).  Speed / tolerance curve of the
+            # mode at the headline size: profiles/r04_fp16x_curve.txt
+            self.x3_round = set(("composed", "od3", "od2", "vgg2", "od4", "od5")[:int(os.environ.get("VNQA_X3_ROUND", "6"))]) if self.x3 else set()
             # VNQA_X3_PLAIN_PREFIX=k (fp16x): the first k stem layers — in the order fused conv1, conv2_1, conv2_2, the composed pair,
             # conv21, conv22, conv31 — run EXACTLY as in precision 'fp16' (plain storage, ONE product, the fast kernels: weights in
             # registers, composed 5x5 with its fp16 border GEMMs, patch-stationary); the layers after the prefix are x3 products (the
-            # first of them with two products: its input is the prefix's rounded fp16 output).  Measured (profiles/r04_fp16x_curve.txt):
-            # the early / middle layers' weight roundings cost far less logits error than their 2 - 3 x matrix work buys.
-            self.x3_prefix = max(1 if self.x3_plain_first else 0, int(os.environ.get("VNQA_X3_PLAIN_PREFIX", "4"))) if self.x3 else 0
+            # first of them with two products: its input is the prefix's rounded fp16 output).  Default 7 — every layer but conv32:
+            # with the prefix's weights rounded coherently (`calibration`, above) the whole plain prefix costs 0.6e-3 rms of logits
+            # error (12 minibatches, profiles/r04_x3_error_budget_coherent.txt; 1.06e-3 with round-to-nearest weights, where the
+            # default had to be 4) at a third to a half of the layers' x3 cost.
+            self.x3_prefix = max(1 if self.x3_plain_first else 0, int(os.environ.get("VNQA_X3_PLAIN_PREFIX", "7"))) if self.x3 else 0
             hp = lambda i: L.half_dtype() if (i < self.x3_prefix or (self.w2 and i == 0)) else None
             self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, cdt=hp(0), m=cm("vgg0")),
                                self._layer(f["5"], relu=True, pool=False, cdt=hp(1), m=cm("vgg1")),
@@ -440,6 +449,8 @@ class FrozenStem(object):
                                 "x3 product (split + conv_igemm_kernel raw + post)" if (self.x3 and not plain) else
                                 "conv_igemm_kernel<..., TAG 4> (two products, x read twice along K)" if self.w2 else
                                 ("conv_ps_kernel" if cp["tile"] == L.TILE_STEM_PS_224x256 else "conv_igemm_kernel")))
+        if self._tap is not None:
+            self._tap[key] = y
         return y
 
     def _buf(self, key, shape, dtype=None):
@@ -523,6 +534,8 @@ class FrozenStem(object):
             if timed:
                 ev1.record()
                 self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9, kname))
+            if self._tap is not None:
+                self._tap[(tag, i)] = x
         return x
 
     # ---- fused fast path: clip -> packed native features ------------------------------------
@@ -562,6 +575,8 @@ class FrozenStem(object):
                 clip = K.expand_u8_clip(clip)
             a = self._buf(("first", H, W), (n_img, H + 2, W + 2, 64))
             K.conv_first(clip, self.first[0], self.first[1], img_of, n_img, self.cdt, out=a)
+            if self._tap is not None:
+                self._tap["first"] = a
             x = self._run(a, self.layers_vgg, "vgg", final=False)
         return self._run_od(x, "od", slot)
 
