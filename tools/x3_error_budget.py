@@ -20,12 +20,23 @@ KEYS = {"PREFIX": "VNQA_X3_PLAIN_PREFIX", "ROUND": "VNQA_X3_ROUND", "TRUNK_FWD":
         "RING_W2": "VNQA_RING_W2", "COH": "VNQA_COHERENT_ROUND"}
 
 
-def batches(args, device, n):
+def batches(args, device, n, data="noise"):
+    """data: 'noise' = i.i.d. uniform pixels (the benchmark's synthetic clips, and what the stem's default calibration frames are);
+    'smooth' = NOT the calibration distribution: 14 x 14 noise per frame bilinearly upsampled 16 x, plus a per-clip brightness and a
+    slow drift over the frames — large flat regions, other channel means."""
+    import torch.nn.functional as F
     out = []
     for i in range(n):
         g = torch.Generator(device="cpu").manual_seed(777 + i)
         B, T = args.batch, args.frames
-        clip = torch.rand(B, 3, args.height, args.width, T, generator=g)
+        if data == "smooth":
+            low = torch.rand(B * T, 3, args.height // 16, args.width // 16, generator=g)
+            up = F.interpolate(low, size=(args.height, args.width), mode="bilinear", align_corners=False).view(B, T, 3, args.height, args.width)
+            gain = 0.3 + 0.7 * torch.rand(B, 1, 1, 1, 1, generator=g)
+            drift = torch.linspace(0, 0.2, T).view(1, T, 1, 1, 1) * torch.rand(B, 1, 1, 1, 1, generator=g)
+            clip = (up * gain + drift).clamp_(0, 1).permute(0, 2, 3, 4, 1).contiguous()
+        else:
+            clip = torch.rand(B, 3, args.height, args.width, T, generator=g)
         q_lens = torch.randint(5, 26, (B,), generator=g)
         q = torch.randint(1, 134, (B, 56), generator=g)
         q = q * (torch.arange(56).unsqueeze(0) < q_lens.unsqueeze(1)).long()
@@ -59,6 +70,8 @@ def run(args, prec, device, data):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", type=int, default=12)
+    ap.add_argument("--data", default="noise", choices=["noise", "smooth"], help="the minibatches' pixel statistics (the default "
+                    "calibration frames are always noise)")
     ap.add_argument("--precision", default="fp16x", help="the precision under test (fp16x, fp16w, fp16)")
     ap.add_argument("settings", nargs="*", default=["PREFIX=4 ROUND=6"])
     o = ap.parse_args()
@@ -67,7 +80,7 @@ def main():
     from videonavqa_amd import _lib as L
     L.set_half("f16")
     device = torch.device("cuda", 0)
-    data = batches(args, device, o.batches)
+    data = batches(args, device, o.batches, o.data)
     ref = run(args, "fp32", device, data)
     print("%-44s %8s %8s %8s  %s   per batch (x 1e-3)" % ("setting", "max", "rms", "mean", "flips"), flush=True)
     for s in o.settings:
