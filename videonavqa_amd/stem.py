@@ -172,14 +172,15 @@ class FrozenStem(object):
         # channel's rounding errors cancel against the mean input, the part of the weight-rounding error that is a constant offset
         # per channel and survives every later pooling.  Same kernels, same bytes; measured at the headline size on 12 minibatches
         # (profiles/r04_x3_error_budget_*.txt): whole-fp16 stem + x3 trunk 1.06e-3 -> 0.62e-3 rms logits error, the fp16 precision
-        # 1.21e-3 -> 0.88e-3.  "auto" = "noise" for precision 'fp16x' (the tolerance mode), None otherwise; VNQA_COHERENT_ROUND=0/1
-        # overrides the default.
+        # 1.21e-3 -> 0.88e-3, bf16 9.0e-3 -> 7.1e-3 on the parity batches.  "auto" = "noise" for every 16-bit precision (the pass
+        # costs one exact-f32 stem plan and 4 frames at construction); VNQA_COHERENT_ROUND=0 turns it off (round-to-nearest).
         self.calib = None
         self._tap = None             # calibration hook: {layer key: output tensor} filled by _run / _run_composed
         if isinstance(calibration, str) and calibration == "auto":
             env = os.environ.get("VNQA_COHERENT_ROUND")
-            calibration = "noise" if (env == "1" or (env is None and precision == "fp16x")) else None
-        if calibration is not None and vgg is not None and objdet is not None and precision != "fp32":
+            calibration = "noise" if env != "0" else None
+        if calibration is not None and vgg is not None and objdet is not None and precision != "fp32" and \
+                vgg.features["0"].weight.is_cuda:
             self.calib = calibration_means(vgg, objdet, None if isinstance(calibration, str) else calibration)
         cm = lambda k: None if self.calib is None else self.calib[k]
         if vgg is not None:
