@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 411
+#define VNQA_ABI_VERSION 412
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -153,12 +153,14 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
  *                         out_x3 != 0: y is 16-bit [..][c_y >= 3 c_out] and receives the halves [hi | lo | hi] instead — the
  *                         next x3 product's operand, no fp32 round trip between consecutive layers; out_x3 == 2: the plain 16-bit
  *                         tensor (one fp16 rounding) for a two-product consumer, which reads it twice (VNQA_CONV_X_WRAP2).
+ *                         out_x3 | VNQA_X3_POST_ZERO_HALO: y is a fresh, uninitialised buffer — its halo ring is written with zeros too.
  *   vnqa_gemm_nt with dtype = VNQA_BF16 | VNQA_GEMM_OUT_F32 : 16-bit operands, fp32 `out` (workspace >= m*n*4 bytes required).
  */
 /* The split scale of a gradient tensor (the backward operands of precision 'fp16x': gradients are 1e-5 .. 1e-8, below fp16's normal
  * range) in ONE launch: state = 16 bytes on the device, ZERO on first use (the call leaves words 0 and 3 zero again):
  *   ((float*)state)[1] = s = the power of two that lifts max |x| into [2^12, 2^13)  (1 for an all-zero or non-finite tensor, never
  *   above 2^112), ((float*)state)[2] = 1 / s — the `scale` of vnqa_split3_f32 and the `raw_scale` of vnqa_x3_post. */
+#define VNQA_X3_POST_ZERO_HALO 4
 int vnqa_grad_split_scale(const float* x, int64_t n, void* state, void* stream);
 
 int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld, int64_t dst_ld,
@@ -369,6 +371,10 @@ int vnqa_unpack_conv_wgrad(const float* dwt, int32_t c_out, int32_t c_in, int32_
                            int32_t c_out_pad, int32_t c_in_pad, float* dw_oihw, void* stream);
 int vnqa_unpack_conv_wgrad_scaled(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps, int32_t c_out_pad,
                                   int32_t c_in_pad, float* dw_oihw, float alpha, void* stream);   /* dw = alpha * un-packed */
+/* ... with a second factor that only exists on the DEVICE (alpha_dev, may be NULL): dw = alpha * *alpha_dev * un-packed — the inverse
+ * split scale of a scaled backward product (vnqa_grad_split_scale) applied here instead of by a pass of its own */
+int vnqa_unpack_conv_wgrad_dev(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps, int32_t c_out_pad, int32_t c_in_pad,
+                               float* dw_oihw, float alpha, const float* alpha_dev, void* stream);
 
 /* fc_embed_attn = nn.Linear(spatial*C -> at_hidden) applied to the NCHW-flattened feature map
  * (models/film_attn_pt_stem.py:56-57,244).  The kernels keep maps as padded NHWC, so its weight is re-laid out once
@@ -389,6 +395,8 @@ int vnqa_unpack_fc_wgrad(const float* dw_nat, int32_t rows, int32_t c, int32_t h
 int vnqa_fc_dx(const void* dout, const void* nat, void* dx, int32_t m, int32_t r, int32_t k, int32_t dtype, void* stream);
 int vnqa_unpack_fc_wgrad_scaled(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad, float* dw,
                                 float alpha, void* stream);
+int vnqa_unpack_fc_wgrad_dev(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad, float* dw,
+                             float alpha, const float* alpha_dev, void* stream);      /* dw = alpha * *alpha_dev * un-packed */
 
 /* Layout converters between the reference's tensors and padded NHWC.
  *   vnqa_feat_to_nhwc : v fp32 [b][c][h][w][t] (the model-input layout, eval/q_and_v_eval.py:110)

@@ -240,6 +240,54 @@ def test_x1g_backward_products_are_the_fp16_backward_on_fp32_tensors(mag):
         assert name == "dbias" or err > 1e-6, (name, "one product expected, not three")
 
 
+def test_deferred_split_scale_is_applied_by_the_unpack_kernels():
+    """conv2d_wgrad / gemm_tn(defer_scale=True): the product stays multiplied by its split scale and carries 1 / scale as a device
+    scalar; vnqa_unpack_conv_wgrad_dev / vnqa_unpack_fc_wgrad_dev apply it in their own pass — same numbers as the separate multiply."""
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(11)
+    n, h, w, c = 4, 14, 14, 128
+    x = _padded(n, h, w, c, 21)
+    dy = _padded(n, h, w, 128, 22, scale=1e-6)
+    a = (torch.randn(280, 64, generator=g) * 1e-7).cuda()
+    b = torch.randn(280, 16 * 16 * 64, generator=g).cuda()
+    for mode in ("x1g", "x3g"):
+        with K.f32_conv_mode(mode):
+            dwt_now, _ = K.conv2d_wgrad(x, dy, 9, want_bias=False)
+            dwt_def, _ = K.conv2d_wgrad(x, dy, 9, want_bias=False, defer_scale=True)
+            tn_now = K.gemm_tn(a, b)
+            tn_def = K.gemm_tn(a, b, defer_scale=True)
+        assert getattr(dwt_def, "_vnqa_inv", None) is not None and float(dwt_def.abs().max()) > 1e3 * float(dwt_now.abs().max())
+        got = K.unpack_conv_wgrad(dwt_def, 128, c, alpha=0.5)
+        want = K.unpack_conv_wgrad(dwt_now, 128, c, alpha=0.5)
+        assert torch.equal(got, want) or float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+        got = K.unpack_fc_wgrad(tn_def, 64, 64, 14, 14, 64, alpha=2.0)
+        want = K.unpack_fc_wgrad(tn_now, 64, 64, 14, 14, 64, alpha=2.0)
+        assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+def test_x3_post_can_zero_the_halo_of_a_fresh_output(monkeypatch):
+    """VNQA_X3_POST_ZERO_HALO: the finishing pass writes the halo ring of an uninitialised output itself (fp32 and the 16-bit operand
+    forms, halo 1 and 2) — same tensor as the separate halo launch produces."""
+    from videonavqa_amd import kernels as K
+    g = torch.Generator().manual_seed(13)
+    x = _padded(3, 12, 10, 64, 31)
+    wgt = (torch.randn(128, 64, 3, 3, generator=g) / 24).cuda()
+    wt = K.pack_conv_weight(wgt, torch.float32)
+    bias = torch.randn(128, generator=g).cuda()
+    for y_halo in (1, 2):
+        for x3_out in (0, 1, 2):
+            outs = []
+            for flag in ("0", "1"):
+                monkeypatch.setenv("VNQA_X3_POST_HALO", flag)
+                torch.empty(8 << 20, device="cuda").fill_(float("nan"))       # (stale NaNs in the allocator's cache would show in an unwritten halo)
+                with K.f32_conv_mode("x3"):
+                    outs.append(K.conv2d_igemm(x, wt, bias=bias, relu=True, y_halo=y_halo, x3_out=x3_out).float().clone())
+            assert torch.equal(outs[0], outs[1]), (y_halo, x3_out)
+            hal = outs[1].clone()
+            hal[:, y_halo:-y_halo, y_halo:-y_halo, :] = 0
+            assert float(hal.abs().max()) == 0
+
+
 @pytest.mark.parametrize("case", QV_CASES)
 def test_fp16x_models_vs_reference_golden(case):
     """precision='fp16x' on the reference's goldens: eval logits and train logits within 1e-3 (north star's tolerance; the

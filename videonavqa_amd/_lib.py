@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 411          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 412          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -54,6 +54,7 @@ class ConvDesc(ctypes.Structure):
 CONV_ZERO_HALO = 1      # vnqa_conv_desc.flags
 CONV_XCD_SPLIT_N = 2
 CONV_X_WRAP2 = 4
+X3_POST_ZERO_HALO = 4      # vnqa_x3_post: or'ed into out_x3
 GEMM_X_WRAP2 = 0x400
 WGRAD_FUSED_REDUCE = 0x100     # option bit of vnqa_conv2d_wgrad's dtype argument
 GEMM_OUT_F32 = 0x200           # option bit of vnqa_gemm_nt's dtype argument: 16-bit operands, fp32 output
@@ -151,6 +152,8 @@ _SIGNATURES = {
     "vnqa_temporal_attn_packed_bwd": (ctypes.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "vnqa_unpack_conv_wgrad_scaled": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _vp]),
     "vnqa_unpack_fc_wgrad_scaled": (ctypes.c_int, [_vp] + [_i32] * 5 + [_vp, _f32, _vp]),
+    "vnqa_unpack_fc_wgrad_dev": (ctypes.c_int, [_vp] + [_i32] * 5 + [_vp, _f32, _vp, _vp]),
+    "vnqa_unpack_conv_wgrad_dev": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _f32, _vp, _vp]),
     "vnqa_sgemm_workspace": (_i64, [_i32, _i32, _i32]),
     "vnqa_sgemm": (ctypes.c_int, [_vp] * 7 + [_i64] * 4 + [_i32] * 6 + [_vp, _vp, _vp]),
     "vnqa_mac_core_workspace": (_i64, [_i32, _i32]),

@@ -30,7 +30,9 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, int c_out, 
 }
 
 __global__ void unpack_conv_wgrad_kernel(const float* __restrict__ dwt, int c_out, int c_in, int taps,
-                                         int c_out_pad, int c_in_pad, float* __restrict__ dw, float alpha) {
+                                         int c_out_pad, int c_in_pad, float* __restrict__ dw, float alpha,
+                                         const float* __restrict__ alpha_dev) {
+  if (alpha_dev != nullptr) alpha *= *alpha_dev;          // (a scale that only exists on the device: the x1g / x3g split scale's inverse)
   const size_t total = (size_t)c_out * c_in * taps;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int tap = (int)(i % taps);
@@ -195,8 +197,10 @@ __global__ void __launch_bounds__(256) fc_pack_nat_t_kernel(const float* __restr
 
 // dw_nat fp32 [rows_pad][(h+2)(w+2)][c_pad] -> dw fp32 [rows][C][h][w]   (block = (row, 64-channel chunk))
 __global__ void __launch_bounds__(256) fc_unpack_grad_kernel(const float* __restrict__ dnat, float* __restrict__ dw, int rows,
-                                                             int C, int h, int wd, int c_pad, float alpha) {
+                                                             int C, int h, int wd, int c_pad, float alpha,
+                                                             const float* __restrict__ alpha_dev) {
   extern __shared__ float tile[];                      // [S][64 + 1]
+  if (alpha_dev != nullptr) alpha *= *alpha_dev;
   const int row = blockIdx.y, c0 = blockIdx.x * 64;
   const int S = h * wd, Sp = (h + 2) * (wd + 2);
   const float* src = dnat + (size_t)row * Sp * c_pad + c0;
@@ -356,14 +360,20 @@ extern "C" int vnqa_pack_conv_weight(const float* w_oihw, int32_t c_out, int32_t
   return VNQA_OK;
 }
 
-extern "C" int vnqa_unpack_conv_wgrad_scaled(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps,
-                                             int32_t c_out_pad, int32_t c_in_pad, float* dw_oihw, float alpha, void* stream) {
+extern "C" int vnqa_unpack_conv_wgrad_dev(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps, int32_t c_out_pad,
+                                          int32_t c_in_pad, float* dw_oihw, float alpha, const float* alpha_dev, void* stream) {
   VNQA_CHECK_ARG(dwt && dw_oihw, "unpack_conv_wgrad: null pointer");
+  VNQA_CHECK_ARG(c_out > 0 && c_in > 0 && taps > 0 && c_out_pad >= c_out && c_in_pad >= c_in, "unpack_conv_wgrad: bad geometry");
   const size_t total = (size_t)c_out * c_in * taps;
   hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dwt, c_out,
-                     c_in, taps, c_out_pad, c_in_pad, dw_oihw, alpha);
+                     c_in, taps, c_out_pad, c_in_pad, dw_oihw, alpha, alpha_dev);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
+}
+
+extern "C" int vnqa_unpack_conv_wgrad_scaled(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps,
+                                             int32_t c_out_pad, int32_t c_in_pad, float* dw_oihw, float alpha, void* stream) {
+  return vnqa_unpack_conv_wgrad_dev(dwt, c_out, c_in, taps, c_out_pad, c_in_pad, dw_oihw, alpha, nullptr, stream);
 }
 
 extern "C" int vnqa_unpack_conv_wgrad(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps,
@@ -477,15 +487,22 @@ extern "C" int vnqa_unpack_fc_wgrad(const float* dw_nat, int32_t rows, int32_t c
   return vnqa_unpack_fc_wgrad_scaled(dw_nat, rows, c, h, wd, c_pad, dw, 1.f, stream);
 }
 
+extern "C" int vnqa_unpack_fc_wgrad_dev(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad,
+                                        float* dw, float alpha, const float* alpha_dev, void* stream);
 extern "C" int vnqa_unpack_fc_wgrad_scaled(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad,
                                            float* dw, float alpha, void* stream) {
+  return vnqa_unpack_fc_wgrad_dev(dw_nat, rows, c, h, wd, c_pad, dw, alpha, nullptr, stream);
+}
+
+extern "C" int vnqa_unpack_fc_wgrad_dev(const float* dw_nat, int32_t rows, int32_t c, int32_t h, int32_t wd, int32_t c_pad,
+                                        float* dw, float alpha, const float* alpha_dev, void* stream) {
   VNQA_CHECK_ARG(dw_nat && dw, "unpack_fc_wgrad: null pointer");
   VNQA_CHECK_ARG(rows > 0 && c > 0 && h > 0 && wd > 0 && c_pad >= c && c_pad % 64 == 0, "unpack_fc_wgrad: bad geometry");
   const size_t lds = (size_t)h * wd * 65 * sizeof(float);
   VNQA_CHECK_ARG(lds <= 160 * 1024, "unpack_fc_wgrad: a %dx%d map does not fit the LDS tile", h, wd);
   if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)fc_unpack_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(fc_unpack_grad_kernel, dim3((c + 63) / 64, rows), dim3(256), lds, (hipStream_t)stream, dw_nat, dw, rows, c, h,
-                     wd, c_pad, alpha);
+                     wd, c_pad, alpha, alpha_dev);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

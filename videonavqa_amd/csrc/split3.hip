@@ -57,6 +57,7 @@ struct PostArgs {
   unsigned short* y16;      // != null: the output as the NEXT x3 product's operand instead — 16-bit [..][c_y], channels
                             // [hi | lo | hi] at c, c_out + c, 2 c_out + c (c_y >= 3 c_out): no fp32 round trip between layers
   int n, h, w, c_out, c_y, y_halo, relu, pool, two;
+  int zero_halo;            // also write zeros to y's halo ring (a fresh, uninitialised output): no separate halo launch
 };
 
 __device__ __forceinline__ float4 post_one(const PostArgs& p, int n, int y, int x, int c, const float4 bias) {
@@ -127,6 +128,27 @@ __global__ void __launch_bounds__(256) x3_post_kernel(const PostArgs p) {
         *(uint2*)(o + p.c_out) = l;
         *(uint2*)(o + 2 * p.c_out) = h;
       }
+    }
+  }
+  if (p.zero_halo && p.y_halo > 0) {          // the halo ring(s) of every image: c_y elements per halo pixel, 8 bytes at a time
+    const int esz = p.y16 == nullptr ? 4 : 2;
+    const int per = (int)((size_t)p.c_y * esz / 8);                    // 8-byte pieces per pixel (c_y % 4 == 0)
+    const int hal = p.y_halo;
+    const long long ring = (long long)hyp * wyp - (long long)ho * wo;   // halo pixels per image
+    const long long tot = (long long)p.n * ring * per;
+    char* const base = p.y16 == nullptr ? (char*)p.y : (char*)p.y16;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+      const int k = (int)(i % per);
+      long long q = i / per;
+      const long long r = q % ring;
+      const int n = (int)(q / ring);
+      int py, px;
+      const long long top = (long long)hal * wyp;
+      if (r < top) { py = (int)(r / wyp); px = (int)(r % wyp); }
+      else if (r < 2 * top) { const long long t = r - top; py = hyp - hal + (int)(t / wyp); px = (int)(t % wyp); }
+      else { const long long t = r - 2 * top; py = hal + (int)(t / (2 * hal)); const int side = (int)(t % (2 * hal));
+             px = side < hal ? side : wyp - 2 * hal + side; }
+      *(uint2*)(base + ((((size_t)n * hyp + py) * wyp + px) * p.c_y) * esz + (size_t)k * 8) = make_uint2(0u, 0u);
     }
   }
 }
@@ -210,6 +232,8 @@ extern "C" int vnqa_x3_post(const float* raw, const float* bias, const float* po
                             const float* border_sub, void* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y,
                             int32_t y_halo, int32_t relu, int32_t pool2, int32_t out_x3, const float* raw_scale, void* stream) {
   VNQA_CHECK_ARG(raw && y, "x3_post: null pointer");
+  const int zero_halo = (out_x3 & VNQA_X3_POST_ZERO_HALO) ? 1 : 0;
+  out_x3 &= ~VNQA_X3_POST_ZERO_HALO;
   VNQA_CHECK_ARG(out_x3 >= 0 && out_x3 <= 2, "x3_post: out_x3 must be 0 (fp32), 1 (16-bit [hi | lo | hi]) or 2 (plain 16-bit)");
   VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0 && c_out > 0 && c_out % 4 == 0 && c_y >= (out_x3 == 1 ? 3 : 1) * c_out && c_y % 4 == 0,
                  "x3_post: bad geometry n=%d h=%d w=%d c_out=%d c_y=%d", n_img, h, w, c_out, c_y);
@@ -223,6 +247,7 @@ extern "C" int vnqa_x3_post(const float* raw, const float* bias, const float* po
   p.y = out_x3 ? nullptr : (float*)y;
   p.y16 = out_x3 ? (unsigned short*)y : nullptr;
   p.two = out_x3 == 2 ? 1 : 0;
+  p.zero_halo = zero_halo;
   p.n = n_img; p.h = h; p.w = w; p.c_out = c_out; p.c_y = c_y; p.y_halo = y_halo; p.relu = relu; p.pool = pool2 ? 1 : 0;
   const long long total = (long long)n_img * (pool2 ? h / 2 : h) * (pool2 ? w / 2 : w) * (c_out / 4);
   hipLaunchKernelGGL(x3_post_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);

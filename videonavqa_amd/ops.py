@@ -130,7 +130,7 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             inv = 1.0 / ctx.grad_scale
-            dwt, dbias = K.conv2d_wgrad(x, dy, k * k)
+            dwt, dbias = K.conv2d_wgrad(x, dy, k * k, defer_scale=True)
             dw = K.unpack_conv_wgrad(dwt, c_out, c_in, alpha=inv)
             db = dbias[:c_out].clone() if inv == 1.0 else dbias[:c_out] * inv
         if ctx.needs_input_grad[0]:
@@ -296,7 +296,7 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         exact = c_pad == C
         dbn_w = _ret(s_bw if exact else None, K.colsum(s2, out=_into(s_bw) if exact else None)[:C])
         dbn_b = _ret(s_bb if exact else None, K.colsum(s1, out=_into(s_bb) if exact else None)[:C])
-        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None)
+        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None, defer_scale=True)
         dconv_w = _ret(s_cw, K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw), alpha=inv))
         dconv_b = _ret(s_cb if exact else None, dbias0[:C])
         if scaled:
@@ -391,7 +391,7 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
                 dz = K.film_relu_res_bwd_ld(dout, z, film[:, col:col + C], film[:, col + C:col + 2 * C], C,
                                             dfilm[:, col:col + C], dfilm[:, col + C:col + 2 * C])
             sw, sb = ctx.sinks[2 * k], sinks[2 * k + 1]
-            dwt, dbias = K.conv2d_wgrad(res, dz, 9, dbias_out=_into(sb))
+            dwt, dbias = K.conv2d_wgrad(res, dz, 9, dbias_out=_into(sb), defer_scale=True)
             grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw), alpha=inv))
             direct_b = sb is not None and dbias.data_ptr() == sb.view.data_ptr()      # (only without channel padding)
             grads_blocks[4 * k + 3] = _ret(sb if direct_b else None, dbias[:C] * inv if scaled else dbias[:C])
@@ -954,7 +954,7 @@ class FcNativeFn(torch.autograd.Function):
             dx = K.fc_dx(dout, nat_t) if ctx.direct_dx else K.gemm_nt(dout, nat_t)     # (direct: the saved tensor is `nat`)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = _ret(ctx.sink_w, K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad, out=_into(ctx.sink_w),
+            dw = _ret(ctx.sink_w, K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous(), defer_scale=True), rows, C, h, w, c_pad, out=_into(ctx.sink_w),
                                                     alpha=1.0 / ctx.grad_scale))
         db = None
         if ctx.needs_input_grad[2]:
