@@ -75,7 +75,7 @@ def build(args, device):
                                        TimeMultiHopFiLMPretrainedStem)
     from videonavqa_amd.stem import FrozenStem, VGGFront
     import torch.nn as nn
-    torch.manual_seed(0)     # identical replicas on every rank
+    torch.manual_seed(int(getattr(args, "seed", 0)))     # identical replicas on every rank (tools/x3_error_budget.py --seed: other weights)
     prec = args.precision
     # experiment hook (fp16x): the trunk behind the x3 stem in another storage — "w2" = precision 'fp16w', "plain" = 'fp16'
     mprec = {"w2": "fp16w", "plain": "fp16"}.get(os.environ.get("VNQA_X3_TRUNK", "x3"), prec) if prec == "fp16x" else prec

@@ -72,11 +72,12 @@ def main():
     ap.add_argument("--batches", type=int, default=12)
     ap.add_argument("--data", default="noise", choices=["noise", "smooth"], help="the minibatches' pixel statistics (the default "
                     "calibration frames are always noise)")
+    ap.add_argument("--seed", type=int, default=0, help="seed of the random weights (0 = the benchmark's)")
     ap.add_argument("--precision", default="fp16x", help="the precision under test (fp16x, fp16w, fp16)")
     ap.add_argument("settings", nargs="*", default=["PREFIX=4 ROUND=6"])
     o = ap.parse_args()
     args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
-                              tail_channels=0)
+                              tail_channels=0, seed=o.seed)
     from videonavqa_amd import _lib as L
     L.set_half("f16")
     device = torch.device("cuda", 0)
