@@ -870,6 +870,17 @@ def main():
                          "gflop_per_launch": round(sum(f for _, f in lst) / len(lst) / 1e9, 1),
                          "achieved_tflops": round(sum(f for _, f in lst) / (tot_ms * 1e-3) / 1e12, 1) if tot_ms > 0 else 0.0,
                          "ms_per_step": round(tot_ms / args.steps, 4)}
+        def peak_for(kname):
+            """MFMA peak a kernel entry is priced against, on its ALGORITHMIC FLOPs: the 16-bit dense peak for one-product kernels
+            (bf16 and fp16 run at the same rate), half / a third of it for the two- / three-product forms of fp16w / fp16x, the
+            exact-f32 MFMA peak for precision 'fp32'."""
+            if args.precision == "fp32":
+                return PEAK_F32_TFLOPS
+            if kname.startswith("x3 product"):
+                return PEAK_BF16_TFLOPS / 3.0
+            if "two products" in kname:
+                return PEAK_BF16_TFLOPS / 2.0
+            return PEAK_BF16_TFLOPS
         alone = {}
         for ev in alone_events:
             k = ev[3] if len(ev) > 3 else "conv_igemm_kernel"
@@ -878,17 +889,13 @@ def main():
         for k, (tot_ms, fl, n) in alone.items():
             if k in kstats and tot_ms > 0:
                 kstats[k]["chip_to_itself"] = {"avg_launch_ms": round(tot_ms / n, 4), "achieved_tflops": round(fl / (tot_ms * 1e-3) / 1e12, 1),
-                                               "frac": round(fl / (tot_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS if args.precision in ("bf16", "fp16") else PEAK_F32_TFLOPS), 4)}
+                                               "frac": round(fl / (tot_ms * 1e-3) / 1e12 / peak_for(k), 4)}
         dom = max(kstats, key=lambda k: kstats[k]["ms_per_step"]) if kstats else "conv_igemm_kernel"
         dstat = kstats.get(dom, {"launches_per_step": 0, "avg_launch_ms": 0.0, "gflop_per_launch": 0.0, "achieved_tflops": 0.0})
         avg_ms, launches_per_step = dstat["avg_launch_ms"], dstat["launches_per_step"]
         flops_per_launch = dstat["gflop_per_launch"] * 1e9
         achieved = dstat["achieved_tflops"]
-        peak = PEAK_BF16_TFLOPS if args.precision in ("bf16", "fp16") else PEAK_F32_TFLOPS      # fp16 MFMA rate == bf16's
-        if args.precision == "fp16w":      # 2 fp16 MFMA products per algorithmic multiply-add in the forward pass
-            peak = PEAK_BF16_TFLOPS / 2.0
-        if args.precision == "fp16x":      # 3 fp16 MFMA products per algorithmic multiply-add: priced on the algorithmic FLOPs
-            peak = PEAK_BF16_TFLOPS / 3.0
+        peak = peak_for(dom)      # (fp16x: its dominant kernel is the plain one-product composed conv of the fp16 prefix)
         # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
         # live; collected with rocprofv3 --pmc in separate runs, corrected per the microarch guide) — only
         # valid for the default workload the passes were taken on
