@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 412
+#define VNQA_ABI_VERSION 413
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -415,6 +415,17 @@ int vnqa_nhwc_to_nchw(const void* x, float* out, int32_t n_img, int32_t c, int32
  * a fresh output buffer needs only this, not a memset of the whole tensor — the conv kernels write every interior
  * pixel and never the halo.  c * element size must be a multiple of 16 bytes. */
 int vnqa_zero_halo(void* y, int32_t n_img, int32_t hp, int32_t wp, int32_t c, int32_t dtype, void* stream);
+
+/* The packed image list of a length-sorted minibatch (film_attn_pt_stem.py:201-208: frame t is processed for the cts[t] samples that
+ * have it) as device tables, written by ONE small kernel from HOST arrays that travel as kernel arguments — no host-to-device copy on
+ * the stem's stream (a 4-KB copy there queues behind the clips' own PCIe transfer):
+ *   v_sorted_host[batch] lengths sorted descending (0..frames), perm_host[batch]: sorted position s holds ORIGINAL sample perm[s];
+ *   img_of[batch * frames]  : image index of (original sample b, frame t) at b * frames + t, or -1;
+ *   frame_of / sample_of [n_img = sum v] : frame and sorted sample of image n (frame-major order);
+ *   offsets[v_sorted[0] + 1] : first image of every frame, then n_img. */
+#define VNQA_LAYOUT_MAX_BATCH 256
+int vnqa_frame_layout(const int32_t* v_sorted_host, const int32_t* perm_host, int32_t batch, int32_t frames, int32_t* img_of,
+                      int32_t* frame_of, int32_t* sample_of, int32_t* offsets, void* stream);
 
 /* conv2d weight gradient (+ optional bias gradient), stride 1 'same'.
  * Replaces the autograd wgrad of nn.Conv2d on the trainable convs

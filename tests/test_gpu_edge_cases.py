@@ -193,3 +193,25 @@ def test_uint8_clip_gives_bit_identical_stem_input_and_features():
         fa = stem.forward_clip(u8.cuda(), lay.img_of, lay.n_img).clone()
         fb = stem.forward_clip(f32.cuda(), lay.img_of, lay.n_img)
         assert torch.equal(fa, fb), prec
+
+
+def test_frame_layout_tables_written_on_the_device_equal_the_host_built_ones(monkeypatch):
+    """vnqa_frame_layout (lengths and sort permutation as kernel arguments, no host-to-device copy) against the host-built tables,
+    for full, ragged, single-sample, zero-length and 70-frame batches with and without a sort permutation
+    (film_attn_pt_stem.py:201-208: frame t is processed for the samples that have it)."""
+    import torch
+    from videonavqa_amd.models.common import FrameLayout
+    g = torch.Generator().manual_seed(3)
+    cases = [([35] * 8, 35), ([35, 30, 30, 12, 7, 3, 3, 1], 35), ([5], 35), ([70, 64, 3], 70), ([4, 0, 0], 6), ([0, 0], 4),
+             (sorted(torch.randint(1, 36, (32,), generator=g).tolist(), reverse=True), 35)]
+    for vl, T in cases:
+        for use_perm in (False, True):
+            perm = torch.randperm(len(vl), generator=g) if use_perm else None
+            monkeypatch.setenv("VNQA_LAYOUT_ON_DEVICE", "1")
+            dev = FrameLayout(vl, T, "cuda", perm=perm)
+            monkeypatch.setenv("VNQA_LAYOUT_ON_DEVICE", "0")
+            host = FrameLayout(vl, T, "cuda", perm=perm)
+            for name in ("img_of", "frame_of_i32", "sample_of_i32", "frame_off_i32"):
+                a, b = getattr(dev, name).cpu(), getattr(host, name).cpu()
+                assert a.shape == b.shape and torch.equal(a, b), (vl, T, use_perm, name)
+            assert dev.n_img == host.n_img == sum(vl) and dev.n_frames == host.n_frames

@@ -14,11 +14,19 @@ ks = [t for t in tabs if 'kernel_symbol' in t][0]
 cols = [r[1] for r in c.execute("pragma table_info(%s)" % kd)]
 q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
 rows = c.execute("select d.start, d.end, s.kernel_name, d.%s from %s d join %s s on d.kernel_id=s.id order by d.start" % (q, kd, ks)).fetchall()
+mc = [t for t in tabs if 'memory_copy' in t and 'rocpd' in t]
+for t in mc[:1]:          # (--memory-copy-trace: copies as rows of a pseudo queue "copy")
+    mcols = [r[1] for r in c.execute("pragma table_info(%s)" % t)]
+    if "start" in mcols and "end" in mcols:
+        size = "size" if "size" in mcols else "0"
+        rows += [(s_, e_, "MEMCPY %d bytes" % (b or 0), "copy") for s_, e_, b in c.execute("select start, end, %s from %s" % (size, t)).fetchall()]
+rows.sort(key=lambda r: r[0])
 adam = [i for i, r in enumerate(rows) if 'clip_adam' in r[2]]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-step = rows[adam[-back] + 1:adam[-back + 1] + 1]
+nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # consecutive steps to list
+step = rows[adam[-back - nsteps + 1] + 1:adam[-back + 1] + 1]
 t0 = step[0][0]
-qs = sorted(set(r[3] for r in step))
+qs = sorted(set(r[3] for r in step), key=str)
 print("step %.3f ms, %d kernels, queues %s" % ((step[-1][1] - t0) / 1e6, len(step), qs))
 busy = dict((k, 0.0) for k in qs)
 for s, e, n, k in step:

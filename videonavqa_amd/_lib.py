@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 412          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 413          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -55,6 +55,7 @@ CONV_ZERO_HALO = 1      # vnqa_conv_desc.flags
 CONV_XCD_SPLIT_N = 2
 CONV_X_WRAP2 = 4
 X3_POST_ZERO_HALO = 4      # vnqa_x3_post: or'ed into out_x3
+LAYOUT_MAX_BATCH = 256     # vnqa_frame_layout: VNQA_LAYOUT_MAX_BATCH
 GEMM_X_WRAP2 = 0x400
 WGRAD_FUSED_REDUCE = 0x100     # option bit of vnqa_conv2d_wgrad's dtype argument
 GEMM_OUT_F32 = 0x200           # option bit of vnqa_gemm_nt's dtype argument: 16-bit operands, fp32 output
@@ -202,6 +203,7 @@ _SIGNATURES = {
     "vnqa_ring_edge_gather_all": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_ring_assemble": (ctypes.c_int, [_vp] * 5 + [_i32] * 5 + [_vp]),
     "vnqa_zero_halo": (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_frame_layout": (ctypes.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_fc_dx": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_pack_fc_weight": (ctypes.c_int, [_vp] + [_i32] * 7 + [_vp, _vp, _vp]),
     "vnqa_unpack_fc_wgrad": (ctypes.c_int, [_vp] + [_i32] * 5 + [_vp, _vp]),

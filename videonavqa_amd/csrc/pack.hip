@@ -507,6 +507,68 @@ extern "C" int vnqa_unpack_fc_wgrad_dev(const float* dw_nat, int32_t rows, int32
   return VNQA_OK;
 }
 
+// ---- frame layout tables on the device (models/common.py: FrameLayout) ------------------------------------------------------------
+// The packed image list of a minibatch: image n <-> (frame t, sorted sample s), frame-major, cts[t] = #samples with v_len > t
+// (film_attn_pt_stem.py:201-208 iterates the frames of the length-sorted batch).  The tables used to be built on the host and copied
+// through pinned memory on the stream the stem runs on; with the clips themselves arriving over PCIe (3 ms of DMA per minibatch)
+// that 4-KB copy queued behind the clip of the minibatch after next and held the stem's first kernel for 0.1 - 0.9 ms.  Here the
+// sorted lengths and the sort permutation travel as KERNEL ARGUMENTS and one workgroup writes the tables: no host-to-device copy.
+struct LayoutArgs {
+  int B, T, n_frames, n_img;
+  int v[VNQA_LAYOUT_MAX_BATCH];       // lengths, sorted descending
+  int perm[VNQA_LAYOUT_MAX_BATCH];    // sorted position s holds ORIGINAL sample perm[s]
+};
+
+__global__ void __launch_bounds__(256) frame_layout_kernel(const LayoutArgs a, int* __restrict__ img_of, int* __restrict__ frame_of,
+                                                           int* __restrict__ sample_of, int* __restrict__ offsets) {
+  __shared__ int off[1025];
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < a.n_frames; ++t) {
+      off[t] = run;
+      int ct = 0;
+      for (int s = 0; s < a.B; ++s) ct += a.v[s] > t ? 1 : 0;
+      run += ct;
+    }
+    off[a.n_frames] = run;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i <= a.n_frames; i += blockDim.x) offsets[i] = off[i];
+  for (int i = threadIdx.x; i < a.B * a.T; i += blockDim.x) {
+    const int s = i / a.T, t = i - s * a.T;               // SORTED position s, frame t
+    const bool live = t < a.n_frames && a.v[s] > t;       // (sorted descending: the live samples of frame t are s = 0 .. ct - 1)
+    const int n = live ? off[t] + s : -1;
+    img_of[a.perm[s] * a.T + t] = n;
+    if (live) {
+      frame_of[n] = t;
+      sample_of[n] = s;
+    }
+  }
+}
+
+extern "C" int vnqa_frame_layout(const int32_t* v_sorted_host, const int32_t* perm_host, int32_t batch, int32_t frames, int32_t* img_of,
+                                 int32_t* frame_of, int32_t* sample_of, int32_t* offsets, void* stream) {
+  VNQA_CHECK_ARG(v_sorted_host && perm_host && img_of && frame_of && sample_of && offsets, "frame_layout: null pointer");
+  VNQA_CHECK_ARG(batch > 0 && batch <= VNQA_LAYOUT_MAX_BATCH && frames > 0 && frames <= 1024,
+                 "frame_layout: batch=%d (1..%d) frames=%d (1..1024)", batch, VNQA_LAYOUT_MAX_BATCH, frames);
+  LayoutArgs a;
+  a.B = batch; a.T = frames;
+  int nf = 0, n_img = 0;
+  for (int s = 0; s < batch; ++s) {
+    VNQA_CHECK_ARG(v_sorted_host[s] >= 0 && v_sorted_host[s] <= frames && (s == 0 || v_sorted_host[s] <= v_sorted_host[s - 1]),
+                   "frame_layout: lengths must be sorted descending and lie in 0..frames (v[%d]=%d)", s, v_sorted_host[s]);
+    VNQA_CHECK_ARG(perm_host[s] >= 0 && perm_host[s] < batch, "frame_layout: perm[%d]=%d out of range", s, perm_host[s]);
+    a.v[s] = v_sorted_host[s];
+    a.perm[s] = perm_host[s];
+    n_img += v_sorted_host[s];
+  }
+  nf = v_sorted_host[0];
+  a.n_frames = nf; a.n_img = n_img;
+  hipLaunchKernelGGL(frame_layout_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, img_of, frame_of, sample_of, offsets);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
 extern "C" int vnqa_zero_halo(void* y, int32_t n_img, int32_t hp, int32_t wp, int32_t c, int32_t dtype, void* stream) {
   VNQA_CHECK_ARG(y && n_img > 0 && hp >= 2 && wp >= 2, "zero_halo: bad arguments");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "zero_halo: bad dtype %d", dtype);

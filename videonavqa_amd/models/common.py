@@ -114,21 +114,35 @@ class FrameLayout(object):
         for ct in self.cts:
             self.offsets.append(self.offsets[-1] + ct)
         self.n_img = self.offsets[-1]
-        img_of = np.full((B * self.T,), -1, np.int32)
-        frame_of, sample_of = [], []
-        for t, ct in enumerate(self.cts):
-            for b in range(ct):
-                img_of[pm[b] * self.T + t] = self.offsets[t] + b
-                frame_of.append(t)
-                sample_of.append(b)
-        # ONE pinned staging buffer and ONE asynchronous H2D copy for all index tables: a pageable-memory copy would
-        # block the launch thread until the stream it is issued on has drained (that stream holds a whole stem pass)
         n_img, nf = self.n_img, self.n_frames
-        packed = torch.from_numpy(np.concatenate([img_of, np.asarray(frame_of, np.int32), np.asarray(sample_of, np.int32),
-                                                  np.asarray(self.offsets, np.int32)]))
         dev = torch.device(device)
-        if dev.type == "cuda":
-            packed = packed.pin_memory().to(dev, non_blocking=True)
+        if dev.type == "cuda" and B <= L.LAYOUT_MAX_BATCH and self.T <= 1024 and os.environ.get("VNQA_LAYOUT_ON_DEVICE", "1") != "0":
+            # the tables are written ON THE DEVICE by one small kernel whose inputs (sorted lengths, sort permutation) travel as kernel
+            # arguments (vnqa_frame_layout): no host-to-device copy on the stem's stream — with the clips arriving over PCIe a 4-KB
+            # pinned-memory copy there queued behind the 3-ms clip transfer and held the stem's first kernel (profiles/r04_h2d.txt)
+            import ctypes
+            packed = torch.empty(B * self.T + 2 * n_img + nf + 1, dtype=torch.int32, device=dev)
+            o1, o2, o3 = B * self.T, B * self.T + n_img, B * self.T + 2 * n_img
+            base = packed.data_ptr()
+            varr = (ctypes.c_int32 * B)(*vl)
+            parr = (ctypes.c_int32 * B)(*pm)
+            L.check(L.lib().vnqa_frame_layout(varr, parr, B, self.T, ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * o1),
+                                              ctypes.c_void_p(base + 4 * o2), ctypes.c_void_p(base + 4 * o3), L.stream()),
+                    "vnqa_frame_layout")
+        else:
+            img_of = np.full((B * self.T,), -1, np.int32)
+            frame_of, sample_of = [], []
+            for t, ct in enumerate(self.cts):
+                for b in range(ct):
+                    img_of[pm[b] * self.T + t] = self.offsets[t] + b
+                    frame_of.append(t)
+                    sample_of.append(b)
+            # ONE pinned staging buffer and ONE asynchronous H2D copy for all index tables: a pageable-memory copy would
+            # block the launch thread until the stream it is issued on has drained (that stream holds a whole stem pass)
+            packed = torch.from_numpy(np.concatenate([img_of, np.asarray(frame_of, np.int32), np.asarray(sample_of, np.int32),
+                                                      np.asarray(self.offsets, np.int32)]))
+            if dev.type == "cuda":
+                packed = packed.pin_memory().to(dev, non_blocking=True)
         o1, o2, o3 = B * self.T, B * self.T + n_img, B * self.T + 2 * n_img
         self.img_of = packed[:o1]
         self.frame_of_i32 = packed[o1:o2]
