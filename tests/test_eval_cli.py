@@ -245,3 +245,43 @@ def test_uint8_video_option_is_bit_identical_to_the_float64_path(tmp_path, monke
     assert lut.dtype == torch.float32 and lut.shape == (256,)
     assert torch.equal(lut[Xu["video"].long()], Xf["video"].float())       # bit-exact, padding frames included
     assert torch.equal(lut, (torch.arange(256, dtype=torch.float64) / 255.0).float())
+
+
+def test_stem_calibration_frames_from_the_dataset():
+    """--stem_calibration: 'noise' / 'off' / 'data' -> FrozenStem's calibration argument; 'data' takes the first valid frames of the
+    first items (the same on every rank), uint8 videos as k / 255."""
+    import argparse
+    from videonavqa_amd.eval.dataset import SyntheticVNQADataset
+    from videonavqa_amd.eval.q_and_v_eval import build_parser, stem_calibration
+    assert build_parser().parse_args(["--model", "film_attn_pt"]).stem_calibration == "noise"
+    ds = SyntheticVNQADataset(5, 32, 48, seed=7)
+    ns = lambda m: argparse.Namespace(stem_calibration=m)
+    assert stem_calibration(ns("noise"), ds) == "noise" and stem_calibration(ns("off"), ds) is None
+    assert stem_calibration(ns("data"), None) == "noise"
+    fr = stem_calibration(ns("data"), ds, n_frames=8)
+    assert fr.shape == (8, 3, 32, 48) and fr.dtype == torch.float32 and float(fr.min()) >= 0 and float(fr.max()) < 1
+    v0 = ds[0][0]["video"]
+    assert torch.equal(fr[0], v0[:, :, :, 0]) and torch.equal(fr[1], v0[:, :, :, 1])      # two frames per item from five items
+    assert torch.equal(fr[2], ds[1][0]["video"][:, :, :, 0])
+
+    class U8(object):
+        def __len__(self):
+            return 1
+
+        def __getitem__(self, i):
+            return {"video": torch.full((3, 4, 4, 6), 51, dtype=torch.uint8), "v_len": 6}, 0
+    fr = stem_calibration(ns("data"), U8(), n_frames=4)
+    assert fr.shape == (4, 3, 4, 4) and float((fr - 0.2).abs().max()) < 1e-7
+
+
+@pytest.mark.gpu
+def test_cli_runs_with_the_stem_calibrated_on_data_and_with_calibration_off(tmp_path, capsys):
+    from videonavqa_amd.eval import q_and_v_eval as E
+    os.chdir(tmp_path)
+    for mode in ("data", "off"):
+        argv = ["--model", "film_attn_pt", "--synthetic", "4", "--batch_size", "2", "--num_workers", "0", "--height", "64",
+                "--width", "96", "--num_res_block_channels", "64", "--hidden_size", "16", "--at_hidden_size", "16",
+                "--embed_size", "16", "--stats_after_every", "1", "--stem_calibration", mode]
+        E.main(argv)
+        out = capsys.readouterr().out
+        assert "Train Epoch: 0" in out and "Validation:" in out

@@ -66,6 +66,9 @@ def build_parser():
     # additions
     parser.add_argument('--synthetic', type=int, default=0)
     parser.add_argument('--precision', type=str, choices=['bf16', 'fp16', 'fp16w', 'fp16x', 'fp32'], default='bf16')
+    # how the frozen stem's 16-bit weights are rounded (stem.coherent_round): against the mean activations of seeded noise frames
+    # ('noise'), of frames of the first training videos ('data'), or to nearest ('off')
+    parser.add_argument('--stem_calibration', type=str, choices=['noise', 'data', 'off'], default='noise')
     parser.add_argument('--height', type=int, default=U.VID_HEIGHT)
     parser.add_argument('--width', type=int, default=U.VID_WIDTH)
     return parser
@@ -225,6 +228,26 @@ def gather_eval_shards(per_batch, loss_sum, n_examples, world, device=None):
     return merged, sum(sh[1] for sh in shards), sum(sh[2] for sh in shards)
 
 
+def stem_calibration(args, dataset, n_frames=8):
+    """FrozenStem's `calibration` argument from --stem_calibration: 'noise' (seeded noise frames), None ('off': round-to-nearest) or
+    [n_frames, 3, H, W] frames in [0, 1] from the FIRST items of `dataset` (the same on every rank) — the first valid frames of as many
+    videos as it takes."""
+    mode = getattr(args, "stem_calibration", "noise")
+    if mode == "off":
+        return None
+    if mode == "noise" or dataset is None or len(dataset) == 0:
+        return "noise"
+    n_items = min(len(dataset), n_frames)
+    per_item = -(-n_frames // n_items)
+    frames = []
+    for i in range(n_items):
+        item = dataset[i][0]
+        v = torch.as_tensor(item['video'])
+        v = v.float() / 255.0 if v.dtype == torch.uint8 else v.float()                # (uint8_video datasets: raw pixels k -> k / 255)
+        frames.append(v[:, :, :, :max(1, min(int(item['v_len']), per_item))].permute(3, 0, 1, 2))
+    return torch.cat(frames)[:n_frames].contiguous()
+
+
 def val_epoch(args, trainer, data_loader, device, rank=0, world=1):
     """q_and_v_eval.py:159-224 on the inference path: Trainer.eval_step (forward-only fused trunk, the stem of the NEXT
     minibatch and its H2D copy overlapping this minibatch's trunk, as in training), loss / predictions / targets kept on the
@@ -325,7 +348,7 @@ def main(argv=None):
     if rank == 0:
         print(obj_detector)
         print(model)
-    stem = FrozenStem(feature_extractor, obj_detector, args.precision)
+    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=stem_calibration(args, train_data))
 
     class_weights = None
     if args.use_class_weights and hasattr(train_data, "get_class_weights"):

@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import utils as U
-from .q_and_v_eval import build_model, build_parser
+from .q_and_v_eval import build_model, build_parser, stem_calibration
 
 
 def _padded(args, Xs, ys):
@@ -118,7 +118,7 @@ def main(argv=None):
     feature_extractor = get_frcnn_feature_extractor(args.frcnn_pretrained_path, args.precision).to(device)
     obj_detector = U.get_object_detector(precision=args.precision,
                                          load=args.synthetic == 0 or os.path.exists(U.OBJ_DETECTOR_PATH)).to(device)
-    stem = FrozenStem(feature_extractor, obj_detector, args.precision)
+    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=stem_calibration(args, test_data))
     reduction = 'mean' if args.loss_reduction == 'elementwise_mean' else args.loss_reduction
     loss_fn = nn.CrossEntropyLoss(reduction=reduction)
     trainer = Trainer(model, stem, loss_reduction=reduction, feature_channels=args.num_input_channels)
