@@ -434,16 +434,8 @@ class FrozenStem(object):
         # 1 022 -> 831 MB per launch (profiles/r04_pmc_traffic*.json), time unchanged (2.166 vs 2.161 ms; end to end 941-943 either way)
         xcd = L.CONV_XCD_SPLIT_N if ((not self.x3 or plain) and os.environ.get("VNQA_STEM_XCD_SPLIT", "1") == "1") else 0
         w2 = self.w2 and K.x3_mode() == "w2"
-        if self.x3 and x3o == 2 and L.is_half(xc.dtype) and os.environ.get("VNQA_X3_COMPOSED_PLAIN", "0") == "1":
-            # experiment: the composed pair as ONE plain fp16 product (its weight rounding stays): the layer at a third of its x3 cost
-            if "wt16" not in cp:
-                cp["wt16"] = cp["wt"].to(L.half_dtype())
-            with K.f32_conv_mode("exact"):
-                y = K.conv2d_igemm(xc, cp["wt16"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
-                                   tile=L.TILE_STEM_256x256, border_sub=ring.to(xc.dtype), desc_flags=L.CONV_XCD_SPLIT_N)
-        else:
-            y = K.conv2d_igemm(xc, cp["wt32"] if w2 else cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
-                               tile=L.TILE_256x256 if w2 else cp["tile"], border_sub=ring, x3_out=x3o, desc_flags=0 if w2 else xcd)
+        y = K.conv2d_igemm(xc, cp["wt32"] if w2 else cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
+                           tile=L.TILE_256x256 if w2 else cp["tile"], border_sub=ring, x3_out=x3o, desc_flags=0 if w2 else xcd)
         if timed:
             ev1.record()
             self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25,
