@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 413
+#define VNQA_ABI_VERSION 414
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -333,6 +333,15 @@ int vnqa_clip_u8_to_nhwc4(const uint8_t* clip, const float* lut, const int32_t* 
 int vnqa_conv_first_c64_fwd(const vnqa_conv_desc* d, const void* img4, const float* w1, const float* b1,
                             const void* wt, const float* bias, const float* post_scale,
                             const float* post_shift, void* y, void* stream);
+/* ... with a DYNAMIC tile schedule: `sched` = 8 bytes on the device, zero on first use (the launch leaves them zero again), owned by one
+ * stream at a time.  The persistent workgroups draw their tiles from a counter instead of owning a fixed stride of them, so a
+ * workgroup whose CU was held by another stream's kernel for a while simply draws fewer: beside the trunk's forward pass (the
+ * pipelined training step) the launch takes its share of the chip's time instead of waiting for its last-started workgroup's
+ * full static share.  Results are identical (the tile -> pixels map does not depend on who computes a tile).  sched == NULL: the
+ * static stride of vnqa_conv_first_c64_fwd. */
+int vnqa_conv_first_c64_fwd_sched(const vnqa_conv_desc* d, const void* img4, const float* w1, const float* b1,
+                                  const void* wt, const float* bias, const float* post_scale,
+                                  const float* post_shift, void* y, void* sched, void* stream);
 
 /* First VGG conv (3 -> c_out, 3x3 pad 1) + ReLU straight from the reference's clip layout.
  * Replaces the strided frame slice v_inputs[:, :, :, :, j] + conv1_1 of the external

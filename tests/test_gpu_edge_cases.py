@@ -215,3 +215,37 @@ def test_frame_layout_tables_written_on_the_device_equal_the_host_built_ones(mon
                 a, b = getattr(dev, name).cpu(), getattr(host, name).cpu()
                 assert a.shape == b.shape and torch.equal(a, b), (vl, T, use_perm, name)
             assert dev.n_img == host.n_img == sum(vl) and dev.n_frames == host.n_frames
+
+
+def test_fused_conv1_dynamic_tile_schedule_is_bit_identical_and_resets_itself(monkeypatch):
+    """vnqa_conv_first_c64_fwd_sched: the persistent workgroups draw their tiles from a device counter (so that a workgroup held up by
+    another stream's kernels draws fewer) — the same bits as the static stride, on repeated launches (the schedule words are left
+    zero), with a kernel of another stream in the way, and for an image count that gives fewer tiles than workgroups."""
+    import torch
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd import _lib as L
+    g = torch.Generator().manual_seed(21)
+    half = L.half_dtype()
+    w1 = (torch.randn(64, 3, 3, 3, generator=g) / 5).cuda()
+    b1 = (torch.randn(64, generator=g) / 10).cuda()
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) / 24).cuda()
+    wt = K.pack_conv_weight(w2, half, c_out_pad=64, c_in_pad=64)
+    bias = torch.randn(64, generator=g).cuda()
+    for n_img, H, W in ((3, 64, 96), (37, 96, 128), (1, 32, 32)):
+        clip = torch.rand(1, 3, H, W, n_img, generator=g).cuda()
+        img_of = torch.arange(n_img, dtype=torch.int32, device="cuda")
+        img4 = torch.zeros(n_img, H + 4, W + 4, 4, dtype=half, device="cuda")
+        K.clip_to_nhwc4(clip, img_of, n_img, out=img4)
+        ref = K.conv_first_c64(img4, w1, b1, wt, bias=bias, relu=True, pool2=True)
+        sched = torch.zeros(2, dtype=torch.int32, device="cuda")
+        side = torch.cuda.Stream()
+        busy = torch.randn(4096, 4096, device="cuda")
+        for rep in range(4):
+            if rep >= 2:              # something else on the chip while the persistent kernel runs
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        busy = torch.tanh(busy)
+            got = K.conv_first_c64(img4, w1, b1, wt, bias=bias, relu=True, pool2=True, sched=sched)
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (n_img, H, W, rep)
+            assert sched.tolist() == [0, 0], (sched.tolist(), rep)

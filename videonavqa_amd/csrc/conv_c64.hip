@@ -51,6 +51,12 @@ struct C64Args {
   const float* w1;              // [64][27] fp32 (OIHW flattened)
   const float* b1;              // [64]
   int reserve_cus;              // CUs the persistent grid leaves to other streams (VNQA_CONV_RESERVE_CUS in vnqa_conv_desc.flags)
+  // != NULL (wide fused kernel, nsplit == 1): DYNAMIC tile schedule — two device words {next tile, workgroups done}, zero on entry and
+  // left zero on exit.  Every workgroup draws its tiles from the counter instead of owning the fixed stride blockIdx.x, + grid, ...:
+  // when another stream's kernels hold some CUs for a while (the trunk's forward runs beside this kernel in the pipelined step), the
+  // workgroups that start late simply draw fewer tiles; with the static stride the launch lasted until the LAST-started workgroup
+  // had finished its full share (1.08 ms alone, 1.89 ms beside the trunk).
+  unsigned* sched;
 };
 
 __device__ __forceinline__ void glds16c(const char* src, char* lds_wave_base) {
@@ -534,7 +540,15 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
 
   // Two workgroup barriers per tile: the image pixels of tile t+1 are fetched under tile t's MFMA loop and put into
   // ldsIn before the barrier that closes the loop, and the pooled epilogue stores straight from registers.
+  const bool dyn = p.sched != nullptr;
+  __shared__ long long s_draw;              // the tile drawn for the NEXT trip (thread 0 writes it, everyone reads it after a barrier)
   long long t_cur = gslot;
+  if (dyn) {
+    if (threadIdx.x == 0) s_draw = (long long)atomicAdd(p.sched, 1u);
+    __syncthreads();
+    t_cur = s_draw;
+    __syncthreads();
+  }
   uint2 px0 = make_uint2(0u, 0u), px1 = make_uint2(0u, 0u);
   auto put_image_px = [&]() {
     *(uint2*)(ldsIn + threadIdx.x * 8) = px0;
@@ -546,15 +560,19 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // resident weights, per-lane tables, first image patch
   __builtin_amdgcn_s_barrier();
-  for (; t_cur < tiles_total; t_cur += gstride) {
-    const bool have_next = t_cur + gstride < tiles_total;
+  long long t_next = t_cur + gstride;
+  for (; t_cur < tiles_total; t_cur = t_next) {
+    if (dyn && threadIdx.x == 0) s_draw = (long long)atomicAdd(p.sched, 1u);     // visible to all after the barrier below
+    if (!dyn) t_next = t_cur + gstride;
 #ifdef VNQA_DIAG_SKIP_DMA   // timing-only: 256 = conv1_1 patch computed for the first tile only, 512 = no epilogue, 1024 = no MFMA loop
     if (!(p.relu & 256) || t_cur == gslot)
 #endif
     compute_patch(t_cur);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (have_next) load_image_px(t_cur + gstride, px0, px1);            // in flight under this tile's MFMA loop
+    if (dyn) t_next = s_draw;
+    const bool have_next = t_next < tiles_total;
+    if (have_next) load_image_px(t_next, px0, px1);                     // in flight under this tile's MFMA loop
 
     vnqa_f32x4 acc[4][4];
 #pragma unroll
@@ -732,6 +750,16 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // C tile consumed: the slot may be refilled
   }
+  if (dyn && threadIdx.x == 0) {
+    // every workgroup's LAST draw was out of range, so when the last workgroup arrives here all draws are over: it leaves both
+    // words zero for the next launch that is handed this schedule
+    __threadfence();
+    if (atomicAdd(p.sched + 1, 1u) == gridDim.x - 1) {
+      p.sched[0] = 0u;
+      p.sched[1] = 0u;
+      __threadfence();
+    }
+  }
 }
 
 // clip fp32 [B][3][H][W][T] (frames last) -> image list [n_img][H+4][W+4][4] bf16 (halo 2 and channel 3 stay zero:
@@ -811,6 +839,7 @@ int c64_fill(const vnqa_conv_desc* d, const void* x, const void* wt, const float
   a.Wyp = wo + 2;
   a.w1 = nullptr;
   a.b1 = nullptr;
+  a.sched = nullptr;
   return VNQA_OK;
 }
 
@@ -854,15 +883,26 @@ extern "C" int vnqa_conv2d_c64_fwd(const vnqa_conv_desc* d, const void* x, const
 
 // conv(3 -> 64) + ReLU fused into the following conv(64 -> c_out): `img4` is the image list [n][h+4][w+4][4] bf16
 // produced by vnqa_clip_to_nhwc4; w1/b1 are the first conv's OIHW fp32 weights [64][3][3][3] and bias.
+extern "C" int vnqa_conv_first_c64_fwd_sched(const vnqa_conv_desc* d, const void* img4, const float* w1, const float* b1,
+                                             const void* wt, const float* bias, const float* post_scale,
+                                             const float* post_shift, void* y, void* sched, void* stream);
 extern "C" int vnqa_conv_first_c64_fwd(const vnqa_conv_desc* d, const void* img4, const float* w1, const float* b1,
                                        const void* wt, const float* bias, const float* post_scale,
                                        const float* post_shift, void* y, void* stream) {
+  return vnqa_conv_first_c64_fwd_sched(d, img4, w1, b1, wt, bias, post_scale, post_shift, y, nullptr, stream);
+}
+
+extern "C" int vnqa_conv_first_c64_fwd_sched(const vnqa_conv_desc* d, const void* img4, const float* w1, const float* b1,
+                                             const void* wt, const float* bias, const float* post_scale,
+                                             const float* post_shift, void* y, void* sched, void* stream) {
   C64Args a;
   const int rc = c64_fill(d, img4, wt, bias, post_scale, post_shift, y, a, "conv_first_c64_fwd");
   if (rc != VNQA_OK) return rc;
   VNQA_CHECK_ARG(w1 && b1, "conv_first_c64_fwd: null first-layer weights");
+  VNQA_CHECK_ARG((((uintptr_t)sched) & 7) == 0, "conv_first_c64_fwd: the schedule words must be 8-byte aligned");
   a.w1 = w1;
   a.b1 = b1;
+  a.sched = (d->tile != 3 && a.nsplit == 1) ? (unsigned*)sched : nullptr;      // (the dynamic schedule serves the wide kernel, 64 couts)
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: a race only repeats it
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_c64_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize,

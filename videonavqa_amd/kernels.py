@@ -719,9 +719,10 @@ def clip_to_nhwc4(clip, img_of, n_img, out=None):
 
 
 def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None,
-                   reserve_cus=0):
+                   reserve_cus=0, sched=None):
     """conv(3->64)+ReLU fused into the following C_in = 64 conv (see vnqa_conv_first_c64_fwd).  img4 from clip_to_nhwc4;
-    w1/b1 the first conv's fp32 OIHW weights and bias; wt/bias/... as conv2d_c64."""
+    w1/b1 the first conv's fp32 OIHW weights and bias; wt/bias/... as conv2d_c64.  sched: int32 [2] device tensor, zero on first
+    use — the dynamic tile schedule (vnqa_conv_first_c64_fwd_sched); None = static stride."""
     N, Hp4, Wp4, c4 = img4.shape
     H, W = Hp4 - 4, Wp4 - 4
     c_out, taps, cin_w = wt.shape
@@ -731,9 +732,9 @@ def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_sc
         out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=img4.dtype, device=img4.device)
     d = L.ConvDesc(L.BF16, N, H, W, 64, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0, 0,
                    L.conv_reserve_flags(reserve_cus))
-    L.check(L.lib().vnqa_conv_first_c64_fwd(ctypes.byref(d), L.ptr(img4), L.ptr(w1.detach().float().contiguous()),
-                                            L.ptr(b1.detach().float().contiguous()), L.ptr(wt), L.ptr(bias),
-                                            L.ptr(post_scale), L.ptr(post_shift), L.ptr(out), L.stream()),
+    L.check(L.lib().vnqa_conv_first_c64_fwd_sched(ctypes.byref(d), L.ptr(img4), L.ptr(w1.detach().float().contiguous()),
+                                                  L.ptr(b1.detach().float().contiguous()), L.ptr(wt), L.ptr(bias),
+                                                  L.ptr(post_scale), L.ptr(post_shift), L.ptr(out), L.ptr(sched), L.stream()),
             "vnqa_conv_first_c64_fwd")
     return out
 

@@ -446,6 +446,18 @@ class FrozenStem(object):
             self._tap[key] = y
         return y
 
+    def _c64_sched(self):
+        """The two schedule words of the fused conv1 kernel's dynamic tile schedule: one pair per stream this plan runs on (a launch
+        leaves them zero; two launches of one plan never overlap on different streams — the Trainer orders its inline and side-stream
+        stem passes).  VNQA_C64_DYNAMIC=0: static stride."""
+        if os.environ.get("VNQA_C64_DYNAMIC", "1") == "0":
+            return None
+        key = ("c64sched", torch.cuda.current_stream().cuda_stream)
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.zeros(2, dtype=torch.int32, device="cuda")
+        return t
+
     def _buf(self, key, shape, dtype=None):
         """Persistent zero-halo activation buffer, grown (never shrunk) along the image axis."""
         dtype = self.cdt if dtype is None else dtype
@@ -560,7 +572,8 @@ class FrozenStem(object):
             for n0 in range(0, n_img, step):
                 K.conv_first_c64(img4[n0:n0 + step], self.first[0], self.first[1], ly["wt"], bias=ly["bias"], relu=ly["relu"],
                                  pool2=ly["pool"], post_scale=post[0] if post else None,
-                                 post_shift=post[1] if post else None, out=out[n0:n0 + step], reserve_cus=self.reserve_cus)
+                                 post_shift=post[1] if post else None, out=out[n0:n0 + step], reserve_cus=self.reserve_cus,
+                                 sched=self._c64_sched())
             x = out
             x = self._run(x, self.layers_vgg[1:], "vgg", first_index=1, final=False)
         else:
