@@ -121,6 +121,31 @@ def fwd_pack_dtype(x):
 
 
 _SCALE_STATES = {}
+_SHARED_GRAD = [None]
+
+
+class shared_grad_operand(object):
+    """Inside this context the split scale and the scaled fp16 cast of gradient tensor `t` are computed ONCE: a layer's backward uses
+    the same d(out) as the operand of its weight gradient and of its data gradient (two max-|t| passes and two casts of a 150 MB
+    tensor otherwise).  Explicit and scoped: the caller vouches that `t` is not modified between the uses."""
+
+    def __init__(self, t):
+        on = t is not None and t.is_cuda and os.environ.get("VNQA_X1_SHARE", "1") != "0"
+        self.state = {"ptr": t.data_ptr(), "numel": t.numel(), "scale": None, "cast": None} if on else None
+
+    def __enter__(self):
+        self.prev = _SHARED_GRAD[0]
+        _SHARED_GRAD[0] = self.state
+        return self
+
+    def __exit__(self, *exc):
+        _SHARED_GRAD[0] = self.prev
+        return False
+
+
+def _shared_for(t):
+    sh = _SHARED_GRAD[0]
+    return sh if (sh is not None and sh["ptr"] == t.data_ptr() and sh["numel"] == t.numel()) else None
 
 
 def grad_split_scale(t):
@@ -128,6 +153,9 @@ def grad_split_scale(t):
     ONE launch (vnqa_grad_split_scale) on a 16-byte state from a ring of 32 per stream (a scale is consumed by the next few launches
     of its own stream: the split, the product's finishing pass, the gradient's un-scaling)."""
     assert t.dtype == torch.float32 and t.is_contiguous()
+    sh = _shared_for(t)
+    if sh is not None and sh["scale"] is not None:
+        return sh["scale"]
     key = (str(t.device), torch.cuda.current_stream().cuda_stream)
     ring = _SCALE_STATES.get(key)
     if ring is None:
@@ -135,6 +163,9 @@ def grad_split_scale(t):
     st = ring[0][ring[1] % 32]
     ring[1] += 1
     L.check(L.lib().vnqa_grad_split_scale(L.ptr(t), t.numel(), L.ptr(st), L.stream()), "vnqa_grad_split_scale")
+    if sh is not None:
+        sh["scale"] = (st[1], st[2])
+        return sh["scale"]
     return st[1], st[2]
 
 
@@ -170,9 +201,18 @@ def cast_hi(x2d, scale=None, name="x1in"):
     """fp32 [rows, c] -> 16-bit [rows, c] = fp16(scale * x): the operand of a ONE-product backward contraction ('x1g')."""
     rows, c = x2d.shape
     assert x2d.dtype == torch.float32 and x2d.stride(1) == 1 and c % 8 == 0
+    sh = _shared_for(x2d) if (scale is not None and x2d.is_contiguous()) else None
+    if sh is not None and sh["scale"] is not None and scale is sh["scale"][0]:
+        if sh["cast"] is not None and sh["cast"].shape == (rows, c):
+            return sh["cast"]
+        name = "x1shared"          # (its own buffer: nothing else overwrites it inside the context)
+    else:
+        sh = None
     out = _x3_buffer(name, rows * c, L.half_dtype(), x2d.device).view(rows, c)
     L.check(L.lib().vnqa_split3_f32(L.vptr(x2d), L.ptr(out), None, None, rows, c, x2d.stride(0), c, L.ptr(scale), L.stream()),
             "vnqa_split3_f32(hi only)")
+    if sh is not None:
+        sh["cast"] = out
     return out
 
 

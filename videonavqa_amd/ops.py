@@ -391,14 +391,15 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
                 dz = K.film_relu_res_bwd_ld(dout, z, film[:, col:col + C], film[:, col + C:col + 2 * C], C,
                                             dfilm[:, col:col + C], dfilm[:, col + C:col + 2 * C])
             sw, sb = ctx.sinks[2 * k], sinks[2 * k + 1]
-            dwt, dbias = K.conv2d_wgrad(res, dz, 9, dbias_out=_into(sb), defer_scale=True)
-            grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw), alpha=inv))
-            direct_b = sb is not None and dbias.data_ptr() == sb.view.data_ptr()      # (only without channel padding)
-            grads_blocks[4 * k + 3] = _ret(sb if direct_b else None, dbias[:C] * inv if scaled else dbias[:C])
-            # (dgrad(dz) + dout) * [res > 0]: the 3x3 conv's dgrad with the residual join and the 1x1 conv's ReLU mask in its
-            # epilogue (VNQA_EPI_ADD_MASK; bit-identical to conv2d_igemm followed by relu_bwd(dres, res, dout))
-            gsum = K.conv2d_igemm_add_mask(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad),
-                                           dout, res, tile=K.ps_fused_tile(dz))
+            with K.shared_grad_operand(dz):         # (fp16x: dz is the operand of the weight gradient AND of the data gradient)
+                dwt, dbias = K.conv2d_wgrad(res, dz, 9, dbias_out=_into(sb), defer_scale=True)
+                grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw), alpha=inv))
+                direct_b = sb is not None and dbias.data_ptr() == sb.view.data_ptr()      # (only without channel padding)
+                grads_blocks[4 * k + 3] = _ret(sb if direct_b else None, dbias[:C] * inv if scaled else dbias[:C])
+                # (dgrad(dz) + dout) * [res > 0]: the 3x3 conv's dgrad with the residual join and the 1x1 conv's ReLU mask in its
+                # epilogue (VNQA_EPI_ADD_MASK; bit-identical to conv2d_igemm followed by relu_bwd(dres, res, dout))
+                gsum = K.conv2d_igemm_add_mask(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad),
+                                               dout, res, tile=K.ps_fused_tile(dz))
             # (the 1x1 convs are frozen upstream — never in parameters() — so they get no weight gradient)
             wt1d = meta.c1_packs[k][1] if meta.c1_packs else \
                 K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad)
