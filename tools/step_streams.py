@@ -21,7 +21,9 @@ for t in mc[:1]:          # (--memory-copy-trace: copies as rows of a pseudo que
         size = "size" if "size" in mcols else "0"
         rows += [(s_, e_, "MEMCPY %d bytes" % (b or 0), "copy") for s_, e_, b in c.execute("select start, end, %s from %s" % (size, t)).fetchall()]
 rows.sort(key=lambda r: r[0])
-adam = [i for i, r in enumerate(rows) if 'clip_adam' in r[2]]
+import os
+mark = os.environ.get("MARK", "clip_adam")          # the kernel that ends a step (inference has no clip_adam: MARK=ce_loss)
+adam = [i for i, r in enumerate(rows) if mark in r[2]]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 1          # consecutive steps to list
 step = rows[adam[-back - nsteps + 1] + 1:adam[-back + 1] + 1]
