@@ -109,7 +109,12 @@ def build(args, device):
                                                num_res_block_channels=args.channels, spatial_size=S, precision=mprec,
                                                **({"num_tail_channels": args.tail_channels} if getattr(args, "tail_channels", 0) else {}))
     vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
-    stem = FrozenStem(vgg, od, prec, out_half=(mprec != prec))
+    # fp16x option (VNQA_X3_HALF_FEATURES=1): the stem hands the FiLM trunks ONE rounded fp16 feature tensor (conv32 as a fused two-product
+    # launch; conv_init reads it as a two-product x3 conv: no fp32 feature tensor, no split pass): +3.2 % (751-754 vs 729-731 clips/s)
+    # for one more activation rounding right in front of the trunk — twelve-minibatch max 0.90e-3 instead of 0.80e-3, rms 0.69 / 0.62:
+    # not the default
+    half_feat = prec == "fp16x" and args.model != "mac" and os.environ.get("VNQA_X3_HALF_FEATURES", "0") == "1"
+    stem = FrozenStem(vgg, od, prec, out_half=(mprec != prec) or half_feat)
     COMPOSED_STEM[0] = stem.composed is not None
     return model, stem, vgg, od
 

@@ -884,16 +884,19 @@ def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, defer_scale=False)
     inverse attached as dwt._vnqa_inv — unpack_conv_wgrad applies it in its own pass (no separate multiply)."""
     N, Hp, Wp, Cin = x.shape
     Cout = dy.shape[-1]
-    assert dy.shape[:3] == x.shape[:3] and dy.dtype == x.dtype
     h, w = Hp - 2, Wp - 2
-    if x3_active(x) and Cin % 8 == 0 and Cout % 8 == 0 and x.is_contiguous() and dy.is_contiguous() and \
-            3 * N * Hp * Wp < (1 << 31):
+    if L.is_half(x.dtype) and x3_active(dy) and _F32_CONV_MODE[0] != "x1g":
+        x = x.float()          # (a 16-bit activation against an fp32 gradient is served by the one-product form only)
+    assert dy.shape[:3] == x.shape[:3] and (dy.dtype == x.dtype or (L.is_half(x.dtype) and x3_active(dy)))
+    if (x3_active(x) or (L.is_half(x.dtype) and x3_active(dy))) and Cin % 8 == 0 and Cout % 8 == 0 and x.is_contiguous() and \
+            dy.is_contiguous() and 3 * N * Hp * Wp < (1 << 31):
         # x3 product over the pixels: dW = sum_p dY[p] X[p + tap]  with  X' = [x_hi; x_hi; x_lo], dY' = s [dy_hi; dy_lo; dy_hi] stacked
         # along the IMAGE axis — the 16-bit weight-gradient kernel on 3 N images computes exactly the three products' sum
         scale, inv = grad_split_scale(dy)
         if _F32_CONV_MODE[0] == "x1g":      # one product: fp16(x) and fp16(s * dy), N images
             nn = N
-            x3 = cast_hi(x.view(N * Hp * Wp, Cin), name="x1rows").view(N, Hp, Wp, Cin)
+            # (x already 16-bit — fp16 features handed over by the stem — is its own operand)
+            x3 = x if L.is_half(x.dtype) else cast_hi(x.view(N * Hp * Wp, Cin), name="x1rows").view(N, Hp, Wp, Cin)
             dy3 = cast_hi(dy.view(N * Hp * Wp, Cout), scale=scale, name="x1rowsdy").view(N, Hp, Wp, Cout)
         else:
             nn = 3 * N

@@ -356,7 +356,9 @@ class FiLMTrunkBase(nn.Module):
         cdt = self.compute_dtype
         if isinstance(v_input, NativeFeatures):
             lay = v_input.layout
-            assert v_input.data.dtype == cdt
+            # (precision 'fp16x' also takes ONE rounded 16-bit feature tensor — FrozenStem(out_half=True): conv_init reads it as a
+            # two-product conv, the trunk's own storage stays fp32)
+            assert v_input.data.dtype == cdt or (self.__dict__.get("x3", False) and L.is_half(v_input.data.dtype))
             return v_input.data, lay, v_input.h, v_input.w
         assert v_input.is_cuda, "the HIP path needs device tensors (no CPU fallback)"
         B, C, h, w, T = v_input.shape
@@ -486,7 +488,7 @@ class FiLMTrunkBase(nn.Module):
         for k in range(self.num_res_blocks):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
             blocks += [c1.weight, c1.bias, c3.weight, c3.bias]
-        meta.c1_packs = self._frozen_c1_packs(x.dtype, L.round_up(C, 64))
+        meta.c1_packs = self._frozen_c1_packs(h.dtype, L.round_up(C, 64))      # (the trunk's storage: fp32 in 'fp16x' whatever the features' type)
         return ops.film_trunk_blocks(h, meta, uniq, blocks)
 
     def _frozen_c1_packs(self, cdt, c_pad):
@@ -539,12 +541,14 @@ class FiLMTrunkBase(nn.Module):
             output (VNQA_EPI_FILM_RES, y = NULL: only the backward reads z).
         No autograd nodes, no statistics, no saved activations."""
         C = self.num_res_block_channels
-        cdt = x.dtype
+        # (precision 'fp16x' with fp16 features from the stem — FrozenStem(out_half=True): the trunk's storage stays fp32, conv_init
+        # reads the rounded features as a two-product x3 conv)
+        cdt = torch.float32 if (K.x3_mode() in ("x3", "x2") and L.is_half(x.dtype)) else x.dtype
         c_pad = L.round_up(C, 64)
         bn = self.bn_init
         scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + BN_EPS)
         shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
-        fdt = K.fwd_pack_dtype(x)          # (fp32 packs in the two-product precision: the conv wrapper splits them)
+        fdt = torch.float32 if cdt != x.dtype else K.fwd_pack_dtype(x)          # (fp32 packs in the two-product precision: the conv wrapper splits them)
         wt0 = K.pack_conv_weight(self.conv_init.weight, fdt, c_out_pad=c_pad, c_in_pad=x.shape[-1])
         h = K.conv2d_igemm(x, wt0, bias=K.pad_vec(self.conv_init.bias, c_pad), relu=True,
                            post_scale=K.pad_vec(scale, c_pad), post_shift=K.pad_vec(shift, c_pad))

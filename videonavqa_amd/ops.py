@@ -252,9 +252,12 @@ class FilmTrunkHeadFn(torch.autograd.Function):
     def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, meta):
         _x3_forward(ctx)
         lay, C = meta.layout, meta.channels
-        cdt = x.dtype
+        # (precision 'fp16x' fed fp16 features — FrozenStem(out_half=True): fp32 storage from here on, conv_init as the two-product
+        # x3 conv of a rounded input)
+        half_in = K.x3_mode() in ("x3", "x2") and L.is_half(x.dtype)
+        cdt = torch.float32 if half_in else x.dtype
         c_pad = L.round_up(C, 64)
-        wt0 = K.pack_conv_weight(conv_w, K.fwd_pack_dtype(x), c_out_pad=c_pad, c_in_pad=x.shape[-1])
+        wt0 = K.pack_conv_weight(conv_w, torch.float32 if half_in else K.fwd_pack_dtype(x), c_out_pad=c_pad, c_in_pad=x.shape[-1])
         b0 = K.pad_vec(conv_b, c_pad)
         fused = None
         if L.is_half(cdt) and not K.w2_active(x):     # fp32 (parity) and the two-product precision keep the two-pass statistics kernel
