@@ -445,6 +445,41 @@ def test_fp16x_default_meets_1e3_on_twelve_full_size_minibatches():
     assert (sum(x * x for x in rel) / len(rel)) ** 0.5 < 0.8e-3, rel
 
 
+def test_fp16x_trunk_accepts_fp16_features_from_the_stem(monkeypatch):
+    """VNQA_X3_HALF_FEATURES=1 (FrozenStem(out_half=True) in front of an fp16x model): the stem's last layer as a fused two-product launch
+    with ONE rounded fp16 output, conv_init reading it as a two-product conv, its weight gradient from the fp16 tensor itself — a
+    training step, an inference step and the logits against the fp32-features form (2e-3 at this small size)."""
+    import argparse
+    import bench as Bn
+    from videonavqa_amd.train import Trainer
+    args = argparse.Namespace(precision="fp16x", batch=3, frames=6, height=64, width=96, blocks=1, channels=128, model="film_attn_pt",
+                              tail_channels=0, seed=0)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(4)
+    clip = torch.rand(3, 3, 64, 96, 6, generator=g).cuda()
+    q = torch.randint(1, 134, (3, 56), generator=g).cuda()
+    v_lens, q_lens = torch.tensor([6, 4, 2]), torch.tensor([7, 12, 5])
+    y = torch.randint(0, 70, (3,), generator=g).cuda()
+    outs, losses = {}, {}
+    for hf in ("0", "1"):
+        monkeypatch.setenv("VNQA_X3_HALF_FEATURES", hf)
+        model, stem, _, _ = Bn.build(args, dev)
+        assert stem.out_half == (hf == "1")
+        tr = Trainer(model, stem, lr=1e-4, clip=1.0, loss_reduction="sum")
+        model.train()
+        native, v_sorted, perm = tr.extract_features(clip, v_lens)
+        assert native.data.dtype == (torch.float16 if hf == "1" else torch.float32)
+        model.init_hidden()
+        outs[hf] = model(native, q[perm.cuda()], v_sorted, q_lens[perm]).detach().float().cpu()
+        loss, _ = tr.step(clip, q, v_lens, q_lens, y)
+        losses[hf] = float(loss)
+        assert torch.isfinite(tr.fp.flat).all()
+        ev = tr.eval_step(clip, q, v_lens, q_lens, y)
+        assert torch.isfinite(ev[1]).all()
+    assert float((outs["1"] - outs["0"]).abs().max()) < 2e-3 * float(outs["0"].abs().max())
+    assert abs(losses["1"] - losses["0"]) < 2e-3 * abs(losses["0"])
+
+
 def test_fp16x_meets_1e3_on_all_three_full_size_parity_batches():
     """the tolerance-compliant 16-bit-MFMA mode at BASELINE.json's full size (8 clips x 35 frames x 224 x 224, default
     FiLM-attn model): logits within 1e-3 of the exact-f32 precision on ALL THREE parity minibatches (north star's tolerance —
