@@ -129,7 +129,9 @@ def test_full_size_training_steps_are_sane(name):
 # change reorders roundings, so the stated tolerance keeps a 30 % margin instead of round 2's 5 %).  The global-max-pooling
 # heads (film_gp_pt, time_multi_hop) pick ONE frame per feature, so a near-tie between frames that flips under bf16
 # rounding moves that feature by the whole difference: stated looser, 3e-2.
-BF16_FULL_SIZE_LOGIT_TOL = {"config4_film_attn": 1.2e-2, "evalsh_film_attn_5x1024_bs32": 1.2e-2,
+# Round 4: with the frozen stem's weights rounded coherently (stem.coherent_round, the default of every 16-bit precision) the headline
+# config measures 7.1e-3 (bf16) / 0.81e-3 (fp16) instead of 9.1e-3 / 1.30e-3: stated 9.5e-3 and 1.1e-3.
+BF16_FULL_SIZE_LOGIT_TOL = {"config4_film_attn": 9.5e-3, "evalsh_film_attn_5x1024_bs32": 1.2e-2,
                             "config3_film_gp": 3e-2, "config5_time_multi_hop_T70": 3e-2,
                             "evalsh_film_gp_4x1024_bs32": 3e-2, "evalsh_time_multi_hop_3x1024_bs16": 3e-2}
 
@@ -147,8 +149,8 @@ def test_bf16_vs_fp32_mode_logits_argmax_at_full_size(name):
         json.dump(res, fh, indent=1)
     print(name, json.dumps(res))
     tol = BF16_FULL_SIZE_LOGIT_TOL[name]
-    if LOW == "fp16":        # 11 significand bits instead of 8: an eighth of the bf16 error (measured 1.3e-3 at the headline
-        tol = tol / 6        # config -> stated 2e-3 for the attention models, 5e-3 for the pooling heads)
+    if LOW == "fp16":        # 11 significand bits instead of 8: an eighth of the bf16 error (measured 0.81e-3 at the headline
+        tol = 1.1e-3 if name == "config4_film_attn" else tol / 6        # config; stated 2e-3 for the other attention models, 5e-3 for the pooling heads)
     err = res[LOW + "_logits_rel_err"]
     assert err < tol, res
     assert res["loss_rel_err"] < tol, res
