@@ -258,7 +258,7 @@ def fp16_leg(args, precision="fp16"):
     backward) measured on the same workload in a CHILD process — one 16-bit storage format per process — after this
     process's own measurement: throughput of a short run and its parity block against the exact-f32 precision."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--precision", precision, "--no-cpu-baseline", "--no-fp16-leg", "--repeats", "1",
+    cmd = [sys.executable, os.path.abspath(__file__), "--precision", precision, "--no-cpu-baseline", "--no-fp16-leg", "--no-eval-leg", "--repeats", "1",
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch", str(args.batch), "--frames", str(args.frames),
            "--height", str(args.height), "--width", str(args.width), "--blocks", str(args.blocks), "--channels", str(args.channels)]
     env = {k: v for k, v in os.environ.items() if k not in ("VNQA_HALF",)}
