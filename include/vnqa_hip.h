@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 414
+#define VNQA_ABI_VERSION 415
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -781,10 +781,14 @@ int vnqa_mac_core_wgrad(const vnqa_mac_wgrad* w, void* stream);
  *   vnqa_l2norm_partial : partial[i] = sum of squares of block i's slice (n_partial = return of
  *                         vnqa_l2norm_blocks(n)); deterministic two-stage reduction
  *   vnqa_clip_adam      : coef = min(1, clip/(sqrt(sum partial)+1e-6)); g*=coef; Adam update of
- *                         p, m, v; g = 0.  step = 1-based step count (bias correction).
- *                         overflow_count (optional device int32): loss-scaled training (fp16 storage) — when the gradient
- *                         norm is not finite the update is SKIPPED (p, m, v untouched, g zeroed) and *overflow_count is
- *                         incremented; the caller reads it back asynchronously to lower its loss scale.
+ *                         p, m, v; g = 0.  When the gradient norm is not finite (fp16 storage: the loss scale overflowed;
+ *                         any precision: an inf / NaN activation) the update is SKIPPED: p, m, v untouched, g zeroed, and
+ *                         *overflow_count (optional device int32) incremented.
+ *                         step = 1-based count of the LAUNCHES that shared this overflow_count; the bias correction uses the
+ *                         number of updates actually applied, step - *overflow_count (>= 1), formed ON THE DEVICE — the
+ *                         caller never has to subtract skipped steps from a host read-back (which would make replicas with
+ *                         different host timing take different bias corrections on the same gradient).  The caller reads
+ *                         *overflow_count back only to steer its loss scale.
  */
 int32_t vnqa_l2norm_blocks(int64_t n);
 int vnqa_l2norm_partial(const float* g, int64_t n, float* partial, void* stream);

@@ -220,3 +220,90 @@ def test_validation_sharded_over_two_ranks_merges_to_the_single_process_order(tm
     assert len(s1) == 5 and s1.global_index == [0, 1, 2, 3, 4] and len(ShardedBatchSampler(23, 4, keep_short=True)) == 6
     (a, b), l, n = gather_eval_shards([(1, [3.0], [4.0]), (0, [1.0], [2.0])], 5.0, 2, 1)
     assert a.tolist() == [1.0, 3.0] and b.tolist() == [2.0, 4.0] and (l, n) == (5.0, 2)
+
+
+def _adam_step_skipping(fp, lr, count, clip=1.0):
+    """The fused kernel's contract on CPU tensors (csrc/optim.hip): a non-finite gradient norm SKIPS the update and bumps the
+    device counter; the bias correction uses launches - skipped, formed next to the update (never from a host read-back)."""
+    fp.step_count += 1
+    g = fp.grad
+    norm = float(g.norm())
+    if not (norm * norm <= 3.0e38):
+        count += 1
+        fp.zero_grad()
+        return False
+    applied = max(fp.step_count - int(count), 1)
+    g = g * min(1.0, clip / (norm + 1e-6))
+    fp.m.mul_(0.9).add_(g, alpha=0.1)
+    fp.v.mul_(0.999).addcmul_(g, g, value=0.001)
+    bc1, bc2 = 1 - 0.9 ** applied, 1 - 0.999 ** applied
+    fp.flat.sub_((lr / bc1) * fp.m / (fp.v.sqrt() / bc2 ** 0.5 + 1e-8))
+    fp.zero_grad()
+    return True
+
+
+def _worker_overflow(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import time
+    from videonavqa_amd.models import common as C
+    from videonavqa_amd.train import DynamicLossScale, FlatParams, OverlappedGradReducer, sync_replicas
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _make_model(seed=300 + rank)
+    sync_replicas(list(model.state_dict().values()))
+    fp = FlatParams(model.parameters())
+    reducer = OverlappedGradReducer(fp, world, "sum", early_numel=100)
+    scaler = DynamicLossScale("cpu", init=1024.0, growth_interval=4)
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(8, 12, generator=g)
+    Y = torch.randint(0, 5, (8,), generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    loss_fn = nn.CrossEntropyLoss(reduction="sum")
+    scales, applied = [], []
+    for it in range(9):
+        scale = C.grad_scale_of(torch.float16)              # what the backward kernels multiply the gradient with
+        (loss_fn(model(xs), ys) * scale).backward()
+        if it == 2 and rank == 1:                           # the loss scale overflows on ONE rank only
+            model[2].bias.grad[1] = float("inf")            # (a late-reduced parameter: its slice has not left this rank yet)
+        reducer.finish()                                    # ... and reaches every rank through the SUM all-reduce
+        fp.grad.div_(scale)
+        applied.append(_adam_step_skipping(fp, 1e-2, scaler.count))
+        if rank == 1:
+            time.sleep(0.02 * (it % 3))                     # ranks with different host timing take the same decisions
+        scaler.after_step()
+        scales.append(scaler.scale)
+    gathered = [torch.zeros_like(fp.flat) for _ in range(world)]
+    dist.all_gather(gathered, fp.flat)
+    assert torch.equal(gathered[0], gathered[1])
+    torch.save({"scales": scales, "applied": applied, "skipped": scaler.skipped_steps, "count": int(scaler.count),
+                "launches": fp.step_count, "state": scaler.state_dict()}, out_path % rank)
+    C.set_fp16_loss_scale(C.FP16_GRAD_SCALE)
+    dist.destroy_process_group()
+
+
+def test_overflow_on_one_rank_skips_and_rescales_identically_on_both(tmp_path):
+    """ADVICE r4 / VERDICT r4 #7: an overflow injected on ONE rank — the update is skipped on both (the reduced gradient is
+    non-finite everywhere), Adam's step count excludes it without any host read-back, and the lagged loss-scale adjustment lands
+    at the same step on both ranks: once, DynamicLossScale.LAG steps after the overflow, then regrowth."""
+    sys.path.insert(0, ROOT)
+    from videonavqa_amd.train import DynamicLossScale
+    out = str(tmp_path / "ovf_%d.pt")
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker_overflow, args=(2, port, out), nprocs=2, join=True)
+    a, b = (torch.load(out % r, weights_only=False) for r in range(2))
+    assert a == b
+    lag = DynamicLossScale.LAG
+    assert a["applied"] == [True, True, False] + [True] * 6 and a["count"] == 1 and a["launches"] == 9
+    # scale after each step: unchanged until the observation LAG steps after the overflow, halved ONCE, doubled after 4 clean ones
+    expect, s, clean = [], 1024.0, 0
+    for it in range(9):
+        if it == 2 + lag:
+            s, clean = s * 0.5, 0
+        else:
+            clean += 1
+            if clean >= 4:
+                s, clean = s * 2.0, 0
+        expect.append(s)
+    assert a["scales"] == expect, (a["scales"], expect)
+    assert a["skipped"] == 1 and a["state"]["skipped_steps"] == 1

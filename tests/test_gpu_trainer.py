@@ -255,17 +255,18 @@ def test_dynamic_loss_scale_halves_after_overflow_and_grows_when_clean():
     try:
         s = DynamicLossScale("cuda", init=1024.0, growth_interval=3)
         assert C.grad_scale_of(torch.float16) == 1024.0 and C.grad_scale_of(torch.bfloat16) == 1.0
-        s.count += 1                       # what the kernel does on an overflowed step
-        seen = 0
-        for _ in range(4):                 # the read-back is asynchronous: observed within a couple of steps
-            torch.cuda.synchronize()
-            seen += s.after_step()
-        assert seen == 1 and s.skipped_steps == 1
-        assert s.scale in (512.0, 1024.0)  # halved once, possibly doubled again by 3 clean steps since
-        for _ in range(8):
-            torch.cuda.synchronize()
+        s.count += 2                       # two overflowed steps inside one observation window: ONE halving
+        seen = [s.after_step() for _ in range(4)]
+        # fixed lag: the copy started at step k is consumed at step k + LAG — never earlier, whatever has arrived
+        assert seen == [0] * s.LAG + [2] + [0] * (3 - s.LAG) and s.skipped_steps == 2
+        assert s.scale == 512.0 and C.grad_scale_of(torch.float16) == 512.0
+        for _ in range(3):
             s.after_step()
-        assert s.scale >= 1024.0 and C.grad_scale_of(torch.float16) == s.scale
+        assert s.scale == 1024.0           # growth_interval clean observations double it
+        d = s.state_dict()
+        t = DynamicLossScale("cuda", init=64.0)
+        t.load_state_dict(d)
+        assert t.scale == s.scale and int(t.count) == 0 and d["skipped_steps"] == 2
     finally:
         C.set_fp16_loss_scale(C.FP16_GRAD_SCALE)
 

@@ -1,0 +1,308 @@
+#!/usr/bin/env python3
+"""ON THE GPU BOX — experiment, not product: the per-rounding-point budget of the 16-bit logits error at the headline size.
+
+The whole path (frozen stem + FiLM-attn train-mode forward) is restated in plain torch fp32 ON THE DEVICE with a hook at every
+tensor a 16-bit precision of the library stores or feeds to an MFMA (activations) and at every weight tensor it rounds.  One
+exact pass per minibatch, then one pass per SETTING (a set of active rounding points); reported per setting: squared-rms / rms / max
+of max|d logit| / max|logit| over the minibatches, pooled over weight seeds.  Rounding errors are small and add in variance, so
+single-point settings give the budget and combined settings check it.
+
+The exact pass is cross-checked against the library's exact-f32 precision (same weights), and the all-points setting against the
+library's own fp16 precision, so the restatement is known to model the product.
+
+  python tools/experiments/precision_budget.py [--seeds 0 1 2 3] [--batches 12] [--data noise|smooth] [--only-combos]
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+BN_EPS = 1e-5
+NEG_MASK = float(-(1 << 31))
+
+STEM_ACTS = ["a_clip", "a_c11", "a_c12", "a_c21", "a_c22", "a_comp", "a_od21", "a_od22", "a_od31", "a_feat"]
+TRUNK_ACTS = ["a_init", "a_bn", "a_res", "a_z", "a_out"]
+TRUNK_W = ["w_init", "w_1x1", "w_3x3", "w_fc"]
+
+
+def budget_mod():
+    spec = importlib.util.spec_from_file_location("x3_error_budget", os.path.join(ROOT, "tools", "x3_error_budget.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+class Setting(object):
+    """acts: set of activation points rounded to fp16; wmode: {weight name: 'rtn' | 'coh'} (absent = exact)."""
+
+    def __init__(self, name, acts=(), wmode=None):
+        self.name, self.acts, self.wmode = name, set(acts), dict(wmode or {})
+
+    def R(self, key, t):
+        return t.half().float() if key in self.acts else t
+
+
+@torch.no_grad()
+def sim_stem(vgg, od, frames, st, chunk=40):
+    f = vgg.features
+    conv = lambda t, c: F.conv2d(t, c.weight.float(), c.bias.float(), padding=1)
+    bn = lambda t, b: F.batch_norm(t, b.running_mean.float(), b.running_var.float(), b.weight.float(), b.bias.float(), False, 0.0, BN_EPS)
+    outs = []
+    n = frames.shape[0]
+    if n % chunk:       # fixed chunk shapes (ragged minibatches would otherwise make MIOpen search a new shape per batch)
+        frames = torch.cat([frames, frames.new_zeros((chunk - n % chunk,) + tuple(frames.shape[1:]))])
+    for i in range(0, frames.shape[0], chunk):
+        x = st.R("a_clip", frames[i:i + chunk])
+        a = st.R("a_c11", F.relu(conv(x, f["0"])))
+        a = st.R("a_c12", F.max_pool2d(F.relu(conv(a, f["2"])), 2))
+        a = st.R("a_c21", F.relu(conv(a, f["5"])))
+        a = st.R("a_c22", bn(F.max_pool2d(F.relu(conv(a, f["7"])), 2), od.bn_input))     # (the producer applies bn_input, rounds once)
+        a = conv(a, od.conv11)                                                            # composed pair: never stored
+        a = st.R("a_comp", F.max_pool2d(F.relu(bn(conv(a, od.conv12), od.bn1)), 2))
+        a = st.R("a_od21", conv(a, od.conv21))
+        a = st.R("a_od22", F.max_pool2d(F.relu(bn(conv(a, od.conv22), od.bn2)), 2))
+        a = st.R("a_od31", conv(a, od.conv31))
+        outs.append(st.R("a_feat", F.relu(bn(conv(a, od.conv32), od.bn3))))
+    return torch.cat(outs)[:n]
+
+
+def lstm_cell(xg, h, c, w_hh, b_hh):
+    g = xg + h @ w_hh.t() + b_hh
+    H = h.shape[1]
+    i, f, gg, o = g[:, :H], g[:, H:2 * H], g[:, 2 * H:3 * H], g[:, 3 * H:]
+    c2 = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+    return torch.sigmoid(o) * torch.tanh(c2), c2
+
+
+@torch.no_grad()
+def question_film(W, q, q_lens, cts):
+    """FiLM values per processed frame: the question LSTM re-run per frame with carried state (film_attn_pt_stem.py:144-181)."""
+    B = q.shape[0]
+    Hq = W["film_layer.1.weight"].shape[1]
+    emb = F.embedding(q, W["embed.weight"])
+    xg = emb @ W["film_layer.0.weight_ih_l0"].t() + W["film_layer.0.bias_ih_l0"]
+    h = emb.new_zeros(B, Hq)
+    c = emb.new_zeros(B, Hq)
+    Lmax = int(q_lens.max())
+    ql = q_lens.to(q.device)
+    out = []
+    for ct in cts:
+        last = emb.new_zeros(B, Hq)
+        for t in range(Lmax):
+            h2, c2 = lstm_cell(xg[:, t], h, c, W["film_layer.0.weight_hh_l0"], W["film_layer.0.bias_hh_l0"])
+            m = (ql > t).float().unsqueeze(1)
+            h = m * h2 + (1 - m) * h
+            c = m * c2 + (1 - m) * c
+            last = torch.where((ql == t + 1).unsqueeze(1), h2, last)
+        out.append(F.relu(last[:ct] @ W["film_layer.1.weight"].t() + W["film_layer.1.bias"]))
+    return out
+
+
+@torch.no_grad()
+def sim_trunk(W, Wq, feat, cts, film, B, T, st, taps=None):
+    """feat [n_img, 512, h, w] frame-major; Wq = the (possibly rounded) conv_init / 1x1 / 3x3 / fc weights of this setting."""
+    C = W["conv_init.weight"].shape[0]
+    at = W["fc_attn_1.weight"].shape[1]
+    all_features = []
+    off = 0
+    masks = feat.new_zeros(B, T, 1)
+    valid = feat.new_zeros(B, T, 1)
+    for i, ct in enumerate(cts):
+        x = feat[off:off + ct]
+        off += ct
+        r = st.R("a_init", F.relu(F.conv2d(x, Wq["w_init"], W["conv_init.bias"], padding=1)))
+        mean = r.mean(dim=(0, 2, 3))
+        var = r.var(dim=(0, 2, 3), unbiased=False)
+        xb = (r - mean.view(1, -1, 1, 1)) * torch.rsqrt(var.view(1, -1, 1, 1) + BN_EPS)
+        xb = st.R("a_bn", xb * W["bn_init.weight"].view(1, -1, 1, 1) + W["bn_init.bias"].view(1, -1, 1, 1))
+        res = st.R("a_res", F.relu(F.conv2d(xb, Wq["w_1x1"], W["conv1x1_layers.0.bias"])))
+        z = st.R("a_z", F.conv2d(res, Wq["w_3x3"], W["film_pipeline.0.bias"], padding=1))
+        fv = film[i]
+        g, b = fv[:, :C].view(-1, C, 1, 1), fv[:, C:2 * C].view(-1, C, 1, 1)
+        out = st.R("a_out", F.relu(g * z + b) + res)
+        if taps is not None:       # input means for the coherent rounding of the trunk's weights (exact pass)
+            for k, t in (("w_init", x), ("w_3x3", res)):
+                taps.setdefault(k, []).append((t.double().sum((0, 2, 3)), t.shape[0] * t.shape[2] * t.shape[3]))
+            taps.setdefault("w_fc", []).append((out.reshape(ct, -1).double().sum(0), ct))
+        fe = out.reshape(ct, -1) @ Wq["w_fc"].t() + W["fc_embed_attn.bias"]
+        all_features.append(F.pad(fe, (0, 0, 0, B - ct)))
+        masks[ct:, i, 0] = NEG_MASK
+        valid[:ct, i, 0] = 1.0
+    all_features = torch.stack(all_features, 0).permute(1, 0, 2)
+    all_features = F.pad(all_features, (0, 0, 0, T - all_features.shape[1]))
+    masks[:, len(cts):, 0] = 0.0
+    features = (all_features @ W["fc_attn_1.weight"].t() + W["fc_attn_1.bias"]) * valid
+    h = feat.new_zeros(B, at)
+    cell = feat.new_zeros(B, at)
+    hs = []
+    for i in range(T):
+        v_i = (h @ W["fc_hidden_attn.weight"].t() + W["fc_hidden_attn.bias"]).view(B, 1, 1)
+        coefs = torch.softmax(v_i + features + masks, dim=1)
+        ctxt = torch.bmm(coefs.permute(0, 2, 1), all_features).view(B, -1)
+        g = ctxt @ W["lstm_attn.weight_ih"].t() + W["lstm_attn.bias_ih"]
+        h, cell = lstm_cell(g, h, cell, W["lstm_attn.weight_hh"], W["lstm_attn.bias_hh"])
+        hs.append(h)
+    hs = torch.stack(hs, 1).reshape(B, -1)
+    return hs @ W["out_linear.weight"].t() + W["out_linear.bias"]
+
+
+def trunk_weights(W, st, means):
+    from videonavqa_amd.stem import coherent_round
+    src = {"w_init": W["conv_init.weight"], "w_1x1": W["conv1x1_layers.0.weight"], "w_3x3": W["film_pipeline.0.weight"],
+           "w_fc": W["fc_embed_attn.weight"]}
+    out = {}
+    for k, w in src.items():
+        mode = st.wmode.get(k)
+        if mode is None:
+            out[k] = w
+        elif mode == "rtn" or (mode == "coh" and k == "w_1x1"):     # (BatchNorm output: zero mean at initialisation, nothing to cancel)
+            out[k] = w.half().float()
+        else:
+            w4 = w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+            out[k] = coherent_round(w4, means[k], torch.float16).view_as(w)
+    return out
+
+
+def pack_frames(clip, v_lens):
+    """Frame-major image list of the valid (sample, frame) pairs, samples in descending-length (stable) order."""
+    B, _, H, W, T = clip.shape
+    v_sorted, perm = torch.sort(v_lens, dim=0, descending=True, stable=True)
+    cts = []
+    for i in range(T):
+        ct = int((v_sorted >= i + 1).sum())
+        if ct == 0:
+            break
+        cts.append(ct)
+    idx_b = torch.cat([perm[:ct] for ct in cts])
+    idx_t = torch.cat([torch.full((ct,), i, dtype=torch.long) for i, ct in enumerate(cts)])
+    frames = clip[idx_b.to(clip.device), :, :, :, idx_t.to(clip.device)]
+    return frames, cts, v_sorted, perm
+
+
+def settings_list(only_combos=False):
+    S = []
+    if not only_combos:
+        for p in STEM_ACTS + TRUNK_ACTS:
+            S.append(Setting(p, [p]))
+        for w in TRUNK_W:
+            S.append(Setting(w + ":rtn", wmode={w: "rtn"}))
+        for w in ("w_init", "w_3x3", "w_fc"):
+            S.append(Setting(w + ":coh", wmode={w: "coh"}))
+    allw = {w: "rtn" for w in TRUNK_W}
+    cohw = {w: "coh" for w in TRUNK_W}
+    S += [Setting("stem acts (all 10)", STEM_ACTS),
+          Setting("stem acts - clip", [a for a in STEM_ACTS if a != "a_clip"]),
+          Setting("stem acts - feat", [a for a in STEM_ACTS if a != "a_feat"]),
+          Setting("stem acts - feat,od31", [a for a in STEM_ACTS if a not in ("a_feat", "a_od31")]),
+          Setting("stem acts - feat,od31,od22", [a for a in STEM_ACTS if a not in ("a_feat", "a_od31", "a_od22")]),
+          Setting("stem acts - feat,od31,od22,clip", [a for a in STEM_ACTS if a not in ("a_feat", "a_od31", "a_od22", "a_clip")]),
+          Setting("stem acts - feat,od31,od22,od21", [a for a in STEM_ACTS if a not in ("a_feat", "a_od31", "a_od22", "a_od21")]),
+          Setting("trunk acts (all 5)", TRUNK_ACTS),
+          Setting("trunk acts - z", [a for a in TRUNK_ACTS if a != "a_z"]),
+          Setting("trunk w rtn (all 4)", wmode=allw),
+          Setting("trunk w coh (all 4)", wmode=cohw),
+          Setting("ALL acts + trunk w rtn  (~ precision fp16, exact stem weights)", STEM_ACTS + TRUNK_ACTS, allw),
+          Setting("ALL acts + trunk w coh", STEM_ACTS + TRUNK_ACTS, cohw),
+          Setting("ALL acts - z + trunk w coh", [a for a in STEM_ACTS + TRUNK_ACTS if a != "a_z"], cohw),
+          # candidate modes: what stays rounded
+          Setting("cand A: stem - feat,od31 ; trunk a_res only ; w coh(init,3x3)",
+                  [a for a in STEM_ACTS if a not in ("a_feat", "a_od31")] + ["a_res"], {"w_init": "coh", "w_3x3": "coh"}),
+          Setting("cand B: stem - feat,od31,od22 ; trunk a_res ; w coh(init,3x3)",
+                  [a for a in STEM_ACTS if a not in ("a_feat", "a_od31", "a_od22")] + ["a_res"], {"w_init": "coh", "w_3x3": "coh"}),
+          Setting("cand C: stem - feat,od31,od22 ; trunk exact",
+                  [a for a in STEM_ACTS if a not in ("a_feat", "a_od31", "a_od22")]),
+          Setting("cand D: stem all ; trunk a_res ; w coh(init,3x3)", STEM_ACTS + ["a_res"], {"w_init": "coh", "w_3x3": "coh"}),
+          Setting("cand E: stem - od31 ; trunk a_res,a_out ; w coh(init,3x3,fc)",
+                  [a for a in STEM_ACTS if a != "a_od31"] + ["a_res", "a_out"], {"w_init": "coh", "w_3x3": "coh", "w_fc": "coh"})]
+    return S
+
+
+def product_logits(args, prec, device, data):
+    bm = budget_mod()
+    return bm.run(args, prec, device, data)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, nargs="*", default=[0, 1, 2, 3])
+    ap.add_argument("--batches", type=int, default=12)
+    ap.add_argument("--data", default="noise", choices=["noise", "smooth"])
+    ap.add_argument("--only-combos", action="store_true")
+    ap.add_argument("--no-product", action="store_true", help="skip the cross-checks against the library's fp32 / fp16 precisions")
+    o = ap.parse_args()
+    from videonavqa_amd import _lib as L
+    L.set_half("f16")
+    dev = torch.device("cuda", 0)
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    bm = budget_mod()
+    S = settings_list(o.only_combos)
+    acc = {s.name: [] for s in S}
+    per_seed = {}
+    t0 = time.time()
+    for seed in o.seeds:
+        args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
+                                  tail_channels=0, seed=seed)
+        data = bm.batches(args, dev, o.batches, o.data)
+        model, stem, vgg, od = bench.build(args, dev)
+        W = {k: v.detach().float() for k, v in model.state_dict().items()}
+        W.update({k: v.detach().float() for k, v in model.extra_state_tensors().items()})
+        exact = Setting("exact")
+        refs, packed, means = [], [], None
+        for bi, (clip, q, v_lens, q_lens) in enumerate(data):
+            frames, cts, v_sorted, perm = pack_frames(clip.to(dev), v_lens)
+            film = question_film(W, q.to(dev)[perm.to(dev)], q_lens[perm], cts)
+            feat = sim_stem(vgg, od, frames, exact)
+            taps = {} if bi == 0 else None
+            ref = sim_trunk(W, trunk_weights(W, exact, None), feat, cts, film, 8, 35, exact, taps)
+            if taps is not None:    # trunk input means from minibatch 0 (a deployment: running means of the previous steps)
+                means = {k: (sum(s for s, _ in v) / sum(n for _, n in v)).float() for k, v in taps.items()}
+            refs.append(ref.cpu())
+            packed.append((frames.cpu(), cts, film, perm, v_sorted, feat.cpu()))
+        if not o.no_product:
+            got = product_logits(args, "fp32", dev, data)
+            e = [float((g - r).abs().max() / r.abs().max()) for g, r in zip(got, refs)]
+            print("seed %d: restatement (exact) vs library precision 'fp32': max %.2e" % (seed, max(e)), flush=True)
+            for prec in ("fp16", "fp16x"):
+                got = product_logits(args, prec, dev, data)
+                e = [float((g - r).abs().max() / r.abs().max()) * 1e3 for g, r in zip(got, refs)]
+                print("seed %d: library precision '%s' vs restatement (exact): max %.3f rms %.3f   %s" %
+                      (seed, prec, max(e), (sum(x * x for x in e) / len(e)) ** 0.5, " ".join("%.2f" % x for x in e)), flush=True)
+        del model, stem
+        torch.cuda.empty_cache()
+        stem_cache = {}
+        for s in S:
+            wq = trunk_weights(W, s, means)
+            errs = []
+            sk = tuple(sorted(a for a in s.acts if a in STEM_ACTS))
+            for bi, (frames, cts, film, perm, v_sorted, feat0) in enumerate(packed):
+                if not sk:
+                    feat = feat0.to(dev)
+                else:
+                    if (sk, bi) not in stem_cache:
+                        stem_cache[(sk, bi)] = sim_stem(vgg, od, frames.to(dev), s).cpu()
+                    feat = stem_cache[(sk, bi)].to(dev)
+                out = sim_trunk(W, wq, feat, cts, film, 8, 35, s).cpu()
+                errs.append(float((out - refs[bi]).abs().max() / refs[bi].abs().max()) * 1e3)
+            acc[s.name] += errs
+            per_seed.setdefault(s.name, []).append(max(errs))
+            if len(stem_cache) > 36:
+                stem_cache.clear()
+        print("seed %d done (%.0f s)" % (seed, time.time() - t0), flush=True)
+    print("\n%-78s %7s %7s %7s   max per seed" % ("setting (x 1e-3; sq = mean squared, x 1e-6)", "sq", "rms", "max"))
+    for s in S:
+        e = acc[s.name]
+        sq = sum(x * x for x in e) / len(e)
+        print("%-78s %7.4f %7.3f %7.3f   %s" % (s.name, sq, sq ** 0.5, max(e), " ".join("%.2f" % x for x in per_seed[s.name])), flush=True)
+
+
+if __name__ == "__main__":
+    main()

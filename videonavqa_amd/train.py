@@ -78,56 +78,87 @@ class FlatParams(object):
 
 
 class DynamicLossScale(object):
-    """Loss scale of the fp16-storage precision, adjusted like torch.amp.GradScaler but WITHOUT a host sync in the step:
-    the fused clip+Adam kernel itself skips an update whose gradient norm is not finite and counts it in a device int32; the
-    host copies that counter into pinned memory asynchronously after every step and looks at the copy that has ARRIVED at the
-    next one — an overflow halves the scale one or two steps late (those steps are skipped on the device too if they
-    overflow), `growth_interval` clean steps double it (cap 2^24).  Powers of two only: scaling is exact."""
+    """Loss scale of the fp16-storage precision, adjusted like torch.amp.GradScaler but WITHOUT a host sync in the step and
+    DETERMINISTICALLY: the fused clip+Adam kernel itself skips an update whose gradient norm is not finite and counts
+    it in a device int32 (`count`; the same kernel derives Adam's bias correction from launches - count ON THE DEVICE, so no host
+    read-back enters an update).  After every step the host starts an asynchronous copy of the counter into one of LAG + 1 pinned
+    words and consumes the copy started exactly LAG steps earlier (`event.synchronize()` on a copy that old returns at once) —
+    never "whichever copy happens to have arrived": data-parallel replicas see identical reduced gradients, hence identical
+    counters, hence take every scale decision at the same step whatever their host timing.  One observation halves the scale
+    ONCE, however many of the lagging steps overflowed with it; `growth_interval` clean observations double it (cap 2^24).
+    Powers of two only: scaling is exact.  With `pinned_scale` the scale never moves (the counter still counts).
+    scale = 1 and growth off is the form every other precision uses (overflow skip + statistics only)."""
+    LAG = 2
 
-    def __init__(self, device, init=None, growth_interval=200, max_scale=2.0 ** 24, min_scale=1.0):
+    def __init__(self, device, init=None, growth_interval=200, max_scale=2.0 ** 24, min_scale=1.0, applies=True):
         from .models import common as C
         self._C = C
-        self.scale = float(C.FP16_GRAD_SCALE if init is None else init)
+        self.applies = bool(applies)         # False: a counter only (precisions without a loss scale)
+        self.scale = float(C.FP16_GRAD_SCALE if init is None else init) if self.applies else 1.0
         self.growth_interval, self.max_scale, self.min_scale = int(growth_interval), float(max_scale), float(min_scale)
         self.count = torch.zeros(1, dtype=torch.int32, device=device)
-        self._host = torch.zeros(1, dtype=torch.int32).pin_memory() if torch.device(device).type == "cuda" else None
-        self._event, self._seen, self._clean = None, 0, 0
+        self._cuda = torch.device(device).type == "cuda"
+        self._host = [torch.zeros(1, dtype=torch.int32) for _ in range(self.LAG + 1)]
+        if self._cuda:
+            self._host = [t.pin_memory() for t in self._host]
+        self._events = [None] * (self.LAG + 1)
+        self._steps, self._seen, self._clean = 0, 0, 0
         self.skipped_steps = 0
-        C.set_fp16_loss_scale(self.scale)
+        if self.applies:
+            C.set_fp16_loss_scale(self.scale)
 
     def after_step(self):
-        """Call right after the clip+Adam launch: consume the previous read-back, start the next one.  Returns the number of
-        newly observed skipped steps (the caller takes them off its Adam step count)."""
+        """Call right after the clip+Adam launch: start this step's read-back, consume the one started LAG steps ago.
+        Returns the number of skipped steps newly observed (statistics; the device keeps Adam's step count itself)."""
         new = 0
-        if self._host is not None:
-            if self._event is not None and self._event.query():
-                seen = int(self._host[0])
-                new = seen - self._seen
-                self._seen = seen
-                self._event = None
-            if self._event is None:
-                self._host.copy_(self.count, non_blocking=True)
-                self._event = torch.cuda.Event()
-                self._event.record()
+        slot = self._steps % (self.LAG + 1)
+        old = (self._steps + 1) % (self.LAG + 1)          # the slot written LAG steps ago (and re-used next step)
+        self._host[slot].copy_(self.count, non_blocking=True)
+        if self._cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        else:                                             # (host tensors — the CPU tests of the host logic: the copy is done)
+            ev = True
+        self._events[slot] = ev
+        if self._events[old] is not None:
+            if self._cuda:
+                self._events[old].synchronize()
+            seen = int(self._host[old][0])
+            new = seen - self._seen
+            self._seen = seen
+        self._steps += 1
         if new > 0:
             self.skipped_steps += new
-            self.scale = max(self.scale * 0.5 ** new, self.min_scale)
             self._clean = 0
+            if self.applies:
+                self.scale = max(self.scale * 0.5, self.min_scale)
         else:
             self._clean += 1
-            if self._clean >= self.growth_interval:
+            if self.applies and self._clean >= self.growth_interval:
                 self.scale = min(self.scale * 2.0, self.max_scale)
                 self._clean = 0
-        self._C.set_fp16_loss_scale(self.scale)
+        if self.applies:
+            self._C.set_fp16_loss_scale(self.scale)
         return new
 
+    def skipped_now(self):
+        """The device counter, read synchronously (checkpoint time)."""
+        return int(self.count.item())
+
     def state_dict(self):
-        return {"scale": self.scale, "clean_steps": self._clean, "skipped_steps": self.skipped_steps}
+        return {"scale": self.scale, "clean_steps": self._clean, "skipped_steps": self.skipped_now()}
 
     def load_state_dict(self, d):
-        self.scale, self._clean = float(d.get("scale", self.scale)), int(d.get("clean_steps", 0))
+        """Restores the scale and the growth counter; the device counter restarts at zero together with the launch count
+        (Trainer.load_checkpoint sets the launch count to the checkpoint's APPLIED steps)."""
+        if self.applies:
+            self.scale = float(d.get("scale", self.scale))
+            self._C.set_fp16_loss_scale(self.scale)
+        self._clean = int(d.get("clean_steps", 0))
         self.skipped_steps = int(d.get("skipped_steps", 0))
-        self._C.set_fp16_loss_scale(self.scale)
+        self.count.zero_()
+        self._events = [None] * (self.LAG + 1)
+        self._steps, self._seen = 0, 0
 
 
 def sync_replicas(tensors, src=0):
@@ -262,11 +293,14 @@ class Trainer(object):
         self._trunk_done = [None] * self._n_slots  # event per slot: last trunk pass that read that slot
         self._inputs_ready = None        # recorded on the CALLER's stream at step() entry: clips / labels produced so far
         # fp16 storage: dynamic loss scale (VNQA_FP16_LOSS_SCALE=<value> pins it: no adjustment, the round-2/3 behaviour)
+        # Every precision gets the device-side skip of a non-finite step and its counter ('fp16x' splits fp32
+        # activations into fp16 halves — |v| > 65504 becomes inf — and had no protection); only fp16 STORAGE has a loss scale.
         self.loss_scaler = None
-        if getattr(model, "compute_dtype", None) == torch.float16 and self.fp.flat.is_cuda:
+        if self.fp.flat.is_cuda:
             pinned = os.environ.get("VNQA_FP16_LOSS_SCALE")
             self.loss_scaler = DynamicLossScale(self.fp.flat.device, init=float(pinned) if pinned else None,
-                                                growth_interval=(1 << 62) if pinned else 200)
+                                                growth_interval=(1 << 62) if pinned else 200,
+                                                applies=getattr(model, "compute_dtype", None) == torch.float16)
         self._in_step = False            # prefetch() called from inside step() (current stream = the trunk stream) or by the caller
         self._inline_stem_done = None    # event after a stem pass that ran INLINE on the trunk / caller's stream (shared buffers)
 
@@ -280,9 +314,11 @@ class Trainer(object):
         """Same structure as torch.optim.Adam(model.parameters()).state_dict(): per-parameter
         step / exp_avg / exp_avg_sq, one param group."""
         state, off = {}, 0
+        # torch's `step` = updates APPLIED = clip+Adam launches minus the launches the device skipped (non-finite gradients)
+        applied = self.fp.step_count - (self.loss_scaler.skipped_now() if self.loss_scaler is not None else 0)
         for i, p in enumerate(self.fp.params):
             k = p.numel()
-            state[i] = {"step": torch.tensor(float(self.fp.step_count)),
+            state[i] = {"step": torch.tensor(float(applied)),
                         "exp_avg": self.fp.m[off:off + k].view_as(p).clone(),
                         "exp_avg_sq": self.fp.v[off:off + k].view_as(p).clone()}
             off += k
@@ -294,7 +330,11 @@ class Trainer(object):
         """CPU copies of the tensors state_dict() does not carry (frozen conv1x1_layers) for the checkpoint's
         'extra_state' key."""
         fn = getattr(self.model, "extra_state_tensors", None)
-        return {k: v.detach().cpu().clone() for k, v in fn().items()} if fn else {}
+        out = {k: v.detach().cpu().clone() for k, v in fn().items()} if fn else {}
+        if self.loss_scaler is not None and self.loss_scaler.applies:
+            # the dynamic loss scale travels with the checkpoint (ADVICE r4: a resume restarted at 2^10)
+            out["_loss_scale"] = dict(self.loss_scaler.state_dict())
+        return out
 
     def load_checkpoint(self, ckpt):
         """Restore model + optimizer from a reference-schema checkpoint dict."""
@@ -316,6 +356,8 @@ class Trainer(object):
                     self.fp.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
                     self.fp.step_count = int(st["step"])
                 off += k
+        if self.loss_scaler is not None:       # launch count := applied steps, device skip counter := 0, saved scale restored
+            self.loss_scaler.load_state_dict((ckpt.get("extra_state") or {}).get("_loss_scale") or {})
 
     def to_device_async(self, t):
         return L.to_device_async(t, self.stem_device)
@@ -490,8 +532,8 @@ class Trainer(object):
             self.fp.grad.clamp_(-clamp, clamp)
         self.fp.clip_adam_step(self.lr, self.clip,        # (the kernel zeroes the gradient buffer; the sinks are reset with it)
                                overflow_count=None if self.loss_scaler is None else self.loss_scaler.count)
-        if self.loss_scaler is not None:      # updates skipped on the device (overflow) do not count as Adam steps
-            self.fp.step_count = max(self.fp.step_count - self.loss_scaler.after_step(), 0)
+        if self.loss_scaler is not None:      # (updates skipped on the device are taken off Adam's step count ON the device)
+            self.loss_scaler.after_step()
         ev = torch.cuda.Event()
         ev.record(main)
         self._trunk_done[self._slot] = ev
