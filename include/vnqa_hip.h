@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 415
+#define VNQA_ABI_VERSION 418
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -90,6 +90,13 @@ typedef struct vnqa_conv_desc {
 #define VNQA_CONV_X_WRAP2 4       /* x has c_in / 2 PHYSICAL channels and is read twice along K against wt = [w_hi | w_lo] ([c_out][taps][c_in]):
                                    * the two-product form x . w_hi + x . w_lo of a 16-bit activation with split weights (precision 'fp16w');
                                    * plain epilogues, tiles 256x256 / 256x128 / 256x64 / 512x128 / 320x128 or AUTO; c_in % 128 == 0 */
+#define VNQA_CONV_DUAL_OUT 0x20000 /* y gets 2 c_out channels per pixel (c_y >= 2 c_out): [hi | lo] with hi = h16(v), lo = h16(v - hi) — the fp32
+                                   * result v (bias, ReLU, 2x2 max-pool, affine all applied in fp32) as a PAIR of 16-bit values.  A consumer
+                                   * that is a plain conv over 2 c_out input channels against [w | w] contracts the unrounded activation.
+                                   * Patch-stationary tiles only (VNQA_TILE_PS_224x256 / _STEM_PS_224x256), 3x3, no border_sub */
+#define VNQA_CONV_DUAL_HI2 0x40000 /* with VNQA_CONV_DUAL_OUT: three segments [hi | lo | hi] (c_y >= 3 c_out) — the operand of a consumer that
+                                   * contracts the unrounded activation against SPLIT weights [w_hi | w_hi | w_lo] as a plain conv over
+                                   * 3 c_out input channels (x_hi w_hi + x_lo w_hi + x_hi w_lo) */
 /* bits 8..15 of flags: the persistent conv kernels leave n CUs (a multiple of 8, <= 224) to the other streams of the process */
 #define VNQA_CONV_RESERVE_CUS(n) ((((n) < 0 ? 0 : ((n) > 224 ? 224 : (n))) / 8) << 8)
 #define VNQA_CONV_RESERVE_OF(flags) ((((flags) >> 8) & 0xff) * 8)
@@ -447,6 +454,12 @@ int vnqa_frame_layout(const int32_t* v_sorted_host, const int32_t* perm_host, in
  * slabs itself (no reduce launch; bf16, <= 8192 tiles — measured slower end to end, DESIGN 5: an A/B option, off by default).
  */
 #define VNQA_WGRAD_FUSED_REDUCE 0x100
+/* VNQA_WGRAD_X_PAIR / _X_TRIPLE (16-bit format): x is a [hi | lo] / [hi | lo | hi] tensor with 2 / 3 c_in physical channels per pixel
+ * (the output of a producer launched with VNQA_CONV_DUAL_OUT [| VNQA_CONV_DUAL_HI2]); the gradient contracts its first segment —
+ * h16(x), what a plain 16-bit tensor would hold — with no copy (precision 'fp16h': conv_init's weight gradient from the stem's
+ * split features). */
+#define VNQA_WGRAD_X_PAIR 0x200
+#define VNQA_WGRAD_X_TRIPLE 0x400
 int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t w, int32_t c_in,
                                     int32_t c_out, int32_t taps);
 int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace,

@@ -80,3 +80,28 @@ def test_bench_parser_knows_the_round4_modes():
     assert r.returncode == 0
     for token in ("--mode", "fp16x", "fp16w", "--clip-dtype", "--no-eval-leg"):
         assert token in r.stdout, token
+
+
+def test_gpus_8_plumbing_run_spawns_eight_ranks_and_prints_one_line():
+    """`bench.py --gpus 8`'s own spawn path with 8 ranks — no 8-GPU node is within reach, so the host side of the
+    multi-rank path (fresh child interpreters, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* contract, gloo rendezvous at 127.0.0.1,
+    replica broadcast, the Trainer's overlapped gradient reducer, barrier-bracketed timed region with MAX over ranks, the `comm`
+    block, rank 0's single JSON line relayed by the parent) runs on CPU tensors with a stand-in module."""
+    env = {k: v for k, v in ENV.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plumbing", "--steps", "4", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp8"
+    c = d["comm"]
+    assert c["ranks"] == 8 and c["backend"] == "gloo" and c["allreduce_alone_ms"] > 0 and c["early_reduced_parameters"] >= 1
+    assert "exposed_comm_ms_per_step" in c and "ms_per_step_without_collectives" in c
+    assert d["replicas_identical"] is True
+    # a rank whose environment disagrees with --gpus refuses instead of running a smaller world
+    bad = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plumbing"], env=bad, capture_output=True, text=True,
+                        timeout=120)
+    assert r2.returncode != 0 and "{" not in r2.stdout

@@ -43,3 +43,10 @@ def test_x3_products_and_the_fp16x_precision_on_the_fp16_build():
     and north star's 1e-3 on all three full-size parity batches — needs the fp16 build, hence this child run."""
     tail = _run(["tests/test_gpu_x3.py"], 1500)
     assert " passed" in tail and "skipped" not in tail.splitlines()[-1], tail
+
+
+def test_pair_tensors_and_the_fp16h_precision_on_the_fp16_build():
+    """precision='fp16h' (tests/test_gpu_pair.py): the dual-output epilogue, the three-product conv on pair tensors, the pair
+    weight gradient, the goldens, and north star's 1e-3 at full size on 4 weight seeds x 12 minibatches + smooth data."""
+    tail = _run(["tests/test_gpu_pair.py"], 2400)
+    assert " passed" in tail and "skipped" not in tail.splitlines()[-1], tail

@@ -1,0 +1,312 @@
+"""GPU: precision='fp16h' — SPLIT activations [hi | lo (| hi)] (the patch-stationary conv's dual epilogue, VNQA_CONV_DUAL_OUT /
+_HI2), the three-product conv on a split tensor (a plain conv over 3 C channels against [w_hi | w_hi | w_lo], plain and with the
+BNSTATS epilogue, on the patch-stationary and the implicit-GEMM tiles), the weight gradient from a split tensor's first segment
+(VNQA_WGRAD_X_PAIR / _X_TRIPLE), and the precision itself against the exact-f32 path, the reference goldens and north
+star's 1e-3 at BASELINE.json's size on 4 weight seeds x 12 minibatches and on data that does not look like the calibration frames.
+
+Runs in the fp16 build of the library (one 16-bit storage format per process): collected only when the process's format is f16
+(VNQA_TEST_LOW_PRECISION=fp16: tests/test_gpu_fp16.py starts that pytest run)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import LOW, QV_CASES, build_product_model, rel_err
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(LOW != "fp16", reason="pair tensors are fp16 halves: run with VNQA_TEST_LOW_PRECISION=fp16 "
+                                                       "(tests/test_gpu_fp16.py does)")]
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _padded(n, h, w, c, seed, scale=1.0, positive=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.zeros(n, h + 2, w + 2, c)
+    v = torch.randn(n, h, w, c, generator=g) * scale
+    x[:, 1:1 + h, 1:1 + w] = v.abs() if positive else v
+    return x.cuda()
+
+
+def _torch_conv(x_pad, w_oihw, bias, relu, pool, post=None):
+    x = x_pad[:, 1:-1, 1:-1].permute(0, 3, 1, 2).double()
+    y = F.conv2d(x, w_oihw.double(), bias.double(), padding=1)
+    if relu:
+        y = F.relu(y)
+    if pool:
+        y = F.max_pool2d(y, 2)
+    if post is not None:
+        y = y * post[0].double().view(1, -1, 1, 1) + post[1].double().view(1, -1, 1, 1)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("cfg", [dict(h=28, w=28, relu=True, pool=True), dict(h=14, w=14, relu=False, pool=False),
+                                 dict(h=14, w=14, relu=True, pool=False, post=True), dict(h=20, w=26, relu=True, pool=True),
+                                 dict(h=28, w=28, relu=True, pool=False, n=3, cout=256)])
+def test_dual_output_pair_holds_the_fp32_result_in_two_halves(cfg):
+    """VNQA_CONV_DUAL_OUT on the patch-stationary tiles (both tile widths, tiles straddling images, pooling, affine, an overlapping
+    last column block): hi is bit for bit the plain launch's 16-bit output; hi + lo reproduces the fp32 result (bias, ReLU, pool,
+    affine in fp32) to 2^-21 — against a float64 torch conv of the same fp16 operands: the accumulation error of K = 4608 fp32 terms."""
+    from videonavqa_amd import _lib as L
+    from videonavqa_amd import kernels as K
+    n, h, w, cin, cout = cfg.get("n", 5), cfg["h"], cfg["w"], 512, cfg.get("cout", 512)
+    x = _padded(n, h, w, cin, 1).half()
+    g = torch.Generator().manual_seed(2)
+    w4 = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda().half().float()
+    wt = K.pack_conv_weight(w4, torch.float16)
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    post = ((torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()) if cfg.get("post") else None
+    kw = dict(bias=bias, relu=cfg["relu"], pool2=cfg["pool"], post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+              tile=L.TILE_STEM_PS_224x256)
+    plain = K.conv2d_igemm(x, wt, **kw)
+    pair = K.conv2d_igemm(x, wt, dual_out=True, **kw)
+    assert pair.shape == plain.shape[:3] + (2 * cout,) and pair.dtype == torch.float16
+    hi, lo = pair[..., :cout], pair[..., cout:]
+    if post is None:
+        assert torch.equal(hi, plain)
+    else:       # (the plain epilogue applies the affine to the storage-rounded value and rounds again; the dual one works in fp32)
+        assert float((hi.float() - plain.float()).abs().max()) <= 2.0 ** -9 * float(plain.float().abs().max())
+    assert float(pair[:, 0].abs().max()) == 0 and float(pair[:, :, -1].abs().max()) == 0          # zero halo (fresh output)
+    ref = _torch_conv(x.float(), w4, bias, cfg["relu"], cfg["pool"], post)
+    got = (hi.double() + lo.double())[:, 1:-1, 1:-1]
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 3e-6 * scale, float((got - ref).abs().max()) / scale
+    assert float((hi.double()[:, 1:-1, 1:-1] - ref).abs().max()) > 1e-4 * scale            # (the hi half alone is an fp16 rounding away)
+    assert float(lo.abs().max()) <= 2.0 ** -10 * float(hi.abs().max())
+
+
+def test_conv_over_a_pair_tensor_with_doubled_weights_contracts_the_unrounded_activation():
+    """The stem's conv31 / conv32 in precision 'fp16h': a plain conv over the pair tensor's 2 C channels against [w | w] equals the
+    conv of the fp32 activation (hi + lo) with w — the consumer no longer sees the producer's storage rounding."""
+    from videonavqa_amd import _lib as L
+    from videonavqa_amd import kernels as K
+    n, h, w, c = 4, 14, 14, 512
+    v = _padded(n, h, w, c, 3, positive=True)                       # the fp32 activation
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    pair = torch.cat([hi, lo], dim=-1).contiguous()
+    g = torch.Generator().manual_seed(4)
+    w4 = (torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5).cuda().half().float()
+    wt = K.pack_conv_weight(w4, torch.float16)
+    wt2 = torch.cat([wt, wt], dim=2).contiguous()
+    bias = torch.zeros(c, device="cuda")
+    got = K.conv2d_igemm(pair, wt2, bias=bias, tile=L.TILE_STEM_PS_224x256, dual_out=True)
+    got = (got[..., :c].double() + got[..., c:].double())[:, 1:-1, 1:-1]
+    ref = _torch_conv(v, w4, bias, False, False)
+    one = _torch_conv(hi.float(), w4, bias, False, False)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 3e-6 * scale
+    assert float((one - ref).abs().max()) > 3e-5 * scale            # what the plain fp16 input would have cost
+
+
+def test_triple_output_feeds_a_plain_conv_with_split_weights_three_products():
+    """VNQA_CONV_DUAL_HI2: the producer lays out [hi | lo | hi]; its consumer — a PLAIN patch-stationary conv over 3 C channels against
+    [w_hi | w_hi | w_lo] — contracts the unrounded activation with unrounded weights (the stem's conv31 / conv32 in precision
+    'fp16h'): against float64 on the fp32 operands, <= 3e-6 (x_lo . w_lo dropped, fp32 accumulation of K = 13 824 terms)."""
+    from videonavqa_amd import _lib as L
+    from videonavqa_amd import kernels as K
+    n, h, w, c = 4, 14, 14, 512
+    x0 = _padded(n, h, w, c, 11).half()
+    g = torch.Generator().manual_seed(12)
+    wa = (torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5).cuda().half().float()
+    wb = (torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5).cuda()                       # fp32 weights, NOT fp16-representable
+    bias = torch.zeros(c, device="cuda")
+    tri = K.conv2d_igemm(x0, K.pack_conv_weight(wa, torch.float16), bias=bias, relu=True, tile=L.TILE_STEM_PS_224x256, dual_out=3)
+    assert tri.shape[-1] == 3 * c and torch.equal(tri[..., :c], tri[..., 2 * c:])
+    v = tri[..., :c].float() + tri[..., c:2 * c].float()                                      # the producer's fp32 result
+    wt3 = K._split_weight(K.pack_conv_weight(wb, torch.float32), "hhl")
+    got = K.conv2d_igemm(tri, wt3, bias=bias, tile=L.TILE_STEM_PS_224x256, dual_out=True)
+    got = (got[..., :c].double() + got[..., c:].double())[:, 1:-1, 1:-1]
+    ref = _torch_conv(v, wb, bias, False, False)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 3e-6 * scale, float((got - ref).abs().max()) / scale
+    rounded = _torch_conv(v.half().float(), wb.half().float(), bias, False, False)            # what one fp16 product would see
+    assert float((rounded - ref).abs().max()) > 1e-4 * scale
+
+
+def _split3(v):
+    hi = v.half()
+    return torch.cat([hi, (v - hi.float()).half(), hi], dim=-1).contiguous()
+
+
+@pytest.mark.parametrize("tile", ["ps", "igemm"])
+@pytest.mark.parametrize("taps", [9, 1])
+def test_three_product_conv_on_a_split_tensor_matches_exact_f32(taps, tile):
+    """split_in: [x_hi | x_lo | x_hi] against [w_hi | w_hi | w_lo] — a plain conv over 3 C channels — against the exact-f32 MFMA
+    conv of the same library on the fp32 activation and fp32 weights: the fp16 OUTPUT rounding is all that is left."""
+    from videonavqa_amd import _lib as L
+    from videonavqa_amd import kernels as K
+    if taps == 1 and tile == "ps":
+        pytest.skip("the patch-stationary kernel is a 3x3 / 5x5 kernel")
+    n, h, w, cin, cout = 6, 14, 14, 512, 512
+    v = _padded(n, h, w, cin, 5, positive=True)
+    tri = _split3(v)
+    g = torch.Generator().manual_seed(6)
+    k = 3 if taps == 9 else 1
+    w4 = (torch.randn(cout, cin, k, k, generator=g) / (cin * taps) ** 0.5).cuda()
+    wt32 = K.pack_conv_weight(w4, torch.float32)
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    ref = K.conv2d_igemm(v, wt32, bias=bias, relu=True)                                      # exact-f32 MFMA path
+    got = K.conv2d_igemm(tri, wt32, bias=bias, relu=True, split_in=True, tile=L.TILE_PS_224x256 if tile == "ps" else L.TILE_AUTO)
+    assert got.dtype == torch.float16 and got.shape == ref.shape
+    assert float((got.float() - ref).abs().max()) < 6e-4 * float(ref.abs().max())
+    plain = K.conv2d_igemm(v.half(), K.pack_conv_weight(w4, torch.float16), bias=bias, relu=True)
+    e3 = float((got.float() - ref).pow(2).mean().sqrt())
+    e1 = float((plain.float() - ref).pow(2).mean().sqrt())
+    r0 = float((ref.half().float() - ref).pow(2).mean().sqrt())                             # the output rounding alone
+    assert e3 < 1.05 * r0 and e1 > 1.3 * r0, (e3, e1, r0)
+
+
+def test_three_product_conv_with_bnstats_epilogue_matches_the_two_pass_statistics():
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd.models.common import FrameLayout
+    lay = FrameLayout([4, 4, 3, 2], 4, "cuda")
+    n, h, w, cin, cout = lay.n_img, 14, 14, 512, 512
+    v = _padded(n, h, w, cin, 7, positive=True)
+    pair = _split3(v)
+    g = torch.Generator().manual_seed(8)
+    w4 = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+    wt32 = K.pack_conv_weight(w4, torch.float32)
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    fused = K.conv2d_igemm_bnstats(pair, wt32, bias, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts), split_in=True)
+    assert fused is not None
+    y, mean, var = fused
+    y2 = K.conv2d_igemm(pair, wt32, bias=bias, relu=True, split_in=True)
+    assert torch.equal(y, y2)
+    m2, v2 = K.frame_bn_stats(y2, lay.frame_off_i32, lay.n_frames)
+    assert float((mean - m2).abs().max()) < 1e-5 * float(m2.abs().max())
+    assert float((var - v2).abs().max()) < 1e-4 * float(v2.abs().max())
+
+
+@pytest.mark.parametrize("segs", [2, 3])
+def test_wgrad_from_a_split_tensor_contracts_its_first_segment(segs):
+    from videonavqa_amd import kernels as K
+    n, h, w, cin, cout = 5, 14, 14, 512, 512
+    v = _padded(n, h, w, cin, 9, positive=True)
+    hi = v.half().contiguous()
+    parts = [hi, (v - hi.float()).half()] + ([hi] if segs == 3 else [])
+    x = torch.cat(parts, dim=-1).contiguous()
+    dy = _padded(n, h, w, cout, 10, scale=0.01).half()
+    a, da = K.conv2d_wgrad(hi, dy, 9)
+    b, db = K.conv2d_wgrad(x, dy, 9, x_segs=segs)
+    assert a.shape == b.shape == (cout, 9, cin)
+    assert torch.equal(a, b) and torch.equal(da, db)
+
+
+def _random_stem(prec):
+    import torch.nn as nn
+    from videonavqa_amd.models import ObjDetectCNN
+    from videonavqa_amd.stem import VGGFront
+    torch.manual_seed(0)
+    vgg, od = VGGFront(prec), ObjDetectCNN(5, 512, 8, 0, True, True, precision=prec)
+    with torch.no_grad():
+        for conv in vgg.features.values():
+            nn.init.kaiming_uniform_(conv.weight, a=1.0)
+        for m in od.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1.0)
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.8, 1.2)
+    return vgg.cuda().eval(), od.cuda().eval()
+
+
+def test_fp16h_stem_split_features_are_closer_to_exact_than_the_fp16_stem():
+    """The frozen stem at 224 x 224 (the geometry whose 28 x 28 / 14 x 14 maps the pair path serves): pair features (hi + lo) against
+    the exact-f32 stem are closer than the fp16 stem's, the hi half is a valid fp16 feature tensor, and with pair_features=False
+    (consumers that read no pairs) the output is a plain tensor of the usual shape.  At 160 x 208 (10 x 13 maps: not served by the
+    patch-stationary kernel) the stem falls back to the fp16 precision's layers, bit for bit."""
+    from videonavqa_amd.models.common import FrameLayout
+    from videonavqa_amd.stem import FrozenStem
+    torch.set_grad_enabled(False)
+    try:
+        clip = torch.rand(2, 3, 224, 224, 2, generator=torch.Generator().manual_seed(5)).cuda()
+        lay = FrameLayout([2, 1], 2, "cuda")
+        out = {}
+        for name, prec, kw in (("ref", "fp32", {}), ("h", "fp16h", {}), ("p", "fp16", {}), ("hp", "fp16h", dict(pair_features=False))):
+            vgg, od = _random_stem(prec)
+            stem = FrozenStem(vgg, od, prec, **kw)
+            out[name] = stem.forward_clip(clip, lay.img_of, lay.n_img).clone()
+        assert out["h"].shape[-1] == 1536 and out["p"].shape[-1] == 512 and out["hp"].shape == out["p"].shape
+        assert torch.equal(out["h"][..., :512], out["h"][..., 1024:])
+        ref = out["ref"][..., :512].double()
+        pair = out["h"][..., :512].double() + out["h"][..., 512:1024].double()
+        e_h = float((pair - ref).pow(2).mean().sqrt())
+        e_p = float((out["p"].double() - ref).pow(2).mean().sqrt())
+        e_hp = float((out["hp"].double() - ref).pow(2).mean().sqrt())
+        assert e_h < 0.8 * e_p and e_hp < 0.95 * e_p, (e_h, e_hp, e_p)
+        assert float((out["h"][..., :512].double() - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+        clip = torch.rand(2, 3, 160, 208, 2, generator=torch.Generator().manual_seed(6)).cuda()
+        res = []
+        for prec in ("fp16h", "fp16"):
+            vgg, od = _random_stem(prec)
+            res.append(FrozenStem(vgg, od, prec).forward_clip(clip, lay.img_of, lay.n_img).clone())
+        assert res[0].shape == res[1].shape and torch.equal(res[0], res[1])
+    finally:
+        torch.set_grad_enabled(True)
+
+
+@pytest.mark.parametrize("case", ["film_attn_s196", "film_attn_full", "film_gp_full", "tmh_ragged"])
+def test_fp16h_models_match_the_reference_goldens(case):
+    """precision='fp16h' on the reference's golden cases (plain feature input: no pair tensors at 8 channels — the trunk's split
+    1x1 / fc weights and the loss-scaled fp16 backward are what runs): train-mode logits and gradients at the fp16 precision's
+    tolerances."""
+    import torch.nn as nn
+    model, g = build_product_model(case, "fp16h")
+    model.train()
+    model.init_hidden()
+    v, q = torch.from_numpy(g["v"]).cuda(), torch.from_numpy(g["q"]).cuda()
+    out = model(v, q, torch.from_numpy(g["v_lens"]), torch.from_numpy(g["q_lens"]))
+    assert rel_err(out.detach().float().cpu().numpy(), g["train_logits"]) < 1e-2
+    loss = nn.CrossEntropyLoss(reduction="sum")(out.float(), torch.from_numpy(g["y"]).cuda())
+    loss.backward()
+    num = den = 0.0
+    for name, p in model.named_parameters():
+        key = "grad/" + name
+        if key in g and p.grad is not None:
+            num += float(((p.grad.float().cpu() - torch.from_numpy(g[key])) ** 2).sum())
+            den += float((torch.from_numpy(g[key]) ** 2).sum())
+    assert den > 0 and (num / den) ** 0.5 < 0.3
+
+
+def _budget_mod():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("x3_error_budget", os.path.join(ROOT, "tools", "x3_error_budget.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _full_size_errors(seed, data, batches=12):
+    bm = _budget_mod()
+    args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
+                              tail_channels=0, seed=seed)
+    dev = torch.device("cuda", 0)
+    d = bm.batches(args, dev, batches, data)
+    ref = bm.run(args, "fp32", dev, d)
+    got = bm.run(args, "fp16h", dev, d)
+    rel = [float((a - b).abs().max() / b.abs().max()) for a, b in zip(got, ref)]
+    flips = sum(int((a.argmax(1) != b.argmax(1)).sum()) for a, b in zip(got, ref))
+    return rel, flips
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_fp16h_meets_1e3_on_twelve_full_size_minibatches_for_every_weight_seed(seed):
+    """North star's tolerance as stated (logits within 1e-3 of the reference forward, answer classes equal) at BASELINE.json's size:
+    precision 'fp16h' against the exact-f32 precision (itself pinned to the oracle at this size, tests/test_gpu_fullsize.py) on twelve
+    seeded minibatches (one full-length, eleven ragged) for FOUR sets of random weights — VERDICT r4 #1: the round-4 tolerance mode
+    read 1.04e-3 on (seed 3, minibatch 9)."""
+    rel, flips = _full_size_errors(seed, "noise")
+    assert max(rel) <= 1e-3, (seed, ["%.2e" % r for r in rel])
+    assert flips == 0, (seed, flips)
+
+
+def test_fp16h_meets_1e3_on_data_that_does_not_look_like_the_calibration_frames():
+    """The stem's weights are rounded coherently against seeded NOISE frames; these clips are smooth (14 x 14 noise upsampled 16 x,
+    per-clip brightness, slow drift): other channel means, large flat regions."""
+    rel, flips = _full_size_errors(0, "smooth")
+    assert max(rel) <= 1e-3, ["%.2e" % r for r in rel]
+    assert flips == 0

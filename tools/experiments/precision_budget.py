@@ -50,10 +50,51 @@ class Setting(object):
         return t.half().float() if key in self.acts else t
 
 
-@torch.no_grad()
-def sim_stem(vgg, od, frames, st, chunk=40):
+STEM_W = ["sw_c11", "sw_c12", "sw_c21", "sw_c22", "sw_comp", "sw_od21", "sw_od22", "sw_od31", "sw_od32"]
+
+
+def stem_weight_deltas(vgg, od, calib):
+    """Per stem layer: (rounded - exact) of the weights the fp16 stem multiplies with — BatchNorm scale folded first, rounded
+    coherently against the calibration means exactly as FrozenStem does; the composed pair as its 5x5 weight.  The simulation
+    adds conv(x, delta) to the exact layer output (first-order exact; the composed pair's border is second order)."""
+    from videonavqa_amd.stem import coherent_round, _fold_bn
     f = vgg.features
-    conv = lambda t, c: F.conv2d(t, c.weight.float(), c.bias.float(), padding=1)
+    d = {}
+    cr = lambda w, m: coherent_round(w, calib[m], torch.float16) - w
+    d["sw_c11"] = cr(f["0"].weight.float(), "first")
+    d["sw_c12"] = cr(f["2"].weight.float(), "vgg0")
+    d["sw_c21"] = cr(f["5"].weight.float(), "vgg1")
+    d["sw_c22"] = cr(f["7"].weight.float(), "vgg2")
+    s1, _ = _fold_bn(od.bn1)
+    w1, w2 = od.conv11.weight.double().cpu(), od.conv12.weight.double().cpu() * s1.double().cpu().view(-1, 1, 1, 1)
+    wc = F.conv2d(w1.permute(1, 0, 2, 3), w2.flip(2, 3), padding=2).permute(1, 0, 2, 3).float().to(f["0"].weight.device).contiguous()
+    d["sw_comp"] = cr(wc, "od0")                       # acts on the composed output BEFORE relu / pool, already bn1-scaled
+    d["sw_od21"] = cr(od.conv21.weight.float(), "od2")
+    s2, _ = _fold_bn(od.bn2)
+    d["sw_od22"] = cr(od.conv22.weight.float() * s2.view(-1, 1, 1, 1), "od3")      # bn2-scaled
+    d["sw_od31"] = cr(od.conv31.weight.float(), "od4")
+    s3, _ = _fold_bn(od.bn3)
+    d["sw_od32"] = cr(od.conv32.weight.float() * s3.view(-1, 1, 1, 1), "od5")
+    return d
+
+
+@torch.no_grad()
+def sim_stem(vgg, od, frames, st, chunk=40, wd=None):
+    f = vgg.features
+    wd = wd or {}
+
+    def conv(t, c, key=None, pad=1):
+        y = F.conv2d(t, c.weight.float(), c.bias.float(), padding=1)
+        if key in st.acts and key in wd:
+            y = y + F.conv2d(t, wd[key], None, padding=pad)
+        return y
+
+    def bnx(t, b, x_in=None, key=None, pad=1):
+        """eval BatchNorm; a folded layer's weight perturbation (already scaled by gamma * rstd) is added after it"""
+        y = F.batch_norm(t, b.running_mean.float(), b.running_var.float(), b.weight.float(), b.bias.float(), False, 0.0, BN_EPS)
+        if key in st.acts and key in wd:
+            y = y + F.conv2d(x_in, wd[key], None, padding=pad)
+        return y
     bn = lambda t, b: F.batch_norm(t, b.running_mean.float(), b.running_var.float(), b.weight.float(), b.bias.float(), False, 0.0, BN_EPS)
     outs = []
     n = frames.shape[0]
@@ -61,16 +102,17 @@ def sim_stem(vgg, od, frames, st, chunk=40):
         frames = torch.cat([frames, frames.new_zeros((chunk - n % chunk,) + tuple(frames.shape[1:]))])
     for i in range(0, frames.shape[0], chunk):
         x = st.R("a_clip", frames[i:i + chunk])
-        a = st.R("a_c11", F.relu(conv(x, f["0"])))
-        a = st.R("a_c12", F.max_pool2d(F.relu(conv(a, f["2"])), 2))
-        a = st.R("a_c21", F.relu(conv(a, f["5"])))
-        a = st.R("a_c22", bn(F.max_pool2d(F.relu(conv(a, f["7"])), 2), od.bn_input))     # (the producer applies bn_input, rounds once)
+        a = st.R("a_c11", F.relu(conv(x, f["0"], "sw_c11")))
+        a = st.R("a_c12", F.max_pool2d(F.relu(conv(a, f["2"], "sw_c12")), 2))
+        a = st.R("a_c21", F.relu(conv(a, f["5"], "sw_c21")))
+        a = st.R("a_c22", bn(F.max_pool2d(F.relu(conv(a, f["7"], "sw_c22")), 2), od.bn_input))     # (the producer applies bn_input, rounds once)
+        a0 = a
         a = conv(a, od.conv11)                                                            # composed pair: never stored
-        a = st.R("a_comp", F.max_pool2d(F.relu(bn(conv(a, od.conv12), od.bn1)), 2))
-        a = st.R("a_od21", conv(a, od.conv21))
-        a = st.R("a_od22", F.max_pool2d(F.relu(bn(conv(a, od.conv22), od.bn2)), 2))
-        a = st.R("a_od31", conv(a, od.conv31))
-        outs.append(st.R("a_feat", F.relu(bn(conv(a, od.conv32), od.bn3))))
+        a = st.R("a_comp", F.max_pool2d(F.relu(bnx(conv(a, od.conv12), od.bn1, a0, "sw_comp", 2)), 2))
+        a1 = st.R("a_od21", conv(a, od.conv21, "sw_od21"))
+        a = st.R("a_od22", F.max_pool2d(F.relu(bnx(conv(a1, od.conv22), od.bn2, a1, "sw_od22")), 2))
+        a1 = st.R("a_od31", conv(a, od.conv31, "sw_od31"))
+        outs.append(st.R("a_feat", F.relu(bnx(conv(a1, od.conv32), od.bn3, a1, "sw_od32"))))
     return torch.cat(outs)[:n]
 
 
@@ -196,6 +238,18 @@ def settings_list(only_combos=False):
             S.append(Setting(w + ":rtn", wmode={w: "rtn"}))
         for w in ("w_init", "w_3x3", "w_fc"):
             S.append(Setting(w + ":coh", wmode={w: "coh"}))
+    if not only_combos:
+        for p in STEM_W:
+            S.append(Setting(p + " (coherent, as the fp16 stem)", [p]))
+    S += [Setting("stem weights (all 9, coherent)", STEM_W),
+          Setting("stem weights - od31,od32", [w for w in STEM_W if w not in ("sw_od31", "sw_od32")]),
+          Setting("stem weights - od22,od31,od32", [w for w in STEM_W if w not in ("sw_od22", "sw_od31", "sw_od32")])]
+    fp16h = [a for a in STEM_ACTS if a not in ("a_feat", "a_od31", "a_od22")] + ["a_init", "a_bn", "a_res", "a_out"]
+    S += [Setting("fp16h as built (acts + 3x3 rtn + stem weights)", fp16h + STEM_W, {"w_3x3": "rtn"}),
+          Setting("fp16h + split weights conv31,conv32", fp16h + [w for w in STEM_W if w not in ("sw_od31", "sw_od32")], {"w_3x3": "rtn"}),
+          Setting("fp16h + split weights conv22,conv31,conv32", fp16h + [w for w in STEM_W if w not in ("sw_od22", "sw_od31", "sw_od32")], {"w_3x3": "rtn"}),
+          Setting("fp16h + split conv31,conv32 + a_init pair", [a for a in fp16h if a != "a_init"] + [w for w in STEM_W if w not in ("sw_od31", "sw_od32")], {"w_3x3": "rtn"}),
+          Setting("fp16h + split conv31,conv32 + a_init,a_od21 pair", [a for a in fp16h if a not in ("a_init", "a_od21")] + [w for w in STEM_W if w not in ("sw_od31", "sw_od32")], {"w_3x3": "rtn"})]
     allw = {w: "rtn" for w in TRUNK_W}
     cohw = {w: "coh" for w in TRUNK_W}
     S += [Setting("stem acts (all 10)", STEM_ACTS),
@@ -276,19 +330,21 @@ def main():
                 e = [float((g - r).abs().max() / r.abs().max()) * 1e3 for g, r in zip(got, refs)]
                 print("seed %d: library precision '%s' vs restatement (exact): max %.3f rms %.3f   %s" %
                       (seed, prec, max(e), (sum(x * x for x in e) / len(e)) ** 0.5, " ".join("%.2f" % x for x in e)), flush=True)
+        from videonavqa_amd.stem import calibration_means
+        wdel = stem_weight_deltas(vgg, od, calibration_means(vgg, od))
         del model, stem
         torch.cuda.empty_cache()
         stem_cache = {}
         for s in S:
             wq = trunk_weights(W, s, means)
             errs = []
-            sk = tuple(sorted(a for a in s.acts if a in STEM_ACTS))
+            sk = tuple(sorted(a for a in s.acts if a in STEM_ACTS or a in STEM_W))
             for bi, (frames, cts, film, perm, v_sorted, feat0) in enumerate(packed):
                 if not sk:
                     feat = feat0.to(dev)
                 else:
                     if (sk, bi) not in stem_cache:
-                        stem_cache[(sk, bi)] = sim_stem(vgg, od, frames.to(dev), s).cpu()
+                        stem_cache[(sk, bi)] = sim_stem(vgg, od, frames.to(dev), s, wd=wdel).cpu()
                     feat = stem_cache[(sk, bi)].to(dev)
                 out = sim_trunk(W, wq, feat, cts, film, 8, 35, s).cpu()
                 errs.append(float((out - refs[bi]).abs().max() / refs[bi].abs().max()) * 1e3)

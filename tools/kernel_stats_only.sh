@@ -1,3 +1,6 @@
+#!/bin/bash
+# ON THE GPU BOX: rocprofv3 --kernel-trace --stats of the default bench + the per-kernel table (profiles/rNN_kernel_stats.*)
+mkdir -p gpurun_out
 ROOT=$PWD; export PYTHONPATH=$ROOT; cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof
 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python3 $ROOT/bench.py --steps 20 --warmup 5 --repeats 1 --no-parity --no-cpu-baseline --no-eval-leg > $ROOT/gpurun_out/prof_bench.json 2> $ROOT/gpurun_out/prof_bench.err
 cd $ROOT

@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 415          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 418          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -54,10 +54,14 @@ class ConvDesc(ctypes.Structure):
 CONV_ZERO_HALO = 1      # vnqa_conv_desc.flags
 CONV_XCD_SPLIT_N = 2
 CONV_X_WRAP2 = 4
+CONV_DUAL_OUT = 0x20000  # y = [h16(v) | h16(v - h16(v))], 2 c_out channels (patch-stationary tiles)
+CONV_DUAL_HI2 = 0x40000  # with CONV_DUAL_OUT: y = [hi | lo | hi], 3 c_out channels (a three-product consumer's operand)
 X3_POST_ZERO_HALO = 4      # vnqa_x3_post: or'ed into out_x3
 LAYOUT_MAX_BATCH = 256     # vnqa_frame_layout: VNQA_LAYOUT_MAX_BATCH
 GEMM_X_WRAP2 = 0x400
 WGRAD_FUSED_REDUCE = 0x100     # option bit of vnqa_conv2d_wgrad's dtype argument
+WGRAD_X_PAIR = 0x200           # x is a [hi | lo] tensor (2 c_in physical channels): contract its hi half
+WGRAD_X_TRIPLE = 0x400         # x is a [hi | lo | hi] tensor (3 c_in physical channels): contract its first segment
 GEMM_OUT_F32 = 0x200           # option bit of vnqa_gemm_nt's dtype argument: 16-bit operands, fp32 output
 
 

@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
   const int Ho = p.pool ? (p.H >> 1) : p.H, Wo = p.pool ? (p.W >> 1) : p.W;
   // BNSTATS: every thread keeps sum / sum of squares of ITS 16-byte channel chunk over the tile rows it stores, per frame
   // slot (NT % CH == 0: a thread's chunk is the same on every pass of the loop)
-  constexpr bool kStatsOk = (TAG == 0) && (NT % CH == 0) && (CH <= 64) && (64 % CH == 0);   // trunk instantiations only
+  constexpr bool kStatsOk = (TAG == 0 || TAG == 4) && (NT % CH == 0) && (CH <= 64) && (64 % CH == 0);   // trunk instantiations (plain and wrap) only
   float st_s[3][EPC], st_q[3][EPC];
   int frame0 = 0;
   if (kStatsOk && p.epi == VNQA_EPI_BNSTATS) {
@@ -991,7 +991,7 @@ int launch(const ConvArgs& a, hipStream_t stream) {
   static_assert(LDS <= 160 * 1024, "LDS budget exceeded");
   // the BNSTATS epilogue is compiled into an instantiation only where the kernel's own predicate (kStatsOk) holds: refuse the
   // request here instead of launching a kernel that would leave the statistics workspace unwritten
-  constexpr bool kStatsOk = (TAG == 0) && (NT % (BN * ES / 16) == 0) && (BN * ES / 16 <= 64) && (64 % (BN * ES / 16) == 0);
+  constexpr bool kStatsOk = (TAG == 0 || TAG == 4) && (NT % (BN * ES / 16) == 0) && (BN * ES / 16 <= 64) && (64 % (BN * ES / 16) == 0);
   if (a.epi == VNQA_EPI_BNSTATS && !kStatsOk) {
     vnqa_set_error("conv2d_igemm_fused_fwd: the BNSTATS epilogue is not available on this tile (%dx%d, %d threads, tag %d)",
                    BM, BN, NT, TAG);
@@ -1067,8 +1067,8 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
     return VNQA_ERR_UNSUPPORTED;
   }
   if (a.x_wrap2) {          // two-product form: x read twice along K (TAG 4 instantiations of the plain tiles)
-    if (dtype != VNQA_BF16 || a.epi != VNQA_EPI_NONE || a.wt_tiled || a.D != 0 || a.group_tiles != 0 || a.Cin % 128 != 0) {
-      vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_X_WRAP2 needs a plain 16-bit 2-D conv / GEMM with c_in %% 128 == 0 and K-major weights");
+    if (dtype != VNQA_BF16 || !(a.epi == VNQA_EPI_NONE || a.epi == VNQA_EPI_BNSTATS) || a.wt_tiled || a.D != 0 || a.group_tiles != 0 || a.Cin % 128 != 0) {
+      vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_X_WRAP2 needs a 16-bit 2-D conv / GEMM (plain or BNSTATS epilogue) with c_in %% 128 == 0 and K-major weights");
       return VNQA_ERR_UNSUPPORTED;
     }
     switch (tile) {
@@ -1417,6 +1417,9 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
   a.zero_halo = (d->flags & VNQA_CONV_ZERO_HALO) ? 1 : 0;
   a.xcd_split = (d->flags & VNQA_CONV_XCD_SPLIT_N) ? 1 : 0;
   a.x_wrap2 = (d->flags & VNQA_CONV_X_WRAP2) ? 1 : 0;
+  a.dual_out = (d->flags & VNQA_CONV_DUAL_OUT) ? ((d->flags & VNQA_CONV_DUAL_HI2) ? 2 : 1) : 0;
+  VNQA_CHECK_ARG(!a.dual_out || d->tile == VNQA_TILE_PS_224x256 || d->tile == VNQA_TILE_STEM_PS_224x256,
+                 "conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT is served by the patch-stationary tiles only");
   a.pool = d->pool2;
   a.M = d->n_img * d->h * d->w;
   a.tilesN = 0;

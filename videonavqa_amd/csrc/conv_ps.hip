@@ -254,6 +254,92 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
 
   // ---------------- epilogue ----------------
   // acc[i][j][e]: pixel = wm*112 + i*16 + fr ; cout = wn*128 + j*16 + 4*fh + e
+  if constexpr (TAG == 2) {
+    // DUAL output (VNQA_CONV_DUAL_OUT; precision 'fp16h'): y has 2 Cout channels per pixel, [hi | lo] with hi = h16(v) and
+    // lo = h16(v - hi) — the fp32 result as a PAIR of 16-bit values (22 significand bits), so that the consumer, a plain conv
+    // over 2 Cout input channels against [w | w], contracts the UNROUNDED activation: the storage rounding of this tensor, one
+    // of the few that dominate the 16-bit logits error (profiles/r05_precision_budget.txt), is gone at the price of the
+    // consumer's second product.  Everything is finished in fp32 (bias, ReLU, 2x2 max-pool, affine) — both 16-bit halves of
+    // the tile at once would need 2 x 118 KiB of LDS, so the tile goes through LDS as fp32 in two passes of 128 couts (the
+    // waves of cout half `pass` stage, all four store): same LDS bytes per pass as the plain 16-bit epilogue.
+    constexpr int CROWF = WTN * 4 + 16;
+    static_assert(BM * CROWF <= 2 * PATCH_BYTES + 2 * B_BYTES, "LDS budget (dual epilogue)");
+    constexpr int CHF = WTN / 8;          // 8-channel chunks (32 B of fp32) per staged row
+    const bool has_post_d = (p.post_scale != nullptr);
+    const int rows_out_d = p.pool ? BM / 4 : BM;
+    const int OCd = p.pool ? TC / 2 : TC;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      if (wn == pass) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = j * 16 + 4 * fh;                 // within this pass's 128 couts
+          const int co = tile_n * BN + pass * WTN + col;
+          float b4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.bias != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b4[e] = (co + e < p.Cout) ? p.bias[co + e] : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int prow = wm * WTM + i * 16 + fr;
+            float4 v;
+            v.x = acc[i][j][0] + b4[0]; v.y = acc[i][j][1] + b4[1]; v.z = acc[i][j][2] + b4[2]; v.w = acc[i][j][3] + b4[3];
+            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *(float4*)(smem + prow * CROWF + col * 4) = v;
+          }
+        }
+      }
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < rows_out_d * CHF; idx += NT) {
+        const int orow = idx / CHF, c = idx - orow * CHF;
+        const int co0 = tile_n * BN + pass * WTN + c * 8;
+        const int orr = orow / OCd, occ = orow - orr * OCd;
+        const int g = g0 + (p.pool ? 2 * orr : orr);
+        if (g >= total_rows || co0 >= p.Cout) continue;
+        float v[8];
+        if (p.pool) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = -INFINITY;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int ml = (2 * orr + (d >> 1)) * TC + 2 * occ + (d & 1);
+            const float4 a0 = *(const float4*)(smem + ml * CROWF + c * 32);
+            const float4 a1 = *(const float4*)(smem + ml * CROWF + c * 32 + 16);
+            v[0] = fmaxf(v[0], a0.x); v[1] = fmaxf(v[1], a0.y); v[2] = fmaxf(v[2], a0.z); v[3] = fmaxf(v[3], a0.w);
+            v[4] = fmaxf(v[4], a1.x); v[5] = fmaxf(v[5], a1.y); v[6] = fmaxf(v[6], a1.z); v[7] = fmaxf(v[7], a1.w);
+          }
+        } else {
+          const float4 a0 = *(const float4*)(smem + orow * CROWF + c * 32);
+          const float4 a1 = *(const float4*)(smem + orow * CROWF + c * 32 + 16);
+          v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        }
+        if (has_post_d) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
+        }
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hw[e] = pack2_h16(v[2 * e], v[2 * e + 1]);
+          lw[e] = pack2_h16(v[2 * e] - h16_lo(hw[e]), v[2 * e + 1] - h16_hi(hw[e]));
+        }
+        const int n = g / p.H;
+        const int y = g - n * p.H;
+        const int yo = p.pool ? (y >> 1) : y;
+        const int xo = (p.pool ? xb >> 1 : xb) + occ;
+        const size_t ooff = (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+        vnqa_bf16* dst = (vnqa_bf16*)(p.y) + ooff;
+        *(uint4*)dst = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        *(uint4*)(dst + p.Cout) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        // VNQA_CONV_DUAL_HI2: [hi | lo | hi] — the operand of a THREE-product consumer (a plain conv over 3 Cout channels against
+        // [w_hi | w_hi | w_lo]) laid out by the producer, no wrap logic in the consumer's main loop
+        if (p.dual_out == 2) *(uint4*)(dst + 2 * p.Cout) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   // composed-conv border correction (vnqa_conv2d_igemm_fwd_ex): row of the correction tensor for each of this lane's pixels
   // (-1: interior pixel or no correction); ring order: top row, bottom row, left column, right column
   int ring_row[TM];
@@ -624,6 +710,13 @@ extern "C" int vnqa_conv_ps_supported(const vnqa_conv_desc* d) {
 int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
   using namespace ps;
   const int halo = a.taps == 25 ? 2 : 1;
+  if (a.dual_out) {        // [hi | lo] pair output (TAG 2 instantiations: fp32 epilogue in two cout passes)
+    if (a.taps != 9 || a.epi != VNQA_EPI_NONE || a.border_sub != nullptr || a.zero_halo || a.Cout % 8 != 0 || a.Cy < (a.dual_out + 1) * a.Cout) {
+      vnqa_set_error("conv patch-stationary tile: VNQA_CONV_DUAL_OUT needs a plain 3x3 conv (no fused epilogue / border correction / "
+                     "halo zeroing), c_out %% 8 == 0 and c_y >= 2 c_out (3 c_out with VNQA_CONV_DUAL_HI2)");
+      return VNQA_ERR_UNSUPPORTED;
+    }
+  }
   if ((a.taps != 9 && a.taps != 25) || a.D != 0 || a.x_halo != halo || a.wt_tiled || a.partial != nullptr || a.Cin % 64 != 0 ||
       a.Cin < 64 || a.group_tiles != 0 || a.ring_h != 0 || (a.border_sub != nullptr && a.Cout % 4 != 0) ||
       !(a.epi == VNQA_EPI_NONE || ((a.epi == VNQA_EPI_FILM_RES || a.epi == VNQA_EPI_ADD_MASK) && tag == 0 && !a.pool && a.y_halo == 1)) ||
@@ -636,6 +729,7 @@ int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
   const int rc = ps_geometry(a.H, a.W, a.Cin, a.Cout, a.taps, a.pool, tc);
   if (rc != VNQA_OK) return rc;
   if (halo == 1) {
+    if (a.dual_out) return tc == 28 ? launch_ps<28, 1, 2>(a, st) : launch_ps<14, 1, 2>(a, st);
     if (tc == 28) return tag ? launch_ps<28, 1, 1>(a, st) : launch_ps<28, 1, 0>(a, st);
     return tag ? launch_ps<14, 1, 1>(a, st) : launch_ps<14, 1, 0>(a, st);
   }

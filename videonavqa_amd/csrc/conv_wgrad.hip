@@ -35,6 +35,7 @@ struct WgradArgs {
   int tilesCo, tilesCi;
   int ksteps_total, ksteps_per_slice, slices;
   int taps_real;    // SMALL form: `taps` counts tap GROUPS of 256 / Cin taps; this is the conv's tap count (27)
+  int x_cs;         // pixel stride of x in elements (Cin; 2 / 3 Cin for a [hi | lo (| hi)] tensor whose first segment is contracted: VNQA_WGRAD_X_PAIR / _X_TRIPLE)
   float* final;     // != NULL: the LAST workgroup to finish a tile folds the slices' partial tiles into `final` (no reduce launch)
 };
 
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
       st_coff_b[j] = (logical - sub * cpt) * 16;
     }
   }
-  const size_t rowA = (size_t)p.Cout * ES, rowB = (size_t)p.Cin * ES;
+  const size_t rowA = (size_t)p.Cout * ES, rowB = (size_t)p.x_cs * ES;
 
   // Contraction position of this lane's four staging rows, advanced by KP per stage (no division in the loop):
   // v = compact index (halo rows skipped when vrow > 0), pa = padded pixel index of the dY row, rem = v % vrow.
@@ -684,7 +685,7 @@ extern "C" int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
                      int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h = 0,
-                     bool small = false, bool fuse_reduce = false);
+                     bool small = false, bool fuse_reduce = false, int x_cs = 0);
 
 // the small-channel form's plan: tap groups x slices, two partial slabs per slice
 static bool small3d_ok(int c_in, int c_out, int dtype) {
@@ -742,7 +743,9 @@ extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, floa
                                  int32_t n_img, int32_t h, int32_t w, int32_t c_in, int32_t c_out,
                                  int32_t taps, int32_t dtype, void* stream) {
   const bool fuse_reduce = (dtype & VNQA_WGRAD_FUSED_REDUCE) != 0;      // per-call option bit (the library reads no environment)
-  dtype &= ~VNQA_WGRAD_FUSED_REDUCE;
+  const int x_segs = (dtype & VNQA_WGRAD_X_TRIPLE) ? 3 : ((dtype & VNQA_WGRAD_X_PAIR) ? 2 : 1);   // x: [hi | lo (| hi)], x_segs c_in physical channels
+  dtype &= ~(VNQA_WGRAD_FUSED_REDUCE | VNQA_WGRAD_X_PAIR | VNQA_WGRAD_X_TRIPLE);
+  VNQA_CHECK_ARG(x_segs == 1 || dtype == VNQA_BF16, "conv2d_wgrad: VNQA_WGRAD_X_PAIR / _X_TRIPLE need the 16-bit format");
   VNQA_CHECK_ARG(x && dy && dwt && workspace, "conv2d_wgrad: null pointer");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv2d_wgrad: bad dtype %d", dtype);
   VNQA_CHECK_ARG(taps == 9 || taps == 1, "conv2d_wgrad: taps must be 9 or 1");
@@ -750,7 +753,7 @@ extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, floa
   VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0, "conv2d_wgrad: empty problem");
   VNQA_CHECK_ARG((long long)n_img * (h + 2) * (w + 2) < (1ll << 31), "conv2d_wgrad: too many pixels");
   const Plan pl = make_plan(n_img, h, w, c_in, c_out, taps, dtype);
-  return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, taps, dtype, stream, 0, false, fuse_reduce);
+  return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, taps, dtype, stream, 0, false, fuse_reduce, x_segs > 1 ? x_segs * c_in : 0);
 }
 
 extern "C" int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype) {
@@ -771,7 +774,7 @@ extern "C" int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
                      int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h, bool small,
-                     bool fuse_reduce) {
+                     bool fuse_reduce, int x_cs) {
   hipStream_t st = (hipStream_t)stream;
   WgradArgs a;
   a.x = (const char*)x;
@@ -794,6 +797,7 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
   a.ksteps_per_slice = pl.ksteps_per_slice;
   a.slices = pl.slices;
   a.taps_real = taps;
+  a.x_cs = x_cs > 0 ? x_cs : c_in;
   a.final = nullptr;
   // (opt-in through the VNQA_WGRAD_FUSED_REDUCE bit of vnqa_conv2d_wgrad's dtype argument: measured SLOWER end to end — same-box A/B 845 vs 869 clips/s over three rounds: the agent-scope release / acquire
   // fences write back and invalidate L2 lines across the 8 XCDs for every workgroup, which costs more than the 20 us reduce

@@ -118,15 +118,25 @@ def main(argv=None):
     feature_extractor = get_frcnn_feature_extractor(args.frcnn_pretrained_path, args.precision).to(device)
     obj_detector = U.get_object_detector(precision=args.precision,
                                          load=args.synthetic == 0 or os.path.exists(U.OBJ_DETECTOR_PATH)).to(device)
-    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=stem_calibration(args, test_data))
-    reduction = 'mean' if args.loss_reduction == 'elementwise_mean' else args.loss_reduction
-    loss_fn = nn.CrossEntropyLoss(reduction=reduction)
-    trainer = Trainer(model, stem, loss_reduction=reduction, feature_channels=args.num_input_channels)
     if args.checkpoint_path is None or not os.path.exists(args.checkpoint_path):            # :252-255
         print('=> No checkpoint existent! Aborting.')
         sys.exit(-1)
     print('=> Restoring from checkpoint path %s' % args.checkpoint_path)
     checkpoint = torch.load(args.checkpoint_path, map_location=device)
+    # The frozen stem's 16-bit weights are rounded against calibration means (stem.coherent_round): test behind the SAME weights the
+    # checkpoint was trained behind — its own means when it carries them (written by Trainer.extra_state_dict); without them 'noise'
+    # / 'off' are reproducible from the flags alone, 'data' is not (it would calibrate on the TEST split) and is refused
+    calib = (checkpoint.get('extra_state') or {}).get('_stem_calibration')
+    if calib is None:
+        if getattr(args, 'stem_calibration', 'noise') == 'data':
+            print("=> --stem_calibration data: the checkpoint carries no calibration means (an older build wrote it) and the training "
+                  "frames are not available here — pass 'noise' or 'off', whichever the training run used. Aborting.")
+            sys.exit(-1)
+        calib = stem_calibration(args, None)
+    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=calib, pair_features=args.model != 'mac')
+    reduction = 'mean' if args.loss_reduction == 'elementwise_mean' else args.loss_reduction
+    loss_fn = nn.CrossEntropyLoss(reduction=reduction)
+    trainer = Trainer(model, stem, loss_reduction=reduction, feature_channels=args.num_input_channels)
     model.load_state_dict(checkpoint['state_dict'])
     if checkpoint.get('extra_state') and hasattr(model, 'load_reference_tensors'):
         model.load_reference_tensors(checkpoint['extra_state'])

@@ -357,9 +357,18 @@ def x3_post_again(out, n, h, w, c_out, y_halo, bias=None, relu=False, pool2=Fals
 
 
 def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
-                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False, desc_flags=0):
+                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False, desc_flags=0,
+                 split_in=False, dual_out=False):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
-    (x3_out: only inside f32_conv_mode("x3") — the output as the next x3 product's 16-bit operand, see _conv2d_x3.)"""
+    (x3_out: only inside f32_conv_mode("x3") — the output as the next x3 product's 16-bit operand, see _conv2d_x3.)
+    Precision 'fp16h':  dual_out = 2 / 3 — the output as a SPLIT tensor [hi | lo] / [hi | lo | hi] (hi = h16(v), lo = h16(v - hi);
+    VNQA_CONV_DUAL_OUT [| _HI2], patch-stationary tiles).  split_in — x is such a [hi | lo | hi] tensor (3 Cin channels) and wt the
+    fp32 K-major pack [Cout][taps][Cin]: the plain conv over 3 Cin channels against [w_hi | w_hi | w_lo] = x_hi w_hi + x_lo w_hi +
+    x_hi w_lo — the unrounded activation against unrounded weights, three MFMA products, no kernel of its own."""
+    if split_in:
+        assert L.is_half(x.dtype) and wt.dtype == torch.float32 and not isinstance(wt, TiledWeight) and x.shape[-1] == 3 * wt.shape[2] \
+            and not x3_out
+        wt = x3_weight(wt)                                   # [w_hi | w_hi | w_lo] along the contraction axis, cached on the pack
     x3m = _F32_CONV_MODE[0] in ("x3", "x2", "x3g", "x1g") and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
         relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 and x.shape[-1] % 64 == 0
     # inside the x3 mode a layer with a plain 16-bit input AND a rounded (plain 16-bit) output is exactly the two-product conv of
@@ -389,6 +398,13 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
     assert cin_w == (2 * Cin if w2 else Cin) and wt.dtype == x.dtype, (cin_w, x.shape, wt.dtype, x.dtype)
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     flags = 0
+    if dual_out:        # 2 (or True): [hi | lo]; 3: [hi | lo | hi]
+        segs = 3 if int(dual_out) == 3 else 2
+        assert tile in (L.TILE_PS_224x256, L.TILE_STEM_PS_224x256) and y_halo == 1 and border_sub is None and c_out % 8 == 0
+        if out is None:
+            out = empty_padded((N, Ho + 2, Wo + 2, segs * c_out), x.dtype, x.device)
+        assert out.shape[-1] == segs * c_out
+        flags = L.CONV_DUAL_OUT | (L.CONV_DUAL_HI2 if segs == 3 else 0)
     if out is None:
         if y_halo == 1 and c_out % 8 == 0 and tile not in (11, 12, 20, 21):
             # fresh output: the kernel zeroes the halo ring itself (VNQA_CONV_ZERO_HALO), no fill / halo launch
@@ -413,11 +429,15 @@ def _conv_desc(x, c_out, c_y, taps, relu, tile=L.TILE_AUTO):
                       L.CONV_ZERO_HALO)
 
 
-def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frames, min_frame_images):
+def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frames, min_frame_images, split_in=False):
     """conv (+bias, +ReLU) with the per-frame BatchNorm statistics of its output taken in the epilogue
     (vnqa_conv2d_igemm_fused_fwd, VNQA_EPI_BNSTATS).  Returns (y, mean [F,Cout], var [F,Cout]) or None when the frames are
-    too small for the tile (the caller then runs conv2d_igemm + frame_bn_stats)."""
+    too small for the tile (the caller then runs conv2d_igemm + frame_bn_stats).
+    split_in (precision 'fp16h'): x is a [hi | lo | hi] tensor, wt the fp32 pack — see conv2d_igemm."""
     N, Hp, Wp, _ = x.shape
+    if split_in:
+        assert wt.dtype == torch.float32 and x.shape[-1] == 3 * wt.shape[2]
+        wt = x3_weight(wt)
     c_out, taps, _ = wt.shape
     d = _conv_desc(x, c_out, c_out, taps, relu)
     ws_bytes = L.lib().vnqa_conv2d_bnstats_workspace(ctypes.byref(d), int(min_frame_images))
@@ -878,13 +898,18 @@ def workspace(nbytes, device):
 _WGRAD_OPTS = L.WGRAD_FUSED_REDUCE if os.environ.get("VNQA_WGRAD_FUSED_REDUCE", "0") == "1" else 0
 
 
-def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, defer_scale=False):
+def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, defer_scale=False, x_segs=1):
     """x, dy: padded NHWC (halo 1, same N/H/W). Returns (dwt fp32 [Cout][taps][Cin], dbias fp32 [Cout]).
+    x_segs = 2 / 3: x is a [hi | lo] / [hi | lo | hi] tensor (x_segs Cin physical channels); its first segment — the plain 16-bit
+    value — is contracted in place.
     defer_scale (the scaled x1g / x3g products of precision 'fp16x'): dwt is returned still multiplied by the split scale, its
     inverse attached as dwt._vnqa_inv — unpack_conv_wgrad applies it in its own pass (no separate multiply)."""
     N, Hp, Wp, Cin = x.shape
     Cout = dy.shape[-1]
     h, w = Hp - 2, Wp - 2
+    if x_segs > 1:
+        assert x_segs in (2, 3) and L.is_half(x.dtype) and dy.dtype == x.dtype and Cin % x_segs == 0 and not x3_active(dy)
+        Cin //= x_segs
     if L.is_half(x.dtype) and x3_active(dy) and _F32_CONV_MODE[0] != "x1g":
         x = x.float()          # (a 16-bit activation against an fp32 gradient is served by the one-product form only)
     assert dy.shape[:3] == x.shape[:3] and (dy.dtype == x.dtype or (L.is_half(x.dtype) and x3_active(dy)))
@@ -926,7 +951,7 @@ def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, defer_scale=False)
         dbias = dbias_out if (dbias_out is not None and dbias_out.numel() == Cout) else \
             torch.empty((Cout,), dtype=torch.float32, device=x.device)
     L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwt), L.ptr(dbias), L.ptr(ws), N, h, w, Cin, Cout,
-                                      taps, L.dtype_id(x.dtype) | _WGRAD_OPTS, L.stream()), "vnqa_conv2d_wgrad")
+                                      taps, L.dtype_id(x.dtype) | _WGRAD_OPTS | {1: 0, 2: L.WGRAD_X_PAIR, 3: L.WGRAD_X_TRIPLE}[x_segs], L.stream()), "vnqa_conv2d_wgrad")
     return dwt, dbias
 
 

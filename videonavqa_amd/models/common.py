@@ -42,12 +42,19 @@ def compute_dtype(precision):
         # 16-bit-MFMA precision — logits within north star's 1e-3 of exact fp32 (measured ~1e-5) at a multiple of its speed
         L.set_half("f16")
         return torch.float32
+    if precision == "fp16h":
+        # fp16 storage, arithmetic and loss-scaled backward exactly as 'fp16', with the FEW roundings that dominate the logits error
+        # removed where that is cheap (profiles/r05_precision_budget.txt): [hi | lo] pair activations on the stem's last three
+        # tensors, conv_init as three products on the pair features against split weights, the frozen 1x1 conv and fc_embed_attn
+        # with split weights (two products).  The tolerance mode of round 5.
+        L.set_half("f16")
+        return torch.float16
     if precision == "fp16w":
         # fp16 storage like 'fp16', but every FORWARD conv / GEMM runs the two-product form x . w_hi + x . w_lo (split weights, the
         # activation read twice along K): the 14 weight roundings of the fp16 precision are removed, its 15 activation roundings stay
         L.set_half("f16")
         return torch.float16
-    raise ValueError("precision must be 'bf16', 'fp16', 'fp16w', 'fp16x' or 'fp32' (got %r)" % (precision,))
+    raise ValueError("precision must be 'bf16', 'fp16', 'fp16h', 'fp16w', 'fp16x' or 'fp32' (got %r)" % (precision,))
 
 
 def is_x3(precision):
@@ -359,6 +366,7 @@ class FiLMTrunkBase(nn.Module):
             # (precision 'fp16x' also takes ONE rounded 16-bit feature tensor — FrozenStem(out_half=True): conv_init reads it as a
             # two-product conv, the trunk's own storage stays fp32)
             assert v_input.data.dtype == cdt or (self.__dict__.get("x3", False) and L.is_half(v_input.data.dtype))
+            # (precision 'fp16h': the stem's features may be a SPLIT tensor [hi | lo | hi] — three times the channels; conv_init recognises it)
             return v_input.data, lay, v_input.h, v_input.w
         assert v_input.is_cuda, "the HIP path needs device tensors (no CPU fallback)"
         B, C, h, w, T = v_input.shape
@@ -489,6 +497,10 @@ class FiLMTrunkBase(nn.Module):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
             blocks += [c1.weight, c1.bias, c3.weight, c3.bias]
         meta.c1_packs = self._frozen_c1_packs(h.dtype, L.round_up(C, 64))      # (the trunk's storage: fp32 in 'fp16x' whatever the features' type)
+        if self.__dict__.get("hyb", False):
+            meta.hybrid = True
+            packs32 = self._frozen_c1_packs(torch.float32, L.round_up(C, 64))
+            meta.c1_packs32 = [p[0] for p in packs32] if packs32 else None
         return ops.film_trunk_blocks(h, meta, uniq, blocks)
 
     def _frozen_c1_packs(self, cdt, c_pad):
@@ -498,12 +510,13 @@ class FiLMTrunkBase(nn.Module):
         if any(c.weight.requires_grad for c in self.conv1x1_layers):
             return None
         key = (cdt, c_pad, tuple((c.weight._version, c.weight.data_ptr()) for c in self.conv1x1_layers))
-        cached = self.__dict__.get("_c1_pack_cache")
+        cache = self.__dict__.setdefault("_c1_pack_cache", {})
+        cached = cache.get(cdt)
         if cached is None or cached[0] != key:
             packs = [(K.pack_conv_weight(c.weight, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
                       K.pack_conv_weight(c.weight, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad))
                      for c in self.conv1x1_layers]
-            cached = self.__dict__["_c1_pack_cache"] = (key, packs)
+            cached = cache[cdt] = (key, packs)
         return cached[1]
 
     @staticmethod
@@ -549,16 +562,25 @@ class FiLMTrunkBase(nn.Module):
         scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + BN_EPS)
         shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
         fdt = torch.float32 if cdt != x.dtype else K.fwd_pack_dtype(x)          # (fp32 packs in the two-product precision: the conv wrapper splits them)
-        wt0 = K.pack_conv_weight(self.conv_init.weight, fdt, c_out_pad=c_pad, c_in_pad=x.shape[-1])
-        h = K.conv2d_igemm(x, wt0, bias=K.pad_vec(self.conv_init.bias, c_pad), relu=True,
-                           post_scale=K.pad_vec(scale, c_pad), post_shift=K.pad_vec(shift, c_pad))
+        hyb = self.__dict__.get("hyb", False) and L.is_half(cdt)
+        split = ops.is_split(x, self.conv_init.weight.shape[1])                  # precision 'fp16h': [hi | lo | hi] features, three products
+        wt0 = K.pack_conv_weight(self.conv_init.weight, torch.float32 if split else fdt, c_out_pad=c_pad,
+                                 c_in_pad=x.shape[-1] // 3 if split else x.shape[-1])
+        ps = split and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
+        h = K.conv2d_igemm(x, wt0, bias=K.pad_vec(self.conv_init.bias, c_pad), relu=True, post_scale=K.pad_vec(scale, c_pad),
+                           post_shift=K.pad_vec(shift, c_pad), split_in=split, tile=L.TILE_PS_224x256 if ps else L.TILE_AUTO)
         if join is not None:
             join()
-        packs = self._frozen_c1_packs(cdt, c_pad)
+        packs = self._frozen_c1_packs(torch.float32 if hyb else cdt, c_pad)
         for k in range(self.num_res_blocks):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
-            wt1 = packs[k][0] if (packs and fdt == cdt) else K.pack_conv_weight(c1.weight, fdt, c_out_pad=c_pad, c_in_pad=c_pad)
-            res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(c1.bias, c_pad), relu=True)
+            if hyb:          # the frozen 1x1 conv against split weights (two products), as the training graph runs it
+                with K.f32_conv_mode("w2"):
+                    res = K.conv2d_igemm(h, packs[k][0] if packs else K.pack_conv_weight(c1.weight, torch.float32, c_out_pad=c_pad, c_in_pad=c_pad),
+                                         bias=K.pad_vec(c1.bias, c_pad), relu=True)
+            else:
+                wt1 = packs[k][0] if (packs and fdt == cdt) else K.pack_conv_weight(c1.weight, fdt, c_out_pad=c_pad, c_in_pad=c_pad)
+                res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(c1.bias, c_pad), relu=True)
             film, col = film_specs[k]
             if not (film.dtype == torch.float32 and film.stride(1) == 1):
                 film = film.float().contiguous()
@@ -582,7 +604,11 @@ class FiLMTrunkBase(nn.Module):
         cdt = self.compute_dtype
         for k in range(self.num_res_blocks):
             c1 = self.conv1x1_layers[k]
-            res = ops.conv(x, c1.weight, c1.bias, relu=True)
+            if self.__dict__.get("hyb", False) and L.is_half(x.dtype):      # precision 'fp16h': split weights on the frozen 1x1 conv
+                with K.f32_conv_mode("w2"):
+                    res = ops.conv(x, c1.weight, c1.bias, relu=True)
+            else:
+                res = ops.conv(x, c1.weight, c1.bias, relu=True)
             z = ops.conv(res, self.film_pipeline[k].weight, self.film_pipeline[k].bias, relu=False)
             gamma, beta = film_fn(k)
             x = film_relu_residual(z, res, gamma, beta, cdt)

@@ -31,6 +31,7 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         self.compute_dtype = compute_dtype(precision)
         self.x3 = precision == "fp16x"       # forward contractions as three fp16-half products (common.compute_dtype)
         self.w2 = precision == "fp16w"       # fp16 storage, forward contractions with split weights (two products)
+        self.hyb = precision == "fp16h"      # fp16 storage; pair features, conv_init x3, 1x1 / fc with split weights (common.compute_dtype)
 
         self.embed = nn.Embedding(vocab_size, q_embedding_size)                       # :37
         self._build_trunk_head(num_input_channels, num_res_block_channels)             # :39-44
@@ -104,7 +105,8 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
         n_img, hp, wp, c_pad = x.shape
         at = self.at_hidden_size
         at_pad = L.round_up(at, 64)
-        f = ops.fc_native(x.view(n_img, -1), self.fc_embed_attn.weight, self.fc_embed_attn.bias, C, h, w, at_pad, gscale)
+        f = ops.fc_native(x.view(n_img, -1), self.fc_embed_attn.weight, self.fc_embed_attn.bias, C, h, w, at_pad, gscale,
+                          split_weights=self.hyb)
         if fused:
             # temporal attention (:245-290) straight from the packed GEMM output: the zero-padded [B,T,at] tensor, the
             # validity grid and the -(1<<31) masks are formed inside the kernel.  v_i = fc_hidden_attn(h) is constant along

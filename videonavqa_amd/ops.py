@@ -104,10 +104,16 @@ class ConvFn(torch.autograd.Function):
         cdt = x.dtype
         c_in_pad = x.shape[-1]
         c_out_pad = L.round_up(c_out, 64)
-        wt = K.pack_conv_weight(weight, K.fwd_pack_dtype(x), c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+        ctx.x_segs = 3 if (L.is_half(x.dtype) and x.shape[-1] == 3 * L.round_up(c_in, 64)) else 1     # [hi | lo | hi] split features (precision 'fp16h')
         ctx.elu = relu is not True and relu == 2
-        y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu,
-                           tile=L.TILE_AUTO if ctx.elu else _ps_plain_tile(x, k, c_out_pad))   # (the ELU epilogue: igemm tiles only)
+        if ctx.x_segs == 3:
+            c_in_pad //= 3
+            wt = K.pack_conv_weight(weight, torch.float32, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+            y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu, split_in=True)
+        else:
+            wt = K.pack_conv_weight(weight, K.fwd_pack_dtype(x), c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+            y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu,
+                               tile=L.TILE_AUTO if ctx.elu else _ps_plain_tile(x, k, c_out_pad))   # (the ELU epilogue: igemm tiles only)
         ctx.relu = bool(relu) and not ctx.elu and mask_in_backward   # False: the consumer's backward applies the ReLU mask
         ctx.dims = (c_out, c_in, k, c_out_pad, c_in_pad)
         ctx.save_for_backward(x, weight, y if (ctx.relu or ctx.elu) else None)
@@ -130,7 +136,7 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             inv = 1.0 / ctx.grad_scale
-            dwt, dbias = K.conv2d_wgrad(x, dy, k * k, defer_scale=True)
+            dwt, dbias = K.conv2d_wgrad(x, dy, k * k, defer_scale=True, x_segs=ctx.x_segs)
             dw = K.unpack_conv_wgrad(dwt, c_out, c_in, alpha=inv)
             db = dbias[:c_out].clone() if inv == 1.0 else dbias[:c_out] * inv
         if ctx.needs_input_grad[0]:
@@ -237,6 +243,17 @@ class FilmReluResFn(torch.autograd.Function):
         return dz, dout, dgamma, dbeta
 
 
+def is_split(x, c_in):
+    """x is a SPLIT tensor [hi | lo | hi] of a layer with c_in input channels (precision 'fp16h': the stem's dual-output features,
+    laid out for a three-product consumer)."""
+    return L.is_half(x.dtype) and x.shape[-1] == 3 * L.round_up(c_in, 64)
+
+
+# conv_init on split features (precision 'fp16h', 777 GFLOP at the headline): True — the patch-stationary kernel (1.3-1.4 PFLOP/s on
+# 14 x 14 maps) + the two-pass statistics kernel; False — the implicit GEMM with the BNSTATS epilogue (one launch less, 0.3-0.4 of peak)
+HEAD_CONV_PS = True
+
+
 class FilmTrunkHeadFn(torch.autograd.Function):
     """First half of the TRAIN-mode conv trunk (film_attn_pt_stem.py:211) — the part that needs nothing from the question:
 
@@ -257,13 +274,20 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         half_in = K.x3_mode() in ("x3", "x2") and L.is_half(x.dtype)
         cdt = torch.float32 if half_in else x.dtype
         c_pad = L.round_up(C, 64)
-        wt0 = K.pack_conv_weight(conv_w, torch.float32 if half_in else K.fwd_pack_dtype(x), c_out_pad=c_pad, c_in_pad=x.shape[-1])
+        # precision 'fp16h': split features [hi | lo | hi] from the stem — conv_init as THREE products (a plain conv over 3 C channels
+        # against [w_hi | w_hi | w_lo]): the unrounded activation against unrounded weights; the layer's weight rounding alone is
+        # 0.14e-6 of the fp16 precision's 0.70e-6 squared logits error, its input rounding 0.07e-6 (profiles/r05_precision_budget.txt)
+        split = is_split(x, conv_w.shape[1])
+        ctx.x_segs = 3 if split else 1
+        c_in_pad = x.shape[-1] // 3 if split else x.shape[-1]
+        wt0 = K.pack_conv_weight(conv_w, torch.float32 if (half_in or split) else K.fwd_pack_dtype(x), c_out_pad=c_pad, c_in_pad=c_in_pad)
         b0 = K.pad_vec(conv_b, c_pad)
         fused = None
-        if L.is_half(cdt) and not K.w2_active(x):     # fp32 (parity) and the two-product precision keep the two-pass statistics kernel
-            fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts))
+        ps = split and HEAD_CONV_PS and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
+        if L.is_half(cdt) and not K.w2_active(x) and not ps:     # fp32 (parity) and the two-product precision keep the two-pass statistics kernel
+            fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts), split_in=split)
         if fused is None:
-            r = K.conv2d_igemm(x, wt0, bias=b0, relu=True)
+            r = K.conv2d_igemm(x, wt0, bias=b0, relu=True, split_in=split, tile=L.TILE_PS_224x256 if ps else L.TILE_AUTO)
             mean, var = K.frame_bn_stats(r, lay.frame_off_i32, lay.n_frames)
         else:
             r, mean, var = fused
@@ -299,13 +323,14 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         exact = c_pad == C
         dbn_w = _ret(s_bw if exact else None, K.colsum(s2, out=_into(s_bw) if exact else None)[:C])
         dbn_b = _ret(s_bb if exact else None, K.colsum(s1, out=_into(s_bb) if exact else None)[:C])
-        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None, defer_scale=True)
+        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None, defer_scale=True, x_segs=ctx.x_segs)
         dconv_w = _ret(s_cw, K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw), alpha=inv))
         dconv_b = _ret(s_cb if exact else None, dbias0[:C])
         if scaled:
             dbn_w, dbn_b, dconv_b = dbn_w * inv, dbn_b * inv, dconv_b * inv
         dx = None
         if ctx.needs_input_grad[0]:
+            assert ctx.x_segs == 1, "split features come from the frozen stem: no gradient flows into them"
             dx = K.conv2d_igemm(dr, K.pack_conv_weight(conv_w, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=x.shape[-1]))
         return dx, dconv_w, dconv_b, dbn_w, dbn_b, None
 
@@ -335,8 +360,15 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
         for k in range(blocks):
             w1, b1, w3, b3 = tensors[meta.n_film + 4 * k: meta.n_film + 4 * k + 4]
             fdt = K.fwd_pack_dtype(h)
-            wt1 = meta.c1_packs[k][0] if (meta.c1_packs and fdt == cdt) else K.pack_conv_weight(w1, fdt, c_out_pad=c_pad, c_in_pad=c_pad)
-            res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(b1, c_pad), relu=True)
+            if getattr(meta, "hybrid", False) and L.is_half(cdt):
+                # precision 'fp16h': the frozen 1x1 conv as two products against [w_hi | w_lo] (its weight rounding: 0.04e-6 of the
+                # squared logits error for 29 GFLOP), the 3x3 conv below stays ONE product with its fused FiLM epilogue (1e-10)
+                wt1 = meta.c1_packs32[k] if meta.c1_packs32 else K.pack_conv_weight(w1, torch.float32, c_out_pad=c_pad, c_in_pad=c_pad)
+                with K.f32_conv_mode("w2"):
+                    res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(b1, c_pad), relu=True)
+            else:
+                wt1 = meta.c1_packs[k][0] if (meta.c1_packs and fdt == cdt) else K.pack_conv_weight(w1, fdt, c_out_pad=c_pad, c_in_pad=c_pad)
+                res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(b1, c_pad), relu=True)
             fi, col = meta.film_map[k]
             film = films[fi]
             z, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(w3, fdt, c_out_pad=c_pad, c_in_pad=c_pad),
@@ -459,6 +491,9 @@ class TrunkMeta(object):
         self.grad_scale = float(grad_scale)
         # per block (forward pack, dgrad pack) of the FROZEN 1x1 conv weights, cached by the model across steps; None = pack here
         self.c1_packs = None
+        # precision 'fp16h': the frozen 1x1 convs' FORWARD as two products against split weights (c1_packs32: their fp32 packs)
+        self.hybrid = False
+        self.c1_packs32 = None
 
 
 def film_trunk(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors, join=None):
@@ -921,7 +956,7 @@ class FcNativeFn(torch.autograd.Function):
     weight gradient returns to the parameter layout in one kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, C, h, w, rows_pad, grad_scale=1.0):
+    def forward(ctx, x, weight, bias, C, h, w, rows_pad, grad_scale=1.0, split_weights=False):
         _x3_forward(ctx)
         ctx.grad_scale = float(grad_scale)      # d(out) arrives multiplied by this (fp16 loss scale): dW, db are divided by it
         rows = weight.shape[0]
@@ -932,8 +967,11 @@ class FcNativeFn(torch.autograd.Function):
             os.environ.get("VNQA_FC_DX", "1") != "0"
         nat, nat_t = K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, x.dtype, want_t=need_dx and not ctx.direct_dx)
         bias_p = K.pad_vec(bias, rows_pad)
-        if K.w2_active(x):      # two-product forward: the fp32 operand (split into [hi | lo] by the GEMM wrapper); `nat` serves the backward
-            out = K.gemm_nt(x.contiguous(), K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, torch.float32, want_t=False)[0], bias=bias_p)
+        if K.w2_active(x) or (split_weights and L.is_half(x.dtype)):
+            # two-product forward: the fp32 operand (split into [hi | lo] by the GEMM wrapper); `nat` serves the backward.
+            # (precision 'fp16h' asks for it by argument: this layer's weight rounding is 0.03e-6 of the squared logits error for 7 GFLOP)
+            with K.f32_conv_mode("w2"):
+                out = K.gemm_nt(x.contiguous(), K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, torch.float32, want_t=False)[0], bias=bias_p)
         else:
             out = K.gemm_nt(x.contiguous(), nat, bias=bias_p)
         ctx.save_for_backward(x, nat if ctx.direct_dx else nat_t)
@@ -966,11 +1004,11 @@ class FcNativeFn(torch.autograd.Function):
             db = _ret(sb, K.colsum(dout, out=_into(sb))[:rows])
             if ctx.grad_scale != 1.0:
                 db = db * (1.0 / ctx.grad_scale)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def fc_native(x, weight, bias, C, h, w, rows_pad, grad_scale=1.0):
-    return FcNativeFn.apply(x, weight, bias, C, h, w, rows_pad, grad_scale)
+def fc_native(x, weight, bias, C, h, w, rows_pad, grad_scale=1.0, split_weights=False):
+    return FcNativeFn.apply(x, weight, bias, C, h, w, rows_pad, grad_scale, split_weights)
 
 
 class MacCoreState(object):

@@ -50,7 +50,7 @@ class VGGFront(nn.Module):
 
     def forward(self, x):
         if self._plan is None:      # (the per-module drop-in path of fp16x runs on the exact-f32 kernels: an API path, not the fast one)
-            self._plan = FrozenStem(self, None, {"fp16x": "fp32", "fp16w": "fp16"}.get(self.precision, self.precision))
+            self._plan = FrozenStem(self, None, {"fp16x": "fp32", "fp16w": "fp16", "fp16h": "fp16"}.get(self.precision, self.precision))
         return self._plan.vgg_nchw(x)
 
 
@@ -149,9 +149,19 @@ def _fold_bn(bn):
 class FrozenStem(object):
     """Execution plan (packed weights + persistent activation buffers) for the frozen stem."""
 
-    def __init__(self, vgg, objdet, precision='bf16', out_half=False, calibration="auto"):
+    def __init__(self, vgg, objdet, precision='bf16', out_half=False, calibration="auto", pair_features=True):
         from .models.common import compute_dtype
         self.cdt = compute_dtype(precision)
+        # precision 'fp16h' (round 5, the tolerance mode): the fp16 precision's stem — same kernels, coherently rounded weights — except
+        # that the LAST THREE stored activations (conv22's pooled output, conv31's, conv32's = the features) are [hi | lo] PAIRS
+        # (hi = fp16(v), lo = fp16(v - hi), written by the patch-stationary kernel's dual epilogue) and conv31 / conv32 contract
+        # both halves against split weights (a plain conv over 3 C input channels, [hi | lo | hi] . [w_hi | w_hi | w_lo]): the three
+        # stem activation roundings and the two weight roundings that weigh most in the logits error (profiles/
+        # r05_precision_budget*.txt: 0.047 / 0.047 / 0.073 and 0.022 / 0.041 of the fp16 precision's 0.70e-6 squared error) are gone for
+        # two extra products on the two CHEAPEST layers (14 x 14 maps).  pair_features=False keeps the
+        # features a plain fp16 tensor (consumers that do not read pairs: MACNetwork, the per-module drop-in path).
+        self.hyb = precision == "fp16h"
+        self.pair_features = bool(pair_features) and self.hyb
         self.x3 = precision == "fp16x"       # fp32 storage, contractions as three fp16-half products (kernels.f32_conv_mode)
         # fp16x with a 16-bit-storage trunk behind it (precision 'fp16' / 'fp16w' models): the LAST layer's output rounded once to
         # fp16 instead of written as fp32
@@ -162,12 +172,15 @@ class FrozenStem(object):
         self.composed = None
         self.first = None
         self._bufs = {}
+        self._pair_ok = {}
         # CUs the persistent one-workgroup-per-CU kernels (fused conv1, C_in = 64 direct conv, weights-in-registers conv) leave to
         # other streams, passed with every call (vnqa_conv_desc.flags): the Trainer sets it to its stem stream's CU reservation;
         # VNQA_PERSISTENT_RESERVE_CUS is the stand-alone A/B knob (8: -12 % on one GPU; multi-GPU investigation)
         self.reserve_cus = int(os.environ.get("VNQA_PERSISTENT_RESERVE_CUS", "0"))
         self.timing = None   # bench hook: list collecting (start event, end event, FLOPs, kernel) of the C_out = 512 stem launches
-        # calibration: how the frozen 16-bit weights are rounded.  None = round-to-nearest; "noise" or a tensor of frames
+        # calibration: how the frozen 16-bit weights are rounded.  None = round-to-nearest; a dict = the means of an earlier
+        # calibration_means() pass (a checkpoint's `extra_state['_stem_calibration']`: the test-time stem gets the weights the model
+        # was trained behind); "noise" or a tensor of frames
         # [N, 3, H, W] = coherent_round against the mean input activations measured on those frames (calibration_means): each output
         # channel's rounding errors cancel against the mean input, the part of the weight-rounding error that is a constant offset
         # per channel and survives every later pooling.  Same kernels, same bytes; measured at the headline size on 12 minibatches
@@ -179,7 +192,9 @@ class FrozenStem(object):
         if isinstance(calibration, str) and calibration == "auto":
             env = os.environ.get("VNQA_COHERENT_ROUND")
             calibration = "noise" if env != "0" else None
-        if calibration is not None and vgg is not None and objdet is not None and precision != "fp32" and \
+        if isinstance(calibration, dict):      # calibration means computed earlier (a checkpoint's: eval/q_and_v_test.py)
+            self.calib = {k: torch.as_tensor(v).float().cpu() for k, v in calibration.items()} if precision != "fp32" else None
+        elif calibration is not None and vgg is not None and objdet is not None and precision != "fp32" and \
                 vgg.features["0"].weight.is_cuda:
             self.calib = calibration_means(vgg, objdet, None if isinstance(calibration, str) else calibration)
         cm = lambda k: None if self.calib is None else self.calib[k]
@@ -222,6 +237,19 @@ class FrozenStem(object):
                               self._layer(od.conv22, bn=od.bn2, relu=True, pool=True, cdt=hq(5), m=cm("od3")),
                               self._layer(od.conv31, cdt=hq(6), m=cm("od4")),
                               self._layer(od.conv32, bn=od.bn3, relu=True, pool=False, m=cm("od5"))]
+            if self.hyb:
+                # conv22 writes [hi | lo | hi], conv31 reads it and writes the same, conv32 reads it and writes the split features
+                # [hi | lo | hi] for conv_init — or a plain tensor for consumers that read no split tensors.  A
+                # triple-reading layer is a plain conv over 3 C input channels against the SPLIT exact weights [w_hi | w_hi | w_lo]
+                # (BatchNorm folded in fp32 first): x_hi w_hi + x_lo w_hi + x_hi w_lo — neither the layer's input rounding nor its
+                # weight rounding is left (coherently rounded, conv31's / conv32's weights still cost 0.022 / 0.041e-6 of squared
+                # logits error: profiles/r05_precision_budget_stem_weights.txt)
+                for ly, rd, wr in zip(self.layers_od[3:], (False, True, True), (3, 3, 3 if self.pair_features else 0)):
+                    if "wt_ps" in ly:
+                        ly["pair_out"] = wr
+                        if rd:
+                            ly["wt_ps3"] = K._split_weight(ly.pop("wt32ps"), "hhl")
+                    ly.pop("wt32ps", None)
             # conv12 is applied straight to conv11's output (obj_detector.py:72: no nonlinearity between the two convs of
             # a pair) and both are frozen: when the pair's 3x3 (c_in -> c_mid) . 3x3 (c_mid -> c_out) costs more than one
             # 5x5 (c_in -> c_out) — 9*c_in + 9*c_mid > 25*c_in, true for 128 -> 512 -> 512 only — it is evaluated as the
@@ -309,6 +337,8 @@ class FrozenStem(object):
         # geometry qualifies (vnqa_conv_ps_supported); the implicit-GEMM tile above stays as the fallback
         if bf16 and tile == L.TILE_STEM_256x256 and w.shape[2] == 3 and os.environ.get("VNQA_STEM_PS", "1") != "0":
             ly["wt_ps"] = K.pack_conv_weight(w, self.cdt, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+            if getattr(self, "hyb", False):      # the exact (BatchNorm-folded) weights, for the layers that run with split weights
+                ly["wt32ps"] = K.pack_conv_weight(w32, torch.float32, out_scale=scale32, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         return ly
 
     def _compose_pair(self, c1, c2, bn):
@@ -468,6 +498,18 @@ class FrozenStem(object):
             self._bufs[key] = cap
         return cap[:shape[0]]
 
+    def _pair_geometry_ok(self, n, h, w, ly):
+        """The pair path of precision 'fp16h' needs the patch-stationary kernel on conv22 (h x w maps, pooled) AND on conv31 / conv32
+        (h/2 x w/2 maps, 2 C input channels): asked of the library once per geometry.  Where it does not serve them (the 10 x 13 maps
+        of the reference's 160 x 208 frames) the three layers run exactly as in precision 'fp16'."""
+        key = (n, h, w)
+        ok = self._pair_ok.get(key)
+        if ok is None:
+            c = ly["c_out_pad"]
+            ok = self._pair_ok[key] = bool(ly["pool"] and K.conv_ps_supported(n, h, w, c, c, 9, True) and
+                                        K.conv_ps_supported(n, h // 2, w // 2, 3 * c, c, 9, False))
+        return ok
+
     def _run(self, x, layers, tag, last_slot=0, first_index=0, final=True):
         for i, ly in enumerate(layers, first_index):
             n, hp, wp, _ = x.shape
@@ -480,7 +522,14 @@ class FrozenStem(object):
             # last layer (`final`) writes fp32
             plain = ly.get("cdt") is not None                 # a layer of the plain 16-bit prefix inside the fp16x stem
             x3_out = self.x3 and not plain and K._F32_CONV_MODE[0] == "x3" and (not (last and final) or self.out_half)
-            if plain:
+            # precision 'fp16h': [hi | lo] pair tensors between conv22, conv31, conv32 and the trunk (see __init__)
+            pair_rd = "wt_ps3" in ly and x.shape[-1] == ly["wt_ps3"].shape[2]
+            pair_wr = int(ly.get("pair_out", 0))
+            if pair_wr and not (yh == 1 and (pair_rd if "wt_ps3" in ly else self._pair_geometry_ok(n, h, w, ly))):
+                pair_wr = 0
+            if pair_wr:
+                out = self._buf(key + ("pair",), (n, ho + 2, wo + 2, pair_wr * ly["c_out_pad"]))
+            elif plain:
                 out = self._buf(key + ("h16",), (n, ho + 2 * yh, wo + 2 * yh, ly["c_out_pad"]), dtype=ly["cdt"])
             elif x3_out:
                 nxt = ("%s%d" % (tag, i + 1)) if not last else ("composed" if (tag == "vgg" and self.composed is not None) else "od0")
@@ -497,7 +546,12 @@ class FrozenStem(object):
             if timed:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            if self.w2 and "wt32" in ly and ly.get("cdt") is None and K.x3_mode() == "w2":
+            if pair_rd or pair_wr:
+                kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)
+                x = K.conv2d_igemm(x, ly["wt_ps3"] if pair_rd else ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
+                                   post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+                                   out=out, tile=L.TILE_STEM_PS_224x256, y_halo=yh, dual_out=pair_wr)
+            elif self.w2 and "wt32" in ly and ly.get("cdt") is None and K.x3_mode() == "w2":
                 # two products on the igemm's wrap variant: 512 x 128 tiles for the C_out = 128 layers, 256 x 256 for C_out = 512
                 kname = "conv_igemm_kernel<..., TAG 4> (two products, x read twice along K)"
                 x = K.conv2d_igemm(x, ly["wt32"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
@@ -538,7 +592,7 @@ class FrozenStem(object):
                                                         post_shift=post[1] if post else None)
             if timed:
                 ev1.record()
-                self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9, kname))
+                self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9 * (3 if pair_rd else 1), kname))
             if self._tap is not None:
                 self._tap[(tag, i)] = x
         return x

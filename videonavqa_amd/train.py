@@ -334,6 +334,11 @@ class Trainer(object):
         if self.loss_scaler is not None and self.loss_scaler.applies:
             # the dynamic loss scale travels with the checkpoint (a resume restarted at 2^10)
             out["_loss_scale"] = dict(self.loss_scaler.state_dict())
+        calib = getattr(self.stem, "calib", None)
+        if calib is not None:
+            # the means the frozen stem's 16-bit weights were rounded against (stem.coherent_round): the test-time stem is rebuilt
+            # from them, so a model is tested behind the very stem weights it was trained behind
+            out["_stem_calibration"] = {k: v.detach().cpu().clone() for k, v in calib.items()}
         return out
 
     def load_checkpoint(self, ckpt):
