@@ -75,10 +75,9 @@ def build(args, device):
                                        TimeMultiHopFiLMPretrainedStem)
     from videonavqa_amd.stem import FrozenStem, VGGFront
     import torch.nn as nn
-    torch.manual_seed(int(getattr(args, "seed", 0)))     # identical replicas on every rank (tools/x3_error_budget.py --seed: other weights)
+    torch.manual_seed(int(getattr(args, "seed", 0)))     # identical replicas on every rank (tools/error_budget.py --seed: other weights)
     prec = args.precision
-    # experiment hook (fp16x): the trunk behind the x3 stem in another storage — "w2" = precision 'fp16w', "plain" = 'fp16'
-    mprec = {"w2": "fp16w", "plain": "fp16"}.get(os.environ.get("VNQA_X3_TRUNK", "x3"), prec) if prec == "fp16x" else prec
+    mprec = prec
     vgg = VGGFront(prec)
     od = ObjDetectCNN(27, 512, 1024, 0, True, True, precision=prec)   # eval/utils.py:43-48
     with torch.no_grad():
@@ -109,12 +108,7 @@ def build(args, device):
                                                num_res_block_channels=args.channels, spatial_size=S, precision=mprec,
                                                **({"num_tail_channels": args.tail_channels} if getattr(args, "tail_channels", 0) else {}))
     vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
-    # fp16x option (VNQA_X3_HALF_FEATURES=1): the stem hands the FiLM trunks ONE rounded fp16 feature tensor (conv32 as a fused two-product
-    # launch; conv_init reads it as a two-product x3 conv: no fp32 feature tensor, no split pass): +3.2 % (751-754 vs 729-731 clips/s)
-    # for one more activation rounding right in front of the trunk — twelve-minibatch max 0.90e-3 instead of 0.80e-3, rms 0.69 / 0.62:
-    # not the default
-    half_feat = prec == "fp16x" and args.model != "mac" and os.environ.get("VNQA_X3_HALF_FEATURES", "0") == "1"
-    stem = FrozenStem(vgg, od, prec, out_half=(mprec != prec) or half_feat, pair_features=args.model != "mac")
+    stem = FrozenStem(vgg, od, prec, split_features=args.model != "mac")
     COMPOSED_STEM[0] = stem.composed is not None
     return model, stem, vgg, od
 
@@ -270,25 +264,13 @@ def fp16_leg(args, precision="fp16"):
             return {"error": (r.stderr or "no output").strip()[-300:]}
         d = json.loads(line[-1])
         p = d.get("parity", {})
-        what = ("bench.py --precision fp16 (fp16 storage, fp32 accumulate, dynamic loss scale from 2^10; the frozen stem's weights rounded "
-                "coherently like in every 16-bit precision — VNQA_COHERENT_ROUND=0, round-to-nearest, reads 0.96 / 1.08 / 1.30e-3 here; over "
-                "twelve minibatches this precision's maximum is 1.07e-3: inside 1e-3 on the three parity batches, NOT the robust "
-                "tolerance mode), %d timed steps, child process"
-                if precision == "fp16" else
-                "bench.py --precision fp16x: the TOLERANCE-COMPLIANT 16-bit-MFMA mode — the frozen stem through conv31 on the plain fp16 "
-                "kernels with COHERENTLY ROUNDED weights (each output channel's fp16 rounding errors cancel against the mean input "
-                "activation, measured on seeded noise calibration frames: stem.coherent_round), conv32 as two fp16 products with an fp32 "
-                "output, the trunk in fp32 storage with every forward conv / GEMM as three fp16-half products (x_hi w_hi + x_lo w_hi + "
-                "x_hi w_lo, fp32 accumulate) on the fp16 matrix cores and the backward as one fp16 product per contraction with the "
-                "gradient operands scaled by a device-chosen power of two; %d timed steps, child process") % d["steps"]
+        what = ("bench.py --precision fp16 (plain fp16 storage, fp32 accumulate, dynamic loss scale from 2^10; the frozen stem's weights rounded "
+                "coherently like in every 16-bit precision): NOT tolerance-compliant — rms logits error 0.6-1.0e-3 by weight seed, worst "
+                "minibatch 1.27e-3 (profiles/r05_precision_budget.txt); %d timed steps, child process") % d["steps"]
         if precision == "bf16":
             what = ("bench.py --precision bf16: BASELINE.json's storage dtype (bf16 storage, fp32 accumulate; the frozen stem's weights rounded "
                     "coherently like in every 16-bit precision) — the round 1-4 headline, NOT tolerance-compliant (logits ~6-7e-3 of exact "
                     "fp32, 21-23 of 24 answer classes at random initialisation); %d timed steps, child process") % d["steps"]
-        if precision == "fp16w":
-            what = ("bench.py --precision fp16w: fp16 storage (the fp16 precision's kernels, epilogues and backward), every FORWARD conv / GEMM after "
-                    "the fused conv1 as two fp16 MFMA products x w_hi + x w_lo (split weights; the activation is read twice along K by the "
-                    "implicit GEMM, no copy): the weight roundings are gone, the activation roundings stay; %d timed steps, child process") % d["steps"]
         key = precision + "_logits_rel_err"
         return {"what": what, "precision": precision,
                 # the precision's own full line: the same fields the top-level line carries, measured the same way
@@ -628,9 +610,9 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
             loss = tr.loss_fn(out, y[perm_d])
         return out, loss
 
-    low = args.precision if args.precision in ("bf16", "fp16", "fp16h", "fp16w", "fp16x") else "bf16"      # the 16-bit precision under test
+    low = args.precision if args.precision in ("bf16", "fp16", "fp16h") else "bf16"      # the 16-bit precision under test
     from videonavqa_amd import _lib as L
-    L.set_half("f16" if low in ("fp16", "fp16h", "fp16w", "fp16x") else "bf16")       # one 16-bit storage format per process: fix it before the fp32 build
+    L.set_half("f16" if low in ("fp16", "fp16h") else "bf16")       # one 16-bit storage format per process: fix it before the fp32 build
     for prec in ("fp32", low):
         a = copy.copy(args)
         a.precision = prec
@@ -664,7 +646,7 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
             lg.append(out.detach().float().cpu())
             ls.append(float(loss.detach()))
         logits[prec], losses[prec] = lg, ls
-        if low in ("fp16x", "fp16h"):      # the tolerance modes: nine more minibatches, forward only (three under-sample the maximum)
+        if low == "fp16h":      # the tolerance mode: nine more minibatches, forward only (three under-sample the maximum)
             for j in range(3):
                 for batch in parity_batches(args, device, first=3 + 3 * j, count=3):
                     more.setdefault(prec, []).append(forward(tr, batch)[0].detach().float().cpu())
@@ -772,13 +754,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--repeats", type=int, default=3, help="the timed K-step region is run this many times back to back; "
                     "the reported value / ms_per_step are the MEDIAN region's, all regions are listed in `repeats`")
-    ap.add_argument("--precision", default="fp16h", choices=["bf16", "fp16", "fp16h", "fp16w", "fp16x", "fp32"],
+    ap.add_argument("--precision", default="fp16h", choices=["bf16", "fp16", "fp16h", "fp32"],
                     help="fp16h (default, the headline): the TOLERANCE-COMPLIANT precision — fp16 storage and fp16 MFMA products with fp32 "
                          "accumulation like 'fp16', plus split [hi | lo | hi] activations on the stem's last three tensors, conv31 / conv32 / "
                          "conv_init as three products against split weights, the frozen 1x1 conv and fc_embed_attn with split weights: logits "
                          "within north star's 1e-3 of exact fp32 on 4 weight seeds x 12 minibatches; bf16: BASELINE.json's storage dtype "
-                         "(7e-3, a leg of the default line); fp16: plain fp16 storage (0.6-1.0e-3 rms by weight seed, a leg); fp16x / fp16w: "
-                         "the round-4 experiments; fp32: the exact-f32 parity precision")
+                         "(7e-3, a leg of the default line); fp16: plain fp16 storage (0.6-1.0e-3 rms by weight seed, a leg); fp32: the exact-f32 "
+                         "parity precision")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU minibatch; default 8 (the metric's), 32 for --model v_only_cnn3d "
                     "(BASELINE config 2)")
     ap.add_argument("--frames", type=int, default=35)
@@ -828,7 +810,7 @@ def main():
             plumbing_rank(args)
         return
 
-    if args.precision in ("fp16", "fp16h", "fp16w", "fp16x"):      # the fp16-storage build of the library (one 16-bit format per process)
+    if args.precision in ("fp16", "fp16h"):      # the fp16-storage build of the library (one 16-bit format per process)
         from videonavqa_amd import _lib as L
         L.set_half("f16")
     if args.model == "v_only_cnn3d":
@@ -1030,7 +1012,7 @@ def main():
         alone_events, stem.timing = stem.timing, None
     parity = None
     # (single-GPU runs only: at N > 1 the other ranks would sit in the barrier below for the minute this takes)
-    if world == 1 and not args.no_parity and args.model != "mac" and args.precision in ("bf16", "fp16", "fp16h", "fp16w", "fp16x"):
+    if world == 1 and not args.no_parity and args.model != "mac" and args.precision in ("bf16", "fp16", "fp16h"):
         loss = loss.clone()
         del trainer, model, stem
         torch.cuda.empty_cache()
@@ -1062,15 +1044,9 @@ def main():
                          "ms_per_step": round(tot_ms / args.steps, 4)}
         def peak_for(kname):
             """MFMA peak a kernel entry is priced against, on its ALGORITHMIC FLOPs: the 16-bit dense peak for one-product kernels
-            (bf16 and fp16 run at the same rate), half / a third of it for the two- / three-product forms of fp16w / fp16x, the
-            exact-f32 MFMA peak for precision 'fp32'."""
-            if args.precision == "fp32":
-                return PEAK_F32_TFLOPS
-            if kname.startswith("x3 product"):
-                return PEAK_BF16_TFLOPS / 3.0
-            if "two products" in kname:
-                return PEAK_BF16_TFLOPS / 2.0
-            return PEAK_BF16_TFLOPS
+            (bf16 and fp16 run at the same rate; the three-product layers of 'fp16h' count the FLOPs they execute), the exact-f32 MFMA
+            peak for precision 'fp32'."""
+            return PEAK_F32_TFLOPS if args.precision == "fp32" else PEAK_BF16_TFLOPS
         alone = {}
         for ev in alone_events:
             k = ev[3] if len(ev) > 3 else "conv_igemm_kernel"
@@ -1085,7 +1061,7 @@ def main():
         avg_ms, launches_per_step = dstat["avg_launch_ms"], dstat["launches_per_step"]
         flops_per_launch = dstat["gflop_per_launch"] * 1e9
         achieved = dstat["achieved_tflops"]
-        peak = peak_for(dom)      # (fp16x: its dominant kernel is the plain one-product composed conv of the fp16 prefix)
+        peak = peak_for(dom)
         # HBM bytes per launch of the same kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read
         # live; collected with rocprofv3 --pmc in separate runs, corrected per the microarch guide) — only
         # valid for the default workload the passes were taken on
@@ -1113,7 +1089,7 @@ def main():
             "metric": METRIC, "value": round(clips, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp16": "f16", "fp16h": "f16 (fp16 storage, fp16 MFMA products, fp32 accumulate; split [hi | lo | hi] activations on the stem's last three tensors, conv31 / conv32 / conv_init as three products against split weights, 1x1 / fc_embed_attn with split weights)", "fp16w": "f16 storage, forward contractions x . w_hi + x . w_lo (split weights, two fp16 MFMA products)", "fp16x": "f16 x3 (forward contractions as three fp16-half MFMA products, fp32 storage / accumulate)", "fp32": "f32"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp16h": "f16 (fp16 storage, fp16 MFMA products, fp32 accumulate; split [hi | lo | hi] activations on the stem's last three tensors, conv31 / conv32 / conv_init as three products against split weights, 1x1 / fc_embed_attn with split weights)", "fp32": "f32"}[args.precision], "data": "synthetic",
             "repeats": {"n": len(regions), "value_is": "median region", "clips_per_s": [round(c, 1) for c in all_clips],
                         "spread_rel": round((max(all_clips) - min(all_clips)) / clips, 4)},
             "config": {"workload": "%s training step: VGG-16[:10]+ObjDetectCNN(512) frozen stem + "

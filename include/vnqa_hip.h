@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 418
+#define VNQA_ABI_VERSION 419
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -144,40 +144,18 @@ int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void*
                              void* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * precision='fp16x': fp32 contractions on the 16-bit matrix cores as three products of fp16 halves (csrc/split3.hip),
- *      x . w = x_hi . w_hi + x_lo . w_hi + x_hi . w_lo,   v_hi = fp16(v), v_lo = fp16(v - v_hi),   fp32 accumulation:
- * the same nn.Conv2d / nn.Linear call sites as vnqa_conv2d_igemm_fwd / vnqa_gemm_nt, for callers that need the reference's
- * fp32 results to north star's 1e-3 (measured ~1e-5) but not bit-exactness, at 3/16 of the exact-f32 matrix path's cost.
- *   vnqa_split3_f32     : rows x c fp32 (row stride src_ld) -> hi, lo (may be NULL: the scaled fp32 -> 16-bit cast of a ONE-product
- *                         backward operand) and (optional, may be NULL) a second copy of hi, each
- *                         rows x c in the library's 16-bit format with row stride dst_ld.  Channel-concatenated operand
- *                         [hi | lo | hi]: (base, base + c, base + 2c), dst_ld = 3c.
- *   vnqa_conv2d_igemm_raw : the 16-bit conv's raw fp32 accumulators [n_img*h*w][c_out] (d: dtype VNQA_BF16, c_in = the
- *                         concatenated channel count, relu = pool2 = 0, flags = 0 or VNQA_CONV_X_WRAP2 (a plain 16-bit input read
- *                         twice against [w_hi | w_lo]), an implicit-GEMM tile id or VNQA_TILE_AUTO).
- *   vnqa_x3_post        : y = post( pool2?( relu?( raw - border_sub + bias ) ) ) in fp32 -> padded NHWC fp32 interior
- *                         (the epilogue contract of vnqa_conv2d_igemm_fwd_ex; border_sub fp32 [n][2w + 2(h-2)][c_out]);
- *                         out_x3 != 0: y is 16-bit [..][c_y >= 3 c_out] and receives the halves [hi | lo | hi] instead — the
- *                         next x3 product's operand, no fp32 round trip between consecutive layers; out_x3 == 2: the plain 16-bit
- *                         tensor (one fp16 rounding) for a two-product consumer, which reads it twice (VNQA_CONV_X_WRAP2).
- *                         out_x3 | VNQA_X3_POST_ZERO_HALO: y is a fresh, uninitialised buffer — its halo ring is written with zeros too.
+ * Split operands (precision 'fp16h', csrc/split3.hip): v = hi + lo, hi = h16(v), lo = h16(v - hi) — an fp32 contraction on the 16-bit
+ * matrix cores as two or three products of halves with fp32 accumulation, x . w = x_hi w_hi + x_lo w_hi + x_hi w_lo, at the same
+ * nn.Conv2d / nn.Linear call sites as vnqa_conv2d_igemm_fwd / vnqa_gemm_nt (models/obj_detector.py:82, film_attn_pt_stem.py:211,219,244).
+ *   vnqa_split3_f32 : rows x c fp32 (row stride src_ld) -> hi, lo (may be NULL) and (optional, may be NULL) a second copy of hi, each
+ *                     rows x c in the library's 16-bit format with row stride dst_ld.  The weight operands: [w_hi | w_lo] =
+ *                     (base, -, base + c) with dst_ld = 2c (VNQA_CONV_X_WRAP2 / VNQA_GEMM_X_WRAP2 consumers), [w_hi | w_hi | w_lo] =
+ *                     (base, base + 2c, base + c) with dst_ld = 3c (consumers of a VNQA_CONV_DUAL_OUT | _HI2 activation).
+ *                     scale: optional DEVICE scalar (a power of two) multiplied in before the split.
  *   vnqa_gemm_nt with dtype = VNQA_BF16 | VNQA_GEMM_OUT_F32 : 16-bit operands, fp32 `out` (workspace >= m*n*4 bytes required).
  */
-/* The split scale of a gradient tensor (the backward operands of precision 'fp16x': gradients are 1e-5 .. 1e-8, below fp16's normal
- * range) in ONE launch: state = 16 bytes on the device, ZERO on first use (the call leaves words 0 and 3 zero again):
- *   ((float*)state)[1] = s = the power of two that lifts max |x| into [2^12, 2^13)  (1 for an all-zero or non-finite tensor, never
- *   above 2^112), ((float*)state)[2] = 1 / s — the `scale` of vnqa_split3_f32 and the `raw_scale` of vnqa_x3_post. */
-#define VNQA_X3_POST_ZERO_HALO 4
-int vnqa_grad_split_scale(const float* x, int64_t n, void* state, void* stream);
-
 int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows, int32_t c, int64_t src_ld, int64_t dst_ld,
-                    const float* scale, void* stream);   /* scale: optional DEVICE scalar (a power of two) applied before the split:
-                                                          * gradient operands are lifted into fp16's normal range */
-int vnqa_conv2d_igemm_raw(const vnqa_conv_desc* d, const void* x, const void* wt, float* raw, void* stream);
-int vnqa_x3_post(const float* raw, const float* bias, const float* post_scale, const float* post_shift, const float* border_sub,
-                 void* y, int32_t n_img, int32_t h, int32_t w, int32_t c_out, int32_t c_y, int32_t y_halo, int32_t relu,
-                 int32_t pool2, int32_t out_x3, const float* raw_scale, void* stream);   /* raw_scale: optional DEVICE scalar
-                                                          * multiplied into the raw sums first (1 / the operand's split scale) */
+                    const float* scale, void* stream);
 #define VNQA_GEMM_OUT_F32 0x200
 #define VNQA_GEMM_X_WRAP2 0x400   /* vnqa_gemm_nt: a has k / 2 physical columns (row stride k / 2), read twice against b = [b_hi | b_lo];
                                    * also accepted in the dtype of vnqa_conv2d_ring_fwd / vnqa_ring_edge_conv_fwd (c_in / c_mid = the contraction's
@@ -387,8 +365,8 @@ int vnqa_unpack_conv_wgrad(const float* dwt, int32_t c_out, int32_t c_in, int32_
                            int32_t c_out_pad, int32_t c_in_pad, float* dw_oihw, void* stream);
 int vnqa_unpack_conv_wgrad_scaled(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps, int32_t c_out_pad,
                                   int32_t c_in_pad, float* dw_oihw, float alpha, void* stream);   /* dw = alpha * un-packed */
-/* ... with a second factor that only exists on the DEVICE (alpha_dev, may be NULL): dw = alpha * *alpha_dev * un-packed — the inverse
- * split scale of a scaled backward product (vnqa_grad_split_scale) applied here instead of by a pass of its own */
+/* ... with a second factor that only exists on the DEVICE (alpha_dev, may be NULL): dw = alpha * *alpha_dev * un-packed — e.g.
+ * the inverse of a scale chosen on the device, applied here instead of by a pass of its own */
 int vnqa_unpack_conv_wgrad_dev(const float* dwt, int32_t c_out, int32_t c_in, int32_t taps, int32_t c_out_pad, int32_t c_in_pad,
                                float* dw_oihw, float alpha, const float* alpha_dev, void* stream);
 

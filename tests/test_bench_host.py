@@ -78,7 +78,7 @@ def test_cpu_child_dumps_the_oracle_logits_of_a_reproducible_workload(tmp_path):
 def test_bench_parser_knows_the_round4_modes():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], env=ENV, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0
-    for token in ("--mode", "fp16x", "fp16w", "--clip-dtype", "--no-eval-leg"):
+    for token in ("--mode", "fp16h", "--plumbing", "--clip-dtype", "--no-eval-leg", "--no-robustness"):
         assert token in r.stdout, token
 
 

@@ -222,7 +222,7 @@ def test_video_only_cnn3d_fused_train_step_vs_oracle_low_precision(monkeypatch):
     state0 = {k: v.clone() for k, v in m.state_dict().items()}
     runs = {}
     for mode in ("fused", "generic"):
-        monkeypatch.setenv("VNQA_CNN3D_GENERIC", "1" if mode == "generic" else "0")
+        m.force_generic = mode == "generic"
         m.load_state_dict(state0)
         m.zero_grad()
         assert m._fast_ok(x.cuda()) == (mode == "fused")
@@ -247,10 +247,10 @@ def test_video_only_cnn3d_fused_train_step_vs_oracle_low_precision(monkeypatch):
     for k in st_f:                                 # BatchNorm running statistics / num_batches_tracked advance alike
         assert _rel(st_f[k].float(), st_g[k].float()) < 2e-2, k
     m.eval()                                       # eval mode: the same kernels on the running statistics
-    monkeypatch.setenv("VNQA_CNN3D_GENERIC", "0")
+    m.force_generic = False
     with torch.no_grad():
         ev = m(x.cuda())
-    monkeypatch.setenv("VNQA_CNN3D_GENERIC", "1")
+    m.force_generic = True
     with torch.no_grad():
         ev_g = m(x.cuda())
     assert _rel(ev.cpu(), ev_g.cpu()) < 0.06

@@ -118,12 +118,13 @@ def test_bench_gpus2_spawns_its_own_ranks_single_device_gloo():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL, one rank per GPU)")
 def test_bench_gpus2_rccl_two_gpus():
     """Two ranks on two MI355X over RCCL through the self-spawning entry point; also A/Bs the persistent conv kernels'
-    CU reservation (VNQA_PERSISTENT_RESERVE_CUS), which exists for exactly this co-scheduling with RCCL's kernels."""
+    CU reservation (VNQA_STEM_RESERVE_CUS: a CU-masked stem stream, the persistent conv kernels sized for it), which exists for exactly
+    this co-scheduling with RCCL's kernels."""
     base = _run_bench({}, ["--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--no-parity"])
     assert base["n_gpus"] == 2 and base["comm"]["backend"] == "rccl" and base["comm"]["ranks"] == 2
-    resv = _run_bench({"VNQA_PERSISTENT_RESERVE_CUS": "8"}, ["--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "1",
-                                                            "--no-cpu-baseline", "--no-parity"])
-    print("dp2 clips/s: reserve 0 -> %.1f, reserve 8 -> %.1f; exposed comm %.3f / %.3f ms"
+    resv = _run_bench({"VNQA_STEM_RESERVE_CUS": "32"}, ["--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "1",
+                                                       "--no-cpu-baseline", "--no-parity"])
+    print("dp2 clips/s: reserve 0 -> %.1f, reserve 32 -> %.1f; exposed comm %.3f / %.3f ms"
           % (base["value"], resv["value"], base["comm"]["exposed_comm_ms_per_step"], resv["comm"]["exposed_comm_ms_per_step"]))
     assert resv["n_gpus"] == 2
 

@@ -207,10 +207,8 @@ def test_frame_layout_tables_written_on_the_device_equal_the_host_built_ones(mon
     for vl, T in cases:
         for use_perm in (False, True):
             perm = torch.randperm(len(vl), generator=g) if use_perm else None
-            monkeypatch.setenv("VNQA_LAYOUT_ON_DEVICE", "1")
             dev = FrameLayout(vl, T, "cuda", perm=perm)
-            monkeypatch.setenv("VNQA_LAYOUT_ON_DEVICE", "0")
-            host = FrameLayout(vl, T, "cuda", perm=perm)
+            host = FrameLayout(vl, T, "cuda", perm=perm, on_device=False)
             for name in ("img_of", "frame_of_i32", "sample_of_i32", "frame_off_i32"):
                 a, b = getattr(dev, name).cpu(), getattr(host, name).cpu()
                 assert a.shape == b.shape and torch.equal(a, b), (vl, T, use_perm, name)

@@ -38,15 +38,8 @@ def test_full_size_parity_of_the_headline_config_on_the_fp16_storage_build():
     assert " passed" in tail, tail
 
 
-def test_x3_products_and_the_fp16x_precision_on_the_fp16_build():
-    """precision='fp16x' (tests/test_gpu_x3.py): three-product fp16 MFMA contractions vs the exact-f32 path, the reference goldens,
-    and north star's 1e-3 on all three full-size parity batches — needs the fp16 build, hence this child run."""
-    tail = _run(["tests/test_gpu_x3.py"], 1500)
-    assert " passed" in tail and "skipped" not in tail.splitlines()[-1], tail
-
-
-def test_pair_tensors_and_the_fp16h_precision_on_the_fp16_build():
-    """precision='fp16h' (tests/test_gpu_pair.py): the dual-output epilogue, the three-product conv on pair tensors, the pair
+def test_split_tensors_and_the_fp16h_precision_on_the_fp16_build():
+    """precision='fp16h' (tests/test_gpu_fp16h.py): the dual-output epilogue, the three-product conv on split tensors, the split
     weight gradient, the goldens, and north star's 1e-3 at full size on 4 weight seeds x 12 minibatches + smooth data."""
-    tail = _run(["tests/test_gpu_pair.py"], 2400)
+    tail = _run(["tests/test_gpu_fp16h.py"], 2400)
     assert " passed" in tail and "skipped" not in tail.splitlines()[-1], tail

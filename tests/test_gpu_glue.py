@@ -2,6 +2,8 @@
 against plain PyTorch fp32 references of the same ops."""
 import pytest
 import torch
+
+import torch_partners
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -236,7 +238,7 @@ def test_multi_hop_generator_hip_vs_torch(v_lens, q_lens, blocks, hidden):
     for mode in ("hip", "torch"):
         model.zero_grad(set_to_none=True)
         model.init_hidden()
-        films = model._generator_hip(q, ql, lay) if mode == "hip" else model._generator_torch(q, ql, lay)
+        films = model._generator_hip(q, ql, lay) if mode == "hip" else torch_partners.multi_hop_generator_torch(model, q, ql, lay)
         g = torch.Generator().manual_seed(3)
         loss = sum((f * torch.randn(f.shape, generator=g).cuda()).sum() for f in films)
         loss.backward()

@@ -13,8 +13,11 @@ pytestmark = pytest.mark.gpu
 def mac_core_impl(request, monkeypatch):
     """Every MAC test runs with all three forms of the reasoning steps: the op-by-op node on torch / rocBLAS GEMMs, one C-ABI
     node per step (vnqa_mac_core_fwd / _bwd) and — the default — all steps as one node (vnqa_mac_chain_fwd / _bwd)."""
-    monkeypatch.setenv("VNQA_MAC_CORE_CABI", "0" if request.param == "rocblas_step" else "1")
-    monkeypatch.setenv("VNQA_MAC_CHAIN", "1" if request.param == "cabi_chain" else "0")
+    from videonavqa_amd import ops
+    import torch_partners
+    monkeypatch.setattr(ops, "MAC_CHAIN", request.param == "cabi_chain")
+    if request.param == "rocblas_step":       # the op-by-op torch / rocBLAS form of the step lives in tests/torch_partners.py
+        monkeypatch.setattr(ops, "mac_core", torch_partners.mac_core_torch)
     return request.param
 
 
@@ -199,7 +202,7 @@ def test_mac_chain_node_is_the_per_step_nodes(case, mac_core_impl, monkeypatch):
         pytest.skip("one comparison is enough")
     res = []
     for chain in ("1", "0"):
-        monkeypatch.setenv("VNQA_MAC_CHAIN", chain)
+        monkeypatch.setattr(__import__("videonavqa_amd.ops", fromlist=["ops"]), "MAC_CHAIN", chain == "1")
         model, g, (v, q, vl, ql, y), masks = _product(case, LOW)
         model.train()
         model.dropout_masks = (torch.cat([m[0] for m in masks]).cuda(), torch.cat([m[1] for m in masks]).cuda())

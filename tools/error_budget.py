@@ -1,11 +1,10 @@
 #!/usr/bin/env python3
-"""ON THE GPU BOX: the logits error of precision 'fp16x' against precision 'fp32' (identical weights, train-mode forward at the
-headline size) for a LIST of knob settings, on N seeded minibatches (default 12: one full-length, the rest ragged) — the error
-budget behind the mode's defaults.  One fp32 pass, then one fp16x build + pass per setting; per setting: the maximum over the
-minibatches (the test's criterion), their RMS and mean, and how many answers differ.
+"""ON THE GPU BOX: the logits error of a precision (default 'fp16h') against precision 'fp32' (identical weights, train-mode forward at
+the headline size) on N seeded minibatches (default 12: one full-length, the rest ragged): the maximum over the minibatches (the
+tests' criterion), their RMS and mean, and how many answers differ.
 
-  python tools/x3_error_budget.py [--batches 12] "PREFIX=4 ROUND=6" "PREFIX=5 ROUND=6 TRUNK_FWD=x2" ...
-(each word KEY=VALUE sets VNQA_X3_KEY=VALUE for that setting; PLAIN_PREFIX is spelled PREFIX)"""
+  python tools/error_budget.py [--batches 12] [--seed S] [--data noise|smooth] [--precision fp16h|fp16|bf16]
+(tools/experiments/precision_budget.py has the per-rounding-point budget behind the mode's design)"""
 import argparse
 import copy
 import os
@@ -16,8 +15,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench  # noqa: E402
 
-KEYS = {"PREFIX": "VNQA_X3_PLAIN_PREFIX", "ROUND": "VNQA_X3_ROUND", "TRUNK_FWD": "VNQA_X3_TRUNK_FWD", "TRUNK": "VNQA_X3_TRUNK",
-        "RING_W2": "VNQA_RING_W2", "COH": "VNQA_COHERENT_ROUND"}
+KEYS = {"COH": "VNQA_COHERENT_ROUND"}
 
 
 def batches(args, device, n, data="noise"):
@@ -73,13 +71,13 @@ def main():
     ap.add_argument("--data", default="noise", choices=["noise", "smooth"], help="the minibatches' pixel statistics (the default "
                     "calibration frames are always noise)")
     ap.add_argument("--seed", type=int, default=0, help="seed of the random weights (0 = the benchmark's)")
-    ap.add_argument("--precision", default="fp16x", help="the precision under test (fp16x, fp16w, fp16)")
-    ap.add_argument("settings", nargs="*", default=["PREFIX=4 ROUND=6"])
+    ap.add_argument("--precision", default="fp16h", help="the precision under test (fp16h, fp16, bf16)")
+    ap.add_argument("settings", nargs="*", default=["COH=1"], help="each word KEY=VALUE sets an environment variable for that pass (COH = VNQA_COHERENT_ROUND)")
     o = ap.parse_args()
     args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
                               tail_channels=0, seed=o.seed)
     from videonavqa_amd import _lib as L
-    L.set_half("f16")
+    L.set_half("bf16" if o.precision == "bf16" else "f16")
     device = torch.device("cuda", 0)
     data = batches(args, device, o.batches, o.data)
     ref = run(args, "fp32", device, data)

@@ -34,7 +34,7 @@ TRUNK_W = ["w_init", "w_1x1", "w_3x3", "w_fc"]
 
 
 def budget_mod():
-    spec = importlib.util.spec_from_file_location("x3_error_budget", os.path.join(ROOT, "tools", "x3_error_budget.py"))
+    spec = importlib.util.spec_from_file_location("error_budget", os.path.join(ROOT, "tools", "error_budget.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
@@ -325,7 +325,7 @@ def main():
             got = product_logits(args, "fp32", dev, data)
             e = [float((g - r).abs().max() / r.abs().max()) for g, r in zip(got, refs)]
             print("seed %d: restatement (exact) vs library precision 'fp32': max %.2e" % (seed, max(e)), flush=True)
-            for prec in ("fp16", "fp16x"):
+            for prec in ("fp16", "fp16h"):
                 got = product_logits(args, prec, dev, data)
                 e = [float((g - r).abs().max() / r.abs().max()) * 1e3 for g, r in zip(got, refs)]
                 print("seed %d: library precision '%s' vs restatement (exact): max %.3f rms %.3f   %s" %

@@ -11,9 +11,8 @@ echo "mac                 $($B --model mac 2>/dev/null | q)"
 echo "5x1024 bs8          $($B --blocks 5 --channels 1024 2>/dev/null | q)"
 echo "5x1024 bs32         $($B --blocks 5 --channels 1024 --batch 32 --steps 8 --warmup 3 2>/dev/null | q)"
 echo "bs32                $($B --batch 32 --steps 8 --warmup 3 2>/dev/null | q)"
+echo "bf16                $($B --precision bf16 2>/dev/null | q)"
 echo "fp16                $($B --precision fp16 2>/dev/null | q)"
-echo "fp16w               $($B --precision fp16w 2>/dev/null | q)"
-echo "fp16x               $($B --precision fp16x --steps 10 2>/dev/null | q)"
 echo "eval (inference)    $($B --mode eval 2>/dev/null | q)"
 echo "film_gp_pt eval     $($B --model film_gp_pt --mode eval 2>/dev/null | q)"
 echo "v_only_cnn3d        $($B --model v_only_cnn3d 2>/dev/null | q)"

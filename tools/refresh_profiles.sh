@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (gpurun -- 'bash tools/refresh_profiles.sh'): regenerates everything under profiles/ for round $1
 # (default 1) from the current build and leaves copies in gpurun_out/ for the merge back.  ~6 minutes.
 #   bench.py default / --no-overlap / layer-by-layer stem, rocprofv3 kernel trace of the bench, two PMC passes.
-R=${1:-4}; TAG=$(printf "r%02d" $R)
+R=${1:-5}; TAG=$(printf "r%02d" $R)
 ROOT=$PWD; export PYTHONPATH=$ROOT
 mkdir -p gpurun_out profiles
 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/bench.err

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     a = ap.parse_args()
     a.model, a.blocks, a.channels, a.tail_channels = "film_attn_pt", 1, 512, 0
-    if a.precision in ("fp16", "fp16x"):
+    if a.precision in ("fp16", "fp16h"):
         from videonavqa_amd import _lib as L
         L.set_half("f16")
     stem = bench.build(a, torch.device("cuda"))[1]

@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 418          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 419          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -56,7 +56,6 @@ CONV_XCD_SPLIT_N = 2
 CONV_X_WRAP2 = 4
 CONV_DUAL_OUT = 0x20000  # y = [h16(v) | h16(v - h16(v))], 2 c_out channels (patch-stationary tiles)
 CONV_DUAL_HI2 = 0x40000  # with CONV_DUAL_OUT: y = [hi | lo | hi], 3 c_out channels (a three-product consumer's operand)
-X3_POST_ZERO_HALO = 4      # vnqa_x3_post: or'ed into out_x3
 LAYOUT_MAX_BATCH = 256     # vnqa_frame_layout: VNQA_LAYOUT_MAX_BATCH
 GEMM_X_WRAP2 = 0x400
 WGRAD_FUSED_REDUCE = 0x100     # option bit of vnqa_conv2d_wgrad's dtype argument
@@ -118,10 +117,7 @@ _SIGNATURES = {
     "vnqa_stream_create_reserved": (ctypes.c_int, [_i32, ctypes.POINTER(ctypes.c_void_p)]),
     "vnqa_stream_create_masked": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(ctypes.c_void_p)]),
     "vnqa_conv2d_igemm_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vnqa_grad_split_scale": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
     "vnqa_split3_f32": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp, _vp]),
-    "vnqa_conv2d_igemm_raw": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
-    "vnqa_x3_post": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_i32] * 9 + [_vp, _vp]),
     "vnqa_conv2d_c64_fwd": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vnqa_layernorm_fwd": (ctypes.c_int, [_vp] * 7 + [_i32, _i32, _f32, _vp]),
     "vnqa_layernorm_bwd": (ctypes.c_int, [_vp] * 9 + [_i32, _i32, _i32, _vp]),

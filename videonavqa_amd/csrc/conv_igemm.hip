@@ -1551,26 +1551,6 @@ extern "C" int64_t vnqa_conv2d_bnstats_workspace(const vnqa_conv_desc* d, int32_
   return tiles_m * 6 * d->c_out * 4;
 }
 
-// The conv's RAW fp32 accumulators [n_img * h * w][c_out] (dense, pixel-major, no bias / activation / pooling / halo): the
-// 16-bit implicit GEMM as a building block of the x3 products (csrc/split3.hip) — the operands are fp16 halves concatenated
-// along K (c_in = 3 x the layer's channels), the caller finishes the sums in fp32 (vnqa_x3_post).
-extern "C" int vnqa_conv2d_igemm_raw(const vnqa_conv_desc* d, const void* x, const void* wt, float* raw, void* stream) {
-  ConvArgs a;
-  const int rc = fill_conv_args(d, x, wt, nullptr, nullptr, nullptr, nullptr, raw, a);
-  if (rc != VNQA_OK) return rc;
-  VNQA_CHECK_ARG(d->dtype == VNQA_BF16 && !d->pool2 && d->depth == 0 && !d->wt_tiled && d->relu == 0 &&
-                     (d->flags & ~VNQA_CONV_X_WRAP2) == 0,
-                 "conv2d_igemm_raw: a plain 16-bit 2-D conv (no pooling / activation / pre-tiled weights; flags: VNQA_CONV_X_WRAP2 only)");
-  VNQA_CHECK_ARG(d->c_out % 4 == 0 && ((uintptr_t)raw & 15) == 0, "conv2d_igemm_raw: c_out %% 4 == 0 and a 16-byte aligned output");
-  VNQA_CHECK_ARG(d->tile != VNQA_TILE_PATCH_224x256 && d->tile != VNQA_TILE_STEM_PATCH_224x256 && d->tile != VNQA_TILE_PS_224x256 &&
-                     d->tile != VNQA_TILE_STEM_PS_224x256,
-                 "conv2d_igemm_raw: implicit-GEMM tiles only (the patch kernels have no raw output)");
-  a.partial = raw;          // slice 0 of a one-slice split-K: the kernel's raw-accumulator store
-  a.slices = 1;
-  a.y = nullptr;
-  return conv_dispatch(a, d->dtype, d->tile, (hipStream_t)stream);
-}
-
 extern "C" int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
                                            const vnqa_conv_epilogue* e, void* y, void* stream) {
   VNQA_CHECK_ARG(e != nullptr, "conv2d_igemm_fused_fwd: null epilogue");

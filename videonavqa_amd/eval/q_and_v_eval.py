@@ -65,7 +65,7 @@ def build_parser():
     parser.add_argument('--best_acc', type=float, default=0)          # passed by eval.sh:57, unused upstream
     # additions
     parser.add_argument('--synthetic', type=int, default=0)
-    parser.add_argument('--precision', type=str, choices=['bf16', 'fp16', 'fp16h', 'fp16w', 'fp16x', 'fp32'], default='bf16')
+    parser.add_argument('--precision', type=str, choices=['bf16', 'fp16', 'fp16h', 'fp32'], default='bf16')
     # how the frozen stem's 16-bit weights are rounded (stem.coherent_round): against the mean activations of seeded noise frames
     # ('noise'), of frames of the first training videos ('data'), or to nearest ('off')
     parser.add_argument('--stem_calibration', type=str, choices=['noise', 'data', 'off'], default='noise')
@@ -349,7 +349,7 @@ def main(argv=None):
         print(obj_detector)
         print(model)
     stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=stem_calibration(args, train_data),
-                      pair_features=args.model != 'mac')
+                      split_features=args.model != 'mac')
 
     class_weights = None
     if args.use_class_weights and hasattr(train_data, "get_class_weights"):

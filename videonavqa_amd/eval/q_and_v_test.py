@@ -133,7 +133,7 @@ def main(argv=None):
                   "frames are not available here — pass 'noise' or 'off', whichever the training run used. Aborting.")
             sys.exit(-1)
         calib = stem_calibration(args, None)
-    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=calib, pair_features=args.model != 'mac')
+    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=calib, split_features=args.model != 'mac')
     reduction = 'mean' if args.loss_reduction == 'elementwise_mean' else args.loss_reduction
     loss_fn = nn.CrossEntropyLoss(reduction=reduction)
     trainer = Trainer(model, stem, loss_reduction=reduction, feature_channels=args.num_input_channels)

@@ -67,181 +67,16 @@ def empty_padded(shape, dtype, device):
     return out
 
 
-# ---- precision='fp16x': fp32 contractions as three fp16-half products on the 16-bit matrix cores (csrc/split3.hip) --------------
-# While the mode is on (f32_conv_mode("x3"): the FORWARD passes of the fp16x models / stem), convs and GEMMs handed fp32 tensors run
-#   split (fp32 -> [hi | lo | hi] 16-bit, one pass) -> the 16-bit implicit GEMM over K' = 3K with raw fp32 accumulators out
-#   -> vnqa_x3_post (bias / ReLU / pool / affine / border correction in fp32)
-# instead of the exact-f32 matrix path (1/16 of the 16-bit MFMA rate).  Everything else of the fp32 precision — statistics, FiLM,
-# LSTMs, the backward pass — is unchanged, so the mode differs from exact fp32 by ~1e-6 per product (x_lo . w_lo dropped).
-_F32_CONV_MODE = ["exact"]
-
-
-class f32_conv_mode(object):
-    """Context manager: how convs / GEMMs on fp32 tensors are evaluated inside it — 'x3' or 'exact' (the default)."""
-
-    def __init__(self, mode):
-        # 'x3g': x3 products whose ACTIVATION-side operand is a gradient tensor (the backward pass): it is multiplied by a
-        # per-tensor power of two chosen on the device (its max lands in [2^12, 2^13)) before the fp16 split — gradients are
-        # 1e-5 .. 1e-8 here, below fp16's normal range — and the fp32 result is divided by it again
-        # 'w2' (precision 'fp16w'): convs / GEMMs with a 16-bit activation and fp32 K-major weights run as the TWO-product form
-        # x . w_hi + x . w_lo — the weight rounding is removed, the activations stay plain fp16 tensors (read twice along K by the
-        # igemm's wrap variant, VNQA_CONV_X_WRAP2: no copy, fused epilogues as usual)
-        # 'x1g': the backward pass as ONE fp16 product per contraction (both operands rounded once, the gradient operand scaled like
-        # 'x3g'): the fp16 precision's backward arithmetic on the fp32-stored tensors of precision 'fp16x' — a third of x3g's matrix work
-        # 'x2': forward products with the fp32 activation rounded ONCE to fp16 against [w_hi | w_lo] — two products instead of three
-        # for one more fp16 rounding per layer input (the trunk's VNQA_X3_TRUNK_FWD=x2 option)
-        assert mode in ("x3", "x2", "x3g", "x1g", "w2", "exact")
-        self.mode = mode
-
-    def __enter__(self):
-        self.prev = _F32_CONV_MODE[0]
-        _F32_CONV_MODE[0] = self.mode
-
-    def __exit__(self, *exc):
-        _F32_CONV_MODE[0] = self.prev
-        return False
-
-
-def x3_active(t):
-    return _F32_CONV_MODE[0] in ("x3", "x2", "x3g", "x1g") and t.dtype == torch.float32 and t.is_cuda
-
-
-def x3_mode():
-    return _F32_CONV_MODE[0]
-
-
-def w2_active(t):
-    return _F32_CONV_MODE[0] == "w2" and L.is_half(t.dtype) and t.is_cuda
-
-
-def fwd_pack_dtype(x):
-    """dtype in which a forward pass packs its weights for activation x: fp32 in the two-product mode (the conv / GEMM wrappers
-    split them into [w_hi | w_lo] themselves), else the activation's own."""
-    return torch.float32 if w2_active(x) else x.dtype
-
-
-_SCALE_STATES = {}
-_SHARED_GRAD = [None]
-
-
-class shared_grad_operand(object):
-    """Inside this context the split scale and the scaled fp16 cast of gradient tensor `t` are computed ONCE: a layer's backward uses
-    the same d(out) as the operand of its weight gradient and of its data gradient (two max-|t| passes and two casts of a 150 MB
-    tensor otherwise).  Explicit and scoped: the caller vouches that `t` is not modified between the uses."""
-
-    def __init__(self, t):
-        on = t is not None and t.is_cuda and os.environ.get("VNQA_X1_SHARE", "1") != "0"
-        self.state = {"ptr": t.data_ptr(), "numel": t.numel(), "scale": None, "cast": None} if on else None
-
-    def __enter__(self):
-        self.prev = _SHARED_GRAD[0]
-        _SHARED_GRAD[0] = self.state
-        return self
-
-    def __exit__(self, *exc):
-        _SHARED_GRAD[0] = self.prev
-        return False
-
-
-def _shared_for(t):
-    sh = _SHARED_GRAD[0]
-    return sh if (sh is not None and sh["ptr"] == t.data_ptr() and sh["numel"] == t.numel()) else None
-
-
-def grad_split_scale(t):
-    """(scale, 1 / scale) as 0-dim device tensors: the power of two that lifts max |t| into [2^12, 2^13) (1 for an all-zero tensor).
-    ONE launch (vnqa_grad_split_scale) on a 16-byte state from a ring of 32 per stream (a scale is consumed by the next few launches
-    of its own stream: the split, the product's finishing pass, the gradient's un-scaling)."""
-    assert t.dtype == torch.float32 and t.is_contiguous()
-    sh = _shared_for(t)
-    if sh is not None and sh["scale"] is not None:
-        return sh["scale"]
-    key = (str(t.device), torch.cuda.current_stream().cuda_stream)
-    ring = _SCALE_STATES.get(key)
-    if ring is None:
-        ring = _SCALE_STATES[key] = [torch.zeros((32, 4), dtype=torch.float32, device=t.device), 0]
-    st = ring[0][ring[1] % 32]
-    ring[1] += 1
-    L.check(L.lib().vnqa_grad_split_scale(L.ptr(t), t.numel(), L.ptr(st), L.stream()), "vnqa_grad_split_scale")
-    if sh is not None:
-        sh["scale"] = (st[1], st[2])
-        return sh["scale"]
-    return st[1], st[2]
-
-
-_X3_WS = {}
-
-
-def _x3_buffer(name, numel, dtype, device):
-    """Reusable scratch per (stream, role): the x3 operand and raw-accumulator buffers of consecutive layers on one stream."""
-    key = (name, str(device), torch.cuda.current_stream().cuda_stream, dtype)
-    buf = _X3_WS.get(key)
-    if buf is None or buf.numel() < numel:
-        buf = _X3_WS[key] = torch.empty(int(numel), dtype=dtype, device=device)
-    return buf[:numel]
-
-
-def split3(x2d, out=None, scale=None):
-    """fp32 [rows, c] -> 16-bit halves, channel-concatenated [rows, 3c] = [hi | lo | hi] (the activation operand of an x3 product).
-    scale: optional 0-dim device tensor multiplied in before the split (grad_split_scale)."""
-    rows, c = x2d.shape
-    assert x2d.dtype == torch.float32 and x2d.stride(1) == 1 and c % 8 == 0
-    half = L.half_dtype()
-    if out is None:
-        out = torch.empty((rows, 3 * c), dtype=half, device=x2d.device)
-    assert out.shape == (rows, 3 * c) and out.is_contiguous()
-    base, es = out.data_ptr(), out.element_size()
-    L.check(L.lib().vnqa_split3_f32(L.vptr(x2d), ctypes.c_void_p(base), ctypes.c_void_p(base + c * es),
-                                    ctypes.c_void_p(base + 2 * c * es), rows, c, x2d.stride(0), 3 * c, L.ptr(scale), L.stream()),
-            "vnqa_split3_f32")
-    return out
-
-
-def cast_hi(x2d, scale=None, name="x1in"):
-    """fp32 [rows, c] -> 16-bit [rows, c] = fp16(scale * x): the operand of a ONE-product backward contraction ('x1g')."""
-    rows, c = x2d.shape
-    assert x2d.dtype == torch.float32 and x2d.stride(1) == 1 and c % 8 == 0
-    sh = _shared_for(x2d) if (scale is not None and x2d.is_contiguous()) else None
-    if sh is not None and sh["scale"] is not None and scale is sh["scale"][0]:
-        if sh["cast"] is not None and sh["cast"].shape == (rows, c):
-            return sh["cast"]
-        name = "x1shared"          # (its own buffer: nothing else overwrites it inside the context)
-    else:
-        sh = None
-    out = _x3_buffer(name, rows * c, L.half_dtype(), x2d.device).view(rows, c)
-    L.check(L.lib().vnqa_split3_f32(L.vptr(x2d), L.ptr(out), None, None, rows, c, x2d.stride(0), c, L.ptr(scale), L.stream()),
-            "vnqa_split3_f32(hi only)")
-    if sh is not None:
-        sh["cast"] = out
-    return out
-
-
-def x1_weight(wt):
-    """fp32 weights rounded once to the 16-bit format (cached on the tensor object like x3_weight)."""
-    cached = getattr(wt, "_vnqa_x1", None)
-    if cached is not None and cached[0] == wt._version:
-        return cached[1]
-    w1 = wt.to(L.half_dtype()).contiguous()
-    try:
-        wt._vnqa_x1 = (wt._version, w1)
-    except (AttributeError, RuntimeError):
-        pass
-    return w1
-
-
-def split3_rows(x2d, order, scale=None, name="x3rows"):
-    """fp32 [rows, c] -> 16-bit [3 * rows, c]: the three halves stacked along the ROWS (the contraction axis of a weight-gradient
-    product), in `order`: 'hhl' = [hi; hi; lo] (the activation operand), 'hlh' = [hi; lo; hi] (the gradient operand)."""
-    rows, c = x2d.shape
-    assert x2d.dtype == torch.float32 and x2d.is_contiguous() and c % 8 == 0 and order in ("hhl", "hlh")
-    out = _x3_buffer(name + order, 3 * rows * c, L.half_dtype(), x2d.device).view(3 * rows, c)
-    base, blk = out.data_ptr(), rows * c * out.element_size()
-    hi, lo, hi2 = (base, base + 2 * blk, base + blk) if order == "hhl" else (base, base + blk, base + 2 * blk)
-    L.check(L.lib().vnqa_split3_f32(L.ptr(x2d), ctypes.c_void_p(hi), ctypes.c_void_p(lo), ctypes.c_void_p(hi2), rows, c, c, c,
-                                    L.ptr(scale), L.stream()), "vnqa_split3_f32")
-    return out
-
-
+# ---- split operands (precision 'fp16h', csrc/split3.hip) ---------------------------------------------------------------------------
+# A 16-bit MFMA operand carries 11 significand bits.  Where the logits-error budget says a rounding matters (profiles/
+# r05_precision_budget*.txt) the operand is SPLIT instead: v = hi + lo with hi = h16(v), lo = h16(v - hi) (22 bits), and the
+# contraction runs as two or three products of 16-bit halves with fp32 accumulation —
+#   weights only   x . w_hi + x . w_lo              the activation is read twice along K by the igemm's wrap variant
+#                                                   (VNQA_CONV_X_WRAP2 / VNQA_GEMM_X_WRAP2: no copy), `split_weights=True`
+#   both operands  x_hi w_hi + x_lo w_hi + x_hi w_lo   the producer lays the activation out as [hi | lo | hi] (VNQA_CONV_DUAL_OUT |
+#                                                   VNQA_CONV_DUAL_HI2), the consumer is a PLAIN conv over 3 C channels against
+#                                                   [w_hi | w_hi | w_lo], `split_in=True`
+# (x_lo . w_lo, 2^-22 relative, is dropped.)  The split weights are made from the fp32 K-major pack in one pass and cached on it.
 def _split_weight(wt, parts):
     """fp32 K-major weights [..][k] -> 16-bit [..][len(parts) * k], the halves named in `parts` ('h' / 'l') along the innermost axis,
     in ONE pass (vnqa_split3_f32)."""
@@ -256,135 +91,48 @@ def _split_weight(wt, parts):
     return out
 
 
-def x3_weight(wt):
-    """fp32 K-major weights [n][...][k] -> 16-bit [n][...][3k] = [w_hi | w_hi | w_lo] along the innermost (contraction) axis, cached
-    on the tensor object for weights that persist (the frozen stem's packs; re-made when the tensor was modified in place)."""
-    cached = getattr(wt, "_vnqa_x3", None)
+def _cached_split(wt, parts, slot):
+    cached = getattr(wt, slot, None)
     if cached is not None and cached[0] == wt._version:
         return cached[1]
-    w3 = _split_weight(wt, "hhl")
+    w = _split_weight(wt, parts)
     try:
-        wt._vnqa_x3 = (wt._version, w3)
+        setattr(wt, slot, (wt._version, w))
     except (AttributeError, RuntimeError):
         pass
-    return w3
+    return w
 
 
-def x3_weight2(wt):
-    """[w_hi | w_lo] along the contraction axis: the weight operand for an input that is ALREADY 16-bit (nothing to split on the
-    activation side: two products instead of three)."""
-    cached = getattr(wt, "_vnqa_x2", None)
-    if cached is not None and cached[0] == wt._version:
-        return cached[1]
-    w2 = _split_weight(wt, "hl")
-    try:
-        wt._vnqa_x2 = (wt._version, w2)
-    except (AttributeError, RuntimeError):
-        pass
-    return w2
+def split_weight3(wt):
+    """[w_hi | w_hi | w_lo] along the contraction axis — the weight operand of a three-product conv over a [hi | lo | hi] activation;
+    cached on the tensor object for packs that persist (re-made when the tensor was modified in place)."""
+    return _cached_split(wt, "hhl", "_vnqa_w3")
 
 
-def _conv2d_x3(x, wt, bias, relu, pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub, x3_out=False):
-    """One conv as an x3 product.  x: fp32 [.., C] (split here), or 16-bit [.., 3C] already in the [hi | lo | hi] operand layout
-    (the previous layer's x3_out), or 16-bit [.., C] (a plain 16-bit activation: [x | x] against [w_hi | w_lo], two products).
-    Output: fp32 padded NHWC, or with x3_out = 1 the next layer's 16-bit operand [.., 3 c_out] = [hi | lo | hi], x3_out = 2 the
-    plain 16-bit tensor [.., c_out] (the output rounded to fp16 once; its consumer runs two products)."""
-    N, Hp, Wp, Cx = x.shape
-    H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
-    c_out, taps, Cin = wt.shape
-    assert wt.dtype == torch.float32 and x.is_contiguous()
-    half = L.half_dtype()
-    inv, wrap = None, 0
-    if x.dtype == torch.float32 and _F32_CONV_MODE[0] == "x1g":      # one product: fp16(s * dy) against fp16(w)
-        assert Cx == Cin
-        k = Cin
-        w3 = x1_weight(wt).view(c_out, taps, k)
-        scale, inv = grad_split_scale(x)
-        xin = cast_hi(x.view(N * Hp * Wp, Cin), scale=scale)
-    elif x.dtype == torch.float32 and _F32_CONV_MODE[0] == "x2" and Cin % 64 == 0:   # two products: fp16(x) read twice against [w_hi | w_lo]
-        assert Cx == Cin
-        k = 2 * Cin
-        w3 = x3_weight2(wt).view(c_out, taps, k)
-        xin = cast_hi(x.view(N * Hp * Wp, Cin), name="x2in")
-        wrap = L.CONV_X_WRAP2
-    elif x.dtype == torch.float32:
-        assert Cx == Cin
-        k = 3 * Cin
-        w3 = x3_weight(wt).view(c_out, taps, k)
-        xin = _x3_buffer("x3in", N * Hp * Wp * k, half, x.device).view(N * Hp * Wp, k)
-        scale = None
-        if _F32_CONV_MODE[0] == "x3g":          # a gradient tensor on the activation side (dgrad): lift it into fp16's range
-            scale, inv = grad_split_scale(x)
-        split3(x.view(N * Hp * Wp, Cin), out=xin, scale=scale)
-    elif Cx == 3 * Cin:
-        assert x.dtype == half
-        k, xin = 3 * Cin, x
-        w3 = x3_weight(wt).view(c_out, taps, k)
-    else:                        # a plain 16-bit activation: two products, read twice along K by the kernel itself (no copy)
-        assert x.dtype == half and Cx == Cin and Cin % 64 == 0
-        k, xin = 2 * Cin, x
-        w3 = x3_weight2(wt).view(c_out, taps, k)
-        wrap = L.CONV_X_WRAP2
-    raw = _x3_buffer("raw", N * H * W * c_out, torch.float32, x.device)
-    d = L.ConvDesc(L.BF16, N, H, W, k, c_out, c_out, taps, x_halo, 0, 0, 0, L.TILE_AUTO, 0, 0, wrap)      # (the 16-bit product picks its own tile)
-    L.check(L.lib().vnqa_conv2d_igemm_raw(ctypes.byref(d), L.ptr(xin), L.ptr(w3), L.ptr(raw), L.stream()), "vnqa_conv2d_igemm_raw")
-    Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
-    odt, oc = (half, (3 if int(x3_out) == 1 else 1) * c_out) if x3_out else (torch.float32, c_out)
-    post_flags = int(x3_out)
-    if out is None:
-        shape = (N, Ho + 2 * y_halo, Wo + 2 * y_halo, oc)
-        if os.environ.get("VNQA_X3_POST_HALO", "0") == "1":      # A/B: the finishing pass zeroes the halo ring itself (measured slower)
-            out = torch.empty(shape, dtype=odt, device=x.device)
-            post_flags |= L.X3_POST_ZERO_HALO
-        else:
-            out = empty_padded(shape, odt, x.device) if y_halo == 1 else torch.zeros(shape, dtype=odt, device=x.device)
-    assert out.dtype == odt and out.shape[:3] == (N, Ho + 2 * y_halo, Wo + 2 * y_halo) and out.shape[-1] >= oc
-    bs = None if border_sub is None else border_sub.float().contiguous()
-    L.check(L.lib().vnqa_x3_post(L.ptr(raw), L.ptr(bias), L.ptr(post_scale), L.ptr(post_shift), L.ptr(bs), L.ptr(out), N, H, W,
-                                 c_out, out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, post_flags, L.ptr(inv),
-                                 L.stream()), "vnqa_x3_post")
-    return out
-
-
-def x3_post_again(out, n, h, w, c_out, y_halo, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None):
-    """The raw sums of the x3 product that JUST ran on this stream (still in its scratch buffer), finished once more as fp32 into
-    `out` — for a layer whose output is needed both as the next product's 16-bit operand and as an fp32 tensor."""
-    raw = _x3_buffer("raw", n * h * w * c_out, torch.float32, out.device)
-    assert out.dtype == torch.float32
-    L.check(L.lib().vnqa_x3_post(L.ptr(raw), L.ptr(bias), L.ptr(post_scale), L.ptr(post_shift), None, L.ptr(out), n, h, w, c_out,
-                                 out.shape[-1], y_halo, 1 if relu else 0, 1 if pool2 else 0, 0, None, L.stream()), "vnqa_x3_post")
-    return out
+def split_weight2(wt):
+    """[w_hi | w_lo] along the contraction axis — the weight operand of a two-product conv / GEMM over a plain 16-bit activation."""
+    return _cached_split(wt, "hl", "_vnqa_w2")
 
 
 def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
-                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, x3_out=False, desc_flags=0,
-                 split_in=False, dual_out=False):
+                 x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, desc_flags=0,
+                 split_in=False, split_weights=False, dual_out=False):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
-    (x3_out: only inside f32_conv_mode("x3") — the output as the next x3 product's 16-bit operand, see _conv2d_x3.)
-    Precision 'fp16h':  dual_out = 2 / 3 — the output as a SPLIT tensor [hi | lo] / [hi | lo | hi] (hi = h16(v), lo = h16(v - hi);
-    VNQA_CONV_DUAL_OUT [| _HI2], patch-stationary tiles).  split_in — x is such a [hi | lo | hi] tensor (3 Cin channels) and wt the
-    fp32 K-major pack [Cout][taps][Cin]: the plain conv over 3 Cin channels against [w_hi | w_hi | w_lo] = x_hi w_hi + x_lo w_hi +
-    x_hi w_lo — the unrounded activation against unrounded weights, three MFMA products, no kernel of its own."""
+    Precision 'fp16h' (see the block comment above):
+      split_weights — x a plain 16-bit tensor, wt the fp32 K-major pack: x . w_hi + x . w_lo on the igemm's wrap variant;
+      split_in      — x a [hi | lo | hi] tensor (3 Cin channels), wt the fp32 pack: the plain conv over 3 Cin channels against
+                      [w_hi | w_hi | w_lo], any tile;
+      dual_out      — 2 / 3: the output as [hi | lo] / [hi | lo | hi] (patch-stationary tiles)."""
     if split_in:
         assert L.is_half(x.dtype) and wt.dtype == torch.float32 and not isinstance(wt, TiledWeight) and x.shape[-1] == 3 * wt.shape[2] \
-            and not x3_out
-        wt = x3_weight(wt)                                   # [w_hi | w_hi | w_lo] along the contraction axis, cached on the pack
-    x3m = _F32_CONV_MODE[0] in ("x3", "x2", "x3g", "x1g") and x.is_cuda and not isinstance(wt, TiledWeight) and wt.dtype == torch.float32 and \
-        relu in (False, True, 0, 1) and wt.shape[0] % 4 == 0 and x.shape[-1] % 64 == 0
-    # inside the x3 mode a layer with a plain 16-bit input AND a rounded (plain 16-bit) output is exactly the two-product conv of
-    # precision 'fp16w': one launch of the wrap variant with its fused epilogue instead of raw sums + a post pass
-    # (not with a border correction: the composed pair keeps its fp32 correction term on the raw-sums path)
-    fused_w2 = x3m and int(x3_out) == 2 and L.is_half(x.dtype) and x.shape[-1] == wt.shape[2] and border_sub is None
-    if x3m and not fused_w2:
-        return _conv2d_x3(x, wt, bias, bool(relu), pool2, post_scale, post_shift, x_halo, y_halo, out, tile, border_sub, x3_out)
-    assert fused_w2 or not x3_out, "x3_out needs f32_conv_mode('x3') and fp32 K-major weights"
+            and not split_weights
+        wt = split_weight3(wt)
     N, Hp, Wp, Cin = x.shape
     H, W = Hp - 2 * x_halo, Wp - 2 * x_halo
     tiled = isinstance(wt, TiledWeight)
-    w2 = (w2_active(x) or fused_w2) and not tiled and wt.dtype == torch.float32
-    if w2:          # two products: x read twice along K against [w_hi | w_lo] (VNQA_CONV_X_WRAP2)
-        assert wt.shape[2] == Cin and Cin % 64 == 0
-        wt = x3_weight2(wt)
+    if split_weights:          # two products: x read twice along K against [w_hi | w_lo] (VNQA_CONV_X_WRAP2)
+        assert L.is_half(x.dtype) and not tiled and wt.dtype == torch.float32 and wt.shape[2] == Cin and Cin % 64 == 0
+        wt = split_weight2(wt)
         desc_flags = int(desc_flags) | L.CONV_X_WRAP2
         if border_sub is not None and border_sub.dtype != x.dtype:       # (the kernel subtracts it in the output's element type)
             border_sub = border_sub.to(x.dtype).contiguous()
@@ -395,7 +143,7 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
         wt = wt.data
     else:
         c_out, taps, cin_w = wt.shape
-    assert cin_w == (2 * Cin if w2 else Cin) and wt.dtype == x.dtype, (cin_w, x.shape, wt.dtype, x.dtype)
+    assert cin_w == (2 * Cin if split_weights else Cin) and wt.dtype == x.dtype, (cin_w, x.shape, wt.dtype, x.dtype)
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     flags = 0
     if dual_out:        # 2 (or True): [hi | lo]; 3: [hi | lo | hi]
@@ -437,7 +185,7 @@ def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frame
     N, Hp, Wp, _ = x.shape
     if split_in:
         assert wt.dtype == torch.float32 and x.shape[-1] == 3 * wt.shape[2]
-        wt = x3_weight(wt)
+        wt = split_weight3(wt)
     c_out, taps, _ = wt.shape
     d = _conv_desc(x, c_out, c_out, taps, relu)
     ws_bytes = L.lib().vnqa_conv2d_bnstats_workspace(ctypes.byref(d), int(min_frame_images))
@@ -463,8 +211,8 @@ def conv_ps_supported(n, h, w, c_in, c_out, taps=9, pool2=False):
 
 def ps_fused_tile(x):
     """TILE_PS_224x256 when the patch-stationary kernel can run a 3x3 conv with a fused FILM_RES / ADD_MASK epilogue on this
-    padded-NHWC input (asked of the library: vnqa_conv_ps_supported), else TILE_AUTO.  VNQA_TRUNK_PS=0 disables."""
-    if os.environ.get("VNQA_TRUNK_PS", "1") == "0" or not L.is_half(x.dtype):
+    padded-NHWC input (asked of the library: vnqa_conv_ps_supported), else TILE_AUTO."""
+    if not L.is_half(x.dtype):
         return L.TILE_AUTO
     N, Hp, Wp, C = x.shape
     return L.TILE_PS_224x256 if (C % 64 == 0 and conv_ps_supported(N, Hp - 2, Wp - 2, C, C)) else L.TILE_AUTO
@@ -478,16 +226,6 @@ def conv2d_igemm_film_res(x, wt, bias, gamma, beta, film_c, res, tile=L.TILE_AUT
     c_out, taps, _ = wt.shape
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.stride(1) == 1 and beta.stride(1) == 1
     assert gamma.stride(0) == beta.stride(0) and res.shape == (N, Hp, Wp, c_out) and res.dtype == x.dtype
-    if x3_active(x) or (w2_active(x) and wt.dtype == torch.float32):
-        # the conv as an x3 / two-product conv, the FiLM affine + ReLU + residual as the separate elementwise kernel
-        z = conv2d_igemm(x, wt, bias=bias)
-        if film_c == c_out:
-            g, b = gamma[:, :c_out].contiguous(), beta[:, :c_out].contiguous()
-        else:
-            g = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
-            b = torch.zeros((N, c_out), dtype=torch.float32, device=x.device)
-            g[:, :film_c], b[:, :film_c] = gamma[:, :film_c], beta[:, :film_c]
-        return (z if keep_z else None), film_relu_res_fwd(z, res, g, b)
     d = _conv_desc(x, c_out, c_out, taps, False, tile if taps == 9 else L.TILE_AUTO)
     z = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device) if keep_z else None
     out = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
@@ -504,8 +242,6 @@ def conv2d_igemm_add_mask(x, wt, add, mask_src, tile=L.TILE_AUTO):
     N, Hp, Wp, _ = x.shape
     c_out, taps, _ = wt.shape
     assert add.shape == (N, Hp, Wp, c_out) and mask_src.shape == add.shape and add.dtype == x.dtype == mask_src.dtype
-    if x3_active(x):       # the dgrad as an x3 product, the residual join + ReLU mask as the separate fp32 kernel
-        return relu_bwd(conv2d_igemm(x, wt), mask_src, add)
     d = _conv_desc(x, c_out, c_out, taps, False, tile if taps == 9 else L.TILE_AUTO)
     y = torch.empty((N, Hp, Wp, c_out), dtype=x.dtype, device=x.device)
     e = L.ConvEpilogue(kind=L.EPI_ADD_MASK, res=add.data_ptr(), y2=mask_src.data_ptr())
@@ -535,8 +271,6 @@ def conv2d_ring(x, wt, bias, H, W, out_padded=None):
     c_out = wt.shape[0]
     R = 2 * (W + 2) + 2 * H
     opt = 0
-    if w2_active(x) and wt.dtype == torch.float32:       # two products: x read twice against [w_hi | w_lo]
-        wt, c_in, opt = x3_weight2(wt), 2 * c_in, L.GEMM_X_WRAP2
     if out_padded is not None:
         assert out_padded.shape == (n, R + 4, c_out) and out_padded.dtype == x.dtype and out_padded.is_contiguous()
         y1 = out_padded
@@ -555,10 +289,6 @@ def ring_edge_conv(y1p, wt_edge, H, W, edge):
     co = wt_edge.shape[0]
     ln = W if edge < 2 else H
     opt = 0
-    if w2_active(y1p) and wt_edge.dtype == torch.float32:
-        # two products per slot: wt_edge [co, 3 * cm] -> [co, 3, 2 cm] = per slot [w_hi | w_lo], y1p read twice
-        wt_edge = x3_weight2(wt_edge.view(co, 3, cm)).view(co, 6 * cm)
-        cm, opt = 2 * cm, L.GEMM_X_WRAP2
     out = torch.empty((n * ln, co), dtype=y1p.dtype, device=y1p.device)
     L.check(L.lib().vnqa_ring_edge_conv_fwd(L.ptr(y1p), L.ptr(wt_edge), L.ptr(out), n, H, W, cm, co, edge,
                                             L.dtype_id(y1p.dtype) | opt, L.stream()), "vnqa_ring_edge_conv_fwd")
@@ -831,9 +561,8 @@ def unpack_fc_wgrad(dw_nat, rows, C, h, wd, c_pad, out=None, alpha=1.0):
     """fp32 gradient of the native-layout weight [rows_pad, (h+2)(wd+2)*c_pad] -> [rows, C*h*wd]."""
     dw = out if out is not None else torch.empty((rows, C * h * wd), dtype=torch.float32, device=dw_nat.device)
     assert dw.shape == (rows, C * h * wd) and dw.is_contiguous() and dw.dtype == torch.float32
-    # (a product whose un-scaling was deferred — gemm_tn(..., defer_scale=True) — carries its inverse split scale: applied here)
     L.check(L.lib().vnqa_unpack_fc_wgrad_dev(L.ptr(dw_nat), rows, C, h, wd, c_pad, L.ptr(dw), float(alpha),
-                                             L.ptr(getattr(dw_nat, "_vnqa_inv", None)), L.stream()), "vnqa_unpack_fc_wgrad")
+                                             None, L.stream()), "vnqa_unpack_fc_wgrad")
     return dw
 
 
@@ -893,57 +622,17 @@ def workspace(nbytes, device):
     return buf
 
 
-# A/B option of the weight-gradient kernel, passed PER CALL in its dtype argument (the library itself reads no environment):
-# VNQA_WGRAD_FUSED_REDUCE=1 folds the split-K slabs in the kernel's tail instead of a reduce launch (-2.5 % end to end)
-_WGRAD_OPTS = L.WGRAD_FUSED_REDUCE if os.environ.get("VNQA_WGRAD_FUSED_REDUCE", "0") == "1" else 0
-
-
-def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, defer_scale=False, x_segs=1):
+def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, x_segs=1):
     """x, dy: padded NHWC (halo 1, same N/H/W). Returns (dwt fp32 [Cout][taps][Cin], dbias fp32 [Cout]).
     x_segs = 2 / 3: x is a [hi | lo] / [hi | lo | hi] tensor (x_segs Cin physical channels); its first segment — the plain 16-bit
-    value — is contracted in place.
-    defer_scale (the scaled x1g / x3g products of precision 'fp16x'): dwt is returned still multiplied by the split scale, its
-    inverse attached as dwt._vnqa_inv — unpack_conv_wgrad applies it in its own pass (no separate multiply)."""
+    value — is contracted in place."""
     N, Hp, Wp, Cin = x.shape
     Cout = dy.shape[-1]
     h, w = Hp - 2, Wp - 2
     if x_segs > 1:
-        assert x_segs in (2, 3) and L.is_half(x.dtype) and dy.dtype == x.dtype and Cin % x_segs == 0 and not x3_active(dy)
+        assert x_segs in (2, 3) and L.is_half(x.dtype) and Cin % x_segs == 0
         Cin //= x_segs
-    if L.is_half(x.dtype) and x3_active(dy) and _F32_CONV_MODE[0] != "x1g":
-        x = x.float()          # (a 16-bit activation against an fp32 gradient is served by the one-product form only)
-    assert dy.shape[:3] == x.shape[:3] and (dy.dtype == x.dtype or (L.is_half(x.dtype) and x3_active(dy)))
-    if (x3_active(x) or (L.is_half(x.dtype) and x3_active(dy))) and Cin % 8 == 0 and Cout % 8 == 0 and x.is_contiguous() and \
-            dy.is_contiguous() and 3 * N * Hp * Wp < (1 << 31):
-        # x3 product over the pixels: dW = sum_p dY[p] X[p + tap]  with  X' = [x_hi; x_hi; x_lo], dY' = s [dy_hi; dy_lo; dy_hi] stacked
-        # along the IMAGE axis — the 16-bit weight-gradient kernel on 3 N images computes exactly the three products' sum
-        scale, inv = grad_split_scale(dy)
-        if _F32_CONV_MODE[0] == "x1g":      # one product: fp16(x) and fp16(s * dy), N images
-            nn = N
-            # (x already 16-bit — fp16 features handed over by the stem — is its own operand)
-            x3 = x if L.is_half(x.dtype) else cast_hi(x.view(N * Hp * Wp, Cin), name="x1rows").view(N, Hp, Wp, Cin)
-            dy3 = cast_hi(dy.view(N * Hp * Wp, Cout), scale=scale, name="x1rowsdy").view(N, Hp, Wp, Cout)
-        else:
-            nn = 3 * N
-            x3 = split3_rows(x.view(N * Hp * Wp, Cin), "hhl").view(3 * N, Hp, Wp, Cin)
-            dy3 = split3_rows(dy.view(N * Hp * Wp, Cout), "hlh", scale=scale, name="x3rowsdy").view(3 * N, Hp, Wp, Cout)
-        ws = workspace(L.lib().vnqa_conv2d_wgrad_workspace(nn, h, w, Cin, Cout, taps), x.device)
-        dwt = torch.empty((Cout, taps, Cin), dtype=torch.float32, device=x.device)
-        L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x3), L.ptr(dy3), L.ptr(dwt), None, L.ptr(ws), nn, h, w, Cin, Cout, taps,
-                                          L.BF16, L.stream()), "vnqa_conv2d_wgrad(x3)")
-        if defer_scale:
-            dwt._vnqa_inv = inv
-        else:
-            dwt.mul_(inv)
-        dbias = None
-        if want_bias:
-            # the bias gradient from the fp32 dy, not from the kernel's fp16 operand (a sum of 55 000 terms that cancel to 1 / 400 of
-            # their magnitude: the fp16-rounded terms miss the golden gradients' 2e-3 by 25 %; measured, tests/test_gpu_x3.py).
-            # (vnqa_colsum is laid out for the small fp32 matrices of the tails: torch's reduction for the 50 - 150 MB gradient)
-            dbias = dbias_out if (dbias_out is not None and dbias_out.numel() == Cout) else \
-                torch.empty((Cout,), dtype=torch.float32, device=x.device)
-            torch.sum(dy.view(N * Hp * Wp, Cout), dim=0, out=dbias)
-        return dwt, dbias
+    assert dy.shape[:3] == x.shape[:3] and dy.dtype == x.dtype
     ws = workspace(L.lib().vnqa_conv2d_wgrad_workspace(N, h, w, Cin, Cout, taps), x.device)
     dwt = torch.empty((Cout, taps, Cin), dtype=torch.float32, device=x.device)
     dbias = None
@@ -951,7 +640,8 @@ def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, defer_scale=False,
         dbias = dbias_out if (dbias_out is not None and dbias_out.numel() == Cout) else \
             torch.empty((Cout,), dtype=torch.float32, device=x.device)
     L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwt), L.ptr(dbias), L.ptr(ws), N, h, w, Cin, Cout,
-                                      taps, L.dtype_id(x.dtype) | _WGRAD_OPTS | {1: 0, 2: L.WGRAD_X_PAIR, 3: L.WGRAD_X_TRIPLE}[x_segs], L.stream()), "vnqa_conv2d_wgrad")
+                                      taps, L.dtype_id(x.dtype) | {1: 0, 2: L.WGRAD_X_PAIR, 3: L.WGRAD_X_TRIPLE}[x_segs], L.stream()),
+            "vnqa_conv2d_wgrad")
     return dwt, dbias
 
 
@@ -963,88 +653,36 @@ def unpack_conv_wgrad(dwt, c_out, c_in, out=None, alpha=1.0):
         out = torch.empty((c_out, c_in) + shape, dtype=torch.float32, device=dwt.device)
     assert out.shape == (c_out, c_in) + shape and out.is_contiguous() and out.dtype == torch.float32
     L.check(L.lib().vnqa_unpack_conv_wgrad_dev(L.ptr(dwt), c_out, c_in, taps, c_out_pad, c_in_pad, L.ptr(out), float(alpha),
-                                               L.ptr(getattr(dwt, "_vnqa_inv", None)), L.stream()), "vnqa_unpack_conv_wgrad")
+                                               None, L.stream()), "vnqa_unpack_conv_wgrad")
     return out
 
 
-def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True):
+def gemm_nt(a, b, bias=None, relu=False, out=None, split_k=True, split_weights=False):
     """out[m][n] = act(sum_k a[m][k] b[n][k] + bias[n]); a [M,K], b [N,K] (same dtype), out dtype = a.dtype.
-    split_k=False: one pass over K in a fixed order (result independent of M's tiling)."""
+    split_k=False: one pass over K in a fixed order (result independent of M's tiling).
+    split_weights (precision 'fp16h'): b is the fp32 operand — a . b_hi + a . b_lo, a read twice along K (VNQA_GEMM_X_WRAP2)."""
     M, Kd = a.shape
     N = b.shape[0]
-    assert b.shape[1] == Kd and (a.dtype == b.dtype or (w2_active(a) and b.dtype == torch.float32))
-    if w2_active(a) and b.dtype == torch.float32 and Kd % 64 == 0 and a.is_contiguous():
-        # two products: a read twice along K against [b_hi | b_lo] (VNQA_GEMM_X_WRAP2)
-        b2 = x3_weight2(b)
-        if out is None:
-            out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-        did = L.dtype_id(a.dtype)
-        ws_bytes = L.lib().vnqa_gemm_nt_workspace(M, N, 2 * Kd, did) if split_k else 0
-        ws = workspace(ws_bytes, a.device) if ws_bytes > 0 else None
-        L.check(L.lib().vnqa_gemm_nt(L.ptr(a), L.ptr(b2), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, 2 * Kd, out.stride(0),
-                                     1 if relu else 0, did | L.GEMM_X_WRAP2, L.stream()), "vnqa_gemm_nt(w2)")
-        return out
-    if x3_active(a) and Kd % 64 == 0 and a.is_contiguous():
-        # x3 product: [a_hi | a_lo | a_hi] . [b_hi | b_hi | b_lo]^T on the 16-bit GEMM with an fp32 output
-        scale = inv = None
-        if _F32_CONV_MODE[0] in ("x3g", "x1g"):   # `a` is a gradient (dX = dOut . W): lifted into fp16's range, divided out below
-            assert bias is None and not relu
-            scale, inv = grad_split_scale(a)
-        gflags = L.BF16 | L.GEMM_OUT_F32
-        if _F32_CONV_MODE[0] == "x1g":            # one product
-            kk, a3, b3 = Kd, cast_hi(a, scale=scale), x1_weight(b)
-        elif _F32_CONV_MODE[0] == "x2":           # two products: fp16(a) read twice against [b_hi | b_lo]
-            kk, a3, b3 = 2 * Kd, cast_hi(a, name="x2in"), x3_weight2(b)
-            gflags |= L.GEMM_X_WRAP2
-        else:
-            kk = 3 * Kd
-            a3 = split3(a, out=_x3_buffer("x3in", M * 3 * Kd, L.half_dtype(), a.device).view(M, 3 * Kd), scale=scale)
-            b3 = x3_weight(b)
-        if out is None:
-            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-        assert out.dtype == torch.float32
-        ws_bytes = max(L.lib().vnqa_gemm_nt_workspace(M, N, kk, L.BF16) if split_k else 0, M * N * 4)
-        ws = workspace(ws_bytes, a.device)
-        L.check(L.lib().vnqa_gemm_nt(L.ptr(a3), L.ptr(b3), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, kk, out.stride(0),
-                                     1 if relu else 0, gflags, L.stream()), "vnqa_gemm_nt(x3)")
-        if inv is not None:
-            out.mul_(inv)
-        return out
+    opt, kk = 0, Kd
+    if split_weights:
+        assert L.is_half(a.dtype) and b.dtype == torch.float32 and Kd % 64 == 0 and a.is_contiguous()
+        b, opt, kk = split_weight2(b), L.GEMM_X_WRAP2, 2 * Kd
+    assert b.shape[1] == kk and a.dtype == b.dtype
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
     did = L.dtype_id(a.dtype)
-    ws_bytes = L.lib().vnqa_gemm_nt_workspace(M, N, Kd, did) if split_k else 0
+    ws_bytes = L.lib().vnqa_gemm_nt_workspace(M, N, kk, did) if split_k else 0
     ws = workspace(ws_bytes, a.device) if ws_bytes > 0 else None
-    L.check(L.lib().vnqa_gemm_nt(L.ptr(a), L.ptr(b), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, Kd, out.stride(0),
-                                 1 if relu else 0, did, L.stream()), "vnqa_gemm_nt")
+    L.check(L.lib().vnqa_gemm_nt(L.ptr(a), L.ptr(b), L.ptr(bias), L.ptr(out), L.ptr(ws), M, N, kk, out.stride(0),
+                                 1 if relu else 0, did | opt, L.stream()), "vnqa_gemm_nt")
     return out
 
 
-def gemm_tn(a, b, out=None, defer_scale=False):
-    """out[m][n] = sum_k a[k][m] b[k][n]; a [K,M], b [K,N] (same dtype) -> fp32 [M,N].
-    defer_scale: see conv2d_wgrad (the consumer must be unpack_fc_wgrad)."""
+def gemm_tn(a, b, out=None):
+    """out[m][n] = sum_k a[k][m] b[k][n]; a [K,M], b [K,N] (same dtype) -> fp32 [M,N]."""
     Kd, M = a.shape
     N = b.shape[1]
     assert b.shape[0] == Kd and a.dtype == b.dtype
-    if x3_active(a) and M % 8 == 0 and N % 8 == 0 and a.is_contiguous() and b.is_contiguous():
-        # x3 product over K (the rows): A' = s [a_hi; a_lo; a_hi] (a: the gradient operand), B' = [b_hi; b_hi; b_lo]
-        scale, inv = grad_split_scale(a)
-        if _F32_CONV_MODE[0] == "x1g":            # one product
-            kk, a3, b3 = Kd, cast_hi(a, scale=scale, name="x1rowsdy"), cast_hi(b, name="x1rows")
-        else:
-            kk = 3 * Kd
-            a3 = split3_rows(a, "hlh", scale=scale, name="x3rowsdy")
-            b3 = split3_rows(b, "hhl")
-        ws = workspace(L.lib().vnqa_gemm_tn_workspace(M, N, kk, L.BF16), a.device)
-        if out is None:
-            out = torch.empty((M, N), dtype=torch.float32, device=a.device)
-        assert out.shape == (M, N) and out.is_contiguous() and out.dtype == torch.float32
-        L.check(L.lib().vnqa_gemm_tn(L.ptr(a3), L.ptr(b3), L.ptr(out), L.ptr(ws), M, N, kk, L.BF16, L.stream()), "vnqa_gemm_tn(x3)")
-        if defer_scale:
-            out._vnqa_inv = inv
-        else:
-            out.mul_(inv)
-        return out
     did = L.dtype_id(a.dtype)
     ws = workspace(L.lib().vnqa_gemm_tn_workspace(M, N, Kd, did), a.device)
     if out is None:
@@ -1265,7 +903,7 @@ def conv3d_igemm(x, wt, bias=None, relu=False, pool2=False, out=None):
     if out is None:
         out = torch.zeros((N, Dp, Ho + 2, Wo + 2, c_out), dtype=x.dtype, device=x.device)
     # 128-cout 3-D convs (VideoOnlyCNN3D conv2 / conv3a): the 512 x 128 tile (tools/ab_c3d_tiles.sh: config 2 +1.5 % over the 256 x 128 default)
-    tile = int(os.environ.get("VNQA_C3D_TILE_%d" % c_out, 15 if c_out == 128 else L.TILE_AUTO)) if L.is_half(x.dtype) else L.TILE_AUTO
+    tile = (15 if c_out == 128 else L.TILE_AUTO) if L.is_half(x.dtype) else L.TILE_AUTO      # (tools/ab_c3d_tiles.sh measured the ids)
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, Cin, c_out, out.shape[-1], 27, 1, 1, int(relu), 1 if pool2 else 0,
                    tile, 0, D)
     L.check(L.lib().vnqa_conv2d_igemm_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), None, None, L.ptr(out),

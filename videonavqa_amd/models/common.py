@@ -36,12 +36,6 @@ def compute_dtype(precision):
         return torch.float16
     if precision in ("fp32", "f32", torch.float32):
         return torch.float32
-    if precision == "fp16x":
-        # fp32 storage and elementwise work as in 'fp32', but the FORWARD contractions run on the fp16 matrix cores as three
-        # products of fp16 halves with fp32 accumulation (kernels.f32_conv_mode / csrc/split3.hip): the tolerance-compliant
-        # 16-bit-MFMA precision — logits within north star's 1e-3 of exact fp32 (measured ~1e-5) at a multiple of its speed
-        L.set_half("f16")
-        return torch.float32
     if precision == "fp16h":
         # fp16 storage, arithmetic and loss-scaled backward exactly as 'fp16', with the FEW roundings that dominate the logits error
         # removed where that is cheap (profiles/r05_precision_budget.txt): [hi | lo] pair activations on the stem's last three
@@ -49,16 +43,7 @@ def compute_dtype(precision):
         # with split weights (two products).  The tolerance mode of round 5.
         L.set_half("f16")
         return torch.float16
-    if precision == "fp16w":
-        # fp16 storage like 'fp16', but every FORWARD conv / GEMM runs the two-product form x . w_hi + x . w_lo (split weights, the
-        # activation read twice along K): the 14 weight roundings of the fp16 precision are removed, its 15 activation roundings stay
-        L.set_half("f16")
-        return torch.float16
-    raise ValueError("precision must be 'bf16', 'fp16', 'fp16h', 'fp16w', 'fp16x' or 'fp32' (got %r)" % (precision,))
-
-
-def is_x3(precision):
-    return precision == "fp16x"
+    raise ValueError("precision must be 'bf16', 'fp16', 'fp16h' or 'fp32' (got %r)" % (precision,))
 
 
 # Loss scale of the fp16-storage precision: the activation gradients that enter the conv trunk from the attention tail are
@@ -101,7 +86,7 @@ class FrameLayout(object):
     """Packed image list for one minibatch: image n <-> (frame t, sample b), frame-major.
     cts[t] = #videos with v_len >= t+1 (film_attn_pt_stem.py:201-208); v_lens sorted descending."""
 
-    def __init__(self, v_lens, num_frames, device, perm=None):
+    def __init__(self, v_lens, num_frames, device, perm=None, on_device=True):
         """perm (optional): sorted position s holds ORIGINAL sample perm[s] (the batch sort of
         eval/q_and_v_eval.py:113-116); img_of is then indexed by the original sample order, so the
         clip tensor itself never needs to be permuted."""
@@ -123,7 +108,7 @@ class FrameLayout(object):
         self.n_img = self.offsets[-1]
         n_img, nf = self.n_img, self.n_frames
         dev = torch.device(device)
-        if dev.type == "cuda" and B <= L.LAYOUT_MAX_BATCH and self.T <= 1024 and os.environ.get("VNQA_LAYOUT_ON_DEVICE", "1") != "0":
+        if dev.type == "cuda" and B <= L.LAYOUT_MAX_BATCH and self.T <= 1024 and on_device:
             # the tables are written ON THE DEVICE by one small kernel whose inputs (sorted lengths, sort permutation) travel as kernel
             # arguments (vnqa_frame_layout): no host-to-device copy on the stem's stream — with the clips arriving over PCIe a 4-KB
             # pinned-memory copy there queued behind the 3-ms clip transfer and held the stem's first kernel (profiles/r04_h2d.txt)
@@ -291,16 +276,6 @@ class FiLMTrunkBase(nn.Module):
     (GPU flavour: film_layer registered, conv1x1_layers a plain list — SURVEY §0.5/0.6);
     their forward() is never called: compute goes through videonavqa_amd.ops."""
 
-    def __call__(self, *args, **kwargs):
-        # precision='fp16x' (self.x3): convs / GEMMs on fp32 tensors inside this forward run as x3 products; the backward pass,
-        # which runs after this context has closed, keeps the exact-f32 matrix path
-        # (VNQA_X3_TRUNK_FWD=x2: two products per contraction, the layer inputs rounded once to fp16)
-        mode = os.environ.get("VNQA_X3_TRUNK_FWD", "x3") if self.__dict__.get("x3", False) else ("w2" if self.__dict__.get("w2", False) else None)
-        if mode is not None:
-            with K.f32_conv_mode(mode):
-                return super().__call__(*args, **kwargs)
-        return super().__call__(*args, **kwargs)
-
     def _build_trunk_head(self, num_input_channels, num_res_block_channels):
         """relu / conv_init / bn_init — registered first, as upstream (film_attn_pt_stem.py:39-42)."""
         self.relu = nn.ReLU(inplace=True)
@@ -363,9 +338,7 @@ class FiLMTrunkBase(nn.Module):
         cdt = self.compute_dtype
         if isinstance(v_input, NativeFeatures):
             lay = v_input.layout
-            # (precision 'fp16x' also takes ONE rounded 16-bit feature tensor — FrozenStem(out_half=True): conv_init reads it as a
-            # two-product conv, the trunk's own storage stays fp32)
-            assert v_input.data.dtype == cdt or (self.__dict__.get("x3", False) and L.is_half(v_input.data.dtype))
+            assert v_input.data.dtype == cdt
             # (precision 'fp16h': the stem's features may be a SPLIT tensor [hi | lo | hi] — three times the channels; conv_init recognises it)
             return v_input.data, lay, v_input.h, v_input.w
         assert v_input.is_cuda, "the HIP path needs device tensors (no CPU fallback)"
@@ -496,7 +469,7 @@ class FiLMTrunkBase(nn.Module):
         for k in range(self.num_res_blocks):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
             blocks += [c1.weight, c1.bias, c3.weight, c3.bias]
-        meta.c1_packs = self._frozen_c1_packs(h.dtype, L.round_up(C, 64))      # (the trunk's storage: fp32 in 'fp16x' whatever the features' type)
+        meta.c1_packs = self._frozen_c1_packs(h.dtype, L.round_up(C, 64))
         if self.__dict__.get("hyb", False):
             meta.hybrid = True
             packs32 = self._frozen_c1_packs(torch.float32, L.round_up(C, 64))
@@ -554,17 +527,14 @@ class FiLMTrunkBase(nn.Module):
             output (VNQA_EPI_FILM_RES, y = NULL: only the backward reads z).
         No autograd nodes, no statistics, no saved activations."""
         C = self.num_res_block_channels
-        # (precision 'fp16x' with fp16 features from the stem — FrozenStem(out_half=True): the trunk's storage stays fp32, conv_init
-        # reads the rounded features as a two-product x3 conv)
-        cdt = torch.float32 if (K.x3_mode() in ("x3", "x2") and L.is_half(x.dtype)) else x.dtype
+        cdt = x.dtype
         c_pad = L.round_up(C, 64)
         bn = self.bn_init
         scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + BN_EPS)
         shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
-        fdt = torch.float32 if cdt != x.dtype else K.fwd_pack_dtype(x)          # (fp32 packs in the two-product precision: the conv wrapper splits them)
         hyb = self.__dict__.get("hyb", False) and L.is_half(cdt)
         split = ops.is_split(x, self.conv_init.weight.shape[1])                  # precision 'fp16h': [hi | lo | hi] features, three products
-        wt0 = K.pack_conv_weight(self.conv_init.weight, torch.float32 if split else fdt, c_out_pad=c_pad,
+        wt0 = K.pack_conv_weight(self.conv_init.weight, torch.float32 if split else cdt, c_out_pad=c_pad,
                                  c_in_pad=x.shape[-1] // 3 if split else x.shape[-1])
         ps = split and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
         h = K.conv2d_igemm(x, wt0, bias=K.pad_vec(self.conv_init.bias, c_pad), relu=True, post_scale=K.pad_vec(scale, c_pad),
@@ -575,16 +545,15 @@ class FiLMTrunkBase(nn.Module):
         for k in range(self.num_res_blocks):
             c1, c3 = self.conv1x1_layers[k], self.film_pipeline[k]
             if hyb:          # the frozen 1x1 conv against split weights (two products), as the training graph runs it
-                with K.f32_conv_mode("w2"):
-                    res = K.conv2d_igemm(h, packs[k][0] if packs else K.pack_conv_weight(c1.weight, torch.float32, c_out_pad=c_pad, c_in_pad=c_pad),
-                                         bias=K.pad_vec(c1.bias, c_pad), relu=True)
+                res = K.conv2d_igemm(h, packs[k][0] if packs else K.pack_conv_weight(c1.weight, torch.float32, c_out_pad=c_pad, c_in_pad=c_pad),
+                                     bias=K.pad_vec(c1.bias, c_pad), relu=True, split_weights=True)
             else:
-                wt1 = packs[k][0] if (packs and fdt == cdt) else K.pack_conv_weight(c1.weight, fdt, c_out_pad=c_pad, c_in_pad=c_pad)
+                wt1 = packs[k][0] if packs else K.pack_conv_weight(c1.weight, cdt, c_out_pad=c_pad, c_in_pad=c_pad)
                 res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(c1.bias, c_pad), relu=True)
             film, col = film_specs[k]
             if not (film.dtype == torch.float32 and film.stride(1) == 1):
                 film = film.float().contiguous()
-            _, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(c3.weight, fdt, c_out_pad=c_pad, c_in_pad=c_pad),
+            _, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(c3.weight, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
                                            K.pad_vec(c3.bias, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res,
                                            tile=K.ps_fused_tile(res), keep_z=False)
         return h
@@ -604,11 +573,8 @@ class FiLMTrunkBase(nn.Module):
         cdt = self.compute_dtype
         for k in range(self.num_res_blocks):
             c1 = self.conv1x1_layers[k]
-            if self.__dict__.get("hyb", False) and L.is_half(x.dtype):      # precision 'fp16h': split weights on the frozen 1x1 conv
-                with K.f32_conv_mode("w2"):
-                    res = ops.conv(x, c1.weight, c1.bias, relu=True)
-            else:
-                res = ops.conv(x, c1.weight, c1.bias, relu=True)
+            # (precision 'fp16h': split weights on the frozen 1x1 conv, as the fused graphs run it)
+            res = ops.conv(x, c1.weight, c1.bias, relu=True, split_weights=self.__dict__.get("hyb", False) and L.is_half(x.dtype))
             z = ops.conv(res, self.film_pipeline[k].weight, self.film_pipeline[k].bias, relu=False)
             gamma, beta = film_fn(k)
             x = film_relu_residual(z, res, gamma, beta, cdt)
@@ -650,28 +616,14 @@ class FiLMTrunkBase(nn.Module):
                     t.record_stream(main)
         return out, join
 
-    def _fc_native_weight(self, weight, channels, h, w, c_pad, rows_pad):
-        """nn.Linear weight over a NCHW-flattened map [rows, channels*h*w] -> the column order of a
-        flattened padded-NHWC image [rows_pad, (h+2)*(w+2)*c_pad] (zero columns on halo/pad)."""
-        rows = weight.shape[0]
-        w4 = weight.view(rows, channels, h, w).permute(0, 2, 3, 1)
-        w4 = F.pad(w4, (0, c_pad - channels, 1, 1, 1, 1, 0, rows_pad - rows))
-        return w4.reshape(rows_pad, -1)
-
     def _gp_tail(self, x, lay, h, w):
         """relu(c1x1_tail) -> zero-padded stack over frames -> max over frames -> out_linear
         (film_global_pooling_pt_stem.py:228-238)."""
         gs = getattr(self, "_trunk_grad_scale", 1.0)      # fp16 storage: the tail conv and the trunk see scaled gradients
         t = ops.conv(x, self.c1x1_tail.weight, self.c1x1_tail.bias, relu=True, grad_scale=gs)     # [n_img,hp,wp,tail_pad]
         tail = self.c1x1_tail.out_channels
-        if t.is_cuda and os.environ.get("VNQA_GP_TAIL_TORCH", "0") != "1":
-            # HIP tail: segmented max over each sample's frames straight from the packed image list, written in the reference's
-            # NCHW-flattened order, then out_linear on the fp32 GEMM (no dense [T, B, ...] stack, no weight re-layout)
-            pooled, self._gp_argmax = ops.frame_max(t, lay, tail, gs, getattr(self, "_gp_route", None))
-            return ops.linear(pooled, self.out_linear.weight, self.out_linear.bias)
-        n_img, hp, wp, tp = t.shape
-        dense = torch.zeros(lay.n_frames, lay.B, hp, wp, tp, device=t.device, dtype=torch.float32)
-        dense = dense.index_put((lay.frame_of, lay.sample_of), ops.scale_grad(t.float(), gs))
-        pooled = dense.max(dim=0)[0].reshape(lay.B, -1)
-        w_nat = self._fc_native_weight(self.out_linear.weight, tail, h, w, tp, self.out_linear.out_features)
-        return pooled @ w_nat.t() + self.out_linear.bias
+        # HIP tail: segmented max over each sample's frames straight from the packed image list, written in the reference's
+        # NCHW-flattened order, then out_linear on the fp32 GEMM (no dense [T, B, ...] stack, no weight re-layout).
+        # (The dense torch form of this tail is test infrastructure: tests/torch_partners.py.)
+        pooled, self._gp_argmax = ops.frame_max(t, lay, tail, gs, getattr(self, "_gp_route", None))
+        return ops.linear(pooled, self.out_linear.weight, self.out_linear.bias)

@@ -21,9 +21,7 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
         self.hidden_size = hidden_size
         self.spatial_size = spatial_size
         self.compute_dtype = compute_dtype(precision)
-        self.x3 = precision == "fp16x"       # forward contractions as three fp16-half products (common.compute_dtype)
-        self.w2 = precision == "fp16w"       # fp16 storage, forward contractions with split weights (two products)
-        self.hyb = precision == "fp16h"      # fp16 storage; pair features, conv_init x3, 1x1 / fc with split weights (common.compute_dtype)
+        self.hyb = precision == "fp16h"      # fp16 storage; split features, conv_init as three products, 1x1 / fc with split weights (common.compute_dtype)
 
         self.embed = nn.Embedding(vocab_size, q_embedding_size, padding_idx=0)        # :34
         self._build_trunk_head(num_input_channels, num_res_block_channels)             # :38-41

@@ -161,9 +161,6 @@ class MACNetwork(nn.Module):
     def _knowledge(self, x):
         """conv -> ELU three times (mac.py:174-179,236); returns the dense interior [n_img*S, c_pad]."""
         for k in (0, 2, 4):
-            if os.environ.get("VNQA_MAC_ELU_FUSED", "1") == "0":
-                x = F.elu(ops.conv(x, self.conv[k].weight, self.conv[k].bias, relu=False))
-                continue
             x = ops.conv(x, self.conv[k].weight, self.conv[k].bias, relu=2)     # ELU in the conv epilogue; elu(0)=0 keeps the halo
         n_img, hp, wp, c_pad = x.shape
         return x[:, 1:-1, 1:-1, :].reshape(n_img * (hp - 2) * (wp - 2), c_pad), n_img, (hp - 2) * (wp - 2), c_pad
@@ -211,8 +208,7 @@ class MACNetwork(nn.Module):
         memory = m.mem_0.expand(n_img, dim)
         if masks is not None:
             control, memory = control * masks[0], memory * masks[1]
-        if (not self.self_attention and not self.memory_gate and os.environ.get("VNQA_MAC_CHAIN", "1") != "0"
-                and os.environ.get("VNQA_MAC_CORE_TORCH", "0") != "1" and os.environ.get("VNQA_MAC_CORE_CABI", "1") != "0"):
+        if not self.self_attention and not self.memory_gate and ops.MAC_CHAIN:
             # the reference's default configuration: all steps as ONE autograd node (ops.MacChainFn), the loop over steps in C++
             return ops.mac_chain(control.contiguous(), memory.contiguous(), pq_all, ctx, kd, pre,
                                  None if masks is None else masks[0], None if masks is None else masks[1], wc,
@@ -249,7 +245,7 @@ class MACNetwork(nn.Module):
         x, lay, h, w = self._prepare_input(images, v_lens)
         dev = x.device
         B = lay.B
-        if torch.is_grad_enabled() and x.is_cuda and os.environ.get("VNQA_MAC_SIDE_QUESTION", "1") != "0":
+        if torch.is_grad_enabled() and x.is_cuda:
             # the question side (embedding, bidirectional LSTM = 24 dependent launches, projections) has no input from the conv
             # stack: it runs on its own high-priority stream next to the three convs, and autograd runs its backward there too,
             # next to the convs' backward — both off the model's dependent chain

@@ -56,5 +56,5 @@ class ObjDetectCNN(nn.Module):
                 "the MI355X path implements ObjDetectCNN as the FROZEN stem (eval mode, "
                 "pretrained_features=True; eval/utils.py:43-50); detector training is out of scope")
         if self._plan is None:
-            self._plan = FrozenStem(None, self, {"fp16x": "fp32", "fp16w": "fp16", "fp16h": "fp16"}.get(self.precision, self.precision))
+            self._plan = FrozenStem(None, self, "fp16" if self.precision == "fp16h" else self.precision)
         return self._plan.objdet_nchw(inputs)

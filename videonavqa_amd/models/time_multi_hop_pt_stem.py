@@ -1,6 +1,4 @@
 """TimeMultiHopFiLMPretrainedStem — drop-in for models/time_multi_hop_pt_stem.py."""
-import os
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -8,7 +6,7 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from .. import ops
-from .common import FiLMTrunkBase, compute_dtype, grad_scale_of, repeated_question_lstm
+from .common import FiLMTrunkBase, compute_dtype, grad_scale_of
 
 
 class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
@@ -24,9 +22,7 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
         self.hidden_size = hidden_size
         self.spatial_size = spatial_size
         self.compute_dtype = compute_dtype(precision)
-        self.x3 = precision == "fp16x"       # forward contractions as three fp16-half products (common.compute_dtype)
-        self.w2 = precision == "fp16w"       # fp16 storage, forward contractions with split weights (two products)
-        self.hyb = precision == "fp16h"      # fp16 storage; pair features, conv_init x3, 1x1 / fc with split weights (common.compute_dtype)
+        self.hyb = precision == "fp16h"      # fp16 storage; split features, conv_init as three products, 1x1 / fc with split weights (common.compute_dtype)
 
         self.embed = nn.Embedding(vocab_size, q_embedding_size, padding_idx=0)        # :30
         self._build_trunk_head(num_input_channels, num_res_block_channels)             # :32-36
@@ -76,26 +72,6 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
         return list(ops.multi_hop_generator(hs.view(B * S, H), (last_rows, base_row, qlen), Lmax, self.num_res_blocks,
                                             self.encoder_norm, self.fc_hidden_attn, self.fc_attn_out, self.decoder_norm))
 
-    def _generator_torch(self, q_input, q_lens, lay):
-        """the same generator op by op on stock torch (CPU / VNQA_HOP_TORCH=1 cross-check)"""
-        B, Fn, Hq = lay.B, lay.n_frames, self.hidden_size
-        emb = self.embed(q_input)
-        h0, c0 = self._question_state(B, Hq, q_lens, q_input.device)
-        h_last, states, (hn, cn) = repeated_question_lstm(self.q_encoder, emb, q_lens, Fn, h0, c0,
-                                                          want_states=True, wgrad_dtype=self._lstm_wgrad_dtype())
-        self._store_question_state(hn, cn, q_lens)
-        enc = self.encoder_norm(h_last)                                   # [B,F,H]   :148
-        # per-image context, reset at every frame (:157-158); the hop chain runs over blocks
-        hv = enc[lay.sample_of, lay.frame_of]                             # [n_img,H]
-        st = states[lay.sample_of, lay.frame_of]                          # [n_img,Lmax,H] zero past q_len
-        film_per_block = []
-        for _ in range(self.num_res_blocks):
-            prod = hv.unsqueeze(1) * st                                   # :170
-            coefs = torch.softmax(self.fc_hidden_attn(prod), dim=1)       # unmasked over words :171-172
-            hv = torch.bmm(coefs.permute(0, 2, 1), prod).squeeze(1)       # :175-176
-            film_per_block.append(self.decoder_norm(self.fc_attn_out(hv)))  # :179,184
-        return film_per_block
-
     def forward(self, v_input, q_input, v_lens, q_lens):
         """time_multi_hop_pt_stem.py:191-250 with compute_film_encoding (:124-158) and
         decode_to_film_values (:165-184) evaluated for all frames at once."""
@@ -105,7 +81,7 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
         B, Fn, Hq = lay.B, lay.n_frames, self.hidden_size
         C = self.num_res_block_channels
         fused = self._use_fused_trunk()
-        gen = self._generator_hip if (x.is_cuda and os.environ.get("VNQA_HOP_TORCH", "0") != "1") else self._generator_torch
+        gen = self._generator_hip      # (its op-by-op torch form is test infrastructure: tests/torch_partners.py)
         join = None
         if fused:       # the generator (question LSTM chain + hop attention) on the side stream, joined after conv_init + BatchNorm
             film_per_block, join = self._fork_generator(lambda: tuple(gen(q_input, q_lens, lay)), n_img=lay.n_img)

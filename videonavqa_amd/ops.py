@@ -4,31 +4,11 @@ Activations are padded-NHWC tensors [N, H+2, W+2, Cpad] in the compute dtype (bf
 a ZERO halo; every op here preserves that invariant (gradients included), because the conv
 kernels get their zero padding — and wgrad its summation domain — from it.
 """
-import contextlib
-import os
 
 import torch
 
 from . import _lib as L
 from . import kernels as K
-
-
-# VNQA_X3_BWD: the backward arithmetic of precision 'fp16x' — "x1g" (default) ONE product per contraction (operands rounded to fp16
-# once, the gradient operand scaled first: the fp16 precision's backward on fp32-stored tensors), "x3g" three.  North star's tolerance
-# is a FORWARD (logits) tolerance; measured flat-gradient error against exact fp32: 0.0056 either way (bench.py parity block)
-_X3_BWD_MODE = os.environ.get("VNQA_X3_BWD", "x1g")
-assert _X3_BWD_MODE in ("x3g", "x1g")
-
-
-def _x3_forward(ctx):
-    """precision='fp16x': remember that this node's forward ran its contractions as x3 products (kernels.f32_conv_mode) ..."""
-    ctx.x3 = K.x3_mode() in ("x3", "x2")
-
-
-def _x3_backward(ctx):
-    """... so that its backward — which autograd runs after the forward's context has closed, on its own thread — runs them as x3
-    products too, with the gradient operands scaled into fp16's range ('x3g')."""
-    return K.f32_conv_mode(_X3_BWD_MODE) if getattr(ctx, "x3", False) else contextlib.nullcontext()
 
 
 class GradSink(object):
@@ -82,14 +62,6 @@ def _ret(sink, value):
     return None
 
 
-def _ps_plain_tile(x, k, c_out_pad):
-    """The patch-stationary kernel for a plain 3x3 conv (or its dgrad) on 14 / 28 wide maps with 256-multiple output channels
-    (MACNetwork's conv stack: 219-224 us against 257 on the 256 x 256 igemm tile), else the library's own choice."""
-    if os.environ.get("VNQA_PLAIN_PS", "0") != "1":
-        return L.TILE_AUTO
-    return K.ps_fused_tile(x) if k == 3 and c_out_pad % 256 == 0 else L.TILE_AUTO
-
-
 class ConvFn(torch.autograd.Function):
     """y = act(conv2d(x, weight) + bias), 3x3 pad 1 or 1x1; weight/bias are the reference-layout
     fp32 parameters (OIHW).  relu: False / True, or 2 = ELU in the conv's epilogue (MACNetwork, models/mac.py:174-179;
@@ -97,8 +69,7 @@ class ConvFn(torch.autograd.Function):
     split-K kernel.  Replaces nn.Conv2d at models/film_attn_pt_stem.py:211,219,224."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, mask_in_backward=True, grad_scale=1.0):
-        _x3_forward(ctx)
+    def forward(ctx, x, weight, bias, relu, mask_in_backward=True, grad_scale=1.0, split_weights=False):
         ctx.grad_scale = float(grad_scale)      # d y arrives multiplied by this (fp16 loss scale): dW, db are divided by it
         c_out, c_in, k, _ = weight.shape
         cdt = x.dtype
@@ -111,9 +82,11 @@ class ConvFn(torch.autograd.Function):
             wt = K.pack_conv_weight(weight, torch.float32, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
             y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu, split_in=True)
         else:
-            wt = K.pack_conv_weight(weight, K.fwd_pack_dtype(x), c_out_pad=c_out_pad, c_in_pad=c_in_pad)
-            y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu,
-                               tile=L.TILE_AUTO if ctx.elu else _ps_plain_tile(x, k, c_out_pad))   # (the ELU epilogue: igemm tiles only)
+            sw = bool(split_weights) and L.is_half(x.dtype)
+            wt = K.pack_conv_weight(weight, torch.float32 if sw else x.dtype, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
+            y = K.conv2d_igemm(x, wt, bias=K.pad_vec(bias, c_out_pad), relu=relu, split_weights=sw,
+                               tile=L.TILE_AUTO)      # (plain convs stay on the igemm tiles: the patch-stationary kernel is faster
+                                                      # alone, 219 vs 257 us, and -1.5 % end to end beside MACNetwork's masked stem)
         ctx.relu = bool(relu) and not ctx.elu and mask_in_backward   # False: the consumer's backward applies the ReLU mask
         ctx.dims = (c_out, c_in, k, c_out_pad, c_in_pad)
         ctx.save_for_backward(x, weight, y if (ctx.relu or ctx.elu) else None)
@@ -121,8 +94,7 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        with _x3_backward(ctx):
-            return ConvFn._backward(ctx, dy)
+        return ConvFn._backward(ctx, dy)
 
     @staticmethod
     def _backward(ctx, dy):
@@ -136,13 +108,13 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             inv = 1.0 / ctx.grad_scale
-            dwt, dbias = K.conv2d_wgrad(x, dy, k * k, defer_scale=True, x_segs=ctx.x_segs)
+            dwt, dbias = K.conv2d_wgrad(x, dy, k * k, x_segs=ctx.x_segs)
             dw = K.unpack_conv_wgrad(dwt, c_out, c_in, alpha=inv)
             db = dbias[:c_out].clone() if inv == 1.0 else dbias[:c_out] * inv
         if ctx.needs_input_grad[0]:
             wt_d = K.pack_conv_weight(weight, dy.dtype, transpose_flip=True, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
-            dx = K.conv2d_igemm(dy, wt_d, tile=_ps_plain_tile(dy, k, c_in_pad))
-        return dx, dw, db, None, None, None
+            dx = K.conv2d_igemm(dy, wt_d)
+        return dx, dw, db, None, None, None, None
 
 
 class LinearNTFn(torch.autograd.Function):
@@ -152,7 +124,6 @@ class LinearNTFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias):
-        _x3_forward(ctx)
         wc = w.to(x.dtype).contiguous()
         out = K.gemm_nt(x.contiguous(), wc, bias=bias.float().contiguous())
         ctx.save_for_backward(x, wc)
@@ -160,8 +131,7 @@ class LinearNTFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        with _x3_backward(ctx):
-            return LinearNTFn._backward(ctx, dout)
+        return LinearNTFn._backward(ctx, dout)
 
     @staticmethod
     def _backward(ctx, dout):
@@ -177,8 +147,9 @@ class LinearNTFn(torch.autograd.Function):
         return dx, dw, db
 
 
-def conv(x, weight, bias, relu=False, mask_in_backward=True, grad_scale=1.0):
-    return ConvFn.apply(x, weight, bias, relu, mask_in_backward, grad_scale)
+def conv(x, weight, bias, relu=False, mask_in_backward=True, grad_scale=1.0, split_weights=False):
+    """split_weights (precision 'fp16h'): the forward as two products against [w_hi | w_lo]."""
+    return ConvFn.apply(x, weight, bias, relu, mask_in_backward, grad_scale, split_weights)
 
 
 class ScaleGradFn(torch.autograd.Function):
@@ -267,12 +238,8 @@ class FilmTrunkHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, meta):
-        _x3_forward(ctx)
         lay, C = meta.layout, meta.channels
-        # (precision 'fp16x' fed fp16 features — FrozenStem(out_half=True): fp32 storage from here on, conv_init as the two-product
-        # x3 conv of a rounded input)
-        half_in = K.x3_mode() in ("x3", "x2") and L.is_half(x.dtype)
-        cdt = torch.float32 if half_in else x.dtype
+        cdt = x.dtype
         c_pad = L.round_up(C, 64)
         # precision 'fp16h': split features [hi | lo | hi] from the stem — conv_init as THREE products (a plain conv over 3 C channels
         # against [w_hi | w_hi | w_lo]): the unrounded activation against unrounded weights; the layer's weight rounding alone is
@@ -280,11 +247,11 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         split = is_split(x, conv_w.shape[1])
         ctx.x_segs = 3 if split else 1
         c_in_pad = x.shape[-1] // 3 if split else x.shape[-1]
-        wt0 = K.pack_conv_weight(conv_w, torch.float32 if (half_in or split) else K.fwd_pack_dtype(x), c_out_pad=c_pad, c_in_pad=c_in_pad)
+        wt0 = K.pack_conv_weight(conv_w, torch.float32 if split else x.dtype, c_out_pad=c_pad, c_in_pad=c_in_pad)
         b0 = K.pad_vec(conv_b, c_pad)
         fused = None
         ps = split and HEAD_CONV_PS and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
-        if L.is_half(cdt) and not K.w2_active(x) and not ps:     # fp32 (parity) and the two-product precision keep the two-pass statistics kernel
+        if L.is_half(cdt) and not ps:     # (the fp32 parity precision keeps the exact two-pass statistics kernel)
             fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts), split_in=split)
         if fused is None:
             r = K.conv2d_igemm(x, wt0, bias=b0, relu=True, split_in=split, tile=L.TILE_PS_224x256 if ps else L.TILE_AUTO)
@@ -303,8 +270,7 @@ class FilmTrunkHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dm, _dv):
-        with _x3_backward(ctx):
-            return FilmTrunkHeadFn._backward(ctx, dout, _dm, _dv)
+        return FilmTrunkHeadFn._backward(ctx, dout, _dm, _dv)
 
     @staticmethod
     def _backward(ctx, dout, _dm, _dv):
@@ -323,7 +289,7 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         exact = c_pad == C
         dbn_w = _ret(s_bw if exact else None, K.colsum(s2, out=_into(s_bw) if exact else None)[:C])
         dbn_b = _ret(s_bb if exact else None, K.colsum(s1, out=_into(s_bb) if exact else None)[:C])
-        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None, defer_scale=True, x_segs=ctx.x_segs)
+        dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None, x_segs=ctx.x_segs)
         dconv_w = _ret(s_cw, K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw), alpha=inv))
         dconv_b = _ret(s_cb if exact else None, dbias0[:C])
         if scaled:
@@ -351,7 +317,6 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, meta, *tensors):
-        _x3_forward(ctx)
         C, blocks = meta.channels, meta.blocks
         films = tensors[:meta.n_film]
         cdt = h.dtype
@@ -359,19 +324,17 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
         saved = []
         for k in range(blocks):
             w1, b1, w3, b3 = tensors[meta.n_film + 4 * k: meta.n_film + 4 * k + 4]
-            fdt = K.fwd_pack_dtype(h)
             if getattr(meta, "hybrid", False) and L.is_half(cdt):
                 # precision 'fp16h': the frozen 1x1 conv as two products against [w_hi | w_lo] (its weight rounding: 0.04e-6 of the
                 # squared logits error for 29 GFLOP), the 3x3 conv below stays ONE product with its fused FiLM epilogue (1e-10)
                 wt1 = meta.c1_packs32[k] if meta.c1_packs32 else K.pack_conv_weight(w1, torch.float32, c_out_pad=c_pad, c_in_pad=c_pad)
-                with K.f32_conv_mode("w2"):
-                    res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(b1, c_pad), relu=True)
+                res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(b1, c_pad), relu=True, split_weights=True)
             else:
-                wt1 = meta.c1_packs[k][0] if (meta.c1_packs and fdt == cdt) else K.pack_conv_weight(w1, fdt, c_out_pad=c_pad, c_in_pad=c_pad)
+                wt1 = meta.c1_packs[k][0] if meta.c1_packs else K.pack_conv_weight(w1, cdt, c_out_pad=c_pad, c_in_pad=c_pad)
                 res = K.conv2d_igemm(h, wt1, bias=K.pad_vec(b1, c_pad), relu=True)
             fi, col = meta.film_map[k]
             film = films[fi]
-            z, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(w3, fdt, c_out_pad=c_pad, c_in_pad=c_pad),
+            z, h = K.conv2d_igemm_film_res(res, K.pack_conv_weight(w3, cdt, c_out_pad=c_pad, c_in_pad=c_pad),
                                            K.pad_vec(b3, c_pad), film[:, col:col + C], film[:, col + C:col + 2 * C], C, res,
                                            tile=K.ps_fused_tile(res))
             saved += [res, z]
@@ -389,8 +352,7 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, dz_tail=None, dres_tail=None):
-        with _x3_backward(ctx):
-            return FilmTrunkBlocksFn._backward(ctx, dout, dz_tail, dres_tail)
+        return FilmTrunkBlocksFn._backward(ctx, dout, dz_tail, dres_tail)
 
     @staticmethod
     def _backward(ctx, dout, dz_tail=None, dres_tail=None):
@@ -426,15 +388,14 @@ class FilmTrunkBlocksFn(torch.autograd.Function):
                 dz = K.film_relu_res_bwd_ld(dout, z, film[:, col:col + C], film[:, col + C:col + 2 * C], C,
                                             dfilm[:, col:col + C], dfilm[:, col + C:col + 2 * C])
             sw, sb = ctx.sinks[2 * k], sinks[2 * k + 1]
-            with K.shared_grad_operand(dz):         # (fp16x: dz is the operand of the weight gradient AND of the data gradient)
-                dwt, dbias = K.conv2d_wgrad(res, dz, 9, dbias_out=_into(sb), defer_scale=True)
-                grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw), alpha=inv))
-                direct_b = sb is not None and dbias.data_ptr() == sb.view.data_ptr()      # (only without channel padding)
-                grads_blocks[4 * k + 3] = _ret(sb if direct_b else None, dbias[:C] * inv if scaled else dbias[:C])
-                # (dgrad(dz) + dout) * [res > 0]: the 3x3 conv's dgrad with the residual join and the 1x1 conv's ReLU mask in its
-                # epilogue (VNQA_EPI_ADD_MASK; bit-identical to conv2d_igemm followed by relu_bwd(dres, res, dout))
-                gsum = K.conv2d_igemm_add_mask(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad),
-                                               dout, res, tile=K.ps_fused_tile(dz))
+            dwt, dbias = K.conv2d_wgrad(res, dz, 9, dbias_out=_into(sb))
+            grads_blocks[4 * k + 2] = _ret(sw, K.unpack_conv_wgrad(dwt, C, C, out=_into(sw), alpha=inv))
+            direct_b = sb is not None and dbias.data_ptr() == sb.view.data_ptr()      # (only without channel padding)
+            grads_blocks[4 * k + 3] = _ret(sb if direct_b else None, dbias[:C] * inv if scaled else dbias[:C])
+            # (dgrad(dz) + dout) * [res > 0]: the 3x3 conv's dgrad with the residual join and the 1x1 conv's ReLU mask in its
+            # epilogue (VNQA_EPI_ADD_MASK; bit-identical to conv2d_igemm followed by relu_bwd(dres, res, dout))
+            gsum = K.conv2d_igemm_add_mask(dz, K.pack_conv_weight(w3, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad),
+                                           dout, res, tile=K.ps_fused_tile(dz))
             # (the 1x1 convs are frozen upstream — never in parameters() — so they get no weight gradient)
             wt1d = meta.c1_packs[k][1] if meta.c1_packs else \
                 K.pack_conv_weight(w1, cdt, transpose_flip=True, c_out_pad=c_pad, c_in_pad=c_pad)
@@ -471,8 +432,8 @@ class FilmTailFn(torch.autograd.Function):
 
 def film_trunk_blocks(h, meta, films, block_tensors):
     """FilmTrunkBlocksFn, with the last block's FiLM backward as its own node (FilmTailFn) when the trunk has ONE block and one FiLM
-    matrix — the headline configuration (VNQA_SPLIT_FILM_TAIL=0: one node, as before)."""
-    if meta.blocks == 1 and len(films) == 1 and os.environ.get("VNQA_SPLIT_FILM_TAIL", "1") != "0":
+    matrix — the headline configuration (the generator's BPTT then starts as soon as d gamma / d beta exist)."""
+    if meta.blocks == 1 and len(films) == 1:
         meta.split_tail = True
         hc, z, res = FilmTrunkBlocksFn.apply(h, meta, *films, *block_tensors)
         return FilmTailFn.apply(z, res, hc, films[0], meta.film_map[0][1], meta.channels, meta.grad_scale)
@@ -957,21 +918,19 @@ class FcNativeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, C, h, w, rows_pad, grad_scale=1.0, split_weights=False):
-        _x3_forward(ctx)
         ctx.grad_scale = float(grad_scale)      # d(out) arrives multiplied by this (fp16 loss scale): dW, db are divided by it
         rows = weight.shape[0]
         c_pad = x.shape[1] // ((h + 2) * (w + 2))
         need_dx = ctx.needs_input_grad[0]
         # dX from the forward operand alone (vnqa_fc_dx) where its shapes allow: no transposed weight copy per step
-        ctx.direct_dx = need_dx and K.fc_dx_supported(x.shape[0], rows_pad, x.shape[1], x.dtype) and \
-            os.environ.get("VNQA_FC_DX", "1") != "0"
+        ctx.direct_dx = need_dx and K.fc_dx_supported(x.shape[0], rows_pad, x.shape[1], x.dtype)
         nat, nat_t = K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, x.dtype, want_t=need_dx and not ctx.direct_dx)
         bias_p = K.pad_vec(bias, rows_pad)
-        if K.w2_active(x) or (split_weights and L.is_half(x.dtype)):
-            # two-product forward: the fp32 operand (split into [hi | lo] by the GEMM wrapper); `nat` serves the backward.
-            # (precision 'fp16h' asks for it by argument: this layer's weight rounding is 0.03e-6 of the squared logits error for 7 GFLOP)
-            with K.f32_conv_mode("w2"):
-                out = K.gemm_nt(x.contiguous(), K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, torch.float32, want_t=False)[0], bias=bias_p)
+        if split_weights and L.is_half(x.dtype):
+            # two-product forward (precision 'fp16h': this layer's weight rounding is 0.03e-6 of the squared logits error for 7 GFLOP):
+            # the fp32 operand, split into [hi | lo] by the GEMM wrapper; `nat` serves the backward
+            out = K.gemm_nt(x.contiguous(), K.pack_fc_weight(weight, C, h, w, c_pad, rows_pad, torch.float32, want_t=False)[0], bias=bias_p,
+                            split_weights=True)
         else:
             out = K.gemm_nt(x.contiguous(), nat, bias=bias_p)
         ctx.save_for_backward(x, nat if ctx.direct_dx else nat_t)
@@ -983,8 +942,7 @@ class FcNativeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        with _x3_backward(ctx):
-            return FcNativeFn._backward(ctx, dout)
+        return FcNativeFn._backward(ctx, dout)
 
     @staticmethod
     def _backward(ctx, dout):
@@ -996,7 +954,7 @@ class FcNativeFn(torch.autograd.Function):
             dx = K.fc_dx(dout, nat_t) if ctx.direct_dx else K.gemm_nt(dout, nat_t)     # (direct: the saved tensor is `nat`)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = _ret(ctx.sink_w, K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous(), defer_scale=True), rows, C, h, w, c_pad, out=_into(ctx.sink_w),
+            dw = _ret(ctx.sink_w, K.unpack_fc_wgrad(K.gemm_tn(dout, x.contiguous()), rows, C, h, w, c_pad, out=_into(ctx.sink_w),
                                                     alpha=1.0 / ctx.grad_scale))
         db = None
         if ctx.needs_input_grad[2]:
@@ -1223,110 +1181,16 @@ def mac_chain(control, memory, pq_all, ctxw, know, pre, mask_c, mask_m, *weights
     return MacChainFn.apply(control, memory, pq_all, ctxw, know, pre, mask_c, mask_m, *weights_and_dims)
 
 
-class MacCoreTorchFn(torch.autograd.Function):
-    """(VNQA_MAC_CORE_TORCH=1: the node issued op by op from Python on torch / rocBLAS GEMMs; the A/B partner of MacCoreFn.)
-    One MAC reasoning step (ControlUnit, ReadUnit and WriteUnit.concat of models/mac.py:28-42,53-62,82-85) for all
-    packed images as ONE autograd node: inside, plain torch GEMMs and the fused attention kernels run without graph
-    recording, and the backward is written out by hand.  Motivation: the MAC training step was bound by the launch
-    thread (autograd bookkeeping of ~75 small ops per step and direction), not by the GPU.
-
-      cq      = control Wc^T + pq                       (pq = position_aware_i(question) Wp^T + b, hoisted by the caller)
-      control'= pool(ctx, cq * w_ca, b_ca) [* mask]     (attention over the question words)
-      mem     = memory Wm^T + bm ;  v = control' * w_ra ;  u = mem * (v W1)
-      read    = pool(know, pre; u, v, b_ra)             (re-associated ReadUnit, see models/mac.py)
-      concat  = read Wr^T + memory Wmm^T + bw
-    Returns (control', concat); self-attention / memory gate / the memory dropout mask stay with the caller."""
-
-    @staticmethod
-    def forward(ctx_, control, memory, pq, ctxw, know, pre, mask_c, wc, w_ca, b_ca, wm, bm, w1, w_ra, b_ra, wr, wmm, bw,
-                state, Lq, S):
-        N, d = control.shape
-        cq = torch.addmm(pq, control, wc.t())
-        qv = (cq * w_ca).contiguous()
-        p_c, cnew = K.mac_read_fwd(ctxw, None, qv, None, b_ca.detach().float().contiguous(), N, Lq, d)
-        if mask_c is not None:
-            cnew = cnew * mask_c
-        mem = torch.addmm(bm, memory, wm.t())
-        v = (cnew * w_ra).contiguous()
-        t = v @ w1
-        u = (mem * t).contiguous()
-        p_r, read = K.mac_read_fwd(know, pre, u, v, b_ra.detach().float().contiguous(), N, S, d)
-        concat = torch.addmm(bw, read, wr.t()).addmm_(memory, wmm.t())
-        ctx_.save_for_backward(control, memory, ctxw, know, pre, mask_c, wc, w_ca, wm, w1, w_ra, wr, wmm,
-                               cq, qv, p_c, cnew, mem, v, t, u, p_r, read)
-        ctx_.state, ctx_.dims, ctx_.index = state, (N, d, Lq, S), state.n_calls
-        state.n_calls += 1
-        return cnew, concat
-
-    @staticmethod
-    def backward(ctx_, d_cnew, d_concat):
-        (control, memory, ctxw, know, pre, mask_c, wc, w_ca, wm, w1, w_ra, wr, wmm,
-         cq, qv, p_c, cnew, mem, v, t, u, p_r, read) = ctx_.saved_tensors
-        N, d, Lq, S = ctx_.dims
-        st = ctx_.state
-        d_concat = d_concat.contiguous()
-        # Parameter gradients are ACCUMULATED in the shared state (GEMM with beta = 1 / GEMV against a ones vector, in
-        # place) and handed to autograd once, by the first step's node: 12 steps x 12 parameters would otherwise be
-        # ~150 AccumulateGrad adds and ~60 reductions of their own.
-        G = st.grads
-        if not G:
-            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=control.device)
-            # wca / wra (gradients of the two attention weight vectors) are sums over images AND steps of an elementwise
-            # product: accumulated per image with one addcmul_ per step and reduced over the images once, by the last node;
-            # bca / bra (sums of the score gradients) come from the stacked score gradients the same node already holds
-            G.update(wc=z(d, d), wca=z(N, d), wm=z(d, d), bm=z(d), w1=z(d, d), wra=z(N, d), wr=z(d, d),
-                     wmm=z(d, d), bw=z(d), ones=torch.ones(N, dtype=torch.float32, device=control.device))
-        ones = G["ones"]
-        # WriteUnit.concat
-        d_read = (d_concat @ wr).contiguous()
-        d_memory = d_concat @ wmm
-        G["wr"].addmm_(d_concat.t(), read)
-        G["wmm"].addmm_(d_concat.t(), memory)
-        G["bw"].addmv_(d_concat.t(), ones)
-        # ReadUnit attention
-        ds_r, du, dv = K.mac_read_bwd(know, pre, p_r, d_read, N, S, d)
-        st.read.append((ds_r, p_r, u, v, d_read))
-        d_mem, d_t = du * t, du * mem
-        dv = dv.addmm_(d_t, w1.t())
-        G["w1"].addmm_(v.t(), d_t)
-        G["wra"].addcmul_(dv, cnew)
-        d_c = dv * w_ra if d_cnew is None else torch.addcmul(d_cnew, dv, w_ra)
-        d_memory = d_memory.addmm_(d_mem, wm)
-        G["wm"].addmm_(d_mem.t(), memory)
-        G["bm"].addmv_(d_mem.t(), ones)
-        if mask_c is not None:
-            d_c = d_c * mask_c
-        d_c = d_c.contiguous()
-        # ControlUnit attention
-        ds_c, dqv, _ = K.mac_read_bwd(ctxw, None, p_c, d_c, N, Lq, d)
-        st.ctrl.append((ds_c, p_c, qv, d_c))
-        d_cq = dqv * w_ca
-        G["wca"].addcmul_(dqv, cq)
-        d_control = d_cq @ wc
-        G["wc"].addmm_(d_cq.t(), control)
-        d_ctxw = d_know = d_pre = None
-        g = [None] * 11
-        if ctx_.index == 0:      # runs last: every later step depends on this one's outputs
-            f = [torch.stack(x) for x in zip(*st.read)]
-            d_know, d_pre = K.mac_read_accum(f[0], f[1], f[2], f[3], f[4], N, S, d, know.shape[-1], know.dtype)
-            c = [torch.stack(x) for x in zip(*st.ctrl)]
-            d_ctxw, _ = K.mac_read_accum(c[0], c[1], c[2], None, c[3], N, Lq, d, ctxw.shape[-1], ctxw.dtype)
-            g = [G["wc"], G["wca"].sum(0, keepdim=True), c[0].sum().view(1), G["wm"], G["bm"], G["w1"],
-                 G["wra"].sum(0, keepdim=True), f[0].sum().view(1), G["wr"], G["wmm"], G["bw"]]
-            st.read, st.ctrl, st.grads = [], [], {}
-        return (d_control, d_memory, d_cq, d_ctxw, d_know, d_pre, None, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7],
-                g[8], g[9], g[10], None, None, None)
+# MAC_CHAIN: all reasoning steps as ONE autograd node (MacChainFn) where the model's options allow it; False = one node per step
+# (MacCoreFn) — the cross-check tests/test_gpu_mac.py runs (they are bit-identical)
+MAC_CHAIN = True
 
 
 def mac_core(control, memory, pq_all, step, *rest):
-    """One reasoning step; `pq_all` [steps, N, d] holds every step's position-aware term and `step` selects this one.
-    Default: the C-ABI node (MacCoreFn: one call per direction, exact-f32 MFMA products with the elementwise products in their
-    epilogues, parameter gradients deferred to one vnqa_mac_core_wgrad call).  VNQA_MAC_CORE_TORCH=1 selects the op-by-op node on
-    torch / rocBLAS GEMMs (MacCoreTorchFn) for the A/B (`tools/ab_mac.sh`); tests/test_gpu_mac.py runs both against the
-    reference goldens."""
-    import os
-    if os.environ.get("VNQA_MAC_CORE_TORCH", "0") == "1" or os.environ.get("VNQA_MAC_CORE_CABI", "1") == "0":
-        return MacCoreTorchFn.apply(control, memory, pq_all[step], *rest)
+    """One reasoning step; `pq_all` [steps, N, d] holds every step's position-aware term and `step` selects this one: the C-ABI
+    node (MacCoreFn: one call per direction, exact-f32 MFMA products with the elementwise products in their epilogues, parameter
+    gradients deferred to one vnqa_mac_core_wgrad call).  (The op-by-op torch / rocBLAS form of the step is test infrastructure:
+    tests/torch_partners.py.)"""
     return MacCoreFn.apply(control, memory, pq_all, *rest, step)
 
 

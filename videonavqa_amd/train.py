@@ -235,7 +235,7 @@ def allreduce_gradients(flat_grad, world_size, loss_reduction="sum"):
 
 class Trainer(object):
     def __init__(self, model, stem, lr=1e-4, clip=1.0, loss_reduction="sum", class_weights=None,
-                 world_size=1, rank=0, feature_channels=512, collectives=None):
+                 world_size=1, rank=0, feature_channels=512, collectives=None, feature_slots=2):
         self.model, self.stem = model, stem
         self.lr, self.clip = lr, clip
         self.world_size, self.rank = world_size, rank
@@ -252,7 +252,7 @@ class Trainer(object):
         self.reducer = OverlappedGradReducer(self.fp, world_size, loss_reduction, active=collectives)
         self.stem_device = self.fp.flat.device
         self.copy_stream = None
-        prio = int(os.environ.get("VNQA_STEM_PRIO", "0"))
+        prio = 0          # (raising the STEM's priority instead of the trunk's costs 9 %: DESIGN 5)
         # CU partition: a model whose trunk is a long dependent chain of SMALL kernels (MACNetwork: ~1 000 launches per step)
         # cannot overlap with full-chip stem kernels that own every CU's LDS — each small kernel would wait for stem workgroups to
         # retire.  Such a model asks for `stem_reserve_cus` CUs the stem stream never touches (its own attribute; env
@@ -284,17 +284,16 @@ class Trainer(object):
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self._prefetched = None          # (key, NativeFeatures, v_sorted, perm, done_event)
         # Feature slots: the stem of minibatch i+1 writes slot (i+1) % n and may start as soon as the trunk pass that last read that
-        # slot is done.  With two slots that is the trunk of minibatch i-1 (stem and trunk start in lockstep); with
-        # VNQA_FEATURE_SLOTS=3 the stem runs up to two minibatches ahead and never waits for the trunk (one more 73 MB buffer).
-        # Measured equal (931 vs 934 clips/s, three interleaved rounds) once the question chain runs on its side stream: the step
+        # slot is done.  With two slots that is the trunk of minibatch i-1 (stem and trunk start in lockstep); a third slot
+        # (`feature_slots=3`: the stem runs up to two minibatches ahead and never waits for the trunk, one more feature buffer)
+        # measured equal (931 vs 934 clips/s, three interleaved rounds) once the question chain runs on its side stream: the step
         # is then bound by summed kernel work, not by who waits for whom — so the default stays 2.
-        self._n_slots = max(2, int(os.environ.get("VNQA_FEATURE_SLOTS", "2")))
+        self._n_slots = max(2, int(feature_slots))
         self._slot = 0
         self._trunk_done = [None] * self._n_slots  # event per slot: last trunk pass that read that slot
         self._inputs_ready = None        # recorded on the CALLER's stream at step() entry: clips / labels produced so far
         # fp16 storage: dynamic loss scale (VNQA_FP16_LOSS_SCALE=<value> pins it: no adjustment, the round-2/3 behaviour)
-        # Every precision gets the device-side skip of a non-finite step and its counter ('fp16x' splits fp32
-        # activations into fp16 halves — |v| > 65504 becomes inf — and had no protection); only fp16 STORAGE has a loss scale.
+        # Every precision gets the device-side skip of a non-finite step and its counter; only fp16 STORAGE has a loss scale.
         self.loss_scaler = None
         if self.fp.flat.is_cuda:
             pinned = os.environ.get("VNQA_FP16_LOSS_SCALE")
