@@ -131,9 +131,14 @@ def test_full_size_training_steps_are_sane(name):
 # rounding moves that feature by the whole difference: stated looser, 3e-2.
 # Round 4: with the frozen stem's weights rounded coherently (stem.coherent_round, the default of every 16-bit precision) the headline
 # config measures 7.1e-3 (bf16) / 0.81e-3 (fp16) instead of 9.1e-3 / 1.30e-3: stated 9.5e-3 and 1.1e-3.
-BF16_FULL_SIZE_LOGIT_TOL = {"config4_film_attn": 9.5e-3, "evalsh_film_attn_5x1024_bs32": 1.2e-2,
-                            "config3_film_gp": 3e-2, "config5_time_multi_hop_T70": 3e-2,
-                            "evalsh_film_gp_4x1024_bs32": 3e-2, "evalsh_time_multi_hop_3x1024_bs16": 3e-2}
+# Round 5: every stated tolerance = the measured value + 30 % (profiles/r05_gpu_tests.txt's run: 7.1e-3, 1.64e-3,
+# 1.64e-2, 1.26e-2, 1.63e-2, 0.90e-2 in this order; flat-gradient errors 0.019, 0.0068, 0.19, 0.24, 0.33, 0.13).
+BF16_FULL_SIZE_LOGIT_TOL = {"config4_film_attn": 9.5e-3, "evalsh_film_attn_5x1024_bs32": 2.2e-3,
+                            "config3_film_gp": 2.15e-2, "config5_time_multi_hop_T70": 1.65e-2,
+                            "evalsh_film_gp_4x1024_bs32": 2.15e-2, "evalsh_time_multi_hop_3x1024_bs16": 1.2e-2}
+BF16_FULL_SIZE_GRAD_TOL = {"config4_film_attn": 0.026, "evalsh_film_attn_5x1024_bs32": 0.01,
+                           "config3_film_gp": 0.25, "config5_time_multi_hop_T70": 0.31,
+                           "evalsh_film_gp_4x1024_bs32": 0.43, "evalsh_time_multi_hop_3x1024_bs16": 0.17}
 
 
 @pytest.mark.parametrize("name", list(FULL_SIZE_CONFIGS))
@@ -165,16 +170,16 @@ def test_bf16_vs_fp32_mode_logits_argmax_at_full_size(name):
     assert abs(fit[LOW + "_loss"] - fit["fp32_loss"]) < 5 * tol * max(1.0, fit["fp32_loss"]), res
     # flat-gradient error of one backward pass at initialisation.  Attention models: 5 % (measured 2.2 % /
     # 0.8 %).  Max-pooling heads: each pooled feature's whole gradient goes to ONE frame and ~10 % of the features pick another
-    # frame under bf16 rounding (1.3 % under fp16): stated 0.5 (measured 0.13 - 0.40 bf16, 0.075 fp16 at config 3), and
+    # frame under bf16 rounding (1.3 % under fp16, 0.9 % under fp16h): measured 0.13 - 0.33 bf16 (stated per config above), and
     # routing the backward by the fp32 run's arg-max frames must not make it worse.
-    gtol = 0.05 if "film_attn" in name else 0.5
-    if LOW == "fp16":
-        gtol = gtol / 2.5
+    gtol = BF16_FULL_SIZE_GRAD_TOL[name]
+    if LOW == "fp16":        # (measured 0.0059 at the headline config)
+        gtol = 0.008 if name == "config4_film_attn" else gtol / 2.5
     assert res["grad_rel_l2_err"] < gtol, res
     if res.get("pooling_head"):
         ph = res["pooling_head"]
         assert ph["grad_rel_l2_err_routed_by_fp32_argmax"] <= res["grad_rel_l2_err"] * 1.02, res
-        assert ph["argmax_frame_flip_frac"] < (0.25 if LOW == "bf16" else 0.05), res
+        assert ph["argmax_frame_flip_frac"] < (0.155 if LOW == "bf16" else 0.03), res      # (measured <= 0.116 bf16 / 0.014 fp16)
 
 
 def test_full_size_trunk_wgrad_vs_torch_and_additivity():

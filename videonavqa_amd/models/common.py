@@ -620,7 +620,10 @@ class FiLMTrunkBase(nn.Module):
         """relu(c1x1_tail) -> zero-padded stack over frames -> max over frames -> out_linear
         (film_global_pooling_pt_stem.py:228-238)."""
         gs = getattr(self, "_trunk_grad_scale", 1.0)      # fp16 storage: the tail conv and the trunk see scaled gradients
-        t = ops.conv(x, self.c1x1_tail.weight, self.c1x1_tail.bias, relu=True, grad_scale=gs)     # [n_img,hp,wp,tail_pad]
+        # (precision 'fp16h': split weights — the tail conv's input is positive, so its weight rounding is a per-channel OFFSET of every
+        # pooled feature, which the max over frames hands straight to out_linear)
+        t = ops.conv(x, self.c1x1_tail.weight, self.c1x1_tail.bias, relu=True, grad_scale=gs,
+                     split_weights=self.__dict__.get("hyb", False) and L.is_half(x.dtype))     # [n_img,hp,wp,tail_pad]
         tail = self.c1x1_tail.out_channels
         # HIP tail: segmented max over each sample's frames straight from the packed image list, written in the reference's
         # NCHW-flattened order, then out_linear on the fp32 GEMM (no dense [T, B, ...] stack, no weight re-layout).
