@@ -790,6 +790,7 @@ def main():
     ap.add_argument("--no-fp16-leg", action="store_true", help="skip the other storage precisions' own short runs (bf16_mode / fp16_mode, child processes)")
     ap.add_argument("--no-robustness", action="store_true", help="skip the tolerance mode's sweep over weight seeds 1..3 and smooth clips (parity.robustness, ~40 s)")
     ap.add_argument("--no-overlap", action="store_true", help="run the stem on the main stream (no side-stream pipeline)")
+    ap.add_argument("--feature-slots", type=int, default=2, help=argparse.SUPPRESS)       # A/B hook: 3 = the stem never waits for the trunk
     ap.add_argument("--cpu-batch", type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-steps", type=int, default=3, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -859,7 +860,7 @@ def main():
 
     from videonavqa_amd.train import Trainer
     model, stem, vgg, od = build(args, device)
-    trainer = Trainer(model, stem, lr=1e-4, clip=1.0, loss_reduction="sum", world_size=world, rank=rank)
+    trainer = Trainer(model, stem, lr=1e-4, clip=1.0, loss_reduction="sum", world_size=world, rank=rank, feature_slots=args.feature_slots)
     NB = max(args.minibatches, 1)
     batches = [synth_batch(args, rank, device, i) for i in range(NB)]
     if args.h2d:

@@ -77,6 +77,33 @@ class FlatParams(object):
                 s._handed = False
 
 
+class phase(object):
+    """roctx range around a phase of the step (stem / trunk_fwd / backward / allreduce / optimizer) on the launch thread: shows up as a
+    marker row in `rocprofv3 --marker-trace` timelines (torch.cuda.nvtx is roctx on ROCm builds).  Host-side only, ~1 us per range."""
+    _nvtx = None
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if phase._nvtx is None:
+            try:
+                phase._nvtx = torch.cuda.nvtx if torch.cuda.is_available() else False
+            except Exception:
+                phase._nvtx = False
+        if phase._nvtx:
+            try:
+                phase._nvtx.range_push(self.name)
+            except Exception:
+                phase._nvtx = False
+        return self
+
+    def __exit__(self, *exc):
+        if phase._nvtx:
+            phase._nvtx.range_pop()
+        return False
+
+
 class DynamicLossScale(object):
     """Loss scale of the fp16-storage precision, adjusted like torch.amp.GradScaler but WITHOUT a host sync in the step and
     DETERMINISTICALLY: the fused clip+Adam kernel itself skips an update whose gradient norm is not finite and counts
@@ -371,7 +398,8 @@ class Trainer(object):
         B, _, H, W, T = clip.shape
         v_sorted, perm = torch.sort(v_lens_cpu, dim=0, descending=True, stable=True)
         lay = FrameLayout(v_sorted, T, clip.device, perm=perm)
-        feats = self.stem.forward_clip(clip, lay.img_of, lay.n_img, slot=slot)
+        with phase("stem"):
+            feats = self.stem.forward_clip(clip, lay.img_of, lay.n_img, slot=slot)
         return NativeFeatures(feats, lay, self.feature_channels, H // 16, W // 16), v_sorted, perm
 
     def upload(self, clip_host):
@@ -526,16 +554,20 @@ class Trainer(object):
         perm_d = L.to_device_async(perm.to(torch.int32), self.stem_device)
         if hasattr(self.model, "init_hidden"):     # `--model mac` has none (eval/q_and_v_eval.py:119-120)
             self.model.init_hidden()
-        logits = self.model(native, q_input.index_select(0, perm_d), v_sorted, q_lens_cpu[perm])
-        # CrossEntropyLoss forward + d logits as one HIP launch; the targets are read through the batch-sort permutation
-        loss = ops.cross_entropy(logits, ys, row_perm=perm_d, weight=self.class_weights, reduction=self.loss_reduction)
-        loss.backward()
-        self.reducer.finish()
-        clamp = getattr(self.model, "grad_clamp", None)
-        if clamp:    # MACNetwork: per-parameter gradient clamp hooks (eval/q_and_v_eval.py:348-351), on the reduced gradient
-            self.fp.grad.clamp_(-clamp, clamp)
-        self.fp.clip_adam_step(self.lr, self.clip,        # (the kernel zeroes the gradient buffer; the sinks are reset with it)
-                               overflow_count=None if self.loss_scaler is None else self.loss_scaler.count)
+        with phase("trunk_fwd"):
+            logits = self.model(native, q_input.index_select(0, perm_d), v_sorted, q_lens_cpu[perm])
+            # CrossEntropyLoss forward + d logits as one HIP launch; the targets are read through the batch-sort permutation
+            loss = ops.cross_entropy(logits, ys, row_perm=perm_d, weight=self.class_weights, reduction=self.loss_reduction)
+        with phase("backward"):
+            loss.backward()
+        with phase("allreduce"):
+            self.reducer.finish()
+        with phase("optimizer"):
+            clamp = getattr(self.model, "grad_clamp", None)
+            if clamp:    # MACNetwork: per-parameter gradient clamp hooks (eval/q_and_v_eval.py:348-351), on the reduced gradient
+                self.fp.grad.clamp_(-clamp, clamp)
+            self.fp.clip_adam_step(self.lr, self.clip,        # (the kernel zeroes the gradient buffer; the sinks are reset with it)
+                                   overflow_count=None if self.loss_scaler is None else self.loss_scaler.count)
         if self.loss_scaler is not None:      # (updates skipped on the device are taken off Adam's step count ON the device)
             self.loss_scaler.after_step()
         ev = torch.cuda.Event()
