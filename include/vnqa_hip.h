@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 419
+#define VNQA_ABI_VERSION 420
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -184,6 +184,10 @@ int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows,
 #define VNQA_EPI_ADD_MASK 3     /* y = (conv + res) * [y2 > 0]  (y2 is READ: the tensor whose sign is the mask) — the FiLM block's
                                  * backward: dgrad of the 3x3 conv + the residual branch's gradient, masked by the 1x1 conv's
                                  * ReLU (models/film_attn_pt_stem.py:219-241 differentiated); bit-identical to vnqa_relu_bwd(a, b, y) */
+#define VNQA_EPI_SPLIT_OUT 4    /* y = h16(v), y2 = h16(v - y): the conv's fp32 result kept as TWO plain 16-bit tensors of y's geometry (hi + lo =
+                                 * v to 2^-22 relative) — conv_init of precision 'fp16h', whose BatchNorm then reads the unrounded value
+                                 * (vnqa_frame_bn_stats_split / _apply_split); patch-stationary tile, 16-bit formats; bias / ReLU of the
+                                 * descriptor apply before the split */
 typedef struct vnqa_conv_epilogue {
   int32_t kind;              /* VNQA_EPI_* */
   int32_t n_frames;          /* BNSTATS */
@@ -197,7 +201,7 @@ typedef struct vnqa_conv_epilogue {
   const float* gamma;        /* FILM_RES */
   const float* beta;         /* FILM_RES */
   const void* res;           /* FILM_RES: padded NHWC like y */
-  void* y2;                  /* FILM_RES: padded NHWC like y */
+  void* y2;                  /* FILM_RES, SPLIT_OUT: padded NHWC like y */
 } vnqa_conv_epilogue;
 int64_t vnqa_conv2d_bnstats_workspace(const vnqa_conv_desc* d, int32_t min_frame_images);
 int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
@@ -486,6 +490,13 @@ int vnqa_frame_bn_stats(const void* x, const int32_t* frame_off, float* mean, fl
 int vnqa_frame_bn_apply(const void* x, const int32_t* frame_of, const float* mean, const float* rstd,
                         const float* gamma, const float* beta, void* y, int32_t n_img, int32_t hp,
                         int32_t wp, int32_t c, int32_t dtype, void* stream);
+/* ... of a SPLIT tensor (two 16-bit tensors x_hi + x_lo, a conv's VNQA_EPI_SPLIT_OUT output): statistics and normalisation of the
+ * unrounded value; y is ONE 16-bit tensor (the single rounding of the layer) */
+int vnqa_frame_bn_stats_split(const void* x_hi, const void* x_lo, const int32_t* frame_off, float* mean, float* var,
+                              int32_t n_frames, int32_t hp, int32_t wp, int32_t c, void* stream);
+int vnqa_frame_bn_apply_split(const void* x_hi, const void* x_lo, const int32_t* frame_of, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, void* y, int32_t n_img, int32_t hp, int32_t wp,
+                              int32_t c, void* stream);
 int vnqa_frame_bn_bwd(const void* dy, const void* x, const int32_t* frame_of, const int32_t* frame_off,
                       const float* mean, const float* rstd, const float* gamma, float* s1, float* s2,
                       void* dx, int32_t n_img, int32_t n_frames, int32_t hp, int32_t wp, int32_t c,

@@ -178,6 +178,45 @@ def test_three_product_conv_with_bnstats_epilogue_matches_the_two_pass_statistic
     assert float((var - v2).abs().max()) < 1e-4 * float(v2.abs().max())
 
 
+def test_split_out_conv_and_the_batchnorm_of_its_two_tensors_match_exact_f32():
+    """VNQA_EPI_SPLIT_OUT + vnqa_frame_bn_stats_split / _apply_split (conv_init of precision 'fp16h'): hi is the plain launch's
+    tensor bit for bit, hi + lo the fp32 result (to the three products' own 1e-5), and the BatchNorm of the pair is the exact-f32 path's up to its ONE
+    output rounding — the plain path's result carries the conv output's rounding as well."""
+    from videonavqa_amd import _lib as L
+    from videonavqa_amd import kernels as K
+    from videonavqa_amd.models.common import FrameLayout
+    lay = FrameLayout([4, 4, 3, 2], 4, "cuda")
+    n, h, w, cin, cout = lay.n_img, 14, 14, 512, 128
+    v = _padded(n, h, w, cin, 17, positive=True)
+    tri = _split3(v)
+    g = torch.Generator().manual_seed(18)
+    w4 = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+    wt32 = K.pack_conv_weight(w4, torch.float32)
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    gamma = (1 + 0.1 * torch.randn(cout, generator=g)).cuda()
+    beta = (0.1 * torch.randn(cout, generator=g)).cuda()
+    ref = K.conv2d_igemm(v, wt32, bias=bias, relu=True)                                      # exact-f32 MFMA path
+    hi, lo = K.conv2d_igemm_split_out(tri, wt32, bias, True, split_in=True)
+    plain = K.conv2d_igemm(tri, wt32, bias=bias, relu=True, split_in=True, tile=L.TILE_PS_224x256)
+    assert torch.equal(hi, plain)
+    # (the three products leave x_lo . w_lo and the operands' own lo roundings: a few 2^-22 of the sums' magnitude)
+    assert float((hi.float() + lo.float() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+    assert float(hi[:, 0].abs().max()) == 0 and float(lo[:, 0].abs().max()) == 0 and float(lo[:, :, -1].abs().max()) == 0
+    m_ref, v_ref = K.frame_bn_stats(ref, lay.frame_off_i32, lay.n_frames)
+    mean, var = K.frame_bn_stats_split(hi, lo, lay.frame_off_i32, lay.n_frames)
+    assert float((mean - m_ref).abs().max()) < 2e-6 * float(m_ref.abs().max())
+    assert float((var - v_ref).abs().max()) < 1e-5 * float(v_ref.abs().max())
+    rstd = torch.rsqrt(v_ref + 1e-5)
+    y_ref = K.frame_bn_apply(ref, lay.frame_of_i32, m_ref, rstd, gamma, beta)
+    y = K.frame_bn_apply_split(hi, lo, lay.frame_of_i32, m_ref, rstd, gamma, beta)
+    y1 = K.frame_bn_apply(hi, lay.frame_of_i32, m_ref, rstd, gamma, beta)
+    assert y.dtype == torch.float16 and float(y[:, 0].abs().max()) == 0
+    r0 = float((y_ref.half().float() - y_ref).pow(2).mean().sqrt())                         # the output rounding alone
+    e2 = float((y.float() - y_ref).pow(2).mean().sqrt())
+    e1 = float((y1.float() - y_ref).pow(2).mean().sqrt())
+    assert e2 < 1.02 * r0 and e1 > 1.2 * r0, (e2, e1, r0)
+
+
 @pytest.mark.parametrize("segs", [2, 3])
 def test_wgrad_from_a_split_tensor_contracts_its_first_segment(segs):
     from videonavqa_amd import kernels as K

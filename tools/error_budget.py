@@ -72,7 +72,8 @@ def main():
                     "calibration frames are always noise)")
     ap.add_argument("--seed", type=int, default=0, help="seed of the random weights (0 = the benchmark's)")
     ap.add_argument("--precision", default="fp16h", help="the precision under test (fp16h, fp16, bf16)")
-    ap.add_argument("settings", nargs="*", default=["COH=1"], help="each word KEY=VALUE sets an environment variable for that pass (COH = VNQA_COHERENT_ROUND)")
+    ap.add_argument("settings", nargs="*", default=["COH=1"], help="one pass per argument; each word KEY=VALUE of it sets an environment variable (COH = VNQA_COHERENT_ROUND) or, "
+                    "as module.ATTRIBUTE=int, a module attribute of the package for that pass")
     o = ap.parse_args()
     args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
                               tail_channels=0, seed=o.seed)
@@ -84,12 +85,22 @@ def main():
     print("%-44s %8s %8s %8s  %s   per batch (x 1e-3)" % ("setting", "max", "rms", "mean", "flips"), flush=True)
     for s in o.settings:
         saved = {}
+        attrs = {}
         for word in s.split():
             k, v = word.split("=")
+            if "." in k:          # module.ATTRIBUTE=int of the package (the A/B switches that are module attributes, e.g. ops.HEAD_SPLIT_OUT=0)
+                import importlib
+                mod, name = k.rsplit(".", 1)
+                m = importlib.import_module("videonavqa_amd." + mod)
+                attrs[(m, name)] = getattr(m, name)
+                setattr(m, name, type(getattr(m, name))(int(v)))
+                continue
             k = KEYS.get(k, k)
             saved[k] = os.environ.get(k)
             os.environ[k] = v
         got = run(args, o.precision, device, data)
+        for (m, name), v in attrs.items():
+            setattr(m, name, v)
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k)

@@ -14,8 +14,8 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof -- python3 $ROOT/bench.py --steps 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -- python3 $ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-parity --no-cpu-baseline --no-overlap > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -- python3 $ROOT/bench.py --steps 3 --warmup 1 --repeats 1 --no-parity --no-cpu-baseline --no-overlap > /dev/null 2>&1
 rm -rf /tmp/pmcM /tmp/pmcS
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d /tmp/pmcM -- python3 $ROOT/tools/stem_only.py --iters 5 > /dev/null 2>$ROOT/gpurun_out/pmcM.err
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/pmcS -- python3 $ROOT/tools/stem_only.py --iters 5 > /dev/null 2>$ROOT/gpurun_out/pmcS.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d /tmp/pmcM -- python3 $ROOT/tools/stem_only.py --precision fp16h --iters 5 > /dev/null 2>$ROOT/gpurun_out/pmcM.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d /tmp/pmcS -- python3 $ROOT/tools/stem_only.py --precision fp16h --iters 5 > /dev/null 2>$ROOT/gpurun_out/pmcS.err
 cd $ROOT
 for f in bench bench_nooverlap bench_layer_by_layer_stem; do tail -1 gpurun_out/${TAG}_$f.json > profiles/${TAG}_$f.json; done
 python tools/profile_summary.py /tmp/prof --steps 28 --round $R --bench profiles/${TAG}_bench.json \

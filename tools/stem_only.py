@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--height", type=int, default=224)
     ap.add_argument("--width", type=int, default=224)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--precision", default="fp16h")
     a = ap.parse_args()
     a.model, a.blocks, a.channels, a.tail_channels = "film_attn_pt", 1, 512, 0
     if a.precision in ("fp16", "fp16h"):

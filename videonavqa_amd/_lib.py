@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 419          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 420          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -78,7 +78,7 @@ class ConvEpilogue(ctypes.Structure):
                 ("gamma", _vp), ("beta", _vp), ("res", _vp), ("y2", _vp)]
 
 
-EPI_NONE, EPI_BNSTATS, EPI_FILM_RES, EPI_ADD_MASK = 0, 1, 2, 3
+EPI_NONE, EPI_BNSTATS, EPI_FILM_RES, EPI_ADD_MASK, EPI_SPLIT_OUT = 0, 1, 2, 3, 4
 
 _MAC_PTRS = ("control memory pq ctxw know pre mask_c wc w_ca b_ca wm bm w1 w_ra b_ra wr wmm bw "
              "cq qv p_c cnew mem v t u p_r read concat d_cnew d_concat d_control d_memory d_cq "
@@ -139,6 +139,8 @@ _SIGNATURES = {
     "vnqa_nhwc_to_nchw": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_frame_bn_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_frame_bn_apply": (ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
+    "vnqa_frame_bn_stats_split": (ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_vp]),
+    "vnqa_frame_bn_apply_split": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
     "vnqa_frame_bn_bwd": (ctypes.c_int, [_vp] * 10 + [_i32] * 7 + [_vp]),
     "vnqa_film_relu_res_fwd": (ctypes.c_int, [_vp] * 5 + [_i32] * 5 + [_vp]),
     "vnqa_film_relu_res_bwd": (ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),

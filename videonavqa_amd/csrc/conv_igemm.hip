@@ -1561,6 +1561,14 @@ extern "C" int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* 
   if (rc != VNQA_OK) return rc;
   if (film_no_z) a.y = nullptr;
   VNQA_CHECK_ARG(!d->pool2 && d->depth == 0 && !d->wt_tiled, "conv2d_igemm_fused_fwd: 2-D, un-pooled, K-major weights only");
+  hipStream_t st = (hipStream_t)stream;
+  if (e->kind == VNQA_EPI_SPLIT_OUT) {      // y = h16(v), y2 = h16(v - y): the fp32 accumulator kept as TWO plain 16-bit tensors
+    VNQA_CHECK_ARG(e->y2 && y && d->tile == VNQA_TILE_PS_224x256 && !(d->flags & VNQA_CONV_DUAL_OUT),
+                   "conv2d_igemm_fused_fwd(SPLIT_OUT): y, y2 and the patch-stationary tile are required");
+    a.dual_out = 4;
+    a.y2 = (char*)e->y2;
+    return conv_dispatch(a, d->dtype, d->tile, st);
+  }
   // (the patch-stationary kernel carries FILM_RES and ADD_MASK in its own store loop: conv_ps.hip)
   const bool ps_tile = d->tile == VNQA_TILE_PS_224x256 && (e->kind == VNQA_EPI_FILM_RES || e->kind == VNQA_EPI_ADD_MASK);
   const int bm = ps_tile ? 224 : fused_rows_for(d);
@@ -1568,7 +1576,6 @@ extern "C" int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* 
     vnqa_set_error("conv2d_igemm_fused_fwd: tile id %d has no fused-epilogue instantiation", d->tile);
     return VNQA_ERR_UNSUPPORTED;
   }
-  hipStream_t st = (hipStream_t)stream;
   if (e->kind == VNQA_EPI_BNSTATS) {
     VNQA_CHECK_ARG(e->frame_of && e->frame_off && e->n_frames > 0 && e->partial && e->mean && e->var,
                    "conv2d_igemm_fused_fwd(BNSTATS): null argument");

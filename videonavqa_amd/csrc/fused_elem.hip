@@ -67,7 +67,7 @@ __device__ __forceinline__ bool is_interior(int pix, int hp, int wp) {
 
 // ---- per-frame BN statistics: mean and biased variance of every (frame, channel) -------------
 template <typename T>
-__global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, const int* __restrict__ frame_off,
+__global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, const T* __restrict__ x_lo, const int* __restrict__ frame_off,
                                                        float* __restrict__ mean, float* __restrict__ var, int hp, int wp,
                                                        int c) {
   __shared__ float s_red[32 * 64];
@@ -78,11 +78,19 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, 
   const long long P = (long long)(i1 - i0) * hp * wp;
   const float n = (float)((i1 - i0) * (hp - 2) * (wp - 2));
   const T* base = x + (size_t)i0 * hp * wp * c + cg * 64 + chunk * 8;
+  // x_lo (optional): x is the hi half of a SPLIT tensor (a conv's VNQA_EPI_SPLIT_OUT output) and x + x_lo the unrounded value
+  const T* base_lo = x_lo != nullptr ? x_lo + (size_t)i0 * hp * wp * c + cg * 64 + chunk * 8 : nullptr;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 4
   for (long long p = prow; p < P; p += 32) {   // halo is zero: plain sum over every padded position (4 loads in flight)
     float v[8];
     load8<T>(base + (size_t)p * c, v);
+    if (base_lo != nullptr) {
+      float w[8];
+      load8<T>(base_lo + (size_t)p * c, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += w[e];
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] += v[e];
   }
@@ -101,6 +109,12 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, 
     if (!is_interior((int)(p % hw), hp, wp)) continue;
     float v[8];
     load8<T>(base + (size_t)p * c, v);
+    if (base_lo != nullptr) {
+      float w[8];
+      load8<T>(base_lo + (size_t)p * c, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += w[e];
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float d = v[e] - m[e];
@@ -119,7 +133,7 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const T* __restrict__ x, 
 
 // y = (x - mean[f]) * rstd[f] * gamma + beta on the interior, 0 on the halo
 template <typename T>
-__global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const int* __restrict__ frame_of,
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ x_lo, const int* __restrict__ frame_of,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        T* __restrict__ y, int hp, int wp, int c) {
@@ -138,6 +152,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ x, 
     float v[8];
     if (is_interior(p, hp, wp)) {
       load8<T>(x + base + (size_t)p * c, v);
+      if (x_lo != nullptr) {
+        float w[8];
+        load8<T>(x_lo + base + (size_t)p * c, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += w[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
     } else {
@@ -364,8 +384,28 @@ extern "C" int vnqa_frame_bn_stats(const void* x, const int32_t* frame_off, floa
   dim3 grid(c / 64, n_frames);
   hipStream_t st = (hipStream_t)stream;
   VNQA_ELEM_DISPATCH(dtype,
-      hipLaunchKernelGGL(bn_stats_kernel<vnqa_bf16>, grid, dim3(256), 0, st, (const vnqa_bf16*)x, frame_off, mean, var, hp, wp, c),
-      hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, frame_off, mean, var, hp, wp, c));
+      hipLaunchKernelGGL(bn_stats_kernel<vnqa_bf16>, grid, dim3(256), 0, st, (const vnqa_bf16*)x, (const vnqa_bf16*)nullptr, frame_off, mean, var, hp, wp, c),
+      hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, frame_off, mean, var, hp, wp, c));
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+// ... of a SPLIT tensor (16-bit format): the statistics of x_hi + x_lo, the unrounded output of a conv launched with VNQA_EPI_SPLIT_OUT
+extern "C" int vnqa_frame_bn_stats_split(const void* x_hi, const void* x_lo, const int32_t* frame_off, float* mean, float* var,
+                                         int32_t n_frames, int32_t hp, int32_t wp, int32_t c, void* stream) {
+  VNQA_CHECK_ARG(x_hi && x_lo && frame_off && mean && var && n_frames > 0 && c % 64 == 0, "frame_bn_stats_split: bad arguments");
+  hipLaunchKernelGGL(bn_stats_kernel<vnqa_bf16>, dim3(c / 64, n_frames), dim3(256), 0, (hipStream_t)stream, (const vnqa_bf16*)x_hi,
+                     (const vnqa_bf16*)x_lo, frame_off, mean, var, hp, wp, c);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+extern "C" int vnqa_frame_bn_apply_split(const void* x_hi, const void* x_lo, const int32_t* frame_of, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, void* y, int32_t n_img, int32_t hp, int32_t wp,
+                                         int32_t c, void* stream) {
+  VNQA_CHECK_ARG(x_hi && x_lo && frame_of && mean && rstd && gamma && beta && y && n_img > 0 && c % 64 == 0, "frame_bn_apply_split: bad arguments");
+  hipLaunchKernelGGL(bn_apply_kernel<vnqa_bf16>, dim3(c / 64, n_img), dim3(256), 0, (hipStream_t)stream, (const vnqa_bf16*)x_hi,
+                     (const vnqa_bf16*)x_lo, frame_of, mean, rstd, gamma, beta, (vnqa_bf16*)y, hp, wp, c);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
@@ -377,8 +417,8 @@ extern "C" int vnqa_frame_bn_apply(const void* x, const int32_t* frame_of, const
   dim3 grid(c / 64, n_img);
   hipStream_t st = (hipStream_t)stream;
   VNQA_ELEM_DISPATCH(dtype,
-      hipLaunchKernelGGL(bn_apply_kernel<vnqa_bf16>, grid, dim3(256), 0, st, (const vnqa_bf16*)x, frame_of, mean, rstd, gamma, beta, (vnqa_bf16*)y, hp, wp, c),
-      hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, frame_of, mean, rstd, gamma, beta, (float*)y, hp, wp, c));
+      hipLaunchKernelGGL(bn_apply_kernel<vnqa_bf16>, grid, dim3(256), 0, st, (const vnqa_bf16*)x, (const vnqa_bf16*)nullptr, frame_of, mean, rstd, gamma, beta, (vnqa_bf16*)y, hp, wp, c),
+      hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, frame_of, mean, rstd, gamma, beta, (float*)y, hp, wp, c));
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

@@ -203,6 +203,24 @@ def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frame
     return y, mean, var
 
 
+def conv2d_igemm_split_out(x, wt, bias, relu, split_in=False):
+    """conv (+bias, +ReLU) on the patch-stationary tile with its fp32 result kept as TWO plain 16-bit tensors (VNQA_EPI_SPLIT_OUT):
+    returns (hi, lo), hi = h16(v), lo = h16(v - hi), both padded NHWC with a zero halo.  split_in: see conv2d_igemm."""
+    N, Hp, Wp, _ = x.shape
+    if split_in:
+        assert wt.dtype == torch.float32 and x.shape[-1] == 3 * wt.shape[2]
+        wt = split_weight3(wt)
+    c_out, taps, _ = wt.shape
+    assert L.is_half(x.dtype) and wt.dtype == x.dtype and taps == 9
+    d = L.ConvDesc(L.dtype_id(x.dtype), N, Hp - 2, Wp - 2, x.shape[-1], c_out, c_out, taps, 1, 1, int(relu), 0, L.TILE_PS_224x256, 0, 0, 0)
+    both = empty_padded((2 * N, Hp, Wp, c_out), x.dtype, x.device)
+    hi, lo = both[:N], both[N:]
+    e = L.ConvEpilogue(kind=L.EPI_SPLIT_OUT, y2=lo.data_ptr())
+    L.check(L.lib().vnqa_conv2d_igemm_fused_fwd(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), ctypes.byref(e),
+                                                L.ptr(hi), L.stream()), "vnqa_conv2d_igemm_fused_fwd(SPLIT_OUT)")
+    return hi, lo
+
+
 def conv_ps_supported(n, h, w, c_in, c_out, taps=9, pool2=False):
     """The library's own answer (vnqa_conv_ps_supported) to: do the patch-stationary tiles serve this 16-bit conv geometry?"""
     d = L.ConvDesc(L.BF16, n, h, w, c_in, c_out, c_out, taps, 2 if taps == 25 else 1, 1, 0, 1 if pool2 else 0, L.TILE_PS_224x256, 0, 0, 0)
@@ -843,6 +861,26 @@ def frame_bn_stats(x, frame_off_i32, n_frames):
     L.check(L.lib().vnqa_frame_bn_stats(L.ptr(x), L.ptr(frame_off_i32), L.ptr(mean), L.ptr(var), n_frames, hp, wp, c,
                                         L.dtype_id(x.dtype), L.stream()), "vnqa_frame_bn_stats")
     return mean, var
+
+
+def frame_bn_stats_split(x_hi, x_lo, frame_off_i32, n_frames):
+    """frame_bn_stats of x_hi + x_lo (conv2d_igemm_split_out's pair)."""
+    N, hp, wp, c = x_hi.shape
+    assert x_lo.shape == x_hi.shape and x_lo.dtype == x_hi.dtype and L.is_half(x_hi.dtype)
+    mean = torch.empty((n_frames, c), dtype=torch.float32, device=x_hi.device)
+    var = torch.empty((n_frames, c), dtype=torch.float32, device=x_hi.device)
+    L.check(L.lib().vnqa_frame_bn_stats_split(L.ptr(x_hi), L.ptr(x_lo), L.ptr(frame_off_i32), L.ptr(mean), L.ptr(var), n_frames, hp, wp, c,
+                                              L.stream()), "vnqa_frame_bn_stats_split")
+    return mean, var
+
+
+def frame_bn_apply_split(x_hi, x_lo, frame_of_i32, mean, rstd, gamma, beta):
+    N, hp, wp, c = x_hi.shape
+    assert x_lo.shape == x_hi.shape and x_lo.dtype == x_hi.dtype and L.is_half(x_hi.dtype)
+    y = torch.empty((N, hp, wp, c), dtype=x_hi.dtype, device=x_hi.device)
+    L.check(L.lib().vnqa_frame_bn_apply_split(L.ptr(x_hi), L.ptr(x_lo), L.ptr(frame_of_i32), L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
+                                              L.ptr(beta), L.ptr(y), N, hp, wp, c, L.stream()), "vnqa_frame_bn_apply_split")
+    return y
 
 
 def frame_bn_apply(x, frame_of_i32, mean, rstd, gamma, beta):

@@ -223,6 +223,7 @@ def is_split(x, c_in):
 # conv_init on split features (precision 'fp16h', 777 GFLOP at the headline): True — the patch-stationary kernel (1.3-1.4 PFLOP/s on
 # 14 x 14 maps) + the two-pass statistics kernel; False — the implicit GEMM with the BNSTATS epilogue (one launch less, 0.3-0.4 of peak)
 HEAD_CONV_PS = True
+HEAD_SPLIT_OUT = True
 
 
 class FilmTrunkHeadFn(torch.autograd.Function):
@@ -253,14 +254,22 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         ps = split and HEAD_CONV_PS and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
         if L.is_half(cdt) and not ps:     # (the fp32 parity precision keeps the exact two-pass statistics kernel)
             fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts), split_in=split)
-        if fused is None:
-            r = K.conv2d_igemm(x, wt0, bias=b0, relu=True, split_in=split, tile=L.TILE_PS_224x256 if ps else L.TILE_AUTO)
-            mean, var = K.frame_bn_stats(r, lay.frame_off_i32, lay.n_frames)
-        else:
-            r, mean, var = fused
-        rstd = torch.rsqrt(var + meta.eps)
         g = K.pad_vec(bn_w, c_pad)
-        h = K.frame_bn_apply(r, lay.frame_of_i32, mean, rstd, g, K.pad_vec(bn_b, c_pad))
+        if ps and HEAD_SPLIT_OUT:
+            # ... and its OUTPUT kept unrounded into the BatchNorm (hi + lo, VNQA_EPI_SPLIT_OUT): 0.020e-6 of the budget; the backward
+            # reads the hi tensor alone (ReLU mask and x-hat)
+            r, r_lo = K.conv2d_igemm_split_out(x, wt0, b0, True, split_in=True)
+            mean, var = K.frame_bn_stats_split(r, r_lo, lay.frame_off_i32, lay.n_frames)
+            rstd = torch.rsqrt(var + meta.eps)
+            h = K.frame_bn_apply_split(r, r_lo, lay.frame_of_i32, mean, rstd, g, K.pad_vec(bn_b, c_pad))
+        else:
+            if fused is None:
+                r = K.conv2d_igemm(x, wt0, bias=b0, relu=True, split_in=split, tile=L.TILE_PS_224x256 if ps else L.TILE_AUTO)
+                mean, var = K.frame_bn_stats(r, lay.frame_off_i32, lay.n_frames)
+            else:
+                r, mean, var = fused
+            rstd = torch.rsqrt(var + meta.eps)
+            h = K.frame_bn_apply(r, lay.frame_of_i32, mean, rstd, g, K.pad_vec(bn_b, c_pad))
         ctx.meta = meta
         with torch.enable_grad():       # gradient sinks (FlatParams): conv_init w/b, bn w/b
             ctx.sinks = [sink_of(t) for t in (conv_w, conv_b, bn_w, bn_b)]
