@@ -47,7 +47,8 @@ def main():
         for n, cnt, tot, mn, mx in rows:
             w.writerow([n, cnt, tot, round(tot / cnt, 1), round(100.0 * tot / total, 3), mn, mx])
     md = ["# Round %d — rocprofv3 --kernel-trace --stats of `%s`" % (a.round, a.command), "",
-          "MI355X (gfx950), 1 GPU, bf16, B=8 clips x 35 frames x 224x224, side-stream stem pipeline on.",
+          "MI355X (gfx950), 1 GPU, precision %s, B=8 clips x 35 frames x 224x224, side-stream stem pipeline on."
+          % (load(a.bench).get("parity", {}).get("precision") or load(a.bench)["dtype"].split(" ")[0]),
           "%d steps profiled.  Raw CSV: `profiles/%s_kernel_stats.csv`; PMC HBM traffic of the dominant kernel: "
           "`profiles/%s_pmc_traffic.json`." % (a.steps, tag, tag), ""]
 
