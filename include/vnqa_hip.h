@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 420
+#define VNQA_ABI_VERSION 421
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -442,6 +442,9 @@ int vnqa_frame_layout(const int32_t* v_sorted_host, const int32_t* perm_host, in
  * split features). */
 #define VNQA_WGRAD_X_PAIR 0x200
 #define VNQA_WGRAD_X_TRIPLE 0x400
+/* VNQA_WGRAD_EIGHT_WAVES (16-bit format): run the first form of the kernel (8 waves, two 64-pixel stages) instead of the default
+ * 4-wave form with its ring of four 32-pixel stages — same tiles, slabs and summation order per slab; the tests' cross-check. */
+#define VNQA_WGRAD_EIGHT_WAVES 0x800
 int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t w, int32_t c_in,
                                     int32_t c_out, int32_t taps);
 int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, float* dbias, void* workspace,

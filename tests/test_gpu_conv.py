@@ -134,6 +134,32 @@ def test_wgrad_vs_torch(dt, cfg):
     assert _rel(dbias, b.grad) < 5e-5
 
 
+@pytest.mark.parametrize("cfg", [(40, 14, 14, 512, 512, 9, 1), (23, 14, 14, 512, 512, 9, 3), (12, 20, 26, 256, 320, 9, 1), (280, 14, 14, 512, 512, 1, 1),
+                                 (5, 7, 7, 128, 64, 9, 1), (3, 40, 52, 64, 128, 9, 1)])
+def test_wgrad_four_wave_ring_form_matches_the_eight_wave_form(cfg):
+    """The default 16-bit weight-gradient kernel (4 waves, ring of four 32-pixel stages, quadrant-rolling fragment reads) against the
+    first form (VNQA_WGRAD_EIGHT_WAVES): same tiles, same split-K slices and slab order — the partial sums differ only by the
+    association inside a slice (32- vs 64-pixel MFMA chains are the same chain: bit-identical is expected, 1e-6 is asserted) —
+    on 14 x 14 trunk maps (several slices), ragged image counts, widths that do not divide 32, a [hi | lo | hi] x, 1 x 1 taps."""
+    from videonavqa_amd import kernels as K
+    N, H, W, Cin, Cout, taps, segs = cfg
+    dt = LOW_DTYPE
+    g = torch.Generator(device="cpu").manual_seed(sum(cfg))
+    x = torch.randn(N, Cin, H, W, generator=g).cuda()
+    dy = torch.randn(N, Cout, H, W, generator=g).cuda()
+    xp, dyp = K.nchw_to_nhwc(x, dt, c_pad=Cin), K.nchw_to_nhwc(dy, dt, c_pad=Cout)
+    if segs == 3:
+        xp = torch.cat([xp, torch.randn_like(xp), xp], dim=-1).contiguous()
+    a, ba = K.conv2d_wgrad(xp, dyp, taps, x_segs=segs)
+    b, bb = K.conv2d_wgrad(xp, dyp, taps, x_segs=segs, eight_waves=True)
+    assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()), float((a - b).abs().max())
+    assert torch.equal(ba, bb)
+    k = 3 if taps == 9 else 1
+    w = torch.zeros(Cout, Cin, k, k).cuda().requires_grad_(True)
+    F.conv2d(_q(x, dt), w, None, padding=k // 2).backward(_q(dy, dt))
+    assert _rel(K.unpack_conv_wgrad(a, Cout, Cin), w.grad) < 5e-5
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_conv_first_vs_torch(dt):
     from videonavqa_amd import kernels as K

@@ -532,6 +532,336 @@ __global__ void __launch_bounds__(512) conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+#ifdef VNQA_H16_IS_F16
+#define VNQA_WG_MFMA "v_mfma_f32_16x16x32_f16"
+#else
+#define VNQA_WG_MFMA "v_mfma_f32_16x16x32_bf16"
+#endif
+// accumulator pinned to the AGPR half ("+a", tied): the 4-wave form's 64 tiles fill all 256 AGPRs, and with the builtin (untied
+// destination) the allocator shuffles tiles through VGPRs around every MFMA
+__device__ __forceinline__ void wg_mfma(vnqa_f32x4& acc, const vnqa_bf16x8& a, const vnqa_bf16x8& b) {
+  asm volatile(VNQA_WG_MFMA " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+// ---- 16-bit weight gradient, second form: 4 waves x 512 registers, ring of four 32-pixel stages ----
+// Same tile (256 co x 256 ci of one tap), same staging images and the same transposed fragment reads as conv_wgrad_kernel<h16>,
+// but laid out like the patch-stationary conv (conv_ps.hip): ONE wave per SIMD with a 128 co x 128 ci tile (64 accumulator tiles
+// of 16 x 16 — 256 registers — beside two fragment sets), so that
+//   * a half-step's 32 transposed reads are requested right before the 64 MFMAs of the half-step BEFORE it and land under them
+//     (the 8-wave form waits for its reads with both waves of a SIMD stalled together: lgkmcnt(0), then 32 MFMAs);
+//   * the LDS read volume per MFMA drops by a third (A + B fragments of a 128 x 128 wave tile against 128 x 64);
+//   * the global -> LDS transfers of THREE later 32-pixel stages are in flight beside the one being consumed (counted vmcnt;
+//     the 8-wave form issues one 64-pixel stage at the top of a K-step and drains it at the bottom).
+// One barrier per half-step (64 MFMAs per wave).  Output layout, split-K slabs and the fused reduce are the 8-wave form's.
+__global__ void __launch_bounds__(256) conv_wgrad4_kernel(const WgradArgs p) {
+  constexpr int ES = 2, BCH = 256, RB = BCH * ES, KH = 32, CPR = RB / 16;
+  constexpr int TILE_BYTES = KH * RB;            // 16 KiB: 32 pixels x 256 channels
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // dY tile, X tile
+  constexpr int NSLOT = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int bid;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_ci = bid % p.tilesCi; bid /= p.tilesCi;
+  const int tap = bid % p.taps; bid /= p.taps;
+  const int tile_co = bid % p.tilesCo; bid /= p.tilesCo;
+  const int slice = bid;
+
+  int dtap = 0;
+  if (p.taps == 9) {
+    const int r = tap / 3, s = tap - 3 * r;
+    dtap = (r - 1) * p.Wp + (s - 1);
+  } else if (p.taps == 27) {
+    const int q = tap / 9, rs = tap - 9 * q, r = rs / 3, s = rs - 3 * r;
+    dtap = ((q - 1) * p.Hp + (r - 1)) * p.Wp + (s - 1);
+  }
+
+  // per-lane staging geometry: instruction q = wave*4 + j covers 1 KiB (two 512-byte rows) of a 16 KiB tile
+  const unsigned rowA32 = (unsigned)(p.Cout * ES), rowB32 = (unsigned)(p.x_cs * ES);
+  const int k_begin = slice * p.ksteps_per_slice;
+  int k_end = k_begin + p.ksteps_per_slice;
+  k_end = k_end < p.ksteps_total ? k_end : p.ksteps_total;
+  const int nh = 2 * (k_end - k_begin);           // half-steps of 32 pixels (the plan counts 64-pixel K-steps)
+  // Contraction position of this lane's four staging rows, advanced by 32 pixels per stage WITHOUT a branch (the staging code
+  // is interleaved with the MFMAs of the half-step it is issued in: one scheduling region).  v = compact pixel index (valid
+  // pixels only when vrow > 0), (y, x) its position in the image, pa the padded pixel index of the dY row:
+  //   x += 32 % W, y += 32 / W, carry x -> y, carry y -> next image;  pa follows with constant increments.
+  // The launcher sends geometries a 32-pixel step could carry twice (H < 32 / W + 1) to the 8-wave form; vrow = 0 (every padded
+  // position is visited: 3-D convs, gemm_tn) is the same code with W = H = INT_MAX.
+  const int W_ = p.vrow > 0 ? p.vw : 0x7fffffff, H_ = p.vrow > 0 ? p.vrow / p.vw : 0x7fffffff;
+  const int q32 = p.vrow > 0 ? KH / W_ : 0, r32 = p.vrow > 0 ? KH % W_ : KH;
+  const int delta = q32 * p.Wp + r32, cfix = p.vrow > 0 ? p.Wp - W_ : 0, dfix = p.vrow > 0 ? p.prow - H_ * p.Wp : 0;
+  const int p_last = (int)(p.Ptot - 1), v_tot = (int)p.Vtot;
+  int st_v[4], st_pa[4], st_x[4], st_y[4];
+  const char* st_a[4];
+  const char* st_b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int lin = (wave * 4 + j) * 64 + lane;
+    const int row = lin / CPR, phys = lin - row * CPR;
+    const int logical = phys ^ swz_tr(row);
+    int ca = tile_co * BCH + logical * 8;
+    int cb = tile_ci * BCH + logical * 8;
+    ca = ca < p.Cout ? ca : p.Cout - 8;           // channel tiles that stick out of the tensor: clamped (their results are dropped)
+    cb = cb < p.Cin ? cb : p.Cin - 8;
+    st_a[j] = p.dy + ca * ES;
+    st_b[j] = p.x + cb * ES;
+    const int v = k_begin * (2 * KH) + row;
+    st_v[j] = v;
+    if (p.vrow > 0) {
+      const unsigned img = (unsigned)v / (unsigned)p.vrow, rem = (unsigned)v - img * (unsigned)p.vrow;
+      const unsigned y = rem / (unsigned)p.vw;
+      st_y[j] = (int)y;
+      st_x[j] = (int)(rem - y * (unsigned)p.vw);
+      st_pa[j] = (int)img * p.prow + (st_y[j] + 1) * p.Wp + st_x[j] + 1;
+    } else {
+      st_y[j] = 0;
+      st_x[j] = v;
+      st_pa[j] = v;
+    }
+  }
+  const char* zero_page = (const char*)vnqa_zero_page;
+  asm volatile("" : "+s"(zero_page));       // (materialised once: re-derived inside the loop it is a scalar load + lgkmcnt(0) in front of the fragment reads)
+  // 8 LDS-DMA instructions per wave and stage (the vmcnt waits below count them).  A piece (one of the wave's four row pairs) is
+  // written as 7 micro-steps of 3-6 VALU instructions: the main loop places one after every other MFMA of a quadrant (the MFMAs
+  // are inline asm — accumulators pinned to the AGPR half — so the interleave is by program order; `tie` keeps a micro-step
+  // between the two MFMAs it was written between).
+  struct Piece { bool live; int pb; const char* ba; const char* bb; unsigned oa, ob; bool c, d; int x, y; };
+  auto tie_i = [](int& v) { asm volatile("" : "+v"(v)); };
+  auto tie_u = [](unsigned& v) { asm volatile("" : "+v"(v)); };
+  auto tie_p = [](const char*& v) { asm volatile("" : "+v"(v)); };
+  auto micro = [&](Piece& t, int slot, int j, int k) {
+    char* lds = smem + slot * STAGE_BYTES;
+    if (k == 0) {
+      tie_i(st_v[j]); tie_i(st_pa[j]);
+      t.live = st_v[j] < v_tot;
+      int pb = st_pa[j] + dtap;
+      pb = pb < 0 ? 0 : (pb < p_last ? pb : p_last);
+      t.oa = t.live ? (unsigned)st_pa[j] : 0u;      // (rows past the contraction range: base = the zero page, offset 0 — selects, no branch)
+      t.ob = t.live ? (unsigned)pb : 0u;
+      tie_u(t.oa); tie_u(t.ob);
+    } else if (k == 1) {
+      t.ba = t.live ? st_a[j] : zero_page;
+      t.bb = t.live ? st_b[j] : zero_page;
+      tie_p(t.ba); tie_p(t.bb);
+    } else if (k == 2) {
+      const char* src = t.ba + (unsigned long long)t.oa * rowA32;
+      tie_p(src);
+#if !defined(VNQA_WG4_DIAG) || VNQA_WG4_DIAG != 1       // timing-only builds: 1 = no global -> LDS transfers, 2 = no MFMAs
+      glds16w(src, lds + (wave * 4 + j) * 1024);
+#endif
+    } else if (k == 3) {
+      const char* src = t.bb + (unsigned long long)t.ob * rowB32;
+      tie_p(src);
+#if !defined(VNQA_WG4_DIAG) || VNQA_WG4_DIAG != 1
+      glds16w(src, lds + TILE_BYTES + (wave * 4 + j) * 1024);
+#endif
+    } else if (k == 4) {
+      tie_i(st_x[j]); tie_i(st_y[j]);
+      st_v[j] += KH;
+      t.x = st_x[j] + r32;
+      t.y = st_y[j] + q32;
+      t.c = t.x >= W_;
+      t.x = t.c ? t.x - W_ : t.x;
+      t.y += t.c ? 1 : 0;
+      tie_i(t.x); tie_i(t.y); tie_i(st_v[j]);
+    } else if (k == 5) {
+      t.d = t.y >= H_;
+      st_y[j] = t.d ? t.y - H_ : t.y;
+      st_x[j] = t.x;
+      tie_i(st_x[j]); tie_i(st_y[j]);
+    } else if (k == 6) {
+      st_pa[j] += delta + (t.c ? cfix : 0) + (t.d ? dfix : 0);
+      tie_i(st_pa[j]);
+    }
+  };
+  auto stage = [&](int slot) {       // the prologue's form: whole pieces back to back
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      Piece t;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) micro(t, slot, j, k);
+    }
+  };
+
+  vnqa_f32x4 acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  // fragment-read lane geometry (conv_wgrad_kernel, 16x16x32 branch): 16-lane group g supplies pixels 8 g .. 8 g + 7
+  const int g = lane >> 4, il = lane & 15, q4 = il >> 2, pp = il & 3;
+  const int row0 = 8 * g + q4;
+  const int sw = swz_tr(row0);
+  const unsigned lane_base = lds_addr(smem) + row0 * RB + ((pp & 1) << 3);
+  unsigned offA[8], offB[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    offA[i] = lane_base + (((((wm * 128 + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
+    offB[i] = lane_base + TILE_BYTES + (((((wn * 128 + i * 16) >> 3) + (pp >> 1)) ^ sw) << 4);
+  }
+  // The wave's 8 x 8 accumulator tiles are walked as four QUADRANTS of 4 x 4 (16 MFMAs, 256 matrix-pipe cycles) over four
+  // fragment sets of 4 (A rows 0-3 / 4-7, B columns 0-3 / 4-7: 64 registers, no double buffer).  A quadrant needs one A and one
+  // B set; while it runs, the set that the quadrant after the next needs first is requested into whichever set fell free:
+  //   even half-step   Q00 (A0 B0) -> Q01 (A0 B1) -> Q11 (A1 B1) -> Q10 (A1 B0)     requests: B1, A1 | next stage's A0, B1
+  //   odd half-step    Q01 (A0 B1) -> Q00 (A0 B0) -> Q10 (A1 B0) -> Q11 (A1 B1)     requests: B0, A1 | next stage's A0, B0
+  // so every fragment read is issued a whole quadrant before its first use, and the pattern closes after two half-steps.
+  s16x4 fa[2][4][2], fb[2][4][2];          // [set][fragment][rows q4 / q4 + 4]
+  auto req_a = [&](int set, unsigned so) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[set][i][0] = lds_tr_read_asm<0>(offA[4 * set + i] + so);
+      fa[set][i][1] = lds_tr_read_asm<4 * RB>(offA[4 * set + i] + so);
+    }
+  };
+  auto req_b = [&](int set, unsigned so) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      fb[set][j][0] = lds_tr_read_asm<0>(offB[4 * set + j] + so);
+      fb[set][j][1] = lds_tr_read_asm<4 * RB>(offB[4 * set + j] + so);
+    }
+  };
+  auto tie = [&](s16x4 (*f)[2]) {          // the fragments exist only after the lgkmcnt wait in front of this
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(f[i][0]), "+v"(f[i][1]));
+  };
+  // one quadrant: wait for every read issued so far, request the next set (REQ: 0 none, 1 A-set `rs`, 2 B-set `rs`, from LDS byte
+  // offset `so`), then the 16 MFMAs with staging piece `piece` of slot `st_slot` in their shadow: one micro-step after every
+  // other MFMA (one wave per SIMD: what is not issued between two MFMAs is issued instead of one)
+  auto quadrant = [&](int as, int bs, int req, int rs, unsigned so, int st_slot, int piece) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tie(fa[as]);
+    tie(fb[bs]);
+    if (req == 1) req_a(rs, so);
+    if (req == 2) req_b(rs, so);
+    vnqa_bf16x8 bf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      bf[j] = vnqa_bf16x8{fb[bs][j][0][0], fb[bs][j][0][1], fb[bs][j][0][2], fb[bs][j][0][3],
+                          fb[bs][j][1][0], fb[bs][j][1][1], fb[bs][j][1][2], fb[bs][j][1][3]};
+    Piece t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const vnqa_bf16x8 af = vnqa_bf16x8{fa[as][i][0][0], fa[as][i][0][1], fa[as][i][0][2], fa[as][i][0][3],
+                                         fa[as][i][1][0], fa[as][i][1][1], fa[as][i][1][2], fa[as][i][1][3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#if !defined(VNQA_WG4_DIAG) || VNQA_WG4_DIAG != 2
+        wg_mfma(acc[4 * as + i][4 * bs + j], af, bf[j]);
+#else
+        asm volatile("" :: "v"(af), "v"(bf[j]));
+#endif
+        const int n = 4 * i + j;
+        if ((n & 1) == 1 && (n >> 1) < 7) micro(t, st_slot, piece, n >> 1);
+      }
+    }
+  };
+  // top of half-step h: stage h+1 has landed for every wave (the last two quadrants read it), every wave is done with slot (h-1) & 3
+  // (stage h+3 goes there).  Stages past the slice's last half-step are issued all the same — rows past the contraction range stage
+  // zeros, nothing consumes them — so the loop has no branch and every wait counts the same 8 transfers per stage.
+  auto top = [&]() {
+#if defined(VNQA_WG4_DIAG) && VNQA_WG4_DIAG == 1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
+    __builtin_amdgcn_s_barrier();
+  };
+
+  stage(0);
+  stage(1);
+  stage(2);
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  req_a(0, 0u);
+  req_b(0, 0u);
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+  for (int h = 0; h < nh; h += 2) {          // (nh is even)
+    const unsigned s0 = (unsigned)(h & (NSLOT - 1)) * STAGE_BYTES, s1 = (unsigned)((h + 1) & (NSLOT - 1)) * STAGE_BYTES,
+                   s2 = (unsigned)((h + 2) & (NSLOT - 1)) * STAGE_BYTES;
+    const int t0 = (h + 3) & (NSLOT - 1), t1 = (h + 4) & (NSLOT - 1);
+    top();
+    quadrant(0, 0, 2, 1, s0, t0, 0);
+    quadrant(0, 1, 1, 1, s0, t0, 1);
+    quadrant(1, 1, 1, 0, s1, t0, 2);
+    quadrant(1, 0, 2, 1, s1, t0, 3);
+    top();
+    quadrant(0, 1, 2, 0, s1, t1, 0);
+    quadrant(0, 0, 1, 1, s1, t1, 1);
+    quadrant(1, 0, 1, 0, s2, t1, 2);
+    quadrant(1, 1, 2, 0, s2, t1, 3);
+    // the accumulators are read right behind the loop (the compiler's AGPR -> VGPR copies sit on the exit edge) and the MFMAs
+    // are inline asm, invisible to the hazard recogniser: the last trip ends with the wait states an 8-pass MFMA needs
+    if (h + 2 >= nh) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+  }
+  __builtin_amdgcn_s_setprio(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the stages and the requests issued past the end
+  // wait states between the last MFMAs (inline asm: invisible to the hazard recogniser) and the first read of an accumulator
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
+  asm volatile("s_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
+
+  // ---- store the partial tile: D[co = 16 i + 4 (lane>>4) + e][ci = 16 j + (lane&15)] ----
+  float* slab = p.out + (size_t)slice * p.Cout * p.taps * p.Cin;
+  const int r16 = lane & 15, h16 = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = tile_ci * BCH + wn * 128 + j * 16 + r16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = tile_co * BCH + wm * 128 + i * 16 + 4 * h16 + e;
+        if (co < p.Cout && ci < p.Cin) slab[((size_t)co * p.taps + tap) * p.Cin + ci] = acc[i][j][e];
+      }
+    }
+  if (p.final != nullptr) {      // fused slab reduce, as in conv_wgrad_kernel
+    __shared__ int s_last4;
+    __threadfence();
+    __syncthreads();
+    const int tile_id = (tile_co * p.taps + tap) * p.tilesCi + tile_ci;
+    if (threadIdx.x == 0) {
+      const int old = atomicAdd(&g_wgrad_arrivals[tile_id], 1);
+      s_last4 = old == p.slices - 1;
+      if (s_last4) g_wgrad_arrivals[tile_id] = 0;
+    }
+    __syncthreads();
+    if (s_last4) {
+      __threadfence();
+      const size_t n_all = (size_t)p.Cout * p.taps * p.Cin;
+      for (int e = threadIdx.x; e < BCH * (BCH / 4); e += 256) {
+        const int co = tile_co * BCH + e / (BCH / 4), ci = tile_ci * BCH + (e % (BCH / 4)) * 4;
+        if (co >= p.Cout || ci >= p.Cin) continue;
+        const size_t off = ((size_t)co * p.taps + tap) * p.Cin + ci;
+        float4 acc4 = *(const float4*)(p.out + off);
+        for (int z = 1; z < p.slices; ++z) {
+          const float4 v = *(const float4*)(p.out + (size_t)z * n_all + off);
+          acc4.x += v.x; acc4.y += v.y; acc4.z += v.z; acc4.w += v.w;
+        }
+        *(float4*)(p.final + off) = acc4;
+      }
+    }
+  }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n, int slices) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float s = 0.f;
@@ -685,7 +1015,7 @@ extern "C" int64_t vnqa_conv2d_wgrad_workspace(int32_t n_img, int32_t h, int32_t
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
                      int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h = 0,
-                     bool small = false, bool fuse_reduce = false, int x_cs = 0);
+                     bool small = false, bool fuse_reduce = false, int x_cs = 0, bool eight_waves = false);
 
 // the small-channel form's plan: tap groups x slices, two partial slabs per slice
 static bool small3d_ok(int c_in, int c_out, int dtype) {
@@ -744,7 +1074,8 @@ extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, floa
                                  int32_t taps, int32_t dtype, void* stream) {
   const bool fuse_reduce = (dtype & VNQA_WGRAD_FUSED_REDUCE) != 0;      // per-call option bit (the library reads no environment)
   const int x_segs = (dtype & VNQA_WGRAD_X_TRIPLE) ? 3 : ((dtype & VNQA_WGRAD_X_PAIR) ? 2 : 1);   // x: [hi | lo (| hi)], x_segs c_in physical channels
-  dtype &= ~(VNQA_WGRAD_FUSED_REDUCE | VNQA_WGRAD_X_PAIR | VNQA_WGRAD_X_TRIPLE);
+  const bool eight_waves = (dtype & VNQA_WGRAD_EIGHT_WAVES) != 0;       // the first 16-bit form (conv_wgrad_kernel<h16>): kept as the cross-check
+  dtype &= ~(VNQA_WGRAD_FUSED_REDUCE | VNQA_WGRAD_X_PAIR | VNQA_WGRAD_X_TRIPLE | VNQA_WGRAD_EIGHT_WAVES);
   VNQA_CHECK_ARG(x_segs == 1 || dtype == VNQA_BF16, "conv2d_wgrad: VNQA_WGRAD_X_PAIR / _X_TRIPLE need the 16-bit format");
   VNQA_CHECK_ARG(x && dy && dwt && workspace, "conv2d_wgrad: null pointer");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv2d_wgrad: bad dtype %d", dtype);
@@ -753,7 +1084,8 @@ extern "C" int vnqa_conv2d_wgrad(const void* x, const void* dy, float* dwt, floa
   VNQA_CHECK_ARG(n_img > 0 && h > 0 && w > 0, "conv2d_wgrad: empty problem");
   VNQA_CHECK_ARG((long long)n_img * (h + 2) * (w + 2) < (1ll << 31), "conv2d_wgrad: too many pixels");
   const Plan pl = make_plan(n_img, h, w, c_in, c_out, taps, dtype);
-  return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, taps, dtype, stream, 0, false, fuse_reduce, x_segs > 1 ? x_segs * c_in : 0);
+  return wgrad_run(x, dy, dwt, dbias, workspace, pl, w, c_in, c_out, taps, dtype, stream, 0, false, fuse_reduce, x_segs > 1 ? x_segs * c_in : 0,
+                   eight_waves);
 }
 
 extern "C" int64_t vnqa_gemm_tn_workspace(int32_t m, int32_t n, int32_t k, int32_t dtype) {
@@ -774,7 +1106,7 @@ extern "C" int vnqa_gemm_tn(const void* a_km, const void* b_kn, float* out, void
 
 static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, void* workspace, const Plan& pl,
                      int32_t w, int32_t c_in, int32_t c_out, int32_t taps, int32_t dtype, void* stream, int32_t h, bool small,
-                     bool fuse_reduce, int x_cs) {
+                     bool fuse_reduce, int x_cs, bool eight_waves) {
   hipStream_t st = (hipStream_t)stream;
   WgradArgs a;
   a.x = (const char*)x;
@@ -827,6 +1159,18 @@ static int wgrad_run(const void* x, const void* dy, float* dwt, float* dbias, vo
       small_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a);
+  } else if (dtype == VNQA_BF16 && !eight_waves && pl.Ptot < (1ll << 31) &&
+             (pl.vrow == 0 || pl.vrow / pl.vw >= 32 / pl.vw + 1)) {      // (its branch-free row stepping carries once per 32 pixels)
+    auto kern = conv_wgrad4_kernel;
+    static std::atomic<bool> four_done{false};
+    if (!four_done) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        vnqa_set_error("conv2d_wgrad: cannot reserve %d B of LDS", lds);
+        return VNQA_ERR_HIP;
+      }
+      four_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   } else if (dtype == VNQA_BF16) {
     auto kern = conv_wgrad_kernel<vnqa_bf16>;
     if (!attr_done[0]) {

@@ -640,10 +640,13 @@ def workspace(nbytes, device):
     return buf
 
 
-def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, x_segs=1):
+WGRAD_EIGHT_WAVES = False      # A/B switch: the first 16-bit form of the weight-gradient kernel for every call
+
+
+def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, x_segs=1, eight_waves=False):
     """x, dy: padded NHWC (halo 1, same N/H/W). Returns (dwt fp32 [Cout][taps][Cin], dbias fp32 [Cout]).
     x_segs = 2 / 3: x is a [hi | lo] / [hi | lo | hi] tensor (x_segs Cin physical channels); its first segment — the plain 16-bit
-    value — is contracted in place."""
+    value — is contracted in place.  eight_waves: the first 16-bit form of the kernel (VNQA_WGRAD_EIGHT_WAVES)."""
     N, Hp, Wp, Cin = x.shape
     Cout = dy.shape[-1]
     h, w = Hp - 2, Wp - 2
@@ -658,7 +661,8 @@ def conv2d_wgrad(x, dy, taps, want_bias=True, dbias_out=None, x_segs=1):
         dbias = dbias_out if (dbias_out is not None and dbias_out.numel() == Cout) else \
             torch.empty((Cout,), dtype=torch.float32, device=x.device)
     L.check(L.lib().vnqa_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dwt), L.ptr(dbias), L.ptr(ws), N, h, w, Cin, Cout,
-                                      taps, L.dtype_id(x.dtype) | {1: 0, 2: L.WGRAD_X_PAIR, 3: L.WGRAD_X_TRIPLE}[x_segs], L.stream()),
+                                      taps, L.dtype_id(x.dtype) | {1: 0, 2: L.WGRAD_X_PAIR, 3: L.WGRAD_X_TRIPLE}[x_segs] |
+                                      (L.WGRAD_EIGHT_WAVES if (eight_waves or WGRAD_EIGHT_WAVES) and L.is_half(x.dtype) else 0), L.stream()),
             "vnqa_conv2d_wgrad")
     return dwt, dbias
 
