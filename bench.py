@@ -775,6 +775,11 @@ def main():
                          "configs 3 and 5, mac is the remaining stem-consuming model of the same CLI")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: clips start in pinned host memory "
                     "and are copied to the GPU every step (on the stem stream); never the headline value")
+    ap.add_argument("--h2d-ablation", default=None, choices=["pinonly", "copyonly", "stem_no_wait", "copy_no_wait", "no_waits"],
+                    help="timing diagnostics of the PCIe-inclusive rate.  Without --h2d: the resident-input loop while the pinned staging clips "
+                    "merely exist / while one H2D copy per step runs into scratch buffers nobody reads.  With --h2d: the pipeline with the "
+                    "stem's wait for its clip's copy, the copy's wait for its buffer's last reader, or both left out (results are NOT "
+                    "valid training steps: the waits are what makes the pipeline correct)")
     ap.add_argument("--clip-dtype", default="f32", choices=["f32", "u8"], help="u8: synthetic clips are RAW 8-bit pixels (value "
                     "k / 255 as eval/dataset.py:91 forms it; VNQADataset(uint8_video=True)) — with --h2d a quarter of the PCIe bytes")
     ap.add_argument("--minibatches", type=int, default=4, help="distinct HBM-resident minibatches (own clips, questions, "
@@ -865,6 +870,13 @@ def main():
     batches = [synth_batch(args, rank, device, i) for i in range(NB)]
     if args.h2d:
         batches = [(b[0].cpu().pin_memory(),) + tuple(b[1:]) for b in batches]
+    # diagnostics of the PCIe-inclusive rate (tools/r05_h2d_ablation.sh): the resident-input loop with ONE ingredient of --h2d added
+    pinned_copies, scratch, scratch_stream = None, None, None
+    if args.h2d_ablation and not args.h2d:
+        pinned_copies = [b[0].cpu().pin_memory() for b in batches]       # 'pinonly': the pinned staging clips exist, nothing reads them
+        if args.h2d_ablation == "copyonly":                                # + one H2D copy per step into scratch buffers nobody reads
+            scratch = [torch.empty_like(batches[0][0]) for _ in range(3)]
+            scratch_stream = torch.cuda.Stream()
     batch = batches[0]
     step_no = [0]
 
@@ -877,6 +889,10 @@ def main():
     # following minibatch (side stream).  The timed region therefore contains exactly K stem passes
     # and K trunk passes: it starts with one stem already in flight from warm-up and ends having
     # produced one for the step after the region.  Steps rotate through the NB resident minibatches.
+    if args.h2d and args.h2d_ablation in ("stem_no_wait", "no_waits"):
+        trainer._diag_stem_no_wait = True
+    if args.h2d and args.h2d_ablation in ("copy_no_wait", "no_waits"):
+        trainer._diag_copy_no_wait = True
     if args.h2d:      # 3-stage input pipeline: H2D(i+2) on the copy engine | stem(i+1) | trunk(i)
         queue = [trainer.upload(batches[0][0]), trainer.upload(batches[1 % NB][0])]
 
@@ -897,7 +913,11 @@ def main():
             b, bn = batches[i % NB], batches[(i + 1) % NB]
             if args.no_overlap:
                 return trainer.step(*b)
-            return trainer.step(*b, next_clip=bn[0], next_v_lens_cpu=bn[2])
+            out = trainer.step(*b, next_clip=bn[0], next_v_lens_cpu=bn[2])
+            if scratch is not None:
+                with torch.cuda.stream(scratch_stream):
+                    scratch[i % 3].copy_(pinned_copies[(i + 2) % NB], non_blocking=True)
+            return out
     for _ in range(3):        # priming (lazy HIP attribute calls, allocator growth, pinned staging): not part of --warmup
         run_step()
     for _ in range(args.warmup):

@@ -26,7 +26,7 @@ class VideoOnlyCNN3D(nn.Module):
     bn_input / pool1 / bn1's statistics fused, pools with arg-max bytes, BatchNorm written into the next conv's padded input)
     plus the 27-tap igemm / small-channel wgrad kernels, and the classifier on vnqa_sgemm + the same BatchNorm kernels.
     precision='fp32' and other geometries (the reference's 160x208x35 clips: W = 35) take the generic path: convs on the
-    igemm / wgrad kernels through padded NDHWC, BatchNorm3d / MaxPool3d / FC on stock PyTorch-ROCm."""
+    igemm / wgrad kernels through padded NDHWC with BatchNorm3d / MaxPool3d on stock PyTorch-ROCm; the classifier is on library kernels in every precision."""
 
     def __init__(self, nb_classes, *, fc6_in_features=7680, precision='bf16'):
         super(VideoOnlyCNN3D, self).__init__()
@@ -75,15 +75,11 @@ class VideoOnlyCNN3D(nn.Module):
 
     def forward(self, inputs):
         """inputs fp32 [B,3,D,H,W] -> logits [B,nb_classes] (v_only_cnn3d.py:59-81)."""
-        fast = self._fast_ok(inputs)
         h = self.features(inputs).flatten(1)
-        if fast:                                  # classifier on vnqa_sgemm + the channel-last BatchNorm kernels
-            for fc, bn in ((self.fc6, self.bn6), (self.fc7, self.bn7)):
-                if self.training:
-                    with torch.no_grad():
-                        bn.num_batches_tracked += 1
-                h = ops.batch_norm_rows(ops.linear(h, fc.weight, fc.bias, relu=True), bn, self.training)
-            return ops.linear(h, self.fc8.weight, self.fc8.bias)
-        h = self.bn6(F.relu(self.fc6(h)))
-        h = self.bn7(F.relu(self.fc7(h)))
-        return self.fc8(h)
+        # classifier on vnqa_sgemm (exact fp32) + the channel-last BatchNorm kernels, in every precision
+        for fc, bn in ((self.fc6, self.bn6), (self.fc7, self.bn7)):
+            if self.training:
+                with torch.no_grad():
+                    bn.num_batches_tracked += 1
+            h = ops.batch_norm_rows(ops.linear(h, fc.weight, fc.bias, relu=True), bn, self.training)
+        return ops.linear(h, self.fc8.weight, self.fc8.bias)
