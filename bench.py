@@ -1110,7 +1110,7 @@ def main():
             "metric": METRIC, "value": round(clips, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp16": "f16", "fp16h": "f16 (fp16 storage, fp16 MFMA products, fp32 accumulate; split [hi | lo | hi] activations on the stem's last three tensors, conv31 / conv32 / conv_init as three products against split weights, 1x1 / fc_embed_attn with split weights)", "fp32": "f32"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp16h": "f16 (fp16 storage, fp16 MFMA products, fp32 accumulate; frozen stem weights second-order rounded on calibration frames; split [hi | lo] activations into conv31 / conv32 (two products each), split features and weights into conv_init (three products), conv_init's output split into its BatchNorm, 1x1 / fc_embed_attn with split weights)", "fp32": "f32"}[args.precision], "data": "synthetic",
             "repeats": {"n": len(regions), "value_is": "median region", "clips_per_s": [round(c, 1) for c in all_clips],
                         "spread_rel": round((max(all_clips) - min(all_clips)) / clips, 4)},
             "config": {"workload": "%s training step: VGG-16[:10]+ObjDetectCNN(512) frozen stem + "

@@ -55,3 +55,29 @@ def test_coherent_round_output_error_on_positive_inputs():
     coh = lambda e: float(e.mean((0, 2, 3)).pow(2).mean().sqrt())
     assert coh(e_coh) < 0.2 * coh(e_rtn)
     assert float(e_coh.pow(2).mean().sqrt()) < float(e_rtn.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_second_order_round_minimises_the_output_error_on_correlated_inputs(dt):
+    """stem.second_order_round (GPTQ-style sequential rounding against the patch second moment H): values on the 16-bit grid, within
+    a few grid steps of the exact weights, and dw^T H dw — the mean squared output error on inputs with that second moment — far below
+    round-to-nearest's and below coherent_round's on positive, spatially correlated inputs (what a post-ReLU layer sees)."""
+    import torch.nn.functional as F
+    from videonavqa_amd.stem import coherent_round, patch_second_moment, second_order_round
+    g = torch.Generator().manual_seed(3)
+    base = torch.rand(12, 4, 9, 9, generator=g)
+    mix = torch.rand(24, 4, generator=g)
+    x = F.relu(F.interpolate(torch.einsum("oc,nchw->nohw", mix, base), scale_factor=2, mode="bilinear") - 0.4) + 0.05      # [12, 24, 18, 18]
+    w = torch.randn(16, 24, 3, 3, generator=g) / 15
+    H = patch_second_moment(x, 3)
+    assert H.shape == (216, 216) and H.dtype == torch.float64 and torch.allclose(H, H.t())
+    q = second_order_round(w, H, dt)
+    assert q.shape == w.shape and torch.equal(q.to(dt).float(), q)
+    ulp = (w.abs().max() * (2.0 ** -10 if dt == torch.float16 else 2.0 ** -7))
+    assert float((q - w).abs().max()) < 8 * float(ulp)
+    err = lambda d: float(((d.reshape(16, -1).double() @ H) * d.reshape(16, -1).double()).sum())
+    rtn, coh, so = err(w.to(dt).float() - w), err(coherent_round(w, x.mean((0, 2, 3)), dt) - w), err(q - w)
+    assert so < 0.25 * rtn and so < 0.7 * coh, (so, coh, rtn)
+    y = F.conv2d(x, w, padding=1)
+    mse = lambda ww: float((F.conv2d(x, ww, padding=1) - y).pow(2).mean())
+    assert mse(q) < 0.3 * mse(w.to(dt).float())

@@ -345,6 +345,55 @@ def test_fp16h_stem_split_features_are_closer_to_exact_than_the_fp16_stem():
         torch.set_grad_enabled(True)
 
 
+def test_second_order_rounded_stem_weights_and_their_reproduction_from_a_checkpoint_calibration():
+    """The default calibration: stem.second_order_round against the patch second moments of CALIBRATION_FRAMES noise frames.
+    (a) the features of precision 'fp16' (every error of that stem is an activation or a weight rounding) are closer to the exact-f32
+    stem's than with round-to-nearest weights, on frames unlike the calibration frames too; (b) a stem rebuilt from the calibration
+    a checkpoint carries (`stem.calib`: the frames' name + the means) has bit-identical 16-bit weights; (c) a means-only calibration
+    (written before round 5) gives the first-order rounding and, in precision 'fp16h', the three-product layers; (d) with the
+    second-order weights conv31 / conv32 of 'fp16h' read [hi | lo] against doubled weights."""
+    import torch.nn.functional as F
+    from videonavqa_amd.models.common import FrameLayout
+    from videonavqa_amd.stem import FrozenStem
+    torch.set_grad_enabled(False)
+    try:
+        lay = FrameLayout([2, 1], 2, "cuda")
+        g = torch.Generator().manual_seed(15)
+        noise = torch.rand(2, 3, 224, 224, 2, generator=g).cuda()
+        low = torch.rand(4, 3, 14, 14, generator=g)
+        smooth = F.interpolate(low, size=(224, 224), mode="bilinear", align_corners=False).view(2, 2, 3, 224, 224).permute(0, 2, 3, 4, 1).contiguous().cuda()
+        vgg32, od32 = _random_stem("fp32")
+        ref = FrozenStem(vgg32, od32, "fp32")
+        vgg, od = _random_stem("fp16")
+        so, rtn = FrozenStem(vgg, od, "fp16"), FrozenStem(vgg, od, "fp16", calibration=None)
+        assert so.second_order and not rtn.second_order and so.calib["frames"] == "noise" and so._H is None
+        for clip in (noise, smooth):
+            r = ref.forward_clip(clip, lay.img_of, lay.n_img).double()[..., :512]
+            e_so = float((so.forward_clip(clip, lay.img_of, lay.n_img).double() - r).pow(2).mean())
+            e_rtn = float((rtn.forward_clip(clip, lay.img_of, lay.n_img).double() - r).pow(2).mean())
+            assert e_so < 0.9 * e_rtn, (e_so, e_rtn)
+        again = FrozenStem(vgg, od, "fp16", calibration=dict(so.calib))
+        assert again.second_order
+        for a, b in zip(so.layers_od + so.layers_vgg, again.layers_od + again.layers_vgg):
+            wa, wb = a["wt"], b["wt"]
+            assert torch.equal(wa.data if hasattr(wa, "data") and not torch.is_tensor(wa) else wa, wb.data if hasattr(wb, "data") and not torch.is_tensor(wb) else wb)
+        assert torch.equal(so.first[0], again.first[0])
+        means_only = {k: v for k, v in so.calib.items() if k != "frames"}
+        vggh, odh = _random_stem("fp16h")
+        h2, h3 = FrozenStem(vggh, odh, "fp16h"), FrozenStem(vggh, odh, "fp16h", calibration=means_only)
+        assert h2.second_order and not h3.second_order
+        assert h2.layers_od[4]["wt_split"].shape[2] == 2 * 512 and h3.layers_od[4]["wt_split"].shape[2] == 3 * 512
+        assert h2.layers_od[3]["split_out"] == 2 and h3.layers_od[3]["split_out"] == 3
+        r = ref.forward_clip(noise, lay.img_of, lay.n_img).double()[..., :512]
+        for st in (h2, h3):
+            f = st.forward_clip(noise, lay.img_of, lay.n_img)
+            assert f.shape[-1] == 1536
+            pair = f[..., :512].double() + f[..., 512:1024].double()
+            assert float((pair - r).abs().max()) < 3e-3 * float(r.abs().max())
+    finally:
+        torch.set_grad_enabled(True)
+
+
 def test_calibration_means_match_a_torch_fp32_pass():
     """stem.calibration_means (the library's exact-f32 stem with tapped layer outputs) against the same means from torch fp32
     convolutions of the reference layer sequence (VGG-16 features[0:10]; models/obj_detector.py:69-86 in eval mode)."""

@@ -228,7 +228,7 @@ def gather_eval_shards(per_batch, loss_sum, n_examples, world, device=None):
     return merged, sum(sh[1] for sh in shards), sum(sh[2] for sh in shards)
 
 
-def stem_calibration(args, dataset, n_frames=8):
+def stem_calibration(args, dataset, n_frames=40):
     """FrozenStem's `calibration` argument from --stem_calibration: 'noise' (seeded noise frames), None ('off': round-to-nearest) or
     [n_frames, 3, H, W] frames in [0, 1] from the FIRST items of `dataset` (the same on every rank) — the first valid frames of as many
     videos as it takes."""

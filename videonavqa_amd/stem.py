@@ -108,7 +108,7 @@ def coherent_round(w, m, dtype):
 
 
 @torch.no_grad()
-def calibration_means(vgg, od, frames=None, n_frames=4, height=224, width=224, seed=4242):
+def calibration_means(vgg, od, frames=None, n_frames=4, height=224, width=224, seed=4242, second_moments=False):
     """Per-input-channel mean activation at every stem layer's input — what coherent_round cancels against — from ONE pass of
     calibration frames [N, 3, H, W] (values in [0, 1]) through the library's own exact-f32 stem (a FrozenStem of precision 'fp32'
     with its layer outputs tapped).  Default frames: seeded uniform noise, the benchmark's kind of data; a deployment passes
@@ -137,7 +137,90 @@ def calibration_means(vgg, od, frames=None, n_frames=4, height=224, width=224, s
     c = od.conv12.out_channels
     m["od2"] = mean(("od", "c") if ref.composed is not None else ("od", 1), c)
     m["od3"], m["od4"], m["od5"] = mean(("od", 2), od.conv21.out_channels), mean(("od", 3), c), mean(("od", 4), od.conv31.out_channels)
+    if second_moments:
+        # ... and the second moment of every layer's input PATCHES (what second_order_round minimises against), on the device; od1
+        # (conv12's input when the pair runs layer by layer) is not stored by the composed pass: that layer keeps coherent_round
+        def nchw(key, c_, halo=1):
+            t = ref._tap[key]
+            return t[:, halo:t.shape[1] - halo, halo:t.shape[2] - halo, :c_].permute(0, 3, 1, 2)
+        halo2 = 2 if ref.composed is not None else 1
+        H = {"first": patch_second_moment(frames, 3), "vgg0": patch_second_moment(nchw("first", 64), 3),
+             "vgg1": patch_second_moment(nchw(("vgg", 0), 64), 3), "vgg2": patch_second_moment(nchw(("vgg", 1), 128), 3),
+             "od0": patch_second_moment(nchw(("vgg", 2), 128, halo2), 3), "od3": patch_second_moment(nchw(("od", 2), od.conv21.out_channels), 3),
+             "od4": patch_second_moment(nchw(("od", 3), c), 3), "od5": patch_second_moment(nchw(("od", 4), od.conv31.out_channels), 3)}
+        if ref.composed is not None:
+            H["od0_5x5"] = patch_second_moment(nchw(("vgg", 2), 128, halo2), 5)
+            H["od2"] = patch_second_moment(nchw(("od", "c"), c), 3)
+        else:
+            H["od2"] = patch_second_moment(nchw(("od", 1), c), 3)
+        m["_H"] = H
     return m
+
+
+@torch.no_grad()
+def second_order_round(w, H, dtype, damp=0.01, block=128):
+    """Weights w [c_out, c_in, kh, kw] (fp32) rounded to `dtype` (a 16-bit format) against the SECOND MOMENT H = E[p p^T] (float64
+    [K, K], K = c_in * kh * kw in w.reshape(c_out, -1)'s order) of the layer's input patches p: E[(p . dw)^2] = dw^T H dw, the mean
+    squared error the rounding adds to the layer's output, is minimised greedily — column by column in order of decreasing H_jj, the
+    rounding error of column j is pushed onto the not yet rounded columns along H^-1 before they are rounded (the GPTQ / OBQ
+    sequential rounding, here onto the fp16 / bf16 grid).  coherent_round cancels the error against the MEAN patch only (first
+    moment); on the frozen stem this form leaves 1/8 of its squared logits error on clips like the calibration frames and 0.43 of it
+    on clips unlike them (tools/experiments/gptq_stem_weights.py, profiles/r05_gptq_stem_weights.txt) — little enough that
+    precision 'fp16h' no longer spends a product on conv31's / conv32's weight roundings.  Returns fp32 values exactly
+    representable in `dtype`.  Deterministic for given inputs (fp64 Cholesky + fixed-order updates)."""
+    co = w.shape[0]
+    W = w.detach().reshape(co, -1).double().clone()
+    K_ = W.shape[1]
+    H = H.to(W.device).double().clone()
+    d = torch.diagonal(H)
+    dead = d == 0                                   # inputs that are always zero (padded channels): any rounding is free
+    d[dead] = 1.0
+    perm = torch.argsort(torch.diagonal(H), descending=True)
+    W = W[:, perm]
+    H = H[perm][:, perm]
+    H += torch.eye(K_, dtype=H.dtype, device=H.device) * (damp * float(torch.diagonal(H).mean()))
+    U = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
+    Q = torch.zeros_like(W)
+    for b0 in range(0, K_, block):
+        b1 = min(b0 + block, K_)
+        Wb = W[:, b0:b1].clone()
+        Eb = torch.zeros_like(Wb)
+        Ub = U[b0:b1, b0:b1]
+        for j in range(b1 - b0):
+            wj = Wb[:, j]
+            q = wj.float().to(dtype).double()
+            Q[:, b0 + j] = q
+            e = (wj - q) / Ub[j, j]
+            Wb[:, j:] -= e.unsqueeze(1) * Ub[j, j:].unsqueeze(0)
+            Eb[:, j] = e
+        W[:, b1:] -= Eb @ U[b0:b1, b1:]
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(K_, device=perm.device)
+    return Q[:, inv].float().view_as(w)
+
+
+@torch.no_grad()
+def patch_second_moment(x, k, max_rows=400000):
+    """H = E[p p^T] (float64 [K, K], K = C k k, channel-major / taps minor) over the k x k 'same'-padded patches of x [N, C, H, W];
+    positions of large maps are subsampled (seeded) to about max_rows."""
+    N, C, Hh, Ww = x.shape
+    K_ = C * k * k
+    H = torch.zeros(K_, K_, dtype=torch.float64, device=x.device)
+    per = Hh * Ww
+    stride = max(1, (N * per + max_rows - 1) // max_rows)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    rows = 0
+    for n in range(N):
+        p = torch.nn.functional.unfold(x[n:n + 1].float(), k, padding=k // 2)[0].t()
+        if stride > 1:
+            p = p[torch.randperm(per, generator=g)[:per // stride].to(x.device)]
+        p = p.double()
+        H += p.t() @ p
+        rows += p.shape[0]
+    return H / max(rows, 1)
+
+
+CALIBRATION_FRAMES = 40      # frames of the default ("noise") calibration pass: 40 x 196 patches > K = 4608 of the 14 x 14 layers
 
 
 def _fold_bn(bn):
@@ -150,22 +233,30 @@ class FrozenStem(object):
     """Execution plan (packed weights + persistent activation buffers) for the frozen stem.
 
     precision: 'bf16' | 'fp16' (16-bit storage, fp32 accumulate: the MFMA fast path), 'fp32' (the exact-f32 parity path), or
-    'fp16h' — the tolerance mode (round 5): the fp16 precision's stem, same kernels and coherently rounded weights, except that the
-    LAST THREE stored activations (conv22's pooled output, conv31's, conv32's = the features) are SPLIT tensors [hi | lo | hi]
-    (hi = fp16(v), lo = fp16(v - hi), written by the patch-stationary kernel's dual epilogue) and conv31 / conv32 are plain convs
-    over 3 C input channels against split exact weights [w_hi | w_hi | w_lo] — x_hi w_hi + x_lo w_hi + x_hi w_lo.  The three stem
-    activation roundings and the two weight roundings that weigh most in the logits error (profiles/r05_precision_budget*.txt: 0.047 /
-    0.047 / 0.073 and 0.022 / 0.041 of the fp16 precision's 0.70e-6 squared error) are gone for two extra products on the two
-    CHEAPEST layers (14 x 14 maps).  split_features=False keeps the features a plain fp16 tensor (consumers that read no split
-    tensors: MACNetwork, the per-module drop-in path).
+    'fp16h' — the tolerance mode (round 5): the fp16 precision's stem, same kernels and rounded weights, except that the LAST THREE
+    stored activations (conv22's pooled output, conv31's, conv32's = the features) are SPLIT tensors (hi = fp16(v), lo = fp16(v - hi),
+    written by the patch-stationary kernel's dual epilogue): conv31 / conv32 are plain convs over 2 C input channels [hi | lo]
+    against the doubled 16-bit weights [wq | wq] — x_hi wq + x_lo wq, the unrounded activation in two products — and the features
+    go out as [hi | lo | hi] for conv_init's three products (its weights are trainable and split per step).  The three activation
+    roundings that weigh most in the logits error (profiles/r05_precision_budget*.txt: 0.047 / 0.047 / 0.073 of the fp16 precision's
+    0.70e-6 squared error) are gone for one extra product on the two CHEAPEST layers (14 x 14 maps); the weight roundings of those
+    layers (0.022 / 0.041 rounded coherently) are 0.0003 / 0.0002 with the second-order rounding below.  Without a calibration
+    (None, or a means-only dict from an older checkpoint) the split-reading layers run as three products over [hi | lo | hi] against
+    split exact weights [w_hi | w_hi | w_lo] instead.  split_features=False keeps the features a plain fp16 tensor (consumers that
+    read no split tensors: MACNetwork, the per-module drop-in path).
 
-    calibration: how the frozen 16-bit weights are rounded.  None = round-to-nearest; a dict = the means of an earlier
-    calibration_means() pass (a checkpoint's `extra_state['_stem_calibration']`: the test-time stem gets the weights the model was
-    trained behind); "noise" or a tensor of frames [N, 3, H, W] = coherent_round against the mean input activations measured on those
-    frames: each output channel's rounding errors cancel against the mean input — the part of the weight-rounding error that is a
-    constant offset per channel and survives every later pooling.  Same kernels, same bytes; at the headline size on 12 minibatches the
-    fp16 precision's rms logits error goes 1.21e-3 -> 0.88e-3, bf16 9.0e-3 -> 7.1e-3.  "auto" = "noise" for every 16-bit precision
-    (one exact-f32 stem pass over 4 frames at construction); VNQA_COHERENT_ROUND=0 turns it off."""
+    calibration: how the frozen 16-bit weights are rounded.  None = round-to-nearest.  "noise" or a tensor of frames [N, 3, H, W]
+    (values in [0, 1]) = ONE exact-f32 stem pass over those frames (CALIBRATION_FRAMES seeded noise frames by default) measures every
+    layer's input-patch second moment H = E[p p^T], and each layer's weights (BatchNorm scale folded, the conv11.conv12 pair composed)
+    are rounded by second_order_round: column by column, the rounding error pushed onto the not yet rounded columns along H^-1, which
+    greedily minimises dw^T H dw — the mean squared error the rounding adds to the layer's output.  (Round 4's coherent_round cancels the
+    error against the MEAN input only; it remains the form for layers without a measured H and for means-only calibrations.)
+    Squared logits error of all nine stem weight roundings, x 1e-6 at the headline size: round-to-nearest 0.58, coherent 0.074, second
+    order 0.009 on clips like the calibration frames; 0.34 / 0.116 / 0.050 on smooth clips with noise calibration
+    (profiles/r05_gptq_stem_weights.txt).  Same kernels, same bytes; ~3 s at construction.  A dict = an earlier calibration (a
+    checkpoint's `extra_state['_stem_calibration']`: its "frames" entry — "noise" or the frames — is what the rounding is redone
+    from, so the test-time stem gets the weights the model was trained behind).  "auto" = "noise" for every 16-bit precision;
+    VNQA_COHERENT_ROUND=0 turns it off."""
 
     def __init__(self, vgg, objdet, precision='bf16', calibration="auto", split_features=True, reserve_cus=0):
         from .models.common import compute_dtype
@@ -186,17 +277,28 @@ class FrozenStem(object):
         self._tap = None     # calibration hook: {layer key: output tensor} filled by _run / _run_composed
         if isinstance(calibration, str) and calibration == "auto":
             calibration = "noise" if os.environ.get("VNQA_COHERENT_ROUND") != "0" else None
-        if isinstance(calibration, dict):      # calibration means computed earlier (a checkpoint's: eval/q_and_v_test.py)
-            self.calib = {k: torch.as_tensor(v).float().cpu() for k, v in calibration.items()} if precision != "fp32" else None
-        elif calibration is not None and vgg is not None and objdet is not None and precision != "fp32" and \
-                vgg.features["0"].weight.is_cuda:
-            self.calib = calibration_means(vgg, objdet, None if isinstance(calibration, str) else calibration)
-        cm = lambda k: None if self.calib is None else self.calib[k]
+        self._H = None       # second moments of every layer's input patches (device, float64): alive during construction only
+        frames = None
+        if isinstance(calibration, dict):      # an earlier calibration (a checkpoint's: eval/q_and_v_test.py)
+            if precision != "fp32":
+                self.calib = {k: (v if isinstance(v, str) else torch.as_tensor(v).float().cpu()) for k, v in calibration.items()}
+                # ... made from these frames: the second-order rounding is redone from them (same frames + same frozen weights = the
+                # same 16-bit weights the model was trained behind); a calibration without frames (written before round 5) has the
+                # means only and gets the first-order rounding it was made for
+                frames = self.calib.get("frames")
+        elif calibration is not None and precision != "fp32":
+            frames = calibration
+        if frames is not None and vgg is not None and objdet is not None and vgg.features["0"].weight.is_cuda:
+            noise = isinstance(frames, str)
+            st = calibration_means(vgg, objdet, None if noise else frames, n_frames=CALIBRATION_FRAMES, second_moments=True)
+            self._H = st.pop("_H")
+            self.calib = st
+            self.calib["frames"] = "noise" if noise else torch.as_tensor(frames).float().cpu()
+        self.second_order = self._H is not None
+        cm = lambda k: k if self.calib is not None else None
         if vgg is not None:
             f = vgg.features
-            w0 = f["0"].weight.detach().float().contiguous()
-            if self.calib is not None:
-                w0 = coherent_round(w0, cm("first"), L.half_dtype()).contiguous()
+            w0 = self._round(f["0"].weight.detach().float().contiguous(), cm("first"), L.half_dtype()).contiguous()
             self.first = (w0, f["0"].bias.detach().float().contiguous())
             self.layers_vgg = [self._layer(f["2"], relu=True, pool=True, m=cm("vgg0")),
                                self._layer(f["5"], relu=True, pool=False, m=cm("vgg1")),
@@ -211,15 +313,21 @@ class FrozenStem(object):
                               self._layer(od.conv31, m=cm("od4")),
                               self._layer(od.conv32, bn=od.bn3, relu=True, pool=False, m=cm("od5"))]
             if self.hyb:
-                # conv22 writes [hi | lo | hi], conv31 reads it and writes the same, conv32 reads it and writes the split features
-                # [hi | lo | hi] for conv_init — or a plain tensor for consumers that read no split tensors.  A split-reading layer is
-                # a plain conv over 3 C input channels against the SPLIT exact weights [w_hi | w_hi | w_lo] (BatchNorm folded in fp32
-                # first): neither the layer's input rounding nor its weight rounding is left
-                for ly, rd, wr in zip(self.layers_od[3:], (False, True, True), (3, 3, 3 if self.split_features else 0)):
+                # conv22 writes a SPLIT tensor, conv31 reads it and writes one, conv32 reads it and writes the split features
+                # [hi | lo | hi] for conv_init (or a plain tensor for consumers that read no split tensors).
+                #  * second-order rounded weights (the default: calibration frames given): the 16-bit weights wq are within 1e-8 of
+                #    exact in the squared logits error, so a split-reading layer is TWO products — a plain conv over 2 C input
+                #    channels [hi | lo] against [wq | wq];
+                #  * otherwise (calibration off / a means-only calibration): THREE products over [hi | lo | hi] against the split
+                #    exact weights [w_hi | w_hi | w_lo] (BatchNorm folded in fp32 first).
+                segs = 2 if self.second_order else 3
+                for ly, rd, wr in zip(self.layers_od[3:], (False, True, True), (segs, segs, 3 if self.split_features else 0)):
                     if "wt_ps" in ly:
                         ly["split_out"] = wr
-                        if rd:
-                            ly["wt_ps3"] = K.split_weight3(ly.pop("wt32ps"))
+                        if rd and segs == 3:
+                            ly["wt_split"] = K.split_weight3(ly["wt32ps"])
+                        elif rd:
+                            ly["wt_split"] = torch.cat([ly["wt_ps"], ly["wt_ps"]], dim=2).contiguous()
                     ly.pop("wt32ps", None)
             # conv12 is applied straight to conv11's output (obj_detector.py:72: no nonlinearity between the two convs of
             # a pair) and both are frozen: when the pair's 3x3 (c_in -> c_mid) . 3x3 (c_mid -> c_out) costs more than one
@@ -236,6 +344,18 @@ class FrozenStem(object):
                 if self.composed is not None:
                     self.layers_vgg[-1]["y_halo"] = 2        # the composed 5x5 conv reads a halo-2 image
 
+        self._H = None       # (0.8 GB of float64 moments: construction only)
+
+    def _round(self, w, key, dtype):
+        """The frozen weights `w` (fp32, BatchNorm scale folded) as the values the 16-bit kernels multiply with: second-order rounded
+        when the calibration pass left the layer's patch moments, else rounded coherently against the mean input, else unchanged
+        (the pack kernel rounds to nearest)."""
+        if key is None or self.calib is None:
+            return w
+        if self._H is not None and key in self._H and self._H[key].shape[0] == w[0].numel():
+            return second_order_round(w, self._H[key], dtype)
+        return coherent_round(w, self.calib[key], dtype) if key in self.calib else w
+
     def _layer(self, conv, bn=None, relu=False, pool=False, m=None):
         w = conv.weight.detach().float()
         b = conv.bias.detach().float()
@@ -249,7 +369,7 @@ class FrozenStem(object):
         w32, scale32 = w, scale
         if m is not None and half:
             # (the BN scale folded first: the values the kernel multiplies with are the ones rounded)
-            w = coherent_round(w if scale is None else w * scale.view(-1, 1, 1, 1), m, self.cdt)
+            w = self._round(w if scale is None else w * scale.view(-1, 1, 1, 1), m, self.cdt)
             scale = None
         if half and c_in_pad == 64:
             tile = None                      # conv_c64 direct kernel (row layout, LDS-resident weights)
@@ -309,7 +429,7 @@ class FrozenStem(object):
         tile = L.TILE_STEM_256x256 if (half and co_pad >= 256) else (L.TILE_AUTO if half else L.TILE_128x128)
         wcf = wc.float().contiguous().to(dev)
         if self.calib is not None and half:
-            wcf = coherent_round(wcf, self.calib["od0"], self.cdt).contiguous()
+            wcf = self._round(wcf, "od0_5x5" if (self._H is not None and "od0_5x5" in self._H) else "od0", self.cdt).contiguous()
         if tile == L.TILE_STEM_256x256:
             wt = K.pack_conv_weight_tiled(wcf, self.cdt, tile, c_out_pad=co_pad, c_in_pad=ci_pad)
         else:
@@ -378,14 +498,14 @@ class FrozenStem(object):
 
     def _split_geometry_ok(self, n, h, w, ly):
         """The split path of precision 'fp16h' needs the patch-stationary kernel on conv22 (h x w maps, pooled) AND on conv31 / conv32
-        (h/2 x w/2 maps, 3 C input channels): asked of the library once per geometry.  Where it does not serve them (the 10 x 13 maps
+        (h/2 x w/2 maps, 2 C or 3 C input channels): asked of the library once per geometry.  Where it does not serve them (the 10 x 13 maps
         of the reference's 160 x 208 frames) the three layers run exactly as in precision 'fp16'."""
         key = (n, h, w)
         ok = self._split_ok.get(key)
         if ok is None:
             c = ly["c_out_pad"]
             ok = self._split_ok[key] = bool(ly["pool"] and K.conv_ps_supported(n, h, w, c, c, 9, True) and
-                                            K.conv_ps_supported(n, h // 2, w // 2, 3 * c, c, 9, False))
+                                            K.conv_ps_supported(n, h // 2, w // 2, (2 if self.second_order else 3) * c, c, 9, False))
         return ok
 
     def _run(self, x, layers, tag, last_slot=0, first_index=0):
@@ -397,9 +517,10 @@ class FrozenStem(object):
             last = not (i + 1 < len(layers) + first_index)
             key = (tag, i, ho, wo) if not last else (tag, i, ho, wo, last_slot)
             # precision 'fp16h': [hi | lo | hi] tensors between conv22, conv31, conv32 and the trunk (see the class docstring)
-            split_rd = "wt_ps3" in ly and x.shape[-1] == ly["wt_ps3"].shape[2]
+            split_rd = "wt_split" in ly and x.shape[-1] == ly["wt_split"].shape[2]
             split_wr = int(ly.get("split_out", 0))
-            if split_wr and not (yh == 1 and (split_rd if "wt_ps3" in ly else self._split_geometry_ok(n, h, w, ly))):
+            x_segs = x.shape[-1] // ly["c_out_pad"] if split_rd else 1      # (c_in == c_out on the split-reading layers)
+            if split_wr and not (yh == 1 and (split_rd if "wt_split" in ly else self._split_geometry_ok(n, h, w, ly))):
                 split_wr = 0
             out = self._buf(key + (("split",) if split_wr else ()), (n, ho + 2 * yh, wo + 2 * yh, max(split_wr, 1) * ly["c_out_pad"]))
             post = ly["post"]
@@ -412,7 +533,7 @@ class FrozenStem(object):
                 ev0.record()
             if split_rd or split_wr:
                 kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)
-                x = K.conv2d_igemm(x, ly["wt_ps3"] if split_rd else ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
+                x = K.conv2d_igemm(x, ly["wt_split"] if split_rd else ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                    post_scale=ps, post_shift=pt, out=out, tile=L.TILE_STEM_PS_224x256, y_halo=yh, dual_out=split_wr)
             elif "wt_rows" in ly and K.conv2d_wreg_supported(x, ly["wt_rows"], pool2=ly["pool"], y_halo=yh):
                 x = K.conv2d_wreg(x, ly["wt_rows"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"], post_scale=ps, post_shift=pt,
@@ -430,7 +551,7 @@ class FrozenStem(object):
                                    out=out, tile=tile, y_halo=yh)
             if timed:
                 ev1.record()
-                self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9 * (3 if split_rd else 1), kname))
+                self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9 * (x_segs if split_rd else 1), kname))
             if self._tap is not None:
                 self._tap[(tag, i)] = x
         return x

@@ -362,9 +362,10 @@ class Trainer(object):
             out["_loss_scale"] = dict(self.loss_scaler.state_dict())
         calib = getattr(self.stem, "calib", None)
         if calib is not None:
-            # the means the frozen stem's 16-bit weights were rounded against (stem.coherent_round): the test-time stem is rebuilt
-            # from them, so a model is tested behind the very stem weights it was trained behind
-            out["_stem_calibration"] = {k: v.detach().cpu().clone() for k, v in calib.items()}
+            # what the frozen stem's 16-bit weights were rounded against (stem.second_order_round / coherent_round): the calibration
+            # FRAMES ("noise" = the seeded default, else the tensor of frames) and the input means measured on them — the test-time
+            # stem redoes the rounding from them, so a model is tested behind the very stem weights it was trained behind
+            out["_stem_calibration"] = {k: (v if isinstance(v, str) else v.detach().cpu().clone()) for k, v in calib.items()}
         return out
 
     def load_checkpoint(self, ckpt):
