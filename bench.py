@@ -264,12 +264,12 @@ def fp16_leg(args, precision="fp16"):
             return {"error": (r.stderr or "no output").strip()[-300:]}
         d = json.loads(line[-1])
         p = d.get("parity", {})
-        what = ("bench.py --precision fp16 (plain fp16 storage, fp32 accumulate, dynamic loss scale from 2^10; the frozen stem's weights rounded "
-                "coherently like in every 16-bit precision): NOT tolerance-compliant — rms logits error 0.6-1.0e-3 by weight seed, worst "
-                "minibatch 1.27e-3 (profiles/r05_precision_budget.txt); %d timed steps, child process") % d["steps"]
+        what = ("bench.py --precision fp16 (plain fp16 storage, fp32 accumulate, dynamic loss scale from 2^10; the frozen stem's weights "
+                "second-order rounded like in every 16-bit precision): NOT tolerance-compliant — rms logits error 0.6-0.95e-3 by weight seed, worst "
+                "minibatch 1.19e-3 (profiles/r05_second_order_stem.txt); %d timed steps, child process") % d["steps"]
         if precision == "bf16":
-            what = ("bench.py --precision bf16: BASELINE.json's storage dtype (bf16 storage, fp32 accumulate; the frozen stem's weights rounded "
-                    "coherently like in every 16-bit precision) — the round 1-4 headline, NOT tolerance-compliant (logits ~6-7e-3 of exact "
+            what = ("bench.py --precision bf16: BASELINE.json's storage dtype (bf16 storage, fp32 accumulate; the frozen stem's weights "
+                    "second-order rounded like in every 16-bit precision) — the round 1-4 headline, NOT tolerance-compliant (logits ~6-7e-3 of exact "
                     "fp32, 21-23 of 24 answer classes at random initialisation); %d timed steps, child process") % d["steps"]
         key = precision + "_logits_rel_err"
         return {"what": what, "precision": precision,
@@ -756,8 +756,9 @@ def main():
                     "the reported value / ms_per_step are the MEDIAN region's, all regions are listed in `repeats`")
     ap.add_argument("--precision", default="fp16h", choices=["bf16", "fp16", "fp16h", "fp32"],
                     help="fp16h (default, the headline): the TOLERANCE-COMPLIANT precision — fp16 storage and fp16 MFMA products with fp32 "
-                         "accumulation like 'fp16', plus split [hi | lo | hi] activations on the stem's last three tensors, conv31 / conv32 / "
-                         "conv_init as three products against split weights, the frozen 1x1 conv and fc_embed_attn with split weights: logits "
+                         "accumulation like 'fp16', plus split activations on the stem's last three tensors (conv31 / conv32 as two products on "
+                         "[hi | lo] against their second-order rounded weights, conv_init as three against split weights), conv_init's output "
+                         "split into its BatchNorm, the frozen 1x1 conv and fc_embed_attn with split weights: logits "
                          "within north star's 1e-3 of exact fp32 on 4 weight seeds x 12 minibatches; bf16: BASELINE.json's storage dtype "
                          "(7e-3, a leg of the default line); fp16: plain fp16 storage (0.6-1.0e-3 rms by weight seed, a leg); fp32: the exact-f32 "
                          "parity precision")

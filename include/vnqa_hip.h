@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 421
+#define VNQA_ABI_VERSION 422
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -142,6 +142,12 @@ int vnqa_conv2d_igemm_fwd(const vnqa_conv_desc* d, const void* x, const void* wt
 int vnqa_conv2d_igemm_fwd_ex(const vnqa_conv_desc* d, const void* x, const void* wt, const float* bias,
                              const float* post_scale, const float* post_shift, const void* border_sub,
                              void* y, void* stream);
+
+/* Second-order rounding of FROZEN weights onto this build's 16-bit grid (stem.second_order_round; the GPTQ / OBQ sequential rounding):
+ * w [rows][k] float64 (one row per output channel, columns in rounding order), u [k][k] float64 = the upper Cholesky factor of H^-1 of the
+ * layer's (damped, equally permuted) input-patch second moment; per row, j = 0 .. k-1: q_j = h16(w_j), e = (w_j - q_j) / u_jj,
+ * w_t -= e u_jt for t > j.  q [rows][k] fp32 receives the rounded values (exactly representable in the 16-bit format).  k <= 16384. */
+int vnqa_second_order_round(const double* w, const double* u, float* q, int32_t rows, int32_t k, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Split operands (precision 'fp16h', csrc/split3.hip): v = hi + lo, hi = h16(v), lo = h16(v - hi) — an fp32 contraction on the 16-bit

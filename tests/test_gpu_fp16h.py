@@ -345,6 +345,26 @@ def test_fp16h_stem_split_features_are_closer_to_exact_than_the_fp16_stem():
         torch.set_grad_enabled(True)
 
 
+def test_second_order_round_kernel_matches_the_tensor_recursion():
+    """vnqa_second_order_round (one workgroup per output channel, the row in LDS as float64) against the same recursion in host tensor
+    arithmetic (blocked updates: another fp64 summation order): same grid, the same objective dw^T H dw."""
+    from videonavqa_amd.stem import patch_second_moment, second_order_round
+    g = torch.Generator().manual_seed(21)
+    x = torch.relu(torch.randn(6, 40, 12, 12, generator=g)) + 0.1
+    w = torch.randn(24, 40, 3, 3, generator=g) / 19
+    H = patch_second_moment(x, 3)
+    q_host = second_order_round(w, H, torch.float16)
+    q_dev = second_order_round(w.cuda(), H.cuda(), torch.float16).cpu()
+    assert torch.equal(q_dev.half().float(), q_dev)
+    err = lambda d: float(((d.reshape(24, -1).double() @ H) * d.reshape(24, -1).double()).sum())
+    # (the greedy recursion amplifies a one-ulp difference of the fp64 sums into other roundings downstream: the two results are
+    # different, equally good members of the same family — same objective to 15 %, both far below round-to-nearest, each within one
+    # grid step of the running value it rounded)
+    assert abs(err(q_dev - w) - err(q_host - w)) < 0.15 * err(q_host - w), (err(q_dev - w), err(q_host - w))
+    assert err(q_dev - w) < 0.4 * err(w.half().float() - w) and err(q_host - w) < 0.4 * err(w.half().float() - w)
+    assert float((q_dev - w).abs().max()) < 8 * float(w.abs().max()) * 2.0 ** -10
+
+
 def test_second_order_rounded_stem_weights_and_their_reproduction_from_a_checkpoint_calibration():
     """The default calibration: stem.second_order_round against the patch second moments of CALIBRATION_FRAMES noise frames.
     (a) the features of precision 'fp16' (every error of that stem is an activation or a weight rounding) are closer to the exact-f32

@@ -36,7 +36,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 421          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 422          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -140,6 +140,7 @@ _SIGNATURES = {
     "vnqa_nhwc_to_nchw": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_frame_bn_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_frame_bn_apply": (ctypes.c_int, [_vp] * 7 + [_i32] * 5 + [_vp]),
+    "vnqa_second_order_round": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "vnqa_frame_bn_stats_split": (ctypes.c_int, [_vp] * 5 + [_i32] * 4 + [_vp]),
     "vnqa_frame_bn_apply_split": (ctypes.c_int, [_vp] * 8 + [_i32] * 4 + [_vp]),
     "vnqa_frame_bn_bwd": (ctypes.c_int, [_vp] * 10 + [_i32] * 7 + [_vp]),

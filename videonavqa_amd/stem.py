@@ -172,6 +172,8 @@ def second_order_round(w, H, dtype, damp=0.01, block=128):
     W = w.detach().reshape(co, -1).double().clone()
     K_ = W.shape[1]
     H = H.to(W.device).double().clone()
+    if not bool(torch.isfinite(H).all()) or float(torch.diagonal(H).sum()) <= 0.0:      # no signal on the calibration frames: nearest
+        return w.detach().float().to(dtype).float()
     d = torch.diagonal(H)
     dead = d == 0                                   # inputs that are always zero (padded channels): any rounding is free
     d[dead] = 1.0
@@ -180,20 +182,27 @@ def second_order_round(w, H, dtype, damp=0.01, block=128):
     H = H[perm][:, perm]
     H += torch.eye(K_, dtype=H.dtype, device=H.device) * (damp * float(torch.diagonal(H).mean()))
     U = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
-    Q = torch.zeros_like(W)
-    for b0 in range(0, K_, block):
-        b1 = min(b0 + block, K_)
-        Wb = W[:, b0:b1].clone()
-        Eb = torch.zeros_like(Wb)
-        Ub = U[b0:b1, b0:b1]
-        for j in range(b1 - b0):
-            wj = Wb[:, j]
-            q = wj.float().to(dtype).double()
-            Q[:, b0 + j] = q
-            e = (wj - q) / Ub[j, j]
-            Wb[:, j:] -= e.unsqueeze(1) * Ub[j, j:].unsqueeze(0)
-            Eb[:, j] = e
-        W[:, b1:] -= Eb @ U[b0:b1, b1:]
+    if W.is_cuda:      # one launch per layer (csrc/round2.hip: a workgroup per output channel, the row in LDS as float64)
+        assert dtype == L.half_dtype(), "the library rounds onto ITS 16-bit format (one format per process)"
+        Qf = torch.empty(W.shape, dtype=torch.float32, device=W.device)
+        Wc, Uc = W.contiguous(), U.contiguous()
+        L.check(L.lib().vnqa_second_order_round(L.ptr(Wc), L.ptr(Uc), L.ptr(Qf), co, K_, L.stream()), "vnqa_second_order_round")
+        Q = Qf.double()
+    else:              # the same recursion in tensor arithmetic (host tensors: tests/test_coherent_round.py)
+        Q = torch.zeros_like(W)
+        for b0 in range(0, K_, block):
+            b1 = min(b0 + block, K_)
+            Wb = W[:, b0:b1].clone()
+            Eb = torch.zeros_like(Wb)
+            Ub = U[b0:b1, b0:b1]
+            for j in range(b1 - b0):
+                wj = Wb[:, j]
+                q = wj.float().to(dtype).double()
+                Q[:, b0 + j] = q
+                e = (wj - q) / Ub[j, j]
+                Wb[:, j:] -= e.unsqueeze(1) * Ub[j, j:].unsqueeze(0)
+                Eb[:, j] = e
+            W[:, b1:] -= Eb @ U[b0:b1, b1:]
     inv = torch.empty_like(perm)
     inv[perm] = torch.arange(K_, device=perm.device)
     return Q[:, inv].float().view_as(w)
