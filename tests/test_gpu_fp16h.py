@@ -398,6 +398,8 @@ def test_second_order_rounded_stem_weights_and_their_reproduction_from_a_checkpo
             wa, wb = a["wt"], b["wt"]
             assert torch.equal(wa.data if hasattr(wa, "data") and not torch.is_tensor(wa) else wa, wb.data if hasattr(wb, "data") and not torch.is_tensor(wb) else wb)
         assert torch.equal(so.first[0], again.first[0])
+        plan = so.packed_tensors()       # what Trainer.sync_replicas broadcasts from rank 0: every device tensor of the plan, once
+        assert len(plan) >= 20 and all(t.is_cuda for t in plan) and len({t.data_ptr() for t in plan}) == len(plan)
         means_only = {k: v for k, v in so.calib.items() if k != "frames"}
         vggh, odh = _random_stem("fp16h")
         h2, h3 = FrozenStem(vggh, odh, "fp16h"), FrozenStem(vggh, odh, "fp16h", calibration=means_only)

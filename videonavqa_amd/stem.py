@@ -355,6 +355,29 @@ class FrozenStem(object):
 
         self._H = None       # (0.8 GB of float64 moments: construction only)
 
+    def packed_tensors(self):
+        """Every device tensor of the execution plan (packed / tiled / split weights, biases, the ring operands): what a data-parallel
+        run broadcasts from rank 0 (Trainer.sync_replicas) so that all replicas multiply with bit-identical 16-bit stem weights even if
+        a rank's calibration pass rounded one tie the other way."""
+        out, seen = [], set()
+
+        def walk(v):
+            if isinstance(v, K.TiledWeight):
+                v = v.data
+            if torch.is_tensor(v):
+                if v.is_cuda and v.data_ptr() not in seen:
+                    seen.add(v.data_ptr())
+                    out.append(v)
+            elif isinstance(v, dict):
+                for x in v.values():
+                    walk(x)
+            elif isinstance(v, (list, tuple)):
+                for x in v:
+                    walk(x)
+        for part in (self.first, self.layers_vgg, self.layers_od, self.composed, getattr(self, "bn_input", None)):
+            walk(part)
+        return out
+
     def _round(self, w, key, dtype):
         """The frozen weights `w` (fp32, BatchNorm scale folded) as the values the 16-bit kernels multiply with: second-order rounded
         when the calibration pass left the layer's patch moments, else rounded coherently against the mean input, else unchanged

@@ -334,6 +334,9 @@ class Trainer(object):
         """Rank 0's weights everywhere, INCLUDING the frozen unregistered conv1x1 layers
         (which state_dict() does not carry)."""
         sync_replicas(list(self.model.state_dict().values()) + list(self.model.extra_state_tensors().values()))
+        plan = getattr(self.stem, "packed_tensors", None)       # the frozen stem's rounded 16-bit weights (stem.FrozenStem)
+        if plan is not None:
+            sync_replicas([t for t in plan() if t.is_contiguous()])
 
     # ---- checkpoint interface with torch.optim.Adam's state_dict layout (eval/q_and_v_eval.py:148-156,344-345) --
     def optimizer_state_dict(self):
