@@ -776,11 +776,9 @@ def main():
                          "configs 3 and 5, mac is the remaining stem-consuming model of the same CLI")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant: clips start in pinned host memory "
                     "and are copied to the GPU every step (on the stem stream); never the headline value")
-    ap.add_argument("--h2d-ablation", default=None, choices=["pinonly", "copyonly", "stem_no_wait", "copy_no_wait", "no_waits"],
-                    help="timing diagnostics of the PCIe-inclusive rate.  Without --h2d: the resident-input loop while the pinned staging clips "
-                    "merely exist / while one H2D copy per step runs into scratch buffers nobody reads.  With --h2d: the pipeline with the "
-                    "stem's wait for its clip's copy, the copy's wait for its buffer's last reader, or both left out (results are NOT "
-                    "valid training steps: the waits are what makes the pipeline correct)")
+    ap.add_argument("--h2d-ablation", default=None, choices=["pinonly", "copyonly"],
+                    help="timing diagnostics of the PCIe-inclusive rate (without --h2d): the resident-input loop while the pinned staging clips "
+                    "merely exist / while one H2D copy per step runs into scratch buffers nobody reads (profiles/r05_h2d.txt)")
     ap.add_argument("--clip-dtype", default="f32", choices=["f32", "u8"], help="u8: synthetic clips are RAW 8-bit pixels (value "
                     "k / 255 as eval/dataset.py:91 forms it; VNQADataset(uint8_video=True)) — with --h2d a quarter of the PCIe bytes")
     ap.add_argument("--minibatches", type=int, default=4, help="distinct HBM-resident minibatches (own clips, questions, "
@@ -890,10 +888,6 @@ def main():
     # following minibatch (side stream).  The timed region therefore contains exactly K stem passes
     # and K trunk passes: it starts with one stem already in flight from warm-up and ends having
     # produced one for the step after the region.  Steps rotate through the NB resident minibatches.
-    if args.h2d and args.h2d_ablation in ("stem_no_wait", "no_waits"):
-        trainer._diag_stem_no_wait = True
-    if args.h2d and args.h2d_ablation in ("copy_no_wait", "no_waits"):
-        trainer._diag_copy_no_wait = True
     if args.h2d:      # 3-stage input pipeline: H2D(i+2) on the copy engine | stem(i+1) | trunk(i)
         queue = [trainer.upload(batches[0][0]), trainer.upload(batches[1 % NB][0])]
 

@@ -424,7 +424,7 @@ class Trainer(object):
         # ended and stem(i+2) waited for the copy — the stem stream, the pipeline's bottleneck, idled for the length of every
         # copy (-4 % with fp32 clips AND with uint8 clips a quarter the size: profiles/r04_h2d.txt).
         ev = self._up_read_done.get(buf.data_ptr())
-        if ev is not None and not getattr(self, "_diag_copy_no_wait", False):      # (_diag_*: bench.py --h2d-ablation, timing diagnostics only)
+        if ev is not None:
             self.copy_stream.wait_event(ev)
         with torch.cuda.stream(self.copy_stream):
             buf.copy_(clip_host, non_blocking=True)
@@ -435,7 +435,7 @@ class Trainer(object):
 
     def _wait_upload(self, clip):
         ev = self._up_events.get(clip.data_ptr()) if self.copy_stream is not None else None
-        if ev is not None and not getattr(self, "_diag_stem_no_wait", False):
+        if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
     def _mark_clip_read(self, clip):
