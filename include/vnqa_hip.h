@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 422
+#define VNQA_ABI_VERSION 423
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -232,6 +232,12 @@ int vnqa_conv2d_ring_fwd(const void* x, const void* wt, const float* bias, void*
  * — the edge products of the border correction without vnqa_ring_edge_gather's [n*len, 3*c_mid] operands. */
 int vnqa_ring_edge_conv_fwd(const void* y1p, const void* wt, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c_mid,
                             int32_t c_out, int32_t edge, int32_t dtype, void* stream);
+/* vnqa_conv2d_ring_fwd for ONE edge of the ring with the three taps that can see the image (a position one pixel outside has six of its nine taps in the zero
+ * halo): a 1x3 (edge 0 / 1 = top / bottom) or 3x1 (edge 2 / 3 = left / right) conv over one image row / column, K = 3 c_in instead of 9 c_in,
+ * the same sums in the same order.  wt [c_out][3][c_in]: kernel row 2 / row 0 / column 2 / column 0 of the 3x3 weights; y1p: the padded ring
+ * layout [n][R + 4][c_out] of vnqa_conv2d_ring_fwd(padded = 1), whose segment of this edge is written (four calls fill it). */
+int vnqa_conv2d_ring_edge_fwd(const void* x, const void* wt, const float* bias, void* y1p, int32_t n_img, int32_t h, int32_t w,
+                              int32_t c_in, int32_t c_out, int32_t edge, int32_t dtype, void* stream);
 int vnqa_ring_im2col(const void* x, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype,
                      void* stream);
 int vnqa_ring_edge_gather(const void* y1, void* out, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t edge,

@@ -558,6 +558,33 @@ def test_ring_conv_implicit_gemm_matches_im2col_gemm(dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(5, 10, 14), (3, 56, 56), (70, 6, 10), (2, 40, 52)])
+def test_ring_conv_edge_by_edge_with_three_taps_gives_the_one_launch_forms_bits(dt, geom):
+    """vnqa_conv2d_ring_edge_fwd x 4 (each edge with the three taps that can see the image: 1x3 along image row 0 / H-1, 3x1 down image
+    column 0 / W-1) against vnqa_conv2d_ring_fwd (nine taps, six of them in the zero halo): the same sums in the same order — bit
+    for bit — and the separator rows of the padded layout stay untouched."""
+    from videonavqa_amd import kernels as K
+    n, H, W = geom
+    ci, co = 128, 192
+    g = torch.Generator().manual_seed(n * 7 + H)
+    x = torch.zeros(n, H + 4, W + 4, ci)
+    x[:, 2:-2, 2:-2] = torch.randn(n, H, W, ci, generator=g)
+    x = x.to(dt).cuda()
+    wt = K.pack_conv_weight((torch.randn(co, ci, 3, 3, generator=g) * 0.05).cuda(), dt)        # [co][9][ci]
+    b = torch.randn(co, generator=g).cuda()
+    R = 2 * (W + 2) + 2 * H
+    one = torch.zeros(n, R + 4, co, dtype=dt, device="cuda")
+    K.conv2d_ring(x, wt, b, H, W, out_padded=one)
+    four = torch.zeros(n, R + 4, co, dtype=dt, device="cuda")
+    edges = K.ring_edge_weights(wt)
+    assert [tuple(e.shape) for e in edges] == [(co, 3, ci)] * 4
+    K.conv2d_ring_edges(x, edges, b, H, W, four)
+    assert torch.equal(four, one)
+    for z in (2 * (W + 2), 2 * (W + 2) + H + 1, 2 * (W + 2) + H + 2, R + 3):
+        assert float(four[:, z].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 def test_ring_edge_convs_match_gathered_edge_gemms(dt):
     """The four edge products of the border correction as implicit 1x3 convs along the zero-separated ring layout against
     the gathered-operand GEMMs they replace (incl. the corner slots that must read zeros on the left / right columns)."""

@@ -34,6 +34,7 @@ struct ConvArgs {
   float* partial;           // [slices][M][Cout] fp32 when slices > 1
   int group_tiles;          // > 0: grouped GEMM — pixel tile t uses weight rows [(t / group_tiles) * Cout, ...) (vnqa_gemm_nt_grouped)
   int x_wrap2 = 0;          // 1: x has Cin / 2 physical channels, read twice along K (VNQA_CONV_X_WRAP2 / VNQA_GEMM_X_WRAP2; TAG 4 kernels)
+  int tap3_vertical = 0;    // taps == 3: the window runs down a COLUMN (tap stride Wp pixels) instead of along a row (vnqa_conv2d_ring_edge_fwd: left / right edges)
   int dual_out = 0;         // 1: y gets 2 Cout channels per pixel, [h16(v) | h16(v - h16(v))] (VNQA_CONV_DUAL_OUT; conv_ps TAG 2); 2: [hi | lo | hi] (VNQA_CONV_DUAL_HI2); 4: hi in y, lo in y2, two plain tensors (VNQA_EPI_SPLIT_OUT)
   int xcd_split = 0;        // 1: TAG 1 launches with two cout tiles give every XCD ONE cout half (VNQA_CONV_XCD_SPLIT_N)
   int zero_halo = 0;        // 1: the store loop also writes zeros to y's (and y2's) 1-pixel halo ring (vnqa_conv_desc.flags)

@@ -239,9 +239,9 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       const int rs = tap - 9 * q;
       r = rs / 3;
       s = rs - 3 * r;
-    } else if (p.taps == 3) {        // 1x3 window along a row (vnqa_ring_edge_conv_fwd)
-      r = 0;
-      s = tap;
+    } else if (p.taps == 3) {        // 1x3 window along a row (vnqa_ring_edge_conv_fwd), or 3x1 down a column (vnqa_conv2d_ring_edge_fwd)
+      r = p.tap3_vertical ? tap : 0;
+      s = p.tap3_vertical ? 0 : tap;
     } else {
       r = p.x_halo;
       s = p.x_halo;
@@ -422,8 +422,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     // K position of a stage (tap = (q, r, sx) window coordinates, kc = 64-channel chunk), advanced incrementally: the
     // per-stage offsets cost a handful of scalar instructions instead of a division chain behind the barrier
-    const int kw = (p.taps == 9 || p.taps == 27 || p.taps == 3) ? 3 : (p.taps == 25 ? 5 : 1);
-    const int kh = (p.taps == 9 || p.taps == 27) ? 3 : (p.taps == 25 ? 5 : 1);
+    const int kw = (p.taps == 9 || p.taps == 27 || (p.taps == 3 && !p.tap3_vertical)) ? 3 : (p.taps == 25 ? 5 : 1);
+    const int kh = (p.taps == 9 || p.taps == 27 || (p.taps == 3 && p.tap3_vertical)) ? 3 : (p.taps == 25 ? 5 : 1);
     const int r_base = (p.taps == 9 || p.taps == 25 || p.taps == 27 || p.taps == 3) ? 0 : p.x_halo;   // 1x1: the centre tap
     struct KPos { int tap, kc, q, r, sx; };
     auto kpos_at = [&](int kt) {
@@ -1530,6 +1530,53 @@ extern "C" int vnqa_ring_edge_conv_fwd(const void* y1p, const void* wt, void* ou
   if (dtype == VNQA_BF16) {
     const int pad256 = (a.M + 255) / 256 * 256, pad128 = (a.M + 127) / 128 * 128;
     tile = (pad128 >= pad256 || wrap2) ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+  }
+  return conv_dispatch(a, dtype, tile, (hipStream_t)stream);
+}
+
+// conv11 at ONE edge of the outside ring, with the three taps that can see the image: a ring position one pixel outside the image has
+// six of its nine taps in the zero halo — the top row sees image row 0 through kernel row 2 only, the left column sees image column 0
+// through kernel column 2 only — so the edge is a 1x3 (top / bottom) or 3x1 (left / right) conv over one image row / column:
+// K = 3 c_in instead of vnqa_conv2d_ring_fwd's 9 c_in (two thirds of whose products are against zeros), same sums in the same
+// order.  x: halo-2 images [n][h+4][w+4][c_in]; wt: [c_out][3][c_in] — kernel row 2 / row 0 / column 2 / column 0 of conv11 for
+// edge 0 / 1 / 2 / 3 = top / bottom / left / right; y1p: the padded ring layout [n][R + 4][c_out] of vnqa_conv2d_ring_fwd(padded = 1),
+// whose segment of this edge (w + 2 or h positions) is written.
+extern "C" int vnqa_conv2d_ring_edge_fwd(const void* x, const void* wt, const float* bias, void* y1p, int32_t n_img, int32_t h, int32_t w,
+                                         int32_t c_in, int32_t c_out, int32_t edge, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(x && wt && y1p && n_img > 0 && h >= 2 && w >= 2 && edge >= 0 && edge < 4, "conv2d_ring_edge_fwd: bad arguments");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv2d_ring_edge_fwd: bad dtype %d", dtype);
+  const int bk = dtype == VNQA_BF16 ? 64 : 32, es = dtype == VNQA_BF16 ? 2 : 4;
+  VNQA_CHECK_ARG(c_in > 0 && c_in % bk == 0 && c_out > 0 && c_out % 8 == 0, "conv2d_ring_edge_fwd: c_in %% %d, c_out %% 8", bk);
+  const int R = 2 * (w + 2) + 2 * h, Rp = R + 4, Wp = w + 4;
+  const int len = edge < 2 ? w + 2 : h;
+  // first window of the edge in the halo-2 image (padded row, column of its first tap) and its segment in the padded ring layout
+  const int row0 = edge == 0 ? 2 : (edge == 1 ? h + 1 : 1), col0 = edge < 2 ? 0 : (edge == 2 ? 2 : w + 1);
+  const int base = edge == 0 ? 0 : (edge == 1 ? w + 2 : (edge == 2 ? 2 * (w + 2) + 1 : 2 * (w + 2) + h + 3));
+  ConvArgs a;
+  a.x = (const char*)x + ((size_t)row0 * Wp + col0) * c_in * es;
+  a.x_wrap2 = 0;
+  a.xcd_split = 0;
+  a.zero_halo = 0;
+  a.wt = (const char*)wt;
+  a.bias = bias; a.post_scale = nullptr; a.post_shift = nullptr;
+  a.y = (char*)y1p + (size_t)base * c_out * es;
+  a.n_img = n_img;
+  a.H = edge < 2 ? 1 : len; a.W = edge < 2 ? len : 1;       // positions run along the row (top / bottom) or down the column (left / right)
+  a.Hp = h + 4; a.Wp = Wp;
+  a.Cin = c_in; a.Cout = c_out; a.Cy = c_out;
+  a.taps = 3; a.tap3_vertical = edge < 2 ? 0 : 1;
+  a.x_halo = 0; a.y_halo = 0; a.relu = 0; a.pool = 0;
+  a.M = n_img * len; a.tilesN = 0; a.wt_tiled = 0; a.D = 0;
+  // output position j of image n -> y1p[n][base + j]: a row of Rp entries per image (positions along x), or Rp rows of one (along y)
+  a.Hyp = edge < 2 ? 1 : Rp; a.Wyp = edge < 2 ? Rp : 1;
+  a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr; a.group_tiles = 0;
+  a.epi = VNQA_EPI_NONE; a.ring_h = 0; a.ring_w = 0;
+  a.frame_of = nullptr; a.stats_partial = nullptr; a.film_gamma = nullptr; a.film_beta = nullptr;
+  a.film_ld = 0; a.film_c = 0; a.res = nullptr; a.y2 = nullptr;
+  int tile = VNQA_TILE_128x128;
+  if (dtype == VNQA_BF16) {
+    const int pad256 = (a.M + 255) / 256 * 256, pad128 = (a.M + 127) / 128 * 128;
+    tile = pad128 >= pad256 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
   }
   return conv_dispatch(a, dtype, tile, (hipStream_t)stream);
 }

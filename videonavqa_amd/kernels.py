@@ -300,6 +300,28 @@ def conv2d_ring(x, wt, bias, H, W, out_padded=None):
     return y1
 
 
+RING_EDGE_TAPS = ((6, 7, 8), (0, 1, 2), (2, 5, 8), (0, 3, 6))      # kernel row 2 / row 0 / column 2 / column 0: what the top / bottom / left / right edge sees
+
+
+def ring_edge_weights(wt):
+    """The four 3-tap slices [c_out][3][c_in] of K-major 3x3 weights wt [c_out][9][c_in] that conv2d_ring_edges multiplies with."""
+    return [wt[:, list(t), :].contiguous() for t in RING_EDGE_TAPS]
+
+
+def conv2d_ring_edges(x, wt_edges, bias, H, W, out_padded):
+    """conv2d_ring(..., out_padded) as four launches, one per edge, each with the three taps that can see the image (a ring position has
+    the other six in the zero halo): K = 3 c_in instead of 9 c_in, the same sums in the same order (vnqa_conv2d_ring_edge_fwd)."""
+    n, _, _, c_in = x.shape
+    c_out = wt_edges[0].shape[0]
+    R = 2 * (W + 2) + 2 * H
+    assert out_padded.shape == (n, R + 4, c_out) and out_padded.dtype == x.dtype and out_padded.is_contiguous()
+    for e in range(4):
+        assert wt_edges[e].shape == (c_out, 3, c_in) and wt_edges[e].is_contiguous() and wt_edges[e].dtype == x.dtype
+        L.check(L.lib().vnqa_conv2d_ring_edge_fwd(L.ptr(x), L.ptr(wt_edges[e]), L.ptr(bias), L.ptr(out_padded), n, H, W, c_in, c_out, e,
+                                                  L.dtype_id(x.dtype), L.stream()), "vnqa_conv2d_ring_edge_fwd")
+    return out_padded
+
+
 def ring_edge_conv(y1p, wt_edge, H, W, edge):
     """One edge product of the border correction as an implicit 1x3 conv along the padded ring rows (vnqa_ring_edge_conv_fwd):
     y1p [n, R+4, cm], wt_edge [co, 3*cm] -> [n * (W | H), co]."""

@@ -229,6 +229,7 @@ def patch_second_moment(x, k, max_rows=400000):
     return H / max(rows, 1)
 
 
+RING_EDGE_LAUNCHES = True    # conv11 on the outside ring as four 3-tap launches (False: one 9-tap launch, same bits: the A/B partner)
 CALIBRATION_FRAMES = 40      # frames of the default ("noise") calibration pass: 40 x 196 patches > K = 4608 of the 14 x 14 layers
 
 
@@ -475,11 +476,12 @@ class FrozenStem(object):
             return e.view(co_pad, -1).to(dev).to(self.cdt).contiguous()
         edges = dict(top=edge(w2[:, :, 0, :]), bottom=edge(w2[:, :, 2, :]), left=edge(w2[:, :, :, 0]), right=edge(w2[:, :, :, 2]))
         return dict(wt=wt, bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges,
+                    w1_edges=K.ring_edge_weights(w1m.view(cm_pad, 9, ci_pad)),
                     c_in=ci, c_out=co, c_out_pad=co_pad, c_mid_pad=cm_pad, tile=tile, taps=25)
 
     def _run_composed(self, x, key):
         """x: halo-2 padded NHWC [n, H+4, W+4, ci_pad] -> relu/pool'ed output of the composed pair (halo 1).
-        Border correction: conv11 at the ring positions straight from the halo-2 image, written into a zero-separated ring layout,
+        Border correction: conv11 at the ring positions straight from the halo-2 image (four 3-tap launches), written into a zero-separated ring layout,
         and the four edge products as 1x3 convs along its rows — both implicit GEMMs (no im2col matrix, no gathered edge operands:
         147 + 4 x 48 MB less written and read back per 280-frame pass than the round-1 form)."""
         cp = self.composed
@@ -488,7 +490,12 @@ class FrozenStem(object):
         cm = cp["c_mid_pad"]
         R = 2 * (W + 2) + 2 * H
         y1p = self._buf(key + ("y1p", H, W), (n, R + 4, cm))
-        K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W, out_padded=y1p)
+        # (edge by edge with the three taps that can see the image: a third of the one-launch form's K, whose other products are against
+        # the zero halo; RING_EDGE_LAUNCHES = False runs that form: the same bits)
+        if RING_EDGE_LAUNCHES:
+            K.conv2d_ring_edges(x, cp["w1_edges"], cp["b1"], H, W, y1p)
+        else:
+            K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W, out_padded=y1p)
         part = [K.ring_edge_conv(y1p, cp["edges"][name], H, W, e) for e, name in enumerate(("top", "bottom", "left", "right"))]
         ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
