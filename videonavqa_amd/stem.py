@@ -167,7 +167,7 @@ def second_order_round(w, H, dtype, damp=0.01, block=128):
     moment); on the frozen stem this form leaves 1/8 of its squared logits error on clips like the calibration frames and 0.43 of it
     on clips unlike them (tools/experiments/gptq_stem_weights.py, profiles/r05_gptq_stem_weights.txt) — little enough that
     precision 'fp16h' no longer spends a product on conv31's / conv32's weight roundings.  Returns fp32 values exactly
-    representable in `dtype`.  Deterministic for given inputs (fp64 Cholesky + fixed-order updates)."""
+    representable in `dtype` (None if H could not be factorised).  Deterministic for given inputs (fp64 Cholesky + fixed-order updates)."""
     co = w.shape[0]
     W = w.detach().reshape(co, -1).double().clone()
     K_ = W.shape[1]
@@ -180,8 +180,26 @@ def second_order_round(w, H, dtype, damp=0.01, block=128):
     perm = torch.argsort(torch.diagonal(H), descending=True)
     W = W[:, perm]
     H = H[perm][:, perm]
-    H += torch.eye(K_, dtype=H.dtype, device=H.device) * (damp * float(torch.diagonal(H).mean()))
-    U = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True)
+    # U = the upper Cholesky factor of H^-1 (H^-1 = U^T U), WITHOUT forming H^-1: with P the index reversal, P H P = L L^T gives
+    # H^-1 = (P L^-1 P)^T (P L^-1 P) and P L^-1 P is upper triangular — one factorisation of the damped (positive definite by
+    # construction) H and one triangular solve.  (The textbook route, cholesky(cholesky_inverse(cholesky(H))), factorises an explicitly
+    # inverted matrix and was seen to fail — "not positive-definite" at a leading minor of order 4260 of 4608 — in one of two
+    # processes calibrating concurrently on one GPU.)  Should the factorisation still fail, the damping grows; the last resort is
+    # round-to-nearest (the caller's coherent rounding is then the better fallback: see FrozenStem._round).
+    eye = torch.eye(K_, dtype=H.dtype, device=H.device)
+    mean_diag = float(torch.diagonal(H).mean())
+    U = None
+    for factor in (1.0, 10.0, 100.0):
+        try:
+            Lr = torch.linalg.cholesky((H + eye * (damp * factor * mean_diag)).flip(0).flip(1))
+            U = torch.linalg.solve_triangular(Lr, eye, upper=False).flip(0).flip(1).contiguous()
+            if bool(torch.isfinite(U).all()):
+                break
+            U = None
+        except RuntimeError:          # torch._C._LinAlgError
+            U = None
+    if U is None:
+        return None
     if W.is_cuda:      # one launch per layer (csrc/round2.hip: a workgroup per output channel, the row in LDS as float64)
         assert dtype == L.half_dtype(), "the library rounds onto ITS 16-bit format (one format per process)"
         Qf = torch.empty(W.shape, dtype=torch.float32, device=W.device)
@@ -386,8 +404,11 @@ class FrozenStem(object):
         if key is None or self.calib is None:
             return w
         if self._H is not None and key in self._H and self._H[key].shape[0] == w[0].numel():
-            return second_order_round(w, self._H[key], dtype)
-        return coherent_round(w, self.calib[key], dtype) if key in self.calib else w
+            q = second_order_round(w, self._H[key], dtype)
+            if q is not None:
+                return q
+        mkey = "od0" if key == "od0_5x5" else key
+        return coherent_round(w, self.calib[mkey], dtype) if mkey in self.calib else w
 
     def _layer(self, conv, bn=None, relu=False, pool=False, m=None):
         w = conv.weight.detach().float()
