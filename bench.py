@@ -869,7 +869,7 @@ def main():
     batches = [synth_batch(args, rank, device, i) for i in range(NB)]
     if args.h2d:
         batches = [(b[0].cpu().pin_memory(),) + tuple(b[1:]) for b in batches]
-    # diagnostics of the PCIe-inclusive rate (tools/r05_h2d_ablation.sh): the resident-input loop with ONE ingredient of --h2d added
+    # diagnostics of the PCIe-inclusive rate (tools/round5/r05_h2d_ablation.sh): the resident-input loop with ONE ingredient of --h2d added
     pinned_copies, scratch, scratch_stream = None, None, None
     if args.h2d_ablation and not args.h2d:
         pinned_copies = [b[0].cpu().pin_memory() for b in batches]       # 'pinonly': the pinned staging clips exist, nothing reads them

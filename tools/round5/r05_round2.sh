@@ -18,4 +18,4 @@ for seed in 0 3; do
 done
 echo "smooth: $(timeout 600 python tools/error_budget.py --precision fp16h --data smooth 2>/dev/null | tail -1)" >> $O
 cat $O
-bash tools/r05_dbg_pmc.sh 2>&1 | tail -8
+bash tools/round5/r05_dbg_pmc.sh 2>&1 | tail -8
