@@ -29,6 +29,10 @@ def main():
     ap.add_argument("--profiled")
     ap.add_argument("--command", default="python3 bench.py --steps 20 --warmup 5 --repeats 1 --no-parity --no-cpu-baseline")
     a = ap.parse_args()
+    if a.trace_dir.endswith(".csv"):      # re-summarise an earlier run from its committed CSV (same columns as written below)
+        with open(a.trace_dir) as f:
+            rows = [(r["Name"], int(r["Calls"]), int(r["TotalDurationNs"]), int(r["MinNs"]), int(r["MaxNs"])) for r in csv.DictReader(f)]
+        return summarise(a, rows)
     db = sorted(glob.glob(os.path.join(a.trace_dir, "**", "*_results.db"), recursive=True))[-1]
     c = sqlite3.connect(db)
     tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -38,14 +42,29 @@ def main():
     name_col = "display_name" if "display_name" in cols else "kernel_name"
     rows = c.execute("select s.%s, count(*), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) from %s d "
                      "join %s s on d.kernel_id=s.id group by s.%s order by 3 desc" % (name_col, kd, ks, name_col)).fetchall()
+    return summarise(a, rows)
+
+
+# kernels of model CONSTRUCTION (they run once per process, not in a step): the fp64 composition of conv11 . conv12 and the
+# calibration pass of the second-order weight rounding (patch moments: fp64 GEMMs over unfolded patches; rocSOLVER factorisation;
+# the library's sequential rounding kernel)
+ONCE = ("second_order_round_kernel", "rocsolver", "_DB_", "double", "im2col_kernel", "trsm", "potf2", "index_elementwise_kernel",
+        "direct_copy_kernel", "triu_tril", "eye_", "randperm", "flip_kernel")
+
+
+def summarise(a, rows):
+    once_rows = [r for r in rows if any(k in r[0] for k in ONCE)]
+    rows_all = rows
+    rows = [r for r in rows if r not in once_rows]
     total = float(sum(r[2] for r in rows))
     tag = "r%02d" % a.round
     out_csv = os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv")
     with open(out_csv, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-        for n, cnt, tot, mn, mx in rows:
-            w.writerow([n, cnt, tot, round(tot / cnt, 1), round(100.0 * tot / total, 3), mn, mx])
+        tot_all = float(sum(r[2] for r in rows_all))
+        for n, cnt, tot, mn, mx in rows_all:
+            w.writerow([n, cnt, tot, round(tot / cnt, 1), round(100.0 * tot / tot_all, 3), mn, mx])
     md = ["# Round %d — rocprofv3 --kernel-trace --stats of `%s`" % (a.round, a.command), "",
           "MI355X (gfx950), 1 GPU, precision %s, B=8 clips x 35 frames x 224x224, side-stream stem pipeline on."
           % (load(a.bench).get("parity", {}).get("precision") or load(a.bench)["dtype"].split(" ")[0]),
@@ -76,11 +95,16 @@ def main():
         md.append("| `%s` | %.1f | %.3f | %.1f | %.1f |" % (n[:110], cnt / a.steps, tot / a.steps / 1e6, tot / cnt / 1e3,
                                                           100.0 * tot / total))
     md.append("")
-    md.append("`Cijk_Ailk_Bljk_DB_*` (an fp64 GEMM) and `im2col_kernel<double>` are ONE-TIME work at model construction — the fp64 "
-              "composition of conv11 and conv12 into the 5x5 kernel (stem.py `_compose_pair`) — divided here by the step count like "
-              "everything else; they do not run inside a training step.")
-    md.append("Sum over all kernels: %.3f ms/step of GPU time (two streams overlap, so this exceeds the wall time per step)."
+    md.append("Sum over these kernels: %.3f ms/step of GPU time (two streams overlap, so this exceeds the wall time per step)."
               % (total / a.steps / 1e6))
+    md += ["", "## One-time work of model construction (NOT in the table above, NOT in a step)", "",
+           "The fp64 composition of conv11 and conv12 into the 5x5 kernel (stem.py `_compose_pair`) and the calibration pass of the "
+           "second-order weight rounding (stem.py `second_order_round`: fp64 patch moments, one rocSOLVER factorisation + triangular solve "
+           "and one `second_order_round_kernel` launch per layer), per stem built in the traced process (the bench builds several: the "
+           "training stem, the parity legs'):", "", "| kernel | calls | total ms |", "|---|---|---|"]
+    for n, cnt, tot, mn, mx in sorted(once_rows, key=lambda r: -r[2])[:12]:
+        md.append("| `%s` | %d | %.2f |" % (n[:110], cnt, tot / 1e6))
+    md.append("| all %d one-time kernel symbols | %d | %.2f |" % (len(once_rows), sum(r[1] for r in once_rows), sum(r[2] for r in once_rows) / 1e6))
     # framework kernels left in the step (everything that is not this library's): ATen elementwise / index / reduce kernels,
     # rocBLAS (Cijk_*) GEMMs, runtime copies
     fw = [(n, cnt, tot) for n, cnt, tot, mn, mx in rows if n.startswith("void at::") or n.startswith("Cijk_") or "rocclr" in n
@@ -90,9 +114,8 @@ def main():
     for n, cnt, tot in fw:
         md.append("| `%s` | %.2f | %.1f | %.3f |" % (n[:100], cnt / a.steps, tot / a.steps / 1e3, 100.0 * tot / total))
     md.append("")
-    once = [r for r in fw if "double" in r[0] or "_DB_" in r[0]]        # fp64: the one-time composition of conv11 . conv12
-    steady = [r for r in fw if r not in once]
-    md.append("Framework kernels excluding the one-time fp64 stem composition (`Cijk_*_DB_*`, `*<double>*`: model construction): "
+    steady = fw
+    md.append("Framework kernels (the one-time construction work is listed above, not here): "
               "%.1f launches/step, %.1f us/step = %.2f %% of the summed GPU kernel time — this still includes the fills / copies of "
               "model construction and of bench.py's warm-up allocation (the whole process is traced); the per-step list of the "
               "steady state is `profiles/%s_trunk_timeline.txt` (rocprofv3 trace of one training step's trunk chain: ~20 framework "
