@@ -13,7 +13,7 @@ import sys
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(HERE, "..", "..", ".."))
 import bench  # noqa: E402
 
 
@@ -24,7 +24,7 @@ def load(name, path):
     return m
 
 
-G = load("gptq_stem_weights", os.path.join(HERE, "gptq_stem_weights.py"))
+G = load("gptq_stem_weights", os.path.join(HERE, "..", "gptq_stem_weights.py"))
 
 
 @torch.no_grad()
