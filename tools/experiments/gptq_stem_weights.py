@@ -140,6 +140,28 @@ def calib_frames(kind, n, seed=4242):
     return torch.cat([noise[:n // 2], smooth[:n - n // 2]])
 
 
+def blocks_batches(bm, args, dev, n):
+    """A THIRD kind of clip, used for evaluation only: piecewise-constant images — 24 random axis-aligned rectangles of random colour
+    over a random background per frame, drifting slowly over the frames — on the 'noise' batches' questions and lengths."""
+    out = []
+    for i, (clip, q, v_lens, q_lens) in enumerate(bm.batches(args, dev, n, "noise")):
+        g = torch.Generator().manual_seed(9000 + i)
+        B, _, H, W, T = clip.shape
+        img = torch.rand(B, 3, 1, 1, 1, generator=g).expand(B, 3, H, W, T).clone()
+        for _ in range(24):
+            y0, x0 = torch.randint(0, H - 8, (B,), generator=g), torch.randint(0, W - 8, (B,), generator=g)
+            hh, ww = torch.randint(8, H // 2, (B,), generator=g), torch.randint(8, W // 2, (B,), generator=g)
+            col = torch.rand(B, 3, generator=g)
+            dx = torch.randint(-2, 3, (B,), generator=g)
+            for b in range(B):
+                for t in range(T):
+                    xs = int(min(max(x0[b] + dx[b] * t, 0), W - 8))
+                    img[b, :, int(y0[b]):int(y0[b] + hh[b]), xs:xs + int(ww[b]), t] = col[b].view(3, 1, 1)
+        mask = (torch.arange(T).view(1, 1, 1, 1, T) < v_lens.view(B, 1, 1, 1, 1)).float()
+        out.append((img * mask, q, v_lens, q_lens))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, nargs="*", default=[0, 1])
@@ -187,8 +209,8 @@ def main():
                 d_gptq[key] = d_coh[key]
         del ins
         torch.cuda.empty_cache()
-        for data_kind in ("noise", "smooth"):
-            data = bm.batches(args, dev, o.batches, data_kind)
+        for data_kind in ("noise", "smooth", "blocks"):
+            data = blocks_batches(bm, args, dev, o.batches) if data_kind == "blocks" else bm.batches(args, dev, o.batches, data_kind)
             for bi, (clip, q, v_lens, q_lens) in enumerate(data):
                 frames, cts, v_sorted, perm = PB.pack_frames(clip.to(dev), v_lens)
                 film = PB.question_film(W, q.to(dev)[perm.to(dev)], q_lens[perm], cts)
@@ -203,7 +225,7 @@ def main():
             print("seed %d %s data done (%.0f s)" % (seed, data_kind, time.time() - t0), flush=True)
     print("\ncalibrated on %d %s frames; squared logits error x 1e-6 (mean over %d minibatches x %d weight seeds) [max x 1e-3]" %
           (o.calib_frames, o.calib, o.batches, len(o.seeds)))
-    for data_kind in ("noise", "smooth"):
+    for data_kind in ("noise", "smooth", "blocks"):
         print("-- evaluated on %s clips" % data_kind)
         for gname, _ in groups:
             row = []
