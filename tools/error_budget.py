@@ -3,7 +3,7 @@
 the headline size) on N seeded minibatches (default 12: one full-length, the rest ragged): the maximum over the minibatches (the
 tests' criterion), their RMS and mean, and how many answers differ.
 
-  python tools/error_budget.py [--batches 12] [--seed S] [--data noise|smooth] [--precision fp16h|fp16|bf16]
+  python tools/error_budget.py [--batches 12] [--seed S] [--data noise|smooth|blocks] [--precision fp16h|fp16|bf16]
 (tools/experiments/precision_budget.py has the per-rounding-point budget behind the mode's design)"""
 import argparse
 import copy
@@ -19,9 +19,10 @@ KEYS = {"COH": "VNQA_COHERENT_ROUND"}
 
 
 def batches(args, device, n, data="noise"):
-    """data: 'noise' = i.i.d. uniform pixels (the benchmark's synthetic clips, and what the stem's default calibration frames are);
-    'smooth' = NOT the calibration distribution: 14 x 14 noise per frame bilinearly upsampled 16 x, plus a per-clip brightness and a
-    slow drift over the frames — large flat regions, other channel means."""
+    """data: 'noise' = i.i.d. uniform pixels (the benchmark's synthetic clips; half of the stem's default calibration frames);
+    'smooth' = 14 x 14 noise per frame bilinearly upsampled 16 x, plus a per-clip brightness and a slow drift over the frames — large
+    flat regions, other channel means (the other half of the calibration frames is of this kind, without the drift);
+    'blocks' = NOT a calibration distribution: piecewise-constant images (bench.blocks_clip)."""
     import torch.nn.functional as F
     out = []
     for i in range(n):
@@ -33,6 +34,8 @@ def batches(args, device, n, data="noise"):
             gain = 0.3 + 0.7 * torch.rand(B, 1, 1, 1, 1, generator=g)
             drift = torch.linspace(0, 0.2, T).view(1, T, 1, 1, 1) * torch.rand(B, 1, 1, 1, 1, generator=g)
             clip = (up * gain + drift).clamp_(0, 1).permute(0, 2, 3, 4, 1).contiguous()
+        elif data == "blocks":       # a THIRD kind, like neither half of the calibration frames: piecewise-constant images
+            clip = bench.blocks_clip(B, T, args.height, args.width, g)
         else:
             clip = torch.rand(B, 3, args.height, args.width, T, generator=g)
         q_lens = torch.randint(5, 26, (B,), generator=g)
@@ -68,8 +71,8 @@ def run(args, prec, device, data):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", type=int, default=12)
-    ap.add_argument("--data", default="noise", choices=["noise", "smooth"], help="the minibatches' pixel statistics (the default "
-                    "calibration frames are always noise)")
+    ap.add_argument("--data", default="noise", choices=["noise", "smooth", "blocks"], help="the minibatches' pixel statistics (the default "
+                    "calibration frames are half uniform noise, half smooth; 'blocks' is like neither)")
     ap.add_argument("--seed", type=int, default=0, help="seed of the random weights (0 = the benchmark's)")
     ap.add_argument("--precision", default="fp16h", help="the precision under test (fp16h, fp16, bf16)")
     ap.add_argument("settings", nargs="*", default=["COH=1"], help="one pass per argument; each word KEY=VALUE of it sets an environment variable (COH = VNQA_COHERENT_ROUND) or, "

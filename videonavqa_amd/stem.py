@@ -107,16 +107,32 @@ def coherent_round(w, m, dtype):
     return out.view_as(w)
 
 
+def default_calibration_frames(n, height=224, width=224, seed=4242):
+    """The seeded SYNTHETIC calibration frames ("noise" calibration): the first half uniform noise (the benchmark's kind of clip), the
+    second half smooth — 14 x 14 noise upsampled bilinearly, with a per-frame brightness.  Second moments measured on the mixture
+    generalise: on a THIRD kind of clip (piecewise-constant 'blocks', tools/error_budget.py --data blocks) the nine stem weight roundings
+    cost 0.022e-6 of squared logits error with this mixture against 0.082 calibrated on noise alone (0.117 mean-coherent, 0.67 nearest;
+    profiles/r05_gptq_stem_weights.txt), with nothing lost on noise clips (0.008)."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(n - n // 2, 3, height, width, generator=g)
+    if n // 2 == 0:
+        return a
+    low = torch.rand(n // 2, 3, max(height // 16, 1), max(width // 16, 1), generator=g)
+    b = torch.nn.functional.interpolate(low, size=(height, width), mode="bilinear", align_corners=False)
+    b = (b * (0.3 + 0.7 * torch.rand(n // 2, 1, 1, 1, generator=g))).clamp_(0, 1)
+    return torch.cat([a, b])
+
+
 @torch.no_grad()
 def calibration_means(vgg, od, frames=None, n_frames=4, height=224, width=224, seed=4242, second_moments=False):
     """Per-input-channel mean activation at every stem layer's input — what coherent_round cancels against — from ONE pass of
     calibration frames [N, 3, H, W] (values in [0, 1]) through the library's own exact-f32 stem (a FrozenStem of precision 'fp32'
-    with its layer outputs tapped).  Default frames: seeded uniform noise, the benchmark's kind of data; a deployment passes
-    frames of its own videos.  Keys: first = conv1_1's input, vgg0 / vgg1 / vgg2 = conv1_2 / conv2_1 / conv2_2, od0 = conv11 (and
+    with its layer outputs tapped).  Default frames: default_calibration_frames (seeded: half uniform noise, half smooth); a deployment
+    passes frames of its own videos.  Keys: first = conv1_1's input, vgg0 / vgg1 / vgg2 = conv1_2 / conv2_1 / conv2_2, od0 = conv11 (and
     the composed 5x5 pair), od1 = conv12, od2 .. od5 = conv21 .. conv32."""
     dev = vgg.features["0"].weight.device
     if frames is None:
-        frames = torch.rand(n_frames, 3, height, width, generator=torch.Generator().manual_seed(seed))
+        frames = default_calibration_frames(n_frames, height, width, seed)
     frames = frames.float().to(dev)
     N, _, H, W = frames.shape
     ref = FrozenStem(vgg, od, "fp32")
@@ -274,7 +290,8 @@ class FrozenStem(object):
     read no split tensors: MACNetwork, the per-module drop-in path).
 
     calibration: how the frozen 16-bit weights are rounded.  None = round-to-nearest.  "noise" or a tensor of frames [N, 3, H, W]
-    (values in [0, 1]) = ONE exact-f32 stem pass over those frames (CALIBRATION_FRAMES seeded noise frames by default) measures every
+    (values in [0, 1]) = ONE exact-f32 stem pass over those frames (CALIBRATION_FRAMES seeded synthetic frames by default — half uniform
+    noise, half smooth: default_calibration_frames) measures every
     layer's input-patch second moment H = E[p p^T], and each layer's weights (BatchNorm scale folded, the conv11.conv12 pair composed)
     are rounded by second_order_round: column by column, the rounding error pushed onto the not yet rounded columns along H^-1, which
     greedily minimises dw^T H dw — the mean squared error the rounding adds to the layer's output.  (Round 4's coherent_round cancels the
