@@ -81,3 +81,18 @@ def test_second_order_round_minimises_the_output_error_on_correlated_inputs(dt):
     y = F.conv2d(x, w, padding=1)
     mse = lambda ww: float((F.conv2d(x, ww, padding=1) - y).pow(2).mean())
     assert mse(q) < 0.3 * mse(w.to(dt).float())
+
+
+def test_default_calibration_frames_are_a_seeded_mixture():
+    """stem.default_calibration_frames: deterministic for a seed, values in [0, 1], the first half i.i.d. noise (neighbouring pixels
+    uncorrelated), the second half smooth (neighbouring pixels nearly equal) — the two kinds whose mixture the second-order rounding of
+    the frozen stem's weights is calibrated on."""
+    from videonavqa_amd.stem import CALIBRATION_FRAMES, default_calibration_frames
+    a = default_calibration_frames(CALIBRATION_FRAMES, 64, 96)
+    b = default_calibration_frames(CALIBRATION_FRAMES, 64, 96)
+    assert a.shape == (CALIBRATION_FRAMES, 3, 64, 96) and torch.equal(a, b) and float(a.min()) >= 0 and float(a.max()) <= 1
+    assert not torch.equal(a, default_calibration_frames(CALIBRATION_FRAMES, 64, 96, seed=1))
+    h = CALIBRATION_FRAMES - CALIBRATION_FRAMES // 2
+    rough = lambda t: float((t[..., 1:] - t[..., :-1]).abs().mean())
+    assert rough(a[:h]) > 0.25 and rough(a[h:]) < 0.05
+    assert default_calibration_frames(1, 32, 32).shape == (1, 3, 32, 32)
