@@ -484,37 +484,49 @@ def oracle_full_size(args, device, dump_path):
     ref, Bs, perm_o = d["logits"].float(), int(d["batch"]), d["perm"].long()
     W_vgg, W_od, W, (clip, q, v_lens, q_lens, y) = oracle_workload(args, Bs)
     S = (args.height // 16) * (args.width // 16)
-    vgg = VGGFront("fp32")
-    od = ObjDetectCNN(27, 512, 1024, 0, True, True, precision="fp32")
-    vgg.load_state_dict(W_vgg)
-    od.load_state_dict(W_od, strict=False)          # (the unused classifier tail / num_batches_tracked are not in the dict)
-    model = FiLMAttnPretrainedStem(Bs, 128, 70, num_res_blocks=args.blocks, num_res_block_channels=args.channels,
-                                   max_num_frames=args.frames, spatial_size=S, precision="fp32")
-    vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
-    model.load_reference_tensors(W)
-    stem = FrozenStem(vgg, od, "fp32")
-    v_sorted, perm = torch.sort(v_lens, dim=0, descending=True, stable=True)
-    lay = FrameLayout(v_sorted, args.frames, device, perm=perm)
-    feats = stem.forward_clip(clip.to(device), lay.img_of, lay.n_img)
-    native = NativeFeatures(feats, lay, 512, args.height // 16, args.width // 16)
-    model.train()
-    model.init_hidden()
-    with torch.no_grad():
-        out = model(native, q.to(device)[perm.to(device)], v_sorted, q_lens[perm]).float().cpu()
-    # rows: product row j = original sample perm[j]; oracle row i = original sample perm_o[i]
-    inv = torch.empty_like(perm)
-    inv[perm] = torch.arange(len(perm))
-    out_o = out[inv[perm_o]]
-    err = float((out_o - ref).abs().max() / ref.abs().max())
-    l2 = float((out_o - ref).norm() / ref.norm())
-    del model, stem, vgg, od, feats
-    torch.cuda.empty_cache()
-    return {"oracle_full_size_rel_err": round(err, 9), "oracle_full_size_rel_l2_err": round(l2, 9),
-            "oracle_full_size_argmax_equal": bool((out_o.argmax(1) == ref.argmax(1)).all()),
-            "oracle_full_size_what": "precision='fp32' HIP path (stem + FiLM-attn train-mode forward) vs oracle/vnqa_oracle.py "
-                                     "(stem_forward + film_attn_forward, run in the CPU child) on identical weights and the CPU "
-                                     "leg's minibatch: %d clips x %d frames %dx%d; max|d logit| / max|logit|"
-                                     % (Bs, args.frames, args.height, args.width)}
+
+    def run(prec):
+        vgg = VGGFront(prec)
+        od = ObjDetectCNN(27, 512, 1024, 0, True, True, precision=prec)
+        vgg.load_state_dict(W_vgg)
+        od.load_state_dict(W_od, strict=False)          # (the unused classifier tail / num_batches_tracked are not in the dict)
+        model = FiLMAttnPretrainedStem(Bs, 128, 70, num_res_blocks=args.blocks, num_res_block_channels=args.channels,
+                                       max_num_frames=args.frames, spatial_size=S, precision=prec)
+        vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
+        model.load_reference_tensors(W)
+        stem = FrozenStem(vgg, od, prec)
+        v_sorted, perm = torch.sort(v_lens, dim=0, descending=True, stable=True)
+        lay = FrameLayout(v_sorted, args.frames, device, perm=perm)
+        feats = stem.forward_clip(clip.to(device), lay.img_of, lay.n_img)
+        native = NativeFeatures(feats, lay, 512, args.height // 16, args.width // 16)
+        model.train()
+        model.init_hidden()
+        with torch.no_grad():
+            out = model(native, q.to(device)[perm.to(device)], v_sorted, q_lens[perm]).float().cpu()
+        # rows: product row j = original sample perm[j]; oracle row i = original sample perm_o[i]
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(len(perm))
+        out_o = out[inv[perm_o]]
+        del model, stem, vgg, od, feats
+        torch.cuda.empty_cache()
+        return (float((out_o - ref).abs().max() / ref.abs().max()), float((out_o - ref).norm() / ref.norm()),
+                bool((out_o.argmax(1) == ref.argmax(1)).all()))
+
+    err, l2, same = run("fp32")
+    res = {"oracle_full_size_rel_err": round(err, 9), "oracle_full_size_rel_l2_err": round(l2, 9),
+           "oracle_full_size_argmax_equal": same,
+           "oracle_full_size_what": "precision='fp32' HIP path (stem + FiLM-attn train-mode forward) vs oracle/vnqa_oracle.py "
+                                    "(stem_forward + film_attn_forward, run in the CPU child) on identical weights and the CPU "
+                                    "leg's minibatch: %d clips x %d frames %dx%d; max|d logit| / max|logit|"
+                                    % (Bs, args.frames, args.height, args.width)}
+    if args.precision in ("fp16h", "fp16", "bf16"):
+        # ... and the HEADLINE precision against the oracle DIRECTLY (not through the product's fp32 mode)
+        e16, l16, same16 = run(args.precision)
+        res.update({"oracle_full_size_%s_rel_err" % args.precision: round(e16, 9),
+                    "oracle_full_size_%s_rel_l2_err" % args.precision: round(l16, 9),
+                    "oracle_full_size_%s_argmax_equal" % args.precision: same16,
+                    "oracle_full_size_%s_within_1e-3" % args.precision: bool(e16 <= 1e-3)})
+    return res
 
 
 def smooth_batches(args, device, first=0, count=12):
@@ -558,14 +570,26 @@ def blocks_clip(B, T, H, W, g, n_rect=24):
     return img
 
 
-def blocks_batches(args, device, first=0, count=12):
+def textured_clip(B, T, H, W, g):
+    """[B, 3, H, W, T]: blocks_clip's flat regions MODULATED by a static low-frequency texture per clip (28 x 28 noise upsampled 8 x, gain
+    0.55 .. 1) and a slow global illumination ramp over the frames — flat regions + texture + temporal coherence, the fourth held-out
+    kind (rendered interiors: textured walls under changing light)."""
+    import torch.nn.functional as F
+    img = blocks_clip(B, T, H, W, g, n_rect=12)
+    low = torch.rand(B, 1, H // 8, W // 8, generator=g)
+    tex = 0.55 + 0.45 * F.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)
+    light = 1.0 - 0.25 * torch.rand(B, 1, 1, 1, 1, generator=g) * torch.linspace(0, 1, T).view(1, 1, 1, 1, T)
+    return (img * tex.unsqueeze(-1) * light).clamp_(0, 1)
+
+
+def blocks_batches(args, device, first=0, count=12, kind="blocks"):
     """Minibatches of a kind the stem's calibration frames (half uniform noise, half smooth) contain nothing of: piecewise-constant
-    images — a background colour and 24 drifting rectangles per clip (blocks_clip)."""
+    images — a background colour and 24 drifting rectangles per clip (blocks_clip); kind 'textured' = textured_clip."""
     out = []
     for i in range(first, first + count):
         g = torch.Generator(device="cpu").manual_seed(777 + i)
         B, T = args.batch, args.frames
-        clip = blocks_clip(B, T, args.height, args.width, g)
+        clip = (textured_clip if kind == "textured" else blocks_clip)(B, T, args.height, args.width, g)
         q_lens = torch.randint(5, 26, (B,), generator=g)
         q = torch.randint(1, 134, (B, 56), generator=g)
         q = q * (torch.arange(56).unsqueeze(0) < q_lens.unsqueeze(1)).long()
@@ -612,15 +636,21 @@ def tolerance_sweep(args, device, seeds=(1, 2, 3), count=12):
     out = {"what": "max |d logit| / max |logit| of precision '%s' against precision 'fp32' (identical weights and inputs, train-mode forward, "
                    "%d clips x %d frames %dx%d) on %d seeded minibatches (one full-length, the rest ragged) per entry: other random "
                    "weights (torch.manual_seed(s) before the models are built) smooth clips (14 x 14 noise upsampled 16 x + brightness "
-                   "+ drift) and — a stress test outside max_over_all — blocks clips (piecewise-constant images: a kind the stem's calibration "
-                   "frames, half uniform noise and half smooth, contain nothing of; flat regions make activation roundings coherent)"
+                   "+ drift) and — stress kinds, counted in max_incl_stress — blocks clips (piecewise-constant images, near-identical frames: a kind "
+                   "the stem's calibration frames, half uniform noise and half smooth, contain nothing of; flat regions and repeated frames make "
+                   "the activation roundings coherent over pixels AND frames) and textured clips (flat regions x static texture x light ramp)"
                    % (args.precision, args.batch, args.frames, args.height, args.width, count)}
     noise = parity_batches(args, device, first=0, count=count)
     for s in seeds:
         out["weight_seed_%d" % s] = compare(s, noise)
     del noise
     out["smooth_clips_weight_seed_0"] = compare(0, smooth_batches(args, device, count=count))
-    out["blocks_clips_weight_seed_0"] = compare(0, blocks_batches(args, device, count=count))
+    # held-out kinds (nothing like them in the calibration frames), temporally COHERENT clips: the stress side of the claim
+    blocks = blocks_batches(args, device, count=count)
+    out["blocks_clips_weight_seed_0"] = compare(0, blocks)
+    out["blocks_clips_weight_seed_3"] = compare(3, blocks)
+    del blocks
+    out["textured_clips_weight_seed_3"] = compare(3, blocks_batches(args, device, count=count, kind="textured"))
     return out
 
 
@@ -764,10 +794,15 @@ def precision_parity(args, device, speed_steps=5, fit_steps=12):
             robust["weight_seed_0"] = {"max": twelve["max"], "rms": twelve["rms"], "argmax_equal": twelve["argmax_equal"]}
             # (the tolerance is stated for the benchmark's clips: the blocks entry — a stress kind in which large flat regions make the
             # stored activations' rounding errors COHERENT over pixels — is reported beside max_over_all, not inside it)
+            stress = ("blocks_clips_weight_seed_0", "blocks_clips_weight_seed_3", "textured_clips_weight_seed_3")
             mx = max([twelve["max"]] + [v["max"] for k, v in robust.items() if isinstance(v, dict) and "max" in v
-                                       and k not in ("weight_seed_0", "blocks_clips_weight_seed_0")])
+                                       and k not in ("weight_seed_0",) + stress])
             robust["max_over_all"] = round(mx, 8)
             robust["within_1e-3"] = bool(mx <= 1e-3)
+            # ... and WITH the held-out stress kinds: the compliance flag must not depend on which kinds are counted
+            ms = max([mx] + [robust[k]["max"] for k in stress if k in robust])
+            robust["max_incl_stress"] = round(ms, 8)
+            robust["within_1e-3_incl_stress"] = bool(ms <= 1e-3)
     return {"reference": "precision='fp32' (exact-f32 MFMA kernels; pinned <= 1e-3 to the reference goldens by tests/test_gpu_models.py)",
             "robustness": robust,
             "batches": "3 x (%d clips x %d frames %dx%d): full length, ragged, ragged; train-mode forward"

@@ -93,7 +93,10 @@ typedef struct vnqa_conv_desc {
 #define VNQA_CONV_DUAL_OUT 0x20000 /* y gets 2 c_out channels per pixel (c_y >= 2 c_out): [hi | lo] with hi = h16(v), lo = h16(v - hi) — the fp32
                                    * result v (bias, ReLU, 2x2 max-pool, affine all applied in fp32) as a PAIR of 16-bit values.  A consumer
                                    * that is a plain conv over 2 c_out input channels against [w | w] contracts the unrounded activation.
-                                   * Patch-stationary tiles only (VNQA_TILE_PS_224x256 / _STEM_PS_224x256), 3x3, no border_sub */
+                                   * Patch-stationary tiles (VNQA_TILE_PS_224x256 / _STEM_PS_224x256: 3x3, no border_sub) and — round 6, for the
+                                   * geometries those do not serve (the 10 x 13 maps of 160 x 208 frames) and for the composed 5x5 conv with its
+                                   * border_sub — the 256x256 implicit-GEMM tiles (VNQA_TILE_256x256 / _STEM_256x256: any taps, K-major or
+                                   * pre-tiled weights); both write the same bits */
 #define VNQA_CONV_DUAL_HI2 0x40000 /* with VNQA_CONV_DUAL_OUT: three segments [hi | lo | hi] (c_y >= 3 c_out) — the operand of a consumer that
                                    * contracts the unrounded activation against SPLIT weights [w_hi | w_hi | w_lo] as a plain conv over
                                    * 3 c_out input channels (x_hi w_hi + x_lo w_hi + x_hi w_lo) */
@@ -192,8 +195,8 @@ int vnqa_split3_f32(const float* x, void* hi, void* lo, void* hi2, int64_t rows,
                                  * ReLU (models/film_attn_pt_stem.py:219-241 differentiated); bit-identical to vnqa_relu_bwd(a, b, y) */
 #define VNQA_EPI_SPLIT_OUT 4    /* y = h16(v), y2 = h16(v - y): the conv's fp32 result kept as TWO plain 16-bit tensors of y's geometry (hi + lo =
                                  * v to 2^-22 relative) — conv_init of precision 'fp16h', whose BatchNorm then reads the unrounded value
-                                 * (vnqa_frame_bn_stats_split / _apply_split); patch-stationary tile, 16-bit formats; bias / ReLU of the
-                                 * descriptor apply before the split */
+                                 * (vnqa_frame_bn_stats_split / _apply_split); patch-stationary tile or VNQA_TILE_256x256, 16-bit formats;
+                                 * bias / ReLU of the descriptor apply before the split */
 typedef struct vnqa_conv_epilogue {
   int32_t kind;              /* VNQA_EPI_* */
   int32_t n_frames;          /* BNSTATS */

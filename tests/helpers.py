@@ -6,13 +6,13 @@ import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# The 16-bit precision the GPU tests exercise next to fp32: 'bf16' (libvnqa_hip.so) by default; VNQA_TEST_LOW_PRECISION=fp16
-# re-runs the very same tests on the fp16-storage build (libvnqa_hip_f16.so) — one 16-bit storage format per process, so that
-# run is a separate pytest process (tests/test_gpu_fp16.py starts it).
-LOW = os.environ.get("VNQA_TEST_LOW_PRECISION", "bf16")
+# The 16-bit precision the GPU tests exercise next to fp32: 'fp16' (libvnqa_hip_f16.so: the storage format of the headline precision
+# 'fp16h' and of every constructor default since round 6) by default; VNQA_TEST_LOW_PRECISION=bf16 re-runs the very same tests on the
+# bf16-storage build (libvnqa_hip.so, BASELINE.json's storage dtype) — one 16-bit storage format per process, so that run is a
+# separate pytest process (tests/test_gpu_bf16.py starts it).
+LOW = os.environ.get("VNQA_TEST_LOW_PRECISION", "fp16")
 LOW_DTYPE = torch.float16 if LOW == "fp16" else torch.bfloat16
-if LOW == "fp16":
-    os.environ.setdefault("VNQA_HALF", "f16")      # read by videonavqa_amd._lib when it is first imported
+os.environ.setdefault("VNQA_HALF", "f16" if LOW == "fp16" else "bf16")      # read by videonavqa_amd._lib when it is first imported
 
 
 def load_golden(name):

@@ -307,3 +307,38 @@ def test_overflow_on_one_rank_skips_and_rescales_identically_on_both(tmp_path):
         expect.append(s)
     assert a["scales"] == expect, (a["scales"], expect)
     assert a["skipped"] == 1 and a["state"]["skipped_steps"] == 1
+
+
+def test_one_overflow_episode_halves_the_scale_once_and_the_skip_count_survives_a_resume():
+    """an overflow at step t is observed LAG calls later; steps t+1 .. t+LAG were launched with the OLD scale and
+    normally overflow too.  The whole episode halves the scale ONCE (it used to cost scale / 8); an overflow of a step launched
+    AFTER the halving took effect halves again.  The cumulative skip count is saved as (count before the load + device count)."""
+    sys.path.insert(0, ROOT)
+    from videonavqa_amd.models import common as C
+    from videonavqa_amd.train import DynamicLossScale
+    try:
+        lag = DynamicLossScale.LAG
+        s = DynamicLossScale("cpu", init=1024.0, growth_interval=1000)
+        scales = []
+        overflowing = {3, 4, 5}                   # step 3 overflows; 4 and 5 (= 3 + LAG) still run at the old scale and overflow with it
+        for it in range(12):
+            if it in overflowing:
+                s.count += 1                      # what the fused clip+Adam kernel does on a non-finite norm
+            s.after_step()
+            scales.append(s.scale)
+        first = 3 + lag                           # the call that observes step 3
+        assert scales[:first] == [1024.0] * first and scales[first:] == [512.0] * (12 - first), scales
+        assert s.skipped_steps == 3
+        s.count += 1                              # a step launched at the new scale overflows: a second episode
+        for _ in range(lag + 1):
+            s.after_step()
+        assert s.scale == 256.0 and s.skipped_steps == 4
+        sd = s.state_dict()
+        assert sd["skipped_steps"] == 4
+        t = DynamicLossScale("cpu", init=64.0)
+        t.load_state_dict(sd)
+        assert t.scale == 256.0 and t.skipped_steps == 4 and int(t.count) == 0
+        t.count += 2
+        assert t.state_dict()["skipped_steps"] == 6          # (was: the device count since the load alone)
+    finally:
+        C.set_fp16_loss_scale(C.FP16_GRAD_SCALE)

@@ -78,6 +78,87 @@ def test_dual_output_pair_holds_the_fp32_result_in_two_halves(cfg):
     assert float(lo.abs().max()) <= 2.0 ** -10 * float(hi.abs().max())
 
 
+@pytest.mark.parametrize("cfg", [dict(h=28, w=28, relu=True, pool=True, segs=2), dict(h=14, w=14, relu=True, pool=False, post=True, segs=3),
+                                 dict(h=20, w=26, relu=True, pool=True, segs=2), dict(h=14, w=14, relu=False, pool=False, segs=2, cin=1024)])
+def test_dual_output_of_the_implicit_gemm_tile_equals_the_patch_stationary_one(cfg):
+    """Round 6: VNQA_CONV_DUAL_OUT [| _HI2] on the 256x256 implicit-GEMM tile (TAG 5: fp32 epilogue in two cout passes) writes the
+    SAME [hi | lo (| hi)] tensor as the patch-stationary kernel wherever both serve the geometry (hi bit for bit; lo is the rounding
+    of an fp32 sum formed in another order, so hi + lo agree to the fp32 accumulation's 2^-21) — incl. the 2 C-channel split INPUT."""
+    from videonavqa_amd import _lib as L
+    from videonavqa_amd import kernels as K
+    n, h, w, cin, cout, segs = 5, cfg["h"], cfg["w"], cfg.get("cin", 512), 512, cfg["segs"]
+    x = _padded(n, h, w, cin, 21).half()
+    g = torch.Generator().manual_seed(22)
+    w4 = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda().half().float()
+    wt = K.pack_conv_weight(w4, torch.float16)
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    post = ((torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()) if cfg.get("post") else None
+    kw = dict(bias=bias, relu=cfg["relu"], pool2=cfg["pool"], post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+              dual_out=segs)
+    a = K.conv2d_igemm(x, wt, tile=L.TILE_STEM_PS_224x256, **kw)
+    b = K.conv2d_igemm(x, wt, tile=L.TILE_STEM_256x256, **kw)
+    assert a.shape == b.shape and b.shape[-1] == segs * cout
+    va, vb = a[..., :cout].double() + a[..., cout:2 * cout].double(), b[..., :cout].double() + b[..., cout:2 * cout].double()
+    scale = float(va.abs().max())
+    assert float((va - vb).abs().max()) < 2e-6 * scale
+    flips = float((a[..., :cout] != b[..., :cout]).float().mean())          # (an fp32 sum within 2^-21 of a rounding midpoint may fall either way)
+    assert flips < 2e-3, flips
+    if segs == 3:
+        assert torch.equal(b[..., :cout], b[..., 2 * cout:])
+    assert float(b[:, 0].abs().max()) == 0 and float(b[:, :, -1].abs().max()) == 0 and float(b[:, :, 0].abs().max()) == 0
+
+
+@pytest.mark.parametrize("cfg", [dict(h=10, w=13, relu=True, pool=False, segs=3), dict(h=10, w=13, relu=False, pool=False, segs=2, post=True),
+                                 dict(h=20, w=26, relu=True, pool=True, segs=2, n=7)])
+def test_dual_output_of_the_implicit_gemm_tile_on_the_reference_geometry(cfg):
+    """... and on the maps of the reference's own 160 x 208 frames (eval/utils.py:24-25: 20 x 26 -> 10 x 13), which the patch-stationary
+    tiles do not serve: hi + lo is the fp32 result against a float64 torch conv of the same fp16 operands; hi is the plain launch."""
+    from videonavqa_amd import _lib as L
+    from videonavqa_amd import kernels as K
+    n, h, w, cin, cout, segs = cfg.get("n", 9), cfg["h"], cfg["w"], 512, 512, cfg["segs"]
+    x = _padded(n, h, w, cin, 31).half()
+    g = torch.Generator().manual_seed(32)
+    w4 = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda().half().float()
+    wt = K.pack_conv_weight(w4, torch.float16)
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    post = ((torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()) if cfg.get("post") else None
+    kw = dict(bias=bias, relu=cfg["relu"], pool2=cfg["pool"], post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+              tile=L.TILE_STEM_256x256)
+    plain = K.conv2d_igemm(x, wt, **kw)
+    pair = K.conv2d_igemm(x, wt, dual_out=segs, **kw)
+    hi, lo = pair[..., :cout], pair[..., cout:2 * cout]
+    if post is None:
+        assert torch.equal(hi, plain)
+    ref = _torch_conv(x.float(), w4, bias, cfg["relu"], cfg["pool"], post)
+    got = (hi.double() + lo.double())[:, 1:-1, 1:-1]
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 3e-6 * scale, float((got - ref).abs().max()) / scale
+    assert float(lo.abs().max()) <= 2.0 ** -10 * float(hi.abs().max())
+    assert float(pair[:, 0].abs().max()) == 0 and float(pair[:, :, -1].abs().max()) == 0
+
+
+def test_split_out_on_the_implicit_gemm_tile_equals_the_patch_stationary_one():
+    """VNQA_EPI_SPLIT_OUT (conv_init of precision 'fp16h') on tile 256x256: the two tensors (hi, lo) of the 10 x 13 trunk."""
+    from videonavqa_amd import _lib as L
+    from videonavqa_amd import kernels as K
+    n, cin, cout = 6, 512, 128
+    g = torch.Generator().manual_seed(42)
+    w4 = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+    wt32 = K.pack_conv_weight(w4, torch.float32)
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    for h, w in ((14, 14), (10, 13)):
+        tri = _split3(_padded(n, h, w, cin, 41, positive=True))
+        hb, lb = K.conv2d_igemm_split_out(tri, wt32, bias, True, split_in=True, tile=L.TILE_256x256)
+        if (h, w) == (14, 14):
+            ha, la = K.conv2d_igemm_split_out(tri, wt32, bias, True, split_in=True)
+            sa, sb = ha.double() + la.double(), hb.double() + lb.double()
+            assert float((sa - sb).abs().max()) < 2e-6 * float(sa.abs().max())
+        plain = K.conv2d_igemm(tri, wt32, bias=bias, relu=True, split_in=True)
+        assert float((hb != plain).float().mean()) < 2e-3
+        assert float(lb.abs().max()) <= 2.0 ** -10 * float(hb.abs().max())
+        assert float(hb[:, 0].abs().max()) == 0 and float(lb[:, :, -1].abs().max()) == 0
+
+
 def test_conv_over_a_pair_tensor_with_doubled_weights_contracts_the_unrounded_activation():
     """The stem's conv31 / conv32 in precision 'fp16h': a plain conv over the pair tensor's 2 C channels against [w | w] equals the
     conv of the fp32 activation (hi + lo) with w — the consumer no longer sees the producer's storage rounding."""
@@ -314,7 +395,7 @@ def test_fp16h_stem_split_features_are_closer_to_exact_than_the_fp16_stem():
     """The frozen stem at 224 x 224 (the geometry whose 28 x 28 / 14 x 14 maps the pair path serves): pair features (hi + lo) against
     the exact-f32 stem are closer than the fp16 stem's, the hi half is a valid fp16 feature tensor, and with split_features=False
     (consumers that read no pairs) the output is a plain tensor of the usual shape.  At 160 x 208 (10 x 13 maps: not served by the
-    patch-stationary kernel) the stem falls back to the fp16 precision's layers, bit for bit."""
+    patch-stationary kernel) the split tensors come from the implicit-GEMM tile's dual epilogue."""
     from videonavqa_amd.models.common import FrameLayout
     from videonavqa_amd.stem import FrozenStem
     torch.set_grad_enabled(False)
@@ -335,12 +416,19 @@ def test_fp16h_stem_split_features_are_closer_to_exact_than_the_fp16_stem():
         e_hp = float((out["hp"].double() - ref).pow(2).mean().sqrt())
         assert e_h < 0.8 * e_p and e_hp < 0.95 * e_p, (e_h, e_hp, e_p)
         assert float((out["h"][..., :512].double() - ref).abs().max()) < 4e-3 * float(ref.abs().max())
+        # the reference's own geometry (eval/utils.py:24-25: 160 x 208 frames -> 20 x 26 and 10 x 13 maps): conv22 on the patch-stationary
+        # tile, conv31 / conv32 on the implicit-GEMM tile's dual epilogue (round 6; rounds 4-5 fell back to plain fp16 here)
         clip = torch.rand(2, 3, 160, 208, 2, generator=torch.Generator().manual_seed(6)).cuda()
-        res = []
-        for prec in ("fp16h", "fp16"):
+        res = {}
+        for prec in ("fp32", "fp16h", "fp16"):
             vgg, od = _random_stem(prec)
-            res.append(FrozenStem(vgg, od, prec).forward_clip(clip, lay.img_of, lay.n_img).clone())
-        assert res[0].shape == res[1].shape and torch.equal(res[0], res[1])
+            res[prec] = FrozenStem(vgg, od, prec).forward_clip(clip, lay.img_of, lay.n_img).clone()
+        assert res["fp16h"].shape == (3, 12, 15, 1536) and res["fp16"].shape == (3, 12, 15, 512)
+        assert torch.equal(res["fp16h"][..., :512], res["fp16h"][..., 1024:])
+        ref = res["fp32"][..., :512].double()
+        pair = res["fp16h"][..., :512].double() + res["fp16h"][..., 512:1024].double()
+        e_h, e_p = float((pair - ref).pow(2).mean().sqrt()), float((res["fp16"].double() - ref).pow(2).mean().sqrt())
+        assert e_h < 0.8 * e_p, (e_h, e_p)
     finally:
         torch.set_grad_enabled(True)
 

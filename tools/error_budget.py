@@ -3,7 +3,7 @@
 the headline size) on N seeded minibatches (default 12: one full-length, the rest ragged): the maximum over the minibatches (the
 tests' criterion), their RMS and mean, and how many answers differ.
 
-  python tools/error_budget.py [--batches 12] [--seed S] [--data noise|smooth|blocks] [--precision fp16h|fp16|bf16]
+  python tools/error_budget.py [--batches 12] [--seed S] [--data noise|smooth|blocks|textured] [--precision fp16h|fp16|bf16]
 (tools/experiments/precision_budget.py has the per-rounding-point budget behind the mode's design)"""
 import argparse
 import copy
@@ -36,6 +36,8 @@ def batches(args, device, n, data="noise"):
             clip = (up * gain + drift).clamp_(0, 1).permute(0, 2, 3, 4, 1).contiguous()
         elif data == "blocks":       # a THIRD kind, like neither half of the calibration frames: piecewise-constant images
             clip = bench.blocks_clip(B, T, args.height, args.width, g)
+        elif data == "textured":     # a FOURTH: flat regions x static texture x slow illumination ramp (bench.textured_clip)
+            clip = bench.textured_clip(B, T, args.height, args.width, g)
         else:
             clip = torch.rand(B, 3, args.height, args.width, T, generator=g)
         q_lens = torch.randint(5, 26, (B,), generator=g)
@@ -71,14 +73,18 @@ def run(args, prec, device, data):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batches", type=int, default=12)
-    ap.add_argument("--data", default="noise", choices=["noise", "smooth", "blocks"], help="the minibatches' pixel statistics (the default "
+    ap.add_argument("--data", default="noise", choices=["noise", "smooth", "blocks", "textured"], help="the minibatches' pixel statistics (the default "
                     "calibration frames are half uniform noise, half smooth; 'blocks' is like neither)")
     ap.add_argument("--seed", type=int, default=0, help="seed of the random weights (0 = the benchmark's)")
     ap.add_argument("--precision", default="fp16h", help="the precision under test (fp16h, fp16, bf16)")
+    ap.add_argument("--height", type=int, default=224)
+    ap.add_argument("--width", type=int, default=224, help="--height 160 --width 208: the reference's own frames (eval/utils.py:24-25)")
+    ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop"])
+    ap.add_argument("--frames", type=int, default=35)
     ap.add_argument("settings", nargs="*", default=["COH=1"], help="one pass per argument; each word KEY=VALUE of it sets an environment variable (COH = VNQA_COHERENT_ROUND) or, "
                     "as module.ATTRIBUTE=int, a module attribute of the package for that pass")
     o = ap.parse_args()
-    args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
+    args = argparse.Namespace(precision="fp32", model=o.model, batch=8, frames=o.frames, height=o.height, width=o.width, blocks=1, channels=512,
                               tail_channels=0, seed=o.seed)
     from videonavqa_amd import _lib as L
     L.set_half("bf16" if o.precision == "bf16" else "f16")

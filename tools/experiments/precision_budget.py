@@ -43,11 +43,43 @@ def budget_mod():
 class Setting(object):
     """acts: set of activation points rounded to fp16; wmode: {weight name: 'rtn' | 'coh'} (absent = exact)."""
 
-    def __init__(self, name, acts=(), wmode=None):
-        self.name, self.acts, self.wmode = name, set(acts), dict(wmode or {})
+    def __init__(self, name, acts=(), wmode=None, amode=None):
+        """amode: {activation point: 'h8' | 'h4' | 'dither'} — what the point stores instead of plain fp16 ('h8': fp16 hi + an e4m3 lo
+        with one power-of-two scale per tensor; 'h4': fp16 hi + an MX-fp4 (e2m1, one E8M0 scale per 32 channels) lo; 'dither': fp16
+        with a position-dependent rounding offset)."""
+        self.name, self.acts, self.wmode, self.amode = name, set(acts), dict(wmode or {}), dict(amode or {})
 
     def R(self, key, t):
-        return t.half().float() if key in self.acts else t
+        if key not in self.acts:
+            return t
+        m = self.amode.get(key)
+        hi = t.half().float()
+        if m is None:
+            return hi
+        lo = t - hi
+        if m == "h8":
+            sc = 2.0 ** torch.floor(torch.log2(256.0 / lo.abs().max().clamp_min(1e-30)))
+            return hi + (lo * sc).to(torch.float8_e4m3fn).float() / sc
+        if m == "h4":
+            return hi + mxfp4(lo)
+        if m == "dither":
+            u = torch.rand_like(t) - 0.5
+            ulp = 2.0 ** (torch.floor(torch.log2(t.abs().clamp_min(6.2e-5))) - 10)
+            return (t + u * ulp).half().float()
+        raise ValueError(m)
+
+
+def mxfp4(lo):
+    """e2m1 values {0, .5, 1, 1.5, 2, 3, 4, 6} x 2^s, one shared s per block of 32 consecutive CHANNELS (dim 1) of a pixel"""
+    n, c, h, w = lo.shape
+    cb = 32 if c % 32 == 0 else c
+    b = lo.view(n, c // cb, cb, h, w)
+    amax = b.abs().amax(dim=2, keepdim=True).clamp_min(1e-30)
+    s = 2.0 ** (torch.floor(torch.log2(amax)) - 2)            # the block maximum lands in [4, 8) -> grid top 6
+    v = (b / s).clamp(-6, 6)
+    a = v.abs()
+    q = torch.where(a < 2, torch.round(a * 2) / 2, torch.where(a < 4, torch.round(a), torch.round(a / 2) * 2))
+    return (torch.sign(v) * q * s).view(n, c, h, w)
 
 
 STEM_W = ["sw_c11", "sw_c12", "sw_c21", "sw_c22", "sw_comp", "sw_od21", "sw_od22", "sw_od31", "sw_od32"]
@@ -279,6 +311,37 @@ def settings_list(only_combos=False):
     return S
 
 
+def settings_round6():
+    """Round 6: what is left of the fp16h precision's error, point by point, on clips of another kind (--data blocks ...), and what the
+    candidate fixes leave."""
+    left = ["a_clip", "a_c11", "a_c12", "a_c21", "a_c22", "a_comp", "a_od21"]
+    trunk = ["a_init", "a_bn", "a_res", "a_out"]
+    S = [Setting(p, [p]) for p in left + ["a_od22", "a_od31", "a_feat"] + trunk]
+    base = left + trunk
+    S.append(Setting("fp16h acts (7 stem + 4 trunk)", base))
+    for p in left:
+        S.append(Setting("fp16h acts - " + p, [a for a in base if a != p]))
+    S.append(Setting("fp16h acts - clip,od21", [a for a in base if a not in ("a_clip", "a_od21")]))
+    S.append(Setting("fp16h acts - clip,od21,comp", [a for a in base if a not in ("a_clip", "a_od21", "a_comp")]))
+    S.append(Setting("fp16h acts - clip,c12,od21", [a for a in base if a not in ("a_clip", "a_c12", "a_od21")]))
+    S.append(Setting("fp16h acts - clip,c12,c21,od21", [a for a in base if a not in ("a_clip", "a_c12", "a_c21", "a_od21")]))
+    S.append(Setting("fp16h acts - clip,c12,c21,comp,od21", [a for a in base if a not in ("a_clip", "a_c12", "a_c21", "a_comp", "a_od21")]))
+    S.append(Setting("fp16h acts - all stem (trunk only)", trunk))
+    S.append(Setting("fp16h acts, od21 as hi + e4m3 lo", base, amode={"a_od21": "h8"}))
+    S.append(Setting("fp16h acts, od21 as hi + mxfp4 lo", base, amode={"a_od21": "h4"}))
+    S.append(Setting("fp16h acts, od21,comp as hi + mxfp4 lo", base, amode={"a_od21": "h4", "a_comp": "h4"}))
+    S.append(Setting("fp16h acts, all 7 stem dithered", base, amode={p: "dither" for p in left}))
+    S.append(Setting("stem acts (all 10)", STEM_ACTS))
+    S.append(Setting("w_3x3:rtn", wmode={"w_3x3": "rtn"}))
+    S.append(Setting("w_init:rtn", wmode={"w_init": "rtn"}))
+    S.append(Setting("w_1x1:rtn", wmode={"w_1x1": "rtn"}))
+    S.append(Setting("w_fc:rtn", wmode={"w_fc": "rtn"}))
+    S.append(Setting("stem weights (all 9, coherent)", STEM_W))
+    S.append(Setting("early stem acts only (clip,c11,c12,c21,c22)", ["a_clip", "a_c11", "a_c12", "a_c21", "a_c22"]))
+    S.append(Setting("trunk acts only (init,bn,res,out)", trunk))
+    return S
+
+
 def product_logits(args, prec, device, data):
     bm = budget_mod()
     return bm.run(args, prec, device, data)
@@ -288,7 +351,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, nargs="*", default=[0, 1, 2, 3])
     ap.add_argument("--batches", type=int, default=12)
-    ap.add_argument("--data", default="noise", choices=["noise", "smooth"])
+    ap.add_argument("--data", default="noise", choices=["noise", "smooth", "blocks", "textured"])
+    ap.add_argument("--height", type=int, default=224)
+    ap.add_argument("--width", type=int, default=224, help="--height 160 --width 208: the reference's own frames (10 x 13 maps)")
+    ap.add_argument("--per-batch", action="store_true", help="print every setting's error per minibatch (last seed) as well")
+    ap.add_argument("--round6", action="store_true", help="the round-6 settings (what is left of fp16h's error, and the candidate fixes)")
     ap.add_argument("--only-combos", action="store_true")
     ap.add_argument("--no-product", action="store_true", help="skip the cross-checks against the library's fp32 / fp16 precisions")
     o = ap.parse_args()
@@ -298,12 +365,12 @@ def main():
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
     bm = budget_mod()
-    S = settings_list(o.only_combos)
+    S = settings_round6() if o.round6 else settings_list(o.only_combos)
     acc = {s.name: [] for s in S}
-    per_seed = {}
+    per_seed, last_errs = {}, {}
     t0 = time.time()
     for seed in o.seeds:
-        args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
+        args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=o.height, width=o.width, blocks=1, channels=512,
                                   tail_channels=0, seed=seed)
         data = bm.batches(args, dev, o.batches, o.data)
         model, stem, vgg, od = bench.build(args, dev)
@@ -338,7 +405,7 @@ def main():
         for s in S:
             wq = trunk_weights(W, s, means)
             errs = []
-            sk = tuple(sorted(a for a in s.acts if a in STEM_ACTS or a in STEM_W))
+            sk = tuple(sorted(a for a in s.acts if a in STEM_ACTS or a in STEM_W)) + tuple(sorted(s.amode.items()))
             for bi, (frames, cts, film, perm, v_sorted, feat0) in enumerate(packed):
                 if not sk:
                     feat = feat0.to(dev)
@@ -349,6 +416,7 @@ def main():
                 out = sim_trunk(W, wq, feat, cts, film, 8, 35, s).cpu()
                 errs.append(float((out - refs[bi]).abs().max() / refs[bi].abs().max()) * 1e3)
             acc[s.name] += errs
+            last_errs[s.name] = errs
             per_seed.setdefault(s.name, []).append(max(errs))
             if len(stem_cache) > 36:
                 stem_cache.clear()
@@ -357,7 +425,8 @@ def main():
     for s in S:
         e = acc[s.name]
         sq = sum(x * x for x in e) / len(e)
-        print("%-78s %7.4f %7.3f %7.3f   %s" % (s.name, sq, sq ** 0.5, max(e), " ".join("%.2f" % x for x in per_seed[s.name])), flush=True)
+        print("%-78s %7.4f %7.3f %7.3f   %s%s" % (s.name, sq, sq ** 0.5, max(e), " ".join("%.2f" % x for x in per_seed[s.name]),
+                                                  ("   | " + " ".join("%.2f" % x for x in last_errs[s.name])) if o.per_batch else ""), flush=True)
 
 
 if __name__ == "__main__":

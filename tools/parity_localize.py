@@ -20,14 +20,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="film_attn_pt")
     ap.add_argument("--frames", type=int, default=35)
-    ap.add_argument("--low", default="bf16", choices=["bf16", "fp16"], help="the 16-bit storage format under test")
+    ap.add_argument("--low", default="bf16", choices=["bf16", "fp16", "fp16h"], help="the 16-bit precision under test")
+    ap.add_argument("--height", type=int, default=224)
+    ap.add_argument("--width", type=int, default=224)
+    ap.add_argument("--seed", type=int, default=0, help="weight seed (bench.build)")
+    ap.add_argument("--batches", type=int, default=0, help="> 0: tools/error_budget.py's seeded minibatches 0..N-1 instead of the three parity batches")
     a = ap.parse_args()
     from videonavqa_amd import _lib as L
-    L.set_half("f16" if a.low == "fp16" else "bf16")      # one 16-bit format per process, fixed before the fp32 build
-    args = argparse.Namespace(precision=a.low, batch=8, frames=a.frames, height=224, width=224, blocks=1, channels=512,
-                              model=a.model)
+    L.set_half("f16" if a.low in ("fp16", "fp16h") else "bf16")      # one 16-bit format per process, fixed before the fp32 build
+    args = argparse.Namespace(precision=a.low, batch=8, frames=a.frames, height=a.height, width=a.width, blocks=1, channels=512,
+                              model=a.model, seed=a.seed, tail_channels=0)
     dev = torch.device("cuda", 0)
-    batches = Bn.parity_batches(args, dev)
+    if a.batches > 0:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("error_budget", os.path.join(os.path.dirname(os.path.abspath(__file__)), "error_budget.py"))
+        eb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(eb)
+        batches = [(c.to(dev), q.to(dev), vl, ql, None) for c, q, vl, ql in eb.batches(args, dev, a.batches)]
+    else:
+        batches = Bn.parity_batches(args, dev)
     tr = {}
     for prec in ("fp32", a.low):
         b = copy.copy(args)
@@ -39,8 +50,14 @@ def main():
     def logits(stem_prec, trunk_prec, batch):
         clip, q, v_lens, q_lens, y = batch
         native, v_sorted, perm = tr[stem_prec].extract_features(clip, v_lens)
-        cdt = torch.float32 if trunk_prec == "fp32" else (torch.float16 if a.low == "fp16" else torch.bfloat16)
-        native = NativeFeatures(native.data.to(cdt), native.layout, native.channels, native.h, native.w)
+        cdt = torch.float32 if trunk_prec == "fp32" else (torch.float16 if a.low in ("fp16", "fp16h") else torch.bfloat16)
+        data = native.data
+        if data.shape[-1] == 3 * 512 and (trunk_prec == "fp32" or stem_prec == "fp32"):      # split features into another precision's trunk: hi + lo
+            data = data[..., :512].float() + data[..., 512:1024].float()
+        if stem_prec == "fp32" and trunk_prec == "fp16h":      # exact features into the split-reading trunk: [hi | lo | hi]
+            hi = data.half()
+            data = torch.cat([hi, (data - hi.float()).half(), hi], dim=-1).contiguous()
+        native = NativeFeatures(data.to(cdt).contiguous(), native.layout, native.channels, native.h, native.w)
         m = tr[trunk_prec].model
         m.init_hidden()
         with torch.no_grad():

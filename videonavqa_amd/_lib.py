@@ -13,7 +13,8 @@ LIB_PATH_F16 = os.path.join(_HERE, "lib", "libvnqa_hip_f16.so")
 
 # The library's 16-bit storage format is a BUILD property (csrc/vnqa_common.h): libvnqa_hip.so stores bf16,
 # libvnqa_hip_f16.so IEEE fp16 (same MFMA rate, 8x finer rounding, +-65504 range).  One format per process: it is fixed by
-# the first model / stem built (precision 'bf16' | 'fp16'; 'fp32' works with either) or by VNQA_HALF=bf16|f16.
+# the first model / stem built (precision 'bf16' | 'fp16' | 'fp16h'; 'fp32' works with either) or by VNQA_HALF=bf16|f16; a process
+# that loads the library before anybody asked gets f16, the format of the default precision 'fp16h' (round 6; bf16 until round 5).
 _half = os.environ.get("VNQA_HALF")          # None until somebody needs a 16-bit format
 
 
@@ -246,8 +247,8 @@ def lib():
     """Load (once) and return the CDLL; raises if the HIP library has not been built."""
     global _lib, _half
     if _lib is None:
-        if _half is None:
-            _half = "bf16"
+        if _half is None:          # nobody asked for a format yet: the one the default precision ('fp16h') stores in
+            _half = "f16"
         path = LIB_PATH_F16 if (_half == "f16" and "VNQA_LIB" not in os.environ) else LIB_PATH
         if "VNQA_LIB" not in os.environ and os.path.exists("/opt/rocm/bin/hipcc") \
                 and os.environ.get("VNQA_NO_REBUILD", "0") != "1":

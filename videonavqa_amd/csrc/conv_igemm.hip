@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     tile_n = swz % p.tilesN;
     tile_m = swz / p.tilesN;
-    if constexpr (TAG == 1) {
+    if constexpr (TAG == 1 || TAG == 5) {
       // VNQA_CONV_XCD_SPLIT_N (stem launches with two cout tiles: the composed 5x5 conv): XCD x owns cout half x & 1 ONLY, the pixel
       // tiles of that half dealt to the four XCDs of its parity in contiguous runs.  An XCD's L2 (4 MiB) then holds ONE half of the
       // weight set (1.65 of the composed conv's 3.3 MB) next to its 32 tiles' activation windows instead of thrashing on both
@@ -611,6 +611,119 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     }
     return;
   }
+  if constexpr (TAG == 5) {
+    // DUAL output on the implicit-GEMM tile (VNQA_CONV_DUAL_OUT [| VNQA_CONV_DUAL_HI2], VNQA_EPI_SPLIT_OUT; precision 'fp16h' on the
+    // geometries the patch-stationary tiles do not serve — the 10 x 13 maps of the reference's 160 x 208 frames, eval/utils.py:24-25 —
+    // and on the composed 5x5 conv): the fp32 result as a PAIR of 16-bit values hi = h16(v), lo = h16(v - hi), channel segments
+    // [hi | lo (| hi)] of y or two plain tensors (y, y2) — the same values, bit for bit, as conv_ps_kernel<.., TAG 2> writes.
+    // Everything is finished in fp32 (bias, border correction, ReLU, 2x2 max-pool, affine); the tile goes through LDS as fp32 in
+    // passes of 128 couts (the wave columns of cout range `pass` stage, all waves store): the LDS bytes of the 16-bit epilogue.
+    static_assert(ES == 2 && MT == 16, "dual epilogue: 16-bit instantiations on the 16x16x32 MFMA");
+    constexpr int PASSES = BN > 128 ? BN / 128 : 1;
+    constexpr int PN = BN / PASSES;                 // couts per pass
+    constexpr int WPP = WAVES_N / PASSES;           // wave columns per pass
+    static_assert(WAVES_N % PASSES == 0 && PN % 8 == 0 && WPP * WTN == PN, "dual epilogue: wave columns / passes mismatch");
+    constexpr int CROWF = PN * 4 + 16;
+    constexpr int CHF = PN / 8;                     // 8-channel chunks (32 B of fp32) per staged row
+    const bool has_post_d = (p.post_scale != nullptr);
+    const int rows_out_d = p.pool ? BM / 4 : BM;
+    const int M_out_d = p.pool ? (p.M >> 2) : p.M;
+    const int Hod = p.pool ? (p.H >> 1) : p.H, Wod = p.pool ? (p.W >> 1) : p.W;
+    int ring_row_d[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ring_row_d[i] = -1;
+      if (p.border_sub != nullptr) {
+        const int m = tile_m * BM + wm * WTM + i * MT + fr;
+        if (m < p.M) {
+          int n, y, x;
+          decode_pixel(m, p.H, p.W, p.pool, n, y, x);
+          int ring = -1;
+          if (y == 0) ring = x;
+          else if (y == p.H - 1) ring = p.W + x;
+          else if (x == 0) ring = 2 * p.W + (y - 1);
+          else if (x == p.W - 1) ring = 2 * p.W + (p.H - 2) + (y - 1);
+          if (ring >= 0) ring_row_d[i] = n * (2 * p.W + 2 * (p.H - 2)) + ring;
+        }
+      }
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass) {
+      if (wn / WPP == pass) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = wn * WTN + j * MT + 4 * fh;          // tile-local cout of e = 0
+          const int co = tile_n * BN + col;
+          float b4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) b4[e] = (p.bias != nullptr && co + e < p.Cout) ? p.bias[co + e] : 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int prow = wm * WTM + i * MT + fr;
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ring_row_d[i] >= 0 && co + 3 < p.Cout) {
+              const uint2 raw = *(const uint2*)((const char*)p.border_sub + ((size_t)ring_row_d[i] * p.Cout + co) * ES);
+              s4[0] = h16_lo(raw.x); s4[1] = h16_hi(raw.x); s4[2] = h16_lo(raw.y); s4[3] = h16_hi(raw.y);
+            }
+            float4 v;
+            v.x = vnqa_conv_act<TAG>(acc[i][j][0] + b4[0] - s4[0], p.relu);
+            v.y = vnqa_conv_act<TAG>(acc[i][j][1] + b4[1] - s4[1], p.relu);
+            v.z = vnqa_conv_act<TAG>(acc[i][j][2] + b4[2] - s4[2], p.relu);
+            v.w = vnqa_conv_act<TAG>(acc[i][j][3] + b4[3] - s4[3], p.relu);
+            *(float4*)(smem + prow * CROWF + (col - pass * PN) * 4) = v;
+          }
+        }
+      }
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < rows_out_d * CHF; idx += NT) {
+        const int orow = idx / CHF, c = idx - orow * CHF;
+        const int mo = tile_m * rows_out_d + orow;
+        const int co0 = tile_n * BN + pass * PN + c * 8;
+        if (mo >= M_out_d || co0 >= p.Cout) continue;
+        float v[8];
+        if (p.pool) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = -INFINITY;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const float4 a0 = *(const float4*)(smem + (orow * 4 + d) * CROWF + c * 32);
+            const float4 a1 = *(const float4*)(smem + (orow * 4 + d) * CROWF + c * 32 + 16);
+            v[0] = fmaxf(v[0], a0.x); v[1] = fmaxf(v[1], a0.y); v[2] = fmaxf(v[2], a0.z); v[3] = fmaxf(v[3], a0.w);
+            v[4] = fmaxf(v[4], a1.x); v[5] = fmaxf(v[5], a1.y); v[6] = fmaxf(v[6], a1.z); v[7] = fmaxf(v[7], a1.w);
+          }
+        } else {
+          const float4 a0 = *(const float4*)(smem + orow * CROWF + c * 32);
+          const float4 a1 = *(const float4*)(smem + orow * CROWF + c * 32 + 16);
+          v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        }
+        if (has_post_d) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
+        }
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hw[e] = pack2_h16(v[2 * e], v[2 * e + 1]);
+          lw[e] = pack2_h16(v[2 * e] - h16_lo(hw[e]), v[2 * e + 1] - h16_hi(hw[e]));
+        }
+        const int n = mo / (Hod * Wod);
+        const int rem = mo - n * (Hod * Wod);
+        const int yo = rem / Wod;
+        const int xo = rem - yo * Wod;
+        const size_t ooff = (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+        vnqa_bf16* dst = (vnqa_bf16*)(p.y) + ooff;
+        *(uint4*)dst = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        if (p.dual_out == 4) {      // VNQA_EPI_SPLIT_OUT: hi and lo as TWO plain tensors of y's geometry (y, y2)
+          *(uint4*)((vnqa_bf16*)(p.y2) + ooff) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+          continue;
+        }
+        *(uint4*)(dst + p.Cout) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        if (p.dual_out == 2) *(uint4*)(dst + 2 * p.Cout) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   // row of the border-correction tensor for each of this lane's pixels (-1: interior pixel or no correction)
   int ring_row[TM];
 #pragma unroll
@@ -1044,6 +1157,21 @@ int fused_tile_rows(int dtype, int tile) {
 
 int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
   tile = resolve_tile(a, dtype, tile);
+  if (a.dual_out && tile != VNQA_TILE_PS_224x256 && tile != VNQA_TILE_STEM_PS_224x256) {
+    // [hi | lo (| hi)] / (hi, lo) output on the implicit-GEMM tile: the TAG 5 instantiation of the 256 x 256 tile (fp32 epilogue)
+    if (dtype != VNQA_BF16 || a.epi != VNQA_EPI_NONE || a.D != 0 || a.ring_h != 0 || a.partial != nullptr || a.group_tiles != 0 ||
+        a.zero_halo || a.x_wrap2 || a.relu == VNQA_ACT_ELU || a.Cout % 8 != 0 || a.Cy < (a.dual_out == 4 ? 1 : a.dual_out + 1) * a.Cout ||
+        (a.dual_out == 4 && a.y2 == nullptr) || (a.pool && (a.H % 2 != 0 || a.W % 2 != 0))) {
+      vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT on the implicit-GEMM tile needs a plain 16-bit 2-D conv (no fused epilogue / "
+                     "split-K / halo zeroing / wrap), c_out %% 8 == 0 and c_y >= 2 c_out (3 c_out with VNQA_CONV_DUAL_HI2)");
+      return VNQA_ERR_UNSUPPORTED;
+    }
+    if (tile != VNQA_TILE_256x256 && tile != VNQA_TILE_STEM_256x256) {
+      vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT is served by the patch-stationary tiles and the 256x256 tiles (got tile %d)", tile);
+      return VNQA_ERR_UNSUPPORTED;
+    }
+    return launch<vnqa_bf16, 256, 256, 2, 4, 5>(a, st);
+  }
   if (a.relu == VNQA_ACT_ELU) {        // own instantiations of the plain tiles (conv_args.h: why not a runtime branch)
     if (a.epi != VNQA_EPI_NONE || a.partial != nullptr || a.pool) {
       vnqa_set_error("conv2d_igemm_fwd: the ELU epilogue comes without pooling, split-K and fused trunk epilogues");
@@ -1418,8 +1546,9 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
   a.xcd_split = (d->flags & VNQA_CONV_XCD_SPLIT_N) ? 1 : 0;
   a.x_wrap2 = (d->flags & VNQA_CONV_X_WRAP2) ? 1 : 0;
   a.dual_out = (d->flags & VNQA_CONV_DUAL_OUT) ? ((d->flags & VNQA_CONV_DUAL_HI2) ? 2 : 1) : 0;
-  VNQA_CHECK_ARG(!a.dual_out || d->tile == VNQA_TILE_PS_224x256 || d->tile == VNQA_TILE_STEM_PS_224x256,
-                 "conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT is served by the patch-stationary tiles only");
+  VNQA_CHECK_ARG(!a.dual_out || d->tile == VNQA_TILE_PS_224x256 || d->tile == VNQA_TILE_STEM_PS_224x256 ||
+                     d->tile == VNQA_TILE_256x256 || d->tile == VNQA_TILE_STEM_256x256,
+                 "conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT is served by the patch-stationary tiles and the 256x256 implicit-GEMM tiles");
   a.pool = d->pool2;
   a.M = d->n_img * d->h * d->w;
   a.tilesN = 0;
@@ -1610,8 +1739,8 @@ extern "C" int vnqa_conv2d_igemm_fused_fwd(const vnqa_conv_desc* d, const void* 
   VNQA_CHECK_ARG(!d->pool2 && d->depth == 0 && !d->wt_tiled, "conv2d_igemm_fused_fwd: 2-D, un-pooled, K-major weights only");
   hipStream_t st = (hipStream_t)stream;
   if (e->kind == VNQA_EPI_SPLIT_OUT) {      // y = h16(v), y2 = h16(v - y): the fp32 accumulator kept as TWO plain 16-bit tensors
-    VNQA_CHECK_ARG(e->y2 && y && d->tile == VNQA_TILE_PS_224x256 && !(d->flags & VNQA_CONV_DUAL_OUT),
-                   "conv2d_igemm_fused_fwd(SPLIT_OUT): y, y2 and the patch-stationary tile are required");
+    VNQA_CHECK_ARG(e->y2 && y && (d->tile == VNQA_TILE_PS_224x256 || d->tile == VNQA_TILE_256x256) && !(d->flags & VNQA_CONV_DUAL_OUT),
+                   "conv2d_igemm_fused_fwd(SPLIT_OUT): y, y2 and the patch-stationary tile (or the 256x256 implicit-GEMM tile) are required");
     a.dual_out = 4;
     a.y2 = (char*)e->y2;
     return conv_dispatch(a, d->dtype, d->tile, st);

@@ -65,7 +65,7 @@ def build_parser():
     parser.add_argument('--best_acc', type=float, default=0)          # passed by eval.sh:57, unused upstream
     # additions
     parser.add_argument('--synthetic', type=int, default=0)
-    parser.add_argument('--precision', type=str, choices=['bf16', 'fp16', 'fp16h', 'fp32'], default='bf16')
+    parser.add_argument('--precision', type=str, choices=['bf16', 'fp16', 'fp16h', 'fp32'], default='fp16h')
     # how the frozen stem's 16-bit weights are rounded (stem.coherent_round): against the mean activations of seeded noise frames
     # ('noise'), of frames of the first training videos ('data'), or to nearest ('off')
     parser.add_argument('--stem_calibration', type=str, choices=['noise', 'data', 'off'], default='noise')
@@ -248,6 +248,20 @@ def stem_calibration(args, dataset, n_frames=40):
     return torch.cat(frames)[:n_frames].contiguous()
 
 
+def check_stem_against_checkpoint(stem, ckpt, rank=0):
+    """The rebuilt stem's rounded 16-bit packs against the checksum the checkpoint carries (Trainer.extra_state_dict): re-rounding from
+    the calibration frames is bit-reproducible on the same GPU / ROCm / torch build only.  Returns True / False / None (nothing to check)."""
+    want = ((ckpt or {}).get('extra_state') or {}).get('_stem_packs_sha256')
+    if want is None or not hasattr(stem, 'packs_checksum'):
+        return None
+    ok = stem.packs_checksum() == want
+    if rank == 0:
+        print('=> stem weights %s' % ('reproduced bit for bit from the checkpoint\'s calibration' if ok else
+                                      'DIFFER from the ones this checkpoint was trained behind (another GPU / ROCm / torch build re-rounded a tie '
+                                      'differently, or another precision / split depth): expect logits differences of the order of one 16-bit weight rounding'))
+    return ok
+
+
 def val_epoch(args, trainer, data_loader, device, rank=0, world=1):
     """q_and_v_eval.py:159-224 on the inference path: Trainer.eval_step (forward-only fused trunk, the stem of the NEXT
     minibatch and its H2D copy overlapping this minibatch's trunk, as in training), loss / predictions / targets kept on the
@@ -348,8 +362,24 @@ def main(argv=None):
     if rank == 0:
         print(obj_detector)
         print(model)
-    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=stem_calibration(args, train_data),
-                      split_features=args.model != 'mac')
+    # A RESUMED run continues behind the stem weights it started with: the checkpoint's own calibration (frames / means), not the
+    # flags' (the flags may disagree, and the default number of calibration frames changed between builds)
+    ckpt = None
+    calib = stem_calibration(args, train_data)
+    if args.checkpoint_path is not None and os.path.exists(args.checkpoint_path):
+        ckpt = torch.load(args.checkpoint_path, map_location=device)
+        saved = (ckpt.get('extra_state') or {}).get('_stem_calibration')
+        if saved is not None and args.precision != 'fp32':
+            kind = saved.get('frames') if isinstance(saved.get('frames'), str) else 'data'
+            if rank == 0 and kind != getattr(args, 'stem_calibration', 'noise'):
+                print("=> WARNING: --stem_calibration %s, but the checkpoint was trained behind a stem calibrated on '%s': using the "
+                      "checkpoint's" % (args.stem_calibration, kind))
+            calib = saved
+    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=calib, split_features=args.model != 'mac')
+    check_stem_against_checkpoint(stem, ckpt, rank)
+    if rank == 0 and args.precision == 'fp16h':
+        print('=> stem: precision fp16h, %d split activation tensors, weights %s' %
+              (stem.split_active, 'second-order rounded' if stem.second_order else 'rounded to nearest / coherently'))
 
     class_weights = None
     if args.use_class_weights and hasattr(train_data, "get_class_weights"):
@@ -367,7 +397,6 @@ def main(argv=None):
         else:
             if rank == 0:
                 print('=> Restoring from checkpoint path %s' % args.checkpoint_path)
-            ckpt = torch.load(args.checkpoint_path, map_location=device)
             start_epoch = ckpt['epoch'] + 1
             trainer.load_checkpoint(ckpt)
             if rank == 0:

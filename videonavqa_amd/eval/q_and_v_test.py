@@ -18,7 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import utils as U
-from .q_and_v_eval import build_model, build_parser, stem_calibration
+from .q_and_v_eval import build_model, build_parser, check_stem_against_checkpoint, stem_calibration
 
 
 def _padded(args, Xs, ys):
@@ -134,6 +134,9 @@ def main(argv=None):
             sys.exit(-1)
         calib = stem_calibration(args, None)
     stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=calib, split_features=args.model != 'mac')
+    check_stem_against_checkpoint(stem, checkpoint)
+    if args.precision == 'fp16h':
+        print('=> stem: precision fp16h, %d split activation tensors' % stem.split_active)
     reduction = 'mean' if args.loss_reduction == 'elementwise_mean' else args.loss_reduction
     loss_fn = nn.CrossEntropyLoss(reduction=reduction)
     trainer = Trainer(model, stem, loss_reduction=reduction, feature_channels=args.num_input_channels)

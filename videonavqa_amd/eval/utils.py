@@ -39,7 +39,7 @@ def per_class_accuracies(y_target, y_pred, num_classes):
     return np.divide(hits, totals, out=np.zeros(num_classes), where=totals > 0)
 
 
-def get_object_detector(path=None, precision='bf16', load=True):
+def get_object_detector(path=None, precision='fp16h', load=True):
     """The frozen ObjDetectCNN of the video-QA pipeline in eval mode — 27 classes, 512 filters,
     1024-wide tail, no dropout, logits, pretrained_features (eval/utils.py:42-51).  `load=False` keeps the
     random initialisation (synthetic benchmarking on a box without obj_detect.pt)."""

@@ -30,7 +30,7 @@ def build_parser():
     ap.add_argument('--val_only', type=yes, default=False)
     ap.add_argument('--synthetic', type=int, default=0)
     ap.add_argument('--clip', type=int, nargs=3, default=[16, 112, 112], metavar=('D', 'H', 'W'))
-    ap.add_argument('--precision', type=str, choices=['bf16', 'fp16', 'fp32'], default='bf16')
+    ap.add_argument('--precision', type=str, choices=['bf16', 'fp16', 'fp16h', 'fp32'], default='fp16h')
     return ap
 
 

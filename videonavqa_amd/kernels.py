@@ -122,7 +122,8 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
       split_weights — x a plain 16-bit tensor, wt the fp32 K-major pack: x . w_hi + x . w_lo on the igemm's wrap variant;
       split_in      — x a [hi | lo | hi] tensor (3 Cin channels), wt the fp32 pack: the plain conv over 3 Cin channels against
                       [w_hi | w_hi | w_lo], any tile;
-      dual_out      — 2 / 3: the output as [hi | lo] / [hi | lo | hi] (patch-stationary tiles)."""
+      dual_out      — 2 / 3: the output as [hi | lo] / [hi | lo | hi] (patch-stationary tiles; the 256x256 implicit-GEMM tiles for the
+                      geometries those do not serve and for the composed 5x5 conv: the same bits)."""
     if split_in:
         assert L.is_half(x.dtype) and wt.dtype == torch.float32 and not isinstance(wt, TiledWeight) and x.shape[-1] == 3 * wt.shape[2] \
             and not split_weights
@@ -148,7 +149,9 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
     flags = 0
     if dual_out:        # 2 (or True): [hi | lo]; 3: [hi | lo | hi]
         segs = 3 if int(dual_out) == 3 else 2
-        assert tile in (L.TILE_PS_224x256, L.TILE_STEM_PS_224x256) and y_halo == 1 and border_sub is None and c_out % 8 == 0
+        # patch-stationary tiles (3x3, no border correction) or — geometries they do not serve, the composed 5x5 — the 256x256 igemm tiles
+        assert y_halo == 1 and c_out % 8 == 0 and (
+            (tile in (L.TILE_PS_224x256, L.TILE_STEM_PS_224x256) and border_sub is None) or tile in (L.TILE_256x256, L.TILE_STEM_256x256)), tile
         if out is None:
             out = empty_padded((N, Ho + 2, Wo + 2, segs * c_out), x.dtype, x.device)
         assert out.shape[-1] == segs * c_out
@@ -203,8 +206,9 @@ def conv2d_igemm_bnstats(x, wt, bias, relu, frame_of_i32, frame_off_i32, n_frame
     return y, mean, var
 
 
-def conv2d_igemm_split_out(x, wt, bias, relu, split_in=False):
-    """conv (+bias, +ReLU) on the patch-stationary tile with its fp32 result kept as TWO plain 16-bit tensors (VNQA_EPI_SPLIT_OUT):
+def conv2d_igemm_split_out(x, wt, bias, relu, split_in=False, tile=L.TILE_PS_224x256):
+    """conv (+bias, +ReLU) on the patch-stationary tile (or, where it does not serve the geometry, tile = TILE_256x256) with its fp32
+    result kept as TWO plain 16-bit tensors (VNQA_EPI_SPLIT_OUT):
     returns (hi, lo), hi = h16(v), lo = h16(v - hi), both padded NHWC with a zero halo.  split_in: see conv2d_igemm."""
     N, Hp, Wp, _ = x.shape
     if split_in:
@@ -212,7 +216,7 @@ def conv2d_igemm_split_out(x, wt, bias, relu, split_in=False):
         wt = split_weight3(wt)
     c_out, taps, _ = wt.shape
     assert L.is_half(x.dtype) and wt.dtype == x.dtype and taps == 9
-    d = L.ConvDesc(L.dtype_id(x.dtype), N, Hp - 2, Wp - 2, x.shape[-1], c_out, c_out, taps, 1, 1, int(relu), 0, L.TILE_PS_224x256, 0, 0, 0)
+    d = L.ConvDesc(L.dtype_id(x.dtype), N, Hp - 2, Wp - 2, x.shape[-1], c_out, c_out, taps, 1, 1, int(relu), 0, tile, 0, 0, 0)
     both = empty_padded((2 * N, Hp, Wp, c_out), x.dtype, x.device)
     hi, lo = both[:N], both[N:]
     e = L.ConvEpilogue(kind=L.EPI_SPLIT_OUT, y2=lo.data_ptr())

@@ -181,8 +181,15 @@ class FrameLayout(object):
 class NativeFeatures(object):
     """Stem output kept in kernel-native form: padded NHWC [n_img, h+2, w+2, Cpad] packed by `layout`."""
 
-    def __init__(self, data, layout, channels, h, w):
+    def __init__(self, data, layout, channels, h, w, segs=None):
         self.data, self.layout, self.channels, self.h, self.w = data, layout, channels, h, w
+        # 1: a plain tensor; 3: a SPLIT tensor [hi | lo | hi] (precision 'fp16h': the stem's dual epilogue).  An explicit marker
+        # (ADVICE r5: consumers used to infer it from the channel count alone); None = stated by nobody, checked against the shape
+        c_pad = L.round_up(channels, 64)
+        inferred = 3 if (L.is_half(data.dtype) and data.shape[-1] == 3 * c_pad) else 1
+        self.segs = inferred if segs is None else int(segs)
+        assert self.segs == inferred and data.shape[-1] == self.segs * c_pad, \
+            "features tensor [..., %d] is not a %d-segment tensor of %d channels" % (data.shape[-1], self.segs, channels)
 
     @property
     def shape(self):  # what the reference tensor [B, C, h, w, T] would report

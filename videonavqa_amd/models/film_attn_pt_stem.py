@@ -18,7 +18,7 @@ class FiLMAttnPretrainedStem(FiLMTrunkBase):
     def __init__(self, batch_size, q_embedding_size, nb_classes, num_input_channels=512,
                  num_res_block_channels=512, num_res_blocks=1, hidden_size=128, at_hidden_size=128,
                  max_num_frames=35, q_encoder='lstm', vocab_size=134, *, spatial_size=130,
-                 precision='bf16'):
+                 precision='fp16h'):
         super(FiLMAttnPretrainedStem, self).__init__()
         assert q_encoder.lower() in ['lstm', 'bow'], "Invalid question encoder! ('lstm', 'bow')"
         self.q_encoder = q_encoder

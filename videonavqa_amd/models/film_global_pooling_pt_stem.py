@@ -11,7 +11,7 @@ class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
 
     def __init__(self, batch_size, q_embedding_size, nb_classes, num_input_channels=512,
                  num_res_block_channels=512, num_tail_channels=16, num_res_blocks=1, hidden_size=128,
-                 q_encoder='lstm', vocab_size=134, *, spatial_size=130, precision='bf16'):
+                 q_encoder='lstm', vocab_size=134, *, spatial_size=130, precision='fp16h'):
         super(FiLMGlobalPoolingPretrainedStem, self).__init__()
         assert q_encoder.lower() in ['lstm', 'bow'], "Invalid question encoder! ('lstm', 'bow')"
         self.q_encoder = q_encoder

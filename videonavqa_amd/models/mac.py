@@ -81,7 +81,7 @@ class MACNetwork(nn.Module):
     stem_reserve_cus = 96
 
     def __init__(self, n_vocab, dim, embed_hidden=300, max_step=12, self_attention=False, memory_gate=False,
-                 classes=28, dropout=0.15, max_num_frames=35, *, precision='bf16'):
+                 classes=28, dropout=0.15, max_num_frames=35, *, precision='fp16h'):
         super(MACNetwork, self).__init__()
         self.compute_dtype = compute_dtype(precision)
         self.conv = nn.Sequential(nn.Conv2d(512, dim, 3, padding=1), nn.ELU(),      # mac.py:174-179

@@ -19,7 +19,7 @@ class ObjDetectCNN(nn.Module):
     obj_detector.py:69-86 on the MFMA igemm with eval-mode BatchNorm folded into the convolutions."""
 
     def __init__(self, nb_classes, num_filters=128, tail_hidden_dim=256, tail_dropout_p=0.5,
-                 logits=False, pretrained_features=False, *, precision='bf16'):
+                 logits=False, pretrained_features=False, *, precision='fp16h'):
         super(ObjDetectCNN, self).__init__()
         self.logits, self.pretrained_features, self.precision = logits, pretrained_features, precision
         width = lambda v: num_filters if v == "F" else v

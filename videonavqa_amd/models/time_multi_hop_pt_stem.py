@@ -14,7 +14,7 @@ class TimeMultiHopFiLMPretrainedStem(FiLMTrunkBase):
 
     def __init__(self, batch_size, q_embedding_size, nb_classes, num_input_channels=512,
                  num_res_block_channels=512, num_res_blocks=1, num_tail_channels=32, hidden_size=128,
-                 vocab_size=134, *, spatial_size=130, precision='bf16'):
+                 vocab_size=134, *, spatial_size=130, precision='fp16h'):
         super(TimeMultiHopFiLMPretrainedStem, self).__init__()
         self.nb_classes = nb_classes
         self.batch_size = batch_size

@@ -28,7 +28,7 @@ class VideoOnlyCNN3D(nn.Module):
     precision='fp32' and other geometries (the reference's 160x208x35 clips: W = 35) take the generic path: convs on the
     igemm / wgrad kernels through padded NDHWC with BatchNorm3d / MaxPool3d on stock PyTorch-ROCm; the classifier is on library kernels in every precision."""
 
-    def __init__(self, nb_classes, *, fc6_in_features=7680, precision='bf16'):
+    def __init__(self, nb_classes, *, fc6_in_features=7680, precision='fp16h'):
         super(VideoOnlyCNN3D, self).__init__()
         self.compute_dtype = compute_dtype(precision)
         self.bn_input = nn.BatchNorm3d(3)

@@ -252,13 +252,16 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         b0 = K.pad_vec(conv_b, c_pad)
         fused = None
         ps = split and HEAD_CONV_PS and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
-        if L.is_half(cdt) and not ps:     # (the fp32 parity precision keeps the exact two-pass statistics kernel)
+        # (maps the patch-stationary tiles do not serve — the 10 x 13 maps of the reference's 160 x 208 frames — take the same split
+        # output from the 256x256 implicit-GEMM tile: round 6)
+        split_out = split and HEAD_SPLIT_OUT and HEAD_CONV_PS
+        if L.is_half(cdt) and not ps and not split_out:     # (the fp32 parity precision keeps the exact two-pass statistics kernel)
             fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts), split_in=split)
         g = K.pad_vec(bn_w, c_pad)
-        if ps and HEAD_SPLIT_OUT:
+        if split_out:
             # ... and its OUTPUT kept unrounded into the BatchNorm (hi + lo, VNQA_EPI_SPLIT_OUT): 0.020e-6 of the budget; the backward
             # reads the hi tensor alone (ReLU mask and x-hat)
-            r, r_lo = K.conv2d_igemm_split_out(x, wt0, b0, True, split_in=True)
+            r, r_lo = K.conv2d_igemm_split_out(x, wt0, b0, True, split_in=True, tile=L.TILE_PS_224x256 if ps else L.TILE_256x256)
             mean, var = K.frame_bn_stats_split(r, r_lo, lay.frame_off_i32, lay.n_frames)
             rstd = torch.rsqrt(var + meta.eps)
             h = K.frame_bn_apply_split(r, r_lo, lay.frame_of_i32, mean, rstd, g, K.pad_vec(bn_b, c_pad))

@@ -33,7 +33,7 @@ class VGGFront(nn.Module):
     """VGG-16 'D' features[0:10] parameter container + drop-in callable
     (`feature_extractor(x)` of eval/q_and_v_eval.py:106): [N,3,H,W] -> [N,128,H/4,W/4]."""
 
-    def __init__(self, precision='bf16'):
+    def __init__(self, precision='fp16h'):
         super(VGGFront, self).__init__()
         self.features = nn.ModuleDict({
             "0": nn.Conv2d(3, 64, 3, padding=1), "2": nn.Conv2d(64, 64, 3, padding=1),
@@ -54,7 +54,7 @@ class VGGFront(nn.Module):
         return self._plan.vgg_nchw(x)
 
 
-def get_frcnn_feature_extractor(path=None, precision='bf16'):
+def get_frcnn_feature_extractor(path=None, precision='fp16h'):
     """Counterpart of `demo.get_frcnn_feature_extractor(path)` (eval/q_and_v_eval.py:17,308).
     Loads `features.{0,2,5,7}.*` from a VGG-16 state dict (e.g. vgg16_caffe.pth) when given."""
     m = VGGFront(precision)
@@ -263,6 +263,7 @@ def patch_second_moment(x, k, max_rows=400000):
     return H / max(rows, 1)
 
 
+SPLIT_DEPTH = 3              # precision 'fp16h': how many of the stem's LAST stored activations are split tensors (see FrozenStem)
 RING_EDGE_LAUNCHES = True    # conv11 on the outside ring as four 3-tap launches (False: one 9-tap launch, same bits: the A/B partner)
 CALIBRATION_FRAMES = 40      # frames of the default ("noise") calibration pass: 40 x 196 patches > K = 4608 of the 14 x 14 layers
 
@@ -303,17 +304,20 @@ class FrozenStem(object):
     from, so the test-time stem gets the weights the model was trained behind).  "auto" = "noise" for every 16-bit precision;
     VNQA_COHERENT_ROUND=0 turns it off."""
 
-    def __init__(self, vgg, objdet, precision='bf16', calibration="auto", split_features=True, reserve_cus=0):
+    def __init__(self, vgg, objdet, precision='fp16h', calibration="auto", split_features=True, reserve_cus=0, split_depth=None):
         from .models.common import compute_dtype
         self.cdt = compute_dtype(precision)
         self.hyb = precision == "fp16h"
         self.split_features = bool(split_features) and self.hyb
+        # 3 (round 5): conv22's, conv31's and conv32's outputs; 4: + conv21's (conv22 then runs as two products); 5: + the composed
+        # conv11.conv12 pair's (conv21 as two products; the pair's dual output comes from the implicit-GEMM tile's fp32 epilogue)
+        self.split_depth = min(5, max(3, int(SPLIT_DEPTH if split_depth is None else split_depth))) if self.hyb else 0
         self.vgg, self.objdet = vgg, objdet
         self.layers_vgg, self.layers_od = [], []
         self.composed = None
         self.first = None
         self._bufs = {}
-        self._split_ok = {}
+        self.split_segs = 0
         # CUs the persistent one-workgroup-per-CU kernels (fused conv1, C_in = 64 direct conv, weights-in-registers conv) leave to
         # other streams, passed with every call (vnqa_conv_desc.flags): the Trainer sets it to its stem stream's CU reservation
         self.reserve_cus = int(reserve_cus)
@@ -366,7 +370,13 @@ class FrozenStem(object):
                 #  * otherwise (calibration off / a means-only calibration): THREE products over [hi | lo | hi] against the split
                 #    exact weights [w_hi | w_hi | w_lo] (BatchNorm folded in fp32 first).
                 segs = 2 if self.second_order else 3
-                for ly, rd, wr in zip(self.layers_od[3:], (False, True, True), (segs, segs, 3 if self.split_features else 0)):
+                first = 6 - self.split_depth            # first layer of layers_od that WRITES a split tensor (3 = conv22; 2 = conv21)
+                for i, ly in enumerate(self.layers_od):
+                    rd = i > max(first, 1) or (i == 2 and self.split_depth >= 5)      # (conv21 reads the composed pair's split output)
+                    wr = 0 if i < first else ((3 if self.split_features else 0) if i == 5 else segs)
+                    if not (rd or wr):
+                        ly.pop("wt32ps", None)
+                        continue
                     if "wt_ps" in ly:
                         ly["split_out"] = wr
                         if rd and segs == 3:
@@ -374,6 +384,7 @@ class FrozenStem(object):
                         elif rd:
                             ly["wt_split"] = torch.cat([ly["wt_ps"], ly["wt_ps"]], dim=2).contiguous()
                     ly.pop("wt32ps", None)
+                self.split_segs = segs
             # conv12 is applied straight to conv11's output (obj_detector.py:72: no nonlinearity between the two convs of
             # a pair) and both are frozen: when the pair's 3x3 (c_in -> c_mid) . 3x3 (c_mid -> c_out) costs more than one
             # 5x5 (c_in -> c_out) — 9*c_in + 9*c_mid > 25*c_in, true for 128 -> 512 -> 512 only — it is evaluated as the
@@ -390,6 +401,16 @@ class FrozenStem(object):
                     self.layers_vgg[-1]["y_halo"] = 2        # the composed 5x5 conv reads a halo-2 image
 
         self._H = None       # (0.8 GB of float64 moments: construction only)
+
+    @property
+    def feature_segs(self):
+        """Channel segments of forward_clip's output: 3 = a split tensor [hi | lo | hi] (precision 'fp16h' with split_features), 1 = a
+        plain tensor.  `split_active`: the number of stored activations this plan keeps as split tensors (0: none)."""
+        return 3 if (self.split_features and self.layers_od and int(self.layers_od[-1].get("split_out", 0)) == 3) else 1
+
+    @property
+    def split_active(self):
+        return self.split_depth if (self.hyb and self.layers_od and "split_out" in self.layers_od[-1]) else 0
 
     def packed_tensors(self):
         """Every device tensor of the execution plan (packed / tiled / split weights, biases, the ring operands): what a data-parallel
@@ -413,6 +434,17 @@ class FrozenStem(object):
         for part in (self.first, self.layers_vgg, self.layers_od, self.composed, getattr(self, "bn_input", None)):
             walk(part)
         return out
+
+    def packs_checksum(self):
+        """sha256 over the bytes of packed_tensors() (in order): written into checkpoints (Trainer.extra_state_dict) so that a stem
+        rebuilt from the checkpoint's calibration — another GPU / ROCm / torch build may flip a rounding tie — can be
+        CHECKED against the 16-bit weights the model was trained behind."""
+        import hashlib
+        h = hashlib.sha256()
+        for t in self.packed_tensors():
+            c = t.detach().contiguous()
+            h.update(c.view(torch.uint8).cpu().numpy().tobytes())
+        return h.hexdigest()
 
     def _round(self, w, key, dtype):
         """The frozen weights `w` (fp32, BatchNorm scale folded) as the values the 16-bit kernels multiply with: second-order rounded
@@ -537,7 +569,9 @@ class FrozenStem(object):
         part = [K.ring_edge_conv(y1p, cp["edges"][name], H, W, e) for e, name in enumerate(("top", "bottom", "left", "right"))]
         ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
-        out = self._buf(key + (ho, wo), (n, ho + 2, wo + 2, cp["c_out_pad"]))
+        # precision 'fp16h' at split depth 5: the pair's output as a split tensor (the igemm tile's fp32 dual epilogue), conv21 reads it
+        dual = self.split_segs if (self.split_depth >= 5 and cp["tile"] == L.TILE_STEM_256x256 and "wt_split" in self.layers_od[2]) else 0
+        out = self._buf(key + (ho, wo) + (("split",) if dual else ()), (n, ho + 2, wo + 2, max(dual, 1) * cp["c_out_pad"]))
         timed = self.timing is not None and cp["tile"] == L.TILE_STEM_256x256
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -545,7 +579,7 @@ class FrozenStem(object):
         # every XCD computes ONE cout half of the composed conv (its L2 then holds 1.65 instead of 3.3 MB of weights): fabric-side reads
         # 1 022 -> 831 MB per launch (profiles/r04_pmc_traffic*.json), time unchanged
         y = K.conv2d_igemm(x, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out, tile=cp["tile"],
-                           border_sub=ring, desc_flags=L.CONV_XCD_SPLIT_N if L.is_half(self.cdt) else 0)
+                           border_sub=ring, desc_flags=L.CONV_XCD_SPLIT_N if L.is_half(self.cdt) else 0, dual_out=dual)
         if timed:
             ev1.record()
             self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25, "conv_igemm_kernel"))
@@ -573,18 +607,6 @@ class FrozenStem(object):
             self._bufs[key] = cap
         return cap[:shape[0]]
 
-    def _split_geometry_ok(self, n, h, w, ly):
-        """The split path of precision 'fp16h' needs the patch-stationary kernel on conv22 (h x w maps, pooled) AND on conv31 / conv32
-        (h/2 x w/2 maps, 2 C or 3 C input channels): asked of the library once per geometry.  Where it does not serve them (the 10 x 13 maps
-        of the reference's 160 x 208 frames) the three layers run exactly as in precision 'fp16'."""
-        key = (n, h, w)
-        ok = self._split_ok.get(key)
-        if ok is None:
-            c = ly["c_out_pad"]
-            ok = self._split_ok[key] = bool(ly["pool"] and K.conv_ps_supported(n, h, w, c, c, 9, True) and
-                                            K.conv_ps_supported(n, h // 2, w // 2, (2 if self.second_order else 3) * c, c, 9, False))
-        return ok
-
     def _run(self, x, layers, tag, last_slot=0, first_index=0):
         for i, ly in enumerate(layers, first_index):
             n, hp, wp, _ = x.shape
@@ -597,7 +619,7 @@ class FrozenStem(object):
             split_rd = "wt_split" in ly and x.shape[-1] == ly["wt_split"].shape[2]
             split_wr = int(ly.get("split_out", 0))
             x_segs = x.shape[-1] // ly["c_out_pad"] if split_rd else 1      # (c_in == c_out on the split-reading layers)
-            if split_wr and not (yh == 1 and (split_rd if "wt_split" in ly else self._split_geometry_ok(n, h, w, ly))):
+            if split_wr and not (yh == 1 and (split_rd or "wt_split" not in ly)):      # (a split-reading layer handed a plain tensor: the chain is off)
                 split_wr = 0
             out = self._buf(key + (("split",) if split_wr else ()), (n, ho + 2 * yh, wo + 2 * yh, max(split_wr, 1) * ly["c_out_pad"]))
             post = ly["post"]
@@ -609,9 +631,14 @@ class FrozenStem(object):
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
             if split_rd or split_wr:
-                kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)
+                # the patch-stationary kernel where it serves the geometry, else (the 10 x 13 maps of the reference's 160 x 208 frames:
+                # eval/utils.py:24-25) the 256x256 implicit-GEMM tile — plain or with ITS dual epilogue: the same values either way
+                on_ps = yh == 1 and K.conv_ps_supported(n, h, w, x.shape[-1], ly["c_out_pad"], 9, ly["pool"])
+                if on_ps:
+                    kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)
                 x = K.conv2d_igemm(x, ly["wt_split"] if split_rd else ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
-                                   post_scale=ps, post_shift=pt, out=out, tile=L.TILE_STEM_PS_224x256, y_halo=yh, dual_out=split_wr)
+                                   post_scale=ps, post_shift=pt, out=out, tile=L.TILE_STEM_PS_224x256 if on_ps else L.TILE_STEM_256x256,
+                                   y_halo=yh, dual_out=split_wr)
             elif "wt_rows" in ly and K.conv2d_wreg_supported(x, ly["wt_rows"], pool2=ly["pool"], y_halo=yh):
                 x = K.conv2d_wreg(x, ly["wt_rows"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"], post_scale=ps, post_shift=pt,
                                   out=out, y_halo=yh, reserve_cus=self.reserve_cus)

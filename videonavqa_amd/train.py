@@ -111,8 +111,10 @@ class DynamicLossScale(object):
     read-back enters an update).  After every step the host starts an asynchronous copy of the counter into one of LAG + 1 pinned
     words and consumes the copy started exactly LAG steps earlier (`event.synchronize()` on a copy that old returns at once) —
     never "whichever copy happens to have arrived": data-parallel replicas see identical reduced gradients, hence identical
-    counters, hence take every scale decision at the same step whatever their host timing.  One observation halves the scale
-    ONCE, however many of the lagging steps overflowed with it; `growth_interval` clean observations double it (cap 2^24).
+    counters, hence take every scale decision at the same step whatever their host timing.  One overflow EPISODE halves the scale
+    once: after a halving, the overflows of the LAG steps that were already launched with the old scale (observed over the next LAG
+    calls) are counted but do not halve again (ADVICE r5: they cost scale / 8 and ~600 clean steps to regrow);
+    `growth_interval` clean observations double it (cap 2^24).
     Powers of two only: scaling is exact.  With `pinned_scale` the scale never moves (the counter still counts).
     scale = 1 and growth off is the form every other precision uses (overflow skip + statistics only)."""
     LAG = 2
@@ -130,6 +132,8 @@ class DynamicLossScale(object):
             self._host = [t.pin_memory() for t in self._host]
         self._events = [None] * (self.LAG + 1)
         self._steps, self._seen, self._clean = 0, 0, 0
+        self._ignore_until = 0               # observations at calls < this index report steps launched before the last halving took effect
+        self._skipped_before = 0             # skipped steps of the run(s) before the last load_state_dict (the device counter restarts at 0)
         self.skipped_steps = 0
         if self.applies:
             C.set_fp16_loss_scale(self.scale)
@@ -153,12 +157,16 @@ class DynamicLossScale(object):
             seen = int(self._host[old][0])
             new = seen - self._seen
             self._seen = seen
+        call = self._steps
         self._steps += 1
         if new > 0:
             self.skipped_steps += new
             self._clean = 0
-            if self.applies:
+            if self.applies and call >= self._ignore_until:
                 self.scale = max(self.scale * 0.5, self.min_scale)
+                # the new scale reaches the step launched after this call; the LAG steps before it ran with the old one and are
+                # observed at the next LAG calls
+                self._ignore_until = call + 1 + self.LAG
         else:
             self._clean += 1
             if self.applies and self._clean >= self.growth_interval:
@@ -173,7 +181,7 @@ class DynamicLossScale(object):
         return int(self.count.item())
 
     def state_dict(self):
-        return {"scale": self.scale, "clean_steps": self._clean, "skipped_steps": self.skipped_now()}
+        return {"scale": self.scale, "clean_steps": self._clean, "skipped_steps": self._skipped_before + self.skipped_now()}
 
     def load_state_dict(self, d):
         """Restores the scale and the growth counter; the device counter restarts at zero together with the launch count
@@ -182,10 +190,10 @@ class DynamicLossScale(object):
             self.scale = float(d.get("scale", self.scale))
             self._C.set_fp16_loss_scale(self.scale)
         self._clean = int(d.get("clean_steps", 0))
-        self.skipped_steps = int(d.get("skipped_steps", 0))
+        self._skipped_before = self.skipped_steps = int(d.get("skipped_steps", 0))      # cumulative over resumes (saved as before + device count)
         self.count.zero_()
         self._events = [None] * (self.LAG + 1)
-        self._steps, self._seen = 0, 0
+        self._steps, self._seen, self._ignore_until = 0, 0, 0
 
 
 def sync_replicas(tensors, src=0):
@@ -336,7 +344,14 @@ class Trainer(object):
         sync_replicas(list(self.model.state_dict().values()) + list(self.model.extra_state_tensors().values()))
         plan = getattr(self.stem, "packed_tensors", None)       # the frozen stem's rounded 16-bit weights (stem.FrozenStem)
         if plan is not None:
-            sync_replicas([t for t in plan() if t.is_contiguous()])
+            # EVERY plan tensor (non-contiguous ones used to be skipped silently — replica identity is the point)
+            for t in plan():
+                if t.is_contiguous():
+                    dist.broadcast(t, src=0)
+                else:
+                    c = t.contiguous()
+                    dist.broadcast(c, src=0)
+                    t.copy_(c)
 
     # ---- checkpoint interface with torch.optim.Adam's state_dict layout (eval/q_and_v_eval.py:148-156,344-345) --
     def optimizer_state_dict(self):
@@ -369,6 +384,12 @@ class Trainer(object):
             # FRAMES ("noise" = the seeded default, else the tensor of frames) and the input means measured on them — the test-time
             # stem redoes the rounding from them, so a model is tested behind the very stem weights it was trained behind
             out["_stem_calibration"] = {k: (v if isinstance(v, str) else v.detach().cpu().clone()) for k, v in calib.items()}
+            if hasattr(self.stem, "packs_checksum"):
+                # ... and a checksum of the rounded packs themselves: the re-rounding is bit-reproducible on the same GPU / ROCm / torch
+                # build only (a different reduction order can flip a tie) — the loader verifies and says so
+                if getattr(self, "_stem_sha", None) is None:
+                    self._stem_sha = self.stem.packs_checksum()
+                out["_stem_packs_sha256"] = self._stem_sha
         return out
 
     def load_checkpoint(self, ckpt):
@@ -404,7 +425,8 @@ class Trainer(object):
         lay = FrameLayout(v_sorted, T, clip.device, perm=perm)
         with phase("stem"):
             feats = self.stem.forward_clip(clip, lay.img_of, lay.n_img, slot=slot)
-        return NativeFeatures(feats, lay, self.feature_channels, H // 16, W // 16), v_sorted, perm
+        segs = int(getattr(self.stem, "feature_segs", 1))       # stated by the producer (FrozenStem), checked against the shape
+        return NativeFeatures(feats, lay, self.feature_channels, H // 16, W // 16, segs=segs), v_sorted, perm
 
     def upload(self, clip_host):
         """Start the H2D copy of a (pinned) host clip on the copy stream into one of three rotating device
