@@ -1032,6 +1032,17 @@ def main():
     regions = [timed_region() for _ in range(max(args.repeats, 1))]
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     dt, t_enqueue, events, loss = regions[order[len(order) // 2]]          # the MEDIAN region is the reported one
+    # Host cost of ONE step's enqueue on an IDLE queue (the in-region figure includes back-pressure — a launch
+    # thread that is ahead of the GPU blocks in the runtime once the hardware queues are full, which looks like launch cost):
+    # synchronize, enqueue one step, stop the clock before waiting for it; median of five.  Not part of the timed region.
+    idle = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_step()
+        idle.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    t_enqueue_idle = sorted(idle)[len(idle) // 2]
 
     # the inference path's throughput next to the training headline (same protocol, same resident minibatches, one region)
     eval_mode = None
@@ -1199,6 +1210,8 @@ def main():
                        "final_loss": round(float(loss), 4), "minibatches_rotated": NB, "inputs": ("pinned host memory, H2D every step" if args.h2d else "resident in HBM") +
                                  (", raw uint8 pixels (k / 255 formed on the device)" if args.clip_dtype == "u8" else ""),
                        "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
+                       # the same step enqueued on an IDLE queue (no back-pressure from a busy GPU): the launch thread's own cost
+                       "host_enqueue_idle_queue_ms_per_step": round(t_enqueue_idle * 1e3, 3),
                        "stem_alone_ms": round(stem_ms, 3),
                        # whole frozen stem alone on the chip: EXECUTED FLOPs / time / peak (hardware utilisation) and the
                        # same with the reference formulation's algorithmic FLOPs (37.167 GF/frame at 224x224)

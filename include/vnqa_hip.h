@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 423
+#define VNQA_ABI_VERSION 430
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -100,6 +100,13 @@ typedef struct vnqa_conv_desc {
 #define VNQA_CONV_DUAL_HI2 0x40000 /* with VNQA_CONV_DUAL_OUT: three segments [hi | lo | hi] (c_y >= 3 c_out) — the operand of a consumer that
                                    * contracts the unrounded activation against SPLIT weights [w_hi | w_hi | w_lo] as a plain conv over
                                    * 3 c_out input channels (x_hi w_hi + x_lo w_hi + x_hi w_lo) */
+#define VNQA_CONV_F32_EPILOGUE 0x80000 /* ONE plain 16-bit output whose bias / border correction / ReLU / 2x2 max-pool / affine are all applied in
+                                   * fp32 and rounded ONCE (the plain epilogues of the LDS-staged tiles round to storage before the affine and again
+                                   * after it): the dual epilogue's hi half alone.  Tiles and restrictions of VNQA_CONV_DUAL_OUT.  Round 6:
+                                   * mean-shifted storage (post_shift = -mean) needs the single rounding to pay */
+#define VNQA_CONV_FIRST_MID_SHIFT 0x100000 /* vnqa_conv_first_c64_fwd[_sched]: b1 has 128 entries [bias (64) | mu (64)] — the first conv's
+                                   * output is kept (in LDS) as relu(.) - mu[c], and as -mu[c] where it is the second conv's zero padding; the
+                                   * caller adds sum_taps(W2 mu) to the second conv's bias.  Wide (default) kernel only */
 /* bits 8..15 of flags: the persistent conv kernels leave n CUs (a multiple of 8, <= 224) to the other streams of the process */
 #define VNQA_CONV_RESERVE_CUS(n) ((((n) < 0 ? 0 : ((n) > 224 ? 224 : (n))) / 8) << 8)
 #define VNQA_CONV_RESERVE_OF(flags) ((((flags) >> 8) & 0xff) * 8)
@@ -328,6 +335,12 @@ int vnqa_conv2d_wreg_fwd(const vnqa_conv_desc* d, const void* x, const void* wt,
  */
 int vnqa_clip_to_nhwc4(const float* clip, const int32_t* img_of, void* img4, int32_t b, int32_t t, int32_t h,
                        int32_t w, void* stream);
+/* vnqa_clip_to_nhwc4_shifted (round 6): either source (lut == NULL: clip is fp32 as in vnqa_clip_to_nhwc4; else uint8 as in
+ * vnqa_clip_u8_to_nhwc4) with MEAN-SHIFTED storage — the list holds pixel - shift[c] (shift: 3 floats on the device), so the 16-bit
+ * rounding error scales with |pixel - shift|; the caller keeps -shift[c] in the list's halo (what a zero pixel becomes) and adds
+ * sum_taps(W1 shift) to the first conv's bias.  Replaces the implicit .half() of the clip a 16-bit torch model would apply. */
+int vnqa_clip_to_nhwc4_shifted(const void* clip, const float* lut, const float* shift, const int32_t* img_of, void* img4, int32_t b,
+                               int32_t t, int32_t h, int32_t w, void* stream);
 /* vnqa_clip_u8_to_nhwc4: the same image list from RAW 8-bit pixels [b][3][h][w][t] (what cv2 decodes, eval/dataset.py:66-77)
  * and the caller's table lut[256] = float32(k / 255.0) evaluated in double precision — bit for bit the value
  * `clip / 255.0` (dataset.py:91, float64) takes after `.float()` (eval/q_and_v_eval.py:92) — so the host uploads a quarter of

@@ -342,3 +342,174 @@ def test_one_overflow_episode_halves_the_scale_once_and_the_skip_count_survives_
         assert t.state_dict()["skipped_steps"] == 6          # (was: the device count since the load alone)
     finally:
         C.set_fp16_loss_scale(C.FP16_GRAD_SCALE)
+
+
+# ---- the REAL Trainer on 4 and 8 ranks ----------------------------------------------------------------------
+# videonavqa_amd.train.Trainer itself — constructor (replica broadcast incl. a non-contiguous stem plan tensor, FlatParams, the
+# overlapped reducer, the dynamic loss scale), _reduce_and_update (the device-independent half of step()), optimizer_state_dict /
+# extra_state_dict / load_checkpoint — on host tensors over gloo.  What needs the GPU is stood in: the model is a small torch module,
+# the forward / backward is driven by the worker, and FlatParams.clip_adam_step's ONE HIP launch is replaced by its restatement
+# (_adam_step_skipping).  Ragged minibatches (every rank another batch size), the early-slice hooks fired in ANOTHER ORDER on every
+# rank, an overflow injected on one rank, a checkpoint round trip in the middle.
+class _HostStem(object):
+    """A stem plan with one contiguous and one NON-contiguous tensor (Trainer.sync_replicas must broadcast both: ADVICE r5)."""
+
+    def __init__(self, rank):
+        self.a = torch.full((6,), float(rank + 1))
+        self.b = torch.full((4, 6), float(rank + 1)).t()          # a transposed view: not contiguous
+        self.split_features, self.calib = False, None
+
+    def packed_tensors(self):
+        return [self.a, self.b]
+
+
+class _HostModel(nn.Sequential):
+    """_make_model's module with the drop-in models' two extras: a frozen tensor state_dict() does not carry (the reference's
+    unregistered conv1x1_layers) and the loader for it."""
+
+    def __init__(self, seed):
+        torch.manual_seed(seed)
+        super(_HostModel, self).__init__(nn.Linear(12, 16), nn.Tanh(), nn.Linear(16, 5))
+        self.__dict__["frozen"] = torch.randn(3, 3)
+
+    def extra_state_tensors(self):
+        return {"conv1x1_layers.0.weight": self.__dict__["frozen"]}
+
+    def load_reference_tensors(self, tensors):
+        if "conv1x1_layers.0.weight" in tensors:
+            self.__dict__["frozen"].copy_(torch.as_tensor(tensors["conv1x1_layers.0.weight"]))
+
+
+def _ragged_global_batch(world, seed=21):
+    g = torch.Generator().manual_seed(seed)
+    sizes = [2 + (r * 3) % 5 for r in range(world)]               # 2, 5, 3, 6, 4, 2, 5, 3
+    X = torch.randn(sum(sizes), 12, generator=g)
+    Y = torch.randint(0, 5, (sum(sizes),), generator=g)
+    offs = [sum(sizes[:r]) for r in range(world + 1)]
+    return X, Y, offs
+
+
+def _trainer_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    from videonavqa_amd.models import common as C
+    from videonavqa_amd.train import Trainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, Y, offs = _ragged_global_batch(world)
+        xs, ys = X[offs[rank]:offs[rank + 1]], Y[offs[rank]:offs[rank + 1]]
+        loss_fn = nn.CrossEntropyLoss(reduction="sum")
+
+        def make(seed):
+            model = _HostModel(seed)
+            model.compute_dtype = torch.float16                   # (a loss-scaled precision: the scaler's decisions are under test)
+            stem = _HostStem(rank)
+            tr = Trainer(model, stem, lr=1e-2, clip=1.0, loss_reduction="sum", world_size=world, rank=rank)
+            tr.reducer = type(tr.reducer)(tr.fp, world, "sum", early_numel=80)     # both weights (192, 80) take the early path
+            tr.fp.clip_adam_step = lambda lr, clip=1.0, overflow_count=None: _adam_step_skipping(tr.fp, lr, overflow_count, clip)
+            return model, stem, tr
+
+        model, stem, tr = make(400 + rank)                        # replicas start DIFFERENT: the constructor's broadcast joins them
+        assert float(stem.a[0]) == 1.0 and float(stem.b[0, 0]) == 1.0 and not stem.b.is_contiguous()      # rank 0's plan everywhere
+        assert len(tr.reducer.early) == 2
+        losses, scales = [], []
+
+        def one_step(it, inject=False):
+            scale = C.grad_scale_of(torch.float16)
+            loss = loss_fn(model(xs), ys)
+            # backward WITHOUT the hooks' natural order: gradients first, then the early-slice hooks fired in a rank- and
+            # step-dependent order (the all-reduces of different slices may be enqueued in any order, as long as every rank
+            # enqueues the SAME slices: gloo matches collectives by sequence, so ranks agree on an order derived from `it`)
+            tr.reducer.enabled = False
+            (loss * scale).backward()
+            tr.reducer.enabled = True
+            if inject:
+                model[2].bias.grad[1] = float("inf")
+            early = list(tr.reducer.early)
+            for p in (early if it % 2 == 0 else early[::-1]):
+                tr.reducer._hook(p)
+            tr._scale_of_step = scale
+            return float(loss)
+
+        def finish_step(scale):
+            # (the product's kernels divide the loss scale out inside their un-pack; here the restated optimizer would see scaled
+            # gradients, so it un-scales between the reduction and the update — linear, hence the same on every rank)
+            orig = tr.fp.clip_adam_step
+
+            def stepper(lr, clip=1.0, overflow_count=None):
+                tr.fp.grad.div_(scale)
+                return orig(lr, clip, overflow_count)
+            tr.fp.clip_adam_step = stepper
+            try:
+                tr._reduce_and_update()
+            finally:
+                tr.fp.clip_adam_step = orig
+
+        for it in range(4):
+            losses.append(one_step(it, inject=(it == 1 and rank == world - 1)))
+            finish_step(tr._scale_of_step)
+            scales.append(tr.loss_scaler.scale)
+        # checkpoint round trip through the reference schema (eval/q_and_v_eval.py:148-156): into a FRESH trainer built from other weights
+        ckpt = {"epoch": 0, "state_dict": {k: v.clone() for k, v in model.state_dict().items()},
+                "optimizer": tr.optimizer_state_dict(), "extra_state": tr.extra_state_dict()}
+        applied = int(ckpt["optimizer"]["state"][0]["step"])
+        model2, stem2, tr2 = make(900 + rank)
+        tr2.load_checkpoint(ckpt)
+        assert torch.equal(tr2.fp.flat, tr.fp.flat) and torch.equal(tr2.fp.m, tr.fp.m) and torch.equal(tr2.fp.v, tr.fp.v)
+        assert tr2.loss_scaler.scale == tr.loss_scaler.scale and tr2.fp.step_count == applied
+        assert torch.equal(model2.extra_state_tensors()["conv1x1_layers.0.weight"], model.extra_state_tensors()["conv1x1_layers.0.weight"])
+        model, stem, tr = model2, stem2, tr2
+        for it in range(4, 8):
+            losses.append(one_step(it))
+            finish_step(tr._scale_of_step)
+            scales.append(tr.loss_scaler.scale)
+        gathered = [torch.zeros_like(tr.fp.flat) for _ in range(world)]
+        dist.all_gather(gathered, tr.fp.flat)
+        assert all(torch.equal(gathered[0], t) for t in gathered[1:])
+        torch.save({"flat": tr.fp.flat.clone(), "losses": losses, "scales": scales, "applied": applied,
+                    "skipped": tr.loss_scaler.state_dict()["skipped_steps"]}, out_path % rank)
+    finally:
+        from videonavqa_amd.models import common as C2
+        C2.set_fp16_loss_scale(C2.FP16_GRAD_SCALE)
+        dist.destroy_process_group()
+
+
+def _single_process_reference(world):
+    """The same 8 steps in ONE process on the concatenated ragged batch (reduction 'sum': the ranks' summed gradient IS the global
+    batch's), with step 1 skipped (the injected overflow) and the optimizer state carried through."""
+    sys.path.insert(0, ROOT)
+    from videonavqa_amd.train import FlatParams
+    X, Y, _ = _ragged_global_batch(world)
+    model = _HostModel(400)                                        # rank 0's initial weights
+    fp = FlatParams(model.parameters())
+    count = torch.zeros(1, dtype=torch.int32)
+    loss_fn = nn.CrossEntropyLoss(reduction="sum")
+    for it in range(8):
+        loss_fn(model(X), Y).backward()
+        if it == 1:
+            fp.grad[0] = float("inf")
+        _adam_step_skipping(fp, 1e-2, count)
+    return fp.flat.clone()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_real_trainer_on_4_and_8_ranks_ragged_out_of_order_overflow_checkpoint(tmp_path, world):
+    """train.Trainer (not a stand-in loop) over gloo on 4 and 8 ranks — see the block comment above.
+    Every rank ends with bit-identical weights, equal to the single-process run on the concatenated ragged batch up to fp32
+    summation order; the injected overflow is skipped everywhere, costs ONE halving, and Adam's step count excludes it."""
+    out = str(tmp_path / "tr_%d.pt")
+    port = 31000 + (os.getpid() % 2000) + world
+    mp.spawn(_trainer_worker, args=(world, port, out), nprocs=world, join=True)
+    res = [torch.load(out % r, weights_only=False) for r in range(world)]
+    for r in res[1:]:
+        assert torch.equal(r["flat"], res[0]["flat"]) and r["scales"] == res[0]["scales"]
+    sys.path.insert(0, ROOT)
+    from videonavqa_amd.train import DynamicLossScale
+    lag = DynamicLossScale.LAG
+    assert res[0]["applied"] == 3 and res[0]["skipped"] == 1                      # 4 launches before the checkpoint, one skipped
+    # the halving is observed `lag` calls after step 1 — i.e. at step 3, before the checkpoint — and never again
+    assert res[0]["scales"] == [1024.0] * (1 + lag) + [512.0] * (8 - 1 - lag), res[0]["scales"]
+    ref = _single_process_reference(world)
+    n = ref.numel()
+    assert float((res[0]["flat"][:n] - ref).abs().max()) < 2e-5 * float(ref.abs().max()), float((res[0]["flat"][:n] - ref).abs().max())

@@ -665,7 +665,10 @@ def test_conv_wreg_vs_torch(cfg):
     y2 = K.conv2d_igemm(xn, wt, bias=b, relu=True, pool2=pool, post_scale=sc if post else None,
                         post_shift=sh if post else None)
     d = (inner.float() - y2.float()).abs().max() / (y2.float().abs().max() + 1e-12)
-    assert float(d) < 4e-3, float(d)
+    # (with an affine the igemm tile rounds to storage, applies it and rounds again; this kernel applies it in fp32 and rounds once —
+    # round 6, tools/stem_layer_errors.py: up to two storage roundings apart.  Without an affine the two agree to the MFMA's K order.)
+    ulp = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert float(d) < (4e-3 if not post else max(4e-3, 2.5 * ulp)), float(d)
 
 
 def test_conv_wreg_unsupported_geometry_is_refused():

@@ -620,3 +620,76 @@ def test_fp16h_meets_1e3_on_data_that_does_not_look_like_the_calibration_frames(
     # error is 1.4 x the noise clips'; measured 0.96e-3 with these weights, 1.08e-3 with weight seed 3: stated 1.1e-3, not the tolerance)
     assert max(rel) <= (1.1e-3 if data == "blocks" else 1e-3), ["%.2e" % r for r in rel]
     assert flips == 0
+
+
+def test_f32_epilogue_rounds_once_after_the_affine():
+    """VNQA_CONV_F32_EPILOGUE (round 6): ONE plain output whose ReLU / pool / affine are applied in fp32 and rounded once — the dual
+    epilogue's hi half, on both tile families; the plain epilogue's double rounding shows against a float64 reference."""
+    from videonavqa_amd import _lib as L
+    from videonavqa_amd import kernels as K
+    n, h, w, cin, cout = 4, 28, 28, 512, 512
+    x = _padded(n, h, w, cin, 51).half()
+    g = torch.Generator().manual_seed(52)
+    w4 = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda().half().float()
+    wt = K.pack_conv_weight(w4, torch.float16)
+    bias = (torch.randn(cout, generator=g) * 0.1).cuda()
+    sc = torch.ones(cout, device="cuda")
+    sh = -(torch.rand(cout, generator=g) * 0.5 + 0.3).cuda()           # a shift that CANCELS most of the value: the case that matters
+    ref = _torch_conv(x.float(), w4, bias, True, True, (sc, sh))
+    kw = dict(bias=bias, relu=True, pool2=True, post_scale=sc, post_shift=sh)
+    for tile in (L.TILE_STEM_PS_224x256, L.TILE_STEM_256x256):
+        one = K.conv2d_igemm(x, wt, tile=tile, f32_epilogue=True, **kw)
+        two = K.conv2d_igemm(x, wt, tile=tile, dual_out=2, **kw)
+        plain = K.conv2d_igemm(x, wt, tile=tile, **kw)
+        assert one.shape == plain.shape and torch.equal(one, two[..., :cout])
+        e1 = float((one.double()[:, 1:-1, 1:-1] - ref).pow(2).mean().sqrt())
+        e2 = float((plain.double()[:, 1:-1, 1:-1] - ref).pow(2).mean().sqrt())
+        assert e1 < 0.8 * e2, (tile, e1, e2)
+        assert float((one.double()[:, 1:-1, 1:-1] - ref).abs().max()) <= 2.0 ** -11 * float(ref.abs().max()) * 1.01
+
+
+def test_mean_shifted_storage_is_exact_algebra_and_lowers_the_stem_error():
+    """Round 6: the stem's stored activations minus their calibration channel means (FrozenStem._setup_mean_shift).  (a) The algebra is
+    exact: the shifted plan reproduces the un-shifted one up to storage roundings — incl. the image border (the halo holds -mu), the
+    composed pair's border ring (per-edge bias corrections) and conv1_1's LDS-resident output — at 224 x 224 and at the reference's
+    160 x 208; (b) its features are closer to the exact-f32 stem's, on noise frames and — by more — on piecewise-constant frames."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from videonavqa_amd import stem as S
+    from videonavqa_amd.models.common import FrameLayout
+    torch.set_grad_enabled(False)
+    try:
+        lay = FrameLayout([2, 1], 2, "cuda")
+        for (H, W) in ((224, 224), (160, 208)):
+            g = torch.Generator().manual_seed(61)
+            clips = {"noise": torch.rand(2, 3, H, W, 2, generator=g).cuda(),
+                     "blocks": bench.blocks_clip(2, 2, H, W, g).cuda()}
+            vgg32, od32 = _random_stem("fp32")
+            ref = S.FrozenStem(vgg32, od32, "fp32")
+            vgg, od = _random_stem("fp16")
+            S.MEAN_SHIFT = 1
+            on = S.FrozenStem(vgg, od, "fp16")
+            S.MEAN_SHIFT = 0
+            off = S.FrozenStem(vgg, od, "fp16")
+            S.MEAN_SHIFT = 1
+            assert on.shift and not off.shift and float(on.shift["c22"].abs().max()) > 0
+            for kind, clip in clips.items():
+                r = ref.forward_clip(clip, lay.img_of, lay.n_img).double()[:, 1:-1, 1:-1, :512]
+                a = on.forward_clip(clip, lay.img_of, lay.n_img).double()[:, 1:-1, 1:-1]
+                b = off.forward_clip(clip, lay.img_of, lay.n_img).double()[:, 1:-1, 1:-1]
+                scale = float(r.abs().max())
+                e_on, e_off = float((a - r).pow(2).mean().sqrt()), float((b - r).pow(2).mean().sqrt())
+                # exact algebra: both within a few storage roundings of the exact stem EVERYWHERE (a wrong border / ring / halo term would
+                # show as an error of the order of the activations themselves on the border pixels)
+                assert float((a - r).abs().max()) < 6e-3 * scale, (H, W, kind, float((a - r).abs().max()) / scale)
+                border = torch.zeros(r.shape[1], r.shape[2], dtype=torch.bool, device=r.device)
+                border[0, :] = border[-1, :] = border[:, 0] = border[:, -1] = True
+                eb = float((a - r)[:, border].pow(2).mean().sqrt())
+                ei = float((a - r)[:, ~border].pow(2).mean().sqrt())
+                assert eb < 2.0 * ei + 1e-4 * scale, (H, W, kind, eb, ei)
+                assert e_on < 0.95 * e_off, (H, W, kind, e_on, e_off)        # (at the FEATURES the later layers' own roundings dilute the gain:
+                # measured 0.80-0.85; the logits error halves — tests below, profiles/r06_mean_shift.txt)
+    finally:
+        S.MEAN_SHIFT = 1
+        torch.set_grad_enabled(True)

@@ -62,6 +62,17 @@ class Setting(object):
             return hi + (lo * sc).to(torch.float8_e4m3fn).float() / sc
         if m == "h4":
             return hi + mxfp4(lo)
+        if m == "shift_own" or m == "shift_cal":
+            # store v - mu_c (a per-channel constant; the consumer's bias absorbs conv(W, mu)): the rounding error scales with |v - mu_c|
+            # instead of |v| — 'own': the tensor's own channel means, 'cal': the calibration frames' (what a frozen stem can know)
+            if key == "a_clip":
+                mu = torch.full((1, t.shape[1], 1, 1), 0.5, device=t.device)
+            elif m == "shift_cal":
+                mu = SHIFT_MEANS[key].to(t.device).view(1, -1, 1, 1)
+            else:
+                mu = t.mean(dim=(0, 2, 3), keepdim=True)
+            mu = mu.half().float()
+            return (t - mu).half().float() + mu
         if m == "dither":
             u = torch.rand_like(t) - 0.5
             ulp = 2.0 ** (torch.floor(torch.log2(t.abs().clamp_min(6.2e-5))) - 10)
@@ -81,6 +92,8 @@ def mxfp4(lo):
     q = torch.where(a < 2, torch.round(a * 2) / 2, torch.where(a < 4, torch.round(a), torch.round(a / 2) * 2))
     return (torch.sign(v) * q * s).view(n, c, h, w)
 
+
+SHIFT_MEANS = {}      # activation point -> per-channel mean on the calibration frames (filled per weight seed in main)
 
 STEM_W = ["sw_c11", "sw_c12", "sw_c21", "sw_c22", "sw_comp", "sw_od21", "sw_od22", "sw_od31", "sw_od32"]
 
@@ -332,6 +345,12 @@ def settings_round6():
     S.append(Setting("fp16h acts, od21,comp as hi + mxfp4 lo", base, amode={"a_od21": "h4", "a_comp": "h4"}))
     S.append(Setting("fp16h acts, all 7 stem dithered", base, amode={p: "dither" for p in left}))
     S.append(Setting("stem acts (all 10)", STEM_ACTS))
+    six = ["a_clip", "a_c12", "a_c21", "a_c22", "a_comp", "a_od21"]
+    for mode in ("shift_own", "shift_cal"):
+        S.append(Setting("fp16h acts, clip..od21 except c11 stored mean-shifted (%s)" % mode, base, amode={p: mode for p in six}))
+        S.append(Setting("fp16h acts, all 7 stem stored mean-shifted (%s)" % mode, base, amode={p: mode for p in left}))
+        for p in six[:1] + ["a_c11"] + six[1:]:
+            S.append(Setting("%s mean-shifted (%s)" % (p, mode), [p], amode={p: mode}))
     S.append(Setting("w_3x3:rtn", wmode={"w_3x3": "rtn"}))
     S.append(Setting("w_init:rtn", wmode={"w_init": "rtn"}))
     S.append(Setting("w_1x1:rtn", wmode={"w_1x1": "rtn"}))
@@ -398,7 +417,10 @@ def main():
                 print("seed %d: library precision '%s' vs restatement (exact): max %.3f rms %.3f   %s" %
                       (seed, prec, max(e), (sum(x * x for x in e) / len(e)) ** 0.5, " ".join("%.2f" % x for x in e)), flush=True)
         from videonavqa_amd.stem import calibration_means
-        wdel = stem_weight_deltas(vgg, od, calibration_means(vgg, od))
+        cal = calibration_means(vgg, od, n_frames=40)
+        for key, ck in (("a_c11", "vgg0"), ("a_c12", "vgg1"), ("a_c21", "vgg2"), ("a_c22", "od0"), ("a_comp", "od2"), ("a_od21", "od3")):
+            SHIFT_MEANS[key] = cal[ck].float()
+        wdel = stem_weight_deltas(vgg, od, cal)
         del model, stem
         torch.cuda.empty_cache()
         stem_cache = {}

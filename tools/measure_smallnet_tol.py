@@ -6,7 +6,9 @@ import numpy as np, torch, torch.nn as nn
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from helpers import QV_CASES, build_product_model, rel_err, LOW
-worst = {"eval_logits": 0, "train_logits": 0, "l2": (0, ""), "elem": (0, "")}
+PREC = sys.argv[1] if len(sys.argv) > 1 else LOW          # e.g. fp16h (fp16 build: the default), fp16; bf16 needs VNQA_TEST_LOW_PRECISION=bf16
+LOW = PREC
+worst = {"eval_logits": 0, "train_logits": 0, "l2": (0, ""), "elem": (0, ""), "whole_grad_l2": (0, "")}
 for case in QV_CASES:
     model, g = build_product_model(case, LOW)
     v, q, vl, ql, y = (torch.from_numpy(g[k]).cuda() for k in ("v", "q", "v_lens", "q_lens", "y"))
@@ -19,6 +21,13 @@ for case in QV_CASES:
     logits = model(v, q, vl, ql)
     nn.CrossEntropyLoss(reduction="sum")(logits, y).backward()
     worst["train_logits"] = max(worst["train_logits"], rel_err(logits.detach().float().cpu().numpy(), g["train_logits"]))
+    num = den = 0.0
+    for name, p in model.named_parameters():
+        if "grad/" + name in g and p.grad is not None:
+            num += float(((p.grad.float().cpu() - torch.from_numpy(g["grad/" + name])) ** 2).sum())
+            den += float((torch.from_numpy(g["grad/" + name]) ** 2).sum())
+    if den > 0 and (num / den) ** 0.5 > worst["whole_grad_l2"][0]:
+        worst["whole_grad_l2"] = (round((num / den) ** 0.5, 4), case)
     for name, p in model.named_parameters():
         ref = g["grad/" + name]
         got = np.zeros_like(ref) if p.grad is None else p.grad.float().cpu().numpy()

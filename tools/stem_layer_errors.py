@@ -80,17 +80,19 @@ def main():
         v = t[..., :c] + (t[..., c:2 * c] if segs > 1 else 0)
         return v[:, halo:v.shape[1] - halo, halo:v.shape[2] - halo].permute(0, 3, 1, 2)
     segs = lambda t, c: 2 if t.shape[-1] >= 2 * c else 1
-    got = {"conv1 (fused conv1_1 + conv1_2, pooled)": nchw(stem._bufs[("vgg", 0, H // 2, W // 2)], 64),
-           "conv2_1": nchw(stem._tap[("vgg", 1)], 128),
-           "conv2_2 (pooled, bn_input)": nchw(stem._tap[("vgg", 2)], 128, halo=2 if stem.composed is not None else 1)}
+    # (mean-shifted storage: the stored tensor is v - mu_c; add the shift back)
+    sh = lambda key, c: (stem.shift[key][:c].view(1, -1, 1, 1) if key in getattr(stem, "shift", {}) else 0.0)
+    got = {"conv1 (fused conv1_1 + conv1_2, pooled)": nchw(stem._bufs[("vgg", 0, H // 2, W // 2)], 64) + sh("c12", 64),
+           "conv2_1": nchw(stem._tap[("vgg", 1)], 128) + sh("c21", 128),
+           "conv2_2 (pooled, bn_input)": nchw(stem._tap[("vgg", 2)], 128, halo=2 if stem.composed is not None else 1) + sh("c22", 128)}
     t = stem._tap[("od", "c")]
-    got["conv11.conv12 (composed, pooled)"] = nchw(t, 512, segs=segs(t, 512))
-    for i, name in ((2, "conv21"), (3, "conv22 (pooled)"), (4, "conv31")):
+    got["conv11.conv12 (composed, pooled)"] = nchw(t, 512, segs=segs(t, 512)) + sh("comp", 512)
+    for i, name, key in ((2, "conv21", "od21"), (3, "conv22 (pooled)", "od22"), (4, "conv31", "od31")):
         t = stem._tap[("od", i)]
-        got[name] = nchw(t, 512, segs=segs(t, 512))
+        got[name] = nchw(t, 512, segs=segs(t, 512)) + sh(key, 512)
     got["conv32 (features)"] = nchw(feat, 512)
     exact = chain(vgg, od, frames, lambda t: t)
-    model = chain(vgg, od, frames, lambda t: t.half().float())
+    model = chain(vgg, od, frames, lambda t: t.half().float())          # (un-shifted fp16 storage: what rounds 3-5 stored)
     print("%dx%d, weight seed %d, minibatch %d (%d images), precision %s, calibration %s" % (H, W, o.seed, o.batch_index, lay.n_img, o.precision, o.calibration))
     print("%-44s %12s %12s %8s   %s" % ("layer output (rel. L2 error vs torch fp32)", "library", "rounding model", "ratio", "max abs err / max |v|: library, model"))
     for k in exact:

@@ -21,7 +21,12 @@ def main():
     ap.add_argument("--width", type=int, default=224)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--precision", default="fp16h")
+    ap.add_argument("--set", nargs="*", default=[], help="module attributes of videonavqa_amd.stem preset for an A/B, e.g. MEAN_SHIFT=0 SPLIT_DEPTH=1")
     a = ap.parse_args()
+    import videonavqa_amd.stem as S
+    for word in a.set:
+        k, v = word.split("=")
+        setattr(S, k, type(getattr(S, k))(int(v)))
     a.model, a.blocks, a.channels, a.tail_channels = "film_attn_pt", 1, 512, 0
     if a.precision in ("fp16", "fp16h"):
         from videonavqa_amd import _lib as L

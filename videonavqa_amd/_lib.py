@@ -37,7 +37,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 423          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 430          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -57,6 +57,8 @@ CONV_XCD_SPLIT_N = 2
 CONV_X_WRAP2 = 4
 CONV_DUAL_OUT = 0x20000  # y = [h16(v) | h16(v - h16(v))], 2 c_out channels (patch-stationary tiles)
 CONV_DUAL_HI2 = 0x40000  # with CONV_DUAL_OUT: y = [hi | lo | hi], 3 c_out channels (a three-product consumer's operand)
+CONV_F32_EPILOGUE = 0x80000      # one plain output, pool / affine in fp32, rounded once
+CONV_FIRST_MID_SHIFT = 0x100000  # vnqa_conv_first_c64_fwd: b1 = [bias | shift of the first conv's stored output]
 LAYOUT_MAX_BATCH = 256     # vnqa_frame_layout: VNQA_LAYOUT_MAX_BATCH
 GEMM_X_WRAP2 = 0x400
 WGRAD_FUSED_REDUCE = 0x100     # option bit of vnqa_conv2d_wgrad's dtype argument
@@ -214,6 +216,7 @@ _SIGNATURES = {
     "vnqa_pack_fc_weight": (ctypes.c_int, [_vp] + [_i32] * 7 + [_vp, _vp, _vp]),
     "vnqa_unpack_fc_wgrad": (ctypes.c_int, [_vp] + [_i32] * 5 + [_vp, _vp]),
     "vnqa_clip_to_nhwc4": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_clip_to_nhwc4_shifted": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_clip_u8_to_nhwc4": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_conv_first_c64_fwd": (ctypes.c_int, [_vp] * 10),
     "vnqa_conv_first_c64_fwd_sched": (ctypes.c_int, [_vp] * 11),

@@ -50,6 +50,8 @@ struct C64Args {
   // fused conv1_1 (FUSE variant): x = image as [n][H+4][W+4][4] bf16 (zero halo of 2, channel 3 zero)
   const float* w1;              // [64][27] fp32 (OIHW flattened)
   const float* b1;              // [64]
+  const float* mu1;             // [64] or NULL (VNQA_CONV_FIRST_MID_SHIFT): the first conv's output is kept in LDS as relu(.) - mu1[c], and as
+                                // -mu1[c] where it is the second conv's zero padding — the caller's second-conv bias carries sum(W2 mu1)
   int reserve_cus;              // CUs the persistent grid leaves to other streams (VNQA_CONV_RESERVE_CUS in vnqa_conv_desc.flags)
   // != NULL (wide fused kernel, nsplit == 1): DYNAMIC tile schedule — two device words {next tile, workgroups done}, zero on entry and
   // left zero on exit.  Every workgroup draws its tiles from the counter instead of owning the fixed stride blockIdx.x, + grid, ...:
@@ -391,7 +393,7 @@ namespace wide {
 constexpr int TX = 32, TY = 16, PX = TX + 2, PY = TY + 2, PROWS_W = PX * PY;       // 612 patch rows
 constexpr int PW_BYTES = ((PROWS_W * 128 + 1023) / 1024) * 1024;                   // 78848
 constexpr int IX = PX + 2, IY = PY + 2, IN_PIX = IX * IY;                          // 36 x 20 = 720 image pixels
-constexpr int X_BYTES = 4096 + 256 + 256;                                         // conv1_1 fragments, its bias, conv1_2's bias
+constexpr int X_BYTES = 4096 + 256 + 256 + 256;                                   // conv1_1 fragments, its bias, conv1_2's bias, conv1_1's output shift
 constexpr int LDS_W = W_BYTES + PW_BYTES + IN_PIX * 8 + X_BYTES;                   // 162944
 static_assert(512 * CROW <= PW_BYTES, "epilogue tile must fit the patch slot");
 static_assert(LDS_W <= 160 * 1024, "LDS budget exceeded");
@@ -445,6 +447,7 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
   char* const ldsX = ldsIn + IN_PIX * 8;
   float* const ldsB1 = (float*)(ldsX + 4096);
   float* const ldsB2 = ldsB1 + 64;
+  float* const ldsM1 = ldsB2 + 64;
   // conv1_1 as TWO MFMAs over a K order that follows the image list's memory order (4 channels per pixel, channel 3 and
   // pixel column 3 carry zero weights), so that the B operand is fetched with aligned 8-byte reads instead of eight
   // 2-byte gathers plus packing:
@@ -471,6 +474,7 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
     }
     ldsB1[lane] = p.b1[lane];
     ldsB2[lane] = p.bias ? p.bias[nsl * 64 + lane] : 0.f;
+    ldsM1[lane] = p.mu1 ? p.mu1[lane] : 0.f;
   }
 
   // image pixels under the patch: thread i fetches pixels i and i + 512 (720 in all), 8 bytes each
@@ -529,12 +533,18 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float4 bb = *(const float4*)(ldsB1 + 16 * j + 4 * fh);
+      // mean-shifted storage (round 6): the 16-bit value kept for conv1_2 is v - mu1[c] (rounding error ~ |v - mu|, not |v|);
+      // conv1_2's ZERO padding is then -mu1[c]; mu1 = 0 (no shift) gives the former bits
+      const float4 mm = *(const float4*)(ldsM1 + 16 * j + 4 * fh);
 #pragma unroll
       for (int gi = 0; gi < 5; ++gi) {
-        uint2 pk = make_uint2(0u, 0u);
+        uint2 pk;
         if (ins[gi]) {
-          pk.x = pack2_h16(fmaxf(a1[gi][j][0] + bb.x, 0.f), fmaxf(a1[gi][j][1] + bb.y, 0.f));
-          pk.y = pack2_h16(fmaxf(a1[gi][j][2] + bb.z, 0.f), fmaxf(a1[gi][j][3] + bb.w, 0.f));
+          pk.x = pack2_h16(fmaxf(a1[gi][j][0] + bb.x, 0.f) - mm.x, fmaxf(a1[gi][j][1] + bb.y, 0.f) - mm.y);
+          pk.y = pack2_h16(fmaxf(a1[gi][j][2] + bb.z, 0.f) - mm.z, fmaxf(a1[gi][j][3] + bb.w, 0.f) - mm.w);
+        } else {
+          pk.x = pack2_h16(0.f - mm.x, 0.f - mm.y);
+          pk.y = pack2_h16(0.f - mm.z, 0.f - mm.w);
         }
         const int pr = prs[gi];
         if (pr < PROWS_W)
@@ -671,11 +681,11 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
             v[e] = fmaxf(t, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF,
                                                                                      0xF, true)));
           }
-          if (has_post) {                            // on the bf16-rounded value, as the LDS-staged variants do
+          if (has_post) {                            // in fp32 on the unrounded value: ONE storage rounding (round 6; rounds 3-5 rounded first)
             const int co = nsl * 64 + 16 * j + 4 * fh;
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = bf16_to_f32(f32_to_bf16(v[e])) * p.post_scale[co + e] + p.post_shift[co + e];
+              v[e] = v[e] * p.post_scale[co + e] + p.post_shift[co + e];
           }
           P[j].x = pack2_h16(v[0], v[1]);
           P[j].y = pack2_h16(v[2], v[3]);
@@ -773,7 +783,8 @@ __global__ void __launch_bounds__(512) conv_first_c64_wide_kernel(const C64Args 
 template <typename SRC>
 __global__ void __launch_bounds__(256) clip_to_nhwc4_kernel(const SRC* __restrict__ clip, const float* __restrict__ lut,
                                                             const int* __restrict__ img_of,
-                                                            unsigned short* __restrict__ out, int T, int H, int W) {
+                                                            unsigned short* __restrict__ out, int T, int H, int W,
+                                                            const float* __restrict__ shift) {
   // SRC = float: the clip's values as they are.  SRC = unsigned char: raw 8-bit pixels k, valued lut[k] — the caller's table of
   // float32(k / 255.0) evaluated in double (eval/dataset.py:91 followed by q_and_v_eval.py:92's .float()), so both sources
   // give the same bits while the upload moves a quarter of the bytes.
@@ -798,8 +809,10 @@ __global__ void __launch_bounds__(256) clip_to_nhwc4_kernel(const SRC* __restric
     const int img = img_of[b * T + t];
     if (img < 0) continue;
     uint2 o;
-    o.x = pack2_h16(val(px * T + t), val(32 * T + px * T + t));
-    o.y = (unsigned)f32_to_bf16(val(2 * 32 * T + px * T + t));
+    // shift != NULL: the image list holds pixel - shift[c] (mean-shifted storage; its halo then holds -shift[c], written by the caller)
+    const float s0 = shift ? shift[0] : 0.f, s1 = shift ? shift[1] : 0.f, s2 = shift ? shift[2] : 0.f;
+    o.x = pack2_h16(val(px * T + t) - s0, val(32 * T + px * T + t) - s1);
+    o.y = (unsigned)f32_to_bf16(val(2 * 32 * T + px * T + t) - s2);
     *(uint2*)(out + ((((size_t)img * (H + 4)) + y + 2) * (W + 4) + x0 + px + 2) * 4) = o;
   }
 }
@@ -823,6 +836,7 @@ int c64_fill(const vnqa_conv_desc* d, const void* x, const void* wt, const float
   a.bias = bias;
   a.post_scale = post_scale;
   a.post_shift = post_shift;
+  a.mu1 = nullptr;
   a.y = (char*)y;
   a.n_img = d->n_img;
   a.H = d->h;
@@ -907,6 +921,8 @@ extern "C" int vnqa_conv_first_c64_fwd_sched(const vnqa_conv_desc* d, const void
   VNQA_CHECK_ARG((((uintptr_t)sched) & 7) == 0, "conv_first_c64_fwd: the schedule words must be 8-byte aligned");
   a.w1 = w1;
   a.b1 = b1;
+  a.mu1 = (d->flags & VNQA_CONV_FIRST_MID_SHIFT) ? b1 + 64 : nullptr;      // b1 = [bias (64) | shift of the first conv's stored output (64)]
+  VNQA_CHECK_ARG(a.mu1 == nullptr || d->tile != 3, "conv_first_c64_fwd: VNQA_CONV_FIRST_MID_SHIFT is served by the wide (default) kernel");
   a.sched = (d->tile != 3 && a.nsplit == 1) ? (unsigned*)sched : nullptr;      // (the dynamic schedule serves the wide kernel, 64 couts)
   static std::atomic<bool> attr_set{false};   // idempotent attribute call: a race only repeats it
   if (!attr_set) {
@@ -939,7 +955,7 @@ extern "C" int vnqa_clip_to_nhwc4(const float* clip, const int32_t* img_of, void
   const size_t lds = (size_t)3 * 32 * t * sizeof(float);
   VNQA_CHECK_ARG(lds <= 64 * 1024, "clip_to_nhwc4: t=%d frames do not fit the LDS stage", t);
   hipLaunchKernelGGL(clip_to_nhwc4_kernel<float>, dim3((w + 31) / 32, h, b), dim3(256), lds, (hipStream_t)stream, clip,
-                     (const float*)nullptr, img_of, (unsigned short*)img4, t, h, w);
+                     (const float*)nullptr, img_of, (unsigned short*)img4, t, h, w, (const float*)nullptr);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }
@@ -953,7 +969,29 @@ extern "C" int vnqa_clip_u8_to_nhwc4(const uint8_t* clip, const float* lut, cons
   const size_t lds = ((size_t)3 * 32 * t + 3) / 4 * 4 + 256 * sizeof(float);
   VNQA_CHECK_ARG(lds <= 64 * 1024, "clip_u8_to_nhwc4: t=%d frames do not fit the LDS stage", t);
   hipLaunchKernelGGL(clip_to_nhwc4_kernel<unsigned char>, dim3((w + 31) / 32, h, b), dim3(256), lds, (hipStream_t)stream, clip,
-                     lut, img_of, (unsigned short*)img4, t, h, w);
+                     lut, img_of, (unsigned short*)img4, t, h, w, (const float*)nullptr);
+  VNQA_CHECK_LAUNCH();
+  return VNQA_OK;
+}
+
+// Either source with MEAN-SHIFTED storage (round 6): the image list holds pixel - shift[c] (shift: 3 floats ON THE DEVICE), so that the
+// 16-bit rounding error scales with |pixel - shift| instead of |pixel|; the caller keeps -shift[c] in the list's halo (what a zero pixel
+// becomes) and adds sum(W1 shift) to the first conv's bias.  lut == NULL: clip is fp32; else clip is uint8 valued lut[k].
+extern "C" int vnqa_clip_to_nhwc4_shifted(const void* clip, const float* lut, const float* shift, const int32_t* img_of, void* img4,
+                                          int32_t b, int32_t t, int32_t h, int32_t w, void* stream) {
+  VNQA_CHECK_ARG(clip && img_of && img4 && shift, "clip_to_nhwc4_shifted: null pointer");
+  VNQA_CHECK_ARG(b > 0 && t > 0 && h > 0 && w > 0, "clip_to_nhwc4_shifted: empty problem");
+  if (lut == nullptr) {
+    const size_t lds = (size_t)3 * 32 * t * sizeof(float);
+    VNQA_CHECK_ARG(lds <= 64 * 1024, "clip_to_nhwc4_shifted: t=%d frames do not fit the LDS stage", t);
+    hipLaunchKernelGGL(clip_to_nhwc4_kernel<float>, dim3((w + 31) / 32, h, b), dim3(256), lds, (hipStream_t)stream, (const float*)clip,
+                       (const float*)nullptr, img_of, (unsigned short*)img4, t, h, w, shift);
+  } else {
+    const size_t lds = ((size_t)3 * 32 * t + 3) / 4 * 4 + 256 * sizeof(float);
+    VNQA_CHECK_ARG(lds <= 64 * 1024, "clip_to_nhwc4_shifted: t=%d frames do not fit the LDS stage", t);
+    hipLaunchKernelGGL(clip_to_nhwc4_kernel<unsigned char>, dim3((w + 31) / 32, h, b), dim3(256), lds, (hipStream_t)stream,
+                       (const unsigned char*)clip, lut, img_of, (unsigned short*)img4, t, h, w, shift);
+  }
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
 }

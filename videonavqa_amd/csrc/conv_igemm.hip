@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     tile_n = swz % p.tilesN;
     tile_m = swz / p.tilesN;
-    if constexpr (TAG == 1 || TAG == 5) {
+    if constexpr (TAG == 1 || TAG == 5 || TAG == 6) {
       // VNQA_CONV_XCD_SPLIT_N (stem launches with two cout tiles: the composed 5x5 conv): XCD x owns cout half x & 1 ONLY, the pixel
       // tiles of that half dealt to the four XCDs of its parity in contiguous runs.  An XCD's L2 (4 MiB) then holds ONE half of the
       // weight set (1.65 of the composed conv's 3.3 MB) next to its 32 tiles' activation windows instead of thrashing on both
@@ -611,7 +611,8 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     }
     return;
   }
-  if constexpr (TAG == 5) {
+  if constexpr (TAG == 5 || TAG == 6) {
+    // (TAG 6 = the same epilogue with ONE plain output, VNQA_CONV_F32_EPILOGUE: its own instantiation, no runtime branch)
     // DUAL output on the implicit-GEMM tile (VNQA_CONV_DUAL_OUT [| VNQA_CONV_DUAL_HI2], VNQA_EPI_SPLIT_OUT; precision 'fp16h' on the
     // geometries the patch-stationary tiles do not serve — the 10 x 13 maps of the reference's 160 x 208 frames, eval/utils.py:24-25 —
     // and on the composed 5x5 conv): the fp32 result as a PAIR of 16-bit values hi = h16(v), lo = h16(v - hi), channel segments
@@ -700,19 +701,20 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
         }
-        unsigned hw[4], lw[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          hw[e] = pack2_h16(v[2 * e], v[2 * e + 1]);
-          lw[e] = pack2_h16(v[2 * e] - h16_lo(hw[e]), v[2 * e + 1] - h16_hi(hw[e]));
-        }
         const int n = mo / (Hod * Wod);
         const int rem = mo - n * (Hod * Wod);
         const int yo = rem / Wod;
         const int xo = rem - yo * Wod;
         const size_t ooff = (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
         vnqa_bf16* dst = (vnqa_bf16*)(p.y) + ooff;
+        unsigned hw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hw[e] = pack2_h16(v[2 * e], v[2 * e + 1]);
         *(uint4*)dst = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        if constexpr (TAG == 6) continue;      // VNQA_CONV_F32_EPILOGUE: ONE plain 16-bit output, rounded once after pool / affine in fp32
+        unsigned lw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lw[e] = pack2_h16(v[2 * e] - h16_lo(hw[e]), v[2 * e + 1] - h16_hi(hw[e]));
         if (p.dual_out == 4) {      // VNQA_EPI_SPLIT_OUT: hi and lo as TWO plain tensors of y's geometry (y, y2)
           *(uint4*)((vnqa_bf16*)(p.y2) + ooff) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
           continue;
@@ -1160,7 +1162,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
   if (a.dual_out && tile != VNQA_TILE_PS_224x256 && tile != VNQA_TILE_STEM_PS_224x256) {
     // [hi | lo (| hi)] / (hi, lo) output on the implicit-GEMM tile: the TAG 5 instantiation of the 256 x 256 tile (fp32 epilogue)
     if (dtype != VNQA_BF16 || a.epi != VNQA_EPI_NONE || a.D != 0 || a.ring_h != 0 || a.partial != nullptr || a.group_tiles != 0 ||
-        a.zero_halo || a.x_wrap2 || a.relu == VNQA_ACT_ELU || a.Cout % 8 != 0 || a.Cy < (a.dual_out == 4 ? 1 : a.dual_out + 1) * a.Cout ||
+        a.zero_halo || a.x_wrap2 || a.relu == VNQA_ACT_ELU || a.Cout % 8 != 0 || a.Cy < ((a.dual_out == 4 || a.dual_out == 8) ? 1 : a.dual_out + 1) * a.Cout ||
         (a.dual_out == 4 && a.y2 == nullptr) || (a.pool && (a.H % 2 != 0 || a.W % 2 != 0))) {
       vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT on the implicit-GEMM tile needs a plain 16-bit 2-D conv (no fused epilogue / "
                      "split-K / halo zeroing / wrap), c_out %% 8 == 0 and c_y >= 2 c_out (3 c_out with VNQA_CONV_DUAL_HI2)");
@@ -1170,7 +1172,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT is served by the patch-stationary tiles and the 256x256 tiles (got tile %d)", tile);
       return VNQA_ERR_UNSUPPORTED;
     }
-    return launch<vnqa_bf16, 256, 256, 2, 4, 5>(a, st);
+    return a.dual_out == 8 ? launch<vnqa_bf16, 256, 256, 2, 4, 6>(a, st) : launch<vnqa_bf16, 256, 256, 2, 4, 5>(a, st);
   }
   if (a.relu == VNQA_ACT_ELU) {        // own instantiations of the plain tiles (conv_args.h: why not a runtime branch)
     if (a.epi != VNQA_EPI_NONE || a.partial != nullptr || a.pool) {
@@ -1545,10 +1547,10 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
   a.zero_halo = (d->flags & VNQA_CONV_ZERO_HALO) ? 1 : 0;
   a.xcd_split = (d->flags & VNQA_CONV_XCD_SPLIT_N) ? 1 : 0;
   a.x_wrap2 = (d->flags & VNQA_CONV_X_WRAP2) ? 1 : 0;
-  a.dual_out = (d->flags & VNQA_CONV_DUAL_OUT) ? ((d->flags & VNQA_CONV_DUAL_HI2) ? 2 : 1) : 0;
+  a.dual_out = (d->flags & VNQA_CONV_DUAL_OUT) ? ((d->flags & VNQA_CONV_DUAL_HI2) ? 2 : 1) : ((d->flags & VNQA_CONV_F32_EPILOGUE) ? 8 : 0);
   VNQA_CHECK_ARG(!a.dual_out || d->tile == VNQA_TILE_PS_224x256 || d->tile == VNQA_TILE_STEM_PS_224x256 ||
                      d->tile == VNQA_TILE_256x256 || d->tile == VNQA_TILE_STEM_256x256,
-                 "conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT is served by the patch-stationary tiles and the 256x256 implicit-GEMM tiles");
+                 "conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT / VNQA_CONV_F32_EPILOGUE are served by the patch-stationary tiles and the 256x256 implicit-GEMM tiles");
   a.pool = d->pool2;
   a.M = d->n_img * d->h * d->w;
   a.tilesN = 0;

@@ -248,10 +248,13 @@ __global__ void __launch_bounds__(256, 1) conv_wreg_kernel(const WregArgs p) {
         } else {
           u = vmax1(acc[h & 1][ro][j][e] + b, relu_floor);
         }
-        if constexpr (POST) {   // affine on the storage-rounded value, as the LDS-staged kernels do
+        if constexpr (POST) {
+          // affine in fp32 on the UNROUNDED value: ONE storage rounding.  (Rounds 3-5 rounded first "as the LDS-staged kernels do" and
+          // rounded the affine's result again: tools/stem_layer_errors.py measured conv2_2's output — the only tensor of the stem
+          // with an affine, bn_input — at 1.17 x the error one rounding explains, 1.6 x in the maximum.)
           const float sc = e == 0 ? ps[j].x : e == 1 ? ps[j].y : e == 2 ? ps[j].z : ps[j].w;
           const float sh = e == 0 ? ph[j].x : e == 1 ? ph[j].y : e == 2 ? ph[j].z : ph[j].w;
-          u = bf16_to_f32(f32_to_bf16(u)) * sc + sh;
+          u = u * sc + sh;
         }
         ev[ro][j][e] = u;
       }

@@ -116,7 +116,7 @@ def split_weight2(wt):
 
 def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
                  x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, desc_flags=0,
-                 split_in=False, split_weights=False, dual_out=False):
+                 split_in=False, split_weights=False, dual_out=False, f32_epilogue=False):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
     Precision 'fp16h' (see the block comment above):
       split_weights — x a plain 16-bit tensor, wt the fp32 K-major pack: x . w_hi + x . w_lo on the igemm's wrap variant;
@@ -156,6 +156,12 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
             out = empty_padded((N, Ho + 2, Wo + 2, segs * c_out), x.dtype, x.device)
         assert out.shape[-1] == segs * c_out
         flags = L.CONV_DUAL_OUT | (L.CONV_DUAL_HI2 if segs == 3 else 0)
+    elif f32_epilogue:      # one plain output, pool / affine in fp32, ONE rounding (VNQA_CONV_F32_EPILOGUE; the dual epilogue's hi half)
+        assert y_halo == 1 and c_out % 8 == 0 and L.is_half(x.dtype) and (
+            (tile in (L.TILE_PS_224x256, L.TILE_STEM_PS_224x256) and border_sub is None) or tile in (L.TILE_256x256, L.TILE_STEM_256x256)), tile
+        if out is None:
+            out = empty_padded((N, Ho + 2, Wo + 2, c_out), x.dtype, x.device)
+        flags = L.CONV_F32_EPILOGUE
     if out is None:
         if y_halo == 1 and c_out % 8 == 0 and tile not in (11, 12, 20, 21):
             # fresh output: the kernel zeroes the halo ring itself (VNQA_CONV_ZERO_HALO), no fill / halo launch
@@ -321,7 +327,8 @@ def conv2d_ring_edges(x, wt_edges, bias, H, W, out_padded):
     assert out_padded.shape == (n, R + 4, c_out) and out_padded.dtype == x.dtype and out_padded.is_contiguous()
     for e in range(4):
         assert wt_edges[e].shape == (c_out, 3, c_in) and wt_edges[e].is_contiguous() and wt_edges[e].dtype == x.dtype
-        L.check(L.lib().vnqa_conv2d_ring_edge_fwd(L.ptr(x), L.ptr(wt_edges[e]), L.ptr(bias), L.ptr(out_padded), n, H, W, c_in, c_out, e,
+        be = bias[e] if isinstance(bias, (list, tuple)) else bias          # (per-edge biases: mean-shifted storage, stem._setup_mean_shift)
+        L.check(L.lib().vnqa_conv2d_ring_edge_fwd(L.ptr(x), L.ptr(wt_edges[e]), L.ptr(be), L.ptr(out_padded), n, H, W, c_in, c_out, e,
                                                   L.dtype_id(x.dtype), L.stream()), "vnqa_conv2d_ring_edge_fwd")
     return out_padded
 
@@ -536,13 +543,20 @@ def expand_u8_clip(clip):
     return pixel_lut(clip.device)[clip.long()]
 
 
-def clip_to_nhwc4(clip, img_of, n_img, out=None):
+def clip_to_nhwc4(clip, img_of, n_img, out=None, shift=None):
     """clip fp32 — or RAW uint8 pixels valued k / 255 — [B,3,H,W,T] (frames last) -> image list bf16 [n_img,H+4,W+4,4]
-    (halo 2 and channel 3 zero)."""
+    (halo 2 and channel 3 zero).  shift (device fp32 [3]): the list holds pixel - shift[c] (mean-shifted storage; the caller keeps
+    -shift[c] in the halo of `out`)."""
     B, C, H, W, T = clip.shape
     assert C == 3 and clip.dtype in (torch.float32, torch.uint8)
     if out is None:
         out = torch.zeros((n_img, H + 4, W + 4, 4), dtype=L.half_dtype(), device=clip.device)
+    if shift is not None:
+        assert shift.dtype == torch.float32 and shift.numel() >= 3 and shift.is_cuda
+        lut = pixel_lut(clip.device) if clip.dtype == torch.uint8 else None
+        L.check(L.lib().vnqa_clip_to_nhwc4_shifted(L.ptr(clip.contiguous()), L.ptr(lut), L.ptr(shift), L.ptr(img_of), L.ptr(out),
+                                                   B, T, H, W, L.stream()), "vnqa_clip_to_nhwc4_shifted")
+        return out
     if clip.dtype == torch.uint8:
         L.check(L.lib().vnqa_clip_u8_to_nhwc4(L.ptr(clip.contiguous()), L.ptr(pixel_lut(clip.device)), L.ptr(img_of), L.ptr(out),
                                               B, T, H, W, L.stream()), "vnqa_clip_u8_to_nhwc4")
@@ -553,7 +567,7 @@ def clip_to_nhwc4(clip, img_of, n_img, out=None):
 
 
 def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None,
-                   reserve_cus=0, sched=None):
+                   reserve_cus=0, sched=None, mid_shift=None):
     """conv(3->64)+ReLU fused into the following C_in = 64 conv (see vnqa_conv_first_c64_fwd).  img4 from clip_to_nhwc4;
     w1/b1 the first conv's fp32 OIHW weights and bias; wt/bias/... as conv2d_c64.  sched: int32 [2] device tensor, zero on first
     use — the dynamic tile schedule (vnqa_conv_first_c64_fwd_sched); None = static stride."""
@@ -564,10 +578,16 @@ def conv_first_c64(img4, w1, b1, wt, bias=None, relu=False, pool2=False, post_sc
     Ho, Wo = (H // 2, W // 2) if pool2 else (H, W)
     if out is None:
         out = torch.zeros((N, Ho + 2, Wo + 2, c_out), dtype=img4.dtype, device=img4.device)
-    d = L.ConvDesc(L.BF16, N, H, W, 64, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0, 0,
-                   L.conv_reserve_flags(reserve_cus))
+    flags = L.conv_reserve_flags(reserve_cus)
+    b1 = b1.detach().float().contiguous()
+    if mid_shift is not None:      # VNQA_CONV_FIRST_MID_SHIFT: b1 = [bias | shift of the first conv's stored output] (callers cache the pair)
+        if b1.numel() == 64:
+            b1 = torch.cat([b1, mid_shift.detach().float().reshape(-1)[:64]]).contiguous()
+        assert b1.numel() == 128
+        flags |= L.CONV_FIRST_MID_SHIFT
+    d = L.ConvDesc(L.BF16, N, H, W, 64, c_out, out.shape[-1], 9, 1, 1, int(relu), 1 if pool2 else 0, 0, 0, 0, flags)
     L.check(L.lib().vnqa_conv_first_c64_fwd_sched(ctypes.byref(d), L.ptr(img4), L.ptr(w1.detach().float().contiguous()),
-                                                  L.ptr(b1.detach().float().contiguous()), L.ptr(wt), L.ptr(bias),
+                                                  L.ptr(b1), L.ptr(wt), L.ptr(bias),
                                                   L.ptr(post_scale), L.ptr(post_shift), L.ptr(out), L.ptr(sched), L.stream()),
             "vnqa_conv_first_c64_fwd")
     return out

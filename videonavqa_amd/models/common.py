@@ -185,11 +185,11 @@ class NativeFeatures(object):
         self.data, self.layout, self.channels, self.h, self.w = data, layout, channels, h, w
         # 1: a plain tensor; 3: a SPLIT tensor [hi | lo | hi] (precision 'fp16h': the stem's dual epilogue).  An explicit marker
         # (consumers used to infer it from the channel count alone); None = stated by nobody, checked against the shape
-        c_pad = L.round_up(channels, 64)
-        inferred = 3 if (L.is_half(data.dtype) and data.shape[-1] == 3 * c_pad) else 1
-        self.segs = inferred if segs is None else int(segs)
-        assert self.segs == inferred and data.shape[-1] == self.segs * c_pad, \
-            "features tensor [..., %d] is not a %d-segment tensor of %d channels" % (data.shape[-1], self.segs, channels)
+        if segs is None:
+            segs = 3 if (L.is_half(data.dtype) and data.shape[-1] == 3 * L.round_up(channels, 64)) else 1
+        self.segs = int(segs)
+        assert self.segs in (1, 3) and data.shape[-1] % (64 * self.segs) == 0 and (self.segs == 1 or L.is_half(data.dtype)), \
+            "features tensor [..., %d] (%s) cannot be a %d-segment tensor" % (data.shape[-1], data.dtype, self.segs)
 
     @property
     def shape(self):  # what the reference tensor [B, C, h, w, T] would report

@@ -263,6 +263,7 @@ def patch_second_moment(x, k, max_rows=400000):
     return H / max(rows, 1)
 
 
+MEAN_SHIFT = 1               # 16-bit precisions with a calibration: store the stem's activations minus their calibration channel means (see FrozenStem)
 SPLIT_DEPTH = 3              # precision 'fp16h': how many of the stem's LAST stored activations are split tensors (see FrozenStem)
 RING_EDGE_LAUNCHES = True    # conv11 on the outside ring as four 3-tap launches (False: one 9-tap launch, same bits: the A/B partner)
 CALIBRATION_FRAMES = 40      # frames of the default ("noise") calibration pass: 40 x 196 patches > K = 4608 of the 14 x 14 layers
@@ -309,9 +310,10 @@ class FrozenStem(object):
         self.cdt = compute_dtype(precision)
         self.hyb = precision == "fp16h"
         self.split_features = bool(split_features) and self.hyb
-        # 3 (round 5): conv22's, conv31's and conv32's outputs; 4: + conv21's (conv22 then runs as two products); 5: + the composed
-        # conv11.conv12 pair's (conv21 as two products; the pair's dual output comes from the implicit-GEMM tile's fp32 epilogue)
-        self.split_depth = min(5, max(3, int(SPLIT_DEPTH if split_depth is None else split_depth))) if self.hyb else 0
+        # 1: the features alone (conv_init's three products; everything before them one product on mean-shifted storage); 3 (round 5):
+        # conv22's, conv31's and conv32's outputs; 4: + conv21's (conv22 then runs as two products); 5: + the composed conv11.conv12
+        # pair's (conv21 as two products; the pair's dual output comes from the implicit-GEMM tile's fp32 epilogue)
+        self.split_depth = min(5, max(1, int(SPLIT_DEPTH if split_depth is None else split_depth))) if self.hyb else 0
         self.vgg, self.objdet = vgg, objdet
         self.layers_vgg, self.layers_od = [], []
         self.composed = None
@@ -400,6 +402,12 @@ class FrozenStem(object):
                 if self.composed is not None:
                     self.layers_vgg[-1]["y_halo"] = 2        # the composed 5x5 conv reads a halo-2 image
 
+        self.shift = {}
+        if (MEAN_SHIFT and os.environ.get("VNQA_MEAN_SHIFT", "1") != "0" and L.is_half(self.cdt) and vgg is not None and objdet is not None
+                and self.calib is not None and all(k in self.calib for k in ("first", "vgg0", "vgg1", "vgg2", "od0", "od2", "od3"))):
+            self._setup_mean_shift()
+        for ly in self.layers_vgg + self.layers_od + ([self.composed] if self.composed is not None else []):
+            ly.pop("_wsum", None)
         self._H = None       # (0.8 GB of float64 moments: construction only)
 
     @property
@@ -431,9 +439,99 @@ class FrozenStem(object):
             elif isinstance(v, (list, tuple)):
                 for x in v:
                     walk(x)
-        for part in (self.first, self.layers_vgg, self.layers_od, self.composed, getattr(self, "bn_input", None)):
+        for part in (self.first, self.layers_vgg, self.layers_od, self.composed, getattr(self, "bn_input", None),
+                     getattr(self, "shift", None), getattr(self, "_b1_pair", None)):
             walk(part)
         return out
+
+    def _setup_mean_shift(self):
+        """MEAN-SHIFTED STORAGE (round 6).  A 16-bit store rounds to a RELATIVE 2^-12 of the stored value, so a tensor with a large
+        per-channel mean and a small spread around it (post-ReLU / post-pool activations, flat image regions) loses its information in
+        the rounding of the mean: measured with tools/experiments/precision_budget.py, the seven single-product stem roundings cost
+        0.75e-6 of squared logits error on piecewise-constant clips and 0.27e-6 on noise clips — and 0.17 / 0.08e-6 when the stored
+        value is v - mu_c instead (mu_c: the calibration frames' channel mean, rounded to the storage format).  No extra product:
+          * the PRODUCER subtracts mu_c in fp32 before its one storage rounding (post affine of the fused first conv / the
+            weights-in-registers conv; VNQA_CONV_F32_EPILOGUE on the composed pair; folded into the bias where no ReLU / pool
+            sits between conv and store: conv21; the image list by vnqa_clip_to_nhwc4_shifted; conv1_1's LDS-resident output by
+            VNQA_CONV_FIRST_MID_SHIFT);
+          * the tensor's HALO holds -mu_c — what the zero padding becomes — written once per buffer;
+          * the CONSUMER's bias gets sum_taps(Wq) mu: exact, because (x' + mu) is the unshifted tensor EVERYWHERE incl. the padding,
+            and Wq are the very 16-bit weights the kernel multiplies with (the border ring of the composed pair likewise).
+        Split tensors (precision 'fp16h') shift their hi half; the features handed to the trainable trunk stay unshifted."""
+        dev = self.first[0].device
+        hd = self.cdt
+        cal = self.calib
+
+        def mu_of(key, c, c_pad):
+            m = torch.zeros(c_pad, dtype=torch.float32)
+            m[:c] = torch.as_tensor(cal[key]).float().reshape(-1)[:c]
+            return m.to(hd).float().to(dev)                       # exactly representable in the storage format
+
+        def corr(wsum, mu, c_out_pad):
+            ci = wsum.shape[1]
+            out = torch.zeros(c_out_pad, dtype=torch.float64, device=dev)
+            out[:wsum.shape[0]] = wsum.to(dev) @ mu[:ci].double()
+            return out.float()
+        v0, v1, v2 = self.layers_vgg
+        od = self.layers_od
+        mu = {"clip": mu_of("first", 3, 4), "c11": mu_of("vgg0", 64, 64), "c12": mu_of("vgg1", v0["c_out"], v0["c_out_pad"]),
+              "c21": mu_of("vgg2", v1["c_out"], v1["c_out_pad"]), "c22": mu_of("od0", v2["c_out"], v2["c_out_pad"]),
+              "comp": mu_of("od2", od[1]["c_out"], od[1]["c_out_pad"]), "od21": mu_of("od3", od[2]["c_out"], od[2]["c_out_pad"])}
+        if v0["tile"] is not None:           # (only the fused conv1 path carries the first two shifts)
+            mu["clip"].zero_()
+            mu["c11"].zero_()
+        ones = lambda n: torch.ones(n, dtype=torch.float32, device=dev)
+        # clip -> conv1_1
+        w0, b0 = self.first
+        self.first = (w0, b0 + corr(w0.to(hd).double().sum((2, 3)), mu["clip"], 64))
+        # conv1_1's LDS-resident output -> conv1_2; conv1_2's output c12
+        v0["bias"] = v0["bias"] + corr(v0["_wsum"], mu["c11"], v0["c_out_pad"])
+        v0["post"] = (ones(v0["c_out_pad"]), -mu["c12"])
+        v0["out_shift"] = mu["c12"]
+        self._b1_pair = torch.cat([self.first[1].float().reshape(-1)[:64], mu["c11"][:64]]).contiguous()
+        # conv2_1: reads c12, writes c21
+        v1["bias"] = v1["bias"] + corr(v1["_wsum"], mu["c12"], v1["c_out_pad"])
+        v1["post"] = (ones(v1["c_out_pad"]), -mu["c21"])
+        v1["out_shift"] = mu["c21"]
+        # conv2_2: reads c21, writes c22 through bn_input's affine (already its post)
+        v2["bias"] = v2["bias"] + corr(v2["_wsum"], mu["c21"], v2["c_out_pad"])
+        s_in, t_in = v2["post"] if v2["post"] is not None else (ones(v2["c_out_pad"]), torch.zeros(v2["c_out_pad"], device=dev))
+        v2["post"] = (s_in, t_in - mu["c22"])
+        v2["out_shift"] = mu["c22"]
+        # the conv11.conv12 pair: reads c22, writes comp
+        if self.composed is not None:
+            cp = self.composed
+            cp["bias"] = cp["bias"] + corr(cp["_wsum"], mu["c22"], cp["c_out_pad"])
+            # the ring's conv11 multiplies its OWN 16-bit pack; the four edge launches compute three taps each (the other six see the
+            # padding, whose unshifted value is 0): each edge's bias is corrected by exactly the taps it computes
+            w1 = cp["w1m"].view(cp["c_mid_pad"], 9, -1).double()
+            cp["b1_edges"] = [cp["b1"] + corr(w1[:, list(t), :].sum(1), mu["c22"], cp["c_mid_pad"]) for t in K.RING_EDGE_TAPS]
+            cp["b1"] = cp["b1"] + corr(w1.sum(1), mu["c22"], cp["c_mid_pad"])            # (the one-launch nine-tap form)
+            cp["post"] = (ones(cp["c_out_pad"]), -mu["comp"])
+            cp["out_shift"] = mu["comp"]
+        else:
+            od[0]["bias"] = od[0]["bias"] + corr(od[0]["_wsum"], mu["c22"], od[0]["c_out_pad"])
+            od[1]["post"] = (ones(od[1]["c_out_pad"]), -mu["comp"])
+            od[1]["out_shift"] = mu["comp"]
+        # conv21: reads comp; its own output (no ReLU / pool before the store) shifted through the bias
+        od[2]["bias"] = od[2]["bias"] + corr(od[2]["_wsum"], mu["comp"], od[2]["c_out_pad"]) - mu["od21"]
+        od[2]["out_shift"] = mu["od21"]
+        # conv22: reads od21
+        od[3]["bias"] = od[3]["bias"] + corr(od[3]["_wsum"], mu["od21"], od[3]["c_out_pad"])
+        # conv22's and conv31's outputs where they are PLAIN tensors (precision 'fp16' / 'bf16', 'fp16h' at split depth < 3 / < 2; a split
+        # tensor's lo half already carries what a shift would save): conv22 through its post affine, conv31 through its bias
+        if not int(od[3].get("split_out", 0)) and "od4" in cal:
+            mu["od22"] = mu_of("od4", od[3]["c_out"], od[3]["c_out_pad"])
+            od[3]["post"] = (ones(od[3]["c_out_pad"]), -mu["od22"])
+            od[3]["out_shift"] = mu["od22"]
+            od[4]["bias"] = od[4]["bias"] + corr(od[4]["_wsum"], mu["od22"], od[4]["c_out_pad"])
+        if not int(od[4].get("split_out", 0)) and "od5" in cal:
+            mu["od31"] = mu_of("od5", od[4]["c_out"], od[4]["c_out_pad"])
+            od[4]["bias"] = od[4]["bias"] - mu["od31"]
+            od[4]["out_shift"] = mu["od31"]
+            od[5]["bias"] = od[5]["bias"] + corr(od[5]["_wsum"], mu["od31"], od[5]["c_out_pad"])
+        self.shift = mu
+        self._fused_first_shift = v0["tile"] is None
 
     def packs_checksum(self):
         """sha256 over the bytes of packed_tensors() (in order): written into checkpoints (Trainer.extra_state_dict) so that a stem
@@ -493,6 +591,10 @@ class FrozenStem(object):
             wt = K.pack_conv_weight_tiled(w, self.cdt, tile, out_scale=scale, c_out_pad=c_out_pad, c_in_pad=c_in_pad)
         ly = dict(wt=wt, bias=K.pad_vec(b, c_out_pad), relu=relu, pool=pool, post=None,
                   c_out=c_out, c_in=c_in, c_out_pad=c_out_pad, tile=tile)
+        if half and m is not None:
+            # sum over the taps of the 16-bit weights the kernel multiplies with (float64 [c_out, c_in]): what a per-channel constant of
+            # the INPUT contributes to every output — the bias correction of mean-shifted storage (_setup_mean_shift); construction only
+            ly["_wsum"] = w.to(self.cdt).double().sum((2, 3))
         # short-K layers of the VGG front (conv1_2 / conv2_1 / conv2_2 shapes): weights-stationary-in-registers direct conv
         # (csrc/conv_wreg.hip) when the run-time geometry has whole tiles; it reads the K-major row pack
         if half and relu and (c_in_pad, c_out_pad, bool(pool)) in ((64, 64, True), (64, 128, False), (128, 128, True)):
@@ -545,7 +647,8 @@ class FrozenStem(object):
             e[:co, :, :cm] = sel.permute(0, 2, 1)
             return e.view(co_pad, -1).to(dev).to(self.cdt).contiguous()
         edges = dict(top=edge(w2[:, :, 0, :]), bottom=edge(w2[:, :, 2, :]), left=edge(w2[:, :, :, 0]), right=edge(w2[:, :, :, 2]))
-        return dict(wt=wt, bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges,
+        wsum = wcf.to(self.cdt).double().sum((2, 3)) if half else None
+        return dict(wt=wt, bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges, _wsum=wsum,
                     w1_edges=K.ring_edge_weights(w1m.view(cm_pad, 9, ci_pad)),
                     c_in=ci, c_out=co, c_out_pad=co_pad, c_mid_pad=cm_pad, tile=tile, taps=25)
 
@@ -563,7 +666,7 @@ class FrozenStem(object):
         # (edge by edge with the three taps that can see the image: a third of the one-launch form's K, whose other products are against
         # the zero halo; RING_EDGE_LAUNCHES = False runs that form: the same bits)
         if RING_EDGE_LAUNCHES:
-            K.conv2d_ring_edges(x, cp["w1_edges"], cp["b1"], H, W, y1p)
+            K.conv2d_ring_edges(x, cp["w1_edges"], cp.get("b1_edges", cp["b1"]), H, W, y1p)
         else:
             K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W, out_padded=y1p)
         part = [K.ring_edge_conv(y1p, cp["edges"][name], H, W, e) for e, name in enumerate(("top", "bottom", "left", "right"))]
@@ -571,7 +674,9 @@ class FrozenStem(object):
         ho, wo = H // 2, W // 2
         # precision 'fp16h' at split depth 5: the pair's output as a split tensor (the igemm tile's fp32 dual epilogue), conv21 reads it
         dual = self.split_segs if (self.split_depth >= 5 and cp["tile"] == L.TILE_STEM_256x256 and "wt_split" in self.layers_od[2]) else 0
-        out = self._buf(key + (ho, wo) + (("split",) if dual else ()), (n, ho + 2, wo + 2, max(dual, 1) * cp["c_out_pad"]))
+        out = self._buf(key + (ho, wo) + (("split",) if dual else ()), (n, ho + 2, wo + 2, max(dual, 1) * cp["c_out_pad"]),
+                        halo=(1, cp.get("out_shift")))
+        post = cp.get("post")      # mean-shifted storage: -mu after ReLU / pool, in fp32 before the ONE rounding (the tile's fp32 epilogue)
         timed = self.timing is not None and cp["tile"] == L.TILE_STEM_256x256
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -579,7 +684,9 @@ class FrozenStem(object):
         # every XCD computes ONE cout half of the composed conv (its L2 then holds 1.65 instead of 3.3 MB of weights): fabric-side reads
         # 1 022 -> 831 MB per launch (profiles/r04_pmc_traffic*.json), time unchanged
         y = K.conv2d_igemm(x, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out, tile=cp["tile"],
-                           border_sub=ring, desc_flags=L.CONV_XCD_SPLIT_N if L.is_half(self.cdt) else 0, dual_out=dual)
+                           border_sub=ring, desc_flags=L.CONV_XCD_SPLIT_N if L.is_half(self.cdt) else 0, dual_out=dual,
+                           post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+                           f32_epilogue=bool(post) and not dual and cp["tile"] == L.TILE_STEM_256x256)
         if timed:
             ev1.record()
             self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25, "conv_igemm_kernel"))
@@ -597,13 +704,23 @@ class FrozenStem(object):
             t = self._bufs[key] = torch.zeros(2, dtype=torch.int32, device="cuda")
         return t
 
-    def _buf(self, key, shape, dtype=None):
-        """Persistent zero-halo activation buffer, grown (never shrunk) along the image axis."""
+    def _buf(self, key, shape, dtype=None, halo=None):
+        """Persistent zero-halo activation buffer, grown (never shrunk) along the image axis.  halo = (width, mu): a MEAN-SHIFTED
+        tensor's buffer — its halo ring holds -mu[c] in the first len(mu) channels (what the zero padding becomes; further channel
+        segments — the lo half of a split tensor — stay zero), written once here: no kernel ever writes a stem buffer's halo."""
         dtype = self.cdt if dtype is None else dtype
         key = key + (str(dtype),) if dtype != self.cdt else key
         cap = self._bufs.get(key)
         if cap is None or cap.shape[0] < shape[0] or tuple(cap.shape[1:]) != tuple(shape[1:]):
             cap = torch.zeros(shape, dtype=dtype, device="cuda")
+            if halo is not None and halo[1] is not None and float(halo[1].abs().max()) > 0:
+                hw, mu = int(halo[0]), halo[1]
+                v = (-mu).to(dtype)
+                c = v.numel()
+                cap[:, :hw, :, :c] = v
+                cap[:, -hw:, :, :c] = v
+                cap[:, :, :hw, :c] = v
+                cap[:, :, -hw:, :c] = v
             self._bufs[key] = cap
         return cap[:shape[0]]
 
@@ -621,7 +738,8 @@ class FrozenStem(object):
             x_segs = x.shape[-1] // ly["c_out_pad"] if split_rd else 1      # (c_in == c_out on the split-reading layers)
             if split_wr and not (yh == 1 and (split_rd or "wt_split" not in ly)):      # (a split-reading layer handed a plain tensor: the chain is off)
                 split_wr = 0
-            out = self._buf(key + (("split",) if split_wr else ()), (n, ho + 2 * yh, wo + 2 * yh, max(split_wr, 1) * ly["c_out_pad"]))
+            out = self._buf(key + (("split",) if split_wr else ()), (n, ho + 2 * yh, wo + 2 * yh, max(split_wr, 1) * ly["c_out_pad"]),
+                            halo=(yh, ly.get("out_shift")))
             post = ly["post"]
             ps, pt = (post[0], post[1]) if post else (None, None)
             tile = ly["tile"]
@@ -644,15 +762,19 @@ class FrozenStem(object):
                                   out=out, y_halo=yh, reserve_cus=self.reserve_cus)
             elif "wt_ps" in ly and yh == 1 and K.conv_ps_supported(n, h, w, x.shape[-1], ly["c_out_pad"], 9, ly["pool"]):
                 kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)      # (one entry per kernel SYMBOL, as rocprofv3 lists them)
+                # (a mean-shifted output with ReLU / pool before the shift: the fp32 epilogue, ONE rounding after the affine)
                 x = K.conv2d_igemm(x, ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"], post_scale=ps, post_shift=pt,
-                                   out=out, tile=L.TILE_STEM_PS_224x256, y_halo=yh)
+                                   out=out, tile=L.TILE_STEM_PS_224x256, y_halo=yh,
+                                   f32_epilogue=post is not None and ly.get("out_shift") is not None)
             elif tile is None:
                 # C_in = 64 layers (conv1_2, conv2_1): persistent direct conv with LDS-resident weights
                 x = K.conv2d_c64(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"], post_scale=ps, post_shift=pt, out=out,
                                  reserve_cus=self.reserve_cus)
             else:
                 x = K.conv2d_igemm(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"], post_scale=ps, post_shift=pt,
-                                   out=out, tile=tile, y_halo=yh)
+                                   out=out, tile=tile, y_halo=yh,
+                                   f32_epilogue=(post is not None and ly.get("out_shift") is not None and yh == 1
+                                                 and tile == L.TILE_STEM_256x256 and ly["c_out_pad"] % 8 == 0))
             if timed:
                 ev1.record()
                 self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9 * (x_segs if split_rd else 1), kname))
@@ -674,14 +796,17 @@ class FrozenStem(object):
         if L.is_half(self.cdt) and ly["tile"] is None:
             # conv1_1 evaluated inside the conv1_2 kernel from a 4-channel 16-bit image list: its 64-channel output
             # (1.8 GB at 280 x 224 x 224) never goes to HBM
-            img4 = self._buf(("img4", H, W), (n_img, H + 4, W + 4, 4))
-            K.clip_to_nhwc4(clip, img_of, n_img, out=img4)
+            mu_clip = self.shift.get("clip") if getattr(self, "_fused_first_shift", False) else None
+            img4 = self._buf(("img4", H, W), (n_img, H + 4, W + 4, 4), halo=(2, mu_clip[:3] if mu_clip is not None else None))
+            K.clip_to_nhwc4(clip, img_of, n_img, out=img4, shift=mu_clip)
             ho, wo = (H // 2, W // 2) if ly["pool"] else (H, W)
-            out = self._buf(("vgg", 0, ho, wo), (n_img, ho + 2, wo + 2, ly["c_out_pad"]))
+            out = self._buf(("vgg", 0, ho, wo), (n_img, ho + 2, wo + 2, ly["c_out_pad"]), halo=(1, ly.get("out_shift")))
             post = ly["post"]
-            K.conv_first_c64(img4, self.first[0], self.first[1], ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
+            mid = self.shift.get("c11") if getattr(self, "_fused_first_shift", False) else None
+            K.conv_first_c64(img4, self.first[0], self._b1_pair if mid is not None else self.first[1], ly["wt"], bias=ly["bias"],
+                             relu=ly["relu"], pool2=ly["pool"],
                              post_scale=post[0] if post else None, post_shift=post[1] if post else None, out=out,
-                             reserve_cus=self.reserve_cus, sched=self._c64_sched())
+                             reserve_cus=self.reserve_cus, sched=self._c64_sched(), mid_shift=mid)
             x = self._run(out, self.layers_vgg[1:], "vgg", first_index=1)
         else:
             if clip.dtype == torch.uint8:        # raw pixels: the un-fused first conv reads the fp32 clip

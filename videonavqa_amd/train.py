@@ -303,7 +303,9 @@ class Trainer(object):
                 warnings.warn("stem CU reservation unavailable (%s): the stem runs on an ordinary stream" % e)
                 self.stem_reserve_cus = 0
         if self.stem_reserve_cus == 0:
-            self.stem_stream = torch.cuda.Stream(priority=prio)
+            # (host tensors — the gloo tests of the data-parallel host logic, tests/test_dp_gloo.py — have no streams: the step's
+            # device-independent half, _reduce_and_update, is all such a Trainer runs)
+            self.stem_stream = torch.cuda.Stream(priority=prio) if self.fp.flat.is_cuda else None
         elif stem is not None:
             # the persistent conv kernels size their grids for the masked stream's CUs: a per-call descriptor field of THIS stem
             stem.reserve_cus = max(int(getattr(stem, "reserve_cus", 0)), self.stem_reserve_cus)
@@ -329,12 +331,10 @@ class Trainer(object):
         self._inputs_ready = None        # recorded on the CALLER's stream at step() entry: clips / labels produced so far
         # fp16 storage: dynamic loss scale (VNQA_FP16_LOSS_SCALE=<value> pins it: no adjustment, the round-2/3 behaviour)
         # Every precision gets the device-side skip of a non-finite step and its counter; only fp16 STORAGE has a loss scale.
-        self.loss_scaler = None
-        if self.fp.flat.is_cuda:
-            pinned = os.environ.get("VNQA_FP16_LOSS_SCALE")
-            self.loss_scaler = DynamicLossScale(self.fp.flat.device, init=float(pinned) if pinned else None,
-                                                growth_interval=(1 << 62) if pinned else 200,
-                                                applies=getattr(model, "compute_dtype", None) == torch.float16)
+        pinned = os.environ.get("VNQA_FP16_LOSS_SCALE")
+        self.loss_scaler = DynamicLossScale(self.fp.flat.device, init=float(pinned) if pinned else None,
+                                            growth_interval=(1 << 62) if pinned else 200,
+                                            applies=getattr(model, "compute_dtype", None) == torch.float16)
         self._in_step = False            # prefetch() called from inside step() (current stream = the trunk stream) or by the caller
         self._inline_stem_done = None    # event after a stem pass that ran INLINE on the trunk / caller's stream (shared buffers)
 
@@ -567,6 +567,22 @@ class Trainer(object):
         self._trunk_done[self._slot] = ev
         return loss.detach(), logits, perm_d
 
+    def _reduce_and_update(self):
+        """The device-independent second half of a step, after backward: finish the gradient all-reduce (the early slices are already
+        in flight), clamp (MACNetwork), global-norm clip + Adam + zero_grad with the device-side skip of a non-finite step, then the
+        lagged loss-scale observation.  Runs unchanged on host tensors over gloo (tests/test_dp_gloo.py: 4 and 8 ranks) with
+        FlatParams.clip_adam_step's HIP launch replaced by its restatement."""
+        with phase("allreduce"):
+            self.reducer.finish()
+        with phase("optimizer"):
+            clamp = getattr(self.model, "grad_clamp", None)
+            if clamp:    # MACNetwork: per-parameter gradient clamp hooks (eval/q_and_v_eval.py:348-351), on the reduced gradient
+                self.fp.grad.clamp_(-clamp, clamp)
+            self.fp.clip_adam_step(self.lr, self.clip,        # (the kernel zeroes the gradient buffer; the sinks are reset with it)
+                                   overflow_count=None if self.loss_scaler is None else self.loss_scaler.count)
+        if self.loss_scaler is not None:      # (updates skipped on the device are taken off Adam's step count ON the device)
+            self.loss_scaler.after_step()
+
     def _step(self, clip, q_input, v_lens_cpu, q_lens_cpu, ys, next_clip=None, next_v_lens_cpu=None):
         """One optimisation step.  v_lens_cpu / q_lens_cpu are host int64 tensors (as a DataLoader
         delivers them); clip, q_input, ys are on the GPU.  If `next_clip` is given, its stem is
@@ -586,16 +602,7 @@ class Trainer(object):
             loss = ops.cross_entropy(logits, ys, row_perm=perm_d, weight=self.class_weights, reduction=self.loss_reduction)
         with phase("backward"):
             loss.backward()
-        with phase("allreduce"):
-            self.reducer.finish()
-        with phase("optimizer"):
-            clamp = getattr(self.model, "grad_clamp", None)
-            if clamp:    # MACNetwork: per-parameter gradient clamp hooks (eval/q_and_v_eval.py:348-351), on the reduced gradient
-                self.fp.grad.clamp_(-clamp, clamp)
-            self.fp.clip_adam_step(self.lr, self.clip,        # (the kernel zeroes the gradient buffer; the sinks are reset with it)
-                                   overflow_count=None if self.loss_scaler is None else self.loss_scaler.count)
-        if self.loss_scaler is not None:      # (updates skipped on the device are taken off Adam's step count ON the device)
-            self.loss_scaler.after_step()
+        self._reduce_and_update()
         ev = torch.cuda.Event()
         ev.record(main)
         self._trunk_done[self._slot] = ev
