@@ -108,7 +108,8 @@ def build(args, device):
                                                num_res_block_channels=args.channels, spatial_size=S, precision=mprec,
                                                **({"num_tail_channels": args.tail_channels} if getattr(args, "tail_channels", 0) else {}))
     vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
-    stem = FrozenStem(vgg, od, prec, split_features=args.model != "mac")
+    # (args.calibration: frames [N, 3, H, W] of the deployment's kind for the stem's weight rounding and channel means — tests / tools)
+    stem = FrozenStem(vgg, od, prec, calibration=getattr(args, "calibration", "auto"), split_features=args.model != "mac")
     COMPOSED_STEM[0] = stem.composed is not None
     return model, stem, vgg, od
 
@@ -498,7 +499,7 @@ def oracle_full_size(args, device, dump_path):
         v_sorted, perm = torch.sort(v_lens, dim=0, descending=True, stable=True)
         lay = FrameLayout(v_sorted, args.frames, device, perm=perm)
         feats = stem.forward_clip(clip.to(device), lay.img_of, lay.n_img)
-        native = NativeFeatures(feats, lay, 512, args.height // 16, args.width // 16)
+        native = NativeFeatures(feats, lay, 512, args.height // 16, args.width // 16, segs=stem.feature_segs, shift=stem.feature_shift)
         model.train()
         model.init_hidden()
         with torch.no_grad():

@@ -103,7 +103,13 @@ typedef struct vnqa_conv_desc {
 #define VNQA_CONV_F32_EPILOGUE 0x80000 /* ONE plain 16-bit output whose bias / border correction / ReLU / 2x2 max-pool / affine are all applied in
                                    * fp32 and rounded ONCE (the plain epilogues of the LDS-staged tiles round to storage before the affine and again
                                    * after it): the dual epilogue's hi half alone.  Tiles and restrictions of VNQA_CONV_DUAL_OUT.  Round 6:
-                                   * mean-shifted storage (post_shift = -mean) needs the single rounding to pay */
+                                   * mean-shifted storage (post_shift = -mean) needs the single rounding to pay.  | VNQA_CONV_DUAL_HI2: the value
+                                   * is written TWICE, y = [v | v] (c_y >= 2 c_out) — the operand of a consumer that is a plain conv over 2 c_out
+                                   * channels against SPLIT weights [w_hi | w_lo]: x w_hi + x w_lo without reading x twice along K */
+#define VNQA_CONV_RELU_FLOOR 0x200000 /* stem-tagged 256x256 implicit-GEMM tile with ReLU: post_shift[c] (post_scale == NULL) is the per-channel FLOOR
+                                   * of the ReLU instead of 0 — relu(a) - mean = max(a - mean, -mean): with the caller's bias carrying -mean_c and
+                                   * floor = -mean_c the tile stores a mean-shifted output with ONE rounding through its ordinary 16-bit epilogue
+                                   * (the pooled maximum of rounded values is the rounded maximum), at no cost: the composed 5x5 conv */
 #define VNQA_CONV_FIRST_MID_SHIFT 0x100000 /* vnqa_conv_first_c64_fwd[_sched]: b1 has 128 entries [bias (64) | mu (64)] — the first conv's
                                    * output is kept (in LDS) as relu(.) - mu[c], and as -mu[c] where it is the second conv's zero padding; the
                                    * caller adds sum_taps(W2 mu) to the second conv's bias.  Wide (default) kernel only */

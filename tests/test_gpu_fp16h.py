@@ -23,6 +23,17 @@ pytestmark = [pytest.mark.gpu,
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
+@pytest.fixture
+def no_mean_shift():
+    """The stem WITHOUT mean-shifted storage (round 6's default for calibrated 16-bit stems): the round-5 forms — split tensors between
+    conv22 / conv31 / conv32, [hi | lo | hi] features — stay supported (calibrations without channel means, VNQA_MEAN_SHIFT=0) and tested."""
+    from videonavqa_amd import stem as S
+    old = S.MEAN_SHIFT
+    S.MEAN_SHIFT = 0
+    yield
+    S.MEAN_SHIFT = old
+
+
 def _padded(n, h, w, c, seed, scale=1.0, positive=False):
     g = torch.Generator().manual_seed(seed)
     x = torch.zeros(n, h + 2, w + 2, c)
@@ -391,7 +402,7 @@ def _random_stem(prec):
     return vgg.cuda().eval(), od.cuda().eval()
 
 
-def test_fp16h_stem_split_features_are_closer_to_exact_than_the_fp16_stem():
+def test_fp16h_stem_split_features_are_closer_to_exact_than_the_fp16_stem(no_mean_shift):
     """The frozen stem at 224 x 224 (the geometry whose 28 x 28 / 14 x 14 maps the pair path serves): pair features (hi + lo) against
     the exact-f32 stem are closer than the fp16 stem's, the hi half is a valid fp16 feature tensor, and with split_features=False
     (consumers that read no pairs) the output is a plain tensor of the usual shape.  At 160 x 208 (10 x 13 maps: not served by the
@@ -453,7 +464,7 @@ def test_second_order_round_kernel_matches_the_tensor_recursion():
     assert float((q_dev - w).abs().max()) < 8 * float(w.abs().max()) * 2.0 ** -10
 
 
-def test_second_order_rounded_stem_weights_and_their_reproduction_from_a_checkpoint_calibration():
+def test_second_order_rounded_stem_weights_and_their_reproduction_from_a_checkpoint_calibration(no_mean_shift):
     """The default calibration: stem.second_order_round against the patch second moments of CALIBRATION_FRAMES noise frames.
     (a) the features of precision 'fp16' (every error of that stem is an activation or a weight rounding) are closer to the exact-f32
     stem's than with round-to-nearest weights, on frames unlike the calibration frames too; (b) a stem rebuilt from the calibration
@@ -535,7 +546,7 @@ def test_calibration_means_match_a_torch_fp32_pass():
     torch.set_grad_enabled(True)
 
 
-def test_coherent_rounding_removes_the_per_channel_offset_of_the_fp16_stem():
+def test_coherent_rounding_removes_the_per_channel_offset_of_the_fp16_stem(no_mean_shift):
     """The fp16-storage stem with coherently rounded weights (calibration on noise frames) against round-to-nearest, both compared
     with the exact-f32 stem on a DIFFERENT clip: the per-channel mean of the feature error (what pooling cannot average away) drops
     by more than 2x; the weights differ in a few percent of the entries only."""
@@ -586,16 +597,18 @@ def _budget_mod():
     return m
 
 
-def _full_size_errors(seed, data, batches=12):
+def _full_size_errors(seed, data, batches=12, height=224, width=224, calibration="auto", model="film_attn_pt", frames=35):
     bm = _budget_mod()
-    args = argparse.Namespace(precision="fp32", model="film_attn_pt", batch=8, frames=35, height=224, width=224, blocks=1, channels=512,
-                              tail_channels=0, seed=seed)
+    args = argparse.Namespace(precision="fp32", model=model, batch=8, frames=frames, height=height, width=width, blocks=1, channels=512,
+                              tail_channels=0, seed=seed, calibration=calibration)
     dev = torch.device("cuda", 0)
     d = bm.batches(args, dev, batches, data)
     ref = bm.run(args, "fp32", dev, d)
     got = bm.run(args, "fp16h", dev, d)
     rel = [float((a - b).abs().max() / b.abs().max()) for a, b in zip(got, ref)]
     flips = sum(int((a.argmax(1) != b.argmax(1)).sum()) for a, b in zip(got, ref))
+    print("fp16h vs fp32, weight seed %d, %s clips, %dx%d, %s: max %.3e rms %.3e" %
+          (seed, data, height, width, model, max(rel), (sum(r * r for r in rel) / len(rel)) ** 0.5))
     return rel, flips
 
 
@@ -603,23 +616,49 @@ def _full_size_errors(seed, data, batches=12):
 def test_fp16h_meets_1e3_on_twelve_full_size_minibatches_for_every_weight_seed(seed):
     """North star's tolerance as stated (logits within 1e-3 of the reference forward, answer classes equal) at BASELINE.json's size:
     precision 'fp16h' against the exact-f32 precision (itself pinned to the oracle at this size, tests/test_gpu_fullsize.py) on twelve
-    seeded minibatches (one full-length, eleven ragged) for FOUR sets of random weights — VERDICT r4 #1: the round-4 tolerance mode
-    read 1.04e-3 on (seed 3, minibatch 9)."""
+    seeded minibatches (one full-length, eleven ragged) for FOUR sets of random weights.  Round 6 (mean-shifted storage): measured
+    0.36 - 0.47e-3 (round 5: 0.67 - 0.89e-3)."""
     rel, flips = _full_size_errors(seed, "noise")
     assert max(rel) <= 1e-3, (seed, ["%.2e" % r for r in rel])
     assert flips == 0, (seed, flips)
 
 
-@pytest.mark.parametrize("data", ["smooth", "blocks"])
-def test_fp16h_meets_1e3_on_data_that_does_not_look_like_the_calibration_frames(data):
-    """The stem's weights are rounded against seeded SYNTHETIC frames, half uniform noise and half smooth.  'smooth' clips (14 x 14 noise
-    upsampled 16 x, per-clip brightness, slow drift) share only the kind with that second half; 'blocks' clips (piecewise-constant
-    images: a background and 24 drifting rectangles) are like NEITHER half — the held-out kind."""
-    rel, flips = _full_size_errors(0, data)
-    # ('blocks' is a stress kind: large flat regions make the rounding errors of the stored activations coherent over pixels — the logits
-    # error is 1.4 x the noise clips'; measured 0.96e-3 with these weights, 1.08e-3 with weight seed 3: stated 1.1e-3, not the tolerance)
-    assert max(rel) <= (1.1e-3 if data == "blocks" else 1e-3), ["%.2e" % r for r in rel]
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_fp16h_meets_1e3_at_the_reference_geometry_160x208(seed):
+    """... and at the reference's ONLY real geometry (eval/utils.py:24-25: 160 x 208 frames -> 10 x 13 maps; the hard-coded 130 of
+    models/film_attn_pt_stem.py:56): rounds 4-5 silently ran plain fp16 here (1.44e-3 on weight seed 3).  Measured 0.27 - 0.52e-3."""
+    rel, flips = _full_size_errors(seed, "noise", height=160, width=208)
+    assert max(rel) <= 1e-3, (seed, ["%.2e" % r for r in rel])
+    assert flips == 0, (seed, flips)
+
+
+@pytest.mark.parametrize("data,seed", [("smooth", 0), ("blocks", 0), ("blocks", 1), ("blocks", 2), ("blocks", 3), ("textured", 3)])
+def test_fp16h_meets_1e3_on_data_that_does_not_look_like_the_calibration_frames(data, seed):
+    """The stem's weights and channel means come from seeded SYNTHETIC frames, half uniform noise and half smooth.  'smooth' clips share only
+    the kind with that second half; 'blocks' (piecewise-constant images: a background and 24 drifting rectangles, near-identical frames)
+    and 'textured' (flat regions x static texture x illumination ramp) are held-out kinds.  Round 5 read 0.96 - 1.18e-3 on 'blocks' (its
+    test stated 1.1e-3); the cause was not coherence but the rounding of large per-channel means — with mean-shifted
+    storage: 0.46 - 0.55e-3, asserted at the tolerance itself on all four weight seeds."""
+    rel, flips = _full_size_errors(seed, data, batches=8)
+    assert max(rel) <= 1e-3, (data, seed, ["%.2e" % r for r in rel])
     assert flips == 0
+
+
+def test_stem_calibration_on_the_deployments_own_frames_is_measured():
+    """`--stem_calibration data` / `FrozenStem(calibration=frames)` (only 'it runs' was tested): calibrating the weight rounding
+    and the channel means on 40 frames of the DEPLOYMENT's kind (here: 'blocks' clips of other seeds) keeps the held-out kind inside the
+    tolerance and is not worse than the synthetic default by more than sampling noise."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    g = torch.Generator().manual_seed(4711)
+    clip = bench.blocks_clip(5, 8, 224, 224, g)                               # [5, 3, H, W, 8]: other clips than the test's minibatches
+    frames = clip.permute(0, 4, 1, 2, 3).reshape(-1, 3, 224, 224)[:40].contiguous()
+    rel_d, flips_d = _full_size_errors(3, "blocks", batches=6, calibration=frames)
+    rel_n, _ = _full_size_errors(3, "blocks", batches=6)
+    assert max(rel_d) <= 1e-3 and flips_d == 0, ["%.2e" % r for r in rel_d]
+    rms = lambda r: (sum(x * x for x in r) / len(r)) ** 0.5
+    assert rms(rel_d) <= 1.25 * rms(rel_n), (rms(rel_d), rms(rel_n))
 
 
 def test_f32_epilogue_rounds_once_after_the_affine():
@@ -676,8 +715,10 @@ def test_mean_shifted_storage_is_exact_algebra_and_lowers_the_stem_error():
             assert on.shift and not off.shift and float(on.shift["c22"].abs().max()) > 0
             for kind, clip in clips.items():
                 r = ref.forward_clip(clip, lay.img_of, lay.n_img).double()[:, 1:-1, 1:-1, :512]
-                a = on.forward_clip(clip, lay.img_of, lay.n_img).double()[:, 1:-1, 1:-1]
-                b = off.forward_clip(clip, lay.img_of, lay.n_img).double()[:, 1:-1, 1:-1]
+                fa = on.forward_clip(clip, lay.img_of, lay.n_img)
+                assert on.feature_shift is not None and fa.shape[-1] == 512 and off.feature_shift is None
+                a = on.plain_features(fa).double()[:, 1:-1, 1:-1, :512]
+                b = off.plain_features(off.forward_clip(clip, lay.img_of, lay.n_img)).double()[:, 1:-1, 1:-1, :512]
                 scale = float(r.abs().max())
                 e_on, e_off = float((a - r).pow(2).mean().sqrt()), float((b - r).pow(2).mean().sqrt())
                 # exact algebra: both within a few storage roundings of the exact stem EVERYWHERE (a wrong border / ring / halo term would

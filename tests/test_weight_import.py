@@ -105,7 +105,7 @@ def test_stem_from_imported_files_vs_oracle(tmp_path, precision):
     lay = FrameLayout([2, 1], T, "cuda")
     feats = stem.forward_clip(clip.cuda(), lay.img_of, lay.n_img)
     assert feats.shape == (3, 12, 15, 512)
-    got = K.nhwc_to_nchw(feats, 512).cpu()
+    got = stem.plain_features(feats)[:, 1:-1, 1:-1, :512].permute(0, 3, 1, 2).cpu()
     W_vgg = {k: v for k, v in vsd.items() if k.startswith("features.")}
     ref = O.stem_forward(clip, W_vgg, {k: v.float() for k, v in osd.items()})          # [B,512,10,13,T]
     tol = 1e-4 if precision == "fp32" else 4e-2

@@ -51,13 +51,10 @@ def main():
         clip, q, v_lens, q_lens, y = batch
         native, v_sorted, perm = tr[stem_prec].extract_features(clip, v_lens)
         cdt = torch.float32 if trunk_prec == "fp32" else (torch.float16 if a.low in ("fp16", "fp16h") else torch.bfloat16)
-        data = native.data
-        if data.shape[-1] == 3 * 512 and (trunk_prec == "fp32" or stem_prec == "fp32"):      # split features into another precision's trunk: hi + lo
-            data = data[..., :512].float() + data[..., 512:1024].float()
-        if stem_prec == "fp32" and trunk_prec == "fp16h":      # exact features into the split-reading trunk: [hi | lo | hi]
-            hi = data.half()
-            data = torch.cat([hi, (data - hi.float()).half(), hi], dim=-1).contiguous()
-        native = NativeFeatures(data.to(cdt).contiguous(), native.layout, native.channels, native.h, native.w)
+        data, shift = native.data, native.shift
+        if trunk_prec != stem_prec:      # another precision's trunk reads PLAIN features (split: hi + lo; mean-shifted: value + shift)
+            data, shift = tr[stem_prec].stem.plain_features(data), None
+        native = NativeFeatures(data.to(cdt).contiguous(), native.layout, native.channels, native.h, native.w, shift=shift)
         m = tr[trunk_prec].model
         m.init_hidden()
         with torch.no_grad():
@@ -69,6 +66,7 @@ def main():
         row = {}
         for name, (sp, tp) in dict(B=(a.low, a.low), C=("fp32", a.low), D=(a.low, "fp32")).items():
             lg, f = logits(sp, tp, batch)
+            f = f[..., :512]
             row[name] = round(float((lg - ref).abs().max() / ref.abs().max()), 6)
             if name == "D":
                 row["stem_feat_rel_l2"] = round(float((f - fref).norm() / fref.norm()), 6)

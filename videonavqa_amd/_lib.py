@@ -58,6 +58,7 @@ CONV_X_WRAP2 = 4
 CONV_DUAL_OUT = 0x20000  # y = [h16(v) | h16(v - h16(v))], 2 c_out channels (patch-stationary tiles)
 CONV_DUAL_HI2 = 0x40000  # with CONV_DUAL_OUT: y = [hi | lo | hi], 3 c_out channels (a three-product consumer's operand)
 CONV_F32_EPILOGUE = 0x80000      # one plain output, pool / affine in fp32, rounded once
+CONV_RELU_FLOOR = 0x200000       # stem 256x256 tile: post_shift (no post_scale) = per-channel ReLU floor (mean-shifted output, one rounding)
 CONV_FIRST_MID_SHIFT = 0x100000  # vnqa_conv_first_c64_fwd: b1 = [bias | shift of the first conv's stored output]
 LAYOUT_MAX_BATCH = 256     # vnqa_frame_layout: VNQA_LAYOUT_MAX_BATCH
 GEMM_X_WRAP2 = 0x400

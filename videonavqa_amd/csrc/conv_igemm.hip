@@ -711,7 +711,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
 #pragma unroll
         for (int e = 0; e < 4; ++e) hw[e] = pack2_h16(v[2 * e], v[2 * e + 1]);
         *(uint4*)dst = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        if constexpr (TAG == 6) continue;      // VNQA_CONV_F32_EPILOGUE: ONE plain 16-bit output, rounded once after pool / affine in fp32
+        if constexpr (TAG == 6) {              // VNQA_CONV_F32_EPILOGUE: ONE 16-bit value, rounded once after pool / affine in fp32 ...
+          if (p.dual_out == 9) *(uint4*)(dst + p.Cout) = make_uint4(hw[0], hw[1], hw[2], hw[3]);      // ... | VNQA_CONV_DUAL_HI2: written TWICE, [v | v]
+          continue;
+        }
         unsigned lw[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) lw[e] = pack2_h16(v[2 * e] - h16_lo(hw[e]), v[2 * e + 1] - h16_hi(hw[e]));
@@ -804,9 +807,28 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       for (int g = 0; g < NG; ++g) {
         const int col = col_of(j, g);  // tile-local cout of e=0
         float v[4];
+        if constexpr (TAG == 1) {
+          // stem launches: the ReLU floor is PER CHANNEL — 0, or -mean_c for a mean-shifted output (post_shift without post_scale; the
+          // caller's bias already carries -mean_c): relu(a) - mean = max(a - mean, -mean), rounded ONCE into the staged tile; the
+          // 2x2 max-pool of the rounded values is the rounding of the pooled one (monotone).  No fp32 staging needed (TAG 6: +0.14 ms).
+          float fl[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.post_scale == nullptr && p.post_shift != nullptr) {
+            const int co = tile_n * BN + col;
+            if (co + 3 < p.Cout) {
+              const float4 f4 = *(const float4*)(p.post_shift + co);
+              fl[0] = f4.x; fl[1] = f4.y; fl[2] = f4.z; fl[3] = f4.w;
+            }
+          }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = vnqa_conv_act<TAG>(acc[i][j][4 * g + e] + bias_r[j][g][e] - sub[j][g][e], p.relu);
+          for (int e = 0; e < 4; ++e) {
+            const float a = acc[i][j][4 * g + e] + bias_r[j][g][e] - sub[j][g][e];
+            v[e] = p.relu ? fmaxf(a, fl[e]) : a;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = vnqa_conv_act<TAG>(acc[i][j][4 * g + e] + bias_r[j][g][e] - sub[j][g][e], p.relu);
+          }
         }
         char* dst = smem + prow * CROW + col * ES;
         if constexpr (ES == 2) {
@@ -1162,7 +1184,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
   if (a.dual_out && tile != VNQA_TILE_PS_224x256 && tile != VNQA_TILE_STEM_PS_224x256) {
     // [hi | lo (| hi)] / (hi, lo) output on the implicit-GEMM tile: the TAG 5 instantiation of the 256 x 256 tile (fp32 epilogue)
     if (dtype != VNQA_BF16 || a.epi != VNQA_EPI_NONE || a.D != 0 || a.ring_h != 0 || a.partial != nullptr || a.group_tiles != 0 ||
-        a.zero_halo || a.x_wrap2 || a.relu == VNQA_ACT_ELU || a.Cout % 8 != 0 || a.Cy < ((a.dual_out == 4 || a.dual_out == 8) ? 1 : a.dual_out + 1) * a.Cout ||
+        a.zero_halo || a.x_wrap2 || a.relu == VNQA_ACT_ELU || a.Cout % 8 != 0 || a.Cy < ((a.dual_out == 4 || a.dual_out == 8) ? 1 : (a.dual_out == 9 ? 2 : a.dual_out + 1)) * a.Cout ||
         (a.dual_out == 4 && a.y2 == nullptr) || (a.pool && (a.H % 2 != 0 || a.W % 2 != 0))) {
       vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT on the implicit-GEMM tile needs a plain 16-bit 2-D conv (no fused epilogue / "
                      "split-K / halo zeroing / wrap), c_out %% 8 == 0 and c_y >= 2 c_out (3 c_out with VNQA_CONV_DUAL_HI2)");
@@ -1172,7 +1194,7 @@ int conv_dispatch(const ConvArgs& a, int dtype, int tile, hipStream_t st) {
       vnqa_set_error("conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT is served by the patch-stationary tiles and the 256x256 tiles (got tile %d)", tile);
       return VNQA_ERR_UNSUPPORTED;
     }
-    return a.dual_out == 8 ? launch<vnqa_bf16, 256, 256, 2, 4, 6>(a, st) : launch<vnqa_bf16, 256, 256, 2, 4, 5>(a, st);
+    return a.dual_out >= 8 ? launch<vnqa_bf16, 256, 256, 2, 4, 6>(a, st) : launch<vnqa_bf16, 256, 256, 2, 4, 5>(a, st);
   }
   if (a.relu == VNQA_ACT_ELU) {        // own instantiations of the plain tiles (conv_args.h: why not a runtime branch)
     if (a.epi != VNQA_EPI_NONE || a.partial != nullptr || a.pool) {
@@ -1519,7 +1541,14 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
                  "conv2d_igemm_fwd: border_sub needs a 2-D conv over images of at least 2x2");
   VNQA_CHECK_ARG(border_sub == nullptr || d->c_out % 4 == 0, "conv2d_igemm_fwd: border_sub needs c_out % 4 == 0");
   VNQA_CHECK_ARG(!d->pool2 || (d->h % 2 == 0 && d->w % 2 == 0), "conv2d_igemm_fwd: pool2 needs even h,w");
-  VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv2d_igemm_fwd: post_scale/post_shift must come together");
+  if (d->flags & VNQA_CONV_RELU_FLOOR) {
+    VNQA_CHECK_ARG(post_scale == nullptr && post_shift != nullptr && d->tile == VNQA_TILE_STEM_256x256 && d->relu == 1 && d->c_out % 4 == 0 &&
+                       !(d->flags & (VNQA_CONV_DUAL_OUT | VNQA_CONV_F32_EPILOGUE)),
+                   "conv2d_igemm_fwd: VNQA_CONV_RELU_FLOOR takes post_shift (the per-channel floor) WITHOUT post_scale on the stem-tagged "
+                   "256x256 tile with ReLU, c_out %% 4 == 0, plain epilogue");
+  } else {
+    VNQA_CHECK_ARG((post_scale == nullptr) == (post_shift == nullptr), "conv2d_igemm_fwd: post_scale/post_shift must come together");
+  }
   VNQA_CHECK_ARG((long long)d->n_img * (d->depth > 0 ? d->depth : 1) * d->h * d->w < (1ll << 31), "conv2d_igemm_fwd: too many pixels");
 
   a.x = (const char*)x;
@@ -1547,7 +1576,8 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
   a.zero_halo = (d->flags & VNQA_CONV_ZERO_HALO) ? 1 : 0;
   a.xcd_split = (d->flags & VNQA_CONV_XCD_SPLIT_N) ? 1 : 0;
   a.x_wrap2 = (d->flags & VNQA_CONV_X_WRAP2) ? 1 : 0;
-  a.dual_out = (d->flags & VNQA_CONV_DUAL_OUT) ? ((d->flags & VNQA_CONV_DUAL_HI2) ? 2 : 1) : ((d->flags & VNQA_CONV_F32_EPILOGUE) ? 8 : 0);
+  a.dual_out = (d->flags & VNQA_CONV_DUAL_OUT) ? ((d->flags & VNQA_CONV_DUAL_HI2) ? 2 : 1)
+                                                : ((d->flags & VNQA_CONV_F32_EPILOGUE) ? ((d->flags & VNQA_CONV_DUAL_HI2) ? 9 : 8) : 0);
   VNQA_CHECK_ARG(!a.dual_out || d->tile == VNQA_TILE_PS_224x256 || d->tile == VNQA_TILE_STEM_PS_224x256 ||
                      d->tile == VNQA_TILE_256x256 || d->tile == VNQA_TILE_STEM_256x256,
                  "conv2d_igemm_fwd: VNQA_CONV_DUAL_OUT / VNQA_CONV_F32_EPILOGUE are served by the patch-stationary tiles and the 256x256 implicit-GEMM tiles");

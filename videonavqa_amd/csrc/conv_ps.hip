@@ -331,7 +331,10 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
         const size_t ooff = (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
         vnqa_bf16* dst = (vnqa_bf16*)(p.y) + ooff;
         *(uint4*)dst = make_uint4(hw[0], hw[1], hw[2], hw[3]);
-        if (p.dual_out == 8) continue;      // VNQA_CONV_F32_EPILOGUE: ONE plain 16-bit output, rounded once after pool / affine in fp32
+        if (p.dual_out >= 8) {              // VNQA_CONV_F32_EPILOGUE: ONE 16-bit value, rounded once after pool / affine in fp32 ...
+          if (p.dual_out == 9) *(uint4*)(dst + p.Cout) = make_uint4(hw[0], hw[1], hw[2], hw[3]);      // ... | VNQA_CONV_DUAL_HI2: written TWICE, [v | v]
+          continue;
+        }
         if (p.dual_out == 4) {      // VNQA_EPI_SPLIT_OUT: hi and lo as TWO plain tensors of y's geometry (y, y2)
           *(uint4*)((vnqa_bf16*)(p.y2) + ooff) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
           continue;
@@ -717,7 +720,7 @@ int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
   const int halo = a.taps == 25 ? 2 : 1;
   if (a.dual_out) {        // [hi | lo] pair output (TAG 2 instantiations: fp32 epilogue in two cout passes)
     if (a.taps != 9 || a.epi != VNQA_EPI_NONE || a.border_sub != nullptr || a.zero_halo || a.Cout % 8 != 0 ||
-        a.Cy < ((a.dual_out == 4 || a.dual_out == 8) ? 1 : a.dual_out + 1) * a.Cout || (a.dual_out == 4 && a.y2 == nullptr)) {
+        a.Cy < ((a.dual_out == 4 || a.dual_out == 8) ? 1 : (a.dual_out == 9 ? 2 : a.dual_out + 1)) * a.Cout || (a.dual_out == 4 && a.y2 == nullptr)) {
       vnqa_set_error("conv patch-stationary tile: VNQA_CONV_DUAL_OUT needs a plain 3x3 conv (no fused epilogue / border correction / "
                      "halo zeroing), c_out %% 8 == 0 and c_y >= 2 c_out (3 c_out with VNQA_CONV_DUAL_HI2)");
       return VNQA_ERR_UNSUPPORTED;

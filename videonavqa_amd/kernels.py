@@ -116,7 +116,7 @@ def split_weight2(wt):
 
 def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None,
                  x_halo=1, y_halo=1, out=None, tile=L.TILE_AUTO, border_sub=None, desc_flags=0,
-                 split_in=False, split_weights=False, dual_out=False, f32_epilogue=False):
+                 split_in=False, split_weights=False, dual_out=False, f32_epilogue=False, relu_floor=None):
     """x: padded NHWC [N,H+2h,W+2h,Cin]; wt: [Cout][taps][Cin] or a TiledWeight; returns padded NHWC output.
     Precision 'fp16h' (see the block comment above):
       split_weights — x a plain 16-bit tensor, wt the fp32 K-major pack: x . w_hi + x . w_lo on the igemm's wrap variant;
@@ -156,12 +156,15 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
             out = empty_padded((N, Ho + 2, Wo + 2, segs * c_out), x.dtype, x.device)
         assert out.shape[-1] == segs * c_out
         flags = L.CONV_DUAL_OUT | (L.CONV_DUAL_HI2 if segs == 3 else 0)
-    elif f32_epilogue:      # one plain output, pool / affine in fp32, ONE rounding (VNQA_CONV_F32_EPILOGUE; the dual epilogue's hi half)
+    elif f32_epilogue:      # one value, pool / affine in fp32, ONE rounding (VNQA_CONV_F32_EPILOGUE; the dual epilogue's hi half);
+        # f32_epilogue == 2: written twice, [v | v] — the operand of a two-product consumer with split WEIGHTS [w_hi | w_lo]
         assert y_halo == 1 and c_out % 8 == 0 and L.is_half(x.dtype) and (
             (tile in (L.TILE_PS_224x256, L.TILE_STEM_PS_224x256) and border_sub is None) or tile in (L.TILE_256x256, L.TILE_STEM_256x256)), tile
+        twin = int(f32_epilogue) == 2
         if out is None:
-            out = empty_padded((N, Ho + 2, Wo + 2, c_out), x.dtype, x.device)
-        flags = L.CONV_F32_EPILOGUE
+            out = empty_padded((N, Ho + 2, Wo + 2, (2 if twin else 1) * c_out), x.dtype, x.device)
+        assert out.shape[-1] >= (2 if twin else 1) * c_out
+        flags = L.CONV_F32_EPILOGUE | (L.CONV_DUAL_HI2 if twin else 0)
     if out is None:
         if y_halo == 1 and c_out % 8 == 0 and tile not in (11, 12, 20, 21):
             # fresh output: the kernel zeroes the halo ring itself (VNQA_CONV_ZERO_HALO), no fill / halo launch
@@ -171,6 +174,10 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
             out = empty_padded((N, Ho + 2, Wo + 2, c_out), x.dtype, x.device)
         else:
             out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
+    if relu_floor is not None:      # VNQA_CONV_RELU_FLOOR: the per-channel floor travels in the post_shift slot (stem 256x256 tile)
+        assert post_scale is None and post_shift is None and relu and not dual_out and not f32_epilogue and tile == L.TILE_STEM_256x256
+        post_shift = relu_floor
+        flags |= L.CONV_RELU_FLOOR
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, cin_w, c_out, out.shape[-1], taps, x_halo, y_halo,
                    int(relu), 1 if pool2 else 0, tile, 1 if tiled else 0, 0, flags | int(desc_flags))
     L.check(L.lib().vnqa_conv2d_igemm_fwd_ex(ctypes.byref(d), L.ptr(x), L.ptr(wt), L.ptr(bias), L.ptr(post_scale),

@@ -181,14 +181,18 @@ class FrameLayout(object):
 class NativeFeatures(object):
     """Stem output kept in kernel-native form: padded NHWC [n_img, h+2, w+2, Cpad] packed by `layout`."""
 
-    def __init__(self, data, layout, channels, h, w, segs=None):
+    def __init__(self, data, layout, channels, h, w, segs=None, shift=None):
         self.data, self.layout, self.channels, self.h, self.w = data, layout, channels, h, w
-        # 1: a plain tensor; 3: a SPLIT tensor [hi | lo | hi] (precision 'fp16h': the stem's dual epilogue).  An explicit marker
+        # shift (fp32 [c_pad] on the device, or None): MEAN-SHIFTED storage — `data` holds feature - shift[c] and -shift[c] in its halo
+        # (stem.FrozenStem.feature_shift); the trunk's conv_init absorbs sum(W) shift in its bias
+        self.shift = shift
+        # 1: a plain tensor; 3: a SPLIT tensor [hi | lo | hi] (the stem's dual epilogue); 2: the mean-shifted features written TWICE,
+        # [x' | x'] (precision 'fp16h': conv_init's two products against split weights).  An explicit marker
         # (ADVICE r5: consumers used to infer it from the channel count alone); None = stated by nobody, checked against the shape
         if segs is None:
             segs = 3 if (L.is_half(data.dtype) and data.shape[-1] == 3 * L.round_up(channels, 64)) else 1
         self.segs = int(segs)
-        assert self.segs in (1, 3) and data.shape[-1] % (64 * self.segs) == 0 and (self.segs == 1 or L.is_half(data.dtype)), \
+        assert self.segs in (1, 2, 3) and data.shape[-1] % (64 * self.segs) == 0 and (self.segs == 1 or L.is_half(data.dtype)), \
             "features tensor [..., %d] (%s) cannot be a %d-segment tensor" % (data.shape[-1], data.dtype, self.segs)
 
     @property
@@ -347,7 +351,11 @@ class FiLMTrunkBase(nn.Module):
             lay = v_input.layout
             assert v_input.data.dtype == cdt
             # (precision 'fp16h': the stem's features may be a SPLIT tensor [hi | lo | hi] — three times the channels; conv_init recognises it)
+            self.__dict__["_in_shift"] = getattr(v_input, "shift", None)      # mean-shifted features: conv_init's bias absorbs the mean
+            self.__dict__["_in_twin"] = getattr(v_input, "segs", 1) == 2
             return v_input.data, lay, v_input.h, v_input.w
+        self.__dict__["_in_shift"] = None
+        self.__dict__["_in_twin"] = False
         assert v_input.is_cuda, "the HIP path needs device tensors (no CPU fallback)"
         B, C, h, w, T = v_input.shape
         lay = FrameLayout(v_lens, T, v_input.device)
@@ -455,6 +463,9 @@ class FiLMTrunkBase(nn.Module):
             return self._trunk_infer(x, lay, film_specs, join)
         C = self.num_res_block_channels
         meta = ops.TrunkMeta(lay, C, self.num_res_blocks, 0, [], BN_EPS, grad_scale=getattr(self, "_trunk_grad_scale", 1.0))
+        meta.in_shift = self.__dict__.get("_in_shift")
+        meta.in_twin = bool(self.__dict__.get("_in_twin", False))
+        meta.hybrid = bool(self.__dict__.get("hyb", False))
         bn = self.bn_init
         S = (x.shape[1] - 2) * (x.shape[2] - 2)
         h, mean, var = ops.FilmTrunkHeadFn.apply(x, self.conv_init.weight, self.conv_init.bias, bn.weight, bn.bias, meta)
@@ -540,11 +551,18 @@ class FiLMTrunkBase(nn.Module):
         scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.detach().float() + BN_EPS)
         shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
         hyb = self.__dict__.get("hyb", False) and L.is_half(cdt)
-        split = ops.is_split(x, self.conv_init.weight.shape[1])                  # precision 'fp16h': [hi | lo | hi] features, three products
-        wt0 = K.pack_conv_weight(self.conv_init.weight, torch.float32 if split else cdt, c_out_pad=c_pad,
-                                 c_in_pad=x.shape[-1] // 3 if split else x.shape[-1])
-        ps = split and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
-        h = K.conv2d_igemm(x, wt0, bias=K.pad_vec(self.conv_init.bias, c_pad), relu=True, post_scale=K.pad_vec(scale, c_pad),
+        twin = bool(self.__dict__.get("_in_twin", False))                        # mean-shifted features written twice: two products, split weights
+        split = ops.is_split(x, self.conv_init.weight.shape[1]) and not twin     # [hi | lo | hi] features, three products
+        wt0 = K.pack_conv_weight(self.conv_init.weight, torch.float32 if (split or twin) else cdt, c_out_pad=c_pad,
+                                 c_in_pad=x.shape[-1] // (3 if split else (2 if twin else 1)))
+        if twin:
+            wt0 = K.split_weight2(wt0)
+        ps = (split or twin) and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
+        b0 = K.pad_vec(self.conv_init.bias, c_pad)
+        in_shift = self.__dict__.get("_in_shift")
+        if in_shift is not None and not split:      # mean-shifted features: W * (x' + mu) = W * x' + sum_taps(W) mu, in fp32 with the exact weights
+            b0 = b0 + ops.shift_bias_correction(self.conv_init.weight.detach(), in_shift, c_pad)
+        h = K.conv2d_igemm(x, wt0, bias=b0, relu=True, post_scale=K.pad_vec(scale, c_pad),
                            post_shift=K.pad_vec(shift, c_pad), split_in=split, tile=L.TILE_PS_224x256 if ps else L.TILE_AUTO)
         if join is not None:
             join()
@@ -573,6 +591,10 @@ class FiLMTrunkBase(nn.Module):
     def _trunk_head(self, x, lay):
         """conv_init -> ReLU -> per-frame BN (film_attn_pt_stem.py:211): the part that does not need the question."""
         # in train mode the BN backward applies conv_init's ReLU mask itself (fused)
+        in_shift = self.__dict__.get("_in_shift")
+        if in_shift is not None and (self.__dict__.get("_in_twin", False) or not ops.is_split(x, self.conv_init.weight.shape[1])):
+            c_in_pad = L.round_up(self.conv_init.weight.shape[1], 64)
+            x = ops.unshift_features(x[..., :c_in_pad].contiguous(), in_shift)      # the op-by-op graph reads plain features (an API path)
         r = ops.conv(x, self.conv_init.weight, self.conv_init.bias, relu=True, mask_in_backward=not self.training)
         return frame_batchnorm(r, self.bn_init, lay, self.training, self.compute_dtype)
 

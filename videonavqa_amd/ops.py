@@ -214,6 +214,25 @@ class FilmReluResFn(torch.autograd.Function):
         return dz, dout, dgamma, dbeta
 
 
+def shift_bias_correction(conv_w, shift, c_pad):
+    """sum_{c, taps} W[o, c, tap] * shift[c], fp32 [c_pad]: what a per-channel constant `shift` of a conv's INPUT adds to every output —
+    the bias term of mean-shifted storage (x = x' + shift everywhere, the halo included: it holds -shift).  Exact fp32 weights."""
+    c_out, c_in = conv_w.shape[0], conv_w.shape[1]
+    out = torch.zeros(c_pad, dtype=torch.float32, device=conv_w.device)
+    out[:c_out] = conv_w.float().sum((2, 3)) @ shift[:c_in].float()
+    return out
+
+
+def unshift_features(x, shift):
+    """Mean-shifted padded-NHWC features -> plain ones (x' + shift on the interior, zero halo), for consumers that read plain tensors."""
+    y = x.float() + shift[:x.shape[-1]].view(1, 1, 1, -1)
+    y[:, 0] = 0
+    y[:, -1] = 0
+    y[:, :, 0] = 0
+    y[:, :, -1] = 0
+    return y.to(x.dtype)
+
+
 def is_split(x, c_in):
     """x is a SPLIT tensor [hi | lo | hi] of a layer with c_in input channels (precision 'fp16h': the stem's dual-output features,
     laid out for a three-product consumer)."""
@@ -245,23 +264,39 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         # precision 'fp16h': split features [hi | lo | hi] from the stem — conv_init as THREE products (a plain conv over 3 C channels
         # against [w_hi | w_hi | w_lo]): the unrounded activation against unrounded weights; the layer's weight rounding alone is
         # 0.14e-6 of the fp16 precision's 0.70e-6 squared logits error, its input rounding 0.07e-6 (profiles/r05_precision_budget.txt)
-        split = is_split(x, conv_w.shape[1])
-        ctx.x_segs = 3 if split else 1
-        c_in_pad = x.shape[-1] // 3 if split else x.shape[-1]
-        wt0 = K.pack_conv_weight(conv_w, torch.float32 if split else x.dtype, c_out_pad=c_pad, c_in_pad=c_in_pad)
+        # twin: the mean-shifted features written TWICE, [x' | x'] (stem: FEATURE_TWIN) — a plain conv over 2 C channels against split
+        # weights [w_hi | w_lo]: x' w_hi + x' w_lo, the weight rounding of the trunk's first layer gone for one more product
+        twin = bool(getattr(meta, "in_twin", False)) and L.is_half(cdt) and x.shape[-1] == 2 * L.round_up(conv_w.shape[1], 64)
+        split = is_split(x, conv_w.shape[1]) and not twin
+        ctx.x_segs = 3 if split else (2 if twin else 1)
+        c_in_pad = x.shape[-1] // ctx.x_segs
+        wt0 = K.pack_conv_weight(conv_w, torch.float32 if (split or twin) else x.dtype, c_out_pad=c_pad, c_in_pad=c_in_pad)
+        if twin:
+            wt0 = K.split_weight2(wt0)
         b0 = K.pad_vec(conv_b, c_pad)
+        # MEAN-SHIFTED features (round 6; stem.FrozenStem.feature_shift): x holds feature - mu_c, its halo -mu_c.  The conv of the true
+        # feature is W * x' + sum_taps(W) mu: the second term goes into the bias in fp32 with the EXACT weights, so the 16-bit weight
+        # rounding multiplies a zero-mean input (its coherent part — 0.14e-6 of the squared logits error on a positive-mean input —
+        # is gone) and ONE product does what three on [hi | lo | hi] features did.  Backward: dW gets mu (x) db for every tap.
+        in_shift = getattr(meta, "in_shift", None) if not split else None
+        ctx.in_shift = in_shift
+        if in_shift is not None:
+            b0 = b0 + shift_bias_correction(conv_w.detach(), in_shift, c_pad)
         fused = None
         ps = split and HEAD_CONV_PS and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
         # (maps the patch-stationary tiles do not serve — the 10 x 13 maps of the reference's 160 x 208 frames — take the same split
         # output from the 256x256 implicit-GEMM tile: round 6)
-        split_out = split and HEAD_SPLIT_OUT and HEAD_CONV_PS
+        hybrid = bool(getattr(meta, "hybrid", False)) and L.is_half(cdt)
+        if (hybrid or twin) and not split:      # precision 'fp16h' on plain / twin mean-shifted features: the patch-stationary tile where it serves
+            ps = HEAD_CONV_PS and K.conv_ps_supported(x.shape[0], x.shape[1] - 2, x.shape[2] - 2, x.shape[-1], c_pad)
+        split_out = (split or hybrid) and HEAD_SPLIT_OUT and HEAD_CONV_PS
         if L.is_half(cdt) and not ps and not split_out:     # (the fp32 parity precision keeps the exact two-pass statistics kernel)
             fused = K.conv2d_igemm_bnstats(x, wt0, b0, True, lay.frame_of_i32, lay.frame_off_i32, lay.n_frames, min(lay.cts), split_in=split)
         g = K.pad_vec(bn_w, c_pad)
         if split_out:
             # ... and its OUTPUT kept unrounded into the BatchNorm (hi + lo, VNQA_EPI_SPLIT_OUT): 0.020e-6 of the budget; the backward
             # reads the hi tensor alone (ReLU mask and x-hat)
-            r, r_lo = K.conv2d_igemm_split_out(x, wt0, b0, True, split_in=True, tile=L.TILE_PS_224x256 if ps else L.TILE_256x256)
+            r, r_lo = K.conv2d_igemm_split_out(x, wt0, b0, True, split_in=split, tile=L.TILE_PS_224x256 if ps else L.TILE_256x256)
             mean, var = K.frame_bn_stats_split(r, r_lo, lay.frame_off_i32, lay.n_frames)
             rstd = torch.rsqrt(var + meta.eps)
             h = K.frame_bn_apply_split(r, r_lo, lay.frame_of_i32, mean, rstd, g, K.pad_vec(bn_b, c_pad))
@@ -302,7 +337,12 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         dbn_w = _ret(s_bw if exact else None, K.colsum(s2, out=_into(s_bw) if exact else None)[:C])
         dbn_b = _ret(s_bb if exact else None, K.colsum(s1, out=_into(s_bb) if exact else None)[:C])
         dwt0, dbias0 = K.conv2d_wgrad(x, dr, 9, dbias_out=_into(s_cb) if exact else None, x_segs=ctx.x_segs)
-        dconv_w = _ret(s_cw, K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw), alpha=inv))
+        dw_t = K.unpack_conv_wgrad(dwt0, C, conv_w.shape[1], out=_into(s_cw), alpha=inv)
+        if ctx.in_shift is not None:
+            # mean-shifted input: the kernel contracted dY with x' (halo -mu included); the true input is x' + mu everywhere, so
+            # every tap gets mu[c] * sum_pixels dY[o] = mu (x) db — added BEFORE the sink is handed on (data-parallel early reduce)
+            dw_t.view(C, conv_w.shape[1], -1).add_((dbias0[:C].float() * inv).view(-1, 1, 1) * ctx.in_shift[:conv_w.shape[1]].view(1, -1, 1))
+        dconv_w = _ret(s_cw, dw_t)
         dconv_b = _ret(s_cb if exact else None, dbias0[:C])
         if scaled:
             dbn_w, dbn_b, dconv_b = dbn_w * inv, dbn_b * inv, dconv_b * inv
@@ -467,6 +507,7 @@ class TrunkMeta(object):
         # precision 'fp16h': the frozen 1x1 convs' FORWARD as two products against split weights (c1_packs32: their fp32 packs)
         self.hybrid = False
         self.c1_packs32 = None
+        self.in_shift = None      # mean-shifted features: the per-channel constant conv_init's bias absorbs (FilmTrunkHeadFn)
 
 
 def film_trunk(x, conv_w, conv_b, bn_w, bn_b, meta, *tensors, join=None):

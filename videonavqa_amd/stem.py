@@ -153,6 +153,7 @@ def calibration_means(vgg, od, frames=None, n_frames=4, height=224, width=224, s
     c = od.conv12.out_channels
     m["od2"] = mean(("od", "c") if ref.composed is not None else ("od", 1), c)
     m["od3"], m["od4"], m["od5"] = mean(("od", 2), od.conv21.out_channels), mean(("od", 3), c), mean(("od", 4), od.conv31.out_channels)
+    m["feat"] = mean(("od", 5), od.conv32.out_channels)          # the features themselves (round 6: mean-shifted storage of the stem's output)
     if second_moments:
         # ... and the second moment of every layer's input PATCHES (what second_order_round minimises against), on the device; od1
         # (conv12's input when the pair runs layer by layer) is not stored by the composed pass: that layer keeps coherent_round
@@ -263,8 +264,11 @@ def patch_second_moment(x, k, max_rows=400000):
     return H / max(rows, 1)
 
 
+FEATURE_TWIN = 1             # precision 'fp16h' with mean-shifted features: write them twice ([x' | x']) for conv_init's two products (split weights)
 MEAN_SHIFT = 1               # 16-bit precisions with a calibration: store the stem's activations minus their calibration channel means (see FrozenStem)
-SPLIT_DEPTH = 3              # precision 'fp16h': how many of the stem's LAST stored activations are split tensors (see FrozenStem)
+SPLIT_DEPTH = 0              # precision 'fp16h': how many of the stem's LAST stored activations are split tensors (see FrozenStem);
+                             # 0 = automatic: none needed with mean-shifted storage (1: the features, only where the consumer cannot
+                             # take shifted ones), 3 without it (round 5's form)
 RING_EDGE_LAUNCHES = True    # conv11 on the outside ring as four 3-tap launches (False: one 9-tap launch, same bits: the A/B partner)
 CALIBRATION_FRAMES = 40      # frames of the default ("noise") calibration pass: 40 x 196 patches > K = 4608 of the 14 x 14 layers
 
@@ -310,10 +314,16 @@ class FrozenStem(object):
         self.cdt = compute_dtype(precision)
         self.hyb = precision == "fp16h"
         self.split_features = bool(split_features) and self.hyb
+        # split_features=True also says "the consumer is the FiLM trunk's conv_init": with a calibration that knows the features' channel
+        # means the features go out as ONE plain tensor holding v - mean_c (feature_shift) — conv_init absorbs the mean in its bias, its
+        # weight rounding then multiplies a zero-mean input, and its three products on [hi | lo | hi] features are not needed
+        self.trunk_features = bool(split_features)
+        self.feature_shift = None
         # 1: the features alone (conv_init's three products; everything before them one product on mean-shifted storage); 3 (round 5):
         # conv22's, conv31's and conv32's outputs; 4: + conv21's (conv22 then runs as two products); 5: + the composed conv11.conv12
         # pair's (conv21 as two products; the pair's dual output comes from the implicit-GEMM tile's fp32 epilogue)
-        self.split_depth = min(5, max(1, int(SPLIT_DEPTH if split_depth is None else split_depth))) if self.hyb else 0
+        self._split_depth_arg = int(SPLIT_DEPTH if split_depth is None else split_depth)
+        self.split_depth = 0          # (fixed below, once the calibration says whether mean-shifted storage is available)
         self.vgg, self.objdet = vgg, objdet
         self.layers_vgg, self.layers_od = [], []
         self.composed = None
@@ -346,6 +356,13 @@ class FrozenStem(object):
             self.calib = st
             self.calib["frames"] = "noise" if noise else torch.as_tensor(frames).float().cpu()
         self.second_order = self._H is not None
+        # mean-shifted storage needs the calibration's channel means of every stored tensor, and the whole stem in one plan
+        self._shift_planned = bool(MEAN_SHIFT and os.environ.get("VNQA_MEAN_SHIFT", "1") != "0" and L.is_half(self.cdt) and vgg is not None
+                                   and objdet is not None and self.calib is not None
+                                   and all(k in self.calib for k in ("first", "vgg0", "vgg1", "vgg2", "od0", "od2", "od3")))
+        if self.hyb:
+            auto = 1 if self._shift_planned else 3
+            self.split_depth = min(5, max(1, self._split_depth_arg if self._split_depth_arg > 0 else auto))
         cm = lambda k: k if self.calib is not None else None
         if vgg is not None:
             f = vgg.features
@@ -403,8 +420,7 @@ class FrozenStem(object):
                     self.layers_vgg[-1]["y_halo"] = 2        # the composed 5x5 conv reads a halo-2 image
 
         self.shift = {}
-        if (MEAN_SHIFT and os.environ.get("VNQA_MEAN_SHIFT", "1") != "0" and L.is_half(self.cdt) and vgg is not None and objdet is not None
-                and self.calib is not None and all(k in self.calib for k in ("first", "vgg0", "vgg1", "vgg2", "od0", "od2", "od3"))):
+        if self._shift_planned:
             self._setup_mean_shift()
         for ly in self.layers_vgg + self.layers_od + ([self.composed] if self.composed is not None else []):
             ly.pop("_wsum", None)
@@ -414,11 +430,30 @@ class FrozenStem(object):
     def feature_segs(self):
         """Channel segments of forward_clip's output: 3 = a split tensor [hi | lo | hi] (precision 'fp16h' with split_features), 1 = a
         plain tensor.  `split_active`: the number of stored activations this plan keeps as split tensors (0: none)."""
+        if self.layers_od and self.layers_od[-1].get("twin_out"):
+            return 2          # [x' | x']: the mean-shifted features written twice (conv_init's two products against split weights)
         return 3 if (self.split_features and self.layers_od and int(self.layers_od[-1].get("split_out", 0)) == 3) else 1
+
+    def plain_features(self, feats):
+        """forward_clip's output as the plain fp32 feature tensor [n, h+2, w+2, C_pad] (zero halo) whatever its storage form: a split
+        tensor's hi + lo, a mean-shifted tensor's value + shift.  For tests, tools and consumers that read plain tensors."""
+        c = self.layers_od[-1]["c_out_pad"]
+        f = feats[..., :c].float()
+        if feats.shape[-1] >= 2 * c and not self.layers_od[-1].get("twin_out"):
+            f = f + feats[..., c:2 * c].float()
+        if self.feature_shift is not None:
+            f = f + self.feature_shift.view(1, 1, 1, -1)
+            f[:, 0] = 0
+            f[:, -1] = 0
+            f[:, :, 0] = 0
+            f[:, :, -1] = 0
+        return f
 
     @property
     def split_active(self):
-        return self.split_depth if (self.hyb and self.layers_od and "split_out" in self.layers_od[-1]) else 0
+        """How many of the stem's stored activations this plan keeps as split tensors."""
+        return sum(1 for ly in self.layers_od if int(ly.get("split_out", 0)) > 0) + \
+            (1 if (self.split_depth >= 5 and self.composed is not None and self.layers_od and "wt_split" in self.layers_od[2]) else 0)
 
     def packed_tensors(self):
         """Every device tensor of the execution plan (packed / tiled / split weights, biases, the ring operands): what a data-parallel
@@ -509,6 +544,10 @@ class FrozenStem(object):
             cp["b1"] = cp["b1"] + corr(w1.sum(1), mu["c22"], cp["c_mid_pad"])            # (the one-launch nine-tap form)
             cp["post"] = (ones(cp["c_out_pad"]), -mu["comp"])
             cp["out_shift"] = mu["comp"]
+            if cp["tile"] == L.TILE_STEM_256x256:
+                # relu(a) - mu = max(a - mu, -mu): -mu in the bias and as the ReLU's per-channel floor (VNQA_CONV_RELU_FLOOR) stores the
+                # shifted output with one rounding through the tile's ordinary epilogue (the fp32 epilogue, TAG 6, costs +0.14 ms here)
+                cp["bias_floor"] = (cp["bias"] - mu["comp"], (-mu["comp"]).contiguous())
         else:
             od[0]["bias"] = od[0]["bias"] + corr(od[0]["_wsum"], mu["c22"], od[0]["c_out_pad"])
             od[1]["post"] = (ones(od[1]["c_out_pad"]), -mu["comp"])
@@ -530,6 +569,16 @@ class FrozenStem(object):
             od[4]["bias"] = od[4]["bias"] - mu["od31"]
             od[4]["out_shift"] = mu["od31"]
             od[5]["bias"] = od[5]["bias"] + corr(od[5]["_wsum"], mu["od31"], od[5]["c_out_pad"])
+        # the features, where the consumer is the trunk's conv_init (it absorbs the mean in its bias: ops.FilmTrunkHeadFn)
+        if self.trunk_features and "feat" in cal and not od[5]["pool"]:
+            mu["feat"] = mu_of("feat", od[5]["c_out"], od[5]["c_out_pad"])
+            od[5]["post"] = (ones(od[5]["c_out_pad"]), -mu["feat"])
+            od[5]["out_shift"] = mu["feat"]
+            od[5]["split_out"] = 0
+            # precision 'fp16h': written TWICE, [x' | x'] — conv_init then runs as x' w_hi + x' w_lo, a plain conv over 2 C channels against
+            # split weights (its remaining weight rounding, ~0.1e-6 of the 0.22e-6 left, for one more product on a 14 x 14 layer)
+            od[5]["twin_out"] = bool(self.hyb and FEATURE_TWIN)
+            self.feature_shift = mu["feat"]
         self.shift = mu
         self._fused_first_shift = v0["tile"] is None
 
@@ -683,10 +732,15 @@ class FrozenStem(object):
             ev0.record()
         # every XCD computes ONE cout half of the composed conv (its L2 then holds 1.65 instead of 3.3 MB of weights): fabric-side reads
         # 1 022 -> 831 MB per launch (profiles/r04_pmc_traffic*.json), time unchanged
-        y = K.conv2d_igemm(x, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out, tile=cp["tile"],
-                           border_sub=ring, desc_flags=L.CONV_XCD_SPLIT_N if L.is_half(self.cdt) else 0, dual_out=dual,
-                           post_scale=post[0] if post else None, post_shift=post[1] if post else None,
-                           f32_epilogue=bool(post) and not dual and cp["tile"] == L.TILE_STEM_256x256)
+        floor = cp.get("bias_floor") if not dual else None
+        if floor is not None:
+            y = K.conv2d_igemm(x, cp["wt"], bias=floor[0], relu=True, pool2=True, x_halo=2, y_halo=1, out=out, tile=cp["tile"],
+                               border_sub=ring, desc_flags=L.CONV_XCD_SPLIT_N, relu_floor=floor[1])
+        else:
+            y = K.conv2d_igemm(x, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out, tile=cp["tile"],
+                               border_sub=ring, desc_flags=L.CONV_XCD_SPLIT_N if L.is_half(self.cdt) else 0, dual_out=dual,
+                               post_scale=post[0] if post else None, post_shift=post[1] if post else None,
+                               f32_epilogue=bool(post) and not dual and cp["tile"] == L.TILE_STEM_256x256)
         if timed:
             ev1.record()
             self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25, "conv_igemm_kernel"))
@@ -738,9 +792,13 @@ class FrozenStem(object):
             x_segs = x.shape[-1] // ly["c_out_pad"] if split_rd else 1      # (c_in == c_out on the split-reading layers)
             if split_wr and not (yh == 1 and (split_rd or "wt_split" not in ly)):      # (a split-reading layer handed a plain tensor: the chain is off)
                 split_wr = 0
-            out = self._buf(key + (("split",) if split_wr else ()), (n, ho + 2 * yh, wo + 2 * yh, max(split_wr, 1) * ly["c_out_pad"]),
-                            halo=(yh, ly.get("out_shift")))
+            twin = bool(ly.get("twin_out")) and not split_wr
+            osh = ly.get("out_shift")
+            out = self._buf(key + (("split",) if split_wr else ()) + (("twin",) if twin else ()),
+                            (n, ho + 2 * yh, wo + 2 * yh, (2 if twin else max(split_wr, 1)) * ly["c_out_pad"]),
+                            halo=(yh, torch.cat([osh, osh]) if (twin and osh is not None) else osh))
             post = ly["post"]
+            f32e = (2 if twin else 1) if (post is not None and osh is not None) else 0
             ps, pt = (post[0], post[1]) if post else (None, None)
             tile = ly["tile"]
             timed = self.timing is not None and tile == L.TILE_STEM_256x256
@@ -756,7 +814,7 @@ class FrozenStem(object):
                     kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)
                 x = K.conv2d_igemm(x, ly["wt_split"] if split_rd else ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"],
                                    post_scale=ps, post_shift=pt, out=out, tile=L.TILE_STEM_PS_224x256 if on_ps else L.TILE_STEM_256x256,
-                                   y_halo=yh, dual_out=split_wr)
+                                   y_halo=yh, dual_out=split_wr, f32_epilogue=0 if split_wr else f32e)
             elif "wt_rows" in ly and K.conv2d_wreg_supported(x, ly["wt_rows"], pool2=ly["pool"], y_halo=yh):
                 x = K.conv2d_wreg(x, ly["wt_rows"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"], post_scale=ps, post_shift=pt,
                                   out=out, y_halo=yh, reserve_cus=self.reserve_cus)
@@ -764,8 +822,7 @@ class FrozenStem(object):
                 kname = "conv_ps_kernel<%d>" % (28 if w % 28 == 0 else 14)      # (one entry per kernel SYMBOL, as rocprofv3 lists them)
                 # (a mean-shifted output with ReLU / pool before the shift: the fp32 epilogue, ONE rounding after the affine)
                 x = K.conv2d_igemm(x, ly["wt_ps"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"], post_scale=ps, post_shift=pt,
-                                   out=out, tile=L.TILE_STEM_PS_224x256, y_halo=yh,
-                                   f32_epilogue=post is not None and ly.get("out_shift") is not None)
+                                   out=out, tile=L.TILE_STEM_PS_224x256, y_halo=yh, f32_epilogue=f32e)
             elif tile is None:
                 # C_in = 64 layers (conv1_2, conv2_1): persistent direct conv with LDS-resident weights
                 x = K.conv2d_c64(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"], post_scale=ps, post_shift=pt, out=out,
@@ -773,8 +830,7 @@ class FrozenStem(object):
             else:
                 x = K.conv2d_igemm(x, ly["wt"], bias=ly["bias"], relu=ly["relu"], pool2=ly["pool"], post_scale=ps, post_shift=pt,
                                    out=out, tile=tile, y_halo=yh,
-                                   f32_epilogue=(post is not None and ly.get("out_shift") is not None and yh == 1
-                                                 and tile == L.TILE_STEM_256x256 and ly["c_out_pad"] % 8 == 0))
+                                   f32_epilogue=f32e if (yh == 1 and tile == L.TILE_STEM_256x256 and ly["c_out_pad"] % 8 == 0) else 0)
             if timed:
                 ev1.record()
                 self.timing.append((ev0, ev1, 2.0 * n * h * w * ly["c_in"] * ly["c_out"] * 9 * (x_segs if split_rd else 1), kname))

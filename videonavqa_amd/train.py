@@ -426,7 +426,8 @@ class Trainer(object):
         with phase("stem"):
             feats = self.stem.forward_clip(clip, lay.img_of, lay.n_img, slot=slot)
         segs = int(getattr(self.stem, "feature_segs", 1))       # stated by the producer (FrozenStem), checked against the shape
-        return NativeFeatures(feats, lay, self.feature_channels, H // 16, W // 16, segs=segs), v_sorted, perm
+        return NativeFeatures(feats, lay, self.feature_channels, H // 16, W // 16, segs=segs,
+                              shift=getattr(self.stem, "feature_shift", None)), v_sorted, perm
 
     def upload(self, clip_host):
         """Start the H2D copy of a (pinned) host clip on the copy stream into one of three rotating device
