@@ -265,13 +265,14 @@ def fp16_leg(args, precision="fp16"):
             return {"error": (r.stderr or "no output").strip()[-300:]}
         d = json.loads(line[-1])
         p = d.get("parity", {})
-        what = ("bench.py --precision fp16 (plain fp16 storage, fp32 accumulate, dynamic loss scale from 2^10; the frozen stem's weights "
-                "second-order rounded like in every 16-bit precision): NOT tolerance-compliant — rms logits error 0.6-0.95e-3 by weight seed, worst "
-                "minibatch 1.19e-3 (profiles/r05_second_order_stem.txt); %d timed steps, child process") % d["steps"]
+        what = ("bench.py --precision fp16 (plain fp16 storage, fp32 accumulate, dynamic loss scale from 2^10; stem weights second-order "
+                "rounded and activations mean-shifted like in every 16-bit precision; no split operands in the trunk): inside 1e-3 on the "
+                "measured kinds with a thin margin — 0.65-0.94e-3 worst of twelve by weight seed and kind of clip "
+                "(profiles/r06_error_by_kind.txt); %d timed steps, child process") % d["steps"]
         if precision == "bf16":
-            what = ("bench.py --precision bf16: BASELINE.json's storage dtype (bf16 storage, fp32 accumulate; the frozen stem's weights "
-                    "second-order rounded like in every 16-bit precision) — the round 1-4 headline, NOT tolerance-compliant (logits ~6-7e-3 of exact "
-                    "fp32, 21-23 of 24 answer classes at random initialisation); %d timed steps, child process") % d["steps"]
+            what = ("bench.py --precision bf16: BASELINE.json's storage dtype (bf16 storage, fp32 accumulate; stem weights second-order "
+                    "rounded and activations mean-shifted like in every 16-bit precision) — the round 1-4 headline, NOT tolerance-compliant "
+                    "(logits ~4e-3 of exact fp32 in round 6, 7e-3 before); %d timed steps, child process") % d["steps"]
         key = precision + "_logits_rel_err"
         return {"what": what, "precision": precision,
                 # the precision's own full line: the same fields the top-level line carries, measured the same way
@@ -833,13 +834,13 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="the timed K-step region is run this many times back to back; "
                     "the reported value / ms_per_step are the MEDIAN region's, all regions are listed in `repeats`")
     ap.add_argument("--precision", default="fp16h", choices=["bf16", "fp16", "fp16h", "fp32"],
-                    help="fp16h (default, the headline): the TOLERANCE-COMPLIANT precision — fp16 storage and fp16 MFMA products with fp32 "
-                         "accumulation like 'fp16', plus split activations on the stem's last three tensors (conv31 / conv32 as two products on "
-                         "[hi | lo] against their second-order rounded weights, conv_init as three against split weights), conv_init's output "
-                         "split into its BatchNorm, the frozen 1x1 conv and fc_embed_attn with split weights: logits "
-                         "within north star's 1e-3 of exact fp32 on 4 weight seeds x 12 minibatches; bf16: BASELINE.json's storage dtype "
-                         "(7e-3, a leg of the default line); fp16: plain fp16 storage (0.6-1.0e-3 rms by weight seed, a leg); fp32: the exact-f32 "
-                         "parity precision")
+                    help="fp16h (default, the headline; also the default of every model constructor and CLI): the TOLERANCE-COMPLIANT precision — "
+                         "fp16 storage and fp16 MFMA products with fp32 accumulation, stem weights second-order rounded on calibration frames, "
+                         "stem activations and features stored mean-shifted, conv_init as two products against split weights with its output "
+                         "split into its BatchNorm, the frozen 1x1 conv and fc_embed_attn with split weights: logits within north star's 1e-3 of "
+                         "exact fp32 on 4 weight seeds x 12 minibatches at 224x224 AND at the reference's 160x208, and on held-out kinds of clip; "
+                         "fp16: the same without the trunk's split operands (a leg); bf16: BASELINE.json's storage dtype (4e-3, a leg); "
+                         "fp32: the exact-f32 parity precision")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU minibatch; default 8 (the metric's), 32 for --model v_only_cnn3d "
                     "(BASELINE config 2)")
     ap.add_argument("--frames", type=int, default=35)
@@ -947,7 +948,7 @@ def main():
     batches = [synth_batch(args, rank, device, i) for i in range(NB)]
     if args.h2d:
         batches = [(b[0].cpu().pin_memory(),) + tuple(b[1:]) for b in batches]
-    # diagnostics of the PCIe-inclusive rate (tools/round5/r05_h2d_ablation.sh): the resident-input loop with ONE ingredient of --h2d added
+    # diagnostics of the PCIe-inclusive rate (round 5's h2d ablation, docs/history): the resident-input loop with ONE ingredient of --h2d added
     pinned_copies, scratch, scratch_stream = None, None, None
     if args.h2d_ablation and not args.h2d:
         pinned_copies = [b[0].cpu().pin_memory() for b in batches]       # 'pinonly': the pinned staging clips exist, nothing reads them
@@ -1172,7 +1173,7 @@ def main():
         # valid for the default workload the passes were taken on
         traffic, traffic_src = None, None
         default_cfg = (args.precision in ("bf16", "fp16", "fp16h") and (B, T, H, W) == (8, 35, 224, 224))     # (the same kernel, shapes and bytes in both 16-bit formats)
-        for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for tname in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tfile = os.path.join(ROOT, "profiles", tname)
             if default_cfg and os.path.exists(tfile):
                 tj = json.load(open(tfile))
@@ -1194,7 +1195,7 @@ def main():
             "metric": METRIC, "value": round(clips, 3), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp16": "f16", "fp16h": "f16 (fp16 storage, fp16 MFMA products, fp32 accumulate; frozen stem weights second-order rounded on calibration frames; split [hi | lo] activations into conv31 / conv32 (two products each), split features and weights into conv_init (three products), conv_init's output split into its BatchNorm, 1x1 / fc_embed_attn with split weights)", "fp32": "f32"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp16h": "f16 (fp16 storage, fp16 MFMA products, fp32 accumulate; frozen stem weights second-order rounded on calibration frames; the stem's activations and features stored mean-shifted — value minus the calibration channel mean, the consumer's bias absorbs the mean —; conv_init as two products against split weights with its output split into its BatchNorm, 1x1 / fc_embed_attn with split weights)", "fp32": "f32"}[args.precision], "data": "synthetic",
             "repeats": {"n": len(regions), "value_is": "median region", "clips_per_s": [round(c, 1) for c in all_clips],
                         "spread_rel": round((max(all_clips) - min(all_clips)) / clips, 4)},
             "config": {"workload": "%s training step: VGG-16[:10]+ObjDetectCNN(512) frozen stem + "

@@ -644,6 +644,21 @@ def test_fp16h_meets_1e3_on_data_that_does_not_look_like_the_calibration_frames(
     assert flips == 0
 
 
+@pytest.mark.parametrize("model,frames,tol", [("time_multi_hop", 70, 1e-3), ("film_gp_pt", 35, 1.75e-3)])
+def test_fp16h_pooling_heads_at_full_size(model, frames, tol):
+    """BASELINE.json configs 5 and 3 in the headline precision.  A pooling head hands single-frame values to its
+    classifier where the attention head averages over frames: 2.5 - 3 x the sensitivity to the same roundings.  Round 6, two weight
+    seeds x three minibatches: the multi-hop model at T = 70 reads 0.44 - 0.63e-3 (round 5: 0.84 - 1.25e-3) and is asserted AT the
+    tolerance; the global-pooling model reads 0.61 - 1.34e-3 (round 5: 1.26 - 1.81e-3): still outside 1e-3 on one of six minibatches —
+    stated measured + 30 %, NOT the tolerance (only precision 'fp32' complies there)."""
+    worst = 0.0
+    for seed in (0, 1):
+        rel, flips = _full_size_errors(seed, "noise", batches=3, model=model, frames=frames)
+        worst = max(worst, max(rel))
+        assert flips == 0, (model, seed, flips)
+    assert worst <= tol, (model, worst)
+
+
 def test_stem_calibration_on_the_deployments_own_frames_is_measured():
     """`--stem_calibration data` / `FrozenStem(calibration=frames)` (only 'it runs' was tested): calibrating the weight rounding
     and the channel means on 40 frames of the DEPLOYMENT's kind (here: 'blocks' clips of other seeds) keeps the held-out kind inside the

@@ -134,12 +134,21 @@ def test_full_size_training_steps_are_sane(name):
 # config measures 7.1e-3 (bf16) / 0.81e-3 (fp16) instead of 9.1e-3 / 1.30e-3: stated 9.5e-3 and 1.1e-3.
 # Round 5: every stated tolerance = the measured value + 30 % (profiles/r05_gpu_tests.txt's run: 7.1e-3, 1.64e-3,
 # 1.64e-2, 1.26e-2, 1.63e-2, 0.90e-2 in this order; flat-gradient errors 0.019, 0.0068, 0.19, 0.24, 0.33, 0.13).
-BF16_FULL_SIZE_LOGIT_TOL = {"config4_film_attn": 9.5e-3, "evalsh_film_attn_5x1024_bs32": 2.2e-3,
-                            "config3_film_gp": 2.15e-2, "config5_time_multi_hop_T70": 1.65e-2,
-                            "evalsh_film_gp_4x1024_bs32": 2.15e-2, "evalsh_time_multi_hop_3x1024_bs16": 1.2e-2}
-BF16_FULL_SIZE_GRAD_TOL = {"config4_film_attn": 0.026, "evalsh_film_attn_5x1024_bs32": 0.01,
-                           "config3_film_gp": 0.25, "config5_time_multi_hop_T70": 0.31,
-                           "evalsh_film_gp_4x1024_bs32": 0.43, "evalsh_time_multi_hop_3x1024_bs16": 0.17}
+# Round 6 (mean-shifted storage of the stem's activations and features, one storage rounding after bn_input's affine — DESIGN.md section 4 —
+# apply to EVERY 16-bit precision): measured, in the order of FULL_SIZE_CONFIGS, bf16 logits 4.2e-3, 8.8e-3, 7.3e-3, 1.3e-3, 9.5e-3, 6.2e-3
+# (flat gradient 0.012, 0.146, 0.195, 0.0049, 0.249, 0.104); fp16 logits 0.53e-3, 1.58e-3, 0.76e-3, 0.20e-3, 1.21e-3, 0.72e-3 (gradient
+# 0.0040, 0.051, 0.072, 0.0015, 0.089, 0.038).  Stated = measured + 35 % (these pin regressions; the COMPLIANCE claim — 1e-3 — belongs to
+# precision 'fp16h' and is asserted at the tolerance itself in tests/test_gpu_fp16h.py).
+FULL_SIZE_LOGIT_TOL = {
+    "bf16": {"config4_film_attn": 5.7e-3, "config3_film_gp": 1.2e-2, "config5_time_multi_hop_T70": 9.9e-3,
+             "evalsh_film_attn_5x1024_bs32": 1.75e-3, "evalsh_film_gp_4x1024_bs32": 1.3e-2, "evalsh_time_multi_hop_3x1024_bs16": 8.4e-3},
+    "fp16": {"config4_film_attn": 7.2e-4, "config3_film_gp": 2.15e-3, "config5_time_multi_hop_T70": 1.05e-3,
+             "evalsh_film_attn_5x1024_bs32": 2.7e-4, "evalsh_film_gp_4x1024_bs32": 1.65e-3, "evalsh_time_multi_hop_3x1024_bs16": 9.8e-4}}
+FULL_SIZE_GRAD_TOL = {
+    "bf16": {"config4_film_attn": 0.016, "config3_film_gp": 0.20, "config5_time_multi_hop_T70": 0.265,
+             "evalsh_film_attn_5x1024_bs32": 0.0067, "evalsh_film_gp_4x1024_bs32": 0.34, "evalsh_time_multi_hop_3x1024_bs16": 0.14},
+    "fp16": {"config4_film_attn": 0.0055, "config3_film_gp": 0.069, "config5_time_multi_hop_T70": 0.098,
+             "evalsh_film_attn_5x1024_bs32": 0.0021, "evalsh_film_gp_4x1024_bs32": 0.121, "evalsh_time_multi_hop_3x1024_bs16": 0.051}}
 
 
 @pytest.mark.parametrize("name", list(FULL_SIZE_CONFIGS))
@@ -154,12 +163,10 @@ def test_bf16_vs_fp32_mode_logits_argmax_at_full_size(name):
     with open(os.path.join(out_dir, "parity_%s%s.json" % (name, "" if LOW == "bf16" else "_" + LOW)), "w") as fh:
         json.dump(res, fh, indent=1)
     print(name, json.dumps(res))
-    tol = BF16_FULL_SIZE_LOGIT_TOL[name]
-    if LOW == "fp16":        # 11 significand bits instead of 8: an eighth of the bf16 error (measured 0.81e-3 at the headline
-        tol = 1.1e-3 if name == "config4_film_attn" else tol / 6        # config; stated 2e-3 for the other attention models, 5e-3 for the pooling heads)
+    tol = FULL_SIZE_LOGIT_TOL[LOW][name]
     err = res[LOW + "_logits_rel_err"]
     assert err < tol, res
-    assert res["loss_rel_err"] < tol, res
+    assert res["loss_rel_err"] < max(tol, 1.5e-3), res
     # an argmax can only flip where the fp32 top-2 gap is below twice the logits error: every flipped sample of the
     # untrained net must be such a near-tie ...
     assert all(g < 2 * err for g in res["fp32_top2_gap_rel_of_flipped_at_init"]), res
@@ -173,14 +180,12 @@ def test_bf16_vs_fp32_mode_logits_argmax_at_full_size(name):
     # 0.8 %).  Max-pooling heads: each pooled feature's whole gradient goes to ONE frame and ~10 % of the features pick another
     # frame under bf16 rounding (1.3 % under fp16, 0.9 % under fp16h): measured 0.13 - 0.33 bf16 (stated per config above), and
     # routing the backward by the fp32 run's arg-max frames must not make it worse.
-    gtol = BF16_FULL_SIZE_GRAD_TOL[name]
-    if LOW == "fp16":        # (measured 0.0059 at the headline config)
-        gtol = 0.008 if name == "config4_film_attn" else gtol / 2.5
+    gtol = FULL_SIZE_GRAD_TOL[LOW][name]
     assert res["grad_rel_l2_err"] < gtol, res
     if res.get("pooling_head"):
         ph = res["pooling_head"]
         assert ph["grad_rel_l2_err_routed_by_fp32_argmax"] <= res["grad_rel_l2_err"] * 1.02, res
-        assert ph["argmax_frame_flip_frac"] < (0.155 if LOW == "bf16" else 0.03), res      # (measured <= 0.116 bf16 / 0.014 fp16)
+        assert ph["argmax_frame_flip_frac"] < (0.088 if LOW == "bf16" else 0.012), res      # (round 6: measured <= 0.065 bf16 / 0.0088 fp16)
 
 
 def test_full_size_trunk_wgrad_vs_torch_and_additivity():
