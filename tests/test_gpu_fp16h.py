@@ -577,7 +577,7 @@ def test_fp16h_models_match_the_reference_goldens(case):
     model.init_hidden()
     v, q = torch.from_numpy(g["v"]).cuda(), torch.from_numpy(g["q"]).cuda()
     out = model(v, q, torch.from_numpy(g["v_lens"]), torch.from_numpy(g["q_lens"]))
-    assert rel_err(out.detach().float().cpu().numpy(), g["train_logits"]) < 1e-2
+    assert rel_err(out.detach().float().cpu().numpy(), g["train_logits"]) < 1.85e-3        # (measured worst 1.40e-3 + 30 %: 8-channel toy nets)
     loss = nn.CrossEntropyLoss(reduction="sum")(out.float(), torch.from_numpy(g["y"]).cuda())
     loss.backward()
     num = den = 0.0
@@ -586,7 +586,7 @@ def test_fp16h_models_match_the_reference_goldens(case):
         if key in g and p.grad is not None:
             num += float(((p.grad.float().cpu() - torch.from_numpy(g[key])) ** 2).sum())
             den += float((torch.from_numpy(g[key]) ** 2).sum())
-    assert den > 0 and (num / den) ** 0.5 < 0.3
+    assert den > 0 and (num / den) ** 0.5 < 0.042                                           # (whole-gradient rel. L2: measured worst 0.032 + 30 %)
 
 
 def _budget_mod():

@@ -18,7 +18,12 @@ from helpers import QV_CASES, build_product_model, load_golden, rel_err, weights
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = {"fp32": 1e-3, "bf16": 2.5e-2, "fp16": 1e-2}
+# Round 6: the 16-bit tolerances are measured + 30 % (tools/measure_smallnet_tol.py, worst over all cases of these
+# 8-channel nets — where ONE 16-bit rounding is 1e-3 of the logits: the full-size 1e-3 claim is tests/test_gpu_fp16h.py's): logits bf16
+# 1.26e-2 / fp16 5.0e-3; per-tensor gradient rel. L2 bf16 0.296 / fp16 0.125; worst element bf16 0.53 / fp16 0.16 of max |grad|.
+LOGIT_TOL = {"fp32": 1e-3, "bf16": 1.65e-2, "fp16": 6.6e-3}
+GRAD_L2_TOL = {"bf16": 0.385, "fp16": 0.165}
+GRAD_ELEM_TOL = {"bf16": 0.69, "fp16": 0.21}
 
 
 def _inputs(g):
@@ -82,8 +87,8 @@ def test_train_forward_backward_vs_reference_golden(case, precision):
             assert err <= 2e-3 * scale + 1e-6, (name, err, scale)
         else:
             l2 = np.linalg.norm(got_g - ref) / (np.linalg.norm(ref) + 1e-9)
-            assert l2 < 0.3 or np.linalg.norm(ref) < 1e-5, (name, l2)
-            assert err <= 0.6 * scale + 1e-6, (name, err, scale)
+            assert l2 < GRAD_L2_TOL[precision] or np.linalg.norm(ref) < 1e-5, (name, l2)
+            assert err <= GRAD_ELEM_TOL[precision] * scale + 1e-6, (name, err, scale)
         checked += 1
     assert checked >= 10
 

@@ -87,6 +87,18 @@ def main():
     print("trunk chain alone = %.3f ms of kernel time, of which chip-time C = %.3f ms (alone duration x chip share)" % (chain, chip))
     print("work conservation: step >= S + C = %.3f ms; measured %.3f ms: %.3f ms beyond it (%.1f %%)" %
           (S + chip, step_ms, step_ms - S - chip, 100 * (step_ms - S - chip) / step_ms))
+    # the stem's kernels: alone (serial run) vs beside the trunk (overlapped run), by kernel name
+    al, ov_ = {}, {}
+    for r in se:
+        if r[2] in stem_names:
+            a = al.setdefault(short(r[2]), [0, 0.0]); a[0] += 1; a[1] += (r[1] - r[0]) / 1e6
+    for r in ov:
+        if r[3] == stem_q:
+            a = ov_.setdefault(short(r[2]), [0, 0.0]); a[0] += 1; a[1] += (r[1] - r[0]) / 1e6
+    print("\n%-66s %5s %9s %10s %8s" % ("stem kernel", "calls", "alone ms", "co-run ms", "stretch"))
+    for k, a in sorted(al.items(), key=lambda kv: -kv[1][1])[:14]:
+        o = ov_.get(k, [0, 0.0])
+        print("%-66s %5d %9.3f %10.3f %8.2f" % (k, a[0], a[1], o[1], o[1] / a[1] if a[1] > 0 else 0.0))
     print("\n%-66s %5s %9s %9s %6s %7s" % ("trunk kernel (serial run)", "calls", "alone ms", "chip ms", "share", "WGs"))
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][2])[:24]:
         print("%-66s %5d %9.3f %9.3f %6.2f %7d" % (k, a[0], a[1], a[2], a[3], a[4]))

@@ -1,6 +1,6 @@
 O=gpurun_out/r06; mkdir -p $O
-timeout 3000 python -m pytest tests -m gpu -q -p no:cacheprovider -rA --durations=12 > $O/gpu_tests_full.txt 2>&1
-grep -E "^(FAILED|ERROR)|passed|failed" $O/gpu_tests_full.txt | tail -20
-for p in fp16 fp16h; do timeout 600 python tools/measure_smallnet_tol.py $p 2>/dev/null | tail -1; done > $O/smallnet_tol.txt; cat $O/smallnet_tol.txt
-VNQA_TEST_LOW_PRECISION=bf16 VNQA_HALF=bf16 timeout 600 python tools/measure_smallnet_tol.py bf16 2>/dev/null | tail -1 >> $O/smallnet_tol.txt; tail -1 $O/smallnet_tol.txt
-bash tools/prof_corun.sh > $O/corun_attribution.txt 2>&1; head -40 $O/corun_attribution.txt | cut -c1-150
+timeout 1500 python -m pytest tests/test_gpu_models.py tests/test_gpu_fp16h.py -m gpu -q -p no:cacheprovider -k "golden or goldens" > $O/t_tol.txt 2>&1; tail -3 $O/t_tol.txt
+for s in 0 1; do timeout 900 python tools/diag_gp_tail.py --seed $s 2>/dev/null | tail -3; done > $O/gp_tail.txt; cat $O/gp_tail.txt
+bash tools/refresh_profiles.sh 6 > $O/refresh.log 2>&1; tail -2 $O/refresh.log | cut -c1-600
+bash tools/prof_corun.sh > $O/corun_attribution.txt 2>&1; head -30 $O/corun_attribution.txt | cut -c1-150
+bash tools/ladder.sh > $O/ladder.txt 2>&1; cat $O/ladder.txt

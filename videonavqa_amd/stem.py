@@ -578,6 +578,7 @@ class FrozenStem(object):
             # precision 'fp16h': written TWICE, [x' | x'] — conv_init then runs as x' w_hi + x' w_lo, a plain conv over 2 C channels against
             # split weights (its remaining weight rounding, ~0.1e-6 of the 0.22e-6 left, for one more product on a 14 x 14 layer)
             od[5]["twin_out"] = bool(self.hyb and FEATURE_TWIN)
+            od[5]["out_shift2"] = torch.cat([mu["feat"], mu["feat"]])          # (the twin buffer's halo: -mean in both halves)
             self.feature_shift = mu["feat"]
         self.shift = mu
         self._fused_first_shift = v0["tile"] is None
@@ -796,7 +797,7 @@ class FrozenStem(object):
             osh = ly.get("out_shift")
             out = self._buf(key + (("split",) if split_wr else ()) + (("twin",) if twin else ()),
                             (n, ho + 2 * yh, wo + 2 * yh, (2 if twin else max(split_wr, 1)) * ly["c_out_pad"]),
-                            halo=(yh, torch.cat([osh, osh]) if (twin and osh is not None) else osh))
+                            halo=(yh, ly.get("out_shift2") if twin else osh))
             post = ly["post"]
             f32e = (2 if twin else 1) if (post is not None and osh is not None) else 0
             ps, pt = (post[0], post[1]) if post else (None, None)
