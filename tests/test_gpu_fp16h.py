@@ -749,3 +749,35 @@ def test_mean_shifted_storage_is_exact_algebra_and_lowers_the_stem_error():
     finally:
         S.MEAN_SHIFT = 1
         torch.set_grad_enabled(True)
+
+
+def test_calibration_without_feature_means_keeps_split_features():
+    """A calibration written before round 6 carries the channel means of the stem's inner tensors but not of the FEATURES ('feat'): the
+    inner tensors are stored mean-shifted, the features go out as the round-5 split tensor [hi | lo | hi] and conv_init runs its
+    three products — every combination stays a supported, tested plan."""
+    from videonavqa_amd.models.common import FrameLayout
+    from videonavqa_amd.stem import FrozenStem
+    torch.set_grad_enabled(False)
+    try:
+        lay = FrameLayout([2, 1], 2, "cuda")
+        clip = torch.rand(2, 3, 224, 224, 2, generator=torch.Generator().manual_seed(71)).cuda()
+        vgg32, od32 = _random_stem("fp32")
+        ref = FrozenStem(vgg32, od32, "fp32")
+        vgg, od = _random_stem("fp16h")
+        full = FrozenStem(vgg, od, "fp16h")
+        assert full.feature_shift is not None and full.feature_segs == 2 and full.split_active == 0
+        # (a means-only calibration: with its "frames" entry the stem would re-run the calibration pass and find the feature means itself)
+        old = {k: v for k, v in full.calib.items() if k not in ("feat", "frames")}
+        part = FrozenStem(vgg, od, "fp16h", calibration=old)
+        assert part.shift and part.feature_shift is None and part.feature_segs == 3 and part.split_active == 1
+        r = ref.forward_clip(clip, lay.img_of, lay.n_img).double()[:, 1:-1, 1:-1, :512]
+        for st in (full, part):
+            f = st.plain_features(st.forward_clip(clip, lay.img_of, lay.n_img)).double()[:, 1:-1, 1:-1, :512]
+            assert float((f - r).abs().max()) < 3e-3 * float(r.abs().max())
+        plain = FrozenStem(vgg, od, "fp16h", split_features=False)          # consumers that read plain, un-shifted features (MACNetwork)
+        assert plain.feature_shift is None and plain.feature_segs == 1
+        f = plain.forward_clip(clip, lay.img_of, lay.n_img)
+        assert f.shape[-1] == 512 and float(f[:, 0].abs().max()) == 0
+        assert float((f.double()[:, 1:-1, 1:-1] - r).abs().max()) < 3e-3 * float(r.abs().max())
+    finally:
+        torch.set_grad_enabled(True)
