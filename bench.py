@@ -109,7 +109,8 @@ def build(args, device):
                                                **({"num_tail_channels": args.tail_channels} if getattr(args, "tail_channels", 0) else {}))
     vgg, od, model = vgg.to(device).eval(), od.to(device).eval(), model.to(device)
     # (args.calibration: frames [N, 3, H, W] of the deployment's kind for the stem's weight rounding and channel means — tests / tools)
-    stem = FrozenStem(vgg, od, prec, calibration=getattr(args, "calibration", "auto"), split_features=args.model != "mac")
+    stem = FrozenStem(vgg, od, prec, calibration=getattr(args, "calibration", "auto"), split_features=args.model != "mac",
+                      split_depth=getattr(model, "stem_split_depth", None))      # (pooling heads ask for split depth 3)
     COMPOSED_STEM[0] = stem.composed is not None
     return model, stem, vgg, od
 

@@ -644,19 +644,20 @@ def test_fp16h_meets_1e3_on_data_that_does_not_look_like_the_calibration_frames(
     assert flips == 0
 
 
-@pytest.mark.parametrize("model,frames,tol", [("time_multi_hop", 70, 1e-3), ("film_gp_pt", 35, 1.75e-3)])
-def test_fp16h_pooling_heads_at_full_size(model, frames, tol):
-    """BASELINE.json configs 5 and 3 in the headline precision.  A pooling head hands single-frame values to its
-    classifier where the attention head averages over frames: 2.5 - 3 x the sensitivity to the same roundings.  Round 6, two weight
-    seeds x three minibatches: the multi-hop model at T = 70 reads 0.44 - 0.63e-3 (round 5: 0.84 - 1.25e-3) and is asserted AT the
-    tolerance; the global-pooling model reads 0.61 - 1.34e-3 (round 5: 1.26 - 1.81e-3): still outside 1e-3 on one of six minibatches —
-    stated measured + 30 %, NOT the tolerance (only precision 'fp32' complies there)."""
+@pytest.mark.parametrize("model,frames", [("time_multi_hop", 70), ("film_gp_pt", 35)])
+def test_fp16h_pooling_heads_at_full_size(model, frames):
+    """BASELINE.json configs 5 and 3 in the headline precision, asserted AT the tolerance.  A pooling head hands
+    single-frame values to its classifier where the attention head averages over frames: 2.5 - 3 x the sensitivity to the same roundings.
+    Two weight seeds x three minibatches: the multi-hop model at T = 70 reads 0.44 - 0.65e-3 on the default stem plan (round 5: 0.84 -
+    1.25e-3); the global-pooling model reads 0.61 - 1.34e-3 on it and 0.68 - 0.82e-3 with conv22's / conv31's outputs kept as split
+    tensors on top of the mean-shifted storage — which its class asks for (`stem_split_depth = 3`, read by bench.build and the CLIs;
+    832 instead of 874 clips/s; round 5: 1.26 - 1.81e-3)."""
     worst = 0.0
     for seed in (0, 1):
         rel, flips = _full_size_errors(seed, "noise", batches=3, model=model, frames=frames)
         worst = max(worst, max(rel))
         assert flips == 0, (model, seed, flips)
-    assert worst <= tol, (model, worst)
+    assert worst <= 1e-3, (model, worst)
 
 
 def test_stem_calibration_on_the_deployments_own_frames_is_measured():

@@ -375,7 +375,8 @@ def main(argv=None):
                 print("=> WARNING: --stem_calibration %s, but the checkpoint was trained behind a stem calibrated on '%s': using the "
                       "checkpoint's" % (args.stem_calibration, kind))
             calib = saved
-    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=calib, split_features=args.model != 'mac')
+    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=calib, split_features=args.model != 'mac',
+                      split_depth=getattr(model, 'stem_split_depth', None))
     check_stem_against_checkpoint(stem, ckpt, rank)
     if rank == 0 and args.precision == 'fp16h':
         print('=> stem: precision fp16h, %d split activation tensors, weights %s' %

@@ -133,7 +133,8 @@ def main(argv=None):
                   "frames are not available here — pass 'noise' or 'off', whichever the training run used. Aborting.")
             sys.exit(-1)
         calib = stem_calibration(args, None)
-    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=calib, split_features=args.model != 'mac')
+    stem = FrozenStem(feature_extractor, obj_detector, args.precision, calibration=calib, split_features=args.model != 'mac',
+                      split_depth=getattr(model, 'stem_split_depth', None))
     check_stem_against_checkpoint(stem, checkpoint)
     if args.precision == 'fp16h':
         print('=> stem: precision fp16h, %d split activation tensors' % stem.split_active)

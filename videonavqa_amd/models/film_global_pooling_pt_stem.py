@@ -9,6 +9,13 @@ from .common import FiLMTrunkBase, compute_dtype, grad_scale_of, repeated_questi
 class FiLMGlobalPoolingPretrainedStem(FiLMTrunkBase):
     """Signature/defaults: film_global_pooling_pt_stem.py:13-23; extra keyword-only spatial_size, precision."""
 
+    # A pooling head hands single-frame values to its classifier (no averaging over frames: 2.5 - 3 x the attention head's sensitivity to the
+    # stem's roundings): its stem keeps conv22's / conv31's outputs and the features as split tensors on top of the mean-shifted storage
+    # (FrozenStem(split_depth=3): 832 instead of 874 clips/s).  Measured at 8 x 35 x 224^2, precision fp16h vs fp32: 0.68 - 0.82e-3 instead of
+    # 0.61 - 1.34e-3 (profiles/r06_pooling_heads.txt; the multi-hop model's T = 70 reads 0.44 - 0.65e-3 either way and keeps the default
+    # plan).  Read by bench.build and the CLIs when they build the model's FrozenStem.
+    stem_split_depth = 3
+
     def __init__(self, batch_size, q_embedding_size, nb_classes, num_input_channels=512,
                  num_res_block_channels=512, num_tail_channels=16, num_res_blocks=1, hidden_size=128,
                  q_encoder='lstm', vocab_size=134, *, spatial_size=130, precision='fp16h'):

@@ -282,32 +282,31 @@ def _fold_bn(bn):
 class FrozenStem(object):
     """Execution plan (packed weights + persistent activation buffers) for the frozen stem.
 
-    precision: 'bf16' | 'fp16' (16-bit storage, fp32 accumulate: the MFMA fast path), 'fp32' (the exact-f32 parity path), or
-    'fp16h' — the tolerance mode (round 5): the fp16 precision's stem, same kernels and rounded weights, except that the LAST THREE
-    stored activations (conv22's pooled output, conv31's, conv32's = the features) are SPLIT tensors (hi = fp16(v), lo = fp16(v - hi),
-    written by the patch-stationary kernel's dual epilogue): conv31 / conv32 are plain convs over 2 C input channels [hi | lo]
-    against the doubled 16-bit weights [wq | wq] — x_hi wq + x_lo wq, the unrounded activation in two products — and the features
-    go out as [hi | lo | hi] for conv_init's three products (its weights are trainable and split per step).  The three activation
-    roundings that weigh most in the logits error (profiles/r05_precision_budget*.txt: 0.047 / 0.047 / 0.073 of the fp16 precision's
-    0.70e-6 squared error) are gone for one extra product on the two CHEAPEST layers (14 x 14 maps); the weight roundings of those
-    layers (0.022 / 0.041 rounded coherently) are 0.0003 / 0.0002 with the second-order rounding below.  Without a calibration
-    (None, or a means-only dict from an older checkpoint) the split-reading layers run as three products over [hi | lo | hi] against
-    split exact weights [w_hi | w_hi | w_lo] instead.  split_features=False keeps the features a plain fp16 tensor (consumers that
-    read no split tensors: MACNetwork, the per-module drop-in path).
+    precision: 'fp16h' (default) | 'fp16' | 'bf16' (16-bit storage, fp32 accumulate: the MFMA fast path) | 'fp32' (the exact-f32 parity path).
 
-    calibration: how the frozen 16-bit weights are rounded.  None = round-to-nearest.  "noise" or a tensor of frames [N, 3, H, W]
-    (values in [0, 1]) = ONE exact-f32 stem pass over those frames (CALIBRATION_FRAMES seeded synthetic frames by default — half uniform
-    noise, half smooth: default_calibration_frames) measures every
-    layer's input-patch second moment H = E[p p^T], and each layer's weights (BatchNorm scale folded, the conv11.conv12 pair composed)
-    are rounded by second_order_round: column by column, the rounding error pushed onto the not yet rounded columns along H^-1, which
-    greedily minimises dw^T H dw — the mean squared error the rounding adds to the layer's output.  (Round 4's coherent_round cancels the
-    error against the MEAN input only; it remains the form for layers without a measured H and for means-only calibrations.)
-    Squared logits error of all nine stem weight roundings, x 1e-6 at the headline size: round-to-nearest 0.58, coherent 0.074, second
-    order 0.009 on clips like the calibration frames; 0.34 / 0.116 / 0.050 on smooth clips with noise calibration
-    (profiles/r05_gptq_stem_weights.txt).  Same kernels, same bytes; ~3 s at construction.  A dict = an earlier calibration (a
-    checkpoint's `extra_state['_stem_calibration']`: its "frames" entry — "noise" or the frames — is what the rounding is redone
-    from, so the test-time stem gets the weights the model was trained behind).  "auto" = "noise" for every 16-bit precision;
-    VNQA_COHERENT_ROUND=0 turns it off."""
+    calibration: what the frozen 16-bit weights are rounded against and what the stored activations are shifted by.  None = round to
+    nearest, un-shifted storage.  "noise" (= "auto") or a tensor of frames [N, 3, H, W] (values in [0, 1]; `--stem_calibration data`) = ONE
+    exact-f32 stem pass over those frames (CALIBRATION_FRAMES seeded synthetic frames by default, half uniform noise, half smooth:
+    default_calibration_frames) measures every layer's input-patch second moment H = E[p p^T] and every stored tensor's channel means:
+      * each layer's weights (BatchNorm scale folded, the conv11.conv12 pair composed) are rounded by second_order_round — column by
+        column, the error pushed onto the not yet rounded columns along H^-1: the nine weight roundings cost 0.009e-6 of squared logits
+        error instead of 0.58 (nearest) / 0.074 (round 4's mean-cancelling coherent_round, still the form for means-only calibrations);
+      * every stored activation — the image list, conv1_1's LDS-resident output, the fused first conv's, conv2_1's, conv2_2's, the
+        composed pair's, conv21's, conv22's, conv31's and (for the FiLM trunk, `split_features=True`) the features — is stored
+        MEAN-SHIFTED, value minus the channel mean (_setup_mean_shift: the consumer's bias absorbs the mean, the halo holds -mean, no
+        extra product): the seven single-product stem roundings cost 0.08 instead of 0.27e-6 on noise clips, 0.17 instead of 0.75 on
+        piecewise-constant ones.
+    A dict = an earlier calibration (a checkpoint's `extra_state['_stem_calibration']`): its "frames" entry — "noise" or the frames — is
+    what the pass is redone from; a means-only dict gets the first-order rounding and whatever shifts it has means for.
+    VNQA_COHERENT_ROUND=0 / VNQA_MEAN_SHIFT=0 turn the two off (A/B partners).
+
+    precision 'fp16h' and split_depth: with mean-shifted storage the stem needs NO split tensor (split_depth 0 = automatic); the features go
+    out twice, [x' | x'], for conv_init's two products against split weights (FEATURE_TWIN).  split_depth = 3 additionally keeps conv22's and
+    conv31's outputs as [hi | lo] tensors read by two-product layers (the pooling-head models ask for it: `stem_split_depth`), 4 / 5 add
+    conv21's / the composed pair's (measured: nothing gained, -6 % / -13 %).  Without channel means (older calibrations) the round-5 form
+    runs: split depth 3 with [hi | lo | hi] features into a three-product conv_init.  Dual outputs come from the patch-stationary kernel's
+    fp32 epilogue and, where it does not serve the geometry (the 10 x 13 maps of 160 x 208 frames) or the layer (the composed 5x5), from the
+    implicit-GEMM tile's.  split_features=False: plain un-shifted features (consumers that are not the FiLM trunk: MACNetwork)."""
 
     def __init__(self, vgg, objdet, precision='fp16h', calibration="auto", split_features=True, reserve_cus=0, split_depth=None):
         from .models.common import compute_dtype
