@@ -16,7 +16,7 @@ import bench as B          # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp16h", "fp32"])
+    ap.add_argument("--precision", default="fp16h", choices=["bf16", "fp16", "fp16h", "fp32"])
     ap.add_argument("--no-prefetch", action="store_true", help="run each step's stem inline instead of under the previous trunk")
     ap.add_argument("--every", type=int, default=25, help="print every N steps")
     ap.add_argument("--model", default="film_attn_pt", choices=["film_attn_pt", "film_gp_pt", "time_multi_hop", "mac"])

@@ -786,7 +786,7 @@ class FrozenStem(object):
             yh = ly.get("y_halo", 1)
             last = not (i + 1 < len(layers) + first_index)
             key = (tag, i, ho, wo) if not last else (tag, i, ho, wo, last_slot)
-            # precision 'fp16h': [hi | lo | hi] tensors between conv22, conv31, conv32 and the trunk (see the class docstring)
+            # split tensors between layers (split_depth >= 2) / mean-shifted outputs / twin features: see the class docstring
             split_rd = "wt_split" in ly and x.shape[-1] == ly["wt_split"].shape[2]
             split_wr = int(ly.get("split_out", 0))
             x_segs = x.shape[-1] // ly["c_out_pad"] if split_rd else 1      # (c_in == c_out on the split-reading layers)
@@ -843,7 +843,10 @@ class FrozenStem(object):
     def forward_clip(self, clip, img_of, n_img, slot=0):
         """clip fp32 [B,3,H,W,T] on the GPU — or uint8 raw pixels k, meaning k / 255 exactly as the reference's loader forms it
         (eval/dataset.py:91; VNQADataset(uint8_video=True)) —; img_of int32 [B*T] (image index or -1).
-        Returns padded NHWC [n_img, H/16+2, W/16+2, Cpad] in the compute dtype (precision 'fp16h': 3 Cpad channels, [hi | lo | hi]).
+        Returns padded NHWC [n_img, H/16+2, W/16+2, feature_segs * Cpad] in the compute dtype — plain features, or (the FiLM trunk's form,
+        see the class docstring) the mean-shifted features `x' = x - feature_shift` once (feature_segs 1: 'fp16' / 'bf16') or twice
+        ([x' | x'], feature_segs 2: 'fp16h'), or a split tensor [hi | lo | hi] (feature_segs 3: calibrations without feature means);
+        plain_features() turns any of them into the plain fp32 tensor.
         `slot` selects one of several OUTPUT buffers (the intermediates are shared), so that the
         features of step i stay alive for its backward while step i+1's stem already runs."""
         assert self.vgg is not None and self.objdet is not None
