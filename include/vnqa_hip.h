@@ -35,7 +35,7 @@ extern "C" {
 /* ABI version of this header: bumped whenever an entry point, a struct layout or an enum value changes.  vnqa_version() returns
  * the value the LIBRARY was built with; the Python binding (videonavqa_amd/_lib.py: ABI_VERSION) refuses a library that
  * reports a different one (a stale build supplied through VNQA_LIB / kept with VNQA_NO_REBUILD=1). */
-#define VNQA_ABI_VERSION 430
+#define VNQA_ABI_VERSION 432
 int vnqa_version(void);
 const char* vnqa_last_error(void);
 
@@ -263,6 +263,18 @@ int vnqa_ring_edge_gather_all(const void* y1, void* out, int32_t n_img, int32_t 
                               int32_t group_rows, int32_t dtype, void* stream);
 int vnqa_ring_assemble(const void* top, const void* bottom, const void* left, const void* right, void* ring,
                        int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream);
+/* Round 6 — the border correction as FOUR composed edge convs (no ring tensor):
+ *   vnqa_conv2d_border_edge_fwd : out[n][j][co] = bias[co] + sum_{t < 5, c} x[n][border row / column, j + t - 2][c] wt[co][t][c] for edge
+ *                           0/1/2/3 = top/bottom/left/right; x: halo-2 images [n][h+4][w+4][c_in]; wt [c_out][5][c_in] = conv12's edge
+ *                           taps composed with conv11's facing taps (stem._compose_pair); out dense [n][w | h][c_out].  K = 5 c_in
+ *                           instead of 3 c_in + 3 c_mid: a quarter of the two-step form's FLOPs at 128 -> 512 -> 512.
+ *   vnqa_ring_assemble_corners : vnqa_ring_assemble with corner [n][4][c] (or NULL) SUBTRACTED from the four corner pixels (top-left,
+ *                           top-right, bottom-left, bottom-right): the outside-ring CORNER position is adjacent to one pixel only, and both
+ *                           of that pixel's edge convs count it. */
+int vnqa_conv2d_border_edge_fwd(const void* x, const void* wt, const float* bias, void* out, int32_t n_img, int32_t h, int32_t w,
+                                int32_t c_in, int32_t c_out, int32_t edge, int32_t dtype, void* stream);
+int vnqa_ring_assemble_corners(const void* top, const void* bottom, const void* left, const void* right, const void* corner, void* ring,
+                               int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream);
 
 /* Persistent direct 3x3 conv for c_in == 64 (bf16): weights resident in LDS, 16x16 tiles with a DMA'd
  * 18x18 halo patch, no barrier inside the K loop.  Same contract as vnqa_conv2d_igemm_fwd restricted to

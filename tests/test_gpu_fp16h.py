@@ -782,3 +782,38 @@ def test_calibration_without_feature_means_keeps_split_features():
         assert float((f.double()[:, 1:-1, 1:-1] - r).abs().max()) < 3e-3 * float(r.abs().max())
     finally:
         torch.set_grad_enabled(True)
+
+
+@pytest.mark.parametrize("prec,hw", [("fp32", (224, 224)), ("fp32", (160, 208)), ("fp16", (224, 224)), ("fp16", (160, 208))])
+def test_composed_edge_border_correction_equals_the_two_step_form(prec, hw):
+    """Round 6: the composed pair's border correction as four composed 1x5 / 5x1 edge convs + a corner term (vnqa_conv2d_border_edge_fwd,
+    vnqa_ring_assemble_corners) against the two-step form (conv11 on the outside ring, then conv12's edge taps).  Exact-f32 precision: the
+    same features to fp32 summation order everywhere incl. the four corner pixels; fp16: within storage roundings, and both equally close
+    to the exact stem on the border."""
+    from videonavqa_amd import stem as S
+    from videonavqa_amd.models.common import FrameLayout
+    H, W = hw
+    torch.set_grad_enabled(False)
+    try:
+        lay = FrameLayout([2, 1], 2, "cuda")
+        clip = torch.rand(2, 3, H, W, 2, generator=torch.Generator().manual_seed(81)).cuda()
+        vgg, od = _random_stem(prec)
+        feats = {}
+        for flag in (True, False):
+            S.RING_COMPOSED_EDGES = flag
+            st = S.FrozenStem(vgg, od, prec)
+            assert st.composed is not None
+            feats[flag] = st.plain_features(st.forward_clip(clip, lay.img_of, lay.n_img)).double()[:, 1:-1, 1:-1, :512].clone()
+        S.RING_COMPOSED_EDGES = True
+        a, b = feats[True], feats[False]
+        scale = float(b.abs().max())
+        if prec == "fp32":
+            assert float((a - b).abs().max()) < 2e-5 * scale, float((a - b).abs().max()) / scale
+        else:
+            vgg32, od32 = _random_stem("fp32")
+            r = S.FrozenStem(vgg32, od32, "fp32").forward_clip(clip, lay.img_of, lay.n_img).double()[:, 1:-1, 1:-1, :512]
+            ea, eb = float((a - r).pow(2).mean().sqrt()), float((b - r).pow(2).mean().sqrt())
+            assert ea < 1.1 * eb and float((a - r).abs().max()) < 6e-3 * scale, (ea, eb)
+    finally:
+        S.RING_COMPOSED_EDGES = True
+        torch.set_grad_enabled(True)

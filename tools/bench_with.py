@@ -11,7 +11,7 @@ for word in sys.argv[1:cut]:
     k, v = word.split("=")
     mod, name = k.rsplit(".", 1)
     m = importlib.import_module("videonavqa_amd." + mod)
-    setattr(m, name, type(getattr(m, name))(int(v)))
+    setattr(m, name, (bool(int(v)) if isinstance(getattr(m, name), bool) else type(getattr(m, name))(int(v))))
 import bench  # noqa: E402
 
 sys.argv = ["bench.py"] + sys.argv[cut + 1:]

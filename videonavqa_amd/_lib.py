@@ -37,7 +37,7 @@ def is_half(dt):
     return dt in (torch.bfloat16, torch.float16)
 
 BF16, F32 = 0, 1
-ABI_VERSION = 430          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
+ABI_VERSION = 432          # include/vnqa_hip.h: VNQA_ABI_VERSION (checked against vnqa_version() of the loaded library)
 TILE_AUTO, TILE_256x256, TILE_256x128, TILE_256x64, TILE_128x128, TILE_128x64, TILE_STEM_256x256 = range(7)
 TILE_256x256_W16 = 13      # include/vnqa_hip.h: VNQA_TILE_256x256_W16
 TILE_I5_256x256, TILE_STEM_I5_256x256 = 18, 19     # hand-pipelined main loop (PIPE 5)
@@ -217,6 +217,8 @@ _SIGNATURES = {
     "vnqa_pack_fc_weight": (ctypes.c_int, [_vp] + [_i32] * 7 + [_vp, _vp, _vp]),
     "vnqa_unpack_fc_wgrad": (ctypes.c_int, [_vp] + [_i32] * 5 + [_vp, _vp]),
     "vnqa_clip_to_nhwc4": (ctypes.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_conv2d_border_edge_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vnqa_ring_assemble_corners": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_clip_to_nhwc4_shifted": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_clip_u8_to_nhwc4": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vnqa_conv_first_c64_fwd": (ctypes.c_int, [_vp] * 10),

@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
       const int rs = tap - 9 * q;
       r = rs / 3;
       s = rs - 3 * r;
-    } else if (p.taps == 3) {        // 1x3 window along a row (vnqa_ring_edge_conv_fwd), or 3x1 down a column (vnqa_conv2d_ring_edge_fwd)
+    } else if (p.taps == 3 || p.taps == 5) {   // 1x3 / 1x5 window along a row, or 3x1 / 5x1 down a column (the border-correction edge launches)
       r = p.tap3_vertical ? tap : 0;
       s = p.tap3_vertical ? 0 : tap;
     } else {
@@ -422,9 +422,10 @@ __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64) conv_igemm_kernel(const
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     // K position of a stage (tap = (q, r, sx) window coordinates, kc = 64-channel chunk), advanced incrementally: the
     // per-stage offsets cost a handful of scalar instructions instead of a division chain behind the barrier
-    const int kw = (p.taps == 9 || p.taps == 27 || (p.taps == 3 && !p.tap3_vertical)) ? 3 : (p.taps == 25 ? 5 : 1);
-    const int kh = (p.taps == 9 || p.taps == 27 || (p.taps == 3 && p.tap3_vertical)) ? 3 : (p.taps == 25 ? 5 : 1);
-    const int r_base = (p.taps == 9 || p.taps == 25 || p.taps == 27 || p.taps == 3) ? 0 : p.x_halo;   // 1x1: the centre tap
+    const bool line = p.taps == 3 || p.taps == 5;      // a 1 x taps (or taps x 1) window
+    const int kw = (p.taps == 9 || p.taps == 27) ? 3 : (p.taps == 25 ? 5 : ((line && !p.tap3_vertical) ? p.taps : 1));
+    const int kh = (p.taps == 9 || p.taps == 27) ? 3 : (p.taps == 25 ? 5 : ((line && p.tap3_vertical) ? p.taps : 1));
+    const int r_base = (p.taps == 9 || p.taps == 25 || p.taps == 27 || line) ? 0 : p.x_halo;   // 1x1: the centre tap
     struct KPos { int tap, kc, q, r, sx; };
     auto kpos_at = [&](int kt) {
       KPos k;
@@ -1730,6 +1731,53 @@ extern "C" int vnqa_conv2d_ring_edge_fwd(const void* x, const void* wt, const fl
   a.M = n_img * len; a.tilesN = 0; a.wt_tiled = 0; a.D = 0;
   // output position j of image n -> y1p[n][base + j]: a row of Rp entries per image (positions along x), or Rp rows of one (along y)
   a.Hyp = edge < 2 ? 1 : Rp; a.Wyp = edge < 2 ? Rp : 1;
+  a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr; a.group_tiles = 0;
+  a.epi = VNQA_EPI_NONE; a.ring_h = 0; a.ring_w = 0;
+  a.frame_of = nullptr; a.stats_partial = nullptr; a.film_gamma = nullptr; a.film_beta = nullptr;
+  a.film_ld = 0; a.film_c = 0; a.res = nullptr; a.y2 = nullptr;
+  int tile = VNQA_TILE_128x128;
+  if (dtype == VNQA_BF16) {
+    const int pad256 = (a.M + 255) / 256 * 256, pad128 = (a.M + 127) / 128 * 128;
+    tile = pad128 >= pad256 ? VNQA_TILE_256x128 : VNQA_TILE_128x128;
+  }
+  return conv_dispatch(a, dtype, tile, (hipStream_t)stream);
+}
+
+// The border correction of the composed conv11.conv12 pair, ONE EDGE, as a single 1x5 (top / bottom) or 5x1 (left / right) conv over the
+// image's border row / column (round 6): conv12's taps that reach outside the image multiply conv11 evaluated on the outside ring, and
+// conv11 there sees the image through ONE kernel row / column only — so edge e's correction of border pixel j is
+//   out[n][j][co] = bias[co] + sum_{t < 5, c} x[n][border row / column, j + t - 2][c] * wt[co][t][c]
+// with wt = the composition of conv12's edge taps and conv11's facing taps (made by the caller in float64: stem._compose_pair) —
+// K = 5 c_in instead of the two-step form's 3 c_in + 3 c_mid (vnqa_conv2d_ring_edge_fwd + vnqa_ring_edge_conv_fwd), a quarter of its FLOPs
+// at 128 -> 512 -> 512, one launch instead of two and no ring tensor.  The four corner pixels' double-counted term is the caller's
+// (vnqa_ring_assemble_corners).  x: halo-2 images [n][h+4][w+4][c_in] (the halo supplies the window's two pixels beyond the image's
+// ends); out: dense [n][w | h][c_out]; edge 0/1/2/3 = top/bottom/left/right.
+extern "C" int vnqa_conv2d_border_edge_fwd(const void* x, const void* wt, const float* bias, void* out, int32_t n_img, int32_t h, int32_t w,
+                                           int32_t c_in, int32_t c_out, int32_t edge, int32_t dtype, void* stream) {
+  VNQA_CHECK_ARG(x && wt && out && n_img > 0 && h >= 2 && w >= 2 && edge >= 0 && edge < 4, "conv2d_border_edge_fwd: bad arguments");
+  VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "conv2d_border_edge_fwd: bad dtype %d", dtype);
+  const int bk = dtype == VNQA_BF16 ? 64 : 32, es = dtype == VNQA_BF16 ? 2 : 4;
+  VNQA_CHECK_ARG(c_in > 0 && c_in % bk == 0 && c_out > 0 && c_out % 8 == 0, "conv2d_border_edge_fwd: c_in %% %d, c_out %% 8", bk);
+  const int Wp = w + 4;
+  const int len = edge < 2 ? w : h;
+  // first tap of the first window in the halo-2 image: (padded row of the border row, padded column 0) / (padded row 0, padded column of the border column)
+  const int row0 = edge == 0 ? 2 : (edge == 1 ? h + 1 : 0), col0 = edge < 2 ? 0 : (edge == 2 ? 2 : w + 1);
+  ConvArgs a;
+  a.x = (const char*)x + ((size_t)row0 * Wp + col0) * c_in * es;
+  a.x_wrap2 = 0;
+  a.xcd_split = 0;
+  a.zero_halo = 0;
+  a.wt = (const char*)wt;
+  a.bias = bias; a.post_scale = nullptr; a.post_shift = nullptr;
+  a.y = (char*)out;
+  a.n_img = n_img;
+  a.H = edge < 2 ? 1 : len; a.W = edge < 2 ? len : 1;
+  a.Hp = h + 4; a.Wp = Wp;
+  a.Cin = c_in; a.Cout = c_out; a.Cy = c_out;
+  a.taps = 5; a.tap3_vertical = edge < 2 ? 0 : 1;
+  a.x_halo = 0; a.y_halo = 0; a.relu = 0; a.pool = 0;
+  a.M = n_img * len; a.tilesN = 0; a.wt_tiled = 0; a.D = 0;
+  a.Hyp = edge < 2 ? 1 : len; a.Wyp = edge < 2 ? len : 1;
   a.slices = 1; a.kt_per_slice = 1 << 30; a.partial = nullptr; a.border_sub = nullptr; a.group_tiles = 0;
   a.epi = VNQA_EPI_NONE; a.ring_h = 0; a.ring_w = 0;
   a.frame_of = nullptr; a.stats_partial = nullptr; a.film_gamma = nullptr; a.film_beta = nullptr;

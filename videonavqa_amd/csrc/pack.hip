@@ -288,10 +288,13 @@ __global__ void __launch_bounds__(256) ring_edge_gather_kernel(const uint4* __re
 
 // ring[n][2W + 2(H-2)][c] = top | bottom | left[1:-1] | right[1:-1], corners += left/right ends   (float accumulate)
 // One thread per 16-byte chunk of a ring row (8 bf16 / 4 f32), 256 threads cover 256 / (C * sizeof(T) / 16) rows.
+// corner != NULL (vnqa_ring_assemble_corners): [n][4][C], SUBTRACTED from the four corner pixels (top-left, top-right, bottom-left,
+// bottom-right): the term both of a corner's edge convs counted (vnqa_conv2d_border_edge_fwd)
 template <typename T>
 __global__ void __launch_bounds__(256) ring_assemble_kernel(const T* __restrict__ top, const T* __restrict__ bottom,
                                                             const T* __restrict__ left, const T* __restrict__ right,
-                                                            T* __restrict__ ring, int n_img, int H, int W, int C) {
+                                                            T* __restrict__ ring, int n_img, int H, int W, int C,
+                                                            const T* __restrict__ corner) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cpr = C / EPC;                                 // chunks per row
   const int RL = 2 * W + 2 * (H - 2);
@@ -309,15 +312,22 @@ __global__ void __launch_bounds__(256) ring_assemble_kernel(const T* __restrict_
   };
 #pragma unroll
   for (int k = 0; k < EPC; ++k) v[k] = 0.f;
+  auto sub_corner = [&](int which) {
+    if (corner == nullptr) return;
+    const uint4 raw = *(const uint4*)(corner + ((size_t)n * 4 + which) * C + c);
+    const T* e = (const T*)&raw;
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) v[k] -= ElemOps<T>::load(e[k]);
+  };
   if (r < W) {
     add(top, r, W);
-    if (r == 0) add(left, 0, H);
-    if (r == W - 1) add(right, 0, H);
+    if (r == 0) { add(left, 0, H); sub_corner(0); }
+    if (r == W - 1) { add(right, 0, H); sub_corner(1); }
   } else if (r < 2 * W) {
     const int x = r - W;
     add(bottom, x, W);
-    if (x == 0) add(left, H - 1, H);
-    if (x == W - 1) add(right, H - 1, H);
+    if (x == 0) { add(left, H - 1, H); sub_corner(2); }
+    if (x == W - 1) { add(right, H - 1, H); sub_corner(3); }
   } else if (r < 2 * W + H - 2) {
     add(left, r - 2 * W + 1, H);
   } else {
@@ -614,8 +624,8 @@ extern "C" int vnqa_ring_edge_gather_all(const void* y1, void* out, int32_t n_im
   return VNQA_OK;
 }
 
-extern "C" int vnqa_ring_assemble(const void* top, const void* bottom, const void* left, const void* right, void* ring,
-                                  int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream) {
+extern "C" int vnqa_ring_assemble_corners(const void* top, const void* bottom, const void* left, const void* right, const void* corner,
+                                          void* ring, int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream) {
   VNQA_CHECK_ARG(top && bottom && left && right && ring && n_img > 0 && h >= 2 && w >= 2, "ring_assemble: bad arguments");
   VNQA_CHECK_ARG(dtype == VNQA_BF16 || dtype == VNQA_F32, "ring_assemble: bad dtype %d", dtype);
   const int es = dtype == VNQA_BF16 ? 2 : 4;
@@ -625,10 +635,15 @@ extern "C" int vnqa_ring_assemble(const void* top, const void* bottom, const voi
   if (dtype == VNQA_BF16)
     hipLaunchKernelGGL(ring_assemble_kernel<vnqa_bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const vnqa_bf16*)top,
                        (const vnqa_bf16*)bottom, (const vnqa_bf16*)left, (const vnqa_bf16*)right, (vnqa_bf16*)ring, n_img, h,
-                       w, c);
+                       w, c, (const vnqa_bf16*)corner);
   else
     hipLaunchKernelGGL(ring_assemble_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)top,
-                       (const float*)bottom, (const float*)left, (const float*)right, (float*)ring, n_img, h, w, c);
+                       (const float*)bottom, (const float*)left, (const float*)right, (float*)ring, n_img, h, w, c, (const float*)corner);
   VNQA_CHECK_LAUNCH();
   return VNQA_OK;
+}
+
+extern "C" int vnqa_ring_assemble(const void* top, const void* bottom, const void* left, const void* right, void* ring,
+                                  int32_t n_img, int32_t h, int32_t w, int32_t c, int32_t dtype, void* stream) {
+  return vnqa_ring_assemble_corners(top, bottom, left, right, nullptr, ring, n_img, h, w, c, dtype, stream);
 }

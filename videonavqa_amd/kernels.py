@@ -397,12 +397,28 @@ def gemm_nt_grouped(a, b, out=None):
     return out
 
 
-def ring_assemble(top, bottom, left, right, n, H, W):
+def ring_assemble(top, bottom, left, right, n, H, W, corner=None):
+    """The four edge parts [n * (W | H), c] -> border_sub [n, 2W + 2(H-2), c] (corner pixels: the sum of their two edges, minus
+    `corner` [n, 4 * c] — top-left, top-right, bottom-left, bottom-right — when given: vnqa_ring_assemble_corners)."""
     c = top.shape[-1]
     ring = torch.empty((n, 2 * W + 2 * (H - 2), c), dtype=top.dtype, device=top.device)
-    L.check(L.lib().vnqa_ring_assemble(L.ptr(top), L.ptr(bottom), L.ptr(left), L.ptr(right), L.ptr(ring), n, H, W, c,
-                                       L.dtype_id(top.dtype), L.stream()), "vnqa_ring_assemble")
+    if corner is not None:
+        assert corner.shape == (n, 4 * c) and corner.dtype == top.dtype and corner.is_contiguous()
+    L.check(L.lib().vnqa_ring_assemble_corners(L.ptr(top), L.ptr(bottom), L.ptr(left), L.ptr(right), L.ptr(corner), L.ptr(ring), n, H, W, c,
+                                               L.dtype_id(top.dtype), L.stream()), "vnqa_ring_assemble")
     return ring
+
+
+def border_edge_conv(x, wt5, bias, H, W, edge):
+    """One edge of the composed pair's border correction as a 1x5 / 5x1 conv over the image's border row / column
+    (vnqa_conv2d_border_edge_fwd): x halo-2 padded NHWC [n, H+4, W+4, c_in], wt5 [c_out, 5, c_in] -> [n * (W | H), c_out]."""
+    n, _, _, c_in = x.shape
+    c_out = wt5.shape[0]
+    assert wt5.shape == (c_out, 5, c_in) and wt5.dtype == x.dtype and wt5.is_contiguous()
+    out = torch.empty((n * (W if edge < 2 else H), c_out), dtype=x.dtype, device=x.device)
+    L.check(L.lib().vnqa_conv2d_border_edge_fwd(L.ptr(x), L.ptr(wt5), L.ptr(bias), L.ptr(out), n, H, W, c_in, c_out, edge,
+                                                L.dtype_id(x.dtype), L.stream()), "vnqa_conv2d_border_edge_fwd")
+    return out
 
 
 def conv2d_c64(x, wt, bias=None, relu=False, pool2=False, post_scale=None, post_shift=None, out=None, shape4=False,

@@ -269,6 +269,8 @@ MEAN_SHIFT = 1               # 16-bit precisions with a calibration: store the s
 SPLIT_DEPTH = 0              # precision 'fp16h': how many of the stem's LAST stored activations are split tensors (see FrozenStem);
                              # 0 = automatic: none needed with mean-shifted storage (1: the features, only where the consumer cannot
                              # take shifted ones), 3 without it (round 5's form)
+RING_COMPOSED_EDGES = True   # the composed pair's border correction as four composed 1x5 / 5x1 edge convs + a corner term (round 6); False: the
+                             # two-step form (conv11 on the outside ring, then conv12's edge taps: RING_EDGE_LAUNCHES) — the A/B partner
 RING_EDGE_LAUNCHES = True    # conv11 on the outside ring as four 3-tap launches (False: one 9-tap launch, same bits: the A/B partner)
 CALIBRATION_FRAMES = 40      # frames of the default ("noise") calibration pass: 40 x 196 patches > K = 4608 of the 14 x 14 layers
 
@@ -541,6 +543,12 @@ class FrozenStem(object):
             w1 = cp["w1m"].view(cp["c_mid_pad"], 9, -1).double()
             cp["b1_edges"] = [cp["b1"] + corr(w1[:, list(t), :].sum(1), mu["c22"], cp["c_mid_pad"]) for t in K.RING_EDGE_TAPS]
             cp["b1"] = cp["b1"] + corr(w1.sum(1), mu["c22"], cp["c_mid_pad"])            # (the one-launch nine-tap form)
+            # the composed edge convs read the shifted tensor (halo -mu) through all five taps; the corner GEMM reads the corner pixels
+            cp["edge5_bias"] = [b + corr(w.double().sum(1), mu["c22"], cp["c_out_pad"]) for w, b in zip(cp["edge5"], cp["edge5_bias"])]
+            ci_pad = cp["edge5"][0].shape[2]
+            cwd = cp["corner_w"].double()
+            cp["corner_bias"] = cp["corner_bias"] + torch.cat(
+                [cwd[k * cp["c_out_pad"]:(k + 1) * cp["c_out_pad"], k * ci_pad:(k + 1) * ci_pad] @ mu["c22"][:ci_pad].double() for k in range(4)]).float()
             cp["post"] = (ones(cp["c_out_pad"]), -mu["comp"])
             cp["out_shift"] = mu["comp"]
             if cp["tile"] == L.TILE_STEM_256x256:
@@ -697,7 +705,33 @@ class FrozenStem(object):
             return e.view(co_pad, -1).to(dev).to(self.cdt).contiguous()
         edges = dict(top=edge(w2[:, :, 0, :]), bottom=edge(w2[:, :, 2, :]), left=edge(w2[:, :, :, 0]), right=edge(w2[:, :, :, 2]))
         wsum = wcf.to(self.cdt).double().sum((2, 3)) if half else None
+        # ... and the SAME border correction with conv11 composed into conv12's edge taps (round 6): a ring position one pixel outside the
+        # image sees the image through ONE kernel row / column of conv11 only, so edge e's correction of border pixel j is a 1x5 / 5x1 conv
+        # over the border row / column, W_e[t] = sum_{a + b = t} (s W2)[edge tap a] W1[facing tap b] (128 -> 512, K = 5 c_in), bias
+        # sum_a (s W2)[a] b1 — a quarter of the two-step form's FLOPs.  The outside CORNER position is adjacent to the corner pixel only and
+        # both of that pixel's edges count it: its term (a 1x1 conv of the corner pixel) is subtracted (ring_assemble(corner=...)).
+        w2e = {0: [w2[:, :, 0, a] for a in range(3)], 1: [w2[:, :, 2, a] for a in range(3)],
+               2: [w2[:, :, a, 0] for a in range(3)], 3: [w2[:, :, a, 2] for a in range(3)]}
+        w1f = {0: [w1[:, :, 2, b] for b in range(3)], 1: [w1[:, :, 0, b] for b in range(3)],
+               2: [w1[:, :, b, 2] for b in range(3)], 3: [w1[:, :, b, 0] for b in range(3)]}
+        edge5, edge5_bias = [], []
+        for e in range(4):
+            we = torch.zeros(co_pad, 5, ci_pad, dtype=torch.float64)
+            for a in range(3):
+                for b in range(3):
+                    we[:co, a + b, :ci] += w2e[e][a] @ w1f[e][b]
+            edge5.append(we.to(dev).to(self.cdt).contiguous())
+            edge5_bias.append(K.pad_vec(sum(w2e[e][a] @ b1 for a in range(3)).float().to(dev), co_pad))
+        # corners (top-left, top-right, bottom-left, bottom-right): (s W2)[corner tap] (b1 + W1[facing corner tap] x[corner pixel]) as ONE
+        # GEMM over the four corner pixels side by side against a block-diagonal weight matrix
+        ctap = [((0, 0), (2, 2)), ((0, 2), (2, 0)), ((2, 0), (0, 2)), ((2, 2), (0, 0))]
+        cw = torch.zeros(4 * co_pad, 4 * ci_pad, dtype=torch.float64)
+        cb = torch.zeros(4 * co_pad, dtype=torch.float64)
+        for k, ((r2, s2), (r1, s1)) in enumerate(ctap):
+            cw[k * co_pad:k * co_pad + co, k * ci_pad:k * ci_pad + ci] = w2[:, :, r2, s2] @ w1[:, :, r1, s1]
+            cb[k * co_pad:k * co_pad + co] = w2[:, :, r2, s2] @ b1
         return dict(wt=wt, bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges, _wsum=wsum,
+                    edge5=edge5, edge5_bias=edge5_bias, corner_w=cw.to(dev).to(self.cdt).contiguous(), corner_bias=cb.float().to(dev),
                     w1_edges=K.ring_edge_weights(w1m.view(cm_pad, 9, ci_pad)),
                     c_in=ci, c_out=co, c_out_pad=co_pad, c_mid_pad=cm_pad, tile=tile, taps=25)
 
@@ -711,15 +745,22 @@ class FrozenStem(object):
         H, W = hp - 4, wp - 4
         cm = cp["c_mid_pad"]
         R = 2 * (W + 2) + 2 * H
-        y1p = self._buf(key + ("y1p", H, W), (n, R + 4, cm))
-        # (edge by edge with the three taps that can see the image: a third of the one-launch form's K, whose other products are against
-        # the zero halo; RING_EDGE_LAUNCHES = False runs that form: the same bits)
-        if RING_EDGE_LAUNCHES:
-            K.conv2d_ring_edges(x, cp["w1_edges"], cp.get("b1_edges", cp["b1"]), H, W, y1p)
+        if RING_COMPOSED_EDGES and "edge5" in cp and cp["edge5"][0].shape[2] == ci_pad:
+            # round 6: four composed 1x5 / 5x1 edge convs straight from the halo-2 image + the corner term (see _compose_pair)
+            part = [K.border_edge_conv(x, cp["edge5"][e], cp["edge5_bias"][e], H, W, e) for e in range(4)]
+            corners = torch.cat([x[:, 2, 2], x[:, 2, W + 1], x[:, H + 1, 2], x[:, H + 1, W + 1]], dim=1)      # [n, 4 ci_pad]
+            cfix = K.gemm_nt(corners, cp["corner_w"], bias=cp["corner_bias"], split_k=False)
+            ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W, corner=cfix)
         else:
-            K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W, out_padded=y1p)
-        part = [K.ring_edge_conv(y1p, cp["edges"][name], H, W, e) for e, name in enumerate(("top", "bottom", "left", "right"))]
-        ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
+            # (edge by edge with the three taps that can see the image: a third of the one-launch form's K, whose other products are against
+            # the zero halo; RING_EDGE_LAUNCHES = False runs that form: the same bits)
+            y1p = self._buf(key + ("y1p", H, W), (n, R + 4, cm))
+            if RING_EDGE_LAUNCHES:
+                K.conv2d_ring_edges(x, cp["w1_edges"], cp.get("b1_edges", cp["b1"]), H, W, y1p)
+            else:
+                K.conv2d_ring(x, cp["w1m"].view(cm, 9, ci_pad), cp["b1"], H, W, out_padded=y1p)
+            part = [K.ring_edge_conv(y1p, cp["edges"][name], H, W, e) for e, name in enumerate(("top", "bottom", "left", "right"))]
+            ring = K.ring_assemble(part[0], part[1], part[2], part[3], n, H, W)
         ho, wo = H // 2, W // 2
         # precision 'fp16h' at split depth 5: the pair's output as a split tensor (the igemm tile's fp32 dual epilogue), conv21 reads it
         dual = self.split_segs if (self.split_depth >= 5 and cp["tile"] == L.TILE_STEM_256x256 and "wt_split" in self.layers_od[2]) else 0
