@@ -218,8 +218,11 @@ def shift_bias_correction(conv_w, shift, c_pad):
     """sum_{c, taps} W[o, c, tap] * shift[c], fp32 [c_pad]: what a per-channel constant `shift` of a conv's INPUT adds to every output —
     the bias term of mean-shifted storage (x = x' + shift everywhere, the halo included: it holds -shift).  Exact fp32 weights."""
     c_out, c_in = conv_w.shape[0], conv_w.shape[1]
+    v = torch.mv(conv_w.float().sum((2, 3)), shift[:c_in].float())          # (two launches; c_out == c_pad for the reference's widths)
+    if c_out == c_pad:
+        return v
     out = torch.zeros(c_pad, dtype=torch.float32, device=conv_w.device)
-    out[:c_out] = conv_w.float().sum((2, 3)) @ shift[:c_in].float()
+    out[:c_out] = v
     return out
 
 
@@ -341,7 +344,7 @@ class FilmTrunkHeadFn(torch.autograd.Function):
         if ctx.in_shift is not None:
             # mean-shifted input: the kernel contracted dY with x' (halo -mu included); the true input is x' + mu everywhere, so
             # every tap gets mu[c] * sum_pixels dY[o] = mu (x) db — added BEFORE the sink is handed on (data-parallel early reduce)
-            dw_t.view(C, conv_w.shape[1], -1).add_((dbias0[:C].float() * inv).view(-1, 1, 1) * ctx.in_shift[:conv_w.shape[1]].view(1, -1, 1))
+            dw_t.view(C, conv_w.shape[1], -1).addcmul_(dbias0[:C].float().view(-1, 1, 1), ctx.in_shift[:conv_w.shape[1]].view(1, -1, 1), value=inv)
         dconv_w = _ret(s_cw, dw_t)
         dconv_b = _ret(s_cb if exact else None, dbias0[:C])
         if scaled:
