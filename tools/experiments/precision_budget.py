@@ -10,7 +10,13 @@ single-point settings give the budget and combined settings check it.
 The exact pass is cross-checked against the library's exact-f32 precision (same weights), and the all-points setting against the
 library's own fp16 precision, so the restatement is known to model the product.
 
-  python tools/experiments/precision_budget.py [--seeds 0 1 2 3] [--batches 12] [--data noise|smooth] [--only-combos]
+  python tools/experiments/precision_budget.py [--seeds 0 1 2 3] [--batches 12] [--data noise|smooth|blocks|textured] [--only-combos]
+      [--height 160 --width 208] [--per-batch] [--no-product]
+      [--round6]   the round-6 settings: what is left of fp16h's error point by point on another kind of clip, candidate lo formats
+                   (e4m3 / MX-fp4), dithered rounding, and MEAN-SHIFTED storage ('shift_own' / 'shift_cal') — the measurement behind
+                   stem.FrozenStem._setup_mean_shift (profiles/r06_precision_budget_*.txt)
+NOTE: the restatement models UN-shifted fp16 storage (rounds 3-5); its cross-check against the library's precisions ("library precision
+... vs restatement") therefore shows the library BELOW the all-points setting since round 6.
 """
 import argparse
 import importlib.util
