@@ -11,7 +11,7 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 The JSON line also carries
-  roofline      dominant kernel (frozen-stem igemm): executed FLOPs / HIP-event launch time vs the dense bf16 MFMA peak
+  roofline      dominant kernel (the frozen stem's composed 5x5 conv): executed FLOPs / HIP-event launch time vs the dense bf16 MFMA peak
   cpu_baseline  the CPU oracle (a port of the reference) on this host's cores: B=8 clips, 1 warm-up + 3 timed steps
   parity        bf16 benchmark precision vs the exact-f32 parity precision on the SAME weights and batches at this very
                 workload: max logits error relative to max |logit|, argmax agreement, loss error, fp32-mode clips/s
@@ -1230,6 +1230,9 @@ def main():
                                                          "the composed 5x5 conv11.conv12 and any C_out=512 layer the patch-stationary "
                                                          "kernel does not serve; FLOPs = those its launches execute)"
                                                          % ("bf16" if args.precision == "bf16" else "f16"),
+                                    "conv_ps_kernel<28,5x5>": "conv_ps_kernel<28,2,TAG=1> (frozen-stem patch-stationary conv on v_mfma_f32_16x16x32, 5x5 "
+                                                              "instantiation: the composed conv11.conv12 on 8 x 28-pixel 2-D tiles, border correction, ReLU "
+                                                              "floor and 2x2 pool fused; FLOPs = those its launches execute)",
                                     "conv_ps_kernel<28>": "conv_ps_kernel<28,1,TAG=1> (patch-stationary 3x3 conv, 4 waves x 512 registers: conv21, "
                                                           "conv22 on 28x28 maps; FLOPs = those its launches execute)",
                                     "conv_ps_kernel<14>": "conv_ps_kernel<14,1,TAG=1> (patch-stationary 3x3 conv: conv31, conv32 on 14x14 maps)"}.get(dom, dom),

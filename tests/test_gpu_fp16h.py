@@ -817,3 +817,44 @@ def test_composed_edge_border_correction_equals_the_two_step_form(prec, hw):
     finally:
         S.RING_COMPOSED_EDGES = True
         torch.set_grad_enabled(True)
+
+
+@pytest.mark.parametrize("calibration", ["noise", None])
+def test_composed_pair_on_2d_patch_stationary_tiles_equals_the_flat_igemm_tile(calibration):
+    """Round 6: at 224 x 224 the composed 5x5 runs on the patch-stationary kernel's 8 x 28-pixel tiles (conv_ps_kernel<28, 2, 1>, with the
+    per-channel ReLU floor of mean-shifted storage, the border correction and the fused pool) instead of the implicit-GEMM tile's flat 256
+    pixels: the same 16-bit operands and fp32 accumulation in another order — the stored 16-bit outputs agree to one rounding step, nearly
+    all of them bit for bit.  At 160 x 208 (40 x 52 maps: no whole 2-D tiles) the plan keeps the igemm tile."""
+    from videonavqa_amd import stem as S
+    from videonavqa_amd.models.common import FrameLayout
+    assert S.COMPOSED_PS
+    torch.set_grad_enabled(False)
+    try:
+        lay = FrameLayout([2, 1], 2, "cuda")
+        vgg, od = _random_stem("fp16")
+        st = S.FrozenStem(vgg, od, "fp16", calibration=calibration)
+        assert st.composed is not None and st.composed.get("wt_ps") is not None
+        outs = {}
+        for hw in ((224, 224), (160, 208)):
+            clip = torch.rand(2, 3, hw[0], hw[1], 2, generator=torch.Generator().manual_seed(83)).cuda()
+            for flag in (True, False):
+                S.COMPOSED_PS = flag
+                st._tap = {}
+                st.timing = []
+                st.forward_clip(clip, lay.img_of, lay.n_img)
+                names = [ev[3] for ev in st.timing if len(ev) > 3]
+                y = [v for v in st._tap.values() if v.shape[1:] == (hw[0] // 8 + 2, hw[1] // 8 + 2, 512)]
+                outs[hw, flag] = (y[0].float().clone(), names)
+                st._tap, st.timing = None, None
+        S.COMPOSED_PS = True
+        a, b = outs[(224, 224), True], outs[(224, 224), False]
+        assert "conv_ps_kernel<28,5x5>" in a[1] and "conv_ps_kernel<28,5x5>" not in b[1] and "conv_igemm_kernel" in b[1]
+        scale = float(b[0].abs().max())
+        d = (a[0] - b[0]).abs()
+        assert float(d.max()) <= 2.0 ** -10 * scale, float(d.max()) / scale
+        assert float((d > 0).float().mean()) < 0.02
+        c, e = outs[(160, 208), True], outs[(160, 208), False]
+        assert "conv_ps_kernel<28,5x5>" not in c[1] and torch.equal(c[0], e[0])
+    finally:
+        S.COMPOSED_PS = True
+        torch.set_grad_enabled(True)

@@ -87,7 +87,8 @@ def summarise(a, rows):
         md.append(line("un-profiled default run (`python bench.py`, profiles/%s_bench.json)" % tag, a.bench))
     if a.bench_nooverlap:
         md.append(line("same without the side-stream pipeline (`--no-overlap`, the stem kernel alone on the chip)", a.bench_nooverlap))
-    md += ["", "The average duration of the `conv_igemm_kernel<..., 256, 256, 2, 4, 1, 2>` row (TAG=1: the frozen-stem launches) is the",
+    md += ["", "The average duration of the `conv_ps_kernel<28, 2, 1>` row (the patch-stationary kernel's 5x5 instantiation: the composed",
+           "conv11.conv12 — `conv_igemm_kernel<..., 256, 256, 2, 4, 1, 2>` where VNQA_COMPOSED_PS=0 or the geometry has no whole 2-D tiles) is the",
            "number `roofline.avg_launch_ms` must agree with (kernel durations are inflated when the trunk co-runs; the stem-alone",
            "passes bench.py runs after the timed region for `stem_alone_ms` are in this trace too).", "",
            "| kernel | calls/step | ms/step | avg µs | % GPU time |", "|---|---|---|---|---|"]

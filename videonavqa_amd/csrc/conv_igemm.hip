@@ -1543,7 +1543,8 @@ static int fill_conv_args(const vnqa_conv_desc* d, const void* x, const void* wt
   VNQA_CHECK_ARG(border_sub == nullptr || d->c_out % 4 == 0, "conv2d_igemm_fwd: border_sub needs c_out % 4 == 0");
   VNQA_CHECK_ARG(!d->pool2 || (d->h % 2 == 0 && d->w % 2 == 0), "conv2d_igemm_fwd: pool2 needs even h,w");
   if (d->flags & VNQA_CONV_RELU_FLOOR) {
-    VNQA_CHECK_ARG(post_scale == nullptr && post_shift != nullptr && d->tile == VNQA_TILE_STEM_256x256 && d->relu == 1 && d->c_out % 4 == 0 &&
+    VNQA_CHECK_ARG(post_scale == nullptr && post_shift != nullptr && (d->tile == VNQA_TILE_STEM_256x256 || d->tile == VNQA_TILE_STEM_PS_224x256) &&
+                       d->relu == 1 && d->c_out % 4 == 0 &&
                        !(d->flags & (VNQA_CONV_DUAL_OUT | VNQA_CONV_F32_EPILOGUE)),
                    "conv2d_igemm_fwd: VNQA_CONV_RELU_FLOOR takes post_shift (the per-channel floor) WITHOUT post_scale on the stem-tagged "
                    "256x256 tile with ReLU, c_out %% 4 == 0, plain epilogue");

@@ -91,6 +91,16 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     tile_n = t % p.tilesN;
     tile_m = t / p.tilesN;
+    if constexpr (TAG == 1) {
+      // VNQA_CONV_XCD_SPLIT_N (the composed 5x5: two cout tiles): XCD x owns cout half x & 1 only (as conv_igemm.hip)
+      if (p.xcd_split && p.tilesN == 2 && (nwg & 1) == 0) {
+        const int par = xcd & 1, j = xcd >> 1;
+        int off = 0;
+        for (int i = 0; i < j; ++i) off += q + ((2 * i + par) < r ? 1 : 0);
+        tile_n = par;
+        tile_m = off + (bid >> 3);
+      }
+    }
   }
   // column blocks: widths that are not a multiple of TC (26-wide maps of the reference's 160 x 208 frames) put the last block at
   // W - TC, overlapping its neighbour — the shared columns are computed twice to the same bits, no masking
@@ -378,6 +388,15 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) b4[e] = (co + e < p.Cout) ? p.bias[co + e] : 0.f;
     }
+    // VNQA_CONV_RELU_FLOOR (stem launches): post_shift WITHOUT post_scale is the ReLU's per-channel floor — relu(a) - m = max(a - m, -m),
+    // a mean-shifted output rounded once through this 16-bit staging (conv_igemm.hip has the same lines)
+    float fl4[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (TAG == 1) {
+      if (p.post_scale == nullptr && p.post_shift != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fl4[e] = (co + e < p.Cout) ? p.post_shift[co + e] : 0.f;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int prow = wm * WTM + i * 16 + fr;
@@ -390,7 +409,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] = acc[i][j][e] + b4[e] - sub[e];
-        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        if (p.relu) v[e] = fmaxf(v[e], fl4[e]);
       }
       uint2 pk;
       pk.x = pack2_h16(v[0], v[1]);

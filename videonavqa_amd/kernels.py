@@ -174,8 +174,8 @@ def conv2d_igemm(x, wt, bias=None, relu=False, pool2=False, post_scale=None, pos
             out = empty_padded((N, Ho + 2, Wo + 2, c_out), x.dtype, x.device)
         else:
             out = torch.zeros((N, Ho + 2 * y_halo, Wo + 2 * y_halo, c_out), dtype=x.dtype, device=x.device)
-    if relu_floor is not None:      # VNQA_CONV_RELU_FLOOR: the per-channel floor travels in the post_shift slot (stem 256x256 tile)
-        assert post_scale is None and post_shift is None and relu and not dual_out and not f32_epilogue and tile == L.TILE_STEM_256x256
+    if relu_floor is not None:      # VNQA_CONV_RELU_FLOOR: the per-channel floor travels in the post_shift slot (the stem's tiles)
+        assert post_scale is None and post_shift is None and relu and not dual_out and not f32_epilogue and tile in (L.TILE_STEM_256x256, L.TILE_STEM_PS_224x256)
         post_shift = relu_floor
         flags |= L.CONV_RELU_FLOOR
     d = L.ConvDesc(L.dtype_id(x.dtype), N, H, W, cin_w, c_out, out.shape[-1], taps, x_halo, y_halo,

@@ -271,6 +271,10 @@ SPLIT_DEPTH = 0              # precision 'fp16h': how many of the stem's LAST st
                              # take shifted ones), 3 without it (round 5's form)
 RING_COMPOSED_EDGES = True   # the composed pair's border correction as four composed 1x5 / 5x1 edge convs + a corner term (round 6); False: the
                              # two-step form (conv11 on the outside ring, then conv12's edge taps: RING_EDGE_LAUNCHES) — the A/B partner
+COMPOSED_PS = os.environ.get("VNQA_COMPOSED_PS", "1") != "0"   # the composed 5x5 on the patch-stationary 2-D tiles (8 x 28 pixels) where they serve the
+                             # geometry (224 x 224 frames: 56 x 56 maps; not the reference's 160 x 208: 40 x 52) — 5 % less kernel time than the flat
+                             # 256-pixel igemm tile (profiles/r06_composed_ps_ab.txt); False / VNQA_COMPOSED_PS=0: the igemm tile everywhere
+COMPOSED_PS_XCD = os.environ.get("VNQA_COMPOSED_PS_XCD", "1") != "0"      # ... with one cout half per XCD (fabric-side reads 1 159 -> 953 MB per launch)
 RING_EDGE_LAUNCHES = True    # conv11 on the outside ring as four 3-tap launches (False: one 9-tap launch, same bits: the A/B partner)
 CALIBRATION_FRAMES = 40      # frames of the default ("noise") calibration pass: 40 x 196 patches > K = 4608 of the 14 x 14 layers
 
@@ -696,6 +700,8 @@ class FrozenStem(object):
             wt = K.pack_conv_weight_tiled(wcf, self.cdt, tile, c_out_pad=co_pad, c_in_pad=ci_pad)
         else:
             wt = K.pack_conv_weight(wcf, self.cdt, c_out_pad=co_pad, c_in_pad=ci_pad)
+        # (K-major copy for the patch-stationary tiles: the same 16-bit values)
+        wt_ps = K.pack_conv_weight(wcf, self.cdt, c_out_pad=co_pad, c_in_pad=ci_pad) if (COMPOSED_PS and tile == L.TILE_STEM_256x256) else None
         # ring operand: W1 K-major [cm_pad][9*ci_pad]; edge operands: (s W2) slices [co_pad][3*cm_pad]
         w1m = K.pack_conv_weight(w1.float().contiguous().to(dev), self.cdt, c_out_pad=cm_pad, c_in_pad=ci_pad).view(cm_pad, -1)
 
@@ -730,7 +736,7 @@ class FrozenStem(object):
         for k, ((r2, s2), (r1, s1)) in enumerate(ctap):
             cw[k * co_pad:k * co_pad + co, k * ci_pad:k * ci_pad + ci] = w2[:, :, r2, s2] @ w1[:, :, r1, s1]
             cb[k * co_pad:k * co_pad + co] = w2[:, :, r2, s2] @ b1
-        return dict(wt=wt, bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges, _wsum=wsum,
+        return dict(wt=wt, wt_ps=wt_ps, bias=K.pad_vec(bc.float().to(dev), co_pad), b1=K.pad_vec(b1.float().to(dev), cm_pad), w1m=w1m, edges=edges, _wsum=wsum,
                     edge5=edge5, edge5_bias=edge5_bias, corner_w=cw.to(dev).to(self.cdt).contiguous(), corner_bias=cb.float().to(dev),
                     w1_edges=K.ring_edge_weights(w1m.view(cm_pad, 9, ci_pad)),
                     c_in=ci, c_out=co, c_out_pad=co_pad, c_mid_pad=cm_pad, tile=tile, taps=25)
@@ -767,16 +773,28 @@ class FrozenStem(object):
         out = self._buf(key + (ho, wo) + (("split",) if dual else ()), (n, ho + 2, wo + 2, max(dual, 1) * cp["c_out_pad"]),
                         halo=(1, cp.get("out_shift")))
         post = cp.get("post")      # mean-shifted storage: -mu after ReLU / pool, in fp32 before the ONE rounding (the tile's fp32 epilogue)
+        floor = cp.get("bias_floor") if not dual else None
+        # 2-D pixel tiles (patch-stationary kernel, 5x5 instantiation) where they serve the geometry and the epilogue is the plain one
+        ps = COMPOSED_PS and cp.get("wt_ps") is not None and not dual and (floor is not None or not post)
+        if ps:
+            ok = cp.setdefault("_ps_ok", {})
+            if (n, H, W) not in ok:
+                ok[(n, H, W)] = K.conv_ps_supported(n, H, W, ci_pad, cp["c_out_pad"], 25, True)
+            ps = ok[(n, H, W)]
         timed = self.timing is not None and cp["tile"] == L.TILE_STEM_256x256
         if timed:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         # every XCD computes ONE cout half of the composed conv (its L2 then holds 1.65 instead of 3.3 MB of weights): fabric-side reads
-        # 1 022 -> 831 MB per launch (profiles/r04_pmc_traffic*.json), time unchanged
-        floor = cp.get("bias_floor") if not dual else None
+        # 1 022 -> 831 MB per launch on the igemm tile (profiles/r04_pmc_traffic*.json), 1 159 -> 953 MB on the 2-D tiles (r06_composed_ps_ab.txt)
+        ps_flags = L.CONV_XCD_SPLIT_N if COMPOSED_PS_XCD else 0
         if floor is not None:
-            y = K.conv2d_igemm(x, cp["wt"], bias=floor[0], relu=True, pool2=True, x_halo=2, y_halo=1, out=out, tile=cp["tile"],
-                               border_sub=ring, desc_flags=L.CONV_XCD_SPLIT_N, relu_floor=floor[1])
+            y = K.conv2d_igemm(x, cp["wt_ps"] if ps else cp["wt"], bias=floor[0], relu=True, pool2=True, x_halo=2, y_halo=1, out=out,
+                               tile=L.TILE_STEM_PS_224x256 if ps else cp["tile"], border_sub=ring, desc_flags=ps_flags if ps else L.CONV_XCD_SPLIT_N,
+                               relu_floor=floor[1])
+        elif ps:
+            y = K.conv2d_igemm(x, cp["wt_ps"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out, tile=L.TILE_STEM_PS_224x256,
+                               border_sub=ring, desc_flags=ps_flags)
         else:
             y = K.conv2d_igemm(x, cp["wt"], bias=cp["bias"], relu=True, pool2=True, x_halo=2, y_halo=1, out=out, tile=cp["tile"],
                                border_sub=ring, desc_flags=L.CONV_XCD_SPLIT_N if L.is_half(self.cdt) else 0, dual_out=dual,
@@ -784,7 +802,7 @@ class FrozenStem(object):
                                f32_epilogue=bool(post) and not dual and cp["tile"] == L.TILE_STEM_256x256)
         if timed:
             ev1.record()
-            self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25, "conv_igemm_kernel"))
+            self.timing.append((ev0, ev1, 2.0 * n * H * W * cp["c_in"] * cp["c_out"] * 25, ("conv_ps_kernel<%d,5x5>" % (28 if W % 28 == 0 else 14)) if ps else "conv_igemm_kernel"))
         if self._tap is not None:
             self._tap[key] = y
         return y
