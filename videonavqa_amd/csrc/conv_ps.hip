@@ -173,6 +173,12 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = vnqa_f32x4{0.f, 0.f, 0.f, 0.f};
   vnqa_f32x4 xf0[TM], wf0[TN], xf1[TM], wf1[TN];
 
+#ifdef VNQA_PS_STAGGER      // experiment builds only (tools/experiments/ps_stagger.sh): do two tiles that read the same lines share them through L2 when
+  // the second asks ~3 us later instead of at the same time?  1: the odd cout half waits; 2: odd pixel tiles wait
+  if ((VNQA_PS_STAGGER == 1 && (tile_n & 1)) || (VNQA_PS_STAGGER == 2 && (tile_m & 1))) {
+    __builtin_amdgcn_s_sleep(100);
+  }
+#endif
   // ---- prologue: the whole patch of chunk 0, weights of K-steps 0 and 1 ----
   asm volatile("s_nop 4" ::: "memory");
 #pragma unroll
