@@ -32,10 +32,13 @@ def timed(fn, it=30):
     return e0.elapsed_time(e1) / it * 1e3
 
 
-for n, h, w, cin, cout, taps, segs in ((280, 14, 14, 512, 512, 9, 1), (280, 14, 14, 512, 512, 9, 3), (280, 14, 14, 512, 512, 1, 1),
-                                       (1120, 14, 14, 1024, 1024, 9, 1), (280, 20, 26, 512, 512, 9, 1)):
+SHAPES = ((280, 14, 14, 512, 512, 9, 1), (280, 14, 14, 512, 512, 9, 3), (280, 14, 14, 512, 512, 1, 1),
+          (1120, 14, 14, 1024, 1024, 9, 1), (280, 20, 26, 512, 512, 9, 1))
+if "--headline-only" in sys.argv:
+    SHAPES = SHAPES[:1]
+for n, h, w, cin, cout, taps, segs in SHAPES:
     x, dy = padded(n, h, w, cin * segs), padded(n, h, w, cout)
     fl = 2.0 * n * h * w * cin * cout * taps
-    for name, ew in (("4-wave ring", False), ("8-wave", True)):
-        us = timed(lambda: K.conv2d_wgrad(x, dy, taps, x_segs=segs, eight_waves=ew))
+    for name, ew, cs in (("4-wave rows", False, False), ("4-wave ring", False, True), ("8-wave", True, False)):
+        us = timed(lambda: K.conv2d_wgrad(x, dy, taps, x_segs=segs, eight_waves=ew, compact_stages=cs))
         print("%4d x %dx%d  %4d -> %4d  taps %d  x segments %d  %-12s %7.1f us  %6.0f TFLOP/s" % (n, h, w, cin, cout, taps, segs, name, us, fl / us / 1e6))
