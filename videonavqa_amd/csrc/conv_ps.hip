@@ -65,6 +65,12 @@ __device__ __forceinline__ void ps_glds(const char* sbase, unsigned voff, unsign
 template <int TC, int HALO> constexpr int ps_rm() { return TC == 14 ? (HALO == 1 ? VNQA_PS_RM14 : 6) : 4; }
 template <int TC, int HALO> __device__ __forceinline__ int ps_swz(int row, int col) { return (col + ps_rm<TC, HALO>() * row) & 6; }
 
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+// Diagnostic build only (tools/experiments/ps_inkernel_clock.py; MI355X_MICROARCH.md, DVFS item 6): s_memtime (shader clock) and s_memrealtime
+// (100 MHz) stamped around the K loop by one lane of every workgroup of the 5x5 instantiation, into a buffer of their own.
+__device__ unsigned long long g_ps_stamps[8 * 16384];
+#endif
+
 template <int TC, int HALO, int TAG>
 __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   using namespace ps;
@@ -76,6 +82,9 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   constexpr int WOFF = 2 * PATCH_BYTES;        // weight slabs behind the two patch buffers
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+  const unsigned long long st_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -202,6 +211,9 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) wf0[j] = *(const vnqa_f32x4*)(smem + w_rd0 + j * 2048);
 
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   int slab = 0;                                  // slab of the current K-step's weights = kt & 1
   constexpr int PPT = (PIW + NTAPS - 4) / (NTAPS - 3);     // patch pieces of the next chunk issued per tap (taps 0 .. NTAPS-4)
   for (int kc = 0; kc < kchunks; ++kc) {
@@ -229,9 +241,13 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
         if (slot < TN) wf1[slot] = *(const vnqa_f32x4*)(smem + (w_rd0 ^ 64) + slab * B_BYTES + slot * 2048);
       }
       __builtin_amdgcn_sched_barrier(0);
+#if !defined(VNQA_PS_DIAG) || VNQA_PS_DIAG != 2
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // weights of K-step kt+1 and any patch piece issued a K-step ago have landed
+#endif
       __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): every fragment of this K-step is in registers
+#if !defined(VNQA_PS_DIAG) || VNQA_PS_DIAG != 1          // timing-only builds (tools/experiments/ps_kstep_diag.sh): 1 = no mid-step barrier, 2 = no DMA wait
       __builtin_amdgcn_s_barrier();                        // slab (kt & 1) is free; slab ((kt+1) & 1) / the next patch are visible
+#endif
       // ---- phase 1: substep 1 MFMAs; behind them the 15 fragment reads of K-step kt+1 / substep 0 (groups 0..7), the 8
       //      weight DMA instructions of K-step kt+2 and the patch pieces of the next chunk ----
 #pragma unroll
@@ -256,6 +272,17 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
       slab ^= 1;
     }
   }
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+  if (HALO == 2 && threadIdx.x == 0 && blockIdx.x < 16384) {
+    const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+    g_ps_stamps[8 * blockIdx.x + 0] = st_c1 - st_c0;
+    g_ps_stamps[8 * blockIdx.x + 1] = st_r1 - st_r0;
+    g_ps_stamps[8 * blockIdx.x + 2] = st_r0 - st_entry;
+    g_ps_stamps[8 * blockIdx.x + 3] = (unsigned long long)kchunks * NTAPS;
+    g_ps_stamps[8 * blockIdx.x + 4] = st_entry;
+    g_ps_stamps[8 * blockIdx.x + 5] = st_r1;
+  }
+#endif
   // wait states between the last MFMAs and the first read of an accumulator (8-pass XDL: 12+), then free the LDS
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -287,26 +314,47 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
       if (wn == pass) {
+        float b4a[TN][4];              // (all of the pass's bias values requested before the first is used: see the plain epilogue)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int co = tile_n * BN + pass * WTN + j * 16 + 4 * fh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float bv = p.bias != nullptr ? p.bias[co + e < p.Cout ? co + e : p.Cout - 1] : 0.f;
+            b4a[j][e] = co + e < p.Cout ? bv : 0.f;
+          }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int col = j * 16 + 4 * fh;                 // within this pass's 128 couts
-          const int co = tile_n * BN + pass * WTN + col;
-          float b4[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias != nullptr) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) b4[e] = (co + e < p.Cout) ? p.bias[co + e] : 0.f;
-          }
+          const float* b4 = b4a[j];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
             const int prow = wm * WTM + i * 16 + fr;
             float4 v;
             v.x = acc[i][j][0] + b4[0]; v.y = acc[i][j][1] + b4[1]; v.z = acc[i][j][2] + b4[2]; v.w = acc[i][j][3] + b4[3];
-            if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (p.relu) {      // (one v_max each: fmaxf canonicalises its operands first)
+              asm("v_max_f32 %0, %0, 0" : "+v"(v.x)); asm("v_max_f32 %0, %0, 0" : "+v"(v.y));
+              asm("v_max_f32 %0, %0, 0" : "+v"(v.z)); asm("v_max_f32 %0, %0, 0" : "+v"(v.w));
+            }
             *(float4*)(smem + prow * CROWF + col * 4) = v;
           }
         }
       }
       __syncthreads();
+      // (a thread keeps its channel chunk over the loop — NT % CHF == 0 —: its 16 affine constants are fetched ONCE per pass, not in
+      // every iteration behind the previous iteration's store)
+      static_assert(NT % CHF == 0, "dual store loop: constant chunk per thread");
+      float psc[8], psh[8];
+      {
+        const int cq = tile_n * BN + pass * WTN + (threadIdx.x % CHF) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int cc = cq + e < p.Cout ? cq + e : p.Cout - 1;
+          psc[e] = has_post_d ? p.post_scale[cc] : 1.f;
+          psh[e] = has_post_d ? p.post_shift[cc] : 0.f;
+        }
+      }
       for (int idx = threadIdx.x; idx < rows_out_d * CHF; idx += NT) {
         const int orow = idx / CHF, c = idx - orow * CHF;
         const int co0 = tile_n * BN + pass * WTN + c * 8;
@@ -332,7 +380,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
         }
         if (has_post_d) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
+          for (int e = 0; e < 8; ++e) v[e] = v[e] * psc[e] + psh[e];
         }
         unsigned hw[4], lw[4];
 #pragma unroll
@@ -367,63 +415,117 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   // composed-conv border correction (vnqa_conv2d_igemm_fwd_ex): row of the correction tensor for each of this lane's pixels
   // (-1: interior pixel or no correction); ring order: top row, bottom row, left column, right column
   int ring_row[TM];
+  {
+    // (5x5 tiles never straddle images — ps_geometry —: one image / first row per tile, scalar; 3x3 tiles may: per pixel)
+    const int n0 = g0 / p.H, y00 = g0 - n0 * p.H;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ring_row[i] = -1;
+      if (p.border_sub != nullptr) {
+        const int ml = wm * WTM + i * 16 + fr;
+        const int tr = ml / TC, tc = ml - tr * TC;
+        const int g = g0 + tr;
+        if (g < total_rows) {
+          int n = n0, y = y00 + tr;
+          if constexpr (HALO != 2) {
+            n = g / p.H;
+            y = g - n * p.H;
+          }
+          const int x = xb + tc;
+          int ring = -1;
+          if (y == 0) ring = x;
+          else if (y == p.H - 1) ring = p.W + x;
+          else if (x == 0) ring = 2 * p.W + (y - 1);
+          else if (x == p.W - 1) ring = 2 * p.W + (p.H - 2) + (y - 1);
+          if (ring >= 0) ring_row[i] = n * (2 * p.W + 2 * (p.H - 2)) + ring;
+        }
+      }
+    }
+  }
+  // Every global operand of this loop — bias, the ReLU floor, the border correction of this lane's border pixels — is requested in ONE batch
+  // before the first is used.  (Round 6: fetched where they were used, each (j, i) fragment waited for its own 8-byte correction load and each j
+  // for its bias / floor loads — up to 40 serial L2 round trips per tile of the composed 5x5, whose every tile touches the image border.)
+  // Unpredicated loads from clamped addresses, selected ONCE where they land: one wave per SIMD pays an issue slot for every instruction of
+  // the 56-fragment loop below, which is down to read accumulator / add / subtract / max / convert / store.
+  // VNQA_CONV_RELU_FLOOR (stem launches): post_shift WITHOUT post_scale is the ReLU's per-channel floor — relu(a) - m = max(a - m, -m),
+  // a mean-shifted output rounded once through this 16-bit staging (conv_igemm.hip has the same lines); no ReLU: floor = -inf.
+  float b4[TN][4], fl4[TN][4];
+  const bool has_floor = TAG == 1 && p.post_scale == nullptr && p.post_shift != nullptr;
+  const bool vec4 = (p.Cout & 3) == 0;       // (always, for the K-major packs of this library: c_out padded to 64)
+  const float* const bias_p = p.bias;
+  const float* const floor_p = p.post_shift;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = tile_n * BN + wn * WTN + j * 16 + 4 * fh;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), fv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec4) {
+      const unsigned cc = co + 3 < p.Cout ? (unsigned)co * 4u : 0u;       // 32-bit byte offset from a uniform base
+      if (bias_p != nullptr) bv = *(const float4*)((const char*)bias_p + cc);
+      if (has_floor) fv = *(const float4*)((const char*)floor_p + cc);
+    } else {
+      float bb[4] = {0.f, 0.f, 0.f, 0.f}, ff[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int cc = co + e < p.Cout ? co + e : p.Cout - 1;
+        if (bias_p != nullptr) bb[e] = bias_p[cc];
+        if (has_floor) ff[e] = floor_p[cc];
+      }
+      bv = make_float4(bb[0], bb[1], bb[2], bb[3]);
+      fv = make_float4(ff[0], ff[1], ff[2], ff[3]);
+    }
+    b4[j][0] = bv.x; b4[j][1] = bv.y; b4[j][2] = bv.z; b4[j][3] = bv.w;       // (couts past the tensor: finite values, never stored)
+    fl4[j][0] = fv.x; fl4[j][1] = fv.y; fl4[j][2] = fv.z; fl4[j][3] = fv.w;
+    if (!p.relu) fl4[j][0] = fl4[j][1] = fl4[j][2] = fl4[j][3] = -INFINITY;
+  }
+  // border correction: only the pixel fragments with a border pixel in this wave ask for it (a wave's 112 pixels are 4 tile rows: the image's
+  // left / right column lands in up to four of its seven fragments, the top / bottom row in two or three), only their border lanes load, and all of
+  // a fragment's eight loads are in flight together; the subtraction below runs under the same lane mask
+  const bool has_sub = p.border_sub != nullptr;
+  // (c_out % 16 == 0 with a correction — the launcher checks —: a 16-cout fragment column is inside the tensor or outside it as a whole, a
+  // wave-uniform test; couts outside are computed on finite garbage and never stored)
+  uint2 subraw[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    ring_row[i] = -1;
-    if (p.border_sub != nullptr) {
-      const int ml = wm * WTM + i * 16 + fr;
-      const int tr = ml / TC, tc = ml - tr * TC;
-      const int g = g0 + tr;
-      if (g < total_rows) {
-        const int n = g / p.H, y = g - n * p.H, x = xb + tc;
-        int ring = -1;
-        if (y == 0) ring = x;
-        else if (y == p.H - 1) ring = p.W + x;
-        else if (x == 0) ring = 2 * p.W + (y - 1);
-        else if (x == p.W - 1) ring = 2 * p.W + (p.H - 2) + (y - 1);
-        if (ring >= 0) ring_row[i] = n * (2 * p.W + 2 * (p.H - 2)) + ring;
+    if (has_sub && ring_row[i] >= 0) {
+      const unsigned ro = (unsigned)ring_row[i] * (unsigned)p.Cout * 2u + (unsigned)(tile_n * BN + wn * WTN + 4 * fh) * 2u;     // (< 2^32: checked by the launcher)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned cj = tile_n * BN + wn * WTN + j * 16 < p.Cout ? (unsigned)(j * 32) : 0u;
+        subraw[i][j] = *(const uint2*)((const char*)p.border_sub + (ro + cj));
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = wn * WTN + j * 16 + 4 * fh;
-    const int co = tile_n * BN + col;
-    float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr) {
+  for (int i = 0; i < TM; ++i) {
+    const int prow = wm * WTM + i * 16 + fr;
+    float v[TN][4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) b4[e] = (co + e < p.Cout) ? p.bias[co + e] : 0.f;
-    }
-    // VNQA_CONV_RELU_FLOOR (stem launches): post_shift WITHOUT post_scale is the ReLU's per-channel floor — relu(a) - m = max(a - m, -m),
-    // a mean-shifted output rounded once through this 16-bit staging (conv_igemm.hip has the same lines)
-    float fl4[4] = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (TAG == 1) {
-      if (p.post_scale == nullptr && p.post_shift != nullptr) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) fl4[e] = (co + e < p.Cout) ? p.post_shift[co + e] : 0.f;
+      for (int e = 0; e < 4; ++e) v[j][e] = acc[i][j][e] + b4[j][e];
+    if (has_sub && ring_row[i] >= 0) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const uint2 raw = subraw[i][j];
+        v[j][0] -= h16_lo(raw.x); v[j][1] -= h16_hi(raw.x); v[j][2] -= h16_lo(raw.y); v[j][3] -= h16_hi(raw.y);
       }
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int prow = wm * WTM + i * 16 + fr;
-      float sub[4] = {0.f, 0.f, 0.f, 0.f};
-      if (ring_row[i] >= 0 && co + 3 < p.Cout) {
-        const uint2 raw = *(const uint2*)((const char*)p.border_sub + ((size_t)ring_row[i] * p.Cout + co) * 2);
-        sub[0] = h16_lo(raw.x); sub[1] = h16_hi(raw.x); sub[2] = h16_lo(raw.y); sub[3] = h16_hi(raw.y);
-      }
-      float v[4];
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * WTN + j * 16 + 4 * fh;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = acc[i][j][e] + b4[e] - sub[e];
-        if (p.relu) v[e] = fmaxf(v[e], fl4[e]);
-      }
+      for (int e = 0; e < 4; ++e)      // max(v, floor) as ONE instruction (fmaxf: a canonicalising v_max of each operand first)
+        asm("v_max_f32 %0, %1, %2" : "=v"(v[j][e]) : "v"(v[j][e]), "v"(fl4[j][e]));
       uint2 pk;
-      pk.x = pack2_h16(v[0], v[1]);
-      pk.y = pack2_h16(v[2], v[3]);
+      pk.x = pack2_h16(v[j][0], v[j][1]);
+      pk.y = pack2_h16(v[j][2], v[j][3]);
       *(uint2*)(smem + prow * CROW + col * 2) = pk;
     }
   }
   __syncthreads();
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+  if (HALO == 2 && threadIdx.x == 0 && blockIdx.x < 16384) g_ps_stamps[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
 
   constexpr int CH = BN * 2 / 16;       // 16-byte chunks per tile row
 #ifndef VNQA_PS_EPI_UNBATCHED       // (tools/build_variant.py unbatched -DVNQA_PS_EPI_UNBATCHED: the A/B partner)
@@ -557,6 +659,17 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   const bool has_post = (p.post_scale != nullptr);
   const int rows_out = p.pool ? BM / 4 : BM;
   const int OC = p.pool ? TC / 2 : TC;  // output columns per tile row
+  static_assert(NT % CH == 0, "store loop: constant chunk per thread");
+  float psc[8], psh[8];                 // (fetched once: a thread keeps its channel chunk)
+  {
+    const int cq = tile_n * BN + (threadIdx.x % CH) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int cc = cq + e < p.Cout ? cq + e : p.Cout - 1;
+      psc[e] = has_post ? p.post_scale[cc] : 1.f;
+      psh[e] = has_post ? p.post_shift[cc] : 0.f;
+    }
+  }
   for (int idx = threadIdx.x; idx < rows_out * CH; idx += NT) {
     const int orow = idx / CH, c = idx - orow * CH;
     const int co0 = tile_n * BN + c * 8;
@@ -589,7 +702,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     }
     if (has_post) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = v[e] * p.post_scale[co0 + e] + p.post_shift[co0 + e];
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * psc[e] + psh[e];
     }
     const int n = g / p.H;
     const int y = g - n * p.H;
@@ -664,6 +777,10 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
       }
     }
   }
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+  __syncthreads();
+  if (HALO == 2 && threadIdx.x == 0 && blockIdx.x < 16384) g_ps_stamps[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int TC, int HALO, int TAG>
@@ -691,6 +808,12 @@ int launch_ps(const ConvArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+extern "C" int vnqa_ps_diag_stamps(unsigned long long* out, int n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ps_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 // Geometry the patch-stationary tiles serve (the ONE copy of the test: vnqa_conv_ps_dispatch and the exported predicate
 // vnqa_conv_ps_supported both call it).  tc: 28-wide tiles for widths that are multiples of 28, else 14-wide ones (any even width
@@ -752,7 +875,8 @@ int vnqa_conv_ps_dispatch(const ConvArgs& a, int tag, hipStream_t st) {
     }
   }
   if ((a.taps != 9 && a.taps != 25) || a.D != 0 || a.x_halo != halo || a.wt_tiled || a.partial != nullptr || a.Cin % 64 != 0 ||
-      a.Cin < 64 || a.group_tiles != 0 || a.ring_h != 0 || (a.border_sub != nullptr && a.Cout % 4 != 0) ||
+      a.Cin < 64 || a.group_tiles != 0 || a.ring_h != 0 ||
+      (a.border_sub != nullptr && (a.Cout % 16 != 0 || (long long)a.n_img * (2 * a.W + 2 * (a.H - 2)) * a.Cout * 2 >= (1ll << 32))) ||
       !(a.epi == VNQA_EPI_NONE || ((a.epi == VNQA_EPI_FILM_RES || a.epi == VNQA_EPI_ADD_MASK) && tag == 0 && !a.pool && a.y_halo == 1)) ||
       (a.zero_halo && a.y_halo != 1) || a.relu == 2) {
     vnqa_set_error("conv patch-stationary tile: needs a bf16 3x3 / 5x5 2-D conv, x_halo = 1 / 2, c_in %% 64 == 0, K-major weights; of the "
