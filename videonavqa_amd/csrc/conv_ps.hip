@@ -118,8 +118,12 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   const int xb = min(cb * TC, p.W - TC);       // first image column of this tile
   const int total_rows = p.n_img * p.H;
   const int g0 = rt * TR;
+  // image of a global row: g / H as ONE multiply-high (the store loops ask once per 16-byte chunk; a 32-bit division by a run-time divisor
+  // is ~30 instructions).  Exact for g * H < 2^32: rows < 2^31 / H is checked by the launcher's 32-bit addressing test.
+  const unsigned h_magic = 0xFFFFFFFFu / (unsigned)p.H + 1u;
+  auto img_of_row = [&](int g) { return p.H == 1 ? g : (int)__umulhi((unsigned)g, h_magic); };
   auto padrow = [&](int g) {
-    const int n = g / p.H;
+    const int n = img_of_row(g);
     return n * p.Hp + (g - n * p.H) + HALO;
   };
   const int g_last = min(g0 + TR - 1, total_rows - 1);
@@ -388,7 +392,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
           hw[e] = pack2_h16(v[2 * e], v[2 * e + 1]);
           lw[e] = pack2_h16(v[2 * e] - h16_lo(hw[e]), v[2 * e + 1] - h16_hi(hw[e]));
         }
-        const int n = g / p.H;
+        const int n = img_of_row(g);
         const int y = g - n * p.H;
         const int yo = p.pool ? (y >> 1) : y;
         const int xo = (p.pool ? xb >> 1 : xb) + occ;
@@ -428,7 +432,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
         if (g < total_rows) {
           int n = n0, y = y00 + tr;
           if constexpr (HALO != 2) {
-            n = g / p.H;
+            n = img_of_row(g);
             y = g - n * p.H;
           }
           const int x = xb + tc;
@@ -556,7 +560,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
           const int g = g0 + orr;
           ok[u] = orow < BM && g < total_rows && co0 < p.Cout;
           const int gg = ok[u] ? g : g0;
-          const int n = gg / p.H, y = gg - n * p.H;
+          const int n = img_of_row(gg), y = gg - n * p.H;
           nn[u] = n;
           ooff[u] = (((size_t)n * p.Hyp + y + 1) * p.Wyp + xb + occ + 1) * (size_t)p.Cy + co0;
           ra[u] = rb[u] = make_uint4(0u, 0u, 0u, 0u);
@@ -677,7 +681,23 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     const int g = g0 + (p.pool ? 2 * orr : orr);
     if (g >= total_rows || co0 >= p.Cout) continue;
     float v[8];
-    if (p.pool) {
+    uint4 o;
+    // no affine, no fused trunk epilogue: the staged 16-bit values go out as they are — copied, or their 2x2 maximum taken on the packed
+    // pairs (the same bits as unpack / fmaxf / repack at a tenth of the instructions: one wave per SIMD pays an issue slot for each)
+    const bool packed = !has_post && (TAG != 0 || p.epi == VNQA_EPI_NONE);
+    if (packed) {
+      if (p.pool) {
+        const int ml = 2 * orr * TC + 2 * occ;
+        const uint4 u0 = *(const uint4*)(smem + ml * CROW + c * 16), u1 = *(const uint4*)(smem + (ml + 1) * CROW + c * 16);
+        const uint4 u2 = *(const uint4*)(smem + (ml + TC) * CROW + c * 16), u3 = *(const uint4*)(smem + (ml + TC + 1) * CROW + c * 16);
+        o.x = h16x2_max(h16x2_max(u0.x, u1.x), h16x2_max(u2.x, u3.x));
+        o.y = h16x2_max(h16x2_max(u0.y, u1.y), h16x2_max(u2.y, u3.y));
+        o.z = h16x2_max(h16x2_max(u0.z, u1.z), h16x2_max(u2.z, u3.z));
+        o.w = h16x2_max(h16x2_max(u0.w, u1.w), h16x2_max(u2.w, u3.w));
+      } else {
+        o = *(const uint4*)(smem + orow * CROW + c * 16);
+      }
+    } else if (p.pool) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = -INFINITY;
 #pragma unroll
@@ -704,14 +724,13 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * psc[e] + psh[e];
     }
-    const int n = g / p.H;
+    const int n = img_of_row(g);
     const int y = g - n * p.H;
     const int yo = p.pool ? (y >> 1) : y;
     const int xo = (p.pool ? xb >> 1 : xb) + occ;
     const size_t ooff = (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
     const bool no_z = TAG == 0 && p.epi == VNQA_EPI_FILM_RES && p.y == nullptr;     // forward-only FiLM block: z is not kept
     vnqa_bf16* dst = no_z ? nullptr : (vnqa_bf16*)(p.y) + ooff;
-    uint4 o;
     if (TAG == 0 && p.epi == VNQA_EPI_ADD_MASK) {
       // y = (conv + add) * [mask > 0] on the storage-rounded conv output (v holds exactly the 16-bit values staged in LDS):
       // the FiLM block's dgrad joined with the residual branch's gradient and masked by the 1x1 conv's ReLU
@@ -725,7 +744,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
         w[2 * e + 1] = h16_hi(mw[e]) > 0.f ? v[2 * e + 1] + h16_hi(aw[e]) : 0.f;
       }
       o.x = pack2_h16(w[0], w[1]); o.y = pack2_h16(w[2], w[3]); o.z = pack2_h16(w[4], w[5]); o.w = pack2_h16(w[6], w[7]);
-    } else {
+    } else if (!packed) {
       o.x = pack2_h16(v[0], v[1]); o.y = pack2_h16(v[2], v[3]); o.z = pack2_h16(v[4], v[5]); o.w = pack2_h16(v[6], v[7]);
     }
     if (!no_z) *(uint4*)dst = o;

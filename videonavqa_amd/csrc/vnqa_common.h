@@ -59,6 +59,12 @@ __device__ __forceinline__ unsigned pack2_h16(float a, float b) {
 }
 __device__ __forceinline__ float h16_lo(unsigned w) { return bf16_to_f32((unsigned short)(w & 0xffffu)); }
 __device__ __forceinline__ float h16_hi(unsigned w) { return bf16_to_f32((unsigned short)(w >> 16)); }
+// element-wise max of two packed pairs (a 2x2 max-pool over stored values: the max of stored values IS a stored value, no rounding)
+__device__ __forceinline__ unsigned h16x2_max(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ vnqa_f32x4 VNQA_MFMA_16x16x32(vnqa_bf16x8 a, vnqa_bf16x8 b, vnqa_f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vnqa_f16x8_, a), __builtin_bit_cast(vnqa_f16x8_, b), c, 0, 0, 0);
 }
@@ -83,6 +89,14 @@ __device__ __forceinline__ unsigned pack2_h16(float a, float b) {
 // the two elements packed in a 32-bit word
 __device__ __forceinline__ float h16_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float h16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+// element-wise max of two packed pairs (a 2x2 max-pool over stored values: the max of stored values IS a stored value, no rounding);
+// bf16 has no packed max: through fp32 and back by bit selection
+__device__ __forceinline__ unsigned h16x2_max(unsigned a, unsigned b) {
+  float lo, hi;
+  asm("v_max_f32 %0, %1, %2" : "=v"(lo) : "v"(__uint_as_float(a << 16)), "v"(__uint_as_float(b << 16)));
+  asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(__uint_as_float(a & 0xffff0000u)), "v"(__uint_as_float(b & 0xffff0000u)));
+  return (__float_as_uint(hi) & 0xffff0000u) | (__float_as_uint(lo) >> 16);
+}
 __device__ __forceinline__ vnqa_f32x4 VNQA_MFMA_16x16x32(vnqa_bf16x8 a, vnqa_bf16x8 b, vnqa_f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
