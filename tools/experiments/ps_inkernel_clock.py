@@ -13,7 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["VNQA_LIB"] = os.path.join(ROOT, "videonavqa_amd", "lib", "libvnqa_psd3.so")
+os.environ["VNQA_LIB"] = os.path.join(ROOT, "videonavqa_amd", "lib", "libvnqa_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "psd3"))
 os.environ["VNQA_NO_REBUILD"] = "1"
 os.environ["VNQA_HALF"] = "bf16"
 import bench  # noqa: E402
@@ -33,7 +33,7 @@ while time.time() - t0 < 3.0:
     torch.cuda.synchronize()
     n += 10
 lib = L.lib()
-words = 8 * 7840
+words = 8 * 16384
 buf = (ctypes.c_ulonglong * words)()
 rc = lib.vnqa_ps_diag_stamps(buf, words)
 s = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)

@@ -69,6 +69,12 @@ template <int TC, int HALO> __device__ __forceinline__ int ps_swz(int row, int c
 // Diagnostic build only (tools/experiments/ps_inkernel_clock.py; MI355X_MICROARCH.md, DVFS item 6): s_memtime (shader clock) and s_memrealtime
 // (100 MHz) stamped around the K loop by one lane of every workgroup of the 5x5 instantiation, into a buffer of their own.
 __device__ unsigned long long g_ps_stamps[8 * 16384];
+#ifndef VNQA_PS_DIAG_TC          // which instantiation stamps (default: the composed pair's <28, 2, 1>)
+#define VNQA_PS_DIAG_TC 28
+#define VNQA_PS_DIAG_HALO 2
+#define VNQA_PS_DIAG_TAG 1
+#endif
+#define PS_DIAG_THIS (TC == VNQA_PS_DIAG_TC && HALO == VNQA_PS_DIAG_HALO && TAG == VNQA_PS_DIAG_TAG)
 #endif
 
 template <int TC, int HALO, int TAG>
@@ -277,7 +283,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     }
   }
 #if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
-  if (HALO == 2 && threadIdx.x == 0 && blockIdx.x < 16384) {
+  if (PS_DIAG_THIS && threadIdx.x == 0 && blockIdx.x < 16384) {
     const unsigned long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
     g_ps_stamps[8 * blockIdx.x + 0] = st_c1 - st_c0;
     g_ps_stamps[8 * blockIdx.x + 1] = st_r1 - st_r0;
@@ -346,6 +352,9 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
         }
       }
       __syncthreads();
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+      if (PS_DIAG_THIS && pass == 0 && threadIdx.x == 0 && blockIdx.x < 16384) g_ps_stamps[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
       // (a thread keeps its channel chunk over the loop — NT % CHF == 0 —: its 16 affine constants are fetched ONCE per pass, not in
       // every iteration behind the previous iteration's store)
       static_assert(NT % CHF == 0, "dual store loop: constant chunk per thread");
@@ -414,6 +423,9 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
       }
       __syncthreads();
     }
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+    if (PS_DIAG_THIS && threadIdx.x == 0 && blockIdx.x < 16384) g_ps_stamps[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
     return;
   }
   // composed-conv border correction (vnqa_conv2d_igemm_fwd_ex): row of the correction tensor for each of this lane's pixels
@@ -528,7 +540,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   }
   __syncthreads();
 #if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
-  if (HALO == 2 && threadIdx.x == 0 && blockIdx.x < 16384) g_ps_stamps[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
+  if (PS_DIAG_THIS && threadIdx.x == 0 && blockIdx.x < 16384) g_ps_stamps[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
 #endif
 
   constexpr int CH = BN * 2 / 16;       // 16-byte chunks per tile row
@@ -674,6 +686,73 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
       psh[e] = has_post ? p.post_shift[cc] : 0.f;
     }
   }
+  // No affine, no fused trunk epilogue (the stem's plain launches): the staged 16-bit values go out as they are — copied, or their 2x2
+  // maximum taken on the packed pairs (the same bits as unpack / fmaxf / repack at a tenth of the instructions) — in batches of UN rows whose
+  // LDS reads are ALL requested before the first store: one row at a time every iteration waited for its own read (7.5 us of a 93-us
+  // conv21 tile, profiles/r06_ps_tile_phases.txt).
+  if (!has_post && (TAG != 0 || p.epi == VNQA_EPI_NONE)) {
+    constexpr int UN = 4, RPP = NT / CH;          // rows per pass of the workgroup
+    const int c = threadIdx.x % CH, co0 = tile_n * BN + c * 8;
+    const int Ho = p.pool ? p.H >> 1 : p.H, Wo = p.pool ? p.W >> 1 : p.W;
+    const long long rs = (long long)p.Wyp * p.Cy, cs = p.Cy;
+    if (co0 < p.Cout) {
+      for (int r0 = threadIdx.x / CH; r0 < rows_out; r0 += UN * RPP) {
+        uint4 o[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int orow = min(r0 + u * RPP, rows_out - 1);
+          if (p.pool) {
+            const int orr = orow / OC, occ = orow - orr * OC;
+            const int ml = 2 * orr * TC + 2 * occ;
+            const uint4 u0 = *(const uint4*)(smem + ml * CROW + c * 16), u1 = *(const uint4*)(smem + (ml + 1) * CROW + c * 16);
+            const uint4 u2 = *(const uint4*)(smem + (ml + TC) * CROW + c * 16), u3 = *(const uint4*)(smem + (ml + TC + 1) * CROW + c * 16);
+            o[u].x = h16x2_max(h16x2_max(u0.x, u1.x), h16x2_max(u2.x, u3.x));
+            o[u].y = h16x2_max(h16x2_max(u0.y, u1.y), h16x2_max(u2.y, u3.y));
+            o[u].z = h16x2_max(h16x2_max(u0.z, u1.z), h16x2_max(u2.z, u3.z));
+            o[u].w = h16x2_max(h16x2_max(u0.w, u1.w), h16x2_max(u2.w, u3.w));
+          } else {
+            o[u] = *(const uint4*)(smem + orow * CROW + c * 16);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int orow = r0 + u * RPP;
+          const int orr = orow / OC, occ = orow - orr * OC;
+          const int g = g0 + (p.pool ? 2 * orr : orr);
+          if (orow >= rows_out || g >= total_rows) continue;
+          const int n = img_of_row(g);
+          const int y = g - n * p.H;
+          const int yo = p.pool ? (y >> 1) : y;
+          const int xo = (p.pool ? xb >> 1 : xb) + occ;
+          vnqa_bf16* b = (vnqa_bf16*)(p.y) + (((size_t)n * p.Hyp + yo + p.y_halo) * p.Wyp + xo + p.y_halo) * (size_t)p.Cy + co0;
+          *(uint4*)b = o[u];
+          if (p.zero_halo) {      // (as in the generic loop below)
+            const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
+            const bool x0 = xo == 0, x1 = xo == Wo - 1, y0 = yo == 0, y1 = yo == Ho - 1;
+            if (x0 | x1 | y0 | y1) {
+              if (x0) *(uint4*)(b - cs) = zz;
+              if (x1) *(uint4*)(b + cs) = zz;
+              if (y0) {
+                *(uint4*)(b - rs) = zz;
+                if (x0) *(uint4*)(b - rs - cs) = zz;
+                if (x1) *(uint4*)(b - rs + cs) = zz;
+              }
+              if (y1) {
+                *(uint4*)(b + rs) = zz;
+                if (x0) *(uint4*)(b + rs - cs) = zz;
+                if (x1) *(uint4*)(b + rs + cs) = zz;
+              }
+            }
+          }
+        }
+      }
+    }
+#if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
+    __syncthreads();
+    if (PS_DIAG_THIS && threadIdx.x == 0 && blockIdx.x < 16384) g_ps_stamps[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
+    return;
+  }
   for (int idx = threadIdx.x; idx < rows_out * CH; idx += NT) {
     const int orow = idx / CH, c = idx - orow * CH;
     const int co0 = tile_n * BN + c * 8;
@@ -682,22 +761,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
     if (g >= total_rows || co0 >= p.Cout) continue;
     float v[8];
     uint4 o;
-    // no affine, no fused trunk epilogue: the staged 16-bit values go out as they are — copied, or their 2x2 maximum taken on the packed
-    // pairs (the same bits as unpack / fmaxf / repack at a tenth of the instructions: one wave per SIMD pays an issue slot for each)
-    const bool packed = !has_post && (TAG != 0 || p.epi == VNQA_EPI_NONE);
-    if (packed) {
-      if (p.pool) {
-        const int ml = 2 * orr * TC + 2 * occ;
-        const uint4 u0 = *(const uint4*)(smem + ml * CROW + c * 16), u1 = *(const uint4*)(smem + (ml + 1) * CROW + c * 16);
-        const uint4 u2 = *(const uint4*)(smem + (ml + TC) * CROW + c * 16), u3 = *(const uint4*)(smem + (ml + TC + 1) * CROW + c * 16);
-        o.x = h16x2_max(h16x2_max(u0.x, u1.x), h16x2_max(u2.x, u3.x));
-        o.y = h16x2_max(h16x2_max(u0.y, u1.y), h16x2_max(u2.y, u3.y));
-        o.z = h16x2_max(h16x2_max(u0.z, u1.z), h16x2_max(u2.z, u3.z));
-        o.w = h16x2_max(h16x2_max(u0.w, u1.w), h16x2_max(u2.w, u3.w));
-      } else {
-        o = *(const uint4*)(smem + orow * CROW + c * 16);
-      }
-    } else if (p.pool) {
+    if (p.pool) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = -INFINITY;
 #pragma unroll
@@ -744,7 +808,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
         w[2 * e + 1] = h16_hi(mw[e]) > 0.f ? v[2 * e + 1] + h16_hi(aw[e]) : 0.f;
       }
       o.x = pack2_h16(w[0], w[1]); o.y = pack2_h16(w[2], w[3]); o.z = pack2_h16(w[4], w[5]); o.w = pack2_h16(w[6], w[7]);
-    } else if (!packed) {
+    } else {
       o.x = pack2_h16(v[0], v[1]); o.y = pack2_h16(v[2], v[3]); o.z = pack2_h16(v[4], v[5]); o.w = pack2_h16(v[6], v[7]);
     }
     if (!no_z) *(uint4*)dst = o;
@@ -798,7 +862,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
   }
 #if defined(VNQA_PS_DIAG) && VNQA_PS_DIAG == 3
   __syncthreads();
-  if (HALO == 2 && threadIdx.x == 0 && blockIdx.x < 16384) g_ps_stamps[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
+  if (PS_DIAG_THIS && threadIdx.x == 0 && blockIdx.x < 16384) g_ps_stamps[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
