@@ -397,10 +397,7 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
         }
         unsigned hw[4], lw[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          hw[e] = pack2_h16(v[2 * e], v[2 * e + 1]);
-          lw[e] = pack2_h16(v[2 * e] - h16_lo(hw[e]), v[2 * e + 1] - h16_hi(hw[e]));
-        }
+        for (int e = 0; e < 4; ++e) hw[e] = pack2_h16(v[2 * e], v[2 * e + 1]);
         const int n = img_of_row(g);
         const int y = g - n * p.H;
         const int yo = p.pool ? (y >> 1) : y;
@@ -410,8 +407,10 @@ __global__ void __launch_bounds__(ps::NT, 1) conv_ps_kernel(const ConvArgs p) {
         *(uint4*)dst = make_uint4(hw[0], hw[1], hw[2], hw[3]);
         if (p.dual_out >= 8) {              // VNQA_CONV_F32_EPILOGUE: ONE 16-bit value, rounded once after pool / affine in fp32 ...
           if (p.dual_out == 9) *(uint4*)(dst + p.Cout) = make_uint4(hw[0], hw[1], hw[2], hw[3]);      // ... | VNQA_CONV_DUAL_HI2: written TWICE, [v | v]
-          continue;
+          continue;                         // (no lo half to form: a wave-uniform exit before its twelve instructions)
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lw[e] = pack2_h16(v[2 * e] - h16_lo(hw[e]), v[2 * e + 1] - h16_hi(hw[e]));
         if (p.dual_out == 4) {      // VNQA_EPI_SPLIT_OUT: hi and lo as TWO plain tensors of y's geometry (y, y2)
           *(uint4*)((vnqa_bf16*)(p.y2) + ooff) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
           continue;
