@@ -52,11 +52,22 @@ __device__ __forceinline__ void ps_mfma(vnqa_f32x4& acc, const vnqa_f32x4& w, co
 }
 
 // LDS-DMA from inline asm (invisible to hipcc's wait counting; every wait is hand-placed): wave-uniform base + 32-bit lane offset
+// (M0 is clobbered, not saved and restored: nothing else in this kernel lives in it — no LDS-DMA builtin, no s_movrel — and with one wave per
+// SIMD the two extra scalar moves per transfer were issue slots of the K loop: 8 transfers per K-step)
+#ifdef VNQA_PS_GLDS_KEEP_M0      // the round 3-6 form (A/B partner)
 __device__ __forceinline__ void ps_glds(const char* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
+#else
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // ("reserved register on the clobber list": that IS the statement)
+__device__ __forceinline__ void ps_glds(const char* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+#endif
 
 // row multiplier of the patch swizzle key (col + RM row) & 6: exhaustive search per geometry (tools/lds_swizzle_check.py)
 #ifndef VNQA_PS_RM14
