@@ -49,11 +49,22 @@ struct WregArgs {
 // reads (cdna_hip_programming.md §5, "Three .s-level traps" (a)) nor counts it: every wait for it below is hand-placed.
 // sbase / lds_addr are wave-uniform; voff is the lane's byte offset.  M0 (the DMA's LDS base) is compiler-reserved: saved
 // and restored inside the statement.
+// (round 6: M0 is declared clobbered instead — nothing else in this kernel lives in it —: 3 instead of 5 issue slots per transfer, which one wave
+// per SIMD pays between its MFMAs; VNQA_GLDS_KEEP_M0: the earlier form, the A/B partner)
+#ifdef VNQA_GLDS_KEEP_M0
 __device__ __forceinline__ void glds16_asm(const char* sbase, unsigned voff, unsigned lds_addr) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
 }
+#else
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void glds16_asm(const char* sbase, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+#endif
 
 // MFMAs issued from inline asm so that the weight fragment's register FILE is ours to choose: 64 of a wave's 72 fragments
 // are pinned in the 256 accumulation registers (constraint "a") and read by the MFMA directly as its A operand, 8 live in
